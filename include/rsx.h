@@ -1,0 +1,142 @@
+/* rsx.h -- C ABI of librsx.so: the MI355X (gfx950) CTR training hot path.
+ *
+ * The reference (wangruichens/recsys) has NO native/FFI/plugin interface: every op below is a
+ * TensorFlow-1.x graph op invoked from the model_fn bodies.  Each entry point cites the reference
+ * call site (file:line under /root/reference) whose arithmetic it replaces; SURVEY.md section 8b is
+ * the contract.  INTEGRATION.md shows the ctypes binding a maintainer adds on the Python side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _h (host).
+ *   - the caller owns all buffers incl. workspaces; the library never allocates or frees device
+ *     memory and never synchronises the stream (safe under hipGraph stream capture).
+ *   - return 0 (RSX_OK) or a negative rsx_status; no exceptions cross the ABI.
+ *   - re-entrant: no global mutable state; one stream per call (rsx_stream_t == hipStream_t).
+ *   - fp32 everywhere; compiled with -ffp-contract=off and correctly rounded div/sqrt so the
+ *     element-wise math is reproducible against an IEEE fp32 restatement.
+ */
+#ifndef RSX_H_
+#define RSX_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rsx_stream_t; /* hipStream_t */
+
+typedef enum {
+  RSX_OK = 0,
+  RSX_EINVAL = -1,       /* bad argument (null pointer, unsupported D, ...) */
+  RSX_ELAUNCH = -2,      /* hipGetLastError() != hipSuccess after a launch */
+  RSX_EUNSUPPORTED = -3, /* valid request outside the implemented envelope */
+  RSX_EDATA = -4         /* corrupt input data (TFRecord crc, malformed Example) */
+} rsx_status;
+
+int rsx_version(void);
+const char* rsx_strerror(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding path
+ * Layout: all F per-field tables concatenated row-wise into tables[R, D] in TF's name-sorted slot
+ * order; row_off[F+1] (int32, device) are the slot offsets; ids[B, F] int32 are table-local ids.
+ * D in {4, 8, 16, 32, 64}.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces tf.feature_column.input_layer(embedding cols) fm/fm.py:118 (deepfm/deepfm.py:85,
+ * xdeepfm/xdeepfm.py:128,185, dcn/dcn.py:123), the first-order one-hot matmul fm/fm.py:117,121
+ * (without bias/relu) and the FM second-order term fm/fm.py:124-129.
+ *   E[B, F*D]   gathered rows (always written)
+ *   S[B, D]     sum over fields (nullable; required when y2 != NULL -- saved for backward)
+ *   y1[B]       sum_f w1[row] over fields whose bit is set in w1_field_mask (nullable with w1)
+ *   y2[B]       0.5 * sum_d((sum_f E)^2 - sum_f E^2)   (nullable)                               */
+int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
+                      float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask,
+                      int B, int F, int D, rsx_stream_t stream);
+
+/* Device workspace written by rsx_field_sort, all caller-owned.  `stride` (>= B) is the per-field
+ * capacity the buffers were allocated with, so partial batches reuse the same workspace:
+ *   perm     int32 [F, stride]    example index b of the i-th entry of field f sorted by (id, b)
+ *   seg_off  int32 [F, stride+1]  start position of the j-th unique id of field f; seg_off[f][nuniq]=B
+ *   uniq_row int32 [F, stride]    global row (row_off[f]+id) of the j-th unique id
+ *   nuniq    int32 [F]            number of unique ids of field f (zero-initialise once)
+ *   slot     int32 [R]            row -> f*stride+j of this step, -1 elsewhere (initialise to -1 once;
+ *                                 the kernel clears the previous step's entries itself)
+ * The sparse gradient lives at the same slot index: G[F*stride, D], gw1[F*stride].                 */
+/* Dedup stage of the sparse gradient (TF: unique() inside safe_embedding_lookup_sparse and
+ * _apply_sparse_duplicate_indices): one workgroup per field does an LDS
+ * bitonic sort of the composite key (id << log2B | b), flags segment heads and scans them.
+ * Depends on ids only, so it may run on a side stream concurrently with the forward pass.
+ * Envelope: B <= 16384 and (max rows per field) << ceil(log2 B) < 2^32.                         */
+int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
+                   int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int max_rows_per_field,
+                   int B, int F, int stride, rsx_stream_t stream);
+
+/* Row-wise gradient "scatter" as a sorted segment-sum (replaces the IndexedSlices gradient of the
+ * gather + tf.unsorted_segment_sum, Appendix A-4): for unique row (f, j)
+ *   G[f*B+j, :]  = sum over its examples b, ascending:  (gy2[b]*S[b,:] - gy2[b]*T[row,:]) + dX[b, f*D:(f+1)*D]
+ *   gw1[f*B+j]   = sum over its examples b, ascending:  gy1[b]       (fields in w1_field_mask)
+ * dX (grad of the flattened embedding from the DNN/CIN/cross consumers), gy2/S (FM term) and
+ * gy1/gw1 (first-order term) are each nullable.  Sums run in ascending b like TF's CPU kernels.   */
+int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
+                   const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq,
+                   float* G, float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride,
+                   rsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer: tf.train.AdamOptimizer(lr).minimize(...) fm/fm.py:162-163.
+ * One launch sweeps any number of variable segments.  state (device, float[4]) =
+ * {beta1^t, beta2^t, <uint32 blocks-done ticket>, <uint32 step t>}; initialise with
+ * rsx_adam_state_init_h.  The last workgroup to finish advances the powers, so the sweep is
+ * replayable from a hipGraph with no per-step host arguments.
+ * ------------------------------------------------------------------------------------------- */
+typedef enum {
+  RSX_ADAM_DENSE = 0,      /* ApplyAdam: m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= (m*a)/(sqrt(v)+eps).
+                              g dense [n]; if zero_grad != 0 g is zeroed after use.                 */
+  RSX_ADAM_TABLE_TF1 = 1,  /* non-lazy sparse (_apply_sparse_shared): whole table decays and moves;
+                              rows with slot[row]>=0 add G[slot[row], :] first.  n = rows, d = D.   */
+  RSX_ADAM_VEC_SLOT = 2,   /* dense formula on a vector whose dense gradient is g[slot[row]] where
+                              slot[row]>=0 and 0 elsewhere (one-hot matmul kernels: w1). n = rows.  */
+  RSX_ADAM_TABLE_ROWS = 3, /* lazy_rows mode (NOT TF semantics): only rows listed in uniq_row/nuniq. */
+  RSX_ADAM_VEC_ROWS = 4    /* lazy_rows counterpart for vectors.                                     */
+} rsx_adam_kind;
+
+typedef struct {
+  int32_t kind;            /* rsx_adam_kind */
+  int32_t d;               /* row width for table kinds */
+  int64_t n;               /* elements (DENSE) or rows (others); for *_ROWS kinds: F*B slots        */
+  float* var;
+  float* m;
+  float* v;
+  float* g;                /* DENSE: grad [n]; TABLE_*: G [F*B, d]; VEC_*: gw1 [F*B]                */
+  const int32_t* slot;     /* TABLE_TF1 / VEC_SLOT: row -> slot map                                  */
+  const int32_t* uniq_row; /* *_ROWS */
+  const int32_t* nuniq;    /* *_ROWS */
+  int32_t B;               /* *_ROWS: examples per field this step (n = F*B)                         */
+  int32_t stride;          /* *_ROWS: per-field capacity of the rsx_field_sort workspace             */
+  int32_t zero_grad;       /* DENSE */
+} rsx_adam_seg;
+
+#define RSX_ADAM_MAX_SEGS 12
+int rsx_adam_state_init_h(float* state_h /* host float[4] */, float beta1, float beta2);
+int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* state, float lr, float beta1,
+                       float beta2, float eps, rsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side ingest ("next" row f-1).  Host pointers only.
+ * ------------------------------------------------------------------------------------------- */
+/* FarmHash Fingerprint64 of n byte strings (concatenated in bytes_h, offs_h[n+1]); replaces the hash
+ * inside categorical_column_with_hash_bucket fm/fm.py:89.  out_h[i] = Fingerprint64(s_i).          */
+int rsx_hash_fp64_h(const uint8_t* bytes_h, const int64_t* offs_h, int64_t n, uint64_t* out_h);
+uint64_t rsx_fingerprint64_h(const uint8_t* s_h, size_t n);
+/* bucketized_column(numeric_column(log(x+shift))) fm/fm.py:76-79: idx = #boundaries <= logf(x+shift) */
+int rsx_bucketize_log_h(const float* x_h, int64_t n, const float* boundaries_h, int nb, float shift,
+                        int32_t* out_h);
+uint32_t rsx_crc32c_h(const uint8_t* data_h, size_t n);
+uint32_t rsx_masked_crc32c_h(const uint8_t* data_h, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H_ */

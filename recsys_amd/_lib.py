@@ -1,0 +1,67 @@
+"""ctypes binding of librsx.so (include/rsx.h).  Fails loudly when the library is missing: there is
+no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsx.so")
+
+RSX_ADAM_DENSE, RSX_ADAM_TABLE_TF1, RSX_ADAM_VEC_SLOT, RSX_ADAM_TABLE_ROWS, RSX_ADAM_VEC_ROWS = range(5)
+RSX_ADAM_MAX_SEGS = 12
+
+
+class RsxError(RuntimeError):
+    pass
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n", C.c_int64),
+                ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
+                ("slot", C.c_void_p), ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p),
+                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32)]
+
+
+_P, _I, _U64, _F = C.c_void_p, C.c_int, C.c_uint64, C.c_float
+_SIGS = {
+    "rsx_version": (C.c_int, []),
+    "rsx_strerror": (C.c_char_p, [_I]),
+    "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
+    "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
+    "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
+    "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
+    "rsx_hash_fp64_h": (_I, [_P, _P, C.c_int64, _P]),
+    "rsx_fingerprint64_h": (C.c_uint64, [_P, C.c_size_t]),
+    "rsx_bucketize_log_h": (_I, [_P, C.c_int64, _P, _I, _F, _P]),
+    "rsx_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
+    "rsx_masked_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librsx.so once.  Raises RsxError (never falls back) when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RsxError("librsx.so not built: run `python -m recsys_amd.build` (hipcc --offload-arch=gfx950); "
+                       "there is no CPU fallback for the hot path")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        if not hasattr(L, name):
+            raise RsxError("librsx.so does not export %s (stale build?)" % name)
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(status, what="rsx call"):
+    if status != 0:
+        raise RsxError("%s failed: %s (%d)" % (what, lib().rsx_strerror(status).decode(), status))

@@ -1,0 +1,44 @@
+"""Builds recsys_amd/librsx.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+`python -m recsys_amd.build` or `__graft_entry__.build()`.  Cross-compiles without a GPU.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librsx.so")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off",          # element-wise fp32 math must match an IEEE restatement (no FMA fusion)
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    if verbose:
+        print("[recsys_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,15 @@
+// Version / error strings of librsx.so.
+#include "rsx.h"
+
+extern "C" int rsx_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* rsx_strerror(int status) {
+  switch (status) {
+    case RSX_OK: return "ok";
+    case RSX_EINVAL: return "invalid argument";
+    case RSX_ELAUNCH: return "kernel launch failed (hipGetLastError)";
+    case RSX_EUNSUPPORTED: return "request outside the implemented envelope";
+    case RSX_EDATA: return "corrupt input data";
+    default: return "unknown rsx status";
+  }
+}

@@ -1,0 +1,263 @@
+// Embedding path of the CTR hot path on gfx950: multi-field gather + first-order + FM second order
+// (forward), per-field LDS sort -> unique rows (dedup), sorted segment-sum (row-wise gradient scatter).
+// Reference call sites: fm/fm.py:117-129, deepfm/deepfm.py:85-98, xdeepfm/xdeepfm.py:128,185,
+// dcn/dcn.py:123 (see include/rsx.h for the per-entry-point citations).
+//
+// HBM layout: tables[R, D] fp32, rows of D*4 bytes (64 B at D=16) -> one row = LPR = D/4 lanes of
+// float4.  A wave handles 64/LPR (b, f) pairs per load instruction; E[B, F*D] is written fully
+// coalesced (consecutive lanes -> consecutive 16 B).  These kernels are HBM/latency-bound integer +
+// fp32 streaming work: no MFMA here by design.
+#include "rsx_common.h"
+
+// ------------------------------------------------------------------ forward --------------------
+// One wave per example b.  lane = (j, q): q = float4 quarter of the row, j = pair slot; the wave
+// walks fields f = j, j+PPP, ...  The field reductions (S, sum of squares, first-order sum) are
+// xor-butterflies over the j bits: a fixed tree, so results are deterministic run to run.
+template <int D>
+__global__ void gather_fm_fwd_k(const float* __restrict__ tables, const float* __restrict__ w1,
+                                const int32_t* __restrict__ row_off, const int32_t* __restrict__ ids,
+                                float* __restrict__ E, float* __restrict__ S, float* __restrict__ y1,
+                                float* __restrict__ y2, uint64_t w1_mask, int B, int F) {
+  constexpr int LPR = D / 4;
+  constexpr int PPP = RSX_WAVE / LPR;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int q = lane % LPR, j = lane / LPR;
+  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(tables);
+  float4* __restrict__ E4 = reinterpret_cast<float4*>(E);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), qq = s;
+  float a1 = 0.f;
+  const int32_t* idb = ids + (size_t)b * F;
+  for (int f = j; f < F; f += PPP) {
+    const int row = row_off[f] + idb[f];
+    const float4 e = T4[(size_t)row * LPR + q];
+    E4[((size_t)b * F + f) * LPR + q] = e;
+    s = f4_add(s, e);
+    qq = f4_add(qq, f4_mul(e, e));
+    if (w1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull)) a1 += w1[row];
+  }
+#pragma unroll
+  for (int m = LPR; m < RSX_WAVE; m <<= 1) {
+    s = f4_add(s, f4_shfl_xor(s, m));
+    qq = f4_add(qq, f4_shfl_xor(qq, m));
+    a1 += __shfl_xor(a1, m);
+  }
+  if (S != nullptr && j == 0) reinterpret_cast<float4*>(S)[(size_t)b * LPR + q] = s;
+  if (y2 != nullptr) {
+    float t = ((s.x * s.x - qq.x) + (s.y * s.y - qq.y)) + ((s.z * s.z - qq.z) + (s.w * s.w - qq.w));
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m);
+    if (lane == 0) y2[b] = 0.5f * t;
+  }
+  if (y1 != nullptr && lane == 0) y1[b] = a1;
+}
+
+// ------------------------------------------------------------------ dedup: per-field LDS sort ---
+// One workgroup per field.  key = (id << bbits) | b is unique, so the (unstable) bitonic network
+// yields entries ordered by id, then by ascending example index -- the order TF's CPU
+// unsorted_segment_sum accumulates in.  n = padded power of two (>= 128), T = min(1024, n/2) threads.
+__global__ __launch_bounds__(1024) void field_sort_k(const int32_t* __restrict__ ids,
+                                                      const int32_t* __restrict__ row_off,
+                                                      int32_t* __restrict__ perm, int32_t* __restrict__ seg_off,
+                                                      int32_t* __restrict__ uniq_row, int32_t* __restrict__ nuniq,
+                                                      int32_t* __restrict__ slot, int B, int F, int stride, int n,
+                                                      int bbits) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* key = lds;            // [n]
+  uint32_t* wsum = lds + n;       // [32]
+  const int f = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int roff = row_off[f];
+  // forget the previous step's rows of this field (they may differ from this step's)
+  const int prev = nuniq[f];
+  for (int jj = tid; jj < prev; jj += T) slot[uniq_row[(size_t)f * stride + jj]] = -1;
+  for (int i = tid; i < n; i += T)
+    key[i] = i < B ? (((uint32_t)ids[(size_t)i * F + f] << bbits) | (uint32_t)i) : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int jst = k >> 1; jst > 0; jst >>= 1) {
+      for (int t = tid; t < (n >> 1); t += T) {
+        const int i = ((t & ~(jst - 1)) << 1) | (t & (jst - 1));
+        const int l = i | jst;
+        const uint32_t a = key[i], c = key[l];
+        const bool up = (i & k) == 0;
+        if ((a > c) == up) {
+          key[i] = c;
+          key[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // head flags + exclusive scan -> unique index j of every sorted position
+  const int ipt = n / T;
+  const int i0 = tid * ipt;
+  const uint32_t bmask = (1u << bbits) - 1u;
+  int cnt = 0;
+  for (int i = i0; i < i0 + ipt; ++i)
+    if (i < B && (i == 0 || (key[i] >> bbits) != (key[i - 1] >> bbits))) ++cnt;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < RSX_WAVE; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += o;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = (uint32_t)incl;
+  __syncthreads();
+  int base = incl - cnt, total = 0;
+  const int nw = (T + 63) >> 6;
+  for (int w = 0; w < nw; ++w) {
+    const int v = (int)wsum[w];
+    if (w < (tid >> 6)) base += v;
+    total += v;
+  }
+  int jn = base;
+  for (int i = i0; i < i0 + ipt; ++i) {
+    if (i >= B) break;
+    const uint32_t kk = key[i];
+    perm[(size_t)f * stride + i] = (int32_t)(kk & bmask);
+    if (i == 0 || (kk >> bbits) != (key[i - 1] >> bbits)) {
+      const int row = roff + (int)(kk >> bbits);
+      uniq_row[(size_t)f * stride + jn] = row;
+      seg_off[(size_t)f * (stride + 1) + jn] = i;
+      slot[row] = f * stride + jn;
+      ++jn;
+    }
+  }
+  if (tid == 0) {
+    seg_off[(size_t)f * (stride + 1) + total] = B;
+    nuniq[f] = total;
+  }
+}
+
+// ------------------------------------------------------------------ backward: sorted segment-sum -
+// LPR lanes per unique row (f, j); the group walks its segment in ascending b and accumulates
+//   (gy2[b]*S[b,:] - gy2[b]*T[row,:]) + dX[b, f*D:(f+1)*D]   (term order = TF autodiff of fm/fm.py:127-129)
+// sequentially, i.e. exactly the order of a CPU unsorted_segment_sum.  E[b,f,:] == T[row,:] for the
+// whole segment, so the row is read once instead of once per example.
+template <int D>
+__global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ tables, const float* __restrict__ S,
+                                                    const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                    const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                    const int32_t* __restrict__ seg_off,
+                                                    const int32_t* __restrict__ uniq_row,
+                                                    const int32_t* __restrict__ nuniq, float* __restrict__ G,
+                                                    float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
+                                                    int stride) {
+  constexpr int LPR = D / 4;
+  const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const int q = threadIdx.x % LPR;
+  if (gid >= F * B) return;
+  const int f = gid / B, j = gid % B;
+  if (j >= nuniq[f]) return;
+  const size_t sl = (size_t)f * stride + j;
+  const int beg = seg_off[(size_t)f * (stride + 1) + j], end = seg_off[(size_t)f * (stride + 1) + j + 1];
+  const int32_t* pf = perm + (size_t)f * stride;
+  const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
+  const float4* __restrict__ X4 = reinterpret_cast<const float4*>(dX);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float a1 = 0.f;
+  float4 e = acc;
+  if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)uniq_row[sl] * LPR + q];
+  const bool do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
+  for (int i = beg; i < end; ++i) {
+    const int b = pf[i];
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy2 != nullptr) {
+      const float g = gy2[b];
+      c = f4_sub(f4_scale(g, S4[(size_t)b * LPR + q]), f4_scale(g, e));
+    }
+    if (dX != nullptr) {
+      const float4 x = X4[((size_t)b * F + f) * LPR + q];
+      c = gy2 != nullptr ? f4_add(c, x) : x;
+    }
+    acc = f4_add(acc, c);
+    if (do1) a1 += gy1[b];
+  }
+  reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
+  if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
+}
+
+// ------------------------------------------------------------------ C ABI ----------------------
+static inline bool d_ok(int D) { return D == 4 || D == 8 || D == 16 || D == 32 || D == 64; }
+
+#define RSX_DISPATCH_D(D, FN, ...)            \
+  switch (D) {                                \
+    case 4: FN<4>(__VA_ARGS__); break;        \
+    case 8: FN<8>(__VA_ARGS__); break;        \
+    case 16: FN<16>(__VA_ARGS__); break;      \
+    case 32: FN<32>(__VA_ARGS__); break;      \
+    default: FN<64>(__VA_ARGS__); break;      \
+  }
+
+template <int D>
+static void launch_gather(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* w1,
+                          const int32_t* row_off, const int32_t* ids, float* E, float* S, float* y1, float* y2,
+                          uint64_t mask, int B, int F) {
+  gather_fm_fwd_k<D><<<grid, block, 0, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F);
+}
+template <int D>
+static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
+                          const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                          const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
+                          int F, int stride) {
+  segsum_bwd_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
+                                          stride);
+}
+
+extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
+                                 float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int B, int F,
+                                 int D, rsx_stream_t stream) {
+  if (!tables || !row_off || !ids || !E || B < 0 || F <= 0 || F > 64 || !d_ok(D)) return RSX_EINVAL;
+  if ((y1 != nullptr) != (w1 != nullptr)) return RSX_EINVAL;
+  if (y2 != nullptr && S == nullptr) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  const int waves = B >= 2048 ? 4 : 1;  // small batches: one wave per workgroup spreads over all 256 CUs
+  const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+  RSX_DISPATCH_D(D, launch_gather, grid, block, rsx_s(stream), tables, w1, row_off, ids, E, S, y1, y2,
+                 w1_field_mask, B, F);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+static inline int ceil_log2(int x) {
+  int b = 0;
+  while ((1 << b) < x) ++b;
+  return b;
+}
+
+extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
+                              int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int max_rows_per_field, int B,
+                              int F, int stride, rsx_stream_t stream) {
+  if (!ids || !row_off || !perm || !seg_off || !uniq_row || !nuniq || !slot || B < 0 || F <= 0 || stride < B ||
+      max_rows_per_field <= 0)
+    return RSX_EINVAL;
+  if (B > 16384) return RSX_EUNSUPPORTED;
+  const int bbits = ceil_log2(B < 2 ? 2 : B);
+  if (((uint64_t)(max_rows_per_field - 1) << bbits) >= (1ull << 32) - 1ull) return RSX_EUNSUPPORTED;
+  int n = 128;
+  while (n < B) n <<= 1;
+  const int T = (n >> 1) < 1024 ? (n >> 1) : 1024;
+  const size_t lds = ((size_t)n + 32) * sizeof(uint32_t);
+  hipLaunchKernelGGL(field_sort_k, dim3(F), dim3(T), lds, rsx_s(stream), ids, row_off, perm, seg_off, uniq_row,
+                     nuniq, slot, B, F, stride, n, bbits);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1,
+                              const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                              const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1,
+                              uint64_t w1_field_mask, int B, int F, int D, int stride, rsx_stream_t stream) {
+  if (!perm || !seg_off || !uniq_row || !nuniq || !G || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D))
+    return RSX_EINVAL;
+  if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
+  if ((gy1 != nullptr) != (gw1 != nullptr)) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  const long long threads = (long long)F * B * (D / 4);
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
+                 nuniq, G, gw1, w1_field_mask, B, F, stride);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}

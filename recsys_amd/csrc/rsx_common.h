@@ -1,0 +1,31 @@
+// Shared helpers for the gfx950 kernels of librsx.so (wave = 64 lanes, hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsx.h"
+
+#define RSX_WAVE 64
+
+#define RSX_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return RSX_ELAUNCH; \
+  } while (0)
+
+static inline hipStream_t rsx_s(rsx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 f4_scale(float s, float4 a) {
+  return make_float4(s * a.x, s * a.y, s * a.z, s * a.w);
+}
+__device__ __forceinline__ float4 f4_shfl_xor(float4 a, int m) {
+  return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m), __shfl_xor(a.w, m));
+}

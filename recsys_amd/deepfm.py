@@ -1,0 +1,159 @@
+"""DeepFM on the Criteo 39-field pipeline -- MI355X-native mirror of the reference's
+`deepfm/deepfm.py:model_fn` (:73-150) married to `fm/fm.py:build_feature_columns` (:47-97), i.e. the
+README's "DeepFM on Criteo, d=16, DNN 100-100, bs=256" (BASELINE config 2).
+
+Same surface as the script: FLAGS-compatible argparse names, `input_fn`, `model_fn(features, labels,
+mode, params)`, `main`.  The embedding gather + first-order + FM term, the row-wise gradient scatter
+and the TF-1 Adam sweep are librsx.so kernels; the 624-100-100-1 tower is rocBLAS via torch.
+"""
+import argparse
+
+import torch
+
+from . import layers as L
+from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
+    train_and_evaluate
+from .feature_columns import CAT_FEATURE, CONT_FEATURE, CriteoLayout, build_feature_columns
+from .ops import EmbeddingArena, gather_fm
+
+
+def _dense_specs(F, D, layers, n_inputs_out, with_dnn=True):
+    """Variable shapes + initialisers (glorot-uniform kernels, zero biases, BN gamma 1 / beta 0: Appendix A-7)."""
+    shapes, init = {}, {}
+    zeros = lambda t, g: t.zero_()
+    ones = lambda t, g: t.fill_(1.0)
+
+    def add_dense(name_w, name_b, fi, fo):
+        shapes[name_w], shapes[name_b] = (fi, fo), (fo,)
+        init[name_w] = lambda t, g, fi=fi, fo=fo: L.glorot_uniform_(t, fi, fo, g)
+        init[name_b] = zeros
+
+    shapes["b1"], init["b1"] = (1,), zeros
+    if with_dnn:
+        d = F * D
+        for i, n in enumerate(layers):
+            add_dense(f"dnn.W{i}", f"dnn.b{i}", d, n)
+            shapes[f"dnn.gamma{i}"], init[f"dnn.gamma{i}"] = (n,), ones
+            shapes[f"dnn.beta{i}"], init[f"dnn.beta{i}"] = (n,), zeros
+            d = n
+        add_dense("dnn.Wout", "dnn.bout", d, 1)
+    add_dense("out.W", "out.b", n_inputs_out, 1)
+    return shapes, init
+
+
+def build_variables(store, params, capacity, with_dnn=True):
+    """Creates what TF creates lazily inside input_layer / tf.layers.* on the first model_fn call."""
+    layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
+    D = params["embedding_size"]
+    lin_keys = {c.key for c in params["linear_feature_columns"] if c.kind.endswith("indicator")}
+    arena = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=True,
+                           w1_field_mask=layout.field_mask(lin_keys))
+    with torch.no_grad():
+        t = torch.empty(arena.R, D)
+        L.trunc_normal_(t, 1.0 / D ** 0.5, store.gen)          # embedding_column initializer (A-4)
+        arena.tables.copy_(t)
+        w = torch.empty(arena.R)
+        L.glorot_uniform_(w, arena.R, 1, store.gen)             # tf.layers.dense kernel [R,1]
+        arena.w1.copy_(w)
+    layers = list(map(int, params["deep_layers"].split(","))) if with_dnn else []
+    shapes, init = _dense_specs(layout.F, D, layers, 3 if with_dnn else 2, with_dnn)
+    store.build({"input_layer": arena}, shapes, init, params["learning_rate"])
+    store.layout = layout
+
+
+def model_fn(features, labels, mode, params):
+    """deepfm/deepfm.py:73-150.  features['ids']: int32 [B,39] table-local ids in slot order
+    (recsys_amd.input_pipeline produces them; hashing/bucketizing is the input_layer's host half)."""
+    store = get_variable_store()
+    ids = features["ids"]
+    if not store.built:
+        build_variables(store, params, capacity=max(int(params.get("max_batch_size", 0)), ids.shape[0]))
+    arena, P = store.embeddings["input_layer"], store.dense
+    training = mode == ModeKeys.TRAIN
+    n_layers = len(params["deep_layers"].split(","))
+    masks = params.get("_dropout_masks")
+
+    if training:
+        arena.field_sort(ids)                                  # dedup for the sparse gradient (ids only)
+    E, y1p, y2 = gather_fm(arena, ids, fm=True, first_order=True)    # embedding_features, first-order, second-order
+    y_1d = torch.relu(y1p + P["b1"])                           # 'first-order' (:90-91)
+    dnn_net = L.tower(E, P, "dnn", n_layers, training, params["dropout"], masks)    # 'dnn' (:100-107)
+    y_dnn = L.dense(dnn_net, P["dnn.Wout"], P["dnn.bout"], relu=True)              # (:108)
+    logits = torch.cat([y_1d[:, None], y2[:, None], y_dnn], -1)                     # (:110)
+    logits = L.dense(logits, P["out.W"], P["out.b"]).reshape(-1)                    # (:111-112)
+    pred = torch.sigmoid(logits)
+    predictions = {"prob": pred}
+    if mode == ModeKeys.PREDICT:
+        return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+    loss = L.sigmoid_ce_mean(logits, labels)
+    if mode == ModeKeys.EVAL:
+        return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
+
+    def train_op():                                            # AdamOptimizer.minimize (:142-143)
+        loss.backward()
+        store.apply_gradients()
+
+    return EstimatorSpec(mode, predictions=predictions, loss=loss, train_op=train_op)
+
+
+# ---- driver (deepfm/deepfm.py:153-234 + fm/fm.py flags) -----------------------------------------
+def define_flags(p=None):
+    p = p or argparse.ArgumentParser()
+    p.add_argument("--embedding_size", type=int, default=16)
+    p.add_argument("--learning_rate", type=float, default=0.001)
+    p.add_argument("--dropout", type=float, default=0.5)
+    p.add_argument("--task_type", default="train", help="{train, infer, eval}")
+    p.add_argument("--num_epochs", type=int, default=10)
+    p.add_argument("--deep_layers", default="100,100")
+    p.add_argument("--train_path", default="/home/wangrc/criteo_data/train/")
+    p.add_argument("--train_parts", type=int, default=150)
+    p.add_argument("--eval_parts", type=int, default=5)
+    p.add_argument("--batch_size", type=int, default=256)
+    p.add_argument("--log_steps", type=int, default=100)
+    p.add_argument("--save_checkpoints_steps", type=int, default=1000)
+    p.add_argument("--num_parallel", type=int, default=8)
+    p.add_argument("--mirror", type=lambda s: s.lower() in ("1", "true", "yes"), default=True)
+    p.add_argument("--model_dir", default="./model/")
+    p.add_argument("--adam_mode", default="tf1_dense")
+    return p
+
+
+def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None):
+    from .input_pipeline import criteo_input_fn
+    return criteo_input_fn(filenames, batch_size, num_epochs, need_shuffle, num_parallel, layout)
+
+
+def make_params(FLAGS, linear="indicator_all"):
+    lin, emb = build_feature_columns(FLAGS.embedding_size, linear)
+    return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
+            "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
+            "max_batch_size": FLAGS.batch_size}
+
+
+def main(argv=None):
+    FLAGS = define_flags().parse_args(argv)
+    files = [FLAGS.train_path + "part-r-{:0>5}".format(i) for i in range(FLAGS.train_parts)]
+    train_files, eval_files = files[:-FLAGS.eval_parts], files[-FLAGS.eval_parts:]
+    params = make_params(FLAGS)
+    config = RunConfig(save_checkpoints_steps=FLAGS.save_checkpoints_steps, keep_checkpoint_max=5,
+                       log_step_count_steps=FLAGS.log_steps, adam_mode=FLAGS.adam_mode)
+    est = Estimator(model_fn, FLAGS.model_dir, params, config)
+    if FLAGS.mirror:
+        from . import dist
+        dist.attach_if_distributed(est)
+    layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
+    if FLAGS.task_type == "train":
+        tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.num_parallel, layout))
+        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
+        train_and_evaluate(est, tr, ev)
+    elif FLAGS.task_type == "eval":
+        est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
+    elif FLAGS.task_type == "infer":
+        for i, p in enumerate(est.predict(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout))):
+            print(p)
+            if i >= 9:
+                break
+
+
+if __name__ == "__main__":
+    main()

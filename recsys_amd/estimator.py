@@ -1,0 +1,326 @@
+"""Estimator-shaped surface of the reference scripts on PyTorch-ROCm.
+
+Mirrors what fm/fm.py:173-224 (and its four twins) use from `tensorflow_estimator`:
+`Estimator(model_fn, model_dir, params, config)`, `.train/.evaluate/.predict`,
+`train_and_evaluate(est, TrainSpec, EvalSpec)`, `RunConfig`, `EstimatorSpec`, `ModeKeys`.
+
+Differences that are deliberate (MI355X-first):
+  * model_fn runs eagerly on `cuda`; its variables live in the Estimator's `VariableStore`
+    (flat HBM arenas) instead of a TF graph.
+  * TRAIN mode returns `train_op` as a closure (backward + one fused Adam launch).  The Estimator
+    captures `model_fn + train_op` ONCE per batch shape into a HIP graph and replays it per step,
+    which removes the Python/launch overhead that dominates at batch 256.
+  * MirroredStrategy (fm/fm.py:184-194) becomes one process per GPU + RCCL (recsys_amd.dist).
+"""
+import os
+import time
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import metrics as _metrics
+from .ops import AdamTF1, DenseArena, EmbeddingArena
+
+
+class ModeKeys:
+    TRAIN = "train"
+    EVAL = "eval"
+    PREDICT = "infer"
+
+
+@dataclass
+class EstimatorSpec:
+    mode: str
+    predictions: Optional[Dict[str, torch.Tensor]] = None
+    loss: Optional[torch.Tensor] = None
+    train_op: Optional[Callable[[], None]] = None
+    eval_metric_ops: Optional[Dict[str, Any]] = None
+    export_outputs: Optional[Dict[str, Any]] = None
+
+
+@dataclass
+class RunConfig:
+    """estimator.RunConfig fields the scripts set (fm/fm.py:187-194)."""
+    save_checkpoints_steps: Optional[int] = None
+    keep_checkpoint_max: int = 5
+    log_step_count_steps: int = 100
+    save_summary_steps: int = 200
+    train_distribute: Any = None
+    eval_distribute: Any = None
+    use_hip_graph: bool = True
+    device: str = "cuda"
+    seed: int = 0
+    adam_mode: str = "tf1_dense"    # 'tf1_dense' (reference semantics) | 'lazy_rows' (NOT TF semantics)
+
+
+@dataclass
+class TrainSpec:
+    input_fn: Callable
+    max_steps: Optional[int] = None
+
+
+@dataclass
+class EvalSpec:
+    input_fn: Callable
+    steps: Optional[int] = 100
+    start_delay_secs: int = 120
+    throttle_secs: int = 600
+
+
+class VariableStore:
+    """The variables of one model: named embedding arenas + one flat dense arena + the optimizer."""
+
+    def __init__(self, device, seed, adam_mode):
+        self.device = torch.device(device)
+        self.embeddings: Dict[str, EmbeddingArena] = {}
+        self.dense: Optional[DenseArena] = None
+        self.opt: Optional[AdamTF1] = None
+        self.built = False
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed(seed)
+        self.adam_mode = adam_mode
+        self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
+
+    def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr):
+        self.embeddings = embeddings
+        self.dense = DenseArena(dense_shapes, self.device)
+        with torch.no_grad():
+            for k, fn in dense_init.items():
+                t = torch.empty(tuple(dense_shapes[k]))
+                fn(t, self.gen)
+                self.dense[k].copy_(t)
+        self.opt = AdamTF1(lr=lr, device=self.device)
+        self.built = True
+
+    def adam_segments(self):
+        lazy = self.adam_mode == "lazy_rows"
+        segs = []
+        for a in self.embeddings.values():
+            segs += a.adam_segments(lazy)
+        segs += self.extra_segments
+        segs += self.dense.adam_segments()
+        return segs
+
+    def apply_gradients(self):
+        self.opt.step(self.adam_segments())
+
+    # -- checkpoint -------------------------------------------------------
+    def state_dict(self):
+        sd = {"opt_state": self.opt.state.cpu(), "dense": {k: getattr(self.dense, k).cpu() for k in ("flat", "m", "v")}}
+        for name, a in self.embeddings.items():
+            sd["emb." + name] = {k: getattr(a, k).cpu() for k in ("tables", "m_t", "v_t", "w1", "m_w", "v_w")
+                                 if getattr(a, k, None) is not None}
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            self.opt.state.copy_(sd["opt_state"])
+            for k in ("flat", "m", "v"):
+                getattr(self.dense, k).copy_(sd["dense"][k])
+            for name, a in self.embeddings.items():
+                for k, v in sd["emb." + name].items():
+                    getattr(a, k).copy_(v)
+
+
+_CURRENT_STORE = []
+
+
+def get_variable_store() -> VariableStore:
+    """What tf.get_variable's implicit graph is to the reference: the calling Estimator's store."""
+    if not _CURRENT_STORE:
+        raise RuntimeError("model_fn must be called by an Estimator (no active VariableStore)")
+    return _CURRENT_STORE[-1]
+
+
+class Estimator:
+    def __init__(self, model_fn, model_dir=None, params=None, config: Optional[RunConfig] = None):
+        self.model_fn = model_fn
+        self.model_dir = model_dir
+        self.params = dict(params or {})
+        self.config = config or RunConfig()
+        self.store = VariableStore(self.config.device, self.config.seed, self.config.adam_mode)
+        self._graphs = {}
+        self._restored = False
+        self._log_t = None
+        self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def _call_model_fn(self, features, labels, mode):
+        _CURRENT_STORE.append(self.store)
+        try:
+            return self.model_fn(features, labels, mode, self.params)
+        finally:
+            _CURRENT_STORE.pop()
+
+    def _to_device(self, x):
+        dev = self.store.device
+        if isinstance(x, dict):
+            return {k: self._to_device(v) for k, v in x.items()}
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        if isinstance(x, torch.Tensor):
+            return x.to(dev, non_blocking=True)
+        return x
+
+    def _train_eager(self, features, labels):
+        spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
+        spec.train_op()
+        return spec.loss
+
+    def _shape_key(self, features, labels):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items())) + (tuple(labels.shape),)
+
+    def _train_step(self, features, labels):
+        """One global step; captured into a HIP graph per input signature after 2 eager warm-up steps."""
+        if not self.config.use_hip_graph:
+            return self._train_eager(features, labels)
+        key = self._shape_key(features, labels)
+        g = self._graphs.get(key)
+        if g is None:
+            g = {"warm": 0}
+            self._graphs[key] = g
+        if "graph" not in g:
+            if g["warm"] < 2:
+                g["warm"] += 1
+                return self._train_eager(features, labels)
+            g["feat"] = {k: v.clone() for k, v in features.items()}
+            g["lab"] = labels.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g["loss"] = self._train_eager(g["feat"], g["lab"])
+            g["graph"] = graph      # capture executes nothing: the static buffers already hold this
+            graph.replay()          # batch (cloned above), so replay once to apply its step
+            return g["loss"]
+        for k, v in features.items():
+            g["feat"][k].copy_(v, non_blocking=True)
+        g["lab"].copy_(labels, non_blocking=True)
+        g["graph"].replay()
+        return g["loss"]
+
+    def _maybe_restore(self):
+        if self._restored or not self.model_dir or not self.store.built:
+            return
+        self._restored = True
+        from . import checkpoint
+        checkpoint.restore_latest(self.model_dir, self.store)
+
+    @property
+    def global_step(self):
+        return self.store.opt.global_step if self.store.built else 0
+
+    # -- public API --------------------------------------------------------------------------
+    def train(self, input_fn, steps=None, max_steps=None):
+        it = iter(input_fn())
+        done = 0
+        cfg = self.config
+        self._log_t, log_step0 = time.time(), None
+        while True:
+            if steps is not None and done >= steps:
+                break
+            if max_steps is not None and self.store.built and self.global_step >= max_steps:
+                break
+            try:
+                features, labels = next(it)
+            except StopIteration:
+                break
+            features, labels = self._to_device(features), self._to_device(labels)
+            if not self.store.built:          # variables are created by the first model_fn call
+                self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                self._maybe_restore()
+            loss = self._train_step(features, labels)
+            done += 1
+            gs = self.global_step if (done % cfg.log_step_count_steps == 0 or
+                                      (cfg.save_checkpoints_steps and done % cfg.save_checkpoints_steps == 0)) else None
+            if gs is not None and done % cfg.log_step_count_steps == 0:
+                now = time.time()
+                if log_step0 is not None:
+                    rate = (gs - log_step0) / max(now - self._log_t, 1e-9)
+                    print("INFO:global_step/sec: %.4g  (examples/sec: %.6g)" % (rate, rate * labels.shape[0]), flush=True)
+                print("INFO:loss = %.7g, step = %d" % (float(loss), gs), flush=True)
+                self._log_t, log_step0 = now, gs
+            if gs is not None and cfg.save_checkpoints_steps and self.model_dir and \
+                    done % cfg.save_checkpoints_steps == 0:
+                from . import checkpoint
+                checkpoint.save(self.model_dir, self.store, gs, cfg.keep_checkpoint_max)
+        if self.model_dir and self.store.built and done:
+            from . import checkpoint
+            checkpoint.save(self.model_dir, self.store, self.global_step, cfg.keep_checkpoint_max)
+        return self
+
+    def evaluate(self, input_fn, steps=None):
+        auc, acc = _metrics.StreamingAUC(self.store.device), _metrics.StreamingAccuracy(self.store.device)
+        loss_sum, n = 0.0, 0
+        with torch.no_grad():
+            for features, labels in input_fn():
+                if steps is not None and n >= steps:
+                    break
+                features, labels = self._to_device(features), self._to_device(labels)
+                if not self.store.built:
+                    self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                self._maybe_restore()
+                spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
+                prob = spec.predictions["prob"]
+                auc.update(labels, prob)
+                acc.update(labels, prob)
+                loss_sum += float(spec.loss)
+                n += 1
+        res = {"AUC": auc.result(), "Accuracy": acc.result(), "loss": loss_sum / max(n, 1), "global_step": self.global_step}
+        print("INFO:Saving dict for global step %d: AUC = %.7g, Accuracy = %.7g, global_step = %d, loss = %.7g"
+              % (res["global_step"], res["AUC"], res["Accuracy"], res["global_step"], res["loss"]), flush=True)
+        return res
+
+    def predict(self, input_fn):
+        with torch.no_grad():
+            for features, labels in input_fn():
+                features = self._to_device(features)
+                if not self.store.built:
+                    self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                self._maybe_restore()
+                spec = self._call_model_fn(features, None, ModeKeys.PREDICT)
+                prob = spec.predictions["prob"].reshape(-1).cpu().numpy()
+                for p in prob:
+                    yield {"prob": p}
+
+
+def train_and_evaluate(estimator: Estimator, train_spec: TrainSpec, eval_spec: EvalSpec, eval_every_steps=None):
+    """estimator.train_and_evaluate (fm/fm.py:222): train until the input is exhausted / max_steps, evaluating
+    at every checkpoint (the TF loop evaluates whenever a new checkpoint appears, throttled)."""
+    every = eval_every_steps or estimator.config.save_checkpoints_steps
+    res = None
+    if not every:
+        estimator.train(train_spec.input_fn, max_steps=train_spec.max_steps)
+        return estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
+    it_fn = _Resumable(train_spec.input_fn)
+    while not it_fn.exhausted:
+        estimator.train(it_fn, steps=every, max_steps=train_spec.max_steps)
+        res = estimator.evaluate(eval_spec.input_fn, steps=eval_spec.steps)
+        if train_spec.max_steps is not None and estimator.global_step >= train_spec.max_steps:
+            break
+    return res
+
+
+class _Resumable:
+    """Keeps one iterator alive across successive Estimator.train(steps=...) calls."""
+
+    def __init__(self, input_fn):
+        self.it = None
+        self.input_fn = input_fn
+        self.exhausted = False
+
+    def __call__(self):
+        if self.it is None:
+            self.it = iter(self.input_fn())
+        return self
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        try:
+            return next(self.it)
+        except StopIteration:
+            self.exhausted = True
+            raise

@@ -1,0 +1,230 @@
+"""Torch-side plumbing over the C ABI (include/rsx.h): device buffers, streams, autograd glue.
+
+PyTorch is only the memory/stream/autograd carrier here; every op of the embedding path and the
+optimizer is a hand-written gfx950 kernel in librsx.so, called with raw device pointers.  There is no
+CPU fallback: constructing these objects without a GPU + librsx.so raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdamSeg, check, lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(dev):
+    if not torch.cuda.is_available():
+        raise _lib.RsxError("recsys_amd hot path needs an MI355X (torch.cuda.is_available() is False); "
+                            "there is no CPU fallback")
+    lib()
+    return torch.device(dev)
+
+
+class EmbeddingArena:
+    """All embedding tables of one `input_layer` call, concatenated row-wise: tables[R, D] (+ the
+    first-order weight vector w1[R] of the indicator columns), their Adam slots and the
+    dedup/scatter workspace.  Mirrors the variables created by
+    tf.feature_column.input_layer(features, embedding cols) (fm/fm.py:118) and the [R,1] kernel of
+    tf.layers.dense(linear_net, 1) (fm/fm.py:121)."""
+
+    def __init__(self, row_off, D, capacity, device="cuda", with_w1=False, w1_field_mask=None,
+                 tables=None, w1=None):
+        dev = _require_cuda(device)
+        self.row_off_np = np.asarray(row_off, np.int64)
+        self.F = len(self.row_off_np) - 1
+        self.R = int(self.row_off_np[-1])
+        self.D = int(D)
+        self.stride = int(capacity)
+        self.max_rows = int(np.diff(self.row_off_np).max())
+        self.row_off = torch.tensor(self.row_off_np, dtype=torch.int32, device=dev)
+        self.tables = torch.empty(self.R, D, device=dev) if tables is None else \
+            torch.as_tensor(tables, dtype=torch.float32).to(dev).contiguous()
+        assert self.tables.shape == (self.R, D)
+        self.m_t = torch.zeros_like(self.tables)
+        self.v_t = torch.zeros_like(self.tables)
+        self.with_w1 = with_w1
+        self.w1_mask = (1 << self.F) - 1 if w1_field_mask is None else int(w1_field_mask)
+        if with_w1:
+            self.w1 = torch.empty(self.R, device=dev) if w1 is None else \
+                torch.as_tensor(w1, dtype=torch.float32).to(dev).contiguous().reshape(-1)
+            self.m_w = torch.zeros_like(self.w1)
+            self.v_w = torch.zeros_like(self.w1)
+        else:
+            self.w1 = None
+        F, st = self.F, self.stride
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.perm = torch.zeros(F * st, **i32)
+        self.seg_off = torch.zeros(F * (st + 1), **i32)
+        self.uniq_row = torch.zeros(F * st, **i32)
+        self.nuniq = torch.zeros(F, **i32)
+        self.slot = torch.full((self.R + 4,), -1, **i32)       # +4: int4 tail reads of VEC_SLOT
+        self.G = torch.zeros(F * st, D, device=dev)
+        self.gw1 = torch.zeros(F * st, device=dev) if with_w1 else None
+        self.last_B = 0
+        # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
+        self.hook = torch.zeros((), device=dev, requires_grad=True)
+
+    # -- kernels ---------------------------------------------------------------------------
+    def field_sort(self, ids):
+        B = ids.shape[0]
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and B <= self.stride
+        check(lib().rsx_field_sort(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
+                                   _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot), self.max_rows,
+                                   B, self.F, self.stride, _stream()), "rsx_field_sort")
+        self.last_B = B
+
+    def gather(self, ids, fm=False, first_order=False):
+        """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd)."""
+        B = ids.shape[0]
+        dev = self.tables.device
+        E = torch.empty(B, self.F * self.D, device=dev)
+        S = torch.empty(B, self.D, device=dev) if fm else None
+        y2 = torch.empty(B, device=dev) if fm else None
+        y1 = torch.empty(B, device=dev) if first_order else None
+        check(lib().rsx_gather_fm_fwd(_ptr(self.tables), _ptr(self.w1) if first_order else None, _ptr(self.row_off),
+                                      _ptr(ids), _ptr(E), _ptr(S), _ptr(y1), _ptr(y2), self.w1_mask,
+                                      B, self.F, self.D, _stream()), "rsx_gather_fm_fwd")
+        return E, S, y1, y2
+
+    def segsum(self, B, S, dX, gy1, gy2):
+        check(lib().rsx_segsum_bwd(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
+                                   _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.G),
+                                   _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
+                                   self.stride, _stream()), "rsx_segsum_bwd")
+
+    # -- optimizer segments ----------------------------------------------------------------
+    def adam_segments(self, lazy=False):
+        segs = []
+        if lazy:
+            segs.append(dict(kind=_lib.RSX_ADAM_TABLE_ROWS, d=self.D, n=self.F * self.last_B, var=self.tables,
+                             m=self.m_t, v=self.v_t, g=self.G, uniq_row=self.uniq_row, nuniq=self.nuniq,
+                             B=self.last_B, stride=self.stride))
+            if self.with_w1:
+                segs.append(dict(kind=_lib.RSX_ADAM_VEC_ROWS, n=self.F * self.last_B, var=self.w1, m=self.m_w,
+                                 v=self.v_w, g=self.gw1, uniq_row=self.uniq_row, nuniq=self.nuniq,
+                                 B=self.last_B, stride=self.stride))
+        else:
+            segs.append(dict(kind=_lib.RSX_ADAM_TABLE_TF1, d=self.D, n=self.R, var=self.tables, m=self.m_t,
+                             v=self.v_t, g=self.G, slot=self.slot))
+            if self.with_w1:
+                segs.append(dict(kind=_lib.RSX_ADAM_VEC_SLOT, n=self.R, var=self.w1, m=self.m_w, v=self.v_w,
+                                 g=self.gw1, slot=self.slot))
+        return segs
+
+
+class GatherFM(torch.autograd.Function):
+    """Autograd node of the fused gather (+first-order +FM2).  backward = sorted segment-sum into the
+    arena's sparse-gradient workspace (the IndexedSlices of TF); returns no tensor gradients."""
+
+    @staticmethod
+    def forward(ctx, hook, arena, ids, fm, first_order):
+        E, S, y1, y2 = arena.gather(ids, fm, first_order)
+        ctx.arena, ctx.B, ctx.S = arena, ids.shape[0], S
+        ctx.fm, ctx.fo = fm, first_order
+        outs = [E]
+        if first_order:
+            outs.append(y1)
+        if fm:
+            outs.append(y2)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gE = grads[0]
+        k = 1
+        gy1 = gy2 = None
+        if ctx.fo:
+            gy1 = grads[k]
+            k += 1
+        if ctx.fm:
+            gy2 = grads[k]
+        gE = None if gE is None else gE.contiguous()
+        gy1 = None if gy1 is None else gy1.contiguous()
+        gy2 = None if gy2 is None else gy2.contiguous()
+        if ctx.fo and gy1 is None:
+            gy1 = torch.zeros(ctx.B, device=ctx.arena.tables.device)
+        ctx.arena.segsum(ctx.B, ctx.S if gy2 is not None else None, gE, gy1, gy2)
+        return None, None, None, None, None
+
+
+def gather_fm(arena, ids, fm=False, first_order=False):
+    return GatherFM.apply(arena.hook, arena, ids, fm, first_order)
+
+
+class DenseArena:
+    """All dense variables of a model as views into ONE flat fp32 buffer (and their grads / Adam slots
+    likewise), so the optimizer sweeps them as a single segment."""
+
+    def __init__(self, shapes, device="cuda"):
+        dev = _require_cuda(device)
+        self.names = list(shapes)
+        self.offsets = {}
+        n = 0
+        for k in self.names:
+            self.offsets[k] = n
+            n += int(np.prod(shapes[k])) if len(shapes[k]) else 1
+            n = (n + 3) & ~3                       # keep every variable 16-byte aligned
+        self.n = n
+        self.flat = torch.zeros(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.params = {}
+        for k in self.names:
+            sz = int(np.prod(shapes[k])) if len(shapes[k]) else 1
+            o = self.offsets[k]
+            p = self.flat[o:o + sz].view(tuple(shapes[k])).requires_grad_()
+            p.grad = self.grad[o:o + sz].view(tuple(shapes[k]))
+            self.params[k] = p
+
+    def __getitem__(self, k):
+        return self.params[k]
+
+    def load(self, values):
+        with torch.no_grad():
+            for k, v in values.items():
+                if k in self.params:
+                    self.params[k].copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(self.params[k].shape))
+
+    def adam_segments(self):
+        return [dict(kind=_lib.RSX_ADAM_DENSE, n=self.n, var=self.flat, m=self.m, v=self.v, g=self.grad,
+                     zero_grad=1)]
+
+
+class AdamTF1:
+    """tf.train.AdamOptimizer (fm/fm.py:162): one rsx_adam_tf1_multi launch per step over every segment."""
+
+    def __init__(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, device="cuda"):
+        dev = _require_cuda(device)
+        self.hp = (float(lr), float(beta1), float(beta2), float(eps))
+        st = np.zeros(4, np.float32)
+        check(lib().rsx_adam_state_init_h(st.ctypes.data_as(C.c_void_p), beta1, beta2))
+        self.state = torch.from_numpy(st).to(dev)
+
+    def step(self, segments):
+        n = len(segments)
+        arr = (AdamSeg * n)()
+        keep = []
+        for i, s in enumerate(segments):
+            a = arr[i]
+            a.kind, a.d, a.n = s["kind"], s.get("d", 0), int(s["n"])
+            for f in ("var", "m", "v", "g", "slot", "uniq_row", "nuniq"):
+                t = s.get(f)
+                setattr(a, f, None if t is None else t.data_ptr())
+                keep.append(t)
+            a.B, a.stride, a.zero_grad = s.get("B", 0), s.get("stride", 0), s.get("zero_grad", 0)
+        lr, b1, b2, eps = self.hp
+        check(lib().rsx_adam_tf1_multi(arr, n, _ptr(self.state), lr, b1, b2, eps, _stream()), "rsx_adam_tf1_multi")
+
+    @property
+    def global_step(self):
+        return int(self.state.view(torch.int32)[3].item()) - 1

@@ -1,0 +1,207 @@
+"""GPU parity tests proper: HIP kernels (through the C ABI) vs the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+
+from oracle import criteo, models, nn
+from tests.parity_util import deepfm_parity_run, synth_ids
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _arena(row_off, D, cap, rng, with_w1=True, mask=None):
+    from recsys_amd.ops import EmbeddingArena
+    R = int(row_off[-1])
+    tables = rng.standard_normal((R, D)).astype(np.float32) * 0.25
+    w1 = rng.standard_normal(R).astype(np.float32) * 0.1
+    a = EmbeddingArena(row_off, D, cap, "cuda", with_w1=with_w1, w1_field_mask=mask, tables=tables, w1=w1 if with_w1 else None)
+    return a, tables, w1
+
+
+@pytest.mark.parametrize("D,B,rows", [(16, 256, None), (16, 1, None), (4, 37, (3, 7, 4, 11, 6)), (8, 130, (5, 1, 9)),
+                                      (32, 65, (63, 8)), (64, 9, (3, 3))])
+def test_gather_fm_fwd(D, B, rows):
+    rng = np.random.default_rng(B + D)
+    row_off = criteo.row_offsets() if rows is None else np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    a, tables, w1 = _arena(row_off, D, max(B, 1), rng)
+    ids = synth_ids(rng, B, row_off)
+    E, S, y1, y2 = a.gather(torch.from_numpy(ids).cuda(), fm=True, first_order=True)
+    torch.cuda.synchronize()
+    _, Eo, y1o, So, y2o = models.gather_fm_fwd(tables, w1, ids, row_off)
+    assert np.array_equal(E.cpu().numpy().reshape(Eo.shape), Eo)           # a gather is bit-exact
+    np.testing.assert_allclose(S.cpu().numpy(), So, rtol=1e-5, atol=1e-6)   # tolerance: fp32, 1e-5 (north_star)
+    np.testing.assert_allclose(y1.cpu().numpy(), y1o, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y2.cpu().numpy(), y2o, rtol=1e-5, atol=2e-5)
+
+
+def test_gather_empty_batch_and_masks():
+    rng = np.random.default_rng(0)
+    row_off = np.array([0, 3, 10, 14], np.int64)
+    a, tables, w1 = _arena(row_off, 16, 8, rng, mask=0b101)
+    ids = torch.zeros((0, 3), dtype=torch.int32, device="cuda")
+    E, S, y1, y2 = a.gather(ids, fm=True, first_order=True)
+    assert E.shape == (0, 48)
+    ids_np = synth_ids(rng, 8, row_off)
+    E, S, y1, y2 = a.gather(torch.from_numpy(ids_np).cuda(), fm=False, first_order=True)
+    rows = ids_np + row_off[None, :-1]
+    want = w1[rows[:, 0]] + w1[rows[:, 2]]                                   # field 1 masked out of the first-order term
+    np.testing.assert_allclose(y1.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    assert S is None and y2 is None
+
+
+@pytest.mark.parametrize("B,rows", [(256, None), (1, None), (100, (3, 7, 4, 11, 6)), (4096, (3, 1000, 50)), (1000, (2,))])
+def test_field_sort_is_exact(B, rows):
+    """Index work is bit-exact: sorted unique rows, segment boundaries, permutation, slot map."""
+    rng = np.random.default_rng(B)
+    row_off = criteo.row_offsets() if rows is None else np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    a, _, _ = _arena(row_off, 16, B + 3, rng)          # stride != B on purpose
+    F = len(row_off) - 1
+    for rep in range(2):                               # second call must clear the first call's slot entries
+        ids = synth_ids(rng, B, row_off)
+        a.field_sort(torch.from_numpy(ids).cuda())
+        torch.cuda.synchronize()
+        st = a.stride
+        perm = a.perm.cpu().numpy().reshape(F, st)
+        seg = a.seg_off.cpu().numpy().reshape(F, st + 1)
+        uniq = a.uniq_row.cpu().numpy().reshape(F, st)
+        nu = a.nuniq.cpu().numpy()
+        slot = a.slot.cpu().numpy()[:a.R]
+        want_slot = np.full(a.R, -1, np.int64)
+        for f in range(F):
+            order = np.lexsort((np.arange(B), ids[:, f]))          # by id, then by example index
+            assert np.array_equal(perm[f, :B], order)
+            u, first = np.unique(ids[order, f], return_index=True)
+            assert nu[f] == len(u)
+            assert np.array_equal(uniq[f, :len(u)], u + row_off[f])
+            assert np.array_equal(seg[f, :len(u)], first) and seg[f, len(u)] == B
+            want_slot[u + row_off[f]] = f * st + np.arange(len(u))
+        assert np.array_equal(slot, want_slot)
+
+
+@pytest.mark.parametrize("B,rows,D", [(256, None, 16), (300, (3, 7, 4, 11, 6), 4), (2048, (2, 500), 16)])
+def test_segsum_bwd(B, rows, D):
+    rng = np.random.default_rng(B + 1)
+    row_off = criteo.row_offsets() if rows is None else np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    a, tables, w1 = _arena(row_off, D, B, rng)
+    F = len(row_off) - 1
+    ids = synth_ids(rng, B, row_off)
+    dX = rng.standard_normal((B, F * D)).astype(np.float32) * 1e-2
+    gy1 = rng.standard_normal(B).astype(np.float32) * 1e-2
+    gy2 = rng.standard_normal(B).astype(np.float32) * 1e-2
+    idt = torch.from_numpy(ids).cuda()
+    a.field_sort(idt)
+    E, S, _, _ = a.gather(idt, fm=True, first_order=True)
+    a.segsum(B, S, torch.from_numpy(dX).cuda(), torch.from_numpy(gy1).cuda(), torch.from_numpy(gy2).cuda())
+    torch.cuda.synchronize()
+    rws = ids.astype(np.int64) + row_off[None, :-1]
+    So = S.cpu().numpy()                                   # same S on both sides -> the rest is order-exact
+    dE = models.fm2_bwd(tables[rws], So, gy2) + dX.reshape(B, F, D)
+    r, v = models._pairs_field_major(rws, dE)
+    uniq, G = nn.segment_sum_rows(r, v)
+    _, g1 = nn.segment_sum_rows(*models._pairs_field_major(rws, np.repeat(gy1[:, None], F, 1)))
+    slot = a.slot.cpu().numpy()[:a.R]
+    Gg = a.G.cpu().numpy()[slot[uniq]]
+    g1g = a.gw1.cpu().numpy()[slot[uniq]]
+    assert (slot[uniq] >= 0).all() and (slot >= 0).sum() == len(uniq)
+    # sequential ascending-b sums with unfused mul/add: identical operation order to the oracle -> bit-exact
+    assert np.array_equal(Gg, G)
+    assert np.array_equal(g1g, g1)
+
+
+def test_adam_tf1_bit_exact_over_steps():
+    """Element-wise optimizer math is reproducible bit for bit (no FMA contraction, IEEE div/sqrt)."""
+    from recsys_amd import _lib
+    from recsys_amd.ops import AdamTF1, DenseArena
+    rng = np.random.default_rng(3)
+    row_off = np.array([0, 5, 25, 26], np.int64)
+    B, D, F = 16, 16, 3
+    a, tables, w1 = _arena(row_off, D, B, rng)
+    dense = DenseArena({"w": (7, 3), "b": (5,)}, "cuda")            # 26 floats: exercises the scalar tail
+    dvals = {"w": rng.standard_normal((7, 3)).astype(np.float32), "b": rng.standard_normal(5).astype(np.float32)}
+    dense.load(dvals)
+    opt = AdamTF1(device="cuda")
+    oo = nn.AdamTF1(dtype=np.float32)
+    T, W = tables.copy(), w1.copy()
+    for step in range(4):
+        ids = synth_ids(rng, B, row_off)
+        dX = (rng.standard_normal((B, F * D)) * 10.0 ** rng.integers(-6, 0)).astype(np.float32)
+        gy1 = rng.standard_normal(B).astype(np.float32) * 1e-3
+        gd = {k: rng.standard_normal(v.shape).astype(np.float32) * 1e-3 for k, v in dvals.items()}
+        idt = torch.from_numpy(ids).cuda()
+        a.field_sort(idt)
+        a.segsum(B, None, torch.from_numpy(dX).cuda(), torch.from_numpy(gy1).cuda(), None)
+        for k in gd:
+            dense[k].grad.copy_(torch.from_numpy(gd[k]))
+        opt.step(a.adam_segments() + dense.adam_segments())
+        torch.cuda.synchronize()
+        rws = ids.astype(np.int64) + row_off[None, :-1]
+        u, G = nn.segment_sum_rows(*models._pairs_field_major(rws, dX.reshape(B, F, D)))
+        _, g1 = nn.segment_sum_rows(*models._pairs_field_major(rws, np.repeat(gy1[:, None], F, 1)))
+        oo.apply_sparse("t", T, u, G)
+        gw = np.zeros_like(W)
+        gw[u] = g1
+        oo.apply_dense("w1", W, gw)
+        for k in gd:
+            oo.apply_dense(k, dvals[k], gd[k])
+        oo.finish_step()
+        assert np.array_equal(a.tables.cpu().numpy(), T), step
+        assert np.array_equal(a.w1.cpu().numpy(), W), step
+        for k in gd:
+            assert np.array_equal(dense[k].detach().cpu().numpy(), dvals[k]), (step, k)
+            assert float(dense[k].grad.abs().max()) == 0.0            # zero_grad after use
+    assert opt.global_step == 4
+
+
+def test_adam_lazy_rows_mode():
+    from recsys_amd.ops import AdamTF1
+    rng = np.random.default_rng(4)
+    row_off = np.array([0, 50, 60], np.int64)
+    B, D, F = 8, 16, 2
+    a, tables, w1 = _arena(row_off, D, B, rng)
+    opt, oo = AdamTF1(device="cuda"), nn.AdamTF1(dtype=np.float32)
+    T, W = tables.copy(), w1.copy()
+    for step in range(3):
+        ids = synth_ids(rng, B, row_off)
+        dX = rng.standard_normal((B, F * D)).astype(np.float32) * 1e-3
+        gy1 = rng.standard_normal(B).astype(np.float32) * 1e-3
+        idt = torch.from_numpy(ids).cuda()
+        a.field_sort(idt)
+        a.segsum(B, None, torch.from_numpy(dX).cuda(), torch.from_numpy(gy1).cuda(), None)
+        opt.step(a.adam_segments(lazy=True))
+        rws = ids.astype(np.int64) + row_off[None, :-1]
+        u, G = nn.segment_sum_rows(*models._pairs_field_major(rws, dX.reshape(B, F, D)))
+        _, g1 = nn.segment_sum_rows(*models._pairs_field_major(rws, np.repeat(gy1[:, None], F, 1)))
+        oo.apply_sparse("t", T, u, G, lazy=True)
+        oo.apply_sparse("w", W, u, g1, lazy=True)
+        oo.finish_step()
+    torch.cuda.synchronize()
+    assert np.array_equal(a.tables.cpu().numpy(), T) and np.array_equal(a.w1.cpu().numpy(), W)
+
+
+def test_deepfm_train_parity_small():
+    err, losses, perr = deepfm_parity_run(B=64, steps=4, seed=2, rows=(3, 7, 40, 11, 600), D=16, layers=(32, 16),
+                                          return_all=True)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5
+    assert max(perr.values()) < 1e-5, perr
+
+
+def test_deepfm_train_parity_criteo_bs256():
+    """BASELINE config 2: DeepFM, Criteo 39 fields, d=16, DNN 100-100, batch 256 -- oracle vs HIP, tolerance 1e-5."""
+    err, losses, perr = deepfm_parity_run(B=256, steps=3, seed=5, return_all=True)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5, losses
+    assert max(perr.values()) < 1e-5, perr
+
+
+def test_deepfm_hip_graph_matches_eager():
+    e1 = deepfm_parity_run(B=128, steps=6, seed=7, rows=(3, 7, 40, 11, 600), layers=(32, 16), use_graph=True)
+    assert e1 < 1e-5, e1
+
+
+def test_deepfm_lazy_rows_mode_parity():
+    err, losses, perr = deepfm_parity_run(B=64, steps=3, seed=8, rows=(3, 7, 40, 11, 600), layers=(32, 16),
+                                          adam_mode="lazy_rows", return_all=True)
+    assert err < 1e-5 and max(perr.values()) < 1e-5, (err, perr)
