@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: examples/sec of DeepFM training on the Criteo 39-field pipeline
+(d=16, DNN 100-100, batch 256 per replica; BASELINE configs[1]) on N MI355X of one node.
+
+A "step" = one full training step (embedding gather + first-order + FM, DNN tower fwd/bwd with
+BatchNorm + dropout 0.5, sorted segment-sum scatter, TF-1 non-lazy Adam over every variable) on one
+synthetic pre-hashed batch already resident in HBM.  Optimizer semantics are the reference's
+(`adam_mode=tf1_dense`): nothing is skipped inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel (adam_multi_k, the TF-faithful dense Adam sweep): algorithmic bytes per
+                  launch / mean launch duration measured with HIP events on the launch stream.
+  cpu_baseline -- the numpy oracle port of the same step timed on the host (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--batch_size", type=int, default=256)
+    p.add_argument("--adam_mode", default="tf1_dense", choices=["tf1_dense", "lazy_rows"])
+    p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_seconds", type=float, default=12.0)
+    p.add_argument("--n_batches", type=int, default=64)
+    return p.parse_args()
+
+
+def cpu_baseline(batches, layout, seconds):
+    """Oracle (numpy port of the reference semantics) timed on the host: same step, same batches."""
+    from oracle import init, models, nn
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(1)
+    except Exception:
+        ctx = None
+    P = init.deepfm_params(0, 16, (100, 100), np.float32, layout.row_off)
+    m = models.DeepFM(P, layout.row_off, 2, 0.5)
+    opt = nn.AdamTF1(dtype=np.float32)
+    rng = np.random.default_rng(0)
+    n, t0 = 0, None
+    B = batches[0][0].shape[0]
+    while True:
+        ids, y, _ = batches[n % len(batches)]
+        masks = [(rng.random((B, 100)) >= 0.5).astype(np.float32) for _ in range(2)]
+        models.train_step(m, opt, (ids,), y, {"masks": masks})
+        n += 1
+        if t0 is None:            # first step is warm-up (page faults of the 3x54 MB state)
+            t0, n0 = time.perf_counter(), n
+        elif time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    steps = n - n0
+    if ctx is not None:
+        ctx.__exit__(None, None, None)
+    return {"value": steps * B / dt, "unit": "examples/sec", "cores": 1, "kind": "port",
+            "sample": "%d DeepFM bs%d training steps of the numpy oracle (fp32, TF-1 dense Adam), %.1f s, 1 thread; "
+                      "TensorFlow itself is not installable here" % (steps, B, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    from recsys_amd import build as _build
+    if rank == 0:
+        _build.build(verbose=False)
+    from recsys_amd import deepfm, dist, synthetic
+    from recsys_amd.estimator import Estimator, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+
+    dp = None
+    if world > 1 or os.environ.get("RSX_FORCE_DIST") == "1":
+        dist.init_process_group("nccl")
+        dp = dist.DataParallel()
+        dp.barrier()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+
+    B = a.batch_size
+    lin, emb = build_feature_columns(16)
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16,
+              "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B}
+    cfg = RunConfig(use_hip_graph=not a.no_graph, adam_mode=a.adam_mode, device=str(dev), seed=1234)
+    est = Estimator(deepfm.model_fn, None, params, cfg)
+    if dp is not None:
+        est.store.dp = dp
+        est.dist = dp
+    layout = CriteoLayout.from_columns(emb)
+    host = synthetic.criteo_id_batches(layout, a.n_batches, B, seed=synthetic.SEED + rank)
+    feats = [({"ids": torch.from_numpy(i).to(dev)}, torch.from_numpy(y).to(dev)) for i, y, _ in host]
+    # variables are created on the first call; then W untimed warm-up steps (includes graph capture)
+    with torch.no_grad():
+        est._call_model_fn(feats[0][0], None, "infer")
+    for s in range(a.warmup):
+        f, y = feats[s % len(feats)]
+        est._train_step(f, y)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        f, y = feats[s % len(feats)]
+        loss = est._train_step(f, y)
+    torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dp is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
+    store = est.store
+    arena = store.embeddings["input_layer"]
+    segs = store.adam_segments()
+    n_dense = store.dense.n
+    alg_bytes = 24 * (arena.R * arena.D + arena.R) + 32 * n_dense if a.adam_mode == "tf1_dense" else None
+    reps = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    f, y = feats[0]
+    adam_ms = 0.0
+    for r in range(reps):
+        # a real step's state: fresh sort + sparse grads, then time only the optimizer launch
+        store.sort_ids_for_backward(arena, f["ids"])
+        e0.record()
+        store.opt.step(segs)
+        e1.record()
+        e1.synchronize()
+        adam_ms += e0.elapsed_time(e1)
+    adam_ms /= reps
+    roof = None
+    if alg_bytes is not None:
+        ach = alg_bytes / (adam_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "adam_multi_k", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(ach / 8000.0, 4), "traffic": None, "alg_bytes_per_launch": alg_bytes,
+                "launch_ms": round(adam_ms, 5)}
+
+    if rank != 0:
+        return
+    N = max(world, 1) if dp is not None else 1
+    out = {"metric": "examples/sec", "value": round(N * B * a.steps / dt, 1), "unit": "examples/sec", "n_gpus": a.gpus,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "deepfm.py Criteo-39 d=16 DNN 100-100 bs=256/replica, full train step "
+                                  "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s" % (a.adam_mode, not a.no_graph),
+                      "global_batch": N * B, "parallelism": "dp%d" % N, "final_loss": round(final_loss, 5)},
+           "roofline": roof}
+    if N == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(host, layout, a.cpu_seconds)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -208,10 +208,11 @@ static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* ta
 extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
                                  float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int B, int F,
                                  int D, rsx_stream_t stream) {
-  if (!tables || !row_off || !ids || !E || B < 0 || F <= 0 || F > 64 || !d_ok(D)) return RSX_EINVAL;
+  if (B < 0 || F <= 0 || F > 64 || !d_ok(D)) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;  // empty batch: nothing to read or write (buffers may be null)
+  if (!tables || !row_off || !ids || !E) return RSX_EINVAL;
   if ((y1 != nullptr) != (w1 != nullptr)) return RSX_EINVAL;
   if (y2 != nullptr && S == nullptr) return RSX_EINVAL;
-  if (B == 0) return RSX_OK;
   const int waves = B >= 2048 ? 4 : 1;  // small batches: one wave per workgroup spreads over all 256 CUs
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
   RSX_DISPATCH_D(D, launch_gather, grid, block, rsx_s(stream), tables, w1, row_off, ids, E, S, y1, y2,

@@ -46,6 +46,8 @@ def build_variables(store, params, capacity, with_dnn=True):
     layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
     D = params["embedding_size"]
     lin_keys = {c.key for c in params["linear_feature_columns"] if c.kind.endswith("indicator")}
+    if store.dp is not None:
+        capacity *= store.dp.world                              # the sort/scatter workspace holds the global batch
     arena = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=True,
                            w1_field_mask=layout.field_mask(lin_keys))
     with torch.no_grad():
@@ -74,8 +76,8 @@ def model_fn(features, labels, mode, params):
     masks = params.get("_dropout_masks")
 
     if training:
-        arena.field_sort(ids)                                  # dedup for the sparse gradient (ids only)
-    E, y1p, y2 = gather_fm(arena, ids, fm=True, first_order=True)    # embedding_features, first-order, second-order
+        store.sort_ids_for_backward(arena, ids)                # dedup for the sparse gradient (ids only)
+    E, y1p, y2 = gather_fm(arena, ids, fm=True, first_order=True, dp=store.dp if training else None)
     y_1d = torch.relu(y1p + P["b1"])                           # 'first-order' (:90-91)
     dnn_net = L.tower(E, P, "dnn", n_layers, training, params["dropout"], masks)    # 'dnn' (:100-107)
     y_dnn = L.dense(dnn_net, P["dnn.Wout"], P["dnn.bout"], relu=True)              # (:108)
@@ -90,8 +92,7 @@ def model_fn(features, labels, mode, params):
         return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
 
     def train_op():                                            # AdamOptimizer.minimize (:142-143)
-        loss.backward()
-        store.apply_gradients()
+        store.minimize(loss)
 
     return EstimatorSpec(mode, predictions=predictions, loss=loss, train_op=train_op)
 

@@ -82,6 +82,7 @@ class VariableStore:
         self.gen.manual_seed(seed)
         self.adam_mode = adam_mode
         self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
+        self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
 
     def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr):
         self.embeddings = embeddings
@@ -102,6 +103,22 @@ class VariableStore:
         segs += self.extra_segments
         segs += self.dense.adam_segments()
         return segs
+
+    def sort_ids_for_backward(self, arena, ids):
+        """Dedup stage of the sparse gradient.  Data-parallel: over the all-gathered global batch."""
+        if self.dp is not None:
+            ids = self.dp.all_gather_rows(ids)
+        arena.field_sort(ids)
+
+    def minimize(self, loss):
+        """optimizer.minimize(loss) (fm/fm.py:162-163) incl. MirroredStrategy's 1/N loss scaling and
+        cross-replica gradient sum (Appendix A-12)."""
+        if self.dp is not None:
+            (loss / self.dp.world).backward()
+            self.dp.all_reduce_sum(self.dense.grad)
+        else:
+            loss.backward()
+        self.apply_gradients()
 
     def apply_gradients(self):
         self.opt.step(self.adam_segments())
@@ -167,7 +184,9 @@ class Estimator:
     def _train_eager(self, features, labels):
         spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
         spec.train_op()
-        return spec.loss
+        # detach: a live loss would keep this step's autograd graph (and its AccumulateGrad nodes, bound to
+        # this stream) alive into the next step, which breaks HIP-graph capture on the capture stream
+        return spec.loss.detach()
 
     def _shape_key(self, features, labels):
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items())) + (tuple(labels.shape),)

@@ -126,9 +126,9 @@ class GatherFM(torch.autograd.Function):
     arena's sparse-gradient workspace (the IndexedSlices of TF); returns no tensor gradients."""
 
     @staticmethod
-    def forward(ctx, hook, arena, ids, fm, first_order):
+    def forward(ctx, hook, arena, ids, fm, first_order, dp=None):
         E, S, y1, y2 = arena.gather(ids, fm, first_order)
-        ctx.arena, ctx.B, ctx.S = arena, ids.shape[0], S
+        ctx.arena, ctx.B, ctx.S, ctx.dp = arena, ids.shape[0], S, dp
         ctx.fm, ctx.fo = fm, first_order
         outs = [E]
         if first_order:
@@ -152,12 +152,21 @@ class GatherFM(torch.autograd.Function):
         gy2 = None if gy2 is None else gy2.contiguous()
         if ctx.fo and gy1 is None:
             gy1 = torch.zeros(ctx.B, device=ctx.arena.tables.device)
-        ctx.arena.segsum(ctx.B, ctx.S if gy2 is not None else None, gE, gy1, gy2)
-        return None, None, None, None, None
+        S = ctx.S if gy2 is not None else None
+        B = ctx.B
+        if ctx.dp is not None:
+            # data parallel: one packed all-gather of the per-example gradient block, then the same sorted
+            # segment-sum over the GLOBAL batch on every rank (arena.field_sort saw the all-gathered ids)
+            if gE is None:
+                gE = torch.zeros(B, ctx.arena.F * ctx.arena.D, device=ctx.arena.tables.device)
+            gE, S, gy1, gy2 = ctx.dp.gather_example_grads(gE, S, gy1, gy2)
+            B = gE.shape[0]
+        ctx.arena.segsum(B, S, gE, gy1, gy2)
+        return None, None, None, None, None, None
 
 
-def gather_fm(arena, ids, fm=False, first_order=False):
-    return GatherFM.apply(arena.hook, arena, ids, fm, first_order)
+def gather_fm(arena, ids, fm=False, first_order=False, dp=None):
+    return GatherFM.apply(arena.hook, arena, ids, fm, first_order, dp)
 
 
 class DenseArena:
