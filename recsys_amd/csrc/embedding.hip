@@ -131,10 +131,61 @@ __global__ __launch_bounds__(1024) void field_sort_k(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------ backward: sorted segment-sum -
-// LPR lanes per unique row (f, j); the group walks its segment in ascending b and accumulates
+// A wave owns GPW = 64/LPR consecutive unique rows (f, j0..j0+GPW-1) of one field; LPR lanes (one float4
+// each) form the group of one row.  Per entry of a segment the contribution is
 //   (gy2[b]*S[b,:] - gy2[b]*T[row,:]) + dX[b, f*D:(f+1)*D]   (term order = TF autodiff of fm/fm.py:127-129)
-// sequentially, i.e. exactly the order of a CPU unsorted_segment_sum.  E[b,f,:] == T[row,:] for the
-// whole segment, so the row is read once instead of once per example.
+// and E[b,f,:] == T[row,:] for the whole segment, so the row is read once instead of once per example.
+//  * short segments (<= SEG_SHORT entries): the group sums sequentially in ascending b -- exactly the
+//    order of a CPU unsorted_segment_sum -- with the loads of 4 entries in flight at a time.
+//  * long segments (tiny-vocabulary fields, Zipf heads): the whole wave cooperates: the segment is cut
+//    into GPW contiguous sub-ranges, each group sums its sub-range in ascending b, and the GPW partials
+//    are added in ascending sub-range order.  A fixed order -> deterministic; no atomics anywhere.
+constexpr int SEG_SHORT = 16;
+
+template <int LPR>
+struct SegCtx {
+  const float4* __restrict__ S4;
+  const float4* __restrict__ X4;
+  const float* __restrict__ gy1;
+  const float* __restrict__ gy2;
+  const int32_t* __restrict__ pf;
+  int F, f, q;
+  bool do1;
+};
+
+// sequential ascending sum over sorted positions [i0, i1) of one field; 4 entries' loads in flight
+template <int LPR>
+__device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4 e, int i0, int i1, float4& acc,
+                                              float& a1) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = i0; i < i1; i += 4) {
+    int bb[4];
+    float g[4], h[4];
+    float4 s[4], x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bb[k] = (i + k < i1) ? c.pf[i + k] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = bb[k] >= 0;
+      const int b = ok ? bb[k] : 0;
+      g[k] = (ok && c.gy2 != nullptr) ? c.gy2[b] : 0.f;
+      s[k] = (ok && c.gy2 != nullptr) ? c.S4[(size_t)b * LPR + c.q] : z;
+      x[k] = (ok && c.X4 != nullptr) ? c.X4[((size_t)b * c.F + c.f) * LPR + c.q] : z;
+      h[k] = (ok && c.do1) ? c.gy1[b] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (bb[k] >= 0) {
+        float4 t = z;
+        if (c.gy2 != nullptr) t = f4_sub(f4_scale(g[k], s[k]), f4_scale(g[k], e));
+        if (c.X4 != nullptr) t = c.gy2 != nullptr ? f4_add(t, x[k]) : x[k];
+        acc = f4_add(acc, t);
+        if (c.do1) a1 += h[k];
+      }
+    }
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ tables, const float* __restrict__ S,
                                                     const float* __restrict__ dX, const float* __restrict__ gy1,
@@ -145,37 +196,67 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
                                                     float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
                                                     int stride) {
   constexpr int LPR = D / 4;
-  const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPR;
-  const int q = threadIdx.x % LPR;
-  if (gid >= F * B) return;
-  const int f = gid / B, j = gid % B;
-  if (j >= nuniq[f]) return;
-  const size_t sl = (size_t)f * stride + j;
-  const int beg = seg_off[(size_t)f * (stride + 1) + j], end = seg_off[(size_t)f * (stride + 1) + j + 1];
-  const int32_t* pf = perm + (size_t)f * stride;
-  const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
-  const float4* __restrict__ X4 = reinterpret_cast<const float4*>(dX);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int GPW = RSX_WAVE / LPR;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, g = lane / LPR;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wpf = (B + GPW - 1) / GPW;  // waves per field: a wave never straddles two fields
+  const int f = wave / wpf;
+  if (f >= F) return;
+  const int j0 = (wave - f * wpf) * GPW;
+  const int nu = nuniq[f];
+  if (j0 >= nu) return;  // wave-uniform
+  const int j = j0 + g;
+  const bool valid = j < nu;
+  const size_t sl = (size_t)f * stride + (valid ? j : j0);
+  const int beg = valid ? seg_off[(size_t)f * (stride + 1) + j] : 0;
+  const int end = valid ? seg_off[(size_t)f * (stride + 1) + j + 1] : 0;
+  const int L = end - beg;
+  SegCtx<LPR> c;
+  c.S4 = reinterpret_cast<const float4*>(S);
+  c.X4 = reinterpret_cast<const float4*>(dX);
+  c.gy1 = gy1;
+  c.gy2 = gy2;
+  c.pf = perm + (size_t)f * stride;
+  c.F = F;
+  c.f = f;
+  c.q = q;
+  c.do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 e = z;
+  if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)uniq_row[sl] * LPR + q];
+  float4 acc = z;
   float a1 = 0.f;
-  float4 e = acc;
-  if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)uniq_row[sl] * LPR + q];
-  const bool do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
-  for (int i = beg; i < end; ++i) {
-    const int b = pf[i];
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gy2 != nullptr) {
-      const float g = gy2[b];
-      c = f4_sub(f4_scale(g, S4[(size_t)b * LPR + q]), f4_scale(g, e));
+  if (valid && L <= SEG_SHORT) seg_range_sum<LPR>(c, e, beg, end, acc, a1);
+  unsigned long long todo = __ballot(valid && L > SEG_SHORT && q == 0);
+  while (todo) {  // wave-uniform loop over the long segments owned by this wave
+    const int src = __ffsll((long long)todo) - 1;  // lane (owner group, q = 0)
+    todo &= todo - 1;
+    const int sb = __shfl(beg, src), se = __shfl(end, src);
+    const float4 es = make_float4(__shfl(e.x, src + q), __shfl(e.y, src + q), __shfl(e.z, src + q), __shfl(e.w, src + q));
+    const int per = (se - sb + GPW - 1) / GPW;
+    const int r0 = sb + g * per;
+    const int r1 = r0 + per < se ? r0 + per : se;
+    float4 p = z;
+    float p1 = 0.f;
+    if (r0 < r1) seg_range_sum<LPR>(c, es, r0, r1, p, p1);
+    float4 tot = make_float4(__shfl(p.x, q), __shfl(p.y, q), __shfl(p.z, q), __shfl(p.w, q));
+    float t1 = __shfl(p1, 0);
+#pragma unroll
+    for (int k = 1; k < GPW; ++k) {  // ascending sub-range order
+      const int ln = k * LPR + q;
+      tot = f4_add(tot, make_float4(__shfl(p.x, ln), __shfl(p.y, ln), __shfl(p.z, ln), __shfl(p.w, ln)));
+      t1 += __shfl(p1, k * LPR);
     }
-    if (dX != nullptr) {
-      const float4 x = X4[((size_t)b * F + f) * LPR + q];
-      c = gy2 != nullptr ? f4_add(c, x) : x;
+    if (g == src / LPR) {
+      acc = tot;
+      a1 = t1;
     }
-    acc = f4_add(acc, c);
-    if (do1) a1 += gy1[b];
   }
-  reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
-  if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
+  if (valid) {
+    reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
+    if (gw1 != nullptr && q == 0) gw1[sl] = c.do1 ? a1 : 0.f;
+  }
 }
 
 // ------------------------------------------------------------------ C ABI ----------------------
@@ -255,8 +336,9 @@ extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* 
   if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
   if ((gy1 != nullptr) != (gw1 != nullptr)) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  const long long threads = (long long)F * B * (D / 4);
-  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  const int gpw = 64 / (D / 4);                                   // unique rows per wave
+  const long long waves = (long long)F * ((B + gpw - 1) / gpw);
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
                  nuniq, G, gw1, w1_field_mask, B, F, stride);
   RSX_CHECK_LAUNCH();

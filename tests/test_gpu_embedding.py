@@ -103,9 +103,19 @@ def test_segsum_bwd(B, rows, D):
     Gg = a.G.cpu().numpy()[slot[uniq]]
     g1g = a.gw1.cpu().numpy()[slot[uniq]]
     assert (slot[uniq] >= 0).all() and (slot >= 0).sum() == len(uniq)
-    # sequential ascending-b sums with unfused mul/add: identical operation order to the oracle -> bit-exact
-    assert np.array_equal(Gg, G)
-    assert np.array_equal(g1g, g1)
+    # short segments (<= 16 examples): sequential ascending-b sums with unfused mul/add = the oracle's operation
+    # order -> bit-exact.  Long segments are summed as 16 ordered sub-range partials (deterministic, different
+    # rounding): fp32 tolerance.
+    cnt = np.bincount(np.searchsorted(uniq, r), minlength=len(uniq))
+    short = cnt <= 16
+    assert short.any()
+    assert np.array_equal(Gg[short], G[short])
+    assert np.array_equal(g1g[short], g1[short])
+    np.testing.assert_allclose(Gg, G, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(g1g, g1, rtol=2e-5, atol=1e-7)
+    a.segsum(B, S, torch.from_numpy(dX).cuda(), torch.from_numpy(gy1).cuda(), torch.from_numpy(gy2).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(a.G.cpu().numpy()[slot[uniq]], Gg)             # deterministic run to run
 
 
 def test_adam_tf1_bit_exact_over_steps():
