@@ -1,0 +1,93 @@
+"""world_size-2 `gloo` test (CPU) of the data-parallel plumbing in recsys_amd/dist.py:
+rank-ordered all-gather of ids and of the packed per-example gradient block, flat dense all-reduce, and the
+identity DP(N=2, b) == single(2b) when the gathered data drive the same dedup + segment-sum + TF-1 Adam
+(here executed by the oracle, since the HIP kernels need a GPU; SURVEY.md section 4 'Distributed' row)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from oracle import init, models, nn
+    from recsys_amd import dist as rdist
+    rdist.init_process_group("gloo")
+    dp = rdist.DataParallel()
+    assert (dp.rank, dp.world) == (rank, world)
+    rows = (3, 7, 40, 11)
+    off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    F, D, b = 4, 4, 6
+    rng = np.random.default_rng(0)                     # same stream on both ranks -> same global batch
+    ids_g = np.stack([rng.integers(0, r, world * b) for r in rows], 1).astype(np.int32)
+    y_g = rng.integers(0, 2, world * b).astype(np.float64)
+    P = init.deepfm_params(1, D, (), np.float64, off, with_dnn=False)     # FM: no BN, so DP == single exactly
+    sl = slice(rank * b, (rank + 1) * b)
+    m = models.FM(P, off)
+    z = m.forward(ids_g[sl])
+    _, dz = nn.sigmoid_ce_mean(z, y_g[sl])
+    g, s = m.backward(dz / world)                      # MirroredStrategy: loss scaled by 1/N
+    # --- product plumbing under test -----------------------------------------------------------
+    ids_all = dp.all_gather_rows(torch.from_numpy(ids_g[sl])).numpy()
+    assert np.array_equal(ids_all, ids_g)
+    rows_local, E, S, y1, cat = m.c
+    gy2 = (dz / world)[:, None] @ P["out.W"].T
+    dX = np.zeros((b, F * D))
+    gy1 = gy2[:, 0] * (y1 > 0)
+    dXg, Sg, gy1g, gy2g = dp.gather_example_grads(torch.from_numpy(dX), torch.from_numpy(S), torch.from_numpy(gy1),
+                                                  torch.from_numpy(np.ascontiguousarray(gy2[:, 1])))
+    names = sorted(g)
+    flat = torch.from_numpy(np.concatenate([g[k].reshape(-1) for k in names]))
+    dp.all_reduce_sum(flat)
+    # --- global update from the gathered blocks (what every rank's HIP kernels would do) -------
+    rws = ids_all.astype(np.int64) + off[None, :-1]
+    dE = models.fm2_bwd(P["tables"][rws], Sg.numpy(), gy2g.numpy()) + dXg.numpy().reshape(-1, F, D)
+    opt = nn.AdamTF1(dtype=np.float64)
+    o = 0
+    for k in names:
+        n = P[k].size
+        opt.apply_dense(k, P[k], flat.numpy()[o:o + n].reshape(P[k].shape))
+        o += n
+    u, G = nn.segment_sum_rows(*models._pairs_field_major(rws, dE))
+    opt.apply_sparse("tables", P["tables"], u, G)
+    _, g1 = nn.segment_sum_rows(*models._pairs_field_major(rws, np.repeat(gy1g.numpy()[:, None], F, 1)))
+    dense = np.zeros_like(P["w1"])
+    dense[u] = g1
+    opt.apply_dense("w1", P["w1"], dense)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **P)
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_equals_single_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle import init, models, nn
+    rows = (3, 7, 40, 11)
+    off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    rng = np.random.default_rng(0)
+    ids_g = np.stack([rng.integers(0, r, world * 6) for r in rows], 1).astype(np.int32)
+    y_g = rng.integers(0, 2, world * 6).astype(np.float64)
+    P = init.deepfm_params(1, 4, (), np.float64, off, with_dnn=False)
+    models.train_step(models.FM(P, off), nn.AdamTF1(dtype=np.float64), (ids_g,), y_g)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    for k in P:
+        assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
+        np.testing.assert_allclose(r0[k], P[k], rtol=0, atol=1e-13, err_msg=k)   # == single batch of N*b
