@@ -61,6 +61,10 @@ def build_variables(store, params, capacity, with_dnn=True):
     shapes, init = _dense_specs(layout.F, D, layers, 3 if with_dnn else 2, with_dnn)
     store.build({"input_layer": arena}, shapes, init, params["learning_rate"])
     store.layout = layout
+    store.tower = None
+    if with_dnn and params.get("tower", "hip") == "hip":
+        from .ops import FusedTower
+        store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
 
 
 def model_fn(features, labels, mode, params):
@@ -75,6 +79,8 @@ def model_fn(features, labels, mode, params):
     n_layers = len(params["deep_layers"].split(","))
     masks = params.get("_dropout_masks")
 
+    if training and getattr(store, "tower", None) is not None:
+        return _train_fused(store, arena, ids, labels, params, masks)
     if training:
         store.sort_ids_for_backward(arena, ids)                # dedup for the sparse gradient (ids only)
     E, y1p, y2 = gather_fm(arena, ids, fm=True, first_order=True, dp=store.dp if training else None)
@@ -95,6 +101,30 @@ def model_fn(features, labels, mode, params):
         store.minimize(loss)
 
     return EstimatorSpec(mode, predictions=predictions, loss=loss, train_op=train_op)
+
+
+def _train_fused(store, arena, ids, labels, params, masks):
+    """TRAIN step with no autograd: explicit kernel sequence field_sort -> gather_fm -> fused tower
+    (fwd, head+loss, bwd) -> [train_op:] sorted segment-sum -> one Adam sweep.  9 launches + 1 mask fill."""
+    dp = store.dp
+    with torch.no_grad():
+        store.sort_ids_for_backward(arena, ids)
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
+        loss, prob, dX, gy1, gy2 = store.tower.train_step(
+            E, labels.reshape(-1).to(torch.float32), params["dropout"], s0=y1p, c0="b1", s1=y2,
+            replicas=dp.world if dp is not None else 1, masks=masks)
+
+    def train_op():
+        with torch.no_grad():
+            if dp is not None:
+                dXg, Sg, gy1g, gy2g = dp.gather_example_grads(dX, S, gy1, gy2)
+                arena.segsum(dXg.shape[0], Sg, dXg, gy1g, gy2g)
+                dp.all_reduce_sum(store.dense.grad)
+            else:
+                arena.segsum(ids.shape[0], S, dX, gy1, gy2)
+            store.apply_gradients()
+
+    return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 
 
 # ---- driver (deepfm/deepfm.py:153-234 + fm/fm.py flags) -----------------------------------------

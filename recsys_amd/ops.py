@@ -237,3 +237,94 @@ class AdamTF1:
     @property
     def global_step(self):
         return int(self.state.view(torch.int32)[3].item()) - 1
+
+
+class FusedTower:
+    """TRAIN-step driver of the fused HIP tower (csrc/tower.hip): L x [dense(relu) -> BN -> dropout], the
+    1-unit output layer, the logits head and the mean sigmoid-CE loss, forward AND backward, in 2L+1
+    launches.  Gradients of the dense variables are written straight into the DenseArena's flat grad
+    buffer; dX / gs0 / gs1 (gradients of the tower inputs) are returned for the embedding scatter.
+    Mirrors deepfm/deepfm.py:100-112 (`dnn` scope + logits) with fm/fm.py:146-149 (loss)."""
+
+    def __init__(self, dense, pre, k0, widths, capacity, device="cuda"):
+        dev = _require_cuda(device)
+        self.P, self.pre, self.k0, self.widths = dense, pre, int(k0), [int(w) for w in widths]
+        if self.k0 % 4 or any(w % 4 for w in self.widths[:-1]) or self.widths[-1] > 256:
+            raise _lib.RsxError("FusedTower envelope: widths multiple of 4, last width <= 256 (use tower='torch')")
+        self.cap = int(capacity)
+        B, RT = self.cap, (self.cap + 15) // 16
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.a = [torch.empty(B, n, device=dev) for n in self.widths]
+        self.dy = [torch.empty(B, n, device=dev) for n in self.widths]
+        self.fstat = [torch.zeros(RT, 2, n, **f64) for n in self.widths]
+        self.bstat = [torch.zeros(RT, 2, n, **f64) for n in self.widths]
+        self.bn = [torch.zeros(2, n, device=dev) for n in self.widths]
+        self.mask_flat = torch.ones(B * sum(self.widths), device=dev)
+        self.dX = torch.empty(B, self.k0, device=dev)
+        self.prob = torch.empty(B, device=dev)
+        self.gs0 = torch.empty(B, device=dev)
+        self.gs1 = torch.empty(B, device=dev)
+        self.dwd_part = torch.zeros(RT, self.widths[-1], device=dev)
+        self.hpart = torch.zeros(RT, 8, **f64)
+        self.loss = torch.zeros(1, device=dev)
+
+    def _masks(self, B, rate, masks):
+        """Per-layer contiguous [B, N_l] views into one flat buffer filled by a single bernoulli launch."""
+        if rate == 0.0:
+            return [None] * len(self.widths)
+        out, o = [], 0
+        tot = B * sum(self.widths)
+        if masks is None:
+            self.mask_flat[:tot].bernoulli_(1.0 - rate)
+        for i, n in enumerate(self.widths):
+            v = self.mask_flat[o:o + B * n].view(B, n)
+            if masks is not None:
+                v.copy_(masks[i])
+            out.append(v)
+            o += B * n
+        return out
+
+    def train_step(self, X, labels, rate, s0=None, c0=None, s1=None, head=("dnn.Wout", "dnn.bout", "out.W", "out.b"),
+                   relu0=True, relu2=True, replicas=1, masks=None):
+        """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
+        c0 = name of the bias added to s0.  Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
+        L, P, pre = lib(), self.P, self.pre
+        B = X.shape[0]
+        assert B <= self.cap and X.is_contiguous() and X.shape[1] == self.k0
+        st = _stream()
+        mk = self._masks(B, rate, masks)
+        nl = len(self.widths)
+        g = lambda name: P[name].grad
+        for l in range(nl):
+            K = self.k0 if l == 0 else self.widths[l - 1]
+            check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
+                                        _ptr(self.a[l]), _ptr(self.fstat[l]),
+                                        _ptr(self.fstat[l - 1]) if l else None,
+                                        _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
+                                        _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
+                                        _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
+                                        rate, B, K, self.widths[l], st), "rsx_tower_fwd_layer")
+        wd, bd, wo, bo = head
+        n_last = self.widths[-1]
+        check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(self.fstat[-1]), _ptr(P[f"{pre}.gamma{nl - 1}"]),
+                               _ptr(P[f"{pre}.beta{nl - 1}"]), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(P[wd]), _ptr(P[bd]),
+                               _ptr(s0), _ptr(P[c0]) if c0 else None, _ptr(s1), _ptr(P[wo]) if wo else None,
+                               _ptr(P[bo]) if bo else None, _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
+                               _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
+                               rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, st), "rsx_tower_head")
+        for l in reversed(range(nl)):
+            K = self.k0 if l == 0 else self.widths[l - 1]
+            last = l == nl - 1
+            check(L.rsx_tower_bwd_layer(
+                _ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(self.a[l]), _ptr(self.dy[l]),
+                _ptr(self.bstat[l]), _ptr(self.bn[l]), _ptr(P[f"{pre}.gamma{l}"]),
+                _ptr(g(f"{pre}.W{l}")), _ptr(g(f"{pre}.b{l}")), _ptr(g(f"{pre}.gamma{l}")), _ptr(g(f"{pre}.beta{l}")),
+                _ptr(self.bn[l - 1]) if l else None, _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
+                _ptr(P[f"{pre}.beta{l - 1}"]) if l else None, _ptr(mk[l - 1]) if l else None,
+                _ptr(self.dy[l - 1]) if l else _ptr(self.dX), _ptr(self.bstat[l - 1]) if l else None,
+                _ptr(self.hpart) if last else None, _ptr(self.dwd_part) if last else None,
+                _ptr(g(wd)) if last else None, _ptr(g(bd)) if last else None,
+                _ptr(g(wo)) if (last and wo) else None, _ptr(g(bo)) if (last and bo) else None,
+                _ptr(g(c0)) if (last and c0) else None, _ptr(self.loss) if last else None,
+                rate, B, K, self.widths[l], st), "rsx_tower_bwd_layer")
+        return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]

@@ -42,7 +42,7 @@ def load_oracle_weights(est, P):
 
 
 def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100), adam_mode="tf1_dense",
-                      use_graph=False, return_all=False):
+                      use_graph=False, return_all=False, tower="hip", dropout=0.0):
     """Train `steps` DeepFM steps (dropout 0) on both sides from identical weights and batches.
     Returns max |logit_gpu - logit_oracle| over all steps (and final parameter errors if return_all)."""
     import torch
@@ -59,13 +59,14 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
     P = init.deepfm_params(seed, D, layers, np.float32, row_off)
     P["b1"] += np.float32(0.05)
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D,
-              "learning_rate": 1e-3, "dropout": 0.0, "deep_layers": ",".join(map(str, layers)), "max_batch_size": B}
+              "learning_rate": 1e-3, "dropout": dropout, "deep_layers": ",".join(map(str, layers)), "max_batch_size": B,
+              "tower": tower}
     est = make_estimator(deepfm.model_fn, params, adam_mode, use_graph)
     batches = [(synth_ids(rng, B, row_off), rng.integers(0, 2, B).astype(np.float32)) for _ in range(steps)]
     ids0 = torch.from_numpy(batches[0][0]).cuda()
     est._call_model_fn({"ids": ids0}, None, ModeKeys.PREDICT)        # creates the variables
     load_oracle_weights(est, P)
-    om = models.DeepFM(P, row_off, len(layers), 0.0)
+    om = models.DeepFM(P, row_off, len(layers), dropout)
     opt = nn.AdamTF1(dtype=np.float32)
     err = 0.0
     losses = []
@@ -74,9 +75,13 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
         lab = torch.from_numpy(y).cuda()
         with torch.no_grad():
             zg = est._call_model_fn(f, None, ModeKeys.PREDICT).predictions["prob"]
+        mk = None
+        if dropout > 0.0:      # injected keep-masks, identical on both sides
+            mk = [(rng.random((B, n)) >= dropout).astype(np.float32) for n in layers]
+            est.params["_dropout_masks"] = [torch.from_numpy(m).cuda() for m in mk]
         loss_g = est._train_step(f, lab)
         zo_eval = nn.sigmoid(om.forward(ids, train=False))
-        loss_o, _ = models.train_step(om, opt, (ids,), y, lazy=(adam_mode == "lazy_rows"))
+        loss_o, _ = models.train_step(om, opt, (ids,), y, {"masks": mk} if mk else None, lazy=(adam_mode == "lazy_rows"))
         err = max(err, float(np.abs(zg.cpu().numpy() - zo_eval).max()))
         losses.append((float(loss_g), float(loss_o)))
     if not return_all:

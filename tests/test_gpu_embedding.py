@@ -188,18 +188,20 @@ def test_adam_lazy_rows_mode():
     assert np.array_equal(a.tables.cpu().numpy(), T) and np.array_equal(a.w1.cpu().numpy(), W)
 
 
-def test_deepfm_train_parity_small():
-    err, losses, perr = deepfm_parity_run(B=64, steps=4, seed=2, rows=(3, 7, 40, 11, 600), D=16, layers=(32, 16),
-                                          return_all=True)
+@pytest.mark.parametrize("tower,dropout,B", [("hip", 0.0, 64), ("torch", 0.0, 64), ("hip", 0.5, 50), ("torch", 0.5, 50)])
+def test_deepfm_train_parity_small(tower, dropout, B):
+    err, losses, perr = deepfm_parity_run(B=B, steps=4, seed=2, rows=(3, 7, 40, 11, 600), D=16, layers=(32, 16),
+                                          return_all=True, tower=tower, dropout=dropout)
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5
     assert max(perr.values()) < 1e-5, perr
 
 
-def test_deepfm_train_parity_criteo_bs256():
+@pytest.mark.parametrize("tower,dropout", [("hip", 0.0), ("hip", 0.5), ("torch", 0.0)])
+def test_deepfm_train_parity_criteo_bs256(tower, dropout):
     """BASELINE config 2: DeepFM, Criteo 39 fields, d=16, DNN 100-100, batch 256 -- oracle vs HIP, tolerance 1e-5."""
-    err, losses, perr = deepfm_parity_run(B=256, steps=3, seed=5, return_all=True)
+    err, losses, perr = deepfm_parity_run(B=256, steps=3, seed=5, return_all=True, tower=tower, dropout=dropout)
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5, losses
