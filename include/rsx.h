@@ -130,7 +130,9 @@ int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* state, float
  * logits of deepfm/deepfm.py:90-91,108-112 and the mean sigmoid-CE of fm/fm.py:146-149.
  * Workspaces (caller-owned), RT = ceil(B/16):
  *   a_l [B,N_l] relu outputs; fstat_l double[RT,2,N_l] partial (sum a, sum a^2); bn_l [2,N_l] mean,rstd;
- *   mask_l [B,N_l] 1 keep / 0 drop (null = no dropout); dy_l [B,N_l] grad wrt BN_l output;
+ *   mask_l [B,N_l] 1 keep / 0 drop, or NULL: the keep mask of layer l is then the counter-based hash
+ *   hash32[element ^ key(seed, *rng_step, l)] >= rate*2^32, re-evaluated wherever it is needed (rng_step is a
+ *   DEVICE uint32 that changes every step, e.g. word 3 of the Adam state); dy_l [B,N_l] grad wrt BN_l output;
  *   bstat_l double[RT,2,N_l] partial (sum dy, sum dy*xhat).
  * K_l % 4 == 0; head width N <= 256.
  * ------------------------------------------------------------------------------------------- */
@@ -138,8 +140,8 @@ int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* state, float
  * dropout(BN(in)) with the previous layer's statistics reduced from fstat_prev (bn_prev_out receives them). */
 int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out, double* fstat_out,
                         const double* fstat_prev, const float* gamma_prev, const float* beta_prev,
-                        const float* mask_prev, float* bn_prev_out, float dropout_rate, int B, int K, int N,
-                        rsx_stream_t stream);
+                        const float* mask_prev, float* bn_prev_out, const uint32_t* rng_step, uint32_t seed,
+                        int layer, float dropout_rate, int B, int K, int N, rsx_stream_t stream);
 /* o = dropout(BN(a_last)); u = o.wd + bd; z = wo[0]*act0(s0+c0) + wo[1]*s1 + wo[2]*act2(u) + bo (wo NULL: plain sum);
  * prob = sigmoid(z); per-row-tile partials of the loss and of every head gradient; dy_last / bstat_last = gradient
  * wrt the last BN output; gs0 / gs1 = d loss / d s0, d s1.  loss_scale = 1/(B*replicas).                    */
@@ -147,8 +149,8 @@ int rsx_tower_head(const float* a_last, const double* fstat_last, const float* g
                    const float* mask, float* bn_out, const float* wd, const float* bd, const float* s0,
                    const float* c0, const float* s1, const float* wo, const float* bo, const float* labels,
                    float* prob, float* dy_last, double* bstat_last, float* dwd_part, double* hpart, float* gs0,
-                   float* gs1, float dropout_rate, float loss_scale, int relu0, int relu2, int B, int N,
-                   rsx_stream_t stream);
+                   float* gs1, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate,
+                   float loss_scale, int relu0, int relu2, int B, int N, rsx_stream_t stream);
 /* Backward of layer l: BN backward + relu mask on load; writes dW, db, dgamma, dbeta, and dy_prev = gradient wrt
  * the previous layer's BN output (+ its bstat_prev partials), or dX for the first layer (bn_prev == NULL).
  * With hpart != NULL (last layer) one extra workgroup reduces the head partials into dwd, dbd, dwo[3], dbo, dc0, loss. */
@@ -157,7 +159,8 @@ int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const f
                         const float* bn_prev, const float* gamma_prev, const float* beta_prev,
                         const float* mask_prev, float* dy_prev, double* bstat_prev, const double* hpart,
                         const float* dwd_part, float* dwd, float* dbd, float* dwo, float* dbo, float* dc0,
-                        float* loss, float dropout_rate, int B, int K, int N, rsx_stream_t stream);
+                        float* loss, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
+                        int K, int N, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.

@@ -28,6 +28,36 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// counter-based dropout keep-mask: lowbias32-style hash of (seed, step, layer, element).  The same
+// function is evaluated wherever the mask is needed (next layer's A-load, head, backward), so no mask
+// buffer exists unless the caller injects one (parity tests).
+__device__ __forceinline__ uint32_t rsx_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+struct DropRng {
+  uint32_t key;        // mixes seed, step and layer
+  uint32_t thresh;     // drop when hash < thresh  (thresh = rate * 2^32)
+  float inv_keep;
+  int mode;            // 0: no dropout, 1: explicit mask buffer, 2: RNG
+};
+__device__ __forceinline__ DropRng drop_make(float rate, const float* mask, const uint32_t* step, uint32_t seed,
+                                             uint32_t layer) {
+  DropRng d;
+  d.inv_keep = 1.0f / (1.0f - rate);
+  d.mode = rate == 0.f ? 0 : (mask != nullptr ? 1 : 2);
+  d.thresh = (uint32_t)((double)rate * 4294967296.0);
+  const uint32_t st = step != nullptr ? step[0] : 0u;
+  d.key = rsx_hash32(seed ^ (st * 0x9E3779B9u) ^ (layer * 0x85EBCA6Bu + 0x27220A95u));
+  return d;
+}
+// multiplier (0 or inv_keep, 1 when dropout is off) for element idx = b*N + c of the layer's output
+__device__ __forceinline__ float drop_mul(const DropRng& d, const float* mask, size_t idx) {
+  if (d.mode == 0) return 1.f;
+  if (d.mode == 1) return mask[idx] * d.inv_keep;
+  return rsx_hash32((uint32_t)idx ^ d.key) < d.thresh ? 0.f : d.inv_keep;
+}
+
 // mean / rstd of one column from the per-row-tile partial sums (sum a, sum a^2), fixed order, fp64
 __device__ __forceinline__ void bn_col_stats(const double* __restrict__ fstat, int RT, int N, int col, int B,
                                              float& mean, float& rstd) {
@@ -43,9 +73,37 @@ __device__ __forceinline__ void bn_col_stats(const double* __restrict__ fstat, i
   rstd = 1.0f / sqrtf((float)var + TOWER_BN_EPS);
 }
 
+// One 16x16 output tile per 256-thread workgroup: the 4 waves split the K loop (k-steps of 16
+// interleaved), each wave keeps two independent accumulators (fp32 MFMA 16x16x4 has a 40-cycle
+// dependent latency) and issues the loads of two k-steps before their 8 MFMAs.  The 4 partial tiles
+// are summed through LDS in wave order by thread t -> element (t/16, t%16).  `ld(ks, a, b)` fills the
+// lane's four A / B operands of k-step ks (operand t <-> k = 16*ks + 4*(lane>>4) + t on both sides).
+template <class Ld>
+__device__ __forceinline__ float tile_ksplit(int nsteps, float* part /* LDS [4][256] */, Ld ld) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int ks = w; ks < nsteps; ks += 8) {
+    float a0[4], b0[4], a1[4], b1[4];
+    ld(ks, a0, b0);
+    const bool two = ks + 4 < nsteps;
+    if (two) ld(ks + 4, a1, b1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc0 = mfma16(a0[t], b0[t], acc0);
+    if (two) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc1 = mfma16(a1[t], b1[t], acc1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[w * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+  __syncthreads();
+  return ((part[tid] + part[256 + tid]) + part[512 + tid]) + part[768 + tid];
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward layer:  a_out = relu(in' . W + bias),  in' = in (first layer) or dropout(BN(in)) (others)
-// grid = (ceil(N/16), ceil(B/16)), block = 64 (one wave per 16x16 tile).  dyn LDS: 2*K floats.
+// grid = (ceil(N/16), ceil(B/16)), block = 256 (one 16x16 tile, K split over 4 waves).
+// dyn LDS: 2*K + 1024 + 256 floats.
 // ---------------------------------------------------------------------------------------------
 struct FwdArgs {
   const float* in;        // [B, K]
@@ -57,20 +115,24 @@ struct FwdArgs {
   const double* fstat_prev;  // [RT, 2, K]
   const float* gamma_prev;
   const float* beta_prev;
-  const float* mask_prev;    // [B, K] 1 keep / 0 drop (null: no dropout)
+  const float* mask_prev;    // [B, K] 1 keep / 0 drop (null: RNG or no dropout)
   float* bn_prev_out;        // [2, K] mean, rstd (written by block (0,0) for the backward pass)
-  float inv_keep;
+  const uint32_t* rng_step;
+  uint32_t seed, layer_prev;
+  float rate;
   int B, K, N, RT;
 };
 
-__global__ __launch_bounds__(64) void tower_fwd_k(const FwdArgs p) {
+__global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sc = lds;          // [K] scale
-  float* sh = lds + p.K;    // [K] shift
-  const int lane = threadIdx.x;
+  float* sc = lds;                    // [K] scale
+  float* sh = lds + p.K;              // [K] shift
+  float* part = lds + 2 * p.K;        // [4][256]
+  double* cred = reinterpret_cast<double*>(part + 1024);   // [4][2][16] column-sum exchange (8-byte aligned: K%4==0)
+  const int tid = threadIdx.x, lane = tid & 63;
   const bool first = p.fstat_prev == nullptr;
   if (!first) {
-    for (int k = lane; k < p.K; k += 64) {
+    for (int k = tid; k < p.K; k += 256) {
       float mean, rstd;
       bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.B, mean, rstd);
       const float inv = rstd * p.gamma_prev[k];
@@ -83,63 +145,60 @@ __global__ __launch_bounds__(64) void tower_fwd_k(const FwdArgs p) {
     }
     __syncthreads();
   }
+  const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
   const int i = lane & 15, kq = lane >> 4;
   const int row = blockIdx.y * TM + i;
-  const int col = blockIdx.x * 16 + i;   // B-operand column for this lane (j = lane & 15)
+  const int col = blockIdx.x * 16 + i;
   const bool rok = row < p.B, cok = col < p.N;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
-    const int kk = k0 + 4 * kq;
-    float4 a = z4;
-    if (rok && kk < p.K) {
-      a = *reinterpret_cast<const float4*>(p.in + (size_t)row * p.K + kk);
-      if (!first) {
-        const float4 s = *reinterpret_cast<const float4*>(sc + kk);
-        const float4 h = *reinterpret_cast<const float4*>(sh + kk);
-        a = make_float4(a.x * s.x + h.x, a.y * s.y + h.y, a.z * s.z + h.z, a.w * s.w + h.w);
-        if (p.mask_prev != nullptr) {
-          const float4 m = *reinterpret_cast<const float4*>(p.mask_prev + (size_t)row * p.K + kk);
-          a = make_float4(a.x * m.x * p.inv_keep, a.y * m.y * p.inv_keep, a.z * m.z * p.inv_keep,
-                          a.w * m.w * p.inv_keep);
+  const float v = tile_ksplit((p.K + 15) / 16, part, [&](int ks, float* a, float* b) {
+    const int kk = ks * 16 + 4 * kq;
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+    b[0] = b[1] = b[2] = b[3] = 0.f;
+    if (kk < p.K) {
+      if (cok) {
+        const float* w = p.W + (size_t)kk * p.N + col;
+        b[0] = w[0];
+        b[1] = w[p.N];
+        b[2] = w[2 * (size_t)p.N];
+        b[3] = w[3 * (size_t)p.N];
+      }
+      if (rok) {
+        av = *reinterpret_cast<const float4*>(p.in + (size_t)row * p.K + kk);
+        if (!first) {
+          const float4 s = *reinterpret_cast<const float4*>(sc + kk);
+          const float4 h = *reinterpret_cast<const float4*>(sh + kk);
+          const size_t e = (size_t)row * p.K + kk;
+          av.x = (av.x * s.x + h.x) * drop_mul(dr, p.mask_prev, e);
+          av.y = (av.y * s.y + h.y) * drop_mul(dr, p.mask_prev, e + 1);
+          av.z = (av.z * s.z + h.z) * drop_mul(dr, p.mask_prev, e + 2);
+          av.w = (av.w * s.w + h.w) * drop_mul(dr, p.mask_prev, e + 3);
         }
       }
     }
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (cok && kk < p.K) {
-      const float* w = p.W + (size_t)kk * p.N + col;
-      b0 = w[0];
-      b1 = w[p.N];
-      b2 = w[2 * (size_t)p.N];
-      b3 = w[3 * (size_t)p.N];
-    }
-    acc = mfma16(a.x, b0, acc);
-    acc = mfma16(a.y, b1, acc);
-    acc = mfma16(a.z, b2, acc);
-    acc = mfma16(a.w, b3, acc);
-  }
-  // epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + r
-  const int ocol = blockIdx.x * 16 + (lane & 15);
-  const float bv = ocol < p.N ? p.bias[ocol] : 0.f;
+    a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+  });
+  // epilogue: thread t owns element (r = t/16, c = t%16)
+  const int orow = blockIdx.y * TM + (tid >> 4), ocol = blockIdx.x * 16 + (tid & 15);
   double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int orow = blockIdx.y * TM + (lane >> 4) * 4 + r;
-    float v = acc[r] + bv;
-    v = v > 0.f ? v : 0.f;
-    if (orow < p.B && ocol < p.N) {
-      p.a_out[(size_t)orow * p.N + ocol] = v;
-      s1 += (double)v;
-      s2 += (double)v * (double)v;
-    }
+  if (orow < p.B && ocol < p.N) {
+    float o = v + p.bias[ocol];
+    o = o > 0.f ? o : 0.f;
+    p.a_out[(size_t)orow * p.N + ocol] = o;
+    s1 = (double)o;
+    s2 = (double)o * (double)o;
   }
-  s1 += __shfl_xor(s1, 16);
-  s2 += __shfl_xor(s2, 16);
-  s1 += __shfl_xor(s1, 32);
-  s2 += __shfl_xor(s2, 32);
-  if (lane < 16 && ocol < p.N && p.fstat_out != nullptr) {
-    p.fstat_out[((size_t)blockIdx.y * 2 + 0) * p.N + ocol] = s1;
-    p.fstat_out[((size_t)blockIdx.y * 2 + 1) * p.N + ocol] = s2;
+  if (p.fstat_out != nullptr) {   // column sums over the tile's 16 rows: 4 rows per wave, then 4 waves
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lane < 16) {
+      cred[((tid >> 6) * 2 + 0) * 16 + lane] = s1;
+      cred[((tid >> 6) * 2 + 1) * 16 + lane] = s2;
+    }
+    __syncthreads();
+    if (tid < 16 && ocol < p.N) {
+      p.fstat_out[((size_t)blockIdx.y * 2 + 0) * p.N + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
+      p.fstat_out[((size_t)blockIdx.y * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
+    }
   }
 }
 
@@ -147,7 +206,7 @@ __global__ __launch_bounds__(64) void tower_fwd_k(const FwdArgs p) {
 // head (DeepFM family):  o = dropout(BN(a_last));  u = o . wd + bd;  t2 = act2(u)
 //   z = wo[0]*act0(s0 + c0) + wo[1]*s1 + wo[2]*t2 + bo ;  loss = mean sigmoid-CE(z, y)
 // and its backward in the same pass: dz, d s0, d s1, d(BN output of the last layer) + partials.
-// act0/act2 = relu when the flag is set.  wo == null means z = s0 + u + s1 (DCN-style sum head).
+// act0/act2 = relu when the flag is set.  wo == null means z = s0 + u + s1 (sum head).
 // grid = RT (16 rows per workgroup), block = 256 (4 waves x 4 rows).  N <= 256.
 // ---------------------------------------------------------------------------------------------
 struct HeadArgs {
@@ -172,7 +231,9 @@ struct HeadArgs {
   double* hpart;             // [RT, 8] partial: loss, dwo0, dwo1, dwo2, dbo, dc0, dbd, -
   float* gs0;                // [B] d loss / d s0
   float* gs1;                // [B] d loss / d s1
-  float inv_keep, loss_scale;  // loss_scale = 1/(B * world)
+  const uint32_t* rng_step;
+  uint32_t seed, layer;
+  float rate, loss_scale;    // loss_scale = 1/(B * replicas)
   int relu0, relu2;
   int B, N, RT;
 };
@@ -197,18 +258,40 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
     }
   }
   __syncthreads();
+  const DropRng dr = drop_make(p.rate, p.mask, p.rng_step, p.seed, p.layer);
   constexpr int CPL = 4;  // columns per lane (N <= 256)
   double sdy[CPL], sdx[CPL];
-  float swd[CPL];
+  float swd[CPL], wdv[CPL];
 #pragma unroll
-  for (int k = 0; k < CPL; ++k) { sdy[k] = 0.0; sdx[k] = 0.0; swd[k] = 0.f; }
+  for (int k = 0; k < CPL; ++k) {
+    sdy[k] = 0.0; sdx[k] = 0.0; swd[k] = 0.f;
+    const int c = lane + 64 * k;
+    wdv[k] = c < p.N ? p.wd[c] : 0.f;
+  }
   double hp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const float bd = p.bd[0];
   const float wo0 = p.wo ? p.wo[0] : 1.f, wo1 = p.wo ? p.wo[1] : 1.f, wo2 = p.wo ? p.wo[2] : 1.f;
   const float bo = p.bo ? p.bo[0] : 0.f;
   const float c0 = p.c0 ? p.c0[0] : 0.f;
+  const int row0 = blockIdx.x * TM + w * 4;
+  // issue every load of the wave's 4 rows first, then the dependent math
+  float av[4][CPL], s0v[4], s1v[4], yv[4];
+#pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
-    const int row = blockIdx.x * TM + w * 4 + rr;
+    const int row = row0 + rr;
+    const bool ok = row < p.B;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      av[rr][k] = (ok && c < p.N) ? p.a_last[(size_t)row * p.N + c] : 0.f;
+    }
+    s0v[rr] = (ok && p.s0) ? p.s0[row] : 0.f;
+    s1v[rr] = (ok && p.s1) ? p.s1[row] : 0.f;
+    yv[rr] = ok ? p.labels[row] : 0.f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = row0 + rr;
     if (row >= p.B) break;  // wave-uniform
     float o[CPL], xh[CPL], mk[CPL];
     float dot = 0.f;
@@ -217,24 +300,23 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
       const int c = lane + 64 * k;
       o[k] = 0.f; xh[k] = 0.f; mk[k] = 0.f;
       if (c < p.N) {
-        const float a = p.a_last[(size_t)row * p.N + c];
-        float v = a * sc[c] + sh[c];
-        mk[k] = p.mask ? p.mask[(size_t)row * p.N + c] * p.inv_keep : 1.f;
-        v *= mk[k];
+        const float a = av[rr][k];
+        mk[k] = drop_mul(dr, p.mask, (size_t)row * p.N + c);
+        const float v = (a * sc[c] + sh[c]) * mk[k];
         o[k] = v;
         xh[k] = (a - mu[c]) * rs[c];
-        dot += v * p.wd[c];
+        dot += v * wdv[k];
       }
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) dot += __shfl_xor(dot, m);
     const float u = dot + bd;
     const float t2 = (p.relu2 && u <= 0.f) ? 0.f : u;
-    const float v0 = p.s0 ? p.s0[row] + c0 : 0.f;
+    const float v0 = p.s0 ? s0v[rr] + c0 : 0.f;
     const float t0 = (p.relu0 && v0 <= 0.f) ? 0.f : v0;
-    const float v1 = p.s1 ? p.s1[row] : 0.f;
+    const float v1 = s1v[rr];
     const float zz = wo0 * t0 + wo1 * v1 + wo2 * t2 + bo;
-    const float y = p.labels[row];
+    const float y = yv[rr];
     const float pr = 1.f / (1.f + expf(-zz));
     const float ce = fmaxf(zz, 0.f) - zz * y + log1pf(expf(-fabsf(zz)));
     const float dz = (pr - y) * p.loss_scale;
@@ -256,7 +338,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
     for (int k = 0; k < CPL; ++k) {
       const int c = lane + 64 * k;
       if (c < p.N) {
-        const float dyv = g2 * p.wd[c] * mk[k];    // d/d(BN output) after dropout backward
+        const float dyv = g2 * wdv[k] * mk[k];    // d/d(BN output) after dropout backward
         p.dy_last[(size_t)row * p.N + c] = dyv;
         sdy[k] += (double)dyv;
         sdx[k] += (double)dyv * (double)xh[k];
@@ -283,13 +365,14 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward layer l.  da = relu'(a) * BNbwd(dy) is applied on load.  Tile families (blockIdx.x ranges):
+// backward layer l.  da = relu'(a) * BNbwd(dy) is applied on load.  Tile families (blockIdx.x ranges), every
+// workgroup = 256 threads = one 16x16 tile with its reduction dimension split over the 4 waves:
 //   [0, n_din)              d(input)[B x K] = da . W^T, then dropout backward of layer l-1 and the
 //                           partial sums for ITS BN backward (or the final dX for the first layer)
-//   [n_din, +n_dw)          dW[K x N] = in'^T . da   (tiled over the output; loops over all B rows)
-//   [.., +n_vec)            db = sum_b da, dgamma = sum dy*xhat, dbeta = sum dy   (one lane per column)
+//   [n_din, +n_dw)          dW[K+1 x N] = [in' | 1]^T . da   (tiled over the OUTPUT, loops over all B rows;
+//                           the extra ones-row K is db; the kf == 0 tiles also emit dgamma / dbeta)
 //   last block (if head)    reduce the head partials: dWd, dbd, dwo, dbo, dc0, loss
-// block = 64.  dyn LDS: 5*N floats (din tiles).
+// dyn LDS: 5*N + 4 + 1024 + 256 floats.
 // ---------------------------------------------------------------------------------------------
 struct BwdArgs {
   // this layer
@@ -315,10 +398,12 @@ struct BwdArgs {
   const double* hpart;      // [RT, 8]
   const float* dwd_part;    // [RT, N]
   float* dwd; float* dbd; float* dwo; float* dbo; float* dc0; float* loss;
-  float inv_keep;
+  const uint32_t* rng_step;
+  uint32_t seed, layer_prev;
+  float rate;
   int has_wo;
   int B, K, N, RT;
-  int n_din, n_dw, n_vec, ct_k, ct_n;
+  int n_din, n_dw, ct_k, ct_k1, ct_n;
 };
 
 struct ColBwd { float mean, rstd, k1, sdy, sdx; };
@@ -343,82 +428,78 @@ __device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float
   return c.k1 * (Bf * dy - c.sdy - xh * c.sdx);
 }
 
-__global__ __launch_bounds__(64) void tower_bwd_k(const BwdArgs p) {
+__global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x;
+  float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
+  float* part = lds + 5 * p.N + ((4 - (5 * p.N) % 4) % 4);         // [4][256], 16-byte aligned
+  double* cred = reinterpret_cast<double*>(part + 1024);              // [4][2][16]
+  const int tid = threadIdx.x, lane = tid & 63;
   const int bid = blockIdx.x;
   const float Bf = (float)p.B;
   const bool first = p.bn_prev == nullptr;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int i = lane & 15, kq = lane >> 4;
   if (bid < p.n_din) {
-    // ---- d(input) tile: rows rt*16.., input columns kc*16.. ; K' = N ------------------------------
-    float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
-    for (int c = lane; c < p.N; c += 64) {
+    // ---- d(input) tile: rows rt*16.., input columns kc*16.. ; reduction over the N outputs ----------
+    for (int c = tid; c < p.N; c += 256) {
       const ColBwd cb = bwd_col(p, c);
       Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
     }
     __syncthreads();
     const int kc = bid % p.ct_k, rt = bid / p.ct_k;
-    const int i = lane & 15, kq = lane >> 4;
     const int row = rt * TM + i;
     const int kcol = kc * 16 + i;   // B-operand "column" = input feature
     const bool rok = row < p.B, cok = kcol < p.K;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int n0 = 0; n0 < p.N; n0 += 16) {
-      const int nn = n0 + 4 * kq;
-      float av[4] = {0.f, 0.f, 0.f, 0.f};
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    const float v = tile_ksplit((p.N + 15) / 16, part, [&](int ks, float* a, float* b) {
+      const int nn = ks * 16 + 4 * kq;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int n = nn + t;
+        a[t] = 0.f;
+        b[t] = 0.f;
         if (n < p.N) {
           if (rok) {
-            const float a = p.a[(size_t)row * p.N + n], dy = p.dy[(size_t)row * p.N + n];
             ColBwd cb; cb.mean = Lm[n]; cb.rstd = Lr[n]; cb.k1 = Lk[n]; cb.sdy = Ls[n]; cb.sdx = Lx[n];
-            av[t] = da_of(a, dy, cb, Bf);
+            a[t] = da_of(p.a[(size_t)row * p.N + n], p.dy[(size_t)row * p.N + n], cb, Bf);
           }
-          if (cok) bv[t] = p.W[(size_t)kcol * p.N + n];
+          if (cok) b[t] = p.W[(size_t)kcol * p.N + n];
         }
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc = mfma16(av[t], bv[t], acc);
-    }
-    const int ocol = kc * 16 + (lane & 15);
+    });
+    const int orow = rt * TM + (tid >> 4), ocol = kc * 16 + (tid & 15);
     double s1 = 0.0, s2 = 0.0;
-    float pm = 0.f, pr = 0.f;
-    if (!first && ocol < p.K) { pm = p.bn_prev[ocol]; pr = p.bn_prev[p.K + ocol]; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int orow = rt * TM + (lane >> 4) * 4 + r;
-      if (orow < p.B && ocol < p.K) {
-        float v = acc[r];
-        if (!first) {
-          if (p.mask_prev) v *= p.mask_prev[(size_t)orow * p.K + ocol] * p.inv_keep;
-          const float xh = (p.in[(size_t)orow * p.K + ocol] - pm) * pr;
-          s1 += (double)v;
-          s2 += (double)v * (double)xh;
-        }
-        p.dy_prev[(size_t)orow * p.K + ocol] = v;
+    if (orow < p.B && ocol < p.K) {
+      float o = v;
+      if (!first) {
+        const DropRng dr = drop_make(p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+        o *= drop_mul(dr, p.mask_prev, (size_t)orow * p.K + ocol);
+        const float xh = (p.in[(size_t)orow * p.K + ocol] - p.bn_prev[ocol]) * p.bn_prev[p.K + ocol];
+        s1 = (double)o;
+        s2 = (double)o * (double)xh;
       }
+      p.dy_prev[(size_t)orow * p.K + ocol] = o;
     }
     if (!first) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      if (lane < 16 && ocol < p.K) {
-        p.bstat_prev[((size_t)rt * 2 + 0) * p.K + ocol] = s1;
-        p.bstat_prev[((size_t)rt * 2 + 1) * p.K + ocol] = s2;
+      if (lane < 16) {
+        cred[((tid >> 6) * 2 + 0) * 16 + lane] = s1;
+        cred[((tid >> 6) * 2 + 1) * 16 + lane] = s2;
+      }
+      __syncthreads();
+      if (tid < 16 && ocol < p.K) {
+        p.bstat_prev[((size_t)rt * 2 + 0) * p.K + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
+        p.bstat_prev[((size_t)rt * 2 + 1) * p.K + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
       }
     }
     return;
   }
   if (bid < p.n_din + p.n_dw) {
-    // ---- dW tile: rows = input features kf*16.., cols = n*16.. ; K'' = B ---------------------------
+    // ---- dW tile: rows = input features kf*16.. (feature K = the ones-row -> db), cols = n*16.. ------
     const int t_id = bid - p.n_din;
     const int nt = t_id % p.ct_n, kf = t_id / p.ct_n;
-    const int i = lane & 15, kq = lane >> 4;
     const int feat = kf * 16 + i;          // A-operand row (input feature)
     const int ncol = nt * 16 + i;          // B-operand column
-    const bool fok = feat < p.K, nok = ncol < p.N;
+    const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
     ColBwd cb = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (nok) cb = bwd_col(p, ncol);
     float fsc = 1.f, fsh = 0.f;
@@ -427,64 +508,53 @@ __global__ __launch_bounds__(64) void tower_bwd_k(const BwdArgs p) {
       fsc = inv;
       fsh = p.beta_prev[feat] - p.bn_prev[feat] * inv;
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int b0 = 0; b0 < p.B; b0 += 16) {
-      float av[4] = {0.f, 0.f, 0.f, 0.f};
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+    const float v = tile_ksplit((p.B + 15) / 16, part, [&](int ks, float* a, float* b) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int b = b0 + 4 * kq + t;
-        if (b < p.B) {
+        const int bb = ks * 16 + 4 * kq + t;
+        a[t] = 0.f;
+        b[t] = 0.f;
+        if (bb < p.B) {
           if (fok) {
-            float v = p.in[(size_t)b * p.K + feat];
-            if (!first) {
-              v = v * fsc + fsh;
-              if (p.mask_prev) v *= p.mask_prev[(size_t)b * p.K + feat] * p.inv_keep;
-            }
-            av[t] = v;
+            float x = p.in[(size_t)bb * p.K + feat];
+            if (!first) x = (x * fsc + fsh) * drop_mul(dr, p.mask_prev, (size_t)bb * p.K + feat);
+            a[t] = x;
+          } else if (ones) {
+            a[t] = 1.f;
           }
-          if (nok) bv[t] = da_of(p.a[(size_t)b * p.N + ncol], p.dy[(size_t)b * p.N + ncol], cb, Bf);
+          if (nok) b[t] = da_of(p.a[(size_t)bb * p.N + ncol], p.dy[(size_t)bb * p.N + ncol], cb, Bf);
         }
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc = mfma16(av[t], bv[t], acc);
+    });
+    const int orow = kf * 16 + (tid >> 4), ocol = nt * 16 + (tid & 15);
+    if (ocol < p.N) {
+      if (orow < p.K) p.dW[(size_t)orow * p.N + ocol] = v;
+      else if (orow == p.K) p.db[ocol] = v;
     }
-    const int ocol = nt * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int orow = kf * 16 + (lane >> 4) * 4 + r;
-      if (orow < p.K && ocol < p.N) p.dW[(size_t)orow * p.N + ocol] = acc[r];
-    }
-    return;
-  }
-  if (bid < p.n_din + p.n_dw + p.n_vec) {
-    // ---- per-column vectors ------------------------------------------------------------------------
-    const int c = (bid - p.n_din - p.n_dw) * 64 + lane;
-    if (c < p.N) {
-      const ColBwd cb = bwd_col(p, c);
-      float s = 0.f;
-      for (int b = 0; b < p.B; ++b) s += da_of(p.a[(size_t)b * p.N + c], p.dy[(size_t)b * p.N + c], cb, Bf);
-      p.db[c] = s;
-      p.dgamma[c] = cb.sdx;
-      p.dbeta[c] = cb.sdy;
+    if (kf == 0 && kq == 0 && nok) {   // lanes 0..15 of every wave hold the same column constants
+      if (tid < 16) {
+        p.dgamma[ncol] = cb.sdx;
+        p.dbeta[ncol] = cb.sdy;
+      }
     }
     return;
   }
   // ---- head partial reduce (last layer only) ---------------------------------------------------------
   if (p.hpart != nullptr) {
-    for (int c = lane; c < p.N; c += 64) {
+    for (int c = tid; c < p.N; c += 256) {
       float s = 0.f;
       for (int r = 0; r < p.RT; ++r) s += p.dwd_part[(size_t)r * p.N + c];
       p.dwd[c] = s;
     }
-    if (lane < 8) {
+    if (tid < 8) {
       double s = 0.0;
-      for (int r = 0; r < p.RT; ++r) s += p.hpart[(size_t)r * 8 + lane];
-      if (lane == 0) p.loss[0] = (float)(s / (double)p.B);
-      if (p.has_wo && lane >= 1 && lane <= 3) p.dwo[lane - 1] = (float)s;
-      if (p.has_wo && lane == 4) p.dbo[0] = (float)s;
-      if (p.dc0 != nullptr && lane == 5) p.dc0[0] = (float)s;
-      if (lane == 6) p.dbd[0] = (float)s;
+      for (int r = 0; r < p.RT; ++r) s += p.hpart[(size_t)r * 8 + tid];
+      if (tid == 0) p.loss[0] = (float)(s / (double)p.B);
+      if (p.has_wo && tid >= 1 && tid <= 3) p.dwo[tid - 1] = (float)s;
+      if (p.has_wo && tid == 4) p.dbo[0] = (float)s;
+      if (p.dc0 != nullptr && tid == 5) p.dc0[0] = (float)s;
+      if (tid == 6) p.dbd[0] = (float)s;
     }
   }
 }
@@ -493,7 +563,8 @@ __global__ __launch_bounds__(64) void tower_bwd_k(const BwdArgs p) {
 extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out,
                                    double* fstat_out, const double* fstat_prev, const float* gamma_prev,
                                    const float* beta_prev, const float* mask_prev, float* bn_prev_out,
-                                   float dropout_rate, int B, int K, int N, rsx_stream_t stream) {
+                                   const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
+                                   int K, int N, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !bias || !a_out) return RSX_EINVAL;
@@ -504,10 +575,11 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   p.in = in; p.W = W; p.bias = bias; p.a_out = a_out; p.fstat_out = fstat_out;
   p.fstat_prev = fstat_prev; p.gamma_prev = gamma_prev; p.beta_prev = beta_prev; p.mask_prev = mask_prev;
   p.bn_prev_out = bn_prev_out;
-  p.inv_keep = 1.0f / (1.0f - dropout_rate);
+  p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
+  p.rate = dropout_rate;
   p.B = B; p.K = K; p.N = N; p.RT = (B + TM - 1) / TM;
   const dim3 grid((N + 15) / 16, p.RT);
-  hipLaunchKernelGGL(tower_fwd_k, grid, dim3(64), (size_t)2 * K * sizeof(float), rsx_s(stream), p);
+  hipLaunchKernelGGL(tower_fwd_k, grid, dim3(256), ((size_t)2 * K + 1024 + 256) * sizeof(float), rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -516,19 +588,22 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
                               const float* mask, float* bn_out, const float* wd, const float* bd, const float* s0,
                               const float* c0, const float* s1, const float* wo, const float* bo,
                               const float* labels, float* prob, float* dy_last, double* bstat_last,
-                              float* dwd_part, double* hpart, float* gs0, float* gs1, float dropout_rate,
-                              float loss_scale, int relu0, int relu2, int B, int N, rsx_stream_t stream) {
+                              float* dwd_part, double* hpart, float* gs0, float* gs1, const uint32_t* rng_step,
+                              uint32_t seed, int layer, float dropout_rate, float loss_scale, int relu0, int relu2,
+                              int B, int N, rsx_stream_t stream) {
   if (B < 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (N > 256) return RSX_EUNSUPPORTED;
   if (!a_last || !fstat_last || !gamma || !beta || !bn_out || !wd || !bd || !labels || !prob || !dy_last ||
       !bstat_last || !dwd_part || !hpart)
     return RSX_EINVAL;
+  if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   HeadArgs p;
   p.a_last = a_last; p.fstat_last = fstat_last; p.gamma = gamma; p.beta = beta; p.mask = mask; p.bn_out = bn_out;
   p.wd = wd; p.bd = bd; p.s0 = s0; p.c0 = c0; p.s1 = s1; p.wo = wo; p.bo = bo; p.labels = labels; p.prob = prob;
   p.dy_last = dy_last; p.bstat_last = bstat_last; p.dwd_part = dwd_part; p.hpart = hpart; p.gs0 = gs0; p.gs1 = gs1;
-  p.inv_keep = 1.0f / (1.0f - dropout_rate);
+  p.rng_step = rng_step; p.seed = seed; p.layer = (uint32_t)layer;
+  p.rate = dropout_rate;
   p.loss_scale = loss_scale;
   p.relu0 = relu0; p.relu2 = relu2;
   p.B = B; p.N = N; p.RT = (B + TM - 1) / TM;
@@ -543,13 +618,15 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    const float* beta_prev, const float* mask_prev, float* dy_prev,
                                    double* bstat_prev, const double* hpart, const float* dwd_part, float* dwd,
                                    float* dbd, float* dwo, float* dbo, float* dc0, float* loss,
-                                   float dropout_rate, int B, int K, int N, rsx_stream_t stream) {
+                                   const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
+                                   int K, int N, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !a || !dy || !bstat || !bn || !gamma || !dW || !db || !dgamma || !dbeta || !dy_prev)
     return RSX_EINVAL;
   if (bn_prev != nullptr && (!gamma_prev || !beta_prev || !bstat_prev)) return RSX_EINVAL;
   if (hpart != nullptr && (!dwd_part || !dwd || !dbd || !loss)) return RSX_EINVAL;
+  if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   BwdArgs p;
   p.in = in; p.W = W; p.a = a; p.dy = dy; p.bstat = bstat; p.bn = bn; p.gamma = gamma;
   p.dW = dW; p.db = db; p.dgamma = dgamma; p.dbeta = dbeta;
@@ -557,16 +634,18 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.dy_prev = dy_prev; p.bstat_prev = bstat_prev;
   p.hpart = hpart; p.dwd_part = dwd_part; p.dwd = dwd; p.dbd = dbd; p.dwo = dwo; p.dbo = dbo; p.dc0 = dc0;
   p.loss = loss;
-  p.inv_keep = 1.0f / (1.0f - dropout_rate);
+  p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
+  p.rate = dropout_rate;
   p.has_wo = dwo != nullptr;
   p.B = B; p.K = K; p.N = N; p.RT = (B + TM - 1) / TM;
   p.ct_k = (K + 15) / 16;
+  p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;
   p.n_din = p.ct_k * p.RT;
-  p.n_dw = p.ct_k * p.ct_n;
-  p.n_vec = (N + 63) / 64;
-  const int total = p.n_din + p.n_dw + p.n_vec + (hpart != nullptr ? 1 : 0);
-  hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(64), (size_t)5 * N * sizeof(float), rsx_s(stream), p);
+  p.n_dw = p.ct_k1 * p.ct_n;
+  const int total = p.n_din + p.n_dw + (hpart != nullptr ? 1 : 0);
+  hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float),
+                     rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

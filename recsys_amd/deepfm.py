@@ -111,7 +111,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
         store.sort_ids_for_backward(arena, ids)
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
-            E, labels.reshape(-1).to(torch.float32), params["dropout"], s0=y1p, c0="b1", s1=y2,
+            E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
+            s0=y1p, c0="b1", s1=y2,
             replicas=dp.world if dp is not None else 1, masks=masks)
 
     def train_op():

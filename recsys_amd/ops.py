@@ -269,25 +269,24 @@ class FusedTower:
         self.loss = torch.zeros(1, device=dev)
 
     def _masks(self, B, rate, masks):
-        """Per-layer contiguous [B, N_l] views into one flat buffer filled by a single bernoulli launch."""
-        if rate == 0.0:
+        """Injected keep-masks (parity tests) as contiguous [B, N_l] views; None -> the kernels derive the mask
+        from the counter-based hash (seed, step, layer, element), no buffer and no launch."""
+        if rate == 0.0 or masks is None:
             return [None] * len(self.widths)
         out, o = [], 0
-        tot = B * sum(self.widths)
-        if masks is None:
-            self.mask_flat[:tot].bernoulli_(1.0 - rate)
         for i, n in enumerate(self.widths):
             v = self.mask_flat[o:o + B * n].view(B, n)
-            if masks is not None:
-                v.copy_(masks[i])
+            v.copy_(masks[i])
             out.append(v)
             o += B * n
         return out
 
-    def train_step(self, X, labels, rate, s0=None, c0=None, s1=None, head=("dnn.Wout", "dnn.bout", "out.W", "out.b"),
-                   relu0=True, relu2=True, replicas=1, masks=None):
+    def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
+                   head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
+                   seed=0x5eed):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
-        c0 = name of the bias added to s0.  Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
+        c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step.
+        Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
         L, P, pre = lib(), self.P, self.pre
         B = X.shape[0]
         assert B <= self.cap and X.is_contiguous() and X.shape[1] == self.k0
@@ -295,6 +294,7 @@ class FusedTower:
         mk = self._masks(B, rate, masks)
         nl = len(self.widths)
         g = lambda name: P[name].grad
+        rs = _ptr(rng_step)
         for l in range(nl):
             K = self.k0 if l == 0 else self.widths[l - 1]
             check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
@@ -303,7 +303,7 @@ class FusedTower:
                                         _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
                                         _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
                                         _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
-                                        rate, B, K, self.widths[l], st), "rsx_tower_fwd_layer")
+                                        rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_fwd_layer")
         wd, bd, wo, bo = head
         n_last = self.widths[-1]
         check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(self.fstat[-1]), _ptr(P[f"{pre}.gamma{nl - 1}"]),
@@ -311,7 +311,8 @@ class FusedTower:
                                _ptr(s0), _ptr(P[c0]) if c0 else None, _ptr(s1), _ptr(P[wo]) if wo else None,
                                _ptr(P[bo]) if bo else None, _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
                                _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
-                               rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, st), "rsx_tower_head")
+                               rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, st),
+              "rsx_tower_head")
         for l in reversed(range(nl)):
             K = self.k0 if l == 0 else self.widths[l - 1]
             last = l == nl - 1
@@ -326,5 +327,5 @@ class FusedTower:
                 _ptr(g(wd)) if last else None, _ptr(g(bd)) if last else None,
                 _ptr(g(wo)) if (last and wo) else None, _ptr(g(bo)) if (last and bo) else None,
                 _ptr(g(c0)) if (last and c0) else None, _ptr(self.loss) if last else None,
-                rate, B, K, self.widths[l], st), "rsx_tower_bwd_layer")
+                rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_bwd_layer")
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
