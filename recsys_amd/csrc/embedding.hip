@@ -203,11 +203,15 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   const int wpf = (B + GPW - 1) / GPW;  // waves per field: a wave never straddles two fields
   const int f = wave / wpf;
   if (f >= F) return;
-  const int j0 = (wave - f * wpf) * GPW;
+  const int wf = wave - f * wpf;
   const int nu = nuniq[f];
+  // fields with few unique rows (tiny vocabularies: every segment is long) spread ONE row per wave over the
+  // field's wpf waves instead of 16 rows on the first wave; group 0 then owns the row, all groups cooperate
+  const bool spread = nu <= wpf;
+  const int j0 = spread ? wf : wf * GPW;
   if (j0 >= nu) return;  // wave-uniform
-  const int j = j0 + g;
-  const bool valid = j < nu;
+  const int j = spread ? j0 : j0 + g;
+  const bool valid = spread ? g == 0 : j < nu;
   const size_t sl = (size_t)f * stride + (valid ? j : j0);
   const int beg = valid ? seg_off[(size_t)f * (stride + 1) + j] : 0;
   const int end = valid ? seg_off[(size_t)f * (stride + 1) + j + 1] : 0;
@@ -227,8 +231,9 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)uniq_row[sl] * LPR + q];
   float4 acc = z;
   float a1 = 0.f;
-  if (valid && L <= SEG_SHORT) seg_range_sum<LPR>(c, e, beg, end, acc, a1);
-  unsigned long long todo = __ballot(valid && L > SEG_SHORT && q == 0);
+  const int short_len = spread ? 2 : SEG_SHORT;   // a spread wave has 15 idle groups: cooperate on anything > 2
+  if (valid && L <= short_len) seg_range_sum<LPR>(c, e, beg, end, acc, a1);
+  unsigned long long todo = __ballot(valid && L > short_len && q == 0);
   while (todo) {  // wave-uniform loop over the long segments owned by this wave
     const int src = __ffsll((long long)todo) - 1;  // lane (owner group, q = 0)
     todo &= todo - 1;

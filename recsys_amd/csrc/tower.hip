@@ -58,14 +58,36 @@ __device__ __forceinline__ float drop_mul(const DropRng& d, const float* mask, s
   return rsx_hash32((uint32_t)idx ^ d.key) < d.thresh ? 0.f : d.inv_keep;
 }
 
-// mean / rstd of one column from the per-row-tile partial sums (sum a, sum a^2), fixed order, fp64
+// fixed-order fp64 sum of the RT per-row-tile partials of one column; 8 loads in flight at a time
+__device__ __forceinline__ void col_partials(const double* __restrict__ st, int RT, int N, int col, double& s1,
+                                             double& s2) {
+  s1 = 0.0;
+  s2 = 0.0;
+  int r = 0;
+  for (; r + 8 <= RT; r += 8) {
+    double t1[8], t2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      t1[u] = st[((size_t)(r + u) * 2 + 0) * N + col];
+      t2[u] = st[((size_t)(r + u) * 2 + 1) * N + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1 += t1[u];
+      s2 += t2[u];
+    }
+  }
+  for (; r < RT; ++r) {
+    s1 += st[((size_t)r * 2 + 0) * N + col];
+    s2 += st[((size_t)r * 2 + 1) * N + col];
+  }
+}
+
+// mean / rstd of one column from the per-row-tile partial sums (sum a, sum a^2)
 __device__ __forceinline__ void bn_col_stats(const double* __restrict__ fstat, int RT, int N, int col, int B,
                                              float& mean, float& rstd) {
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < RT; ++r) {
-    s1 += fstat[((size_t)r * 2 + 0) * N + col];
-    s2 += fstat[((size_t)r * 2 + 1) * N + col];
-  }
+  double s1, s2;
+  col_partials(fstat, RT, N, col, s1, s2);
   const double mu = s1 / B;
   double var = s2 / B - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -409,11 +431,8 @@ struct BwdArgs {
 struct ColBwd { float mean, rstd, k1, sdy, sdx; };
 
 __device__ __forceinline__ ColBwd bwd_col(const BwdArgs& p, int c) {
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < p.RT; ++r) {
-    s1 += p.bstat[((size_t)r * 2 + 0) * p.N + c];
-    s2 += p.bstat[((size_t)r * 2 + 1) * p.N + c];
-  }
+  double s1, s2;
+  col_partials(p.bstat, p.RT, p.N, c, s1, s2);
   ColBwd o;
   o.mean = p.bn[c];
   o.rstd = p.bn[p.N + c];

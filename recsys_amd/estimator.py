@@ -69,6 +69,52 @@ class EvalSpec:
     throttle_secs: int = 600
 
 
+class PackedBatch:
+    """(features, labels) of one batch packed into ONE contiguous byte buffer, so a training step needs a single
+    host->device (or device->device) copy into the HIP graph's static input buffer instead of one per tensor."""
+
+    def __init__(self, features, labels, device=None, pin=False):
+        items = [("__label__", labels)] + sorted(features.items())
+        self.layout, off = [], 0
+        arrs = []
+        for k, v in items:
+            t = torch.as_tensor(v).contiguous()
+            nb = t.numel() * t.element_size()
+            self.layout.append((k, t.dtype, tuple(t.shape), off, nb))
+            arrs.append(t)
+            off = (off + nb + 15) & ~15
+        self.nbytes = off
+        flat = torch.zeros(off, dtype=torch.uint8)
+        for (k, dt, sh, o, nb), t in zip(self.layout, arrs):
+            flat[o:o + nb] = t.cpu().view(-1).view(torch.uint8) if nb else flat[o:o]
+        if pin and torch.cuda.is_available():
+            flat = flat.pin_memory()
+        self.flat = flat if device is None else flat.to(device)
+
+    def key(self):
+        return tuple((k, str(dt), sh) for k, dt, sh, _, _ in self.layout)
+
+    def to(self, device):
+        o = PackedBatch.__new__(PackedBatch)
+        o.layout, o.nbytes, o.flat = self.layout, self.nbytes, self.flat.to(device, non_blocking=True)
+        return o
+
+    def clone(self):
+        o = PackedBatch.__new__(PackedBatch)
+        o.layout, o.nbytes, o.flat = self.layout, self.nbytes, self.flat.clone()
+        return o
+
+    def views(self):
+        feats, labels = {}, None
+        for k, dt, sh, o, nb in self.layout:
+            v = self.flat[o:o + nb].view(dt).view(sh)
+            if k == "__label__":
+                labels = v
+            else:
+                feats[k] = v
+        return feats, labels
+
+
 class VariableStore:
     """The variables of one model: named embedding arenas + one flat dense arena + the optimizer."""
 
@@ -83,6 +129,7 @@ class VariableStore:
         self.adam_mode = adam_mode
         self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
         self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
+        self.side_stream = None      # the ids-only dedup sort runs here, concurrent with the forward pass
 
     def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr):
         self.embeddings = embeddings
@@ -104,11 +151,26 @@ class VariableStore:
         segs += self.dense.adam_segments()
         return segs
 
-    def sort_ids_for_backward(self, arena, ids):
-        """Dedup stage of the sparse gradient.  Data-parallel: over the all-gathered global batch."""
+    def sort_ids_for_backward(self, arena, ids, overlap=False):
+        """Dedup stage of the sparse gradient.  Data-parallel: over the all-gathered global batch.
+        overlap=True: run on a side HIP stream (it depends on ids only) -- call join_sort() before the scatter."""
+        if overlap:
+            if self.side_stream is None:
+                self.side_stream = torch.cuda.Stream(device=self.device)
+            cur = torch.cuda.current_stream()
+            self.side_stream.wait_stream(cur)
+            with torch.cuda.stream(self.side_stream):
+                g = self.dp.all_gather_rows(ids) if self.dp is not None else ids
+                arena.field_sort(g)
+                self._sort_keepalive = g
+            return
         if self.dp is not None:
             ids = self.dp.all_gather_rows(ids)
         arena.field_sort(ids)
+
+    def join_sort(self):
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def minimize(self, loss):
         """optimizer.minimize(loss) (fm/fm.py:162-163) incl. MirroredStrategy's 1/N loss scaling and
@@ -191,8 +253,11 @@ class Estimator:
     def _shape_key(self, features, labels):
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items())) + (tuple(labels.shape),)
 
-    def _train_step(self, features, labels):
-        """One global step; captured into a HIP graph per input signature after 2 eager warm-up steps."""
+    def _train_step(self, features, labels=None):
+        """One global step; captured into a HIP graph per input signature after 2 eager warm-up steps.
+        `features` may be a PackedBatch (then one copy feeds the graph's static input buffer)."""
+        if isinstance(features, PackedBatch):
+            return self._train_step_packed(features)
         if not self.config.use_hip_graph:
             return self._train_eager(features, labels)
         key = self._shape_key(features, labels)
@@ -217,6 +282,68 @@ class Estimator:
             g["feat"][k].copy_(v, non_blocking=True)
         g["lab"].copy_(labels, non_blocking=True)
         g["graph"].replay()
+        return g["loss"]
+
+    def _train_step_packed(self, pb):
+        if pb.flat.device != self.store.device:
+            pb = pb.to(self.store.device)
+        if not self.config.use_hip_graph:
+            return self._train_eager(*pb.views())
+        key = ("packed",) + pb.key()
+        g = self._graphs.setdefault(key, {"warm": 0})
+        if "graph" not in g:
+            if g["warm"] < 2:
+                g["warm"] += 1
+                return self._train_eager(*pb.views())
+            g["static"] = pb.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g["loss"] = self._train_eager(*g["static"].views())
+            g["graph"] = graph
+            graph.replay()
+            return g["loss"]
+        g["static"].flat.copy_(pb.flat, non_blocking=True)
+        g["graph"].replay()
+        return g["loss"]
+
+    def train_resident(self, batches, steps, steps_per_graph=8):
+        """Train `steps` steps over a list of HBM-resident PackedBatch objects (cycled in order).  Groups of
+        `steps_per_graph` consecutive batches are captured into ONE HIP graph each that reads the resident
+        buffers directly: no per-step input copy and one graph launch per group ("capture launch-bound inner
+        loops in hipGraphs").  An input pipeline refills the buffers in place between replays."""
+        n = len(batches)
+        if not self.config.use_hip_graph or n % steps_per_graph != 0:
+            for s in range(steps):
+                loss = self._train_step(batches[s % n])
+            return loss
+        key = ("resident", id(batches[0]), n, steps_per_graph)
+        g = self._graphs.get(key)
+        done = 0
+        if g is None:
+            for s in range(min(2, steps)):                     # eager warm-up (allocator, lazy init)
+                self._train_eager(*batches[s % n].views())
+            done = min(2, steps)
+            g = {"graphs": [], "loss": None}
+            torch.cuda.synchronize()
+            for gi in range(n // steps_per_graph):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for k in range(steps_per_graph):
+                        g["loss"] = self._train_eager(*batches[gi * steps_per_graph + k].views())
+                g["graphs"].append(graph)
+            self._graphs[key] = g
+        # continue from the batch index that follows the steps already done, on group boundaries
+        pos = done % n
+        while done < steps:
+            if pos % steps_per_graph == 0 and steps - done >= steps_per_graph:
+                g["graphs"][pos // steps_per_graph].replay()
+                done += steps_per_graph
+                pos = (pos + steps_per_graph) % n
+            else:
+                self._train_eager(*batches[pos].views())
+                done += 1
+                pos = (pos + 1) % n
         return g["loss"]
 
     def _maybe_restore(self):

@@ -219,3 +219,51 @@ def test_deepfm_lazy_rows_mode_parity():
     err, losses, perr = deepfm_parity_run(B=64, steps=3, seed=8, rows=(3, 7, 40, 11, 600), layers=(32, 16),
                                           adam_mode="lazy_rows", return_all=True)
     assert err < 1e-5 and max(perr.values()) < 1e-5, (err, perr)
+
+
+def _hash32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def test_tower_rng_dropout_is_the_documented_hash_and_consistent_fwd_bwd():
+    """The in-kernel dropout mask (no mask buffer) must be the documented counter hash: training one step with the
+    RNG must equal, bit for bit, training the same step with that mask injected explicitly -- which also proves the
+    forward (next layer's A-load / head) and backward (d-input epilogue, dW A-load) evaluate the SAME mask."""
+    from recsys_amd import deepfm
+    from recsys_amd.feature_columns import build_feature_columns  # noqa: F401
+    from tests.parity_util import load_oracle_weights, make_estimator, small_columns
+    from oracle import init
+    rows, D, layers, B, rate, seed = (3, 7, 40, 11, 600), 16, (32, 16), 96, 0.5, 0x5eed
+    lin, emb = small_columns(rows, D)
+    row_off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    P = init.deepfm_params(3, D, layers, np.float32, row_off)
+    rng = np.random.default_rng(9)
+    ids = synth_ids(rng, B, row_off)
+    y = rng.integers(0, 2, B).astype(np.float32)
+    outs = []
+    for inject in (False, True):
+        params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D, "learning_rate": 1e-3,
+                  "dropout": rate, "deep_layers": "32,16", "max_batch_size": B, "tower": "hip"}
+        est = make_estimator(deepfm.model_fn, params)
+        f = {"ids": torch.from_numpy(ids).cuda()}
+        est._call_model_fn(f, None, "infer")
+        load_oracle_weights(est, P)
+        if inject:
+            step = 1                                              # Adam state word 3 before the first step
+            masks = []
+            for l, n in enumerate(layers):
+                key = _hash32(np.array([(seed ^ ((step * 0x9E3779B9) & 0xFFFFFFFF) ^ ((l * 0x85EBCA6B + 0x27220A95) & 0xFFFFFFFF))]))[0]
+                h = _hash32(np.arange(B * n, dtype=np.uint64) ^ key)
+                masks.append(torch.from_numpy((h >= np.uint64(int(rate * 2 ** 32))).astype(np.float32).reshape(B, n)).cuda())
+            keep = float(torch.cat([m.reshape(-1) for m in masks]).mean())
+            assert 0.45 < keep < 0.55                              # ~Bernoulli(1 - rate)
+            est.params["_dropout_masks"] = masks
+        loss = float(est._train_step(f, torch.from_numpy(y).cuda()))
+        a = est.store.embeddings["input_layer"]
+        outs.append((loss, a.tables.cpu().numpy().copy(), est.store.dense.flat.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
