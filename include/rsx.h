@@ -163,6 +163,21 @@ int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const f
                         int K, int N, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DCN cross layers, dcn/dcn.py:132-142: x_{l+1} = (x_l . w_l) * x0 + x_l + b_l, all L
+ * layers fused per example.  dim % 4 == 0, dim <= 1024, L <= 8.
+ * ------------------------------------------------------------------------------------------- */
+/* s[B,L] receives the per-layer scalars (saved for backward); xL (nullable) the final x_L; cz (nullable, needs wout)
+ * the logit contribution <x_L, wout> of tf.layers.dense(concat[deep, x_L], 1) dcn/dcn.py:151-152.                  */
+int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, const float* wout, float* s, float* xL, float* cz,
+                  int B, int dim, int L, rsx_stream_t stream);
+size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L);
+/* Given dxL [B,dim] and/or gz [B] (gradient of cz): dX (+)= d loss/d x0, dW[L,dim], dB[L,dim], dwout[dim].
+ * x_1..x_L are recomputed from s.  workspace: rsx_cross_bwd_workspace_floats() floats.                             */
+int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, const float* s, const float* dxL, const float* gz,
+                  const float* wout, float* dX, int accumulate, float* dW, float* dB, float* dwout, float* workspace,
+                  int B, int dim, int L, rsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.
  * ------------------------------------------------------------------------------------------- */
 /* FarmHash Fingerprint64 of n byte strings (concatenated in bytes_h, offs_h[n+1]); replaces the hash

@@ -1,0 +1,241 @@
+// DCN cross layers on gfx950, all L layers fused, forward and backward.
+// Reference call site: dcn/dcn.py:132-142 -- per layer  x_{l+1} = (x_l . w_l) * x0 + x_l + b_l  with
+// w_l, b_l in R^dim (dim = 39*16 = 624).  SURVEY.md 8a row a-9: element-wise/reduce work, HBM-bound:
+// fused, one example costs 2 496 B read (+ 2 496 B written in backward), not 2*L passes.
+//
+// One wave per example; a lane keeps NV float4 of x0 and of the running x_l in registers (dim <= 1024).
+// The per-layer dot product is a fixed xor-butterfly.  Backward recomputes x_1..x_L from the saved
+// scalars s_l instead of storing L activations.  Batch reductions (dW, dB, d wout) are deterministic:
+// each wave accumulates its examples in order into a lane-private LDS slab, the per-wave partials are
+// summed in order by cross_reduce_k.  No atomics.
+#include "rsx_common.h"
+
+constexpr int CROSS_MAX_L = 8;
+constexpr int CROSS_NV = 4;   // float4 per lane -> dim <= 1024
+
+struct CrossFwdArgs {
+  const float* x0;     // [B, dim]
+  const float* W;      // [L, dim]
+  const float* Bc;     // [L, dim]
+  const float* wout;   // [dim] or null
+  float* s;            // [B, L]
+  float* xL;           // [B, dim] or null
+  float* cz;           // [B] <x_L, wout> or null
+  int B, dim, L;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+__global__ __launch_bounds__(256) void cross_fwd_k(const CrossFwdArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= p.B) return;
+  const int n4 = p.dim >> 2;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 x0[CROSS_NV], x[CROSS_NV];
+#pragma unroll
+  for (int v = 0; v < CROSS_NV; ++v) {
+    const int e = lane + 64 * v;
+    x0[v] = e < n4 ? reinterpret_cast<const float4*>(p.x0)[(size_t)b * n4 + e] : z;
+    x[v] = x0[v];
+  }
+  for (int l = 0; l < p.L; ++l) {
+    float4 w[CROSS_NV], bb[CROSS_NV];
+    float part = 0.f;
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      const int e = lane + 64 * v;
+      w[v] = e < n4 ? reinterpret_cast<const float4*>(p.W)[(size_t)l * n4 + e] : z;
+      bb[v] = e < n4 ? reinterpret_cast<const float4*>(p.Bc)[(size_t)l * n4 + e] : z;
+      part += dot4(x[v], w[v]);
+    }
+    const float s = wave_sum(part);
+    if (lane == 0) p.s[(size_t)b * p.L + l] = s;
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) x[v] = f4_add(f4_add(f4_scale(s, x0[v]), x[v]), bb[v]);
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int v = 0; v < CROSS_NV; ++v) {
+    const int e = lane + 64 * v;
+    if (e < n4) {
+      if (p.xL != nullptr) reinterpret_cast<float4*>(p.xL)[(size_t)b * n4 + e] = x[v];
+      if (p.wout != nullptr) part += dot4(x[v], reinterpret_cast<const float4*>(p.wout)[e]);
+    }
+  }
+  if (p.cz != nullptr) {
+    const float c = wave_sum(part);
+    if (lane == 0) p.cz[b] = c;
+  }
+}
+
+struct CrossBwdArgs {
+  const float* x0;     // [B, dim]
+  const float* W;      // [L, dim]
+  const float* Bc;     // [L, dim]
+  const float* s;      // [B, L]
+  const float* dxL;    // [B, dim] or null
+  const float* gz;     // [B] or null (d loss / d cz)
+  const float* wout;   // [dim] (required with gz)
+  float* dX;           // [B, dim]
+  float* part;         // [RT, 2L+1, dim]: dW (L), dB (L), dwout
+  int accumulate;      // dX += (1) or dX = (0)
+  int B, dim, L;
+};
+
+// grid = ceil(B/epw), block = 64: ONE wave walks `epw` examples and accumulates dW / dB / dwout in its own
+// LDS slab (lane-private float4 slots: no conflicts, no barriers), then writes the slab as one partial.
+// dyn LDS: (2L+1)*dim floats.
+__global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int n4 = p.dim >> 2;
+  const int nvec = 2 * p.L + 1;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* acc = reinterpret_cast<float4*>(lds);
+  for (int e = lane; e < nvec * n4; e += 64) acc[e] = z;
+  __syncthreads();   // single wave: orders the zero fill before the per-lane read-modify-writes below
+  float4 wv[CROSS_MAX_L][CROSS_NV];
+#pragma unroll
+  for (int l = 0; l < CROSS_MAX_L; ++l)
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      const int e = lane + 64 * v;
+      wv[l][v] = (l < p.L && e < n4) ? reinterpret_cast<const float4*>(p.W)[(size_t)l * n4 + e] : z;
+    }
+  for (int rr = 0; rr < epw; ++rr) {
+    const int b = blockIdx.x * epw + rr;
+    if (b >= p.B) break;
+    float4 x0[CROSS_NV], xs[CROSS_MAX_L][CROSS_NV], x[CROSS_NV], dx[CROSS_NV], dx0[CROSS_NV];
+    float sl[CROSS_MAX_L];
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      const int e = lane + 64 * v;
+      x0[v] = e < n4 ? reinterpret_cast<const float4*>(p.x0)[(size_t)b * n4 + e] : z;
+      x[v] = x0[v];
+      dx0[v] = z;
+    }
+#pragma unroll
+    for (int l = 0; l < CROSS_MAX_L; ++l) {   // recompute x_0 .. x_{L-1} (and x_L in `x`)
+      if (l < p.L) {
+        sl[l] = p.s[(size_t)b * p.L + l];
+#pragma unroll
+        for (int v = 0; v < CROSS_NV; ++v) {
+          const int e = lane + 64 * v;
+          xs[l][v] = x[v];
+          const float4 bb = e < n4 ? reinterpret_cast<const float4*>(p.Bc)[(size_t)l * n4 + e] : z;
+          x[v] = f4_add(f4_add(f4_scale(sl[l], x0[v]), x[v]), bb);
+        }
+      }
+    }
+    const float g = p.gz != nullptr ? p.gz[b] : 0.f;
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      const int e = lane + 64 * v;
+      float4 d = z;
+      if (e < n4) {
+        if (p.dxL != nullptr) d = reinterpret_cast<const float4*>(p.dxL)[(size_t)b * n4 + e];
+        if (p.gz != nullptr) {
+          d = f4_add(d, f4_scale(g, reinterpret_cast<const float4*>(p.wout)[e]));
+          float4* o = acc + (size_t)(2 * p.L) * n4 + e;
+          *o = f4_add(*o, f4_scale(g, x[v]));                       // d wout += gz * x_L
+        }
+      }
+      dx[v] = d;
+    }
+#pragma unroll
+    for (int l = CROSS_MAX_L - 1; l >= 0; --l) {
+      if (l < p.L) {
+        float part = 0.f;
+#pragma unroll
+        for (int v = 0; v < CROSS_NV; ++v) part += dot4(dx[v], x0[v]);
+        const float ds = wave_sum(part);
+#pragma unroll
+        for (int v = 0; v < CROSS_NV; ++v) {
+          const int e = lane + 64 * v;
+          if (e < n4) {
+            float4* db = acc + (size_t)(p.L + l) * n4 + e;
+            float4* dw = acc + (size_t)l * n4 + e;
+            *db = f4_add(*db, dx[v]);                                  // dB_l += dx_{l+1}
+            *dw = f4_add(*dw, f4_scale(ds, xs[l][v]));                 // dW_l += ds * x_l
+          }
+          dx0[v] = f4_add(dx0[v], f4_scale(sl[l], dx[v]));             // dx0 += s_l * dx_{l+1}
+          dx[v] = f4_add(dx[v], f4_scale(ds, wv[l][v]));               // dx_l = dx_{l+1} + ds * w_l
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      const int e = lane + 64 * v;
+      if (e < n4) {
+        float4 o = f4_add(dx0[v], dx[v]);
+        float4* dst = reinterpret_cast<float4*>(p.dX) + (size_t)b * n4 + e;
+        if (p.accumulate) o = f4_add(*dst, o);
+        *dst = o;
+      }
+    }
+  }
+  __syncthreads();
+  float4* dst = reinterpret_cast<float4*>(p.part) + (size_t)blockIdx.x * nvec * n4;
+  for (int e = lane; e < nvec * n4; e += 64) dst[e] = acc[e];
+}
+
+// out[j] = sum over workgroup partials in order.  grid = ceil(n/256)
+__global__ __launch_bounds__(256) void cross_reduce_k(const float* __restrict__ part, int RT, int n, float* __restrict__ dW,
+                                                      float* __restrict__ dB, float* __restrict__ dwout, int L, int dim) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < RT; ++r) s += part[(size_t)r * n + j];
+  const int vec = j / dim, e = j - vec * dim;
+  if (vec < L) dW[(size_t)vec * dim + e] = s;
+  else if (vec < 2 * L) dB[(size_t)(vec - L) * dim + e] = s;
+  else if (dwout != nullptr) dwout[e] = s;
+}
+
+extern "C" int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, const float* wout, float* s, float* xL,
+                             float* cz, int B, int dim, int L, rsx_stream_t stream) {
+  if (B < 0 || dim <= 0 || L <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!x0 || !W || !Bc || !s || (cz != nullptr && wout == nullptr)) return RSX_EINVAL;
+  if (dim % 4 != 0 || dim > 256 * CROSS_NV || L > CROSS_MAX_L) return RSX_EUNSUPPORTED;
+  CrossFwdArgs p{x0, W, Bc, wout, s, xL, cz, B, dim, L};
+  hipLaunchKernelGGL(cross_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), p);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+static inline int cross_epw(int B) { return B <= 1024 ? 4 : 16; }   // examples per wave
+
+extern "C" size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L) {
+  const int epw = cross_epw(B);
+  return (size_t)((B + epw - 1) / epw) * (size_t)(2 * L + 1) * (size_t)dim;
+}
+
+extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, const float* s, const float* dxL,
+                             const float* gz, const float* wout, float* dX, int accumulate, float* dW, float* dB,
+                             float* dwout, float* workspace, int B, int dim, int L, rsx_stream_t stream) {
+  if (B < 0 || dim <= 0 || L <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!x0 || !W || !Bc || !s || !dX || !dW || !dB || !workspace) return RSX_EINVAL;
+  if (gz != nullptr && (!wout || !dwout)) return RSX_EINVAL;
+  if (dxL == nullptr && gz == nullptr) return RSX_EINVAL;
+  if (dim % 4 != 0 || dim > 256 * CROSS_NV || L > CROSS_MAX_L) return RSX_EUNSUPPORTED;
+  CrossBwdArgs p{x0, W, Bc, s, dxL, gz, wout, dX, workspace, accumulate, B, dim, L};
+  const int epw = cross_epw(B);
+  const int RT = (B + epw - 1) / epw;
+  const size_t lds = (size_t)(2 * L + 1) * dim * sizeof(float);
+  if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
+  hipLaunchKernelGGL(cross_bwd_k, dim3(RT), dim3(64), lds, rsx_s(stream), p, epw);
+  RSX_CHECK_LAUNCH();
+  const int n = (2 * L + 1) * dim;
+  hipLaunchKernelGGL(cross_reduce_k, dim3((n + 255) / 256), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,
+                     L, dim);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}

@@ -1,0 +1,132 @@
+"""Deep & Cross Network on the Criteo 39-field pipeline -- MI355X-native mirror of `dcn/dcn.py`
+(model_fn :117-190, build_feature_columns :49-99, flags :16-39).
+
+x0 = the 39x16 = 624-wide embedding vector; `cross_layers` cross layers (csrc/cross.hip, all fused);
+deep tower [dense(relu) -> BN -> dropout] x n WITHOUT a final 1-unit layer (:144-149);
+logits = dense(concat[deep, x_L], 1) (:151-152).  No first-order term (linear columns are built but unused, :96,128).
+"""
+import torch
+
+from . import layers as L
+from .deepfm import define_flags as _deepfm_flags
+from .deepfm import input_fn, run_main  # noqa: F401
+from .estimator import EstimatorSpec, ModeKeys, get_variable_store
+from .feature_columns import CriteoLayout, build_feature_columns
+from .ops import CrossFn, CrossLayers, EmbeddingArena, FusedTower, gather_fm
+
+
+def build_variables(store, params, capacity):
+    layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
+    D = params["embedding_size"]
+    dim = layout.F * D
+    nL = int(params["cross_layers"])
+    if store.dp is not None:
+        capacity *= store.dp.world
+    arena = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=False)
+    with torch.no_grad():
+        t = torch.empty(arena.R, D)
+        L.trunc_normal_(t, 1.0 / D ** 0.5, store.gen)
+        arena.tables.copy_(t)
+    layers = list(map(int, params["deep_layers"].split(",")))
+    shapes, init = {}, {}
+    zeros = lambda t, g: t.zero_()
+    ones = lambda t, g: t.fill_(1.0)
+    # dcn/dcn.py:139-140: weight AND bias are glorot-normal over a 1-D [dim] shape (fan_in = fan_out = dim)
+    shapes["cross.W"], shapes["cross.b"] = (nL, dim), (nL, dim)
+    init["cross.W"] = lambda t, g: L.glorot_normal_(t, dim, dim, g)
+    init["cross.b"] = lambda t, g: L.glorot_normal_(t, dim, dim, g)
+    d = dim
+    for i, n in enumerate(layers):
+        shapes[f"dnn.W{i}"], shapes[f"dnn.b{i}"] = (d, n), (n,)
+        init[f"dnn.W{i}"] = lambda t, g, fi=d, fo=n: L.glorot_uniform_(t, fi, fo, g)
+        init[f"dnn.b{i}"] = zeros
+        shapes[f"dnn.gamma{i}"], init[f"dnn.gamma{i}"] = (n,), ones
+        shapes[f"dnn.beta{i}"], init[f"dnn.beta{i}"] = (n,), zeros
+        d = n
+    shapes["out.W"], shapes["out.b"] = (d + dim, 1), (1,)
+    init["out.W"] = lambda t, g, fi=d + dim: L.glorot_uniform_(t, fi, 1, g)
+    init["out.b"] = zeros
+    store.build({"input_layer": arena}, shapes, init, params["learning_rate"])
+    store.layout = layout
+    store.cross = CrossLayers(dim, nL, capacity, store.device)
+    store.tower = None
+    if params.get("tower", "hip") == "hip":
+        store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
+
+
+def _train_fused(store, arena, ids, labels, params, masks):
+    dp, P = store.dp, store.dense
+    nh = store.tower.widths[-1]
+    oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
+    with torch.no_grad():
+        store.sort_ids_for_backward(arena, ids)
+        x0, _, _, _ = arena.gather(ids)
+        _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
+        loss, prob, dX, gz, _ = store.tower.train_step(
+            x0, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
+            s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,
+            replicas=dp.world if dp is not None else 1, masks=masks)
+        store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
+                             gz=gz, wout=oW[nh:], dwout=oG[nh:])
+
+    def train_op():
+        with torch.no_grad():
+            if dp is not None:
+                dXg, _, _, _ = dp.gather_example_grads(dX)
+                arena.segsum(dXg.shape[0], None, dXg, None, None)
+                dp.all_reduce_sum(store.dense.grad)
+            else:
+                arena.segsum(ids.shape[0], None, dX, None, None)
+            store.apply_gradients()
+
+    return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
+
+
+def model_fn(features, labels, mode, params):
+    """dcn/dcn.py:117-190."""
+    store = get_variable_store()
+    ids = features["ids"]
+    if not store.built:
+        build_variables(store, params, capacity=max(int(params.get("max_batch_size", 0)), ids.shape[0]))
+    arena, P = store.embeddings["input_layer"], store.dense
+    training = mode == ModeKeys.TRAIN
+    layers = params["deep_layers"].split(",")
+    masks = params.get("_dropout_masks")
+    if training and store.tower is not None:
+        return _train_fused(store, arena, ids, labels, params, masks)
+    if training:
+        store.sort_ids_for_backward(arena, ids)
+    (x0,) = gather_fm(arena, ids, dp=store.dp if training else None)               # embedding_net (:123)
+    xl = CrossFn.apply(x0, P["cross.W"], P["cross.b"], store.cross)                # 'cross_layers' (:132-142)
+    dnn_net = L.tower(x0, P, "dnn", len(layers), training, params["dropout"], masks)   # 'deep_layers' (:144-149)
+    logits = L.dense(torch.cat([dnn_net, xl], -1), P["out.W"], P["out.b"]).reshape(-1)   # (:151-152)
+    pred = torch.sigmoid(logits)
+    predictions = {"prob": pred}
+    if mode == ModeKeys.PREDICT:
+        return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+    loss = L.sigmoid_ce_mean(logits, labels)
+    if mode == ModeKeys.EVAL:
+        return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
+    return EstimatorSpec(mode, predictions=predictions, loss=loss, train_op=lambda: store.minimize(loss))
+
+
+def define_flags():
+    p = _deepfm_flags()
+    p.add_argument("--cross_layers", type=int, default=4)      # dcn/dcn.py:24
+    p.set_defaults(save_checkpoints_steps=2000)
+    return p
+
+
+def make_params(FLAGS):
+    lin, emb = build_feature_columns(FLAGS.embedding_size, "numeric")
+    return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
+            "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
+            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size}
+
+
+def main(argv=None):
+    run_main(model_fn, define_flags().parse_args(argv), make_params)
+
+
+if __name__ == "__main__":
+    main()

@@ -165,11 +165,11 @@ def make_params(FLAGS, linear="indicator_all"):
             "max_batch_size": FLAGS.batch_size}
 
 
-def main(argv=None):
-    FLAGS = define_flags().parse_args(argv)
+def run_main(model_fn, FLAGS, make_params_fn):
+    """The `main(_)` driver shared by the Criteo scripts (fm/fm.py:173-224, deepfm/deepfm.py:153-234, ...)."""
     files = [FLAGS.train_path + "part-r-{:0>5}".format(i) for i in range(FLAGS.train_parts)]
     train_files, eval_files = files[:-FLAGS.eval_parts], files[-FLAGS.eval_parts:]
-    params = make_params(FLAGS)
+    params = make_params_fn(FLAGS)
     config = RunConfig(save_checkpoints_steps=FLAGS.save_checkpoints_steps, keep_checkpoint_max=5,
                        log_step_count_steps=FLAGS.log_steps, adam_mode=FLAGS.adam_mode)
     est = Estimator(model_fn, FLAGS.model_dir, params, config)
@@ -180,14 +180,22 @@ def main(argv=None):
     if FLAGS.task_type == "train":
         tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.num_parallel, layout))
         ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
-        train_and_evaluate(est, tr, ev)
-    elif FLAGS.task_type == "eval":
-        est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
-    elif FLAGS.task_type == "infer":
+        return train_and_evaluate(est, tr, ev)
+    if FLAGS.task_type == "eval":
+        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
+    if FLAGS.task_type == "infer":
+        out = []
         for i, p in enumerate(est.predict(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout))):
             print(p)
+            out.append(p)
             if i >= 9:
                 break
+        return out
+    raise SystemExit("unknown --task_type %r" % FLAGS.task_type)
+
+
+def main(argv=None):
+    run_main(model_fn, define_flags().parse_args(argv), make_params)
 
 
 if __name__ == "__main__":

@@ -304,12 +304,15 @@ class FusedTower:
                                         _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
                                         _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
                                         rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_fwd_layer")
+        # head parameters: a variable name, or an explicit (tensor, grad_tensor) pair (e.g. a slice of out.W)
+        pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
+        gv = lambda x: None if x is None else (P[x].grad if isinstance(x, str) else x[1])
         wd, bd, wo, bo = head
         n_last = self.widths[-1]
         check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(self.fstat[-1]), _ptr(P[f"{pre}.gamma{nl - 1}"]),
-                               _ptr(P[f"{pre}.beta{nl - 1}"]), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(P[wd]), _ptr(P[bd]),
-                               _ptr(s0), _ptr(P[c0]) if c0 else None, _ptr(s1), _ptr(P[wo]) if wo else None,
-                               _ptr(P[bo]) if bo else None, _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
+                               _ptr(P[f"{pre}.beta{nl - 1}"]), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)),
+                               _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
+                               _ptr(pv(bo)), _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
                                _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
                                rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, st),
               "rsx_tower_head")
@@ -324,8 +327,52 @@ class FusedTower:
                 _ptr(P[f"{pre}.beta{l - 1}"]) if l else None, _ptr(mk[l - 1]) if l else None,
                 _ptr(self.dy[l - 1]) if l else _ptr(self.dX), _ptr(self.bstat[l - 1]) if l else None,
                 _ptr(self.hpart) if last else None, _ptr(self.dwd_part) if last else None,
-                _ptr(g(wd)) if last else None, _ptr(g(bd)) if last else None,
-                _ptr(g(wo)) if (last and wo) else None, _ptr(g(bo)) if (last and bo) else None,
-                _ptr(g(c0)) if (last and c0) else None, _ptr(self.loss) if last else None,
+                _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
+                _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
+                _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
                 rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_bwd_layer")
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
+
+
+class CrossLayers:
+    """DCN cross layers (csrc/cross.hip) with their backward workspace.  dcn/dcn.py:132-142."""
+
+    def __init__(self, dim, L, capacity, device="cuda"):
+        dev = _require_cuda(device)
+        self.dim, self.L, self.cap = int(dim), int(L), int(capacity)
+        self.s = torch.empty(self.cap, self.L, device=dev)
+        self.cz = torch.empty(self.cap, device=dev)
+        n = lib().rsx_cross_bwd_workspace_floats(self.cap, self.dim, self.L)
+        self.ws = torch.empty(max(n, lib().rsx_cross_bwd_workspace_floats(1024, self.dim, self.L)), device=dev)
+
+    def forward(self, x0, W, Bc, wout=None, want_xL=False):
+        B = x0.shape[0]
+        xL = torch.empty_like(x0) if want_xL else None
+        check(lib().rsx_cross_fwd(_ptr(x0), _ptr(W), _ptr(Bc), _ptr(wout), _ptr(self.s), _ptr(xL),
+                                  _ptr(self.cz) if wout is not None else None, B, self.dim, self.L, _stream()),
+              "rsx_cross_fwd")
+        return self.s[:B], xL, (self.cz[:B] if wout is not None else None)
+
+    def backward(self, x0, W, Bc, dW, dB, dX, accumulate, dxL=None, gz=None, wout=None, dwout=None):
+        B = x0.shape[0]
+        check(lib().rsx_cross_bwd(_ptr(x0), _ptr(W), _ptr(Bc), _ptr(self.s), _ptr(dxL), _ptr(gz), _ptr(wout), _ptr(dX),
+                                  int(accumulate), _ptr(dW), _ptr(dB), _ptr(dwout), _ptr(self.ws), B, self.dim, self.L,
+                                  _stream()), "rsx_cross_bwd")
+
+
+class CrossFn(torch.autograd.Function):
+    """Autograd wrapper (used by the torch-tower path and by the op-level parity tests)."""
+
+    @staticmethod
+    def forward(ctx, x0, W, Bc, op):
+        _, xL, _ = op.forward(x0.contiguous(), W, Bc, None, want_xL=True)
+        ctx.op = op
+        ctx.save_for_backward(x0, W, Bc)
+        return xL
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, W, Bc = ctx.saved_tensors
+        dW, dB, dX = torch.empty_like(W), torch.empty_like(Bc), torch.empty_like(x0)
+        ctx.op.backward(x0.contiguous(), W, Bc, dW, dB, dX, False, dxL=g.contiguous())
+        return dX, dW, dB, None

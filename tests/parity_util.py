@@ -42,11 +42,11 @@ def load_oracle_weights(est, P):
 
 
 def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100), adam_mode="tf1_dense",
-                      use_graph=False, return_all=False, tower="hip", dropout=0.0):
-    """Train `steps` DeepFM steps (dropout 0) on both sides from identical weights and batches.
-    Returns max |logit_gpu - logit_oracle| over all steps (and final parameter errors if return_all)."""
+                      use_graph=False, return_all=False, tower="hip", dropout=0.0, kind="deepfm", cross_layers=3):
+    """Train `steps` steps of `kind` in {deepfm, fm, dcn} on both sides from identical weights and batches (injected
+    dropout masks).  Returns max |prob_gpu - prob_oracle| over all steps (and losses / final parameter errors)."""
     import torch
-    from recsys_amd import deepfm
+    from recsys_amd import dcn, deepfm, fm
     from recsys_amd.estimator import ModeKeys
     from recsys_amd.feature_columns import build_feature_columns
     rng = np.random.default_rng(seed)
@@ -56,17 +56,27 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
     else:
         lin, emb = small_columns(rows, D)
         row_off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-    P = init.deepfm_params(seed, D, layers, np.float32, row_off)
-    P["b1"] += np.float32(0.05)
+    if kind == "dcn":
+        P = init.dcn_params(seed, D, layers, cross_layers, np.float32, row_off)
+        mfn = dcn.model_fn
+    elif kind == "fm":
+        P = init.deepfm_params(seed, D, (), np.float32, row_off, with_dnn=False)
+        mfn, layers = fm.model_fn, ()
+    else:
+        P = init.deepfm_params(seed, D, layers, np.float32, row_off)
+        mfn = deepfm.model_fn
+    if "b1" in P:
+        P["b1"] += np.float32(0.05)
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D,
               "learning_rate": 1e-3, "dropout": dropout, "deep_layers": ",".join(map(str, layers)), "max_batch_size": B,
-              "tower": tower}
-    est = make_estimator(deepfm.model_fn, params, adam_mode, use_graph)
+              "tower": tower, "cross_layers": cross_layers}
+    est = make_estimator(mfn, params, adam_mode, use_graph)
     batches = [(synth_ids(rng, B, row_off), rng.integers(0, 2, B).astype(np.float32)) for _ in range(steps)]
     ids0 = torch.from_numpy(batches[0][0]).cuda()
     est._call_model_fn({"ids": ids0}, None, ModeKeys.PREDICT)        # creates the variables
     load_oracle_weights(est, P)
-    om = models.DeepFM(P, row_off, len(layers), dropout)
+    om = {"dcn": lambda: models.DCN(P, row_off, len(layers), dropout), "fm": lambda: models.FM(P, row_off),
+          "deepfm": lambda: models.DeepFM(P, row_off, len(layers), dropout)}[kind]()
     opt = nn.AdamTF1(dtype=np.float32)
     err = 0.0
     losses = []
@@ -76,20 +86,21 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
         with torch.no_grad():
             zg = est._call_model_fn(f, None, ModeKeys.PREDICT).predictions["prob"]
         mk = None
-        if dropout > 0.0:      # injected keep-masks, identical on both sides
+        if dropout > 0.0 and len(layers):      # injected keep-masks, identical on both sides
             mk = [(rng.random((B, n)) >= dropout).astype(np.float32) for n in layers]
             est.params["_dropout_masks"] = [torch.from_numpy(m).cuda() for m in mk]
         loss_g = est._train_step(f, lab)
         zo_eval = nn.sigmoid(om.forward(ids, train=False))
         loss_o, _ = models.train_step(om, opt, (ids,), y, {"masks": mk} if mk else None, lazy=(adam_mode == "lazy_rows"))
-        err = max(err, float(np.abs(zg.cpu().numpy() - zo_eval).max()))
+        err = max(err, float(np.abs(zg.cpu().numpy().reshape(-1) - zo_eval).max()))
         losses.append((float(loss_g), float(loss_o)))
     if not return_all:
         return err
     st = est.store
     a = st.embeddings["input_layer"]
-    perr = {"tables": float(np.abs(a.tables.cpu().numpy() - P["tables"]).max()),
-            "w1": float(np.abs(a.w1.cpu().numpy() - P["w1"]).max())}
+    perr = {"tables": float(np.abs(a.tables.cpu().numpy() - P["tables"]).max())}
+    if a.with_w1:
+        perr["w1"] = float(np.abs(a.w1.cpu().numpy() - P["w1"]).max())
     for k, p in st.dense.params.items():
         perr[k] = float(np.abs(p.detach().cpu().numpy() - P[k].reshape(p.shape)).max())
     return err, losses, perr

@@ -267,3 +267,55 @@ def test_tower_rng_dropout_is_the_documented_hash_and_consistent_fwd_bwd():
         outs.append((loss, a.tables.cpu().numpy().copy(), est.store.dense.flat.cpu().numpy().copy()))
     assert outs[0][0] == outs[1][0]
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+# ------------------------------------------------------------------------------------------- FM / DCN
+def test_fm_train_parity_criteo_bs256():
+    """BASELINE config 1 (fm.py Criteo d=16 bs=256): oracle vs the fused embedding kernels."""
+    err, losses, perr = deepfm_parity_run(B=256, steps=3, seed=11, return_all=True, kind="fm")
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("B,dim,L", [(33, 624, 3), (256, 624, 4), (5, 64, 1), (70, 1024, 7), (1500, 624, 3)])
+def test_cross_layers_op_parity(B, dim, L):
+    from recsys_amd.ops import CrossFn, CrossLayers
+    rng = np.random.default_rng(B + L)
+    x0 = rng.standard_normal((B, dim)).astype(np.float32) * 0.3
+    W = rng.standard_normal((L, dim)).astype(np.float32) * 0.05
+    Bc = rng.standard_normal((L, dim)).astype(np.float32) * 0.05
+    g = rng.standard_normal((B, dim)).astype(np.float32)
+    xs, ss = models.cross_fwd(x0, W, Bc)
+    dx0, dW, dB = models.cross_bwd(xs, ss, W, g)
+    op = CrossLayers(dim, L, B)
+    tx, tW, tB = (torch.from_numpy(a).cuda().requires_grad_() for a in (x0, W, Bc))
+    out = CrossFn.apply(tx, tW, tB, op)
+    out.backward(torch.from_numpy(g).cuda())
+    tol = dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), xs[-1], **tol)
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), dx0, **tol)
+    np.testing.assert_allclose(tW.grad.cpu().numpy(), dW, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(tB.grad.cpu().numpy(), dB, rtol=1e-4, atol=1e-4)
+    assert tuple(models.cross_fwd(np.array([[1.0, 2.0, 0, 0]], np.float32), np.array([[1.0, 1, 0, 0]], np.float32),
+                                  np.zeros((1, 4), np.float32))[0][-1][0][:2]) == (4.0, 8.0)   # Appendix B-6 KAT
+
+
+@pytest.mark.parametrize("tower,dropout", [("hip", 0.0), ("hip", 0.5), ("torch", 0.5)])
+def test_dcn_train_parity_small(tower, dropout):
+    err, losses, perr = deepfm_parity_run(B=48, steps=4, seed=12, rows=(3, 7, 40, 11, 600), D=16, layers=(32, 16),
+                                          return_all=True, tower=tower, dropout=dropout, kind="dcn", cross_layers=3)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+def test_dcn_train_parity_criteo():
+    """BASELINE config 4 shape (dcn.py Criteo d=16, 3 cross layers) at a batch the oracle finishes in seconds."""
+    err, losses, perr = deepfm_parity_run(B=512, steps=2, seed=13, return_all=True, kind="dcn", cross_layers=3, dropout=0.5)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 2e-5, losses
+    assert max(perr.values()) < 5e-5, perr
