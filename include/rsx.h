@@ -190,6 +190,27 @@ int rsx_bucketize_log_h(const float* x_h, int64_t n, const float* boundaries_h, 
 uint32_t rsx_crc32c_h(const uint8_t* data_h, size_t n);
 uint32_t rsx_masked_crc32c_h(const uint8_t* data_h, size_t n);
 
+/* TFRecord framing scan of a whole shard image (tf.data.TFRecordDataset fm/fm.py:107): returns the record count
+ * (payload offsets / lengths written up to max_records) or RSX_EDATA on truncation / crc mismatch.            */
+int64_t rsx_tfrecord_index_h(const uint8_t* buf_h, size_t n, int64_t* offsets_h, int64_t* lengths_h,
+                             int64_t max_records, int verify_crc);
+/* tf.parse_single_example(feature_description) fm/fm.py:43-44,100-103 fused with the host half of input_layer:
+ * records -> label[n], cont_log[n,13] (nullable), ids[n,F] in slot order.  Multi-threaded over records.          */
+int rsx_criteo_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n,
+                       const int32_t* slot_src_h, const int32_t* slot_rows_h, const float* bnd_h,
+                       const int32_t* bnd_off_h, const float* shift_h, int F, float* label_h, float* cont_log_h,
+                       int32_t* ids_h, int threads);
+/* din/din.py:44-57: label, i_id, i_cate and the two VarLen histories densified / zero padded to P.               */
+int rsx_din_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n, int P,
+                    int64_t* label_h, int64_t* i_id_h, int64_t* i_cate_h, int64_t* hist_i_h, int64_t* hist_c_h,
+                    int threads);
+/* Writers for synthetic shards of the two schemas (the reference's own sample shard is a missing blob).  Return bytes
+ * written, or -(needed+16) when cap is too small.                                                               */
+int64_t rsx_criteo_encode_h(const float* label_h, const float* cont_h, const uint8_t* cat_bytes_h,
+                            const int64_t* cat_offs_h, int64_t n, uint8_t* out_h, int64_t cap);
+int64_t rsx_din_encode_h(const int64_t* label_h, const int64_t* i_id_h, const int64_t* i_cate_h, const int64_t* hist_i_h,
+                         const int64_t* hist_c_h, int64_t n, int P, int keep_padding, uint8_t* out_h, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

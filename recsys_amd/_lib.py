@@ -39,6 +39,11 @@ _SIGS = {
     "rsx_hash_fp64_h": (_I, [_P, _P, C.c_int64, _P]),
     "rsx_fingerprint64_h": (C.c_uint64, [_P, C.c_size_t]),
     "rsx_bucketize_log_h": (_I, [_P, C.c_int64, _P, _I, _F, _P]),
+    "rsx_tfrecord_index_h": (C.c_int64, [_P, C.c_size_t, _P, _P, C.c_int64, _I]),
+    "rsx_criteo_parse_h": (_I, [_P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I]),
+    "rsx_din_parse_h": (_I, [_P, _P, _P, C.c_int64, _I, _P, _P, _P, _P, _P, _I]),
+    "rsx_criteo_encode_h": (C.c_int64, [_P, _P, _P, _P, C.c_int64, _P, C.c_int64]),
+    "rsx_din_encode_h": (C.c_int64, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _P, C.c_int64]),
     "rsx_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
     "rsx_masked_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
 }

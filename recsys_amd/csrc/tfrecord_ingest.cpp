@@ -1,0 +1,373 @@
+// Host-side TFRecord / tf.train.Example ingest of librsx.so (no device code).
+// Replaces tf.data.TFRecordDataset + tf.parse_single_example of fm/fm.py:100-112 (deepfm/deepfm.py:54-70,
+// xdeepfm/xdeepfm.py:95-118, dcn/dcn.py:100-112, din/din.py:52-80) and produces what the reference's
+// feature columns produce next: table-local ids (FarmHash % bucket, bucketize(log(x+shift))), the label
+// and the log-normalised numerics.  Format per SURVEY.md Appendix A-14 (what xdeepfm/gen_tfrecords.py:31-40
+// writes through spark-tensorflow-connector).  Multi-threaded over records; a writer for synthetic shards
+// is included because the reference's only sample shard is a missing blob.
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rsx.h"
+
+extern "C" uint64_t rsx_fingerprint64_h(const uint8_t* s, size_t n);
+
+namespace {
+struct Span { const uint8_t* p; size_t n; };
+
+inline bool rd_varint(const uint8_t*& p, const uint8_t* e, uint64_t& v) {
+  v = 0;
+  for (int s = 0; s < 64 && p < e; s += 7) {
+    const uint8_t b = *p++;
+    v |= (uint64_t)(b & 0x7f) << s;
+    if (!(b & 0x80)) return true;
+  }
+  return false;
+}
+// next field of a message: returns false at end or on malformed input (ok=false)
+inline bool next_field(const uint8_t*& p, const uint8_t* e, uint32_t& fno, uint32_t& wt, Span& val, uint64_t& num, bool& ok) {
+  if (p >= e) return false;
+  uint64_t tag;
+  if (!rd_varint(p, e, tag)) { ok = false; return false; }
+  fno = (uint32_t)(tag >> 3);
+  wt = (uint32_t)(tag & 7);
+  if (wt == 2) {
+    uint64_t n;
+    if (!rd_varint(p, e, n) || n > (uint64_t)(e - p)) { ok = false; return false; }
+    val = {p, (size_t)n};
+    p += n;
+  } else if (wt == 0) {
+    if (!rd_varint(p, e, num)) { ok = false; return false; }
+  } else if (wt == 5) {
+    if (e - p < 4) { ok = false; return false; }
+    val = {p, 4};
+    p += 4;
+  } else if (wt == 1) {
+    if (e - p < 8) { ok = false; return false; }
+    val = {p, 8};
+    p += 8;
+  } else {
+    ok = false;
+    return false;
+  }
+  return true;
+}
+
+// Visits every (key, Feature payload) of one serialized Example.
+template <class F>
+bool for_each_feature(const uint8_t* rec, size_t n, F f) {
+  bool ok = true;
+  const uint8_t *p = rec, *e = rec + n;
+  uint32_t fno, wt; Span v; uint64_t num;
+  while (next_field(p, e, fno, wt, v, num, ok)) {
+    if (fno != 1 || wt != 2) continue;                 // Example.features
+    const uint8_t *q = v.p, *qe = v.p + v.n;
+    Span ent;
+    while (next_field(q, qe, fno, wt, ent, num, ok)) {
+      if (fno != 1 || wt != 2) continue;               // Features.feature (map entry)
+      const uint8_t *r = ent.p, *re = ent.p + ent.n;
+      Span key{nullptr, 0}, feat{nullptr, 0}, t;
+      while (next_field(r, re, fno, wt, t, num, ok)) {
+        if (fno == 1 && wt == 2) key = t;
+        else if (fno == 2 && wt == 2) feat = t;
+      }
+      if (!ok) return false;
+      if (key.p) f(key, feat);
+    }
+  }
+  return ok;
+}
+
+// Feature -> first float of float_list (kind 2)
+inline bool feat_first_float(Span feat, float& out) {
+  bool ok = true;
+  const uint8_t *p = feat.p, *e = feat.p + feat.n;
+  uint32_t fno, wt; Span v; uint64_t num;
+  while (next_field(p, e, fno, wt, v, num, ok)) {
+    if (fno != 2 || wt != 2) continue;
+    const uint8_t *q = v.p, *qe = v.p + v.n;
+    Span x;
+    while (next_field(q, qe, fno, wt, x, num, ok)) {
+      if (fno != 1) continue;
+      if ((wt == 2 && x.n >= 4) || wt == 5) { std::memcpy(&out, x.p, 4); return true; }
+    }
+  }
+  return false;
+}
+// Feature -> first bytes value of bytes_list (kind 1)
+inline bool feat_first_bytes(Span feat, Span& out) {
+  bool ok = true;
+  const uint8_t *p = feat.p, *e = feat.p + feat.n;
+  uint32_t fno, wt; Span v; uint64_t num;
+  while (next_field(p, e, fno, wt, v, num, ok)) {
+    if (fno != 1 || wt != 2) continue;
+    const uint8_t *q = v.p, *qe = v.p + v.n;
+    Span x;
+    while (next_field(q, qe, fno, wt, x, num, ok))
+      if (fno == 1 && wt == 2) { out = x; return true; }
+  }
+  return false;
+}
+// Feature -> all int64 of int64_list (kind 3); returns count (writes at most cap)
+inline int64_t feat_int64s(Span feat, int64_t* out, int64_t cap) {
+  bool ok = true;
+  int64_t n = 0;
+  const uint8_t *p = feat.p, *e = feat.p + feat.n;
+  uint32_t fno, wt; Span v; uint64_t num;
+  while (next_field(p, e, fno, wt, v, num, ok)) {
+    if (fno != 3 || wt != 2) continue;
+    const uint8_t *q = v.p, *qe = v.p + v.n;
+    Span x;
+    while (next_field(q, qe, fno, wt, x, num, ok)) {
+      if (fno != 1) continue;
+      if (wt == 0) { if (n < cap) out[n] = (int64_t)num; ++n; }
+      else if (wt == 2) {
+        const uint8_t *r = x.p, *re = x.p + x.n;
+        uint64_t y;
+        while (r < re && rd_varint(r, re, y)) { if (n < cap) out[n] = (int64_t)y; ++n; }
+      }
+    }
+  }
+  return n;
+}
+
+inline int key_cN(Span key) {   // "_c0".."_c39" -> 0..39, else -1
+  if (key.n < 3 || key.n > 4 || key.p[0] != '_' || key.p[1] != 'c') return -1;
+  int v = 0;
+  for (size_t i = 2; i < key.n; ++i) {
+    if (key.p[i] < '0' || key.p[i] > '9') return -1;
+    v = v * 10 + (key.p[i] - '0');
+  }
+  return v <= 39 ? v : -1;
+}
+
+template <class F>
+void parallel_for(int64_t n, int threads, F f) {
+  if (threads <= 1 || n < 64) { f(0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; ++t) {
+    const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
+    if (a >= b) break;
+    th.emplace_back([=] { f(a, b); });
+  }
+  for (auto& x : th) x.join();
+}
+
+inline void put_varint(std::string& s, uint64_t v) {
+  while (v >= 0x80) { s.push_back((char)(v | 0x80)); v >>= 7; }
+  s.push_back((char)v);
+}
+inline void put_ld(std::string& s, uint32_t field, const std::string& payload) {
+  put_varint(s, (field << 3) | 2);
+  put_varint(s, payload.size());
+  s += payload;
+}
+}  // namespace
+
+// Scans the framing `u64 len | u32 masked_crc(len) | data | u32 masked_crc(data)` of a whole shard image.
+// Returns the number of records (offsets/lengths of the payloads are written up to max_records), or a negative
+// rsx_status: RSX_EDATA on a truncated record or a crc mismatch (TF raises DataLossError there).
+extern "C" int64_t rsx_tfrecord_index_h(const uint8_t* buf_h, size_t n, int64_t* offsets_h, int64_t* lengths_h,
+                                        int64_t max_records, int verify_crc) {
+  if (n > 0 && !buf_h) return RSX_EINVAL;
+  size_t p = 0;
+  int64_t cnt = 0;
+  while (p < n) {
+    if (n - p < 12) return RSX_EDATA;
+    uint64_t len;
+    std::memcpy(&len, buf_h + p, 8);
+    uint32_t c;
+    std::memcpy(&c, buf_h + p + 8, 4);
+    if (verify_crc && c != rsx_masked_crc32c_h(buf_h + p, 8)) return RSX_EDATA;
+    if (len > n - p - 12 || n - p - 12 - len < 4) return RSX_EDATA;
+    if (verify_crc) {
+      std::memcpy(&c, buf_h + p + 12 + len, 4);
+      if (c != rsx_masked_crc32c_h(buf_h + p + 12, (size_t)len)) return RSX_EDATA;
+    }
+    if (cnt < max_records && offsets_h && lengths_h) {
+      offsets_h[cnt] = (int64_t)(p + 12);
+      lengths_h[cnt] = (int64_t)len;
+    }
+    ++cnt;
+    p += 16 + len;
+  }
+  return cnt;
+}
+
+// Criteo records -> label[n], cont_log[n,13] = log(x + shift_j), ids[n,F] in slot order.
+//   slot_src[F]   source feature index j of each slot (1..13 numeric, 14..39 categorical)
+//   slot_rows[F]  bucket count of the slot; bnd / bnd_off[F+1]: boundaries of the numeric slots
+//   shift[13]     log shift of _c1.._c13 (1, except 4 for _c2: fm/fm.py:77-78)
+// Absent categorical feature -> the 'NULL' default (fm/fm.py:44); absent numeric or label -> RSX_EDATA (TF:
+// FixedLenFeature without default).
+extern "C" int rsx_criteo_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n,
+                                  const int32_t* slot_src_h, const int32_t* slot_rows_h, const float* bnd_h,
+                                  const int32_t* bnd_off_h, const float* shift_h, int F, float* label_h,
+                                  float* cont_log_h, int32_t* ids_h, int threads) {
+  if (n < 0 || F <= 0 || F > 64) return RSX_EINVAL;
+  if (n == 0) return RSX_OK;
+  if (!buf_h || !offsets_h || !lengths_h || !slot_src_h || !slot_rows_h || !bnd_off_h || !shift_h || !label_h || !ids_h)
+    return RSX_EINVAL;
+  const uint64_t null_hash = rsx_fingerprint64_h(reinterpret_cast<const uint8_t*>("NULL"), 4);
+  std::atomic<int> status{RSX_OK};
+  parallel_for(n, threads, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; ++r) {
+      float fv[14];
+      bool have_f[14] = {false};
+      uint64_t hv[40];
+      bool have_h[40] = {false};
+      const bool ok = for_each_feature(buf_h + offsets_h[r], (size_t)lengths_h[r], [&](Span key, Span feat) {
+        const int j = key_cN(key);
+        if (j < 0) return;
+        if (j <= 13) {
+          float x;
+          if (feat_first_float(feat, x)) { fv[j] = x; have_f[j] = true; }
+        } else {
+          Span s;
+          if (feat_first_bytes(feat, s)) { hv[j] = rsx_fingerprint64_h(s.p, s.n); have_h[j] = true; }
+        }
+      });
+      bool good = ok;
+      for (int j = 0; j <= 13; ++j) good = good && have_f[j];
+      if (!good) { status.store(RSX_EDATA); continue; }
+      label_h[r] = fv[0];
+      float lg[14];
+      for (int j = 1; j <= 13; ++j) {
+        lg[j] = logf(fv[j] + shift_h[j - 1]);
+        if (cont_log_h) cont_log_h[r * 13 + (j - 1)] = lg[j];
+      }
+      for (int s = 0; s < F; ++s) {
+        const int j = slot_src_h[s];
+        int32_t id;
+        if (j <= 13) {
+          const float v = lg[j];
+          const float* bd = bnd_h + bnd_off_h[s];
+          const int nb = bnd_off_h[s + 1] - bnd_off_h[s];
+          if (v != v) id = nb;
+          else {
+            int lo = 0, hi = nb;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (bd[mid] <= v) lo = mid + 1; else hi = mid; }
+            id = lo;
+          }
+        } else {
+          id = (int32_t)((have_h[j] ? hv[j] : null_hash) % (uint64_t)slot_rows_h[s]);
+        }
+        ids_h[r * F + s] = id;
+      }
+    }
+  });
+  return status.load();
+}
+
+// DIN records (din/din.py:44-57): label, i_id, i_cate scalars (int64) and the VarLen histories, densified and zero
+// padded / truncated to P like sparse_tensor_to_dense + batch.
+extern "C" int rsx_din_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n, int P,
+                               int64_t* label_h, int64_t* i_id_h, int64_t* i_cate_h, int64_t* hist_i_h,
+                               int64_t* hist_c_h, int threads) {
+  if (n < 0 || P <= 0) return RSX_EINVAL;
+  if (n == 0) return RSX_OK;
+  if (!buf_h || !offsets_h || !lengths_h || !label_h || !i_id_h || !i_cate_h || !hist_i_h || !hist_c_h) return RSX_EINVAL;
+  std::atomic<int> status{RSX_OK};
+  parallel_for(n, threads, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; ++r) {
+      bool got[3] = {false, false, false};
+      std::memset(hist_i_h + r * P, 0, sizeof(int64_t) * P);
+      std::memset(hist_c_h + r * P, 0, sizeof(int64_t) * P);
+      const bool ok = for_each_feature(buf_h + offsets_h[r], (size_t)lengths_h[r], [&](Span key, Span feat) {
+        const std::string k(reinterpret_cast<const char*>(key.p), key.n);
+        if (k == "label") got[0] = feat_int64s(feat, label_h + r, 1) >= 1;
+        else if (k == "i_id") got[1] = feat_int64s(feat, i_id_h + r, 1) >= 1;
+        else if (k == "i_cate") got[2] = feat_int64s(feat, i_cate_h + r, 1) >= 1;
+        else if (k == "u_iid_seq") feat_int64s(feat, hist_i_h + r * P, P);
+        else if (k == "u_icat_seq") feat_int64s(feat, hist_c_h + r * P, P);
+      });
+      if (!ok || !got[0] || !got[1] || !got[2]) status.store(RSX_EDATA);
+    }
+  });
+  return status.load();
+}
+
+static void frame_into(std::string& out, const std::string& ex) {
+  uint64_t len = ex.size();
+  char hdr[8];
+  std::memcpy(hdr, &len, 8);
+  uint32_t c = rsx_masked_crc32c_h(reinterpret_cast<const uint8_t*>(hdr), 8);
+  out.append(hdr, 8);
+  out.append(reinterpret_cast<const char*>(&c), 4);
+  out += ex;
+  c = rsx_masked_crc32c_h(reinterpret_cast<const uint8_t*>(ex.data()), ex.size());
+  out.append(reinterpret_cast<const char*>(&c), 4);
+}
+static void add_feature(std::string& feats, const std::string& key, uint32_t kind, const std::string& list_payload) {
+  std::string lst, feat, entry;
+  put_ld(lst, 1, list_payload);       // value = 1 (packed for float/int64)
+  put_ld(feat, kind, lst);
+  put_ld(entry, 1, key);
+  put_ld(entry, 2, feat);
+  put_ld(feats, 1, entry);
+}
+
+// Writer for synthetic Criteo shards with the schema of fm/fm.py:39-44: floats _c0.._c13 as float_list,
+// strings _c14.._c39 as bytes_list, values equal to "NULL" omitted like the Spark connector omits nulls.
+// Returns bytes written, or -needed when cap is too small, or a negative rsx_status.
+extern "C" int64_t rsx_criteo_encode_h(const float* label_h, const float* cont_h, const uint8_t* cat_bytes_h,
+                                       const int64_t* cat_offs_h, int64_t n, uint8_t* out_h, int64_t cap) {
+  if (n < 0 || (n > 0 && (!label_h || !cont_h || !cat_offs_h))) return RSX_EINVAL;
+  std::string out;
+  for (int64_t r = 0; r < n; ++r) {
+    std::string feats, ex;
+    for (int j = 0; j <= 13; ++j) {
+      const float v = j == 0 ? label_h[r] : cont_h[r * 13 + j - 1];
+      add_feature(feats, "_c" + std::to_string(j), 2, std::string(reinterpret_cast<const char*>(&v), 4));
+    }
+    for (int j = 14; j <= 39; ++j) {
+      const int64_t a = cat_offs_h[r * 26 + j - 14], b = cat_offs_h[r * 26 + j - 14 + 1];
+      if (b - a == 4 && std::memcmp(cat_bytes_h + a, "NULL", 4) == 0) continue;
+      std::string lst, feat, entry;
+      put_ld(lst, 1, std::string(reinterpret_cast<const char*>(cat_bytes_h + a), (size_t)(b - a)));
+      put_ld(feat, 1, lst);
+      put_ld(entry, 1, "_c" + std::to_string(j));
+      put_ld(entry, 2, feat);
+      put_ld(feats, 1, entry);
+    }
+    put_ld(ex, 1, feats);
+    frame_into(out, ex);
+  }
+  if ((int64_t)out.size() > cap || !out_h) return -(int64_t)out.size() - 16;
+  std::memcpy(out_h, out.data(), out.size());
+  return (int64_t)out.size();
+}
+
+// Writer for synthetic DIN shards (din/din.py:44-50): int64 label, i_id, i_cate and the two VarLen histories
+// (trailing zero padding is dropped, so the sequences are really variable-length on disk).
+extern "C" int64_t rsx_din_encode_h(const int64_t* label_h, const int64_t* i_id_h, const int64_t* i_cate_h,
+                                    const int64_t* hist_i_h, const int64_t* hist_c_h, int64_t n, int P, int keep_padding,
+                                    uint8_t* out_h, int64_t cap) {
+  if (n < 0 || P <= 0) return RSX_EINVAL;
+  std::string out;
+  auto ints = [](const int64_t* v, int64_t cnt) {
+    std::string s;
+    for (int64_t i = 0; i < cnt; ++i) put_varint(s, (uint64_t)v[i]);
+    return s;
+  };
+  for (int64_t r = 0; r < n; ++r) {
+    std::string feats, ex;
+    add_feature(feats, "label", 3, ints(label_h + r, 1));
+    add_feature(feats, "i_id", 3, ints(i_id_h + r, 1));
+    add_feature(feats, "i_cate", 3, ints(i_cate_h + r, 1));
+    int64_t len = P;
+    if (!keep_padding) while (len > 0 && hist_i_h[r * P + len - 1] == 0) --len;
+    add_feature(feats, "u_iid_seq", 3, ints(hist_i_h + r * P, len));
+    add_feature(feats, "u_icat_seq", 3, ints(hist_c_h + r * P, len));
+    put_ld(ex, 1, feats);
+    frame_into(out, ex);
+  }
+  if ((int64_t)out.size() > cap || !out_h) return -(int64_t)out.size() - 16;
+  std::memcpy(out_h, out.data(), out.size());
+  return (int64_t)out.size();
+}

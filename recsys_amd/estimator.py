@@ -372,11 +372,11 @@ class Estimator:
                 features, labels = next(it)
             except StopIteration:
                 break
-            features, labels = self._to_device(features), self._to_device(labels)
             if not self.store.built:          # variables are created by the first model_fn call
-                self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                self._call_model_fn(self._to_device(features), self._to_device(labels), ModeKeys.PREDICT)
                 self._maybe_restore()
-            loss = self._train_step(features, labels)
+            # one packed host buffer -> one H2D copy -> the HIP graph's static input
+            loss = self._train_step(PackedBatch(features, labels))
             done += 1
             gs = self.global_step if (done % cfg.log_step_count_steps == 0 or
                                       (cfg.save_checkpoints_steps and done % cfg.save_checkpoints_steps == 0)) else None

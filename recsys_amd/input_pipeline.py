@@ -1,0 +1,187 @@
+"""Input pipeline: the reference's `input_fn` (fm/fm.py:106-112, deepfm/deepfm.py:60-70, xdeepfm/xdeepfm.py:101-118,
+dcn/dcn.py:106-112, din/din.py:61-80) on top of librsx.so's multi-threaded TFRecord / Example ingest.
+
+Order of transformations is the reference's:
+    TFRecordDataset(files) -> map(parse) -> batch(bs) -> [shuffle(buffer of BATCHES)] -> prefetch -> repeat(epochs)
+i.e. shuffling permutes whole batches inside a sliding window and the final partial batch of an epoch is kept.
+The host half of `input_layer` (FarmHash % bucket, bucketize(log(x+shift))) runs inside the C++ parse, so the
+pipeline yields `features = {'ids': int32 [B,39], 'cont_log': float32 [B,13]}` and `labels` float32 [B,1].
+"""
+import ctypes as C
+import queue
+import threading
+
+import numpy as np
+
+from ._lib import RsxError, check, lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def read_shard(path, verify_crc=True):
+    """-> (buf uint8, offsets int64 [n], lengths int64 [n]).  Raises RsxError on a corrupt record (TF: DataLossError)."""
+    buf = np.fromfile(path, dtype=np.uint8)
+    L = lib()
+    n = L.rsx_tfrecord_index_h(_p(buf), buf.size, None, None, 0, 0)
+    if n < 0:
+        raise RsxError("%s: %s" % (path, L.rsx_strerror(int(n)).decode()))
+    offs, lens = np.empty(n, np.int64), np.empty(n, np.int64)
+    n2 = L.rsx_tfrecord_index_h(_p(buf), buf.size, _p(offs), _p(lens), n, int(verify_crc))
+    if n2 < 0:
+        raise RsxError("%s: %s" % (path, L.rsx_strerror(int(n2)).decode()))
+    return buf, offs, lens
+
+
+class _CriteoParser:
+    def __init__(self, layout, threads):
+        self.F = layout.F
+        self.threads = int(threads)
+        self.slot_src = np.array([int(c.key[2:]) for c in layout.columns], np.int32)
+        self.slot_rows = np.array([c.rows for c in layout.columns], np.int32)
+        bnd, off = [], [0]
+        for c in layout.columns:
+            bnd += list(c.boundaries or [])
+            off.append(len(bnd))
+        self.bnd = np.array(bnd if bnd else [0.0], np.float32)
+        self.bnd_off = np.array(off, np.int32)
+        shift = np.ones(13, np.float32)
+        for c in layout.columns:
+            if c.boundaries is not None:
+                shift[int(c.key[2:]) - 1] = c.log_shift
+        self.shift = shift
+
+    def __call__(self, buf, offs, lens):
+        n = len(offs)
+        label = np.empty((n, 1), np.float32)
+        cont = np.empty((n, 13), np.float32)
+        ids = np.empty((n, self.F), np.int32)
+        check(lib().rsx_criteo_parse_h(_p(buf), _p(offs), _p(lens), n, _p(self.slot_src), _p(self.slot_rows), _p(self.bnd),
+                                       _p(self.bnd_off), _p(self.shift), self.F, _p(label), _p(cont), _p(ids), self.threads),
+              "rsx_criteo_parse_h")
+        return {"ids": ids, "cont_log": cont}, label
+
+
+def _batched(parse, filenames, batch_size, num_epochs, chunk_records=65536):
+    """map(parse) -> batch: record streams of consecutive files are concatenated before batching, like TFRecordDataset."""
+    epoch = 0
+    while num_epochs < 0 or epoch < num_epochs:
+        carry_f, carry_l = None, None
+        for path in filenames:
+            buf, offs, lens = read_shard(path)
+            for s in range(0, len(offs), chunk_records):
+                feats, lab = parse(buf, offs[s:s + chunk_records], lens[s:s + chunk_records])
+                if carry_l is not None:
+                    feats = {k: np.concatenate([carry_f[k], v]) for k, v in feats.items()}
+                    lab = np.concatenate([carry_l, lab])
+                n = lab.shape[0]
+                full = (n // batch_size) * batch_size
+                for b in range(0, full, batch_size):
+                    yield {k: v[b:b + batch_size] for k, v in feats.items()}, lab[b:b + batch_size]
+                carry_f = {k: v[full:] for k, v in feats.items()} if full < n else None
+                carry_l = lab[full:] if full < n else None
+        if carry_l is not None and carry_l.shape[0]:
+            yield carry_f, carry_l                      # the final partial batch is kept
+        epoch += 1
+
+
+def _shuffled(it, buffer_size, seed):
+    """tf.data shuffle(buffer_size) applied AFTER batch: a sliding window of whole batches."""
+    rng = np.random.default_rng(seed)
+    buf = []
+    for x in it:
+        if len(buf) < buffer_size:
+            buf.append(x)
+            continue
+        i = int(rng.integers(0, buffer_size))
+        out, buf[i] = buf[i], x
+        yield out
+    rng.shuffle(buf)
+    yield from buf
+
+
+def _prefetched(it, depth):
+    q = queue.Queue(maxsize=max(1, depth))
+    end = object()
+
+    def work():
+        try:
+            for x in it:
+                q.put(x)
+            q.put(end)
+        except BaseException as e:  # surfaced in the consumer
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        x = q.get()
+        if x is end:
+            return
+        if isinstance(x, BaseException):
+            raise x
+        yield x
+
+
+def criteo_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None,
+                    shuffle_buffer=1000, prefetch=16, seed=0):
+    """fm/fm.py:106-112.  Returns an iterator of (features, labels)."""
+    if layout is None:
+        from .feature_columns import CriteoLayout, build_feature_columns
+        layout = CriteoLayout.from_columns(build_feature_columns(16)[1])
+    it = _batched(_CriteoParser(layout, num_parallel), list(filenames), batch_size, num_epochs)
+    if need_shuffle:
+        it = _shuffled(it, shuffle_buffer, seed)
+    return _prefetched(it, prefetch)
+
+
+def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=6, hist_len=100,
+                 shuffle_buffer=1000, prefetch=16, seed=0):
+    """din/din.py:61-80: features {'i_id','i_cate' int64 [B]; 'u_iid_seq','u_icat_seq' int64 [B,P]}, labels int64 [B]."""
+    P = int(hist_len)
+
+    def parse(buf, offs, lens):
+        n = len(offs)
+        lab, iid, icat = (np.empty(n, np.int64) for _ in range(3))
+        hi, hc = np.empty((n, P), np.int64), np.empty((n, P), np.int64)
+        check(lib().rsx_din_parse_h(_p(buf), _p(offs), _p(lens), n, P, _p(lab), _p(iid), _p(icat), _p(hi), _p(hc),
+                                    int(num_parallel)), "rsx_din_parse_h")
+        return {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab
+
+    it = _batched(parse, list(filenames), batch_size, num_epochs)
+    if need_shuffle:
+        it = _shuffled(it, shuffle_buffer, seed)
+    return _prefetched(it, prefetch)
+
+
+# ---- synthetic shard writers (the reference's sample shard is a missing blob) ------------
+def write_criteo_shard(path, label, cont, cat):
+    """label [n] f32, cont [n,13] f32, cat: n lists of 26 bytes values ('NULL' entries are omitted on disk)."""
+    from .synthetic import pack_cat
+    label = np.ascontiguousarray(label, np.float32).reshape(-1)
+    cont = np.ascontiguousarray(cont, np.float32)
+    buf, offs = pack_cat(cat)
+    L = lib()
+    need = L.rsx_criteo_encode_h(_p(label), _p(cont), _p(buf), _p(offs), len(label), None, 0)
+    cap = -int(need)
+    out = np.empty(cap, np.uint8)
+    n = L.rsx_criteo_encode_h(_p(label), _p(cont), _p(buf), _p(offs), len(label), _p(out), cap)
+    if n < 0:
+        raise RsxError("rsx_criteo_encode_h failed (%d)" % n)
+    out[:n].tofile(path)
+    return int(n)
+
+
+def write_din_shard(path, batch, keep_padding=False):
+    lab, iid, icat = (np.ascontiguousarray(batch[k], np.int64) for k in ("label", "i_id", "i_cate"))
+    hi, hc = np.ascontiguousarray(batch["u_iid_seq"], np.int64), np.ascontiguousarray(batch["u_icat_seq"], np.int64)
+    L = lib()
+    n_ex, P = hi.shape
+    need = L.rsx_din_encode_h(_p(lab), _p(iid), _p(icat), _p(hi), _p(hc), n_ex, P, int(keep_padding), None, 0)
+    cap = -int(need)
+    out = np.empty(cap, np.uint8)
+    n = L.rsx_din_encode_h(_p(lab), _p(iid), _p(icat), _p(hi), _p(hc), n_ex, P, int(keep_padding), _p(out), cap)
+    if n < 0:
+        raise RsxError("rsx_din_encode_h failed (%d)" % n)
+    out[:n].tofile(path)
+    return int(n)
