@@ -125,7 +125,7 @@ def make_params(FLAGS):
 
 
 def main(argv=None):
-    run_main(model_fn, define_flags().parse_args(argv), make_params)
+    return run_main(model_fn, define_flags().parse_args(argv), make_params)
 
 
 if __name__ == "__main__":

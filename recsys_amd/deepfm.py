@@ -195,7 +195,7 @@ def run_main(model_fn, FLAGS, make_params_fn):
 
 
 def main(argv=None):
-    run_main(model_fn, define_flags().parse_args(argv), make_params)
+    return run_main(model_fn, define_flags().parse_args(argv), make_params)
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@ def model_fn(features, labels, mode, params):
 
 
 def main(argv=None):
-    run_main(model_fn, define_flags().parse_args(argv), make_params)
+    return run_main(model_fn, define_flags().parse_args(argv), make_params)
 
 
 if __name__ == "__main__":

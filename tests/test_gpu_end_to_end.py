@@ -16,9 +16,8 @@ def _make_shards(d, n_files=4, per_file=700, seed=0):
     rng = np.random.default_rng(seed)
     for k in range(n_files):
         label, cont, cat = synthetic.criteo_raw_batch(rng, per_file)
-        # learnable signal: the label depends on one categorical and one numeric feature
-        key = np.array([int(c[0][-1:], 16) if c[0] != b"NULL" else 0 for c in cat])
-        label = ((key % 2 == 0) ^ (cont[:, 0] > 8)).astype(np.float32)
+        # learnable, generalisable signal: the label follows the bucket of _c1 (10 % label noise)
+        label = ((cont[:, 0] > 8) ^ (rng.random(per_file) < 0.1)).astype(np.float32)
         write_criteo_shard(os.path.join(d, "part-r-%05d" % k), label, cont, cat)
 
 
@@ -33,7 +32,7 @@ def test_script_main_train_eval_predict_resume(tmp_path, mod):
               "--save_checkpoints_steps", "8", "--log_steps", "4", "--dropout", "0.1", "--learning_rate", "0.01"]
     res = m.main(common + ["--task_type", "train", "--num_epochs", "6"])
     assert res is not None and np.isfinite(res["loss"])
-    assert res["AUC"] > 0.6, res                                   # it learns the planted signal
+    assert res["AUC"] > (0.6 if mod == "fm" else 0.75), res                                  # it learns the planted signal
     ck = sorted(glob.glob(model_dir + "/model.ckpt-*.pt"))
     assert 1 <= len(ck) <= 5                                       # keep_checkpoint_max = 5
     step_after_train = res["global_step"]
