@@ -178,6 +178,23 @@ int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, const float*
                   int B, int dim, int L, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DIN: attention-weighted masked history sum din/din.py:118-124 and the generic
+ * sparse-row segment builder for tables whose entry count exceeds one LDS tile (din/din.py:96-105 lookups).
+ * K in {4, 8, 16, 32, 64}.
+ * ------------------------------------------------------------------------------------------- */
+/* out[b,:] = sum_p H[b,p,:] * w[b,p] * (ids[b,p] > 0)      H [B,P,K] gathered rows, w [B,P], ids int32 [B,P]      */
+int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K,
+                     rsx_stream_t stream);
+/* dH[b,p,:] (+)= dout[b,:] * w[b,p] * mask ;  dw[b,p] = <H[b,p,:], dout[b,:]> * mask                              */
+int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH, float* dw,
+                     int accumulate, int B, int P, int K, rsx_stream_t stream);
+/* Sorted row keys (stable sort done by the caller) -> uniq_row[U], seg_off[U+1], nuniq[0] = U and the row -> j slot
+ * map (previous call's entries cleared first): the same workspace contract as rsx_field_sort with F = 1, so
+ * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.       */
+int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* uniq_row, int32_t* seg_off, int32_t* nuniq,
+                        int32_t* slot, rsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.
  * ------------------------------------------------------------------------------------------- */
 /* FarmHash Fingerprint64 of n byte strings (concatenated in bytes_h, offs_h[n+1]); replaces the hash

@@ -189,7 +189,7 @@ class VariableStore:
     def state_dict(self):
         sd = {"opt_state": self.opt.state.cpu(), "dense": {k: getattr(self.dense, k).cpu() for k in ("flat", "m", "v")}}
         for name, a in self.embeddings.items():
-            sd["emb." + name] = {k: getattr(a, k).cpu() for k in ("tables", "m_t", "v_t", "w1", "m_w", "v_w")
+            sd["emb." + name] = {k: getattr(a, k).cpu() for k in ("tables", "m_t", "v_t", "w1", "m_w", "v_w", "table", "m", "v")
                                  if getattr(a, k, None) is not None}
         return sd
 

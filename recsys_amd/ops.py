@@ -376,3 +376,106 @@ class CrossFn(torch.autograd.Function):
         dW, dB, dX = torch.empty_like(W), torch.empty_like(Bc), torch.empty_like(x0)
         ctx.op.backward(x0.contiguous(), W, Bc, dW, dB, dX, False, dxL=g.contiguous())
         return dX, dW, dB, None
+
+
+class SparseTable:
+    """One embedding variable looked up with tf.nn.embedding_lookup / tf.gather several times per step
+    (din/din.py:88-105): table[R,K] + Adam slots + the sorted-segment workspace for up to `capacity` entries.
+    Lookups register their (ids, grad) pairs during backward; `finalize()` concatenates them in registration
+    order, sorts by row (stable, so duplicate rows are summed in entry order like TF's
+    _apply_sparse_duplicate_indices), builds the segments and the summed gradient G, which the non-lazy TF-1
+    Adam kind pulls through `slot`.  The sort itself is a library radix sort (torch.sort); everything else
+    is librsx.so kernels."""
+
+    def __init__(self, rows, K, capacity, device="cuda", table=None):
+        dev = _require_cuda(device)
+        self.R, self.K, self.cap = int(rows), int(K), int(capacity)
+        self.table = torch.zeros(self.R, self.K, device=dev) if table is None else \
+            torch.as_tensor(table, dtype=torch.float32).to(dev).contiguous()
+        self.m = torch.zeros_like(self.table)
+        self.v = torch.zeros_like(self.table)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.row_off = torch.zeros(2, **i32)
+        self.row_off[1] = self.R
+        self.uniq_row = torch.zeros(self.cap, **i32)
+        self.seg_off = torch.zeros(self.cap + 1, **i32)
+        self.nuniq = torch.zeros(1, **i32)
+        self.slot = torch.full((self.R + 4,), -1, **i32)
+        self.G = torch.zeros(self.cap, self.K, device=dev)
+        self.hook = torch.zeros((), device=dev, requires_grad=True)
+        self.pending = []
+        self._seq = 0
+
+    def gather(self, ids):
+        """ids: int32 tensor of any shape -> rows [*ids.shape, K] (no autograd)."""
+        flat = ids.reshape(-1, 1).contiguous()
+        out = torch.empty(flat.shape[0], self.K, device=self.table.device)
+        check(lib().rsx_gather_fm_fwd(_ptr(self.table), None, _ptr(self.row_off), _ptr(flat), _ptr(out), None, None, None,
+                                      0, flat.shape[0], 1, self.K, _stream()), "rsx_gather_fm_fwd")
+        return out.view(*ids.shape, self.K)
+
+    def lookup(self, ids):
+        return _LookupFn.apply(self.hook, self, ids)
+
+    def finalize(self, dp=None):
+        """Dedup + ordered segment-sum of everything registered since the last call (forward lookup order, which is
+        the order TF concatenates the IndexedSlices of one variable in).  dp: all-gather the entries first."""
+        if not self.pending:
+            return
+        self.pending.sort(key=lambda t: t[0])
+        ids = torch.cat([i.reshape(-1) for _, i, _ in self.pending])
+        vals = torch.cat([g.reshape(-1, self.K) for _, _, g in self.pending]).contiguous()
+        self.pending, self._seq = [], 0
+        if dp is not None:
+            ids, vals = dp.all_gather_rows(ids), dp.all_gather_rows(vals)
+        N = ids.shape[0]
+        assert N <= self.cap, "SparseTable capacity %d < %d entries" % (self.cap, N)
+        skeys, perm = torch.sort(ids, stable=True)
+        perm = perm.to(torch.int32)
+        check(lib().rsx_sorted_segments(_ptr(skeys), N, _ptr(self.uniq_row), _ptr(self.seg_off), _ptr(self.nuniq),
+                                        _ptr(self.slot), _stream()), "rsx_sorted_segments")
+        check(lib().rsx_segsum_bwd(None, None, _ptr(vals), None, None, _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row),
+                                   _ptr(self.nuniq), _ptr(self.G), None, 0, N, 1, self.K, self.cap, _stream()),
+              "rsx_segsum_bwd")
+        self._keep = (skeys, perm, vals)
+
+    def adam_segments(self, lazy=False):
+        if lazy:
+            raise _lib.RsxError("lazy_rows is not implemented for SparseTable (DIN); use adam_mode='tf1_dense'")
+        return [dict(kind=_lib.RSX_ADAM_TABLE_TF1, d=self.K, n=self.R, var=self.table, m=self.m, v=self.v, g=self.G,
+                     slot=self.slot)]
+
+
+class _LookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hook, tbl, ids):
+        ctx.tbl, ctx.ids, ctx.seq = tbl, ids, tbl._seq
+        tbl._seq += 1
+        return tbl.gather(ids)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.tbl.pending.append((ctx.seq, ctx.ids, g.contiguous()))
+        return None, None, None
+
+
+class DinPoolFn(torch.autograd.Function):
+    """sum_p H[b,p,:] * w[b,p] * (ids > 0)   (din/din.py:118-124)."""
+
+    @staticmethod
+    def forward(ctx, H, w, ids):
+        B, P, K = H.shape
+        H, w = H.contiguous(), w.contiguous()
+        out = torch.empty(B, K, device=H.device)
+        check(lib().rsx_din_pool_fwd(_ptr(H), _ptr(w), _ptr(ids), _ptr(out), B, P, K, _stream()), "rsx_din_pool_fwd")
+        ctx.save_for_backward(H, w, ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, w, ids = ctx.saved_tensors
+        B, P, K = H.shape
+        dH, dw = torch.empty_like(H), torch.empty_like(w)
+        check(lib().rsx_din_pool_bwd(_ptr(H), _ptr(w), _ptr(ids), _ptr(g.contiguous()), _ptr(dH), _ptr(dw), 0, B, P, K,
+                                     _stream()), "rsx_din_pool_bwd")
+        return dH, dw, None
