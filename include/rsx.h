@@ -195,6 +195,18 @@ int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* uniq_row, in
                         int32_t* slot, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * xDeepFM CIN layer, xdeepfm/xdeepfm.py:145-172, fp32 MFMA.  D must be 16, H <= 128.
+ *   out[b,n,d] = relu( sum_{f,h} X0[b,f,d] * Xk[b,h,d] * W[f*H+h, n] + c[n] )     (f major, h minor: Appendix A-13)
+ * ------------------------------------------------------------------------------------------- */
+int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const float* c, float* out, int B, int F,
+                      int H, int N, int D, rsx_stream_t stream);
+/* dout = gradient wrt `out` (the relu mask is taken from `out`).  Writes dW[F*H,N], dc[N]; dXk[B,H,D] and dX0[B,F,D]
+ * are overwritten or accumulated (acc_* != 0).  When Xk aliases X0 (first layer) pass distinct dXk / dX0 buffers.   */
+int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout, float* dXk,
+                      int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, int B, int F, int H, int N, int D,
+                      rsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.
  * ------------------------------------------------------------------------------------------- */
 /* FarmHash Fingerprint64 of n byte strings (concatenated in bytes_h, offs_h[n+1]); replaces the hash

@@ -1,0 +1,328 @@
+// xDeepFM Compressed Interaction Network layer on gfx950 (fp32 MFMA), forward and backward.
+// Reference call site: xdeepfm/xdeepfm.py:145-172 -- Z[b,d,f*H+h] = X0[b,f,d]*Xk[b,h,d] (split + batched matmul +
+// reshape + transpose), X^{k+1}[b,n,d] = relu(sum_j Z[b,d,j] W[j,n] + c[n]) (1x1 conv1d).  SURVEY.md 8a row a-8:
+// the only genuinely GEMM-shaped op of the path (M = B*D rows, K = F*H, N outputs; 6.8 GFLOP fwd at [128,128], B=256).
+//
+// Formulation used here (never materialises Z, 25-82 MB in TF): with m = (b, d)
+//     pre[m, n] = sum_f X0[m, f] * T_f[m, n],   T_f = Xk[m, :] . W_f[:, n]        (W_f = rows f*H .. f*H+H-1 of W)
+// i.e. a grouped GEMM whose A operand (Xk) is shared by all F groups and whose per-group results are row-scaled by
+// X0[:, f].  Because D = 16, the 16 rows of one MFMA tile are exactly the 16 embedding dims of ONE example, so
+// A[i=d][k=h] = Xk[b][h][d] is a unit-stride 64 B read and the output tile out[b][n0..n0+15][0..15] is one contiguous
+// 1 KiB store.  fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32, an exact fmaf chain) keeps the 1e-5 parity bar;
+// a bf16 path is a later-round item.
+//   cin_fwd_k     wave = (2 examples) x (16 outputs); Xk, X0 tiles of the examples staged in LDS
+//   cin_bwd_dx_k  workgroup = (2 examples) x all H-tiles; U_f = dpre . W_f^T, dXk += X0_f * U_f, dX0_f = <Xk, U_f>
+//   cin_bwd_dw_k  wave = (3 fields) x (16 h) x (16 n); dW = Z^T . dpre with Z generated on load; ones-row -> dc
+// All reductions are in fixed order: deterministic, no atomics.
+#include "rsx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 cin_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+constexpr int CIN_D = 16;
+constexpr int CIN_BT = 2;   // examples per wave (independent accumulator chains hide the 40-cycle MFMA latency)
+
+// ----------------------------------------------------------------------------------------------- forward
+struct CinFwdArgs {
+  const float* X0;   // [B, F, 16]
+  const float* Xk;   // [B, H, 16]
+  const float* W;    // [F*H, N]
+  const float* c;    // [N]
+  float* out;        // [B, N, 16]
+  int B, F, H, N;
+};
+
+// grid = (ceil(N/16), ceil(B/2)), block = 64.  dyn LDS: 2 * (H + F) * 16 floats.
+__global__ __launch_bounds__(64) void cin_fwd_k(const CinFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sXk = lds;                              // [BT][H*16]
+  float* sX0 = lds + CIN_BT * p.H * CIN_D;       // [BT][F*16]
+  const int lane = threadIdx.x;
+  const int b0 = blockIdx.y * CIN_BT;
+  for (int bt = 0; bt < CIN_BT; ++bt) {
+    const int b = b0 + bt;
+    for (int e = lane; e < p.H * 4; e += 64)
+      reinterpret_cast<float4*>(sXk + bt * p.H * CIN_D)[e] =
+          b < p.B ? reinterpret_cast<const float4*>(p.Xk + (size_t)b * p.H * CIN_D)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = lane; e < p.F * 4; e += 64)
+      reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e] =
+          b < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)b * p.F * CIN_D)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int i = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.x * 16 + i;             // B-operand column
+  const bool nok = n < p.N;
+  const int hs = (p.H + 3) >> 2;
+  f32x4 acc[CIN_BT];
+#pragma unroll
+  for (int bt = 0; bt < CIN_BT; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < p.F; ++f) {
+    f32x4 T[CIN_BT];
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt) T[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* Wf = p.W + (size_t)f * p.H * p.N + n;
+#pragma unroll 4
+    for (int s = 0; s < hs; ++s) {
+      const int h = 4 * s + kq;
+      const bool hok = h < p.H;
+      const float bw = (hok && nok) ? Wf[(size_t)h * p.N] : 0.f;
+#pragma unroll
+      for (int bt = 0; bt < CIN_BT; ++bt) {
+        const float a = hok ? sXk[bt * p.H * CIN_D + h * CIN_D + i] : 0.f;
+        T[bt] = cin_mfma(a, bw, T[bt]);
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt) {
+      const float4 x = *reinterpret_cast<const float4*>(sX0 + bt * p.F * CIN_D + f * CIN_D + kq * 4);  // rows d = 4*kq + r
+      acc[bt][0] += x.x * T[bt][0];
+      acc[bt][1] += x.y * T[bt][1];
+      acc[bt][2] += x.z * T[bt][2];
+      acc[bt][3] += x.w * T[bt][3];
+    }
+  }
+  if (nok) {
+    const float cv = p.c[n];
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt) {
+      const int b = b0 + bt;
+      if (b < p.B) {
+        float4 o;
+        o.x = fmaxf(acc[bt][0] + cv, 0.f);
+        o.y = fmaxf(acc[bt][1] + cv, 0.f);
+        o.z = fmaxf(acc[bt][2] + cv, 0.f);
+        o.w = fmaxf(acc[bt][3] + cv, 0.f);
+        *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n) * CIN_D + kq * 4) = o;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- backward: dXk, dX0
+struct CinBwdDxArgs {
+  const float* X0;    // [B, F, 16]
+  const float* Xk;    // [B, H, 16]
+  const float* W;     // [F*H, N]
+  const float* out;   // [B, N, 16] this layer's relu output
+  const float* dout;  // [B, N, 16] gradient wrt the relu output
+  float* dXk;         // [B, H, 16]
+  float* dX0;         // [B, F, 16]
+  int acc_dxk, acc_dx0;
+  int B, F, H, N;
+};
+
+// grid = ceil(B/2), block = 64 * ceil(H/16) (one wave per 16-wide h tile, <= 8 waves).
+// dyn LDS: 2*(N + F + H)*16 + HT*2*F*16 floats.
+__global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HT = blockDim.x >> 6;
+  float* sDp = lds;                                  // [BT][N*16] dpre
+  float* sX0 = sDp + CIN_BT * p.N * CIN_D;           // [BT][F*16]
+  float* sXk = sX0 + CIN_BT * p.F * CIN_D;           // [BT][H*16]
+  float* sP = sXk + CIN_BT * p.H * CIN_D;            // [HT][BT][F*16] dX0 partials
+  const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6;
+  const int b0 = blockIdx.x * CIN_BT;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int bt = 0; bt < CIN_BT; ++bt) {
+    const int b = b0 + bt;
+    for (int e = tid; e < p.N * 4; e += blockDim.x) {
+      float4 v = z4;
+      if (b < p.B) {
+        const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)b * p.N * CIN_D)[e];
+        const float4 g = reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CIN_D)[e];
+        v = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+      }
+      reinterpret_cast<float4*>(sDp + bt * p.N * CIN_D)[e] = v;
+    }
+    for (int e = tid; e < p.F * 4; e += blockDim.x)
+      reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e] =
+          b < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)b * p.F * CIN_D)[e] : z4;
+    for (int e = tid; e < p.H * 4; e += blockDim.x)
+      reinterpret_cast<float4*>(sXk + bt * p.H * CIN_D)[e] =
+          b < p.B ? reinterpret_cast<const float4*>(p.Xk + (size_t)b * p.H * CIN_D)[e] : z4;
+  }
+  __syncthreads();
+  const int i = lane & 15, kq = lane >> 4;
+  const int h = ht * 16 + i;                // B-operand column = h
+  const bool hok = h < p.H;
+  const int ns = (p.N + 15) >> 4;
+  f32x4 dxk[CIN_BT];
+  float4 xkv[CIN_BT];                       // Xk[bt][h][d = 4*kq .. +3] for the <Xk, U_f> dot
+#pragma unroll
+  for (int bt = 0; bt < CIN_BT; ++bt) {
+    dxk[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    xkv[bt] = hok ? *reinterpret_cast<const float4*>(sXk + bt * p.H * CIN_D + h * CIN_D + kq * 4) : z4;
+  }
+  for (int f = 0; f < p.F; ++f) {
+    f32x4 U[CIN_BT];
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt) U[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* Wr = p.W + ((size_t)f * p.H + (hok ? h : 0)) * p.N;
+#pragma unroll 2
+    for (int s = 0; s < ns; ++s) {
+      const int nn = 16 * s + 4 * kq;
+      float bw[4] = {0.f, 0.f, 0.f, 0.f};
+      if (hok) {
+        if (nn + 3 < p.N && (p.N & 3) == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(Wr + nn);
+          bw[0] = t.x; bw[1] = t.y; bw[2] = t.z; bw[3] = t.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bw[t] = nn + t < p.N ? Wr[nn + t] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = nn + t;
+#pragma unroll
+        for (int bt = 0; bt < CIN_BT; ++bt) {
+          const float a = n < p.N ? sDp[bt * p.N * CIN_D + n * CIN_D + i] : 0.f;
+          U[bt] = cin_mfma(a, bw[t], U[bt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt) {
+      const float4 x = *reinterpret_cast<const float4*>(sX0 + bt * p.F * CIN_D + f * CIN_D + kq * 4);
+      dxk[bt][0] += x.x * U[bt][0];
+      dxk[bt][1] += x.y * U[bt][1];
+      dxk[bt][2] += x.z * U[bt][2];
+      dxk[bt][3] += x.w * U[bt][3];
+      // dX0[bt][f][d] partial over this wave's 16 h: sum over the 16 column lanes of U * Xk
+      float q0 = U[bt][0] * xkv[bt].x, q1 = U[bt][1] * xkv[bt].y, q2 = U[bt][2] * xkv[bt].z, q3 = U[bt][3] * xkv[bt].w;
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        q0 += __shfl_xor(q0, m); q1 += __shfl_xor(q1, m); q2 += __shfl_xor(q2, m); q3 += __shfl_xor(q3, m);
+      }
+      if (i == 0) *reinterpret_cast<float4*>(sP + ((ht * CIN_BT + bt) * p.F + f) * CIN_D + kq * 4) = make_float4(q0, q1, q2, q3);
+    }
+  }
+  if (hok) {
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt) {
+      const int b = b0 + bt;
+      if (b < p.B) {
+        float4* dst = reinterpret_cast<float4*>(p.dXk + ((size_t)b * p.H + h) * CIN_D + kq * 4);
+        float4 o = make_float4(dxk[bt][0], dxk[bt][1], dxk[bt][2], dxk[bt][3]);
+        if (p.acc_dxk) o = f4_add(*dst, o);
+        *dst = o;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < CIN_BT * p.F * 4; e += blockDim.x) {   // sum the HT partials in wave order
+    const int bt = e / (p.F * 4), r = e - bt * p.F * 4;
+    const int b = b0 + bt;
+    if (b >= p.B) continue;
+    float4 s = z4;
+    for (int w = 0; w < HT; ++w) s = f4_add(s, reinterpret_cast<const float4*>(sP + (w * CIN_BT + bt) * p.F * CIN_D)[r]);
+    float4* dst = reinterpret_cast<float4*>(p.dX0 + (size_t)b * p.F * CIN_D) + r;
+    if (p.acc_dx0) s = f4_add(*dst, s);
+    *dst = s;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- backward: dW, dc
+struct CinBwdDwArgs {
+  const float* X0; const float* Xk; const float* out; const float* dout;
+  float* dW;   // [F*H, N]
+  float* dc;   // [N]
+  int B, F, H, N, FG;   // FG = ceil(F/3) field groups
+};
+constexpr int CIN_FT = 3;   // fields per wave
+
+// grid = (ceil(N/16), ceil(H/16), FG), block = 64.  Reduction over all m = (b, d): one example per k-step group.
+__global__ __launch_bounds__(64) void cin_bwd_dw_k(const CinBwdDwArgs p) {
+  const int lane = threadIdx.x;
+  const int i = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.x * 16 + i;        // B-operand column
+  const int h = blockIdx.y * 16 + i;        // A-operand row (within each field)
+  const int f0 = blockIdx.z * CIN_FT;
+  const bool nok = n < p.N, hok = h < p.H;
+  const bool want_dc = blockIdx.y == 0 && blockIdx.z == 0;
+  f32x4 acc[CIN_FT], accc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < CIN_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float one = i == 0 ? 1.f : 0.f;
+#pragma unroll 2
+  for (int b = 0; b < p.B; ++b) {
+    float4 dp = z4, xk = z4, x0[CIN_FT];
+    if (nok) {
+      const float4 o = *reinterpret_cast<const float4*>(p.out + ((size_t)b * p.N + n) * CIN_D + kq * 4);
+      const float4 g = *reinterpret_cast<const float4*>(p.dout + ((size_t)b * p.N + n) * CIN_D + kq * 4);
+      dp = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    }
+    if (hok) xk = *reinterpret_cast<const float4*>(p.Xk + ((size_t)b * p.H + h) * CIN_D + kq * 4);
+#pragma unroll
+    for (int t = 0; t < CIN_FT; ++t)
+      x0[t] = f0 + t < p.F ? *reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f0 + t) * CIN_D + kq * 4) : z4;
+#pragma unroll
+    for (int t = 0; t < CIN_FT; ++t) {
+      acc[t] = cin_mfma(x0[t].x * xk.x, dp.x, acc[t]);
+      acc[t] = cin_mfma(x0[t].y * xk.y, dp.y, acc[t]);
+      acc[t] = cin_mfma(x0[t].z * xk.z, dp.z, acc[t]);
+      acc[t] = cin_mfma(x0[t].w * xk.w, dp.w, acc[t]);
+    }
+    if (want_dc) {   // ones-row: row 0 of this tile accumulates sum_m dpre[m, n]
+      accc = cin_mfma(one, dp.x, accc);
+      accc = cin_mfma(one, dp.y, accc);
+      accc = cin_mfma(one, dp.z, accc);
+      accc = cin_mfma(one, dp.w, accc);
+    }
+  }
+  // C layout: col = lane & 15 (n), row = 4*kq + r (h within the tile)
+  if (nok) {
+#pragma unroll
+    for (int t = 0; t < CIN_FT; ++t) {
+      if (f0 + t < p.F) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hr = blockIdx.y * 16 + kq * 4 + r;
+          if (hr < p.H) p.dW[((size_t)(f0 + t) * p.H + hr) * p.N + n] = acc[t][r];
+        }
+      }
+    }
+    if (want_dc && kq == 0) p.dc[n] = accc[0];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- C ABI
+extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const float* c, float* out, int B,
+                                 int F, int H, int N, int D, rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!X0 || !Xk || !W || !c || !out) return RSX_EINVAL;
+  if (D != CIN_D) return RSX_EUNSUPPORTED;
+  const size_t lds = (size_t)CIN_BT * (H + F) * CIN_D * sizeof(float);
+  if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
+  CinFwdArgs p{X0, Xk, W, c, out, B, F, H, N};
+  hipLaunchKernelGGL(cin_fwd_k, dim3((N + 15) / 16, (B + CIN_BT - 1) / CIN_BT), dim3(64), lds, rsx_s(stream), p);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout,
+                                 float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, int B, int F,
+                                 int H, int N, int D, rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc) return RSX_EINVAL;
+  if (D != CIN_D || H > 128) return RSX_EUNSUPPORTED;
+  const int HT = (H + 15) / 16;
+  const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D) * sizeof(float);
+  if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
+  if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return RSX_ELAUNCH;
+  }
+  CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, acc_dxk, acc_dx0, B, F, H, N};
+  hipLaunchKernelGGL(cin_bwd_dx_k, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
+  RSX_CHECK_LAUNCH();
+  CinBwdDwArgs w{X0, Xk, out, dout, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT};
+  hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG), dim3(64), 0, rsx_s(stream), w);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}

@@ -479,3 +479,30 @@ class DinPoolFn(torch.autograd.Function):
         check(lib().rsx_din_pool_bwd(_ptr(H), _ptr(w), _ptr(ids), _ptr(g.contiguous()), _ptr(dH), _ptr(dw), 0, B, P, K,
                                      _stream()), "rsx_din_pool_bwd")
         return dH, dw, None
+
+
+class CinLayerFn(torch.autograd.Function):
+    """One CIN layer (csrc/cin.hip): out[b,n,d] = relu(sum_{f,h} X0[b,f,d] Xk[b,h,d] W[f*H+h,n] + c[n]).
+    xdeepfm/xdeepfm.py:145-172."""
+
+    @staticmethod
+    def forward(ctx, X0, Xk, W, c):
+        B, F, D = X0.shape
+        H, N = Xk.shape[1], W.shape[1]
+        X0, Xk = X0.contiguous(), Xk.contiguous()
+        out = torch.empty(B, N, D, device=X0.device)
+        check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(c), _ptr(out), B, F, H, N, D, _stream()),
+              "rsx_cin_layer_fwd")
+        ctx.save_for_backward(X0, Xk, W, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X0, Xk, W, out = ctx.saved_tensors
+        B, F, D = X0.shape
+        H, N = Xk.shape[1], W.shape[1]
+        dX0, dXk = torch.empty_like(X0), torch.empty_like(Xk)
+        dW, dc = torch.empty_like(W), torch.empty(N, device=W.device)
+        check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(out), _ptr(g.contiguous()), _ptr(dXk), 0, _ptr(dX0),
+                                      0, _ptr(dW), _ptr(dc), B, F, H, N, D, _stream()), "rsx_cin_layer_bwd")
+        return dX0, dXk, dW, dc

@@ -56,7 +56,9 @@ def test_sparse_table_segments_and_ordered_sums():
         assert np.array_equal(np.flatnonzero(slot >= 0), uniq) and np.array_equal(slot[uniq], np.arange(U))
         cnt = np.bincount(np.searchsorted(uniq, rows), minlength=U)
         Gg = tbl.G.cpu().numpy()[:U]
-        assert np.array_equal(Gg[cnt <= 16], G[cnt <= 16])          # entry-order sums: bit-exact for short segments
+        # entry-order sums: bit-exact up to 64/(K/4) = 8 entries (one entry per lane group); longer segments are
+        # summed as ordered sub-range partials (deterministic, fp32-tolerance vs the sequential order)
+        assert np.array_equal(Gg[cnt <= 8], G[cnt <= 8])
         np.testing.assert_allclose(Gg, G, rtol=2e-5, atol=1e-6)
 
 
