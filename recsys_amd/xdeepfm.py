@@ -1,0 +1,166 @@
+"""xDeepFM on the Criteo 39-field pipeline -- MI355X-native mirror of `xdeepfm/xdeepfm.py`
+(model_fn :123-233, build_feature_columns :44-94, flags :12-34; BASELINE config 3: CIN [128,128]).
+
+logits = dense([linear_y, cin_y, dnn_y], 1) (:194-195) with
+  linear_y = relu(dense([13 log-values | 26 one-hot blocks], 1))                    (:127,131)
+  cin_y    = relu(dense(sum_d concat_k X^k, 1)), X^{k+1} = CIN layer(X^0, X^k)      (:135-182, csrc/cin.hip)
+  dnn_y    = relu(dense(tower(E_dnn), 1)) over a SECOND, independent embedding set  (:185-192)
+"""
+import torch
+
+from . import layers as L
+from .deepfm import define_flags as _deepfm_flags
+from .deepfm import input_fn, run_main  # noqa: F401
+from .estimator import EstimatorSpec, ModeKeys, get_variable_store
+from .feature_columns import CriteoLayout, build_feature_columns
+from .ops import CinLayerFn, EmbeddingArena, FusedTower
+
+
+def build_variables(store, params, capacity):
+    layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
+    D = params["embedding_size"]
+    F = layout.F
+    cin = list(map(int, params["cross_layers"].split(",")))
+    layers = list(map(int, params["deep_layers"].split(",")))
+    if store.dp is not None:
+        capacity *= store.dp.world
+    cat_keys = {c.key for c in params["linear_feature_columns"] if c.kind == "hash_indicator"}
+    a1 = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=True, w1_field_mask=layout.field_mask(cat_keys))
+    a2 = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=False)
+    n_lin = 13 + sum(c.rows for c in params["linear_feature_columns"] if c.kind == "hash_indicator")
+    with torch.no_grad():
+        for a in (a1, a2):
+            t = torch.empty(a.R, D)
+            L.trunc_normal_(t, 1.0 / D ** 0.5, store.gen)
+            a.tables.copy_(t)
+        w = torch.empty(a1.R)
+        L.glorot_uniform_(w, n_lin, 1, store.gen)
+        a1.w1.copy_(w)
+    shapes, init = {}, {}
+    zeros = lambda t, g: t.zero_()
+    ones = lambda t, g: t.fill_(1.0)
+    shapes["lin.wnum"], init["lin.wnum"] = (13,), lambda t, g: L.glorot_uniform_(t, n_lin, 1, g)
+    shapes["lin.b"], init["lin.b"] = (1,), zeros
+    H = F
+    for k, n in enumerate(cin):
+        # tf.get_variable without initializer -> glorot-uniform over [1, F*H, N] (A-7)
+        shapes[f"cin.W{k}"], init[f"cin.W{k}"] = (F * H, n), lambda t, g, fi=F * H, fo=n: L.glorot_uniform_(t, fi, fo, g)
+        shapes[f"cin.c{k}"], init[f"cin.c{k}"] = (n,), zeros
+        H = n
+    tot = sum(cin)
+    shapes["cin.Wout"], init["cin.Wout"] = (tot, 1), lambda t, g: L.glorot_uniform_(t, tot, 1, g)
+    shapes["cin.bout"], init["cin.bout"] = (1,), zeros
+    d = F * D
+    for i, n in enumerate(layers):
+        shapes[f"dnn.W{i}"], shapes[f"dnn.b{i}"] = (d, n), (n,)
+        init[f"dnn.W{i}"] = lambda t, g, fi=d, fo=n: L.glorot_uniform_(t, fi, fo, g)
+        init[f"dnn.b{i}"] = zeros
+        shapes[f"dnn.gamma{i}"], init[f"dnn.gamma{i}"] = (n,), ones
+        shapes[f"dnn.beta{i}"], init[f"dnn.beta{i}"] = (n,), zeros
+        d = n
+    shapes["dnn.Wout"], shapes["dnn.bout"] = (d, 1), (1,)
+    init["dnn.Wout"] = lambda t, g, fi=d: L.glorot_uniform_(t, fi, 1, g)
+    init["dnn.bout"] = zeros
+    shapes["out.W"], shapes["out.b"] = (3, 1), (1,)
+    init["out.W"] = lambda t, g: L.glorot_uniform_(t, 3, 1, g)
+    init["out.b"] = zeros
+    store.build({"input_layer": a1, "input_layer_1": a2}, shapes, init, params["learning_rate"])
+    store.layout = layout
+    store.cin_sizes = cin
+    store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
+
+
+def _cin(X0, P, sizes):
+    """'cin_net' (:135-182): every layer's full map is both the next hidden state and a direct output."""
+    outs, Xk = [], X0
+    for k in range(len(sizes)):
+        Xk = CinLayerFn.apply(X0, Xk, P[f"cin.W{k}"], P[f"cin.c{k}"])
+        outs.append(Xk)
+    res = torch.cat(outs, 1).sum(-1)                                        # (:180-181)
+    return L.dense(res, P["cin.Wout"], P["cin.bout"], relu=True)            # cin_y [B,1] (:182)
+
+
+def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
+    dp, P = store.dp, store.dense
+    B = ids.shape[0]
+    with torch.no_grad():
+        store.sort_ids_for_backward(a1, ids)
+        store.sort_ids_for_backward(a2, ids)
+        E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
+        lin_pre = torch.addmv(y1cat, logx, P["lin.wnum"])                   # + 13 numeric log-values (:127)
+        E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
+    X0 = E1.view(B, a1.F, a1.D).requires_grad_()
+    cin_y = _cin(X0, P, store.cin_sizes)
+    with torch.no_grad():
+        loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
+            E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
+            s0=lin_pre, c0="lin.b", s1=cin_y.detach().reshape(-1), replicas=dp.world if dp is not None else 1, masks=masks)
+    cin_y.backward(g_cin.reshape(B, 1))                                     # CIN backward -> X0.grad, cin.* grads
+    with torch.no_grad():
+        P["lin.wnum"].grad.copy_(logx.t() @ g_lin)
+    dX1 = X0.grad.reshape(B, -1)
+
+    def train_op():
+        with torch.no_grad():
+            if dp is not None:
+                d1, _, g1, _ = dp.gather_example_grads(dX1, None, g_lin, None)
+                a1.segsum(d1.shape[0], None, d1, g1, None)
+                d2, _, _, _ = dp.gather_example_grads(dX2)
+                a2.segsum(d2.shape[0], None, d2, None, None)
+                dp.all_reduce_sum(store.dense.grad)
+            else:
+                a1.segsum(B, None, dX1.contiguous(), g_lin, None)
+                a2.segsum(B, None, dX2, None, None)
+            store.apply_gradients()
+
+    return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
+
+
+def model_fn(features, labels, mode, params):
+    """xdeepfm/xdeepfm.py:123-233.  features: 'ids' int32 [B,39], 'cont_log' float32 [B,13] (log(x+shift) of _c1.._c13)."""
+    store = get_variable_store()
+    ids, logx = features["ids"], features["cont_log"]
+    if not store.built:
+        build_variables(store, params, capacity=max(int(params.get("max_batch_size", 0)), ids.shape[0]))
+    a1, a2, P = store.embeddings["input_layer"], store.embeddings["input_layer_1"], store.dense
+    masks = params.get("_dropout_masks")
+    if mode == ModeKeys.TRAIN:
+        return _train_fused(store, a1, a2, ids, logx, labels, params, masks)
+    B = ids.shape[0]
+    n_layers = len(params["deep_layers"].split(","))
+    E1, _, y1cat, _ = a1.gather(ids, first_order=True)
+    linear_y = torch.relu(torch.addmv(y1cat, logx, P["lin.wnum"]) + P["lin.b"])                 # (:131)
+    cin_y = _cin(E1.view(B, a1.F, a1.D), P, store.cin_sizes)
+    E2, _, _, _ = a2.gather(ids)
+    dnn_net = L.tower(E2, P, "dnn", n_layers, False, params["dropout"])
+    dnn_y = L.dense(dnn_net, P["dnn.Wout"], P["dnn.bout"], relu=True)                          # (:192)
+    logits = L.dense(torch.cat([linear_y[:, None], cin_y, dnn_y], -1), P["out.W"], P["out.b"])  # (:194-195) [B,1]
+    pred = torch.sigmoid(logits)
+    predictions = {"prob": pred}
+    if mode == ModeKeys.PREDICT:
+        return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+    loss = L.sigmoid_ce_mean(logits, labels)
+    return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
+
+
+def define_flags():
+    p = _deepfm_flags()
+    p.add_argument("--cross_layers", default="20,10,10")       # xdeepfm/xdeepfm.py:19 (BASELINE config 3 uses 128,128)
+    p.add_argument("--eval_steps", type=int, default=200)
+    p.set_defaults(num_epochs=5, eval_parts=10, log_steps=50, save_checkpoints_steps=2000)
+    return p
+
+
+def make_params(FLAGS):
+    lin, emb = build_feature_columns(FLAGS.embedding_size, "numeric+indicator")
+    return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
+            "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
+            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size}
+
+
+def main(argv=None):
+    return run_main(model_fn, define_flags().parse_args(argv), make_params)
+
+
+if __name__ == "__main__":
+    main()

@@ -50,3 +50,94 @@ def test_cin_first_layer_aliasing_x0():
     out = CinLayerFn.apply(tx, tx, torch.from_numpy(W).cuda(), torch.from_numpy(c).cuda())
     out.backward(torch.from_numpy(g).cuda())
     np.testing.assert_allclose(tx.grad.cpu().numpy(), d0 + dk, rtol=1e-4, atol=1e-4)
+
+
+def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False):
+    from recsys_amd import xdeepfm
+    from recsys_amd.estimator import ModeKeys
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    from tests.parity_util import make_estimator
+    rng = np.random.default_rng(seed)
+    lin, emb = build_feature_columns(16, "numeric+indicator")
+    lay = CriteoLayout.from_columns(emb)
+    row_off = criteo.row_offsets()
+    cat_slot, cat_off = init.xdeepfm_layout()
+    P = init.xdeepfm_params(seed, 16, layers, cin, np.float32, row_off)
+    for k in ("lin.b", "cin.bout", "dnn.bout"):
+        P[k] += np.float32(0.05)
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+              "dropout": dropout, "deep_layers": ",".join(map(str, layers)), "cross_layers": ",".join(map(str, cin)),
+              "max_batch_size": B}
+    est = make_estimator(xdeepfm.model_fn, params, use_graph=use_graph)
+    batches = []
+    for _ in range(steps):
+        ids = synth_ids(rng, B, row_off)
+        logx = np.log(np.floor(np.exp(rng.normal(2, 1, (B, 13)))) + 1.0).astype(np.float32)
+        batches.append((ids, logx, rng.integers(0, 2, B).astype(np.float32)))
+
+    def feats(ids, logx):
+        return {"ids": torch.from_numpy(ids).cuda(), "cont_log": torch.from_numpy(logx).cuda()}
+
+    est._call_model_fn(feats(*batches[0][:2]), None, ModeKeys.PREDICT)
+    st = est.store
+    w1 = np.zeros(int(row_off[-1]), np.float32)                     # oracle lin.wcat -> arena w1 (slot-order rows)
+    for j in range(26):
+        s = int(cat_slot[j])
+        w1[row_off[s]:row_off[s + 1]] = P["lin.wcat"][cat_off[j]:cat_off[j + 1]]
+    with torch.no_grad():
+        st.embeddings["input_layer"].tables.copy_(torch.from_numpy(P["tables"]))
+        st.embeddings["input_layer"].w1.copy_(torch.from_numpy(w1))
+        st.embeddings["input_layer_1"].tables.copy_(torch.from_numpy(P["tables2"]))
+    st.dense.load({k: v for k, v in P.items() if k in st.dense.params})
+    # The CIN contraction sums ~F*H products per output; two fp32 implementations with different summation orders
+    # (numpy einsum vs the MFMA k-order) differ by a few 1e-5 on the logits, so the reference here is the fp64 oracle.
+    P = {k: v.astype(np.float64) for k, v in P.items()}
+    om = models.XDeepFM(P, row_off, cat_slot, cat_off, cin, len(layers), dropout)
+    opt = nn.AdamTF1(dtype=np.float64)
+    err, losses = 0.0, []
+    for ids, logx, y in batches:
+        mk = None
+        if dropout > 0:
+            mk = [(rng.random((B, n)) >= dropout).astype(np.float32) for n in layers]
+            est.params["_dropout_masks"] = [torch.from_numpy(m).cuda() for m in mk]
+        f = feats(ids, logx)
+        with torch.no_grad():
+            pg = est._call_model_fn(f, None, ModeKeys.PREDICT).predictions["prob"].cpu().numpy().reshape(-1)
+        po = nn.sigmoid(om.forward(ids, logx.astype(np.float64), train=False))
+        err = max(err, float(np.abs(pg - po).max()))
+        lg = float(est._train_step(f, torch.from_numpy(y).cuda()))
+        lo, _ = models.train_step(om, opt, (ids, logx.astype(np.float64)), y.astype(np.float64),
+                                  {"masks": [m.astype(np.float64) for m in mk]} if mk else None)
+        losses.append((lg, float(lo)))
+    a1 = st.embeddings["input_layer"]
+    w1g = a1.w1.cpu().numpy()
+    wcat = np.concatenate([w1g[row_off[int(cat_slot[j])]:row_off[int(cat_slot[j]) + 1]] for j in range(26)])
+    perr = {"tables": float(np.abs(a1.tables.cpu().numpy() - P["tables"]).max()),
+            "tables2": float(np.abs(st.embeddings["input_layer_1"].tables.cpu().numpy() - P["tables2"]).max()),
+            "lin.wcat": float(np.abs(wcat - P["lin.wcat"]).max())}
+    for k, p in st.dense.params.items():
+        perr[k] = float(np.abs(p.detach().cpu().numpy() - P[k].reshape(p.shape)).max())
+    return err, losses, perr
+
+
+@pytest.mark.parametrize("cin,dropout,B", [((8, 4), 0.0, 16), ((20, 10, 10), 0.5, 24)])
+def test_xdeepfm_train_parity(cin, dropout, B):
+    err, losses, perr = _xdeepfm_run(B=B, steps=3, seed=21, cin=cin, layers=(32, 16), dropout=dropout)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+def test_xdeepfm_train_parity_config3():
+    """BASELINE config 3: xdeepfm.py Criteo d=16, CIN [128,128], DNN 100-100 (batch reduced for the numpy oracle)."""
+    err, losses, perr = _xdeepfm_run(B=64, steps=2, seed=22, cin=(128, 128), layers=(100, 100), dropout=0.5)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 2e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+def test_xdeepfm_hip_graph():
+    err, losses, perr = _xdeepfm_run(B=32, steps=5, seed=23, cin=(16, 16), layers=(32, 16), dropout=0.0, use_graph=True)
+    assert err < 1e-5 and max(perr.values()) < 5e-5, (err, perr)
