@@ -168,6 +168,9 @@ def main():
                 "frac": round(ach / 8000.0, 4), "traffic": None, "alg_bytes_per_launch": alg_bytes,
                 "launch_ms": round(adam_ms, 5)}
 
+    if dp is not None:
+        dp.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     N = max(world, 1) if dp is not None else 1

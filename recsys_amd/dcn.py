@@ -59,7 +59,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
     nh = store.tower.widths[-1]
     oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
     with torch.no_grad():
-        store.sort_ids_for_backward(arena, ids)
+        if dp is None:
+            store.sort_ids_for_backward(arena, ids)
         x0, _, _, _ = arena.gather(ids)
         _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
         loss, prob, dX, gz, _ = store.tower.train_step(
@@ -72,7 +73,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
     def train_op():
         with torch.no_grad():
             if dp is not None:
-                dXg, _, _, _ = dp.gather_example_grads(dX)
+                dXg, _, _, _, idsg = dp.gather_example_grads(dX, ids=ids)
+                arena.field_sort(idsg)
                 arena.segsum(dXg.shape[0], None, dXg, None, None)
                 dp.all_reduce_sum(store.dense.grad)
             else:

@@ -110,7 +110,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
     with torch.no_grad():
         # The ids-only sort could run on a side stream, but inside a HIP graph the fork/join across HW queues costs
         # ~10 us each way on this stack (profiles/r01_*), more than the 9 us it hides: keep it in-stream.
-        store.sort_ids_for_backward(arena, ids, overlap=bool(params.get("overlap_sort", False)))
+        if dp is None:
+            store.sort_ids_for_backward(arena, ids, overlap=bool(params.get("overlap_sort", False)))
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
@@ -120,8 +121,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
     def train_op():
         with torch.no_grad():
             store.join_sort()
-            if dp is not None:
-                dXg, Sg, gy1g, gy2g = dp.gather_example_grads(dX, S, gy1, gy2)
+            if dp is not None:      # ONE packed all-gather (grad block + ids), then the global sort + segment-sum
+                dXg, Sg, gy1g, gy2g, idsg = dp.gather_example_grads(dX, S, gy1, gy2, ids=ids)
+                arena.field_sort(idsg)
                 arena.segsum(dXg.shape[0], Sg, dXg, gy1g, gy2g)
                 dp.all_reduce_sum(store.dense.grad)
             else:

@@ -84,8 +84,9 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     dp, P = store.dp, store.dense
     B = ids.shape[0]
     with torch.no_grad():
-        store.sort_ids_for_backward(a1, ids)
-        store.sort_ids_for_backward(a2, ids)
+        if dp is None:
+            store.sort_ids_for_backward(a1, ids)
+            store.sort_ids_for_backward(a2, ids)
         E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
         lin_pre = torch.addmv(y1cat, logx, P["lin.wnum"])                   # + 13 numeric log-values (:127)
         E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
@@ -103,10 +104,13 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     def train_op():
         with torch.no_grad():
             if dp is not None:
-                d1, _, g1, _ = dp.gather_example_grads(dX1, None, g_lin, None)
-                a1.segsum(d1.shape[0], None, d1, g1, None)
-                d2, _, _, _ = dp.gather_example_grads(dX2)
-                a2.segsum(d2.shape[0], None, d2, None, None)
+                both = torch.cat([dX1, dX2], 1)          # both table sets' gradients + ids in ONE all-gather
+                dg, _, g1, _, idsg = dp.gather_example_grads(both, None, g_lin, None, ids=ids)
+                w = dX1.shape[1]
+                a1.field_sort(idsg)
+                a2.field_sort(idsg)
+                a1.segsum(dg.shape[0], None, dg[:, :w].contiguous(), g1, None)
+                a2.segsum(dg.shape[0], None, dg[:, w:].contiguous(), None, None)
                 dp.all_reduce_sum(store.dense.grad)
             else:
                 a1.segsum(B, None, dX1.contiguous(), g_lin, None)

@@ -42,7 +42,8 @@ def load_oracle_weights(est, P):
 
 
 def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100), adam_mode="tf1_dense",
-                      use_graph=False, return_all=False, tower="hip", dropout=0.0, kind="deepfm", cross_layers=3):
+                      use_graph=False, return_all=False, tower="hip", dropout=0.0, kind="deepfm", cross_layers=3,
+                      data_parallel=False):
     """Train `steps` steps of `kind` in {deepfm, fm, dcn} on both sides from identical weights and batches (injected
     dropout masks).  Returns max |prob_gpu - prob_oracle| over all steps (and losses / final parameter errors)."""
     import torch
@@ -71,6 +72,10 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
               "learning_rate": 1e-3, "dropout": dropout, "deep_layers": ",".join(map(str, layers)), "max_batch_size": B,
               "tower": tower, "cross_layers": cross_layers}
     est = make_estimator(mfn, params, adam_mode, use_graph)
+    if data_parallel:        # world_size-1 RCCL: exercises the collective code path; results must not change
+        from recsys_amd import dist as rdist
+        rdist.init_process_group("nccl")
+        est.store.dp = est.dist = rdist.DataParallel()
     batches = [(synth_ids(rng, B, row_off), rng.integers(0, 2, B).astype(np.float32)) for _ in range(steps)]
     ids0 = torch.from_numpy(batches[0][0]).cuda()
     est._call_model_fn({"ids": ids0}, None, ModeKeys.PREDICT)        # creates the variables

@@ -50,6 +50,10 @@ def _worker(rank, world, port, out_dir):
     gy2 = (dz / world)[:, None] @ P["out.W"].T
     dX = np.zeros((b, F * D))
     gy1 = gy2[:, 0] * (y1 > 0)
+    dXg, Sg, gy1g, gy2g, ids_pk = dp.gather_example_grads(
+        torch.from_numpy(dX.astype(np.float32)), torch.from_numpy(S.astype(np.float32)), torch.from_numpy(gy1.astype(np.float32)),
+        torch.from_numpy(np.ascontiguousarray(gy2[:, 1]).astype(np.float32)), ids=torch.from_numpy(ids_g[sl]))
+    assert np.array_equal(ids_pk.numpy(), ids_g)                     # int32 ids survive the float32 bit-cast ride
     dXg, Sg, gy1g, gy2g = dp.gather_example_grads(torch.from_numpy(dX), torch.from_numpy(S), torch.from_numpy(gy1),
                                                   torch.from_numpy(np.ascontiguousarray(gy2[:, 1])))
     names = sorted(g)

@@ -1,0 +1,32 @@
+"""Data-parallel code path on ONE GPU (world_size 1 over RCCL): the all-gather / all-reduce plumbing, the global sort +
+segment-sum on gathered blocks and HIP-graph capture of the collectives.  With one replica the numbers must equal
+the single-process run, i.e. stay within the oracle tolerance.  (N > 1 is covered by tests/test_dist_gloo.py on CPU.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+from tests.parity_util import deepfm_parity_run
+for kind, graph in (("deepfm", False), ("deepfm", True), ("dcn", False)):
+    err, losses, perr = deepfm_parity_run(B=64, steps=5, seed=31, rows=(3, 7, 40, 11, 600), layers=(32, 16), return_all=True,
+                                          kind=kind, dropout=0.5, use_graph=graph, data_parallel=True)
+    assert err < 1e-5, (kind, err)
+    assert all(abs(a - b) < 1e-5 for a, b in losses), (kind, losses)
+    assert max(perr.values()) < 5e-5, (kind, perr)
+import torch.distributed as dist
+dist.destroy_process_group()
+print("DP_OK")
+""" % ROOT
+
+
+def test_dp_world1_rccl_matches_oracle():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
