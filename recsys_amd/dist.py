@@ -70,8 +70,9 @@ class DataParallel:
     def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None):
         """Packs the per-example gradient block, all-gathers it once, and returns the global views
         dX_g [N*b, F*D], S_g [N*b, D]|None, gy1_g [N*b]|None, gy2_g [N*b]|None (contiguous).
-        ids (int32 [b,F], optional) ride in the same block bit-cast to float32 -> a 5th return value ids_g [N*b,F]:
-        one collective per step instead of two."""
+        ids (int32 [b,F], optional) ride in the same block -> a 5th return value ids_g [N*b,F]: one collective per
+        step instead of two.  The block travels as int32 BITS (floats bit-cast to int32, never the reverse): small
+        integer ids viewed as fp32 are subnormals, which float copy kernels may flush to zero."""
         b = dX.shape[0]
         parts = [dX]
         if gy2 is not None:
@@ -79,9 +80,13 @@ class DataParallel:
         if gy1 is not None:
             parts += [gy1.reshape(b, 1)]
         if ids is not None:
-            parts += [ids.contiguous().view(torch.float32)]
-        pack = torch.cat(parts, 1) if len(parts) > 1 else dX
-        g = self.all_gather_rows(pack)
+            parts = [p.contiguous().view(torch.int32) for p in parts] + [ids.contiguous()]
+            g = self.all_gather_rows(torch.cat(parts, 1))
+            gi = g
+            g = g.view(torch.float32)
+        else:
+            pack = torch.cat(parts, 1) if len(parts) > 1 else dX
+            g = self.all_gather_rows(pack)
         o = dX.shape[1]
         dX_g = g[:, :o].contiguous()
         S_g = gy2_g = gy1_g = None
@@ -94,7 +99,7 @@ class DataParallel:
             gy1_g = g[:, o].contiguous()
             o += 1
         if ids is not None:
-            return dX_g, S_g, gy1_g, gy2_g, g[:, o:o + ids.shape[1]].contiguous().view(torch.int32)
+            return dX_g, S_g, gy1_g, gy2_g, gi[:, o:o + ids.shape[1]].contiguous()
         return dX_g, S_g, gy1_g, gy2_g
 
     # -- dense gradients ------------------------------------------------------------------------
