@@ -36,6 +36,9 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_seconds", type=float, default=12.0)
     p.add_argument("--n_batches", type=int, default=64)
+    p.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm", "din"],
+                   help="deepfm = the BASELINE metric's config (configs[1]); the others are the remaining BASELINE configs "
+                        "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
     p.add_argument("--steps_per_graph", type=int, default=8, help="training steps captured per HIP graph (1: per-step "
                    "graph fed by one D2D copy of the batch)")
     return p.parse_args()
@@ -95,20 +98,32 @@ def main():
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
 
+    from recsys_amd import dcn, din, fm, xdeepfm
+    from recsys_amd.estimator import PackedBatch
     B = a.batch_size
-    lin, emb = build_feature_columns(16)
-    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16,
-              "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B}
+    if a.model != "deepfm" and a.batch_size == 256:
+        B = {"dcn": 4096, "din": 1024}.get(a.model, 256)
+    linear = {"deepfm": "indicator_all", "fm": "indicator_all", "dcn": "numeric", "xdeepfm": "numeric+indicator"}.get(a.model)
+    lin, emb = build_feature_columns(16, linear) if linear else (None, None)
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if a.model == "din" else 16,
+              "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
+              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(a.model)}
+    mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[a.model]
     cfg = RunConfig(use_hip_graph=not a.no_graph, adam_mode=a.adam_mode, device=str(dev), seed=1234)
-    est = Estimator(deepfm.model_fn, None, params, cfg)
+    est = Estimator(mfn, None, params, cfg)
     if dp is not None:
         est.store.dp = dp
         est.dist = dp
-    layout = CriteoLayout.from_columns(emb)
-    host = synthetic.criteo_id_batches(layout, a.n_batches, B, seed=synthetic.SEED + rank)
-    from recsys_amd.estimator import PackedBatch
-    # one packed HBM-resident buffer per batch (ids + labels): a step = 1 D2D copy into the graph input + 1 replay
-    feats = [PackedBatch({"ids": i}, y, device=dev) for i, y, _ in host]
+    layout = CriteoLayout.from_columns(emb) if emb else None
+    if a.model == "din":
+        rng = np.random.default_rng(synthetic.SEED + rank)
+        raw = [synthetic.din_batch(rng, B) for _ in range(a.n_batches)]
+        host = None
+        feats = [PackedBatch({k: v for k, v in b.items() if k != "label"}, b["label"], device=dev) for b in raw]
+    else:
+        host = synthetic.criteo_id_batches(layout, a.n_batches, B, seed=synthetic.SEED + rank)
+        # one packed HBM-resident buffer per batch (ids [+ log-values] + labels): no per-step input copy
+        feats = [PackedBatch({"ids": i, "cont_log": c} if a.model == "xdeepfm" else {"ids": i}, y, device=dev) for i, y, c in host]
     # variables are created on the first call; then W untimed warm-up steps (includes graph capture)
     with torch.no_grad():
         est._call_model_fn(feats[0].views()[0], None, "infer")
@@ -143,18 +158,18 @@ def main():
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
     store = est.store
-    arena = store.embeddings["input_layer"]
     segs = store.adam_segments()
     n_dense = store.dense.n
-    alg_bytes = 24 * (arena.R * arena.D + arena.R) + 32 * n_dense if a.adam_mode == "tf1_dense" else None
+    # algorithmic bytes of the TF-faithful sweep: 24 B per table / first-order element (var, m, v read + written),
+    # 32 B per dense element (+ gradient read and zeroed)
+    n_sparse = sum(int(sg["n"]) * int(sg.get("d", 1) or 1) for sg in segs if sg["kind"] in (1, 2))
+    alg_bytes = 24 * n_sparse + 32 * n_dense if a.adam_mode == "tf1_dense" else None
     reps = 200
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    f, y = feats[0].views()
     adam_ms = 0.0
     for r in range(reps):
-        # a real step's state: fresh sort + sparse grads, then time only the optimizer launch
-        store.sort_ids_for_backward(arena, f["ids"])
+        # the step's own state (slot map + sparse grads of the last batch) is live; time only the optimizer launch
         e0.record()
         store.opt.step(segs)
         e1.record()
@@ -177,12 +192,16 @@ def main():
     out = {"metric": "examples/sec", "value": round(N * B * a.steps / dt, 1), "unit": "examples/sec", "n_gpus": a.gpus,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "deepfm.py Criteo-39 d=16 DNN 100-100 bs=256/replica, full train step "
+           "config": {"workload": "%s.py %s bs=%d/replica, full train step "
                                   "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, steps_per_graph=%d"
-                                  % (a.adam_mode, not a.no_graph, a.steps_per_graph),
+                                  % (a.model, {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16",
+                                               "dcn": "Criteo-39 d=16 3 cross layers DNN 100-100",
+                                               "xdeepfm": "Criteo-39 d=16 CIN 128,128 DNN 100-100",
+                                               "din": "Amazon-Electronics-shaped hist_len=100 K=32"}[a.model], B,
+                                     a.adam_mode, not a.no_graph, a.steps_per_graph),
                       "global_batch": N * B, "parallelism": "dp%d" % N, "final_loss": round(final_loss, 5)},
            "roofline": roof}
-    if N == 1 and not a.no_cpu_baseline:
+    if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":
         out["cpu_baseline"] = cpu_baseline(host, layout, a.cpu_seconds)
     print(json.dumps(out), flush=True)
 

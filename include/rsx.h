@@ -136,6 +136,9 @@ int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* state, float
  *   bstat_l double[RT,2,N_l] partial (sum dy, sum dy*xhat).
  * K_l % 4 == 0; head width N <= 256.
  * ------------------------------------------------------------------------------------------- */
+/* Batches > 512: every statistics buffer (fstat_l, bstat_l) must be folded by this call between its producer and its
+ * consumer (row 0 then holds the column totals and consumers read one row); a no-op for B <= 512.               */
+int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_t stream);
 /* a_out = relu(in' . W + bias); in' = in for the first layer (fstat_prev == NULL), else
  * dropout(BN(in)) with the previous layer's statistics reduced from fstat_prev (bn_prev_out receives them). */
 int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out, double* fstat_out,
@@ -193,6 +196,11 @@ int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const f
  * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.       */
 int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* uniq_row, int32_t* seg_off, int32_t* nuniq,
                         int32_t* slot, rsx_stream_t stream);
+/* Ordered segment-sum of generic per-entry row gradients vals[N,K] (the F = 1 case of rsx_segsum_bwd).  null_row >= 0
+ * names a padding row whose entries carry exactly-zero gradients by construction (DIN history padding id 0,
+ * din/din.py:107): its segment is not walked and G = 0 is written for it; -1 = no such row.                        */
+int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                    const int32_t* nuniq, float* G, int N, int K, int stride, int null_row, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * xDeepFM CIN layer, xdeepfm/xdeepfm.py:145-172, fp32 MFMA.  D must be 16, H <= 128.

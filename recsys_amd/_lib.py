@@ -31,6 +31,7 @@ _SIGS = {
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
     "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
     "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P]),
+    "rsx_tower_reduce_partials": (_I, [_P, _I, _I, _P]),
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
@@ -38,6 +39,7 @@ _SIGS = {
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_fwd": (_I, [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
+    "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "rsx_sorted_segments": (_I, [_P, _I, _P, _P, _P, _P, _P]),
     "rsx_cin_layer_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "rsx_cin_layer_bwd": (_I, [_P] * 6 + [_I, _P, _I, _P, _P] + [_I] * 5 + [_P]),

@@ -185,17 +185,27 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
   for (int e = lane; e < nvec * n4; e += 64) dst[e] = acc[e];
 }
 
-// out[j] = sum over workgroup partials in order.  grid = ceil(n/256)
+// out[j] = sum over the RT per-wave partials.  16 threads per output: thread q sums partials q, q+16, ... in order,
+// then the 16 totals are added in ascending q through LDS (fixed order).  grid = ceil(n/16), block = 256.
 __global__ __launch_bounds__(256) void cross_reduce_k(const float* __restrict__ part, int RT, int n, float* __restrict__ dW,
                                                       float* __restrict__ dB, float* __restrict__ dwout, int L, int dim) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ float red[16][16];
+  const int jl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + jl;
   float s = 0.f;
-  for (int r = 0; r < RT; ++r) s += part[(size_t)r * n + j];
-  const int vec = j / dim, e = j - vec * dim;
-  if (vec < L) dW[(size_t)vec * dim + e] = s;
-  else if (vec < 2 * L) dB[(size_t)(vec - L) * dim + e] = s;
-  else if (dwout != nullptr) dwout[e] = s;
+  if (j < n)
+    for (int r = q; r < RT; r += 16) s += part[(size_t)r * n + j];
+  red[q][jl] = s;
+  __syncthreads();
+  if (q == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][jl];
+    const int vec = j / dim, e = j - vec * dim;
+    if (vec < L) dW[(size_t)vec * dim + e] = t;
+    else if (vec < 2 * L) dB[(size_t)(vec - L) * dim + e] = t;
+    else if (dwout != nullptr) dwout[e] = t;
+  }
 }
 
 extern "C" int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, const float* wout, float* s, float* xL,
@@ -234,7 +244,7 @@ extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, c
   hipLaunchKernelGGL(cross_bwd_k, dim3(RT), dim3(64), lds, rsx_s(stream), p, epw);
   RSX_CHECK_LAUNCH();
   const int n = (2 * L + 1) * dim;
-  hipLaunchKernelGGL(cross_reduce_k, dim3((n + 255) / 256), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,
+  hipLaunchKernelGGL(cross_reduce_k, dim3((n + 15) / 16), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,
                      L, dim);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

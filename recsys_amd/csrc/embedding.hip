@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
                                                     const int32_t* __restrict__ uniq_row,
                                                     const int32_t* __restrict__ nuniq, float* __restrict__ G,
                                                     float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
-                                                    int stride) {
+                                                    int stride, int null_row) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   const bool valid = spread ? g == 0 : j < nu;
   const size_t sl = (size_t)f * stride + (valid ? j : j0);
   const int beg = valid ? seg_off[(size_t)f * (stride + 1) + j] : 0;
-  const int end = valid ? seg_off[(size_t)f * (stride + 1) + j + 1] : 0;
+  int end = valid ? seg_off[(size_t)f * (stride + 1) + j + 1] : 0;
+  // null_row: a padding row whose per-entry gradients are exactly zero by construction (DIN history padding id 0,
+  // din/din.py:107): its (possibly huge) segment is not walked, G = 0 is written -- the same value the sum would give
+  if (valid && null_row >= 0 && uniq_row[sl] == null_row) end = beg;
   const int L = end - beg;
   SegCtx<LPR> c;
   c.S4 = reinterpret_cast<const float4*>(S);
@@ -286,9 +289,9 @@ template <int D>
 static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
                           const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                           const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
-                          int F, int stride) {
+                          int F, int stride, int null_row) {
   segsum_bwd_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
-                                          stride);
+                                          stride, null_row);
 }
 
 extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
@@ -332,10 +335,10 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
   return RSX_OK;
 }
 
-extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1,
-                              const float* gy2, const int32_t* perm, const int32_t* seg_off,
-                              const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1,
-                              uint64_t w1_field_mask, int B, int F, int D, int stride, rsx_stream_t stream) {
+static int segsum_impl(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
+                       const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq, float* G,
+                       float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
+                       rsx_stream_t stream) {
   if (!perm || !seg_off || !uniq_row || !nuniq || !G || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D))
     return RSX_EINVAL;
   if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
@@ -345,7 +348,22 @@ extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* 
   const long long waves = (long long)F * ((B + gpw - 1) / gpw);
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                 nuniq, G, gw1, w1_field_mask, B, F, stride);
+                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1,
+                              const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                              const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1,
+                              uint64_t w1_field_mask, int B, int F, int D, int stride, rsx_stream_t stream) {
+  return segsum_impl(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, w1_field_mask, B, F, D, stride, -1,
+                     stream);
+}
+
+extern "C" int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                               const int32_t* nuniq, float* G, int N, int K, int stride, int null_row,
+                               rsx_stream_t stream) {
+  return segsum_impl(nullptr, nullptr, vals, nullptr, nullptr, perm, seg_off, uniq_row, nuniq, G, nullptr, 0, N, 1, K,
+                     stride, null_row, stream);
 }

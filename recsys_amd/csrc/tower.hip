@@ -424,7 +424,7 @@ struct BwdArgs {
   uint32_t seed, layer_prev;
   float rate;
   int has_wo;
-  int B, K, N, RT;
+  int B, K, N, RT, RTh;      // RT: rows of the (possibly pre-reduced) bstat; RTh: row tiles = rows of hpart / dwd_part
   int n_din, n_dw, ct_k, ct_k1, ct_n;
 };
 
@@ -563,12 +563,12 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   if (p.hpart != nullptr) {
     for (int c = tid; c < p.N; c += 256) {
       float s = 0.f;
-      for (int r = 0; r < p.RT; ++r) s += p.dwd_part[(size_t)r * p.N + c];
+      for (int r = 0; r < p.RTh; ++r) s += p.dwd_part[(size_t)r * p.N + c];
       p.dwd[c] = s;
     }
     if (tid < 8) {
       double s = 0.0;
-      for (int r = 0; r < p.RT; ++r) s += p.hpart[(size_t)r * 8 + tid];
+      for (int r = 0; r < p.RTh; ++r) s += p.hpart[(size_t)r * 8 + tid];
       if (tid == 0) p.loss[0] = (float)(s / (double)p.B);
       if (p.has_wo && tid >= 1 && tid <= 3) p.dwo[tid - 1] = (float)s;
       if (p.has_wo && tid == 4) p.dbo[0] = (float)s;
@@ -576,6 +576,37 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       if (tid == 6) p.dbd[0] = (float)s;
     }
   }
+}
+
+// Large batches: fold the RT per-row-tile partials of a statistics buffer into row 0 (fixed order), so that every
+// consumer workgroup reads ONE partial per column instead of RT.  grid = ceil(2N/64), block = 64.
+__global__ __launch_bounds__(64) void tower_reduce_partials_k(double* __restrict__ st, int RT, int N2) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= N2) return;
+  double s = 0.0;
+  int r = 0;
+  for (; r + 8 <= RT; r += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; r < RT; ++r) s += st[(size_t)r * N2 + c];
+  st[c] = s;
+}
+
+// consumers read pre-reduced statistics (1 row) when the batch is large: see rsx_tower_reduce_partials
+static inline int stat_rows(int B) { return B > 512 ? 1 : (B + TM - 1) / TM; }
+
+extern "C" int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_t stream) {
+  if (B < 0 || N <= 0) return RSX_EINVAL;
+  if (B <= 512) return RSX_OK;   // small batches: consumers sum the <= 32 partials themselves
+  if (!stat) return RSX_EINVAL;
+  const int RT = (B + TM - 1) / TM;
+  hipLaunchKernelGGL(tower_reduce_partials_k, dim3((2 * N + 63) / 64), dim3(64), 0, rsx_s(stream), stat, RT, 2 * N);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
 }
 
 // ------------------------------------------------------------------ C ABI ----------------------------
@@ -596,8 +627,8 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   p.bn_prev_out = bn_prev_out;
   p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
   p.rate = dropout_rate;
-  p.B = B; p.K = K; p.N = N; p.RT = (B + TM - 1) / TM;
-  const dim3 grid((N + 15) / 16, p.RT);
+  p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B);
+  const dim3 grid((N + 15) / 16, (B + TM - 1) / TM);
   hipLaunchKernelGGL(tower_fwd_k, grid, dim3(256), ((size_t)2 * K + 1024 + 256) * sizeof(float), rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -625,8 +656,8 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   p.rate = dropout_rate;
   p.loss_scale = loss_scale;
   p.relu0 = relu0; p.relu2 = relu2;
-  p.B = B; p.N = N; p.RT = (B + TM - 1) / TM;
-  hipLaunchKernelGGL(tower_head_k, dim3(p.RT), dim3(256), 0, rsx_s(stream), p);
+  p.B = B; p.N = N; p.RT = stat_rows(B);
+  hipLaunchKernelGGL(tower_head_k, dim3((B + TM - 1) / TM), dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -656,11 +687,11 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
   p.rate = dropout_rate;
   p.has_wo = dwo != nullptr;
-  p.B = B; p.K = K; p.N = N; p.RT = (B + TM - 1) / TM;
+  p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B); p.RTh = (B + TM - 1) / TM;
   p.ct_k = (K + 15) / 16;
   p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;
-  p.n_din = p.ct_k * p.RT;
+  p.n_din = p.ct_k * p.RTh;
   p.n_dw = p.ct_k1 * p.ct_n;
   const int total = p.n_din + p.n_dw + (hpart != nullptr ? 1 : 0);
   hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float),

@@ -26,8 +26,10 @@ def build_variables(store, params, B, P):
     n_item, n_cate = params.get("n_item", N_ITEM), params.get("n_cate", N_CATE)
     world = store.dp.world if store.dp is not None else 1
     cap = (B * (P + 1)) * world
-    item = SparseTable(n_item, K, cap, store.device)
-    cate = SparseTable(n_cate, K, cap, store.device)
+    # id 0 is the history padding (din/din.py:56-57,107): its gradient entries are exactly zero (masked sum), so the
+    # sparse path may skip that one huge segment; direct lookups never use id 0
+    item = SparseTable(n_item, K, cap, store.device, null_row=0)
+    cate = SparseTable(n_cate, K, cap, store.device, null_row=0)
     bias = SparseTable(n_item, 4, B * world, store.device)     # i_item [n_item] stored as column 0 of a 4-wide table
     with torch.no_grad():
         for tbl, rows in ((item, n_item), (cate, n_cate)):

@@ -304,6 +304,7 @@ class FusedTower:
                                         _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
                                         _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
                                         rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_fwd_layer")
+            check(L.rsx_tower_reduce_partials(_ptr(self.fstat[l]), B, self.widths[l], st))      # no-op for B <= 512
         # head parameters: a variable name, or an explicit (tensor, grad_tensor) pair (e.g. a slice of out.W)
         pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
         gv = lambda x: None if x is None else (P[x].grad if isinstance(x, str) else x[1])
@@ -316,6 +317,7 @@ class FusedTower:
                                _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
                                rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, st),
               "rsx_tower_head")
+        check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
         for l in reversed(range(nl)):
             K = self.k0 if l == 0 else self.widths[l - 1]
             last = l == nl - 1
@@ -331,6 +333,8 @@ class FusedTower:
                 _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
                 rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_bwd_layer")
+            if l:
+                check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
 
 
@@ -387,9 +391,10 @@ class SparseTable:
     Adam kind pulls through `slot`.  The sort itself is a library radix sort (torch.sort); everything else
     is librsx.so kernels."""
 
-    def __init__(self, rows, K, capacity, device="cuda", table=None):
+    def __init__(self, rows, K, capacity, device="cuda", table=None, null_row=-1):
         dev = _require_cuda(device)
         self.R, self.K, self.cap = int(rows), int(K), int(capacity)
+        self.null_row = int(null_row)     # padding id whose entries carry exactly-zero gradients (DIN: 0), or -1
         self.table = torch.zeros(self.R, self.K, device=dev) if table is None else \
             torch.as_tensor(table, dtype=torch.float32).to(dev).contiguous()
         self.m = torch.zeros_like(self.table)
@@ -434,9 +439,8 @@ class SparseTable:
         perm = perm.to(torch.int32)
         check(lib().rsx_sorted_segments(_ptr(skeys), N, _ptr(self.uniq_row), _ptr(self.seg_off), _ptr(self.nuniq),
                                         _ptr(self.slot), _stream()), "rsx_sorted_segments")
-        check(lib().rsx_segsum_bwd(None, None, _ptr(vals), None, None, _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row),
-                                   _ptr(self.nuniq), _ptr(self.G), None, 0, N, 1, self.K, self.cap, _stream()),
-              "rsx_segsum_bwd")
+        check(lib().rsx_segsum_rows(_ptr(vals), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq),
+                                    _ptr(self.G), N, self.K, self.cap, self.null_row, _stream()), "rsx_segsum_rows")
         self._keep = (skeys, perm, vals)
 
     def adam_segments(self, lazy=False):

@@ -319,3 +319,15 @@ def test_dcn_train_parity_criteo():
     for lg, lo in losses:
         assert abs(lg - lo) < 2e-5, losses
     assert max(perr.values()) < 5e-5, perr
+
+
+def test_large_batch_tower_and_dcn_parity_bs1024():
+    """B > 512 takes the pre-reduced statistics path (rsx_tower_reduce_partials) and the 16-examples-per-wave cross
+    backward: DeepFM and DCN at batch 1024 on a small layout vs the oracle."""
+    for kind in ("deepfm", "dcn"):
+        err, losses, perr = deepfm_parity_run(B=1024, steps=2, seed=41, rows=(3, 7, 40, 11, 600), D=16, layers=(32, 16),
+                                              return_all=True, dropout=0.5, kind=kind, cross_layers=3)
+        assert err < 1e-5, (kind, err)
+        for lg, lo in losses:
+            assert abs(lg - lo) < 2e-5, (kind, losses)
+        assert max(perr.values()) < 5e-5, (kind, perr)
