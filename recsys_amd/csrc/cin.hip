@@ -33,27 +33,35 @@ struct CinFwdArgs {
   int B, F, H, N;
 };
 
-// grid = (ceil(N/16), ceil(B/2)), block = 64.  dyn LDS: 2 * (H + F) * 16 floats.
+// grid = (ceil(N/16), ceil(B/2)), block = 64.  dyn LDS: 2 * F * 16 floats (X0 tiles).
+// The A operand Xk[b][h][d] does not depend on f: each lane keeps its HS = ceil(H/4) values per example in registers
+// for the whole kernel (HSMAX is the compile-time bound: 10 covers H <= 40, 32 covers H <= 128), so the inner loop is
+// only "8 W loads in flight -> 16 MFMAs".
+template <int HSMAX>
 __global__ __launch_bounds__(64) void cin_fwd_k(const CinFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sXk = lds;                              // [BT][H*16]
-  float* sX0 = lds + CIN_BT * p.H * CIN_D;       // [BT][F*16]
+  float* sX0 = lds;                              // [BT][F*16]
   const int lane = threadIdx.x;
   const int b0 = blockIdx.y * CIN_BT;
   for (int bt = 0; bt < CIN_BT; ++bt) {
     const int b = b0 + bt;
-    for (int e = lane; e < p.H * 4; e += 64)
-      reinterpret_cast<float4*>(sXk + bt * p.H * CIN_D)[e] =
-          b < p.B ? reinterpret_cast<const float4*>(p.Xk + (size_t)b * p.H * CIN_D)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = lane; e < p.F * 4; e += 64)
       reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e] =
           b < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)b * p.F * CIN_D)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
   const int i = lane & 15, kq = lane >> 4;
   const int n = blockIdx.x * 16 + i;             // B-operand column
   const bool nok = n < p.N;
   const int hs = (p.H + 3) >> 2;
+  float areg[CIN_BT][HSMAX];
+#pragma unroll
+  for (int bt = 0; bt < CIN_BT; ++bt)
+#pragma unroll
+    for (int s_ = 0; s_ < HSMAX; ++s_) {
+      const int h = 4 * s_ + kq, b = b0 + bt;
+      areg[bt][s_] = (h < p.H && b < p.B) ? p.Xk[((size_t)b * p.H + h) * CIN_D + i] : 0.f;
+    }
+  __syncthreads();
   f32x4 acc[CIN_BT];
 #pragma unroll
   for (int bt = 0; bt < CIN_BT; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -62,15 +70,22 @@ __global__ __launch_bounds__(64) void cin_fwd_k(const CinFwdArgs p) {
 #pragma unroll
     for (int bt = 0; bt < CIN_BT; ++bt) T[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* Wf = p.W + (size_t)f * p.H * p.N + n;
-#pragma unroll 4
-    for (int s = 0; s < hs; ++s) {
-      const int h = 4 * s + kq;
-      const bool hok = h < p.H;
-      const float bw = (hok && nok) ? Wf[(size_t)h * p.N] : 0.f;
 #pragma unroll
-      for (int bt = 0; bt < CIN_BT; ++bt) {
-        const float a = hok ? sXk[bt * p.H * CIN_D + h * CIN_D + i] : 0.f;
-        T[bt] = cin_mfma(a, bw, T[bt]);
+    for (int s0 = 0; s0 < HSMAX; s0 += 8) {     // 8 k-steps' W loads in flight, then their 16 MFMAs
+      if (s0 < hs) {                            // wave-uniform
+        float bw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int h = 4 * (s0 + u) + kq;
+          bw[u] = (s0 + u < HSMAX && h < p.H && nok) ? Wf[(size_t)h * p.N] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + u < HSMAX) {
+#pragma unroll
+            for (int bt = 0; bt < CIN_BT; ++bt) T[bt] = cin_mfma(areg[bt][s0 + u < HSMAX ? s0 + u : 0], bw[u], T[bt]);
+          }
+        }
       }
     }
 #pragma unroll
@@ -113,7 +128,10 @@ struct CinBwdDxArgs {
 };
 
 // grid = ceil(B/2), block = 64 * ceil(H/16) (one wave per 16-wide h tile, <= 8 waves).
-// dyn LDS: 2*(N + F + H)*16 + HT*2*F*16 floats.
+// dyn LDS: 2*(N + F + H)*16 + HT*2*F*16 floats.  The A operand dpre[b][n][d] does not depend on f: after staging it
+// through LDS (the relu mask is applied once) each lane keeps its 4*NSMAX values per example in registers
+// (NSMAX = 8 covers N <= 128), so the f loop is "4 float4 W loads in flight -> 32 MFMAs".
+template <int NSMAX>
 __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HT = blockDim.x >> 6;
@@ -149,36 +167,55 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   const int ns = (p.N + 15) >> 4;
   f32x4 dxk[CIN_BT];
   float4 xkv[CIN_BT];                       // Xk[bt][h][d = 4*kq .. +3] for the <Xk, U_f> dot
+  float areg[CIN_BT][NSMAX][4];             // dpre[bt][n = 16 s + 4 kq + t][d = i]
 #pragma unroll
   for (int bt = 0; bt < CIN_BT; ++bt) {
     dxk[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     xkv[bt] = hok ? *reinterpret_cast<const float4*>(sXk + bt * p.H * CIN_D + h * CIN_D + kq * 4) : z4;
+#pragma unroll
+    for (int s_ = 0; s_ < NSMAX; ++s_)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = 16 * s_ + 4 * kq + t;
+        areg[bt][s_][t] = n < p.N ? sDp[bt * p.N * CIN_D + n * CIN_D + i] : 0.f;
+      }
   }
+  const bool vec_ok = (p.N & 3) == 0;
   for (int f = 0; f < p.F; ++f) {
     f32x4 U[CIN_BT];
 #pragma unroll
     for (int bt = 0; bt < CIN_BT; ++bt) U[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* Wr = p.W + ((size_t)f * p.H + (hok ? h : 0)) * p.N;
-#pragma unroll 2
-    for (int s = 0; s < ns; ++s) {
-      const int nn = 16 * s + 4 * kq;
-      float bw[4] = {0.f, 0.f, 0.f, 0.f};
-      if (hok) {
-        if (nn + 3 < p.N && (p.N & 3) == 0) {
-          const float4 t = *reinterpret_cast<const float4*>(Wr + nn);
-          bw[0] = t.x; bw[1] = t.y; bw[2] = t.z; bw[3] = t.w;
-        } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bw[t] = nn + t < p.N ? Wr[nn + t] : 0.f;
+    for (int s0 = 0; s0 < NSMAX; s0 += 4) {     // 4 float4 W loads in flight, then their 32 MFMAs
+      if (s0 < ns) {                            // wave-uniform
+        float4 bw4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int nn = 16 * (s0 + u) + 4 * kq;
+          float4 t = z4;
+          if (hok && nn < p.N) {
+            if (vec_ok && nn + 3 < p.N) t = *reinterpret_cast<const float4*>(Wr + nn);
+            else {
+              t.x = Wr[nn];
+              t.y = nn + 1 < p.N ? Wr[nn + 1] : 0.f;
+              t.z = nn + 2 < p.N ? Wr[nn + 2] : 0.f;
+              t.w = nn + 3 < p.N ? Wr[nn + 3] : 0.f;
+            }
+          }
+          bw4[u] = t;
         }
-      }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int n = nn + t;
+        for (int u = 0; u < 4; ++u) {
+          if (s0 + u < NSMAX) {
 #pragma unroll
-        for (int bt = 0; bt < CIN_BT; ++bt) {
-          const float a = n < p.N ? sDp[bt * p.N * CIN_D + n * CIN_D + i] : 0.f;
-          U[bt] = cin_mfma(a, bw[t], U[bt]);
+            for (int bt = 0; bt < CIN_BT; ++bt) {
+              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][0], bw4[u].x, U[bt]);
+              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][1], bw4[u].y, U[bt]);
+              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][2], bw4[u].z, U[bt]);
+              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][3], bw4[u].w, U[bt]);
+            }
+          }
         }
       }
     }
@@ -232,9 +269,12 @@ struct CinBwdDwArgs {
 };
 constexpr int CIN_FT = 3;   // fields per wave
 
-// grid = (ceil(N/16), ceil(H/16), FG), block = 64.  Reduction over all m = (b, d): one example per k-step group.
-__global__ __launch_bounds__(64) void cin_bwd_dw_k(const CinBwdDwArgs p) {
-  const int lane = threadIdx.x;
+// grid = (ceil(N/16), ceil(H/16), FG), block = 256.  Reduction over all m = (b, d): one example per k-step group; the
+// 4 waves of the workgroup take b = w, w+4, ... (4x the waves in flight to hide the operand loads) and their partial
+// tiles are added in wave order through LDS.
+__global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
+  __shared__ float red[4][CIN_FT + 1][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int n = blockIdx.x * 16 + i;        // B-operand column
   const int h = blockIdx.y * 16 + i;        // A-operand row (within each field)
@@ -246,9 +286,11 @@ __global__ __launch_bounds__(64) void cin_bwd_dw_k(const CinBwdDwArgs p) {
   for (int t = 0; t < CIN_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float one = i == 0 ? 1.f : 0.f;
-#pragma unroll 2
-  for (int b = 0; b < p.B; ++b) {
-    float4 dp = z4, xk = z4, x0[CIN_FT];
+  auto load = [&](int b, float4& dp, float4& xk, float4* x0) {
+    dp = z4; xk = z4;
+#pragma unroll
+    for (int t = 0; t < CIN_FT; ++t) x0[t] = z4;
+    if (b >= p.B) return;
     if (nok) {
       const float4 o = *reinterpret_cast<const float4*>(p.out + ((size_t)b * p.N + n) * CIN_D + kq * 4);
       const float4 g = *reinterpret_cast<const float4*>(p.dout + ((size_t)b * p.N + n) * CIN_D + kq * 4);
@@ -257,7 +299,9 @@ __global__ __launch_bounds__(64) void cin_bwd_dw_k(const CinBwdDwArgs p) {
     if (hok) xk = *reinterpret_cast<const float4*>(p.Xk + ((size_t)b * p.H + h) * CIN_D + kq * 4);
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t)
-      x0[t] = f0 + t < p.F ? *reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f0 + t) * CIN_D + kq * 4) : z4;
+      if (f0 + t < p.F) x0[t] = *reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f0 + t) * CIN_D + kq * 4);
+  };
+  auto fma_b = [&](const float4& dp, const float4& xk, const float4* x0) {
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t) {
       acc[t] = cin_mfma(x0[t].x * xk.x, dp.x, acc[t]);
@@ -271,6 +315,40 @@ __global__ __launch_bounds__(64) void cin_bwd_dw_k(const CinBwdDwArgs p) {
       accc = cin_mfma(one, dp.z, accc);
       accc = cin_mfma(one, dp.w, accc);
     }
+  };
+  // software pipeline: the operands of examples b+2, b+3 are loading while b, b+1 feed the matrix pipe
+  float4 dpA, xkA, x0A[CIN_FT], dpB, xkB, x0B[CIN_FT], dpC, xkC, x0C[CIN_FT], dpD, xkD, x0D[CIN_FT];
+  load(wv, dpA, xkA, x0A);
+  load(wv + 4, dpB, xkB, x0B);
+  for (int b = wv; b < p.B; b += 16) {
+    load(b + 8, dpC, xkC, x0C);
+    load(b + 12, dpD, xkD, x0D);
+    fma_b(dpA, xkA, x0A);
+    fma_b(dpB, xkB, x0B);
+    load(b + 16, dpA, xkA, x0A);
+    load(b + 20, dpB, xkB, x0B);
+    fma_b(dpC, xkC, x0C);
+    fma_b(dpD, xkD, x0D);
+  }
+  // per-wave partial tiles -> LDS in C layout order (row = 4*kq + r, col = lane & 15), summed in wave order
+#pragma unroll
+  for (int t = 0; t < CIN_FT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][t][(kq * 4 + r) * 16 + i] = acc[t][r];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wv][CIN_FT][(kq * 4 + r) * 16 + i] = accc[r];
+  __syncthreads();
+  if (wv != 0) return;
+#pragma unroll
+  for (int t = 0; t < CIN_FT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = (kq * 4 + r) * 16 + i;
+      acc[t][r] = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+    }
+  {
+    const int e = i;   // row 0
+    accc[0] = ((red[0][CIN_FT][e] + red[1][CIN_FT][e]) + red[2][CIN_FT][e]) + red[3][CIN_FT][e];
   }
   // C layout: col = lane & 15 (n), row = 4*kq + r (h within the tile)
   if (nok) {
@@ -295,10 +373,13 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !W || !c || !out) return RSX_EINVAL;
   if (D != CIN_D) return RSX_EUNSUPPORTED;
-  const size_t lds = (size_t)CIN_BT * (H + F) * CIN_D * sizeof(float);
+  if (H > 128) return RSX_EUNSUPPORTED;
+  const size_t lds = (size_t)CIN_BT * F * CIN_D * sizeof(float);
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
   CinFwdArgs p{X0, Xk, W, c, out, B, F, H, N};
-  hipLaunchKernelGGL(cin_fwd_k, dim3((N + 15) / 16, (B + CIN_BT - 1) / CIN_BT), dim3(64), lds, rsx_s(stream), p);
+  const dim3 grid((N + 15) / 16, (B + CIN_BT - 1) / CIN_BT);
+  if (H <= 40) hipLaunchKernelGGL(cin_fwd_k<10>, grid, dim3(64), lds, rsx_s(stream), p);
+  else hipLaunchKernelGGL(cin_fwd_k<32>, grid, dim3(64), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -309,20 +390,23 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc) return RSX_EINVAL;
-  if (D != CIN_D || H > 128) return RSX_EUNSUPPORTED;
+  if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
   const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D) * sizeof(float);
   if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
   if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return RSX_ELAUNCH;
   }
   CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, acc_dxk, acc_dx0, B, F, H, N};
-  hipLaunchKernelGGL(cin_bwd_dx_k, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
+  if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
+  else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   CinBwdDwArgs w{X0, Xk, out, dout, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT};
-  hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG), dim3(64), 0, rsx_s(stream), w);
+  hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG), dim3(256), 0, rsx_s(stream), w);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
