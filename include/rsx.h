@@ -154,6 +154,17 @@ int rsx_tower_head(const float* a_last, const double* fstat_last, const float* g
                    float* prob, float* dy_last, double* bstat_last, float* dwd_part, double* hpart, float* gs0,
                    float* gs1, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate,
                    float loss_scale, int relu0, int relu2, int B, int N, rsx_stream_t stream);
+/* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
+typedef struct {
+  const int32_t* ids;
+  const int32_t* row_off;
+  int32_t* perm;
+  int32_t* seg_off;
+  int32_t* uniq_row;
+  int32_t* nuniq;
+  int32_t* slot;
+  int32_t max_rows_per_field, B, F, stride;
+} rsx_sort_job;
 /* Backward of layer l: BN backward + relu mask on load; writes dW, db, dgamma, dbeta, and dy_prev = gradient wrt
  * the previous layer's BN output (+ its bstat_prev partials), or dX for the first layer (bn_prev == NULL).
  * With hpart != NULL (last layer) one extra workgroup reduces the head partials into dwd, dbd, dwo[3], dbo, dc0, loss. */
@@ -163,7 +174,10 @@ int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const f
                         const float* mask_prev, float* dy_prev, double* bstat_prev, const double* hpart,
                         const float* dwd_part, float* dwd, float* dbd, float* dwo, float* dbo, float* dc0,
                         float* loss, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                        int K, int N, rsx_stream_t stream);
+                        int K, int N, const rsx_sort_job* sort_h, rsx_stream_t stream);
+/* sort_h (host pointer, nullable): the step's rsx_field_sort job executed by F extra workgroups of this launch.  The
+ * sort depends on ids only and is first consumed by rsx_segsum_bwd, so its latency hides behind the tower backward
+ * instead of occupying its own slot on the critical path (same results as a separate rsx_field_sort call).        */
 
 /* ---------------------------------------------------------------------------------------------
  * DCN cross layers, dcn/dcn.py:132-142: x_{l+1} = (x_l . w_l) * x0 + x_l + b_l, all L

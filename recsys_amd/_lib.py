@@ -21,6 +21,12 @@ class AdamSeg(C.Structure):
                 ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32)]
 
 
+class SortJob(C.Structure):
+    _fields_ = [("ids", C.c_void_p), ("row_off", C.c_void_p), ("perm", C.c_void_p), ("seg_off", C.c_void_p),
+                ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p),
+                ("max_rows_per_field", C.c_int32), ("B", C.c_int32), ("F", C.c_int32), ("stride", C.c_int32)]
+
+
 _P, _I, _U64, _F = C.c_void_p, C.c_int, C.c_uint64, C.c_float
 _SIGS = {
     "rsx_version": (C.c_int, []),
@@ -33,7 +39,7 @@ _SIGS = {
     "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P]),
     "rsx_tower_reduce_partials": (_I, [_P, _I, _I, _P]),
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P]),
-    "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P]),
+    "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),

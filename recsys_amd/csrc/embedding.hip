@@ -8,6 +8,7 @@
 // coalesced (consecutive lanes -> consecutive 16 B).  These kernels are HBM/latency-bound integer +
 // fp32 streaming work: no MFMA here by design.
 #include "rsx_common.h"
+#include "sort_device.h"
 
 // ------------------------------------------------------------------ forward --------------------
 // One wave per example b.  lane = (j, q): q = float4 quarter of the row, j = pair slot; the wave
@@ -54,80 +55,10 @@ __global__ void gather_fm_fwd_k(const float* __restrict__ tables, const float* _
 }
 
 // ------------------------------------------------------------------ dedup: per-field LDS sort ---
-// One workgroup per field.  key = (id << bbits) | b is unique, so the (unstable) bitonic network
-// yields entries ordered by id, then by ascending example index -- the order TF's CPU
-// unsorted_segment_sum accumulates in.  n = padded power of two (>= 128), T = min(1024, n/2) threads.
-__global__ __launch_bounds__(1024) void field_sort_k(const int32_t* __restrict__ ids,
-                                                      const int32_t* __restrict__ row_off,
-                                                      int32_t* __restrict__ perm, int32_t* __restrict__ seg_off,
-                                                      int32_t* __restrict__ uniq_row, int32_t* __restrict__ nuniq,
-                                                      int32_t* __restrict__ slot, int B, int F, int stride, int n,
-                                                      int bbits) {
+// One workgroup per field (sort_device.h).  n = padded power of two (>= 128), T = min(1024, n/2) threads.
+__global__ __launch_bounds__(1024) void field_sort_k(const SortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint32_t* key = lds;            // [n]
-  uint32_t* wsum = lds + n;       // [32]
-  const int f = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-  const int roff = row_off[f];
-  // forget the previous step's rows of this field (they may differ from this step's)
-  const int prev = nuniq[f];
-  for (int jj = tid; jj < prev; jj += T) slot[uniq_row[(size_t)f * stride + jj]] = -1;
-  for (int i = tid; i < n; i += T)
-    key[i] = i < B ? (((uint32_t)ids[(size_t)i * F + f] << bbits) | (uint32_t)i) : 0xFFFFFFFFu;
-  __syncthreads();
-  for (int k = 2; k <= n; k <<= 1) {
-    for (int jst = k >> 1; jst > 0; jst >>= 1) {
-      for (int t = tid; t < (n >> 1); t += T) {
-        const int i = ((t & ~(jst - 1)) << 1) | (t & (jst - 1));
-        const int l = i | jst;
-        const uint32_t a = key[i], c = key[l];
-        const bool up = (i & k) == 0;
-        if ((a > c) == up) {
-          key[i] = c;
-          key[l] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // head flags + exclusive scan -> unique index j of every sorted position
-  const int ipt = n / T;
-  const int i0 = tid * ipt;
-  const uint32_t bmask = (1u << bbits) - 1u;
-  int cnt = 0;
-  for (int i = i0; i < i0 + ipt; ++i)
-    if (i < B && (i == 0 || (key[i] >> bbits) != (key[i - 1] >> bbits))) ++cnt;
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < RSX_WAVE; d <<= 1) {
-    const int o = __shfl_up(incl, d);
-    if ((tid & 63) >= d) incl += o;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = (uint32_t)incl;
-  __syncthreads();
-  int base = incl - cnt, total = 0;
-  const int nw = (T + 63) >> 6;
-  for (int w = 0; w < nw; ++w) {
-    const int v = (int)wsum[w];
-    if (w < (tid >> 6)) base += v;
-    total += v;
-  }
-  int jn = base;
-  for (int i = i0; i < i0 + ipt; ++i) {
-    if (i >= B) break;
-    const uint32_t kk = key[i];
-    perm[(size_t)f * stride + i] = (int32_t)(kk & bmask);
-    if (i == 0 || (kk >> bbits) != (key[i - 1] >> bbits)) {
-      const int row = roff + (int)(kk >> bbits);
-      uniq_row[(size_t)f * stride + jn] = row;
-      seg_off[(size_t)f * (stride + 1) + jn] = i;
-      slot[row] = f * stride + jn;
-      ++jn;
-    }
-  }
-  if (tid == 0) {
-    seg_off[(size_t)f * (stride + 1) + total] = B;
-    nuniq[f] = total;
-  }
+  field_sort_block(a, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------ backward: sorted segment-sum -
@@ -310,27 +241,20 @@ extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int
   return RSX_OK;
 }
 
-static inline int ceil_log2(int x) {
-  int b = 0;
-  while ((1 << b) < x) ++b;
-  return b;
-}
-
 extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
                               int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int max_rows_per_field, int B,
                               int F, int stride, rsx_stream_t stream) {
   if (!ids || !row_off || !perm || !seg_off || !uniq_row || !nuniq || !slot || B < 0 || F <= 0 || stride < B ||
       max_rows_per_field <= 0)
     return RSX_EINVAL;
-  if (B > 16384) return RSX_EUNSUPPORTED;
-  const int bbits = ceil_log2(B < 2 ? 2 : B);
-  if (((uint64_t)(max_rows_per_field - 1) << bbits) >= (1ull << 32) - 1ull) return RSX_EUNSUPPORTED;
+  SortArgs a{ids, row_off, perm, seg_off, uniq_row, nuniq, slot, B, F, stride, 0, 0};
   int n = 128;
   while (n < B) n <<= 1;
   const int T = (n >> 1) < 1024 ? (n >> 1) : 1024;
-  const size_t lds = ((size_t)n + 32) * sizeof(uint32_t);
-  hipLaunchKernelGGL(field_sort_k, dim3(F), dim3(T), lds, rsx_s(stream), ids, row_off, perm, seg_off, uniq_row,
-                     nuniq, slot, B, F, stride, n, bbits);
+  const int rc = rsx_sort_args(a, max_rows_per_field, T);
+  if (rc != RSX_OK) return rc;
+  const size_t lds = ((size_t)a.n + 32) * sizeof(uint32_t);
+  hipLaunchKernelGGL(field_sort_k, dim3(F), dim3(T), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -18,6 +18,7 @@
 // at rounding-order level.  One wave per 16x16 output tile: these GEMMs are latency-bound, the lever is
 // spreading tiles over the 256 CUs, not per-CU efficiency.
 #include "rsx_common.h"
+#include "sort_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -426,6 +427,9 @@ struct BwdArgs {
   int has_wo;
   int B, K, N, RT, RTh;      // RT: rows of the (possibly pre-reduced) bstat; RTh: row tiles = rows of hpart / dwd_part
   int n_din, n_dw, ct_k, ct_k1, ct_n;
+  int n_head;                // 1 when the head-partial reduce block is present
+  int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
+  SortArgs sort;
 };
 
 struct ColBwd { float mean, rstd, k1, sdy, sdx; };
@@ -447,8 +451,12 @@ __device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float
   return c.k1 * (Bf * dy - c.sdy - xh * c.sdx);
 }
 
+#ifndef RSX_ABLATE
+#define RSX_ABLATE 0
+#endif
 __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (RSX_ABLATE == 1) return;                       // launch floor
   float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
   float* part = lds + 5 * p.N + ((4 - (5 * p.N) % 4) % 4);         // [4][256], 16-byte aligned
   double* cred = reinterpret_cast<double*>(part + 1024);              // [4][2][16]
@@ -464,6 +472,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
     }
     __syncthreads();
+    if (RSX_ABLATE == 2) return;                     // prologue only
     const int kc = bid % p.ct_k, rt = bid / p.ct_k;
     const int row = rt * TM + i;
     const int kcol = kc * 16 + i;   // B-operand "column" = input feature
@@ -486,6 +495,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     });
     const int orow = rt * TM + (tid >> 4), ocol = kc * 16 + (tid & 15);
     double s1 = 0.0, s2 = 0.0;
+    if (RSX_ABLATE == 3) { if (v == 12345.f) p.dy_prev[0] = v; return; }   // prologue + K loop
     if (orow < p.B && ocol < p.K) {
       float o = v;
       if (!first) {
@@ -520,6 +530,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
     ColBwd cb = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (RSX_ABLATE == 4) return;                     // dW tiles off
     if (nok) cb = bwd_col(p, ncol);
     float fsc = 1.f, fsh = 0.f;
     if (!first && fok) {
@@ -557,6 +568,11 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         p.dbeta[ncol] = cb.sdy;
       }
     }
+    return;
+  }
+  if (bid >= p.n_din + p.n_dw + p.n_head) {
+    // ---- piggy-backed dedup sort: independent of the tower, first needed by the segment-sum -----------
+    field_sort_block(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
     return;
   }
   // ---- head partial reduce (last layer only) ---------------------------------------------------------
@@ -669,7 +685,7 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    double* bstat_prev, const double* hpart, const float* dwd_part, float* dwd,
                                    float* dbd, float* dwo, float* dbo, float* dc0, float* loss,
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                                   int K, int N, rsx_stream_t stream) {
+                                   int K, int N, const rsx_sort_job* sort_h, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !a || !dy || !bstat || !bn || !gamma || !dW || !db || !dgamma || !dbeta || !dy_prev)
@@ -693,9 +709,24 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.ct_n = (N + 15) / 16;
   p.n_din = p.ct_k * p.RTh;
   p.n_dw = p.ct_k1 * p.ct_n;
-  const int total = p.n_din + p.n_dw + (hpart != nullptr ? 1 : 0);
-  hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float),
-                     rsx_s(stream), p);
+  p.n_head = hpart != nullptr ? 1 : 0;
+  p.n_sort = 0;
+  size_t lds = ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float);
+  if (sort_h != nullptr) {
+    const rsx_sort_job& j = *sort_h;
+    if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
+        j.stride < j.B || j.max_rows_per_field <= 0)
+      return RSX_EINVAL;
+    p.sort = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.B, j.F, j.stride, 0, 0};
+    const int rc = rsx_sort_args(p.sort, j.max_rows_per_field, 256);
+    if (rc != RSX_OK) return rc;
+    const size_t need = ((size_t)p.sort.n + 32) * sizeof(uint32_t);
+    if (need > 64 * 1024) return RSX_EUNSUPPORTED;
+    if (need > lds) lds = need;
+    p.n_sort = j.F;
+  }
+  const int total = p.n_din + p.n_dw + p.n_head + p.n_sort;
+  hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

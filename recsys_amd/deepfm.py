@@ -110,13 +110,14 @@ def _train_fused(store, arena, ids, labels, params, masks):
     with torch.no_grad():
         # The ids-only sort could run on a side stream, but inside a HIP graph the fork/join across HW queues costs
         # ~10 us each way on this stack (profiles/r01_*), more than the 9 us it hides: keep it in-stream.
-        if dp is None:
-            store.sort_ids_for_backward(arena, ids, overlap=bool(params.get("overlap_sort", False)))
+        # the ids-only dedup sort rides along in the tower-backward launch (extra workgroups): off the critical path.
+        # (A side HIP stream was measured instead: inside a graph the fork/join across HW queues costs ~10 us each way.)
+        job = arena.sort_job(ids) if dp is None else None
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
-            replicas=dp.world if dp is not None else 1, masks=masks)
+            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job)
 
     def train_op():
         with torch.no_grad():

@@ -82,6 +82,17 @@ class EmbeddingArena:
                                    B, self.F, self.stride, _stream()), "rsx_field_sort")
         self.last_B = B
 
+    def sort_job(self, ids):
+        """The rsx_field_sort call of this step as a job another launch can carry (FusedTower.train_step)."""
+        B = ids.shape[0]
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and B <= self.stride
+        self.last_B = B
+        j = _lib.SortJob()
+        j.ids, j.row_off, j.perm, j.seg_off = ids.data_ptr(), self.row_off.data_ptr(), self.perm.data_ptr(), self.seg_off.data_ptr()
+        j.uniq_row, j.nuniq, j.slot = self.uniq_row.data_ptr(), self.nuniq.data_ptr(), self.slot.data_ptr()
+        j.max_rows_per_field, j.B, j.F, j.stride = self.max_rows, B, self.F, self.stride
+        return j
+
     def gather(self, ids, fm=False, first_order=False):
         """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd)."""
         B = ids.shape[0]
@@ -283,9 +294,10 @@ class FusedTower:
 
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
-                   seed=0x5eed):
+                   seed=0x5eed, sort_job=None):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
-        c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step.
+        c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
+        sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch.
         Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
         L, P, pre = lib(), self.P, self.pre
         B = X.shape[0]
@@ -332,7 +344,8 @@ class FusedTower:
                 _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
                 _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
-                rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_bwd_layer")
+                rs, seed, l, rate, B, K, self.widths[l], C.byref(sort_job) if (last and sort_job is not None) else None, st),
+                "rsx_tower_bwd_layer")
             if l:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
