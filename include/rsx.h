@@ -98,8 +98,13 @@ typedef enum {
                               rows with slot[row]>=0 add G[slot[row], :] first.  n = rows, d = D.   */
   RSX_ADAM_VEC_SLOT = 2,   /* dense formula on a vector whose dense gradient is g[slot[row]] where
                               slot[row]>=0 and 0 elsewhere (one-hot matmul kernels: w1). n = rows.  */
-  RSX_ADAM_TABLE_ROWS = 3, /* lazy_rows mode (NOT TF semantics): only rows listed in uniq_row/nuniq. */
-  RSX_ADAM_VEC_ROWS = 4    /* lazy_rows counterpart for vectors.                                     */
+  RSX_ADAM_TABLE_ROWS = 3, /* only the rows listed in uniq_row/nuniq, sparse formula with their gradient.  Alone it is the
+                              lazy_rows mode (NOT TF semantics); together with TABLE_TF1_COLD it is the exact TF-1 update. */
+  RSX_ADAM_VEC_ROWS = 4,   /* lazy_rows counterpart for vectors (sparse formula).                                        */
+  RSX_ADAM_TABLE_TF1_COLD = 5, /* the untouched part of TABLE_TF1: rows with slot[row] < 0 decay and move, touched rows
+                              are skipped (they are updated by a TABLE_ROWS segment once their gradient exists).  g unused. */
+  RSX_ADAM_VEC_COLD = 6,   /* the untouched part of VEC_SLOT (dense formula, zero gradient); touched elements skipped.   */
+  RSX_ADAM_VEC_ROWS_DENSE = 7 /* touched elements of a VEC_SLOT variable, ApplyAdam formula.                            */
 } rsx_adam_kind;
 
 typedef struct {
@@ -123,6 +128,23 @@ int rsx_adam_state_init_h(float* state_h /* host float[4] */, float beta1, float
 int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* state, float lr, float beta1,
                        float beta2, float eps, rsx_stream_t stream);
 
+/* Split form of the same TF-1 update, for overlapping the HBM-bound sweep with latency-bound kernels:
+ * the untouched rows (*_COLD kinds) depend only on the PREVIOUS optimizer state and on which rows this step touches
+ * (the slot map of rsx_field_sort), so their sweep may run -- cut into slices of workgroups -- as extra workgroups of
+ * the tower launches (rsx_tower_fwd_layer / rsx_tower_head / rsx_tower_bwd_layer `sweep_h`) or stand-alone
+ * (rsx_adam_slice_run); the touched rows + dense variables follow in one rsx_adam_tf1_multi launch
+ * (TABLE_ROWS / VEC_ROWS_DENSE / DENSE kinds), which also advances the beta powers.  COLD slices never advance them.
+ * Element for element the arithmetic is that of TABLE_TF1 / VEC_SLOT.                                               */
+typedef struct {
+  const rsx_adam_seg* segs;   /* host array, *_COLD kinds                                  */
+  int32_t nseg;
+  float lr, beta1, beta2, eps;
+  float* state;               /* device float[4], read only                                 */
+  uint32_t blk_lo, blk_hi;    /* workgroup range [lo, hi) out of rsx_adam_num_blocks(segs)  */
+} rsx_adam_slice;
+int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg);
+int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused DNN tower + head, TRAIN step: per layer
  * tf.layers.dense(relu) -> tf.layers.batch_normalization(training=True) -> tf.layers.dropout
@@ -144,7 +166,8 @@ int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_t stream);
 int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out, double* fstat_out,
                         const double* fstat_prev, const float* gamma_prev, const float* beta_prev,
                         const float* mask_prev, float* bn_prev_out, const uint32_t* rng_step, uint32_t seed,
-                        int layer, float dropout_rate, int B, int K, int N, rsx_stream_t stream);
+                        int layer, float dropout_rate, int B, int K, int N, const rsx_adam_slice* sweep_h,
+                        rsx_stream_t stream);
 /* o = dropout(BN(a_last)); u = o.wd + bd; z = wo[0]*act0(s0+c0) + wo[1]*s1 + wo[2]*act2(u) + bo (wo NULL: plain sum);
  * prob = sigmoid(z); per-row-tile partials of the loss and of every head gradient; dy_last / bstat_last = gradient
  * wrt the last BN output; gs0 / gs1 = d loss / d s0, d s1.  loss_scale = 1/(B*replicas).                    */
@@ -153,7 +176,8 @@ int rsx_tower_head(const float* a_last, const double* fstat_last, const float* g
                    const float* c0, const float* s1, const float* wo, const float* bo, const float* labels,
                    float* prob, float* dy_last, double* bstat_last, float* dwd_part, double* hpart, float* gs0,
                    float* gs1, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate,
-                   float loss_scale, int relu0, int relu2, int B, int N, rsx_stream_t stream);
+                   float loss_scale, int relu0, int relu2, int B, int N, const rsx_adam_slice* sweep_h,
+                   rsx_stream_t stream);
 /* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
 typedef struct {
   const int32_t* ids;
@@ -174,8 +198,11 @@ int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const f
                         const float* mask_prev, float* dy_prev, double* bstat_prev, const double* hpart,
                         const float* dwd_part, float* dwd, float* dbd, float* dwo, float* dbo, float* dc0,
                         float* loss, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                        int K, int N, const rsx_sort_job* sort_h, rsx_stream_t stream);
-/* sort_h (host pointer, nullable): the step's rsx_field_sort job executed by F extra workgroups of this launch.  The
+                        int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* sweep_h (host pointer, nullable, on all three tower entry points): a slice of the untouched-row optimizer sweep
+ * (see rsx_adam_slice) executed by extra workgroups appended after the launch's own ones -- the HBM-bound stream fills the
+ * CUs the latency-bound tower workgroups leave idle.
+ * sort_h (host pointer, nullable): the step's rsx_field_sort job executed by F extra workgroups of this launch.  The
  * sort depends on ids only and is first consumed by rsx_segsum_bwd, so its latency hides behind the tower backward
  * instead of occupying its own slot on the critical path (same results as a separate rsx_field_sort call).        */
 

@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librsx.so")
 
-RSX_ADAM_DENSE, RSX_ADAM_TABLE_TF1, RSX_ADAM_VEC_SLOT, RSX_ADAM_TABLE_ROWS, RSX_ADAM_VEC_ROWS = range(5)
+(RSX_ADAM_DENSE, RSX_ADAM_TABLE_TF1, RSX_ADAM_VEC_SLOT, RSX_ADAM_TABLE_ROWS, RSX_ADAM_VEC_ROWS, RSX_ADAM_TABLE_TF1_COLD,
+ RSX_ADAM_VEC_COLD, RSX_ADAM_VEC_ROWS_DENSE) = range(8)
 RSX_ADAM_MAX_SEGS = 12
 
 
@@ -19,6 +20,12 @@ class AdamSeg(C.Structure):
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
                 ("slot", C.c_void_p), ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p),
                 ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32)]
+
+
+class AdamSlice(C.Structure):
+    _fields_ = [("segs", C.POINTER(AdamSeg)), ("nseg", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("state", C.c_void_p), ("blk_lo", C.c_uint32),
+                ("blk_hi", C.c_uint32)]
 
 
 class SortJob(C.Structure):
@@ -36,10 +43,12 @@ _SIGS = {
     "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
     "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
-    "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P]),
+    "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P]),
     "rsx_tower_reduce_partials": (_I, [_P, _I, _I, _P]),
-    "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P]),
-    "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P]),
+    "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P, _P]),
+    "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P]),
+    "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
+    "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),

@@ -1,0 +1,276 @@
+// TF-1.x Adam sweep as device/host building blocks shared by adam.hip (the stand-alone launch) and tower.hip (where
+// slices of the untouched-row sweep ride along in the tower launches).  See adam.hip for the semantics.
+#pragma once
+#include "rsx_common.h"
+
+struct SegDev {
+  int32_t kind, d;
+  long long n;
+  float *var, *m, *v, *g;
+  const int32_t *slot, *uniq_row, *nuniq;
+  int32_t B, stride, zero_grad;
+  uint32_t blk_begin;
+};
+struct AdamArgs {
+  SegDev seg[RSX_ADAM_MAX_SEGS];
+  int32_t nseg;
+  float lr, b1, b2, eps;
+  float* state;
+  uint32_t total_blocks;
+};
+
+struct Hp {
+  float alpha, b1, b2, omb1, omb2, eps;
+};
+
+__device__ __forceinline__ void adam_sparse1(float& var, float& m, float& v, float g, bool has, const Hp& h) {
+  float m1 = m * h.b1;
+  float v1 = v * h.b2;
+  if (has) {
+    m1 = m1 + g * h.omb1;
+    v1 = v1 + (g * g) * h.omb2;
+  }
+  var = var - (h.alpha * m1) / (sqrtf(v1) + h.eps);
+  m = m1;
+  v = v1;
+}
+__device__ __forceinline__ void adam_dense1(float& var, float& m, float& v, float g, const Hp& h) {
+  const float m1 = m + (g - m) * h.omb1;
+  const float v1 = v + (g * g - v) * h.omb2;
+  var = var - (m1 * h.alpha) / (sqrtf(v1) + h.eps);
+  m = m1;
+  v = v1;
+}
+
+#define F4_APPLY(FN, VAR, M, V, G, ...)   \
+  FN(VAR.x, M.x, V.x, G.x, __VA_ARGS__);  \
+  FN(VAR.y, M.y, V.y, G.y, __VA_ARGS__);  \
+  FN(VAR.z, M.z, V.z, G.z, __VA_ARGS__);  \
+  FN(VAR.w, M.w, V.w, G.w, __VA_ARGS__)
+
+constexpr int ADAM_T = 256;    // threads per workgroup
+constexpr int ADAM_U = 4;      // float4 per lane
+constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
+
+// One workgroup (ADAM_T = 256 threads) of the sweep: block `blk` of the launch-wide block index space of `a`.
+__device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk) {
+  const float b1p = a.state[0], b2p = a.state[1];
+  Hp h;
+  h.b1 = a.b1;
+  h.b2 = a.b2;
+  h.omb1 = 1.0f - a.b1;
+  h.omb2 = 1.0f - a.b2;
+  h.eps = a.eps;
+  h.alpha = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  int si = 0;
+#pragma unroll 1
+  for (int k = 1; k < a.nseg; ++k)
+    if (blk >= a.seg[k].blk_begin) si = k;
+  const SegDev& s = a.seg[si];
+  const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
+  float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
+  float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
+  float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (s.kind == RSX_ADAM_TABLE_TF1 || s.kind == RSX_ADAM_TABLE_TF1_COLD) {
+    const bool cold_only = s.kind == RSX_ADAM_TABLE_TF1_COLD;   // touched rows are left to the TABLE_ROWS launch
+    const int lpr = s.d >> 2;
+    const long long n4 = s.n * lpr;
+    const float4* __restrict__ G4 = reinterpret_cast<const float4*>(s.g);
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      if (e < n4) {
+        const long long row = e / lpr;
+        const int q = (int)(e - row * lpr);
+        const int sl = s.slot[row];
+        if (cold_only && sl >= 0) continue;
+        float4 var = var4[e], m = m4[e], v = v4[e];
+        const bool has = sl >= 0;
+        const float4 g = has ? G4[(long long)sl * lpr + q] : z4;
+        F4_APPLY(adam_sparse1, var, m, v, g, has, h);
+        var4[e] = var;
+        m4[e] = m;
+        v4[e] = v;
+      }
+    }
+  } else if (s.kind == RSX_ADAM_DENSE) {
+    float4* __restrict__ g4 = reinterpret_cast<float4*>(s.g);
+    const long long n4 = s.n >> 2;
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      if (e < n4) {
+        float4 var = var4[e], m = m4[e], v = v4[e];
+        const float4 g = g4[e];
+        F4_APPLY(adam_dense1, var, m, v, g, h);
+        var4[e] = var;
+        m4[e] = m;
+        v4[e] = v;
+        if (s.zero_grad) g4[e] = z4;
+      } else if (e == n4) {  // scalar tail (n not a multiple of 4)
+        for (long long i = n4 * 4; i < s.n; ++i) {
+          adam_dense1(s.var[i], s.m[i], s.v[i], s.g[i], h);
+          if (s.zero_grad) s.g[i] = 0.f;
+        }
+      }
+    }
+  } else if (s.kind == RSX_ADAM_VEC_SLOT || s.kind == RSX_ADAM_VEC_COLD) {
+    const bool cold_only = s.kind == RSX_ADAM_VEC_COLD;         // touched elements keep their state for VEC_ROWS_DENSE
+    const long long n4 = s.n >> 2;
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      if (e < n4) {
+        const int4 sl = reinterpret_cast<const int4*>(s.slot)[e];
+        float4 g;
+        g.x = (!cold_only && sl.x >= 0) ? s.g[sl.x] : 0.f;     // COLD: g is not provided (touched elements are restored below)
+        g.y = (!cold_only && sl.y >= 0) ? s.g[sl.y] : 0.f;
+        g.z = (!cold_only && sl.z >= 0) ? s.g[sl.z] : 0.f;
+        g.w = (!cold_only && sl.w >= 0) ? s.g[sl.w] : 0.f;
+        float4 var = var4[e], m = m4[e], v = v4[e];
+        const float4 var0 = var, m0 = m, v0 = v;
+        F4_APPLY(adam_dense1, var, m, v, g, h);
+        if (cold_only) {   // element-wise: leave the touched elements exactly as they were
+          if (sl.x >= 0) { var.x = var0.x; m.x = m0.x; v.x = v0.x; }
+          if (sl.y >= 0) { var.y = var0.y; m.y = m0.y; v.y = v0.y; }
+          if (sl.z >= 0) { var.z = var0.z; m.z = m0.z; v.z = v0.z; }
+          if (sl.w >= 0) { var.w = var0.w; m.w = m0.w; v.w = v0.w; }
+        }
+        var4[e] = var;
+        m4[e] = m;
+        v4[e] = v;
+      } else if (e == n4) {
+        for (long long i = n4 * 4; i < s.n; ++i) {
+          const int sl = s.slot[i];
+          if (cold_only && sl >= 0) continue;
+          adam_dense1(s.var[i], s.m[i], s.v[i], sl >= 0 ? s.g[sl] : 0.f, h);
+        }
+      }
+    }
+  } else if (s.kind == RSX_ADAM_TABLE_ROWS) {
+    // lazy_rows mode: n = F*B slots, lpr lanes per slot; only listed rows move (NOT TF semantics)
+    const int lpr = s.d >> 2;
+    const long long n4 = s.n * lpr;
+    const float4* __restrict__ G4 = reinterpret_cast<const float4*>(s.g);
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      if (e < n4) {
+        const long long sidx = e / lpr;
+        const int q = (int)(e - sidx * lpr);
+        const int f = (int)(sidx / s.B), j = (int)(sidx - (long long)f * s.B);
+        if (j < s.nuniq[f]) {
+          const long long sl = (long long)f * s.stride + j;
+          const long long r = (long long)s.uniq_row[sl] * lpr + q;
+          float4 var = var4[r], m = m4[r], v = v4[r];
+          const float4 g = G4[sl * lpr + q];
+          F4_APPLY(adam_sparse1, var, m, v, g, true, h);
+          var4[r] = var;
+          m4[r] = m;
+          v4[r] = v;
+        }
+      }
+    }
+  } else {  // RSX_ADAM_VEC_ROWS (sparse formula) / RSX_ADAM_VEC_ROWS_DENSE (ApplyAdam formula)
+#pragma unroll
+    for (int u = 0; u < ADAM_U; ++u) {
+      const long long sidx = base + (long long)u * ADAM_T + threadIdx.x;
+      if (sidx < s.n) {
+        const int f = (int)(sidx / s.B), j = (int)(sidx - (long long)f * s.B);
+        if (j < s.nuniq[f]) {
+          const long long sl = (long long)f * s.stride + j;
+          const int r = s.uniq_row[sl];
+          if (s.kind == RSX_ADAM_VEC_ROWS_DENSE) adam_dense1(s.var[r], s.m[r], s.v[r], s.g[sl], h);
+          else adam_sparse1(s.var[r], s.m[r], s.v[r], s.g[sl], true, h);
+        }
+      }
+    }
+  }
+}
+
+// Host: validates the segment list and lays the segments out over the launch-wide block index space.
+// Returns an rsx_status; *blocks_out = number of workgroups (0 when there is nothing to do).
+static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* state, float lr, float beta1, float beta2,
+                                  float eps, AdamArgs& a, uint32_t* blocks_out) {
+  if (!segs_h || !state || nseg <= 0 || nseg > RSX_ADAM_MAX_SEGS) return RSX_EINVAL;
+  uint32_t blocks = 0;
+  int k = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const rsx_adam_seg& s = segs_h[i];
+    if (s.n < 0 || !s.var || !s.m || !s.v) return RSX_EINVAL;
+    long long work;  // float4 (or slot) units
+    switch (s.kind) {
+      case RSX_ADAM_DENSE:
+        if (!s.g) return RSX_EINVAL;
+        work = (s.n >> 2) + 1;
+        break;
+      case RSX_ADAM_TABLE_TF1:
+      case RSX_ADAM_TABLE_TF1_COLD:
+        if (!s.slot || (!s.g && s.kind == RSX_ADAM_TABLE_TF1) || s.d < 4 || (s.d & 3)) return RSX_EINVAL;
+        work = s.n * (s.d >> 2);
+        break;
+      case RSX_ADAM_VEC_SLOT:
+      case RSX_ADAM_VEC_COLD:
+        if (!s.slot || (!s.g && s.kind == RSX_ADAM_VEC_SLOT)) return RSX_EINVAL;
+        work = (s.n >> 2) + 1;
+        break;
+      case RSX_ADAM_TABLE_ROWS:
+        if (!s.g || !s.uniq_row || !s.nuniq || s.B <= 0 || s.d < 4 || (s.d & 3)) return RSX_EINVAL;
+        work = s.n * (s.d >> 2);
+        break;
+      case RSX_ADAM_VEC_ROWS:
+      case RSX_ADAM_VEC_ROWS_DENSE:
+        if (!s.g || !s.uniq_row || !s.nuniq || s.B <= 0) return RSX_EINVAL;
+        work = s.n;
+        break;
+      default: return RSX_EINVAL;
+    }
+    if (s.n == 0) continue;
+    SegDev& d = a.seg[k++];
+    d.kind = s.kind;
+    d.d = s.d;
+    d.n = s.n;
+    d.var = s.var;
+    d.m = s.m;
+    d.v = s.v;
+    d.g = s.g;
+    d.slot = s.slot;
+    d.uniq_row = s.uniq_row;
+    d.nuniq = s.nuniq;
+    d.B = s.B;
+    d.stride = s.stride;
+    d.zero_grad = s.zero_grad;
+    d.blk_begin = blocks;
+    blocks += (uint32_t)((work + ADAM_Q - 1) / ADAM_Q);
+  }
+  a.nseg = k;
+  a.lr = lr;
+  a.b1 = beta1;
+  a.b2 = beta2;
+  a.eps = eps;
+  a.state = state;
+  a.total_blocks = blocks;
+  *blocks_out = k == 0 ? 0u : blocks;
+  return RSX_OK;
+}
+
+// A slice [blk_lo, blk_hi) of a COLD sweep carried by another kernel's launch as extra workgroups.
+struct AdamSlice {
+  AdamArgs args;
+  uint32_t blk_lo, n_blk;     // n_blk == 0: no slice
+};
+static inline int adam_build_slice(const rsx_adam_slice* sl_h, AdamSlice& out) {
+  out.n_blk = 0;
+  out.blk_lo = 0;
+  if (sl_h == nullptr) return RSX_OK;
+  uint32_t blocks = 0;
+  const int rc = adam_build_args(sl_h->segs, sl_h->nseg, sl_h->state, sl_h->lr, sl_h->beta1, sl_h->beta2, sl_h->eps,
+                                 out.args, &blocks);
+  if (rc != RSX_OK) return rc;
+  if (sl_h->blk_hi < sl_h->blk_lo || sl_h->blk_hi > blocks) return RSX_EINVAL;
+  out.blk_lo = sl_h->blk_lo;
+  out.n_blk = sl_h->blk_hi - sl_h->blk_lo;
+  return RSX_OK;
+}

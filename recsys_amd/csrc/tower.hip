@@ -19,6 +19,7 @@
 // spreading tiles over the 256 CUs, not per-CU efficiency.
 #include "rsx_common.h"
 #include "sort_device.h"
+#include "adam_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -144,10 +145,17 @@ struct FwdArgs {
   uint32_t seed, layer_prev;
   float rate;
   int B, K, N, RT;
+  int ct, n_own;          // column tiles; ct * row tiles = workgroups of the layer itself
+  AdamSlice sweep;        // optional slice of the untouched-row optimizer sweep carried as extra workgroups
 };
 
 __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= p.n_own) {
+    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
+    return;
+  }
+  const int bx = blockIdx.x % p.ct, by = blockIdx.x / p.ct;
   float* sc = lds;                    // [K] scale
   float* sh = lds + p.K;              // [K] shift
   float* part = lds + 2 * p.K;        // [4][256]
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
       const float inv = rstd * p.gamma_prev[k];
       sc[k] = inv;
       sh[k] = p.beta_prev[k] - mean * inv;
-      if (blockIdx.x == 0 && blockIdx.y == 0) {
+      if (bx == 0 && by == 0) {
         p.bn_prev_out[k] = mean;
         p.bn_prev_out[p.K + k] = rstd;
       }
@@ -170,8 +178,8 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   }
   const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
   const int i = lane & 15, kq = lane >> 4;
-  const int row = blockIdx.y * TM + i;
-  const int col = blockIdx.x * 16 + i;
+  const int row = by * TM + i;
+  const int col = bx * 16 + i;
   const bool rok = row < p.B, cok = col < p.N;
   const float v = tile_ksplit((p.K + 15) / 16, part, [&](int ks, float* a, float* b) {
     const int kk = ks * 16 + 4 * kq;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
   });
   // epilogue: thread t owns element (r = t/16, c = t%16)
-  const int orow = blockIdx.y * TM + (tid >> 4), ocol = blockIdx.x * 16 + (tid & 15);
+  const int orow = by * TM + (tid >> 4), ocol = bx * 16 + (tid & 15);
   double s1 = 0.0, s2 = 0.0;
   if (orow < p.B && ocol < p.N) {
     float o = v + p.bias[ocol];
@@ -219,8 +227,8 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     }
     __syncthreads();
     if (tid < 16 && ocol < p.N) {
-      p.fstat_out[((size_t)blockIdx.y * 2 + 0) * p.N + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
-      p.fstat_out[((size_t)blockIdx.y * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
+      p.fstat_out[((size_t)by * 2 + 0) * p.N + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
+      p.fstat_out[((size_t)by * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
     }
   }
 }
@@ -259,9 +267,15 @@ struct HeadArgs {
   float rate, loss_scale;    // loss_scale = 1/(B * replicas)
   int relu0, relu2;
   int B, N, RT;
+  int n_own;
+  AdamSlice sweep;
 };
 
 __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
+  if ((int)blockIdx.x >= p.n_own) {
+    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
+    return;
+  }
   __shared__ float sc[256], sh[256], mu[256], rs[256];
   __shared__ double red[4][2][256];
   __shared__ float redw[4][256];
@@ -430,6 +444,7 @@ struct BwdArgs {
   int n_head;                // 1 when the head-partial reduce block is present
   int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
   SortArgs sort;
+  AdamSlice sweep;           // optional slice of the untouched-row optimizer sweep (after the sort workgroups)
 };
 
 struct ColBwd { float mean, rstd, k1, sdy, sdx; };
@@ -570,6 +585,10 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     }
     return;
   }
+  if (bid >= p.n_din + p.n_dw + p.n_head + p.n_sort) {
+    adam_block(p.sweep.args, p.sweep.blk_lo + (bid - (p.n_din + p.n_dw + p.n_head + p.n_sort)));
+    return;
+  }
   if (bid >= p.n_din + p.n_dw + p.n_head) {
     // ---- piggy-backed dedup sort: independent of the tower, first needed by the segment-sum -----------
     field_sort_block(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
@@ -630,7 +649,7 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
                                    double* fstat_out, const double* fstat_prev, const float* gamma_prev,
                                    const float* beta_prev, const float* mask_prev, float* bn_prev_out,
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                                   int K, int N, rsx_stream_t stream) {
+                                   int K, int N, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !bias || !a_out) return RSX_EINVAL;
@@ -644,8 +663,12 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
   p.rate = dropout_rate;
   p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B);
-  const dim3 grid((N + 15) / 16, (B + TM - 1) / TM);
-  hipLaunchKernelGGL(tower_fwd_k, grid, dim3(256), ((size_t)2 * K + 1024 + 256) * sizeof(float), rsx_s(stream), p);
+  p.ct = (N + 15) / 16;
+  p.n_own = p.ct * ((B + TM - 1) / TM);
+  const int rcs = adam_build_slice(sweep_h, p.sweep);
+  if (rcs != RSX_OK) return rcs;
+  hipLaunchKernelGGL(tower_fwd_k, dim3(p.n_own + p.sweep.n_blk), dim3(256), ((size_t)2 * K + 1024 + 256) * sizeof(float),
+                     rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -656,7 +679,7 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
                               const float* labels, float* prob, float* dy_last, double* bstat_last,
                               float* dwd_part, double* hpart, float* gs0, float* gs1, const uint32_t* rng_step,
                               uint32_t seed, int layer, float dropout_rate, float loss_scale, int relu0, int relu2,
-                              int B, int N, rsx_stream_t stream) {
+                              int B, int N, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (N > 256) return RSX_EUNSUPPORTED;
@@ -673,7 +696,10 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   p.loss_scale = loss_scale;
   p.relu0 = relu0; p.relu2 = relu2;
   p.B = B; p.N = N; p.RT = stat_rows(B);
-  hipLaunchKernelGGL(tower_head_k, dim3((B + TM - 1) / TM), dim3(256), 0, rsx_s(stream), p);
+  p.n_own = (B + TM - 1) / TM;
+  const int rcs = adam_build_slice(sweep_h, p.sweep);
+  if (rcs != RSX_OK) return rcs;
+  hipLaunchKernelGGL(tower_head_k, dim3(p.n_own + p.sweep.n_blk), dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -685,7 +711,8 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    double* bstat_prev, const double* hpart, const float* dwd_part, float* dwd,
                                    float* dbd, float* dwo, float* dbo, float* dc0, float* loss,
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                                   int K, int N, const rsx_sort_job* sort_h, rsx_stream_t stream) {
+                                   int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
+                                   rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !a || !dy || !bstat || !bn || !gamma || !dW || !db || !dgamma || !dbeta || !dy_prev)
@@ -725,7 +752,9 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
     if (need > lds) lds = need;
     p.n_sort = j.F;
   }
-  const int total = p.n_din + p.n_dw + p.n_head + p.n_sort;
+  const int rcs = adam_build_slice(sweep_h, p.sweep);
+  if (rcs != RSX_OK) return rcs;
+  const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
   hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

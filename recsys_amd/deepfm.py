@@ -65,6 +65,8 @@ def build_variables(store, params, capacity, with_dnn=True):
     if with_dnn and params.get("tower", "hip") == "hip":
         from .ops import FusedTower
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
+        # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0] ~ their stand-alone durations
+        store.sweep_weights = params.get("sweep_weights") or ([1.0] * len(layers) + [2.0] + [2.5] * len(layers))
 
 
 def model_fn(features, labels, mode, params):
@@ -112,12 +114,22 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # ~10 us each way on this stack (profiles/r01_*), more than the 9 us it hides: keep it in-stream.
         # the ids-only dedup sort rides along in the tower-backward launch (extra workgroups): off the critical path.
         # (A side HIP stream was measured instead: inside a graph the fork/join across HW queues costs ~10 us each way.)
-        job = arena.sort_job(ids) if dp is None else None
+        overlap = dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
+        job, sweeps, hot = None, None, None
+        if overlap:
+            # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
+            # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
+            # workgroups, filling the CUs the latency-bound tower leaves idle; touched rows + dense follow the scatter.
+            arena.field_sort(ids)
+            cold, hot = arena.adam_split_segments()
+            sweeps = store.opt.cold_slices(cold, store.sweep_weights)
+        elif dp is None:
+            job = arena.sort_job(ids)
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
-            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job)
+            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job, sweeps=sweeps)
 
     def train_op():
         with torch.no_grad():
@@ -129,7 +141,10 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 dp.all_reduce_sum(store.dense.grad)
             else:
                 arena.segsum(ids.shape[0], S, dX, gy1, gy2)
-            store.apply_gradients()
+            if hot is not None:
+                store.opt.step(hot + store.dense.adam_segments())     # touched rows + dense; advances the beta powers
+            else:
+                store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 

@@ -113,6 +113,19 @@ class EmbeddingArena:
                                    self.stride, _stream()), "rsx_segsum_bwd")
 
     # -- optimizer segments ----------------------------------------------------------------
+    def adam_split_segments(self):
+        """(cold, hot): the exact TF-1 update split into the untouched-row sweep (depends only on the slot map, may
+        overlap the tower) and the touched rows (needs this step's gradients)."""
+        cold = [dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=self.D, n=self.R, var=self.tables, m=self.m_t, v=self.v_t,
+                     slot=self.slot)]
+        hot = [dict(kind=_lib.RSX_ADAM_TABLE_ROWS, d=self.D, n=self.F * self.last_B, var=self.tables, m=self.m_t,
+                    v=self.v_t, g=self.G, uniq_row=self.uniq_row, nuniq=self.nuniq, B=self.last_B, stride=self.stride)]
+        if self.with_w1:
+            cold.append(dict(kind=_lib.RSX_ADAM_VEC_COLD, n=self.R, var=self.w1, m=self.m_w, v=self.v_w, slot=self.slot))
+            hot.append(dict(kind=_lib.RSX_ADAM_VEC_ROWS_DENSE, n=self.F * self.last_B, var=self.w1, m=self.m_w, v=self.v_w,
+                            g=self.gw1, uniq_row=self.uniq_row, nuniq=self.nuniq, B=self.last_B, stride=self.stride))
+        return cold, hot
+
     def adam_segments(self, lazy=False):
         segs = []
         if lazy:
@@ -230,20 +243,50 @@ class AdamTF1:
         check(lib().rsx_adam_state_init_h(st.ctypes.data_as(C.c_void_p), beta1, beta2))
         self.state = torch.from_numpy(st).to(dev)
 
-    def step(self, segments):
+    @staticmethod
+    def _seg_array(segments):
         n = len(segments)
         arr = (AdamSeg * n)()
-        keep = []
         for i, s in enumerate(segments):
             a = arr[i]
             a.kind, a.d, a.n = s["kind"], s.get("d", 0), int(s["n"])
             for f in ("var", "m", "v", "g", "slot", "uniq_row", "nuniq"):
                 t = s.get(f)
                 setattr(a, f, None if t is None else t.data_ptr())
-                keep.append(t)
             a.B, a.stride, a.zero_grad = s.get("B", 0), s.get("stride", 0), s.get("zero_grad", 0)
+        return arr, n
+
+    def step(self, segments):
+        arr, n = self._seg_array(segments)
         lr, b1, b2, eps = self.hp
         check(lib().rsx_adam_tf1_multi(arr, n, _ptr(self.state), lr, b1, b2, eps, _stream()), "rsx_adam_tf1_multi")
+
+    def cold_slices(self, cold_segments, weights):
+        """Cuts the untouched-row sweep (COLD kinds) into len(weights) consecutive workgroup ranges, proportional to
+        `weights`, as rsx_adam_slice structs for the tower launches.  Returns a list (entries may be None)."""
+        arr, n = self._seg_array(cold_segments)
+        nb = int(lib().rsx_adam_num_blocks(arr, n))
+        if nb < 0:
+            check(nb, "rsx_adam_num_blocks")
+        lr, b1, b2, eps = self.hp
+        tot = float(sum(weights))
+        out, lo, acc = [], 0, 0.0
+        for i, w in enumerate(weights):
+            acc += w
+            hi = nb if i == len(weights) - 1 else min(nb, int(round(nb * acc / tot)))
+            if hi > lo:
+                sl = _lib.AdamSlice()
+                sl.segs, sl.nseg, sl.lr, sl.beta1, sl.beta2, sl.eps = arr, n, lr, b1, b2, eps
+                sl.state, sl.blk_lo, sl.blk_hi = self.state.data_ptr(), lo, hi
+                sl._keep = arr
+                out.append(sl)
+            else:
+                out.append(None)
+            lo = hi
+        return out
+
+    def run_slice(self, sl):
+        check(lib().rsx_adam_slice_run(C.byref(sl), _stream()), "rsx_adam_slice_run")
 
     @property
     def global_step(self):
@@ -294,10 +337,12 @@ class FusedTower:
 
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
-                   seed=0x5eed, sort_job=None):
+                   seed=0x5eed, sort_job=None, sweeps=None):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch.
+        sweeps = 2L+1 rsx_adam_slice structs (or None) for [fwd_0..fwd_{L-1}, head, bwd_{L-1}..bwd_0]: slices of the
+        untouched-row optimizer sweep that ride along as extra workgroups (AdamTF1.cold_slices).
         Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
         L, P, pre = lib(), self.P, self.pre
         B = X.shape[0]
@@ -307,6 +352,8 @@ class FusedTower:
         nl = len(self.widths)
         g = lambda name: P[name].grad
         rs = _ptr(rng_step)
+        sw = list(sweeps) if sweeps is not None else [None] * (2 * nl + 1)
+        ref = lambda x: None if x is None else C.byref(x)
         for l in range(nl):
             K = self.k0 if l == 0 else self.widths[l - 1]
             check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
@@ -315,7 +362,7 @@ class FusedTower:
                                         _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
                                         _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
                                         _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
-                                        rs, seed, l, rate, B, K, self.widths[l], st), "rsx_tower_fwd_layer")
+                                        rs, seed, l, rate, B, K, self.widths[l], ref(sw[l]), st), "rsx_tower_fwd_layer")
             check(L.rsx_tower_reduce_partials(_ptr(self.fstat[l]), B, self.widths[l], st))      # no-op for B <= 512
         # head parameters: a variable name, or an explicit (tensor, grad_tensor) pair (e.g. a slice of out.W)
         pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
@@ -327,7 +374,7 @@ class FusedTower:
                                _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
                                _ptr(pv(bo)), _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
                                _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
-                               rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, st),
+                               rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, ref(sw[nl]), st),
               "rsx_tower_head")
         check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
         for l in reversed(range(nl)):
@@ -344,8 +391,8 @@ class FusedTower:
                 _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
                 _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
-                rs, seed, l, rate, B, K, self.widths[l], C.byref(sort_job) if (last and sort_job is not None) else None, st),
-                "rsx_tower_bwd_layer")
+                rs, seed, l, rate, B, K, self.widths[l], C.byref(sort_job) if (last and sort_job is not None) else None,
+                ref(sw[nl + 1 + (nl - 1 - l)]), st), "rsx_tower_bwd_layer")
             if l:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
