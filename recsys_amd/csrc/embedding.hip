@@ -9,6 +9,7 @@
 // fp32 streaming work: no MFMA here by design.
 #include "rsx_common.h"
 #include "sort_device.h"
+#include "adam_device.h"
 
 // ------------------------------------------------------------------ forward --------------------
 // One wave per example b.  lane = (j, q): q = float4 quarter of the row, j = pair slot; the wave
@@ -117,38 +118,41 @@ __device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4
   }
 }
 
+// The per-wave body of the segment-sum: returns false when the wave owns no unique row.  On return, for lanes with
+// `valid`: sl = slot index of the row, acc = summed gradient quarter, a1 = summed first-order gradient (q == 0 lanes),
+// e = the table row quarter (loaded only when the FM term is active), row = global row.
 template <int D>
-__global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ tables, const float* __restrict__ S,
-                                                    const float* __restrict__ dX, const float* __restrict__ gy1,
-                                                    const float* __restrict__ gy2, const int32_t* __restrict__ perm,
-                                                    const int32_t* __restrict__ seg_off,
-                                                    const int32_t* __restrict__ uniq_row,
-                                                    const int32_t* __restrict__ nuniq, float* __restrict__ G,
-                                                    float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
-                                                    int stride, int null_row) {
+__device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ tables, const float* __restrict__ S,
+                                            const float* __restrict__ dX, const float* __restrict__ gy1,
+                                            const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                            const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
+                                            const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
+                                            int null_row, bool& valid, size_t& sl, float4& acc, float& a1, float4& e,
+                                            int& row, bool& do1) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
   const int q = lane % LPR, g = lane / LPR;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int wpf = (B + GPW - 1) / GPW;  // waves per field: a wave never straddles two fields
   const int f = wave / wpf;
-  if (f >= F) return;
+  valid = false;
+  if (f >= F) return false;
   const int wf = wave - f * wpf;
   const int nu = nuniq[f];
   // fields with few unique rows (tiny vocabularies: every segment is long) spread ONE row per wave over the
   // field's wpf waves instead of 16 rows on the first wave; group 0 then owns the row, all groups cooperate
   const bool spread = nu <= wpf;
   const int j0 = spread ? wf : wf * GPW;
-  if (j0 >= nu) return;  // wave-uniform
+  if (j0 >= nu) return false;  // wave-uniform
   const int j = spread ? j0 : j0 + g;
-  const bool valid = spread ? g == 0 : j < nu;
-  const size_t sl = (size_t)f * stride + (valid ? j : j0);
+  valid = spread ? g == 0 : j < nu;
+  sl = (size_t)f * stride + (valid ? j : j0);
   const int beg = valid ? seg_off[(size_t)f * (stride + 1) + j] : 0;
   int end = valid ? seg_off[(size_t)f * (stride + 1) + j + 1] : 0;
+  row = valid ? uniq_row[sl] : 0;
   // null_row: a padding row whose per-entry gradients are exactly zero by construction (DIN history padding id 0,
   // din/din.py:107): its (possibly huge) segment is not walked, G = 0 is written -- the same value the sum would give
-  if (valid && null_row >= 0 && uniq_row[sl] == null_row) end = beg;
+  if (valid && null_row >= 0 && row == null_row) end = beg;
   const int L = end - beg;
   SegCtx<LPR> c;
   c.S4 = reinterpret_cast<const float4*>(S);
@@ -160,11 +164,12 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   c.f = f;
   c.q = q;
   c.do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
+  do1 = c.do1;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 e = z;
-  if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)uniq_row[sl] * LPR + q];
-  float4 acc = z;
-  float a1 = 0.f;
+  e = z;
+  if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+  acc = z;
+  a1 = 0.f;
   const int short_len = spread ? 2 : SEG_SHORT;   // a spread wave has 15 idle groups: cooperate on anything > 2
   if (valid && L <= short_len) seg_range_sum<LPR>(c, e, beg, end, acc, a1);
   unsigned long long todo = __ballot(valid && L > short_len && q == 0);
@@ -192,9 +197,91 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
       a1 = t1;
     }
   }
+  return true;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ tables, const float* __restrict__ S,
+                                                    const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                    const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                    const int32_t* __restrict__ seg_off,
+                                                    const int32_t* __restrict__ uniq_row,
+                                                    const int32_t* __restrict__ nuniq, float* __restrict__ G,
+                                                    float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
+                                                    int stride, int null_row) {
+  constexpr int LPR = D / 4;
+  const int q = (threadIdx.x & 63) % LPR;
+  bool valid, do1;
+  size_t sl;
+  float4 acc, e;
+  float a1;
+  int row;
+  if (!segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
+                      nuniq, w1_mask, B, F, stride, null_row, valid, sl, acc, a1, e, row, do1))
+    return;
   if (valid) {
     reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
-    if (gw1 != nullptr && q == 0) gw1[sl] = c.do1 ? a1 : 0.f;
+    if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
+  }
+}
+
+// Segment-sum fused with the touched-row half of the exact TF-1 Adam update (the untouched rows are swept by COLD
+// slices): the group that owns unique row (f, j) has its summed gradient in registers and is the only reader/writer
+// of that row, so it applies   m = m*b1 + g(1-b1); v = v*b2 + g*g(1-b2); var -= (alpha*m)/(sqrt(v)+eps)   at once --
+// no G round trip, no separate launch.  The first-order vector uses the ApplyAdam (dense) formula.  Extra
+// workgroups carry the dense-variable segment; the last workgroup to finish advances the beta powers.
+struct HotAdam {
+  float* tables; float* m_t; float* v_t;
+  float* w1; float* m_w; float* v_w;     // nullable
+  float lr, b1, b2, eps;
+  float* state;
+  uint32_t n_own, total_blocks;
+  AdamSlice extra;                       // dense variables (any non-COLD kinds), n_blk may be 0
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S, const float* __restrict__ dX,
+                                                     const float* __restrict__ gy1, const float* __restrict__ gy2,
+                                                     const int32_t* __restrict__ perm, const int32_t* __restrict__ seg_off,
+                                                     const int32_t* __restrict__ uniq_row,
+                                                     const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F,
+                                                     int stride, const HotAdam h) {
+  constexpr int LPR = D / 4;
+  const float b1p = h.state[0], b2p = h.state[1];
+  if (blockIdx.x >= h.n_own) {
+    adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - h.n_own));
+  } else {
+    const int q = (threadIdx.x & 63) % LPR;
+    bool valid, do1;
+    size_t sl;
+    float4 acc, e;
+    float a1;
+    int row;
+    if (segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
+                       nuniq, w1_mask, B, F, stride, -1, valid, sl, acc, a1, e, row, do1) && valid) {
+      Hp hp;
+      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
+      hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      const size_t o = (size_t)row * LPR + q;
+      float4 var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(h.tables)[o];
+      float4 m = reinterpret_cast<const float4*>(h.m_t)[o], v = reinterpret_cast<const float4*>(h.v_t)[o];
+      F4_APPLY(adam_sparse1, var, m, v, acc, true, hp);
+      reinterpret_cast<float4*>(h.tables)[o] = var;
+      reinterpret_cast<float4*>(h.m_t)[o] = m;
+      reinterpret_cast<float4*>(h.v_t)[o] = v;
+      if (h.w1 != nullptr && q == 0) adam_dense1(h.w1[row], h.m_w[row], h.v_w[row], do1 ? a1 : 0.f, hp);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(h.state + 2);
+    const uint32_t t = atomicAdd(ticket, 1u);
+    if (t == h.total_blocks - 1u) {
+      h.state[0] = b1p * h.b1;
+      h.state[1] = b2p * h.b2;
+      *ticket = 0u;
+      reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
+    }
   }
 }
 
@@ -250,7 +337,7 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
   SortArgs a{ids, row_off, perm, seg_off, uniq_row, nuniq, slot, B, F, stride, 0, 0};
   int n = 128;
   while (n < B) n <<= 1;
-  const int T = (n >> 1) < 1024 ? (n >> 1) : 1024;
+  const int T = n <= 512 ? n : ((n >> 1) < 1024 ? (n >> 1) : 1024);   // n <= 512: one thread per key (rank sort)
   const int rc = rsx_sort_args(a, max_rows_per_field, T);
   if (rc != RSX_OK) return rc;
   const size_t lds = ((size_t)a.n + 32) * sizeof(uint32_t);
@@ -283,6 +370,46 @@ extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* 
                               uint64_t w1_field_mask, int B, int F, int D, int stride, rsx_stream_t stream) {
   return segsum_impl(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, w1_field_mask, B, F, D, stride, -1,
                      stream);
+}
+
+template <int D>
+static void launch_segsum_adam(dim3 grid, dim3 block, hipStream_t st, const float* S, const float* dX, const float* gy1,
+                               const float* gy2, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                               const int32_t* nuniq, uint64_t mask, int B, int F, int stride, const HotAdam& h) {
+  segsum_adam_k<D><<<grid, block, 0, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h);
+}
+
+extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w,
+                                    const float* S, const float* dX, const float* gy1, const float* gy2,
+                                    const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                                    const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
+                                    const rsx_adam_seg* extra_segs_h, int n_extra, float* state, float lr, float beta1,
+                                    float beta2, float eps, rsx_stream_t stream) {
+  if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
+      stride < B || !d_ok(D))
+    return RSX_EINVAL;
+  if (gy2 != nullptr && S == nullptr) return RSX_EINVAL;
+  if ((gy1 != nullptr) != (w1 != nullptr)) return RSX_EINVAL;
+  if (w1 != nullptr && (!m_w || !v_w)) return RSX_EINVAL;
+  HotAdam h;
+  h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
+  h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state;
+  h.extra.n_blk = 0; h.extra.blk_lo = 0;
+  if (n_extra > 0) {
+    uint32_t blocks = 0;
+    const int rc = adam_build_args(extra_segs_h, n_extra, state, lr, beta1, beta2, eps, h.extra.args, &blocks);
+    if (rc != RSX_OK) return rc;
+    h.extra.n_blk = blocks;
+  }
+  const int gpw = 64 / (D / 4);
+  const long long waves = (long long)F * ((B + gpw - 1) / gpw);
+  h.n_own = (uint32_t)((waves + 3) / 4);
+  h.total_blocks = h.n_own + h.extra.n_blk;
+  const dim3 grid(h.total_blocks), block(256);
+  RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,
+                 w1_field_mask, B, F, stride, h);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
 }
 
 extern "C" int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,

@@ -30,19 +30,35 @@ __device__ __forceinline__ void field_sort_block(const SortArgs& a, int f, uint3
   for (int i = tid; i < n; i += T)
     key[i] = i < B ? (((uint32_t)a.ids[(size_t)i * a.F + f] << bbits) | (uint32_t)i) : 0xFFFFFFFFu;
   __syncthreads();
-  for (int k = 2; k <= n; k <<= 1) {
-    for (int jst = k >> 1; jst > 0; jst >>= 1) {
-      for (int t = tid; t < (n >> 1); t += T) {
-        const int i = ((t & ~(jst - 1)) << 1) | (t & (jst - 1));
-        const int l = i | jst;
-        const uint32_t x = key[i], c = key[l];
-        const bool up = (i & k) == 0;
-        if ((x > c) == up) {
-          key[i] = c;
-          key[l] = x;
+  if (n <= 512 && n <= T) {
+    // small batches: rank sort.  Keys are unique, so rank = #{keys smaller than mine}; every thread scans the n keys
+    // with broadcast LDS reads (4 per ds_read_b128) -- n/4 iterations, NO barriers, vs 36+ barrier-separated bitonic
+    // stages.  n <= 512 keeps the O(n^2) compare count below the bitonic latency.
+    const uint32_t mine = tid < n ? key[tid] : 0xFFFFFFFFu;
+    int rank = 0;
+    const uint4* k4 = reinterpret_cast<const uint4*>(key);
+    for (int i = 0; i < (n >> 2); ++i) {
+      const uint4 q = k4[i];
+      rank += (q.x < mine) + (q.y < mine) + (q.z < mine) + (q.w < mine);
+    }
+    __syncthreads();
+    if (tid < n) key[rank] = mine;     // real keys land on 0..B-1; the equal padding keys all write slot B (never read)
+    __syncthreads();
+  } else {
+    for (int k = 2; k <= n; k <<= 1) {
+      for (int jst = k >> 1; jst > 0; jst >>= 1) {
+        for (int t = tid; t < (n >> 1); t += T) {
+          const int i = ((t & ~(jst - 1)) << 1) | (t & (jst - 1));
+          const int l = i | jst;
+          const uint32_t x = key[i], c = key[l];
+          const bool up = (i & k) == 0;
+          if ((x > c) == up) {
+            key[i] = c;
+            key[l] = x;
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   // head flags + exclusive scan -> unique index j of every sorted position

@@ -139,11 +139,11 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 arena.field_sort(idsg)
                 arena.segsum(dXg.shape[0], Sg, dXg, gy1g, gy2g)
                 dp.all_reduce_sum(store.dense.grad)
+                store.apply_gradients()
+            elif hot is not None:    # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
+                arena.segsum_adam(ids.shape[0], S, dX, gy1, gy2, store.opt, store.dense.adam_segments())
             else:
                 arena.segsum(ids.shape[0], S, dX, gy1, gy2)
-            if hot is not None:
-                store.opt.step(hot + store.dense.adam_segments())     # touched rows + dense; advances the beta powers
-            else:
                 store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
