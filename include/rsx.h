@@ -72,6 +72,17 @@ int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_o
 int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
                    int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int max_rows_per_field,
                    int B, int F, int stride, rsx_stream_t stream);
+/* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
+typedef struct {
+  const int32_t* ids;
+  const int32_t* row_off;
+  int32_t* perm;
+  int32_t* seg_off;
+  int32_t* uniq_row;
+  int32_t* nuniq;
+  int32_t* slot;
+  int32_t max_rows_per_field, B, F, stride;
+} rsx_sort_job;
 
 /* Row-wise gradient "scatter" as a sorted segment-sum (replaces the IndexedSlices gradient of the
  * gather + tf.unsorted_segment_sum, Appendix A-4): for unique row (f, j)
@@ -175,8 +186,8 @@ int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_t stream);
 int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out, double* fstat_out,
                         const double* fstat_prev, const float* gamma_prev, const float* beta_prev,
                         const float* mask_prev, float* bn_prev_out, const uint32_t* rng_step, uint32_t seed,
-                        int layer, float dropout_rate, int B, int K, int N, const rsx_adam_slice* sweep_h,
-                        rsx_stream_t stream);
+                        int layer, float dropout_rate, int B, int K, int N, const rsx_sort_job* sort_h,
+                        const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 /* o = dropout(BN(a_last)); u = o.wd + bd; z = wo[0]*act0(s0+c0) + wo[1]*s1 + wo[2]*act2(u) + bo (wo NULL: plain sum);
  * prob = sigmoid(z); per-row-tile partials of the loss and of every head gradient; dy_last / bstat_last = gradient
  * wrt the last BN output; gs0 / gs1 = d loss / d s0, d s1.  loss_scale = 1/(B*replicas).                    */
@@ -187,17 +198,6 @@ int rsx_tower_head(const float* a_last, const double* fstat_last, const float* g
                    float* gs1, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate,
                    float loss_scale, int relu0, int relu2, int B, int N, const rsx_adam_slice* sweep_h,
                    rsx_stream_t stream);
-/* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
-typedef struct {
-  const int32_t* ids;
-  const int32_t* row_off;
-  int32_t* perm;
-  int32_t* seg_off;
-  int32_t* uniq_row;
-  int32_t* nuniq;
-  int32_t* slot;
-  int32_t max_rows_per_field, B, F, stride;
-} rsx_sort_job;
 /* Backward of layer l: BN backward + relu mask on load; writes dW, db, dgamma, dbeta, and dy_prev = gradient wrt
  * the previous layer's BN output (+ its bstat_prev partials), or dX for the first layer (bn_prev == NULL).
  * With hpart != NULL (last layer) one extra workgroup reduces the head partials into dwd, dbd, dwo[3], dbo, dc0, loss. */

@@ -146,13 +146,19 @@ struct FwdArgs {
   float rate;
   int B, K, N, RT;
   int ct, n_own;          // column tiles; ct * row tiles = workgroups of the layer itself
+  int n_sort;             // extra workgroups running the step's per-field dedup sort (0: none), before the sweep slice
+  SortArgs sort;
   AdamSlice sweep;        // optional slice of the untouched-row optimizer sweep carried as extra workgroups
 };
 
 __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x >= p.n_own) {
-    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
+  if ((int)blockIdx.x >= p.n_own + p.n_sort) {
+    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
+    return;
+  }
+  if ((int)blockIdx.x >= p.n_own) {   // piggy-backed dedup sort (ids only; first consumed by later launches)
+    field_sort_block(p.sort, blockIdx.x - p.n_own, reinterpret_cast<uint32_t*>(lds));
     return;
   }
   const int bx = blockIdx.x % p.ct, by = blockIdx.x / p.ct;
@@ -631,6 +637,20 @@ __global__ __launch_bounds__(64) void tower_reduce_partials_k(double* __restrict
   st[c] = s;
 }
 
+// validates a piggy-backed sort job for a 256-thread carrier launch and grows the launch's dynamic LDS if needed
+static inline int sort_job_args(const rsx_sort_job& j, SortArgs& out, size_t* lds) {
+  if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
+      j.stride < j.B || j.max_rows_per_field <= 0)
+    return RSX_EINVAL;
+  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.B, j.F, j.stride, 0, 0};
+  const int rc = rsx_sort_args(out, j.max_rows_per_field, 256);
+  if (rc != RSX_OK) return rc;
+  const size_t need = ((size_t)out.n + 32) * sizeof(uint32_t);
+  if (need > 64 * 1024) return RSX_EUNSUPPORTED;
+  if (need > *lds) *lds = need;
+  return RSX_OK;
+}
+
 // consumers read pre-reduced statistics (1 row) when the batch is large: see rsx_tower_reduce_partials
 static inline int stat_rows(int B) { return B > 512 ? 1 : (B + TM - 1) / TM; }
 
@@ -649,7 +669,8 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
                                    double* fstat_out, const double* fstat_prev, const float* gamma_prev,
                                    const float* beta_prev, const float* mask_prev, float* bn_prev_out,
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                                   int K, int N, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+                                   int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
+                                   rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !bias || !a_out) return RSX_EINVAL;
@@ -667,8 +688,14 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   p.n_own = p.ct * ((B + TM - 1) / TM);
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
-  hipLaunchKernelGGL(tower_fwd_k, dim3(p.n_own + p.sweep.n_blk), dim3(256), ((size_t)2 * K + 1024 + 256) * sizeof(float),
-                     rsx_s(stream), p);
+  size_t lds = ((size_t)2 * K + 1024 + 256) * sizeof(float);
+  p.n_sort = 0;
+  if (sort_h != nullptr) {
+    const int rc = sort_job_args(*sort_h, p.sort, &lds);
+    if (rc != RSX_OK) return rc;
+    p.n_sort = sort_h->F;
+  }
+  hipLaunchKernelGGL(tower_fwd_k, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -740,17 +767,9 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.n_sort = 0;
   size_t lds = ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float);
   if (sort_h != nullptr) {
-    const rsx_sort_job& j = *sort_h;
-    if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
-        j.stride < j.B || j.max_rows_per_field <= 0)
-      return RSX_EINVAL;
-    p.sort = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.B, j.F, j.stride, 0, 0};
-    const int rc = rsx_sort_args(p.sort, j.max_rows_per_field, 256);
+    const int rc = sort_job_args(*sort_h, p.sort, &lds);
     if (rc != RSX_OK) return rc;
-    const size_t need = ((size_t)p.sort.n + 32) * sizeof(uint32_t);
-    if (need > 64 * 1024) return RSX_EUNSUPPORTED;
-    if (need > lds) lds = need;
-    p.n_sort = j.F;
+    p.n_sort = sort_h->F;
   }
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;

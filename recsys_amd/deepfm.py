@@ -7,6 +7,7 @@ mode, params)`, `main`.  The embedding gather + first-order + FM term, the row-w
 and the TF-1 Adam sweep are librsx.so kernels; the 624-100-100-1 tower is rocBLAS via torch.
 """
 import argparse
+import os
 
 import torch
 
@@ -66,7 +67,9 @@ def build_variables(store, params, capacity, with_dnn=True):
         from .ops import FusedTower
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0] ~ their stand-alone durations
-        store.sweep_weights = params.get("sweep_weights") or ([1.0] * len(layers) + [2.0] + [2.5] * len(layers))
+        env = os.environ.get("RSX_SWEEP_WEIGHTS")
+        store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
+                                                              [0.0] * len(layers) + [2.0] + [3.0] * len(layers))
 
 
 def model_fn(features, labels, mode, params):
@@ -120,16 +123,17 @@ def _train_fused(store, arena, ids, labels, params, masks):
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
             # workgroups, filling the CUs the latency-bound tower leaves idle; touched rows + dense follow the scatter.
-            arena.field_sort(ids)
+            job = arena.sort_job(ids)                  # rides in the first tower-forward launch
             cold, hot = arena.adam_split_segments()
             sweeps = store.opt.cold_slices(cold, store.sweep_weights)
+            assert sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
         elif dp is None:
             job = arena.sort_job(ids)
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
-            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job, sweeps=sweeps)
+            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job, sweeps=sweeps, sort_in_fwd=overlap)
 
     def train_op():
         with torch.no_grad():

@@ -348,10 +348,11 @@ class FusedTower:
 
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
-                   seed=0x5eed, sort_job=None, sweeps=None):
+                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
-        sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch.
+        sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
+        FIRST layer's forward launch when sort_in_fwd (required when sweeps are used: they read its slot map).
         sweeps = 2L+1 rsx_adam_slice structs (or None) for [fwd_0..fwd_{L-1}, head, bwd_{L-1}..bwd_0]: slices of the
         untouched-row optimizer sweep that ride along as extra workgroups (AdamTF1.cold_slices).
         Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
@@ -373,7 +374,9 @@ class FusedTower:
                                         _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
                                         _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
                                         _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
-                                        rs, seed, l, rate, B, K, self.widths[l], ref(sw[l]), st), "rsx_tower_fwd_layer")
+                                        rs, seed, l, rate, B, K, self.widths[l],
+                                        ref(sort_job) if (l == 0 and sort_in_fwd) else None, ref(sw[l]), st),
+                  "rsx_tower_fwd_layer")
             check(L.rsx_tower_reduce_partials(_ptr(self.fstat[l]), B, self.widths[l], st))      # no-op for B <= 512
         # head parameters: a variable name, or an explicit (tensor, grad_tensor) pair (e.g. a slice of out.W)
         pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
@@ -402,7 +405,8 @@ class FusedTower:
                 _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
                 _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
-                rs, seed, l, rate, B, K, self.widths[l], C.byref(sort_job) if (last and sort_job is not None) else None,
+                rs, seed, l, rate, B, K, self.widths[l],
+                C.byref(sort_job) if (last and sort_job is not None and not sort_in_fwd) else None,
                 ref(sw[nl + 1 + (nl - 1 - l)]), st), "rsx_tower_bwd_layer")
             if l:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
