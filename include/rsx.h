@@ -157,12 +157,14 @@ int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg);
 /* rsx_segsum_bwd fused with the touched-row half of the split update: the group that sums the gradient of unique row
  * (f, j) applies the TABLE_ROWS (and VEC_ROWS_DENSE for w1) update to it at once; `extra_segs_h` (e.g. the DENSE segment)
  * ride along as extra workgroups and the last workgroup advances the beta powers.  Replaces
- * rsx_segsum_bwd + rsx_adam_tf1_multi(TABLE_ROWS, VEC_ROWS_DENSE, DENSE) with identical arithmetic.                */
+ * rsx_segsum_bwd + rsx_adam_tf1_multi(TABLE_ROWS, VEC_ROWS_DENSE, DENSE) with identical arithmetic.  sweep_h
+ * (nullable) may carry TABLE_TF1_COLD segments only: a VEC_COLD slice restores touched elements of its float4s and
+ * would race with this launch's own update of them (RSX_EINVAL).                                                */
 int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w, const float* S,
                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
-                         int stride, const rsx_adam_seg* extra_segs_h, int n_extra, float* state, float lr, float beta1,
-                         float beta2, float eps, rsx_stream_t stream);
+                         int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
+                         float* state, float lr, float beta1, float beta2, float eps, rsx_stream_t stream);
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -237,6 +237,7 @@ struct HotAdam {
   float* state;
   uint32_t n_own, total_blocks;
   AdamSlice extra;                       // dense variables (any non-COLD kinds), n_blk may be 0
+  AdamSlice cold;                        // optional slice of the untouched-row sweep (rows disjoint from the touched ones)
 };
 
 template <int D>
@@ -248,7 +249,9 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
                                                      int stride, const HotAdam h) {
   constexpr int LPR = D / 4;
   const float b1p = h.state[0], b2p = h.state[1];
-  if (blockIdx.x >= h.n_own) {
+  if (blockIdx.x >= h.n_own + h.extra.n_blk) {
+    adam_block(h.cold.args, h.cold.blk_lo + (blockIdx.x - h.n_own - h.extra.n_blk));
+  } else if (blockIdx.x >= h.n_own) {
     adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - h.n_own));
   } else {
     const int q = (threadIdx.x & 63) % LPR;
@@ -383,8 +386,8 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const float* S, const float* dX, const float* gy1, const float* gy2,
                                     const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
-                                    const rsx_adam_seg* extra_segs_h, int n_extra, float* state, float lr, float beta1,
-                                    float beta2, float eps, rsx_stream_t stream) {
+                                    const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
+                                    float* state, float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
@@ -404,7 +407,13 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   const int gpw = 64 / (D / 4);
   const long long waves = (long long)F * ((B + gpw - 1) / gpw);
   h.n_own = (uint32_t)((waves + 3) / 4);
-  h.total_blocks = h.n_own + h.extra.n_blk;
+  const int rcs = adam_build_slice(sweep_h, h.cold);
+  if (rcs != RSX_OK) return rcs;
+  // A VEC_COLD slice rewrites (restores) the touched elements of its float4s: racing with this launch's own update of
+  // those elements.  Only table slices (whole touched rows are skipped, never written) may ride here.
+  for (int k = 0; h.cold.n_blk != 0 && k < h.cold.args.nseg; ++k)
+    if (h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
+  h.total_blocks = h.n_own + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,
                  w1_field_mask, B, F, stride, h);

@@ -118,14 +118,16 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # the ids-only dedup sort rides along in the tower-backward launch (extra workgroups): off the critical path.
         # (A side HIP stream was measured instead: inside a graph the fork/join across HW queues costs ~10 us each way.)
         overlap = dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        job, sweeps, hot = None, None, None
+        job, sweeps, hot, last_sweep = None, None, None, None
         if overlap:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
             # workgroups, filling the CUs the latency-bound tower leaves idle; touched rows + dense follow the scatter.
             job = arena.sort_job(ids)                  # rides in the first tower-forward launch
             cold, hot = arena.adam_split_segments()
-            sweeps = store.opt.cold_slices(cold, store.sweep_weights)
+            sweeps = store.opt.cold_slices(cold, store.sweep_weights)      # [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
+            last_sweep = sweeps[-1] if len(sweeps) == 2 * len(store.tower.widths) + 2 else None
+            sweeps = sweeps[:2 * len(store.tower.widths) + 1]
             assert sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
         elif dp is None:
             job = arena.sort_job(ids)
@@ -145,7 +147,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 dp.all_reduce_sum(store.dense.grad)
                 store.apply_gradients()
             elif hot is not None:    # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
-                arena.segsum_adam(ids.shape[0], S, dX, gy1, gy2, store.opt, store.dense.adam_segments())
+                arena.segsum_adam(ids.shape[0], S, dX, gy1, gy2, store.opt, store.dense.adam_segments(), last_sweep)
             else:
                 arena.segsum(ids.shape[0], S, dX, gy1, gy2)
                 store.apply_gradients()

@@ -112,7 +112,7 @@ class EmbeddingArena:
                                    _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
                                    self.stride, _stream()), "rsx_segsum_bwd")
 
-    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments):
+    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups)."""
         arr, n = opt._seg_array(extra_segments)
         lr, b1, b2, eps = opt.hp
@@ -121,6 +121,7 @@ class EmbeddingArena:
                                          _ptr(self.m_w) if w else None, _ptr(self.v_w) if w else None, _ptr(S), _ptr(dX),
                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
+                                         None if sweep is None else C.byref(sweep),
                                          _ptr(opt.state), lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
 
     # -- optimizer segments ----------------------------------------------------------------
