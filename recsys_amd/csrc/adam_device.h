@@ -48,8 +48,14 @@ __device__ __forceinline__ void adam_dense1(float& var, float& m, float& v, floa
   FN(VAR.z, M.z, V.z, G.z, __VA_ARGS__);  \
   FN(VAR.w, M.w, V.w, G.w, __VA_ARGS__)
 
-constexpr int ADAM_T = 256;    // threads per workgroup
-constexpr int ADAM_U = 4;      // float4 per lane
+#ifndef RSX_ADAM_U
+#define RSX_ADAM_U 8
+#endif
+#ifndef RSX_ADAM_NT
+#define RSX_ADAM_NT 0
+#endif
+constexpr int ADAM_T = 256;         // threads per workgroup
+constexpr int ADAM_U = RSX_ADAM_U;  // float4 per lane
 constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
 
 // One workgroup (ADAM_T = 256 threads) of the sweep: block `blk` of the launch-wide block index space of `a`.
@@ -86,13 +92,24 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         const int q = (int)(e - row * lpr);
         const int sl = s.slot[row];
         if (cold_only && sl >= 0) continue;
+#if RSX_ADAM_NT
+        float4 var = __builtin_nontemporal_load(&var4[e]), m = __builtin_nontemporal_load(&m4[e]),
+               v = __builtin_nontemporal_load(&v4[e]);
+#else
         float4 var = var4[e], m = m4[e], v = v4[e];
+#endif
         const bool has = sl >= 0;
         const float4 g = has ? G4[(long long)sl * lpr + q] : z4;
         F4_APPLY(adam_sparse1, var, m, v, g, has, h);
+#if RSX_ADAM_NT
+        __builtin_nontemporal_store(var, &var4[e]);
+        __builtin_nontemporal_store(m, &m4[e]);
+        __builtin_nontemporal_store(v, &v4[e]);
+#else
         var4[e] = var;
         m4[e] = m;
         v4[e] = v;
+#endif
       }
     }
   } else if (s.kind == RSX_ADAM_DENSE) {

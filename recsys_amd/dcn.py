@@ -52,6 +52,7 @@ def build_variables(store, params, capacity):
     store.tower = None
     if params.get("tower", "hip") == "hip":
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
+        store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
 
 def _train_fused(store, arena, ids, labels, params, masks):

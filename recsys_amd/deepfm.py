@@ -66,6 +66,7 @@ def build_variables(store, params, capacity, with_dnn=True):
     if with_dnn and params.get("tower", "hip") == "hip":
         from .ops import FusedTower
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
+        store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0] ~ their stand-alone durations
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
         store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
@@ -113,25 +114,24 @@ def _train_fused(store, arena, ids, labels, params, masks):
     (fwd, head+loss, bwd) -> [train_op:] sorted segment-sum -> one Adam sweep.  9 launches + 1 mask fill."""
     dp = store.dp
     with torch.no_grad():
-        # The ids-only sort could run on a side stream, but inside a HIP graph the fork/join across HW queues costs
-        # ~10 us each way on this stack (profiles/r01_*), more than the 9 us it hides: keep it in-stream.
-        # the ids-only dedup sort rides along in the tower-backward launch (extra workgroups): off the critical path.
-        # (A side HIP stream was measured instead: inside a graph the fork/join across HW queues costs ~10 us each way.)
-        overlap = dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        job, sweeps, hot, last_sweep = None, None, None, None
+        # The ids-only dedup sort rides in the first tower-forward launch as extra workgroups.  (A side HIP stream was
+        # measured instead: inside a graph the fork/join across HW queues costs ~10 us each way, more than it hides.)
+        overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
+        # data-parallel: the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices), so the
+        # dedup sort runs over the all-gathered ids -- a 40 KB collective issued right after the local gather launch
+        ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
+        job = arena.sort_job(ids_sort)
+        sweeps, hot, last_sweep = None, None, None
         if overlap:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
             # workgroups, filling the CUs the latency-bound tower leaves idle; touched rows + dense follow the scatter.
-            job = arena.sort_job(ids)                  # rides in the first tower-forward launch
             cold, hot = arena.adam_split_segments()
             sweeps = store.opt.cold_slices(cold, store.sweep_weights)      # [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
             last_sweep = sweeps[-1] if len(sweeps) == 2 * len(store.tower.widths) + 2 else None
             sweeps = sweeps[:2 * len(store.tower.widths) + 1]
             assert sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
-        elif dp is None:
-            job = arena.sort_job(ids)
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
@@ -139,17 +139,14 @@ def _train_fused(store, arena, ids, labels, params, masks):
 
     def train_op():
         with torch.no_grad():
-            store.join_sort()
-            if dp is not None:      # ONE packed all-gather (grad block + ids), then the global sort + segment-sum
-                dXg, Sg, gy1g, gy2g, idsg = dp.gather_example_grads(dX, S, gy1, gy2, ids=ids)
-                arena.field_sort(idsg)
-                arena.segsum(dXg.shape[0], Sg, dXg, gy1g, gy2g)
-                dp.all_reduce_sum(store.dense.grad)
-                store.apply_gradients()
-            elif hot is not None:    # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
-                arena.segsum_adam(ids.shape[0], S, dX, gy1, gy2, store.opt, store.dense.adam_segments(), last_sweep)
+            Sg, dXg, gy1g, gy2g = S, dX, gy1, gy2
+            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order)
+                dXg, Sg, gy1g, gy2g = dp.gather_example_grads(dX, S, gy1, gy2, dense=store.dense.grad)
+            Bg = dXg.shape[0]
+            if hot is not None:     # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
+                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, store.dense.adam_segments(), last_sweep)
             else:
-                arena.segsum(ids.shape[0], S, dX, gy1, gy2)
+                arena.segsum(Bg, Sg, dXg, gy1g, gy2g)
                 store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)

@@ -42,6 +42,71 @@ def init_process_group(backend=None):
     dist.init_process_group(backend)
 
 
+class SegmentedGraph:
+    """A training step captured as HIP-graph SEGMENTS with the RCCL collectives launched eagerly between them:
+    [graph | collective]* replayed in order on the current stream.  The compute stays launch-free (graphs) while
+    the collectives take RCCL's ordinary, un-captured path -- robust on every RCCL build, and the collectives' host
+    cost (a few us each) hides behind the previous segment's GPU time.  RSX_DP_CAPTURE=1 captures the collectives
+    into the graph instead (single segment).
+
+    Rule for code running under capture: a collective's input and output tensors must exist BEFORE the break (they
+    are then allocated from the graphs' shared private pool, so their addresses are the ones every replay uses)."""
+    _active = None
+
+    def __init__(self):
+        self.items = []                 # torch.cuda.CUDAGraph | callable
+        self._pool = None
+        self._ctx = None
+        self._graph = None
+
+    def _begin(self):
+        self._graph = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self._graph, pool=self._pool)
+        self._ctx.__enter__()
+
+    def _end(self):
+        self._ctx.__exit__(None, None, None)
+        if self._pool is None:
+            self._pool = self._graph.pool()
+        self.items.append(self._graph)
+        self._ctx = self._graph = None
+
+    def capture(self, fn):
+        """Runs fn() under capture (fn's collectives call graph_break); returns fn's result."""
+        assert SegmentedGraph._active is None
+        SegmentedGraph._active = self
+        self._begin()
+        try:
+            out = fn()
+        finally:
+            self._end()
+            SegmentedGraph._active = None
+        return out
+
+    def run_eager(self, op):
+        self._end()
+        op()
+        self.items.append(op)
+        self._begin()
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
+def graph_break(op):
+    """Run the collective `op` now; under a SegmentedGraph capture, end the current segment first and record `op` so
+    every replay re-issues it between the segments."""
+    seg = SegmentedGraph._active
+    if seg is None or os.environ.get("RSX_DP_CAPTURE") == "1":
+        op()
+    else:
+        seg.run_eager(op)
+
+
 class DataParallel:
     def __init__(self, group=None):
         assert dist.is_initialized(), "call recsys_amd.dist.init_process_group() first"
@@ -54,7 +119,7 @@ class DataParallel:
         """x [b, ...] on every rank (same b) -> [N*b, ...] in rank order."""
         x = x.contiguous()
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=self.group)
+        graph_break(lambda: dist.all_gather_into_tensor(out, x, group=self.group))
         return out
 
     # -- sparse gradient block ----------------------------------------------------------------
@@ -67,23 +132,46 @@ class DataParallel:
             w += [("gy1", 1)]
         return w
 
-    def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None):
+    def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None, dense=None):
         """Packs the per-example gradient block, all-gathers it once, and returns the global views
         dX_g [N*b, F*D], S_g [N*b, D]|None, gy1_g [N*b]|None, gy2_g [N*b]|None (contiguous).
         ids (int32 [b,F], optional) ride in the same block -> a 5th return value ids_g [N*b,F]: one collective per
         step instead of two.  The block travels as int32 BITS (floats bit-cast to int32, never the reverse): small
-        integer ids viewed as fp32 are subnormals, which float copy kernels may flush to zero."""
-        b = dX.shape[0]
+        integer ids viewed as fp32 are subnormals, which float copy kernels may flush to zero.
+        dense (flat fp32 [n], optional): this replica's dense-gradient arena rides behind the example block and is
+        summed over replicas IN PLACE, in rank order on every rank (bit-identical replicas) -- the dense all-reduce
+        folded into the same collective: the step is latency-bound, so one collective beats two."""
+        b, N = dX.shape[0], self.world
         parts = [dX]
         if gy2 is not None:
             parts += [S, gy2.reshape(b, 1)]
         if gy1 is not None:
             parts += [gy1.reshape(b, 1)]
         if ids is not None:
+            assert dense is None
             parts = [p.contiguous().view(torch.int32) for p in parts] + [ids.contiguous()]
             g = self.all_gather_rows(torch.cat(parts, 1))
             gi = g
             g = g.view(torch.float32)
+        elif dense is not None:
+            W = sum(p.shape[1] for p in parts)
+            out = self.all_gather_rows(torch.cat([p.reshape(-1) for p in parts] + [dense]).view(1, -1))   # [N, L+n]
+            torch.sum(out[:, -dense.numel():], 0, out=dense)
+            # per-rank block = the parts back to back, each [b, w_i] row-major
+            res, o = [], 0
+            for p in parts:
+                w = p.shape[1]
+                res.append(out[:, o:o + b * w].reshape(N * b, w))
+                o += b * w
+            dX_g = res[0]
+            S_g = gy2_g = gy1_g = None
+            k = 1
+            if gy2 is not None:
+                S_g, gy2_g = res[1], res[2].reshape(-1)
+                k = 3
+            if gy1 is not None:
+                gy1_g = res[k].reshape(-1)
+            return dX_g, S_g, gy1_g, gy2_g
         else:
             pack = torch.cat(parts, 1) if len(parts) > 1 else dX
             g = self.all_gather_rows(pack)
@@ -104,7 +192,7 @@ class DataParallel:
 
     # -- dense gradients ------------------------------------------------------------------------
     def all_reduce_sum(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        graph_break(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
         return flat
 
     def barrier(self):

@@ -129,6 +129,7 @@ class VariableStore:
         self.adam_mode = adam_mode
         self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
         self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
+        self.graph_safe_dp = False   # set by model code whose DP collectives run outside autograd (segmentable)
         self.side_stream = None      # the ids-only dedup sort runs here, concurrent with the forward pass
 
     def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr):
@@ -250,6 +251,26 @@ class Estimator:
         # this stream) alive into the next step, which breaks HIP-graph capture on the capture stream
         return spec.loss.detach()
 
+    def _use_graph(self):
+        """HIP graphs are on unless the step has data-parallel collectives issued from inside autograd's backward
+        (worker thread: the capture cannot be segmented there); RSX_DP_CAPTURE=1 captures the collectives too."""
+        if not self.config.use_hip_graph:
+            return False
+        return self.store.dp is None or self.store.graph_safe_dp or os.environ.get("RSX_DP_CAPTURE") == "1"
+
+    def _capture(self, fn):
+        """-> (replayable, fn's result).  Data-parallel steps become graph segments with eager RCCL calls between
+        them (dist.SegmentedGraph); single-process steps one HIP graph."""
+        torch.cuda.synchronize()
+        if self.store.dp is not None and os.environ.get("RSX_DP_CAPTURE") != "1":
+            from .dist import SegmentedGraph
+            seg = SegmentedGraph()
+            return seg, seg.capture(fn)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fn()
+        return graph, out
+
     def _shape_key(self, features, labels):
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items())) + (tuple(labels.shape),)
 
@@ -258,7 +279,7 @@ class Estimator:
         `features` may be a PackedBatch (then one copy feeds the graph's static input buffer)."""
         if isinstance(features, PackedBatch):
             return self._train_step_packed(features)
-        if not self.config.use_hip_graph:
+        if not self._use_graph():
             return self._train_eager(features, labels)
         key = self._shape_key(features, labels)
         g = self._graphs.get(key)
@@ -271,10 +292,7 @@ class Estimator:
                 return self._train_eager(features, labels)
             g["feat"] = {k: v.clone() for k, v in features.items()}
             g["lab"] = labels.clone()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g["loss"] = self._train_eager(g["feat"], g["lab"])
+            graph, g["loss"] = self._capture(lambda: self._train_eager(g["feat"], g["lab"]))
             g["graph"] = graph      # capture executes nothing: the static buffers already hold this
             graph.replay()          # batch (cloned above), so replay once to apply its step
             return g["loss"]
@@ -287,7 +305,7 @@ class Estimator:
     def _train_step_packed(self, pb):
         if pb.flat.device != self.store.device:
             pb = pb.to(self.store.device)
-        if not self.config.use_hip_graph:
+        if not self._use_graph():
             return self._train_eager(*pb.views())
         key = ("packed",) + pb.key()
         g = self._graphs.setdefault(key, {"warm": 0})
@@ -296,10 +314,7 @@ class Estimator:
                 g["warm"] += 1
                 return self._train_eager(*pb.views())
             g["static"] = pb.clone()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g["loss"] = self._train_eager(*g["static"].views())
+            graph, g["loss"] = self._capture(lambda: self._train_eager(*g["static"].views()))
             g["graph"] = graph
             graph.replay()
             return g["loss"]
@@ -313,8 +328,9 @@ class Estimator:
         buffers directly: no per-step input copy and one graph launch per group ("capture launch-bound inner
         loops in hipGraphs").  An input pipeline refills the buffers in place between replays."""
         n = len(batches)
-        if not self.config.use_hip_graph or n % steps_per_graph != 0:
-            for s in range(steps):
+        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or \
+                (self.store.dp is not None and os.environ.get("RSX_DP_CAPTURE") != "1"):
+            for s in range(steps):          # data-parallel: per-step segmented graphs fed by one D2D copy
                 loss = self._train_step(batches[s % n])
             return loss
         key = ("resident", id(batches[0]), n, steps_per_graph)

@@ -68,6 +68,7 @@ def build_variables(store, params, capacity):
     store.layout = layout
     store.cin_sizes = cin
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
+    store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
 
 def _cin(X0, P, sizes):

@@ -58,7 +58,14 @@ def _worker(rank, world, port, out_dir):
                                                   torch.from_numpy(np.ascontiguousarray(gy2[:, 1])))
     names = sorted(g)
     flat = torch.from_numpy(np.concatenate([g[k].reshape(-1) for k in names]))
+    # the dense arena folded into the same collective (summed in rank order) == the separate all-reduce
+    flat2 = flat.clone()
+    r2 = dp.gather_example_grads(torch.from_numpy(dX), torch.from_numpy(S), torch.from_numpy(gy1),
+                                 torch.from_numpy(np.ascontiguousarray(gy2[:, 1])), dense=flat2)
     dp.all_reduce_sum(flat)
+    assert torch.allclose(flat2, flat, rtol=0, atol=1e-15)
+    for a_, b_ in zip(r2, (dXg, Sg, gy1g, gy2g)):
+        assert torch.equal(a_, b_)
     # --- global update from the gathered blocks (what every rank's HIP kernels would do) -------
     rws = ids_all.astype(np.int64) + off[None, :-1]
     dE = models.fm2_bwd(P["tables"][rws], Sg.numpy(), gy2g.numpy()) + dXg.numpy().reshape(-1, F, D)
