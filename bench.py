@@ -33,6 +33,8 @@ def parse():
     p.add_argument("--batch_size", type=int, default=256)
     p.add_argument("--adam_mode", default="tf1_dense", choices=["tf1_dense", "lazy_rows"])
     p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--emulate_world", type=int, default=0, help="profiling aid: time the per-rank COMPUTE of an N-GPU "
+                   "data-parallel step on one GPU (collectives replaced by local tiling; not a throughput claim)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_seconds", type=float, default=12.0)
     p.add_argument("--n_batches", type=int, default=64)
@@ -97,6 +99,9 @@ def main():
         dp.barrier()
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    emu = None
+    if a.emulate_world > 1 and dp is None:
+        emu = dist.EmulatedDataParallel(a.emulate_world)
 
     from recsys_amd import dcn, din, fm, xdeepfm
     from recsys_amd.estimator import PackedBatch
@@ -111,9 +116,9 @@ def main():
     mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[a.model]
     cfg = RunConfig(use_hip_graph=not a.no_graph, adam_mode=a.adam_mode, device=str(dev), seed=1234)
     est = Estimator(mfn, None, params, cfg)
-    if dp is not None:
-        est.store.dp = dp
-        est.dist = dp
+    if dp is not None or emu is not None:
+        est.store.dp = dp or emu
+        est.dist = dp or emu
     layout = CriteoLayout.from_columns(emb) if emb else None
     if a.model == "din":
         rng = np.random.default_rng(synthetic.SEED + rank)
@@ -214,7 +219,7 @@ def main():
                                                "xdeepfm": "Criteo-39 d=16 CIN 128,128 DNN 100-100",
                                                "din": "Amazon-Electronics-shaped hist_len=100 K=32"}[a.model], B,
                                      a.adam_mode, not a.no_graph, a.steps_per_graph),
-                      "global_batch": N * B, "parallelism": "dp%d" % N, "final_loss": round(final_loss, 5)},
+                      "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5)},
            "roofline": roof}
     if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":
         out["cpu_baseline"] = cpu_baseline(host, layout, a.cpu_seconds)

@@ -343,7 +343,12 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
   const int T = n <= 512 ? n : ((n >> 1) < 1024 ? (n >> 1) : 1024);   // n <= 512: one thread per key (rank sort)
   const int rc = rsx_sort_args(a, max_rows_per_field, T);
   if (rc != RSX_OK) return rc;
-  const size_t lds = ((size_t)a.n + 32) * sizeof(uint32_t);
+  const size_t lds = rsx_sort_lds_bytes(a, T);
+  if (lds > 64 * 1024) {     // opt in to the CU's full 160 KB LDS (B > 4096)
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(field_sort_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return RSX_EUNSUPPORTED;
+  }
   hipLaunchKernelGGL(field_sort_k, dim3(F), dim3(T), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -645,8 +645,8 @@ static inline int sort_job_args(const rsx_sort_job& j, SortArgs& out, size_t* ld
   out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.B, j.F, j.stride, 0, 0};
   const int rc = rsx_sort_args(out, j.max_rows_per_field, 256);
   if (rc != RSX_OK) return rc;
-  const size_t need = ((size_t)out.n + 32) * sizeof(uint32_t);
-  if (need > 64 * 1024) return RSX_EUNSUPPORTED;
+  const size_t need = rsx_sort_lds_bytes(out, 256);
+  if (need > 64 * 1024) return RSX_EUNSUPPORTED;         // carrier launches keep the default 64 KB window (B <= 4096)
   if (need > *lds) *lds = need;
   return RSX_OK;
 }

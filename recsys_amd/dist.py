@@ -199,6 +199,25 @@ class DataParallel:
         dist.barrier(group=self.group)
 
 
+class EmulatedDataParallel(DataParallel):
+    """PROFILING AID (bench.py --emulate_world N): one process plays N identical replicas -- all_gather_rows tiles the
+    local block N times, all_reduce_sum multiplies by N -- so the per-rank COMPUTE of an N-GPU step (global dedup
+    sort, scatter and Adam over N*b examples) can be timed on one GPU.  No collective latency is modelled."""
+
+    def __init__(self, world):
+        self.group, self.rank, self.world = None, 0, int(world)
+
+    def all_gather_rows(self, x):
+        x = x.contiguous()
+        return x.repeat((self.world,) + (1,) * (x.dim() - 1))
+
+    def all_reduce_sum(self, flat):
+        return flat.mul_(self.world)
+
+    def barrier(self):
+        pass
+
+
 def attach_if_distributed(estimator):
     """`--mirror` (fm/fm.py:36,184-186): data-parallel when launched with WORLD_SIZE > 1."""
     if not is_distributed_env():

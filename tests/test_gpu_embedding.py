@@ -49,7 +49,9 @@ def test_gather_empty_batch_and_masks():
     assert S is None and y2 is None
 
 
-@pytest.mark.parametrize("B,rows", [(256, None), (1, None), (100, (3, 7, 4, 11, 6)), (4096, (3, 1000, 50)), (1000, (2,))])
+@pytest.mark.parametrize("B,rows", [(256, None), (1, None), (100, (3, 7, 4, 11, 6)), (4096, (3, 1000, 50)), (1000, (2,)),
+                                    (600, (3, 1000, 50)), (2048, None), (5000, (1, 65536, 65537, 256, 257)),
+                                    (16384, (3, 100000, 257))])
 def test_field_sort_is_exact(B, rows):
     """Index work is bit-exact: sorted unique rows, segment boundaries, permutation, slot map."""
     rng = np.random.default_rng(B)
