@@ -63,15 +63,19 @@ int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_o
  *   nuniq    int32 [F]            number of unique ids of field f (zero-initialise once)
  *   slot     int32 [R]            row -> f*stride+j of this step, -1 elsewhere (initialise to -1 once;
  *                                 the kernel clears the previous step's entries itself)
+ *   segid    int32 [F*stride + 2F + F*ceil(stride/16)]  (optional, B > 512 only) two-stage segment-sum workspace:
+ *                                 unique index j of the segment holding sorted position i, then the per-field counts
+ *                                 and lists of the long (> 16 entries) and huge (> 256) segments
  * The sparse gradient lives at the same slot index: G[F*stride, D], gw1[F*stride].                 */
 /* Dedup stage of the sparse gradient (TF: unique() inside safe_embedding_lookup_sparse and
- * _apply_sparse_duplicate_indices): one workgroup per field does an LDS
- * bitonic sort of the composite key (id << log2B | b), flags segment heads and scans them.
- * Depends on ids only, so it may run on a side stream concurrently with the forward pass.
+ * _apply_sparse_duplicate_indices): one workgroup per field sorts the
+ * composite key (id << log2B | b) in LDS -- a barrier-free rank sort for B <= 512, a stable LSD radix
+ * sort over the id bits above -- then flags segment heads and scans them.
+ * Depends on ids only, so it may ride in another launch (rsx_sort_job).  segid is nullable.
  * Envelope: B <= 16384 and (max rows per field) << ceil(log2 B) < 2^32.                         */
 int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
-                   int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int max_rows_per_field,
-                   int B, int F, int stride, rsx_stream_t stream);
+                   int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid,
+                   int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream);
 /* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
 typedef struct {
   const int32_t* ids;
@@ -81,8 +85,27 @@ typedef struct {
   int32_t* uniq_row;
   int32_t* nuniq;
   int32_t* slot;
+  int32_t* segid;             /* nullable */
   int32_t max_rows_per_field, B, F, stride;
 } rsx_sort_job;
+
+/* Workspace of the two-stage segment-sum (large / skewed batches), caller-owned, host struct; nch = ceil(stride/16):
+ *   segid  written by rsx_field_sort (see above);  P float [F, nch, 2, D];  P1 float [F, nch, 2].
+ * Stage A, rsx_segsum_partials: every 16-position chunk of the sorted order sums its overlap with the LONG segments
+ * (> 16 entries; at most two per chunk) -- uniform work however skewed the ids are (Zipf heads, 3-row vocabularies).
+ * Stage B, rsx_segsum_bwd / _rows / _adam_rows with partials_h != NULL: every long segment gets a helper group (a
+ * whole wave above 256 entries) that adds its chunk partials in ascending chunk order; segments of <= 16 entries are
+ * summed entry by entry exactly as in the single-stage form.  Both forms are deterministic; they differ in the
+ * rounding of long segments only.  B passed to stage A and stage B must be the B of the sort.                   */
+typedef struct {
+  const int32_t* segid;
+  float* P;
+  float* P1;                  /* nullable when gy1 is NULL */
+} rsx_seg_partials;
+int rsx_segsum_partials(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
+                        const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                        const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B, int F, int D, int stride,
+                        int null_row, rsx_stream_t stream);
 
 /* Row-wise gradient "scatter" as a sorted segment-sum (replaces the IndexedSlices gradient of the
  * gather + tf.unsorted_segment_sum, Appendix A-4): for unique row (f, j)
@@ -93,7 +116,7 @@ typedef struct {
 int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                    const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq,
                    float* G, float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride,
-                   rsx_stream_t stream);
+                   const rsx_seg_partials* partials_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: tf.train.AdamOptimizer(lr).minimize(...) fm/fm.py:162-163.
@@ -164,7 +187,8 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
                          int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                         float* state, float lr, float beta1, float beta2, float eps, rsx_stream_t stream);
+                         const rsx_seg_partials* partials_h, float* state, float lr, float beta1, float beta2, float eps,
+                         rsx_stream_t stream);
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -252,7 +276,8 @@ int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* uniq_row, in
  * names a padding row whose entries carry exactly-zero gradients by construction (DIN history padding id 0,
  * din/din.py:107): its segment is not walked and G = 0 is written for it; -1 = no such row.                        */
 int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
-                    const int32_t* nuniq, float* G, int N, int K, int stride, int null_row, rsx_stream_t stream);
+                    const int32_t* nuniq, float* G, int N, int K, int stride, int null_row,
+                    const rsx_seg_partials* partials_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * xDeepFM CIN layer, xdeepfm/xdeepfm.py:145-172, fp32 MFMA.  D must be 16, H <= 128.

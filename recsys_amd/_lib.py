@@ -28,9 +28,13 @@ class AdamSlice(C.Structure):
                 ("blk_hi", C.c_uint32)]
 
 
+class SegPartials(C.Structure):
+    _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p)]
+
+
 class SortJob(C.Structure):
     _fields_ = [("ids", C.c_void_p), ("row_off", C.c_void_p), ("perm", C.c_void_p), ("seg_off", C.c_void_p),
-                ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p),
+                ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p), ("segid", C.c_void_p),
                 ("max_rows_per_field", C.c_int32), ("B", C.c_int32), ("F", C.c_int32), ("stride", C.c_int32)]
 
 
@@ -39,15 +43,16 @@ _SIGS = {
     "rsx_version": (C.c_int, []),
     "rsx_strerror": (C.c_char_p, [_I]),
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
-    "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
+    "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P, _P]),
+    "rsx_segsum_partials": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P]),
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
     "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
     "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P]),
     "rsx_tower_reduce_partials": (_I, [_P, _I, _I, _P]),
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P]),
-    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _F, _F, _F, _F, _P]),
+    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _F, _F, _F, _F, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
@@ -55,7 +60,7 @@ _SIGS = {
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_fwd": (_I, [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
-    "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
+    "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P, _P]),
     "rsx_sorted_segments": (_I, [_P, _I, _P, _P, _P, _P, _P]),
     "rsx_cin_layer_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "rsx_cin_layer_bwd": (_I, [_P] * 6 + [_I, _P, _I, _P, _P] + [_I] * 5 + [_P]),

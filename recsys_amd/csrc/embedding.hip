@@ -118,6 +118,156 @@ __device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4
   }
 }
 
+// Two-stage mode (B > 512).  Stage A (segsum_partials_k): every SEG_CHUNK-position chunk of the sorted order sums its
+// overlap with the LONG segments (> SEG_SHORT entries) -- uniform work units however skewed the ids are -- and the
+// chunk where a long segment starts appends it to the field's long list.  Stage B: row-owner waves sum the segments of
+// <= SEG_SHORT entries entry by entry (the oracle's order); every long segment gets a helper wave of its own (the
+// waves past the row owners) that adds its chunk partials in ascending chunk order.  SEG_CHUNK == SEG_SHORT, so a
+// chunk overlaps at most two long segments: partial slot 0 = the segment holding the chunk's first position, slot 1 =
+// the one holding its last.
+constexpr int SEG_CHUNK = SEG_SHORT;
+constexpr int SEG_HUGE = 256;   // above: a helper WAVE per segment; SEG_SHORT+1..SEG_HUGE: a helper GROUP per segment
+// stage-B waves per field: row owners + long-segment groups + huge-segment waves (+ rounding slack)
+__host__ __device__ inline int seg_waves_per_field(int B, int gpw, bool two_stage) {
+  const int own = (B + gpw - 1) / gpw;
+  return two_stage ? own + (B / (SEG_SHORT + 1) + gpw - 1) / gpw + B / (SEG_HUGE + 1) + 2 : own;
+}
+struct SegPartials {
+  const int32_t* segid;   // [F, stride] then [F] long- and [F] huge-segment counters (reset by the sort)
+  float* P;               // [F, nch, 2, D]
+  float* P1;              // [F, nch, 2]
+  // segid + F*stride: [F] long- and [F] huge-segment counts, then the long list [F, nch] (unique index j of the
+  // field's long segments from the front, huge ones from the back) -- all written by the sort
+  __host__ __device__ const int32_t* counts(int F, int stride) const { return segid + (size_t)F * stride; }
+  __host__ __device__ const int32_t* long_list(int F, int stride) const { return segid + (size_t)F * stride + 2 * F; }
+};
+
+// sequential ascending sum of chunk partials t in [t0, t1) of one long segment whose first chunk is `base`
+template <int LPR>
+__device__ __forceinline__ void partial_range_sum(const float4* __restrict__ P4, const float* __restrict__ P1, size_t base,
+                                                  bool first_slot1, int q, bool do1, int t0, int t1, float4& acc,
+                                                  float& a1) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = t0; t < t1; t += 8) {
+    float4 v[8];
+    float h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = t + k < t1;
+      const size_t idx = (base + (size_t)(ok ? t + k : t0)) * 2 + ((t + k) == 0 && first_slot1 ? 1 : 0);
+      v[k] = ok ? P4[idx * LPR + q] : z;
+      h[k] = (ok && do1) ? P1[idx] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (t + k < t1) {
+        acc = f4_add(acc, v[k]);
+        if (do1) a1 += h[k];
+      }
+    }
+  }
+}
+
+// Stage B wave body (same contract as segsum_wave).  Waves [0, nact) of a field own GPW unique rows each and sum the
+// short ones; wave nact + k is the helper of the field's k-th long segment.
+template <int D>
+__device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__ tables, const float* __restrict__ S,
+                                             const float* __restrict__ dX, const float* __restrict__ gy1,
+                                             const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
+                                             const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
+                                             int null_row, const SegPartials& part, bool& valid, size_t& sl, float4& acc,
+                                             float& a1, float4& e, int& row, bool& do1) {
+  constexpr int LPR = D / 4;
+  constexpr int GPW = RSX_WAVE / LPR;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, g = lane / LPR;
+  const int wpf = seg_waves_per_field(B, GPW, true);
+  const int f = wave / wpf;
+  valid = false;
+  if (f >= F) return false;
+  const int wf = wave - f * wpf;
+  const int nu = nuniq[f];
+  const int nact = (nu + GPW - 1) / GPW;
+  const int32_t* so = seg_off + (size_t)f * (stride + 1);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
+  acc = z;
+  a1 = 0.f;
+  e = z;
+  if (wf < nact) {
+    const int j = wf * GPW + g;
+    const bool own = j < nu;
+    sl = (size_t)f * stride + (own ? j : wf * GPW);
+    const int beg = own ? so[j] : 0;
+    int end = own ? so[j + 1] : 0;
+    row = own ? uniq_row[sl] : 0;
+    const bool is_null = own && null_row >= 0 && row == null_row;
+    if (is_null) end = beg;
+    valid = own && end - beg <= SEG_SHORT;        // long rows belong to their helper wave
+    if (!valid) return true;
+    SegCtx<LPR> c;
+    c.S4 = reinterpret_cast<const float4*>(S);
+    c.X4 = reinterpret_cast<const float4*>(dX);
+    c.gy1 = gy1;
+    c.gy2 = gy2;
+    c.pf = perm + (size_t)f * stride;
+    c.F = F;
+    c.f = f;
+    c.q = q;
+    c.do1 = do1;
+    if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+    seg_range_sum<LPR>(c, e, beg, end, acc, a1);
+    return true;
+  }
+  const size_t nch = (size_t)(B + SEG_CHUNK - 1) / SEG_CHUNK;
+  const int nlong = part.counts(F, stride)[f], nhuge = part.counts(F, stride)[F + f];
+  const int32_t* ll = part.long_list(F, stride) + (size_t)f * nch;
+  const int nlw = (nlong + GPW - 1) / GPW;
+  const float4* P4 = reinterpret_cast<const float4*>(part.P);
+  if (wf < nact + nlw) {
+    // long segments (SEG_SHORT < entries <= SEG_HUGE): one GROUP each, <= 17 chunk partials in ascending order
+    const int k = (wf - nact) * GPW + g;
+    valid = k < nlong;
+    if (!valid) return true;
+    const int j = ll[k];
+    const int sb = so[j], se = so[j + 1];
+    sl = (size_t)f * stride + j;
+    row = uniq_row[sl];
+    if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+    const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
+    partial_range_sum<LPR>(P4, part.P1, (size_t)f * nch + c0, sb % SEG_CHUNK != 0, q, do1, 0, nt, acc, a1);
+    return true;
+  }
+  // huge segments: a whole wave each; the groups sum contiguous sub-ranges of the partials, combined in ascending order
+  const int k = wf - nact - nlw;
+  if (k >= nhuge) return false;
+  const int j = ll[nch - 1 - k];
+  const int sb = so[j], se = so[j + 1];
+  sl = (size_t)f * stride + j;
+  row = uniq_row[sl];
+  valid = g == 0;
+  if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+  const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
+  const int per = (nt + GPW - 1) / GPW;
+  const int t0 = g * per;
+  const int t1 = t0 + per < nt ? t0 + per : nt;
+  float4 p = z;
+  float p1 = 0.f;
+  if (t0 < t1) partial_range_sum<LPR>(P4, part.P1, (size_t)f * nch + c0, sb % SEG_CHUNK != 0, q, do1, t0, t1, p, p1);
+  float4 tot = make_float4(__shfl(p.x, q), __shfl(p.y, q), __shfl(p.z, q), __shfl(p.w, q));
+  float t1s = __shfl(p1, 0);
+#pragma unroll
+  for (int kk = 1; kk < GPW; ++kk) {  // ascending sub-range order
+    const int ln = kk * LPR + q;
+    tot = f4_add(tot, make_float4(__shfl(p.x, ln), __shfl(p.y, ln), __shfl(p.z, ln), __shfl(p.w, ln)));
+    t1s += __shfl(p1, kk * LPR);
+  }
+  acc = tot;
+  a1 = t1s;
+  return true;
+}
+
 // The per-wave body of the segment-sum: returns false when the wave owns no unique row.  On return, for lanes with
 // `valid`: sl = slot index of the row, acc = summed gradient quarter, a1 = summed first-order gradient (q == 0 lanes),
 // e = the table row quarter (loaded only when the FM term is active), row = global row.
@@ -127,8 +277,11 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
                                             const float* __restrict__ gy2, const int32_t* __restrict__ perm,
                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
                                             const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
-                                            int null_row, bool& valid, size_t& sl, float4& acc, float& a1, float4& e,
-                                            int& row, bool& do1) {
+                                            int null_row, const SegPartials& part, bool& valid, size_t& sl, float4& acc,
+                                            float& a1, float4& e, int& row, bool& do1) {
+  if (part.P != nullptr)
+    return segsum_wave2<D>(wave, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride, null_row,
+                           part, valid, sl, acc, a1, e, row, do1);
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -201,6 +354,94 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
 }
 
 template <int D>
+__global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict__ tables, const float* __restrict__ S,
+                                                         const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                         const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                         const int32_t* __restrict__ seg_off,
+                                                         const int32_t* __restrict__ uniq_row, const SegPartials ws,
+                                                         uint64_t w1_mask, int B, int F, int stride, int null_row) {
+  constexpr int LPR = D / 4;
+  constexpr int GPW = RSX_WAVE / LPR;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int q = lane % LPR, g = lane / LPR;
+  const int nch = (B + SEG_CHUNK - 1) / SEG_CHUNK;
+  const int wpf = (nch + GPW - 1) / GPW;
+  const int f = wave / wpf;
+  if (f >= F) return;
+  const int ch = (wave - f * wpf) * GPW + g;
+  const bool active = ch < nch;
+  const int p0 = active ? ch * SEG_CHUNK : 0;
+  const int p1 = active ? (p0 + SEG_CHUNK < B ? p0 + SEG_CHUNK : B) : 1;
+  // the chunk's example indices do not depend on the segment structure: fetch them alongside it
+  const int32_t* pf = perm + (size_t)f * stride;
+  int pb[SEG_CHUNK];
+#pragma unroll
+  for (int k = 0; k < SEG_CHUNK; ++k) pb[k] = p0 + k < p1 ? pf[p0 + k] : 0;
+  const int32_t* sid = ws.segid + (size_t)f * stride;
+  const int32_t* so = seg_off + (size_t)f * (stride + 1);
+  const int jf = sid[p0], jl = sid[p1 - 1];
+  const int bf = so[jf], ef = so[jf + 1], bl = so[jl], el = so[jl + 1];
+  const int rowf = uniq_row[(size_t)f * stride + jf], rowl = uniq_row[(size_t)f * stride + jl];
+  const bool long0 = active && ef - bf > SEG_SHORT && !(null_row >= 0 && rowf == null_row);
+  const bool long1 = active && jl != jf && el - bl > SEG_SHORT && !(null_row >= 0 && rowl == null_row);
+  if (!long0 && !long1) return;
+  const bool fm = gy2 != nullptr, has_x = dX != nullptr;
+  const bool do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* T4 = reinterpret_cast<const float4*>(tables);
+  const float4* S4 = reinterpret_cast<const float4*>(S);
+  const float4* X4 = reinterpret_cast<const float4*>(dX);
+  const float4 e0 = (fm && long0) ? T4[(size_t)rowf * LPR + q] : z;
+  const float4 e1 = (fm && long1) ? T4[(size_t)rowl * LPR + q] : z;
+  const int hi0 = long0 ? (ef < p1 ? ef : p1) : p0;   // positions [p0, hi0) -> slot 0
+  const int lo1 = long1 ? bl : p1;                     // positions [lo1, p1) -> slot 1
+  float4 acc0 = z, acc1 = z;
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < SEG_CHUNK; k0 += 8) {          // 8 entries' loads in flight, summed in ascending position
+    float gg[8], hh[8];
+    float4 ss[8], xx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pos = p0 + k0 + k;
+      const bool use = pos < hi0 || (pos >= lo1 && pos < p1);
+      const int b = pb[k0 + k];
+      gg[k] = (use && fm) ? gy2[b] : 0.f;
+      ss[k] = (use && fm) ? S4[(size_t)b * LPR + q] : z;
+      xx[k] = (use && has_x) ? X4[((size_t)b * F + f) * LPR + q] : z;
+      hh[k] = (use && do1) ? gy1[b] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pos = p0 + k0 + k;
+      const bool in0 = pos < hi0, in1 = pos >= lo1 && pos < p1;
+      if (in0 || in1) {
+        float4 t = z;
+        if (fm) t = f4_sub(f4_scale(gg[k], ss[k]), f4_scale(gg[k], in0 ? e0 : e1));
+        if (has_x) t = fm ? f4_add(t, xx[k]) : xx[k];
+        if (in0) {
+          acc0 = f4_add(acc0, t);
+          a0 += hh[k];
+        } else {
+          acc1 = f4_add(acc1, t);
+          a1 += hh[k];
+        }
+      }
+    }
+  }
+  float4* P4 = reinterpret_cast<float4*>(ws.P);
+  const size_t o = ((size_t)f * nch + ch) * 2;
+  if (long0) {
+    P4[o * LPR + q] = acc0;
+    if (do1) ws.P1[o] = a0;
+  }
+  if (long1) {
+    P4[(o + 1) * LPR + q] = acc1;
+    if (do1) ws.P1[o + 1] = a1;
+  }
+}
+
+template <int D>
 __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ tables, const float* __restrict__ S,
                                                     const float* __restrict__ dX, const float* __restrict__ gy1,
                                                     const float* __restrict__ gy2, const int32_t* __restrict__ perm,
@@ -208,7 +449,7 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
                                                     const int32_t* __restrict__ uniq_row,
                                                     const int32_t* __restrict__ nuniq, float* __restrict__ G,
                                                     float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
-                                                    int stride, int null_row) {
+                                                    int stride, int null_row, const SegPartials part) {
   constexpr int LPR = D / 4;
   const int q = (threadIdx.x & 63) % LPR;
   bool valid, do1;
@@ -217,7 +458,7 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   float a1;
   int row;
   if (!segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                      nuniq, w1_mask, B, F, stride, null_row, valid, sl, acc, a1, e, row, do1))
+                      nuniq, w1_mask, B, F, stride, null_row, part, valid, sl, acc, a1, e, row, do1))
     return;
   if (valid) {
     reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
@@ -246,7 +487,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ seg_off,
                                                      const int32_t* __restrict__ uniq_row,
                                                      const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F,
-                                                     int stride, const HotAdam h) {
+                                                     int stride, const HotAdam h, const SegPartials part) {
   constexpr int LPR = D / 4;
   const float b1p = h.state[0], b2p = h.state[1];
   if (blockIdx.x >= h.n_own + h.extra.n_blk) {
@@ -261,7 +502,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float a1;
     int row;
     if (segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                       nuniq, w1_mask, B, F, stride, -1, valid, sl, acc, a1, e, row, do1) && valid) {
+                       nuniq, w1_mask, B, F, stride, -1, part, valid, sl, acc, a1, e, row, do1) && valid) {
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
@@ -310,9 +551,25 @@ template <int D>
 static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
                           const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                           const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
-                          int F, int stride, int null_row) {
+                          int F, int stride, int null_row, const SegPartials& part) {
   segsum_bwd_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
-                                          stride, null_row);
+                                          stride, null_row, part);
+}
+template <int D>
+static void launch_partials(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
+                            const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                            const int32_t* uniq_row, const SegPartials& ws, uint64_t mask, int B, int F, int stride,
+                            int null_row) {
+  segsum_partials_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F, stride,
+                                               null_row);
+}
+// host view of the two-stage workspace; nullptr -> single-stage
+static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegPartials& out) {
+  out = SegPartials{nullptr, nullptr, nullptr};
+  if (h == nullptr) return RSX_OK;
+  if (!h->segid || !h->P || (need_p1 && !h->P1)) return RSX_EINVAL;
+  out = SegPartials{h->segid, h->P, h->P1};
+  return RSX_OK;
 }
 
 extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
@@ -332,12 +589,12 @@ extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int
 }
 
 extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
-                              int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int max_rows_per_field, int B,
-                              int F, int stride, rsx_stream_t stream) {
+                              int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int max_rows_per_field,
+                              int B, int F, int stride, rsx_stream_t stream) {
   if (!ids || !row_off || !perm || !seg_off || !uniq_row || !nuniq || !slot || B < 0 || F <= 0 || stride < B ||
       max_rows_per_field <= 0)
     return RSX_EINVAL;
-  SortArgs a{ids, row_off, perm, seg_off, uniq_row, nuniq, slot, B, F, stride, 0, 0};
+  SortArgs a{ids, row_off, perm, seg_off, uniq_row, nuniq, slot, segid, B, F, stride, 0, 0};
   int n = 128;
   while (n < B) n <<= 1;
   const int T = n <= 512 ? n : ((n >> 1) < 1024 ? (n >> 1) : 1024);   // n <= 512: one thread per key (rank sort)
@@ -357,17 +614,20 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
 static int segsum_impl(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                        const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq, float* G,
                        float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
-                       rsx_stream_t stream) {
+                       const rsx_seg_partials* partials_h, rsx_stream_t stream) {
   if (!perm || !seg_off || !uniq_row || !nuniq || !G || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D))
     return RSX_EINVAL;
   if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
   if ((gy1 != nullptr) != (gw1 != nullptr)) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
+  SegPartials part;
+  const int rcp = seg_partials(partials_h, gy1 != nullptr, part);
+  if (rcp != RSX_OK) return rcp;
   const int gpw = 64 / (D / 4);                                   // unique rows per wave
-  const long long waves = (long long)F * ((B + gpw - 1) / gpw);
+  const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);   // two-stage: + helpers
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row);
+                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row, part);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -375,16 +635,38 @@ static int segsum_impl(const float* tables, const float* S, const float* dX, con
 extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1,
                               const float* gy2, const int32_t* perm, const int32_t* seg_off,
                               const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1,
-                              uint64_t w1_field_mask, int B, int F, int D, int stride, rsx_stream_t stream) {
+                              uint64_t w1_field_mask, int B, int F, int D, int stride,
+                              const rsx_seg_partials* partials_h, rsx_stream_t stream) {
   return segsum_impl(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, w1_field_mask, B, F, D, stride, -1,
-                     stream);
+                     partials_h, stream);
+}
+
+extern "C" int rsx_segsum_partials(const float* tables, const float* S, const float* dX, const float* gy1,
+                                   const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                                   const int32_t* uniq_row, const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B,
+                                   int F, int D, int stride, int null_row, rsx_stream_t stream) {
+  if (!perm || !seg_off || !uniq_row || !ws_h || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D)) return RSX_EINVAL;
+  if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  SegPartials ws;
+  const int rc = seg_partials(ws_h, gy1 != nullptr, ws);
+  if (rc != RSX_OK) return rc;
+  const int gpw = 64 / (D / 4);                                   // chunks per wave
+  const int nch = (B + SEG_CHUNK - 1) / SEG_CHUNK;
+  const long long waves = (long long)F * ((nch + gpw - 1) / gpw);
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  RSX_DISPATCH_D(D, launch_partials, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws,
+                 w1_field_mask, B, F, stride, null_row);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
 }
 
 template <int D>
 static void launch_segsum_adam(dim3 grid, dim3 block, hipStream_t st, const float* S, const float* dX, const float* gy1,
                                const float* gy2, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
-                               const int32_t* nuniq, uint64_t mask, int B, int F, int stride, const HotAdam& h) {
-  segsum_adam_k<D><<<grid, block, 0, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h);
+                               const int32_t* nuniq, uint64_t mask, int B, int F, int stride, const HotAdam& h,
+                               const SegPartials& part) {
+  segsum_adam_k<D><<<grid, block, 0, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h, part);
 }
 
 extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w,
@@ -392,13 +674,17 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
                                     const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                                    float* state, float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
+                                    const rsx_seg_partials* partials_h, float* state, float lr, float beta1, float beta2,
+                                    float eps, rsx_stream_t stream) {
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
   if (gy2 != nullptr && S == nullptr) return RSX_EINVAL;
   if ((gy1 != nullptr) != (w1 != nullptr)) return RSX_EINVAL;
   if (w1 != nullptr && (!m_w || !v_w)) return RSX_EINVAL;
+  SegPartials part;
+  const int rcp = seg_partials(partials_h, gy1 != nullptr, part);
+  if (rcp != RSX_OK) return rcp;
   HotAdam h;
   h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
   h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state;
@@ -410,7 +696,7 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
     h.extra.n_blk = blocks;
   }
   const int gpw = 64 / (D / 4);
-  const long long waves = (long long)F * ((B + gpw - 1) / gpw);
+  const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);
   h.n_own = (uint32_t)((waves + 3) / 4);
   const int rcs = adam_build_slice(sweep_h, h.cold);
   if (rcs != RSX_OK) return rcs;
@@ -421,14 +707,14 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   h.total_blocks = h.n_own + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,
-                 w1_field_mask, B, F, stride, h);
+                 w1_field_mask, B, F, stride, h, part);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
 
 extern "C" int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                const int32_t* nuniq, float* G, int N, int K, int stride, int null_row,
-                               rsx_stream_t stream) {
+                               const rsx_seg_partials* partials_h, rsx_stream_t stream) {
   return segsum_impl(nullptr, nullptr, vals, nullptr, nullptr, perm, seg_off, uniq_row, nuniq, G, nullptr, 0, N, 1, K,
-                     stride, null_row, stream);
+                     stride, null_row, partials_h, stream);
 }

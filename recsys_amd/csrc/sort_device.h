@@ -12,6 +12,9 @@ struct SortArgs {
   int32_t* uniq_row;
   int32_t* nuniq;
   int32_t* slot;
+  // nullable (two-stage segment-sum workspace, B > 512 only): [F, stride] segment index j of every sorted position,
+  // then [F] long- and [F] huge-segment counts, then [F, ceil(B/16)] the long list (long from the front, huge from the back)
+  int32_t* segid;
   int B, F, stride, n, bbits;
 };
 
@@ -180,20 +183,22 @@ __device__ __forceinline__ void field_sort_block(const SortArgs& a, int f, uint3
         a.slot[row] = f * stride + jn;
         ++jn;
       }
+      if (a.segid != nullptr) a.segid[(size_t)f * stride + i] = jn - 1;
     }
   } else {
     // unique index of every head position into the idle LDS buffer, then ONE coalesced, store-only pass
     uint32_t* jix = key == lds ? lds + n : lds;
     for (int i = i0; i < i0 + ipt; ++i) {
       const bool head = i < B && (i == 0 || (key[i] >> bbits) != (key[i - 1] >> bbits));
-      jix[i] = head ? (uint32_t)jn : 0xFFFFFFFFu;
       jn += head;
+      jix[i] = (uint32_t)(jn - 1) | (head ? 0x80000000u : 0u);     // segment index of position i; top bit = head
     }
     __syncthreads();
     for (int i = tid; i < B; i += T) {
-      const uint32_t kk = key[i], j = jix[i];
+      const uint32_t kk = key[i], jh = jix[i], j = jh & 0x7FFFFFFFu;
       a.perm[(size_t)f * stride + i] = (int32_t)(kk & bmask);
-      if (j != 0xFFFFFFFFu) {
+      if (a.segid != nullptr) a.segid[(size_t)f * stride + i] = (int32_t)j;
+      if (jh & 0x80000000u) {
         const int row = roff + (int)(kk >> bbits);
         a.uniq_row[(size_t)f * stride + j] = row;
         a.seg_off[(size_t)f * (stride + 1) + j] = i;
@@ -204,6 +209,27 @@ __device__ __forceinline__ void field_sort_block(const SortArgs& a, int f, uint3
   if (tid == 0) {
     a.seg_off[(size_t)f * (stride + 1) + total] = B;
     a.nuniq[f] = total;
+  }
+  if (a.segid != nullptr && !small) {
+    // long-segment lists of the two-stage scatter (> 16 entries: a helper group, > 256: a helper wave each), from the
+    // segment starts gathered in the now idle key buffer.  List order is arrival order: it only assigns work.
+    uint32_t* jix = key == lds ? lds + n : lds;
+    uint32_t* hs = key;
+    __syncthreads();
+    for (int i = tid; i < B; i += T)
+      if (jix[i] & 0x80000000u) hs[jix[i] & 0x7FFFFFFFu] = (uint32_t)i;
+    if (tid < 2) wsum[tid] = 0;
+    __syncthreads();
+    const int nch = (B + 15) >> 4;
+    int32_t* cnt = a.segid + (size_t)a.F * stride;
+    int32_t* ll = cnt + 2 * a.F + (size_t)f * nch;
+    for (int j = tid; j < total; j += T) {
+      const int L = (j + 1 < total ? (int)hs[j + 1] : B) - (int)hs[j];
+      if (L > 256) ll[nch - 1 - (int)atomicAdd(&wsum[1], 1u)] = j;
+      else if (L > 16) ll[atomicAdd(&wsum[0], 1u)] = j;
+    }
+    __syncthreads();
+    if (tid < 2) cnt[tid * a.F + f] = (int32_t)wsum[tid];
   }
 }
 
@@ -216,6 +242,7 @@ static inline int rsx_ceil_log2(int x) {
 // Fills n / bbits for a launch with `threads` threads per workgroup; returns an rsx_status.
 static inline int rsx_sort_args(SortArgs& a, int max_rows_per_field, int threads) {
   if (a.B > 16384) return RSX_EUNSUPPORTED;              // 2n keys must fit the 160 KB LDS of one workgroup
+  if (a.segid != nullptr && a.B <= 512) return RSX_EINVAL;   // the two-stage workspace is for B > 512
   a.bbits = rsx_ceil_log2(a.B < 2 ? 2 : a.B);
   if (((uint64_t)(max_rows_per_field - 1) << a.bbits) >= (1ull << 32) - 1ull) return RSX_EUNSUPPORTED;
   int n = 128;

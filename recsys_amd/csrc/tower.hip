@@ -642,7 +642,7 @@ static inline int sort_job_args(const rsx_sort_job& j, SortArgs& out, size_t* ld
   if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
       j.stride < j.B || j.max_rows_per_field <= 0)
     return RSX_EINVAL;
-  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.B, j.F, j.stride, 0, 0};
+  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.segid, j.B, j.F, j.stride, 0, 0};
   const int rc = rsx_sort_args(out, j.max_rows_per_field, 256);
   if (rc != RSX_OK) return rc;
   const size_t need = rsx_sort_lds_bytes(out, 256);

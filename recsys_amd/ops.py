@@ -70,15 +70,31 @@ class EmbeddingArena:
         self.G = torch.zeros(F * st, D, device=dev)
         self.gw1 = torch.zeros(F * st, device=dev) if with_w1 else None
         self.last_B = 0
+        # two-stage segment-sum workspace (B > TWO_STAGE_MIN_B): segment index per sorted position + chunk partials
+        self.partials = None
+        if st > self.TWO_STAGE_MIN_B:
+            nch = (st + 15) // 16
+            self.segid = torch.zeros(F * st + 2 * F + F * nch, **i32)
+            self.P = torch.zeros(F * nch * 2, D, device=dev)
+            self.P1 = torch.zeros(F * nch * 2, device=dev) if with_w1 else None
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1))
         # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
         self.hook = torch.zeros((), device=dev, requires_grad=True)
+
+    # Above this batch size the scatter runs in two stages (uniform 16-position chunks feed the long segments): small
+    # batches are latency-bound and one launch wins; large / skewed ones are bound by the longest segment chain.
+    TWO_STAGE_MIN_B = 512
+
+    def _two_stage(self, B):
+        return self.partials is not None and B > self.TWO_STAGE_MIN_B
 
     # -- kernels ---------------------------------------------------------------------------
     def field_sort(self, ids):
         B = ids.shape[0]
         assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and B <= self.stride
         check(lib().rsx_field_sort(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
-                                   _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot), self.max_rows,
+                                   _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot),
+                                   _ptr(self.segid) if self._two_stage(B) else None, self.max_rows,
                                    B, self.F, self.stride, _stream()), "rsx_field_sort")
         self.last_B = B
 
@@ -90,6 +106,7 @@ class EmbeddingArena:
         j = _lib.SortJob()
         j.ids, j.row_off, j.perm, j.seg_off = ids.data_ptr(), self.row_off.data_ptr(), self.perm.data_ptr(), self.seg_off.data_ptr()
         j.uniq_row, j.nuniq, j.slot = self.uniq_row.data_ptr(), self.nuniq.data_ptr(), self.slot.data_ptr()
+        j.segid = self.segid.data_ptr() if self._two_stage(B) else None
         j.max_rows_per_field, j.B, j.F, j.stride = self.max_rows, B, self.F, self.stride
         return j
 
@@ -106,22 +123,33 @@ class EmbeddingArena:
                                       B, self.F, self.D, _stream()), "rsx_gather_fm_fwd")
         return E, S, y1, y2
 
+    def _stage_a(self, B, S, dX, gy1, gy2):
+        """Stage A of the two-stage scatter; returns the partials handle stage B takes (None: single stage)."""
+        if not self._two_stage(B):
+            return None
+        check(lib().rsx_segsum_partials(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
+                                        _ptr(self.seg_off), _ptr(self.uniq_row), C.byref(self.partials), self.w1_mask,
+                                        B, self.F, self.D, self.stride, -1, _stream()), "rsx_segsum_partials")
+        return C.byref(self.partials)
+
     def segsum(self, B, S, dX, gy1, gy2):
+        part = self._stage_a(B, S, dX, gy1, gy2)
         check(lib().rsx_segsum_bwd(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
                                    _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.G),
                                    _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
-                                   self.stride, _stream()), "rsx_segsum_bwd")
+                                   self.stride, part, _stream()), "rsx_segsum_bwd")
 
     def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups)."""
         arr, n = opt._seg_array(extra_segments)
         lr, b1, b2, eps = opt.hp
         w = self.with_w1 and gy1 is not None
+        part = self._stage_a(B, S, dX, gy1, gy2)
         check(lib().rsx_segsum_adam_rows(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), _ptr(self.w1) if w else None,
                                          _ptr(self.m_w) if w else None, _ptr(self.v_w) if w else None, _ptr(S), _ptr(dX),
                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
-                                         None if sweep is None else C.byref(sweep),
+                                         None if sweep is None else C.byref(sweep), part,
                                          _ptr(opt.state), lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
 
     # -- optimizer segments ----------------------------------------------------------------
@@ -516,7 +544,7 @@ class SparseTable:
         check(lib().rsx_sorted_segments(_ptr(skeys), N, _ptr(self.uniq_row), _ptr(self.seg_off), _ptr(self.nuniq),
                                         _ptr(self.slot), _stream()), "rsx_sorted_segments")
         check(lib().rsx_segsum_rows(_ptr(vals), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq),
-                                    _ptr(self.G), N, self.K, self.cap, self.null_row, _stream()), "rsx_segsum_rows")
+                                    _ptr(self.G), N, self.K, self.cap, self.null_row, None, _stream()), "rsx_segsum_rows")
         self._keep = (skeys, perm, vals)
 
     def adam_segments(self, lazy=False):
