@@ -233,7 +233,12 @@ int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const f
                         const float* mask_prev, float* dy_prev, double* bstat_prev, const double* hpart,
                         const float* dwd_part, float* dwd, float* dbd, float* dwo, float* dbo, float* dc0,
                         float* loss, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
-                        int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+                        int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h, float* dw_partials,
+                        rsx_stream_t stream);
+/* dw_partials (nullable): rsx_tower_bwd_workspace_floats(B, K, N) floats that let a large batch (B >= 1024) split every
+ * dW tile's reduction over the batch into up to 32 row blocks; a second small launch adds the partial tiles in ascending
+ * block order (deterministic).  Without it one workgroup per tile walks the whole batch.                               */
+size_t rsx_tower_bwd_workspace_floats(int B, int K, int N);
 /* sweep_h (host pointer, nullable, on all three tower entry points): a slice of the untouched-row optimizer sweep
  * (see rsx_adam_slice) executed by extra workgroups appended after the launch's own ones -- the HBM-bound stream fills the
  * CUs the latency-bound tower workgroups leave idle.

@@ -447,6 +447,10 @@ struct BwdArgs {
   int has_wo;
   int B, K, N, RT, RTh;      // RT: rows of the (possibly pre-reduced) bstat; RTh: row tiles = rows of hpart / dwd_part
   int n_din, n_dw, ct_k, ct_k1, ct_n;
+  // dW tiles split their reduction over the batch into `sb` row blocks of `ksb` k-steps (large batches: the serial chain
+  // of one workgroup per tile would span the whole batch); tower_reduce_dw_k then adds the sb partial tiles in order
+  int sb, ksb;
+  float* dwp;                // [tiles, sb, 256] partial tiles
   int n_head;                // 1 when the head-partial reduce block is present
   int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
   SortArgs sort;
@@ -482,7 +486,10 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   float* part = lds + 5 * p.N + ((4 - (5 * p.N) % 4) % 4);         // [4][256], 16-byte aligned
   double* cred = reinterpret_cast<double*>(part + 1024);              // [4][2][16]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int bid = blockIdx.x;
+  // dispatch order: the dW tiles first -- their reduction over the batch is the longest dependent chain of the launch,
+  // so it must start at t = 0 and let the (many, short) d(input) tiles fill in around it
+  int bid = blockIdx.x;
+  bid = bid < p.n_dw ? bid + p.n_din : (bid < p.n_dw + p.n_din ? bid - p.n_dw : bid);
   const float Bf = (float)p.B;
   const bool first = p.bn_prev == nullptr;
   const int i = lane & 15, kq = lane >> 4;
@@ -546,7 +553,11 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   if (bid < p.n_din + p.n_dw) {
     // ---- dW tile: rows = input features kf*16.. (feature K = the ones-row -> db), cols = n*16.. ------
     const int t_id = bid - p.n_din;
-    const int nt = t_id % p.ct_n, kf = t_id / p.ct_n;
+    const int sbi = t_id % p.sb, tile = t_id / p.sb;
+    const int nt = tile % p.ct_n, kf = tile / p.ct_n;
+    const int ks0 = sbi * p.ksb;
+    const int ks_all = (p.B + 15) / 16;
+    const int nks = ks0 + p.ksb < ks_all ? p.ksb : ks_all - ks0;
     const int feat = kf * 16 + i;          // A-operand row (input feature)
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
@@ -560,10 +571,14 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       fsh = p.beta_prev[feat] - p.bn_prev[feat] * inv;
     }
     const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
-    const float v = tile_ksplit((p.B + 15) / 16, part, [&](int ks, float* a, float* b) {
+    if (kf == 0 && sbi == 0 && nok && tid < 16) {   // lanes 0..15 of wave 0 hold the column constants
+      p.dgamma[ncol] = cb.sdx;
+      p.dbeta[ncol] = cb.sdy;
+    }
+    float v = tile_ksplit(nks, part, [&](int ks, float* a, float* b) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int bb = ks * 16 + 4 * kq + t;
+        const int bb = (ks0 + ks) * 16 + 4 * kq + t;
         a[t] = 0.f;
         b[t] = 0.f;
         if (bb < p.B) {
@@ -578,16 +593,14 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         }
       }
     });
+    if (p.sb > 1) {   // partial tile; tower_reduce_dw_k adds the sb partials in ascending block order
+      p.dwp[((size_t)tile * p.sb + sbi) * 256 + tid] = v;
+      return;
+    }
     const int orow = kf * 16 + (tid >> 4), ocol = nt * 16 + (tid & 15);
     if (ocol < p.N) {
       if (orow < p.K) p.dW[(size_t)orow * p.N + ocol] = v;
       else if (orow == p.K) p.db[ocol] = v;
-    }
-    if (kf == 0 && kq == 0 && nok) {   // lanes 0..15 of every wave hold the same column constants
-      if (tid < 16) {
-        p.dgamma[ncol] = cb.sdx;
-        p.dbeta[ncol] = cb.sdy;
-      }
     }
     return;
   }
@@ -619,22 +632,57 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   }
 }
 
-// Large batches: fold the RT per-row-tile partials of a statistics buffer into row 0 (fixed order), so that every
-// consumer workgroup reads ONE partial per column instead of RT.  grid = ceil(2N/64), block = 64.
-__global__ __launch_bounds__(64) void tower_reduce_partials_k(double* __restrict__ st, int RT, int N2) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= N2) return;
-  double s = 0.0;
-  int r = 0;
-  for (; r + 8 <= RT; r += 8) {
-    double t[8];
+// Large batches: dW[tile] = sum of the tile's sb partials in ascending row-block order.  grid = tiles, block = 256.
+__global__ __launch_bounds__(256) void tower_reduce_dw_k(const float* __restrict__ dwp, float* __restrict__ dW,
+                                                         float* __restrict__ db, int sb, int ct_n, int K, int N) {
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const float* all = dwp + (size_t)tile * sb * 256;
+  float s = 0.f;
+  for (int q = 0; q < sb; q += 8) {
+    float t[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
+    for (int u = 0; u < 8; ++u) t[u] = q + u < sb ? all[(size_t)(q + u) * 256 + tid] : 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += t[u];
   }
-  for (; r < RT; ++r) s += st[(size_t)r * N2 + c];
-  st[c] = s;
+  const int nt = tile % ct_n, kf = tile / ct_n;
+  const int orow = kf * 16 + (tid >> 4), ocol = nt * 16 + (tid & 15);
+  if (ocol < N) {
+    if (orow < K) dW[(size_t)orow * N + ocol] = s;
+    else if (orow == K) db[ocol] = s;
+  }
+}
+
+// Large batches: fold the RT per-row-tile partials of a statistics buffer into row 0 (fixed order), so that every
+// consumer workgroup reads ONE partial per column instead of RT.  grid = ceil(2N/64), block = 64.
+__global__ __launch_bounds__(1024) void tower_reduce_partials_k(double* __restrict__ st, int RT, int N2) {
+  // 16 waves: wave w sums the contiguous row range [w*per, (w+1)*per) of its 64 columns (8 loads in flight), then the
+  // 16 partials are added in ascending wave order -- a fixed association, and 16x shorter dependent chains
+  __shared__ double part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int per = (RT + 15) / 16;
+  const int r0 = w * per, r1 = r0 + per < RT ? r0 + per : RT;
+  double s = 0.0;
+  if (c < N2) {
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; r < r1; ++r) s += st[(size_t)r * N2 + c];
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < N2) {
+    double t = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][lane];
+    st[c] = t;
+  }
 }
 
 // validates a piggy-backed sort job for a 256-thread carrier launch and grows the launch's dynamic LDS if needed
@@ -659,7 +707,7 @@ extern "C" int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_
   if (B <= 512) return RSX_OK;   // small batches: consumers sum the <= 32 partials themselves
   if (!stat) return RSX_EINVAL;
   const int RT = (B + TM - 1) / TM;
-  hipLaunchKernelGGL(tower_reduce_partials_k, dim3((2 * N + 63) / 64), dim3(64), 0, rsx_s(stream), stat, RT, 2 * N);
+  hipLaunchKernelGGL(tower_reduce_partials_k, dim3((2 * N + 63) / 64), dim3(1024), 0, rsx_s(stream), stat, RT, 2 * N);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -731,6 +779,17 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   return RSX_OK;
 }
 
+// row blocks a dW tile's batch reduction is split into (1 without workspace or for small batches)
+static inline int rsx_tower_dw_blocks(int B, bool have_ws) {
+  if (!have_ws || B < 1024) return 1;
+  const int sb = (B + 255) / 256;
+  return sb > 32 ? 32 : sb;
+}
+
+extern "C" size_t rsx_tower_bwd_workspace_floats(int B, int K, int N) {
+  return (size_t)((K + 1 + 15) / 16) * ((N + 15) / 16) * rsx_tower_dw_blocks(B, true) * 256;
+}
+
 extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const float* dy,
                                    const double* bstat, const float* bn, const float* gamma, float* dW, float* db,
                                    float* dgamma, float* dbeta, const float* bn_prev, const float* gamma_prev,
@@ -739,7 +798,7 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    float* dbd, float* dwo, float* dbo, float* dc0, float* loss,
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
                                    int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
-                                   rsx_stream_t stream) {
+                                   float* dw_partials, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !a || !dy || !bstat || !bn || !gamma || !dW || !db || !dgamma || !dbeta || !dy_prev)
@@ -762,7 +821,10 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;
   p.n_din = p.ct_k * p.RTh;
-  p.n_dw = p.ct_k1 * p.ct_n;
+  p.sb = rsx_tower_dw_blocks(B, dw_partials != nullptr);
+  p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
+  p.dwp = dw_partials;
+  p.n_dw = p.ct_k1 * p.ct_n * p.sb;
   p.n_head = hpart != nullptr ? 1 : 0;
   p.n_sort = 0;
   size_t lds = ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float);
@@ -776,5 +838,10 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
   hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
+  if (p.sb > 1) {
+    hipLaunchKernelGGL(tower_reduce_dw_k, dim3(p.ct_k1 * p.ct_n), dim3(256), 0, rsx_s(stream), dw_partials, dW, db, p.sb,
+                       p.ct_n, K, N);
+    RSX_CHECK_LAUNCH();
+  }
   return RSX_OK;
 }

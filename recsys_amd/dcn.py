@@ -5,6 +5,8 @@ x0 = the 39x16 = 624-wide embedding vector; `cross_layers` cross layers (csrc/cr
 deep tower [dense(relu) -> BN -> dropout] x n WITHOUT a final 1-unit layer (:144-149);
 logits = dense(concat[deep, x_L], 1) (:151-152).  No first-order term (linear columns are built but unused, :96,128).
 """
+import os
+
 import torch
 
 from . import layers as L
@@ -53,34 +55,55 @@ def build_variables(store, params, capacity):
     if params.get("tower", "hip") == "hip":
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
+        # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0]
+        env = os.environ.get("RSX_SWEEP_WEIGHTS")
+        store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
+                                                              [0.0] * len(layers) + [1.0] + [3.0] * len(layers))
 
 
 def _train_fused(store, arena, ids, labels, params, masks):
+    """TRAIN step, explicit kernel sequence (same structure as recsys_amd/deepfm.py::_train_fused): gather -> cross fwd ->
+    tower fwd (first launch carries the dedup sort) / head / bwd (carrying slices of the untouched-row Adam sweep) ->
+    cross bwd -> [train_op:] scatter + touched-row Adam + dense Adam in one launch."""
     dp, P = store.dp, store.dense
     nh = store.tower.widths[-1]
+    nl = len(store.tower.widths)
     oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
     with torch.no_grad():
-        if dp is None:
-            store.sort_ids_for_backward(arena, ids)
+        overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
         x0, _, _, _ = arena.gather(ids)
+        ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
+        job, sweeps, hot, last_sweep = None, None, None, None
+        if ids_sort.shape[0] <= 4096:                # the sort rides in the first tower-forward launch (LDS window)
+            job = arena.sort_job(ids_sort)
+        else:
+            arena.field_sort(ids_sort)
+        if overlap:
+            cold, hot = arena.adam_split_segments()
+            sweeps = store.opt.cold_slices(cold, store.sweep_weights)
+            last_sweep = sweeps[-1] if len(sweeps) == 2 * nl + 2 else None
+            sweeps = sweeps[:2 * nl + 1]
+            if job is not None:
+                assert sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
         _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
         loss, prob, dX, gz, _ = store.tower.train_step(
             x0, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,
-            replicas=dp.world if dp is not None else 1, masks=masks)
+            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job, sweeps=sweeps, sort_in_fwd=True)
         store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
                              gz=gz, wout=oW[nh:], dwout=oG[nh:])
 
     def train_op():
         with torch.no_grad():
-            if dp is not None:
-                dXg, _, _, _, idsg = dp.gather_example_grads(dX, ids=ids)
-                arena.field_sort(idsg)
-                arena.segsum(dXg.shape[0], None, dXg, None, None)
-                dp.all_reduce_sum(store.dense.grad)
+            dXg = dX
+            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order)
+                dXg, _, _, _ = dp.gather_example_grads(dX, dense=store.dense.grad)
+            Bg = dXg.shape[0]
+            if hot is not None:
+                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, store.dense.adam_segments(), last_sweep)
             else:
-                arena.segsum(ids.shape[0], None, dX, None, None)
-            store.apply_gradients()
+                arena.segsum(Bg, None, dXg, None, None)
+                store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 

@@ -121,7 +121,11 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # data-parallel: the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices), so the
         # dedup sort runs over the all-gathered ids -- a 40 KB collective issued right after the local gather launch
         ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
-        job = arena.sort_job(ids_sort)
+        job = None
+        if ids_sort.shape[0] <= 4096:                # rides in a tower launch (64 KB LDS window of the carrier)
+            job = arena.sort_job(ids_sort)
+        else:
+            arena.field_sort(ids_sort)
         sweeps, hot, last_sweep = None, None, None
         if overlap:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
@@ -131,7 +135,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             sweeps = store.opt.cold_slices(cold, store.sweep_weights)      # [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
             last_sweep = sweeps[-1] if len(sweeps) == 2 * len(store.tower.widths) + 2 else None
             sweeps = sweeps[:2 * len(store.tower.widths) + 1]
-            assert sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
+            assert job is None or sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,

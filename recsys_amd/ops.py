@@ -361,6 +361,12 @@ class FusedTower:
         self.dwd_part = torch.zeros(RT, self.widths[-1], device=dev)
         self.hpart = torch.zeros(RT, 8, **f64)
         self.loss = torch.zeros(1, device=dev)
+        # large batches: every dW tile's reduction over the batch is split into row blocks (csrc/tower.hip)
+        self.dwp = []
+        for l, n in enumerate(self.widths):
+            K = self.k0 if l == 0 else self.widths[l - 1]
+            self.dwp.append(torch.empty(int(lib().rsx_tower_bwd_workspace_floats(self.cap, K, n)), device=dev)
+                            if self.cap >= 1024 else None)
 
     def _masks(self, B, rate, masks):
         """Injected keep-masks (parity tests) as contiguous [B, N_l] views; None -> the kernels derive the mask
@@ -436,7 +442,7 @@ class FusedTower:
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
                 rs, seed, l, rate, B, K, self.widths[l],
                 C.byref(sort_job) if (last and sort_job is not None and not sort_in_fwd) else None,
-                ref(sw[nl + 1 + (nl - 1 - l)]), st), "rsx_tower_bwd_layer")
+                ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), st), "rsx_tower_bwd_layer")
             if l:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
