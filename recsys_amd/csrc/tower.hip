@@ -479,6 +479,9 @@ __device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float
 #ifndef RSX_ABLATE
 #define RSX_ABLATE 0
 #endif
+// SPLIT: the dW tiles' batch reduction is cut into p.sb row blocks (large batches); false keeps the single-block code
+// path free of the block arithmetic
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (RSX_ABLATE == 1) return;                       // launch floor
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   // dispatch order: the dW tiles first -- their reduction over the batch is the longest dependent chain of the launch,
   // so it must start at t = 0 and let the (many, short) d(input) tiles fill in around it
   int bid = blockIdx.x;
-  bid = bid < p.n_dw ? bid + p.n_din : (bid < p.n_dw + p.n_din ? bid - p.n_dw : bid);
+  if (SPLIT) bid = bid < p.n_dw ? bid + p.n_din : (bid < p.n_dw + p.n_din ? bid - p.n_dw : bid);
   const float Bf = (float)p.B;
   const bool first = p.bn_prev == nullptr;
   const int i = lane & 15, kq = lane >> 4;
@@ -553,11 +556,11 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   if (bid < p.n_din + p.n_dw) {
     // ---- dW tile: rows = input features kf*16.. (feature K = the ones-row -> db), cols = n*16.. ------
     const int t_id = bid - p.n_din;
-    const int sbi = t_id % p.sb, tile = t_id / p.sb;
+    const int sbi = SPLIT ? t_id % p.sb : 0, tile = SPLIT ? t_id / p.sb : t_id;
     const int nt = tile % p.ct_n, kf = tile / p.ct_n;
-    const int ks0 = sbi * p.ksb;
+    const int ks0 = SPLIT ? sbi * p.ksb : 0;
     const int ks_all = (p.B + 15) / 16;
-    const int nks = ks0 + p.ksb < ks_all ? p.ksb : ks_all - ks0;
+    const int nks = SPLIT ? (ks0 + p.ksb < ks_all ? p.ksb : ks_all - ks0) : ks_all;
     const int feat = kf * 16 + i;          // A-operand row (input feature)
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         }
       }
     });
-    if (p.sb > 1) {   // partial tile; tower_reduce_dw_k adds the sb partials in ascending block order
+    if (SPLIT) {      // partial tile; tower_reduce_dw_k adds the sb partials in ascending block order
       p.dwp[((size_t)tile * p.sb + sbi) * 256 + tid] = v;
       return;
     }
@@ -615,14 +618,46 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   }
   // ---- head partial reduce (last layer only) ---------------------------------------------------------
   if (p.hpart != nullptr) {
-    for (int c = tid; c < p.N; c += 256) {
+    // RTh row-tile partials per column: the 4 waves take contiguous quarter ranges of the rows (8 loads in flight),
+    // lane = column; the quarters are then added in ascending order -- fixed association, short dependent chains
+    const int w = tid >> 6;
+    const int per = (p.RTh + 3) / 4;
+    const int r0 = w * per, r1 = r0 + per < p.RTh ? r0 + per : p.RTh;
+    for (int c0 = 0; c0 < p.N; c0 += 64) {
+      const int c = c0 + lane;
       float s = 0.f;
-      for (int r = 0; r < p.RTh; ++r) s += p.dwd_part[(size_t)r * p.N + c];
-      p.dwd[c] = s;
+      if (c < p.N) {
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = p.dwd_part[(size_t)(r + u) * p.N + c];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; r < r1; ++r) s += p.dwd_part[(size_t)r * p.N + c];
+      }
+      __syncthreads();
+      part[w * 64 + lane] = s;
+      __syncthreads();
+      if (w == 0 && c < p.N) p.dwd[c] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
     }
+    double hs = 0.0;
+    if (lane < 8) {
+      int r = r0;
+      for (; r + 8 <= r1; r += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p.hpart[(size_t)(r + u) * 8 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hs += t[u];
+      }
+      for (; r < r1; ++r) hs += p.hpart[(size_t)r * 8 + lane];
+      cred[w * 8 + lane] = hs;
+    }
+    __syncthreads();
     if (tid < 8) {
-      double s = 0.0;
-      for (int r = 0; r < p.RTh; ++r) s += p.hpart[(size_t)r * 8 + tid];
+      const double s = ((cred[tid] + cred[8 + tid]) + cred[16 + tid]) + cred[24 + tid];
       if (tid == 0) p.loss[0] = (float)(s / (double)p.B);
       if (p.has_wo && tid >= 1 && tid <= 3) p.dwo[tid - 1] = (float)s;
       if (p.has_wo && tid == 4) p.dbo[0] = (float)s;
@@ -836,7 +871,8 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
   const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
-  hipLaunchKernelGGL(tower_bwd_k, dim3(total), dim3(256), lds, rsx_s(stream), p);
+  if (p.sb > 1) hipLaunchKernelGGL(tower_bwd_k<true>, dim3(total), dim3(256), lds, rsx_s(stream), p);
+  else hipLaunchKernelGGL(tower_bwd_k<false>, dim3(total), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   if (p.sb > 1) {
     hipLaunchKernelGGL(tower_reduce_dw_k, dim3(p.ct_k1 * p.ct_n), dim3(256), 0, rsx_s(stream), dw_partials, dW, db, p.sb,
