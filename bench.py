@@ -86,17 +86,18 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
     from recsys_amd import build as _build
-    if rank == 0:
-        _build.build(verbose=False)
-    from recsys_amd import deepfm, dist, synthetic
-    from recsys_amd.estimator import Estimator, RunConfig
-    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
-
+    from recsys_amd import dist
     dp = None
     if world > 1 or os.environ.get("RSX_FORCE_DIST") == "1":
         dist.init_process_group("nccl")
         dp = dist.DataParallel()
-        dp.barrier()
+    if rank == 0:
+        _build.build(verbose=False)          # no-op when the in-tree librsx.so is current
+    if dp is not None:
+        dp.barrier()                         # the other ranks load the library only after rank 0's build check
+    from recsys_amd import deepfm, synthetic
+    from recsys_amd.estimator import Estimator, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     emu = None

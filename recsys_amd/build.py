@@ -33,10 +33,16 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    tmp = LIB + ".tmp.%d" % os.getpid()      # link to a private name, then rename: a concurrent loader (another rank)
+    cmd = [hipcc] + FLAGS + sources() + ["-o", tmp]   # never sees a half-written library
     if verbose:
         print("[recsys_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

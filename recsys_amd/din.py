@@ -21,7 +21,20 @@ MLP_LAYERS = [100, 50, 20]       # din/din.py:86 (the deep_layers flag is ignore
 N_ITEM, N_CATE = 63002, 802      # din/din.py:88-90
 
 
+def _prefer_rocblas():
+    """The attention MLP's weight gradients are [K, B*P] x [B*P, N] GEMMs with B*P = 102 400: torch's default fp32 path
+    (hipBLASLt) runs them in 270-360 us each, rocBLAS in 38-54 us (scripts/gemm_probe.py; 6 of them per step)."""
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.backends.cuda.preferred_blas_library("cublas")      # "cublas" names rocBLAS on ROCm
+    except Exception:                                                  # knob absent in this torch: keep the default
+        pass
+
+
 def build_variables(store, params, B, P):
+    _prefer_rocblas()
     K = params["embedding_size"]
     n_item, n_cate = params.get("n_item", N_ITEM), params.get("n_cate", N_CATE)
     world = store.dp.world if store.dp is not None else 1
