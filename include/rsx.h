@@ -274,9 +274,11 @@ int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const f
                      int accumulate, int B, int P, int K, rsx_stream_t stream);
 /* Sorted row keys (stable sort done by the caller) -> uniq_row[U], seg_off[U+1], nuniq[0] = U and the row -> j slot
  * map (previous call's entries cleared first): the same workspace contract as rsx_field_sort with F = 1, so
- * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.       */
+ * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.
+ * segid (nullable; int32 [stride + 2 + ceil(stride/16)], stride >= N): the two-stage segment-sum workspace, as written by
+ * rsx_field_sort.  scratch: int32 [ceil(N/1024) + 1].  Multi-workgroup: three small launches.                         */
 int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* uniq_row, int32_t* seg_off, int32_t* nuniq,
-                        int32_t* slot, rsx_stream_t stream);
+                        int32_t* slot, int32_t* segid, int stride, int32_t* scratch, rsx_stream_t stream);
 /* Ordered segment-sum of generic per-entry row gradients vals[N,K] (the F = 1 case of rsx_segsum_bwd).  null_row >= 0
  * names a padding row whose entries carry exactly-zero gradients by construction (DIN history padding id 0,
  * din/din.py:107): its segment is not walked and G = 0 is written for it; -1 = no such row.                        */

@@ -64,51 +64,111 @@ __global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ 
 }
 
 // -------------------------------------------------------------------------------------------------
-// Sorted keys -> segments.  Input: keys sorted ascending (any stable sort; ties keep entry order).  One
-// workgroup: head flags + block scan ->  uniq_row[j], seg_off[j] (seg_off[U] = N), nuniq[0] = U, and the
-// row -> j slot map (clearing the previous call's entries first).  Same outputs as rsx_field_sort with F = 1.
+// Sorted keys -> segments.  Input: keys sorted ascending (any stable sort; ties keep entry order).  Outputs: uniq_row[j],
+// seg_off[j] (seg_off[U] = N), nuniq[0] = U and the row -> j slot map (the previous call's entries cleared first) -- the
+// rsx_field_sort contract with F = 1 -- plus, when segid != NULL, the two-stage segment-sum workspace (segment index of
+// every position, long / huge segment lists).  Three small launches over 1024-key blocks: head counts (+ slot clearing),
+// emit (each block adds the counts of the blocks before it: <= N/1024 values), long lists.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sorted_segments_k(const int32_t* __restrict__ keys, int N,
-                                                          int32_t* __restrict__ uniq_row, int32_t* __restrict__ seg_off,
-                                                          int32_t* __restrict__ nuniq, int32_t* __restrict__ slot) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
+constexpr int SS_T = 256, SS_IPT = 4, SS_BLK = SS_T * SS_IPT;
+
+__global__ __launch_bounds__(SS_T) void sorted_heads_k(const int32_t* __restrict__ keys, int N,
+                                                       const int32_t* __restrict__ uniq_row,
+                                                       const int32_t* __restrict__ nuniq, int32_t* __restrict__ slot,
+                                                       int32_t* __restrict__ blk_cnt, int32_t* __restrict__ long_cnt) {
+  __shared__ int wsum[SS_T / 64];
   const int tid = threadIdx.x;
   const int prev = nuniq[0];
-  for (int jj = tid; jj < prev; jj += 1024) slot[uniq_row[jj]] = -1;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  const int per = (N + 1023) / 1024;
-  const int i0 = tid * per, i1 = i0 + per < N ? i0 + per : N;
+  for (int jj = blockIdx.x * SS_T + tid; jj < prev; jj += gridDim.x * SS_T) slot[uniq_row[jj]] = -1;
+  if (long_cnt != nullptr && blockIdx.x == 0 && tid < 2) long_cnt[tid] = 0;
+  const int i0 = blockIdx.x * SS_BLK + tid * SS_IPT;
   int cnt = 0;
-  for (int i = i0; i < i1; ++i)
-    if (i == 0 || keys[i] != keys[i - 1]) ++cnt;
+#pragma unroll
+  for (int k = 0; k < SS_IPT; ++k) {
+    const int i = i0 + k;
+    if (i < N && (i == 0 || keys[i] != keys[i - 1])) ++cnt;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+  if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) blk_cnt[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(SS_T) void sorted_emit_k(const int32_t* __restrict__ keys, int N,
+                                                      int32_t* __restrict__ uniq_row, int32_t* __restrict__ seg_off,
+                                                      int32_t* __restrict__ nuniq, int32_t* __restrict__ slot,
+                                                      int32_t* __restrict__ segid, const int32_t* __restrict__ blk_cnt) {
+  __shared__ int wsum[SS_T / 64];
+  __shared__ int red[SS_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // heads in the blocks before this one
+  int before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += SS_T) before += blk_cnt[b];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  if (lane == 0) red[w] = before;
+  const int i0 = blockIdx.x * SS_BLK + tid * SS_IPT;
+  int key[SS_IPT], pk = 0;
+  bool head[SS_IPT];
+  int cnt = 0;
+  if (i0 > 0 && i0 < N) pk = keys[i0 - 1];
+#pragma unroll
+  for (int k = 0; k < SS_IPT; ++k) {
+    const int i = i0 + k;
+    key[k] = i < N ? keys[i] : 0;
+    head[k] = i < N && (i == 0 || key[k] != (k == 0 ? pk : key[k - 1]));
+    cnt += head[k];
+  }
   int incl = cnt;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int o = __shfl_up(incl, d);
-    if ((tid & 63) >= d) incl += o;
+    if (lane >= d) incl += o;
   }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  if (lane == 63) wsum[w] = incl;
   __syncthreads();
-  int base = incl - cnt, total = 0;
-  for (int w = 0; w < 16; ++w) {
-    if (w < (tid >> 6)) base += wsum[w];
-    total += wsum[w];
-  }
-  int jn = base;
-  for (int i = i0; i < i1; ++i) {
-    if (i == 0 || keys[i] != keys[i - 1]) {
-      uniq_row[jn] = keys[i];
+  int jn = (red[0] + red[1]) + (red[2] + red[3]) + incl - cnt;
+  for (int ww = 0; ww < w; ++ww) jn += wsum[ww];
+#pragma unroll
+  for (int k = 0; k < SS_IPT; ++k) {
+    const int i = i0 + k;
+    if (i >= N) break;
+    if (head[k]) {
+      uniq_row[jn] = key[k];
       seg_off[jn] = i;
-      slot[keys[i]] = jn;
+      slot[key[k]] = jn;
       ++jn;
     }
+    if (segid != nullptr) segid[i] = jn - 1;
   }
-  if (tid == 0) {
-    seg_off[total] = N;
-    nuniq[0] = total;
+  if (i0 + SS_IPT >= N && i0 < N) {   // the thread holding the last key: jn is now the total
+    seg_off[jn] = N;
+    nuniq[0] = jn;
   }
+  if (N == 0 && blockIdx.x == 0 && tid == 0) {
+    seg_off[0] = 0;
+    nuniq[0] = 0;
+  }
+}
+
+// long (> 16 entries) segments from the front of the list, huge (> 256) from the back; one returning atomic per wave
+__global__ __launch_bounds__(256) void sorted_long_lists_k(const int32_t* __restrict__ seg_off,
+                                                           const int32_t* __restrict__ nuniq, int32_t* __restrict__ cnt,
+                                                           int32_t* __restrict__ ll, int nch) {
+  const int j = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const int U = nuniq[0];
+  const int L = j < U ? seg_off[j + 1] - seg_off[j] : 0;
+  const bool lg = L > 16 && L <= 256, hg = L > 256;
+  const uint64_t ml = __ballot(lg), mh = __ballot(hg);
+  int bl = 0, bh = 0;
+  if (lane == 0 && ml) bl = atomicAdd(cnt, __popcll(ml));
+  if (lane == 0 && mh) bh = atomicAdd(cnt + 1, __popcll(mh));
+  bl = __shfl(bl, 0);
+  bh = __shfl(bh, 0);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  if (lg) ll[bl + __popcll(ml & lt)] = j;
+  if (hg) ll[nch - 1 - (bh + __popcll(mh & lt))] = j;
 }
 
 template <int K>
@@ -156,11 +216,23 @@ extern "C" int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* i
 }
 
 extern "C" int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* uniq_row, int32_t* seg_off,
-                                   int32_t* nuniq, int32_t* slot, rsx_stream_t stream) {
+                                   int32_t* nuniq, int32_t* slot, int32_t* segid, int stride, int32_t* scratch,
+                                   rsx_stream_t stream) {
   if (N < 0) return RSX_EINVAL;
-  if (!uniq_row || !seg_off || !nuniq || !slot || (N > 0 && !sorted_keys)) return RSX_EINVAL;
-  hipLaunchKernelGGL(sorted_segments_k, dim3(1), dim3(1024), 0, rsx_s(stream), sorted_keys, N, uniq_row, seg_off, nuniq,
-                     slot);
+  if (!uniq_row || !seg_off || !nuniq || !slot || !scratch || (N > 0 && !sorted_keys)) return RSX_EINVAL;
+  if (segid != nullptr && stride < N) return RSX_EINVAL;
+  const int nblk = N > 0 ? (N + SS_BLK - 1) / SS_BLK : 1;
+  int32_t* cnt = segid != nullptr ? segid + stride : nullptr;       // [2] counts, then the list [ceil(N/16)]
+  hipLaunchKernelGGL(sorted_heads_k, dim3(nblk), dim3(SS_T), 0, rsx_s(stream), sorted_keys, N, uniq_row, nuniq, slot,
+                     scratch, cnt);
   RSX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sorted_emit_k, dim3(nblk), dim3(SS_T), 0, rsx_s(stream), sorted_keys, N, uniq_row, seg_off, nuniq,
+                     slot, segid, scratch);
+  RSX_CHECK_LAUNCH();
+  if (segid != nullptr && N > 0) {
+    hipLaunchKernelGGL(sorted_long_lists_k, dim3((N + 255) / 256), dim3(256), 0, rsx_s(stream), seg_off, nuniq, cnt,
+                       cnt + 2, (N + 15) / 16);
+    RSX_CHECK_LAUNCH();
+  }
   return RSX_OK;
 }

@@ -234,6 +234,10 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
     const int sb = so[j], se = so[j + 1];
     sl = (size_t)f * stride + j;
     row = uniq_row[sl];
+    if (null_row >= 0 && row == null_row) {   // the padding row is written (as zero) by its row-owner group
+      valid = false;
+      return true;
+    }
     if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
     const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
     partial_range_sum<LPR>(P4, part.P1, (size_t)f * nch + c0, sb % SEG_CHUNK != 0, q, do1, 0, nt, acc, a1);
@@ -246,6 +250,7 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
   const int sb = so[j], se = so[j + 1];
   sl = (size_t)f * stride + j;
   row = uniq_row[sl];
+  if (null_row >= 0 && row == null_row) return false;   // the padding row is written (as zero) by its row-owner group
   valid = g == 0;
   if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
   const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;

@@ -517,6 +517,12 @@ class SparseTable:
         self.nuniq = torch.zeros(1, **i32)
         self.slot = torch.full((self.R + 4,), -1, **i32)
         self.G = torch.zeros(self.cap, self.K, device=dev)
+        self.scratch = torch.zeros((self.cap + 1023) // 1024 + 1, **i32)
+        # two-stage segment-sum workspace (Zipf-head rows make a few segments thousands of entries long)
+        nch = (self.cap + 15) // 16
+        self.segid = torch.zeros(self.cap + 2 + nch, **i32)
+        self.P = torch.zeros(nch * 2, self.K, device=dev)
+        self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), None)
         self.hook = torch.zeros((), device=dev, requires_grad=True)
         self.pending = []
         self._seq = 0
@@ -547,10 +553,18 @@ class SparseTable:
         assert N <= self.cap, "SparseTable capacity %d < %d entries" % (self.cap, N)
         skeys, perm = torch.sort(ids, stable=True)
         perm = perm.to(torch.int32)
+        two = N > EmbeddingArena.TWO_STAGE_MIN_B
         check(lib().rsx_sorted_segments(_ptr(skeys), N, _ptr(self.uniq_row), _ptr(self.seg_off), _ptr(self.nuniq),
-                                        _ptr(self.slot), _stream()), "rsx_sorted_segments")
+                                        _ptr(self.slot), _ptr(self.segid) if two else None, self.cap, _ptr(self.scratch),
+                                        _stream()), "rsx_sorted_segments")
+        part = None
+        if two:
+            part = C.byref(self.partials)
+            check(lib().rsx_segsum_partials(None, None, _ptr(vals), None, None, _ptr(perm), _ptr(self.seg_off),
+                                            _ptr(self.uniq_row), part, 0, N, 1, self.K, self.cap, self.null_row, _stream()),
+                  "rsx_segsum_partials")
         check(lib().rsx_segsum_rows(_ptr(vals), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq),
-                                    _ptr(self.G), N, self.K, self.cap, self.null_row, None, _stream()), "rsx_segsum_rows")
+                                    _ptr(self.G), N, self.K, self.cap, self.null_row, part, _stream()), "rsx_segsum_rows")
         self._keep = (skeys, perm, vals)
 
     def adam_segments(self, lazy=False):
