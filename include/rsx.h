@@ -102,10 +102,17 @@ typedef struct {
   float* P;
   float* P1;                  /* nullable when gy1 is NULL */
 } rsx_seg_partials;
+/* Layout of the per-example inputs (dX, S, gy1, gy2) when they are read in place from an all-gathered buffer (data
+ * parallel): example e lives in rank block e / examples at local index e % examples; blocks are stride_floats apart
+ * (a multiple of 4) and each pointer names its array inside block 0.  NULL = contiguous over the batch.            */
+typedef struct {
+  int32_t examples;
+  int64_t stride_floats;
+} rsx_example_blocks;
 int rsx_segsum_partials(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                         const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                         const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B, int F, int D, int stride,
-                        int null_row, rsx_stream_t stream);
+                        int null_row, const rsx_example_blocks* blocks_h, rsx_stream_t stream);
 
 /* Row-wise gradient "scatter" as a sorted segment-sum (replaces the IndexedSlices gradient of the
  * gather + tf.unsorted_segment_sum, Appendix A-4): for unique row (f, j)
@@ -116,7 +123,7 @@ int rsx_segsum_partials(const float* tables, const float* S, const float* dX, co
 int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                    const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq,
                    float* G, float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride,
-                   const rsx_seg_partials* partials_h, rsx_stream_t stream);
+                   const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: tf.train.AdamOptimizer(lr).minimize(...) fm/fm.py:162-163.
@@ -187,8 +194,8 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
                          int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                         const rsx_seg_partials* partials_h, float* state, float lr, float beta1, float beta2, float eps,
-                         rsx_stream_t stream);
+                         const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state, float lr,
+                         float beta1, float beta2, float eps, rsx_stream_t stream);
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

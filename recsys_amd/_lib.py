@@ -28,6 +28,10 @@ class AdamSlice(C.Structure):
                 ("blk_hi", C.c_uint32)]
 
 
+class ExampleBlocks(C.Structure):
+    _fields_ = [("examples", C.c_int32), ("stride_floats", C.c_int64)]
+
+
 class SegPartials(C.Structure):
     _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p)]
 
@@ -44,8 +48,8 @@ _SIGS = {
     "rsx_strerror": (C.c_char_p, [_I]),
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P, _P]),
-    "rsx_segsum_partials": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P]),
+    "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P, _P, _P]),
+    "rsx_segsum_partials": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P, _P]),
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
     "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
     "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P]),
@@ -53,7 +57,7 @@ _SIGS = {
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
-    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _F, _F, _F, _F, _P]),
+    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _F, _F, _F, _F, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),

@@ -74,8 +74,27 @@ __global__ __launch_bounds__(1024) void field_sort_k(const SortArgs a) {
 //    are added in ascending sub-range order.  A fixed order -> deterministic; no atomics anywhere.
 constexpr int SEG_SHORT = 16;
 
+// Per-example inputs (dX, S, gy1, gy2) either contiguous over the batch (b == 0) or RANK-BLOCKED as an all-gather leaves
+// them: example e lives in block r = e / b at local index e % b, blocks `stride` floats apart (each pointer names its
+// array inside block 0).  Lets the data-parallel scatter read the gathered buffer in place.
+struct ExBlocks {
+  int b;
+  long long stride;
+};
+__device__ __forceinline__ void ex_locate(const ExBlocks& xb, int e, int& i, size_t& off) {
+  if (xb.b > 0) {
+    const int r = (int)((unsigned)e / (unsigned)xb.b);
+    i = e - r * xb.b;
+    off = (size_t)r * (size_t)xb.stride;
+  } else {
+    i = e;
+    off = 0;
+  }
+}
+
 template <int LPR>
 struct SegCtx {
+  ExBlocks xb;
   const float4* __restrict__ S4;
   const float4* __restrict__ X4;
   const float* __restrict__ gy1;
@@ -100,10 +119,13 @@ __device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4
     for (int k = 0; k < 4; ++k) {
       const bool ok = bb[k] >= 0;
       const int b = ok ? bb[k] : 0;
-      g[k] = (ok && c.gy2 != nullptr) ? c.gy2[b] : 0.f;
-      s[k] = (ok && c.gy2 != nullptr) ? c.S4[(size_t)b * LPR + c.q] : z;
-      x[k] = (ok && c.X4 != nullptr) ? c.X4[((size_t)b * c.F + c.f) * LPR + c.q] : z;
-      h[k] = (ok && c.do1) ? c.gy1[b] : 0.f;
+      int bi;
+      size_t bo;
+      ex_locate(c.xb, b, bi, bo);
+      g[k] = (ok && c.gy2 != nullptr) ? c.gy2[bo + bi] : 0.f;
+      s[k] = (ok && c.gy2 != nullptr) ? c.S4[bo / 4 + (size_t)bi * LPR + c.q] : z;
+      x[k] = (ok && c.X4 != nullptr) ? c.X4[bo / 4 + ((size_t)bi * c.F + c.f) * LPR + c.q] : z;
+      h[k] = (ok && c.do1) ? c.gy1[bo + bi] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -176,8 +198,8 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
                                              const float* __restrict__ gy2, const int32_t* __restrict__ perm,
                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
                                              const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
-                                             int null_row, const SegPartials& part, bool& valid, size_t& sl, float4& acc,
-                                             float& a1, float4& e, int& row, bool& do1) {
+                                             int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
+                                             float4& acc, float& a1, float4& e, int& row, bool& do1) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -207,6 +229,7 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
     valid = own && end - beg <= SEG_SHORT;        // long rows belong to their helper wave
     if (!valid) return true;
     SegCtx<LPR> c;
+    c.xb = xb;
     c.S4 = reinterpret_cast<const float4*>(S);
     c.X4 = reinterpret_cast<const float4*>(dX);
     c.gy1 = gy1;
@@ -282,11 +305,11 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
                                             const float* __restrict__ gy2, const int32_t* __restrict__ perm,
                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
                                             const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
-                                            int null_row, const SegPartials& part, bool& valid, size_t& sl, float4& acc,
-                                            float& a1, float4& e, int& row, bool& do1) {
+                                            int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
+                                            float4& acc, float& a1, float4& e, int& row, bool& do1) {
   if (part.P != nullptr)
     return segsum_wave2<D>(wave, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride, null_row,
-                           part, valid, sl, acc, a1, e, row, do1);
+                           part, xb, valid, sl, acc, a1, e, row, do1);
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -313,6 +336,7 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   if (valid && null_row >= 0 && row == null_row) end = beg;
   const int L = end - beg;
   SegCtx<LPR> c;
+  c.xb = xb;
   c.S4 = reinterpret_cast<const float4*>(S);
   c.X4 = reinterpret_cast<const float4*>(dX);
   c.gy1 = gy1;
@@ -364,7 +388,8 @@ __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict
                                                          const float* __restrict__ gy2, const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ seg_off,
                                                          const int32_t* __restrict__ uniq_row, const SegPartials ws,
-                                                         uint64_t w1_mask, int B, int F, int stride, int null_row) {
+                                                         uint64_t w1_mask, int B, int F, int stride, int null_row,
+                                                         const ExBlocks xb) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -411,10 +436,13 @@ __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict
       const int pos = p0 + k0 + k;
       const bool use = pos < hi0 || (pos >= lo1 && pos < p1);
       const int b = pb[k0 + k];
-      gg[k] = (use && fm) ? gy2[b] : 0.f;
-      ss[k] = (use && fm) ? S4[(size_t)b * LPR + q] : z;
-      xx[k] = (use && has_x) ? X4[((size_t)b * F + f) * LPR + q] : z;
-      hh[k] = (use && do1) ? gy1[b] : 0.f;
+      int bi;
+      size_t bo;
+      ex_locate(xb, b, bi, bo);
+      gg[k] = (use && fm) ? gy2[bo + bi] : 0.f;
+      ss[k] = (use && fm) ? S4[bo / 4 + (size_t)bi * LPR + q] : z;
+      xx[k] = (use && has_x) ? X4[bo / 4 + ((size_t)bi * F + f) * LPR + q] : z;
+      hh[k] = (use && do1) ? gy1[bo + bi] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -454,7 +482,8 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
                                                     const int32_t* __restrict__ uniq_row,
                                                     const int32_t* __restrict__ nuniq, float* __restrict__ G,
                                                     float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
-                                                    int stride, int null_row, const SegPartials part) {
+                                                    int stride, int null_row, const SegPartials part,
+                                                    const ExBlocks xb) {
   constexpr int LPR = D / 4;
   const int q = (threadIdx.x & 63) % LPR;
   bool valid, do1;
@@ -463,7 +492,7 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   float a1;
   int row;
   if (!segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                      nuniq, w1_mask, B, F, stride, null_row, part, valid, sl, acc, a1, e, row, do1))
+                      nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1))
     return;
   if (valid) {
     reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
@@ -492,7 +521,8 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ seg_off,
                                                      const int32_t* __restrict__ uniq_row,
                                                      const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F,
-                                                     int stride, const HotAdam h, const SegPartials part) {
+                                                     int stride, const HotAdam h, const SegPartials part,
+                                                     const ExBlocks xb) {
   constexpr int LPR = D / 4;
   const float b1p = h.state[0], b2p = h.state[1];
   if (blockIdx.x >= h.n_own + h.extra.n_blk) {
@@ -507,7 +537,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float a1;
     int row;
     if (segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                       nuniq, w1_mask, B, F, stride, -1, part, valid, sl, acc, a1, e, row, do1) && valid) {
+                       nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1) && valid) {
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
@@ -556,17 +586,26 @@ template <int D>
 static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
                           const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                           const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
-                          int F, int stride, int null_row, const SegPartials& part) {
+                          int F, int stride, int null_row, const SegPartials& part, const ExBlocks& xb) {
   segsum_bwd_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
-                                          stride, null_row, part);
+                                          stride, null_row, part, xb);
 }
 template <int D>
 static void launch_partials(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
                             const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                             const int32_t* uniq_row, const SegPartials& ws, uint64_t mask, int B, int F, int stride,
-                            int null_row) {
+                            int null_row, const ExBlocks& xb) {
   segsum_partials_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F, stride,
-                                               null_row);
+                                               null_row, xb);
+}
+// host view of the rank-blocked input layout; nullptr -> contiguous
+static inline int ex_blocks(const rsx_example_blocks* h, int B, ExBlocks& out) {
+  out = ExBlocks{0, 0};
+  if (h == nullptr) return RSX_OK;
+  if (h->examples <= 0 || h->stride_floats < 0 || (h->stride_floats & 3) != 0) return RSX_EINVAL;
+  if (h->examples >= B) return RSX_OK;                 // one block: contiguous
+  out = ExBlocks{h->examples, (long long)h->stride_floats};
+  return RSX_OK;
 }
 // host view of the two-stage workspace; nullptr -> single-stage
 static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegPartials& out) {
@@ -619,7 +658,7 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
 static int segsum_impl(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                        const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq, float* G,
                        float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
-                       const rsx_seg_partials* partials_h, rsx_stream_t stream) {
+                       const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, rsx_stream_t stream) {
   if (!perm || !seg_off || !uniq_row || !nuniq || !G || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D))
     return RSX_EINVAL;
   if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
@@ -628,11 +667,14 @@ static int segsum_impl(const float* tables, const float* S, const float* dX, con
   SegPartials part;
   const int rcp = seg_partials(partials_h, gy1 != nullptr, part);
   if (rcp != RSX_OK) return rcp;
+  ExBlocks xb;
+  const int rcb = ex_blocks(blocks_h, B, xb);
+  if (rcb != RSX_OK) return rcb;
   const int gpw = 64 / (D / 4);                                   // unique rows per wave
   const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);   // two-stage: + helpers
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row, part);
+                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row, part, xb);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -641,27 +683,32 @@ extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* 
                               const float* gy2, const int32_t* perm, const int32_t* seg_off,
                               const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1,
                               uint64_t w1_field_mask, int B, int F, int D, int stride,
-                              const rsx_seg_partials* partials_h, rsx_stream_t stream) {
+                              const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
+                              rsx_stream_t stream) {
   return segsum_impl(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, w1_field_mask, B, F, D, stride, -1,
-                     partials_h, stream);
+                     partials_h, blocks_h, stream);
 }
 
 extern "C" int rsx_segsum_partials(const float* tables, const float* S, const float* dX, const float* gy1,
                                    const float* gy2, const int32_t* perm, const int32_t* seg_off,
                                    const int32_t* uniq_row, const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B,
-                                   int F, int D, int stride, int null_row, rsx_stream_t stream) {
+                                   int F, int D, int stride, int null_row, const rsx_example_blocks* blocks_h,
+                                   rsx_stream_t stream) {
   if (!perm || !seg_off || !uniq_row || !ws_h || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D)) return RSX_EINVAL;
   if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   SegPartials ws;
   const int rc = seg_partials(ws_h, gy1 != nullptr, ws);
   if (rc != RSX_OK) return rc;
+  ExBlocks xb;
+  const int rcb = ex_blocks(blocks_h, B, xb);
+  if (rcb != RSX_OK) return rcb;
   const int gpw = 64 / (D / 4);                                   // chunks per wave
   const int nch = (B + SEG_CHUNK - 1) / SEG_CHUNK;
   const long long waves = (long long)F * ((nch + gpw - 1) / gpw);
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   RSX_DISPATCH_D(D, launch_partials, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws,
-                 w1_field_mask, B, F, stride, null_row);
+                 w1_field_mask, B, F, stride, null_row, xb);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -670,8 +717,9 @@ template <int D>
 static void launch_segsum_adam(dim3 grid, dim3 block, hipStream_t st, const float* S, const float* dX, const float* gy1,
                                const float* gy2, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                const int32_t* nuniq, uint64_t mask, int B, int F, int stride, const HotAdam& h,
-                               const SegPartials& part) {
-  segsum_adam_k<D><<<grid, block, 0, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h, part);
+                               const SegPartials& part, const ExBlocks& xb) {
+  segsum_adam_k<D><<<grid, block, 0, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h, part,
+                                           xb);
 }
 
 extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w,
@@ -679,8 +727,8 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
                                     const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                                    const rsx_seg_partials* partials_h, float* state, float lr, float beta1, float beta2,
-                                    float eps, rsx_stream_t stream) {
+                                    const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state,
+                                    float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
@@ -690,6 +738,9 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   SegPartials part;
   const int rcp = seg_partials(partials_h, gy1 != nullptr, part);
   if (rcp != RSX_OK) return rcp;
+  ExBlocks xb;
+  const int rcb = ex_blocks(blocks_h, B, xb);
+  if (rcb != RSX_OK) return rcb;
   HotAdam h;
   h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
   h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state;
@@ -712,7 +763,7 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   h.total_blocks = h.n_own + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,
-                 w1_field_mask, B, F, stride, h, part);
+                 w1_field_mask, B, F, stride, h, part, xb);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -721,5 +772,5 @@ extern "C" int rsx_segsum_rows(const float* vals, const int32_t* perm, const int
                                const int32_t* nuniq, float* G, int N, int K, int stride, int null_row,
                                const rsx_seg_partials* partials_h, rsx_stream_t stream) {
   return segsum_impl(nullptr, nullptr, vals, nullptr, nullptr, perm, seg_off, uniq_row, nuniq, G, nullptr, 0, N, 1, K,
-                     stride, null_row, partials_h, stream);
+                     stride, null_row, partials_h, nullptr, stream);
 }

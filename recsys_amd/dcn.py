@@ -95,14 +95,15 @@ def _train_fused(store, arena, ids, labels, params, masks):
 
     def train_op():
         with torch.no_grad():
-            dXg = dX
-            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order)
-                dXg, _, _, _ = dp.gather_example_grads(dX, dense=store.dense.grad)
-            Bg = dXg.shape[0]
+            dXg, blocks, Bg = dX, None, dX.shape[0]
+            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order);
+                # the scatter then reads every rank's block in place from the gathered buffer
+                dXg, _, _, _, blocks = dp.gather_example_grads(dX, dense=store.dense.grad, blocked=True)
+                Bg = dX.shape[0] * dp.world
             if hot is not None:
-                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, store.dense.adam_segments(), last_sweep)
+                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, store.dense.adam_segments(), last_sweep, blocks=blocks)
             else:
-                arena.segsum(Bg, None, dXg, None, None)
+                arena.segsum(Bg, None, dXg, None, None, blocks=blocks)
                 store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)

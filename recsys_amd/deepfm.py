@@ -143,14 +143,15 @@ def _train_fused(store, arena, ids, labels, params, masks):
 
     def train_op():
         with torch.no_grad():
-            Sg, dXg, gy1g, gy2g = S, dX, gy1, gy2
-            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order)
-                dXg, Sg, gy1g, gy2g = dp.gather_example_grads(dX, S, gy1, gy2, dense=store.dense.grad)
-            Bg = dXg.shape[0]
+            Sg, dXg, gy1g, gy2g, blocks, Bg = S, dX, gy1, gy2, None, dX.shape[0]
+            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order);
+                # the scatter then reads every rank's block in place from the gathered buffer
+                dXg, Sg, gy1g, gy2g, blocks = dp.gather_example_grads(dX, S, gy1, gy2, dense=store.dense.grad, blocked=True)
+                Bg = dX.shape[0] * dp.world
             if hot is not None:     # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
-                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, store.dense.adam_segments(), last_sweep)
+                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, store.dense.adam_segments(), last_sweep, blocks=blocks)
             else:
-                arena.segsum(Bg, Sg, dXg, gy1g, gy2g)
+                arena.segsum(Bg, Sg, dXg, gy1g, gy2g, blocks=blocks)
                 store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)

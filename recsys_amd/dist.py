@@ -132,7 +132,7 @@ class DataParallel:
             w += [("gy1", 1)]
         return w
 
-    def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None, dense=None):
+    def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None, dense=None, blocked=False):
         """Packs the per-example gradient block, all-gathers it once, and returns the global views
         dX_g [N*b, F*D], S_g [N*b, D]|None, gy1_g [N*b]|None, gy2_g [N*b]|None (contiguous).
         ids (int32 [b,F], optional) ride in the same block -> a 5th return value ids_g [N*b,F]: one collective per
@@ -140,7 +140,10 @@ class DataParallel:
         integer ids viewed as fp32 are subnormals, which float copy kernels may flush to zero.
         dense (flat fp32 [n], optional): this replica's dense-gradient arena rides behind the example block and is
         summed over replicas IN PLACE, in rank order on every rank (bit-identical replicas) -- the dense all-reduce
-        folded into the same collective: the step is latency-bound, so one collective beats two."""
+        folded into the same collective: the step is latency-bound, so one collective beats two.
+        blocked=True (with dense): nothing is copied after the collective -- the returned tensors are the arrays of RANK
+        BLOCK 0 inside the gathered buffer plus a 5th value `blocks` = (b, floats between rank blocks) for
+        EmbeddingArena.segsum*(…, blocks=blocks), which read every rank's block in place."""
         b, N = dX.shape[0], self.world
         parts = [dX]
         if gy2 is not None:
@@ -154,9 +157,25 @@ class DataParallel:
             gi = g
             g = g.view(torch.float32)
         elif dense is not None:
-            W = sum(p.shape[1] for p in parts)
-            out = self.all_gather_rows(torch.cat([p.reshape(-1) for p in parts] + [dense]).view(1, -1))   # [N, L+n]
-            torch.sum(out[:, -dense.numel():], 0, out=dense)
+            L = sum(p.numel() for p in parts)
+            pad = (-(L + dense.numel())) % 4                     # rank blocks stay 16-byte aligned for float4 loads
+            tail = [dense] if pad == 0 else [dense, dense.new_zeros(pad)]
+            out = self.all_gather_rows(torch.cat([p.reshape(-1) for p in parts] + tail).view(1, -1))   # [N, L+n(+pad)]
+            torch.sum(out[:, L:L + dense.numel()], 0, out=dense)
+            if blocked:
+                views, o = [], 0
+                for p in parts:
+                    views.append(out[0, o:o + p.numel()])
+                    o += p.numel()
+                S_v = gy2_v = gy1_v = None
+                k = 1
+                if gy2 is not None:
+                    S_v, gy2_v = views[1], views[2]
+                    k = 3
+                if gy1 is not None:
+                    gy1_v = views[k]
+                self._keep = out
+                return views[0], S_v, gy1_v, gy2_v, (b, out.shape[1])
             # per-rank block = the parts back to back, each [b, w_i] row-major
             res, o = [], 0
             for p in parts:

@@ -123,33 +123,41 @@ class EmbeddingArena:
                                       B, self.F, self.D, _stream()), "rsx_gather_fm_fwd")
         return E, S, y1, y2
 
-    def _stage_a(self, B, S, dX, gy1, gy2):
+    @staticmethod
+    def _blocks(blocks):
+        """blocks = (examples per rank block, floats between blocks) for inputs read in place from an all-gathered buffer
+        (dist.DataParallel.gather_example_grads(blocked=True)); None = contiguous."""
+        return None if blocks is None else C.byref(_lib.ExampleBlocks(int(blocks[0]), int(blocks[1])))
+
+    def _stage_a(self, B, S, dX, gy1, gy2, blk=None):
         """Stage A of the two-stage scatter; returns the partials handle stage B takes (None: single stage)."""
         if not self._two_stage(B):
             return None
         check(lib().rsx_segsum_partials(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
                                         _ptr(self.seg_off), _ptr(self.uniq_row), C.byref(self.partials), self.w1_mask,
-                                        B, self.F, self.D, self.stride, -1, _stream()), "rsx_segsum_partials")
+                                        B, self.F, self.D, self.stride, -1, blk, _stream()), "rsx_segsum_partials")
         return C.byref(self.partials)
 
-    def segsum(self, B, S, dX, gy1, gy2):
-        part = self._stage_a(B, S, dX, gy1, gy2)
+    def segsum(self, B, S, dX, gy1, gy2, blocks=None):
+        blk = self._blocks(blocks)
+        part = self._stage_a(B, S, dX, gy1, gy2, blk)
         check(lib().rsx_segsum_bwd(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
                                    _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.G),
                                    _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
-                                   self.stride, part, _stream()), "rsx_segsum_bwd")
+                                   self.stride, part, blk, _stream()), "rsx_segsum_bwd")
 
-    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None):
+    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups)."""
+        blk = self._blocks(blocks)
         arr, n = opt._seg_array(extra_segments)
         lr, b1, b2, eps = opt.hp
         w = self.with_w1 and gy1 is not None
-        part = self._stage_a(B, S, dX, gy1, gy2)
+        part = self._stage_a(B, S, dX, gy1, gy2, blk)
         check(lib().rsx_segsum_adam_rows(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), _ptr(self.w1) if w else None,
                                          _ptr(self.m_w) if w else None, _ptr(self.v_w) if w else None, _ptr(S), _ptr(dX),
                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
-                                         None if sweep is None else C.byref(sweep), part,
+                                         None if sweep is None else C.byref(sweep), part, blk,
                                          _ptr(opt.state), lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
 
     # -- optimizer segments ----------------------------------------------------------------
@@ -561,7 +569,8 @@ class SparseTable:
         if two:
             part = C.byref(self.partials)
             check(lib().rsx_segsum_partials(None, None, _ptr(vals), None, None, _ptr(perm), _ptr(self.seg_off),
-                                            _ptr(self.uniq_row), part, 0, N, 1, self.K, self.cap, self.null_row, _stream()),
+                                            _ptr(self.uniq_row), part, 0, N, 1, self.K, self.cap, self.null_row, None,
+                                            _stream()),
                   "rsx_segsum_partials")
         check(lib().rsx_segsum_rows(_ptr(vals), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq),
                                     _ptr(self.G), N, self.K, self.cap, self.null_row, part, _stream()), "rsx_segsum_rows")

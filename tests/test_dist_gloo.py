@@ -62,6 +62,15 @@ def _worker(rank, world, port, out_dir):
     flat2 = flat.clone()
     r2 = dp.gather_example_grads(torch.from_numpy(dX), torch.from_numpy(S), torch.from_numpy(gy1),
                                  torch.from_numpy(np.ascontiguousarray(gy2[:, 1])), dense=flat2)
+    # blocked form: no copies after the collective, rank blocks are read in place
+    flat3 = flat.clone()
+    v = dp.gather_example_grads(torch.from_numpy(dX), torch.from_numpy(S), torch.from_numpy(gy1),
+                                torch.from_numpy(np.ascontiguousarray(gy2[:, 1])), dense=flat3, blocked=True)
+    bb, stride = v[4]
+    buf = dp._keep
+    assert bb == b and stride == buf.shape[1] and stride % 4 == 0
+    assert v[0].data_ptr() == buf.data_ptr() and torch.equal(buf[:, :dX.size].reshape(world * b, -1), r2[0])
+    assert torch.equal(buf[:, dX.size:dX.size + S.size].reshape(world * b, -1), r2[1]) and torch.equal(flat3, flat2)
     dp.all_reduce_sum(flat)
     assert torch.allclose(flat2, flat, rtol=0, atol=1e-15)
     for a_, b_ in zip(r2, (dXg, Sg, gy1g, gy2g)):
