@@ -303,7 +303,9 @@ int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const fl
  * are overwritten or accumulated (acc_* != 0).  When Xk aliases X0 (first layer) pass distinct dXk / dX0 buffers.   */
 int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout, float* dXk,
                       int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, int B, int F, int H, int N, int D,
-                      rsx_stream_t stream);
+                      const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* sweep_h (nullable): a slice of the untouched-row optimizer sweep carried by extra workgroups of the dW launch (the
+ * MFMA-bound tiles leave HBM idle), as on the tower entry points.                                                  */
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.

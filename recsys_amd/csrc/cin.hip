@@ -15,13 +15,17 @@
 //   cin_bwd_dw_k  wave = (3 fields) x (16 h) x (16 n); dW = Z^T . dpre with Z generated on load; ones-row -> dc
 // All reductions are in fixed order: deterministic, no atomics.
 #include "rsx_common.h"
+#include "adam_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 cin_mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 constexpr int CIN_D = 16;
-constexpr int CIN_BT = 2;   // examples per wave (independent accumulator chains hide the 40-cycle MFMA latency)
+#ifndef RSX_CIN_BT
+#define RSX_CIN_BT 1
+#endif
+constexpr int CIN_BT = RSX_CIN_BT;   // examples per workgroup: 1 doubles the waves in flight (B = 256 gives few tiles); 2 was 20-25 % slower
 
 // ----------------------------------------------------------------------------------------------- forward
 struct CinFwdArgs {
@@ -33,84 +37,108 @@ struct CinFwdArgs {
   int B, F, H, N;
 };
 
-// grid = (ceil(N/16), ceil(B/2)), block = 64.  dyn LDS: 2 * F * 16 floats (X0 tiles).
-// The A operand Xk[b][h][d] does not depend on f: each lane keeps its HS = ceil(H/4) values per example in registers
-// for the whole kernel (HSMAX is the compile-time bound: 10 covers H <= 40, 32 covers H <= 128), so the inner loop is
-// only "8 W loads in flight -> 16 MFMAs".
+// grid = (ceil(N/16), ceil(B/4)), block = 256: wave w owns example 4*blockIdx.y + w and the 16 outputs n0.. of the
+// workgroup.  The B operand is staged through LDS: per field f the workgroup copies the [H, 16] slice of W_f ONCE
+// (coalesced float4 global loads, double-buffered: the loads of f+1 are in flight during the MFMAs of f) and its 4 waves
+// read it back transposed, so one L2 read feeds 4 MFMAs instead of 1 and a lane fetches the operands of 4 k-steps with a
+// single ds_read_b128.  k-permutation: k-step 4*ks + t uses h = 16*ks + 4*(lane>>4) + t on both operands.
+// The A operand Xk[b][h][d] does not depend on f: HSMAX (= k-steps, a multiple of 4: 12 covers H <= 48, 32 covers
+// H <= 128) values per lane stay in registers for the whole kernel.
+// dyn LDS: 2 * 16 * (4*HSMAX + 4) + 4 * F * 16 floats.
 template <int HSMAX>
-__global__ __launch_bounds__(64) void cin_fwd_k(const CinFwdArgs p) {
+__global__ __launch_bounds__(256) void cin_fwd_k(const CinFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sX0 = lds;                              // [BT][F*16]
-  const int lane = threadIdx.x;
-  const int b0 = blockIdx.y * CIN_BT;
-  for (int bt = 0; bt < CIN_BT; ++bt) {
-    const int b = b0 + bt;
-    for (int e = lane; e < p.F * 4; e += 64)
-      reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e] =
-          b < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)b * p.F * CIN_D)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  constexpr int HP = 4 * HSMAX + 4;              // padded h-stride of the transposed tile
+  constexpr int R = (HSMAX * 16 + 255) / 256;    // float4 per thread per tile
+  float* sW = lds;                               // [2][16][HP]
+  float* sX0 = lds + 2 * 16 * HP;                // [4][F*16]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int n = blockIdx.x * 16 + i;             // B-operand column
-  const bool nok = n < p.N;
-  const int hs = (p.H + 3) >> 2;
-  float areg[CIN_BT][HSMAX];
-#pragma unroll
-  for (int bt = 0; bt < CIN_BT; ++bt)
-#pragma unroll
-    for (int s_ = 0; s_ < HSMAX; ++s_) {
-      const int h = 4 * s_ + kq, b = b0 + bt;
-      areg[bt][s_] = (h < p.H && b < p.B) ? p.Xk[((size_t)b * p.H + h) * CIN_D + i] : 0.f;
-    }
-  __syncthreads();
-  f32x4 acc[CIN_BT];
-#pragma unroll
-  for (int bt = 0; bt < CIN_BT; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int f = 0; f < p.F; ++f) {
-    f32x4 T[CIN_BT];
-#pragma unroll
-    for (int bt = 0; bt < CIN_BT; ++bt) T[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* Wf = p.W + (size_t)f * p.H * p.N + n;
-#pragma unroll
-    for (int s0 = 0; s0 < HSMAX; s0 += 8) {     // 8 k-steps' W loads in flight, then their 16 MFMAs
-      if (s0 < hs) {                            // wave-uniform
-        float bw[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int h = 4 * (s0 + u) + kq;
-          bw[u] = (s0 + u < HSMAX && h < p.H && nok) ? Wf[(size_t)h * p.N] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (s0 + u < HSMAX) {
-#pragma unroll
-            for (int bt = 0; bt < CIN_BT; ++bt) T[bt] = cin_mfma(areg[bt][s0 + u < HSMAX ? s0 + u : 0], bw[u], T[bt]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int bt = 0; bt < CIN_BT; ++bt) {
-      const float4 x = *reinterpret_cast<const float4*>(sX0 + bt * p.F * CIN_D + f * CIN_D + kq * 4);  // rows d = 4*kq + r
-      acc[bt][0] += x.x * T[bt][0];
-      acc[bt][1] += x.y * T[bt][1];
-      acc[bt][2] += x.z * T[bt][2];
-      acc[bt][3] += x.w * T[bt][3];
-    }
+  const int n0 = blockIdx.x * 16;
+  const int b = blockIdx.y * 4 + wv;
+  const bool bok = b < p.B, nok = n0 + i < p.N;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = tid; e < 2 * 16 * HP; e += 256) sW[e] = 0.f;          // rows h >= H must read as zero
+  for (int e = tid; e < 4 * p.F * 4; e += 256) {
+    const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
+    const int bb = blockIdx.y * 4 + ex;
+    reinterpret_cast<float4*>(sX0)[e] = bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[r] : z4;
   }
-  if (nok) {
-    const float cv = p.c[n];
+  float areg[HSMAX];
 #pragma unroll
-    for (int bt = 0; bt < CIN_BT; ++bt) {
-      const int b = b0 + bt;
-      if (b < p.B) {
-        float4 o;
-        o.x = fmaxf(acc[bt][0] + cv, 0.f);
-        o.y = fmaxf(acc[bt][1] + cv, 0.f);
-        o.z = fmaxf(acc[bt][2] + cv, 0.f);
-        o.w = fmaxf(acc[bt][3] + cv, 0.f);
-        *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n) * CIN_D + kq * 4) = o;
+  for (int s_ = 0; s_ < HSMAX; ++s_) {
+    const int h = 16 * (s_ >> 2) + 4 * kq + (s_ & 3);
+    areg[s_] = (h < p.H && bok) ? p.Xk[((size_t)b * p.H + h) * CIN_D + i] : 0.f;
+  }
+  float4 wreg[R];
+  auto load_tile = [&](int f) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int q = tid + 256 * r, h = q >> 2, j = q & 3;
+      const int nn = n0 + 4 * j;
+      if ((p.N & 3) == 0) {                      // aligned rows: one float4
+        const bool ok = h < p.H && nn < p.N;
+        wreg[r] = *reinterpret_cast<const float4*>(p.W + ((size_t)f * p.H + (ok ? h : 0)) * p.N + (ok ? nn : 0));
+        if (!ok) wreg[r] = z4;
+      } else {                                   // odd widths (tests, tiny models): element-wise
+        const float* w = p.W + ((size_t)f * p.H + (h < p.H ? h : 0)) * p.N;
+        const bool hok = h < p.H;
+        wreg[r].x = (hok && nn + 0 < p.N) ? w[nn + 0] : 0.f;
+        wreg[r].y = (hok && nn + 1 < p.N) ? w[nn + 1] : 0.f;
+        wreg[r].z = (hok && nn + 2 < p.N) ? w[nn + 2] : 0.f;
+        wreg[r].w = (hok && nn + 3 < p.N) ? w[nn + 3] : 0.f;
       }
     }
+  };
+  auto store_tile = [&](int buf) {
+    float* t = sW + buf * 16 * HP;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int q = tid + 256 * r, h = q >> 2, j = q & 3;
+      if (h < p.H) {
+        t[(4 * j + 0) * HP + h] = wreg[r].x;
+        t[(4 * j + 1) * HP + h] = wreg[r].y;
+        t[(4 * j + 2) * HP + h] = wreg[r].z;
+        t[(4 * j + 3) * HP + h] = wreg[r].w;
+      }
+    }
+  };
+  load_tile(0);
+  __syncthreads();                               // zero fill done
+  store_tile(0);
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nks = (p.H + 15) >> 4;
+  for (int f = 0; f < p.F; ++f) {
+    if (f + 1 < p.F) load_tile(f + 1);
+    const float* t = sW + (f & 1) * 16 * HP + i * HP + 4 * kq;
+    f32x4 T = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < HSMAX / 4; ++ks) {
+      if (ks < nks) {                            // wave-uniform
+        const float4 bq = *reinterpret_cast<const float4*>(t + 16 * ks);
+        T = cin_mfma(areg[4 * ks + 0], bq.x, T);
+        T = cin_mfma(areg[4 * ks + 1], bq.y, T);
+        T = cin_mfma(areg[4 * ks + 2], bq.z, T);
+        T = cin_mfma(areg[4 * ks + 3], bq.w, T);
+      }
+    }
+    const float4 x = *reinterpret_cast<const float4*>(sX0 + wv * p.F * CIN_D + f * CIN_D + kq * 4);  // rows d = 4*kq + r
+    acc[0] += x.x * T[0];
+    acc[1] += x.y * T[1];
+    acc[2] += x.z * T[2];
+    acc[3] += x.w * T[3];
+    if (f + 1 < p.F) store_tile((f + 1) & 1);
+    __syncthreads();
+  }
+  if (nok && bok) {
+    const float cv = p.c[n0 + i];
+    float4 o;
+    o.x = fmaxf(acc[0] + cv, 0.f);
+    o.y = fmaxf(acc[1] + cv, 0.f);
+    o.z = fmaxf(acc[2] + cv, 0.f);
+    o.w = fmaxf(acc[3] + cv, 0.f);
+    *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n0 + i) * CIN_D + kq * 4) = o;
   }
 }
 
@@ -266,6 +294,8 @@ struct CinBwdDwArgs {
   float* dW;   // [F*H, N]
   float* dc;   // [N]
   int B, F, H, N, FG;   // FG = ceil(F/3) field groups
+  AdamSlice sweep;      // optional slice of the untouched-row optimizer sweep: extra z-planes of the grid (the MFMA-bound
+                        // tiles leave HBM idle; the sweep is pure streaming)
 };
 constexpr int CIN_FT = 3;   // fields per wave
 
@@ -273,6 +303,11 @@ constexpr int CIN_FT = 3;   // fields per wave
 // 4 waves of the workgroup take b = w, w+4, ... (4x the waves in flight to hide the operand loads) and their partial
 // tiles are added in wave order through LDS.
 __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
+  if ((int)blockIdx.z >= p.FG) {   // piggy-backed optimizer sweep
+    const uint32_t lin = (((uint32_t)blockIdx.z - (uint32_t)p.FG) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin);
+    return;
+  }
   __shared__ float red[4][CIN_FT + 1][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
@@ -374,19 +409,20 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
   if (!X0 || !Xk || !W || !c || !out) return RSX_EINVAL;
   if (D != CIN_D) return RSX_EUNSUPPORTED;
   if (H > 128) return RSX_EUNSUPPORTED;
-  const size_t lds = (size_t)CIN_BT * F * CIN_D * sizeof(float);
+  const int hsmax = H <= 48 ? 12 : 32;
+  const size_t lds = ((size_t)2 * 16 * (4 * hsmax + 4) + (size_t)4 * F * CIN_D) * sizeof(float);
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
   CinFwdArgs p{X0, Xk, W, c, out, B, F, H, N};
-  const dim3 grid((N + 15) / 16, (B + CIN_BT - 1) / CIN_BT);
-  if (H <= 40) hipLaunchKernelGGL(cin_fwd_k<10>, grid, dim3(64), lds, rsx_s(stream), p);
-  else hipLaunchKernelGGL(cin_fwd_k<32>, grid, dim3(64), lds, rsx_s(stream), p);
+  const dim3 grid((N + 15) / 16, (B + 3) / 4);
+  if (H <= 48) hipLaunchKernelGGL(cin_fwd_k<12>, grid, dim3(256), lds, rsx_s(stream), p);
+  else hipLaunchKernelGGL(cin_fwd_k<32>, grid, dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
 
 extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout,
                                  float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, int B, int F,
-                                 int H, int N, int D, rsx_stream_t stream) {
+                                 int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc) return RSX_EINVAL;
@@ -405,8 +441,12 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
   else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
-  CinBwdDwArgs w{X0, Xk, out, dout, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT};
-  hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG), dim3(256), 0, rsx_s(stream), w);
+  CinBwdDwArgs w{X0, Xk, out, dout, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT, {}};
+  const int rcs = adam_build_slice(sweep_h, w.sweep);
+  if (rcs != RSX_OK) return rcs;
+  const unsigned plane = (unsigned)((N + 15) / 16) * (unsigned)HT;
+  const unsigned zs = (w.sweep.n_blk + plane - 1) / plane;           // extra z-planes that carry the sweep
+  hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG + zs), dim3(256), 0, rsx_s(stream), w);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

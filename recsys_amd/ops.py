@@ -623,7 +623,8 @@ class CinLayerFn(torch.autograd.Function):
     xdeepfm/xdeepfm.py:145-172."""
 
     @staticmethod
-    def forward(ctx, X0, Xk, W, c):
+    def forward(ctx, X0, Xk, W, c, sweep=None):
+        """sweep: optional rsx_adam_slice (AdamTF1.cold_slices) carried by this layer's weight-gradient launch."""
         B, F, D = X0.shape
         H, N = Xk.shape[1], W.shape[1]
         X0, Xk = X0.contiguous(), Xk.contiguous()
@@ -631,6 +632,7 @@ class CinLayerFn(torch.autograd.Function):
         check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(c), _ptr(out), B, F, H, N, D, _stream()),
               "rsx_cin_layer_fwd")
         ctx.save_for_backward(X0, Xk, W, out)
+        ctx.sweep = sweep
         return out
 
     @staticmethod
@@ -641,5 +643,6 @@ class CinLayerFn(torch.autograd.Function):
         dX0, dXk = torch.empty_like(X0), torch.empty_like(Xk)
         dW, dc = torch.empty_like(W), torch.empty(N, device=W.device)
         check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(out), _ptr(g.contiguous()), _ptr(dXk), 0, _ptr(dX0),
-                                      0, _ptr(dW), _ptr(dc), B, F, H, N, D, _stream()), "rsx_cin_layer_bwd")
-        return dX0, dXk, dW, dc
+                                      0, _ptr(dW), _ptr(dc), B, F, H, N, D,
+                                      None if ctx.sweep is None else C.byref(ctx.sweep), _stream()), "rsx_cin_layer_bwd")
+        return dX0, dXk, dW, dc, None

@@ -71,11 +71,12 @@ def build_variables(store, params, capacity):
     store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
 
-def _cin(X0, P, sizes):
-    """'cin_net' (:135-182): every layer's full map is both the next hidden state and a direct output."""
+def _cin(X0, P, sizes, sweeps=None):
+    """'cin_net' (:135-182): every layer's full map is both the next hidden state and a direct output.
+    sweeps[k]: slice of the untouched-row optimizer sweep carried by layer k's weight-gradient launch."""
     outs, Xk = [], X0
     for k in range(len(sizes)):
-        Xk = CinLayerFn.apply(X0, Xk, P[f"cin.W{k}"], P[f"cin.c{k}"])
+        Xk = CinLayerFn.apply(X0, Xk, P[f"cin.W{k}"], P[f"cin.c{k}"], None if sweeps is None else sweeps[k])
         outs.append(Xk)
     res = torch.cat(outs, 1).sum(-1)                                        # (:180-181)
     return L.dense(res, P["cin.Wout"], P["cin.bout"], relu=True)            # cin_y [B,1] (:182)
@@ -84,15 +85,25 @@ def _cin(X0, P, sizes):
 def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     dp, P = store.dp, store.dense
     B = ids.shape[0]
+    sweeps, hot = None, None
     with torch.no_grad():
         if dp is None:
             store.sort_ids_for_backward(a1, ids)
             store.sort_ids_for_backward(a2, ids)
+            if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
+                # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
+                # (700 MB of streaming) rides in the CIN weight-gradient launches, which are MFMA-bound; the touched rows
+                # and the dense variables follow the scatter in one small launch
+                c1, h1 = a1.adam_split_segments()
+                c2, h2 = a2.adam_split_segments()
+                w = [float(store.cin_sizes[k]) * (a1.F if k == 0 else store.cin_sizes[k - 1]) for k in range(len(store.cin_sizes))]
+                sweeps = store.opt.cold_slices(c1 + c2, w)
+                hot = h1 + h2
         E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
         lin_pre = torch.addmv(y1cat, logx, P["lin.wnum"])                   # + 13 numeric log-values (:127)
         E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
     X0 = E1.view(B, a1.F, a1.D).requires_grad_()
-    cin_y = _cin(X0, P, store.cin_sizes)
+    cin_y = _cin(X0, P, store.cin_sizes, sweeps)
     with torch.no_grad():
         loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
@@ -116,7 +127,10 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             else:
                 a1.segsum(B, None, dX1.contiguous(), g_lin, None)
                 a2.segsum(B, None, dX2, None, None)
-            store.apply_gradients()
+            if hot is not None:
+                store.opt.step(hot + store.dense.adam_segments())            # touched rows + dense; advances the powers
+            else:
+                store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 
