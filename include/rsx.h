@@ -76,6 +76,14 @@ int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_o
 int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
                    int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid,
                    int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream);
+/* The same contract for batches beyond one workgroup's LDS (B > 16384: data-parallel steps sort N*b examples): a stable
+ * LSD radix sort over the id bits through global memory (transpose, 2 x {histogram, scan, stable scatter}, multi-workgroup
+ * segment detection), all fields per launch.  workspace: rsx_field_sort_large_workspace_ints(B, F, stride) int32.
+ * Envelope: max rows per field <= 2^18, B <= 2^24.  Works for any B >= 1; rsx_field_sort is faster below 16384.        */
+size_t rsx_field_sort_large_workspace_ints(int B, int F, int stride);
+int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
+                         int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace,
+                         int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream);
 /* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
 typedef struct {
   const int32_t* ids;

@@ -48,6 +48,8 @@ _SIGS = {
     "rsx_strerror": (C.c_char_p, [_I]),
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rsx_field_sort_large": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
+    "rsx_field_sort_large_workspace_ints": (C.c_size_t, [_I, _I, _I]),
     "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P, _P, _P]),
     "rsx_segsum_partials": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P, _P]),
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),

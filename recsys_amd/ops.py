@@ -70,6 +70,10 @@ class EmbeddingArena:
         self.G = torch.zeros(F * st, D, device=dev)
         self.gw1 = torch.zeros(F * st, device=dev) if with_w1 else None
         self.last_B = 0
+        # batches beyond one workgroup's LDS sort through global memory (csrc/sort_large.hip)
+        self.sort_ws = None
+        if st > self.LDS_SORT_MAX_B:
+            self.sort_ws = torch.zeros(int(lib().rsx_field_sort_large_workspace_ints(st, F, st)), **i32)
         # two-stage segment-sum workspace (B > TWO_STAGE_MIN_B): segment index per sorted position + chunk partials
         self.partials = None
         if st > self.TWO_STAGE_MIN_B:
@@ -84,6 +88,8 @@ class EmbeddingArena:
     # Above this batch size the scatter runs in two stages (uniform 16-position chunks feed the long segments): small
     # batches are latency-bound and one launch wins; large / skewed ones are bound by the longest segment chain.
     TWO_STAGE_MIN_B = 512
+    LDS_SORT_MAX_B = 8192         # above: rsx_field_sort_large (multi-workgroup; measured crossover ~8192, scripts/sort_time.py;
+                                  # rsx_field_sort itself reaches 16384)
 
     def _two_stage(self, B):
         return self.partials is not None and B > self.TWO_STAGE_MIN_B
@@ -92,10 +98,16 @@ class EmbeddingArena:
     def field_sort(self, ids):
         B = ids.shape[0]
         assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and B <= self.stride
-        check(lib().rsx_field_sort(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
-                                   _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot),
-                                   _ptr(self.segid) if self._two_stage(B) else None, self.max_rows,
-                                   B, self.F, self.stride, _stream()), "rsx_field_sort")
+        if B > self.LDS_SORT_MAX_B:
+            check(lib().rsx_field_sort_large(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
+                                             _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid),
+                                             _ptr(self.sort_ws), self.max_rows, B, self.F, self.stride, _stream()),
+                  "rsx_field_sort_large")
+        else:
+            check(lib().rsx_field_sort(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
+                                       _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot),
+                                       _ptr(self.segid) if self._two_stage(B) else None, self.max_rows,
+                                       B, self.F, self.stride, _stream()), "rsx_field_sort")
         self.last_B = B
 
     def sort_job(self, ids):

@@ -50,19 +50,18 @@ lay = CriteoLayout.from_columns(build_feature_columns(16)[1])
 rng = np.random.default_rng(0)
 F, D = 39, 16
 for B in (256, 4096, 16384, 65536):
-    arena = EmbeddingArena(lay.row_off, D, min(B, 16384), dev, with_w1=True, tables=np.zeros((int(lay.row_off[-1]), D), np.float32) + 0.01,
+    arena = EmbeddingArena(lay.row_off, D, B, dev, with_w1=True, tables=np.zeros((int(lay.row_off[-1]), D), np.float32) + 0.01,
                            w1=np.zeros(int(lay.row_off[-1]), np.float32))
     ids = torch.from_numpy(synth_ids(rng, B, lay.row_off)).to(dev)
     us = timeit(lambda: arena.gather(ids, fm=True, first_order=True))
     rec("gather_fm_fwd_k (+FM +1st order)", "B=%d F=39 D=16" % B, us, nbytes=B * F * (4 + 64 + 64))
-    if B <= 16384:
-        us = timeit(lambda: arena.field_sort(ids))
-        rec("field_sort_k", "B=%d" % B, us, nbytes=B * F * (4 + 16))
-        E, S, y1, y2 = arena.gather(ids, fm=True, first_order=True)
-        dX = torch.randn(B, F * D, device=dev); g1 = torch.randn(B, device=dev); g2 = torch.randn(B, device=dev)
-        us = timeit(lambda: arena.segsum(B, S, dX, g1, g2))
-        U = int(arena.nuniq.sum().item())
-        rec("segsum_bwd_k (scatter)", "B=%d U=%d" % (B, U), us, nbytes=B * F * (4 + 64) + U * 64)
+    us = timeit(lambda: arena.field_sort(ids))
+    rec("field_sort_k" if B <= 16384 else "field_sort_large (10 launches)", "B=%d" % B, us, nbytes=B * F * (4 + 16))
+    E, S, y1, y2 = arena.gather(ids, fm=True, first_order=True)
+    dX = torch.randn(B, F * D, device=dev); g1 = torch.randn(B, device=dev); g2 = torch.randn(B, device=dev)
+    us = timeit(lambda: arena.segsum(B, S, dX, g1, g2))
+    U = int(arena.nuniq.sum().item())
+    rec("segsum (scatter%s)" % (", 2 launches" if B > 512 else ""), "B=%d U=%d" % (B, U), us, nbytes=B * F * (4 + 64) + U * 64)
     del arena
 # optimizer sweep
 arena = EmbeddingArena(lay.row_off, D, 256, dev, with_w1=True, tables=np.zeros((int(lay.row_off[-1]), D), np.float32), w1=np.zeros(int(lay.row_off[-1]), np.float32))

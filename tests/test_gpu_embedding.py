@@ -51,7 +51,8 @@ def test_gather_empty_batch_and_masks():
 
 @pytest.mark.parametrize("B,rows", [(256, None), (1, None), (100, (3, 7, 4, 11, 6)), (4096, (3, 1000, 50)), (1000, (2,)),
                                     (600, (3, 1000, 50)), (2048, None), (5000, (1, 65536, 65537, 256, 257)),
-                                    (16384, (3, 100000, 257))])
+                                    (16384, (3, 100000, 257)), (20000, (3, 100000, 257, 1, 70000)), (40000, None),
+                                    (65536, (2, 262144, 513))])
 def test_field_sort_is_exact(B, rows):
     """Index work is bit-exact: sorted unique rows, segment boundaries, permutation, slot map."""
     rng = np.random.default_rng(B)
@@ -82,7 +83,7 @@ def test_field_sort_is_exact(B, rows):
 
 @pytest.mark.parametrize("B,rows,D", [(256, None, 16), (300, (3, 7, 4, 11, 6), 4), (2048, (2, 500), 16),
                                       (2048, None, 16), (4099, (3, 1000, 50, 100000, 1), 16), (1500, (7, 300), 8),
-                                      (16384, (3, 40000), 32)])
+                                      (16384, (3, 40000), 32), (30000, (3, 100000, 40), 16)])
 def test_segsum_bwd(B, rows, D):
     rng = np.random.default_rng(B + 1)
     row_off = criteo.row_offsets() if rows is None else np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
