@@ -476,15 +476,11 @@ __device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float
   return c.k1 * (Bf * dy - c.sdy - xh * c.sdx);
 }
 
-#ifndef RSX_ABLATE
-#define RSX_ABLATE 0
-#endif
 // SPLIT: the dW tiles' batch reduction is cut into p.sb row blocks (large batches); false keeps the single-block code
 // path free of the block arithmetic
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (RSX_ABLATE == 1) return;                       // launch floor
   float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
   float* part = lds + 5 * p.N + ((4 - (5 * p.N) % 4) % 4);         // [4][256], 16-byte aligned
   double* cred = reinterpret_cast<double*>(part + 1024);              // [4][2][16]
@@ -503,7 +499,6 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
     }
     __syncthreads();
-    if (RSX_ABLATE == 2) return;                     // prologue only
     const int kc = bid % p.ct_k, rt = bid / p.ct_k;
     const int row = rt * TM + i;
     const int kcol = kc * 16 + i;   // B-operand "column" = input feature
@@ -526,7 +521,6 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     });
     const int orow = rt * TM + (tid >> 4), ocol = kc * 16 + (tid & 15);
     double s1 = 0.0, s2 = 0.0;
-    if (RSX_ABLATE == 3) { if (v == 12345.f) p.dy_prev[0] = v; return; }   // prologue + K loop
     if (orow < p.B && ocol < p.K) {
       float o = v;
       if (!first) {
@@ -565,7 +559,6 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
     ColBwd cb = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (RSX_ABLATE == 4) return;                     // dW tiles off
     if (nok) cb = bwd_col(p, ncol);
     float fsc = 1.f, fsh = 0.f;
     if (!first && fok) {

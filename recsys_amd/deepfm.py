@@ -110,8 +110,10 @@ def model_fn(features, labels, mode, params):
 
 
 def _train_fused(store, arena, ids, labels, params, masks):
-    """TRAIN step with no autograd: explicit kernel sequence field_sort -> gather_fm -> fused tower
-    (fwd, head+loss, bwd) -> [train_op:] sorted segment-sum -> one Adam sweep.  9 launches + 1 mask fill."""
+    """TRAIN step with no autograd, 7 launches: gather_fm -> tower forward x2 (the first carries the dedup sort) -> head +
+    loss (+ a slice of the untouched-row Adam sweep) -> tower backward x2 (+ sweep slices) -> [train_op:] sorted
+    segment-sum fused with the touched-row and dense-variable Adam.  Data-parallel: two all-gathers (ids; gradient block
+    + dense arena) around the same launches."""
     dp = store.dp
     with torch.no_grad():
         # The ids-only dedup sort rides in the first tower-forward launch as extra workgroups.  (A side HIP stream was

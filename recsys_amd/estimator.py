@@ -130,7 +130,6 @@ class VariableStore:
         self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
         self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
         self.graph_safe_dp = False   # set by model code whose DP collectives run outside autograd (segmentable)
-        self.side_stream = None      # the ids-only dedup sort runs here, concurrent with the forward pass
 
     def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr):
         self.embeddings = embeddings
@@ -152,26 +151,12 @@ class VariableStore:
         segs += self.dense.adam_segments()
         return segs
 
-    def sort_ids_for_backward(self, arena, ids, overlap=False):
-        """Dedup stage of the sparse gradient.  Data-parallel: over the all-gathered global batch.
-        overlap=True: run on a side HIP stream (it depends on ids only) -- call join_sort() before the scatter."""
-        if overlap:
-            if self.side_stream is None:
-                self.side_stream = torch.cuda.Stream(device=self.device)
-            cur = torch.cuda.current_stream()
-            self.side_stream.wait_stream(cur)
-            with torch.cuda.stream(self.side_stream):
-                g = self.dp.all_gather_rows(ids) if self.dp is not None else ids
-                arena.field_sort(g)
-                self._sort_keepalive = g
-            return
+    def sort_ids_for_backward(self, arena, ids):
+        """Dedup stage of the sparse gradient (ids only).  Data-parallel: over the all-gathered global batch.  (The fused
+        TRAIN steps do not call this: their sort rides in the first tower launch.)"""
         if self.dp is not None:
             ids = self.dp.all_gather_rows(ids)
         arena.field_sort(ids)
-
-    def join_sort(self):
-        if self.side_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def minimize(self, loss):
         """optimizer.minimize(loss) (fm/fm.py:162-163) incl. MirroredStrategy's 1/N loss scaling and
