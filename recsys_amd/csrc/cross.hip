@@ -8,6 +8,8 @@
 // scalars s_l instead of storing L activations.  Batch reductions (dW, dB, d wout) are deterministic:
 // each wave accumulates its examples in order into a lane-private LDS slab, the per-wave partials are
 // summed in order by cross_reduce_k.  No atomics.
+#include <cstdlib>
+
 #include "rsx_common.h"
 
 constexpr int CROSS_MAX_L = 8;
@@ -193,8 +195,17 @@ __global__ __launch_bounds__(256) void cross_reduce_k(const float* __restrict__ 
   const int jl = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + jl;
   float s = 0.f;
-  if (j < n)
-    for (int r = q; r < RT; r += 16) s += part[(size_t)r * n + j];
+  if (j < n) {   // row group q takes rows q, q+16, ...: 8 loads in flight, fixed order
+    int r = q;
+    for (; r + 7 * 16 < RT; r += 8 * 16) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(r + 16 * u) * n + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; r < RT; r += 16) s += part[(size_t)r * n + j];
+  }
   red[q][jl] = s;
   __syncthreads();
   if (q == 0 && j < n) {
@@ -220,7 +231,11 @@ extern "C" int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, c
   return RSX_OK;
 }
 
-static inline int cross_epw(int B) { return B <= 1024 ? 4 : 16; }   // examples per wave
+static inline int cross_epw(int B) {   // examples per wave
+  static const int forced = getenv("RSX_CROSS_EPW") ? atoi(getenv("RSX_CROSS_EPW")) : 0;   // tuning aid
+  if (forced > 0) return forced;
+  return B <= 512 ? 1 : (B <= 2048 ? 2 : 4);   // ~4 us of dependent latency per example: parallelism first (measured)
+}
 
 extern "C" size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L) {
   const int epw = cross_epw(B);

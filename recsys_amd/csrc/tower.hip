@@ -451,6 +451,7 @@ struct BwdArgs {
   // of one workgroup per tile would span the whole batch); tower_reduce_dw_k then adds the sb partial tiles in order
   int sb, ksb;
   float* dwp;                // [tiles, sb, 256] partial tiles
+  int din_rtw;               // row tiles per d(input) workgroup (1, or 4 for large batches)
   int n_head;                // 1 when the head-partial reduce block is present
   int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
   SortArgs sort;
@@ -499,10 +500,18 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
     }
     __syncthreads();
-    const int kc = bid % p.ct_k, rt = bid / p.ct_k;
-    const int row = rt * TM + i;
+    // large batches (SPLIT): one workgroup walks din_rtw consecutive row tiles of its column tile, so the column
+    // constants above (and the launch's workgroup count) are amortised; small batches: one tile per workgroup
+    const int rtw = SPLIT ? p.din_rtw : 1;
+    const int kc = bid % p.ct_k, rt0 = (bid / p.ct_k) * rtw;
     const int kcol = kc * 16 + i;   // B-operand "column" = input feature
-    const bool rok = row < p.B, cok = kcol < p.K;
+    const bool cok = kcol < p.K;
+    for (int rr = 0; rr < rtw; ++rr) {
+    const int rt = rt0 + rr;
+    if (rt >= p.RTh) break;         // workgroup-uniform
+    if (rr) __syncthreads();        // `part` / `cred` of the previous tile have been consumed
+    const int row = rt * TM + i;
+    const bool rok = row < p.B;
     const float v = tile_ksplit((p.N + 15) / 16, part, [&](int ks, float* a, float* b) {
       const int nn = ks * 16 + 4 * kq;
 #pragma unroll
@@ -544,6 +553,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         p.bstat_prev[((size_t)rt * 2 + 0) * p.K + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
         p.bstat_prev[((size_t)rt * 2 + 1) * p.K + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
       }
+    }
     }
     return;
   }
@@ -848,8 +858,9 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.ct_k = (K + 15) / 16;
   p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;
-  p.n_din = p.ct_k * p.RTh;
   p.sb = rsx_tower_dw_blocks(B, dw_partials != nullptr);
+  p.din_rtw = p.sb > 1 ? 4 : 1;
+  p.n_din = p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
   p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
   p.dwp = dw_partials;
   p.n_dw = p.ct_k1 * p.ct_n * p.sb;
