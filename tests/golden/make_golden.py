@@ -83,6 +83,44 @@ def main():
     np.savez_compressed(os.path.join(HERE, "deepfm_trajectory.npz"), rows=np.array(rows), ids=ids, labels=y, losses=np.array(losses),
                         probs=np.stack(probs), **{"init." + k: v.astype(np.float32) for k, v in P0.items()},
                         **{"final." + k: v for k, v in P.items()})
+    # 5. a DCN trajectory (3 cross layers) on the same small layout -----------------------------------------------
+    Pd = init.dcn_params(11, 16, (32, 16), 3, np.float64, off)
+    Pd0 = {k: v.copy() for k, v in Pd.items()}
+    md, optd = models.DCN(Pd, off, 2, 0.0), nn.AdamTF1(dtype=np.float64)
+    ids_d = np.stack([np.stack([rng.integers(0, r, Bt) for r in rows], 1) for _ in range(steps)]).astype(np.int32)
+    y_d = rng.integers(0, 2, (steps, Bt)).astype(np.float64)
+    losses, probs = [], []
+    for s in range(steps):
+        probs.append(nn.sigmoid(md.forward(ids_d[s], train=False)))
+        loss, _ = models.train_step(md, optd, (ids_d[s],), y_d[s])
+        losses.append(float(loss))
+    np.savez_compressed(os.path.join(HERE, "dcn_trajectory.npz"), rows=np.array(rows), ids=ids_d, labels=y_d,
+                        losses=np.array(losses), probs=np.stack(probs),
+                        **{"init." + k: v.astype(np.float32) for k, v in Pd0.items()}, **{"final." + k: v for k, v in Pd.items()})
+
+    # 6. a DIN trajectory: tiny vocabularies, ragged zero-padded histories (padding id 0), K = 16 -------------------
+    n_item, n_cate, Bd, Pn, Kd = 50, 7, 6, 5, 16
+    Pn_ = init.din_params(5, Kd, n_item, n_cate, np.float64)
+    Pn_["item_bias"] += rng.standard_normal(n_item) * 0.01
+    Pn0 = {k: v.copy() for k, v in Pn_.items()}
+    mdin, optn = models.DIN(Pn_, 0.0), nn.AdamTF1(dtype=np.float64)
+    cate_of = rng.integers(1, n_cate, n_item)
+    cate_of[0] = 0
+    bat, losses, probs = [], [], []
+    for s in range(steps):
+        i_id = rng.integers(1, n_item, Bd)
+        hist = rng.integers(1, n_item, (Bd, Pn))
+        hist[np.arange(Pn)[None, :] >= rng.integers(1, Pn + 1, Bd)[:, None]] = 0
+        b = dict(i_id=i_id, i_cate=cate_of[i_id], u_iid_seq=hist, u_icat_seq=cate_of[hist], label=rng.integers(0, 2, Bd))
+        args = (b["i_id"], b["i_cate"], b["u_iid_seq"], b["u_icat_seq"])
+        probs.append(nn.sigmoid(mdin.forward(*args, train=False)))
+        loss, _ = models.train_step(mdin, optn, args, b["label"].astype(np.float64))
+        losses.append(float(loss))
+        bat.append(b)
+    np.savez_compressed(os.path.join(HERE, "din_trajectory.npz"), n_item=n_item, n_cate=n_cate, K=Kd,
+                        losses=np.array(losses), probs=np.stack(probs),
+                        **{"batch.%s" % k: np.stack([b[k] for b in bat]).astype(np.int64) for k in bat[0]},
+                        **{"init." + k: v.astype(np.float32) for k, v in Pn0.items()}, **{"final." + k: v for k, v in Pn_.items()})
     print("golden fixtures written to", HERE)
 
 

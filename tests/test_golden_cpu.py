@@ -62,3 +62,25 @@ def test_oracle_reproduces_golden_ops_and_trajectory():
         assert abs(float(loss) - float(t["losses"][s])) < 1e-6      # init.* is stored in fp32
     for k in P:
         np.testing.assert_allclose(P[k], t["final." + k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_oracle_reproduces_golden_dcn_and_din_trajectories():
+    t = np.load(os.path.join(G, "dcn_trajectory.npz"))
+    rows = tuple(int(r) for r in t["rows"])
+    off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    P = {k[5:]: t[k].astype(np.float64) for k in t.files if k.startswith("init.")}
+    m, opt = models.DCN(P, off, 2, 0.0), nn.AdamTF1(dtype=np.float64)
+    for s in range(t["ids"].shape[0]):
+        loss, _ = models.train_step(m, opt, (t["ids"][s],), t["labels"][s])
+        assert abs(float(loss) - float(t["losses"][s])) < 1e-6
+    for k in P:
+        np.testing.assert_allclose(P[k], t["final." + k], rtol=0, atol=2e-6, err_msg=k)
+    d = np.load(os.path.join(G, "din_trajectory.npz"))
+    P = {k[5:]: d[k].astype(np.float64) for k in d.files if k.startswith("init.")}
+    m, opt = models.DIN(P, 0.0), nn.AdamTF1(dtype=np.float64)
+    for s in range(d["losses"].shape[0]):
+        args = tuple(d["batch." + k][s] for k in ("i_id", "i_cate", "u_iid_seq", "u_icat_seq"))
+        loss, _ = models.train_step(m, opt, args, d["batch.label"][s].astype(np.float64))
+        assert abs(float(loss) - float(d["losses"][s])) < 1e-6
+    for k in P:
+        np.testing.assert_allclose(P[k], d["final." + k], rtol=0, atol=2e-6, err_msg=k)
