@@ -287,6 +287,26 @@ int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* ids, float* 
 /* dH[b,p,:] (+)= dout[b,:] * w[b,p] * mask ;  dw[b,p] = <H[b,p,:], dout[b,:]> * mask                              */
 int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH, float* dw,
                      int accumulate, int B, int P, int K, rsx_stream_t stream);
+/* Fused attention MLP of `_attention` (din/din.py:111-121): for every history position m = (b, p)
+ *   w[m] = W2 . drop(relu(W1^T . drop(relu(W0^T . [h, q, h*q, h-q] + b0)) + b1)) + b2,   h = H[m,:], q = q[b,:]
+ * without materialising the [B*P, 4K] concat; a1 [M,N1] / a2 [M,N2] (relu outputs before dropout) are saved for the
+ * backward pass.  Dropout: mask1 / mask2 (0/1 keep masks, parity tests) or the counter hash of the fused tower
+ * (rng_step, seed, layers layer0 and layer0+1).  Envelope: K in {16, 32}, N1 <= 80, N2 <= 48 (the reference hard-codes
+ * 80, 40: din/din.py:85).                                                                                            */
+int rsx_din_attn_fwd(const float* H, const float* q, const float* W0, const float* b0, const float* W1, const float* b1,
+                     const float* W2, const float* b2, float* a1, float* a2, float* w, const float* mask1,
+                     const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0, float dropout_rate, int B,
+                     int P, int K, int N1, int N2, rsx_stream_t stream);
+/* Backward of rsx_din_attn_fwd given dw [B*P] = d loss / d w: dH [B*P, K] (the attention's share; the pooling's share
+ * comes from rsx_din_pool_bwd), dq [B, K] (summed over the P positions), and grads = [dW0 (4K x N1) | db0 (N1) |
+ * dW1 (N1 x N2) | db1 (N2) | dW2 (N2) | db2 (1)] as one flat array.  Persistent workgroups keep their weight-gradient
+ * tiles in registers over all their 64-row blocks and write one partial each; partials are added in workgroup order.
+ * workspace: rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2) floats.  Same masks / rng arguments as the forward.   */
+size_t rsx_din_attn_bwd_workspace_floats(int B, int P, int K, int N1, int N2);
+int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2, const float* a1,
+                     const float* a2, const float* dw, float* dH, float* dq, float* grads, float* workspace,
+                     const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
+                     float dropout_rate, int B, int P, int K, int N1, int N2, rsx_stream_t stream);
 /* Sorted row keys (stable sort done by the caller) -> uniq_row[U], seg_off[U+1], nuniq[0] = U and the row -> j slot
  * map (previous call's entries cleared first): the same workspace contract as rsx_field_sort with F = 1, so
  * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.

@@ -1,0 +1,587 @@
+// DIN attention MLP, fused (fp32 MFMA), forward and backward.  Reference: din/din.py:103-121 `_attention` --
+//   att_in = concat[h, q, h*q, h-q]  [B*P, 4K];  a1 = dropout(relu(att_in.W0 + b0));  a2 = dropout(relu(a1.W1 + b1));
+//   w = a2.W2 + b2  (one logit per history position; no softmax, no scaling)
+// with h = history embedding rows [B*P, K], q = the query embedding [B, K] tiled over the P positions.  SURVEY.md 8a row
+// a-10: M = B*P = 102 400 rows at the reference's batch; through library GEMMs + element-wise kernels this is ~100
+// launches and ~0.5 GB of [M, 128] / [M, 80] round trips per call.  Here one launch per direction:
+//   * the [M, 4K] concat is never materialised: a lane builds its A operands from the h / q float4s it holds;
+//   * weights live in LDS (transposed / padded so that one ds_read_b128 feeds four k-steps);
+//   * layer outputs change from the MFMA C layout to the A layout through a per-wave LDS tile, never through HBM
+//     (a1 / a2 are written once for the backward pass);
+//   * dropout is the counter hash of the fused tower (drop_device.h) or an injected mask (parity tests).
+// One wave = one 16-row tile; k-permutation as in tower.hip / cin.hip: k-step 4*kb + t uses k = 16*kb + 4*(lane>>4) + t.
+#include "drop_device.h"
+#include "rsx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 att_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct AttnFwdArgs {
+  const float* H;       // [M, K]
+  const float* q;       // [B, K]
+  const float* W0;      // [4K, N1]
+  const float* b0;      // [N1]
+  const float* W1;      // [N1, N2]
+  const float* b1;      // [N2]
+  const float* W2;      // [N2]
+  const float* b2;      // [1]
+  float* a1;            // [M, N1]  relu output, before dropout (saved for backward)
+  float* a2;            // [M, N2]
+  float* w;             // [M]
+  const float* mask1;   // [M, N1] keep masks (parity tests) or null
+  const float* mask2;   // [M, N2]
+  const uint32_t* rng_step;
+  uint32_t seed, layer0;
+  float rate;
+  int M, P, N1, N2;
+};
+
+// KB = K/16, NT1 = ceil(N1/16), NT2 = ceil(N2/16).  grid = ceil(M/64), block = 256.
+// dyn LDS (floats): 16*NT1*(64*KB+4) + 16*NT2*(16*NT1+4) + 4*16*(16*NT1+4) + 16*NT1 + 2*16*NT2
+template <int KB, int NT1, int NT2>
+__global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = 16 * KB, K4 = 4 * K, LD0 = K4 + 4, N1P = 16 * NT1, LD1 = N1P + 4, N2P = 16 * NT2;
+  float* sW0 = lds;                       // [N1P][LD0]  W0 transposed: sW0[n][k]
+  float* sW1 = sW0 + N1P * LD0;           // [N2P][LD1]  W1 transposed: sW1[n2][n1]
+  float* sS = sW1 + N2P * LD1;            // [4 waves][16][LD1]  a1 (after dropout) in row-major for the A layout
+  float* sb0 = sS + 4 * 16 * LD1;         // [N1P]
+  float* sb1 = sb0 + N1P;                 // [N2P]
+  float* sw2 = sb1 + N2P;                 // [N2P]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  // weights: zero fill (padding rows / columns), then coalesced global reads scattered into the transposed layout
+  for (int e = tid; e < N1P * LD0 + N2P * LD1; e += 256) sW0[e] = 0.f;
+  __syncthreads();
+  for (int e = tid; e < K4 * p.N1; e += 256) {
+    const int k = e / p.N1, n = e - k * p.N1;
+    sW0[n * LD0 + k] = p.W0[e];
+  }
+  for (int e = tid; e < p.N1 * p.N2; e += 256) {
+    const int k = e / p.N2, n = e - k * p.N2;
+    sW1[n * LD1 + k] = p.W1[e];
+  }
+  for (int e = tid; e < N1P; e += 256) sb0[e] = e < p.N1 ? p.b0[e] : 0.f;
+  for (int e = tid; e < N2P; e += 256) {
+    sb1[e] = e < p.N2 ? p.b1[e] : 0.f;
+    sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
+  }
+  __syncthreads();
+  const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
+  const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
+  const int nblk = (p.M + 63) / 64;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {    // persistent: the weights are staged once per workgroup
+  const int m0 = (blk * 4 + wv) * 16;
+  const int m = m0 + i;                          // A-layout row of this lane
+  const bool mok = m < p.M;
+  const int mc = mok ? m : 0;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 h4[KB], q4[KB];
+#pragma unroll
+  for (int c = 0; c < KB; ++c) {
+    h4[c] = mok ? *reinterpret_cast<const float4*>(p.H + (size_t)mc * K + 16 * c + 4 * kq) : z4;
+    q4[c] = mok ? *reinterpret_cast<const float4*>(p.q + (size_t)(mc / p.P) * K + 16 * c + 4 * kq) : z4;
+  }
+  // ---- layer 0: z1 = [h, q, h*q, h-q] . W0 ----------------------------------------------------------------------
+  f32x4 acc1[NT1];
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int seg = 0; seg < 4; ++seg)
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const float4 hv = h4[c], qv = q4[c];
+      float4 a;
+      if (seg == 0) a = hv;
+      else if (seg == 1) a = qv;
+      else if (seg == 2) a = make_float4(hv.x * qv.x, hv.y * qv.y, hv.z * qv.z, hv.w * qv.w);
+      else a = make_float4(hv.x - qv.x, hv.y - qv.y, hv.z - qv.z, hv.w - qv.w);
+      const int kb = seg * KB + c;
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+        const float4 b = *reinterpret_cast<const float4*>(sW0 + (16 * nt + i) * LD0 + 16 * kb + 4 * kq);
+        acc1[nt] = att_mfma(a.x, b.x, acc1[nt]);
+        acc1[nt] = att_mfma(a.y, b.y, acc1[nt]);
+        acc1[nt] = att_mfma(a.z, b.z, acc1[nt]);
+        acc1[nt] = att_mfma(a.w, b.w, acc1[nt]);
+      }
+    }
+  // C layout: acc1[nt][r] = z1[row 4*kq + r][n = 16*nt + i]
+  float* S = sS + wv * 16 * LD1;
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) {
+    const int n = 16 * nt + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * kq + r, mm = m0 + row;
+      float v = 0.f;
+      if (n < p.N1 && mm < p.M) {
+        v = fmaxf(acc1[nt][r] + sb0[n], 0.f);
+        p.a1[(size_t)mm * p.N1 + n] = v;
+        v *= drop_mul(d1, p.mask1, (size_t)mm * p.N1 + n);
+      }
+      S[row * LD1 + n] = v;
+    }
+  }
+  __syncthreads();
+  // ---- layer 1: z2 = a1d . W1 -----------------------------------------------------------------------------------
+  f32x4 acc2[NT2];
+#pragma unroll
+  for (int nt = 0; nt < NT2; ++nt) acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NT1; ++kb) {
+    const float4 a = *reinterpret_cast<const float4*>(S + i * LD1 + 16 * kb + 4 * kq);
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      const float4 b = *reinterpret_cast<const float4*>(sW1 + (16 * nt + i) * LD1 + 16 * kb + 4 * kq);
+      acc2[nt] = att_mfma(a.x, b.x, acc2[nt]);
+      acc2[nt] = att_mfma(a.y, b.y, acc2[nt]);
+      acc2[nt] = att_mfma(a.z, b.z, acc2[nt]);
+      acc2[nt] = att_mfma(a.w, b.w, acc2[nt]);
+    }
+  }
+  // ---- layer 2: w = a2d . W2 + b2 (row sums over the 16 column lanes) --------------------------------------------
+  float pw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < NT2; ++nt) {
+    const int n = 16 * nt + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mm = m0 + 4 * kq + r;
+      if (n < p.N2 && mm < p.M) {
+        const float v = fmaxf(acc2[nt][r] + sb1[n], 0.f);
+        p.a2[(size_t)mm * p.N2 + n] = v;
+        pw[r] += v * drop_mul(d2, p.mask2, (size_t)mm * p.N2 + n) * sw2[n];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) pw[r] += __shfl_xor(pw[r], s);
+    const int mm = m0 + 4 * kq + r;
+    if (i == 0 && mm < p.M) p.w[mm] = pw[r] + p.b2[0];
+  }
+  __syncthreads();                               // S is rewritten by the next block
+  }
+}
+
+static inline size_t attn_fwd_lds_floats(int KB, int NT1, int NT2) {
+  const size_t LD0 = 64 * KB + 4, N1P = 16 * NT1, LD1 = N1P + 4, N2P = 16 * NT2;
+  return N1P * LD0 + N2P * LD1 + 4 * 16 * LD1 + N1P + 2 * N2P;
+}
+
+extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0, const float* b0, const float* W1,
+                                const float* b1, const float* W2, const float* b2, float* a1, float* a2, float* w,
+                                const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed,
+                                int layer0, float dropout_rate, int B, int P, int K, int N1, int N2,
+                                rsx_stream_t stream) {
+  if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!H || !q || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !a1 || !a2 || !w) return RSX_EINVAL;
+  if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
+  if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;     // instantiated envelope (din/din.py:85)
+  AttnFwdArgs p{H, q, W0, b0, W1, b1, W2, b2, a1, a2, w, mask1, mask2, rng_step, seed, (uint32_t)layer0, dropout_rate,
+                B * P, P, N1, N2};
+  const int nblk = (p.M + 63) / 64;
+  const dim3 grid((unsigned)(nblk < 512 ? nblk : 512)), block(256);    // <= 2 workgroups per CU (80 KB of LDS each)
+  if (K == 32) {
+    const size_t lds = attn_fwd_lds_floats(2, 5, 3) * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_k<2, 5, 3>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return RSX_EUNSUPPORTED;
+    hipLaunchKernelGGL((din_attn_fwd_k<2, 5, 3>), grid, block, lds, rsx_s(stream), p);
+  } else {
+    const size_t lds = attn_fwd_lds_floats(1, 5, 3) * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_k<1, 5, 3>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return RSX_EUNSUPPORTED;
+    hipLaunchKernelGGL((din_attn_fwd_k<1, 5, 3>), grid, block, lds, rsx_s(stream), p);
+  }
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+// =====================================================================================================================
+// Backward.  Persistent workgroups (grid <= 256, one per CU: ~135 KB of LDS) walk 64-row blocks (wave = 16 rows):
+//   g2  = dw * W2 * drop2 * (a2 > 0)                 built in the A layout straight from the a2 loads
+//   g1  = (g2 . W1^T) * drop1 * (a1 > 0)             MFMA, B operand = W1 row-major in LDS
+//   dx  = g1 . W0^T   -> dH = dx_h + dx_hq*q + dx_h-q ;  dq(row) = dx_q + dx_hq*h - dx_h-q      (per row; the sum of
+//                                                     dq over the P positions is a second small kernel)
+//   dW1 += a1d^T . g2,  dW0 += [h,q,h*q,h-q]^T . g1   reduction over the block's 64 rows, operands from the block's LDS
+//                                                     tiles, output tiles split over the 4 waves and kept in registers
+//                                                     across ALL blocks of the workgroup
+// Every workgroup writes ONE partial of all weight gradients; din_attn_reduce_k adds the partials in workgroup order.
+// =====================================================================================================================
+struct AttnBwdArgs {
+  const float* H; const float* q; const float* W0; const float* W1; const float* W2;
+  const float* a1; const float* a2; const float* dw;     // dw [M]: gradient of the logits
+  float* dH;            // [M, K]
+  float* dqr;           // [M, K] per-row query gradient (summed over p by din_attn_dq_k)
+  float* part;          // [G, NPART] weight-gradient partials
+  const float* mask1; const float* mask2;
+  const uint32_t* rng_step;
+  uint32_t seed, layer0;
+  float rate;
+  int M, P, N1, N2, nblk;
+};
+
+template <int KB, int NT1, int NT2>
+struct AttnDims {
+  static constexpr int K = 16 * KB, K4 = 4 * K, N1P = 16 * NT1, N2P = 16 * NT2, LD1 = N1P + 4, LD2 = N2P + 4, LDH = K + 4;
+  static constexpr int MT0 = K4 / 16;                        // row tiles of dW0
+  static constexpr int W0_PER = (MT0 + 3) / 4, W1_PER = (NT1 + 3) / 4;   // dW0 / dW1 row tiles per wave
+};
+
+template <int KB, int NT1, int NT2>
+__global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
+  using D = AttnDims<KB, NT1, NT2>;
+  constexpr int K = D::K, K4 = D::K4, N1P = D::N1P, N2P = D::N2P, LD1 = D::LD1, LD2 = D::LD2, LDH = D::LDH;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sW0 = lds;                        // [K4][LD1]   W0 row-major
+  float* sW1 = sW0 + K4 * LD1;             // [N1P][LD2]  W1 row-major
+  float* sw2 = sW1 + N1P * LD2;            // [N2P]
+  float* sG1 = sw2 + N2P;                  // [64][LD1]
+  float* sA1 = sG1 + 64 * LD1;             // [64][LD1]
+  float* sG2 = sA1 + 64 * LD1;             // [64][LD2]
+  float* sH = sG2 + 64 * LD2;              // [64][LDH]
+  float* sQ = sH + 64 * LDH;               // [64][LDH]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  for (int e = tid; e < K4 * LD1; e += 256) {
+    const int k = e / LD1, n = e - k * LD1;
+    sW0[e] = n < p.N1 ? p.W0[(size_t)k * p.N1 + n] : 0.f;
+  }
+  for (int e = tid; e < N1P * LD2; e += 256) {
+    const int k = e / LD2, n = e - k * LD2;
+    sW1[e] = (k < p.N1 && n < p.N2) ? p.W1[(size_t)k * p.N2 + n] : 0.f;
+  }
+  for (int e = tid; e < N2P; e += 256) sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
+  const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
+  const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+  // weight-gradient accumulators, alive across all blocks of this workgroup
+  f32x4 accW0[D::W0_PER][NT1], accW1[D::W1_PER][NT2];
+#pragma unroll
+  for (int a = 0; a < D::W0_PER; ++a)
+#pragma unroll
+    for (int b = 0; b < NT1; ++b) accW0[a][b] = zf;
+#pragma unroll
+  for (int a = 0; a < D::W1_PER; ++a)
+#pragma unroll
+    for (int b = 0; b < NT2; ++b) accW1[a][b] = zf;
+  float db0acc[NT1], db1acc[NT2][4], dw2acc[NT2][4], db2acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < NT1; ++a) db0acc[a] = 0.f;
+#pragma unroll
+  for (int a = 0; a < NT2; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) db1acc[a][t] = dw2acc[a][t] = 0.f;
+  __syncthreads();
+
+  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
+    const int mb = blk * 64 + 16 * wv;            // first row of this wave's tile
+    const int m = mb + i;                         // A-layout row
+    const bool mok = m < p.M;
+    const size_t mc = mok ? (size_t)m : 0;
+    // ---- S1/S2: g2 (A layout, registers) + the h / q / g2 tiles of the block ------------------------------------
+    const float dz = mok ? p.dw[mc] : 0.f;
+    float g2[NT2][4];
+#pragma unroll
+    for (int kb = 0; kb < NT2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = 16 * kb + 4 * kq + t;
+        float gv = 0.f;
+        if (mok && n < p.N2) {
+          const float av = p.a2[mc * p.N2 + n];
+          const float mul = drop_mul(d2, p.mask2, mc * p.N2 + n);
+          dw2acc[kb][t] += av * mul * dz;
+          gv = av > 0.f ? dz * sw2[n] * mul : 0.f;
+          db1acc[kb][t] += gv;
+        }
+        g2[kb][t] = gv;
+        sG2[(16 * wv + i) * LD2 + n] = gv;
+      }
+    if (kq == 0) db2acc += dz;
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const float4 hv = mok ? *reinterpret_cast<const float4*>(p.H + mc * K + 16 * c + 4 * kq) : z4;
+      const float4 qv = mok ? *reinterpret_cast<const float4*>(p.q + (mc / p.P) * K + 16 * c + 4 * kq) : z4;
+      *reinterpret_cast<float4*>(sH + (16 * wv + i) * LDH + 16 * c + 4 * kq) = hv;
+      *reinterpret_cast<float4*>(sQ + (16 * wv + i) * LDH + 16 * c + 4 * kq) = qv;
+    }
+    // ---- S3: dg1 = g2 . W1^T  (C layout: rows 4*kq + r, column n1 = 16*nt + i) ------------------------------------
+    f32x4 dg1[NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) dg1[nt] = zf;
+#pragma unroll
+    for (int kb = 0; kb < NT2; ++kb)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+        const float4 b = *reinterpret_cast<const float4*>(sW1 + (16 * nt + i) * LD2 + 16 * kb + 4 * kq);
+        dg1[nt] = att_mfma(g2[kb][0], b.x, dg1[nt]);
+        dg1[nt] = att_mfma(g2[kb][1], b.y, dg1[nt]);
+        dg1[nt] = att_mfma(g2[kb][2], b.z, dg1[nt]);
+        dg1[nt] = att_mfma(g2[kb][3], b.w, dg1[nt]);
+      }
+    // ---- S4: g1 = dg1 * drop1 * (a1 > 0); tiles g1 / a1d ----------------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+      const int n = 16 * nt + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wv + 4 * kq + r;
+        const size_t mm = (size_t)blk * 64 + row;
+        float gv = 0.f, ad = 0.f;
+        if (mm < (size_t)p.M && n < p.N1) {
+          const float av = p.a1[mm * p.N1 + n];
+          const float mul = drop_mul(d1, p.mask1, mm * p.N1 + n);
+          ad = av * mul;
+          gv = av > 0.f ? dg1[nt][r] * mul : 0.f;
+        }
+        db0acc[nt] += gv;
+        sG1[row * LD1 + n] = gv;
+        sA1[row * LD1 + n] = ad;
+      }
+    }
+    __syncthreads();
+    // ---- S5: dx = g1 . W0^T -> dH, per-row dq ---------------------------------------------------------------------
+    {
+      f32x4 dx[4 * KB];
+#pragma unroll
+      for (int jt = 0; jt < 4 * KB; ++jt) dx[jt] = zf;
+#pragma unroll
+      for (int kb = 0; kb < NT1; ++kb) {
+        const float4 a = *reinterpret_cast<const float4*>(sG1 + (16 * wv + i) * LD1 + 16 * kb + 4 * kq);
+#pragma unroll
+        for (int jt = 0; jt < 4 * KB; ++jt) {
+          const float4 b = *reinterpret_cast<const float4*>(sW0 + (16 * jt + i) * LD1 + 16 * kb + 4 * kq);
+          dx[jt] = att_mfma(a.x, b.x, dx[jt]);
+          dx[jt] = att_mfma(a.y, b.y, dx[jt]);
+          dx[jt] = att_mfma(a.z, b.z, dx[jt]);
+          dx[jt] = att_mfma(a.w, b.w, dx[jt]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < KB; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * wv + 4 * kq + r, col = 16 * c + i;
+          const size_t mm = (size_t)blk * 64 + row;
+          if (mm < (size_t)p.M) {
+            const float hv = sH[row * LDH + col], qv = sQ[row * LDH + col];
+            const float xh = dx[c][r], xq = dx[KB + c][r], xp = dx[2 * KB + c][r], xd = dx[3 * KB + c][r];
+            p.dH[mm * K + col] = (xh + xp * qv) + xd;
+            p.dqr[mm * K + col] = (xq + xp * hv) - xd;
+          }
+        }
+    }
+    // ---- S6: weight gradients over the block's 64 rows (k-step (kb, t) <-> row 16*kb + 4*kq + t) --------------------
+#pragma unroll
+    for (int a = 0; a < D::W1_PER; ++a) {
+      const int mt = wv + 4 * a;                       // wave-uniform
+      if (mt < NT1) {
+        float av[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) av[kb][t] = sA1[(16 * kb + 4 * kq + t) * LD1 + 16 * mt + i];
+#pragma unroll
+        for (int jt = 0; jt < NT2; ++jt)
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              accW1[a][jt] = att_mfma(av[kb][t], sG2[(16 * kb + 4 * kq + t) * LD2 + 16 * jt + i], accW1[a][jt]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < D::W0_PER; ++a) {
+      const int mt = wv + 4 * a;                       // row tile of dW0: input features 16*mt .. (segment mt / KB)
+      if (mt < D::MT0) {
+        const int seg = mt / KB, col = 16 * (mt - seg * KB) + i;
+        float av[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int row = 16 * kb + 4 * kq + t;
+            const float hv = sH[row * LDH + col], qv = sQ[row * LDH + col];
+            av[kb][t] = seg == 0 ? hv : (seg == 1 ? qv : (seg == 2 ? hv * qv : hv - qv));
+          }
+#pragma unroll
+        for (int jt = 0; jt < NT1; ++jt)
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              accW0[a][jt] = att_mfma(av[kb][t], sG1[(16 * kb + 4 * kq + t) * LD1 + 16 * jt + i], accW0[a][jt]);
+      }
+    }
+    __syncthreads();                                   // the tiles are rewritten by the next block
+  }
+
+  // ---- this workgroup's partial of every weight gradient: [dW0 | db0 | dW1 | db1 | dW2 | db2] --------------------------
+  float* out = p.part + (size_t)blockIdx.x * ((size_t)K4 * p.N1 + p.N1 + (size_t)p.N1 * p.N2 + 2 * p.N2 + 1);
+  float* o_dW0 = out;
+  float* o_db0 = o_dW0 + (size_t)K4 * p.N1;
+  float* o_dW1 = o_db0 + p.N1;
+  float* o_db1 = o_dW1 + (size_t)p.N1 * p.N2;
+  float* o_dW2 = o_db1 + p.N2;
+  float* o_db2 = o_dW2 + p.N2;
+#pragma unroll
+  for (int a = 0; a < D::W0_PER; ++a) {
+    const int mt = wv + 4 * a;
+    if (mt < D::MT0)
+#pragma unroll
+      for (int jt = 0; jt < NT1; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kin = 16 * mt + 4 * kq + r, n = 16 * jt + i;
+          if (n < p.N1) o_dW0[(size_t)kin * p.N1 + n] = accW0[a][jt][r];
+        }
+  }
+#pragma unroll
+  for (int a = 0; a < D::W1_PER; ++a) {
+    const int mt = wv + 4 * a;
+    if (mt < NT1)
+#pragma unroll
+      for (int jt = 0; jt < NT2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k1 = 16 * mt + 4 * kq + r, n = 16 * jt + i;
+          if (k1 < p.N1 && n < p.N2) o_dW1[(size_t)k1 * p.N2 + n] = accW1[a][jt][r];
+        }
+  }
+  // bias-like sums: per-lane partials -> fixed-order sums over lanes and waves through LDS (tiles are idle now)
+  float* red = sG1;                                    // [4 waves][64 lanes][NT1 + 8*NT2 + 1]
+  constexpr int NR = NT1 + 8 * NT2 + 1;
+  {
+    float* r_ = red + (wv * 64 + lane) * NR;
+#pragma unroll
+    for (int a = 0; a < NT1; ++a) r_[a] = db0acc[a];
+#pragma unroll
+    for (int a = 0; a < NT2; ++a)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        r_[NT1 + 4 * a + t] = db1acc[a][t];
+        r_[NT1 + 4 * NT2 + 4 * a + t] = dw2acc[a][t];
+      }
+    r_[NT1 + 8 * NT2] = db2acc;
+  }
+  __syncthreads();
+  // db0[n1 = 16*nt + i]: sum over waves and the 4 kq lanes of column i
+  for (int n = tid; n < p.N1; n += 256) {
+    const int nt = n >> 4, ii = n & 15;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int k4 = 0; k4 < 4; ++k4) s += red[(w * 64 + 16 * k4 + ii) * NR + nt];
+    o_db0[n] = s;
+  }
+  // db1 / dW2 [n2 = 16*kb + 4*kq + t]: sum over waves and the 16 row lanes i of group kq
+  for (int n = tid; n < p.N2; n += 256) {
+    const int kb = n >> 4, k4 = (n >> 2) & 3, t = n & 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int ii = 0; ii < 16; ++ii) {
+        s1 += red[(w * 64 + 16 * k4 + ii) * NR + NT1 + 4 * kb + t];
+        s2 += red[(w * 64 + 16 * k4 + ii) * NR + NT1 + 4 * NT2 + 4 * kb + t];
+      }
+    o_db1[n] = s1;
+    o_dW2[n] = s2;
+  }
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int ii = 0; ii < 16; ++ii) s += red[(w * 64 + ii) * NR + NT1 + 8 * NT2];
+    o_db2[0] = s;
+  }
+}
+
+// grads[j] = sum over the G workgroup partials, ascending.  One element per thread, 8 loads in flight.
+__global__ __launch_bounds__(256) void din_attn_reduce_k(const float* __restrict__ part, int G, int n,
+                                                         float* __restrict__ grads) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  int g = 0;
+  for (; g + 8 <= G; g += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(g + u) * n + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; g < G; ++g) s += part[(size_t)g * n + j];
+  grads[j] = s;
+}
+
+// dq[b, c] = sum_p dqr[b*P + p, c], ascending p.
+__global__ __launch_bounds__(256) void din_attn_dq_k(const float* __restrict__ dqr, float* __restrict__ dq, int B, int P,
+                                                     int K) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * K) return;
+  const int b = e / K, c = e - b * K;
+  const float* src = dqr + (size_t)b * P * K + c;
+  float s = 0.f;
+  int pp = 0;
+  for (; pp + 8 <= P; pp += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(pp + u) * K];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; pp < P; ++pp) s += src[(size_t)pp * K];
+  dq[e] = s;
+}
+
+static inline int attn_bwd_groups(int M) {
+  const int nblk = (M + 63) / 64;
+  return nblk < 256 ? nblk : 256;
+}
+static inline size_t attn_npart(int K, int N1, int N2) { return (size_t)4 * K * N1 + N1 + (size_t)N1 * N2 + 2 * N2 + 1; }
+
+extern "C" size_t rsx_din_attn_bwd_workspace_floats(int B, int P, int K, int N1, int N2) {
+  const size_t M = (size_t)B * P;
+  return M * K + (size_t)attn_bwd_groups((int)M) * attn_npart(K, N1, N2);
+}
+
+template <int KB, int NT1, int NT2>
+static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
+  using D = AttnDims<KB, NT1, NT2>;
+  const size_t fl = (size_t)D::K4 * D::LD1 + (size_t)D::N1P * D::LD2 + D::N2P + 2 * 64 * D::LD1 + 64 * D::LD2 + 2 * 64 * D::LDH;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_k<KB, NT1, NT2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess || fl * sizeof(float) > 160 * 1024) return RSX_EUNSUPPORTED;
+  hipLaunchKernelGGL((din_attn_bwd_k<KB, NT1, NT2>), dim3(G), dim3(256), fl * sizeof(float), st, p);
+  return RSX_OK;
+}
+
+extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
+                                const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
+                                float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
+                                uint32_t seed, int layer0, float dropout_rate, int B, int P, int K, int N1, int N2,
+                                rsx_stream_t stream) {
+  if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!H || !q || !W0 || !W1 || !W2 || !a1 || !a2 || !dw || !dH || !dq || !grads || !workspace) return RSX_EINVAL;
+  if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
+  if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;
+  const int M = B * P, G = attn_bwd_groups(M);
+  AttnBwdArgs p{H, q, W0, W1, W2, a1, a2, dw, dH, workspace, workspace + (size_t)M * K, mask1, mask2, rng_step, seed,
+                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64};
+  hipStream_t st = rsx_s(stream);
+  const int rc = K == 32 ? launch_attn_bwd<2, 5, 3>(p, G, st) : launch_attn_bwd<1, 5, 3>(p, G, st);
+  if (rc != RSX_OK) return rc;
+  RSX_CHECK_LAUNCH();
+  const int n = (int)attn_npart(K, N1, N2);
+  hipLaunchKernelGGL(din_attn_reduce_k, dim3((n + 255) / 256), dim3(256), 0, st, p.part, G, n, grads);
+  hipLaunchKernelGGL(din_attn_dq_k, dim3((B * K + 255) / 256), dim3(256), 0, st, p.dqr, dq, B, P, K);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}

@@ -14,7 +14,7 @@ import torch
 from . import layers as L
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
-from .ops import DinPoolFn, SparseTable
+from .ops import DinAttnFn, DinPoolFn, SparseTable
 
 ATTENTION_LAYERS = [80, 40]      # din/din.py:85 (the din_layers flag is ignored by the reference)
 MLP_LAYERS = [100, 50, 20]       # din/din.py:86 (the deep_layers flag is ignored by the reference)
@@ -69,11 +69,20 @@ def build_variables(store, params, B, P):
     store.build({"i_id": item, "i_cate": cate, "i_item": bias}, shapes, init, params["learning_rate"])
 
 
-def _attention(tbl, hist, q, P_, pre, training, rate, masks):
+def _attention(tbl, hist, q, P_, pre, training, rate, masks, store=None, layer0=0):
     """din/din.py:103-125."""
     B, Pn = hist.shape
     K = tbl.K
     H = tbl.lookup(hist)                                                   # dense_emb [B,P,K] (:105)
+    n1, n2 = P_[f"{pre}.W0"].shape[1], P_[f"{pre}.W1"].shape[1]
+    if len(ATTENTION_LAYERS) == 2 and DinAttnFn.supported(K, n1, n2) and store is not None:
+        # fused MFMA kernel: the [B*P, 4K] concat, the tiled query and the layer outputs never round-trip through HBM;
+        # dropout = the counter hash of the fused tower (keyed by the optimizer's device-side step counter)
+        r = rate if training else 0.0
+        w = DinAttnFn.apply(H, q, P_[f"{pre}.W0"], P_[f"{pre}.b0"], P_[f"{pre}.W1"], P_[f"{pre}.b1"], P_[f"{pre}.W2"],
+                            P_[f"{pre}.b2"], r, masks if (training and r > 0.0) else None,
+                            store.opt.state.view(torch.int32)[3:4], 0xD1A77, layer0)
+        return DinPoolFn.apply(H, w, hist)                                  # masked weighted sum (:122-124)
     hist_emb = H.reshape(B * Pn, K)
     query_emb = q[:, None, :].expand(B, Pn, K).reshape(B * Pn, K)          # tile + reshape (:111)
     att = torch.cat([hist_emb, query_emb, hist_emb * query_emb, hist_emb - query_emb], 1)     # (:114)
@@ -102,8 +111,9 @@ def model_fn(features, labels, mode, params):
     i_b = bias.lookup(i_id)[:, 0]                                          # tf.gather(pkg_w, i_id) (:96)
     pkg_emb = item.lookup(i_id)                                            # (:100)
     pkgc_emb = cate.lookup(i_cate)                                         # (:101)
-    pkg_emb_h = _attention(item, hist_i, pkg_emb, P_, "att_i", training, rate, mk.get("att_i"))
-    pkgc_emb_h = _attention(cate, hist_c, pkgc_emb, P_, "att_c", training, rate, mk.get("att_c"))
+    fused = store if params.get("fused_attention", True) else None
+    pkg_emb_h = _attention(item, hist_i, pkg_emb, P_, "att_i", training, rate, mk.get("att_i"), fused, 0)
+    pkgc_emb_h = _attention(cate, hist_c, pkgc_emb, P_, "att_c", training, rate, mk.get("att_c"), fused, 2)
     net = torch.cat([pkg_emb, pkg_emb_h, pkgc_emb_h], 1)                   # 'mlp_layer' (:131)
     for i in range(len(MLP_LAYERS)):
         net = L.dense(net, P_[f"mlp.W{i}"], P_[f"mlp.b{i}"], relu=True)

@@ -630,6 +630,53 @@ class DinPoolFn(torch.autograd.Function):
         return dH, dw, None
 
 
+class DinAttnFn(torch.autograd.Function):
+    """The attention MLP of `_attention` (din/din.py:111-121) as one fused launch per direction (csrc/din_attn.hip):
+    w[b,p] = W2 . drop(relu(W1^T . drop(relu(W0^T . [h, q, h*q, h-q] + b0)) + b1)) + b2."""
+
+    @staticmethod
+    def supported(K, N1, N2):
+        return K in (16, 32) and N1 <= 80 and N2 <= 48
+
+    @staticmethod
+    def forward(ctx, H, q, W0, b0, W1, b1, W2, b2, rate, masks, rng_step, seed, layer0):
+        B, P, K = H.shape
+        N1, N2 = W0.shape[1], W1.shape[1]
+        H, q = H.contiguous(), q.contiguous()
+        dev = H.device
+        a1, a2 = torch.empty(B * P, N1, device=dev), torch.empty(B * P, N2, device=dev)
+        w = torch.empty(B, P, device=dev)
+        m1, m2 = (None, None) if masks is None else (masks[0].contiguous(), masks[1].contiguous())
+        check(lib().rsx_din_attn_fwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(a1),
+                                     _ptr(a2), _ptr(w), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0, rate, B, P, K,
+                                     N1, N2, _stream()), "rsx_din_attn_fwd")
+        ctx.save_for_backward(H, q, W0, W1, W2, a1, a2)
+        ctx.cfg = (rate, m1, m2, rng_step, seed, layer0)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        H, q, W0, W1, W2, a1, a2 = ctx.saved_tensors
+        rate, m1, m2, rng_step, seed, layer0 = ctx.cfg
+        B, P, K = H.shape
+        N1, N2 = W0.shape[1], W1.shape[1]
+        dev = H.device
+        dH, dq = torch.empty_like(H), torch.empty_like(q)
+        n0, n1 = 4 * K * N1, N1 * N2
+        grads = torch.empty(n0 + N1 + n1 + 2 * N2 + 1, device=dev)
+        ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2)), device=dev)
+        check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2),
+                                     _ptr(g.contiguous()), _ptr(dH), _ptr(dq), _ptr(grads), _ptr(ws), _ptr(m1), _ptr(m2),
+                                     _ptr(rng_step), seed, layer0, rate, B, P, K, N1, N2, _stream()), "rsx_din_attn_bwd")
+        o = 0
+        out = []
+        for n, shape in ((n0, W0.shape), (N1, (N1,)), (n1, W1.shape), (N2, (N2,)), (N2, W2.shape), (1, (1,))):
+            out.append(grads[o:o + n].view(shape))
+            o += n
+        dW0, db0, dW1, db1, dW2, db2 = out
+        return dH, dq, dW0, db0, dW1, db1, dW2, db2, None, None, None, None, None
+
+
 class CinLayerFn(torch.autograd.Function):
     """One CIN layer (csrc/cin.hip): out[b,n,d] = relu(sum_{f,h} X0[b,f,d] Xk[b,h,d] W[f*H+h,n] + c[n]).
     xdeepfm/xdeepfm.py:145-172."""

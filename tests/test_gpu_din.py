@@ -133,3 +133,69 @@ def test_din_train_parity_config5_shape():
 def test_din_hip_graph_steps():
     err, losses, perr = _din_run(B=32, Pn=20, K=32, n_item=500, n_cate=30, steps=6, seed=5, dropout=0.0, use_graph=True)
     assert err < 1e-5 and max(perr.values()) < 5e-5, (err, perr)
+
+
+@pytest.mark.parametrize("B,P,K,rate", [(3, 5, 16, 0.0), (7, 13, 32, 0.5), (64, 100, 32, 0.5), (300, 70, 32, 0.0)])
+def test_fused_attention_mlp_matches_reference_expression(B, P, K, rate):
+    """rsx_din_attn_fwd / _bwd (one launch per direction) vs the reference expression of din/din.py:111-121 evaluated
+    in fp64 by torch autograd: logits and every gradient (history rows, query, 3 weight matrices, 3 biases), with
+    injected dropout masks.  Tolerance 1e-5 relative to the largest reference entry (fp32, north_star)."""
+    from recsys_amd.ops import DinAttnFn
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + P)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    M = B * P
+    H, q = rn(B, P, K).requires_grad_(), rn(B, K).requires_grad_()
+    W0, b0 = (rn(4 * K, 80) * 0.1).requires_grad_(), (rn(80) * 0.1).requires_grad_()
+    W1, b1 = (rn(80, 40) * 0.1).requires_grad_(), (rn(40) * 0.1).requires_grad_()
+    W2, b2 = (rn(40, 1) * 0.1).requires_grad_(), rn(1).requires_grad_()
+    masks = None
+    if rate > 0:
+        masks = [(torch.rand(M, n, device="cuda", generator=g) >= rate).float() for n in (80, 40)]
+    dw = rn(B, P)
+    w = DinAttnFn.apply(H, q, W0, b0, W1, b1, W2, b2, rate, masks, None, 0, 0)
+    (w * dw).sum().backward()
+    got = [w.detach()] + [t.grad.clone() for t in (H, q, W0, b0, W1, b1, W2, b2)]
+    t64 = [t.detach().double().requires_grad_() for t in (H, q, W0, b0, W1, b1, W2, b2)]
+    Hd, qd, W0d, b0d, W1d, b1d, W2d, b2d = t64
+    hh = Hd.reshape(M, K)
+    qq = qd[:, None, :].expand(B, P, K).reshape(M, K)
+    x = torch.cat([hh, qq, hh * qq, hh - qq], 1)
+    a = torch.relu(x @ W0d + b0d)
+    a = a * (masks[0].double() / (1 - rate)) if masks else a
+    a = torch.relu(a @ W1d + b1d)
+    a = a * (masks[1].double() / (1 - rate)) if masks else a
+    wr = (a @ W2d + b2d).reshape(B, P)
+    (wr * dw.double()).sum().backward()
+    ref = [wr.detach()] + [t.grad for t in t64]
+    for name, a_, b_ in zip(("w", "dH", "dq", "dW0", "db0", "dW1", "db1", "dW2", "db2"), got, ref):
+        err = float((a_.double() - b_).abs().max() / (b_.abs().max() + 1e-30))
+        assert err < 1e-5, (name, err)
+
+
+def test_fused_attention_rng_dropout_consistent_between_forward_and_backward():
+    """Hash-RNG dropout (no mask buffers): the backward pass must regenerate exactly the forward's keep pattern.  With
+    W2 = 1, b = 0 and non-negative pre-activations, d w / d b1[n] counts the kept (row, n) pairs scaled by 1/keep, which
+    must equal the forward's sum of a2-dropout indicators recovered from w itself."""
+    from recsys_amd.ops import DinAttnFn
+    B, P, K, rate = 16, 20, 32, 0.5
+    g = torch.Generator(device="cuda").manual_seed(5)
+    H = torch.rand(B, P, K, device="cuda", generator=g).requires_grad_()
+    q = torch.rand(B, K, device="cuda", generator=g).requires_grad_()
+    W0 = (torch.rand(4 * K, 80, device="cuda", generator=g) * 0.01).requires_grad_()
+    b0 = torch.ones(80, device="cuda").requires_grad_()
+    W1 = torch.zeros(80, 40, device="cuda").requires_grad_()
+    b1 = torch.ones(40, device="cuda").requires_grad_()          # a2 == 1 everywhere before dropout
+    W2 = torch.ones(40, 1, device="cuda").requires_grad_()
+    b2 = torch.zeros(1, device="cuda").requires_grad_()
+    step = torch.tensor([7], dtype=torch.int32, device="cuda")
+    w = DinAttnFn.apply(H, q, W0, b0, W1, b1, W2, b2, rate, None, step, 123, 0)
+    kept = w.detach() * (1 - rate)                               # number of kept units of layer 2 per row
+    assert float(kept.min()) >= 0 and abs(float(kept.mean()) - 20.0) < 1.5      # ~ Binomial(40, 0.5)
+    w.sum().backward()
+    # d w / d b1[n] = sum_rows keep2[row, n] / (1 - rate)  ->  summed over n it must reproduce sum_rows w
+    assert abs(float(b1.grad.sum()) - float(w.detach().sum())) < 1e-2 * float(w.detach().sum())
+    w2 = DinAttnFn.apply(H, q, W0, b0, W1, b1, W2, b2, rate, None, step, 123, 0)
+    assert torch.equal(w2.detach(), w.detach())                  # same (seed, step, layer) -> same pattern
+    step += 1
+    w3 = DinAttnFn.apply(H, q, W0, b0, W1, b1, W2, b2, rate, None, step, 123, 0)
+    assert not torch.equal(w3.detach(), w.detach())              # next step -> new pattern
