@@ -518,8 +518,7 @@ class SparseTable:
     Lookups register their (ids, grad) pairs during backward; `finalize()` concatenates them in registration
     order, sorts by row (stable, so duplicate rows are summed in entry order like TF's
     _apply_sparse_duplicate_indices), builds the segments and the summed gradient G, which the non-lazy TF-1
-    Adam kind pulls through `slot`.  The sort itself is a library radix sort (torch.sort); everything else
-    is librsx.so kernels."""
+    Adam kind pulls through `slot`.  Sort, segments and sums are the same librsx.so kernels as the Criteo fields (F = 1)."""
 
     def __init__(self, rows, K, capacity, device="cuda", table=None, null_row=-1):
         dev = _require_cuda(device)
@@ -537,7 +536,9 @@ class SparseTable:
         self.nuniq = torch.zeros(1, **i32)
         self.slot = torch.full((self.R + 4,), -1, **i32)
         self.G = torch.zeros(self.cap, self.K, device=dev)
-        self.scratch = torch.zeros((self.cap + 1023) // 1024 + 1, **i32)
+        self.perm = torch.zeros(self.cap, **i32)
+        self.sort_ws = torch.zeros(int(lib().rsx_field_sort_large_workspace_ints(self.cap, 1, self.cap)), **i32) \
+            if self.cap > EmbeddingArena.LDS_SORT_MAX_B else None
         # two-stage segment-sum workspace (Zipf-head rows make a few segments thousands of entries long)
         nch = (self.cap + 15) // 16
         self.segid = torch.zeros(self.cap + 2 + nch, **i32)
@@ -571,12 +572,19 @@ class SparseTable:
             ids, vals = dp.all_gather_rows(ids), dp.all_gather_rows(vals)
         N = ids.shape[0]
         assert N <= self.cap, "SparseTable capacity %d < %d entries" % (self.cap, N)
-        skeys, perm = torch.sort(ids, stable=True)
-        perm = perm.to(torch.int32)
+        # dedup sort of the row keys by the same kernels as the Criteo fields (F = 1): stable by entry order, so duplicate
+        # rows are summed in entry order like TF's _apply_sparse_duplicate_indices
+        ids2 = ids.to(torch.int32).reshape(N, 1).contiguous()
         two = N > EmbeddingArena.TWO_STAGE_MIN_B
-        check(lib().rsx_sorted_segments(_ptr(skeys), N, _ptr(self.uniq_row), _ptr(self.seg_off), _ptr(self.nuniq),
-                                        _ptr(self.slot), _ptr(self.segid) if two else None, self.cap, _ptr(self.scratch),
-                                        _stream()), "rsx_sorted_segments")
+        perm = self.perm
+        if N > EmbeddingArena.LDS_SORT_MAX_B:
+            check(lib().rsx_field_sort_large(_ptr(ids2), _ptr(self.row_off), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row),
+                                             _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid), _ptr(self.sort_ws), self.R,
+                                             N, 1, self.cap, _stream()), "rsx_field_sort_large")
+        else:
+            check(lib().rsx_field_sort(_ptr(ids2), _ptr(self.row_off), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row),
+                                       _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid) if two else None, self.R, N, 1,
+                                       self.cap, _stream()), "rsx_field_sort")
         part = None
         if two:
             part = C.byref(self.partials)
@@ -586,7 +594,7 @@ class SparseTable:
                   "rsx_segsum_partials")
         check(lib().rsx_segsum_rows(_ptr(vals), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row), _ptr(self.nuniq),
                                     _ptr(self.G), N, self.K, self.cap, self.null_row, part, _stream()), "rsx_segsum_rows")
-        self._keep = (skeys, perm, vals)
+        self._keep = (ids2, vals)
 
     def adam_segments(self, lazy=False):
         if lazy:
