@@ -89,7 +89,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
         loss, prob, dX, gz, _ = store.tower.train_step(
             x0, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,
-            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job, sweeps=sweeps, sort_in_fwd=True)
+            replicas=dp.world if dp is not None else 1, masks=masks,
+            seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
+            sort_job=job, sweeps=sweeps, sort_in_fwd=True)
         store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
                              gz=gz, wout=oW[nh:], dwout=oG[nh:])
 

@@ -141,7 +141,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
-            replicas=dp.world if dp is not None else 1, masks=masks, sort_job=job, sweeps=sweeps, sort_in_fwd=overlap)
+            replicas=dp.world if dp is not None else 1, masks=masks,
+            seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
+            sort_job=job, sweeps=sweeps, sort_in_fwd=overlap)
 
     def train_op():
         with torch.no_grad():
