@@ -97,6 +97,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RsxError("librsx.so not built: run `python -m recsys_amd.build` (hipcc --offload-arch=gfx950); "
                        "there is no CPU fallback for the hot path")
+    # torch first: it bundles its own libamdhip64; librsx.so must bind to THAT runtime (the streams and device pointers it
+    # receives belong to it).  Loaded the other way round, /opt/rocm's copy comes in as a second HIP runtime and the first
+    # kernel launch fails.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         if not hasattr(L, name):

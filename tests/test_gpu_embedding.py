@@ -339,3 +339,16 @@ def test_large_batch_tower_and_dcn_parity_bs1024():
         for lg, lo in losses:
             assert abs(lg - lo) < 2e-5, (kind, losses)
         assert max(perr.values()) < 5e-5, (kind, perr)
+
+
+def test_library_loaded_before_torch_still_launches():
+    """__graft_entry__.build() followed by smoke() in ONE process: the C-ABI library is dlopen'ed before anything touched
+    torch.cuda.  It must still bind to torch's HIP runtime (recsys_amd._lib.lib imports torch first); with /opt/rocm's
+    libamdhip64 loaded as a second runtime the first kernel launch fails."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.build(); g.smoke(); print('ORDER_OK')" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "ORDER_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
