@@ -214,12 +214,15 @@ def main():
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s.py %s bs=%d/replica, full train step "
-                                  "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, steps_per_graph=%d"
+                                  "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, %s"
                                   % (a.model, {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16",
                                                "dcn": "Criteo-39 d=16 3 cross layers DNN 100-100",
                                                "xdeepfm": "Criteo-39 d=16 CIN 128,128 DNN 100-100",
                                                "din": "Amazon-Electronics-shaped hist_len=100 K=32"}[a.model], B,
-                                     a.adam_mode, not a.no_graph, a.steps_per_graph),
+                                     a.adam_mode, not a.no_graph,
+                                     ("steps_per_graph=%d" % a.steps_per_graph) if (dp is None and emu is None) else
+                                     ("per-step graph segments, RCCL collectives %s" %
+                                      ("captured" if os.environ.get("RSX_DP_CAPTURE") == "1" else "eager between segments"))),
                       "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5)},
            "roofline": roof}
     if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":
