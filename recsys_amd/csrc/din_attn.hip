@@ -243,11 +243,14 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
   float* sW0 = lds;                        // [K4][LD1]   W0 row-major
   float* sW1 = sW0 + K4 * LD1;             // [N1P][LD2]  W1 row-major
   float* sw2 = sW1 + N1P * LD2;            // [N2P]
-  float* sG1 = sw2 + N2P;                  // [64][LD1]
-  float* sA1 = sG1 + 64 * LD1;             // [64][LD1]
-  float* sG2 = sA1 + 64 * LD1;             // [64][LD2]
-  float* sH = sG2 + 64 * LD2;              // [64][LDH]
-  float* sQ = sH + 64 * LDH;               // [64][LDH]
+  // the block's 64-row tiles are stored TRANSPOSED ([feature][row], row stride LDR): the weight-gradient GEMMs reduce over
+  // rows, so a lane fetches the operands of 4 k-steps (4 consecutive rows) with one ds_read_b128
+  constexpr int LDR = 68;
+  float* sG1 = sw2 + N2P;                  // [N1P][LDR]  g1^T
+  float* sA1 = sG1 + N1P * LDR;            // [N1P][LDR]  (a1 after dropout)^T
+  float* sG2 = sA1 + N1P * LDR;            // [N2P][LDR]  g2^T
+  float* sH = sG2 + N2P * LDR;             // [K][LDR]    h^T
+  float* sQ = sH + K * LDR;                // [K][LDR]    q^T
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   for (int e = tid; e < K4 * LD1; e += 256) {
@@ -282,37 +285,77 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
     for (int t = 0; t < 4; ++t) db1acc[a][t] = dw2acc[a][t] = 0.f;
   __syncthreads();
 
+  // Global operands of a block (dw, a2, h, q in the A layout; a1 in the C layout): loaded one block AHEAD, unconditionally
+  // on clamped addresses, so that their latency hides behind the previous block's MFMAs (one wave per SIMD here: nothing
+  // else would cover it) and no load sits in a branch of its own.
+  float dzN, a2N[NT2][4], a1N[NT1][4];
+  float4 hN[KB], qN[KB];
+  auto prefetch = [&](int blk) {
+    const size_t last = (size_t)p.M - 1;
+    const size_t mA = (size_t)blk * 64 + 16 * wv + i;
+    const size_t mc = mA < last ? mA : last;
+    dzN = p.dw[mc];
+#pragma unroll
+    for (int kb = 0; kb < NT2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = 16 * kb + 4 * kq + t;
+        a2N[kb][t] = p.a2[mc * p.N2 + (n < p.N2 ? n : p.N2 - 1)];
+      }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      hN[c] = *reinterpret_cast<const float4*>(p.H + mc * K + 16 * c + 4 * kq);
+      qN[c] = *reinterpret_cast<const float4*>(p.q + (mc / p.P) * K + 16 * c + 4 * kq);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+      const int n = 16 * nt + i, nc = n < p.N1 ? n : p.N1 - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t mm = (size_t)blk * 64 + 16 * wv + 4 * kq + r;
+        a1N[nt][r] = p.a1[(mm < last ? mm : last) * p.N1 + nc];
+      }
+    }
+  };
+  prefetch(blockIdx.x);
   for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
     const int mb = blk * 64 + 16 * wv;            // first row of this wave's tile
     const int m = mb + i;                         // A-layout row
     const bool mok = m < p.M;
     const size_t mc = mok ? (size_t)m : 0;
     // ---- S1/S2: g2 (A layout, registers) + the h / q / g2 tiles of the block ------------------------------------
-    const float dz = mok ? p.dw[mc] : 0.f;
-    float g2[NT2][4];
+    const float dz = mok ? dzN : 0.f;
+    float g2[NT2][4], a1raw[NT1][4];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1raw[nt][r] = a1N[nt][r];
 #pragma unroll
     for (int kb = 0; kb < NT2; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int n = 16 * kb + 4 * kq + t;
-        float gv = 0.f;
-        if (mok && n < p.N2) {
-          const float av = p.a2[mc * p.N2 + n];
-          const float mul = drop_mul(d2, p.mask2, mc * p.N2 + n);
-          dw2acc[kb][t] += av * mul * dz;
-          gv = av > 0.f ? dz * sw2[n] * mul : 0.f;
-          db1acc[kb][t] += gv;
-        }
+        const bool ok = mok && n < p.N2;
+        const float av = a2N[kb][t] * (ok ? 1.f : 0.f);
+        const float mul = d2.mode == 0 ? 1.f : (ok ? drop_mul(d2, p.mask2, mc * p.N2 + n) : 0.f);
+        dw2acc[kb][t] += av * mul * dz;
+        const float gv = av > 0.f ? dz * sw2[n] * mul : 0.f;
+        db1acc[kb][t] += gv;
         g2[kb][t] = gv;
-        sG2[(16 * wv + i) * LD2 + n] = gv;
+        sG2[n * LDR + 16 * wv + i] = gv;
       }
     if (kq == 0) db2acc += dz;
 #pragma unroll
     for (int c = 0; c < KB; ++c) {
-      const float4 hv = mok ? *reinterpret_cast<const float4*>(p.H + mc * K + 16 * c + 4 * kq) : z4;
-      const float4 qv = mok ? *reinterpret_cast<const float4*>(p.q + (mc / p.P) * K + 16 * c + 4 * kq) : z4;
-      *reinterpret_cast<float4*>(sH + (16 * wv + i) * LDH + 16 * c + 4 * kq) = hv;
-      *reinterpret_cast<float4*>(sQ + (16 * wv + i) * LDH + 16 * c + 4 * kq) = qv;
+      const float4 hv = mok ? hN[c] : z4;
+      const float4 qv = mok ? qN[c] : z4;
+      const int cc = 16 * c + 4 * kq, rr = 16 * wv + i;
+      sH[(cc + 0) * LDR + rr] = hv.x; sH[(cc + 1) * LDR + rr] = hv.y; sH[(cc + 2) * LDR + rr] = hv.z; sH[(cc + 3) * LDR + rr] = hv.w;
+      sQ[(cc + 0) * LDR + rr] = qv.x; sQ[(cc + 1) * LDR + rr] = qv.y; sQ[(cc + 2) * LDR + rr] = qv.z; sQ[(cc + 3) * LDR + rr] = qv.w;
+    }
+    {   // next block's operands: in flight during this block's MFMAs
+      const int nb = blk + (int)gridDim.x;
+      prefetch(nb < p.nblk ? nb : p.nblk - 1);
     }
     // ---- S3: dg1 = g2 . W1^T  (C layout: rows 4*kq + r, column n1 = 16*nt + i) ------------------------------------
     f32x4 dg1[NT1];
@@ -332,21 +375,22 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) {
       const int n = 16 * nt + i;
+      float gq[4], aq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * wv + 4 * kq + r;
         const size_t mm = (size_t)blk * 64 + row;
-        float gv = 0.f, ad = 0.f;
-        if (mm < (size_t)p.M && n < p.N1) {
-          const float av = p.a1[mm * p.N1 + n];
-          const float mul = drop_mul(d1, p.mask1, mm * p.N1 + n);
-          ad = av * mul;
-          gv = av > 0.f ? dg1[nt][r] * mul : 0.f;
-        }
+        const bool ok = mm < (size_t)p.M && n < p.N1;
+        const float av = a1raw[nt][r] * (ok ? 1.f : 0.f);
+        const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mm * p.N1 + n) : 0.f);
+        const float ad = av * mul;
+        const float gv = av > 0.f ? dg1[nt][r] * mul : 0.f;
         db0acc[nt] += gv;
-        sG1[row * LD1 + n] = gv;
-        sA1[row * LD1 + n] = ad;
+        gq[r] = gv;
+        aq[r] = ad;
       }
+      *reinterpret_cast<float4*>(sG1 + n * LDR + 16 * wv + 4 * kq) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+      *reinterpret_cast<float4*>(sA1 + n * LDR + 16 * wv + 4 * kq) = make_float4(aq[0], aq[1], aq[2], aq[3]);
     }
     __syncthreads();
     // ---- S5: dx = g1 . W0^T -> dH, per-row dq ---------------------------------------------------------------------
@@ -356,7 +400,9 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
       for (int jt = 0; jt < 4 * KB; ++jt) dx[jt] = zf;
 #pragma unroll
       for (int kb = 0; kb < NT1; ++kb) {
-        const float4 a = *reinterpret_cast<const float4*>(sG1 + (16 * wv + i) * LD1 + 16 * kb + 4 * kq);
+        const int nn = 16 * kb + 4 * kq, rr = 16 * wv + i;
+        const float4 a = make_float4(sG1[(nn + 0) * LDR + rr], sG1[(nn + 1) * LDR + rr], sG1[(nn + 2) * LDR + rr],
+                                     sG1[(nn + 3) * LDR + rr]);
 #pragma unroll
         for (int jt = 0; jt < 4 * KB; ++jt) {
           const float4 b = *reinterpret_cast<const float4*>(sW0 + (16 * jt + i) * LD1 + 16 * kb + 4 * kq);
@@ -373,7 +419,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
           const int row = 16 * wv + 4 * kq + r, col = 16 * c + i;
           const size_t mm = (size_t)blk * 64 + row;
           if (mm < (size_t)p.M) {
-            const float hv = sH[row * LDH + col], qv = sQ[row * LDH + col];
+            const float hv = sH[col * LDR + row], qv = sQ[col * LDR + row];
             const float xh = dx[c][r], xq = dx[KB + c][r], xp = dx[2 * KB + c][r], xd = dx[3 * KB + c][r];
             p.dH[mm * K + col] = (xh + xp * qv) + xd;
             p.dqr[mm * K + col] = (xq + xp * hv) - xd;
@@ -385,18 +431,22 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
     for (int a = 0; a < D::W1_PER; ++a) {
       const int mt = wv + 4 * a;                       // wave-uniform
       if (mt < NT1) {
-        float av[4][4];
+        float4 av[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb) av[kb] = *reinterpret_cast<const float4*>(sA1 + (16 * mt + i) * LDR + 16 * kb + 4 * kq);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) av[kb][t] = sA1[(16 * kb + 4 * kq + t) * LD1 + 16 * mt + i];
+        for (int jt = 0; jt < NT2; ++jt) {
+          float4 bv[4];
 #pragma unroll
-        for (int jt = 0; jt < NT2; ++jt)
+          for (int kb = 0; kb < 4; ++kb) bv[kb] = *reinterpret_cast<const float4*>(sG2 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
 #pragma unroll
-          for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              accW1[a][jt] = att_mfma(av[kb][t], sG2[(16 * kb + 4 * kq + t) * LD2 + 16 * jt + i], accW1[a][jt]);
+          for (int kb = 0; kb < 4; ++kb) {
+            accW1[a][jt] = att_mfma(av[kb].x, bv[kb].x, accW1[a][jt]);
+            accW1[a][jt] = att_mfma(av[kb].y, bv[kb].y, accW1[a][jt]);
+            accW1[a][jt] = att_mfma(av[kb].z, bv[kb].z, accW1[a][jt]);
+            accW1[a][jt] = att_mfma(av[kb].w, bv[kb].w, accW1[a][jt]);
+          }
+        }
       }
     }
 #pragma unroll
@@ -404,22 +454,29 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
       const int mt = wv + 4 * a;                       // row tile of dW0: input features 16*mt .. (segment mt / KB)
       if (mt < D::MT0) {
         const int seg = mt / KB, col = 16 * (mt - seg * KB) + i;
-        float av[4][4];
+        float4 av[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb) {
+          const float4 hv = *reinterpret_cast<const float4*>(sH + col * LDR + 16 * kb + 4 * kq);
+          const float4 qv = *reinterpret_cast<const float4*>(sQ + col * LDR + 16 * kb + 4 * kq);
+          av[kb] = seg == 0 ? hv
+                   : seg == 1 ? qv
+                   : seg == 2 ? make_float4(hv.x * qv.x, hv.y * qv.y, hv.z * qv.z, hv.w * qv.w)
+                              : make_float4(hv.x - qv.x, hv.y - qv.y, hv.z - qv.z, hv.w - qv.w);
+        }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int row = 16 * kb + 4 * kq + t;
-            const float hv = sH[row * LDH + col], qv = sQ[row * LDH + col];
-            av[kb][t] = seg == 0 ? hv : (seg == 1 ? qv : (seg == 2 ? hv * qv : hv - qv));
+        for (int jt = 0; jt < NT1; ++jt) {
+          float4 bv[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) bv[kb] = *reinterpret_cast<const float4*>(sG1 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            accW0[a][jt] = att_mfma(av[kb].x, bv[kb].x, accW0[a][jt]);
+            accW0[a][jt] = att_mfma(av[kb].y, bv[kb].y, accW0[a][jt]);
+            accW0[a][jt] = att_mfma(av[kb].z, bv[kb].z, accW0[a][jt]);
+            accW0[a][jt] = att_mfma(av[kb].w, bv[kb].w, accW0[a][jt]);
           }
-#pragma unroll
-        for (int jt = 0; jt < NT1; ++jt)
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              accW0[a][jt] = att_mfma(av[kb][t], sG1[(16 * kb + 4 * kq + t) * LD1 + 16 * jt + i], accW0[a][jt]);
+        }
       }
     }
     __syncthreads();                                   // the tiles are rewritten by the next block
@@ -502,42 +559,60 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
   }
 }
 
-// grads[j] = sum over the G workgroup partials, ascending.  One element per thread, 8 loads in flight.
-__global__ __launch_bounds__(256) void din_attn_reduce_k(const float* __restrict__ part, int G, int n,
-                                                         float* __restrict__ grads) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+// grads[j] = sum over the G workgroup partials.  block = 1024 = 16 waves x 64 elements: wave w adds the contiguous
+// partial range [w*per, (w+1)*per) (8 loads in flight), the 16 sub-sums are then added in ascending wave order -- a fixed
+// association with 16x shorter dependent chains than one thread walking all G partials.
+__global__ __launch_bounds__(1024) void din_attn_reduce_k(const float* __restrict__ part, int G, int n,
+                                                          float* __restrict__ grads) {
+  __shared__ float sub[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int per = (G + 15) / 16;
+  const int g0 = w * per, g1 = g0 + per < G ? g0 + per : G;
   float s = 0.f;
-  int g = 0;
-  for (; g + 8 <= G; g += 8) {
-    float t[8];
+  if (j < n) {
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+      float t[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(g + u) * n + j];
+      for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(g + u) * n + j];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += t[u];
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; g < g1; ++g) s += part[(size_t)g * n + j];
   }
-  for (; g < G; ++g) s += part[(size_t)g * n + j];
-  grads[j] = s;
+  sub[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && j < n) {
+    float t = sub[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sub[k][lane];
+    grads[j] = t;
+  }
 }
 
-// dq[b, c] = sum_p dqr[b*P + p, c], ascending p.
+// dq[b, c] = sum_p dqr[b*P + p, c].  One workgroup per example: 256 threads = (256/K) position groups x K columns; group g
+// adds positions g, g+G', ... (ascending), the groups are then added in ascending order.
 __global__ __launch_bounds__(256) void din_attn_dq_k(const float* __restrict__ dqr, float* __restrict__ dq, int B, int P,
                                                      int K) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= B * K) return;
-  const int b = e / K, c = e - b * K;
+  __shared__ float sub[256];
+  const int b = blockIdx.x, c = threadIdx.x % K, g = threadIdx.x / K, ng = 256 / K;
   const float* src = dqr + (size_t)b * P * K + c;
   float s = 0.f;
-  int pp = 0;
-  for (; pp + 8 <= P; pp += 8) {
-    float t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(pp + u) * K];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += t[u];
+  int pp = g;
+  for (; pp + 3 * ng < P; pp += 4 * ng) {
+    const float t0 = src[(size_t)pp * K], t1 = src[(size_t)(pp + ng) * K], t2 = src[(size_t)(pp + 2 * ng) * K],
+                t3 = src[(size_t)(pp + 3 * ng) * K];
+    s += t0; s += t1; s += t2; s += t3;
   }
-  for (; pp < P; ++pp) s += src[(size_t)pp * K];
-  dq[e] = s;
+  for (; pp < P; pp += ng) s += src[(size_t)pp * K];
+  sub[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = sub[c];
+    for (int k = 1; k < ng; ++k) t += sub[k * K + c];
+    dq[(size_t)b * K + c] = t;
+  }
 }
 
 static inline int attn_bwd_groups(int M) {
@@ -554,7 +629,7 @@ extern "C" size_t rsx_din_attn_bwd_workspace_floats(int B, int P, int K, int N1,
 template <int KB, int NT1, int NT2>
 static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
   using D = AttnDims<KB, NT1, NT2>;
-  const size_t fl = (size_t)D::K4 * D::LD1 + (size_t)D::N1P * D::LD2 + D::N2P + 2 * 64 * D::LD1 + 64 * D::LD2 + 2 * 64 * D::LDH;
+  const size_t fl = (size_t)D::K4 * D::LD1 + (size_t)D::N1P * D::LD2 + D::N2P + (size_t)68 * (2 * D::N1P + D::N2P + 2 * D::K);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_k<KB, NT1, NT2>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess || fl * sizeof(float) > 160 * 1024) return RSX_EUNSUPPORTED;
@@ -580,8 +655,8 @@ extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0,
   if (rc != RSX_OK) return rc;
   RSX_CHECK_LAUNCH();
   const int n = (int)attn_npart(K, N1, N2);
-  hipLaunchKernelGGL(din_attn_reduce_k, dim3((n + 255) / 256), dim3(256), 0, st, p.part, G, n, grads);
-  hipLaunchKernelGGL(din_attn_dq_k, dim3((B * K + 255) / 256), dim3(256), 0, st, p.dqr, dq, B, P, K);
+  hipLaunchKernelGGL(din_attn_reduce_k, dim3((n + 63) / 64), dim3(1024), 0, st, p.part, G, n, grads);
+  hipLaunchKernelGGL(din_attn_dq_k, dim3(B), dim3(256), 0, st, p.dqr, dq, B, P, K);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
