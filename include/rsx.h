@@ -330,8 +330,9 @@ int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const fl
 /* dout = gradient wrt `out` (the relu mask is taken from `out`).  Writes dW[F*H,N], dc[N]; dXk[B,H,D] and dX0[B,F,D]
  * are overwritten or accumulated (acc_* != 0).  When Xk aliases X0 (first layer) pass distinct dXk / dX0 buffers.   */
 int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout, float* dXk,
-                      int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, int B, int F, int H, int N, int D,
-                      const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+                      int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, float* dpre_ws, int B, int F, int H,
+                      int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* dpre_ws: B*N*D floats of scratch (the relu-masked dout, written by the dX launch and read by the dW launch).       */
 /* sweep_h (nullable): a slice of the untouched-row optimizer sweep carried by extra workgroups of the dW launch (the
  * MFMA-bound tiles leave HBM idle), as on the tower entry points.                                                  */
 

@@ -151,6 +151,7 @@ struct CinBwdDxArgs {
   const float* dout;  // [B, N, 16] gradient wrt the relu output
   float* dXk;         // [B, H, 16]
   float* dX0;         // [B, F, 16]
+  float* dpre;        // [B, N, 16] out: dout with the relu mask applied, consumed by cin_bwd_dw_k
   int acc_dxk, acc_dx0;
   int B, F, H, N;
 };
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
         const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)b * p.N * CIN_D)[e];
         const float4 g = reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CIN_D)[e];
         v = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+        reinterpret_cast<float4*>(p.dpre + (size_t)b * p.N * CIN_D)[e] = v;
       }
       reinterpret_cast<float4*>(sDp + bt * p.N * CIN_D)[e] = v;
     }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
 
 // ----------------------------------------------------------------------------------------------- backward: dW, dc
 struct CinBwdDwArgs {
-  const float* X0; const float* Xk; const float* out; const float* dout;
+  const float* X0; const float* Xk; const float* dpre;   // dpre [B, N, 16] = relu-masked dout (written by cin_bwd_dx_k)
   float* dW;   // [F*H, N]
   float* dc;   // [N]
   int B, F, H, N, FG;   // FG = ceil(F/3) field groups
@@ -321,22 +323,24 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
   for (int t = 0; t < CIN_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float one = i == 0 ? 1.f : 0.f;
-  auto load = [&](int b, float4& dp, float4& xk, float4* x0) {
-    dp = z4; xk = z4;
+  // Operand loads are unconditional on clamped indices: out-of-range columns / rows / fields only feed output elements
+  // that are never stored, and an example past the batch is neutralised by zeroing its A operand (xk) and the ones-row.
+  const int nc = nok ? n : 0, hc = hok ? h : 0;
+  auto load = [&](int b, float4& dp, float4& xk, float4* x0, float& ob) {
+    const bool bok = b < p.B;
+    const size_t bc = bok ? (size_t)b : (size_t)p.B - 1;
+    ob = bok ? one : 0.f;
+    dp = *reinterpret_cast<const float4*>(p.dpre + (bc * p.N + nc) * CIN_D + kq * 4);
+    const float4 xr = *reinterpret_cast<const float4*>(p.Xk + (bc * p.H + hc) * CIN_D + kq * 4);
+    const float okf = bok ? 1.f : 0.f;
+    xk = make_float4(xr.x * okf, xr.y * okf, xr.z * okf, xr.w * okf);
 #pragma unroll
-    for (int t = 0; t < CIN_FT; ++t) x0[t] = z4;
-    if (b >= p.B) return;
-    if (nok) {
-      const float4 o = *reinterpret_cast<const float4*>(p.out + ((size_t)b * p.N + n) * CIN_D + kq * 4);
-      const float4 g = *reinterpret_cast<const float4*>(p.dout + ((size_t)b * p.N + n) * CIN_D + kq * 4);
-      dp = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    for (int t = 0; t < CIN_FT; ++t) {
+      const int ff = f0 + t < p.F ? f0 + t : p.F - 1;
+      x0[t] = *reinterpret_cast<const float4*>(p.X0 + (bc * p.F + ff) * CIN_D + kq * 4);
     }
-    if (hok) xk = *reinterpret_cast<const float4*>(p.Xk + ((size_t)b * p.H + h) * CIN_D + kq * 4);
-#pragma unroll
-    for (int t = 0; t < CIN_FT; ++t)
-      if (f0 + t < p.F) x0[t] = *reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f0 + t) * CIN_D + kq * 4);
   };
-  auto fma_b = [&](const float4& dp, const float4& xk, const float4* x0) {
+  auto fma_b = [&](const float4& dp, const float4& xk, const float4* x0, float ob) {
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t) {
       acc[t] = cin_mfma(x0[t].x * xk.x, dp.x, acc[t]);
@@ -345,25 +349,26 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
       acc[t] = cin_mfma(x0[t].w * xk.w, dp.w, acc[t]);
     }
     if (want_dc) {   // ones-row: row 0 of this tile accumulates sum_m dpre[m, n]
-      accc = cin_mfma(one, dp.x, accc);
-      accc = cin_mfma(one, dp.y, accc);
-      accc = cin_mfma(one, dp.z, accc);
-      accc = cin_mfma(one, dp.w, accc);
+      accc = cin_mfma(ob, dp.x, accc);
+      accc = cin_mfma(ob, dp.y, accc);
+      accc = cin_mfma(ob, dp.z, accc);
+      accc = cin_mfma(ob, dp.w, accc);
     }
   };
   // software pipeline: the operands of examples b+2, b+3 are loading while b, b+1 feed the matrix pipe
   float4 dpA, xkA, x0A[CIN_FT], dpB, xkB, x0B[CIN_FT], dpC, xkC, x0C[CIN_FT], dpD, xkD, x0D[CIN_FT];
-  load(wv, dpA, xkA, x0A);
-  load(wv + 4, dpB, xkB, x0B);
+  float oA, oB, oC, oD;
+  load(wv, dpA, xkA, x0A, oA);
+  load(wv + 4, dpB, xkB, x0B, oB);
   for (int b = wv; b < p.B; b += 16) {
-    load(b + 8, dpC, xkC, x0C);
-    load(b + 12, dpD, xkD, x0D);
-    fma_b(dpA, xkA, x0A);
-    fma_b(dpB, xkB, x0B);
-    load(b + 16, dpA, xkA, x0A);
-    load(b + 20, dpB, xkB, x0B);
-    fma_b(dpC, xkC, x0C);
-    fma_b(dpD, xkD, x0D);
+    load(b + 8, dpC, xkC, x0C, oC);
+    load(b + 12, dpD, xkD, x0D, oD);
+    fma_b(dpA, xkA, x0A, oA);
+    fma_b(dpB, xkB, x0B, oB);
+    load(b + 16, dpA, xkA, x0A, oA);
+    load(b + 20, dpB, xkB, x0B, oB);
+    fma_b(dpC, xkC, x0C, oC);
+    fma_b(dpD, xkD, x0D, oD);
   }
   // per-wave partial tiles -> LDS in C layout order (row = 4*kq + r, col = lane & 15), summed in wave order
 #pragma unroll
@@ -421,11 +426,11 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
 }
 
 extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout,
-                                 float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, int B, int F,
-                                 int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+                                 float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, float* dpre_ws,
+                                 int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc) return RSX_EINVAL;
+  if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc || !dpre_ws) return RSX_EINVAL;
   if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
   const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D) * sizeof(float);
@@ -437,11 +442,11 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
                             (int)lds) != hipSuccess)
       return RSX_ELAUNCH;
   }
-  CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, acc_dxk, acc_dx0, B, F, H, N};
+  CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N};
   if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
   else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
-  CinBwdDwArgs w{X0, Xk, out, dout, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT, {}};
+  CinBwdDwArgs w{X0, Xk, dpre_ws, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT, {}};
   const int rcs = adam_build_slice(sweep_h, w.sweep);
   if (rcs != RSX_OK) return rcs;
   const unsigned plane = (unsigned)((N + 15) / 16) * (unsigned)HT;

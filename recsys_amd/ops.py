@@ -709,7 +709,8 @@ class CinLayerFn(torch.autograd.Function):
         H, N = Xk.shape[1], W.shape[1]
         dX0, dXk = torch.empty_like(X0), torch.empty_like(Xk)
         dW, dc = torch.empty_like(W), torch.empty(N, device=W.device)
+        ws = torch.empty_like(out)
         check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(out), _ptr(g.contiguous()), _ptr(dXk), 0, _ptr(dX0),
-                                      0, _ptr(dW), _ptr(dc), B, F, H, N, D,
+                                      0, _ptr(dW), _ptr(dc), _ptr(ws), B, F, H, N, D,
                                       None if ctx.sweep is None else C.byref(ctx.sweep), _stream()), "rsx_cin_layer_bwd")
         return dX0, dXk, dW, dc, None
