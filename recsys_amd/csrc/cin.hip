@@ -220,20 +220,27 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
     for (int s0 = 0; s0 < NSMAX; s0 += 4) {     // 4 float4 W loads in flight, then their 32 MFMAs
       if (s0 < ns) {                            // wave-uniform
         float4 bw4[4];
+        if (vec_ok) {
+          // unconditional float4 loads on clamped addresses: a row h >= H only feeds a column that is never stored, and
+          // k-steps with n >= N multiply A operands that are zero (areg is zero-padded) -- no mask needed, no branch per load
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int nn = 16 * (s0 + u) + 4 * kq;
-          float4 t = z4;
-          if (hok && nn < p.N) {
-            if (vec_ok && nn + 3 < p.N) t = *reinterpret_cast<const float4*>(Wr + nn);
-            else {
+          for (int u = 0; u < 4; ++u) {
+            const int nn = 16 * (s0 + u) + 4 * kq;
+            bw4[u] = *reinterpret_cast<const float4*>(Wr + (nn + 3 < p.N ? nn : p.N - 4));
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int nn = 16 * (s0 + u) + 4 * kq;
+            float4 t = z4;
+            if (hok && nn < p.N) {
               t.x = Wr[nn];
               t.y = nn + 1 < p.N ? Wr[nn + 1] : 0.f;
               t.z = nn + 2 < p.N ? Wr[nn + 2] : 0.f;
               t.w = nn + 3 < p.N ? Wr[nn + 3] : 0.f;
             }
+            bw4[u] = t;
           }
-          bw4[u] = t;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
