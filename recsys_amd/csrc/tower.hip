@@ -483,20 +483,25 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     if (rr) __syncthreads();        // `part` / `cred` of the previous tile have been consumed
     const int row = rt * TM + i;
     const bool rok = row < p.B;
+    const size_t arow = (size_t)(rok ? row : p.B - 1) * p.N, wrow = (size_t)(cok ? kcol : 0) * p.N;
     const float v = tile_ksplit((p.N + 15) / 16, part, [&](int ks, float* a, float* b) {
       const int nn = ks * 16 + 4 * kq;
+      float ar[4], dyr[4], wr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {                    // unconditional loads on clamped indices (see the dW tiles)
+        const int nc = nn + t < p.N ? nn + t : p.N - 1;
+        ar[t] = p.a[arow + nc];
+        dyr[t] = p.dy[arow + nc];
+        wr[t] = p.W[wrow + nc];
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int n = nn + t;
-        a[t] = 0.f;
-        b[t] = 0.f;
-        if (n < p.N) {
-          if (rok) {
-            ColBwd cb; cb.mean = Lm[n]; cb.rstd = Lr[n]; cb.k1 = Lk[n]; cb.sdy = Ls[n]; cb.sdx = Lx[n];
-            a[t] = da_of(p.a[(size_t)row * p.N + n], p.dy[(size_t)row * p.N + n], cb, Bf);
-          }
-          if (cok) b[t] = p.W[(size_t)kcol * p.N + n];
-        }
+        const int nc = n < p.N ? n : p.N - 1;
+        const float nf = n < p.N ? 1.f : 0.f;
+        ColBwd cb; cb.mean = Lm[nc]; cb.rstd = Lr[nc]; cb.k1 = Lk[nc]; cb.sdy = Ls[nc]; cb.sdx = Lx[nc];
+        a[t] = da_of(ar[t], dyr[t], cb, Bf) * (rok ? nf : 0.f);
+        b[t] = wr[t] * (cok ? nf : 0.f);
       }
     });
     const int orow = rt * TM + (tid >> 4), ocol = kc * 16 + (tid & 15);
@@ -552,22 +557,28 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       p.dgamma[ncol] = cb.sdx;
       p.dbeta[ncol] = cb.sdy;
     }
+    const int featc = fok ? feat : 0, ncolc = nok ? ncol : 0;
     float v = tile_ksplit(nks, part, [&](int ks, float* a, float* b) {
+      // operand loads unconditional on clamped indices, masked by multiplication afterwards (a guarded load is compiled
+      // into a branch of its own, and the four k-steps' loads then complete one after the other)
+      float xr[4], ar[4], dyr[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int bb = (ks0 + ks) * 16 + 4 * kq + t;
-        a[t] = 0.f;
-        b[t] = 0.f;
-        if (bb < p.B) {
-          if (fok) {
-            float x = p.in[(size_t)bb * p.K + feat];
-            if (!first) x = (x * fsc + fsh) * drop_mul(dr, p.mask_prev, (size_t)bb * p.K + feat);
-            a[t] = x;
-          } else if (ones) {
-            a[t] = 1.f;
-          }
-          if (nok) b[t] = da_of(p.a[(size_t)bb * p.N + ncol], p.dy[(size_t)bb * p.N + ncol], cb, Bf);
-        }
+        const size_t bc = (size_t)(bb < p.B ? bb : p.B - 1);
+        xr[t] = p.in[bc * p.K + featc];
+        ar[t] = p.a[bc * p.N + ncolc];
+        dyr[t] = p.dy[bc * p.N + ncolc];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int bb = (ks0 + ks) * 16 + 4 * kq + t;
+        const float vf = bb < p.B ? 1.f : 0.f;
+        float x = xr[t];
+        if (!first) x = (x * fsc + fsh) * drop_mul(dr, p.mask_prev, (size_t)(bb < p.B ? bb : p.B - 1) * p.K + featc);
+        x = fok ? x : (ones ? 1.f : 0.f);
+        a[t] = x * vf;
+        b[t] = da_of(ar[t], dyr[t], cb, Bf) * (nok ? vf : 0.f);
       }
     });
     if (SPLIT) {      // partial tile; tower_reduce_dw_k adds the sb partials in ascending block order
