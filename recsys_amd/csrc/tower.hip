@@ -158,32 +158,31 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   const int row = by * TM + i;
   const int col = bx * 16 + i;
   const bool rok = row < p.B, cok = col < p.N;
+  const size_t irow = (size_t)(rok ? row : p.B - 1) * p.K;
+  const int colc = cok ? col : 0;
+  const float rokf = rok ? 1.f : 0.f;
   const float v = tile_ksplit((p.K + 15) / 16, part, [&](int ks, float* a, float* b) {
+    // operand loads unconditional on clamped indices; a k-step past K is neutralised by zeroing its A operand (a guarded
+    // load is compiled into a branch of its own and the loads then complete one after the other)
     const int kk = ks * 16 + 4 * kq;
-    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-    b[0] = b[1] = b[2] = b[3] = 0.f;
-    if (kk < p.K) {
-      if (cok) {
-        const float* w = p.W + (size_t)kk * p.N + col;
-        b[0] = w[0];
-        b[1] = w[p.N];
-        b[2] = w[2 * (size_t)p.N];
-        b[3] = w[3 * (size_t)p.N];
-      }
-      if (rok) {
-        av = *reinterpret_cast<const float4*>(p.in + (size_t)row * p.K + kk);
-        if (!first) {
-          const float4 s = *reinterpret_cast<const float4*>(sc + kk);
-          const float4 h = *reinterpret_cast<const float4*>(sh + kk);
-          const size_t e = (size_t)row * p.K + kk;
-          av.x = (av.x * s.x + h.x) * drop_mul(dr, p.mask_prev, e);
-          av.y = (av.y * s.y + h.y) * drop_mul(dr, p.mask_prev, e + 1);
-          av.z = (av.z * s.z + h.z) * drop_mul(dr, p.mask_prev, e + 2);
-          av.w = (av.w * s.w + h.w) * drop_mul(dr, p.mask_prev, e + 3);
-        }
-      }
+    const int kc = kk < p.K ? kk : p.K - 4;
+    const float okf = kk < p.K ? rokf : 0.f;
+    const float* w = p.W + (size_t)kc * p.N + colc;
+    b[0] = w[0];
+    b[1] = w[p.N];
+    b[2] = w[2 * (size_t)p.N];
+    b[3] = w[3 * (size_t)p.N];
+    float4 av = *reinterpret_cast<const float4*>(p.in + irow + kc);
+    if (!first) {
+      const float4 s = *reinterpret_cast<const float4*>(sc + kc);
+      const float4 h = *reinterpret_cast<const float4*>(sh + kc);
+      const size_t e = irow + kc;
+      av.x = (av.x * s.x + h.x) * drop_mul(dr, p.mask_prev, e);
+      av.y = (av.y * s.y + h.y) * drop_mul(dr, p.mask_prev, e + 1);
+      av.z = (av.z * s.z + h.z) * drop_mul(dr, p.mask_prev, e + 2);
+      av.w = (av.w * s.w + h.w) * drop_mul(dr, p.mask_prev, e + 3);
     }
-    a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+    a[0] = av.x * okf; a[1] = av.y * okf; a[2] = av.z * okf; a[3] = av.w * okf;
   });
   // epilogue: thread t owns element (r = t/16, c = t%16)
   const int orow = by * TM + (tid >> 4), ocol = bx * 16 + (tid & 15);
