@@ -291,16 +291,17 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
   float av[4][CPL], s0v[4], s1v[4], yv[4];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
-    const int row = row0 + rr;
-    const bool ok = row < p.B;
+    // unconditional on clamped indices (rows past the batch are skipped below, columns past N are masked there): a
+    // guarded load is compiled into a branch of its own
+    const size_t row = (size_t)(row0 + rr < p.B ? row0 + rr : p.B - 1);
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int c = lane + 64 * k;
-      av[rr][k] = (ok && c < p.N) ? p.a_last[(size_t)row * p.N + c] : 0.f;
+      av[rr][k] = p.a_last[row * p.N + (c < p.N ? c : p.N - 1)];
     }
-    s0v[rr] = (ok && p.s0) ? p.s0[row] : 0.f;
-    s1v[rr] = (ok && p.s1) ? p.s1[row] : 0.f;
-    yv[rr] = ok ? p.labels[row] : 0.f;
+    s0v[rr] = p.s0 ? p.s0[row] : 0.f;
+    s1v[rr] = p.s1 ? p.s1[row] : 0.f;
+    yv[rr] = p.labels[row];
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
