@@ -483,6 +483,16 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     if (rr) __syncthreads();        // `part` / `cred` of the previous tile have been consumed
     const int row = rt * TM + i;
     const bool rok = row < p.B;
+    // the epilogue's operands (previous layer's activation and BN statistics of this thread's output element) do not depend
+    // on the tile: issue them now, unconditionally on clamped indices, so they arrive during the MFMA loop
+    const int orow = rt * TM + (tid >> 4), ocol = kc * 16 + (tid & 15);
+    float xin_e = 0.f, bnm_e = 0.f, bnr_e = 0.f;
+    if (!first) {   // workgroup-uniform
+      const int oc = ocol < p.K ? ocol : p.K - 1;
+      xin_e = p.in[(size_t)(orow < p.B ? orow : p.B - 1) * p.K + oc];
+      bnm_e = p.bn_prev[oc];
+      bnr_e = p.bn_prev[p.K + oc];
+    }
     const size_t arow = (size_t)(rok ? row : p.B - 1) * p.N, wrow = (size_t)(cok ? kcol : 0) * p.N;
     const float v = tile_ksplit((p.N + 15) / 16, part, [&](int ks, float* a, float* b) {
       const int nn = ks * 16 + 4 * kq;
@@ -504,14 +514,13 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         b[t] = wr[t] * (cok ? nf : 0.f);
       }
     });
-    const int orow = rt * TM + (tid >> 4), ocol = kc * 16 + (tid & 15);
     double s1 = 0.0, s2 = 0.0;
     if (orow < p.B && ocol < p.K) {
       float o = v;
       if (!first) {
         const DropRng dr = drop_make(p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
         o *= drop_mul(dr, p.mask_prev, (size_t)orow * p.K + ocol);
-        const float xh = (p.in[(size_t)orow * p.K + ocol] - p.bn_prev[ocol]) * p.bn_prev[p.K + ocol];
+        const float xh = (xin_e - bnm_e) * bnr_e;
         s1 = (double)o;
         s2 = (double)o * (double)xh;
       }
