@@ -15,6 +15,14 @@
 constexpr int CROSS_MAX_L = 8;
 constexpr int CROSS_NV = 4;   // float4 per lane -> dim <= 1024
 
+// float4 #e of a row of n4 float4s; lanes past the row read the last element (in range) and get zero by multiplication:
+// a guarded load is compiled into a branch of its own and the vectors of a lane then load one after the other
+__device__ __forceinline__ float4 cross_ld(const float4* __restrict__ row, int e, int n4) {
+  const float4 v = row[e < n4 ? e : n4 - 1];
+  const float f = e < n4 ? 1.f : 0.f;
+  return make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+}
+
 struct CrossFwdArgs {
   const float* x0;     // [B, dim]
   const float* W;      // [L, dim]
@@ -43,7 +51,7 @@ __global__ __launch_bounds__(256) void cross_fwd_k(const CrossFwdArgs p) {
 #pragma unroll
   for (int v = 0; v < CROSS_NV; ++v) {
     const int e = lane + 64 * v;
-    x0[v] = e < n4 ? reinterpret_cast<const float4*>(p.x0)[(size_t)b * n4 + e] : z;
+    x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, e, n4);
     x[v] = x0[v];
   }
   for (int l = 0; l < p.L; ++l) {
@@ -52,8 +60,8 @@ __global__ __launch_bounds__(256) void cross_fwd_k(const CrossFwdArgs p) {
 #pragma unroll
     for (int v = 0; v < CROSS_NV; ++v) {
       const int e = lane + 64 * v;
-      w[v] = e < n4 ? reinterpret_cast<const float4*>(p.W)[(size_t)l * n4 + e] : z;
-      bb[v] = e < n4 ? reinterpret_cast<const float4*>(p.Bc)[(size_t)l * n4 + e] : z;
+      w[v] = cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, e, n4);
+      bb[v] = cross_ld(reinterpret_cast<const float4*>(p.Bc) + (size_t)l * n4, e, n4);
       part += dot4(x[v], w[v]);
     }
     const float s = wave_sum(part);
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
 #pragma unroll
     for (int v = 0; v < CROSS_NV; ++v) {
       const int e = lane + 64 * v;
-      wv[l][v] = (l < p.L && e < n4) ? reinterpret_cast<const float4*>(p.W)[(size_t)l * n4 + e] : z;
+      wv[l][v] = l < p.L ? cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, e, n4) : z;   // l: uniform
     }
   for (int rr = 0; rr < epw; ++rr) {
     const int b = blockIdx.x * epw + rr;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
 #pragma unroll
     for (int v = 0; v < CROSS_NV; ++v) {
       const int e = lane + 64 * v;
-      x0[v] = e < n4 ? reinterpret_cast<const float4*>(p.x0)[(size_t)b * n4 + e] : z;
+      x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, e, n4);
       x[v] = x0[v];
       dx0[v] = z;
     }
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
         for (int v = 0; v < CROSS_NV; ++v) {
           const int e = lane + 64 * v;
           xs[l][v] = x[v];
-          const float4 bb = e < n4 ? reinterpret_cast<const float4*>(p.Bc)[(size_t)l * n4 + e] : z;
+          const float4 bb = cross_ld(reinterpret_cast<const float4*>(p.Bc) + (size_t)l * n4, e, n4);
           x[v] = f4_add(f4_add(f4_scale(sl[l], x0[v]), x[v]), bb);
         }
       }
@@ -140,10 +148,10 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
     for (int v = 0; v < CROSS_NV; ++v) {
       const int e = lane + 64 * v;
       float4 d = z;
-      if (e < n4) {
-        if (p.dxL != nullptr) d = reinterpret_cast<const float4*>(p.dxL)[(size_t)b * n4 + e];
-        if (p.gz != nullptr) {
-          d = f4_add(d, f4_scale(g, reinterpret_cast<const float4*>(p.wout)[e]));
+      if (p.dxL != nullptr) d = cross_ld(reinterpret_cast<const float4*>(p.dxL) + (size_t)b * n4, e, n4);   // uniform
+      if (p.gz != nullptr) {
+        d = f4_add(d, f4_scale(g, cross_ld(reinterpret_cast<const float4*>(p.wout), e, n4)));
+        if (e < n4) {
           float4* o = acc + (size_t)(2 * p.L) * n4 + e;
           *o = f4_add(*o, f4_scale(g, x[v]));                       // d wout += gz * x_L
         }
