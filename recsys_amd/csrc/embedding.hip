@@ -31,13 +31,36 @@ __global__ void gather_fm_fwd_k(const float* __restrict__ tables, const float* _
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), qq = s;
   float a1 = 0.f;
   const int32_t* idb = ids + (size_t)b * F;
-  for (int f = j; f < F; f += PPP) {
-    const int row = row_off[f] + idb[f];
-    const float4 e = T4[(size_t)row * LPR + q];
-    E4[((size_t)b * F + f) * LPR + q] = e;
-    s = f4_add(s, e);
-    qq = f4_add(qq, f4_mul(e, e));
-    if (w1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull)) a1 += w1[row];
+  // The lane's fields f = j, j + PPP, ... in batches of 4: ids and offsets of the batch first, then its row loads, all
+  // unconditional on clamped field indices (one dependent chain per batch instead of one per field; a load behind a
+  // per-lane guard is compiled into a branch of its own).  Sums run in ascending f as before.
+  for (int f0 = j; f0 < F; f0 += 4 * PPP) {
+    int row[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * PPP;
+      ok[k] = f < F;
+      const int fc = ok[k] ? f : F - 1;
+      row[k] = row_off[fc] + idb[fc];
+    }
+    float4 e[4];
+    float wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k] = T4[(size_t)row[k] * LPR + q];
+      wv[k] = w1 != nullptr ? w1[row[k]] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * PPP;
+      if (ok[k]) {
+        E4[((size_t)b * F + f) * LPR + q] = e[k];
+        s = f4_add(s, e[k]);
+        qq = f4_add(qq, f4_mul(e[k], e[k]));
+        if (q == 0 && ((w1_mask >> f) & 1ull)) a1 += wv[k];
+      }
+    }
   }
 #pragma unroll
   for (int m = LPR; m < RSX_WAVE; m <<= 1) {
