@@ -16,12 +16,22 @@ __global__ __launch_bounds__(256) void din_pool_fwd_k(const float* __restrict__ 
   if (b >= B) return;
   const int q = lane % LPR, j = lane / LPR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p = j; p < P; p += RPW) {
-    const size_t e = (size_t)b * P + p;
-    if (ids[e] > 0) {
-      const float4 h = reinterpret_cast<const float4*>(H)[e * LPR + q];
-      acc = f4_add(acc, f4_scale(w[e], h));
+  // positions p = j, j + RPW, ... in batches of 4: ids, weights and rows of the batch loaded unconditionally on clamped
+  // positions, padding (id 0) and the tail masked by a zero weight -- a load behind `if (ids > 0)` is a branch of its own
+  // and the positions would then load one after the other.  Adding w*h with w = 0 is exact, the order stays ascending p.
+  for (int p0 = j; p0 < P; p0 += 4 * RPW) {
+    float wv[4];
+    float4 hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pp = p0 + k * RPW;
+      const size_t e = (size_t)b * P + (pp < P ? pp : P - 1);
+      const float keep = (pp < P && ids[e] > 0) ? 1.f : 0.f;
+      wv[k] = w[e] * keep;
+      hv[k] = reinterpret_cast<const float4*>(H)[e * LPR + q];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = f4_add(acc, f4_scale(wv[k], hv[k]));
   }
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
@@ -45,14 +55,11 @@ __global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ 
     const int p = p0 + j;
     const bool in = p < P;
     const size_t e = (size_t)b * P + (in ? p : 0);
-    const bool on = in && ids[e] > 0;
-    float d = 0.f;
-    float4 o = z;
-    if (on) {
-      const float4 h = reinterpret_cast<const float4*>(H)[e * LPR + q];
-      d = (h.x * g.x + h.y * g.y) + (h.z * g.z + h.w * g.w);
-      o = f4_scale(w[e], g);
-    }
+    // unconditional loads, padding masked by multiplication (a load behind `if (ids > 0)` is a branch of its own)
+    const float keep = (in && ids[e] > 0) ? 1.f : 0.f;
+    const float4 h = reinterpret_cast<const float4*>(H)[e * LPR + q];
+    float d = ((h.x * g.x + h.y * g.y) + (h.z * g.z + h.w * g.w)) * keep;
+    const float4 o = f4_scale(w[e] * keep, g);
 #pragma unroll
     for (int m = 1; m < LPR; m <<= 1) d += __shfl_xor(d, m);
     if (in) {
