@@ -553,8 +553,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     const int feat = kf * 16 + i;          // A-operand row (input feature)
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
-    ColBwd cb = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (nok) cb = bwd_col(p, ncol);
+    const ColBwd cb = bwd_col(p, nok ? ncol : 0);     // unconditional (clamped column): no branch around its loads
     float fsc = 1.f, fsh = 0.f;
     if (!first && fok) {
       const float inv = p.bn_prev[p.K + feat] * p.gamma_prev[feat];
