@@ -65,10 +65,15 @@ __global__ __launch_bounds__(256) void cin_fwd_k(const CinFwdArgs p) {
     reinterpret_cast<float4*>(sX0)[e] = bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[r] : z4;
   }
   float areg[HSMAX];
+  {
+    // unconditional on clamped indices, masked by multiplication: HSMAX guarded loads would be HSMAX branches, i.e. as
+    // many dependent memory round trips before the first MFMA
+    const float* xk = p.Xk + (size_t)(bok ? b : p.B - 1) * p.H * CIN_D + i;
 #pragma unroll
-  for (int s_ = 0; s_ < HSMAX; ++s_) {
-    const int h = 16 * (s_ >> 2) + 4 * kq + (s_ & 3);
-    areg[s_] = (h < p.H && bok) ? p.Xk[((size_t)b * p.H + h) * CIN_D + i] : 0.f;
+    for (int s_ = 0; s_ < HSMAX; ++s_) {
+      const int h = 16 * (s_ >> 2) + 4 * kq + (s_ & 3);
+      areg[s_] = xk[(size_t)(h < p.H ? h : p.H - 1) * CIN_D] * ((h < p.H && bok) ? 1.f : 0.f);
+    }
   }
   float4 wreg[R];
   auto load_tile = [&](int f) {
