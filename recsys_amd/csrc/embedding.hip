@@ -78,6 +78,22 @@ __global__ void gather_fm_fwd_k(const float* __restrict__ tables, const float* _
   if (y1 != nullptr && lane == 0) y1[b] = a1;
 }
 
+// F = 1 (tf.nn.embedding_lookup of one table: DIN's item / category / history lookups, din/din.py:96-105): a plain row
+// gather.  The multi-field kernel would keep one wave per id with D/4 of its 64 lanes busy; here a wave serves 64/(D/4)
+// ids at once, one float4 per lane, fully coalesced on the output side.
+template <int D>
+__global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ table, const int32_t* __restrict__ row_off,
+                                                     const int32_t* __restrict__ ids, float* __restrict__ out,
+                                                     long long n) {
+  constexpr int LPR = D / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long e = t / LPR;
+  if (e >= n) return;
+  const int q = (int)(t - e * LPR);
+  const long long row = (long long)row_off[0] + ids[e];
+  reinterpret_cast<float4*>(out)[e * LPR + q] = reinterpret_cast<const float4*>(table)[row * LPR + q];
+}
+
 // ------------------------------------------------------------------ dedup: per-field LDS sort ---
 // One workgroup per field (sort_device.h).  n = padded power of two (>= 128), T = min(1024, n/2) threads.
 __global__ __launch_bounds__(1024) void field_sort_k(const SortArgs a) {
@@ -639,6 +655,12 @@ static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegParti
   return RSX_OK;
 }
 
+template <int D>
+static void launch_gather_rows(dim3 grid, dim3 block, hipStream_t st, const float* tables, const int32_t* row_off,
+                               const int32_t* ids, float* E, long long n) {
+  gather_rows_k<D><<<grid, block, 0, st>>>(tables, row_off, ids, E, n);
+}
+
 extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
                                  float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int B, int F,
                                  int D, rsx_stream_t stream) {
@@ -647,6 +669,13 @@ extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int
   if (!tables || !row_off || !ids || !E) return RSX_EINVAL;
   if ((y1 != nullptr) != (w1 != nullptr)) return RSX_EINVAL;
   if (y2 != nullptr && S == nullptr) return RSX_EINVAL;
+  if (F == 1 && w1 == nullptr && S == nullptr && y2 == nullptr) {   // one table, rows only
+    const long long lanes = (long long)B * (D / 4);
+    RSX_DISPATCH_D(D, launch_gather_rows, dim3((unsigned)((lanes + 255) / 256)), dim3(256), rsx_s(stream), tables, row_off,
+                   ids, E, (long long)B);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+  }
   const int waves = B >= 2048 ? 4 : 1;  // small batches: one wave per workgroup spreads over all 256 CUs
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
   RSX_DISPATCH_D(D, launch_gather, grid, block, rsx_s(stream), tables, w1, row_off, ids, E, S, y1, y2,
