@@ -71,7 +71,17 @@ __global__ __launch_bounds__(LS_BINS) void ls_scan_k(const LargeSort a) {
   const int f = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
   int32_t* h = a.hist + ((size_t)f * LS_BINS + d) * a.nT;
   int tot = 0;
-  for (int t = 0; t < a.nT; ++t) tot += h[t];
+  {
+    int t = 0;
+    for (; t + 8 <= a.nT; t += 8) {     // 8 loads in flight (one dependent L2 round trip per tile would dominate)
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = h[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot += c[u];
+    }
+    for (; t < a.nT; ++t) tot += h[t];
+  }
   int incl = tot;
 #pragma unroll
   for (int s = 1; s < 64; s <<= 1) {
@@ -82,10 +92,23 @@ __global__ __launch_bounds__(LS_BINS) void ls_scan_k(const LargeSort a) {
   __syncthreads();
   int run = incl - tot;
   for (int ww = 0; ww < w; ++ww) run += wsum[ww];
-  for (int t = 0; t < a.nT; ++t) {
-    const int c = h[t];
-    h[t] = run;
-    run += c;
+  {
+    int t = 0;
+    for (; t + 8 <= a.nT; t += 8) {
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = h[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        h[t + u] = run;
+        run += c[u];
+      }
+    }
+    for (; t < a.nT; ++t) {
+      const int c = h[t];
+      h[t] = run;
+      run += c;
+    }
   }
 }
 
