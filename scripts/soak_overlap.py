@@ -1,0 +1,44 @@
+"""GPU box: soak / race check of the overlapped split optimizer.  Trains DeepFM bs256 for N steps twice from identical
+weights and batches -- (a) the production path (sort riding in the first forward launch, untouched-row sweep carried by the
+tower launches, scatter fused with the touched-row Adam, HIP graphs of 8 steps) and (b) the plain path (stand-alone sort,
+segment-sum, ONE full Adam sweep, no graphs) -- and compares every parameter.  The split is exact arithmetic, so any
+difference beyond fp32 re-association of long segments (none at this batch size) points at a race."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from recsys_amd import deepfm, synthetic
+from recsys_amd.estimator import Estimator, PackedBatch, RunConfig
+from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+B = 256
+lin, emb = build_feature_columns(16, "indicator_all")
+layout = CriteoLayout.from_columns(emb)
+host = synthetic.criteo_id_batches(layout, 64, B, seed=123)
+res = []
+for overlap, graph in ((True, True), (False, False)):
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+              "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B, "overlap_adam": overlap}
+    est = Estimator(deepfm.model_fn, None, params, RunConfig(use_hip_graph=graph, adam_mode="tf1_dense", device="cuda", seed=77))
+    feats = [PackedBatch({"ids": i}, y, device="cuda") for i, y, _ in host]
+    with torch.no_grad():
+        est._call_model_fn(feats[0].views()[0], None, "infer")
+    if graph:
+        est.train_resident(feats, N, 8)
+    else:
+        for s in range(N):
+            est._train_step(feats[s % 64])
+    torch.cuda.synchronize()
+    a = est.store.embeddings["input_layer"]
+    res.append({"tables": a.tables.clone(), "m": a.m_t.clone(), "v": a.v_t.clone(), "w1": a.w1.clone(), "dense": est.store.dense.flat.clone(),
+                "step": est.global_step})
+a, b = res
+print("steps", a["step"], b["step"])
+bad = 0
+for k in ("tables", "m", "v", "w1", "dense"):
+    d = (a[k] - b[k]).abs().max().item()
+    eq = torch.equal(a[k], b[k])
+    print("%-7s bit-identical=%s  max|diff|=%.3e  finite=%s" % (k, eq, d, bool(torch.isfinite(a[k]).all())))
+    bad += (not eq)
+print("SOAK_OK" if bad == 0 else "SOAK_DIFF")

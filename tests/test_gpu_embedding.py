@@ -352,3 +352,38 @@ def test_library_loaded_before_torch_still_launches():
     code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.build(); g.smoke(); print('ORDER_OK')" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "ORDER_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_overlapped_optimizer_is_bit_identical_to_the_plain_path():
+    """The production step (dedup sort riding in the first forward launch, untouched-row Adam sweep carried by the tower
+    launches, scatter fused with the touched-row update, 8-step HIP graphs) against the plain one (stand-alone sort,
+    segment-sum, ONE full TF-1 Adam sweep, eager): same weights, same batches, dropout by the counter hash.  The split is
+    exact arithmetic, so after hundreds of steps every table row, Adam slot and dense variable must be bit-identical; a
+    race between the carried sweep and the touched-row update would show here (scripts/soak_overlap.py runs it longer)."""
+    from recsys_amd import deepfm, synthetic
+    from recsys_amd.estimator import Estimator, PackedBatch, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    N, B = 320, 256
+    lin, emb = build_feature_columns(16, "indicator_all")
+    layout = CriteoLayout.from_columns(emb)
+    host = synthetic.criteo_id_batches(layout, 16, B, seed=321)
+    res = []
+    for overlap, graph in ((True, True), (False, False)):
+        params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+                  "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B, "overlap_adam": overlap}
+        est = Estimator(deepfm.model_fn, None, params, RunConfig(use_hip_graph=graph, adam_mode="tf1_dense", device="cuda", seed=9))
+        feats = [PackedBatch({"ids": i}, y, device="cuda") for i, y, _ in host]
+        with torch.no_grad():
+            est._call_model_fn(feats[0].views()[0], None, "infer")
+        if graph:
+            est.train_resident(feats, N, 8)
+        else:
+            for s_ in range(N):
+                est._train_step(feats[s_ % 16])
+        torch.cuda.synchronize()
+        a = est.store.embeddings["input_layer"]
+        assert est.global_step == N
+        res.append((a.tables.clone(), a.m_t.clone(), a.v_t.clone(), a.w1.clone(), est.store.dense.flat.clone()))
+    for name, x, y in zip(("tables", "m", "v", "w1", "dense"), *res):
+        assert torch.isfinite(x).all(), name
+        assert torch.equal(x, y), (name, float((x - y).abs().max()))
