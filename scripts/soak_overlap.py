@@ -12,15 +12,18 @@ from recsys_amd.estimator import Estimator, PackedBatch, RunConfig
 from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-B = 256
-lin, emb = build_feature_columns(16, "indicator_all")
+MODEL = sys.argv[2] if len(sys.argv) > 2 else "deepfm"          # deepfm (bs 256) | dcn (bs 4096: two-stage scatter, split dW)
+from recsys_amd import dcn
+B = 256 if MODEL == "deepfm" else 4096
+mfn = deepfm.model_fn if MODEL == "deepfm" else dcn.model_fn
+lin, emb = build_feature_columns(16, "indicator_all" if MODEL == "deepfm" else "numeric")
 layout = CriteoLayout.from_columns(emb)
 host = synthetic.criteo_id_batches(layout, 64, B, seed=123)
 res = []
 for overlap, graph in ((True, True), (False, False)):
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
-              "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B, "overlap_adam": overlap}
-    est = Estimator(deepfm.model_fn, None, params, RunConfig(use_hip_graph=graph, adam_mode="tf1_dense", device="cuda", seed=77))
+              "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B, "overlap_adam": overlap, "cross_layers": 3}
+    est = Estimator(mfn, None, params, RunConfig(use_hip_graph=graph, adam_mode="tf1_dense", device="cuda", seed=77))
     feats = [PackedBatch({"ids": i}, y, device="cuda") for i, y, _ in host]
     with torch.no_grad():
         est._call_model_fn(feats[0].views()[0], None, "infer")
@@ -31,7 +34,8 @@ for overlap, graph in ((True, True), (False, False)):
             est._train_step(feats[s % 64])
     torch.cuda.synchronize()
     a = est.store.embeddings["input_layer"]
-    res.append({"tables": a.tables.clone(), "m": a.m_t.clone(), "v": a.v_t.clone(), "w1": a.w1.clone(), "dense": est.store.dense.flat.clone(),
+    res.append({"tables": a.tables.clone(), "m": a.m_t.clone(), "v": a.v_t.clone(),
+                "w1": a.w1.clone() if a.with_w1 else torch.zeros(1), "dense": est.store.dense.flat.clone(),
                 "step": est.global_step})
 a, b = res
 print("steps", a["step"], b["step"])
