@@ -239,6 +239,13 @@ int rsx_tower_head(const float* a_last, const double* fstat_last, const float* g
                    float* gs1, const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate,
                    float loss_scale, int relu0, int relu2, int B, int N, const rsx_adam_slice* sweep_h,
                    rsx_stream_t stream);
+/* FM head with its backward (fm/fm.py:120-133,146-149): z = wo[0]*relu(y1 + c0) + wo[1]*y2 + bo; prob = sigmoid(z);
+ * loss = mean sigmoid-CE; gy1 / gy2 = d loss / d y1, y2 (inputs of rsx_segsum_bwd); dwo[2], dbo, dc0.
+ * loss_scale = 1/(B * replicas).  sweep_h (nullable): a slice of the untouched-row optimizer sweep carried by extra
+ * workgroups.                                                                                                       */
+int rsx_fm_head(const float* y1, const float* y2, const float* c0, const float* wo, const float* bo,
+                const float* labels, float* prob, float* gy1, float* gy2, float* dwo, float* dbo, float* dc0,
+                float* loss, float loss_scale, int B, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 /* Backward of layer l: BN backward + relu mask on load; writes dW, db, dgamma, dbeta, and dy_prev = gradient wrt
  * the previous layer's BN output (+ its bstat_prev partials), or dX for the first layer (bn_prev == NULL).
  * With hpart != NULL (last layer) one extra workgroup reduces the head partials into dwd, dbd, dwo[3], dbo, dc0, loss. */

@@ -807,6 +807,76 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   return RSX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// FM head (fm/fm.py:120-133, 146-149): z = wo[0]*relu(y1 + c0) + wo[1]*y2 + bo, prob = sigmoid(z), mean sigmoid-CE, and
+// the whole backward of it: gy1 = d loss / d y1, gy2 = d loss / d y2, dwo[2], dbo, dc0, loss.  One workgroup walks the
+// batch (the model is the embedding kernels; this is ~10 flops per example) and reduces in fp64 in a fixed order; extra
+// workgroups carry a slice of the untouched-row optimizer sweep, as on the tower entry points.
+// ---------------------------------------------------------------------------------------------
+struct FmHeadArgs {
+  const float* y1; const float* y2; const float* c0; const float* wo; const float* bo; const float* labels;
+  float* prob; float* gy1; float* gy2; float* dwo; float* dbo; float* dc0; float* loss;
+  float loss_scale;
+  int B;
+  AdamSlice sweep;
+};
+
+__global__ __launch_bounds__(256) void fm_head_k(const FmHeadArgs p) {
+  if (blockIdx.x > 0) {
+    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - 1));
+    return;
+  }
+  __shared__ double red[4][5];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float c0 = p.c0[0], w0 = p.wo[0], w1 = p.wo[1], bo = p.bo[0];
+  double acc[5] = {0, 0, 0, 0, 0};                   // loss, dwo0, dwo1, dbo, dc0
+  for (int b = tid; b < p.B; b += 256) {
+    const float v0 = p.y1[b] + c0, v1 = p.y2[b], y = p.labels[b];
+    const float t0 = v0 > 0.f ? v0 : 0.f;
+    const float z = w0 * t0 + w1 * v1 + bo;
+    const float pr = 1.f / (1.f + expf(-z));
+    const float ce = fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+    const float dz = (pr - y) * p.loss_scale;
+    const float g0 = v0 > 0.f ? dz * w0 : 0.f;
+    p.prob[b] = pr;
+    p.gy1[b] = g0;
+    p.gy2[b] = dz * w1;
+    acc[0] += (double)ce;
+    acc[1] += (double)(dz * t0);
+    acc[2] += (double)(dz * v1);
+    acc[3] += (double)dz;
+    acc[4] += (double)g0;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) acc[k] += __shfl_xor(acc[k], m);
+    if (lane == 0) red[w][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < 5) {
+    const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid == 0) p.loss[0] = (float)(s / (double)p.B);
+    else if (tid <= 2) p.dwo[tid - 1] = (float)s;
+    else if (tid == 3) p.dbo[0] = (float)s;
+    else p.dc0[0] = (float)s;
+  }
+}
+
+extern "C" int rsx_fm_head(const float* y1, const float* y2, const float* c0, const float* wo, const float* bo,
+                           const float* labels, float* prob, float* gy1, float* gy2, float* dwo, float* dbo, float* dc0,
+                           float* loss, float loss_scale, int B, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  if (B <= 0) return B == 0 ? RSX_OK : RSX_EINVAL;
+  if (!y1 || !y2 || !c0 || !wo || !bo || !labels || !prob || !gy1 || !gy2 || !dwo || !dbo || !dc0 || !loss)
+    return RSX_EINVAL;
+  FmHeadArgs p{y1, y2, c0, wo, bo, labels, prob, gy1, gy2, dwo, dbo, dc0, loss, loss_scale, B, {}};
+  const int rcs = adam_build_slice(sweep_h, p.sweep);
+  if (rcs != RSX_OK) return rcs;
+  hipLaunchKernelGGL(fm_head_k, dim3(1 + p.sweep.n_blk), dim3(256), 0, rsx_s(stream), p);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
 // row blocks a dW tile's batch reduction is split into (1 without workspace or for small batches)
 static inline int rsx_tower_dw_blocks(int B, bool have_ws) {
   if (!have_ws || B < 1024) return 1;

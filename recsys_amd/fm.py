@@ -4,13 +4,16 @@
 logits = dense([relu(first_order), fm_second_order], 1).  The whole model is the fused embedding kernels
 (gather + first-order + FM forward, sorted segment-sum backward) plus a 2->1 dense head.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from . import layers as L
 from .deepfm import build_variables as _build
 from .deepfm import define_flags, input_fn, make_params, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
-from .ops import gather_fm
+from .ops import _ptr, _stream, gather_fm
 
 
 def model_fn(features, labels, mode, params):
@@ -21,6 +24,8 @@ def model_fn(features, labels, mode, params):
         _build(store, params, capacity=max(int(params.get("max_batch_size", 0)), ids.shape[0]), with_dnn=False)
     arena, P = store.embeddings["input_layer"], store.dense
     training = mode == ModeKeys.TRAIN
+    if training and store.dp is None and store.adam_mode == "tf1_dense" and params.get("fused", True):
+        return _train_fused(store, arena, ids, labels)
     if training:
         store.sort_ids_for_backward(arena, ids)
     _, y1p, y2 = gather_fm(arena, ids, fm=True, first_order=True, dp=store.dp if training else None)
@@ -34,6 +39,33 @@ def model_fn(features, labels, mode, params):
     if mode == ModeKeys.EVAL:
         return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
     return EstimatorSpec(mode, predictions=predictions, loss=loss, train_op=lambda: store.minimize(loss))
+
+
+def _train_fused(store, arena, ids, labels):
+    """TRAIN step as 4 launches, no autograd: dedup sort -> gather (+ first order + FM) -> FM head with its backward,
+    carrying the whole untouched-row Adam sweep as extra workgroups -> segment-sum fused with the touched-row and dense
+    Adam.  Same exact split of the TF-1 update as deepfm.py."""
+    P = store.dense
+    B = ids.shape[0]
+    dev = ids.device
+    with torch.no_grad():
+        arena.field_sort(ids)
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
+        cold, hot = arena.adam_split_segments()
+        sweep = store.opt.cold_slices(cold, [1.0])[0]
+        prob, gy1, gy2 = (torch.empty(B, device=dev) for _ in range(3))
+        loss = torch.empty(1, device=dev)
+        oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
+        _lib.check(_lib.lib().rsx_fm_head(_ptr(y1p), _ptr(y2), _ptr(P["b1"]), _ptr(oW), _ptr(P["out.b"]),
+                                          _ptr(labels.reshape(-1).to(torch.float32)), _ptr(prob), _ptr(gy1), _ptr(gy2),
+                                          _ptr(oG), _ptr(P["out.b"].grad), _ptr(P["b1"].grad), _ptr(loss), 1.0 / B, B,
+                                          None if sweep is None else C.byref(sweep), _stream()), "rsx_fm_head")
+
+    def train_op():
+        with torch.no_grad():
+            arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), None)
+
+    return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 
 
 def main(argv=None):
