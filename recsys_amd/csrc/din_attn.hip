@@ -231,14 +231,19 @@ struct AttnBwdArgs {
 template <int KB, int NT1, int NT2>
 struct AttnDims {
   static constexpr int K = 16 * KB, K4 = 4 * K, N1P = 16 * NT1, N2P = 16 * NT2, LD1 = N1P + 4, LD2 = N2P + 4, LDH = K + 4;
-  static constexpr int MT0 = K4 / 16;                        // row tiles of dW0
-  static constexpr int W0_PER = (MT0 + 3) / 4, W1_PER = (NT1 + 3) / 4;   // dW0 / dW1 row tiles per wave
+  static constexpr int MT0 = K4 / 16;                        // row tiles of dW0 (<= 8: one per wave)
 };
 
+// 512 threads = 8 waves per workgroup: wave = (half hf, row tile rt).  The two halves of a row tile split the OUTPUT
+// columns of every per-row stage (g1 columns, dx columns), the 8 waves split the weight-gradient tiles; per wave that is
+// ~170 registers, so two waves share a SIMD and one's VALU / LDS work overlaps the other's MFMAs (with 4 waves of 417
+// registers the kernel was instruction-issue bound: 13 non-MFMA instructions per MFMA, one wave per SIMD).
 template <int KB, int NT1, int NT2>
-__global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
+__global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
   using D = AttnDims<KB, NT1, NT2>;
-  constexpr int K = D::K, K4 = D::K4, N1P = D::N1P, N2P = D::N2P, LD1 = D::LD1, LD2 = D::LD2, LDH = D::LDH;
+  constexpr int K = D::K, K4 = D::K4, N1P = D::N1P, N2P = D::N2P, LD1 = D::LD1, LD2 = D::LD2;
+  constexpr int NH1 = (NT1 + 1) / 2;       // g1 column tiles per half
+  constexpr int CH = (KB + 1) / 2;         // dx column blocks (of each of the 4 segments) per half
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sW0 = lds;                        // [K4][LD1]   W0 row-major
   float* sW1 = sW0 + K4 * LD1;             // [N1P][LD2]  W1 row-major
@@ -251,85 +256,66 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
   float* sG2 = sA1 + N1P * LDR;            // [N2P][LDR]  g2^T
   float* sH = sG2 + N2P * LDR;             // [K][LDR]    h^T
   float* sQ = sH + K * LDR;                // [K][LDR]    q^T
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rt = wave & 3, hf = wave >> 2;
   const int i = lane & 15, kq = lane >> 4;
-  for (int e = tid; e < K4 * LD1; e += 256) {
+  const int nt0 = hf * NH1;                // this half's first g1 column tile
+  for (int e = tid; e < K4 * LD1; e += 512) {
     const int k = e / LD1, n = e - k * LD1;
     sW0[e] = n < p.N1 ? p.W0[(size_t)k * p.N1 + n] : 0.f;
   }
-  for (int e = tid; e < N1P * LD2; e += 256) {
+  for (int e = tid; e < N1P * LD2; e += 512) {
     const int k = e / LD2, n = e - k * LD2;
     sW1[e] = (k < p.N1 && n < p.N2) ? p.W1[(size_t)k * p.N2 + n] : 0.f;
   }
-  for (int e = tid; e < N2P; e += 256) sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
+  for (int e = tid; e < N2P; e += 512) sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
   const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
   const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
-  // weight-gradient accumulators, alive across all blocks of this workgroup
-  f32x4 accW0[D::W0_PER][NT1], accW1[D::W1_PER][NT2];
+  // weight-gradient accumulators, alive across all blocks: wave w owns row tile w of dW0 (w < 4*KB) and of dW1 (w < NT1)
+  f32x4 accW0[NT1], accW1[NT2];
 #pragma unroll
-  for (int a = 0; a < D::W0_PER; ++a)
+  for (int b = 0; b < NT1; ++b) accW0[b] = zf;
 #pragma unroll
-    for (int b = 0; b < NT1; ++b) accW0[a][b] = zf;
+  for (int b = 0; b < NT2; ++b) accW1[b] = zf;
+  float db0acc[NH1], db1acc[NT2][4], dw2acc[NT2][4], db2acc = 0.f;
 #pragma unroll
-  for (int a = 0; a < D::W1_PER; ++a)
-#pragma unroll
-    for (int b = 0; b < NT2; ++b) accW1[a][b] = zf;
-  float db0acc[NT1], db1acc[NT2][4], dw2acc[NT2][4], db2acc = 0.f;
-#pragma unroll
-  for (int a = 0; a < NT1; ++a) db0acc[a] = 0.f;
+  for (int a = 0; a < NH1; ++a) db0acc[a] = 0.f;
 #pragma unroll
   for (int a = 0; a < NT2; ++a)
 #pragma unroll
     for (int t = 0; t < 4; ++t) db1acc[a][t] = dw2acc[a][t] = 0.f;
   __syncthreads();
 
-  // Global operands of a block (dw, a2, h, q in the A layout; a1 in the C layout): loaded one block AHEAD, unconditionally
-  // on clamped addresses, so that their latency hides behind the previous block's MFMAs (one wave per SIMD here: nothing
-  // else would cover it) and no load sits in a branch of its own.
-  float dzN, a2N[NT2][4], a1N[NT1][4];
-  float4 hN[KB], qN[KB];
-  auto prefetch = [&](int blk) {
+  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
+    const int m = blk * 64 + 16 * rt + i;         // A-layout row
+    const bool mok = m < p.M;
+    const size_t mc = mok ? (size_t)m : 0;
+    // ---- S1/S2: g2 (A layout, registers; both halves), the h / q / g2 tiles of the block (half 0) -----------------
+    // global operands: unconditional on clamped addresses (no branch per load); with two waves per SIMD the other wave's
+    // MFMAs cover their latency, so nothing is prefetched across blocks (that cost 41 registers and spilled)
     const size_t last = (size_t)p.M - 1;
-    const size_t mA = (size_t)blk * 64 + 16 * wv + i;
-    const size_t mc = mA < last ? mA : last;
-    dzN = p.dw[mc];
+    const size_t mcl = (size_t)m < last ? (size_t)m : last;
+    const float dz = mok ? p.dw[mcl] : 0.f;
+    float a2N[NT2][4], a1N[NH1][4];
 #pragma unroll
     for (int kb = 0; kb < NT2; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int n = 16 * kb + 4 * kq + t;
-        a2N[kb][t] = p.a2[mc * p.N2 + (n < p.N2 ? n : p.N2 - 1)];
+        a2N[kb][t] = p.a2[mcl * p.N2 + (n < p.N2 ? n : p.N2 - 1)];
       }
 #pragma unroll
-    for (int c = 0; c < KB; ++c) {
-      hN[c] = *reinterpret_cast<const float4*>(p.H + mc * K + 16 * c + 4 * kq);
-      qN[c] = *reinterpret_cast<const float4*>(p.q + (mc / p.P) * K + 16 * c + 4 * kq);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) {
-      const int n = 16 * nt + i, nc = n < p.N1 ? n : p.N1 - 1;
+    for (int u = 0; u < NH1; ++u) {
+      const int n = 16 * (nt0 + u) + i, nc = n < p.N1 ? n : p.N1 - 1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const size_t mm = (size_t)blk * 64 + 16 * wv + 4 * kq + r;
-        a1N[nt][r] = p.a1[(mm < last ? mm : last) * p.N1 + nc];
+        const size_t mm = (size_t)blk * 64 + 16 * rt + 4 * kq + r;
+        a1N[u][r] = p.a1[(mm < last ? mm : last) * p.N1 + nc];
       }
     }
-  };
-  prefetch(blockIdx.x);
-  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
-    const int mb = blk * 64 + 16 * wv;            // first row of this wave's tile
-    const int m = mb + i;                         // A-layout row
-    const bool mok = m < p.M;
-    const size_t mc = mok ? (size_t)m : 0;
-    // ---- S1/S2: g2 (A layout, registers) + the h / q / g2 tiles of the block ------------------------------------
-    const float dz = mok ? dzN : 0.f;
-    float g2[NT2][4], a1raw[NT1][4];
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a1raw[nt][r] = a1N[nt][r];
+    float g2[NT2][4];
 #pragma unroll
     for (int kb = 0; kb < NT2; ++kb)
 #pragma unroll
@@ -338,144 +324,136 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
         const bool ok = mok && n < p.N2;
         const float av = a2N[kb][t] * (ok ? 1.f : 0.f);
         const float mul = d2.mode == 0 ? 1.f : (ok ? drop_mul(d2, p.mask2, mc * p.N2 + n) : 0.f);
-        dw2acc[kb][t] += av * mul * dz;
         const float gv = av > 0.f ? dz * sw2[n] * mul : 0.f;
-        db1acc[kb][t] += gv;
         g2[kb][t] = gv;
-        sG2[n * LDR + 16 * wv + i] = gv;
+        if (hf == 0) {
+          dw2acc[kb][t] += av * mul * dz;
+          db1acc[kb][t] += gv;
+          sG2[n * LDR + 16 * rt + i] = gv;
+        }
       }
-    if (kq == 0) db2acc += dz;
+    if (hf == 0) {
+      if (kq == 0) db2acc += dz;
 #pragma unroll
-    for (int c = 0; c < KB; ++c) {
-      const float4 hv = mok ? hN[c] : z4;
-      const float4 qv = mok ? qN[c] : z4;
-      const int cc = 16 * c + 4 * kq, rr = 16 * wv + i;
-      sH[(cc + 0) * LDR + rr] = hv.x; sH[(cc + 1) * LDR + rr] = hv.y; sH[(cc + 2) * LDR + rr] = hv.z; sH[(cc + 3) * LDR + rr] = hv.w;
-      sQ[(cc + 0) * LDR + rr] = qv.x; sQ[(cc + 1) * LDR + rr] = qv.y; sQ[(cc + 2) * LDR + rr] = qv.z; sQ[(cc + 3) * LDR + rr] = qv.w;
+      for (int c = 0; c < KB; ++c) {
+        const float4 hr = *reinterpret_cast<const float4*>(p.H + mcl * K + 16 * c + 4 * kq);
+        const float4 qr = *reinterpret_cast<const float4*>(p.q + (mcl / p.P) * K + 16 * c + 4 * kq);
+        const float4 hv = mok ? hr : z4;
+        const float4 qv = mok ? qr : z4;
+        const int cc = 16 * c + 4 * kq, rr = 16 * rt + i;
+        sH[(cc + 0) * LDR + rr] = hv.x; sH[(cc + 1) * LDR + rr] = hv.y; sH[(cc + 2) * LDR + rr] = hv.z; sH[(cc + 3) * LDR + rr] = hv.w;
+        sQ[(cc + 0) * LDR + rr] = qv.x; sQ[(cc + 1) * LDR + rr] = qv.y; sQ[(cc + 2) * LDR + rr] = qv.z; sQ[(cc + 3) * LDR + rr] = qv.w;
+      }
     }
-    {   // next block's operands: in flight during this block's MFMAs
-      const int nb = blk + (int)gridDim.x;
-      prefetch(nb < p.nblk ? nb : p.nblk - 1);
-    }
-    // ---- S3: dg1 = g2 . W1^T  (C layout: rows 4*kq + r, column n1 = 16*nt + i) ------------------------------------
-    f32x4 dg1[NT1];
+    // ---- S3: dg1 = g2 . W1^T for this half's column tiles (C layout: rows 4*kq + r, column n1 = 16*nt + i) ----------
+    f32x4 dg1[NH1];
 #pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) dg1[nt] = zf;
+    for (int u = 0; u < NH1; ++u) dg1[u] = zf;
 #pragma unroll
     for (int kb = 0; kb < NT2; ++kb)
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) {
-        const float4 b = *reinterpret_cast<const float4*>(sW1 + (16 * nt + i) * LD2 + 16 * kb + 4 * kq);
-        dg1[nt] = att_mfma(g2[kb][0], b.x, dg1[nt]);
-        dg1[nt] = att_mfma(g2[kb][1], b.y, dg1[nt]);
-        dg1[nt] = att_mfma(g2[kb][2], b.z, dg1[nt]);
-        dg1[nt] = att_mfma(g2[kb][3], b.w, dg1[nt]);
-      }
-    // ---- S4: g1 = dg1 * drop1 * (a1 > 0); tiles g1 / a1d ----------------------------------------------------------
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) {
-      const int n = 16 * nt + i;
-      float gq[4], aq[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * wv + 4 * kq + r;
-        const size_t mm = (size_t)blk * 64 + row;
-        const bool ok = mm < (size_t)p.M && n < p.N1;
-        const float av = a1raw[nt][r] * (ok ? 1.f : 0.f);
-        const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mm * p.N1 + n) : 0.f);
-        const float ad = av * mul;
-        const float gv = av > 0.f ? dg1[nt][r] * mul : 0.f;
-        db0acc[nt] += gv;
-        gq[r] = gv;
-        aq[r] = ad;
-      }
-      *reinterpret_cast<float4*>(sG1 + n * LDR + 16 * wv + 4 * kq) = make_float4(gq[0], gq[1], gq[2], gq[3]);
-      *reinterpret_cast<float4*>(sA1 + n * LDR + 16 * wv + 4 * kq) = make_float4(aq[0], aq[1], aq[2], aq[3]);
-    }
-    __syncthreads();
-    // ---- S5: dx = g1 . W0^T -> dH, per-row dq ---------------------------------------------------------------------
-    {
-      f32x4 dx[4 * KB];
-#pragma unroll
-      for (int jt = 0; jt < 4 * KB; ++jt) dx[jt] = zf;
-#pragma unroll
-      for (int kb = 0; kb < NT1; ++kb) {
-        const int nn = 16 * kb + 4 * kq, rr = 16 * wv + i;
-        const float4 a = make_float4(sG1[(nn + 0) * LDR + rr], sG1[(nn + 1) * LDR + rr], sG1[(nn + 2) * LDR + rr],
-                                     sG1[(nn + 3) * LDR + rr]);
-#pragma unroll
-        for (int jt = 0; jt < 4 * KB; ++jt) {
-          const float4 b = *reinterpret_cast<const float4*>(sW0 + (16 * jt + i) * LD1 + 16 * kb + 4 * kq);
-          dx[jt] = att_mfma(a.x, b.x, dx[jt]);
-          dx[jt] = att_mfma(a.y, b.y, dx[jt]);
-          dx[jt] = att_mfma(a.z, b.z, dx[jt]);
-          dx[jt] = att_mfma(a.w, b.w, dx[jt]);
+      for (int u = 0; u < NH1; ++u) {
+        if (nt0 + u < NT1) {                           // wave-uniform
+          const float4 b = *reinterpret_cast<const float4*>(sW1 + (16 * (nt0 + u) + i) * LD2 + 16 * kb + 4 * kq);
+          dg1[u] = att_mfma(g2[kb][0], b.x, dg1[u]);
+          dg1[u] = att_mfma(g2[kb][1], b.y, dg1[u]);
+          dg1[u] = att_mfma(g2[kb][2], b.z, dg1[u]);
+          dg1[u] = att_mfma(g2[kb][3], b.w, dg1[u]);
         }
       }
+    // ---- S4: g1 = dg1 * drop1 * (a1 > 0); tiles g1^T / a1d^T --------------------------------------------------------
 #pragma unroll
-      for (int c = 0; c < KB; ++c)
+    for (int u = 0; u < NH1; ++u) {
+      if (nt0 + u < NT1) {
+        const int n = 16 * (nt0 + u) + i;
+        float gq[4], aq[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * wv + 4 * kq + r, col = 16 * c + i;
+          const int row = 16 * rt + 4 * kq + r;
+          const size_t mm = (size_t)blk * 64 + row;
+          const bool ok = mm < (size_t)p.M && n < p.N1;
+          const float av = a1N[u][r] * (ok ? 1.f : 0.f);
+          const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mm * p.N1 + n) : 0.f);
+          const float gv = av > 0.f ? dg1[u][r] * mul : 0.f;
+          db0acc[u] += gv;
+          gq[r] = gv;
+          aq[r] = av * mul;
+        }
+        *reinterpret_cast<float4*>(sG1 + n * LDR + 16 * rt + 4 * kq) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        *reinterpret_cast<float4*>(sA1 + n * LDR + 16 * rt + 4 * kq) = make_float4(aq[0], aq[1], aq[2], aq[3]);
+      }
+    }
+    __syncthreads();
+    // ---- S5: dx = g1 . W0^T for this half's column blocks of the 4 segments -> dH, per-row dq ---------------------------
+#pragma unroll
+    for (int cu = 0; cu < CH; ++cu) {
+      const int c = hf * CH + cu;                      // wave-uniform
+      if (c < KB) {
+        f32x4 dx[4] = {zf, zf, zf, zf};
+#pragma unroll
+        for (int kb = 0; kb < NT1; ++kb) {
+          const int nn = 16 * kb + 4 * kq, rr = 16 * rt + i;
+          const float a0 = sG1[(nn + 0) * LDR + rr], a1_ = sG1[(nn + 1) * LDR + rr], a2_ = sG1[(nn + 2) * LDR + rr],
+                      a3 = sG1[(nn + 3) * LDR + rr];
+#pragma unroll
+          for (int sg = 0; sg < 4; ++sg) {
+            const float4 b = *reinterpret_cast<const float4*>(sW0 + (16 * (sg * KB + c) + i) * LD1 + 16 * kb + 4 * kq);
+            dx[sg] = att_mfma(a0, b.x, dx[sg]);
+            dx[sg] = att_mfma(a1_, b.y, dx[sg]);
+            dx[sg] = att_mfma(a2_, b.z, dx[sg]);
+            dx[sg] = att_mfma(a3, b.w, dx[sg]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rt + 4 * kq + r, col = 16 * c + i;
           const size_t mm = (size_t)blk * 64 + row;
           if (mm < (size_t)p.M) {
             const float hv = sH[col * LDR + row], qv = sQ[col * LDR + row];
-            const float xh = dx[c][r], xq = dx[KB + c][r], xp = dx[2 * KB + c][r], xd = dx[3 * KB + c][r];
-            p.dH[mm * K + col] = (xh + xp * qv) + xd;
-            p.dqr[mm * K + col] = (xq + xp * hv) - xd;
-          }
-        }
-    }
-    // ---- S6: weight gradients over the block's 64 rows (k-step (kb, t) <-> row 16*kb + 4*kq + t) --------------------
-#pragma unroll
-    for (int a = 0; a < D::W1_PER; ++a) {
-      const int mt = wv + 4 * a;                       // wave-uniform
-      if (mt < NT1) {
-        float4 av[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) av[kb] = *reinterpret_cast<const float4*>(sA1 + (16 * mt + i) * LDR + 16 * kb + 4 * kq);
-#pragma unroll
-        for (int jt = 0; jt < NT2; ++jt) {
-          float4 bv[4];
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) bv[kb] = *reinterpret_cast<const float4*>(sG2 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            accW1[a][jt] = att_mfma(av[kb].x, bv[kb].x, accW1[a][jt]);
-            accW1[a][jt] = att_mfma(av[kb].y, bv[kb].y, accW1[a][jt]);
-            accW1[a][jt] = att_mfma(av[kb].z, bv[kb].z, accW1[a][jt]);
-            accW1[a][jt] = att_mfma(av[kb].w, bv[kb].w, accW1[a][jt]);
+            p.dH[mm * K + col] = (dx[0][r] + dx[2][r] * qv) + dx[3][r];
+            p.dqr[mm * K + col] = (dx[1][r] + dx[2][r] * hv) - dx[3][r];
           }
         }
       }
     }
+    // ---- S6: weight gradients over the block's 64 rows (k-step (kb, t) <-> row 16*kb + 4*kq + t) --------------------
+    if (wave < NT1) {                                  // dW1 row tile `wave`
+      float4 av[4];
 #pragma unroll
-    for (int a = 0; a < D::W0_PER; ++a) {
-      const int mt = wv + 4 * a;                       // row tile of dW0: input features 16*mt .. (segment mt / KB)
-      if (mt < D::MT0) {
-        const int seg = mt / KB, col = 16 * (mt - seg * KB) + i;
-        float4 av[4];
+      for (int kb = 0; kb < 4; ++kb) av[kb] = *reinterpret_cast<const float4*>(sA1 + (16 * wave + i) * LDR + 16 * kb + 4 * kq);
+#pragma unroll
+      for (int jt = 0; jt < NT2; ++jt) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          const float4 hv = *reinterpret_cast<const float4*>(sH + col * LDR + 16 * kb + 4 * kq);
-          const float4 qv = *reinterpret_cast<const float4*>(sQ + col * LDR + 16 * kb + 4 * kq);
-          av[kb] = seg == 0 ? hv
-                   : seg == 1 ? qv
-                   : seg == 2 ? make_float4(hv.x * qv.x, hv.y * qv.y, hv.z * qv.z, hv.w * qv.w)
-                              : make_float4(hv.x - qv.x, hv.y - qv.y, hv.z - qv.z, hv.w - qv.w);
+          const float4 bv = *reinterpret_cast<const float4*>(sG2 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
+          accW1[jt] = att_mfma(av[kb].x, bv.x, accW1[jt]);
+          accW1[jt] = att_mfma(av[kb].y, bv.y, accW1[jt]);
+          accW1[jt] = att_mfma(av[kb].z, bv.z, accW1[jt]);
+          accW1[jt] = att_mfma(av[kb].w, bv.w, accW1[jt]);
         }
+      }
+    }
+    if (wave < D::MT0) {                               // dW0 row tile `wave`: input features 16*wave .. (segment wave / KB)
+      const int seg = wave / KB, col = 16 * (wave - seg * KB) + i;
+      float4 av[4];
 #pragma unroll
-        for (int jt = 0; jt < NT1; ++jt) {
-          float4 bv[4];
+      for (int kb = 0; kb < 4; ++kb) {
+        const float4 hv = *reinterpret_cast<const float4*>(sH + col * LDR + 16 * kb + 4 * kq);
+        const float4 qv = *reinterpret_cast<const float4*>(sQ + col * LDR + 16 * kb + 4 * kq);
+        av[kb] = seg == 0 ? hv
+                 : seg == 1 ? qv
+                 : seg == 2 ? make_float4(hv.x * qv.x, hv.y * qv.y, hv.z * qv.z, hv.w * qv.w)
+                            : make_float4(hv.x - qv.x, hv.y - qv.y, hv.z - qv.z, hv.w - qv.w);
+      }
 #pragma unroll
-          for (int kb = 0; kb < 4; ++kb) bv[kb] = *reinterpret_cast<const float4*>(sG1 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
+      for (int jt = 0; jt < NT1; ++jt) {
 #pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            accW0[a][jt] = att_mfma(av[kb].x, bv[kb].x, accW0[a][jt]);
-            accW0[a][jt] = att_mfma(av[kb].y, bv[kb].y, accW0[a][jt]);
-            accW0[a][jt] = att_mfma(av[kb].z, bv[kb].z, accW0[a][jt]);
-            accW0[a][jt] = att_mfma(av[kb].w, bv[kb].w, accW0[a][jt]);
-          }
+        for (int kb = 0; kb < 4; ++kb) {
+          const float4 bv = *reinterpret_cast<const float4*>(sG1 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
+          accW0[jt] = att_mfma(av[kb].x, bv.x, accW0[jt]);
+          accW0[jt] = att_mfma(av[kb].y, bv.y, accW0[jt]);
+          accW0[jt] = att_mfma(av[kb].z, bv.z, accW0[jt]);
+          accW0[jt] = att_mfma(av[kb].w, bv.w, accW0[jt]);
         }
       }
     }
@@ -490,72 +468,67 @@ __global__ __launch_bounds__(256) void din_attn_bwd_k(const AttnBwdArgs p) {
   float* o_db1 = o_dW1 + (size_t)p.N1 * p.N2;
   float* o_dW2 = o_db1 + p.N2;
   float* o_db2 = o_dW2 + p.N2;
+  if (wave < D::MT0) {
 #pragma unroll
-  for (int a = 0; a < D::W0_PER; ++a) {
-    const int mt = wv + 4 * a;
-    if (mt < D::MT0)
+    for (int jt = 0; jt < NT1; ++jt)
 #pragma unroll
-      for (int jt = 0; jt < NT1; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kin = 16 * mt + 4 * kq + r, n = 16 * jt + i;
-          if (n < p.N1) o_dW0[(size_t)kin * p.N1 + n] = accW0[a][jt][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int kin = 16 * wave + 4 * kq + r, n = 16 * jt + i;
+        if (n < p.N1) o_dW0[(size_t)kin * p.N1 + n] = accW0[jt][r];
+      }
   }
+  if (wave < NT1) {
 #pragma unroll
-  for (int a = 0; a < D::W1_PER; ++a) {
-    const int mt = wv + 4 * a;
-    if (mt < NT1)
+    for (int jt = 0; jt < NT2; ++jt)
 #pragma unroll
-      for (int jt = 0; jt < NT2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k1 = 16 * mt + 4 * kq + r, n = 16 * jt + i;
-          if (k1 < p.N1 && n < p.N2) o_dW1[(size_t)k1 * p.N2 + n] = accW1[a][jt][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int k1 = 16 * wave + 4 * kq + r, n = 16 * jt + i;
+        if (k1 < p.N1 && n < p.N2) o_dW1[(size_t)k1 * p.N2 + n] = accW1[jt][r];
+      }
   }
-  // bias-like sums: per-lane partials -> fixed-order sums over lanes and waves through LDS (tiles are idle now)
-  float* red = sG1;                                    // [4 waves][64 lanes][NT1 + 8*NT2 + 1]
-  constexpr int NR = NT1 + 8 * NT2 + 1;
+  // bias-like sums: per-lane partials -> fixed-order sums over lanes and waves through LDS (the tiles are idle now)
+  float* red = sG1;                                    // [8 waves][64 lanes][NR], spans the g1 / a1 / g2 tiles
+  constexpr int NR = NH1 + 8 * NT2 + 1;
+  static_assert(8 * 64 * NR <= 68 * (2 * N1P + N2P + 2 * K), "reduction scratch must fit the block tiles");
   {
-    float* r_ = red + (wv * 64 + lane) * NR;
+    float* r_ = red + (wave * 64 + lane) * NR;
 #pragma unroll
-    for (int a = 0; a < NT1; ++a) r_[a] = db0acc[a];
+    for (int a = 0; a < NH1; ++a) r_[a] = db0acc[a];
 #pragma unroll
     for (int a = 0; a < NT2; ++a)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        r_[NT1 + 4 * a + t] = db1acc[a][t];
-        r_[NT1 + 4 * NT2 + 4 * a + t] = dw2acc[a][t];
+        r_[NH1 + 4 * a + t] = db1acc[a][t];
+        r_[NH1 + 4 * NT2 + 4 * a + t] = dw2acc[a][t];
       }
-    r_[NT1 + 8 * NT2] = db2acc;
+    r_[NH1 + 8 * NT2] = db2acc;
   }
   __syncthreads();
-  // db0[n1 = 16*nt + i]: sum over waves and the 4 kq lanes of column i
-  for (int n = tid; n < p.N1; n += 256) {
-    const int nt = n >> 4, ii = n & 15;
-    float s = 0.f;
+  // db0[n1 = 16*nt + i]: nt belongs to half nt / NH1; sum over that half's 4 row-tile waves and the 4 kq lanes of column i
+  for (int n = tid; n < p.N1; n += 512) {
+    const int nt = n >> 4, ii = n & 15, h_ = nt / NH1, u = nt - h_ * NH1;
+    float s_ = 0.f;
     for (int w = 0; w < 4; ++w)
-      for (int k4 = 0; k4 < 4; ++k4) s += red[(w * 64 + 16 * k4 + ii) * NR + nt];
-    o_db0[n] = s;
+      for (int k4 = 0; k4 < 4; ++k4) s_ += red[((h_ * 4 + w) * 64 + 16 * k4 + ii) * NR + u];
+    o_db0[n] = s_;
   }
-  // db1 / dW2 [n2 = 16*kb + 4*kq + t]: sum over waves and the 16 row lanes i of group kq
-  for (int n = tid; n < p.N2; n += 256) {
+  // db1 / dW2 [n2 = 16*kb + 4*kq + t]: accumulated by half 0; sum over its 4 waves and the 16 row lanes of group kq
+  for (int n = tid; n < p.N2; n += 512) {
     const int kb = n >> 4, k4 = (n >> 2) & 3, t = n & 3;
     float s1 = 0.f, s2 = 0.f;
     for (int w = 0; w < 4; ++w)
       for (int ii = 0; ii < 16; ++ii) {
-        s1 += red[(w * 64 + 16 * k4 + ii) * NR + NT1 + 4 * kb + t];
-        s2 += red[(w * 64 + 16 * k4 + ii) * NR + NT1 + 4 * NT2 + 4 * kb + t];
+        s1 += red[(w * 64 + 16 * k4 + ii) * NR + NH1 + 4 * kb + t];
+        s2 += red[(w * 64 + 16 * k4 + ii) * NR + NH1 + 4 * NT2 + 4 * kb + t];
       }
     o_db1[n] = s1;
     o_dW2[n] = s2;
   }
   if (tid == 0) {
-    float s = 0.f;
+    float s_ = 0.f;
     for (int w = 0; w < 4; ++w)
-      for (int ii = 0; ii < 16; ++ii) s += red[(w * 64 + ii) * NR + NT1 + 8 * NT2];
-    o_db2[0] = s;
+      for (int ii = 0; ii < 16; ++ii) s_ += red[(w * 64 + ii) * NR + NH1 + 8 * NT2];
+    o_db2[0] = s_;
   }
 }
 
@@ -633,7 +606,7 @@ static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_k<KB, NT1, NT2>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess || fl * sizeof(float) > 160 * 1024) return RSX_EUNSUPPORTED;
-  hipLaunchKernelGGL((din_attn_bwd_k<KB, NT1, NT2>), dim3(G), dim3(256), fl * sizeof(float), st, p);
+  hipLaunchKernelGGL((din_attn_bwd_k<KB, NT1, NT2>), dim3(G), dim3(512), fl * sizeof(float), st, p);
   return RSX_OK;
 }
 
