@@ -202,8 +202,10 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
                          int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                         const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state, float lr,
-                         float beta1, float beta2, float eps, rsx_stream_t stream);
+                         const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state,
+                         int advance_step, float lr, float beta1, float beta2, float eps, rsx_stream_t stream);
+/* advance_step = 0: this launch leaves the beta powers / step counter alone because a later launch of the SAME step advances
+ * them (models with two table sets: xdeepfm.py); 1 otherwise.                                                      */
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -60,7 +60,7 @@ _SIGS = {
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
-    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _F, _F, _F, _F, _P]),
+    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),

@@ -550,6 +550,8 @@ struct HotAdam {
   float lr, b1, b2, eps;
   float* state;
   uint32_t n_own, total_blocks;
+  int advance;                           // the last workgroup advances the beta powers / step counter (0: a later launch of the
+                                         // same step does -- e.g. the first of xDeepFM's two table sets)
   AdamSlice extra;                       // dense variables (any non-COLD kinds), n_blk may be 0
   AdamSlice cold;                        // optional slice of the untouched-row sweep (rows disjoint from the touched ones)
 };
@@ -595,10 +597,12 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     uint32_t* ticket = reinterpret_cast<uint32_t*>(h.state + 2);
     const uint32_t t = atomicAdd(ticket, 1u);
     if (t == h.total_blocks - 1u) {
-      h.state[0] = b1p * h.b1;
-      h.state[1] = b2p * h.b2;
       *ticket = 0u;
-      reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
+      if (h.advance) {
+        h.state[0] = b1p * h.b1;
+        h.state[1] = b2p * h.b2;
+        reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
+      }
     }
   }
 }
@@ -780,7 +784,7 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
                                     const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
                                     const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state,
-                                    float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
+                                    int advance_step, float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
@@ -795,7 +799,7 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   if (rcb != RSX_OK) return rcb;
   HotAdam h;
   h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
-  h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state;
+  h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state; h.advance = advance_step != 0;
   h.extra.n_blk = 0; h.extra.blk_lo = 0;
   if (n_extra > 0) {
     uint32_t blocks = 0;

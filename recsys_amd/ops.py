@@ -158,7 +158,7 @@ class EmbeddingArena:
                                    _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
                                    self.stride, part, blk, _stream()), "rsx_segsum_bwd")
 
-    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None):
+    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups)."""
         blk = self._blocks(blocks)
         arr, n = opt._seg_array(extra_segments)
@@ -170,7 +170,7 @@ class EmbeddingArena:
                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
                                          None if sweep is None else C.byref(sweep), part, blk,
-                                         _ptr(opt.state), lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
+                                         _ptr(opt.state), 1 if advance else 0, lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
 
     # -- optimizer segments ----------------------------------------------------------------
     def adam_split_segments(self):

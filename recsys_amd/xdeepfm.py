@@ -124,12 +124,15 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 a1.segsum(dg.shape[0], None, dg[:, :w].contiguous(), g1, None)
                 a2.segsum(dg.shape[0], None, dg[:, w:].contiguous(), None, None)
                 dp.all_reduce_sum(store.dense.grad)
+                store.apply_gradients()
+            elif hot is not None:
+                # scatter + touched-row Adam per table set; the second launch also carries the dense variables and advances
+                # the beta powers for the step
+                a1.segsum_adam(B, None, dX1.contiguous(), g_lin, None, store.opt, [], None, advance=False)
+                a2.segsum_adam(B, None, dX2, None, None, store.opt, store.dense.adam_segments(), None)
             else:
                 a1.segsum(B, None, dX1.contiguous(), g_lin, None)
                 a2.segsum(B, None, dX2, None, None)
-            if hot is not None:
-                store.opt.step(hot + store.dense.adam_segments())            # touched rows + dense; advances the powers
-            else:
                 store.apply_gradients()
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
