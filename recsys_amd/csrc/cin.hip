@@ -159,21 +159,25 @@ struct CinBwdDxArgs {
   float* dpre;        // [B, N, 16] out: dout with the relu mask applied, consumed by cin_bwd_dw_k
   int acc_dxk, acc_dx0;
   int B, F, H, N;
+  int HT;             // 16-wide h tiles; the block holds HT * FS waves, FS = 2 when HT <= 4: the two halves of a tile's
+                      // fields (f even / odd) run on separate waves so that a short H still fills the SIMDs
 };
 
-// grid = ceil(B/2), block = 64 * ceil(H/16) (one wave per 16-wide h tile, <= 8 waves).
+// grid = ceil(B/BT), block = 64 * HT * FS (<= 8 waves).
 // dyn LDS: 2*(N + F + H)*16 + HT*2*F*16 floats.  The A operand dpre[b][n][d] does not depend on f: after staging it
 // through LDS (the relu mask is applied once) each lane keeps its 4*NSMAX values per example in registers
 // (NSMAX = 8 covers N <= 128), so the f loop is "4 float4 W loads in flight -> 32 MFMAs".
 template <int NSMAX>
 __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int HT = blockDim.x >> 6;
+  const int HT = p.HT, FS = (int)(blockDim.x >> 6) / HT;
   float* sDp = lds;                                  // [BT][N*16] dpre
   float* sX0 = sDp + CIN_BT * p.N * CIN_D;           // [BT][F*16]
   float* sXk = sX0 + CIN_BT * p.F * CIN_D;           // [BT][H*16]
   float* sP = sXk + CIN_BT * p.H * CIN_D;            // [HT][BT][F*16] dX0 partials
-  const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6;
+  float* sDx = sP + HT * CIN_BT * p.F * CIN_D;       // [HT][BT][64*4] dXk of the odd-field waves
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ht = wave % HT, part = wave / HT;
   const int b0 = blockIdx.x * CIN_BT;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int bt = 0; bt < CIN_BT; ++bt) {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
       }
   }
   const bool vec_ok = (p.N & 3) == 0;
-  for (int f = 0; f < p.F; ++f) {
+  for (int f = part; f < p.F; f += FS) {
     f32x4 U[CIN_BT];
 #pragma unroll
     for (int bt = 0; bt < CIN_BT; ++bt) U[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -277,19 +281,25 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
       if (i == 0) *reinterpret_cast<float4*>(sP + ((ht * CIN_BT + bt) * p.F + f) * CIN_D + kq * 4) = make_float4(q0, q1, q2, q3);
     }
   }
-  if (hok) {
+  if (part == 1) {
+#pragma unroll
+    for (int bt = 0; bt < CIN_BT; ++bt)
+      *reinterpret_cast<float4*>(sDx + ((ht * CIN_BT + bt) * 64 + lane) * 4) = make_float4(dxk[bt][0], dxk[bt][1], dxk[bt][2], dxk[bt][3]);
+  }
+  __syncthreads();
+  if (hok && part == 0) {
 #pragma unroll
     for (int bt = 0; bt < CIN_BT; ++bt) {
       const int b = b0 + bt;
       if (b < p.B) {
         float4* dst = reinterpret_cast<float4*>(p.dXk + ((size_t)b * p.H + h) * CIN_D + kq * 4);
         float4 o = make_float4(dxk[bt][0], dxk[bt][1], dxk[bt][2], dxk[bt][3]);
+        if (FS == 2) o = f4_add(o, *reinterpret_cast<const float4*>(sDx + ((ht * CIN_BT + bt) * 64 + lane) * 4));
         if (p.acc_dxk) o = f4_add(*dst, o);
         *dst = o;
       }
     }
   }
-  __syncthreads();
   for (int e = tid; e < CIN_BT * p.F * 4; e += blockDim.x) {   // sum the HT partials in wave order
     const int bt = e / (p.F * 4), r = e - bt * p.F * 4;
     const int b = b0 + bt;
@@ -445,7 +455,8 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc || !dpre_ws) return RSX_EINVAL;
   if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
-  const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D) * sizeof(float);
+  const int FS = HT <= 4 ? 2 : 1;
+  const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D + (size_t)HT * CIN_BT * 256) * sizeof(float);
   if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
   if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -454,9 +465,9 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
                             (int)lds) != hipSuccess)
       return RSX_ELAUNCH;
   }
-  CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N};
-  if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
-  else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT), lds, rsx_s(stream), a);
+  CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N, HT};
+  if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
+  else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   CinBwdDwArgs w{X0, Xk, dpre_ws, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT, {}};
   const int rcs = adam_build_slice(sweep_h, w.sweep);
