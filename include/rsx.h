@@ -337,13 +337,27 @@ int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_o
 int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const float* c, float* out, int B, int F,
                       int H, int N, int D, rsx_stream_t stream);
 /* dout = gradient wrt `out` (the relu mask is taken from `out`).  Writes dW[F*H,N], dc[N]; dXk[B,H,D] and dX0[B,F,D]
- * are overwritten or accumulated (acc_* != 0).  When Xk aliases X0 (first layer) pass distinct dXk / dX0 buffers.   */
-int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout, float* dXk,
-                      int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, float* dpre_ws, int B, int F, int H,
-                      int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+ * are overwritten or accumulated (acc_* != 0).  When Xk aliases X0 (first layer) pass either distinct dXk / dX0 buffers
+ * or ONE buffer for both with acc_dx0 != 0 (the two gradient roles of X0 are then added in place).
+ * gs / wout (nullable pair): the layer's direct connection into the 'cin_net' head (xdeepfm.py:175-182) --
+ * gs[b] * wout[n], broadcast over d, is added to dout (dout itself may then be NULL: last layer).                    */
+int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout,
+                      const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW,
+                      float* dc, float* dpre_ws, int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h,
+                      rsx_stream_t stream);
 /* dpre_ws: B*N*D floats of scratch (the relu-masked dout, written by the dX launch and read by the dW launch).       */
 /* sweep_h (nullable): a slice of the untouched-row optimizer sweep carried by extra workgroups of the dW launch (the
  * MFMA-bound tiles leave HBM idle), as on the tower entry points.                                                  */
+/* 'cin_net' output head, xdeepfm/xdeepfm.py:180-182 (concat of the L layer maps on axis 1, reduce_sum over d, dense(1, relu)):
+ *   y[b] = relu(bout + sum_k sum_n Wout[off_k + n] * sum_d out_k[b,n,d]),  off_k = n_0 + .. + n_{k-1}
+ * outs_h: HOST array of L device pointers [B, n_k, 16]; sizes_h: HOST array of the n_k.  L <= 8.  The concat is never
+ * materialised.                                                                                                     */
+int rsx_cin_out_fwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* Wout, const float* bout,
+                    float* y, int B, int D, rsx_stream_t stream);
+/* Backward of the head: gs[b] = gy[b] * (y[b] > 0) (consumed by rsx_cin_layer_bwd), dWout[off_k + n] =
+ * sum_b gs[b] * sum_d out_k[b,n,d], dbout = sum_b gs[b]; fixed summation order.                                      */
+int rsx_cin_out_bwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy, float* gs,
+                    float* dWout, float* dbout, int B, int D, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.

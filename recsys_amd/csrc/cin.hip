@@ -153,7 +153,9 @@ struct CinBwdDxArgs {
   const float* Xk;    // [B, H, 16]
   const float* W;     // [F*H, N]
   const float* out;   // [B, N, 16] this layer's relu output
-  const float* dout;  // [B, N, 16] gradient wrt the relu output
+  const float* dout;  // [B, N, 16] gradient wrt the relu output (nullable when gs is given)
+  const float* gs;    // [B]  nullable: the direct-connect gradient gs[b] * wout[n], broadcast over d, is added to dout
+  const float* wout;  // [N]
   float* dXk;         // [B, H, 16]
   float* dX0;         // [B, F, 16]
   float* dpre;        // [B, N, 16] out: dout with the relu mask applied, consumed by cin_bwd_dw_k
@@ -186,7 +188,11 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
       float4 v = z4;
       if (b < p.B) {
         const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)b * p.N * CIN_D)[e];
-        const float4 g = reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CIN_D)[e];
+        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CIN_D)[e] : z4;
+        if (p.gs) {
+          const float a = p.gs[b] * p.wout[e >> 2];
+          g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
+        }
         v = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
         reinterpret_cast<float4*>(p.dpre + (size_t)b * p.N * CIN_D)[e] = v;
       }
@@ -300,6 +306,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
       }
     }
   }
+  if (p.dXk == p.dX0) __syncthreads();   // first layer, one gradient buffer for both roles of X0: dXk lands before dX0 adds
   for (int e = tid; e < CIN_BT * p.F * 4; e += blockDim.x) {   // sum the HT partials in wave order
     const int bt = e / (p.F * 4), r = e - bt * p.F * 4;
     const int b = b0 + bt;
@@ -448,11 +455,13 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
 }
 
 extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout,
-                                 float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, float* dpre_ws,
+                                 const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, float* dpre_ws,
                                  int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  if (!X0 || !Xk || !W || !out || !dout || !dXk || !dX0 || !dW || !dc || !dpre_ws) return RSX_EINVAL;
+  if (!X0 || !Xk || !W || !out || !dXk || !dX0 || !dW || !dc || !dpre_ws) return RSX_EINVAL;
+  if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
+  if (dXk == dX0 && !(Xk == X0 && acc_dx0)) return RSX_EINVAL;   // one buffer only for the first layer, accumulating
   if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
   const int FS = HT <= 4 ? 2 : 1;
@@ -465,7 +474,7 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
                             (int)lds) != hipSuccess)
       return RSX_ELAUNCH;
   }
-  CinBwdDxArgs a{X0, Xk, W, out, dout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N, HT};
+  CinBwdDxArgs a{X0, Xk, W, out, dout, gs, wout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N, HT};
   if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
@@ -475,6 +484,126 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   const unsigned plane = (unsigned)((N + 15) / 16) * (unsigned)HT;
   const unsigned zs = (w.sweep.n_blk + plane - 1) / plane;           // extra z-planes that carry the sweep
   hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG + zs), dim3(256), 0, rsx_s(stream), w);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- 'cin_net' output head
+// xdeepfm/xdeepfm.py:180-182: result = reduce_sum(concat(final_result, 1), -1); cin_y = dense(result, 1, relu).
+// The concat and the [B, sum N] reduce_sum are never materialised: forward and backward read the layer maps in place.
+constexpr int CIN_MAXL = 8;
+struct CinOutArgs {
+  const float* out[CIN_MAXL];   // [B, n_k, 16] each
+  int n[CIN_MAXL], off[CIN_MAXL];
+  int L, B, tot;
+  const float* Wout;   // [tot]
+  const float* bout;   // [1]
+  float* y;            // [B]
+  const float* gy;     // [B]       (backward)
+  float* gs;           // [B]  out: gy * relu'(y)
+  float* dWout;        // [tot]
+  float* dbout;        // [1]
+};
+
+// one wave per example: lane e walks the float4 of each map, fixed-order butterfly at the end
+__global__ __launch_bounds__(256) void cin_out_fwd_k(const CinOutArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= p.B) return;
+  float s = 0.f;
+  for (int k = 0; k < p.L; ++k) {
+    const float4* src = reinterpret_cast<const float4*>(p.out[k] + (size_t)b * p.n[k] * CIN_D);
+    const float* w = p.Wout + p.off[k];
+    for (int e = lane; e < p.n[k] * 4; e += 64) {
+      const float4 v = src[e];
+      s += w[e >> 2] * ((v.x + v.y) + (v.z + v.w));
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+  if (lane == 0) p.y[b] = fmaxf(s + p.bout[0], 0.f);
+}
+
+// grid = ceil(tot/16) + 1, block = 1024: workgroup j owns 16 columns of the concatenated map (a layer's width is a
+// multiple of 16 or the tile is clipped to its layer); wave w takes examples w, w+16, ...; partials added in wave order.
+// The last workgroup writes gs and dbout.
+__global__ __launch_bounds__(1024) void cin_out_bwd_k(const CinOutArgs p) {
+  __shared__ float red[16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (blockIdx.x == gridDim.x - 1) {
+    float s = 0.f;
+    for (int b = tid; b < p.B; b += 1024) {
+      const float g = p.y[b] > 0.f ? p.gy[b] : 0.f;
+      p.gs[b] = g;
+    }
+    // dbout: one wave, fixed order
+    if (wv == 0) {
+      for (int b = lane; b < p.B; b += 64) s += p.y[b] > 0.f ? p.gy[b] : 0.f;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+      if (lane == 0) p.dbout[0] = s;
+    }
+    return;
+  }
+  // tile -> (layer k, first column n0): tiles are counted per layer
+  int k = 0, t = blockIdx.x;
+  while (k < p.L - 1 && t >= (p.n[k] + 15) / 16) { t -= (p.n[k] + 15) / 16; ++k; }
+  const int n0 = t * 16, nl = lane >> 2, dq = lane & 3;
+  const int n = n0 + nl;
+  const bool ok = n < p.n[k];
+  const float* src = p.out[k] + ((size_t)(ok ? n : 0)) * CIN_D + dq * 4;
+  float s = 0.f;
+  for (int b = wv; b < p.B; b += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)b * p.n[k] * CIN_D);
+    const float g = p.y[b] > 0.f ? p.gy[b] : 0.f;
+    s += g * ((v.x + v.y) + (v.z + v.w));
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  red[wv][lane] = s;
+  __syncthreads();
+  if (tid < 16) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a += red[w][tid * 4];
+    if (n0 + tid < p.n[k]) p.dWout[p.off[k] + n0 + tid] = a;
+  }
+}
+
+static int cin_out_args(CinOutArgs& a, const float* const* outs_h, const int32_t* sizes_h, int L, int B, int D) {
+  if (!outs_h || !sizes_h || L <= 0 || B < 0) return RSX_EINVAL;
+  if (L > CIN_MAXL || D != CIN_D) return RSX_EUNSUPPORTED;
+  a.L = L; a.B = B; a.tot = 0;
+  for (int k = 0; k < L; ++k) {
+    if (!outs_h[k] || sizes_h[k] <= 0) return RSX_EINVAL;
+    a.out[k] = outs_h[k]; a.n[k] = sizes_h[k]; a.off[k] = a.tot; a.tot += sizes_h[k];
+  }
+  return RSX_OK;
+}
+
+extern "C" int rsx_cin_out_fwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* Wout,
+                               const float* bout, float* y, int B, int D, rsx_stream_t stream) {
+  CinOutArgs a{};
+  const int rc = cin_out_args(a, outs_h, sizes_h, L, B, D);
+  if (rc != RSX_OK) return rc;
+  if (B == 0) return RSX_OK;
+  if (!Wout || !bout || !y) return RSX_EINVAL;
+  a.Wout = Wout; a.bout = bout; a.y = y;
+  hipLaunchKernelGGL(cin_out_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), a);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_cin_out_bwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy,
+                               float* gs, float* dWout, float* dbout, int B, int D, rsx_stream_t stream) {
+  CinOutArgs a{};
+  const int rc = cin_out_args(a, outs_h, sizes_h, L, B, D);
+  if (rc != RSX_OK) return rc;
+  if (!y || !gy || !gs || !dWout || !dbout) return RSX_EINVAL;
+  a.y = const_cast<float*>(y); a.gy = gy; a.gs = gs; a.dWout = dWout; a.dbout = dbout;
+  int tiles = 0;
+  for (int k = 0; k < L; ++k) tiles += (sizes_h[k] + 15) / 16;
+  hipLaunchKernelGGL(cin_out_bwd_k, dim3(tiles + 1), dim3(1024), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -710,7 +710,59 @@ class CinLayerFn(torch.autograd.Function):
         dX0, dXk = torch.empty_like(X0), torch.empty_like(Xk)
         dW, dc = torch.empty_like(W), torch.empty(N, device=W.device)
         ws = torch.empty_like(out)
-        check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(out), _ptr(g.contiguous()), _ptr(dXk), 0, _ptr(dX0),
+        check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(out), _ptr(g.contiguous()), None, None, _ptr(dXk), 0, _ptr(dX0),
                                       0, _ptr(dW), _ptr(dc), _ptr(ws), B, F, H, N, D,
                                       None if ctx.sweep is None else C.byref(ctx.sweep), _stream()), "rsx_cin_layer_bwd")
         return dX0, dXk, dW, dc, None
+
+
+class CinNet:
+    """'cin_net' of the training step (xdeepfm/xdeepfm.py:135-182) without autograd or glue kernels: L rsx_cin_layer_fwd +
+    rsx_cin_out_fwd forward; rsx_cin_out_bwd + L rsx_cin_layer_bwd backward.  The concat / reduce_sum / dense head and the
+    broadcast of its gradient back into every layer map happen inside those kernels; the gradients of X^0 from all layers
+    (and from its second role as X^k of layer 0) accumulate in one buffer; weight gradients land in the dense arena."""
+
+    def __init__(self, F, D, sizes, capacity, device="cuda"):
+        dev = _require_cuda(device)
+        self.F, self.D, self.sizes, self.L = F, D, [int(n) for n in sizes], len(sizes)
+        self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
+        self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
+        self.dpre = torch.empty(capacity, max(self.sizes), D, device=dev)
+        self.dX0 = torch.empty(capacity, F, D, device=dev)
+        self.y, self.gs = torch.empty(capacity, device=dev), torch.empty(capacity, device=dev)
+        self._sizes_h = (C.c_int32 * self.L)(*self.sizes)
+        self._outs_h = (C.c_void_p * self.L)(*[o.data_ptr() for o in self.outs])
+        self.offs = [sum(self.sizes[:k]) for k in range(self.L)]
+
+    def forward(self, X0, P):
+        """X0 [B,F,D] contiguous -> cin_y [B] (view of an internal buffer)."""
+        B = X0.shape[0]
+        Xk, H = X0, self.F
+        for k, n in enumerate(self.sizes):
+            check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]), B,
+                                          self.F, H, n, self.D, _stream()), "rsx_cin_layer_fwd")
+            Xk, H = self.outs[k], n
+        check(lib().rsx_cin_out_fwd(self._outs_h, self._sizes_h, self.L, _ptr(P["cin.Wout"]), _ptr(P["cin.bout"]), _ptr(self.y),
+                                    B, self.D, _stream()), "rsx_cin_out_fwd")
+        return self.y[:B]
+
+    def backward(self, X0, P, gy, sweeps=None):
+        """gy [B]: gradient wrt cin_y.  Writes the cin.* gradients into P[...].grad and returns dX0 [B,F,D] (internal
+        buffer).  sweeps[k]: slice of the untouched-row optimizer sweep carried by layer k's weight-gradient launch."""
+        B, L = X0.shape[0], self.L
+        check(lib().rsx_cin_out_bwd(self._outs_h, self._sizes_h, L, _ptr(self.y), _ptr(gy), _ptr(self.gs), _ptr(P["cin.Wout"].grad),
+                                    _ptr(P["cin.bout"].grad), B, self.D, _stream()), "rsx_cin_out_bwd")
+        wout = P["cin.Wout"].data_ptr()
+        for k in range(L - 1, -1, -1):
+            Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])
+            dout = None if k == L - 1 else _ptr(self.dmap[k])
+            if k == 0:   # X0 in both roles: one buffer, accumulating
+                dxk, acc_dxk, acc_dx0 = self.dX0, 1 if L > 1 else 0, 1
+            else:
+                dxk, acc_dxk, acc_dx0 = self.dmap[k - 1], 0, 0 if k == L - 1 else 1
+            sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
+            check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(self.outs[k]), dout, _ptr(self.gs),
+                                          C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(self.dX0), acc_dx0,
+                                          _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
+                                          self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
+        return self.dX0[:B]

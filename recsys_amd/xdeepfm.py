@@ -13,7 +13,7 @@ from .deepfm import define_flags as _deepfm_flags
 from .deepfm import input_fn, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
 from .feature_columns import CriteoLayout, build_feature_columns
-from .ops import CinLayerFn, EmbeddingArena, FusedTower
+from .ops import CinLayerFn, CinNet, EmbeddingArena, FusedTower
 
 
 def build_variables(store, params, capacity):
@@ -68,6 +68,7 @@ def build_variables(store, params, capacity):
     store.layout = layout
     store.cin_sizes = cin
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
+    store.cin = CinNet(F, D, cin, capacity, store.device)
     store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
 
@@ -102,16 +103,13 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
         lin_pre = torch.addmv(y1cat, logx, P["lin.wnum"])                   # + 13 numeric log-values (:127)
         E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
-    X0 = E1.view(B, a1.F, a1.D).requires_grad_()
-    cin_y = _cin(X0, P, store.cin_sizes, sweeps)
-    with torch.no_grad():
+        X0 = E1.view(B, a1.F, a1.D)
+        cin_y = store.cin.forward(X0, P)                                    # 'cin_net' (:135-182), csrc/cin.hip
         loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
-            s0=lin_pre, c0="lin.b", s1=cin_y.detach().reshape(-1), replicas=dp.world if dp is not None else 1, masks=masks)
-    cin_y.backward(g_cin.reshape(B, 1))                                     # CIN backward -> X0.grad, cin.* grads
-    with torch.no_grad():
+            s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks)
+        dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), sweeps).view(B, -1)   # cin.* grads land in the dense arena
         P["lin.wnum"].grad.copy_(logx.t() @ g_lin)
-    dX1 = X0.grad.reshape(B, -1)
 
     def train_op():
         with torch.no_grad():
@@ -128,10 +126,10 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             elif hot is not None:
                 # scatter + touched-row Adam per table set; the second launch also carries the dense variables and advances
                 # the beta powers for the step
-                a1.segsum_adam(B, None, dX1.contiguous(), g_lin, None, store.opt, [], None, advance=False)
+                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, [], None, advance=False)
                 a2.segsum_adam(B, None, dX2, None, None, store.opt, store.dense.adam_segments(), None)
             else:
-                a1.segsum(B, None, dX1.contiguous(), g_lin, None)
+                a1.segsum(B, None, dX1, g_lin, None)
                 a2.segsum(B, None, dX2, None, None)
                 store.apply_gradients()
 

@@ -141,3 +141,50 @@ def test_xdeepfm_train_parity_config3():
 def test_xdeepfm_hip_graph():
     err, losses, perr = _xdeepfm_run(B=32, steps=5, seed=23, cin=(16, 16), layers=(32, 16), dropout=0.0, use_graph=True)
     assert err < 1e-5 and max(perr.values()) < 5e-5, (err, perr)
+
+
+@pytest.mark.parametrize("B,F,sizes", [(7, 39, (128, 128)), (5, 6, (20, 10, 10)), (3, 9, (33,)), (64, 39, (40, 8))])
+def test_cin_net_fused_head(B, F, sizes):
+    """CinNet (layers + the concat / reduce_sum / dense(relu) head, xdeepfm.py:135-182) against the fp64 oracle chain."""
+    from recsys_amd.ops import CinNet, DenseArena
+    rng = np.random.default_rng(B + 10 * len(sizes))
+    D = 16
+    shapes, H = {}, F
+    for k, n in enumerate(sizes):
+        shapes[f"cin.W{k}"], shapes[f"cin.c{k}"] = (F * H, n), (n,)
+        H = n
+    shapes["cin.Wout"], shapes["cin.bout"] = (sum(sizes), 1), (1,)
+    P = DenseArena(shapes)
+    vals = {k: (rng.standard_normal(s) * (0.3 if k == "cin.Wout" else 0.1)).astype(np.float32) for k, s in shapes.items()}
+    vals["cin.bout"] = np.asarray([0.2], np.float32)
+    P.load(vals)
+    X0 = (rng.standard_normal((B, F, D)) * 0.4).astype(np.float32)
+    gy = rng.standard_normal(B).astype(np.float32)
+    V = {k: v.astype(np.float64) for k, v in vals.items()}
+    X64, Xs = X0.astype(np.float64), []
+    Xs.append(X64)
+    for k in range(len(sizes)):
+        Xs.append(models.cin_layer_fwd(X64, Xs[-1], V[f"cin.W{k}"], V[f"cin.c{k}"]))
+    res = np.concatenate(Xs[1:], 1).sum(-1)
+    y_o = nn.dense_fwd(res, V["cin.Wout"], V["cin.bout"], relu=True)
+    dres, dWout_o, dbout_o = nn.dense_bwd(res, V["cin.Wout"], y_o, gy.astype(np.float64)[:, None], relu=True)
+    g_o, dX0_o, off, dnext = {}, np.zeros_like(X64), np.cumsum((0,) + tuple(sizes)), None
+    for k in range(len(sizes) - 1, -1, -1):
+        dout = np.repeat(dres[:, off[k]:off[k + 1], None], D, 2)
+        if dnext is not None:
+            dout = dout + dnext
+        d0, dnext, g_o[f"cin.W{k}"], g_o[f"cin.c{k}"] = models.cin_layer_bwd(X64, Xs[k], V[f"cin.W{k}"], Xs[k + 1], dout)
+        dX0_o += d0
+    dX0_o += dnext
+    net = CinNet(F, D, sizes, B + 3)
+    tx = torch.from_numpy(X0).cuda()
+    y = net.forward(tx, P)
+    np.testing.assert_allclose(y.cpu().numpy(), y_o.reshape(-1), rtol=2e-5, atol=2e-5)
+    dX0 = net.backward(tx, P, torch.from_numpy(gy).cuda())
+    tol = dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dX0.cpu().numpy(), dX0_o, **tol)
+    np.testing.assert_allclose(P["cin.Wout"].grad.cpu().numpy(), dWout_o, **tol)
+    np.testing.assert_allclose(P["cin.bout"].grad.cpu().numpy(), dbout_o.reshape(1), **tol)
+    for k in range(len(sizes)):
+        np.testing.assert_allclose(P[f"cin.W{k}"].grad.cpu().numpy(), g_o[f"cin.W{k}"], **tol)
+        np.testing.assert_allclose(P[f"cin.c{k}"].grad.cpu().numpy(), g_o[f"cin.c{k}"], **tol)
