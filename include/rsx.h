@@ -192,6 +192,11 @@ typedef struct {
   uint32_t blk_lo, blk_hi;    /* workgroup range [lo, hi) out of rsx_adam_num_blocks(segs)  */
 } rsx_adam_slice;
 int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg);
+typedef struct rsx_table_set {
+  float* tables; float* m; float* v;        /* [R, D] each */
+  const float* dX;                           /* [B, F*D] */
+  const rsx_seg_partials* partials;          /* two-stage workspace of this set (P filled by rsx_segsum_partials), or NULL */
+} rsx_table_set;
 /* rsx_segsum_bwd fused with the touched-row half of the split update: the group that sums the gradient of unique row
  * (f, j) applies the TABLE_ROWS (and VEC_ROWS_DENSE for w1) update to it at once; `extra_segs_h` (e.g. the DENSE segment)
  * ride along as extra workgroups and the last workgroup advances the beta powers.  Replaces
@@ -202,8 +207,12 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
                          int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                         const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state,
-                         int advance_step, float lr, float beta1, float beta2, float eps, rsx_stream_t stream);
+                         const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
+                         const rsx_table_set* second_h, float* state, int advance_step, float lr, float beta1, float beta2,
+                         float eps, rsx_stream_t stream);
+/* second_h (nullable): a second table set looked up with the SAME ids (one sort serves both: xDeepFM's two input_layer
+ * calls, xdeepfm/xdeepfm.py:125,185); its row-owner workgroups run in the same launch.  It has no first-order vector and
+ * no FM term; its gradient rows dX use the same example blocks.                                                      */
 /* advance_step = 0: this launch leaves the beta powers / step counter alone because a later launch of the SAME step advances
  * them (models with two table sets: xdeepfm.py); 1 otherwise.                                                      */
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
@@ -335,7 +344,7 @@ int rsx_segsum_rows(const float* vals, const int32_t* perm, const int32_t* seg_o
  *   out[b,n,d] = relu( sum_{f,h} X0[b,f,d] * Xk[b,h,d] * W[f*H+h, n] + c[n] )     (f major, h minor: Appendix A-13)
  * ------------------------------------------------------------------------------------------- */
 int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const float* c, float* out, int B, int F,
-                      int H, int N, int D, rsx_stream_t stream);
+                      int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 /* dout = gradient wrt `out` (the relu mask is taken from `out`).  Writes dW[F*H,N], dc[N]; dXk[B,H,D] and dX0[B,F,D]
  * are overwritten or accumulated (acc_* != 0).  When Xk aliases X0 (first layer) pass either distinct dXk / dX0 buffers
  * or ONE buffer for both with acc_dx0 != 0 (the two gradient roles of X0 are then added in place).

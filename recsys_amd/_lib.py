@@ -36,6 +36,10 @@ class SegPartials(C.Structure):
     _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p)]
 
 
+class TableSet(C.Structure):
+    _fields_ = [("tables", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("dX", C.c_void_p), ("partials", C.c_void_p)]
+
+
 class SortJob(C.Structure):
     _fields_ = [("ids", C.c_void_p), ("row_off", C.c_void_p), ("perm", C.c_void_p), ("seg_off", C.c_void_p),
                 ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p), ("segid", C.c_void_p),
@@ -60,7 +64,7 @@ _SIGS = {
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
-    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),
+    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
@@ -73,7 +77,7 @@ _SIGS = {
     "rsx_din_attn_bwd": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _I, _I, _I, _I, _P]),
     "rsx_din_attn_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "rsx_sorted_segments": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "rsx_cin_layer_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
+    "rsx_cin_layer_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P, _P]),
     "rsx_cin_layer_bwd": (_I, [_P] * 8 + [_I, _P, _I, _P, _P, _P] + [_I] * 5 + [_P, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),

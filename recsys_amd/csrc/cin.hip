@@ -35,6 +35,8 @@ struct CinFwdArgs {
   const float* c;    // [N]
   float* out;        // [B, N, 16]
   int B, F, H, N;
+  int nby;           // tile rows of the grid; rows >= nby carry the optimizer sweep slice
+  AdamSlice sweep;
 };
 
 // grid = (ceil(N/16), ceil(B/4)), block = 256: wave w owns example 4*blockIdx.y + w and the 16 outputs n0.. of the
@@ -52,6 +54,11 @@ __global__ __launch_bounds__(256) void cin_fwd_k(const CinFwdArgs p) {
   constexpr int R = (HSMAX * 16 + 255) / 256;    // float4 per thread per tile
   float* sW = lds;                               // [2][16][HP]
   float* sX0 = lds + 2 * 16 * HP;                // [4][F*16]
+  if ((int)blockIdx.y >= p.nby) {   // piggy-backed optimizer sweep (untouched rows): streaming beside the MFMA tiles
+    const uint32_t lin = ((uint32_t)blockIdx.y - (uint32_t)p.nby) * gridDim.x + blockIdx.x;
+    if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 16;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   float* sX0 = sDp + CIN_BT * p.N * CIN_D;           // [BT][F*16]
   float* sXk = sX0 + CIN_BT * p.F * CIN_D;           // [BT][H*16]
   float* sP = sXk + CIN_BT * p.H * CIN_D;            // [HT][BT][F*16] dX0 partials
-  float* sDx = sP + HT * CIN_BT * p.F * CIN_D;       // [HT][BT][64*4] dXk of the odd-field waves
+  float* sDx = sP + HT * CIN_BT * p.F * CIN_D;       // [FS][HT][BT][16*16] dXk tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ht = wave % HT, part = wave / HT;
   const int b0 = blockIdx.x * CIN_BT;
@@ -207,16 +214,22 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   }
   __syncthreads();
   const int i = lane & 15, kq = lane >> 4;
-  const int h = ht * 16 + i;                // B-operand column = h
+  const int h = ht * 16 + i;                // A-operand row = h (W rows); the dpre operand's column = d = i
   const bool hok = h < p.H;
   const int ns = (p.N + 15) >> 4;
+  // U_f^T tile in C layout: lane (i, kq) holds U_f[h = 16 ht + 4 kq + r][d = i], r = 0..3 -- the <Xk, U_f> reduction over
+  // h is then 4 in-lane FMAs + 2 cross-lane steps (over kq) for ONE value, not 4 steps for 4 values
   f32x4 dxk[CIN_BT];
-  float4 xkv[CIN_BT];                       // Xk[bt][h][d = 4*kq .. +3] for the <Xk, U_f> dot
+  float xkv[CIN_BT][4];                     // Xk[bt][h = 16 ht + 4 kq + r][d = i], zero for h >= H
   float areg[CIN_BT][NSMAX][4];             // dpre[bt][n = 16 s + 4 kq + t][d = i]
 #pragma unroll
   for (int bt = 0; bt < CIN_BT; ++bt) {
     dxk[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    xkv[bt] = hok ? *reinterpret_cast<const float4*>(sXk + bt * p.H * CIN_D + h * CIN_D + kq * 4) : z4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hr = ht * 16 + 4 * kq + r;
+      xkv[bt][r] = hr < p.H ? sXk[bt * p.H * CIN_D + hr * CIN_D + i] : 0.f;
+    }
 #pragma unroll
     for (int s_ = 0; s_ < NSMAX; ++s_)
 #pragma unroll
@@ -226,84 +239,99 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
       }
   }
   const bool vec_ok = (p.N & 3) == 0;
-  for (int f = part; f < p.F; f += FS) {
+  // W rows of field f for this lane: NSMAX float4 (n = 16 s + 4 kq ..).  Unconditional loads on clamped addresses when
+  // N % 4 == 0: a row h >= H only feeds a column that is never stored, and k-steps with n >= N multiply A operands that
+  // are zero (areg is zero-padded) -- no mask needed, no branch per load.
+  auto load_w = [&](int f, float4* bw) {
+    const float* Wr = p.W + ((size_t)(f < p.F ? f : p.F - 1) * p.H + (hok ? h : 0)) * p.N;
+    if (vec_ok) {
+#pragma unroll
+      for (int u = 0; u < NSMAX; ++u) {
+        const int nn = 16 * u + 4 * kq;
+#ifdef CIN_DX_NOLOAD
+        bw[u] = make_float4(0.1f * f, 0.2f, 0.3f * u, 0.4f);
+#else
+        bw[u] = *reinterpret_cast<const float4*>(Wr + (nn + 3 < p.N ? nn : p.N - 4));
+#endif
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NSMAX; ++u) {
+        const int nn = 16 * u + 4 * kq;
+        float4 t = z4;
+        if (hok && nn < p.N) {
+          t.x = Wr[nn];
+          t.y = nn + 1 < p.N ? Wr[nn + 1] : 0.f;
+          t.z = nn + 2 < p.N ? Wr[nn + 2] : 0.f;
+          t.w = nn + 3 < p.N ? Wr[nn + 3] : 0.f;
+        }
+        bw[u] = t;
+      }
+    }
+  };
+  // one field: U_f = dpre . W_f^T (4 * NSMAX MFMAs on the rows already in registers), then dXk += X0_f * U_f and the
+  // dX0_f partial of this wave's 16 h
+  auto field = [&](int f, const float4* bw) {
     f32x4 U[CIN_BT];
 #pragma unroll
     for (int bt = 0; bt < CIN_BT; ++bt) U[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* Wr = p.W + ((size_t)f * p.H + (hok ? h : 0)) * p.N;
 #pragma unroll
-    for (int s0 = 0; s0 < NSMAX; s0 += 4) {     // 4 float4 W loads in flight, then their 32 MFMAs
-      if (s0 < ns) {                            // wave-uniform
-        float4 bw4[4];
-        if (vec_ok) {
-          // unconditional float4 loads on clamped addresses: a row h >= H only feeds a column that is never stored, and
-          // k-steps with n >= N multiply A operands that are zero (areg is zero-padded) -- no mask needed, no branch per load
+    for (int u = 0; u < NSMAX; ++u) {
+      if (u < ns) {                               // wave-uniform
+#ifdef CIN_DX_NOMFMA
+        for (int bt = 0; bt < CIN_BT; ++bt) { U[bt][0] += bw[u].x * areg[bt][u][0]; U[bt][1] += bw[u].y* areg[bt][u][1]; U[bt][2] += bw[u].z* areg[bt][u][2]; U[bt][3] += bw[u].w* areg[bt][u][3]; }
+        continue;
+#endif
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int nn = 16 * (s0 + u) + 4 * kq;
-            bw4[u] = *reinterpret_cast<const float4*>(Wr + (nn + 3 < p.N ? nn : p.N - 4));
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int nn = 16 * (s0 + u) + 4 * kq;
-            float4 t = z4;
-            if (hok && nn < p.N) {
-              t.x = Wr[nn];
-              t.y = nn + 1 < p.N ? Wr[nn + 1] : 0.f;
-              t.z = nn + 2 < p.N ? Wr[nn + 2] : 0.f;
-              t.w = nn + 3 < p.N ? Wr[nn + 3] : 0.f;
-            }
-            bw4[u] = t;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (s0 + u < NSMAX) {
-#pragma unroll
-            for (int bt = 0; bt < CIN_BT; ++bt) {
-              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][0], bw4[u].x, U[bt]);
-              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][1], bw4[u].y, U[bt]);
-              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][2], bw4[u].z, U[bt]);
-              U[bt] = cin_mfma(areg[bt][s0 + u < NSMAX ? s0 + u : 0][3], bw4[u].w, U[bt]);
-            }
-          }
+        for (int bt = 0; bt < CIN_BT; ++bt) {
+          U[bt] = cin_mfma(bw[u].x, areg[bt][u][0], U[bt]);
+          U[bt] = cin_mfma(bw[u].y, areg[bt][u][1], U[bt]);
+          U[bt] = cin_mfma(bw[u].z, areg[bt][u][2], U[bt]);
+          U[bt] = cin_mfma(bw[u].w, areg[bt][u][3], U[bt]);
         }
       }
     }
 #pragma unroll
     for (int bt = 0; bt < CIN_BT; ++bt) {
-      const float4 x = *reinterpret_cast<const float4*>(sX0 + bt * p.F * CIN_D + f * CIN_D + kq * 4);
-      dxk[bt][0] += x.x * U[bt][0];
-      dxk[bt][1] += x.y * U[bt][1];
-      dxk[bt][2] += x.z * U[bt][2];
-      dxk[bt][3] += x.w * U[bt][3];
-      // dX0[bt][f][d] partial over this wave's 16 h: sum over the 16 column lanes of U * Xk
-      float q0 = U[bt][0] * xkv[bt].x, q1 = U[bt][1] * xkv[bt].y, q2 = U[bt][2] * xkv[bt].z, q3 = U[bt][3] * xkv[bt].w;
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        q0 += __shfl_xor(q0, m); q1 += __shfl_xor(q1, m); q2 += __shfl_xor(q2, m); q3 += __shfl_xor(q3, m);
-      }
-      if (i == 0) *reinterpret_cast<float4*>(sP + ((ht * CIN_BT + bt) * p.F + f) * CIN_D + kq * 4) = make_float4(q0, q1, q2, q3);
+      const float x = sX0[bt * p.F * CIN_D + f * CIN_D + i];
+      dxk[bt][0] += x * U[bt][0];
+      dxk[bt][1] += x * U[bt][1];
+      dxk[bt][2] += x * U[bt][2];
+      dxk[bt][3] += x * U[bt][3];
+      // dX0[bt][f][d = i] partial over this wave's 16 h
+      float q = ((U[bt][0] * xkv[bt][0] + U[bt][1] * xkv[bt][1]) + U[bt][2] * xkv[bt][2]) + U[bt][3] * xkv[bt][3];
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (kq == 0) sP[((ht * CIN_BT + bt) * p.F + f) * CIN_D + i] = q;
+    }
+  };
+  // software pipeline over the fields: the W rows of the next field load while this field's MFMAs run (the workgroup
+  // is alone on its CU, so the second register set is free)
+  float4 wa[NSMAX], wb[NSMAX];
+  load_w(part, wa);
+  for (int f = part; f < p.F; f += 2 * FS) {
+    load_w(f + FS, wb);
+    field(f, wa);
+    if (f + FS < p.F) {                           // wave-uniform
+      load_w(f + 2 * FS, wa);
+      field(f + FS, wb);
     }
   }
-  if (part == 1) {
+  // dXk tiles -> LDS as [part][ht][bt][h_local][d], then float4 rows out (parts added in order)
 #pragma unroll
-    for (int bt = 0; bt < CIN_BT; ++bt)
-      *reinterpret_cast<float4*>(sDx + ((ht * CIN_BT + bt) * 64 + lane) * 4) = make_float4(dxk[bt][0], dxk[bt][1], dxk[bt][2], dxk[bt][3]);
-  }
+  for (int bt = 0; bt < CIN_BT; ++bt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sDx[(((part * HT + ht) * CIN_BT + bt) * 16 + 4 * kq + r) * CIN_D + i] = dxk[bt][r];
   __syncthreads();
-  if (hok && part == 0) {
-#pragma unroll
-    for (int bt = 0; bt < CIN_BT; ++bt) {
-      const int b = b0 + bt;
-      if (b < p.B) {
-        float4* dst = reinterpret_cast<float4*>(p.dXk + ((size_t)b * p.H + h) * CIN_D + kq * 4);
-        float4 o = make_float4(dxk[bt][0], dxk[bt][1], dxk[bt][2], dxk[bt][3]);
-        if (FS == 2) o = f4_add(o, *reinterpret_cast<const float4*>(sDx + ((ht * CIN_BT + bt) * 64 + lane) * 4));
-        if (p.acc_dxk) o = f4_add(*dst, o);
-        *dst = o;
-      }
+  for (int e = tid; e < HT * CIN_BT * 64; e += blockDim.x) {
+    const int t = e >> 6, hl = (e & 63) >> 2, dq = e & 3;      // t = ht * BT + bt
+    const int bt = t % CIN_BT, hh = (t / CIN_BT) * 16 + hl, b = b0 + bt;
+    if (hh < p.H && b < p.B) {
+      float4 o = *reinterpret_cast<const float4*>(sDx + (t * 16 + hl) * CIN_D + dq * 4);
+      if (FS == 2) o = f4_add(o, *reinterpret_cast<const float4*>(sDx + ((HT * CIN_BT + t) * 16 + hl) * CIN_D + dq * 4));
+      float4* dst = reinterpret_cast<float4*>(p.dXk + ((size_t)b * p.H + hh) * CIN_D + dq * 4);
+      if (p.acc_dxk) o = f4_add(*dst, o);
+      *dst = o;
     }
   }
   if (p.dXk == p.dX0) __syncthreads();   // first layer, one gradient buffer for both roles of X0: dXk lands before dX0 adds
@@ -334,8 +362,9 @@ constexpr int CIN_FT = 3;   // fields per wave
 // 4 waves of the workgroup take b = w, w+4, ... (4x the waves in flight to hide the operand loads) and their partial
 // tiles are added in wave order through LDS.
 __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
-  if ((int)blockIdx.z >= p.FG) {   // piggy-backed optimizer sweep
-    const uint32_t lin = (((uint32_t)blockIdx.z - (uint32_t)p.FG) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int zt = blockIdx.z, zsw = (int)blockIdx.z - p.FG;     // tile plane / sweep plane (after the tiles)
+  if (zsw >= 0) {   // piggy-backed optimizer sweep
+    const uint32_t lin = ((uint32_t)zsw * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin);
     return;
   }
@@ -344,9 +373,9 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
   const int i = lane & 15, kq = lane >> 4;
   const int n = blockIdx.x * 16 + i;        // B-operand column
   const int h = blockIdx.y * 16 + i;        // A-operand row (within each field)
-  const int f0 = blockIdx.z * CIN_FT;
+  const int f0 = zt * CIN_FT;
   const bool nok = n < p.N, hok = h < p.H;
-  const bool want_dc = blockIdx.y == 0 && blockIdx.z == 0;
+  const bool want_dc = blockIdx.y == 0 && zt == 0;
   f32x4 acc[CIN_FT], accc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < CIN_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -359,19 +388,32 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
     const bool bok = b < p.B;
     const size_t bc = bok ? (size_t)b : (size_t)p.B - 1;
     ob = bok ? one : 0.f;
+#ifdef CIN_DW_NOLOAD
+    dp = make_float4(0.1f * b, 0.2f, 0.3f, 0.4f);
+    const float4 xr = make_float4(0.1f, 0.2f * b, 0.3f, 0.4f);
+#else
     dp = *reinterpret_cast<const float4*>(p.dpre + (bc * p.N + nc) * CIN_D + kq * 4);
     const float4 xr = *reinterpret_cast<const float4*>(p.Xk + (bc * p.H + hc) * CIN_D + kq * 4);
+#endif
     const float okf = bok ? 1.f : 0.f;
     xk = make_float4(xr.x * okf, xr.y * okf, xr.z * okf, xr.w * okf);
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t) {
       const int ff = f0 + t < p.F ? f0 + t : p.F - 1;
+#ifdef CIN_DW_NOLOAD
+      x0[t] = make_float4(0.1f, 0.2f, 0.3f * b, 0.4f + ff);
+#else
       x0[t] = *reinterpret_cast<const float4*>(p.X0 + (bc * p.F + ff) * CIN_D + kq * 4);
+#endif
     }
   };
   auto fma_b = [&](const float4& dp, const float4& xk, const float4* x0, float ob) {
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t) {
+#ifdef CIN_DW_NOMFMA
+      acc[t][0] += x0[t].x * xk.x * dp.x; acc[t][1] += x0[t].y * xk.y * dp.y; acc[t][2] += x0[t].z * xk.z * dp.z; acc[t][3] += x0[t].w * xk.w * dp.w;
+      continue;
+#endif
       acc[t] = cin_mfma(x0[t].x * xk.x, dp.x, acc[t]);
       acc[t] = cin_mfma(x0[t].y * xk.y, dp.y, acc[t]);
       acc[t] = cin_mfma(x0[t].z * xk.z, dp.z, acc[t]);
@@ -437,7 +479,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
 
 // ----------------------------------------------------------------------------------------------- C ABI
 extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* W, const float* c, float* out, int B,
-                                 int F, int H, int N, int D, rsx_stream_t stream) {
+                                 int F, int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !W || !c || !out) return RSX_EINVAL;
@@ -446,8 +488,11 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
   const int hsmax = H <= 48 ? 12 : 32;
   const size_t lds = ((size_t)2 * 16 * (4 * hsmax + 4) + (size_t)4 * F * CIN_D) * sizeof(float);
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
-  CinFwdArgs p{X0, Xk, W, c, out, B, F, H, N};
-  const dim3 grid((N + 15) / 16, (B + 3) / 4);
+  CinFwdArgs p{X0, Xk, W, c, out, B, F, H, N, (B + 3) / 4, {}};
+  const int rcs = adam_build_slice(sweep_h, p.sweep);
+  if (rcs != RSX_OK) return rcs;
+  const unsigned gx = (unsigned)((N + 15) / 16);
+  const dim3 grid(gx, p.nby + (p.sweep.n_blk + gx - 1) / gx);
   if (H <= 48) hipLaunchKernelGGL(cin_fwd_k<12>, grid, dim3(256), lds, rsx_s(stream), p);
   else hipLaunchKernelGGL(cin_fwd_k<32>, grid, dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
@@ -465,7 +510,7 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
   const int FS = HT <= 4 ? 2 : 1;
-  const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D + (size_t)HT * CIN_BT * 256) * sizeof(float);
+  const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D + (size_t)FS * HT * CIN_BT * 256) * sizeof(float);
   if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
   if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -474,15 +519,20 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
                             (int)lds) != hipSuccess)
       return RSX_ELAUNCH;
   }
+#ifndef CIN_SKIP_DX
   CinBwdDxArgs a{X0, Xk, W, out, dout, gs, wout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N, HT};
   if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
+#endif
   CinBwdDwArgs w{X0, Xk, dpre_ws, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT, {}};
   const int rcs = adam_build_slice(sweep_h, w.sweep);
   if (rcs != RSX_OK) return rcs;
   const unsigned plane = (unsigned)((N + 15) / 16) * (unsigned)HT;
   const unsigned zs = (w.sweep.n_blk + plane - 1) / plane;           // extra z-planes that carry the sweep
+#ifdef CIN_SKIP_DW
+  return RSX_OK;
+#endif
   hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG + zs), dim3(256), 0, rsx_s(stream), w);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -552,6 +552,10 @@ struct HotAdam {
   uint32_t n_own, total_blocks;
   int advance;                           // the last workgroup advances the beta powers / step counter (0: a later launch of the
                                          // same step does -- e.g. the first of xDeepFM's two table sets)
+  // optional second table set looked up with the same ids (same sort outputs): its row-owner workgroups follow the first
+  // set's in the same grid (xDeepFM's two input_layer calls); no first-order vector, no FM term
+  float* tables2; float* m_t2; float* v_t2; const float* dX2;
+  SegPartials part2;
   AdamSlice extra;                       // dense variables (any non-COLD kinds), n_blk may be 0
   AdamSlice cold;                        // optional slice of the untouched-row sweep (rows disjoint from the touched ones)
 };
@@ -566,10 +570,32 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
                                                      const ExBlocks xb) {
   constexpr int LPR = D / 4;
   const float b1p = h.state[0], b2p = h.state[1];
-  if (blockIdx.x >= h.n_own + h.extra.n_blk) {
-    adam_block(h.cold.args, h.cold.blk_lo + (blockIdx.x - h.n_own - h.extra.n_blk));
-  } else if (blockIdx.x >= h.n_own) {
-    adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - h.n_own));
+  const uint32_t n_rows = h.tables2 != nullptr ? 2u * h.n_own : h.n_own;
+  if (blockIdx.x >= n_rows + h.extra.n_blk) {
+    adam_block(h.cold.args, h.cold.blk_lo + (blockIdx.x - n_rows - h.extra.n_blk));
+  } else if (blockIdx.x >= n_rows) {
+    adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - n_rows));
+  } else if (blockIdx.x >= h.n_own) {     // second table set
+    const int q = (threadIdx.x & 63) % LPR;
+    bool valid, do1;
+    size_t sl;
+    float4 acc, e;
+    float a1;
+    int row;
+    if (segsum_wave<D>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr, nullptr,
+                       perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1) &&
+        valid) {
+      Hp hp;
+      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
+      hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      const size_t o = (size_t)row * LPR + q;
+      float4 var = reinterpret_cast<const float4*>(h.tables2)[o];
+      float4 m = reinterpret_cast<const float4*>(h.m_t2)[o], v = reinterpret_cast<const float4*>(h.v_t2)[o];
+      F4_APPLY(adam_sparse1, var, m, v, acc, true, hp);
+      reinterpret_cast<float4*>(h.tables2)[o] = var;
+      reinterpret_cast<float4*>(h.m_t2)[o] = m;
+      reinterpret_cast<float4*>(h.v_t2)[o] = v;
+    }
   } else {
     const int q = (threadIdx.x & 63) % LPR;
     bool valid, do1;
@@ -783,8 +809,9 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
                                     const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
-                                    const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, float* state,
-                                    int advance_step, float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
+                                    const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
+                                    const rsx_table_set* second_h, float* state, int advance_step, float lr, float beta1,
+                                    float beta2, float eps, rsx_stream_t stream) {
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
@@ -800,6 +827,15 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   HotAdam h;
   h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
   h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state; h.advance = advance_step != 0;
+  h.tables2 = nullptr; h.m_t2 = nullptr; h.v_t2 = nullptr; h.dX2 = nullptr;
+  h.part2.segid = nullptr; h.part2.P = nullptr; h.part2.P1 = nullptr;
+  if (second_h != nullptr) {
+    if (!second_h->tables || !second_h->m || !second_h->v || !second_h->dX) return RSX_EINVAL;
+    h.tables2 = second_h->tables; h.m_t2 = second_h->m; h.v_t2 = second_h->v; h.dX2 = second_h->dX;
+    const int rc2 = seg_partials(second_h->partials, false, h.part2);
+    if (rc2 != RSX_OK) return rc2;
+    if ((h.part2.P != nullptr) != (part.P != nullptr)) return RSX_EINVAL;   // both sets one- or two-stage
+  }
   h.extra.n_blk = 0; h.extra.blk_lo = 0;
   if (n_extra > 0) {
     uint32_t blocks = 0;
@@ -816,7 +852,7 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   // those elements.  Only table slices (whole touched rows are skipped, never written) may ride here.
   for (int k = 0; h.cold.n_blk != 0 && k < h.cold.args.nseg; ++k)
     if (h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
-  h.total_blocks = h.n_own + h.extra.n_blk + h.cold.n_blk;
+  h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,
                  w1_field_mask, B, F, stride, h, part, xb);

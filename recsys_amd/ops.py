@@ -94,10 +94,26 @@ class EmbeddingArena:
     def _two_stage(self, B):
         return self.partials is not None and B > self.TWO_STAGE_MIN_B
 
+    def share_sort_of(self, other):
+        """Two table sets looked up with the SAME ids over the same field layout (xDeepFM's two input_layer calls,
+        xdeepfm/xdeepfm.py:125,185) have one dedup result: alias `other`'s sort outputs; field_sort here becomes a no-op."""
+        assert np.array_equal(self.row_off_np, other.row_off_np) and self.stride == other.stride
+        self._sort_owner = other
+        for k in ("perm", "seg_off", "uniq_row", "nuniq", "slot", "sort_ws"):
+            setattr(self, k, getattr(other, k))
+        if self.partials is not None:
+            self.segid = other.segid
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1))
+
     # -- kernels ---------------------------------------------------------------------------
     def field_sort(self, ids):
         B = ids.shape[0]
         assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and B <= self.stride
+        owner = getattr(self, "_sort_owner", None)
+        if owner is not None:
+            assert owner.last_B == B, "shared sort: sort the owning arena first"
+            self.last_B = B
+            return
         if B > self.LDS_SORT_MAX_B:
             check(lib().rsx_field_sort_large(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
                                              _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid),
@@ -158,9 +174,18 @@ class EmbeddingArena:
                                    _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
                                    self.stride, part, blk, _stream()), "rsx_segsum_bwd")
 
-    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True):
-        """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups)."""
+    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True, second=None):
+        """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups).
+        second = (arena2, dX2): a table set sharing this arena's sort (share_sort_of), updated by the same launch."""
         blk = self._blocks(blocks)
+        sec = None
+        if second is not None:
+            a2, dX2 = second
+            assert getattr(a2, "_sort_owner", None) is self and a2.D == self.D and dX2.is_contiguous()
+            two = a2._stage_a(B, None, dX2, None, None, blk) is not None
+            sec_obj = _lib.TableSet(a2.tables.data_ptr(), a2.m_t.data_ptr(), a2.v_t.data_ptr(), dX2.data_ptr(),
+                                    C.addressof(a2.partials) if two else None)
+            sec = C.byref(sec_obj)
         arr, n = opt._seg_array(extra_segments)
         lr, b1, b2, eps = opt.hp
         w = self.with_w1 and gy1 is not None
@@ -169,7 +194,7 @@ class EmbeddingArena:
                                          _ptr(self.m_w) if w else None, _ptr(self.v_w) if w else None, _ptr(S), _ptr(dX),
                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
-                                         None if sweep is None else C.byref(sweep), part, blk,
+                                         None if sweep is None else C.byref(sweep), part, blk, sec,
                                          _ptr(opt.state), 1 if advance else 0, lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
 
     # -- optimizer segments ----------------------------------------------------------------
@@ -696,7 +721,7 @@ class CinLayerFn(torch.autograd.Function):
         H, N = Xk.shape[1], W.shape[1]
         X0, Xk = X0.contiguous(), Xk.contiguous()
         out = torch.empty(B, N, D, device=X0.device)
-        check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(c), _ptr(out), B, F, H, N, D, _stream()),
+        check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(c), _ptr(out), B, F, H, N, D, None, _stream()),
               "rsx_cin_layer_fwd")
         ctx.save_for_backward(X0, Xk, W, out)
         ctx.sweep = sweep
@@ -734,13 +759,15 @@ class CinNet:
         self._outs_h = (C.c_void_p * self.L)(*[o.data_ptr() for o in self.outs])
         self.offs = [sum(self.sizes[:k]) for k in range(self.L)]
 
-    def forward(self, X0, P):
-        """X0 [B,F,D] contiguous -> cin_y [B] (view of an internal buffer)."""
+    def forward(self, X0, P, sweeps=None):
+        """X0 [B,F,D] contiguous -> cin_y [B] (view of an internal buffer).  sweeps[k]: slice of the untouched-row
+        optimizer sweep carried by layer k's forward launch."""
         B = X0.shape[0]
         Xk, H = X0, self.F
         for k, n in enumerate(self.sizes):
+            sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]), B,
-                                          self.F, H, n, self.D, _stream()), "rsx_cin_layer_fwd")
+                                          self.F, H, n, self.D, sw, _stream()), "rsx_cin_layer_fwd")
             Xk, H = self.outs[k], n
         check(lib().rsx_cin_out_fwd(self._outs_h, self._sizes_h, self.L, _ptr(P["cin.Wout"]), _ptr(P["cin.bout"]), _ptr(self.y),
                                     B, self.D, _stream()), "rsx_cin_out_fwd")

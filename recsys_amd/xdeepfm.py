@@ -6,6 +6,8 @@ logits = dense([linear_y, cin_y, dnn_y], 1) (:194-195) with
   cin_y    = relu(dense(sum_d concat_k X^k, 1)), X^{k+1} = CIN layer(X^0, X^k)      (:135-182, csrc/cin.hip)
   dnn_y    = relu(dense(tower(E_dnn), 1)) over a SECOND, independent embedding set  (:185-192)
 """
+import os
+
 import torch
 
 from . import layers as L
@@ -27,6 +29,7 @@ def build_variables(store, params, capacity):
     cat_keys = {c.key for c in params["linear_feature_columns"] if c.kind == "hash_indicator"}
     a1 = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=True, w1_field_mask=layout.field_mask(cat_keys))
     a2 = EmbeddingArena(layout.row_off, D, capacity, store.device, with_w1=False)
+    a2.share_sort_of(a1)                       # same ids, same layout: one dedup sort per step serves both table sets
     n_lin = 13 + sum(c.rows for c in params["linear_feature_columns"] if c.kind == "hash_indicator")
     with torch.no_grad():
         for a in (a1, a2):
@@ -86,11 +89,11 @@ def _cin(X0, P, sizes, sweeps=None):
 def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     dp, P = store.dp, store.dense
     B = ids.shape[0]
-    sweeps, hot = None, None
+    sweeps, hot, L = None, None, len(store.cin_sizes)
     with torch.no_grad():
         if dp is None:
-            store.sort_ids_for_backward(a1, ids)
-            store.sort_ids_for_backward(a2, ids)
+            store.sort_ids_for_backward(a1, ids)                            # serves a2 as well (share_sort_of)
+            a2.last_B = B
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
                 # (700 MB of streaming) rides in the CIN weight-gradient launches, which are MFMA-bound; the touched rows
@@ -98,17 +101,19 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 c1, h1 = a1.adam_split_segments()
                 c2, h2 = a2.adam_split_segments()
                 w = [float(store.cin_sizes[k]) * (a1.F if k == 0 else store.cin_sizes[k - 1]) for k in range(len(store.cin_sizes))]
-                sweeps = store.opt.cold_slices(c1 + c2, w)
+                share = float(os.environ.get("RSX_CIN_FWD_SHARE", "0.3"))    # part of the sweep carried by the forward launches
+                tw = sum(w)
+                sweeps = store.opt.cold_slices(c1 + c2, [share * x / tw for x in w] + [(1.0 - share) * x / tw for x in w])
                 hot = h1 + h2
         E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
         lin_pre = torch.addmv(y1cat, logx, P["lin.wnum"])                   # + 13 numeric log-values (:127)
         E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
         X0 = E1.view(B, a1.F, a1.D)
-        cin_y = store.cin.forward(X0, P)                                    # 'cin_net' (:135-182), csrc/cin.hip
+        cin_y = store.cin.forward(X0, P, None if sweeps is None else sweeps[:L])                                   # 'cin_net' (:135-182), csrc/cin.hip
         loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks)
-        dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), sweeps).view(B, -1)   # cin.* grads land in the dense arena
+        dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:]).view(B, -1)   # cin.* grads land in the dense arena
         P["lin.wnum"].grad.copy_(logx.t() @ g_lin)
 
     def train_op():
@@ -124,10 +129,9 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 dp.all_reduce_sum(store.dense.grad)
                 store.apply_gradients()
             elif hot is not None:
-                # scatter + touched-row Adam per table set; the second launch also carries the dense variables and advances
-                # the beta powers for the step
-                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, [], None, advance=False)
-                a2.segsum_adam(B, None, dX2, None, None, store.opt, store.dense.adam_segments(), None)
+                # scatter + touched-row Adam of BOTH table sets (one shared sort) in one launch, which also carries the
+                # dense variables and advances the beta powers
+                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, store.dense.adam_segments(), None, second=(a2, dX2))
             else:
                 a1.segsum(B, None, dX1, g_lin, None)
                 a2.segsum(B, None, dX2, None, None)

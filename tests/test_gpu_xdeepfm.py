@@ -188,3 +188,38 @@ def test_cin_net_fused_head(B, F, sizes):
     for k in range(len(sizes)):
         np.testing.assert_allclose(P[f"cin.W{k}"].grad.cpu().numpy(), g_o[f"cin.W{k}"], **tol)
         np.testing.assert_allclose(P[f"cin.c{k}"].grad.cpu().numpy(), g_o[f"cin.c{k}"], **tol)
+
+
+@pytest.mark.parametrize("B", [48, 1500])
+def test_two_table_sets_in_one_scatter_launch_is_bit_identical(B):
+    """rsx_segsum_adam_rows(second_h): xDeepFM's two table sets (one shared sort) updated by ONE launch == two launches."""
+    from recsys_amd.ops import AdamTF1, DenseArena, EmbeddingArena
+    rng = np.random.default_rng(B)
+    row_off = np.concatenate([[0], np.cumsum(rng.integers(3, 60, 7))]).astype(np.int64)
+    F, D, R = 7, 16, int(row_off[-1])
+    ids = torch.from_numpy(synth_ids(rng, B, row_off)).cuda()
+    t1, t2 = rng.standard_normal((R, D)).astype(np.float32), rng.standard_normal((R, D)).astype(np.float32)
+    w1 = rng.standard_normal(R).astype(np.float32)
+    dX1 = torch.from_numpy(rng.standard_normal((B, F * D)).astype(np.float32)).cuda()
+    dX2 = torch.from_numpy(rng.standard_normal((B, F * D)).astype(np.float32)).cuda()
+    g1 = torch.from_numpy(rng.standard_normal(B).astype(np.float32)).cuda()
+    res = []
+    for merged in (False, True):
+        a1 = EmbeddingArena(row_off, D, B, "cuda", with_w1=True, tables=t1.copy(), w1=w1.copy())
+        a2 = EmbeddingArena(row_off, D, B, "cuda", with_w1=False, tables=t2.copy())
+        a2.share_sort_of(a1)
+        dense = DenseArena({"w": (33,)})
+        dense.grad.copy_(torch.arange(dense.n, device="cuda") * 0.01)
+        opt = AdamTF1(device="cuda")
+        for _ in range(3):
+            a1.field_sort(ids)
+            a2.field_sort(ids)
+            if merged:
+                a1.segsum_adam(B, None, dX1, g1, None, opt, dense.adam_segments(), None, second=(a2, dX2))
+            else:
+                a1.segsum_adam(B, None, dX1, g1, None, opt, [], None, advance=False)
+                a2.segsum_adam(B, None, dX2, None, None, opt, dense.adam_segments(), None)
+            dense.grad.copy_(torch.arange(dense.n, device="cuda") * 0.01)
+        res.append([x.cpu().numpy().copy() for x in (a1.tables, a1.m_t, a1.v_t, a1.w1, a2.tables, a2.m_t, a2.v_t, dense.flat, opt.state)])
+    for x, y in zip(*res):
+        np.testing.assert_array_equal(x, y)
