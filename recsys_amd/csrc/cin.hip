@@ -603,10 +603,19 @@ __global__ __launch_bounds__(1024) void cin_out_bwd_k(const CinOutArgs p) {
   const bool ok = n < p.n[k];
   const float* src = p.out[k] + ((size_t)(ok ? n : 0)) * CIN_D + dq * 4;
   float s = 0.f;
-  for (int b = wv; b < p.B; b += 16) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)b * p.n[k] * CIN_D);
-    const float g = p.y[b] > 0.f ? p.gy[b] : 0.f;
-    s += g * ((v.x + v.y) + (v.z + v.w));
+  for (int b0 = wv; b0 < p.B; b0 += 16 * 8) {      // 8 independent loads in flight (clamped index, masked weight)
+    float4 v[8];
+    float g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 16 * u;
+      const int bc = b < p.B ? b : p.B - 1;
+      v[u] = *reinterpret_cast<const float4*>(src + (size_t)bc * p.n[k] * CIN_D);
+      const float yv = p.y[bc], gv = p.gy[bc];
+      g[u] = (b < p.B && yv > 0.f) ? gv : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += g[u] * ((v[u].x + v[u].y) + (v[u].z + v[u].w));
   }
   s += __shfl_xor(s, 1);
   s += __shfl_xor(s, 2);

@@ -106,7 +106,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 sweeps = store.opt.cold_slices(c1 + c2, [share * x / tw for x in w] + [(1.0 - share) * x / tw for x in w])
                 hot = h1 + h2
         E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
-        lin_pre = torch.addmv(y1cat, logx, P["lin.wnum"])                   # + 13 numeric log-values (:127)
+        lin_pre = y1cat.addmv_(logx, P["lin.wnum"])                         # + 13 numeric log-values (:127), in place
         E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
         X0 = E1.view(B, a1.F, a1.D)
         cin_y = store.cin.forward(X0, P, None if sweeps is None else sweeps[:L])                                   # 'cin_net' (:135-182), csrc/cin.hip
@@ -114,7 +114,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks)
         dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:]).view(B, -1)   # cin.* grads land in the dense arena
-        P["lin.wnum"].grad.copy_(logx.t() @ g_lin)
+        torch.mv(logx.t(), g_lin, out=P["lin.wnum"].grad)
 
     def train_op():
         with torch.no_grad():
