@@ -59,7 +59,7 @@ constexpr int ADAM_U = RSX_ADAM_U;  // float4 per lane
 constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
 
 // One workgroup (ADAM_T = 256 threads) of the sweep: block `blk` of the launch-wide block index space of `a`.
-__device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk) {
+__device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk, const int tid = threadIdx.x) {
   const float b1p = a.state[0], b2p = a.state[1];
   Hp h;
   h.b1 = a.b1;
@@ -86,7 +86,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
     const float4* __restrict__ G4 = reinterpret_cast<const float4*>(s.g);
 #pragma unroll
     for (int u = 0; u < ADAM_U; ++u) {
-      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         const long long row = e / lpr;
         const int q = (int)(e - row * lpr);
@@ -117,7 +117,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
     const long long n4 = s.n >> 2;
 #pragma unroll
     for (int u = 0; u < ADAM_U; ++u) {
-      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         float4 var = var4[e], m = m4[e], v = v4[e];
         const float4 g = g4[e];
@@ -138,7 +138,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
     const long long n4 = s.n >> 2;
 #pragma unroll
     for (int u = 0; u < ADAM_U; ++u) {
-      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         const int4 sl = reinterpret_cast<const int4*>(s.slot)[e];
         float4 g;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
     const float4* __restrict__ G4 = reinterpret_cast<const float4*>(s.g);
 #pragma unroll
     for (int u = 0; u < ADAM_U; ++u) {
-      const long long e = base + (long long)u * ADAM_T + threadIdx.x;
+      const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         const long long sidx = e / lpr;
         const int q = (int)(e - sidx * lpr);
@@ -193,7 +193,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   } else {  // RSX_ADAM_VEC_ROWS (sparse formula) / RSX_ADAM_VEC_ROWS_DENSE (ApplyAdam formula)
 #pragma unroll
     for (int u = 0; u < ADAM_U; ++u) {
-      const long long sidx = base + (long long)u * ADAM_T + threadIdx.x;
+      const long long sidx = base + (long long)u * ADAM_T + tid;
       if (sidx < s.n) {
         const int f = (int)(sidx / s.B), j = (int)(sidx - (long long)f * s.B);
         if (j < s.nuniq[f]) {

@@ -168,16 +168,16 @@ struct CinBwdDxArgs {
   float* dpre;        // [B, N, 16] out: dout with the relu mask applied, consumed by cin_bwd_dw_k
   int acc_dxk, acc_dx0;
   int B, F, H, N;
-  int HT;             // 16-wide h tiles; the block holds HT * FS waves, FS = 2 when HT <= 4: the two halves of a tile's
-                      // fields (f even / odd) run on separate waves so that a short H still fills the SIMDs
+  int HT;             // 16-wide h tiles; the block holds HT * FS waves: for a short H the fields of a tile are dealt
+                      // round-robin to FS = 2 or 4 waves so that the workgroup still loads its CU's 4 SIMDs evenly
 };
 
-// grid = ceil(B/BT), block = 64 * HT * FS (<= 8 waves).
+// grid = ceil(B/BT), block = 64 * HT * FS (<= 12 waves).
 // dyn LDS: 2*(N + F + H)*16 + HT*2*F*16 floats.  The A operand dpre[b][n][d] does not depend on f: after staging it
 // through LDS (the relu mask is applied once) each lane keeps its 4*NSMAX values per example in registers
 // (NSMAX = 8 covers N <= 128), so the f loop is "4 float4 W loads in flight -> 32 MFMAs".
 template <int NSMAX>
-__global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
+__global__ __launch_bounds__(768) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HT = p.HT, FS = (int)(blockDim.x >> 6) / HT;
   float* sDp = lds;                                  // [BT][N*16] dpre
@@ -248,11 +248,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
 #pragma unroll
       for (int u = 0; u < NSMAX; ++u) {
         const int nn = 16 * u + 4 * kq;
-#ifdef CIN_DX_NOLOAD
-        bw[u] = make_float4(0.1f * f, 0.2f, 0.3f * u, 0.4f);
-#else
         bw[u] = *reinterpret_cast<const float4*>(Wr + (nn + 3 < p.N ? nn : p.N - 4));
-#endif
       }
     } else {
 #pragma unroll
@@ -278,10 +274,6 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
 #pragma unroll
     for (int u = 0; u < NSMAX; ++u) {
       if (u < ns) {                               // wave-uniform
-#ifdef CIN_DX_NOMFMA
-        for (int bt = 0; bt < CIN_BT; ++bt) { U[bt][0] += bw[u].x * areg[bt][u][0]; U[bt][1] += bw[u].y* areg[bt][u][1]; U[bt][2] += bw[u].z* areg[bt][u][2]; U[bt][3] += bw[u].w* areg[bt][u][3]; }
-        continue;
-#endif
 #pragma unroll
         for (int bt = 0; bt < CIN_BT; ++bt) {
           U[bt] = cin_mfma(bw[u].x, areg[bt][u][0], U[bt]);
@@ -328,7 +320,8 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_k(const CinBwdDxArgs p) {
     const int bt = t % CIN_BT, hh = (t / CIN_BT) * 16 + hl, b = b0 + bt;
     if (hh < p.H && b < p.B) {
       float4 o = *reinterpret_cast<const float4*>(sDx + (t * 16 + hl) * CIN_D + dq * 4);
-      if (FS == 2) o = f4_add(o, *reinterpret_cast<const float4*>(sDx + ((HT * CIN_BT + t) * 16 + hl) * CIN_D + dq * 4));
+      for (int pp = 1; pp < FS; ++pp)     // field parts in order
+        o = f4_add(o, *reinterpret_cast<const float4*>(sDx + ((pp * HT * CIN_BT + t) * 16 + hl) * CIN_D + dq * 4));
       float4* dst = reinterpret_cast<float4*>(p.dXk + ((size_t)b * p.H + hh) * CIN_D + dq * 4);
       if (p.acc_dxk) o = f4_add(*dst, o);
       *dst = o;
@@ -352,128 +345,150 @@ struct CinBwdDwArgs {
   const float* X0; const float* Xk; const float* dpre;   // dpre [B, N, 16] = relu-masked dout (written by cin_bwd_dx_k)
   float* dW;   // [F*H, N]
   float* dc;   // [N]
-  int B, F, H, N, FG;   // FG = ceil(F/3) field groups
+  int B, F, H, N, FG;   // FG = ceil(F/FT) field groups
   AdamSlice sweep;      // optional slice of the untouched-row optimizer sweep: extra z-planes of the grid (the MFMA-bound
                         // tiles leave HBM idle; the sweep is pure streaming)
 };
-constexpr int CIN_FT = 3;   // fields per wave
 
-// grid = (ceil(N/16), ceil(H/16), FG), block = 256.  Reduction over all m = (b, d): one example per k-step group; the
-// 4 waves of the workgroup take b = w, w+4, ... (4x the waves in flight to hide the operand loads) and their partial
-// tiles are added in wave order through LDS.
-__global__ __launch_bounds__(256) void cin_bwd_dw_k(const CinBwdDwArgs p) {
+// grid = (ceil(N/(16 NT)), ceil(H/16), FG), block = 64 NW.  A wave owns the (CIN_FT fields) x (16 h) x (NT 16-wide n tiles)
+// output tiles: per example it loads Xk (1 float4 / lane), X0 (CIN_FT) and dpre (NT) and issues 4 CIN_FT NT MFMAs, so the
+// operand bytes per MFMA fall with NT (the launch is bound by L1/L2 operand traffic as much as by the matrix pipe).
+// Reduction over all m = (b, d): one example per k-step group; the NW waves of the workgroup take b = w, w+NW, ... and
+// their partial tiles are added in wave order through LDS.
+template <int CIN_FT, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void cin_bwd_dw_k(const CinBwdDwArgs p) {
   const int zt = blockIdx.z, zsw = (int)blockIdx.z - p.FG;     // tile plane / sweep plane (after the tiles)
-  if (zsw >= 0) {   // piggy-backed optimizer sweep
-    const uint32_t lin = ((uint32_t)zsw * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin);
+  if (zsw >= 0) {   // piggy-backed optimizer sweep: one 256-thread sweep block per 4 waves of the workgroup
+    const uint32_t lin = (((uint32_t)zsw * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NW / 4) + (threadIdx.x >> 8);
+    if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin, threadIdx.x & 255);
     return;
   }
-  __shared__ float red[4][CIN_FT + 1][256];
+  constexpr int TT = CIN_FT * NT;            // output tiles per wave
+  constexpr int CH = 4;                      // tiles per reduction pass (<= NW)
+  __shared__ float red[NW][CH][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int n = blockIdx.x * 16 + i;        // B-operand column
+  const int nb = blockIdx.x * 16 * NT;      // first column of this wave's n tiles
   const int h = blockIdx.y * 16 + i;        // A-operand row (within each field)
   const int f0 = zt * CIN_FT;
-  const bool nok = n < p.N, hok = h < p.H;
+  const bool hok = h < p.H;
   const bool want_dc = blockIdx.y == 0 && zt == 0;
-  f32x4 acc[CIN_FT], accc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[CIN_FT][NT], accc[NT];
 #pragma unroll
-  for (int t = 0; t < CIN_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < NT; ++j) {
+    accc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < CIN_FT; ++t) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const float one = i == 0 ? 1.f : 0.f;
   // Operand loads are unconditional on clamped indices: out-of-range columns / rows / fields only feed output elements
   // that are never stored, and an example past the batch is neutralised by zeroing its A operand (xk) and the ones-row.
-  const int nc = nok ? n : 0, hc = hok ? h : 0;
-  auto load = [&](int b, float4& dp, float4& xk, float4* x0, float& ob) {
+  int nc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) nc[j] = nb + 16 * j + i < p.N ? nb + 16 * j + i : 0;
+  const int hc = hok ? h : 0;
+  struct Ops { float4 dp[NT]; float4 xk; float4 x0[CIN_FT]; float ob; };
+  auto load = [&](int b, Ops& o) {
     const bool bok = b < p.B;
     const size_t bc = bok ? (size_t)b : (size_t)p.B - 1;
-    ob = bok ? one : 0.f;
-#ifdef CIN_DW_NOLOAD
-    dp = make_float4(0.1f * b, 0.2f, 0.3f, 0.4f);
-    const float4 xr = make_float4(0.1f, 0.2f * b, 0.3f, 0.4f);
-#else
-    dp = *reinterpret_cast<const float4*>(p.dpre + (bc * p.N + nc) * CIN_D + kq * 4);
+    o.ob = bok ? one : 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) o.dp[j] = *reinterpret_cast<const float4*>(p.dpre + (bc * p.N + nc[j]) * CIN_D + kq * 4);
     const float4 xr = *reinterpret_cast<const float4*>(p.Xk + (bc * p.H + hc) * CIN_D + kq * 4);
-#endif
     const float okf = bok ? 1.f : 0.f;
-    xk = make_float4(xr.x * okf, xr.y * okf, xr.z * okf, xr.w * okf);
+    o.xk = make_float4(xr.x * okf, xr.y * okf, xr.z * okf, xr.w * okf);
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t) {
       const int ff = f0 + t < p.F ? f0 + t : p.F - 1;
-#ifdef CIN_DW_NOLOAD
-      x0[t] = make_float4(0.1f, 0.2f, 0.3f * b, 0.4f + ff);
-#else
-      x0[t] = *reinterpret_cast<const float4*>(p.X0 + (bc * p.F + ff) * CIN_D + kq * 4);
-#endif
+      o.x0[t] = *reinterpret_cast<const float4*>(p.X0 + (bc * p.F + ff) * CIN_D + kq * 4);
     }
   };
-  auto fma_b = [&](const float4& dp, const float4& xk, const float4* x0, float ob) {
+  auto fma_b = [&](const Ops& o) {
+    float a[CIN_FT][4];
 #pragma unroll
     for (int t = 0; t < CIN_FT; ++t) {
-#ifdef CIN_DW_NOMFMA
-      acc[t][0] += x0[t].x * xk.x * dp.x; acc[t][1] += x0[t].y * xk.y * dp.y; acc[t][2] += x0[t].z * xk.z * dp.z; acc[t][3] += x0[t].w * xk.w * dp.w;
-      continue;
-#endif
-      acc[t] = cin_mfma(x0[t].x * xk.x, dp.x, acc[t]);
-      acc[t] = cin_mfma(x0[t].y * xk.y, dp.y, acc[t]);
-      acc[t] = cin_mfma(x0[t].z * xk.z, dp.z, acc[t]);
-      acc[t] = cin_mfma(x0[t].w * xk.w, dp.w, acc[t]);
+      a[t][0] = o.x0[t].x * o.xk.x; a[t][1] = o.x0[t].y * o.xk.y; a[t][2] = o.x0[t].z * o.xk.z; a[t][3] = o.x0[t].w * o.xk.w;
     }
-    if (want_dc) {   // ones-row: row 0 of this tile accumulates sum_m dpre[m, n]
-      accc = cin_mfma(ob, dp.x, accc);
-      accc = cin_mfma(ob, dp.y, accc);
-      accc = cin_mfma(ob, dp.z, accc);
-      accc = cin_mfma(ob, dp.w, accc);
+    // component-major order: consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < CIN_FT; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bv = c == 0 ? o.dp[j].x : c == 1 ? o.dp[j].y : c == 2 ? o.dp[j].z : o.dp[j].w;
+          acc[t][j] = cin_mfma(a[t][c], bv, acc[t][j]);
+        }
+    if (want_dc) {   // ones-row: row 0 of the tile accumulates sum_m dpre[m, n]
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        accc[j] = cin_mfma(o.ob, o.dp[j].x, accc[j]);
+        accc[j] = cin_mfma(o.ob, o.dp[j].y, accc[j]);
+        accc[j] = cin_mfma(o.ob, o.dp[j].z, accc[j]);
+        accc[j] = cin_mfma(o.ob, o.dp[j].w, accc[j]);
+      }
     }
   };
-  // software pipeline: the operands of examples b+2, b+3 are loading while b, b+1 feed the matrix pipe
-  float4 dpA, xkA, x0A[CIN_FT], dpB, xkB, x0B[CIN_FT], dpC, xkC, x0C[CIN_FT], dpD, xkD, x0D[CIN_FT];
-  float oA, oB, oC, oD;
-  load(wv, dpA, xkA, x0A, oA);
-  load(wv + 4, dpB, xkB, x0B, oB);
-  for (int b = wv; b < p.B; b += 16) {
-    load(b + 8, dpC, xkC, x0C, oC);
-    load(b + 12, dpD, xkD, x0D, oD);
-    fma_b(dpA, xkA, x0A, oA);
-    fma_b(dpB, xkB, x0B, oB);
-    load(b + 16, dpA, xkA, x0A, oA);
-    load(b + 20, dpB, xkB, x0B, oB);
-    fma_b(dpC, xkC, x0C, oC);
-    fma_b(dpD, xkD, x0D, oD);
+  // software pipeline: the operands of the wave's examples two steps ahead are loading while two feed the matrix pipe
+  Ops A, Bq, Cq, Dq;
+  load(wv, A);
+  load(wv + NW, Bq);
+  for (int b = wv; b < p.B; b += 4 * NW) {
+    load(b + 2 * NW, Cq);
+    load(b + 3 * NW, Dq);
+    fma_b(A);
+    fma_b(Bq);
+    load(b + 4 * NW, A);
+    load(b + 5 * NW, Bq);
+    fma_b(Cq);
+    fma_b(Dq);
   }
-  // per-wave partial tiles -> LDS in C layout order (row = 4*kq + r, col = lane & 15), summed in wave order
+  // per-wave partial tiles -> LDS in C layout order (row = 4*kq + r, col = lane & 15), summed in wave order.  CH tiles
+  // per pass keep the buffer small: the sweep workgroups of this launch inherit its LDS footprint.
+  f32x4 tl[TT + NT];
 #pragma unroll
   for (int t = 0; t < CIN_FT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wv][t][(kq * 4 + r) * 16 + i] = acc[t][r];
+    for (int j = 0; j < NT; ++j) tl[t * NT + j] = acc[t][j];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wv][CIN_FT][(kq * 4 + r) * 16 + i] = accc[r];
-  __syncthreads();
-  if (wv != 0) return;
+  for (int j = 0; j < NT; ++j) tl[TT + j] = accc[j];
 #pragma unroll
-  for (int t = 0; t < CIN_FT; ++t)
+  for (int c0 = 0; c0 < TT + NT; c0 += CH) {
+    if (c0) __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = (kq * 4 + r) * 16 + i;
-      acc[t][r] = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
-    }
-  {
-    const int e = i;   // row 0
-    accc[0] = ((red[0][CIN_FT][e] + red[1][CIN_FT][e]) + red[2][CIN_FT][e]) + red[3][CIN_FT][e];
-  }
-  // C layout: col = lane & 15 (n), row = 4*kq + r (h within the tile)
-  if (nok) {
+    for (int u = 0; u < CH; ++u)
+      if (c0 + u < TT + NT) {
 #pragma unroll
-    for (int t = 0; t < CIN_FT; ++t) {
-      if (f0 + t < p.F) {
+        for (int r = 0; r < 4; ++r) red[wv][u][(kq * 4 + r) * 16 + i] = tl[c0 + u][r];
+      }
+    __syncthreads();
+    // tile c0 + u is summed and stored by wave u (u < CH <= NW).  C layout: col = lane & 15 (n), row = 4*kq + r
+    const int tt = c0 + wv;
+    if (wv < CH && tt < TT + NT) {
+      const bool is_dc = tt >= TT;
+      const int t = is_dc ? 0 : tt / NT, j = is_dc ? tt - TT : tt % NT;
+      const int n = nb + 16 * j + i;
+      if (n < p.N) {
+        if (is_dc) {
+          if (want_dc && kq == 0) {
+            float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int hr = blockIdx.y * 16 + kq * 4 + r;
-          if (hr < p.H) p.dW[((size_t)(f0 + t) * p.H + hr) * p.N + n] = acc[t][r];
+            for (int w = 0; w < NW; ++w) a += red[w][wv][i];     // row 0
+            p.dc[n] = a;
+          }
+        } else if (f0 + t < p.F) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = (kq * 4 + r) * 16 + i;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[w][wv][e];
+            const int hr = blockIdx.y * 16 + kq * 4 + r;
+            if (hr < p.H) p.dW[((size_t)(f0 + t) * p.H + hr) * p.N + n] = a;
+          }
         }
       }
     }
-    if (want_dc && kq == 0) p.dc[n] = accc[0];
   }
 }
 
@@ -509,7 +524,7 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   if (dXk == dX0 && !(Xk == X0 && acc_dx0)) return RSX_EINVAL;   // one buffer only for the first layer, accumulating
   if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
-  const int FS = HT <= 4 ? 2 : 1;
+  const int FS = HT <= 3 ? 4 : HT <= 4 ? 2 : 1;   // waves = HT * FS <= 12, an even load for the 4 SIMDs
   const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D + (size_t)FS * HT * CIN_BT * 256) * sizeof(float);
   if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
   if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
@@ -519,21 +534,41 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
                             (int)lds) != hipSuccess)
       return RSX_ELAUNCH;
   }
-#ifndef CIN_SKIP_DX
   CinBwdDxArgs a{X0, Xk, W, out, dout, gs, wout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N, HT};
   if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
-#endif
-  CinBwdDwArgs w{X0, Xk, dpre_ws, dW, dc, B, F, H, N, (F + CIN_FT - 1) / CIN_FT, {}};
+  // Wave tile = FT fields x 16 h x (NT x 16) n, NW waves split the batch.  The configuration is chosen for BALANCE first
+  // (workgroups are equal-sized: ceil(WGs / 256 CUs) rounds of FT*NT work each), then for the larger tile (fewer operand
+  // bytes per MFMA).
+  static const int force = getenv("RSX_CIN_DW_CFG") ? atoi(getenv("RSX_CIN_DW_CFG")) : -1;
+  static const int cfgs[5][3] = {{5, 2, 8}, {5, 1, 4}, {3, 1, 4}, {2, 2, 8}, {2, 1, 4}};
+  int best = 0;
+  double best_cost = 1e30;
+  for (int c = 0; c < 5; ++c) {
+    const int ft = cfgs[c][0], nt = cfgs[c][1];
+    const long wgs = (long)((N + 16 * nt - 1) / (16 * nt)) * HT * ((F + ft - 1) / ft);
+    const double cost = (double)((wgs + 255) / 256) * ft * nt * (1.0 + 0.02 * c);   // earlier entries win ties
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  if (sweep_h != nullptr) best = 2;   // carrying sweep workgroups: they inherit the tile kernel's footprint, and the small
+                                      // 4-wave / 104-VGPR configuration co-runs best with them (measured end to end)
+  if (force >= 0 && force < 5) best = force;
+  const int FT = cfgs[best][0], NT = cfgs[best][1], NW = cfgs[best][2];
+  CinBwdDwArgs w{X0, Xk, dpre_ws, dW, dc, B, F, H, N, (F + FT - 1) / FT, {}};
   const int rcs = adam_build_slice(sweep_h, w.sweep);
   if (rcs != RSX_OK) return rcs;
-  const unsigned plane = (unsigned)((N + 15) / 16) * (unsigned)HT;
+  const unsigned gx = (unsigned)((N + 16 * NT - 1) / (16 * NT));
+  const unsigned plane = gx * (unsigned)HT * (unsigned)(NW / 4);
   const unsigned zs = (w.sweep.n_blk + plane - 1) / plane;           // extra z-planes that carry the sweep
-#ifdef CIN_SKIP_DW
-  return RSX_OK;
-#endif
-  hipLaunchKernelGGL(cin_bwd_dw_k, dim3((N + 15) / 16, HT, w.FG + zs), dim3(256), 0, rsx_s(stream), w);
+  const dim3 grid(gx, HT, w.FG + zs);
+  switch (best) {
+    case 0: hipLaunchKernelGGL((cin_bwd_dw_k<5, 2, 8>), grid, dim3(512), 0, rsx_s(stream), w); break;
+    case 1: hipLaunchKernelGGL((cin_bwd_dw_k<5, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
+    case 2: hipLaunchKernelGGL((cin_bwd_dw_k<3, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
+    case 3: hipLaunchKernelGGL((cin_bwd_dw_k<2, 2, 8>), grid, dim3(512), 0, rsx_s(stream), w); break;
+    default: hipLaunchKernelGGL((cin_bwd_dw_k<2, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
+  }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

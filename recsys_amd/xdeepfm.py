@@ -96,12 +96,12 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             a2.last_B = B
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
-                # (700 MB of streaming) rides in the CIN weight-gradient launches, which are MFMA-bound; the touched rows
+                # (700 MB of streaming) rides in the CIN forward and weight-gradient launches (MFMA work, little HBM); the touched rows
                 # and the dense variables follow the scatter in one small launch
                 c1, h1 = a1.adam_split_segments()
                 c2, h2 = a2.adam_split_segments()
                 w = [float(store.cin_sizes[k]) * (a1.F if k == 0 else store.cin_sizes[k - 1]) for k in range(len(store.cin_sizes))]
-                share = float(os.environ.get("RSX_CIN_FWD_SHARE", "0.3"))    # part of the sweep carried by the forward launches
+                share = 0.5                      # part of the sweep carried by the forward launches (measured best)
                 tw = sum(w)
                 sweeps = store.opt.cold_slices(c1 + c2, [share * x / tw for x in w] + [(1.0 - share) * x / tw for x in w])
                 hot = h1 + h2
