@@ -354,7 +354,9 @@ int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const fl
                       const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW,
                       float* dc, float* dpre_ws, int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h,
                       rsx_stream_t stream);
-/* dpre_ws: B*N*D floats of scratch (the relu-masked dout, written by the dX launch and read by the dW launch).       */
+/* dpre_ws: rsx_cin_bwd_workspace_floats(B, F, H, N) floats of scratch (the relu-masked dout, written by the dX launch and
+ * read by the dW launch, followed by the per-h-tile partial sums of dX0).                                             */
+size_t rsx_cin_bwd_workspace_floats(int B, int F, int H, int N);
 /* sweep_h (nullable): a slice of the untouched-row optimizer sweep carried by extra workgroups of the dW launch (the
  * MFMA-bound tiles leave HBM idle), as on the tower entry points.                                                  */
 /* 'cin_net' output head, xdeepfm/xdeepfm.py:180-182 (concat of the L layer maps on axis 1, reduce_sum over d, dense(1, relu)):

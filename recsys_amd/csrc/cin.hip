@@ -340,6 +340,173 @@ __global__ __launch_bounds__(768) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------- backward: dXk, dX0 (tiled)
+// The same math as cin_bwd_dx_k with the weight slice SHARED between examples: grid = (ceil(H/16), ceil(B/EB)), block =
+// 64 * EB * FS.  Wave (e, part) owns example b0 + e and the fields f = part (mod FS); per step the workgroup copies the FS
+// slices W_f[16 h][N] once (coalesced float4, double-buffered through registers while the previous step's MFMAs run) and
+// its waves read them back as MFMA A operands with ds_read_b128 -- 1/EB of the L2 -> L1 traffic of cin_bwd_dx_k, which is
+// bound by exactly that traffic (every workgroup there streams the whole W).  The <Xk, U_f> partial of this h tile goes
+// to part[ht][b][f][d]; cin_dx0_reduce_k adds the tiles in order.  Requires N % 4 == 0.
+template <int NSMAX, int EB, int FS>
+__global__ __launch_bounds__(64 * EB * FS) void cin_bwd_dx2_k(const CinBwdDxArgs p, float* __restrict__ part_ws) {
+  constexpr int NW = EB * FS, NTHR = 64 * NW;
+  constexpr int RMAX = (FS * 16 * 32 + NTHR - 1) / NTHR;     // float4 per thread per step at N = 128
+  static_assert(RMAX <= 4, "copy slots");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int NP = p.N + 4, N4 = p.N >> 2;
+  float* sW = lds;                              // [2][FS][16][NP]      (aliases sDp: dpre is consumed before the loop)
+  float* sDp = lds;                             // [EB][N*16]
+  const int r0 = 2 * FS * 16 * NP, r1 = EB * p.N * CIN_D;
+  float* sX0 = lds + (r0 > r1 ? r0 : r1);       // [EB][F*16]
+  float* sXk = sX0 + EB * p.F * CIN_D;          // [EB][16*16]  this h tile
+  float* sDx = sXk + EB * 256;                  // [FS][EB][256] dXk tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e = wave % EB, part = wave / EB;
+  const int ht = blockIdx.x, b0 = blockIdx.y * EB, b = b0 + e;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int bt = 0; bt < EB; ++bt) {
+    const int bb = b0 + bt;
+    for (int e4 = tid; e4 < p.N * 4; e4 += NTHR) {
+      float4 v = z4;
+      if (bb < p.B) {
+        const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)bb * p.N * CIN_D)[e4];
+        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)bb * p.N * CIN_D)[e4] : z4;
+        if (p.gs) {
+          const float a = p.gs[bb] * p.wout[e4 >> 2];
+          g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
+        }
+        v = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+        if (ht == 0) reinterpret_cast<float4*>(p.dpre + (size_t)bb * p.N * CIN_D)[e4] = v;
+      }
+      reinterpret_cast<float4*>(sDp + bt * p.N * CIN_D)[e4] = v;
+    }
+    for (int e4 = tid; e4 < p.F * 4; e4 += NTHR)
+      reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e4] =
+          bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[e4] : z4;
+    for (int e4 = tid; e4 < 64; e4 += NTHR) {
+      const int hh = ht * 16 + (e4 >> 2);
+      reinterpret_cast<float4*>(sXk + bt * 256)[e4] =
+          (bb < p.B && hh < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)bb * p.H + hh) * CIN_D)[e4 & 3] : z4;
+    }
+  }
+  __syncthreads();
+  const int i = lane & 15, kq = lane >> 4;
+  const int ns = (p.N + 15) >> 4;
+  f32x4 dxk = {0.f, 0.f, 0.f, 0.f};
+  float xkv[4];                             // Xk[b][h = 16 ht + 4 kq + r][d = i] (zero rows for h >= H)
+  float areg[NSMAX][4];                     // dpre[b][n = 16 s + 4 kq + t][d = i]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xkv[r] = sXk[e * 256 + (4 * kq + r) * CIN_D + i];
+#pragma unroll
+  for (int s_ = 0; s_ < NSMAX; ++s_)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = 16 * s_ + 4 * kq + t;
+      areg[s_][t] = n < p.N ? sDp[e * p.N * CIN_D + n * CIN_D + i] : 0.f;
+    }
+  __syncthreads();                          // sDp is dead: its space becomes the W double buffer
+  const int steps = (p.F + FS - 1) / FS;
+  const int slice4 = FS * 16 * N4;          // float4 per step
+  // per-thread copy slots (fixed over the steps): field part, offset of the float4 inside a field's [H][N] block, LDS offset
+  int cp_pf[RMAX], cp_g[RMAX], cp_l[RMAX];
+#pragma unroll
+  for (int k = 0; k < RMAX; ++k) {
+    const int idx0 = tid + k * NTHR;
+    const int idx = idx0 < slice4 ? idx0 : slice4 - 1;
+    const int pf = idx / (16 * N4), rem = idx - pf * 16 * N4;
+    const int r = rem / N4, c4 = rem - r * N4;
+    const int hh = ht * 16 + r < p.H ? ht * 16 + r : p.H - 1;
+    cp_pf[k] = pf;
+    cp_g[k] = hh * N4 + c4;
+    cp_l[k] = idx0 < slice4 ? (pf * 16 + r) * NP + c4 * 4 : -1;
+  }
+  const float4* W4 = reinterpret_cast<const float4*>(p.W);
+  const size_t fstride4 = (size_t)p.H * N4;
+  // the double buffer starts as zeros: the row pads and the columns past N that the fixed NSMAX reads touch must be finite
+  for (int e4 = tid; e4 < (2 * FS * 16 * NP) / 4; e4 += NTHR) reinterpret_cast<float4*>(sW)[e4] = z4;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RMAX; ++k) {
+    const int f = cp_pf[k] < p.F ? cp_pf[k] : p.F - 1;
+    const float4 v = W4[(size_t)f * fstride4 + cp_g[k]];
+    if (cp_l[k] >= 0) *reinterpret_cast<float4*>(sW + cp_l[k]) = v;
+  }
+  __syncthreads();
+  for (int s_ = 0; s_ < steps; ++s_) {
+    // next step's slices: global loads in flight during this step's MFMAs (clamped step: the last one reloads itself)
+    const int sn = s_ + 1 < steps ? s_ + 1 : s_;
+    float4 st0 = z4, st1 = z4, st2 = z4, st3 = z4;
+    {
+      const int f0_ = sn * FS + cp_pf[0] < p.F ? sn * FS + cp_pf[0] : p.F - 1;
+      st0 = W4[(size_t)f0_ * fstride4 + cp_g[0]];
+      if (RMAX > 1) { const int f1_ = sn * FS + cp_pf[RMAX > 1 ? 1 : 0] < p.F ? sn * FS + cp_pf[RMAX > 1 ? 1 : 0] : p.F - 1; st1 = W4[(size_t)f1_ * fstride4 + cp_g[RMAX > 1 ? 1 : 0]]; }
+      if (RMAX > 2) { const int f2_ = sn * FS + cp_pf[RMAX > 2 ? 2 : 0] < p.F ? sn * FS + cp_pf[RMAX > 2 ? 2 : 0] : p.F - 1; st2 = W4[(size_t)f2_ * fstride4 + cp_g[RMAX > 2 ? 2 : 0]]; }
+      if (RMAX > 3) { const int f3_ = sn * FS + cp_pf[RMAX > 3 ? 3 : 0] < p.F ? sn * FS + cp_pf[RMAX > 3 ? 3 : 0] : p.F - 1; st3 = W4[(size_t)f3_ * fstride4 + cp_g[RMAX > 3 ? 3 : 0]]; }
+    }
+    const int f = s_ * FS + part;
+    if (f < p.F) {                          // wave-uniform
+      const float* wr = sW + (((s_ & 1) * FS + part) * 16 + i) * NP + 4 * kq;
+      float4 bw[NSMAX];
+#pragma unroll
+      for (int u = 0; u < NSMAX; ++u) bw[u] = *reinterpret_cast<const float4*>(wr + 16 * u);   // all reads up front
+      f32x4 U = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NSMAX; ++u) {
+        if (u < ns) {                       // uniform
+          U = cin_mfma(bw[u].x, areg[u][0], U);
+          U = cin_mfma(bw[u].y, areg[u][1], U);
+          U = cin_mfma(bw[u].z, areg[u][2], U);
+          U = cin_mfma(bw[u].w, areg[u][3], U);
+        }
+      }
+      const float x = sX0[e * p.F * CIN_D + f * CIN_D + i];
+      dxk[0] += x * U[0];
+      dxk[1] += x * U[1];
+      dxk[2] += x * U[2];
+      dxk[3] += x * U[3];
+      float q = ((U[0] * xkv[0] + U[1] * xkv[1]) + U[2] * xkv[2]) + U[3] * xkv[3];
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (kq == 0 && b < p.B) part_ws[(((size_t)ht * p.B + b) * p.F + f) * CIN_D + i] = q;
+    }
+    float* dstb = sW + ((s_ + 1) & 1) * FS * 16 * NP;
+    if (cp_l[0] >= 0) *reinterpret_cast<float4*>(dstb + cp_l[0]) = st0;
+    if (RMAX > 1 && cp_l[RMAX > 1 ? 1 : 0] >= 0) *reinterpret_cast<float4*>(dstb + cp_l[RMAX > 1 ? 1 : 0]) = st1;
+    if (RMAX > 2 && cp_l[RMAX > 2 ? 2 : 0] >= 0) *reinterpret_cast<float4*>(dstb + cp_l[RMAX > 2 ? 2 : 0]) = st2;
+    if (RMAX > 3 && cp_l[RMAX > 3 ? 3 : 0] >= 0) *reinterpret_cast<float4*>(dstb + cp_l[RMAX > 3 ? 3 : 0]) = st3;
+    __syncthreads();
+  }
+  // dXk tiles -> LDS as [part][e][h_local][d], then float4 rows out (parts added in order)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sDx[((part * EB + e) * 16 + 4 * kq + r) * CIN_D + i] = dxk[r];
+  __syncthreads();
+  for (int e4 = tid; e4 < EB * 64; e4 += NTHR) {
+    const int ex = e4 >> 6, hl = (e4 & 63) >> 2, dq = e4 & 3;
+    const int hh = ht * 16 + hl, bb = b0 + ex;
+    if (hh < p.H && bb < p.B) {
+      float4 o = *reinterpret_cast<const float4*>(sDx + (ex * 16 + hl) * CIN_D + dq * 4);
+#pragma unroll
+      for (int pp = 1; pp < FS; ++pp)
+        o = f4_add(o, *reinterpret_cast<const float4*>(sDx + ((pp * EB + ex) * 16 + hl) * CIN_D + dq * 4));
+      float4* dst = reinterpret_cast<float4*>(p.dXk + ((size_t)bb * p.H + hh) * CIN_D + dq * 4);
+      if (p.acc_dxk) o = f4_add(*dst, o);
+      *dst = o;
+    }
+  }
+}
+
+// dX0[b][f][d] (=|+=) sum over the h tiles, in tile order
+__global__ __launch_bounds__(256) void cin_dx0_reduce_k(const float* __restrict__ part_ws, float* __restrict__ dX0, int HT,
+                                                        long long n4, int acc) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  float4 s = reinterpret_cast<const float4*>(part_ws)[e];
+  for (int t = 1; t < HT; ++t) s = f4_add(s, reinterpret_cast<const float4*>(part_ws)[(long long)t * n4 + e]);
+  float4* dst = reinterpret_cast<float4*>(dX0) + e;
+  if (acc) s = f4_add(*dst, s);
+  *dst = s;
+}
+
 // ----------------------------------------------------------------------------------------------- backward: dW, dc
 struct CinBwdDwArgs {
   const float* X0; const float* Xk; const float* dpre;   // dpre [B, N, 16] = relu-masked dout (written by cin_bwd_dx_k)
@@ -514,6 +681,11 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
   return RSX_OK;
 }
 
+extern "C" size_t rsx_cin_bwd_workspace_floats(int B, int F, int H, int N) {
+  if (B <= 0 || F <= 0 || H <= 0 || N <= 0) return 0;
+  return (size_t)B * N * CIN_D + (size_t)((H + 15) / 16) * B * F * CIN_D;     // dpre + per-h-tile dX0 partials
+}
+
 extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* W, const float* out, const float* dout,
                                  const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0, float* dW, float* dc, float* dpre_ws,
                                  int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
@@ -524,20 +696,42 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   if (dXk == dX0 && !(Xk == X0 && acc_dx0)) return RSX_EINVAL;   // one buffer only for the first layer, accumulating
   if (D != CIN_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int HT = (H + 15) / 16;
-  const int FS = HT <= 3 ? 4 : HT <= 4 ? 2 : 1;   // waves = HT * FS <= 12, an even load for the 4 SIMDs
-  const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D + (size_t)FS * HT * CIN_BT * 256) * sizeof(float);
-  if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
-  if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return RSX_ELAUNCH;
-  }
   CinBwdDxArgs a{X0, Xk, W, out, dout, gs, wout, dXk, dX0, dpre_ws, acc_dxk, acc_dx0, B, F, H, N, HT};
-  if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
-  else hipLaunchKernelGGL(cin_bwd_dx_k<8>, dim3((B + CIN_BT - 1) / CIN_BT), dim3(64 * HT * FS), lds, rsx_s(stream), a);
-  RSX_CHECK_LAUNCH();
+  static const int dx_force = getenv("RSX_CIN_DX") ? atoi(getenv("RSX_CIN_DX")) : -1;
+  // Many h tiles (H > 64): weight slices shared by 4 examples through LDS (measured 131 vs 137 us backward at H = N = 128);
+  // few: one workgroup per example with the rows in registers (66 vs 75 us at H = 39).
+  const bool tiled = (N & 3) == 0 && (dx_force >= 0 ? dx_force != 0 : HT >= 5);
+  if (tiled) {
+    const int EB = 4, FS = 1;
+    const int NP = N + 4;
+    const size_t r0 = (size_t)2 * FS * 16 * NP, r1 = (size_t)EB * N * CIN_D;
+    const size_t lds = ((r0 > r1 ? r0 : r1) + (size_t)EB * F * CIN_D + (size_t)EB * 256 + (size_t)FS * EB * 256) * sizeof(float);
+    if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
+    float* part_ws = dpre_ws + (size_t)B * N * CIN_D;
+    const dim3 grid(HT, (B + EB - 1) / EB), block(64 * EB * FS);
+    if (N <= 32) hipLaunchKernelGGL((cin_bwd_dx2_k<2, 4, 1>), grid, block, lds, rsx_s(stream), a, part_ws);
+    else hipLaunchKernelGGL((cin_bwd_dx2_k<8, 4, 1>), grid, block, lds, rsx_s(stream), a, part_ws);
+    RSX_CHECK_LAUNCH();
+    const long long n4 = (long long)B * F * 4;
+    hipLaunchKernelGGL(cin_dx0_reduce_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, rsx_s(stream), part_ws, dX0, HT, n4,
+                       acc_dx0);
+    RSX_CHECK_LAUNCH();
+  } else {
+    const int FS = HT <= 3 ? 4 : HT <= 4 ? 2 : 1;   // waves = HT * FS <= 12, an even load for the 4 SIMDs
+    const size_t lds = ((size_t)CIN_BT * (N + F + H) * CIN_D + (size_t)HT * CIN_BT * F * CIN_D + (size_t)FS * HT * CIN_BT * 256) * sizeof(float);
+    if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
+    if (lds > 64 * 1024) {   // gfx950 has 160 KiB of LDS per CU; above 64 KiB the kernel must opt in (host-side attribute)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bwd_dx_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return RSX_ELAUNCH;
+    }
+    const dim3 grid((B + CIN_BT - 1) / CIN_BT), block(64 * HT * FS);
+    if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, grid, block, lds, rsx_s(stream), a);
+    else hipLaunchKernelGGL(cin_bwd_dx_k<8>, grid, block, lds, rsx_s(stream), a);
+    RSX_CHECK_LAUNCH();
+  }
   // Wave tile = FT fields x 16 h x (NT x 16) n, NW waves split the batch.  The configuration is chosen for BALANCE first
   // (workgroups are equal-sized: ceil(WGs / 256 CUs) rounds of FT*NT work each), then for the larger tile (fewer operand
   // bytes per MFMA).

@@ -734,7 +734,7 @@ class CinLayerFn(torch.autograd.Function):
         H, N = Xk.shape[1], W.shape[1]
         dX0, dXk = torch.empty_like(X0), torch.empty_like(Xk)
         dW, dc = torch.empty_like(W), torch.empty(N, device=W.device)
-        ws = torch.empty_like(out)
+        ws = torch.empty(int(lib().rsx_cin_bwd_workspace_floats(B, F, H, N)), device=W.device)
         check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(W), _ptr(out), _ptr(g.contiguous()), None, None, _ptr(dXk), 0, _ptr(dX0),
                                       0, _ptr(dW), _ptr(dc), _ptr(ws), B, F, H, N, D,
                                       None if ctx.sweep is None else C.byref(ctx.sweep), _stream()), "rsx_cin_layer_bwd")
@@ -752,7 +752,8 @@ class CinNet:
         self.F, self.D, self.sizes, self.L = F, D, [int(n) for n in sizes], len(sizes)
         self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
         self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
-        self.dpre = torch.empty(capacity, max(self.sizes), D, device=dev)
+        hs = [F] + self.sizes[:-1]
+        self.dpre = torch.empty(max(int(lib().rsx_cin_bwd_workspace_floats(capacity, F, h, n)) for h, n in zip(hs, self.sizes)), device=dev)
         self.dX0 = torch.empty(capacity, F, D, device=dev)
         self.y, self.gs = torch.empty(capacity, device=dev), torch.empty(capacity, device=dev)
         self._sizes_h = (C.c_int32 * self.L)(*self.sizes)
