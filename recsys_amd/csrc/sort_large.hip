@@ -25,6 +25,7 @@ struct LargeSort {
   int32_t* valA;            // [F, stride]
   int32_t* perm;            // [F, stride]  final example indices
   int32_t* hist;            // [F, LS_BINS, nT]
+  int32_t* dtot;            // [2 passes, F, LS_BINS] digit totals (integer atomics: order-independent), zeroed by the transpose
   int B, F, stride, nT;
 };
 
@@ -44,6 +45,8 @@ __global__ __launch_bounds__(1024) void ls_transpose_k(const LargeSort a) {
   if (b0 + ty < a.B && f0 + tx < a.F) tile[ty][tx] = a.ids[(size_t)(b0 + ty) * a.F + f0 + tx];
   __syncthreads();
   if (f0 + ty < a.F && b0 + tx < a.B) a.idsT[(size_t)(f0 + ty) * a.stride + b0 + tx] = tile[tx][ty];
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < 2 * a.F * LS_BINS; i += 1024) a.dtot[i] = 0;
 }
 
 // grid (nT, F).  pass 0 reads idsT; pass 1 reads keyA.
@@ -62,11 +65,47 @@ __global__ __launch_bounds__(LS_T) void ls_hist_k(const LargeSort a, int pass) {
     if (i < a.B) atomicAdd(&h[((uint32_t)src[i] >> sh) & mask], 1u);
   }
   __syncthreads();
-  for (int d = tid; d < LS_BINS; d += LS_T) a.hist[((size_t)f * LS_BINS + d) * a.nT + t] = (int32_t)h[d];
+  for (int d = tid; d < LS_BINS; d += LS_T) {
+    a.hist[((size_t)f * LS_BINS + d) * a.nT + t] = (int32_t)h[d];
+    if (h[d]) atomicAdd(&a.dtot[((size_t)pass * a.F + f) * LS_BINS + d], (int32_t)h[d]);
+  }
 }
 
-// grid F, block 512: exclusive scan of hist[f] in (digit-major, tile-minor) order, in place.
-__global__ __launch_bounds__(LS_BINS) void ls_scan_k(const LargeSort a) {
+// grid F * LS_BINS / 4, block 256: exclusive scan of hist[f] in (digit-major, tile-minor) order, in place.  One wave per
+// (field, digit): its base is the sum of the smaller digits' totals (accumulated by ls_hist_k), its tiles are scanned 64 at a
+// time with lane shuffles.  (One workgroup per field walking the tiles serially cost 16 us at F = 1.)
+__global__ __launch_bounds__(256) void ls_scan_k(const LargeSort a, int pass) {
+  const int wid = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int f = wid / LS_BINS, d = wid - f * LS_BINS;
+  if (f >= a.F) return;
+  const int32_t* tot = a.dtot + ((size_t)pass * a.F + f) * LS_BINS;
+  int base = 0;
+#pragma unroll
+  for (int k = 0; k < LS_BINS / 64; ++k) {
+    const int dd = lane + 64 * k;
+    const int v = tot[dd];
+    base += dd < d ? v : 0;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) base += __shfl_xor(base, m);
+  int32_t* h = a.hist + ((size_t)f * LS_BINS + d) * a.nT;
+  for (int t0 = 0; t0 < a.nT; t0 += 64) {
+    const int t = t0 + lane;
+    const int c = t < a.nT ? h[t] : 0;
+    int incl = c;
+#pragma unroll
+    for (int s_ = 1; s_ < 64; s_ <<= 1) {
+      const int o = __shfl_up(incl, s_);
+      if (lane >= s_) incl += o;
+    }
+    if (t < a.nT) h[t] = base + incl - c;
+    base += __shfl(incl, 63);
+  }
+}
+
+// grid F, block 512: the same scan with one workgroup per field, each thread walking its digit's tiles (many fields: the
+// fields themselves fill the chip and the per-digit version's re-reads of the totals cost more than they save).
+__global__ __launch_bounds__(LS_BINS) void ls_scan_field_k(const LargeSort a) {
   __shared__ int wsum[LS_BINS / 64];
   const int f = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
   int32_t* h = a.hist + ((size_t)f * LS_BINS + d) * a.nT;
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(256) void ls_long_lists_k(const LargeSeg a) {
 extern "C" size_t rsx_field_sort_large_workspace_ints(int B, int F, int stride) {
   (void)B;
   const size_t nT = ((size_t)stride + LS_TILE - 1) / LS_TILE, nblk = ((size_t)stride + SG_BLK - 1) / SG_BLK;
-  return (size_t)3 * F * stride + (size_t)F * LS_BINS * nT + (size_t)F * nblk;
+  return (size_t)3 * F * stride + (size_t)F * LS_BINS * nT + (size_t)F * nblk + (size_t)2 * F * LS_BINS;
 }
 
 extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
@@ -303,10 +342,12 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   a.valA = workspace + (size_t)2 * F * stride;
   a.hist = workspace + (size_t)3 * F * stride;
   const size_t nT_cap = ((size_t)stride + LS_TILE - 1) / LS_TILE;
+  a.dtot = a.hist + (size_t)F * LS_BINS * nT_cap + (size_t)F * (((size_t)stride + SG_BLK - 1) / SG_BLK);
   hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     hipLaunchKernelGGL(ls_hist_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
-    hipLaunchKernelGGL(ls_scan_k, dim3(F), dim3(LS_BINS), 0, st, a);
+    if (F >= 16) hipLaunchKernelGGL(ls_scan_field_k, dim3(F), dim3(LS_BINS), 0, st, a);
+    else hipLaunchKernelGGL(ls_scan_k, dim3((unsigned)((F * LS_BINS + 3) / 4)), dim3(256), 0, st, a, pass);
     hipLaunchKernelGGL(ls_scatter_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
   }
   RSX_CHECK_LAUNCH();
@@ -314,6 +355,7 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   g.keys = a.idsT; g.row_off = row_off; g.seg_off = seg_off; g.uniq_row = uniq_row; g.nuniq = nuniq; g.slot = slot;
   g.segid = segid;
   g.blk_cnt = a.hist + (size_t)F * LS_BINS * nT_cap;
+  // (a.dtot sits after blk_cnt's F * nblk ints)
   g.B = B; g.F = F; g.stride = stride; g.nblk = (B + SG_BLK - 1) / SG_BLK;
   hipLaunchKernelGGL(ls_heads_k, dim3(g.nblk, F), dim3(SG_T), 0, st, g);
   hipLaunchKernelGGL(ls_emit_k, dim3(g.nblk, F), dim3(SG_T), 0, st, g);

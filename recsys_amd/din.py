@@ -81,7 +81,8 @@ def _attention(tbl, hist, q, P_, pre, training, rate, masks, store=None, layer0=
         r = rate if training else 0.0
         w = DinAttnFn.apply(H, q, P_[f"{pre}.W0"], P_[f"{pre}.b0"], P_[f"{pre}.W1"], P_[f"{pre}.b1"], P_[f"{pre}.W2"],
                             P_[f"{pre}.b2"], r, masks if (training and r > 0.0) else None,
-                            store.opt.state.view(torch.int32)[3:4], 0xD1A77, layer0)
+                            store.opt.state.view(torch.int32)[3:4], 0xD1A77, layer0,
+                            P_.packed_grad([f"{pre}.{v}{i}" for i in range(3) for v in ("W", "b")]) if training else None)
         return DinPoolFn.apply(H, w, hist)                                  # masked weighted sum (:122-124)
     hist_emb = H.reshape(B * Pn, K)
     query_emb = q[:, None, :].expand(B, Pn, K).reshape(B * Pn, K)          # tile + reshape (:111)

@@ -317,6 +317,18 @@ class DenseArena:
         return [dict(kind=_lib.RSX_ADAM_DENSE, n=self.n, var=self.flat, m=self.m, v=self.v, g=self.grad,
                      zero_grad=1)]
 
+    def packed_grad(self, names):
+        """The grad-arena slice covering `names` when they sit back to back without padding (every size but the last a
+        multiple of 4) -- a kernel that emits their gradients as one flat array can then write straight into it.  None if
+        they are not packed."""
+        o = self.offsets[names[0]]
+        e = o
+        for k in names:
+            if self.offsets[k] != e:
+                return None
+            e += self.params[k].numel()
+        return self.grad[o:e]
+
 
 class AdamTF1:
     """tf.train.AdamOptimizer (fm/fm.py:162): one rsx_adam_tf1_multi launch per step over every segment."""
@@ -672,7 +684,10 @@ class DinAttnFn(torch.autograd.Function):
         return K in (16, 32) and N1 <= 80 and N2 <= 48
 
     @staticmethod
-    def forward(ctx, H, q, W0, b0, W1, b1, W2, b2, rate, masks, rng_step, seed, layer0):
+    def forward(ctx, H, q, W0, b0, W1, b1, W2, b2, rate, masks, rng_step, seed, layer0, grad_out=None):
+        """grad_out: optional flat fp32 buffer [dW0|db0|dW1|db1|dW2|db2] (e.g. the dense arena's grad slice of these six
+        variables, DenseArena.packed_grad): the backward kernel writes the weight gradients THERE and autograd gets None for
+        them -- no per-variable accumulate launches."""
         B, P, K = H.shape
         N1, N2 = W0.shape[1], W1.shape[1]
         H, q = H.contiguous(), q.contiguous()
@@ -685,6 +700,7 @@ class DinAttnFn(torch.autograd.Function):
                                      N1, N2, _stream()), "rsx_din_attn_fwd")
         ctx.save_for_backward(H, q, W0, W1, W2, a1, a2)
         ctx.cfg = (rate, m1, m2, rng_step, seed, layer0)
+        ctx.grad_out = grad_out
         return w
 
     @staticmethod
@@ -696,7 +712,11 @@ class DinAttnFn(torch.autograd.Function):
         dev = H.device
         dH, dq = torch.empty_like(H), torch.empty_like(q)
         n0, n1 = 4 * K * N1, N1 * N2
-        grads = torch.empty(n0 + N1 + n1 + 2 * N2 + 1, device=dev)
+        ng = n0 + N1 + n1 + 2 * N2 + 1
+        direct = ctx.grad_out is not None
+        if direct:
+            assert ctx.grad_out.is_contiguous() and ctx.grad_out.numel() >= ng
+        grads = ctx.grad_out if direct else torch.empty(ng, device=dev)
         ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2)), device=dev)
         check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2),
                                      _ptr(g.contiguous()), _ptr(dH), _ptr(dq), _ptr(grads), _ptr(ws), _ptr(m1), _ptr(m2),
@@ -707,7 +727,9 @@ class DinAttnFn(torch.autograd.Function):
             out.append(grads[o:o + n].view(shape))
             o += n
         dW0, db0, dW1, db1, dW2, db2 = out
-        return dH, dq, dW0, db0, dW1, db1, dW2, db2, None, None, None, None, None
+        if direct:
+            return (dH, dq) + (None,) * 12
+        return dH, dq, dW0, db0, dW1, db1, dW2, db2, None, None, None, None, None, None
 
 
 class CinLayerFn(torch.autograd.Function):

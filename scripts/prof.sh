@@ -15,8 +15,8 @@ c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 mid = len(rows) // 2
 print("\n# timeline sample (us from first row; one training step ~ between two field_sort_k):")
-for r in rows[mid:mid + 40]:
-    print("%-60s start=%10.2f dur=%8.2f" % (r[0][:60], (r[1] - rows[mid][1]) / 1e3, (r[2] - r[1]) / 1e3))
+for r in rows[mid:mid + 130]:
+    print("%-150s start=%10.2f dur=%8.2f" % (r[0][:150], (r[1] - rows[mid][1]) / 1e3, (r[2] - r[1]) / 1e3))
 PY
 grep metric $root/gpurun_out/$name.log | cut -c1-300
 rm -rf /tmp/prof_$name
