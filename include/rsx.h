@@ -229,6 +229,9 @@ int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
  *   DEVICE uint32 that changes every step, e.g. word 3 of the Adam state); dy_l [B,N_l] grad wrt BN_l output;
  *   bstat_l double[RT,2,N_l] partial (sum dy, sum dy*xhat).
  * K_l % 4 == 0; head width N <= 256.
+ * Layers WITHOUT batch-norm (din/din.py:132-137: dense(relu) -> dropout): pass gamma = beta = NULL for that layer on every
+ * entry point (and bn_prev_out / dgamma / dbeta NULL); the statistics workspaces are still required (fstat_prev / bn_prev
+ * non-NULL is what marks "there is a previous layer") but their contents are not used.
  * ------------------------------------------------------------------------------------------- */
 /* Batches > 512: every statistics buffer (fstat_l, bstat_l) must be folded by this call between its producer and its
  * consumer (row 0 then holds the column totals and consumers read one row); a no-op for B <= 512.               */

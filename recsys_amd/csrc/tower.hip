@@ -141,6 +141,11 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   const bool first = p.fstat_prev == nullptr;
   if (!first) {
     for (int k = tid; k < p.K; k += 256) {
+      if (p.gamma_prev == nullptr) {   // previous layer without batch-norm (din/din.py MLP): dropout only
+        sc[k] = 1.f;
+        sh[k] = 0.f;
+        continue;
+      }
       float mean, rstd;
       bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.B, mean, rstd);
       const float inv = rstd * p.gamma_prev[k];
@@ -258,6 +263,10 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
   __shared__ double hred[4][8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int c = tid; c < p.N; c += 256) {
+    if (p.gamma == nullptr) {   // no batch-norm on the last layer: dy_last is the gradient wrt the dropout input
+      sc[c] = 1.f; sh[c] = 0.f; mu[c] = 0.f; rs[c] = 0.f;
+      continue;
+    }
     float mean, rstd;
     bn_col_stats(p.fstat_last, p.RT, p.N, c, p.B, mean, rstd);
     const float inv = rstd * p.gamma[c];
@@ -435,6 +444,10 @@ __device__ __forceinline__ ColBwd bwd_col(const BwdArgs& p, int c) {
   double s1, s2;
   col_partials(p.bstat, p.RT, p.N, c, s1, s2);
   ColBwd o;
+  if (p.gamma == nullptr) {   // layer without batch-norm: da_of passes dy through the relu mask
+    o.mean = 0.f; o.rstd = 0.f; o.k1 = 0.f; o.sdy = 0.f; o.sdx = 0.f;
+    return o;
+  }
   o.mean = p.bn[c];
   o.rstd = p.bn[p.N + c];
   o.k1 = p.gamma[c] * o.rstd / (float)p.B;
@@ -442,8 +455,9 @@ __device__ __forceinline__ ColBwd bwd_col(const BwdArgs& p, int c) {
   o.sdx = (float)s2;
   return o;
 }
-__device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float Bf) {
+__device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float Bf, bool nobn = false) {
   if (a <= 0.f) return 0.f;
+  if (nobn) return dy;
   const float xh = (a - c.mean) * c.rstd;
   return c.k1 * (Bf * dy - c.sdy - xh * c.sdx);
 }
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   if (SPLIT) bid = bid < p.n_dw ? bid + p.n_din : (bid < p.n_dw + p.n_din ? bid - p.n_dw : bid);
   const float Bf = (float)p.B;
   const bool first = p.bn_prev == nullptr;
+  const bool nobn = p.gamma == nullptr;          // this layer has no batch-norm (uniform)
   const int i = lane & 15, kq = lane >> 4;
   if (bid < p.n_din) {
     // ---- d(input) tile: rows rt*16.., input columns kc*16.. ; reduction over the N outputs ----------
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         const int nc = n < p.N ? n : p.N - 1;
         const float nf = n < p.N ? 1.f : 0.f;
         ColBwd cb; cb.mean = Lm[nc]; cb.rstd = Lr[nc]; cb.k1 = Lk[nc]; cb.sdy = Ls[nc]; cb.sdx = Lx[nc];
-        a[t] = da_of(ar[t], dyr[t], cb, Bf) * (rok ? nf : 0.f);
+        a[t] = da_of(ar[t], dyr[t], cb, Bf, nobn) * (rok ? nf : 0.f);
         b[t] = wr[t] * (cok ? nf : 0.f);
       }
     });
@@ -555,13 +570,13 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
     const ColBwd cb = bwd_col(p, nok ? ncol : 0);     // unconditional (clamped column): no branch around its loads
     float fsc = 1.f, fsh = 0.f;
-    if (!first && fok) {
+    if (!first && fok && p.gamma_prev != nullptr) {   // (previous layer without batch-norm: identity)
       const float inv = p.bn_prev[p.K + feat] * p.gamma_prev[feat];
       fsc = inv;
       fsh = p.beta_prev[feat] - p.bn_prev[feat] * inv;
     }
     const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
-    if (kf == 0 && sbi == 0 && nok && tid < 16) {   // lanes 0..15 of wave 0 hold the column constants
+    if (kf == 0 && sbi == 0 && nok && tid < 16 && !nobn) {   // lanes 0..15 of wave 0 hold the column constants
       p.dgamma[ncol] = cb.sdx;
       p.dbeta[ncol] = cb.sdy;
     }
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         if (!first) x = (x * fsc + fsh) * drop_mul(dr, p.mask_prev, (size_t)(bb < p.B ? bb : p.B - 1) * p.K + featc);
         x = fok ? x : (ones ? 1.f : 0.f);
         a[t] = x * vf;
-        b[t] = da_of(ar[t], dyr[t], cb, Bf) * (nok ? vf : 0.f);
+        b[t] = da_of(ar[t], dyr[t], cb, Bf, nobn) * (nok ? vf : 0.f);
       }
     });
     if (SPLIT) {      // partial tile; tower_reduce_dw_k adds the sb partials in ascending block order
@@ -751,7 +766,9 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   if (B == 0) return RSX_OK;
   if (!in || !W || !bias || !a_out) return RSX_EINVAL;
   if (K % 4 != 0) return RSX_EUNSUPPORTED;
-  if (fstat_prev != nullptr && (!gamma_prev || !beta_prev || !bn_prev_out)) return RSX_EINVAL;
+  // previous layer with batch-norm: gamma, beta and bn_prev_out all given; without (din MLP): all three NULL
+  if (fstat_prev != nullptr && gamma_prev != nullptr && (!beta_prev || !bn_prev_out)) return RSX_EINVAL;
+  if (gamma_prev == nullptr && (beta_prev || bn_prev_out)) return RSX_EINVAL;
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   FwdArgs p;
   p.in = in; p.W = W; p.bias = bias; p.a_out = a_out; p.fstat_out = fstat_out;
@@ -786,9 +803,9 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   if (B < 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (N > 256) return RSX_EUNSUPPORTED;
-  if (!a_last || !fstat_last || !gamma || !beta || !bn_out || !wd || !bd || !labels || !prob || !dy_last ||
-      !bstat_last || !dwd_part || !hpart)
+  if (!a_last || !fstat_last || !wd || !bd || !labels || !prob || !dy_last || !bstat_last || !dwd_part || !hpart)
     return RSX_EINVAL;
+  if (gamma != nullptr ? (!beta || !bn_out) : (beta != nullptr)) return RSX_EINVAL;   // gamma NULL: no batch-norm
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   HeadArgs p;
   p.a_last = a_last; p.fstat_last = fstat_last; p.gamma = gamma; p.beta = beta; p.mask = mask; p.bn_out = bn_out;
@@ -899,9 +916,10 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    float* dw_partials, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  if (!in || !W || !a || !dy || !bstat || !bn || !gamma || !dW || !db || !dgamma || !dbeta || !dy_prev)
-    return RSX_EINVAL;
-  if (bn_prev != nullptr && (!gamma_prev || !beta_prev || !bstat_prev)) return RSX_EINVAL;
+  if (!in || !W || !a || !dy || !bstat || !bn || !dW || !db || !dy_prev) return RSX_EINVAL;
+  if (gamma != nullptr && (!dgamma || !dbeta)) return RSX_EINVAL;           // gamma NULL: this layer has no batch-norm
+  if (bn_prev != nullptr && !bstat_prev) return RSX_EINVAL;
+  if (bn_prev != nullptr && gamma_prev != nullptr && !beta_prev) return RSX_EINVAL;   // gamma_prev NULL: previous layer has none
   if (hpart != nullptr && (!dwd_part || !dwd || !dbd || !loss)) return RSX_EINVAL;
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   BwdArgs p;

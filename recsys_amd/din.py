@@ -14,7 +14,7 @@ import torch
 from . import layers as L
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
-from .ops import DinAttnFn, DinPoolFn, SparseTable
+from .ops import DinAttnFn, DinPoolFn, FusedTower, SparseTable
 
 ATTENTION_LAYERS = [80, 40]      # din/din.py:85 (the din_layers flag is ignored by the reference)
 MLP_LAYERS = [100, 50, 20]       # din/din.py:86 (the deep_layers flag is ignored by the reference)
@@ -66,7 +66,44 @@ def build_variables(store, params, B, P):
     shapes["mlp.Wout"], shapes["mlp.bout"] = (d, 1), (1,)
     init["mlp.Wout"] = lambda t, g, fi=d: L.glorot_uniform_(t, fi, 1, g)
     init["mlp.bout"] = zeros
-    store.build({"i_id": item, "i_cate": cate, "i_item": bias}, shapes, init, params["learning_rate"])
+    # The fused tower reads activation rows as float4: layer widths are STORED padded to a multiple of 4 (50 -> 52); the
+    # variables keep their reference shapes as leading slices, the pad units have zero weights, zero bias, zero gradient.
+    pad4 = lambda n: (n + 3) & ~3
+    widths = [pad4(n) for n in MLP_LAYERS]
+    storage, dprev = {}, 3 * K
+    for i, n in enumerate(widths):
+        storage[f"mlp.W{i}"], storage[f"mlp.b{i}"] = (dprev, n), (n,)
+        dprev = n
+    storage["mlp.Wout"] = (dprev, 1)
+    store.build({"i_id": item, "i_cate": cate, "i_item": bias}, shapes, init, params["learning_rate"], storage)
+    store.tower = None
+    if (3 * K) % 4 == 0 and widths[-1] <= 256:
+        store.tower = FusedTower(store.dense, "mlp", 3 * K, widths, B, store.device, batch_norm=False)
+
+
+class DinHeadFn(torch.autograd.Function):
+    """'mlp_layer' + logits + loss of the TRAIN step (din/din.py:131-147) through the fused tower kernels (csrc/tower.hip,
+    no batch-norm): forward AND backward run inside forward(); backward() hands the stored input gradients to autograd
+    (the attention / pooling / lookups upstream stay autograd Functions).  The loss already carries the 1/(B*replicas)
+    scale, so backward() expects an incoming gradient of 1."""
+
+    @staticmethod
+    def forward(ctx, X, i_b, labels, store, rate, masks, replicas):
+        t = store.tower
+        if masks is not None:       # injected keep masks (parity tests) arrive with the reference widths: pad to storage
+            masks = [torch.nn.functional.pad(m, (0, w - m.shape[1]), value=1.0) for m, w in zip(masks, t.widths)]
+        loss, prob, dX, gs0, _ = t.train_step(
+            X.contiguous(), labels.reshape(-1).to(torch.float32), rate, store.opt.state.view(torch.int32)[3:4],
+            s0=i_b.contiguous(), head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=replicas,
+            masks=masks, seed=0xD1AD)
+        ctx.save_for_backward(dX, gs0)
+        ctx.mark_non_differentiable(prob)
+        return loss[0], prob
+
+    @staticmethod
+    def backward(ctx, g_loss, g_prob):
+        dX, gs0 = ctx.saved_tensors
+        return dX, gs0, None, None, None, None, None
 
 
 def _attention(tbl, hist, q, P_, pre, training, rate, masks, store=None, layer0=0):
@@ -116,6 +153,21 @@ def model_fn(features, labels, mode, params):
     pkg_emb_h = _attention(item, hist_i, pkg_emb, P_, "att_i", training, rate, mk.get("att_i"), fused, 0)
     pkgc_emb_h = _attention(cate, hist_c, pkgc_emb, P_, "att_c", training, rate, mk.get("att_c"), fused, 2)
     net = torch.cat([pkg_emb, pkg_emb_h, pkgc_emb_h], 1)                   # 'mlp_layer' (:131)
+    fused_head = training and store.tower is not None and params.get("fused_head", True)
+    if fused_head:
+        dp = store.dp
+        loss, pred = DinHeadFn.apply(net, i_b, labels, store, rate, mk.get("mlp"), dp.world if dp is not None else 1)
+
+        def train_op_fused():                                              # AdamOptimizer.minimize (:172-173)
+            loss.backward()                                                # (1/world is inside the fused head's loss scale)
+            with torch.no_grad():
+                for tbl in (item, cate, bias):
+                    tbl.finalize(dp)
+                if dp is not None:
+                    dp.all_reduce_sum(store.dense.grad)
+                store.apply_gradients()
+
+        return EstimatorSpec(mode, predictions={"prob": pred}, loss=loss, train_op=train_op_fused)
     for i in range(len(MLP_LAYERS)):
         net = L.dense(net, P_[f"mlp.W{i}"], P_[f"mlp.b{i}"], relu=True)
         net = L.dropout(net, rate, training, mk["mlp"][i] if "mlp" in mk else None)

@@ -131,9 +131,9 @@ class VariableStore:
         self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
         self.graph_safe_dp = False   # set by model code whose DP collectives run outside autograd (segmentable)
 
-    def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr):
+    def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr, storage_shapes=None):
         self.embeddings = embeddings
-        self.dense = DenseArena(dense_shapes, self.device)
+        self.dense = DenseArena(dense_shapes, self.device, storage_shapes)
         with torch.no_grad():
             for k, fn in dense_init.items():
                 t = torch.empty(tuple(dense_shapes[k]))

@@ -282,14 +282,19 @@ class DenseArena:
     """All dense variables of a model as views into ONE flat fp32 buffer (and their grads / Adam slots
     likewise), so the optimizer sweeps them as a single segment."""
 
-    def __init__(self, shapes, device="cuda"):
+    def __init__(self, shapes, device="cuda", storage_shapes=None):
+        """storage_shapes: optional {name: padded shape}: the variable is STORED with that (larger) shape and exposed as the
+        leading slice of the logical shape (e.g. a [100, 50] kernel stored as [100, 52] so that a fused kernel sees row
+        strides that are multiples of 4).  Pad elements start at zero and, receiving zero gradients, stay zero."""
         dev = _require_cuda(device)
         self.names = list(shapes)
+        storage_shapes = storage_shapes or {}
+        self.storage = {k: tuple(storage_shapes.get(k, shapes[k])) for k in self.names}
         self.offsets = {}
         n = 0
         for k in self.names:
             self.offsets[k] = n
-            n += int(np.prod(shapes[k])) if len(shapes[k]) else 1
+            n += int(np.prod(self.storage[k])) if len(self.storage[k]) else 1
             n = (n + 3) & ~3                       # keep every variable 16-byte aligned
         self.n = n
         self.flat = torch.zeros(n, device=dev)
@@ -298,10 +303,13 @@ class DenseArena:
         self.v = torch.zeros(n, device=dev)
         self.params = {}
         for k in self.names:
-            sz = int(np.prod(shapes[k])) if len(shapes[k]) else 1
+            st = self.storage[k]
+            sz = int(np.prod(st)) if len(st) else 1
             o = self.offsets[k]
-            p = self.flat[o:o + sz].view(tuple(shapes[k])).requires_grad_()
-            p.grad = self.grad[o:o + sz].view(tuple(shapes[k]))
+            sl = tuple(slice(0, d) for d in shapes[k])
+            assert len(st) == len(shapes[k]) and all(a >= b for a, b in zip(st, shapes[k]))
+            p = self.flat[o:o + sz].view(st)[sl].requires_grad_()
+            p.grad = self.grad[o:o + sz].view(st)[sl]
             self.params[k] = p
 
     def __getitem__(self, k):
@@ -324,7 +332,7 @@ class DenseArena:
         o = self.offsets[names[0]]
         e = o
         for k in names:
-            if self.offsets[k] != e:
+            if self.offsets[k] != e or tuple(self.params[k].shape) != self.storage[k]:
                 return None
             e += self.params[k].numel()
         return self.grad[o:e]
@@ -397,8 +405,10 @@ class FusedTower:
     buffer; dX / gs0 / gs1 (gradients of the tower inputs) are returned for the embedding scatter.
     Mirrors deepfm/deepfm.py:100-112 (`dnn` scope + logits) with fm/fm.py:146-149 (loss)."""
 
-    def __init__(self, dense, pre, k0, widths, capacity, device="cuda"):
+    def __init__(self, dense, pre, k0, widths, capacity, device="cuda", batch_norm=True):
+        """batch_norm=False: L x [dense(relu) -> dropout] (din/din.py:132-137), no gamma/beta variables."""
         dev = _require_cuda(device)
+        self.bn_on = bool(batch_norm)
         self.P, self.pre, self.k0, self.widths = dense, pre, int(k0), [int(w) for w in widths]
         if self.k0 % 4 or any(w % 4 for w in self.widths[:-1]) or self.widths[-1] > 256:
             raise _lib.RsxError("FusedTower envelope: widths multiple of 4, last width <= 256 (use tower='torch')")
@@ -455,6 +465,8 @@ class FusedTower:
         mk = self._masks(B, rate, masks)
         nl = len(self.widths)
         g = lambda name: P[name].grad
+        bnp = (lambda name: _ptr(P[name])) if self.bn_on else (lambda name: None)        # gamma / beta (None: no batch-norm)
+        bng = (lambda name: _ptr(P[name].grad)) if self.bn_on else (lambda name: None)
         rs = _ptr(rng_step)
         sw = list(sweeps) if sweeps is not None else [None] * (2 * nl + 1)
         ref = lambda x: None if x is None else C.byref(x)
@@ -463,9 +475,9 @@ class FusedTower:
             check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
                                         _ptr(self.a[l]), _ptr(self.fstat[l]),
                                         _ptr(self.fstat[l - 1]) if l else None,
-                                        _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
-                                        _ptr(P[f"{pre}.beta{l - 1}"]) if l else None,
-                                        _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if l else None,
+                                        bnp(f"{pre}.gamma{l - 1}") if l else None,
+                                        bnp(f"{pre}.beta{l - 1}") if l else None,
+                                        _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if (l and self.bn_on) else None,
                                         rs, seed, l, rate, B, K, self.widths[l],
                                         ref(sort_job) if (l == 0 and sort_in_fwd) else None, ref(sw[l]), st),
                   "rsx_tower_fwd_layer")
@@ -475,8 +487,8 @@ class FusedTower:
         gv = lambda x: None if x is None else (P[x].grad if isinstance(x, str) else x[1])
         wd, bd, wo, bo = head
         n_last = self.widths[-1]
-        check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(self.fstat[-1]), _ptr(P[f"{pre}.gamma{nl - 1}"]),
-                               _ptr(P[f"{pre}.beta{nl - 1}"]), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)),
+        check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(self.fstat[-1]), bnp(f"{pre}.gamma{nl - 1}"),
+                               bnp(f"{pre}.beta{nl - 1}"), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)),
                                _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
                                _ptr(pv(bo)), _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
                                _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
@@ -488,10 +500,10 @@ class FusedTower:
             last = l == nl - 1
             check(L.rsx_tower_bwd_layer(
                 _ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(self.a[l]), _ptr(self.dy[l]),
-                _ptr(self.bstat[l]), _ptr(self.bn[l]), _ptr(P[f"{pre}.gamma{l}"]),
-                _ptr(g(f"{pre}.W{l}")), _ptr(g(f"{pre}.b{l}")), _ptr(g(f"{pre}.gamma{l}")), _ptr(g(f"{pre}.beta{l}")),
-                _ptr(self.bn[l - 1]) if l else None, _ptr(P[f"{pre}.gamma{l - 1}"]) if l else None,
-                _ptr(P[f"{pre}.beta{l - 1}"]) if l else None, _ptr(mk[l - 1]) if l else None,
+                _ptr(self.bstat[l]), _ptr(self.bn[l]), bnp(f"{pre}.gamma{l}"),
+                _ptr(g(f"{pre}.W{l}")), _ptr(g(f"{pre}.b{l}")), bng(f"{pre}.gamma{l}"), bng(f"{pre}.beta{l}"),
+                _ptr(self.bn[l - 1]) if l else None, bnp(f"{pre}.gamma{l - 1}") if l else None,
+                bnp(f"{pre}.beta{l - 1}") if l else None, _ptr(mk[l - 1]) if l else None,
                 _ptr(self.dy[l - 1]) if l else _ptr(self.dX), _ptr(self.bstat[l - 1]) if l else None,
                 _ptr(self.hpart) if last else None, _ptr(self.dwd_part) if last else None,
                 _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
