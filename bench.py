@@ -125,7 +125,8 @@ def main():
         rng = np.random.default_rng(synthetic.SEED + rank)
         raw = [synthetic.din_batch(rng, B) for _ in range(a.n_batches)]
         host = None
-        feats = [PackedBatch({k: v for k, v in b.items() if k != "label"}, b["label"], device=dev) for b in raw]
+        # id features narrowed to int32 on the host, as din.input_fn delivers them (ids_int32=True)
+        feats = [PackedBatch({k: v.astype(np.int32) for k, v in b.items() if k != "label"}, b["label"], device=dev) for b in raw]
     else:
         host = synthetic.criteo_id_batches(layout, a.n_batches, B, seed=synthetic.SEED + rank)
         # one packed HBM-resident buffer per batch (ids [+ log-values] + labels): no per-step input copy

@@ -215,7 +215,7 @@ def define_flags():
 
 def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, hist_len=100):
     from .input_pipeline import din_input_fn
-    return din_input_fn(filenames, batch_size, num_epochs, need_shuffle, hist_len=hist_len)
+    return din_input_fn(filenames, batch_size, num_epochs, need_shuffle, hist_len=hist_len, ids_int32=True)
 
 
 def main(argv=None):

@@ -136,8 +136,10 @@ def criteo_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, nu
 
 
 def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=6, hist_len=100,
-                 shuffle_buffer=1000, prefetch=16, seed=0):
-    """din/din.py:61-80: features {'i_id','i_cate' int64 [B]; 'u_iid_seq','u_icat_seq' int64 [B,P]}, labels int64 [B]."""
+                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False):
+    """din/din.py:61-80: features {'i_id','i_cate' int64 [B]; 'u_iid_seq','u_icat_seq' int64 [B,P]}, labels int64 [B].
+    ids_int32: narrow the id features to int32 on the HOST (the device kernels index with int32; like the Criteo parse,
+    which emits int32 row ids) so that the training step has no per-feature cast launches."""
     P = int(hist_len)
 
     def parse(buf, offs, lens):
@@ -146,6 +148,8 @@ def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_p
         hi, hc = np.empty((n, P), np.int64), np.empty((n, P), np.int64)
         check(lib().rsx_din_parse_h(_p(buf), _p(offs), _p(lens), n, P, _p(lab), _p(iid), _p(icat), _p(hi), _p(hc),
                                     int(num_parallel)), "rsx_din_parse_h")
+        if ids_int32:
+            iid, icat, hi, hc = (x.astype(np.int32) for x in (iid, icat, hi, hc))
         return {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab
 
     it = _batched(parse, list(filenames), batch_size, num_epochs)

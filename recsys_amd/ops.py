@@ -481,7 +481,8 @@ class FusedTower:
                                         rs, seed, l, rate, B, K, self.widths[l],
                                         ref(sort_job) if (l == 0 and sort_in_fwd) else None, ref(sw[l]), st),
                   "rsx_tower_fwd_layer")
-            check(L.rsx_tower_reduce_partials(_ptr(self.fstat[l]), B, self.widths[l], st))      # no-op for B <= 512
+            if self.bn_on:
+                check(L.rsx_tower_reduce_partials(_ptr(self.fstat[l]), B, self.widths[l], st))  # no-op for B <= 512
         # head parameters: a variable name, or an explicit (tensor, grad_tensor) pair (e.g. a slice of out.W)
         pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
         gv = lambda x: None if x is None else (P[x].grad if isinstance(x, str) else x[1])
@@ -494,7 +495,8 @@ class FusedTower:
                                _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
                                rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, ref(sw[nl]), st),
               "rsx_tower_head")
-        check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
+        if self.bn_on:
+            check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
         for l in reversed(range(nl)):
             K = self.k0 if l == 0 else self.widths[l - 1]
             last = l == nl - 1
@@ -512,7 +514,7 @@ class FusedTower:
                 rs, seed, l, rate, B, K, self.widths[l],
                 C.byref(sort_job) if (last and sort_job is not None and not sort_in_fwd) else None,
                 ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), st), "rsx_tower_bwd_layer")
-            if l:
+            if l and self.bn_on:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
         return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
 
