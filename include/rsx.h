@@ -80,6 +80,8 @@ int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, in
  * LSD radix sort over the id bits through global memory (transpose, 2 x {histogram, scan, stable scatter}, multi-workgroup
  * segment detection), all fields per launch.  workspace: rsx_field_sort_large_workspace_ints(B, F, stride) int32.
  * Envelope: max rows per field <= 2^18, B <= 2^24.  Works for any B >= 1; rsx_field_sort is faster below 16384.        */
+/* The workspace must be ZERO before its first use with a given (F, stride); every call leaves it reusable (the digit
+ * totals it accumulates with integer atomics are cleared again by the call itself).                                  */
 size_t rsx_field_sort_large_workspace_ints(int B, int F, int stride);
 int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
                          int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace,

@@ -25,7 +25,9 @@ struct LargeSort {
   int32_t* valA;            // [F, stride]
   int32_t* perm;            // [F, stride]  final example indices
   int32_t* hist;            // [F, LS_BINS, nT]
-  int32_t* dtot;            // [2 passes, F, LS_BINS] digit totals (integer atomics: order-independent), zeroed by the transpose
+  int32_t* dtot;            // [2 passes, F, LS_BINS] digit totals (integer atomics: order-independent); NULL: not used (many
+                            // fields).  All zero between calls: each pass's scatter launch clears what its scan consumed
+  const int32_t* src0;      // pass-0 keys: idsT, or ids itself when F == 1 (the transpose is then the identity)
   int B, F, stride, nT;
 };
 
@@ -45,8 +47,6 @@ __global__ __launch_bounds__(1024) void ls_transpose_k(const LargeSort a) {
   if (b0 + ty < a.B && f0 + tx < a.F) tile[ty][tx] = a.ids[(size_t)(b0 + ty) * a.F + f0 + tx];
   __syncthreads();
   if (f0 + ty < a.F && b0 + tx < a.B) a.idsT[(size_t)(f0 + ty) * a.stride + b0 + tx] = tile[tx][ty];
-  if (blockIdx.x == 0 && blockIdx.y == 0)
-    for (int i = threadIdx.x; i < 2 * a.F * LS_BINS; i += 1024) a.dtot[i] = 0;
 }
 
 // grid (nT, F).  pass 0 reads idsT; pass 1 reads keyA.
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(LS_T) void ls_hist_k(const LargeSort a, int pass) {
   const uint32_t mask = (1u << nb) - 1u;
   for (int i = tid; i < LS_BINS; i += LS_T) h[i] = 0;
   __syncthreads();
-  const int32_t* src = (pass == 0 ? a.idsT : a.keyA) + (size_t)f * a.stride;
+  const int32_t* src = (pass == 0 ? a.src0 : a.keyA) + (size_t)f * a.stride;
 #pragma unroll
   for (int k = 0; k < LS_TILE / LS_T; ++k) {
     const int i = t * LS_TILE + k * LS_T + tid;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(LS_T) void ls_hist_k(const LargeSort a, int pass) {
   __syncthreads();
   for (int d = tid; d < LS_BINS; d += LS_T) {
     a.hist[((size_t)f * LS_BINS + d) * a.nT + t] = (int32_t)h[d];
-    if (h[d]) atomicAdd(&a.dtot[((size_t)pass * a.F + f) * LS_BINS + d], (int32_t)h[d]);
+    if (a.dtot != nullptr && h[d]) atomicAdd(&a.dtot[((size_t)pass * a.F + f) * LS_BINS + d], (int32_t)h[d]);
   }
 }
 
@@ -161,8 +161,10 @@ __global__ __launch_bounds__(LS_T) void ls_scatter_k(const LargeSort a, int pass
   const uint32_t mask = (1u << nb) - 1u;
   for (int i = tid; i < (LS_T / 64) * LS_BINS; i += LS_T) (&cnt[0][0])[i] = 0;
   __syncthreads();
+  if (a.dtot != nullptr && t == 0)      // the scan of this pass is done: leave the totals clean for the next call
+    for (int i = tid; i < LS_BINS; i += LS_T) a.dtot[((size_t)pass * a.F + f) * LS_BINS + i] = 0;
   const size_t fo = (size_t)f * a.stride;
-  const int32_t* skey = (pass == 0 ? a.idsT : a.keyA) + fo;
+  const int32_t* skey = (pass == 0 ? a.src0 : a.keyA) + fo;
   const int32_t* sval = a.valA + fo;                 // pass 1 only; pass 0: value = position
   int32_t* dkey = (pass == 0 ? a.keyA : a.idsT) + fo;
   int32_t* dval = (pass == 0 ? a.valA : a.perm) + fo;
@@ -342,8 +344,9 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   a.valA = workspace + (size_t)2 * F * stride;
   a.hist = workspace + (size_t)3 * F * stride;
   const size_t nT_cap = ((size_t)stride + LS_TILE - 1) / LS_TILE;
-  a.dtot = a.hist + (size_t)F * LS_BINS * nT_cap + (size_t)F * (((size_t)stride + SG_BLK - 1) / SG_BLK);
-  hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
+  a.dtot = F >= 16 ? nullptr : a.hist + (size_t)F * LS_BINS * nT_cap + (size_t)F * (((size_t)stride + SG_BLK - 1) / SG_BLK);
+  a.src0 = F == 1 ? ids : a.idsT;
+  if (F > 1) hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     hipLaunchKernelGGL(ls_hist_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
     if (F >= 16) hipLaunchKernelGGL(ls_scan_field_k, dim3(F), dim3(LS_BINS), 0, st, a);
