@@ -329,7 +329,8 @@ size_t rsx_din_attn_bwd_workspace_floats(int B, int P, int K, int N1, int N2);
 int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2, const float* a1,
                      const float* a2, const float* dw, float* dH, float* dq, float* grads, float* workspace,
                      const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
-                     float dropout_rate, int B, int P, int K, int N1, int N2, rsx_stream_t stream);
+                     float dropout_rate, int accumulate_dH, int B, int P, int K, int N1, int N2, rsx_stream_t stream);
+/* accumulate_dH != 0: dH += (rsx_din_pool_bwd has already written its share of the gradient of H into the same buffer). */
 /* Sorted row keys (stable sort done by the caller) -> uniq_row[U], seg_off[U+1], nuniq[0] = U and the row -> j slot
  * map (previous call's entries cleared first): the same workspace contract as rsx_field_sort with F = 1, so
  * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.

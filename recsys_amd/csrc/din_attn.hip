@@ -226,6 +226,7 @@ struct AttnBwdArgs {
   uint32_t seed, layer0;
   float rate;
   int M, P, N1, N2, nblk;
+  int acc_dH;           // dH += (the pooling backward already wrote its part of the same gradient)
 };
 
 template <int KB, int NT1, int NT2>
@@ -410,7 +411,8 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
           const size_t mm = (size_t)blk * 64 + row;
           if (mm < (size_t)p.M) {
             const float hv = sH[col * LDR + row], qv = sQ[col * LDR + row];
-            p.dH[mm * K + col] = (dx[0][r] + dx[2][r] * qv) + dx[3][r];
+            const float dh = (dx[0][r] + dx[2][r] * qv) + dx[3][r];
+            p.dH[mm * K + col] = p.acc_dH ? p.dH[mm * K + col] + dh : dh;
             p.dqr[mm * K + col] = (dx[1][r] + dx[2][r] * hv) - dx[3][r];
           }
         }
@@ -613,8 +615,8 @@ static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
 extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
                                 const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
                                 float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
-                                uint32_t seed, int layer0, float dropout_rate, int B, int P, int K, int N1, int N2,
-                                rsx_stream_t stream) {
+                                uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, int B, int P, int K,
+                                int N1, int N2, rsx_stream_t stream) {
   if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!H || !q || !W0 || !W1 || !W2 || !a1 || !a2 || !dw || !dH || !dq || !grads || !workspace) return RSX_EINVAL;
@@ -622,7 +624,7 @@ extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0,
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;
   const int M = B * P, G = attn_bwd_groups(M);
   AttnBwdArgs p{H, q, W0, W1, W2, a1, a2, dw, dH, workspace, workspace + (size_t)M * K, mask1, mask2, rng_step, seed,
-                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64};
+                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64, accumulate_dH != 0};
   hipStream_t st = rsx_s(stream);
   const int rc = K == 32 ? launch_attn_bwd<2, 5, 3>(p, G, st) : launch_attn_bwd<1, 5, 3>(p, G, st);
   if (rc != RSX_OK) return rc;

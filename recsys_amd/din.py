@@ -14,7 +14,7 @@ import torch
 from . import layers as L
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
-from .ops import DinAttnFn, DinPoolFn, FusedTower, SparseTable
+from .ops import DinAttnFn, DinAttnPoolFn, DinPoolFn, FusedTower, SparseTable
 
 ATTENTION_LAYERS = [80, 40]      # din/din.py:85 (the din_layers flag is ignored by the reference)
 MLP_LAYERS = [100, 50, 20]       # din/din.py:86 (the deep_layers flag is ignored by the reference)
@@ -116,10 +116,14 @@ def _attention(tbl, hist, q, P_, pre, training, rate, masks, store=None, layer0=
         # fused MFMA kernel: the [B*P, 4K] concat, the tiled query and the layer outputs never round-trip through HBM;
         # dropout = the counter hash of the fused tower (keyed by the optimizer's device-side step counter)
         r = rate if training else 0.0
-        w = DinAttnFn.apply(H, q, P_[f"{pre}.W0"], P_[f"{pre}.b0"], P_[f"{pre}.W1"], P_[f"{pre}.b1"], P_[f"{pre}.W2"],
-                            P_[f"{pre}.b2"], r, masks if (training and r > 0.0) else None,
-                            store.opt.state.view(torch.int32)[3:4], 0xD1A77, layer0,
-                            P_.packed_grad([f"{pre}.{v}{i}" for i in range(3) for v in ("W", "b")]) if training else None)
+        mk2 = masks if (training and r > 0.0) else None
+        names = [f"{pre}.{v}{i}" for i in range(3) for v in ("W", "b")]
+        gout = P_.packed_grad(names) if training else None
+        Ws = [P_[n] for n in names]
+        step = store.opt.state.view(torch.int32)[3:4]
+        if gout is not None:        # TRAIN: attention + pooling as one node, weight gradients straight into the arena
+            return DinAttnPoolFn.apply(H, q, hist, *Ws, r, mk2, step, 0xD1A77, layer0, gout)
+        w = DinAttnFn.apply(H, q, *Ws, r, mk2, step, 0xD1A77, layer0)
         return DinPoolFn.apply(H, w, hist)                                  # masked weighted sum (:122-124)
     hist_emb = H.reshape(B * Pn, K)
     query_emb = q[:, None, :].expand(B, Pn, K).reshape(B * Pn, K)          # tile + reshape (:111)

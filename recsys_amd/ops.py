@@ -734,7 +734,7 @@ class DinAttnFn(torch.autograd.Function):
         ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2)), device=dev)
         check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2),
                                      _ptr(g.contiguous()), _ptr(dH), _ptr(dq), _ptr(grads), _ptr(ws), _ptr(m1), _ptr(m2),
-                                     _ptr(rng_step), seed, layer0, rate, B, P, K, N1, N2, _stream()), "rsx_din_attn_bwd")
+                                     _ptr(rng_step), seed, layer0, rate, 0, B, P, K, N1, N2, _stream()), "rsx_din_attn_bwd")
         o = 0
         out = []
         for n, shape in ((n0, W0.shape), (N1, (N1,)), (n1, W1.shape), (N2, (N2,)), (N2, W2.shape), (1, (1,))):
@@ -744,6 +744,48 @@ class DinAttnFn(torch.autograd.Function):
         if direct:
             return (dH, dq) + (None,) * 12
         return dH, dq, dW0, db0, dW1, db1, dW2, db2, None, None, None, None, None, None
+
+
+class DinAttnPoolFn(torch.autograd.Function):
+    """DinAttnFn followed by DinPoolFn as ONE autograd node (din/din.py:111-124): the backward runs the pooling backward
+    first (dH share + the logits' gradient dw) and lets the attention backward ACCUMULATE into the same dH buffer, so
+    autograd never adds two [B,P,K] gradients; weight gradients go straight to `grad_out` (see DinAttnFn)."""
+
+    @staticmethod
+    def forward(ctx, H, q, hist, W0, b0, W1, b1, W2, b2, rate, masks, rng_step, seed, layer0, grad_out):
+        B, P, K = H.shape
+        N1, N2 = W0.shape[1], W1.shape[1]
+        H, q = H.contiguous(), q.contiguous()
+        dev = H.device
+        a1, a2 = torch.empty(B * P, N1, device=dev), torch.empty(B * P, N2, device=dev)
+        w, out = torch.empty(B, P, device=dev), torch.empty(B, K, device=dev)
+        m1, m2 = (None, None) if masks is None else (masks[0].contiguous(), masks[1].contiguous())
+        check(lib().rsx_din_attn_fwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(a1),
+                                     _ptr(a2), _ptr(w), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0, rate, B, P, K,
+                                     N1, N2, _stream()), "rsx_din_attn_fwd")
+        check(lib().rsx_din_pool_fwd(_ptr(H), _ptr(w), _ptr(hist), _ptr(out), B, P, K, _stream()), "rsx_din_pool_fwd")
+        ctx.save_for_backward(H, q, hist, W0, W1, W2, a1, a2, w)
+        ctx.cfg = (rate, m1, m2, rng_step, seed, layer0)
+        ctx.grad_out = grad_out
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, q, hist, W0, W1, W2, a1, a2, w = ctx.saved_tensors
+        rate, m1, m2, rng_step, seed, layer0 = ctx.cfg
+        B, P, K = H.shape
+        N1, N2 = W0.shape[1], W1.shape[1]
+        dev = H.device
+        dH, dw, dq = torch.empty_like(H), torch.empty_like(w), torch.empty_like(q)
+        check(lib().rsx_din_pool_bwd(_ptr(H), _ptr(w), _ptr(hist), _ptr(g.contiguous()), _ptr(dH), _ptr(dw), 0, B, P, K,
+                                     _stream()), "rsx_din_pool_bwd")
+        ng = 4 * K * N1 + N1 + N1 * N2 + 2 * N2 + 1
+        assert ctx.grad_out.is_contiguous() and ctx.grad_out.numel() >= ng
+        ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2)), device=dev)
+        check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2), _ptr(dw), _ptr(dH),
+                                     _ptr(dq), _ptr(ctx.grad_out), _ptr(ws), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0,
+                                     rate, 1, B, P, K, N1, N2, _stream()), "rsx_din_attn_bwd")
+        return (dH, dq) + (None,) * 13
 
 
 class CinLayerFn(torch.autograd.Function):

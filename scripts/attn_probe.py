@@ -23,7 +23,7 @@ def run(B, P, K, rate, mk, time_it=False):
     grads = torch.empty(n, device=dev)
     ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, 80, 40)), device=dev)
     bwd = lambda: check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2), _ptr(dw), _ptr(dH), _ptr(dq), _ptr(grads),
-                                               _ptr(ws), M1, M2, None, 0, 0, rate, B, P, K, 80, 40, _stream()), "bwd")
+                                               _ptr(ws), M1, M2, None, 0, 0, rate, 0, B, P, K, 80, 40, _stream()), "bwd")
     bwd()
     torch.cuda.synchronize()
     if time_it:
