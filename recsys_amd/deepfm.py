@@ -124,7 +124,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # dedup sort runs over the all-gathered ids -- a 40 KB collective issued right after the local gather launch
         ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
         job = None
-        if ids_sort.shape[0] <= 2048:                # rides in a tower launch; larger sorts are faster with 1024 threads of their own
+        if ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in a tower launch; larger sorts are faster with 1024 threads of their own
             job = arena.sort_job(ids_sort)
         else:
             arena.field_sort(ids_sort)
