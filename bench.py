@@ -35,6 +35,9 @@ def parse():
     p.add_argument("--no_graph", action="store_true")
     p.add_argument("--emulate_world", type=int, default=0, help="profiling aid: time the per-rank COMPUTE of an N-GPU "
                    "data-parallel step on one GPU (collectives replaced by local tiling; not a throughput claim)")
+    p.add_argument("--host_input", action="store_true", help="measurement aid: every step's batch starts in pinned HOST "
+                   "memory and crosses PCIe inside the timed region (one packed copy per step, per-step graphs); the "
+                   "reported `value` of the default run never includes this")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_seconds", type=float, default=12.0)
     p.add_argument("--n_batches", type=int, default=64)
@@ -134,7 +137,15 @@ def main():
     # variables are created on the first call; then W untimed warm-up steps (includes graph capture)
     with torch.no_grad():
         est._call_model_fn(feats[0].views()[0], None, "infer")
+    host_pbs = None
+    if a.host_input:
+        host_pbs = [PackedBatch(*f.to("cpu").views(), pin=True) for f in feats]
+
     def run(nsteps):
+        if host_pbs is not None:
+            for s in range(nsteps):
+                loss = est._train_step(host_pbs[s % len(host_pbs)])
+            return loss
         if a.steps_per_graph > 1:
             return est.train_resident(feats, nsteps, a.steps_per_graph)
         for s in range(nsteps):
@@ -213,7 +224,7 @@ def main():
     N = max(world, 1) if dp is not None else 1
     out = {"metric": "examples/sec", "value": round(N * B * a.steps / dt, 1), "unit": "examples/sec", "n_gpus": a.gpus,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
            "config": {"workload": "%s.py %s bs=%d/replica, full train step "
                                   "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, %s"
                                   % (a.model, {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16",

@@ -288,12 +288,17 @@ class Estimator:
         return g["loss"]
 
     def _train_step_packed(self, pb):
+        key = ("packed",) + pb.key()
+        g = self._graphs.setdefault(key, {"warm": 0}) if self._use_graph() else None
+        if g is not None and "graph" in g:
+            # ONE copy per step, host (pinned) or device -> the graph's static input buffer
+            g["static"].flat.copy_(pb.flat, non_blocking=True)
+            g["graph"].replay()
+            return g["loss"]
         if pb.flat.device != self.store.device:
             pb = pb.to(self.store.device)
-        if not self._use_graph():
+        if g is None:
             return self._train_eager(*pb.views())
-        key = ("packed",) + pb.key()
-        g = self._graphs.setdefault(key, {"warm": 0})
         if "graph" not in g:
             if g["warm"] < 2:
                 g["warm"] += 1
@@ -303,9 +308,6 @@ class Estimator:
             g["graph"] = graph
             graph.replay()
             return g["loss"]
-        g["static"].flat.copy_(pb.flat, non_blocking=True)
-        g["graph"].replay()
-        return g["loss"]
 
     def train_resident(self, batches, steps, steps_per_graph=8):
         """Train `steps` steps over a list of HBM-resident PackedBatch objects (cycled in order).  Groups of
