@@ -87,7 +87,9 @@ class EmbeddingArena:
 
     # Above this batch size the scatter runs in two stages (uniform 16-position chunks feed the long segments): small
     # batches are latency-bound and one launch wins; large / skewed ones are bound by the longest segment chain.
-    TWO_STAGE_MIN_B = 512
+    # Measured on Criteo-39 (scripts/segsum_modes.py, scatter+Adam): B=1024 15.6 us single vs 28.4 two-stage, 2048: 33.5
+    # vs 35.9 stand-alone but 31 us better two-stage inside the data-parallel step, 4096: 72.4 vs 53.9.
+    TWO_STAGE_MIN_B = 1024
     LDS_SORT_MAX_B = 8192         # above: rsx_field_sort_large (multi-workgroup; measured crossover ~8192, scripts/sort_time.py;
                                   # rsx_field_sort itself reaches 16384)
 

@@ -36,12 +36,12 @@ def test_dp_world1_rccl_matches_oracle(capture_collectives):
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("kind,B,world", [("deepfm", 48, 3), ("dcn", 40, 2), ("deepfm", 300, 4)])
+@pytest.mark.parametrize("kind,B,world", [("deepfm", 48, 3), ("dcn", 40, 2), ("deepfm", 300, 4), ("deepfm", 600, 4)])
 def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world):
     """Multi-block data-parallel compute on one GPU: `world` identical replicas of a batch b (collectives replaced by
     local tiling) must train exactly like ONE process on the batch repeated `world` times -- same BN statistics, same
     mean loss, gradients summed over replicas with the 1/N loss scale.  Exercises the global dedup sort, the scatter
-    reading rank blocks in place from the gathered buffer, and (B*world > 512) its two-stage form."""
+    reading rank blocks in place from the gathered buffer, and (B*world > 1024) its two-stage form."""
     import numpy as np
     import torch
     from oracle import init

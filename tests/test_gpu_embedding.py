@@ -330,7 +330,7 @@ def test_dcn_train_parity_criteo():
 
 def test_large_batch_tower_and_dcn_parity_bs1024():
     """B > 512 takes the pre-reduced statistics path (rsx_tower_reduce_partials); B >= 1024 the split-batch dW tiles
-    (+ tower_reduce_dw_k), 4 row tiles per d(input) workgroup and the two-stage scatter: DeepFM and DCN at batch
+    (+ tower_reduce_dw_k) and 4 row tiles per d(input) workgroup: DeepFM and DCN at batch
     1024 / 1100 (ragged last tiles) on a small layout vs the oracle."""
     for kind, B in (("deepfm", 1024), ("dcn", 1100)):
         err, losses, perr = deepfm_parity_run(B=B, steps=2, seed=41, rows=(3, 7, 40, 11, 600), D=16, layers=(32, 16),
