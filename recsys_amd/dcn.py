@@ -71,8 +71,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
     oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
     with torch.no_grad():
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
+        ids_sort = dp.all_gather_rows(ids) if dp is not None else ids       # first: see deepfm._train_fused
         x0, _, _, _ = arena.gather(ids)
-        ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
         job, sweeps, hot, last_sweep = None, None, None, None
         if ids_sort.shape[0] <= 2048:                # the sort rides in the first tower-forward launch; larger ones run stand-alone
             # (a 256-thread carrier workgroup sorts 4096 keys in 55 us, the 1024-thread kernel in 26 us)

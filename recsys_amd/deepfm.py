@@ -119,10 +119,11 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # The ids-only dedup sort rides in the first tower-forward launch as extra workgroups.  (A side HIP stream was
         # measured instead: inside a graph the fork/join across HW queues costs ~10 us each way, more than it hides.)
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         # data-parallel: the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices), so the
-        # dedup sort runs over the all-gathered ids -- a 40 KB collective issued right after the local gather launch
+        # dedup sort runs over the all-gathered ids -- a 40 KB collective issued FIRST (ids depend on nothing of this step),
+        # so that every launch from the gather to the last backward layer is one graph segment
         ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         job = None
         if ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in a tower launch; larger sorts are faster with 1024 threads of their own
             job = arena.sort_job(ids_sort)

@@ -18,6 +18,7 @@ MI355X design (tables are only 54 MB, replicated -- no row sharding / all-to-all
     each peer its slice over a dedicated link (7 x ~153 GB/s) instead of a ring.
 """
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -65,7 +66,9 @@ class SegmentedGraph:
         self._ctx.__enter__()
 
     def _end(self):
-        self._ctx.__exit__(None, None, None)
+        with warnings.catch_warnings():      # a step that OPENS with a collective ends an empty first segment: legal, and
+            warnings.filterwarnings("ignore", message="The CUDA Graph is empty")     # replaying it is a no-op
+            self._ctx.__exit__(None, None, None)
         if self._pool is None:
             self._pool = self._graph.pool()
         self.items.append(self._graph)
@@ -215,7 +218,10 @@ class DataParallel:
         return flat
 
     def barrier(self):
-        dist.barrier(group=self.group)
+        if dist.get_backend(self.group) == "nccl":      # name the device: RCCL otherwise guesses it from the current context
+            dist.barrier(group=self.group, device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier(group=self.group)
 
 
 class EmulatedDataParallel(DataParallel):
