@@ -850,8 +850,12 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   if (rcs != RSX_OK) return rcs;
   // A VEC_COLD slice rewrites (restores) the touched elements of its float4s: racing with this launch's own update of
   // those elements.  Only table slices (whole touched rows are skipped, never written) may ride here.
-  for (int k = 0; h.cold.n_blk != 0 && k < h.cold.args.nseg; ++k)
-    if (h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
+  for (int k = 0; h.cold.n_blk != 0 && k < h.cold.args.nseg; ++k) {
+    const uint32_t b0 = h.cold.args.seg[k].blk_begin;
+    const uint32_t b1 = k + 1 < h.cold.args.nseg ? h.cold.args.seg[k + 1].blk_begin : h.cold.args.total_blocks;
+    const bool overlaps = b0 < h.cold.blk_lo + h.cold.n_blk && h.cold.blk_lo < b1;     // segment k has blocks in the slice
+    if (overlaps && h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
+  }
   h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,

@@ -55,10 +55,10 @@ def build_variables(store, params, capacity):
     if params.get("tower", "hip") == "hip":
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
-        # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0]
+        # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
         store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
-                                                              [0.0] * len(layers) + [1.0] + [3.0] * len(layers))
+                                                              [0.0] * len(layers) + [1.0] + [3.0] * len(layers) + [1.0])
 
 
 def _train_fused(store, arena, ids, labels, params, masks):
