@@ -43,8 +43,8 @@ def model_fn(features, labels, mode, params):
 
 def _train_fused(store, arena, ids, labels):
     """TRAIN step as 4 launches, no autograd: dedup sort -> gather (+ first order + FM) -> FM head with its backward,
-    carrying the whole untouched-row Adam sweep as extra workgroups -> segment-sum fused with the touched-row and dense
-    Adam.  Same exact split of the TF-1 update as deepfm.py."""
+    carrying most of the untouched-row Adam sweep as extra workgroups -> segment-sum fused with the touched-row and dense
+    Adam (+ the rest of the sweep).  Same exact split of the TF-1 update as deepfm.py."""
     P = store.dense
     B = ids.shape[0]
     dev = ids.device
@@ -52,7 +52,9 @@ def _train_fused(store, arena, ids, labels):
         arena.field_sort(ids)
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
         cold, hot = arena.adam_split_segments()
-        sweep = store.opt.cold_slices(cold, [1.0])[0]
+        # 70 % of the untouched-row sweep rides in the head launch, 30 % (table blocks only: the first-order vector goes first)
+        # in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)
+        sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
         prob, gy1, gy2 = (torch.empty(B, device=dev) for _ in range(3))
         loss = torch.empty(1, device=dev)
         oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
@@ -63,7 +65,7 @@ def _train_fused(store, arena, ids, labels):
 
     def train_op():
         with torch.no_grad():
-            arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), None)
+            arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2)
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 
