@@ -256,6 +256,18 @@ class Estimator:
             out = fn()
         return graph, out
 
+    def _capture_step(self, features, labels):
+        """The TRAIN step over static input tensors -> (replayable, static loss).  Data-parallel steps whose train_op is
+        plain kernel calls (store.graph_safe_dp): only model_fn is captured; train_op -- pack, the gradient all-gather, 2-3
+        launches -- is re-issued eagerly on every replay.  A graph launch costs ~9 us of start-up and ~8 us before the next
+        un-captured operation begins (measured through RCCL at world 1): a graph around so few launches loses more than it saves."""
+        if self.store.dp is not None and self.store.graph_safe_dp and os.environ.get("RSX_DP_CAPTURE") != "1" and \
+                os.environ.get("RSX_DP_EAGER_TAIL", "1") == "1":
+            seg, spec = self._capture(lambda: self._call_model_fn(features, labels, ModeKeys.TRAIN))
+            seg.items.append(spec.train_op)      # re-executed (eagerly) by every replay, after the captured segments
+            return seg, spec.loss.detach()
+        return self._capture(lambda: self._train_eager(features, labels))
+
     def _shape_key(self, features, labels):
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items())) + (tuple(labels.shape),)
 
@@ -277,7 +289,7 @@ class Estimator:
                 return self._train_eager(features, labels)
             g["feat"] = {k: v.clone() for k, v in features.items()}
             g["lab"] = labels.clone()
-            graph, g["loss"] = self._capture(lambda: self._train_eager(g["feat"], g["lab"]))
+            graph, g["loss"] = self._capture_step(g["feat"], g["lab"])
             g["graph"] = graph      # capture executes nothing: the static buffers already hold this
             graph.replay()          # batch (cloned above), so replay once to apply its step
             return g["loss"]
@@ -304,7 +316,7 @@ class Estimator:
                 g["warm"] += 1
                 return self._train_eager(*pb.views())
             g["static"] = pb.clone()
-            graph, g["loss"] = self._capture(lambda: self._train_eager(*g["static"].views()))
+            graph, g["loss"] = self._capture_step(*g["static"].views())
             g["graph"] = graph
             graph.replay()
             return g["loss"]
