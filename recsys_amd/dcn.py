@@ -55,6 +55,10 @@ def build_variables(store, params, capacity):
     if params.get("tower", "hip") == "hip":
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
+        store.dp_block = False
+        if store.dp is not None and params.get("dp_send_block", True):      # zero-copy gradient exchange (see deepfm.py)
+            store.dp.make_send_block(store.dense, capacity // store.dp.world, [dim])
+            store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
         store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
@@ -72,6 +76,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
     with torch.no_grad():
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
         ids_sort = dp.all_gather_rows(ids) if dp is not None else ids       # first: see deepfm._train_fused
+        zc = dp is not None and store.dp_block
         x0, _, _, _ = arena.gather(ids)
         job, sweeps, hot, last_sweep = None, None, None, None
         if ids_sort.shape[0] <= 2048:                # the sort rides in the first tower-forward launch; larger ones run stand-alone
@@ -92,14 +97,17 @@ def _train_fused(store, arena, ids, labels, params, masks):
             s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,
             replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
-            sort_job=job, sweeps=sweeps, sort_in_fwd=True)
+            sort_job=job, sweeps=sweeps, sort_in_fwd=True, outs=(dp.send_views(ids.shape[0])[0], None, None) if zc else None)
         store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
                              gz=gz, wout=oW[nh:], dwout=oG[nh:])
 
     def train_op():
         with torch.no_grad():
             dXg, blocks, Bg = dX, None, dX.shape[0]
-            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order);
+            if zc:                  # ONE collective straight from the send block (dense arena + dX)
+                (dXg,), blocks = dp.gather_send_block(dX.shape[0])
+                Bg = dX.shape[0] * dp.world
+            elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
                 dXg, _, _, _, blocks = dp.gather_example_grads(dX, dense=store.dense.grad, blocked=True)
                 Bg = dX.shape[0] * dp.world

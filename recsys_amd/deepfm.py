@@ -67,6 +67,12 @@ def build_variables(store, params, capacity, with_dnn=True):
         from .ops import FusedTower
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
+        store.dp_block = False
+        if store.dp is not None and params.get("dp_send_block", True):
+            # zero-copy gradient exchange: the dense gradient arena and the tower / gather outputs of the per-example block
+            # live inside ONE persistent send buffer (no pack launch before the all-gather)
+            store.dp.make_send_block(store.dense, capacity // store.dp.world, [layout.F * D, D, 1, 1])
+            store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter] (measured: the
         # latency-bound scatter + touched-row Adam launch hides 1/5 of the sweep for free: 98.9 -> 96.2 us per step)
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
@@ -124,7 +130,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # dedup sort runs over the all-gathered ids -- a 40 KB collective issued FIRST (ids depend on nothing of this step),
         # so that every launch from the gather to the last backward layer is one graph segment
         ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
+        zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
+        dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)
         job = None
         if ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in a tower launch; larger sorts are faster with 1024 threads of their own
             job = arena.sort_job(ids_sort)
@@ -146,12 +154,15 @@ def _train_fused(store, arena, ids, labels, params, masks):
             s0=y1p, c0="b1", s1=y2,
             replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
-            sort_job=job, sweeps=sweeps, sort_in_fwd=overlap)
+            sort_job=job, sweeps=sweeps, sort_in_fwd=overlap, outs=(dXv, gy1v, gy2v) if zc else None)
 
     def train_op():
         with torch.no_grad():
             Sg, dXg, gy1g, gy2g, blocks, Bg = S, dX, gy1, gy2, None, dX.shape[0]
-            if dp is not None:      # ONE collective: per-example gradient block + dense arena (summed in rank order);
+            if zc:                  # ONE collective straight from the send block (dense arena + per-example block)
+                (dXg, Sg, gy2g, gy1g), blocks = dp.gather_send_block(dX.shape[0])
+                Bg = dX.shape[0] * dp.world
+            elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
                 dXg, Sg, gy1g, gy2g, blocks = dp.gather_example_grads(dX, S, gy1, gy2, dense=store.dense.grad, blocked=True)
                 Bg = dX.shape[0] * dp.world

@@ -135,6 +135,42 @@ class DataParallel:
             w += [("gy1", 1)]
         return w
 
+    # -- zero-copy send block -------------------------------------------------------------------
+    def make_send_block(self, dense, b_max, widths):
+        """One persistent buffer [dense gradient arena | pad | per-example block of up to b_max examples]; the dense arena's
+        grad views are moved into it.  widths: per-example float counts of the parts in block order (e.g. F*D, D, 1, 1)."""
+        n0 = (dense.n + 3) & ~3
+        self._send = torch.zeros(n0 + b_max * sum(widths) + 4, device=dense.grad.device)
+        self._send_n0, self._send_widths, self._send_dense = n0, list(widths), dense
+        dense.rebind_grad(self._send)
+        return self._send
+
+    def send_views(self, b):
+        """The parts of the example block for a batch of b examples, as views of the send block: [b, w] each (w = 1: [b])."""
+        out, o = [], self._send_n0
+        for w in self._send_widths:
+            v = self._send[o:o + b * w]
+            out.append(v if w == 1 else v.view(b, w))
+            o += b * w
+        return out
+
+    def gather_send_block(self, b):
+        """All-gathers [dense | block(b)] in place (no pack copy), sums the dense arenas over the ranks in rank order into the
+        local one, and returns (views of RANK 0's parts inside the gathered buffer, blocks descriptor) for
+        EmbeddingArena.segsum*(..., blocks=)."""
+        n0, n = self._send_n0, self._send_dense.n
+        L = b * sum(self._send_widths)
+        ln = (n0 + L + 3) & ~3                                   # rank blocks stay 16-byte aligned
+        out = self.all_gather_rows(self._send[:ln].view(1, ln))  # [N, ln]
+        torch.sum(out[:, :n], 0, out=self._send_dense.grad)
+        views, o = [], n0
+        for w in self._send_widths:
+            v = out[0, o:o + b * w]
+            views.append(v if w == 1 else v.view(b, w))
+            o += b * w
+        self._keep = out
+        return views, (b, ln)
+
     def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None, dense=None, blocked=False):
         """Packs the per-example gradient block, all-gathers it once, and returns the global views
         dX_g [N*b, F*D], S_g [N*b, D]|None, gy1_g [N*b]|None, gy2_g [N*b]|None (contiguous).

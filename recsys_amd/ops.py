@@ -140,12 +140,13 @@ class EmbeddingArena:
         j.max_rows_per_field, j.B, j.F, j.stride = self.max_rows, B, self.F, self.stride
         return j
 
-    def gather(self, ids, fm=False, first_order=False):
-        """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd)."""
+    def gather(self, ids, fm=False, first_order=False, S_out=None):
+        """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd).  S_out: caller-owned [B,D] buffer for S
+        (e.g. a view of the data-parallel send block)."""
         B = ids.shape[0]
         dev = self.tables.device
         E = torch.empty(B, self.F * self.D, device=dev)
-        S = torch.empty(B, self.D, device=dev) if fm else None
+        S = (S_out if S_out is not None else torch.empty(B, self.D, device=dev)) if fm else None
         y2 = torch.empty(B, device=dev) if fm else None
         y1 = torch.empty(B, device=dev) if first_order else None
         check(lib().rsx_gather_fm_fwd(_ptr(self.tables), _ptr(self.w1) if first_order else None, _ptr(self.row_off),
@@ -327,6 +328,19 @@ class DenseArena:
         return [dict(kind=_lib.RSX_ADAM_DENSE, n=self.n, var=self.flat, m=self.m, v=self.v, g=self.grad,
                      zero_grad=1)]
 
+    def rebind_grad(self, storage):
+        """Moves the gradient arena into caller-owned storage (flat fp32, >= n): the data-parallel send block keeps it in
+        front of the per-example gradient block so that ONE buffer goes into the collective without a pack copy."""
+        assert storage.is_contiguous() and storage.numel() >= self.n and storage.dtype == torch.float32
+        g = storage[:self.n]
+        g.copy_(self.grad)
+        self.grad = g
+        for k, p in self.params.items():
+            st = self.storage[k]
+            sz = int(np.prod(st)) if len(st) else 1
+            o = self.offsets[k]
+            p.grad = g[o:o + sz].view(st)[tuple(slice(0, d) for d in p.shape)]
+
     def packed_grad(self, names):
         """The grad-arena slice covering `names` when they sit back to back without padding (every size but the last a
         multiple of 4) -- a kernel that emits their gradients as one flat array can then write straight into it.  None if
@@ -452,15 +466,18 @@ class FusedTower:
 
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
-                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False):
+                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
         FIRST layer's forward launch when sort_in_fwd (required when sweeps are used: they read its slot map).
         sweeps = 2L+1 rsx_adam_slice structs (or None) for [fwd_0..fwd_{L-1}, head, bwd_{L-1}..bwd_0]: slices of the
         untouched-row optimizer sweep that ride along as extra workgroups (AdamTF1.cold_slices).
+        outs = (dX [B,k0], gs0 [B], gs1 [B]): caller-owned contiguous output buffers (views of the data-parallel send block)
+        instead of the tower's own.
         Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
         L, P, pre = lib(), self.P, self.pre
+        o_dX, o_gs0, o_gs1 = [o if o is not None else d for o, d in zip(outs or (None,) * 3, (self.dX, self.gs0, self.gs1))]
         B = X.shape[0]
         assert B <= self.cap and X.is_contiguous() and X.shape[1] == self.k0
         st = _stream()
@@ -494,7 +511,7 @@ class FusedTower:
                                bnp(f"{pre}.beta{nl - 1}"), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)),
                                _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
                                _ptr(pv(bo)), _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
-                               _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1),
+                               _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(o_gs0), _ptr(o_gs1),
                                rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, ref(sw[nl]), st),
               "rsx_tower_head")
         if self.bn_on:
@@ -508,7 +525,7 @@ class FusedTower:
                 _ptr(g(f"{pre}.W{l}")), _ptr(g(f"{pre}.b{l}")), bng(f"{pre}.gamma{l}"), bng(f"{pre}.beta{l}"),
                 _ptr(self.bn[l - 1]) if l else None, bnp(f"{pre}.gamma{l - 1}") if l else None,
                 bnp(f"{pre}.beta{l - 1}") if l else None, _ptr(mk[l - 1]) if l else None,
-                _ptr(self.dy[l - 1]) if l else _ptr(self.dX), _ptr(self.bstat[l - 1]) if l else None,
+                _ptr(self.dy[l - 1]) if l else _ptr(o_dX), _ptr(self.bstat[l - 1]) if l else None,
                 _ptr(self.hpart) if last else None, _ptr(self.dwd_part) if last else None,
                 _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
                 _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
@@ -518,7 +535,7 @@ class FusedTower:
                 ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), st), "rsx_tower_bwd_layer")
             if l and self.bn_on:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
-        return self.loss, self.prob[:B], self.dX[:B], self.gs0[:B], self.gs1[:B]
+        return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
 
 
 class CrossLayers:
