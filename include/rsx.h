@@ -169,8 +169,9 @@ typedef struct {
   const int32_t* slot;     /* TABLE_TF1 / VEC_SLOT: row -> slot map                                  */
   const int32_t* uniq_row; /* *_ROWS */
   const int32_t* nuniq;    /* *_ROWS */
-  int32_t B;               /* *_ROWS: examples per field this step (n = F*B)                         */
-  int32_t stride;          /* *_ROWS: per-field capacity of the rsx_field_sort workspace             */
+  int32_t B;               /* *_ROWS: examples per field this step (n = F*B).  DENSE: replicas whose arenas are summed */
+  int32_t stride;          /* *_ROWS: per-field capacity of the rsx_field_sort workspace.  DENSE with B > 1: floats
+                              between the replicas' arenas inside g (an all-gathered buffer), summed in order r = 0.. */
   int32_t zero_grad;       /* DENSE */
 } rsx_adam_seg;
 

@@ -115,12 +115,20 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   } else if (s.kind == RSX_ADAM_DENSE) {
     float4* __restrict__ g4 = reinterpret_cast<float4*>(s.g);
     const long long n4 = s.n >> 2;
+    // B > 1: the gradient is the sum of B replicas' arenas, `stride` floats apart inside an all-gathered buffer, added in
+    // rank order (every rank computes the same bits) -- the data-parallel dense all-reduce folded into the update
+    const int nrep = s.B > 1 ? s.B : 1;
+    const long long rs4 = (long long)s.stride >> 2;
 #pragma unroll
     for (int u = 0; u < ADAM_U; ++u) {
       const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         float4 var = var4[e], m = m4[e], v = v4[e];
-        const float4 g = g4[e];
+        float4 g = g4[e];
+        for (int r = 1; r < nrep; ++r) {
+          const float4 gr = g4[e + r * rs4];
+          g.x += gr.x; g.y += gr.y; g.z += gr.z; g.w += gr.w;
+        }
         F4_APPLY(adam_dense1, var, m, v, g, h);
         var4[e] = var;
         m4[e] = m;
@@ -128,7 +136,9 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         if (s.zero_grad) g4[e] = z4;
       } else if (e == n4) {  // scalar tail (n not a multiple of 4)
         for (long long i = n4 * 4; i < s.n; ++i) {
-          adam_dense1(s.var[i], s.m[i], s.v[i], s.g[i], h);
+          float g = s.g[i];
+          for (int r = 1; r < nrep; ++r) g += s.g[i + (long long)r * s.stride];
+          adam_dense1(s.var[i], s.m[i], s.v[i], g, h);
           if (s.zero_grad) s.g[i] = 0.f;
         }
       }
@@ -221,6 +231,7 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
     switch (s.kind) {
       case RSX_ADAM_DENSE:
         if (!s.g) return RSX_EINVAL;
+        if (s.B > 1 && (s.stride < s.n || (s.stride & 3))) return RSX_EINVAL;     // replica sum: 16-byte aligned blocks
         work = (s.n >> 2) + 1;
         break;
       case RSX_ADAM_TABLE_TF1:

@@ -103,16 +103,16 @@ def _train_fused(store, arena, ids, labels, params, masks):
 
     def train_op():
         with torch.no_grad():
-            dXg, blocks, Bg = dX, None, dX.shape[0]
+            dXg, blocks, Bg, dense_segs = dX, None, dX.shape[0], None
             if zc:                  # ONE collective straight from the send block (dense arena + dX)
-                (dXg,), blocks = dp.gather_send_block(dX.shape[0])
+                (dXg,), blocks, dense_segs = dp.gather_send_block(dX.shape[0], fold_dense=hot is not None)
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
                 dXg, _, _, _, blocks = dp.gather_example_grads(dX, dense=store.dense.grad, blocked=True)
                 Bg = dX.shape[0] * dp.world
             if hot is not None:
-                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, store.dense.adam_segments(), last_sweep, blocks=blocks)
+                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, dense_segs or store.dense.adam_segments(), last_sweep, blocks=blocks)
             else:
                 arena.segsum(Bg, None, dXg, None, None, blocks=blocks)
                 store.apply_gradients()

@@ -158,16 +158,16 @@ def _train_fused(store, arena, ids, labels, params, masks):
 
     def train_op():
         with torch.no_grad():
-            Sg, dXg, gy1g, gy2g, blocks, Bg = S, dX, gy1, gy2, None, dX.shape[0]
+            Sg, dXg, gy1g, gy2g, blocks, Bg, dense_segs = S, dX, gy1, gy2, None, dX.shape[0], None
             if zc:                  # ONE collective straight from the send block (dense arena + per-example block)
-                (dXg, Sg, gy2g, gy1g), blocks = dp.gather_send_block(dX.shape[0])
+                (dXg, Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(dX.shape[0], fold_dense=hot is not None)
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
                 dXg, Sg, gy1g, gy2g, blocks = dp.gather_example_grads(dX, S, gy1, gy2, dense=store.dense.grad, blocked=True)
                 Bg = dX.shape[0] * dp.world
             if hot is not None:     # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
-                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, store.dense.adam_segments(), last_sweep, blocks=blocks)
+                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, dense_segs or store.dense.adam_segments(), last_sweep, blocks=blocks)
             else:
                 arena.segsum(Bg, Sg, dXg, gy1g, gy2g, blocks=blocks)
                 store.apply_gradients()

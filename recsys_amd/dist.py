@@ -154,22 +154,30 @@ class DataParallel:
             o += b * w
         return out
 
-    def gather_send_block(self, b):
-        """All-gathers [dense | block(b)] in place (no pack copy), sums the dense arenas over the ranks in rank order into the
-        local one, and returns (views of RANK 0's parts inside the gathered buffer, blocks descriptor) for
-        EmbeddingArena.segsum*(..., blocks=)."""
+    def gather_send_block(self, b, fold_dense=False):
+        """All-gathers [dense | block(b)] in place (no pack copy) and returns (views of RANK 0's parts inside the gathered
+        buffer, blocks descriptor) for EmbeddingArena.segsum*(..., blocks=).  The dense arenas of the ranks are summed in rank
+        order: into the local arena by one launch here, or -- fold_dense -- inside the optimizer launch itself: a third return
+        value (else None) then replaces DenseArena.adam_segments() (RSX_ADAM_DENSE with B = world replicas `stride` floats apart)."""
+        from . import _lib
         n0, n = self._send_n0, self._send_dense.n
         L = b * sum(self._send_widths)
         ln = (n0 + L + 3) & ~3                                   # rank blocks stay 16-byte aligned
         out = self.all_gather_rows(self._send[:ln].view(1, ln))  # [N, ln]
-        torch.sum(out[:, :n], 0, out=self._send_dense.grad)
+        d = self._send_dense
+        seg = None
+        if fold_dense:
+            seg = [dict(kind=_lib.RSX_ADAM_DENSE, n=d.n, var=d.flat, m=d.m, v=d.v, g=out[0, :n], B=self.world, stride=ln,
+                        zero_grad=0)]
+        else:
+            torch.sum(out[:, :n], 0, out=d.grad)
         views, o = [], n0
         for w in self._send_widths:
             v = out[0, o:o + b * w]
             views.append(v if w == 1 else v.view(b, w))
             o += b * w
         self._keep = out
-        return views, (b, ln)
+        return views, (b, ln), seg
 
     def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None, dense=None, blocked=False):
         """Packs the per-example gradient block, all-gathers it once, and returns the global views
