@@ -327,9 +327,25 @@ class Estimator:
         buffers directly: no per-step input copy and one graph launch per group ("capture launch-bound inner
         loops in hipGraphs").  An input pipeline refills the buffers in place between replays."""
         n = len(batches)
-        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or \
-                (self.store.dp is not None and os.environ.get("RSX_DP_CAPTURE") != "1"):
-            for s in range(steps):          # data-parallel: per-step segmented graphs fed by one D2D copy
+        if self._use_graph() and self.store.dp is not None and os.environ.get("RSX_DP_CAPTURE") != "1":
+            # data-parallel with eager collectives: one segmented step per RESIDENT batch, reading its buffer in place
+            # (no per-step input copy); steps cannot be grouped because the collectives sit between the segments
+            key = ("resident-dp", id(batches[0]), n)
+            g = self._graphs.get(key)
+            done = 0
+            if g is None:
+                for s in range(min(2, steps)):
+                    self._train_eager(*batches[s % n].views())
+                done = min(2, steps)
+                g = {"steps": [self._capture_step(*b.views()) for b in batches]}
+                self._graphs[key] = g
+            loss = None
+            for s in range(done, steps):
+                seg, loss = g["steps"][s % n]
+                seg.replay()
+            return loss if loss is not None else g["steps"][0][1]
+        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
+            for s in range(steps):
                 loss = self._train_step(batches[s % n])
             return loss
         key = ("resident", id(batches[0]), n, steps_per_graph)
