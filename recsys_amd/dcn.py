@@ -75,7 +75,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
     oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
     with torch.no_grad():
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        ids_sort = dp.all_gather_rows(ids) if dp is not None else ids       # first: see deepfm._train_fused
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids       # first: see deepfm._train_fused
         zc = dp is not None and store.dp_block
         x0, _, _, _ = arena.gather(ids)
         job, sweeps, hot, last_sweep = None, None, None, None

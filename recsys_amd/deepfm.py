@@ -129,7 +129,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # data-parallel: the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices), so the
         # dedup sort runs over the all-gathered ids -- a 40 KB collective issued FIRST (ids depend on nothing of this step),
         # so that every launch from the gather to the last backward layer is one graph segment
-        ids_sort = dp.all_gather_rows(ids) if dp is not None else ids
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids
         zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)

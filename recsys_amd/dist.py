@@ -56,6 +56,7 @@ class SegmentedGraph:
 
     def __init__(self):
         self.items = []                 # torch.cuda.CUDAGraph | callable
+        self.prefetch = None            # the step's _PrefetchableAllGather item, if any
         self._pool = None
         self._ctx = None
         self._graph = None
@@ -92,12 +93,36 @@ class SegmentedGraph:
         self.items.append(op)
         self._begin()
 
-    def replay(self):
+    def replay(self, next_seg=None):
+        """next_seg: the step that will be replayed after this one (resident batches): its prefetchable collective (the ids
+        all-gather, whose input depends on nothing this step computes) is issued as soon as this step's own has been
+        consumed, so that it runs on RCCL's stream underneath this step's kernels."""
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
                 it()
+                if it is self.prefetch and next_seg is not None and next_seg.prefetch is not None:
+                    next_seg.prefetch.issue()
+
+
+class _PrefetchableAllGather:
+    """An all-gather whose input is ready before the step starts (the batch ids).  As a SegmentedGraph item it either waits
+    for the asynchronous launch a previous step issued for it (`issue`) or runs synchronously."""
+
+    def __init__(self, out, x, group):
+        self.out, self.x, self.group, self.work = out, x, group, None
+
+    def issue(self):
+        if self.work is None:
+            self.work = dist.all_gather_into_tensor(self.out, self.x, group=self.group, async_op=True)
+
+    def __call__(self):
+        if self.work is not None:
+            self.work.wait()            # the current stream waits for RCCL's; the host does not block
+            self.work = None
+        else:
+            dist.all_gather_into_tensor(self.out, self.x, group=self.group)
 
 
 def graph_break(op):
@@ -118,11 +143,19 @@ class DataParallel:
         self.world = dist.get_world_size(group)
 
     # -- inputs -------------------------------------------------------------------------------
-    def all_gather_rows(self, x):
-        """x [b, ...] on every rank (same b) -> [N*b, ...] in rank order."""
+    def all_gather_rows(self, x, prefetchable=False):
+        """x [b, ...] on every rank (same b) -> [N*b, ...] in rank order.  prefetchable: x is an INPUT of the step (ready
+        before it starts); under a segmented capture the collective is then recorded so that the previous step may issue it
+        early (SegmentedGraph.replay(next_seg=...))."""
         x = x.contiguous()
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        graph_break(lambda: dist.all_gather_into_tensor(out, x, group=self.group))
+        seg = SegmentedGraph._active
+        if prefetchable and seg is not None and os.environ.get("RSX_DP_CAPTURE") != "1" and seg.prefetch is None:
+            op = _PrefetchableAllGather(out, x, self.group)
+            seg.prefetch = op
+            seg.run_eager(op)
+        else:
+            graph_break(lambda: dist.all_gather_into_tensor(out, x, group=self.group))
         return out
 
     # -- sparse gradient block ----------------------------------------------------------------
@@ -276,7 +309,7 @@ class EmulatedDataParallel(DataParallel):
     def __init__(self, world):
         self.group, self.rank, self.world = None, 0, int(world)
 
-    def all_gather_rows(self, x):
+    def all_gather_rows(self, x, prefetchable=False):
         x = x.contiguous()
         return x.repeat((self.world,) + (1,) * (x.dim() - 1))
 

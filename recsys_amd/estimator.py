@@ -342,7 +342,12 @@ class Estimator:
             loss = None
             for s in range(done, steps):
                 seg, loss = g["steps"][s % n]
-                seg.replay()
+                # RSX_DP_PREFETCH=1: the next batch's ids all-gather is issued underneath this step (not after the last one:
+                # nothing would consume it before the buffers may be refilled).  Off by default: through RCCL at world 1 the
+                # async launch + stream hand-over costs 7 us more than it hides; whether real xGMI latency reverses that can
+                # only be measured on a multi-GPU node.
+                nxt = g["steps"][(s + 1) % n][0] if (s + 1 < steps and os.environ.get("RSX_DP_PREFETCH", "0") == "1") else None
+                seg.replay(nxt)
             return loss if loss is not None else g["steps"][0][1]
         if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
             for s in range(steps):
