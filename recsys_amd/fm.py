@@ -21,10 +21,17 @@ def model_fn(features, labels, mode, params):
     store = get_variable_store()
     ids = features["ids"]
     if not store.built:
-        _build(store, params, capacity=max(int(params.get("max_batch_size", 0)), ids.shape[0]), with_dnn=False)
+        cap = max(int(params.get("max_batch_size", 0)), ids.shape[0])
+        _build(store, params, capacity=cap, with_dnn=False)
+        store.dp_block = False
+        if store.dp is not None and params.get("fused", True):
+            # data-parallel: [S | gy2 | gy1] of the local batch + the dense gradient arena in one persistent send block
+            store.dp.make_send_block(store.dense, cap, [store.embeddings["input_layer"].D, 1, 1])
+            store.dp_block = True
+            store.graph_safe_dp = True       # the fused step issues its collectives outside autograd
     arena, P = store.embeddings["input_layer"], store.dense
     training = mode == ModeKeys.TRAIN
-    if training and store.dp is None and store.adam_mode == "tf1_dense" and params.get("fused", True):
+    if training and store.adam_mode == "tf1_dense" and params.get("fused", True) and (store.dp is None or store.dp_block):
         return _train_fused(store, arena, ids, labels)
     if training:
         store.sort_ids_for_backward(arena, ids)
@@ -45,27 +52,36 @@ def _train_fused(store, arena, ids, labels):
     """TRAIN step as 4 launches, no autograd: dedup sort -> gather (+ first order + FM) -> FM head with its backward,
     carrying most of the untouched-row Adam sweep as extra workgroups -> segment-sum fused with the touched-row and dense
     Adam (+ the rest of the sweep).  Same exact split of the TF-1 update as deepfm.py."""
-    P = store.dense
+    P, dp = store.dense, store.dp
     B = ids.shape[0]
     dev = ids.device
     with torch.no_grad():
-        arena.field_sort(ids)
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
+        # data-parallel: the optimizer sees the GLOBAL batch -- dedup sort over the all-gathered ids, per-example gradient
+        # block [S | gy2 | gy1] + dense arena exchanged by ONE all-gather straight from the send block (see deepfm.py)
+        arena.field_sort(dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids)
+        Sv, gy2v, gy1v = dp.send_views(B) if dp is not None else (None,) * 3
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)
         cold, hot = arena.adam_split_segments()
         # 70 % of the untouched-row sweep rides in the head launch, 30 % (table blocks only: the first-order vector goes first)
         # in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)
         sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
-        prob, gy1, gy2 = (torch.empty(B, device=dev) for _ in range(3))
+        prob = torch.empty(B, device=dev)
+        gy1, gy2 = (gy1v, gy2v) if dp is not None else (torch.empty(B, device=dev) for _ in range(2))
         loss = torch.empty(1, device=dev)
         oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
+        world = dp.world if dp is not None else 1
         _lib.check(_lib.lib().rsx_fm_head(_ptr(y1p), _ptr(y2), _ptr(P["b1"]), _ptr(oW), _ptr(P["out.b"]),
                                           _ptr(labels.reshape(-1).to(torch.float32)), _ptr(prob), _ptr(gy1), _ptr(gy2),
-                                          _ptr(oG), _ptr(P["out.b"].grad), _ptr(P["b1"].grad), _ptr(loss), 1.0 / B, B,
+                                          _ptr(oG), _ptr(P["out.b"].grad), _ptr(P["b1"].grad), _ptr(loss), 1.0 / (B * world), B,
                                           None if sweep is None else C.byref(sweep), _stream()), "rsx_fm_head")
 
     def train_op():
         with torch.no_grad():
-            arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2)
+            if dp is not None:
+                (Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(B, fold_dense=True)
+                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs, sweep2, blocks=blocks)
+            else:
+                arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2)
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 

@@ -36,7 +36,7 @@ def test_dp_world1_rccl_matches_oracle(capture_collectives):
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("kind,B,world", [("deepfm", 48, 3), ("dcn", 40, 2), ("deepfm", 300, 4), ("deepfm", 600, 4)])
+@pytest.mark.parametrize("kind,B,world", [("deepfm", 48, 3), ("dcn", 40, 2), ("deepfm", 300, 4), ("deepfm", 600, 4), ("fm", 56, 3)])
 def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world):
     """Multi-block data-parallel compute on one GPU: `world` identical replicas of a batch b (collectives replaced by
     local tiling) must train exactly like ONE process on the batch repeated `world` times -- same BN statistics, same
@@ -45,7 +45,7 @@ def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world)
     import numpy as np
     import torch
     from oracle import init
-    from recsys_amd import dcn, deepfm
+    from recsys_amd import dcn, deepfm, fm
     from recsys_amd.dist import EmulatedDataParallel
     from recsys_amd.estimator import PackedBatch
     from tests.parity_util import load_oracle_weights, make_estimator, small_columns, synth_ids
@@ -53,10 +53,10 @@ def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world)
     row_off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
     lin, emb = small_columns(rows, D)
     rng = np.random.default_rng(7)
-    mfn = {"deepfm": deepfm.model_fn, "dcn": dcn.model_fn}[kind]
+    mfn = {"deepfm": deepfm.model_fn, "dcn": dcn.model_fn, "fm": fm.model_fn}[kind]
     base = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D, "learning_rate": 1e-3,
             "dropout": 0.0, "deep_layers": ",".join(map(str, layers)), "cross_layers": 2}
-    P = init.deepfm_params(3, D, layers, np.float32, row_off) if kind == "deepfm" else \
+    P = init.deepfm_params(3, D, layers, np.float32, row_off, with_dnn=kind != "fm") if kind in ("deepfm", "fm") else \
         init.dcn_params(3, D, layers, 2, np.float32, row_off)
     ests = []
     for w in (world, 1):
