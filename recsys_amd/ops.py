@@ -871,10 +871,12 @@ class CinNet:
                                     B, self.D, _stream()), "rsx_cin_out_fwd")
         return self.y[:B]
 
-    def backward(self, X0, P, gy, sweeps=None):
+    def backward(self, X0, P, gy, sweeps=None, dX0_out=None):
         """gy [B]: gradient wrt cin_y.  Writes the cin.* gradients into P[...].grad and returns dX0 [B,F,D] (internal
-        buffer).  sweeps[k]: slice of the untouched-row optimizer sweep carried by layer k's weight-gradient launch."""
+        buffer, or dX0_out: a caller-owned contiguous [B,F,D] buffer).  sweeps[k]: slice of the untouched-row optimizer sweep
+        carried by layer k's weight-gradient launch."""
         B, L = X0.shape[0], self.L
+        dX0 = self.dX0 if dX0_out is None else dX0_out
         check(lib().rsx_cin_out_bwd(self._outs_h, self._sizes_h, L, _ptr(self.y), _ptr(gy), _ptr(self.gs), _ptr(P["cin.Wout"].grad),
                                     _ptr(P["cin.bout"].grad), B, self.D, _stream()), "rsx_cin_out_bwd")
         wout = P["cin.Wout"].data_ptr()
@@ -882,12 +884,12 @@ class CinNet:
             Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])
             dout = None if k == L - 1 else _ptr(self.dmap[k])
             if k == 0:   # X0 in both roles: one buffer, accumulating
-                dxk, acc_dxk, acc_dx0 = self.dX0, 1 if L > 1 else 0, 1
+                dxk, acc_dxk, acc_dx0 = dX0, 1 if L > 1 else 0, 1
             else:
                 dxk, acc_dxk, acc_dx0 = self.dmap[k - 1], 0, 0 if k == L - 1 else 1
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(self.outs[k]), dout, _ptr(self.gs),
-                                          C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(self.dX0), acc_dx0,
+                                          C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
                                           self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
-        return self.dX0[:B]
+        return dX0[:B]

@@ -72,6 +72,10 @@ def build_variables(store, params, capacity):
     store.cin_sizes = cin
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
     store.cin = CinNet(F, D, cin, capacity, store.device)
+    store.dp_block = False
+    if store.dp is not None and params.get("dp_send_block", True):          # zero-copy gradient exchange (see deepfm.py)
+        store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])
+        store.dp_block = True
     store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
 
@@ -90,10 +94,14 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     dp, P = store.dp, store.dense
     B = ids.shape[0]
     sweeps, hot, L = None, None, len(store.cin_sizes)
+    zc = dp is not None and getattr(store, "dp_block", False)
     with torch.no_grad():
-        if dp is None:
-            store.sort_ids_for_backward(a1, ids)                            # serves a2 as well (share_sort_of)
-            a2.last_B = B
+        # data-parallel: the optimizer sees the GLOBAL batch -- the dedup sort runs over the all-gathered ids (issued first:
+        # they depend on nothing of the step), so the same exact split of the TF-1 update applies as on one GPU
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if zc else ids
+        if dp is None or zc:
+            a1.field_sort(ids_sort)                                         # serves a2 as well (share_sort_of)
+            a2.last_B = ids_sort.shape[0]
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
                 # (700 MB of streaming) rides in the CIN forward and weight-gradient launches (MFMA work, little HBM); the touched rows
@@ -105,6 +113,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 tw = sum(w)
                 sweeps = store.opt.cold_slices(c1 + c2, [share * x / tw for x in w] + [(1.0 - share) * x / tw for x in w])
                 hot = h1 + h2
+        dX1v, dX2v, glv = dp.send_views(B) if zc else (None,) * 3          # per-example gradient block, written in place
         E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
         lin_pre = y1cat.addmv_(logx, P["lin.wnum"])                         # + 13 numeric log-values (:127), in place
         E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
@@ -112,13 +121,27 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         cin_y = store.cin.forward(X0, P, None if sweeps is None else sweeps[:L])                                   # 'cin_net' (:135-182), csrc/cin.hip
         loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
-            s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks)
-        dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:]).view(B, -1)   # cin.* grads land in the dense arena
+            s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks,
+            seed=0x5eed + (7919 * dp.rank if dp is not None else 0),       # replicas draw independent dropout patterns
+            outs=(dX2v, glv, None) if zc else None)
+        dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:],
+                                 dX0_out=dX1v.view(B, a1.F, a1.D) if zc else None).view(B, -1)   # cin.* grads land in the dense arena
         torch.mv(logx.t(), g_lin, out=P["lin.wnum"].grad)
 
     def train_op():
         with torch.no_grad():
-            if dp is not None:
+            if zc:
+                # ONE collective straight from the send block [dense arena | dX1 | dX2 | g_lin]; both table sets' scatter +
+                # touched-row Adam + the dense update (replica arenas summed in rank order) in one launch
+                (dX1g, dX2g, glg), blocks, dense_segs = dp.gather_send_block(B, fold_dense=hot is not None)
+                Bg = B * dp.world
+                if hot is not None:
+                    a1.segsum_adam(Bg, None, dX1g, glg, None, store.opt, dense_segs, None, blocks=blocks, second=(a2, dX2g))
+                else:
+                    a1.segsum(Bg, None, dX1g, glg, None, blocks=blocks)
+                    a2.segsum(Bg, None, dX2g, None, None, blocks=blocks)
+                    store.apply_gradients()
+            elif dp is not None:
                 both = torch.cat([dX1, dX2], 1)          # both table sets' gradients + ids in ONE all-gather
                 dg, _, g1, _, idsg = dp.gather_example_grads(both, None, g_lin, None, ids=ids)
                 w = dX1.shape[1]

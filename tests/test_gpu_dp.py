@@ -82,3 +82,42 @@ def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world)
         ta, tb = a.store.embeddings[name].tables, b.store.embeddings[name].tables
         assert float((ta - tb).abs().max()) < 2e-6, name
     assert float((a.store.dense.flat - b.store.dense.flat).abs().max()) < 2e-6
+
+
+def test_xdeepfm_blocked_data_parallel_equals_single_batch():
+    """xdeepfm.py's data-parallel step (global sort first, sweep slices in the CIN launches, send block [dX1 | dX2 | g_lin |
+    dense], both table sets in one scatter + Adam launch reading rank blocks in place): an emulated world of 2 replicas of
+    a batch must train exactly like one process on the batch repeated twice.  Both sides start from the same seeded init."""
+    import numpy as np
+    import torch
+    from recsys_amd import xdeepfm
+    from recsys_amd.dist import EmulatedDataParallel
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    from tests.parity_util import make_estimator, synth_ids
+    B, world = 40, 2
+    rng = np.random.default_rng(11)
+    lin, emb = build_feature_columns(16, "numeric+indicator")
+    row_off = CriteoLayout.from_columns(emb).row_off
+    base = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+            "dropout": 0.0, "deep_layers": "32,16", "cross_layers": "16,8"}
+    ests = []
+    for w in (world, 1):
+        est = make_estimator(xdeepfm.model_fn, dict(base, max_batch_size=B * (1 if w > 1 else world)))
+        if w > 1:
+            est.store.dp = EmulatedDataParallel(w)
+        ests.append(est)
+    for step in range(3):
+        ids = synth_ids(rng, B, np.asarray(row_off))
+        logx = np.log(np.floor(np.exp(rng.normal(2, 1, (B, 13)))) + 1.0).astype(np.float32)
+        y = (rng.random(B) < 0.3).astype(np.float32)
+        losses = []
+        for est, rep in zip(ests, (1, world)):
+            f = {"ids": torch.from_numpy(np.tile(ids, (rep, 1))).cuda(), "cont_log": torch.from_numpy(np.tile(logx, (rep, 1))).cuda()}
+            losses.append(float(est._train_step(f, torch.from_numpy(np.tile(y, rep)).cuda())))
+        assert abs(losses[0] - losses[1]) < 1e-6, losses
+    a, b = ests
+    for name in a.store.embeddings:
+        ta, tb = a.store.embeddings[name].tables, b.store.embeddings[name].tables
+        assert float((ta - tb).abs().max()) < 2e-6, name
+    assert float((a.store.embeddings["input_layer"].w1 - b.store.embeddings["input_layer"].w1).abs().max()) < 2e-6
+    assert float((a.store.dense.flat - b.store.dense.flat).abs().max()) < 2e-6
