@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm", "din"],
                    help="deepfm = the BASELINE metric's config (configs[1]); the others are the remaining BASELINE configs "
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
-    p.add_argument("--steps_per_graph", type=int, default=8, help="training steps captured per HIP graph (1: per-step "
+    p.add_argument("--steps_per_graph", type=int, default=16, help="training steps captured per HIP graph (1: per-step "
                    "graph fed by one D2D copy of the batch)")
     return p.parse_args()
 
