@@ -1,0 +1,97 @@
+"""Argument validation of the device entry points (include/rsx.h): every call below is rejected
+BEFORE any HIP call is made, so the checks run without a GPU.  Pointers are fake non-NULL addresses -- they are never read."""
+import ctypes as C
+
+import pytest
+
+EINVAL, EUNSUPPORTED, OK = -1, -3, 0
+P = C.c_void_p(0x1000)          # "some non-NULL pointer"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from recsys_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.lib()
+
+
+def test_gather_and_sort_reject_bad_shapes(L):
+    assert L.rsx_gather_fm_fwd(None, None, P, P, P, None, None, None, 0, 8, 4, 16, None) == EINVAL          # no tables
+    assert L.rsx_gather_fm_fwd(P, None, P, P, P, None, None, None, 0, 8, 4, 12, None) in (EINVAL, EUNSUPPORTED)   # D = 12
+    assert L.rsx_field_sort(P, P, P, P, P, P, P, None, 100, 8, 4, 4, None) == EINVAL                      # stride < B
+    assert L.rsx_field_sort(P, P, P, P, P, P, P, None, 100, 1 << 20, 4, 1 << 20, None) == EUNSUPPORTED    # one workgroup's LDS
+    assert L.rsx_field_sort_large(P, P, P, P, P, P, P, None, None, 100, 8, 4, 8, None) == EINVAL          # no workspace
+    assert L.rsx_field_sort_large(P, P, P, P, P, P, P, None, P, 1 << 19, 8, 4, 8, None) == EUNSUPPORTED   # > 2^18 rows per field
+    assert L.rsx_field_sort_large_workspace_ints(100, 3, 128) > 3 * 3 * 128
+
+
+def test_cin_entry_points_reject_bad_arguments(L):
+    sizes = (C.c_int32 * 9)(*([16] * 9))
+    outs = (C.c_void_p * 9)(*([0x1000] * 9))
+    assert L.rsx_cin_out_fwd(outs, sizes, 9, P, P, P, 4, 16, None) == EUNSUPPORTED                        # > 8 layers
+    assert L.rsx_cin_out_fwd(outs, sizes, 2, P, P, P, 4, 8, None) == EUNSUPPORTED                         # D != 16
+    assert L.rsx_cin_out_fwd(None, sizes, 2, P, P, P, 4, 16, None) == EINVAL
+    assert L.rsx_cin_out_fwd(outs, sizes, 2, None, P, P, 4, 16, None) == EINVAL
+    assert L.rsx_cin_out_fwd(outs, sizes, 2, P, P, P, 0, 16, None) == OK                                  # empty batch
+    assert L.rsx_cin_out_bwd(outs, sizes, 2, P, P, None, P, P, 4, 16, None) == EINVAL                     # no gs
+    assert L.rsx_cin_layer_fwd(P, P, P, P, P, 4, 39, 200, 16, 16, None, None) == EUNSUPPORTED             # H > 128
+    # backward: neither dout nor the direct-connect pair
+    assert L.rsx_cin_layer_bwd(P, P, P, P, None, None, None, P, 0, C.c_void_p(0x2000), 0, P, P, P, 4, 39, 39, 16, 16, None, None) == EINVAL
+    # gs without wout
+    assert L.rsx_cin_layer_bwd(P, P, P, P, None, P, None, P, 0, C.c_void_p(0x2000), 0, P, P, P, 4, 39, 39, 16, 16, None, None) == EINVAL
+    # one gradient buffer for both roles of X0 is legal only for the first layer (Xk == X0) and accumulating
+    assert L.rsx_cin_layer_bwd(P, C.c_void_p(0x3000), P, P, P, None, None, P, 0, P, 1, P, P, P, 4, 39, 39, 16, 16, None, None) == EINVAL
+    assert L.rsx_cin_layer_bwd(P, P, P, P, P, None, None, P, 0, P, 0, P, P, P, 4, 39, 39, 16, 16, None, None) == EINVAL
+    assert L.rsx_cin_bwd_workspace_floats(4, 39, 128, 128) == 4 * 128 * 16 + 8 * 4 * 39 * 16
+
+
+def test_tower_batch_norm_free_mode_is_all_or_nothing(L):
+    u32 = C.c_uint32
+    # forward: previous layer present (fstat_prev) with gamma but no beta / bn_prev_out
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, P, P, None, None, None, P, u32(1), 1, 0.0, 8, 16, 16, None, None, None) == EINVAL
+    # forward: gamma NULL but beta given
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, P, None, P, None, None, P, u32(1), 1, 0.0, 8, 16, 16, None, None, None) == EINVAL
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, None, None, None, None, None, P, u32(1), 0, 0.0, 8, 18, 16, None, None, None) == EUNSUPPORTED  # K % 4
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, None, None, None, None, None, P, u32(1), 0, 1.0, 8, 16, 16, None, None, None) == EINVAL       # rate
+    # head: gamma NULL with beta non-NULL
+    args = [P, P, None, P, None, P, P, P] + [None] * 5 + [P, P, P, P, P, P, None, None, P]
+    assert L.rsx_tower_head(*args, u32(1), 0, 0.0, 1.0, 0, 0, 8, 16, None, None) == EINVAL
+    args[2], args[3] = None, None                                                                        # no batch-norm: fine up to ...
+    assert L.rsx_tower_head(*args, u32(1), 0, 0.0, 1.0, 0, 0, 8, 300, None, None) == EUNSUPPORTED        # ... the width limit
+
+
+def test_optimizer_segments_are_validated(L):
+    from recsys_amd._lib import AdamSeg, RSX_ADAM_DENSE, RSX_ADAM_TABLE_TF1
+    seg = (AdamSeg * 1)()
+    seg[0].kind, seg[0].n = RSX_ADAM_DENSE, 100
+    for f in ("var", "m", "v", "g"):
+        setattr(seg[0], f, 0x1000)
+    seg[0].B, seg[0].stride = 4, 64                     # replica sum: stride shorter than the arena
+    assert L.rsx_adam_tf1_multi(seg, 1, P, 1e-3, 0.9, 0.999, 1e-8, None) == EINVAL
+    seg[0].stride = 102                                 # not a multiple of 4 floats
+    assert L.rsx_adam_tf1_multi(seg, 1, P, 1e-3, 0.9, 0.999, 1e-8, None) == EINVAL
+    seg[0].kind, seg[0].d, seg[0].B, seg[0].stride = RSX_ADAM_TABLE_TF1, 6, 0, 0     # row width not a multiple of 4
+    seg[0].slot = 0x1000
+    assert L.rsx_adam_tf1_multi(seg, 1, P, 1e-3, 0.9, 0.999, 1e-8, None) == EINVAL
+    assert L.rsx_adam_tf1_multi(seg, 13, P, 1e-3, 0.9, 0.999, 1e-8, None) == EINVAL   # > RSX_ADAM_MAX_SEGS
+    assert L.rsx_adam_num_blocks(seg, 1) < 0
+
+
+def test_scatter_second_table_set_is_validated(L):
+    from recsys_amd._lib import TableSet
+    ts = TableSet(0x1000, 0x1000, 0, 0x1000, None)      # no v
+    r = L.rsx_segsum_adam_rows(P, P, P, None, None, None, None, P, None, None, P, P, P, P, 0, 8, 4, 16, 8, None, 0, None, None,
+                               None, C.byref(ts), P, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+    assert r == EINVAL
+    # first-order gradient without the first-order vector
+    r = L.rsx_segsum_adam_rows(P, P, P, None, None, None, None, P, P, None, P, P, P, P, 0, 8, 4, 16, 8, None, 0, None, None,
+                               None, None, P, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+    assert r == EINVAL
+
+
+def test_attention_envelope(L):
+    u32 = C.c_uint32
+    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, 4, 10, 24, 80, 40, None) == EUNSUPPORTED  # K
+    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, 4, 10, 32, 96, 40, None) == EUNSUPPORTED  # N1
+    assert L.rsx_din_attn_bwd(P, P, P, P, P, P, P, P, None, P, P, P, None, None, P, u32(1), 0, 0.0, 0, 4, 10, 32, 80, 40, None) == EINVAL
+    assert L.rsx_din_attn_bwd_workspace_floats(4, 10, 32, 80, 40) > 0
