@@ -121,6 +121,21 @@ def main():
                         losses=np.array(losses), probs=np.stack(probs),
                         **{"batch.%s" % k: np.stack([b[k] for b in bat]).astype(np.int64) for k in bat[0]},
                         **{"init." + k: v.astype(np.float32) for k, v in Pn0.items()}, **{"final." + k: v for k, v in Pn_.items()})
+    # 7. an FM trajectory (fm/fm.py: first order + FM second order + 2->1 head) on the small layout ------------------
+    Pf = init.deepfm_params(13, 16, (), np.float64, off, with_dnn=False)
+    Pf["b1"] += 0.05
+    Pf0 = {k: v.copy() for k, v in Pf.items()}
+    mf, optf = models.FM(Pf, off), nn.AdamTF1(dtype=np.float64)
+    ids_f = np.stack([np.stack([rng.integers(0, r, Bt) for r in rows], 1) for _ in range(steps)]).astype(np.int32)
+    y_f = rng.integers(0, 2, (steps, Bt)).astype(np.float64)
+    losses, probs = [], []
+    for s in range(steps):
+        probs.append(nn.sigmoid(mf.forward(ids_f[s], train=False)))
+        loss, _ = models.train_step(mf, optf, (ids_f[s],), y_f[s])
+        losses.append(float(loss))
+    np.savez_compressed(os.path.join(HERE, "fm_trajectory.npz"), rows=np.array(rows), ids=ids_f, labels=y_f,
+                        losses=np.array(losses), probs=np.stack(probs),
+                        **{"init." + k: v.astype(np.float32) for k, v in Pf0.items()}, **{"final." + k: v for k, v in Pf.items()})
     print("golden fixtures written to", HERE)
 
 

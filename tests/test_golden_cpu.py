@@ -84,3 +84,16 @@ def test_oracle_reproduces_golden_dcn_and_din_trajectories():
         assert abs(float(loss) - float(d["losses"][s])) < 1e-6
     for k in P:
         np.testing.assert_allclose(P[k], d["final." + k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_oracle_reproduces_golden_fm_trajectory():
+    t = np.load(os.path.join(G, "fm_trajectory.npz"))
+    rows = tuple(int(r) for r in t["rows"])
+    off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    P = {k[5:]: t[k].astype(np.float64) for k in t.files if k.startswith("init.")}
+    m, opt = models.FM(P, off), nn.AdamTF1(dtype=np.float64)
+    for s in range(t["ids"].shape[0]):
+        loss, _ = models.train_step(m, opt, (t["ids"][s],), t["labels"][s])
+        assert abs(float(loss) - float(t["losses"][s])) < 1e-6
+    for k in P:
+        np.testing.assert_allclose(P[k], t["final." + k], rtol=0, atol=2e-6, err_msg=k)
