@@ -29,6 +29,7 @@ struct LargeSort {
                             // fields).  All zero between calls: each pass's scatter launch clears what its scan consumed
   const int32_t* src0;      // pass-0 keys: idsT, or ids itself when F == 1 (the transpose is then the identity)
   int B, F, stride, nT;
+  int fuse_scan;            // few tiles: every scatter workgroup derives its own offsets from the raw counts (no scan launch)
 };
 
 __device__ __forceinline__ void digit_split(const int32_t* row_off, int f, int pass, int& sh, int& nb) {
@@ -161,8 +162,11 @@ __global__ __launch_bounds__(LS_T) void ls_scatter_k(const LargeSort a, int pass
   const uint32_t mask = (1u << nb) - 1u;
   for (int i = tid; i < (LS_T / 64) * LS_BINS; i += LS_T) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  if (a.dtot != nullptr && t == 0)      // the scan of this pass is done: leave the totals clean for the next call
-    for (int i = tid; i < LS_BINS; i += LS_T) a.dtot[((size_t)pass * a.F + f) * LS_BINS + i] = 0;
+  // Leave the digit totals clean for the next call once nobody reads them any more: with a scan launch that is now (this
+  // pass's scan is done); with the scan fused into this kernel the pass-0 totals are cleared by the pass-1 launch and the
+  // pass-1 totals by the segment kernels.
+  if (a.dtot != nullptr && t == 0 && (!a.fuse_scan || pass == 1))
+    for (int i = tid; i < LS_BINS; i += LS_T) a.dtot[((size_t)(a.fuse_scan ? 0 : pass) * a.F + f) * LS_BINS + i] = 0;
   const size_t fo = (size_t)f * a.stride;
   const int32_t* skey = (pass == 0 ? a.src0 : a.keyA) + fo;
   const int32_t* sval = a.valA + fo;                 // pass 1 only; pass 0: value = position
@@ -181,8 +185,43 @@ __global__ __launch_bounds__(LS_T) void ls_scatter_k(const LargeSort a, int pass
     if (ok[k]) atomicAdd(&cnt[w][(key[k] >> sh) & mask], 1u);
   }
   __syncthreads();
+  __shared__ int wtot[LS_BINS / 64];
+  uint32_t run0 = 0;
+  if (a.fuse_scan) {
+    // offset of (digit, this tile) = keys of smaller digits (exclusive scan of the digit totals) + keys of this digit in
+    // earlier tiles (raw counts: the scan launch is skipped)
+    int tot = 0, before = 0;
+    if (tid < LS_BINS) {
+      tot = a.dtot[((size_t)pass * a.F + f) * LS_BINS + tid];
+      const int32_t* h = a.hist + ((size_t)f * LS_BINS + tid) * a.nT;
+      int tt = 0;
+      for (; tt + 8 <= t; tt += 8) {
+        int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = h[tt + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) before += c[u];
+      }
+      for (; tt < t; ++tt) before += h[tt];
+    }
+    int incl = tot;
+#pragma unroll
+    for (int s_ = 1; s_ < 64; s_ <<= 1) {
+      const int o = __shfl_up(incl, s_);
+      if (lane >= s_) incl += o;
+    }
+    if (tid < LS_BINS && lane == 63) wtot[w] = incl;
+    __syncthreads();
+    if (tid < LS_BINS) {
+      int base = incl - tot;
+      for (int ww = 0; ww < w; ++ww) base += wtot[ww];
+      run0 = (uint32_t)(base + before);
+    }
+  } else if (tid < LS_BINS) {
+    run0 = (uint32_t)a.hist[((size_t)f * LS_BINS + tid) * a.nT + t];
+  }
   if (tid < LS_BINS) {
-    uint32_t run = (uint32_t)a.hist[((size_t)f * LS_BINS + tid) * a.nT + t];
+    uint32_t run = run0;
 #pragma unroll
     for (int ww = 0; ww < LS_T / 64; ++ww) {
       const uint32_t c = cnt[ww][tid];
@@ -223,6 +262,7 @@ struct LargeSeg {
   int32_t* slot;            // [R]
   int32_t* segid;           // nullable: [F*stride | 2F counts | F*nch lists]
   int32_t* blk_cnt;         // [F, nblk]
+  int32_t* dtot1;           // nullable: the sort's pass-1 digit totals [F, LS_BINS], cleared here when its scan was fused
   int B, F, stride, nblk;
 };
 
@@ -233,6 +273,8 @@ __global__ __launch_bounds__(SG_T) void ls_heads_k(const LargeSeg a) {
   const int prev = a.nuniq[f];
   for (int jj = blockIdx.x * SG_T + tid; jj < prev; jj += gridDim.x * SG_T) a.slot[a.uniq_row[(size_t)f * a.stride + jj]] = -1;
   if (a.segid != nullptr && blockIdx.x == 0 && tid < 2) a.segid[(size_t)a.F * a.stride + tid * a.F + f] = 0;
+  if (a.dtot1 != nullptr && blockIdx.x == 0)
+    for (int i = tid; i < LS_BINS; i += SG_T) a.dtot1[(size_t)f * LS_BINS + i] = 0;
   const int32_t* keys = a.keys + (size_t)f * a.stride;
   const int i0 = blockIdx.x * SG_BLK + tid * SG_IPT;
   int cnt = 0;
@@ -346,10 +388,12 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   const size_t nT_cap = ((size_t)stride + LS_TILE - 1) / LS_TILE;
   a.dtot = F >= 16 ? nullptr : a.hist + (size_t)F * LS_BINS * nT_cap + (size_t)F * (((size_t)stride + SG_BLK - 1) / SG_BLK);
   a.src0 = F == 1 ? ids : a.idsT;
+  a.fuse_scan = a.dtot != nullptr && a.nT <= 64;
   if (F > 1) hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     hipLaunchKernelGGL(ls_hist_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
-    if (F >= 16) hipLaunchKernelGGL(ls_scan_field_k, dim3(F), dim3(LS_BINS), 0, st, a);
+    if (a.fuse_scan) {}      // the scatter workgroups derive their offsets themselves
+    else if (F >= 16) hipLaunchKernelGGL(ls_scan_field_k, dim3(F), dim3(LS_BINS), 0, st, a);
     else hipLaunchKernelGGL(ls_scan_k, dim3((unsigned)((F * LS_BINS + 3) / 4)), dim3(256), 0, st, a, pass);
     hipLaunchKernelGGL(ls_scatter_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
   }
@@ -357,6 +401,7 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   LargeSeg g;
   g.keys = a.idsT; g.row_off = row_off; g.seg_off = seg_off; g.uniq_row = uniq_row; g.nuniq = nuniq; g.slot = slot;
   g.segid = segid;
+  g.dtot1 = a.fuse_scan ? a.dtot + (size_t)F * LS_BINS : nullptr;
   g.blk_cnt = a.hist + (size_t)F * LS_BINS * nT_cap;
   // (a.dtot sits after blk_cnt's F * nblk ints)
   g.B = B; g.F = F; g.stride = stride; g.nblk = (B + SG_BLK - 1) / SG_BLK;
