@@ -8,11 +8,13 @@ and dropout stay per replica; one global step per synchronous step.
 
 MI355X design (tables are only 54 MB, replicated -- no row sharding / all-to-all):
   * dense grads: ONE flat all-reduce(sum) over the dense arena's gradient buffer (<= 0.4 MB, latency
-    bound, so a single bucket).
+    bound, so a single bucket) -- in the fused steps folded into the sparse collective below: the arena rides in
+    front of the per-example block and the optimizer launch adds the replicas' arenas in rank order.
   * sparse (embedding) grads: TF concatenates the replicas' IndexedSlices and dedups in the optimizer.
-    Here each rank all-gathers the batch ids (at step start, they are inputs) and ONE packed
-    per-example gradient block [dX | S | gy1 | gy2] (after backward); every rank then runs the same
-    per-field sort + sorted segment-sum over the GLOBAL batch of N*b examples.  DP(N, b) is therefore
+    Here each rank all-gathers the batch ids (at step start, they are inputs) and ONE per-example gradient
+    block [dense | dX | S | gy2 | gy1] (after backward), sent straight from a persistent send block that the
+    kernels write in place; every rank then runs the same per-field sort + sorted segment-sum over the GLOBAL
+    batch of N*b examples, reading every rank's block in place from the gathered buffer.  DP(N, b) is therefore
     the single-process computation on N*b examples by construction, in a fixed (rank, example) order,
     and every replica applies bit-identical updates.  On the 8-GPU xGMI full mesh an all-gather sends
     each peer its slice over a dedicated link (7 x ~153 GB/s) instead of a ring.
@@ -45,10 +47,11 @@ def init_process_group(backend=None):
 
 class SegmentedGraph:
     """A training step captured as HIP-graph SEGMENTS with the RCCL collectives launched eagerly between them:
-    [graph | collective]* replayed in order on the current stream.  The compute stays launch-free (graphs) while
-    the collectives take RCCL's ordinary, un-captured path -- robust on every RCCL build, and the collectives' host
-    cost (a few us each) hides behind the previous segment's GPU time.  RSX_DP_CAPTURE=1 captures the collectives
-    into the graph instead (single segment).
+    [graph | collective | eager callable]* replayed in order on the current stream.  The compute stays launch-free
+    (graphs) while the collectives take RCCL's ordinary, un-captured path -- robust on every RCCL build, and the
+    collectives' host cost (a few us each) hides behind the previous segment's GPU time.  The Estimator appends the
+    step's train_op as an eager callable (a graph around its 2-3 launches costs more than it saves).
+    RSX_DP_CAPTURE=1 captures the collectives into the graph instead (single segment).
 
     Rule for code running under capture: a collective's input and output tensors must exist BEFORE the break (they
     are then allocated from the graphs' shared private pool, so their addresses are the ones every replay uses)."""
