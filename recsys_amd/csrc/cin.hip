@@ -793,9 +793,19 @@ __global__ __launch_bounds__(256) void cin_out_fwd_k(const CinOutArgs p) {
   for (int k = 0; k < p.L; ++k) {
     const float4* src = reinterpret_cast<const float4*>(p.out[k] + (size_t)b * p.n[k] * CIN_D);
     const float* w = p.Wout + p.off[k];
-    for (int e = lane; e < p.n[k] * 4; e += 64) {
-      const float4 v = src[e];
-      s += w[e >> 2] * ((v.x + v.y) + (v.z + v.w));
+    const int n4 = p.n[k] * 4;
+    for (int e0 = lane; e0 < n4; e0 += 64 * 8) {      // 8 independent loads in flight (clamped index, masked weight)
+      float4 v[8];
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u;
+        const int ec = e < n4 ? e : n4 - 1;
+        v[u] = src[ec];
+        wv[u] = w[ec >> 2] * (e < n4 ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += wv[u] * ((v[u].x + v[u].y) + (v[u].z + v[u].w));
     }
   }
 #pragma unroll
