@@ -897,7 +897,9 @@ extern "C" int rsx_fm_head(const float* y1, const float* y2, const float* c0, co
 // row blocks a dW tile's batch reduction is split into (1 without workspace or for small batches)
 static inline int rsx_tower_dw_blocks(int B, bool have_ws) {
   if (!have_ws || B < 1024) return 1;
-  const int sb = (B + 255) / 256;
+  // rows per dW row block: 512 measured 2-3 % faster than 256 on dcn.py bs 4096 (fewer partial tiles to write and re-add)
+  static const int rows = getenv("RSX_TOWER_SB_ROWS") ? atoi(getenv("RSX_TOWER_SB_ROWS")) : 512;
+  const int sb = (B + rows - 1) / rows;
   return sb > 32 ? 32 : sb;
 }
 
@@ -937,7 +939,8 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;
   p.sb = rsx_tower_dw_blocks(B, dw_partials != nullptr);
-  p.din_rtw = p.sb > 1 ? 4 : 1;
+  static const int rtw_env = getenv("RSX_TOWER_RTW") ? atoi(getenv("RSX_TOWER_RTW")) : 4;
+  p.din_rtw = p.sb > 1 ? rtw_env : 1;
   p.n_din = p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
   p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
   p.dwp = dw_partials;
