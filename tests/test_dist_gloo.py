@@ -111,3 +111,79 @@ def test_dp2_equals_single_batch(tmp_path):
     for k in P:
         assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
         np.testing.assert_allclose(r0[k], P[k], rtol=0, atol=1e-13, err_msg=k)   # == single batch of N*b
+
+
+class _FakeDenseArena:
+    """The few members of ops.DenseArena that dist.DataParallel's send block touches (the real one needs a GPU)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.flat, self.m, self.v = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+        self.grad = torch.zeros(n)
+
+    def rebind_grad(self, storage):
+        g = storage[:self.n]
+        g.copy_(self.grad)
+        self.grad = g
+
+
+def _send_block_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from recsys_amd import _lib
+    from recsys_amd import dist as rdist
+    rdist.init_process_group("gloo")
+    dp = rdist.DataParallel()
+    n, b_max, widths = 37, 8, [12, 4, 1, 1]                  # dense arena of 37 floats -> the block starts at float 40
+    dense = _FakeDenseArena(n)
+    send = dp.make_send_block(dense, b_max, widths)
+    assert dense.grad.data_ptr() == send.data_ptr()           # the arena's gradient lives at the head of the send block
+    for b in (8, 5):                                          # full and ragged last batch
+        dense.grad.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        dX, S, gy2, gy1 = dp.send_views(b)
+        assert dX.shape == (b, 12) and S.shape == (b, 4) and gy2.shape == (b,) and gy1.shape == (b,)
+        assert dX.data_ptr() == send.data_ptr() + 40 * 4
+        base = 1000.0 * (rank + 1)
+        dX.copy_(base + torch.arange(b * 12, dtype=torch.float32).view(b, 12))
+        S.fill_(base + 0.5)
+        gy2.fill_(base + 0.25)
+        gy1.fill_(base + 0.125)
+        views, (bb, stride), seg = dp.gather_send_block(b, fold_dense=True)
+        out = dp._keep
+        assert bb == b and stride % 4 == 0 and out.shape == (world, stride) and stride >= 40 + b * 18
+        for r in range(world):                                # every rank's block sits `stride` floats after the previous one
+            rb = 1000.0 * (r + 1)
+            assert torch.equal(out[r, :n], torch.arange(n, dtype=torch.float32) * (r + 1))
+            assert torch.equal(out[r, 40:40 + b * 12].view(b, 12), rb + torch.arange(b * 12, dtype=torch.float32).view(b, 12))
+            assert torch.equal(out[r, 40 + b * 12:40 + b * 16], torch.full((b * 4,), rb + 0.5))
+            assert torch.equal(out[r, 40 + b * 16:40 + b * 17], torch.full((b,), rb + 0.25))
+            assert torch.equal(out[r, 40 + b * 17:40 + b * 18], torch.full((b,), rb + 0.125))
+        assert views[0].data_ptr() == out.data_ptr() + 40 * 4 and views[0].shape == (b, 12) and views[3].shape == (b,)
+        # the optimizer segment that folds the dense all-reduce: B replicas, `stride` floats apart, starting at rank 0's arena
+        (sg,) = seg
+        assert sg["kind"] == _lib.RSX_ADAM_DENSE and sg["B"] == world and sg["stride"] == stride and sg["n"] == n
+        assert sg["g"].data_ptr() == out.data_ptr() and sg["var"] is dense.flat
+        # the un-folded form sums the arenas in rank order into the local one
+        _, _, seg2 = dp.gather_send_block(b, fold_dense=False)
+        assert seg2 is None
+        assert torch.equal(dense.grad, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+    # the prefetchable ids all-gather: synchronous when nobody issued it, otherwise it waits for the asynchronous launch
+    x = torch.full((3, 2), rank, dtype=torch.int32)
+    outp = torch.empty(world * 3, 2, dtype=torch.int32)
+    op = rdist._PrefetchableAllGather(outp, x, None)
+    want = torch.cat([torch.full((3, 2), r, dtype=torch.int32) for r in range(world)])
+    op()
+    assert torch.equal(outp, want)
+    outp.zero_()
+    op.issue()
+    op.issue()                                                # idempotent while one launch is pending
+    op()
+    assert torch.equal(outp, want) and op.work is None
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_send_block_layout_world2(tmp_path):
+    """The zero-copy data-parallel exchange (DataParallel.make_send_block / send_views / gather_send_block) over a real
+    2-process gloo group: block layout, rank stride, alignment, the replica-sum optimizer segment."""
+    mp.spawn(_send_block_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
