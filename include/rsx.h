@@ -319,8 +319,18 @@ int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const f
  * 80, 40: din/din.py:85).                                                                                            */
 int rsx_din_attn_fwd(const float* H, const float* q, const float* W0, const float* b0, const float* W1, const float* b1,
                      const float* W2, const float* b2, float* a1, float* a2, float* w, const float* mask1,
-                     const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0, float dropout_rate, int B,
-                     int P, int K, int N1, int N2, rsx_stream_t stream);
+                     const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0, float dropout_rate,
+                     const int32_t* rows, const int32_t* count, int B, int P, int K, int N1, int N2, rsx_stream_t stream);
+/* rows / count (nullable pair, from rsx_din_valid_rows): evaluate only the listed history positions -- the padded ones
+ * (id 0) are masked out of the weighted sum anyway (din/din.py:118-124) and receive no gradient, so half of a ragged batch
+ * need not go through the MLP at all.  a1 / a2 / w stay indexed by the original position; entries of skipped positions are
+ * not written (w: see rsx_din_valid_rows).                                                                            */
+/* Row list of the positions with ids[b,p] > 0, ascending: rows int32 [B*P], count int32 [1 + ceil(B*P/1024)] (device;
+ * count[0] = the number of rows, the rest is scratch).  w_zero_padded
+ * (nullable, [B*P]): set to 0 at every padded position, so that rsx_din_pool_fwd -- which multiplies w by the mask -- never
+ * meets an unwritten value.  Two small launches; B*P <= 2^24.                                                                */
+int rsx_din_valid_rows(const int32_t* ids, int B, int P, int32_t* rows, int32_t* count, float* w_zero_padded,
+                       rsx_stream_t stream);
 /* Backward of rsx_din_attn_fwd given dw [B*P] = d loss / d w: dH [B*P, K] (the attention's share; the pooling's share
  * comes from rsx_din_pool_bwd), dq [B, K] (summed over the P positions), and grads = [dW0 (4K x N1) | db0 (N1) |
  * dW1 (N1 x N2) | db1 (N2) | dW2 (N2) | db2 (1)] as one flat array.  Persistent workgroups keep their weight-gradient
@@ -330,8 +340,11 @@ size_t rsx_din_attn_bwd_workspace_floats(int B, int P, int K, int N1, int N2);
 int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2, const float* a1,
                      const float* a2, const float* dw, float* dH, float* dq, float* grads, float* workspace,
                      const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
-                     float dropout_rate, int accumulate_dH, int B, int P, int K, int N1, int N2, rsx_stream_t stream);
-/* accumulate_dH != 0: dH += (rsx_din_pool_bwd has already written its share of the gradient of H into the same buffer). */
+                     float dropout_rate, int accumulate_dH, const int32_t* rows, const int32_t* count, const int32_t* ids,
+                     int B, int P, int K, int N1, int N2, rsx_stream_t stream);
+/* accumulate_dH != 0: dH += (rsx_din_pool_bwd has already written its share of the gradient of H into the same buffer).
+ * rows / count / ids (nullable together): the forward's row list and the [B*P] ids it came from; only listed positions get
+ * their dH written (accumulated) and contribute to dq.                                                                   */
 /* Sorted row keys (stable sort done by the caller) -> uniq_row[U], seg_off[U+1], nuniq[0] = U and the row -> j slot
  * map (previous call's entries cleared first): the same workspace contract as rsx_field_sort with F = 1, so
  * rsx_segsum_bwd(F = 1, B = N, perm = the sort permutation) and the TABLE_TF1 Adam kind consume it unchanged.

@@ -73,8 +73,9 @@ _SIGS = {
     "rsx_din_pool_fwd": (_I, [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P, _P]),
-    "rsx_din_attn_fwd": (_I, [_P] * 14 + [C.c_uint32, _I, _F, _I, _I, _I, _I, _I, _P]),
-    "rsx_din_attn_bwd": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _I, _I, _I, _I, _I, _P]),
+    "rsx_din_attn_fwd": (_I, [_P] * 14 + [C.c_uint32, _I, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rsx_din_valid_rows": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "rsx_din_attn_bwd": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rsx_din_attn_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "rsx_sorted_segments": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "rsx_cin_layer_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P, _P]),

@@ -36,6 +36,10 @@ struct AttnFwdArgs {
   uint32_t seed, layer0;
   float rate;
   int M, P, N1, N2;
+  // optional row list (rsx_din_valid_rows): only the rows[0 .. count[0]) -- the history positions that are not padding --
+  // are evaluated; a1 / a2 / w / masks / RNG stay indexed by the ORIGINAL row, so nothing downstream changes
+  const int32_t* rows;
+  const int32_t* count;
 };
 
 // KB = K/16, NT1 = ceil(N1/16), NT2 = ceil(N2/16).  grid = ceil(M/64), block = 256.
@@ -71,12 +75,17 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
   __syncthreads();
   const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
   const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
-  const int nblk = (p.M + 63) / 64;
+  const int Mv = p.count ? p.count[0] : p.M;     // rows to evaluate (valid history positions, or all)
+  const int nblk = (Mv + 63) / 64;
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {    // persistent: the weights are staged once per workgroup
-  const int m0 = (blk * 4 + wv) * 16;
-  const int m = m0 + i;                          // A-layout row of this lane
-  const bool mok = m < p.M;
+  const int m0 = (blk * 4 + wv) * 16;            // position in the (possibly compacted) row list
+  const bool mok = m0 + i < Mv;
+  const int jc = mok ? m0 + i : 0;
+  const int m = p.rows ? p.rows[jc] : jc;        // A-layout row of this lane (original row index)
   const int mc = mok ? m : 0;
+  int mrow[4];                                   // original indices of this lane's C-layout rows 4*kq + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mrow[r] = __shfl(mc, 4 * kq + r);   // lane 4*kq + r (kq' = 0) holds that row's index
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 h4[KB], q4[KB];
 #pragma unroll
@@ -115,9 +124,9 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
     const int n = 16 * nt + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 4 * kq + r, mm = m0 + row;
+      const int row = 4 * kq + r, mm = mrow[r];
       float v = 0.f;
-      if (n < p.N1 && mm < p.M) {
+      if (n < p.N1 && m0 + row < Mv) {
         v = fmaxf(acc1[nt][r] + sb0[n], 0.f);
         p.a1[(size_t)mm * p.N1 + n] = v;
         v *= drop_mul(d1, p.mask1, (size_t)mm * p.N1 + n);
@@ -149,8 +158,8 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
     const int n = 16 * nt + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int mm = m0 + 4 * kq + r;
-      if (n < p.N2 && mm < p.M) {
+      const int mm = mrow[r];
+      if (n < p.N2 && m0 + 4 * kq + r < Mv) {
         const float v = fmaxf(acc2[nt][r] + sb1[n], 0.f);
         p.a2[(size_t)mm * p.N2 + n] = v;
         pw[r] += v * drop_mul(d2, p.mask2, (size_t)mm * p.N2 + n) * sw2[n];
@@ -161,8 +170,8 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
     for (int s = 1; s < 16; s <<= 1) pw[r] += __shfl_xor(pw[r], s);
-    const int mm = m0 + 4 * kq + r;
-    if (i == 0 && mm < p.M) p.w[mm] = pw[r] + p.b2[0];
+    const int mm = mrow[r];
+    if (i == 0 && m0 + 4 * kq + r < Mv) p.w[mm] = pw[r] + p.b2[0];
   }
   __syncthreads();                               // S is rewritten by the next block
   }
@@ -176,15 +185,16 @@ static inline size_t attn_fwd_lds_floats(int KB, int NT1, int NT2) {
 extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0, const float* b0, const float* W1,
                                 const float* b1, const float* W2, const float* b2, float* a1, float* a2, float* w,
                                 const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed,
-                                int layer0, float dropout_rate, int B, int P, int K, int N1, int N2,
-                                rsx_stream_t stream) {
+                                int layer0, float dropout_rate, const int32_t* rows, const int32_t* count, int B, int P,
+                                int K, int N1, int N2, rsx_stream_t stream) {
   if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!H || !q || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !a1 || !a2 || !w) return RSX_EINVAL;
+  if ((rows == nullptr) != (count == nullptr)) return RSX_EINVAL;
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;     // instantiated envelope (din/din.py:85)
   AttnFwdArgs p{H, q, W0, b0, W1, b1, W2, b2, a1, a2, w, mask1, mask2, rng_step, seed, (uint32_t)layer0, dropout_rate,
-                B * P, P, N1, N2};
+                B * P, P, N1, N2, rows, count};
   const int nblk = (p.M + 63) / 64;
   const dim3 grid((unsigned)(nblk < 512 ? nblk : 512)), block(256);    // <= 2 workgroups per CU (80 KB of LDS each)
   if (K == 32) {
@@ -227,6 +237,8 @@ struct AttnBwdArgs {
   float rate;
   int M, P, N1, N2, nblk;
   int acc_dH;           // dH += (the pooling backward already wrote its part of the same gradient)
+  const int32_t* rows;  // optional row list, as in the forward: only rows[0 .. count[0]) are walked (their dH / dqr written)
+  const int32_t* count;
 };
 
 template <int KB, int NT1, int NT2>
@@ -289,15 +301,20 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
     for (int t = 0; t < 4; ++t) db1acc[a][t] = dw2acc[a][t] = 0.f;
   __syncthreads();
 
-  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
-    const int m = blk * 64 + 16 * rt + i;         // A-layout row
-    const bool mok = m < p.M;
-    const size_t mc = mok ? (size_t)m : 0;
+  const int Mv = p.count ? p.count[0] : p.M;       // rows to walk (valid history positions, or all)
+  const int nblk = (Mv + 63) / 64;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int jrow = blk * 64 + 16 * rt + i;       // position in the (possibly compacted) row list
+    const bool mok = jrow < Mv;
+    const int jc = mok ? jrow : 0;
+    const size_t mc = mok ? (size_t)(p.rows ? p.rows[jc] : jc) : 0;     // A-layout row (original index; 0 when past the end)
+    const size_t mcl = mc;
+    size_t mrow[4];                                // original indices of this lane's C-layout rows 16*rt + 4*kq + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mrow[r] = (size_t)__shfl((int)mc, 4 * kq + r);
     // ---- S1/S2: g2 (A layout, registers; both halves), the h / q / g2 tiles of the block (half 0) -----------------
     // global operands: unconditional on clamped addresses (no branch per load); with two waves per SIMD the other wave's
     // MFMAs cover their latency, so nothing is prefetched across blocks (that cost 41 registers and spilled)
-    const size_t last = (size_t)p.M - 1;
-    const size_t mcl = (size_t)m < last ? (size_t)m : last;
     const float dz = mok ? p.dw[mcl] : 0.f;
     float a2N[NT2][4], a1N[NH1][4];
 #pragma unroll
@@ -312,8 +329,7 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
       const int n = 16 * (nt0 + u) + i, nc = n < p.N1 ? n : p.N1 - 1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const size_t mm = (size_t)blk * 64 + 16 * rt + 4 * kq + r;
-        a1N[u][r] = p.a1[(mm < last ? mm : last) * p.N1 + nc];
+        a1N[u][r] = p.a1[mrow[r] * p.N1 + nc];
       }
     }
     float g2[NT2][4];
@@ -371,8 +387,8 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * rt + 4 * kq + r;
-          const size_t mm = (size_t)blk * 64 + row;
-          const bool ok = mm < (size_t)p.M && n < p.N1;
+          const size_t mm = mrow[r];
+          const bool ok = blk * 64 + row < Mv && n < p.N1;
           const float av = a1N[u][r] * (ok ? 1.f : 0.f);
           const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mm * p.N1 + n) : 0.f);
           const float gv = av > 0.f ? dg1[u][r] * mul : 0.f;
@@ -408,8 +424,8 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * rt + 4 * kq + r, col = 16 * c + i;
-          const size_t mm = (size_t)blk * 64 + row;
-          if (mm < (size_t)p.M) {
+          const size_t mm = mrow[r];
+          if (blk * 64 + row < Mv) {
             const float hv = sH[col * LDR + row], qv = sQ[col * LDR + row];
             const float dh = (dx[0][r] + dx[2][r] * qv) + dx[3][r];
             p.dH[mm * K + col] = p.acc_dH ? p.dH[mm * K + col] + dh : dh;
@@ -568,19 +584,29 @@ __global__ __launch_bounds__(1024) void din_attn_reduce_k(const float* __restric
 
 // dq[b, c] = sum_p dqr[b*P + p, c].  One workgroup per example: 256 threads = (256/K) position groups x K columns; group g
 // adds positions g, g+G', ... (ascending), the groups are then added in ascending order.
+// valid (nullable, [B*P] ids): with a row list only the positions whose id is > 0 were written to dqr -- the others are skipped
+// (selected away, never multiplied: they may hold anything).
 __global__ __launch_bounds__(256) void din_attn_dq_k(const float* __restrict__ dqr, float* __restrict__ dq, int B, int P,
-                                                     int K) {
+                                                     int K, const int32_t* __restrict__ valid) {
   __shared__ float sub[256];
   const int b = blockIdx.x, c = threadIdx.x % K, g = threadIdx.x / K, ng = 256 / K;
   const float* src = dqr + (size_t)b * P * K + c;
+  const int32_t* vid = valid ? valid + (size_t)b * P : nullptr;
   float s = 0.f;
   int pp = g;
   for (; pp + 3 * ng < P; pp += 4 * ng) {
-    const float t0 = src[(size_t)pp * K], t1 = src[(size_t)(pp + ng) * K], t2 = src[(size_t)(pp + 2 * ng) * K],
-                t3 = src[(size_t)(pp + 3 * ng) * K];
+    float t0 = src[(size_t)pp * K], t1 = src[(size_t)(pp + ng) * K], t2 = src[(size_t)(pp + 2 * ng) * K],
+          t3 = src[(size_t)(pp + 3 * ng) * K];
+    if (vid) {
+      const int v0 = vid[pp], v1 = vid[pp + ng], v2 = vid[pp + 2 * ng], v3 = vid[pp + 3 * ng];
+      t0 = v0 > 0 ? t0 : 0.f; t1 = v1 > 0 ? t1 : 0.f; t2 = v2 > 0 ? t2 : 0.f; t3 = v3 > 0 ? t3 : 0.f;
+    }
     s += t0; s += t1; s += t2; s += t3;
   }
-  for (; pp < P; pp += ng) s += src[(size_t)pp * K];
+  for (; pp < P; pp += ng) {
+    const float t = src[(size_t)pp * K];
+    s += (vid == nullptr || vid[pp] > 0) ? t : 0.f;
+  }
   sub[threadIdx.x] = s;
   __syncthreads();
   if (g == 0) {
@@ -588,6 +614,73 @@ __global__ __launch_bounds__(256) void din_attn_dq_k(const float* __restrict__ d
     for (int k = 1; k < ng; ++k) t += sub[k * K + c];
     dq[(size_t)b * K + c] = t;
   }
+}
+
+// ---- row list of the history positions that are not padding (id > 0), din/din.py:118-124 -------------------------------
+// Two small launches over 1024-position tiles: (1) valid positions per tile; (2) every tile adds the counts of the tiles
+// before it (<= a few hundred ints), compacts its own positions with ballots in ascending order and -- if asked -- zeroes w
+// at the padded positions (the pooling multiplies w by the mask).
+__global__ __launch_bounds__(256) void din_tile_counts_k(const int32_t* __restrict__ ids, int M, int32_t* __restrict__ tcnt) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = blockIdx.x * 1024 + 256 * k + tid;
+    c += (e < M && ids[e] > 0) ? 1 : 0;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
+  if (lane == 0) wsum[wv] = c;
+  __syncthreads();
+  if (tid == 0) tcnt[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void din_valid_rows_k(const int32_t* __restrict__ ids, int M, int32_t* __restrict__ rows,
+                                                        int32_t* __restrict__ count, const int32_t* __restrict__ tcnt,
+                                                        float* __restrict__ w) {
+  __shared__ int wsum[4];
+  __shared__ int sbase;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t0 = blockIdx.x * 1024;
+  int before = 0;
+  for (int t = tid; t < (int)blockIdx.x; t += 256) before += tcnt[t];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) before += __shfl_xor(before, m);
+  if (lane == 0) wsum[wv] = before;
+  __syncthreads();
+  if (tid == 0) sbase = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  __syncthreads();
+  int base = sbase;
+  // the tile in 4 passes of 256 consecutive positions: wave w of pass k covers positions t0 + 256 k + 64 w ..
+  for (int k = 0; k < 4; ++k) {
+    const int e = t0 + 256 * k + tid;
+    const bool ok = e < M && ids[e] > 0;
+    if (e < M && !ok && w != nullptr) w[e] = 0.f;
+    const uint64_t bal = __ballot(ok);
+    __syncthreads();
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int ww = 0; ww < wv; ++ww) off += wsum[ww];
+    if (ok) rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+    base += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) count[0] = base;
+}
+
+extern "C" int rsx_din_valid_rows(const int32_t* ids, int B, int P, int32_t* rows, int32_t* count, float* w_zero_padded,
+                                  rsx_stream_t stream) {
+  if (B < 0 || P <= 0) return RSX_EINVAL;
+  if (!ids || !rows || !count) return RSX_EINVAL;
+  const long long M = (long long)B * P;
+  if (M > (1ll << 24)) return RSX_EUNSUPPORTED;
+  const int nt = M == 0 ? 1 : (int)((M + 1023) / 1024);
+  hipLaunchKernelGGL(din_tile_counts_k, dim3(nt), dim3(256), 0, rsx_s(stream), ids, (int)M, count + 1);
+  hipLaunchKernelGGL(din_valid_rows_k, dim3(nt), dim3(256), 0, rsx_s(stream), ids, (int)M, rows, count, count + 1,
+                     w_zero_padded);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
 }
 
 static inline int attn_bwd_groups(int M) {
@@ -615,23 +708,25 @@ static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
 extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
                                 const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
                                 float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
-                                uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, int B, int P, int K,
-                                int N1, int N2, rsx_stream_t stream) {
+                                uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, const int32_t* rows,
+                                const int32_t* count, const int32_t* ids, int B, int P, int K, int N1, int N2,
+                                rsx_stream_t stream) {
   if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!H || !q || !W0 || !W1 || !W2 || !a1 || !a2 || !dw || !dH || !dq || !grads || !workspace) return RSX_EINVAL;
+  if ((rows == nullptr) != (count == nullptr) || (rows != nullptr && ids == nullptr)) return RSX_EINVAL;
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;
   const int M = B * P, G = attn_bwd_groups(M);
   AttnBwdArgs p{H, q, W0, W1, W2, a1, a2, dw, dH, workspace, workspace + (size_t)M * K, mask1, mask2, rng_step, seed,
-                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64, accumulate_dH != 0};
+                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64, accumulate_dH != 0, rows, count};
   hipStream_t st = rsx_s(stream);
   const int rc = K == 32 ? launch_attn_bwd<2, 5, 3>(p, G, st) : launch_attn_bwd<1, 5, 3>(p, G, st);
   if (rc != RSX_OK) return rc;
   RSX_CHECK_LAUNCH();
   const int n = (int)attn_npart(K, N1, N2);
   hipLaunchKernelGGL(din_attn_reduce_k, dim3((n + 63) / 64), dim3(1024), 0, st, p.part, G, n, grads);
-  hipLaunchKernelGGL(din_attn_dq_k, dim3(B), dim3(256), 0, st, p.dqr, dq, B, P, K);
+  hipLaunchKernelGGL(din_attn_dq_k, dim3(B), dim3(256), 0, st, p.dqr, dq, B, P, K, rows ? ids : nullptr);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -729,8 +729,8 @@ class DinAttnFn(torch.autograd.Function):
         w = torch.empty(B, P, device=dev)
         m1, m2 = (None, None) if masks is None else (masks[0].contiguous(), masks[1].contiguous())
         check(lib().rsx_din_attn_fwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(a1),
-                                     _ptr(a2), _ptr(w), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0, rate, B, P, K,
-                                     N1, N2, _stream()), "rsx_din_attn_fwd")
+                                     _ptr(a2), _ptr(w), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0, rate, None, None,
+                                     B, P, K, N1, N2, _stream()), "rsx_din_attn_fwd")
         ctx.save_for_backward(H, q, W0, W1, W2, a1, a2)
         ctx.cfg = (rate, m1, m2, rng_step, seed, layer0)
         ctx.grad_out = grad_out
@@ -753,7 +753,8 @@ class DinAttnFn(torch.autograd.Function):
         ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2)), device=dev)
         check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2),
                                      _ptr(g.contiguous()), _ptr(dH), _ptr(dq), _ptr(grads), _ptr(ws), _ptr(m1), _ptr(m2),
-                                     _ptr(rng_step), seed, layer0, rate, 0, B, P, K, N1, N2, _stream()), "rsx_din_attn_bwd")
+                                     _ptr(rng_step), seed, layer0, rate, 0, None, None, None, B, P, K, N1, N2, _stream()),
+              "rsx_din_attn_bwd")
         o = 0
         out = []
         for n, shape in ((n0, W0.shape), (N1, (N1,)), (n1, W1.shape), (N2, (N2,)), (N2, W2.shape), (1, (1,))):
@@ -779,10 +780,16 @@ class DinAttnPoolFn(torch.autograd.Function):
         a1, a2 = torch.empty(B * P, N1, device=dev), torch.empty(B * P, N2, device=dev)
         w, out = torch.empty(B, P, device=dev), torch.empty(B, K, device=dev)
         m1, m2 = (None, None) if masks is None else (masks[0].contiguous(), masks[1].contiguous())
+        # only the history positions that are not padding go through the MLP (they are masked out of the sum and get no
+        # gradient: din/din.py:118-124); w is zeroed at the padded ones
+        rows = torch.empty(B * P + 2 + (B * P + 1023) // 1024, dtype=torch.int32, device=dev)     # row list | count | scratch
+        cnt = rows[B * P:]
+        check(lib().rsx_din_valid_rows(_ptr(hist), B, P, _ptr(rows), _ptr(cnt), _ptr(w), _stream()), "rsx_din_valid_rows")
         check(lib().rsx_din_attn_fwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(a1),
-                                     _ptr(a2), _ptr(w), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0, rate, B, P, K,
-                                     N1, N2, _stream()), "rsx_din_attn_fwd")
+                                     _ptr(a2), _ptr(w), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0, rate, _ptr(rows),
+                                     _ptr(cnt), B, P, K, N1, N2, _stream()), "rsx_din_attn_fwd")
         check(lib().rsx_din_pool_fwd(_ptr(H), _ptr(w), _ptr(hist), _ptr(out), B, P, K, _stream()), "rsx_din_pool_fwd")
+        ctx.rows = rows
         ctx.save_for_backward(H, q, hist, W0, W1, W2, a1, a2, w)
         ctx.cfg = (rate, m1, m2, rng_step, seed, layer0)
         ctx.grad_out = grad_out
@@ -803,7 +810,8 @@ class DinAttnPoolFn(torch.autograd.Function):
         ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, N1, N2)), device=dev)
         check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2), _ptr(dw), _ptr(dH),
                                      _ptr(dq), _ptr(ctx.grad_out), _ptr(ws), _ptr(m1), _ptr(m2), _ptr(rng_step), seed, layer0,
-                                     rate, 1, B, P, K, N1, N2, _stream()), "rsx_din_attn_bwd")
+                                     rate, 1, _ptr(ctx.rows), _ptr(ctx.rows[B * P:]), _ptr(hist), B, P, K, N1, N2, _stream()),
+              "rsx_din_attn_bwd")
         return (dH, dq) + (None,) * 13
 
 

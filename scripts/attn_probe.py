@@ -16,14 +16,14 @@ def run(B, P, K, rate, mk, time_it=False):
     a1 = torch.empty(M, 80, device=dev); a2 = torch.empty(M, 40, device=dev); w = torch.empty(M, device=dev)
     M1, M2 = (_ptr(m1), _ptr(m2)) if mk else (None, None)
     fwd = lambda: check(lib().rsx_din_attn_fwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(a1), _ptr(a2), _ptr(w),
-                                               M1, M2, None, 0, 0, rate, B, P, K, 80, 40, _stream()), "fwd")
+                                               M1, M2, None, 0, 0, rate, None, None, B, P, K, 80, 40, _stream()), "fwd")
     fwd()
     dH = torch.empty(M, K, device=dev); dq = torch.empty(B, K, device=dev)
     n = 4 * K * 80 + 80 + 80 * 40 + 40 + 40 + 1
     grads = torch.empty(n, device=dev)
     ws = torch.empty(int(lib().rsx_din_attn_bwd_workspace_floats(B, P, K, 80, 40)), device=dev)
     bwd = lambda: check(lib().rsx_din_attn_bwd(_ptr(H), _ptr(q), _ptr(W0), _ptr(W1), _ptr(W2), _ptr(a1), _ptr(a2), _ptr(dw), _ptr(dH), _ptr(dq), _ptr(grads),
-                                               _ptr(ws), M1, M2, None, 0, 0, rate, 0, B, P, K, 80, 40, _stream()), "bwd")
+                                               _ptr(ws), M1, M2, None, 0, 0, rate, 0, None, None, None, B, P, K, 80, 40, _stream()), "bwd")
     bwd()
     torch.cuda.synchronize()
     if time_it:

@@ -91,7 +91,12 @@ def test_scatter_second_table_set_is_validated(L):
 
 def test_attention_envelope(L):
     u32 = C.c_uint32
-    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, 4, 10, 24, 80, 40, None) == EUNSUPPORTED  # K
-    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, 4, 10, 32, 96, 40, None) == EUNSUPPORTED  # N1
-    assert L.rsx_din_attn_bwd(P, P, P, P, P, P, P, P, None, P, P, P, None, None, P, u32(1), 0, 0.0, 0, 4, 10, 32, 80, 40, None) == EINVAL
+    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, None, None, 4, 10, 24, 80, 40, None) == EUNSUPPORTED  # K
+    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, None, None, 4, 10, 32, 96, 40, None) == EUNSUPPORTED  # N1
+    assert L.rsx_din_attn_fwd(P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, P, None, 4, 10, 32, 80, 40, None) == EINVAL     # rows without count
+    assert L.rsx_din_attn_bwd(P, P, P, P, P, P, P, P, None, P, P, P, None, None, P, u32(1), 0, 0.0, 0, None, None, None, 4, 10, 32, 80, 40, None) == EINVAL
+    # a row list needs the ids it was made from (the dq reduction masks by them)
+    assert L.rsx_din_attn_bwd(P, P, P, P, P, P, P, P, P, P, P, P, None, None, P, u32(1), 0, 0.0, 0, P, P, None, 4, 10, 32, 80, 40, None) == EINVAL
+    assert L.rsx_din_valid_rows(None, 4, 10, P, P, None, None) == EINVAL
+    assert L.rsx_din_valid_rows(P, 1 << 20, 1 << 10, P, P, None, None) == EUNSUPPORTED
     assert L.rsx_din_attn_bwd_workspace_floats(4, 10, 32, 80, 40) > 0

@@ -199,3 +199,53 @@ def test_fused_attention_rng_dropout_consistent_between_forward_and_backward():
     step += 1
     w3 = DinAttnFn.apply(H, q, W0, b0, W1, b1, W2, b2, rate, None, step, 123, 0)
     assert not torch.equal(w3.detach(), w.detach())              # next step -> new pattern
+
+
+@pytest.mark.parametrize("B,P", [(9, 20), (40, 100), (3, 1)])
+def test_valid_rows_list_is_exact(B, P):
+    """rsx_din_valid_rows: ascending list of the non-padding positions, their count, w zeroed at the padded ones."""
+    import ctypes as C
+    from recsys_amd.ops import _ptr, _stream, check, lib
+    rng = np.random.default_rng(B * P)
+    ids = rng.integers(0, 4, (B, P)).astype(np.int32)          # ~25 % padding anywhere (not only as a suffix)
+    ids[0] = 0                                                 # an all-padding example
+    t = torch.from_numpy(ids).cuda()
+    rows = torch.full((B * P + 2 + (B * P + 1023) // 1024,), -7, dtype=torch.int32, device="cuda")
+    w = torch.full((B, P), 3.0, device="cuda")
+    check(lib().rsx_din_valid_rows(_ptr(t), B, P, _ptr(rows), _ptr(rows[B * P:]), _ptr(w), _stream()))
+    want = np.flatnonzero(ids.reshape(-1) > 0).astype(np.int32)
+    r = rows.cpu().numpy()
+    assert int(r[B * P]) == len(want)
+    np.testing.assert_array_equal(r[:len(want)], want)
+    np.testing.assert_array_equal(w.cpu().numpy(), np.where(ids > 0, 3.0, 0.0).astype(np.float32))
+
+
+def test_attention_over_the_valid_rows_equals_attention_over_all_rows():
+    """DinAttnPoolFn (row list: padded positions skipped) == DinAttnFn + DinPoolFn over every position: same pooled output,
+    same dH / dq / weight gradients (the skipped rows contribute exact zeros; only the summation grouping differs)."""
+    from recsys_amd.ops import DinAttnFn, DinAttnPoolFn, DinPoolFn
+    rng = np.random.default_rng(5)
+    B, P, K, N1, N2 = 12, 37, 32, 80, 40
+    H = (rng.standard_normal((B, P, K)) * 0.5).astype(np.float32)
+    q = (rng.standard_normal((B, K)) * 0.5).astype(np.float32)
+    lens = rng.integers(1, P + 1, B)
+    hist = rng.integers(1, 50, (B, P)).astype(np.int32)
+    hist[np.arange(P)[None, :] >= lens[:, None]] = 0
+    Ws = [rng.standard_normal(s).astype(np.float32) * 0.2 for s in ((4 * K, N1), (N1,), (N1, N2), (N2,), (N2, 1), (1,))]
+    g = rng.standard_normal((B, K)).astype(np.float32)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = []
+    for fused in (True, False):
+        tH, tq = torch.from_numpy(H).cuda().requires_grad_(), torch.from_numpy(q).cuda().requires_grad_()
+        tW = [torch.from_numpy(x).cuda().requires_grad_() for x in Ws]
+        th = torch.from_numpy(hist).cuda()
+        gout = torch.zeros(sum(x.size for x in Ws), device="cuda")
+        if fused:
+            out = DinAttnPoolFn.apply(tH, tq, th, *tW, 0.0, None, step, 1, 0, gout)
+        else:
+            out = DinPoolFn.apply(tH, DinAttnFn.apply(tH, tq, *tW, 0.0, None, step, 1, 0), th)
+        out.backward(torch.from_numpy(g).cuda())
+        wg = gout.cpu().numpy() if fused else np.concatenate([x.grad.cpu().numpy().reshape(-1) for x in tW])
+        res.append((out.detach().cpu().numpy(), tH.grad.cpu().numpy(), tq.grad.cpu().numpy(), wg))
+    for a, b, name in zip(res[0], res[1], ("out", "dH", "dq", "weights")):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5, err_msg=name)
