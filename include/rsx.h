@@ -389,6 +389,13 @@ int rsx_cin_out_fwd(const float* const* outs_h, const int32_t* sizes_h, int L, c
  * sum_b gs[b] * sum_d out_k[b,n,d], dbout = sum_b gs[b]; fixed summation order.                                      */
 int rsx_cin_out_bwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy, float* gs,
                     float* dWout, float* dbout, int B, int D, rsx_stream_t stream);
+/* xDeepFM's input side in one launch (xdeepfm/xdeepfm.py:125-131,185): the same ids gather the rows of TWO table sets
+ * (E1 [B,F*D] for the CIN, E2 for the DNN: the script calls input_layer twice) and y1[b] = sum of the indicator weights
+ * w1[row] over the fields of w1_field_mask + <num_x[b,:], num_w> -- the pre-activation of linear_net = dense([ND numeric
+ * log-values | one-hot blocks], 1) without its bias.  ND <= 64.                                                        */
+int rsx_gather_two_fwd(const float* tables1, const float* w1, const float* tables2, const int32_t* row_off,
+                       const int32_t* ids, const float* num_x, const float* num_w, float* E1, float* E2, float* y1,
+                       uint64_t w1_field_mask, int B, int F, int D, int ND, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side ingest ("next" row f-1).  Host pointers only.

@@ -15,7 +15,8 @@ from .deepfm import define_flags as _deepfm_flags
 from .deepfm import input_fn, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
 from .feature_columns import CriteoLayout, build_feature_columns
-from .ops import CinLayerFn, CinNet, EmbeddingArena, FusedTower
+from . import _lib
+from .ops import CinLayerFn, CinNet, EmbeddingArena, FusedTower, _ptr, _stream
 
 
 def build_variables(store, params, capacity):
@@ -114,9 +115,13 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 sweeps = store.opt.cold_slices(c1 + c2, [share * x / tw for x in w] + [(1.0 - share) * x / tw for x in w])
                 hot = h1 + h2
         dX1v, dX2v, glv = dp.send_views(B) if zc else (None,) * 3          # per-example gradient block, written in place
-        E1, _, y1cat, _ = a1.gather(ids, first_order=True)                  # CIN embeddings + one-hot part of linear_net
-        lin_pre = y1cat.addmv_(logx, P["lin.wnum"])                         # + 13 numeric log-values (:127), in place
-        E2, _, _, _ = a2.gather(ids)                                        # second input_layer call (:185)
+        # both input_layer calls (:125,185) + the pre-activation of linear_net (one-hot weights + 13 numeric log-values, :127)
+        E1 = torch.empty(B, a1.F * a1.D, device=ids.device)
+        E2 = torch.empty(B, a1.F * a1.D, device=ids.device)
+        lin_pre = torch.empty(B, device=ids.device)
+        _lib.check(_lib.lib().rsx_gather_two_fwd(_ptr(a1.tables), _ptr(a1.w1), _ptr(a2.tables), _ptr(a1.row_off), _ptr(ids),
+                                                 _ptr(logx.contiguous()), _ptr(P["lin.wnum"]), _ptr(E1), _ptr(E2), _ptr(lin_pre), a1.w1_mask,
+                                                 B, a1.F, a1.D, logx.shape[1], _stream()), "rsx_gather_two_fwd")
         X0 = E1.view(B, a1.F, a1.D)
         cin_y = store.cin.forward(X0, P, None if sweeps is None else sweeps[:L])                                   # 'cin_net' (:135-182), csrc/cin.hip
         loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
