@@ -23,6 +23,11 @@ def test_gather_and_sort_reject_bad_shapes(L):
     assert L.rsx_field_sort_large(P, P, P, P, P, P, P, None, None, 100, 8, 4, 8, None) == EINVAL          # no workspace
     assert L.rsx_field_sort_large(P, P, P, P, P, P, P, None, P, 1 << 19, 8, 4, 8, None) == EUNSUPPORTED   # > 2^18 rows per field
     assert L.rsx_field_sort_large_workspace_ints(100, 3, 128) > 3 * 3 * 128
+    # xDeepFM's fused input side: both table sets, the first-order vector and the numeric part are all required
+    assert L.rsx_gather_two_fwd(P, P, None, P, P, P, P, P, P, P, 0, 8, 4, 16, 13, None) == EINVAL
+    assert L.rsx_gather_two_fwd(P, P, P, P, P, P, P, P, P, P, 0, 8, 4, 16, 65, None) == EINVAL      # > 64 numeric features
+    assert L.rsx_gather_two_fwd(P, P, P, P, P, P, P, P, P, P, 0, 8, 4, 12, 13, None) == EINVAL      # D = 12
+    assert L.rsx_gather_two_fwd(None, None, None, None, None, None, None, None, None, None, 0, 0, 4, 16, 13, None) == OK   # empty batch
 
 
 def test_cin_entry_points_reject_bad_arguments(L):
