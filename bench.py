@@ -10,7 +10,8 @@ synthetic pre-hashed batch already resident in HBM.  Optimizer semantics are the
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- dominant kernel (adam_multi_k, the TF-faithful dense Adam sweep): algorithmic bytes per
                   launch / mean launch duration measured with HIP events on the launch stream.
-  cpu_baseline -- the numpy oracle port of the same step timed on the host (N=1, rank 0 only).
+                  step_achieved / step_frac: the same bytes over the measured STEP time.
+  cpu_baseline -- the same step on PyTorch-CPU fp32 with every host core (oracle/torch_ref.py; N=1, rank 0 only).
 """
 import argparse
 import json
@@ -38,8 +39,9 @@ def parse():
     p.add_argument("--host_input", action="store_true", help="measurement aid: every step's batch starts in pinned HOST "
                    "memory and crosses PCIe inside the timed region (one packed copy per step, per-step graphs); the "
                    "reported `value` of the default run never includes this")
+    p.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; the median is reported")
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_seconds", type=float, default=12.0)
+    p.add_argument("--cpu_seconds", type=float, default=25.0)
     p.add_argument("--n_batches", type=int, default=64)
     p.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm", "din"],
                    help="deepfm = the BASELINE metric's config (configs[1]); the others are the remaining BASELINE configs "
@@ -50,35 +52,64 @@ def parse():
 
 
 def cpu_baseline(batches, layout, seconds):
-    """Oracle (numpy port of the reference semantics) timed on the host: same step, same batches."""
-    from oracle import init, models, nn
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(1)
-    except Exception:
-        ctx = None
-    P = init.deepfm_params(0, 16, (100, 100), np.float32, layout.row_off)
-    m = models.DeepFM(P, layout.row_off, 2, 0.5)
-    opt = nn.AdamTF1(dtype=np.float32)
-    rng = np.random.default_rng(0)
-    n, t0 = 0, None
+    """the same DeepFM bs-256 TRAIN step on PyTorch-CPU fp32 with every host core
+    (oracle/torch_ref.DeepFMCpuBaseline -- TensorFlow itself cannot be installed here): 20 warm-up steps, then 5 timed
+    repeats of R steps (R scaled so that the leg stays inside `seconds`), median repeat.  `value` = the efficient
+    variant (gathers + sparse gradients); `tf_literal` = the variant that builds the dense [B, 840 646] one-hot
+    input_layer and multiplies it with the [R, 1] kernel, which is what fm/fm.py:117,121 makes TensorFlow do."""
+    from oracle import init, torch_ref
+    host_cores = os.cpu_count() or 1
     B = batches[0][0].shape[0]
-    while True:
-        ids, y, _ = batches[n % len(batches)]
-        masks = [(rng.random((B, 100)) >= 0.5).astype(np.float32) for _ in range(2)]
-        models.train_step(m, opt, (ids,), y, {"masks": masks})
-        n += 1
-        if t0 is None:            # first step is warm-up (page faults of the 3x54 MB state)
-            t0, n0 = time.perf_counter(), n
-        elif time.perf_counter() - t0 > seconds:
+    P = init.deepfm_params(0, 16, (100, 100), np.float32, layout.row_off)
+
+    def timed(literal, warm, budget, max_per_rep):
+        m = torch_ref.DeepFMCpuBaseline(P, layout.row_off, 2, 0.5, literal=literal)
+        n = 0
+        t0 = time.perf_counter()
+        for _ in range(warm):
+            m.step(batches[n % len(batches)][0], batches[n % len(batches)][1])
+            n += 1
+        per = (time.perf_counter() - t0) / max(warm, 1)
+        reps = 5
+        r = int(max(1, min(max_per_rep, budget / (reps * max(per, 1e-6)))))
+        dts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(r):
+                m.step(batches[n % len(batches)][0], batches[n % len(batches)][1])
+                n += 1
+            dts.append(time.perf_counter() - t0)
+        return r * B / sorted(dts)[reps // 2], r, warm
+
+    # "All cores" is not the fastest setting on a many-core host: the step is a chain of small ops plus a memory-bound
+    # sweep, and 256 intra-op threads measured 35 examples/s on the GPU box (7 s per step of barrier thrash).  So the
+    # thread count is swept upwards and the BEST one is the baseline; every point is reported.
+    sweep, best_t, best_per = [], 1, float("inf")
+    probe = torch_ref.DeepFMCpuBaseline(P, layout.row_off, 2, 0.5, literal=False)
+    for t in sorted(set(c for c in (4, 8, 16, 32, 64, 128, host_cores) if c <= host_cores)):
+        torch.set_num_threads(t)
+        probe.step(batches[0][0], batches[0][1])
+        t0 = time.perf_counter()
+        for k in range(3):
+            probe.step(batches[k % len(batches)][0], batches[k % len(batches)][1])
+        per = (time.perf_counter() - t0) / 3
+        sweep.append((t, round(B / per, 1)))
+        if per < best_per:
+            best_t, best_per = t, per
+        elif per > 2.0 * best_per:
             break
-    dt = time.perf_counter() - t0
-    steps = n - n0
-    if ctx is not None:
-        ctx.__exit__(None, None, None)
-    return {"value": steps * B / dt, "unit": "examples/sec", "cores": 1, "kind": "port",
-            "sample": "%d DeepFM bs%d training steps of the numpy oracle (fp32, TF-1 dense Adam), %.1f s, 1 thread; "
-                      "TensorFlow itself is not installable here" % (steps, B, dt)}
+    del probe
+    torch.set_num_threads(best_t)
+    eff, r_e, w_e = timed(False, 20, seconds * 0.6, 40)          # 5 x 40 = the 200 timed steps of section 8(d)
+    lit, r_l, w_l = timed(True, 2, seconds * 0.25, 4)
+    return {"value": eff, "unit": "examples/sec", "cores": best_t, "host_cores": host_cores, "kind": "port",
+            "thread_sweep_examples_per_sec": sweep,
+            "tf_literal": {"value": lit, "unit": "examples/sec",
+                           "what": "dense [B, 840646] one-hot input_layer x [R,1] kernel, dense kernel gradient"},
+            "sample": "DeepFM bs%d TRAIN step (fwd + autograd bwd + TF-1 non-lazy Adam over all 345 MB of state), PyTorch-CPU "
+                      "fp32, torch.set_num_threads(%d) = the best point of the thread sweep on this %d-core host; efficient "
+                      "variant %d warm + 5 x %d timed steps (median repeat), TF-literal one-hot variant %d warm + 5 x %d; "
+                      "TensorFlow itself is not installable here" % (B, best_t, host_cores, w_e, r_e, w_l, r_l)}
 
 
 def main():
@@ -153,6 +184,10 @@ def main():
         return loss
 
     run(a.warmup)
+    if host_pbs is None and a.steps_per_graph > 1:
+        # every HIP graph the timed schedule replays is captured HERE (capturing executes nothing), so the timed
+        # region below is pure replay whatever `steps % steps_per_graph` is
+        est.prepare_resident(feats, a.steps, a.steps_per_graph)
 
     def sync():
         torch.cuda.synchronize()
@@ -160,18 +195,25 @@ def main():
             dp.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    loss = run(a.steps)
-    torch.cuda.synchronize()
-    if dp is not None:
-        dp.barrier()
+    # EXACTLY `steps` steps per timed region, bracketed by barrier + synchronize on both sides, MAX over ranks; the
+    # region is repeated `--repeats` times back to back and the MEDIAN repeat is reported (a 20-step region is 2 ms:
+    # one repeat is at the mercy of a single clock ramp or host hiccup).  All repeats are listed in config.
+    dts = []
+    for _ in range(max(1, a.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        loss = run(a.steps)
         torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dp is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        if dp is not None:
+            dp.barrier()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dp is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        dts.append(dt)
+    dt = sorted(dts)[len(dts) // 2]
     final_loss = float(loss)
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
@@ -212,9 +254,17 @@ def main():
         traffic = None
     if alg_bytes is not None:
         ach = alg_bytes / (adam_ms * 1e-3) / 1e9
+        # step-level figure beside the stand-alone kernel: in the timed step the sweep does not run as adam_multi_k
+        # but rides, slice by slice, in the tower / head / scatter launches (same per-workgroup code); the bytes it has
+        # to move per step are the same, so `step_achieved` = those bytes / the measured step time.
+        step_ach = alg_bytes / (dt / a.steps) / 1e9
         roof = {"bound": "hbm", "kernel": "adam_multi_k", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(ach / 8000.0, 4), "traffic": traffic, "alg_bytes_per_launch": alg_bytes,
-                "launch_ms": round(adam_ms, 5)}
+                "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                "traffic_source": "offline: separate rocprofv3 --pmc passes of this command (scripts/pmc.sh), "
+                                  "2 x FETCH_SIZE + WRITE_SIZE, committed as profiles/pmc_adam_multi_k.json" if traffic else None,
+                "alg_bytes_per_launch": alg_bytes, "launch_ms": round(adam_ms, 5),
+                "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / 8000.0, 4),
+                "step_floor_ms": round(alg_bytes / 8e12 * 1e3, 5)}
 
     if dp is not None:
         dp.barrier()
@@ -235,7 +285,8 @@ def main():
                                      ("steps_per_graph=%d" % a.steps_per_graph) if (dp is None and emu is None) else
                                      ("per-step graph segments, RCCL collectives %s" %
                                       ("captured" if os.environ.get("RSX_DP_CAPTURE") == "1" else "eager between segments"))),
-                      "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5)},
+                      "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5),
+                      "timed_repeats_ms_per_step": [round(x / a.steps * 1e3, 5) for x in dts], "reported": "median repeat"},
            "roofline": roof}
     if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":
         out["cpu_baseline"] = cpu_baseline(host, layout, a.cpu_seconds)

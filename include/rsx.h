@@ -415,7 +415,9 @@ uint32_t rsx_masked_crc32c_h(const uint8_t* data_h, size_t n);
 int64_t rsx_tfrecord_index_h(const uint8_t* buf_h, size_t n, int64_t* offsets_h, int64_t* lengths_h,
                              int64_t max_records, int verify_crc);
 /* tf.parse_single_example(feature_description) fm/fm.py:43-44,100-103 fused with the host half of input_layer:
- * records -> label[n], cont_log[n,13] (nullable), ids[n,F] in slot order.  Multi-threaded over records.          */
+ * records -> label[n], cont_log[n,13] (nullable), ids[n,F] in slot order.  Multi-threaded over records.
+ * threads: low 16 bits = worker threads; bit 16 (0x10000) = the label feature `_c0` is optional and parses as 0 when
+ * absent -- serialized Examples of a serving request (deepfm/grpc_client.py:50-76) carry no label.                  */
 int rsx_criteo_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n,
                        const int32_t* slot_src_h, const int32_t* slot_rows_h, const float* bnd_h,
                        const int32_t* bnd_off_h, const float* shift_h, int F, float* label_h, float* cont_log_h,
@@ -430,6 +432,53 @@ int64_t rsx_criteo_encode_h(const float* label_h, const float* cont_h, const uin
                             const int64_t* cat_offs_h, int64_t n, uint8_t* out_h, int64_t cap);
 int64_t rsx_din_encode_h(const int64_t* label_h, const int64_t* i_id_h, const int64_t* i_cate_h, const int64_t* hist_i_h,
                          const int64_t* hist_c_h, int64_t n, int P, int keep_padding, uint8_t* out_h, int64_t cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming reader: the whole `input_fn` front end -- tf.data.TFRecordDataset(filenames)
+ * .map(_parse_examples, num_parallel_calls).batch(batch_size)[.repeat(num_epochs)] of fm/fm.py:106-112
+ * (deepfm/deepfm.py:60-70, xdeepfm/xdeepfm.py:101-118, dcn/dcn.py:106-112, din/din.py:61-80) -- as one host object:
+ * files mmap'ed and touched once, a scanner thread on the record framing, `threads` workers that verify the masked
+ * CRC-32C (SSE4.2) and parse each Example straight into its row of a batch buffer, `queue_batches` batches in flight.
+ * Records of consecutive files form ONE stream; the final partial batch of an epoch is kept unless drop_remainder;
+ * num_epochs < 0 repeats forever.  Data-parallel sharding (MirroredStrategy gives successive batches of the stream to
+ * successive replicas, fm/fm.py:184-194): batch b of an epoch belongs to rank b % shard_world; only complete rounds of
+ * shard_world FULL batches are delivered, so every rank runs the same number of equal-size steps.
+ * next(): fills the caller's arrays (host; pinned on the training path) with the next batch of THIS rank, in stream
+ * order; returns the number of rows (batch_size, or fewer for a final partial batch), 0 at the end of the data, or a
+ * negative status code (RSX_EDATA: truncated file, crc mismatch, malformed Example, missing required feature --
+ * TF raises DataLossError / InvalidArgument there).  open() returns NULL on invalid arguments.  One consumer thread. */
+typedef struct rsx_reader rsx_reader;
+rsx_reader* rsx_criteo_reader_open_h(const char* const* paths_h, int n_paths, const int32_t* slot_src_h,
+                                     const int32_t* slot_rows_h, const float* bnd_h, const int32_t* bnd_off_h,
+                                     const float* shift_h, int F, int batch_size, int num_epochs, int shard_rank,
+                                     int shard_world, int drop_remainder, int threads, int verify_crc, int queue_batches);
+int rsx_criteo_reader_next_h(rsx_reader* r, float* label_h /*[bs]*/, float* cont_log_h /*[bs,13], nullable*/,
+                             int32_t* ids_h /*[bs,F]*/);
+rsx_reader* rsx_din_reader_open_h(const char* const* paths_h, int n_paths, int P, int batch_size, int num_epochs,
+                                  int shard_rank, int shard_world, int drop_remainder, int threads, int verify_crc,
+                                  int queue_batches);
+int rsx_din_reader_next_h(rsx_reader* r, int64_t* label_h, int64_t* i_id_h, int64_t* i_cate_h, int64_t* hist_i_h /*[bs,P]*/,
+                          int64_t* hist_c_h /*[bs,P]*/);
+int64_t rsx_reader_records_parsed_h(const rsx_reader* r);
+void rsx_reader_close_h(rsx_reader* r);
+/* the table-driven CRC-32C regardless of CPU support (rsx_crc32c_h uses the SSE4.2 instruction when present) */
+uint32_t rsx_crc32c_table_h(const uint8_t* data_h, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming eval metrics: eval_metric_ops = {tf.metrics.auc(labels, pred),
+ * tf.metrics.accuracy(labels, tf.round(pred))} fm/fm.py:150-153 + the Estimator's running mean of the batch
+ * losses, as evaluate(steps=200) fm/fm.py:221 accumulates them.
+ * One launch per eval batch adds the batch into `state` (uint64 [rsx_eval_metrics_state_words(T)], device,
+ * zeroed by the caller before the first batch; read back once at the end):
+ *   state[k], state[T+1+k], k = 0..T  examples with label 1 / label 0 whose prediction exceeds exactly k of the
+ *                                     ascending thresholds (strict fp32 `pred > t`), so that
+ *                                     tp[i] = sum_{k > i} state[k], fp[i] = sum_{k > i} state[T+1+k]
+ *   state[2T+2] examples with rint(pred) == label (tf.round: half to even)   state[2T+3] examples
+ *   state[2T+4] batches       state[2T+5] sum of batch_loss[0] over the launches (bits of a double; nullable input)
+ * thresholds: fp32 [T] ascending (TF: -1e-7, i/(T-1), 1+1e-7), T <= 256.  Integer atomics only (deterministic). */
+int rsx_eval_metrics_state_words(int num_thresholds);
+int rsx_eval_metrics_update(const float* prob, const float* labels, const float* thresholds, int num_thresholds,
+                            const float* batch_loss, uint64_t* state, int B, rsx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,15 @@ _SIGS = {
     "rsx_din_encode_h": (C.c_int64, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _P, C.c_int64]),
     "rsx_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
     "rsx_masked_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
+    "rsx_crc32c_table_h": (C.c_uint32, [_P, C.c_size_t]),
+    "rsx_criteo_reader_open_h": (_P, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "rsx_criteo_reader_next_h": (_I, [_P, _P, _P, _P]),
+    "rsx_din_reader_open_h": (_P, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "rsx_din_reader_next_h": (_I, [_P, _P, _P, _P, _P, _P]),
+    "rsx_reader_records_parsed_h": (C.c_int64, [_P]),
+    "rsx_reader_close_h": (None, [_P]),
+    "rsx_eval_metrics_state_words": (_I, [_I]),
+    "rsx_eval_metrics_update": (_I, [_P, _P, _P, _I, _P, _P, _I, _P]),
 }
 
 _lib = None

@@ -20,7 +20,7 @@ def _list(model_dir):
 def save(model_dir, store, global_step, keep_max=5):
     os.makedirs(model_dir, exist_ok=True)
     path = os.path.join(model_dir, "model.ckpt-%d.pt" % global_step)
-    tmp = path + ".tmp"
+    tmp = path + ".tmp.%d" % os.getpid()
     torch.save(store.state_dict(), tmp)
     os.replace(tmp, path)
     for _, p in _list(model_dir)[:-keep_max]:
@@ -38,5 +38,6 @@ def restore_latest(model_dir, store):
     if p is None:
         return None
     store.load_state_dict(torch.load(p, map_location="cpu"))
-    print("INFO:Restoring parameters from %s" % p, flush=True)
+    if store.dp is None or getattr(store.dp, "rank", 0) == 0:
+        print("INFO:Restoring parameters from %s" % p, flush=True)
     return p

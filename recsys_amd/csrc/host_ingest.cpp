@@ -133,7 +133,7 @@ extern "C" int rsx_bucketize_log_h(const float* x_h, int64_t n, const float* bou
   return RSX_OK;
 }
 
-extern "C" uint32_t rsx_crc32c_h(const uint8_t* p, size_t n) {
+static uint32_t crc32c_table(const uint8_t* p, size_t n) {
   (void)crc_ready;
   uint32_t c = 0xFFFFFFFFu;
   while (n >= 8) {  // slicing-by-8
@@ -148,6 +148,31 @@ extern "C" uint32_t rsx_crc32c_h(const uint8_t* p, size_t n) {
   while (n--) c = crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;
 }
+
+// CRC-32C is the polynomial of the x86 `crc32` instruction (SSE4.2): 8 bytes per instruction, 3-cycle latency.  Three
+// independent streams would hide the latency; records are ~800 B and are parsed right after, so the plain chain
+// (~2.7 GB/s per core, 3x the table version) already leaves the CRC well below the parse cost.
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const uint8_t* p, size_t n) {
+  uint64_t c = 0xFFFFFFFFu;
+  while (n >= 8) {
+    uint64_t w;
+    std::memcpy(&w, p, 8);
+    c = __builtin_ia32_crc32di(c, w);
+    p += 8;
+    n -= 8;
+  }
+  uint32_t c32 = (uint32_t)c;
+  while (n--) c32 = __builtin_ia32_crc32qi(c32, *p++);
+  return c32 ^ 0xFFFFFFFFu;
+}
+
+extern "C" uint32_t rsx_crc32c_h(const uint8_t* p, size_t n) {
+  static const bool hw = __builtin_cpu_supports("sse4.2");
+  return hw ? crc32c_hw(p, n) : crc32c_table(p, n);
+}
+
+// test hook: the table implementation regardless of the CPU (the two must agree bit for bit)
+extern "C" uint32_t rsx_crc32c_table_h(const uint8_t* p, size_t n) { return crc32c_table(p, n); }
 
 extern "C" uint32_t rsx_masked_crc32c_h(const uint8_t* p, size_t n) {
   const uint32_t c = rsx_crc32c_h(p, n);

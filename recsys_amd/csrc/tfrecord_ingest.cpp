@@ -199,12 +199,62 @@ extern "C" int64_t rsx_tfrecord_index_h(const uint8_t* buf_h, size_t n, int64_t*
   return cnt;
 }
 
-// Criteo records -> label[n], cont_log[n,13] = log(x + shift_j), ids[n,F] in slot order.
+// One Criteo record -> one row: label, cont_log[13] = log(x + shift_j) (nullable), ids[F] in slot order.
 //   slot_src[F]   source feature index j of each slot (1..13 numeric, 14..39 categorical)
 //   slot_rows[F]  bucket count of the slot; bnd / bnd_off[F+1]: boundaries of the numeric slots
 //   shift[13]     log shift of _c1.._c13 (1, except 4 for _c2: fm/fm.py:77-78)
 // Absent categorical feature -> the 'NULL' default (fm/fm.py:44); absent numeric or label -> RSX_EDATA (TF:
-// FixedLenFeature without default).
+// FixedLenFeature without default).  Shared by the batch entry point below and the streaming reader.
+int rsx_criteo_parse_row(const uint8_t* rec, size_t n, const int32_t* slot_src, const int32_t* slot_rows, const float* bnd,
+                         const int32_t* bnd_off, const float* shift, int F, uint64_t null_hash, float* label,
+                         float* cont_log, int32_t* ids, bool label_optional) {
+  float fv[14];
+  fv[0] = 0.f;
+  bool have_f[14] = {false};
+  uint64_t hv[40];
+  bool have_h[40] = {false};
+  const bool ok = for_each_feature(rec, n, [&](Span key, Span feat) {
+    const int j = key_cN(key);
+    if (j < 0) return;
+    if (j <= 13) {
+      float x;
+      if (feat_first_float(feat, x)) { fv[j] = x; have_f[j] = true; }
+    } else {
+      Span s;
+      if (feat_first_bytes(feat, s)) { hv[j] = rsx_fingerprint64_h(s.p, s.n); have_h[j] = true; }
+    }
+  });
+  bool good = ok;
+  for (int j = label_optional ? 1 : 0; j <= 13; ++j) good = good && have_f[j];
+  if (!good) return RSX_EDATA;
+  *label = fv[0];
+  float lg[14];
+  for (int j = 1; j <= 13; ++j) {
+    lg[j] = logf(fv[j] + shift[j - 1]);
+    if (cont_log) cont_log[j - 1] = lg[j];
+  }
+  for (int s = 0; s < F; ++s) {
+    const int j = slot_src[s];
+    int32_t id;
+    if (j <= 13) {
+      const float v = lg[j];
+      const float* bd = bnd + bnd_off[s];
+      const int nb = bnd_off[s + 1] - bnd_off[s];
+      if (v != v) id = nb;
+      else {
+        int lo = 0, hi = nb;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (bd[mid] <= v) lo = mid + 1; else hi = mid; }
+        id = lo;
+      }
+    } else {
+      id = (int32_t)((have_h[j] ? hv[j] : null_hash) % (uint64_t)slot_rows[s]);
+    }
+    ids[s] = id;
+  }
+  return RSX_OK;
+}
+
+// Criteo records -> label[n], cont_log[n,13], ids[n,F]: the row parser over a list of records, multi-threaded.
 extern "C" int rsx_criteo_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n,
                                   const int32_t* slot_src_h, const int32_t* slot_rows_h, const float* bnd_h,
                                   const int32_t* bnd_off_h, const float* shift_h, int F, float* label_h,
@@ -214,58 +264,38 @@ extern "C" int rsx_criteo_parse_h(const uint8_t* buf_h, const int64_t* offsets_h
   if (!buf_h || !offsets_h || !lengths_h || !slot_src_h || !slot_rows_h || !bnd_off_h || !shift_h || !label_h || !ids_h)
     return RSX_EINVAL;
   const uint64_t null_hash = rsx_fingerprint64_h(reinterpret_cast<const uint8_t*>("NULL"), 4);
+  const bool label_optional = (threads & 0x10000) != 0;      // serving requests carry no label (see rsx.h)
+  threads &= 0xFFFF;
   std::atomic<int> status{RSX_OK};
   parallel_for(n, threads, [&](int64_t a, int64_t b) {
     for (int64_t r = a; r < b; ++r) {
-      float fv[14];
-      bool have_f[14] = {false};
-      uint64_t hv[40];
-      bool have_h[40] = {false};
-      const bool ok = for_each_feature(buf_h + offsets_h[r], (size_t)lengths_h[r], [&](Span key, Span feat) {
-        const int j = key_cN(key);
-        if (j < 0) return;
-        if (j <= 13) {
-          float x;
-          if (feat_first_float(feat, x)) { fv[j] = x; have_f[j] = true; }
-        } else {
-          Span s;
-          if (feat_first_bytes(feat, s)) { hv[j] = rsx_fingerprint64_h(s.p, s.n); have_h[j] = true; }
-        }
-      });
-      bool good = ok;
-      for (int j = 0; j <= 13; ++j) good = good && have_f[j];
-      if (!good) { status.store(RSX_EDATA); continue; }
-      label_h[r] = fv[0];
-      float lg[14];
-      for (int j = 1; j <= 13; ++j) {
-        lg[j] = logf(fv[j] + shift_h[j - 1]);
-        if (cont_log_h) cont_log_h[r * 13 + (j - 1)] = lg[j];
-      }
-      for (int s = 0; s < F; ++s) {
-        const int j = slot_src_h[s];
-        int32_t id;
-        if (j <= 13) {
-          const float v = lg[j];
-          const float* bd = bnd_h + bnd_off_h[s];
-          const int nb = bnd_off_h[s + 1] - bnd_off_h[s];
-          if (v != v) id = nb;
-          else {
-            int lo = 0, hi = nb;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (bd[mid] <= v) lo = mid + 1; else hi = mid; }
-            id = lo;
-          }
-        } else {
-          id = (int32_t)((have_h[j] ? hv[j] : null_hash) % (uint64_t)slot_rows_h[s]);
-        }
-        ids_h[r * F + s] = id;
-      }
+      const int st = rsx_criteo_parse_row(buf_h + offsets_h[r], (size_t)lengths_h[r], slot_src_h, slot_rows_h, bnd_h,
+                                          bnd_off_h, shift_h, F, null_hash, label_h + r,
+                                          cont_log_h ? cont_log_h + r * 13 : nullptr, ids_h + r * F, label_optional);
+      if (st != RSX_OK) status.store(st);
     }
   });
   return status.load();
 }
 
-// DIN records (din/din.py:44-57): label, i_id, i_cate scalars (int64) and the VarLen histories, densified and zero
+// One DIN record (din/din.py:44-57): label, i_id, i_cate scalars (int64) and the VarLen histories, densified and zero
 // padded / truncated to P like sparse_tensor_to_dense + batch.
+int rsx_din_parse_row(const uint8_t* rec, size_t n, int P, int64_t* label, int64_t* i_id, int64_t* i_cate, int64_t* hist_i,
+                      int64_t* hist_c) {
+  bool got[3] = {false, false, false};
+  std::memset(hist_i, 0, sizeof(int64_t) * P);
+  std::memset(hist_c, 0, sizeof(int64_t) * P);
+  auto is = [](Span k, const char* lit, size_t len) { return k.n == len && std::memcmp(k.p, lit, len) == 0; };
+  const bool ok = for_each_feature(rec, n, [&](Span key, Span feat) {
+    if (is(key, "label", 5)) got[0] = feat_int64s(feat, label, 1) >= 1;
+    else if (is(key, "i_id", 4)) got[1] = feat_int64s(feat, i_id, 1) >= 1;
+    else if (is(key, "i_cate", 6)) got[2] = feat_int64s(feat, i_cate, 1) >= 1;
+    else if (is(key, "u_iid_seq", 9)) feat_int64s(feat, hist_i, P);
+    else if (is(key, "u_icat_seq", 10)) feat_int64s(feat, hist_c, P);
+  });
+  return (ok && got[0] && got[1] && got[2]) ? RSX_OK : RSX_EDATA;
+}
+
 extern "C" int rsx_din_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n, int P,
                                int64_t* label_h, int64_t* i_id_h, int64_t* i_cate_h, int64_t* hist_i_h,
                                int64_t* hist_c_h, int threads) {
@@ -275,18 +305,9 @@ extern "C" int rsx_din_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, c
   std::atomic<int> status{RSX_OK};
   parallel_for(n, threads, [&](int64_t a, int64_t b) {
     for (int64_t r = a; r < b; ++r) {
-      bool got[3] = {false, false, false};
-      std::memset(hist_i_h + r * P, 0, sizeof(int64_t) * P);
-      std::memset(hist_c_h + r * P, 0, sizeof(int64_t) * P);
-      const bool ok = for_each_feature(buf_h + offsets_h[r], (size_t)lengths_h[r], [&](Span key, Span feat) {
-        const std::string k(reinterpret_cast<const char*>(key.p), key.n);
-        if (k == "label") got[0] = feat_int64s(feat, label_h + r, 1) >= 1;
-        else if (k == "i_id") got[1] = feat_int64s(feat, i_id_h + r, 1) >= 1;
-        else if (k == "i_cate") got[2] = feat_int64s(feat, i_cate_h + r, 1) >= 1;
-        else if (k == "u_iid_seq") feat_int64s(feat, hist_i_h + r * P, P);
-        else if (k == "u_icat_seq") feat_int64s(feat, hist_c_h + r * P, P);
-      });
-      if (!ok || !got[0] || !got[1] || !got[2]) status.store(RSX_EDATA);
+      const int st = rsx_din_parse_row(buf_h + offsets_h[r], (size_t)lengths_h[r], P, label_h + r, i_id_h + r, i_cate_h + r,
+                                       hist_i_h + r * P, hist_c_h + r * P);
+      if (st != RSX_OK) status.store(st);
     }
   });
   return status.load();

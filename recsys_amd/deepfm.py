@@ -197,9 +197,9 @@ def define_flags(p=None):
     return p
 
 
-def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None):
+def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None, shard=None):
     from .input_pipeline import criteo_input_fn
-    return criteo_input_fn(filenames, batch_size, num_epochs, need_shuffle, num_parallel, layout)
+    return criteo_input_fn(filenames, batch_size, num_epochs, need_shuffle, num_parallel, layout, shard=shard)
 
 
 def make_params(FLAGS, linear="indicator_all"):
@@ -217,20 +217,27 @@ def run_main(model_fn, FLAGS, make_params_fn):
     config = RunConfig(save_checkpoints_steps=FLAGS.save_checkpoints_steps, keep_checkpoint_max=5,
                        log_step_count_steps=FLAGS.log_steps, adam_mode=FLAGS.adam_mode)
     est = Estimator(model_fn, FLAGS.model_dir, params, config)
+    shard = None
     if FLAGS.mirror:
         from . import dist
-        dist.attach_if_distributed(est)
+        dp = dist.attach_if_distributed(est)
+        if dp is not None:
+            # MirroredStrategy (fm/fm.py:184-194): ONE batch stream, successive batches go to successive replicas -- rank r
+            # trains on batches r, r+N, ... (disjoint records, same step count on every rank: csrc/tfrecord_reader.cpp)
+            # and evaluates its own share of the eval stream; the metric counters are summed in Estimator.evaluate.
+            shard = (dp.rank, dp.world)
     layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
     if FLAGS.task_type == "train":
-        tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.num_parallel, layout))
-        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
+        tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.num_parallel, layout, shard))
+        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout, shard), steps=200)
         return train_and_evaluate(est, tr, ev)
     if FLAGS.task_type == "eval":
-        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout), steps=200)
+        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout, shard), steps=200)
     if FLAGS.task_type == "infer":
         out = []
         for i, p in enumerate(est.predict(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout))):
-            print(p)
+            if est._is_chief():
+                print(p)
             out.append(p)
             if i >= 9:
                 break

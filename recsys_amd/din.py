@@ -183,10 +183,12 @@ def model_fn(features, labels, mode, params):
     loss = L.sigmoid_ce_mean(logits, labels)
     if mode == ModeKeys.EVAL:
         return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
+    dp = store.dp
+    if dp is not None:          # MirroredStrategy scales the replica loss by 1/N (the fused head does the same inside)
+        loss = loss / dp.world
 
     def train_op():                                                        # AdamOptimizer.minimize (:172-173)
-        dp = store.dp
-        (loss / dp.world if dp is not None else loss).backward()
+        loss.backward()
         with torch.no_grad():
             for tbl in (item, cate, bias):
                 tbl.finalize(dp)
@@ -217,28 +219,31 @@ def define_flags():
     return p
 
 
-def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, hist_len=100):
+def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, hist_len=100, shard=None):
     from .input_pipeline import din_input_fn
-    return din_input_fn(filenames, batch_size, num_epochs, need_shuffle, hist_len=hist_len, ids_int32=True)
+    return din_input_fn(filenames, batch_size, num_epochs, need_shuffle, hist_len=hist_len, ids_int32=True, shard=shard)
 
 
 def main(argv=None):
     FLAGS = define_flags().parse_args(argv)
     train_files, eval_files = [FLAGS.train_path + "train2"], [FLAGS.train_path + "valid2"]      # din/din.py:197-198
     params = {"embedding_size": FLAGS.embedding_size, "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout,
-              "max_batch_size": FLAGS.batch_size}
+              "max_batch_size": FLAGS.batch_size, "hist_len": FLAGS.hist_len}
     cfg = RunConfig(save_checkpoints_steps=FLAGS.save_checkpoints_steps, keep_checkpoint_max=5,
                     log_step_count_steps=FLAGS.log_steps)
     est = Estimator(model_fn, FLAGS.model_dir, params, cfg)
+    shard = None
     if FLAGS.mirror:
         from . import dist
-        dist.attach_if_distributed(est)
+        dp = dist.attach_if_distributed(est)
+        if dp is not None:          # every replica takes its own batches of the one stream (MirroredStrategy, din/din.py:187-190)
+            shard = (dp.rank, dp.world)
     if FLAGS.task_type == "train":
-        tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.hist_len))
-        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len), steps=FLAGS.eval_steps)
+        tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.hist_len, shard))
+        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len, shard), steps=FLAGS.eval_steps)
         return train_and_evaluate(est, tr, ev)
     if FLAGS.task_type == "eval":
-        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len), steps=FLAGS.eval_steps)
+        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len, shard), steps=FLAGS.eval_steps)
     return list(zip(range(10), est.predict(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len))))
 
 

@@ -35,13 +35,15 @@ def init_process_group(backend=None):
     if dist.is_initialized():
         return
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # RSX_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) -- used by the world-2 test of
+        # the script-level data-parallel path on the single-GPU test box
+        backend = os.environ.get("RSX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend)
 
 

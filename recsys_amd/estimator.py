@@ -355,41 +355,65 @@ class Estimator:
             return loss
         key = ("resident", id(batches[0]), n, steps_per_graph)
         g = self._graphs.get(key)
-        done = 0
         if g is None:
-            for s in range(min(2, steps)):                     # eager warm-up (allocator, lazy init)
-                self._train_eager(*batches[s % n].views())
-            done = min(2, steps)
-            g = {"graphs": [], "loss": None}
-            torch.cuda.synchronize()
-            for gi in range(n // steps_per_graph):
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    for k in range(steps_per_graph):
-                        g["loss"] = self._train_eager(*batches[gi * steps_per_graph + k].views())
-                g["graphs"].append(graph)
+            g = {"groups": {}, "tails": {}, "loss": None, "warm": 0}
             self._graphs[key] = g
-        # continue from the batch index that follows the steps already done, on group boundaries
-        pos = done % n
-        while done < steps:
-            if pos % steps_per_graph == 0 and steps - done >= steps_per_graph:
-                g["graphs"][pos // steps_per_graph].replay()
-                done += steps_per_graph
-                pos = (pos + steps_per_graph) % n
-            else:
-                # off a group boundary (or fewer steps left than a group): a one-step graph of this resident batch,
-                # captured on first use -- an eager step costs ~3x a captured one
-                single = g.setdefault("single", {})
-                if pos not in single:
-                    torch.cuda.synchronize()
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        g["loss"] = self._train_eager(*batches[pos].views())
-                    single[pos] = graph
-                single[pos].replay()
-                done += 1
-                pos = (pos + 1) % n
+        done = 0
+        while g["warm"] < 2 and done < steps:                  # eager warm-up (allocator, lazy init), first call only
+            g["loss"] = self._train_eager(*batches[done % n].views())
+            g["warm"] += 1
+            done += 1
+        # The schedule is a function of (start, count) only: a head graph up to the next group boundary (first call: the
+        # two eager warm-up steps leave the stream at batch 2), full groups, then ONE tail graph holding the remaining
+        # (< steps_per_graph) steps -- batches are consumed strictly in order.  Every graph is captured before anything is
+        # replayed, and a caller that times this function calls prepare_resident() first, so no capture ever falls
+        # inside a timed region.
+        for graph, loss in self._resident_schedule(g, batches, done, steps - done, steps_per_graph):
+            graph.replay()
+            g["loss"] = loss
         return g["loss"]
+
+    def _resident_schedule(self, g, batches, start, steps, spg):
+        n = len(batches)
+
+        def capture(first, count):
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(count):
+                    loss = self._train_eager(*batches[first + k].views())
+            return graph, loss        # `loss`: the static output of the graph's last step
+
+        def partial(first, count):
+            if (first, count) not in g["tails"]:
+                g["tails"][(first, count)] = capture(first, count)
+            return g["tails"][(first, count)]
+
+        sched, pos, left = [], start % n, steps
+        if pos % spg and left > 0:
+            cnt = min(spg - pos % spg, left)
+            sched.append(partial(pos, cnt))
+            pos, left = (pos + cnt) % n, left - cnt
+        while left >= spg:
+            gi = pos // spg
+            if gi not in g["groups"]:
+                g["groups"][gi] = capture(pos, spg)
+            sched.append(g["groups"][gi])
+            pos, left = (pos + spg) % n, left - spg
+        if left:
+            sched.append(partial(pos, left))
+        return sched
+
+    def prepare_resident(self, batches, steps, steps_per_graph=8):
+        """Capture (without running) every HIP graph train_resident(batches, steps, steps_per_graph) will replay."""
+        n = len(batches)
+        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
+            return
+        g = self._graphs.get(("resident", id(batches[0]), n, steps_per_graph))
+        if g is None or g["warm"] < 2:
+            self.train_resident(batches, 2, steps_per_graph)       # the two eager warm-up steps
+            g = self._graphs[("resident", id(batches[0]), n, steps_per_graph)]
+        self._resident_schedule(g, batches, 0, steps, steps_per_graph)
 
     def _maybe_restore(self):
         if self._restored or not self.model_dir or not self.store.built:
@@ -427,53 +451,119 @@ class Estimator:
                                       (cfg.save_checkpoints_steps and done % cfg.save_checkpoints_steps == 0)) else None
             if gs is not None and done % cfg.log_step_count_steps == 0:
                 now = time.time()
-                if log_step0 is not None:
-                    rate = (gs - log_step0) / max(now - self._log_t, 1e-9)
-                    print("INFO:global_step/sec: %.4g  (examples/sec: %.6g)" % (rate, rate * labels.shape[0]), flush=True)
-                print("INFO:loss = %.7g, step = %d" % (float(loss), gs), flush=True)
+                world = 1
+                if self.store.dp is not None:
+                    # every TRAIN step returns its replica's mean loss / N (MirroredStrategy's loss scaling): the sum over
+                    # replicas is the mean loss of the global batch, which is what gets logged
+                    loss = self.store.dp.all_reduce_sum(loss.detach().clone().reshape(1))
+                    world = self.store.dp.world
+                if self._is_chief():
+                    if log_step0 is not None:
+                        rate = (gs - log_step0) / max(now - self._log_t, 1e-9)
+                        print("INFO:global_step/sec: %.4g  (examples/sec: %.6g)" % (rate, rate * labels.shape[0] * world), flush=True)
+                    print("INFO:loss = %.7g, step = %d" % (float(loss), gs), flush=True)
                 self._log_t, log_step0 = now, gs
             if gs is not None and cfg.save_checkpoints_steps and self.model_dir and \
                     done % cfg.save_checkpoints_steps == 0:
-                from . import checkpoint
-                checkpoint.save(self.model_dir, self.store, gs, cfg.keep_checkpoint_max)
+                self._save_checkpoint(gs)
         if self.model_dir and self.store.built and done:
-            from . import checkpoint
-            checkpoint.save(self.model_dir, self.store, self.global_step, cfg.keep_checkpoint_max)
+            self._save_checkpoint(self.global_step)
         return self
 
     def evaluate(self, input_fn, steps=None):
-        auc, acc = _metrics.StreamingAUC(self.store.device), _metrics.StreamingAccuracy(self.store.device)
-        loss_sum, n = 0.0, 0
-        with torch.no_grad():
-            for features, labels in input_fn():
-                if steps is not None and n >= steps:
-                    break
-                features, labels = self._to_device(features), self._to_device(labels)
-                if not self.store.built:
-                    self._call_model_fn(features, labels, ModeKeys.PREDICT)
-                self._maybe_restore()
-                spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
-                prob = spec.predictions["prob"]
-                auc.update(labels, prob)
-                acc.update(labels, prob)
-                loss_sum += float(spec.loss)
-                n += 1
-        res = {"AUC": auc.result(), "Accuracy": acc.result(), "loss": loss_sum / max(n, 1), "global_step": self.global_step}
-        print("INFO:Saving dict for global step %d: AUC = %.7g, Accuracy = %.7g, global_step = %d, loss = %.7g"
-              % (res["global_step"], res["AUC"], res["Accuracy"], res["global_step"], res["loss"]), flush=True)
+        """Estimator.evaluate (fm/fm.py:216-221): AUC-200 / Accuracy / mean batch loss accumulated ON DEVICE by one
+        launch per batch (metrics.EvalMetrics); the host synchronises once, when the counters are read back.
+        Data-parallel: every rank evaluates its own shard of the eval stream and the integer counters are summed."""
+        met = _metrics.EvalMetrics(self.store.device)
+        n = 0
+        it = input_fn()
+        try:
+            with torch.no_grad():
+                for features, labels in it:
+                    if steps is not None and n >= steps:
+                        break
+                    features, labels = self._to_device(features), self._to_device(labels)
+                    if not self.store.built:
+                        self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                    self._maybe_restore()
+                    spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
+                    met.update(labels, spec.predictions["prob"], spec.loss)
+                    n += 1
+        finally:
+            _close_iter(it)
+        if self.store.dp is not None:
+            met.all_reduce(self.store.dp)
+        res = met.result()
+        res = {"AUC": res["AUC"], "Accuracy": res["Accuracy"], "loss": res["loss"], "global_step": self.global_step}
+        if self._is_chief():
+            print("INFO:Saving dict for global step %d: AUC = %.7g, Accuracy = %.7g, global_step = %d, loss = %.7g"
+                  % (res["global_step"], res["AUC"], res["Accuracy"], res["global_step"], res["loss"]), flush=True)
         return res
 
+    def _is_chief(self):
+        return self.store.dp is None or getattr(self.store.dp, "rank", 0) == 0
+
+    def _save_checkpoint(self, step):
+        """Replicas are bit-identical by construction: rank 0 writes, everybody waits (MirroredStrategy: the chief saves)."""
+        from . import checkpoint
+        if self._is_chief():
+            checkpoint.save(self.model_dir, self.store, step, self.config.keep_checkpoint_max)
+        if self.store.dp is not None:
+            self.store.dp.barrier()
+
     def predict(self, input_fn):
+        it = input_fn()
+        try:
+            with torch.no_grad():
+                for features, labels in it:
+                    features = self._to_device(features)
+                    if not self.store.built:
+                        self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                    self._maybe_restore()
+                    spec = self._call_model_fn(features, None, ModeKeys.PREDICT)
+                    prob = spec.predictions["prob"].reshape(-1).cpu().numpy()
+                    for p in prob:
+                        yield {"prob": p}
+        finally:
+            _close_iter(it)        # the caller usually breaks out after a few results (fm/fm.py:216-219)
+
+
+    def predict_examples(self, serialized, parse_fn=None, batch_size=4096):
+        """Inference entry that takes what a serving client sends: a list of serialized `tf.train.Example` byte strings
+        (deepfm/grpc_client.py:50-76 builds exactly these; the reference's exported SavedModel parses them with the
+        script's feature_description, deepfm/deepfm.py:213-233) -> {'prob': float32 [n]}.
+        parse_fn(list[bytes]) -> (features, labels); default: the Criteo parse spec of the params' embedding columns, or
+        the DIN spec (din/din.py:44-57) when the params hold no feature columns."""
+        from . import input_pipeline as ip
+        if parse_fn is None:
+            cols = self.params.get("embedding_feature_columns")
+            if cols is not None:
+                from .feature_columns import CriteoLayout
+                layout = CriteoLayout.from_columns(cols)
+                parse_fn = lambda ex: ip.parse_criteo_examples(ex, layout)          # noqa: E731
+            else:
+                P = int(self.params.get("hist_len", 100))
+                parse_fn = lambda ex: ip.parse_din_examples(ex, P)                  # noqa: E731
+        serialized = list(serialized)
+        out = []
         with torch.no_grad():
-            for features, labels in input_fn():
+            for s in range(0, len(serialized), batch_size):
+                features, labels = parse_fn(serialized[s:s + batch_size])
                 features = self._to_device(features)
                 if not self.store.built:
-                    self._call_model_fn(features, labels, ModeKeys.PREDICT)
+                    self._call_model_fn(features, self._to_device(labels), ModeKeys.PREDICT)
                 self._maybe_restore()
                 spec = self._call_model_fn(features, None, ModeKeys.PREDICT)
-                prob = spec.predictions["prob"].reshape(-1).cpu().numpy()
-                for p in prob:
-                    yield {"prob": p}
+                out.append(spec.predictions["prob"].reshape(-1).float().cpu().numpy())
+        return {"prob": np.concatenate(out) if out else np.zeros(0, np.float32)}
+
+
+def _close_iter(it):
+    """Stop a prefetching input iterator whose consumer leaves early (evaluate(steps=...), predict's caller breaking
+    out): generators get close(), which runs their `finally` and stops the producer thread."""
+    close = getattr(it, "close", None)
+    if close is not None:
+        close()
 
 
 def train_and_evaluate(estimator: Estimator, train_spec: TrainSpec, eval_spec: EvalSpec, eval_every_steps=None):

@@ -1,5 +1,6 @@
 """Input pipeline: the reference's `input_fn` (fm/fm.py:106-112, deepfm/deepfm.py:60-70, xdeepfm/xdeepfm.py:101-118,
-dcn/dcn.py:106-112, din/din.py:61-80) on top of librsx.so's multi-threaded TFRecord / Example ingest.
+dcn/dcn.py:106-112, din/din.py:61-80) on top of librsx.so's streaming TFRecord reader (csrc/tfrecord_reader.cpp: mmap, SSE4.2 CRC, parse and batch assembly in
+C++ worker threads, data-parallel sharding of the batch stream).
 
 Order of transformations is the reference's:
     TFRecordDataset(files) -> map(parse) -> batch(bs) -> [shuffle(buffer of BATCHES)] -> prefetch -> repeat(epochs)
@@ -35,9 +36,9 @@ def read_shard(path, verify_crc=True):
 
 
 class _CriteoParser:
-    def __init__(self, layout, threads):
+    def __init__(self, layout, threads, label_optional=False):
         self.F = layout.F
-        self.threads = int(threads)
+        self.threads = int(threads) | (0x10000 if label_optional else 0)    # bit 16: a missing `_c0` parses as label 0
         self.slot_src = np.array([int(c.key[2:]) for c in layout.columns], np.int32)
         self.slot_rows = np.array([c.rows for c in layout.columns], np.int32)
         bnd, off = [], [0]
@@ -102,60 +103,203 @@ def _shuffled(it, buffer_size, seed):
 
 
 def _prefetched(it, depth):
+    """prefetch(buffer_size): a producer thread runs `it` up to `depth` batches ahead.  When the consumer stops early
+    (evaluate(steps=...), predict's caller breaking out, garbage collection of the generator) the `finally` below sets
+    the stop event; the producer notices within one put-timeout, closes the upstream generator (releasing the shard
+    image it holds) and exits -- no thread or buffer outlives its consumer."""
     q = queue.Queue(maxsize=max(1, depth))
     end = object()
+    stop = threading.Event()
+
+    def put(x):
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
             for x in it:
-                q.put(x)
-            q.put(end)
+                if not put(x):
+                    break
+            else:
+                put(end)
         except BaseException as e:  # surfaced in the consumer
-            q.put(e)
+            put(e)
+        finally:
+            close = getattr(it, "close", None)
+            if close is not None:
+                close()
 
-    threading.Thread(target=work, daemon=True).start()
-    while True:
-        x = q.get()
-        if x is end:
-            return
-        if isinstance(x, BaseException):
-            raise x
-        yield x
+    t = threading.Thread(target=work, daemon=True, name="rsx-prefetch")
+    t.start()
+    try:
+        while True:
+            x = q.get()
+            if x is end:
+                return
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+    finally:
+        stop.set()
+        t.join(timeout=5.0)
+
+
+def _shard_from_env(shard):
+    """(rank, world) of the data-parallel job this process belongs to; explicit `shard` wins."""
+    if shard is not None:
+        return int(shard[0]), int(shard[1])
+    return 0, 1
+
+
+class _Reader:
+    """Owner of one C++ streaming reader (csrc/tfrecord_reader.cpp); closed by the generator's `finally`, i.e. also when
+    the consumer stops early or drops the iterator -- no thread or mapping outlives its consumer."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RsxError("could not open the TFRecord reader (bad arguments)")
+        self.h = C.c_void_p(handle)
+
+    def close(self):
+        if self.h is not None:
+            lib().rsx_reader_close_h(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _paths_array(filenames):
+    arr = (C.c_char_p * len(filenames))(*[str(f).encode() for f in filenames])
+    return arr
+
+
+def _criteo_batches(filenames, batch_size, num_epochs, layout, threads, shard, verify_crc, queue_batches, drop_remainder):
+    ps = _CriteoParser(layout, threads)
+    rank, world = shard
+    paths = _paths_array(filenames)
+    rd = _Reader(lib().rsx_criteo_reader_open_h(paths, len(filenames), _p(ps.slot_src), _p(ps.slot_rows), _p(ps.bnd),
+                                                _p(ps.bnd_off), _p(ps.shift), ps.F, int(batch_size), int(num_epochs), rank,
+                                                world, int(drop_remainder), int(threads), int(verify_crc), int(queue_batches)))
+    F, bs = ps.F, int(batch_size)
+    try:
+        while True:
+            # ONE flat host buffer per batch, laid out like estimator.PackedBatch packs it (label | cont_log | ids, 16-byte
+            # aligned parts), so the Estimator's single H2D copy can take it as it is
+            o_cont = (bs * 4 + 15) & ~15
+            o_ids = (o_cont + bs * 52 + 15) & ~15
+            flat = np.empty(o_ids + bs * F * 4, np.uint8)
+            label = flat[:bs * 4].view(np.float32).reshape(bs, 1)
+            cont = flat[o_cont:o_cont + bs * 52].view(np.float32).reshape(bs, 13)
+            ids = flat[o_ids:o_ids + bs * F * 4].view(np.int32).reshape(bs, F)
+            n = lib().rsx_criteo_reader_next_h(rd.h, _p(label), _p(cont), _p(ids))
+            if n == 0:
+                return
+            if n < 0:
+                raise RsxError("%s: %s" % (filenames[0] if len(filenames) == 1 else "TFRecord stream",
+                                           lib().rsx_strerror(int(n)).decode()))
+            if n < bs:
+                label, cont, ids = label[:n], cont[:n], ids[:n]
+            yield {"ids": ids, "cont_log": cont}, label
+    finally:
+        rd.close()
 
 
 def criteo_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None,
-                    shuffle_buffer=1000, prefetch=16, seed=0):
-    """fm/fm.py:106-112.  Returns an iterator of (features, labels)."""
+                    shuffle_buffer=1000, prefetch=16, seed=0, shard=None, verify_crc=True):
+    """fm/fm.py:106-112.  Returns an iterator of (features, labels).
+    shard=(rank, world): this replica's share of the batch stream (see csrc/tfrecord_reader.cpp); each replica then
+    shuffles its own sub-stream with its own seed.  `prefetch` = batches the C++ reader keeps in flight."""
     if layout is None:
         from .feature_columns import CriteoLayout, build_feature_columns
         layout = CriteoLayout.from_columns(build_feature_columns(16)[1])
-    it = _batched(_CriteoParser(layout, num_parallel), list(filenames), batch_size, num_epochs)
+    rank, world = _shard_from_env(shard)
+    it = _criteo_batches(list(filenames), batch_size, num_epochs, layout, num_parallel, (rank, world), verify_crc,
+                         max(2, prefetch), drop_remainder=False)
     if need_shuffle:
-        it = _shuffled(it, shuffle_buffer, seed)
-    return _prefetched(it, prefetch)
+        it = _shuffled(it, shuffle_buffer, seed + 7919 * rank)
+    return it
 
 
 def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=6, hist_len=100,
-                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False):
+                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False, shard=None, verify_crc=True):
     """din/din.py:61-80: features {'i_id','i_cate' int64 [B]; 'u_iid_seq','u_icat_seq' int64 [B,P]}, labels int64 [B].
     ids_int32: narrow the id features to int32 on the HOST (the device kernels index with int32; like the Criteo parse,
     which emits int32 row ids) so that the training step has no per-feature cast launches."""
-    P = int(hist_len)
+    P, bs = int(hist_len), int(batch_size)
+    rank, world = _shard_from_env(shard)
+    filenames = list(filenames)
 
-    def parse(buf, offs, lens):
-        n = len(offs)
-        lab, iid, icat = (np.empty(n, np.int64) for _ in range(3))
-        hi, hc = np.empty((n, P), np.int64), np.empty((n, P), np.int64)
-        check(lib().rsx_din_parse_h(_p(buf), _p(offs), _p(lens), n, P, _p(lab), _p(iid), _p(icat), _p(hi), _p(hc),
-                                    int(num_parallel)), "rsx_din_parse_h")
-        if ids_int32:
-            iid, icat, hi, hc = (x.astype(np.int32) for x in (iid, icat, hi, hc))
-        return {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab
+    def gen():
+        paths = _paths_array(filenames)
+        rd = _Reader(lib().rsx_din_reader_open_h(paths, len(filenames), P, bs, int(num_epochs), rank, world, 0,
+                                                 int(num_parallel), int(verify_crc), max(2, int(prefetch))))
+        try:
+            while True:
+                lab, iid, icat = (np.empty(bs, np.int64) for _ in range(3))
+                hi, hc = np.empty((bs, P), np.int64), np.empty((bs, P), np.int64)
+                n = lib().rsx_din_reader_next_h(rd.h, _p(lab), _p(iid), _p(icat), _p(hi), _p(hc))
+                if n == 0:
+                    return
+                if n < 0:
+                    raise RsxError("DIN TFRecord stream: %s" % lib().rsx_strerror(int(n)).decode())
+                if n < bs:
+                    lab, iid, icat, hi, hc = lab[:n], iid[:n], icat[:n], hi[:n], hc[:n]
+                if ids_int32:
+                    iid, icat, hi, hc = (x.astype(np.int32) for x in (iid, icat, hi, hc))
+                yield {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab
+        finally:
+            rd.close()
 
-    it = _batched(parse, list(filenames), batch_size, num_epochs)
+    it = gen()
     if need_shuffle:
-        it = _shuffled(it, shuffle_buffer, seed)
-    return _prefetched(it, prefetch)
+        it = _shuffled(it, shuffle_buffer, seed + 7919 * rank)
+    return it
+
+
+# ---- serialized tf.train.Example entry (SURVEY.md 8f-4) -------------------------------------------------------------
+def _pack_serialized(serialized):
+    """list of bytes -> (buf uint8, offsets int64 [n], lengths int64 [n])."""
+    lens = np.fromiter((len(x) for x in serialized), np.int64, len(serialized))
+    offs = np.zeros(len(serialized), np.int64)
+    if len(serialized) > 1:
+        np.cumsum(lens[:-1], out=offs[1:])
+    buf = np.frombuffer(b"".join(serialized), np.uint8)
+    if buf.size == 0:
+        buf = np.zeros(1, np.uint8)
+    return buf, offs, lens
+
+
+def parse_criteo_examples(serialized, layout, threads=1):
+    """What the exported model's parsing signature does with the strings a serving client sends
+    (deepfm/grpc_client.py:50-76 builds one serialized tf.train.Example per request row; the SavedModel parses them with
+    the script's feature_description, deepfm/deepfm.py:213-233): -> (features, labels) like one input_fn batch.
+    The label feature `_c0` is optional here (serving requests carry none)."""
+    if not len(serialized):
+        raise ValueError("no examples")
+    buf, offs, lens = _pack_serialized(serialized)
+    feats, label = _CriteoParser(layout, threads, label_optional=True)(buf, offs, lens)
+    return feats, label
+
+
+def parse_din_examples(serialized, hist_len=100, ids_int32=True):
+    """din/din.py:44-57 parse spec applied to in-memory serialized Examples."""
+    if not len(serialized):
+        raise ValueError("no examples")
+    buf, offs, lens = _pack_serialized(serialized)
+    n, P = len(serialized), int(hist_len)
+    lab, iid, icat = (np.empty(n, np.int64) for _ in range(3))
+    hi, hc = np.empty((n, P), np.int64), np.empty((n, P), np.int64)
+    check(lib().rsx_din_parse_h(_p(buf), _p(offs), _p(lens), n, P, _p(lab), _p(iid), _p(icat), _p(hi), _p(hc), 1),
+          "rsx_din_parse_h")
+    if ids_int32:
+        iid, icat, hi, hc = (x.astype(np.int32) for x in (iid, icat, hi, hc))
+    return {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab
 
 
 # ---- synthetic shard writers (SURVEY.md section 0-6: the reference's sample shard is a missing blob) ------------

@@ -1,0 +1,70 @@
+"""World-2 run of the SCRIPT-LEVEL data-parallel path on one GPU (two processes on cuda:0, gloo collectives -- RCCL
+refuses two ranks on one device): `deepfm.main(--mirror true)` exactly as torchrun would start it.  Asserts what
+VERDICT r1 found broken: the two ranks consume DISJOINT records (rank r gets batches r, r+2, ...), run the same number of
+steps, only rank 0 writes checkpoints, and both replicas end with BIT-IDENTICAL variables; the summed eval counters
+give both ranks the same AUC."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _shards(d, n_files=4, per_file=400, seed=3):
+    from recsys_amd import synthetic
+    from recsys_amd.input_pipeline import write_criteo_shard
+    rng = np.random.default_rng(seed)
+    tag = 0
+    for k in range(n_files):
+        label, cont, cat = synthetic.criteo_raw_batch(rng, per_file)
+        label = ((cont[:, 0] > 8) ^ (rng.random(per_file) < 0.1)).astype(np.float32)
+        cont[:, 12] = np.arange(tag, tag + per_file) + 1.0           # _c13 = record number + 1 (unique fingerprint)
+        tag += per_file
+        write_criteo_shard(os.path.join(d, "part-r-%05d" % k), label, cont, cat)
+
+
+@pytest.mark.parametrize("mod", ["deepfm", "xdeepfm"])
+def test_run_main_world2_disjoint_records_identical_replicas(tmp_path, mod):
+    d = str(tmp_path) + "/"
+    _shards(d)
+    out = tmp_path / "out"
+    out.mkdir()
+    model_dir = str(tmp_path / "model")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK="0", RSX_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_run_main_worker.py"), mod, d, model_dir,
+                                       str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all("WORKER_OK" in o for o in logs), "\n=====\n".join(o[-3000:] for o in logs)
+    r = [json.load(open(out / ("rank%d.json" % k))) for k in range(2)]
+    # same number of steps, disjoint records, and rank r holds batches r, r+2, ... of the 3 training shards (1200 records)
+    assert r[0]["batches"] == r[1]["batches"] > 0 and r[0]["global_step"] == r[1]["global_step"] == r[0]["batches"]
+    s0, s1 = set(r[0]["seen"]), set(r[1]["seen"])
+    assert not (s0 & s1), "ranks trained on the same records"
+    per_epoch = (1200 // (64 * 2)) * 64            # complete rounds only
+    assert len(r[0]["seen"]) == len(r[1]["seen"]) == 2 * per_epoch
+    assert len(s0) == per_epoch and len(s1) == per_epoch          # epoch 2 revisits the rank's own records
+    # bit-identical replicas
+    assert r[0]["digest"] == r[1]["digest"]
+    # evaluate(): counters summed across ranks -> the same numbers everywhere
+    assert r[0]["res"]["AUC"] == r[1]["res"]["AUC"] and r[0]["res"]["loss"] == r[1]["res"]["loss"]
+    # only the chief wrote checkpoints, no stray tmp files
+    assert glob.glob(model_dir + "/model.ckpt-*.pt") and not glob.glob(model_dir + "/*.tmp*")
+    # rank 1 stayed quiet
+    assert "INFO:loss" in logs[0] and "INFO:loss" not in logs[1]
