@@ -70,13 +70,13 @@ def test_din_main_train_eval_predict_resume(tmp_path):
     d = str(tmp_path) + "/"
     rng = np.random.default_rng(0)
     for name, n in (("train2", 1500), ("valid2", 600)):
-        b = synthetic.din_batch(rng, n, P=30)
-        b["label"] = ((b["i_id"] % 7 < 3) ^ (rng.random(n) < 0.1)).astype(np.int64)      # planted signal on the target item
+        b = synthetic.din_batch(rng, n, P=30, n_item=300, n_cate=20)      # small vocabulary: valid2 revisits train2's ids
+        b["label"] = ((b["i_cate"] % 2 == 0) ^ (rng.random(n) < 0.1)).astype(np.int64)   # planted signal on the category
         write_din_shard(d + name, b)
     model_dir = str(tmp_path / "model")
     common = ["--train_path", d, "--batch_size", "128", "--model_dir", model_dir, "--save_checkpoints_steps", "10",
               "--log_steps", "5", "--dropout", "0.1", "--learning_rate", "0.01", "--hist_len", "30", "--eval_steps", "4"]
-    res = din.main(common + ["--task_type", "train", "--num_epochs", "8"])
+    res = din.main(common + ["--task_type", "train", "--num_epochs", "4"])
     assert np.isfinite(res["loss"]) and res["AUC"] > 0.7, res
     ev = din.main(common + ["--task_type", "eval"])
     assert ev["global_step"] == res["global_step"] and abs(ev["AUC"] - res["AUC"]) < 1e-6
