@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm", "din"],
                    help="deepfm = the BASELINE metric's config (configs[1]); the others are the remaining BASELINE configs "
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
+    p.add_argument("--cin_bf16", action="store_true", help="xdeepfm: CIN contraction on the bf16 MFMA path (fp32 accumulate); the "
+                   "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
     p.add_argument("--steps_per_graph", type=int, default=16, help="training steps captured per HIP graph (1: per-step "
                    "graph fed by one D2D copy of the batch)")
     return p.parse_args()
@@ -147,7 +149,7 @@ def main():
     lin, emb = build_feature_columns(16, linear) if linear else (None, None)
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if a.model == "din" else 16,
               "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
-              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(a.model)}
+              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(a.model), "cin_bf16": a.cin_bf16}
     mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[a.model]
     cfg = RunConfig(use_hip_graph=not a.no_graph, adam_mode=a.adam_mode, device=str(dev), seed=1234)
     est = Estimator(mfn, None, params, cfg)
@@ -274,7 +276,8 @@ def main():
     N = max(world, 1) if dp is not None else 1
     out = {"metric": "examples/sec", "value": round(N * B * a.steps / dt, 1), "unit": "examples/sec", "n_gpus": a.gpus,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if not (a.cin_bf16 and a.model == "xdeepfm") else "bf16 CIN operands / f32 accumulate, f32 elsewhere (max |dlogit| vs f32 path: see DESIGN.md)", "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
            "config": {"workload": "%s.py %s bs=%d/replica, full train step "
                                   "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, %s"
                                   % (a.model, {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16",

@@ -433,6 +433,26 @@ int64_t rsx_criteo_encode_h(const float* label_h, const float* cont_h, const uin
 int64_t rsx_din_encode_h(const int64_t* label_h, const int64_t* i_id_h, const int64_t* i_cate_h, const int64_t* hist_i_h,
                          const int64_t* hist_c_h, int64_t n, int P, int keep_padding, uint8_t* out_h, int64_t cap);
 
+/* bf16 MFMA path of the CIN layer (north_star: "MFMA only on the CIN feature-map contraction where it is genuinely a
+ * dense bf16 GEMM"; xdeepfm/xdeepfm.py:145-169).  Same contract as rsx_cin_layer_fwd / rsx_cin_layer_bwd, with the
+ * filter W replaced by a bf16 image prepared once per step:
+ *   rsx_cin_prep_bf16      W fp32 [F*H, N] -> w16 (rsx_cin_bf16_weight_elems(F,H,N) 16-bit elements, caller-owned):
+ *                          the two zero-padded operand layouts (n-contiguous and h-contiguous) the kernels read with
+ *                          16-byte loads
+ *   rsx_cin_layer_fwd_bf16 Xk and W rounded to bf16 (RNE), fp32 accumulation, X0 / bias / relu in fp32
+ *   rsx_cin_layer_bwd_bf16 dpre and W (and the products X0*Xk of the weight gradient) rounded to bf16, every sum fp32;
+ *                          dc summed in fp32 from the unrounded dpre.  ws: rsx_cin_bf16_bwd_workspace_bytes(B, N) bytes.
+ * fp32 (rsx_cin_layer_fwd/bwd) stays the parity path; the tolerance of this one is stated in DESIGN.md / the tests.  */
+size_t rsx_cin_bf16_weight_elems(int F, int H, int N);
+size_t rsx_cin_bf16_bwd_workspace_bytes(int B, int N);
+int rsx_cin_prep_bf16(const float* W, void* w16, int F, int H, int N, rsx_stream_t stream);
+int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const void* w16, const float* c, float* out, int B, int F,
+                           int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                           const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
+                           float* dW, float* dc, void* ws, int B, int F, int H, int N, int D,
+                           const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Streaming reader: the whole `input_fn` front end -- tf.data.TFRecordDataset(filenames)
  * .map(_parse_examples, num_parallel_calls).batch(batch_size)[.repeat(num_epochs)] of fm/fm.py:106-112

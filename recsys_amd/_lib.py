@@ -82,6 +82,11 @@ _SIGS = {
     "rsx_cin_layer_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P, _P]),
     "rsx_cin_layer_bwd": (_I, [_P] * 8 + [_I, _P, _I, _P, _P, _P] + [_I] * 5 + [_P, _P]),
     "rsx_cin_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I, _I]),
+    "rsx_cin_bf16_weight_elems": (C.c_size_t, [_I, _I, _I]),
+    "rsx_cin_bf16_bwd_workspace_bytes": (C.c_size_t, [_I, _I]),
+    "rsx_cin_prep_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "rsx_cin_layer_fwd_bf16": (_I, [_P] * 5 + [_I] * 5 + [_P, _P]),
+    "rsx_cin_layer_bwd_bf16": (_I, [_P] * 8 + [_I, _P, _I, _P, _P, _P] + [_I] * 5 + [_P, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rsx_hash_fp64_h": (_I, [_P, _P, C.c_int64, _P]),

@@ -852,9 +852,18 @@ class CinNet:
     broadcast of its gradient back into every layer map happen inside those kernels; the gradients of X^0 from all layers
     (and from its second role as X^k of layer 0) accumulate in one buffer; weight gradients land in the dense arena."""
 
-    def __init__(self, F, D, sizes, capacity, device="cuda"):
+    def __init__(self, F, D, sizes, capacity, device="cuda", bf16=False):
         dev = _require_cuda(device)
         self.F, self.D, self.sizes, self.L = F, D, [int(n) for n in sizes], len(sizes)
+        # bf16=True: the contraction runs on the bf16 MFMA path (csrc/cin_bf16.hip: Xk / W / dpre rounded to bf16, fp32
+        # accumulation) -- NOT the parity path; fp32 (False) is the default everywhere
+        self.bf16 = bool(bf16)
+        if self.bf16:
+            hs16 = [F] + self.sizes[:-1]
+            self.w16 = [torch.empty(int(lib().rsx_cin_bf16_weight_elems(F, h, n)), dtype=torch.int16, device=dev)
+                        for h, n in zip(hs16, self.sizes)]
+            self.ws16 = torch.empty(max(int(lib().rsx_cin_bf16_bwd_workspace_bytes(capacity, n)) for n in self.sizes),
+                                    dtype=torch.uint8, device=dev)
         self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
         self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
         hs = [F] + self.sizes[:-1]
@@ -872,6 +881,12 @@ class CinNet:
         Xk, H = X0, self.F
         for k, n in enumerate(self.sizes):
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
+            if self.bf16:
+                check(lib().rsx_cin_prep_bf16(_ptr(P[f"cin.W{k}"]), _ptr(self.w16[k]), self.F, H, n, _stream()), "rsx_cin_prep_bf16")
+                check(lib().rsx_cin_layer_fwd_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]),
+                                                   B, self.F, H, n, self.D, sw, _stream()), "rsx_cin_layer_fwd_bf16")
+                Xk, H = self.outs[k], n
+                continue
             check(lib().rsx_cin_layer_fwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]), B,
                                           self.F, H, n, self.D, sw, _stream()), "rsx_cin_layer_fwd")
             Xk, H = self.outs[k], n
@@ -896,6 +911,12 @@ class CinNet:
             else:
                 dxk, acc_dxk, acc_dx0 = self.dmap[k - 1], 0, 0 if k == L - 1 else 1
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
+            if self.bf16:       # w16[k] was prepared by this step's forward (the filters do not change in between)
+                check(lib().rsx_cin_layer_bwd_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
+                                                   C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
+                                                   _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.ws16), B,
+                                                   self.F, H, self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd_bf16")
+                continue
             check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,

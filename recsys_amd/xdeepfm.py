@@ -72,7 +72,8 @@ def build_variables(store, params, capacity):
     store.layout = layout
     store.cin_sizes = cin
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
-    store.cin = CinNet(F, D, cin, capacity, store.device)
+    # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
+    store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
     store.dp_block = False
     if store.dp is not None and params.get("dp_send_block", True):          # zero-copy gradient exchange (see deepfm.py)
         store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])
@@ -198,6 +199,8 @@ def model_fn(features, labels, mode, params):
 def define_flags():
     p = _deepfm_flags()
     p.add_argument("--cross_layers", default="20,10,10")       # xdeepfm/xdeepfm.py:19 (BASELINE config 3 uses 128,128)
+    p.add_argument("--cin_bf16", type=lambda s: s.lower() in ("1", "true", "yes"), default=False,
+                   help="CIN contraction on bf16 MFMA (fp32 accumulate); not the reference-parity path")
     p.add_argument("--eval_steps", type=int, default=200)
     p.set_defaults(num_epochs=5, eval_parts=10, log_steps=50, save_checkpoints_steps=2000)
     return p
@@ -207,7 +210,7 @@ def make_params(FLAGS):
     lin, emb = build_feature_columns(FLAGS.embedding_size, "numeric+indicator")
     return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
             "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
-            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size}
+            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size, "cin_bf16": FLAGS.cin_bf16}
 
 
 def main(argv=None):
