@@ -48,6 +48,8 @@ def parse():
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
     p.add_argument("--cin_bf16", action="store_true", help="xdeepfm: CIN contraction on the bf16 MFMA path (fp32 accumulate); the "
                    "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
+    p.add_argument("--no_overlap", action="store_true", help="profiling aid: plain path (stand-alone sort, segment-sum, ONE full "
+                   "optimizer sweep) instead of sweep slices riding in the tower launches -- shows every kernel's own duration")
     p.add_argument("--steps_per_graph", type=int, default=16, help="training steps captured per HIP graph (1: per-step "
                    "graph fed by one D2D copy of the batch)")
     return p.parse_args()
@@ -150,6 +152,8 @@ def main():
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if a.model == "din" else 16,
               "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
               "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(a.model), "cin_bf16": a.cin_bf16}
+    if a.no_overlap:
+        params["overlap_adam"] = False
     mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[a.model]
     cfg = RunConfig(use_hip_graph=not a.no_graph, adam_mode=a.adam_mode, device=str(dev), seed=1234)
     est = Estimator(mfn, None, params, cfg)

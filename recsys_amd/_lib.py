@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsx.so")
+# RSX_LIB_PATH: an alternative build of the same library (profiling variants, scripts/stamp_probe.py); never a fallback
+LIB_PATH = os.environ.get("RSX_LIB_PATH") or os.path.join(_HERE, "librsx.so")
 
 (RSX_ADAM_DENSE, RSX_ADAM_TABLE_TF1, RSX_ADAM_VEC_SLOT, RSX_ADAM_TABLE_ROWS, RSX_ADAM_VEC_ROWS, RSX_ADAM_TABLE_TF1_COLD,
  RSX_ADAM_VEC_COLD, RSX_ADAM_VEC_ROWS_DENSE) = range(8)

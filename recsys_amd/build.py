@@ -22,12 +22,24 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
+STAMP = LIB + ".srchash"
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS[:-2]).encode())
+    for p in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """Content hash, not mtimes: the snapshot that carries the tree to the GPU box does not preserve modification times,
+    and a spurious rebuild there costs 25 s per process (and a hipcc run inside every rocprofv3 trace)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(p) > t for p in deps)
+    return open(STAMP).read().strip() != _source_hash()
 
 
 def build(force=False, verbose=True):
@@ -41,6 +53,8 @@ def build(force=False, verbose=True):
     try:
         subprocess.run(cmd, check=True)
         os.replace(tmp, LIB)
+        with open(STAMP, "w") as f:
+            f.write(_source_hash())
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)

@@ -47,17 +47,33 @@ __device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------------ weight preparation
+// Fragment-major images: the 64 lanes' 16-byte operand quads of one (field, tile, k-step) are 1 KiB contiguous, so every
+// operand load of the kernels below is one fully coalesced wave load (lane l = 16 kq + i reads bytes [16 l, 16 l + 16)).
+//   W16f  [F][H16/16][Np/32][64][8]:  element j of lane (i, kq) = W[f][h = 16 ht + i][n = 32 ks + 8 kq + j]   (A of dX)
+//   Wt16f [F][N16/16][Hp/32][64][8]:  element j of lane (i, kq) = W[f][h = 32 ks + 8 kq + j][n = 16 nt + i]   (B of fwd)
 __global__ __launch_bounds__(256) void cin_prep_bf16_k(const float* __restrict__ W, bf16_t* __restrict__ W16,
                                                        bf16_t* __restrict__ Wt16, int F, int H, int N, int H16, int N16,
                                                        int Hp, int Np) {
   const long long n1 = (long long)F * H16 * Np, n2 = (long long)F * N16 * Hp;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n1 + n2; e += (long long)gridDim.x * 256) {
     if (e < n1) {
-      const int n = (int)(e % Np), h = (int)((e / Np) % H16), f = (int)(e / ((long long)Np * H16));
+      const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+      long long r = e >> 9;
+      const int KSn = Np >> 5;
+      const int ks = (int)(r % KSn);
+      r /= KSn;
+      const int ht = (int)(r % (H16 >> 4)), f = (int)(r / (H16 >> 4));
+      const int h = 16 * ht + (lane & 15), n = 32 * ks + 8 * (lane >> 4) + j;
       W16[e] = (bf16_t)((h < H && n < N) ? W[((size_t)f * H + h) * N + n] : 0.f);
     } else {
       const long long q = e - n1;
-      const int h = (int)(q % Hp), n = (int)((q / Hp) % N16), f = (int)(q / ((long long)Hp * N16));
+      const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
+      long long r = q >> 9;
+      const int KSh = Hp >> 5;
+      const int ks = (int)(r % KSh);
+      r /= KSh;
+      const int nt = (int)(r % (N16 >> 4)), f = (int)(r / (N16 >> 4));
+      const int n = 16 * nt + (lane & 15), h = 32 * ks + 8 * (lane >> 4) + j;
       Wt16[q] = (bf16_t)((h < H && n < N) ? W[((size_t)f * H + h) * N + n] : 0.f);
     }
   }
@@ -67,7 +83,7 @@ __global__ __launch_bounds__(256) void cin_prep_bf16_k(const float* __restrict__
 struct CbFwdArgs {
   const float* X0;      // [B, F, 16]
   const float* Xk;      // [B, H, 16]
-  const bf16_t* Wt16;   // [F, N16, Hp]
+  const bf16_t* Wt16;   // fragment-major, see cin_prep_bf16_k
   const float* c;       // [N]
   float* out;           // [B, N, 16]
   int B, F, H, N, N16, Hp;
@@ -75,33 +91,36 @@ struct CbFwdArgs {
   AdamSlice sweep;
 };
 
-// grid = (N16/16, ceil(B/8) [+ sweep rows]), block = 256: wave w owns examples 8*blockIdx.y + 2w, +1 and the 16 outputs
-// n0.. of the workgroup (the 4 waves read the same W_f slices, so three of four reads hit the CU's L1).
-// KS = Hp / 32 k-steps per field.  LDS: 8 * F * 16 floats (X0 of the workgroup's examples).
+// grid = (N16/16, ceil(B/2) [+ sweep rows]), block = 256.  The workgroup owns examples 2*blockIdx.y, +1 and the 16
+// outputs n0..; its 4 waves split the FIELDS (wave w takes f = w, w + 4, ...: ten dependent steps instead of 39, and 4096
+// waves for the latency-bound W stream to hide behind), their partial sums are added in wave order through LDS.
+// KS = Hp / 32 k-steps per field.  The W fragments of two fields are in flight while the previous two are multiplied.
+// LDS: 2*F*16 (X0 of the two examples) + 4*2*256 (partials) floats.
 template <int KS>
-__global__ __launch_bounds__(256) void cin_fwd_bf16_k(const CbFwdArgs p) {
+__global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.y >= p.nby) {
     const uint32_t lin = ((uint32_t)blockIdx.y - (uint32_t)p.nby) * gridDim.x + blockIdx.x;
     if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin);
     return;
   }
-  constexpr int FG = 4;                          // fields per load group
+  constexpr int FG = KS >= 4 ? 1 : 2;            // fields per load group (register budget: 128 per lane, 4 waves per SIMD)
+  float* sX0 = lds;                              // [2][F*16]
+  float* sR = lds + 2 * p.F * CB_D;              // [4 waves][2 examples][4][64]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const int bw = blockIdx.y * 8;
+  const int b0 = blockIdx.y * 2;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int e = tid; e < 8 * p.F * 4; e += 256) {
+  for (int e = tid; e < 2 * p.F * 4; e += 256) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
-    const int bb = bw + ex;
-    reinterpret_cast<float4*>(lds)[e] = bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CB_D)[r] : z4;
+    reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : z4;
   }
   // A operand: Xk[b][h = 32 ks + 8 kq + j][d = i], the same for every field -> registers for the whole kernel
   bf16x8 a[2][KS];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const int b = bw + 2 * wv + e;
+    const int b = b0 + e;
     const float* xk = p.Xk + (size_t)(b < p.B ? b : p.B - 1) * p.H * CB_D + i;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -115,28 +134,30 @@ __global__ __launch_bounds__(256) void cin_fwd_bf16_k(const CbFwdArgs p) {
       for (int j = 0; j < 8; ++j) a[e][ks][j] = (bf16_t)v[j];
     }
   }
-  const bf16_t* wbase = p.Wt16 + ((size_t)(n0 + i) * p.Hp + 8 * kq);
+  const bf16_t* wbase = p.Wt16 + ((size_t)blockIdx.x * KS * 64 + lane) * 8;
   const size_t fstride = (size_t)p.N16 * p.Hp;
   bf16x8 wa[FG][KS], wb[FG][KS];
-  auto load_group = [&](int f0, bf16x8 (*w)[KS]) {
+  auto load_group = [&](int g0, bf16x8 (*w)[KS]) {        // group g0: fields wv + 4*(g0 + g)
 #pragma unroll
     for (int g = 0; g < FG; ++g) {
-      const int f = f0 + g < p.F ? f0 + g : p.F - 1;
+      const int ff = wv + 4 * (g0 + g);
+      const int f = ff < p.F ? ff : p.F - 1;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) w[g][ks] = ld_bf16x8(wbase + (size_t)f * fstride + 32 * ks);
+      for (int ks = 0; ks < KS; ++ks) w[g][ks] = ld_bf16x8(wbase + (size_t)f * fstride + (size_t)ks * 512);
     }
   };
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  auto run_group = [&](int f0, bf16x8 (*w)[KS]) {
+  auto run_group = [&](int g0, bf16x8 (*w)[KS]) {
 #pragma unroll
     for (int g = 0; g < FG; ++g) {
-      if (f0 + g < p.F) {                         // wave-uniform
+      const int f = wv + 4 * (g0 + g);
+      if (f < p.F) {                              // wave-uniform
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           f32x4 T = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) T = mfma_bf16(a[e][ks], w[g][ks], T);
-          const float4 x = *reinterpret_cast<const float4*>(lds + ((2 * wv + e) * p.F + f0 + g) * CB_D + kq * 4);
+          const float4 x = *reinterpret_cast<const float4*>(sX0 + (e * p.F + f) * CB_D + kq * 4);
           acc[e][0] += x.x * T[0];
           acc[e][1] += x.y * T[1];
           acc[e][2] += x.z * T[2];
@@ -145,29 +166,33 @@ __global__ __launch_bounds__(256) void cin_fwd_bf16_k(const CbFwdArgs p) {
       }
     }
   };
+  const int ng = (p.F + 4 * FG - 1) / (4 * FG);   // load groups per wave
   load_group(0, wa);
   __syncthreads();                                // X0 staged
-  for (int f0 = 0; f0 < p.F; f0 += 2 * FG) {
-    load_group(f0 + FG, wb);                      // (clamped: a group past F is loaded but never used)
-    run_group(f0, wa);
-    if (f0 + FG < p.F) {
-      load_group(f0 + 2 * FG, wa);
-      run_group(f0 + FG, wb);
-    }
+  for (int g0 = 0; g0 < ng * FG; g0 += 2 * FG) {
+    load_group(g0 + FG, wb);                      // (clamped: a group past F is loaded but never used)
+    run_group(g0, wa);
+    load_group(g0 + 2 * FG, wa);
+    run_group(g0 + FG, wb);
   }
-  const bool nok = n0 + i < p.N;
-  const float cv = p.c[nok ? n0 + i : 0];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int b = bw + 2 * wv + e;
-    if (nok && b < p.B) {
-      float4 o;
-      o.x = fmaxf(acc[e][0] + cv, 0.f);
-      o.y = fmaxf(acc[e][1] + cv, 0.f);
-      o.z = fmaxf(acc[e][2] + cv, 0.f);
-      o.w = fmaxf(acc[e][3] + cv, 0.f);
-      *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n0 + i) * CB_D + kq * 4) = o;
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = acc[e][r];
+  __syncthreads();
+  if (wv < 2) {                                   // wave e finishes example e: partials in wave (= field residue) order
+    const int e = wv, b = b0 + e;
+    const bool nok = n0 + i < p.N;
+    const float cv = p.c[nok ? n0 + i : 0];
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = ((sR[((0 * 2 + e) * 4 + r) * 64 + lane] + sR[((1 * 2 + e) * 4 + r) * 64 + lane]) +
+                       sR[((2 * 2 + e) * 4 + r) * 64 + lane]) + sR[((3 * 2 + e) * 4 + r) * 64 + lane];
+      o[r] = fmaxf(s + cv, 0.f);
     }
+    if (nok && b < p.B)
+      *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n0 + i) * CB_D + kq * 4) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -175,39 +200,43 @@ __global__ __launch_bounds__(256) void cin_fwd_bf16_k(const CbFwdArgs p) {
 struct CbDxArgs {
   const float* X0;      // [B, F, 16]
   const float* Xk;      // [B, H, 16]
-  const bf16_t* W16;    // [F, H16, Np]
+  const bf16_t* W16;    // fragment-major, see cin_prep_bf16_k
   const float* out;     // [B, N, 16] this layer's relu output
   const float* dout;    // [B, N, 16] gradient wrt the relu output (nullable when gs is given)
   const float* gs;      // [B] nullable: direct-connect gradient gs[b] * wout[n], broadcast over d, added to dout
   const float* wout;    // [N]
   float* dXk;           // [B, H, 16]
   float* dX0;           // [B, F, 16]
-  bf16_t* dpre16;       // [B, N16, 16] out: relu-masked dout (zero rows for n >= N), B operand of the dW kernel
+  bf16_t* dpre16;       // [ceil(B/2)][N16/16][64][8] out: relu-masked dout as the B-operand fragments of the dW kernel:
+                        // element j of lane (i, kq) = dpre[b = 2 g + (kq >> 1)][n = 16 nt + i][d = 8 (kq & 1) + j]
   float* dc_part;       // [ceil(B/2), N16] out: per-workgroup column sums of the UNROUNDED dpre
   int acc_dxk, acc_dx0;
   int B, F, H, N, H16, N16, Np;
-  int HT;
+  int HT, PART;
 };
 
-// grid = ceil(B/2), block = 64 * HT (HT = H16/16 <= 8): wave ht owns the h tile [16 ht, 16 ht + 16).
-// U_f^T[h, d] = sum_n W_f[h, n] dpre[b, n, d]: A = W16 tile from L2/L1 (the HT waves of a workgroup read different rows, the
-// 128 workgroups the same 1.25 MB), B = dpre[b] transposed to [d][n] through LDS once and kept in registers.
-// dyn LDS: 2*16*(Np+8) bf16 + 2*F*16 + HT*2*F*16 floats.
+// grid = ceil(B/2), block = 64 * HT * PART (HT = H16/16 h tiles; the fields are dealt to PART waves per tile so that the
+// workgroup has 12-16 waves): wave (ht, part) owns h in [16 ht, 16 ht + 16) and f = part, part + PART, ...
+// U_f^T[h, d] = sum_n W_f[h, n] dpre[b, n, d]: A = W16 fragments (coalesced 1 KiB wave loads, two fields in flight), B =
+// dpre[b] transposed to [d][n] through LDS once and kept in registers.
+// dyn LDS: 2*16*(Np+8) bf16 + 2*F*16 + HT*2*F*16 + (PART-1)*HT*2*256 floats.
 template <int KSN>
-__global__ __launch_bounds__(512) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
+__global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int FG = 4;
-  const int HT = p.HT, NPP = p.Np + 8;
+  constexpr int FG = KSN >= 4 ? 1 : 2;
+  const int HT = p.HT, PART = p.PART, NPP = p.Np + 8;
   bf16_t* sDpT = reinterpret_cast<bf16_t*>(lds);                 // [2][16][NPP]
-  float* sX0 = lds + (2 * 16 * NPP) / 2;                         // [2][F*16]
+  float* sX0 = lds + 16 * NPP;                                   // [2][F*16]
   float* sP = sX0 + 2 * p.F * CB_D;                              // [HT][2][F][16]
-  const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, nthr = blockDim.x;
+  float* sDx = sP + HT * 2 * p.F * CB_D;                         // [PART-1][HT][2][4][64] dXk partials of parts 1..
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int ht = wave % HT, part = wave / HT;
   const int i = lane & 15, kq = lane >> 4;
   const int b0 = blockIdx.x * 2;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e = tid; e < 16 * NPP; e += nthr) reinterpret_cast<uint32_t*>(sDpT)[e] = 0u;     // k padding must read as zero
   __syncthreads();
-  // dpre = relu'(out) * (dout + gs*wout): fp32 column sums -> dc_part, bf16 copy -> global (dW kernel) and LDS (transposed)
+  // dpre = relu'(out) * (dout + gs*wout): fp32 column sums -> dc_part, bf16 copy -> global (dW fragments) and LDS (transposed)
   for (int e4 = tid; e4 < p.N16 * 4; e4 += nthr) {
     const int n = e4 >> 2, dq = e4 & 3;
     float s = 0.f;
@@ -227,7 +256,10 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
       s += (v.x + v.y) + (v.z + v.w);
       bf16x4 q;
       q[0] = (bf16_t)v.x; q[1] = (bf16_t)v.y; q[2] = (bf16_t)v.z; q[3] = (bf16_t)v.w;
-      if (b < p.B) *reinterpret_cast<bf16x4*>(p.dpre16 + ((size_t)b * p.N16 + n) * CB_D + dq * 4) = q;
+      {   // fragment of the dW kernel: lane (i = n & 15, kq = 2 e + (d >> 3)), elements j = d & 7
+        const size_t fr = (((size_t)blockIdx.x * (p.N16 >> 4) + (n >> 4)) * 64 + (2 * e + (dq >> 1)) * 16 + (n & 15)) * 8 + (dq & 1) * 4;
+        *reinterpret_cast<bf16x4*>(p.dpre16 + fr) = q;
+      }
       bf16_t* t = sDpT + (size_t)e * 16 * NPP + n;
       t[(dq * 4 + 0) * NPP] = q[0];
       t[(dq * 4 + 1) * NPP] = q[1];
@@ -256,22 +288,23 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
       xkv[e][r] = p.Xk[((size_t)b * p.H + (h < p.H ? h : p.H - 1)) * CB_D + i] * ((h < p.H && b0 + e < p.B) ? 1.f : 0.f);
     }
   }
-  const bf16_t* wbase = p.W16 + ((size_t)(16 * ht + i) * p.Np + 8 * kq);
+  const bf16_t* wbase = p.W16 + ((size_t)ht * KSN * 64 + lane) * 8;
   const size_t fstride = (size_t)p.H16 * p.Np;
   bf16x8 wa[FG][KSN], wb[FG][KSN];
-  auto load_group = [&](int f0, bf16x8 (*w)[KSN]) {
+  auto load_group = [&](int g0, bf16x8 (*w)[KSN]) {       // group g0: fields part + PART*(g0 + g)
 #pragma unroll
     for (int g = 0; g < FG; ++g) {
-      const int f = f0 + g < p.F ? f0 + g : p.F - 1;
+      const int ff = part + PART * (g0 + g);
+      const int f = ff < p.F ? ff : p.F - 1;
 #pragma unroll
-      for (int ks = 0; ks < KSN; ++ks) w[g][ks] = ld_bf16x8(wbase + (size_t)f * fstride + 32 * ks);
+      for (int ks = 0; ks < KSN; ++ks) w[g][ks] = ld_bf16x8(wbase + (size_t)f * fstride + (size_t)ks * 512);
     }
   };
   f32x4 dxk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  auto run_group = [&](int f0, bf16x8 (*w)[KSN]) {
+  auto run_group = [&](int g0, bf16x8 (*w)[KSN]) {
 #pragma unroll
     for (int g = 0; g < FG; ++g) {
-      const int f = f0 + g;
+      const int f = part + PART * (g0 + g);
       if (f < p.F) {                              // wave-uniform
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -291,29 +324,39 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
       }
     }
   };
+  const int ng = (p.F + PART * FG - 1) / (PART * FG);
   load_group(0, wa);
-  for (int f0 = 0; f0 < p.F; f0 += 2 * FG) {
-    load_group(f0 + FG, wb);
-    run_group(f0, wa);
-    if (f0 + FG < p.F) {
-      load_group(f0 + 2 * FG, wa);
-      run_group(f0 + FG, wb);
-    }
+  for (int g0 = 0; g0 < ng * FG; g0 += 2 * FG) {
+    load_group(g0 + FG, wb);
+    run_group(g0, wa);
+    load_group(g0 + 2 * FG, wa);
+    run_group(g0 + FG, wb);
   }
-  // dXk[b][h][d]: lane (i, kq) holds h = 16 ht + 4 kq + r, d = i -- 16 lanes write 64 contiguous bytes
+  if (part > 0) {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int b = b0 + e;
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int h = 16 * ht + 4 * kq + r;
-      if (b < p.B && h < p.H) {
-        float* dst = p.dXk + ((size_t)b * p.H + h) * CB_D + i;
-        *dst = p.acc_dxk ? *dst + dxk[e][r] : dxk[e][r];
+      for (int r = 0; r < 4; ++r) sDx[((((part - 1) * HT + ht) * 2 + e) * 4 + r) * 64 + lane] = dxk[e][r];
+  }
+  __syncthreads();
+  if (part == 0) {
+    // dXk[b][h][d]: lane (i, kq) holds h = 16 ht + 4 kq + r, d = i -- 16 lanes write 64 contiguous bytes; field parts in order
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int b = b0 + e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = dxk[e][r];
+        for (int pp = 1; pp < PART; ++pp) s += sDx[((((pp - 1) * HT + ht) * 2 + e) * 4 + r) * 64 + lane];
+        const int h = 16 * ht + 4 * kq + r;
+        if (b < p.B && h < p.H) {
+          float* dst = p.dXk + ((size_t)b * p.H + h) * CB_D + i;
+          *dst = p.acc_dxk ? *dst + s : s;
+        }
       }
     }
   }
-  __syncthreads();     // sP complete; first layer (dXk == dX0, one buffer for both roles of X0): dXk landed before dX0 adds
+  __syncthreads();     // first layer (dXk == dX0, one buffer for both roles of X0): dXk landed before dX0 adds
   for (int e4 = tid; e4 < 2 * p.F * 4; e4 += nthr) {
     const int ex = e4 / (p.F * 4), r = e4 - ex * p.F * 4;
     const int b = b0 + ex;
@@ -330,7 +373,7 @@ __global__ __launch_bounds__(512) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
 struct CbDwArgs {
   const float* X0;        // [B, F, 16]
   const float* Xk;        // [B, H, 16]
-  const bf16_t* dpre16;   // [B, N16, 16]
+  const bf16_t* dpre16;   // fragments, see CbDxArgs
   const float* dc_part;   // [ceil(B/2), N16]
   float* dW;              // [F*H, N]
   float* dc;              // [N]
@@ -339,18 +382,19 @@ struct CbDwArgs {
   AdamSlice sweep;
 };
 
-// grid = (N16/(16 NT), H16/16, FGn + extra planes), block = 256 = 4 waves that split the k-steps (pairs of examples).
+// grid = (N16/(16 NT), H16/16, FGn + extra planes), block = 512 = 8 waves that split the k-steps (pairs of examples).
 // Plane FGn: block 0 adds the dc partials in order; the other blocks of that plane and of the following planes carry the
-// optimizer sweep slice.  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is formed in fp32 and rounded once.
+// optimizer sweep slice (two 256-thread sweep blocks per workgroup).  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is
+// formed in fp32 and rounded once.  Partial tiles: waves 4..7 -> LDS, waves 0..3 add; waves 1..3 -> LDS, wave 0 adds.
 template <int FT, int NT>
-__global__ __launch_bounds__(256) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
-  __shared__ float red[3][FT * NT][256];          // partial tiles of waves 1..3
+__global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
+  __shared__ float red[4][FT * NT][256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if ((int)blockIdx.z >= p.FGn) {
     const uint32_t lin = (((uint32_t)blockIdx.z - (uint32_t)p.FGn) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (lin == 0) {                               // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
       const int G = (p.B + 1) / 2;
-      for (int n = tid; n < p.N; n += 256) {
+      for (int n = tid; n < p.N; n += 512) {
         float s = 0.f;
         int g = 0;
         for (; g + 8 <= G; g += 8) {
@@ -363,13 +407,15 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
         for (; g < G; ++g) s += p.dc_part[(size_t)g * p.N16 + n];
         p.dc[n] = s;
       }
-    } else if (lin - 1 < p.sweep.n_blk) {
-      adam_block(p.sweep.args, p.sweep.blk_lo + lin - 1);
+    } else {
+      const uint32_t blk = 2 * (lin - 1) + (uint32_t)(tid >> 8);
+      if (blk < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + blk, tid & 255);
     }
     return;
   }
   const int i = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 16 * NT, ht = blockIdx.y, f0 = blockIdx.z * FT;
+  const int ntg = blockIdx.x * NT, ht = blockIdx.y, f0 = blockIdx.z * FT;
+  const int NT16 = p.N16 >> 4;
   const int h = 16 * ht + i;
   const int hc = h < p.H ? h : p.H - 1;
   const int d0 = (kq & 1) * 8, eb = kq >> 1;      // k = 8 kq + j  <->  example 2 ks + (kq >> 1), dims d0 .. d0 + 7
@@ -388,6 +434,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   auto load = [&](int ks, Ld& L) {
     const int b = 2 * ks + eb;
     const int bc = b < p.B ? b : p.B - 1;
+    const int ksc = ks < nks ? ks : nks - 1;
     L.m = (b < p.B && ks < nks && h < p.H) ? 1.f : 0.f;
     const float4* xk = reinterpret_cast<const float4*>(p.Xk + ((size_t)bc * p.H + hc) * CB_D + d0);
     L.xk[0] = xk[0];
@@ -400,9 +447,9 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
       L.x0[ft][1] = x0[1];
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {             // rows n >= N are zero; tiles past N16 re-read the last row (never stored)
-      const int n = n0 + 16 * nt + i;
-      L.dp[nt] = ld_bf16x8(p.dpre16 + ((size_t)bc * p.N16 + (n < p.N16 ? n : p.N16 - 1)) * CB_D + d0);
+    for (int nt = 0; nt < NT; ++nt) {             // n tiles past N16 re-read the last tile (never stored)
+      const int t = ntg + nt < NT16 ? ntg + nt : NT16 - 1;
+      L.dp[nt] = ld_bf16x8(p.dpre16 + (((size_t)ksc * NT16 + t) * 64 + lane) * 8);
     }
   };
   auto run = [&](const Ld& L) {
@@ -416,22 +463,38 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   };
   Ld La, Lb;
   load(wv, La);
-  for (int ks = wv; ks < nks; ks += 8) {          // this wave's k-steps: wv, wv + 4, ...
-    load(ks + 4 < nks ? ks + 4 : ks, Lb);
+  for (int ks = wv; ks < nks; ks += 16) {         // this wave's k-steps: wv, wv + 8, ...
+    load(ks + 8, Lb);                             // (clamped + masked past the batch)
     run(La);
-    if (ks + 4 < nks) {
-      load(ks + 8 < nks ? ks + 8 : ks + 4, La);
-      run(Lb);
-    }
+    load(ks + 16, La);
+    run(Lb);
   }
-  // partial tiles of waves 1..3 -> LDS; wave 0 adds them in wave order and stores
-  if (wv > 0) {
+  // partial tiles, fixed order: ((w0 + w4) + (w1 + w5) ... ) as two rounds through one 4-slot LDS buffer
+  if (wv >= 4) {
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wv - 1][ft * NT + nt][r * 64 + lane] = acc[ft][nt][r];
+        for (int r = 0; r < 4; ++r) red[wv - 4][ft * NT + nt][r * 64 + lane] = acc[ft][nt][r];
+  }
+  __syncthreads();
+  if (wv < 4) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ft][nt][r] += red[wv][ft * NT + nt][r * 64 + lane];
+  }
+  __syncthreads();
+  if (wv >= 1 && wv < 4) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][ft * NT + nt][r * 64 + lane] = acc[ft][nt][r];
   }
   __syncthreads();
   if (wv == 0) {
@@ -440,12 +503,12 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
       const int f = f0 + ft;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + 16 * nt + i;
+        const int n = 16 * (ntg + nt) + i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int hh = 16 * ht + 4 * kq + r;
-          const float s = ((acc[ft][nt][r] + red[0][ft * NT + nt][r * 64 + lane]) + red[1][ft * NT + nt][r * 64 + lane]) +
-                          red[2][ft * NT + nt][r * 64 + lane];
+          const float s = ((acc[ft][nt][r] + red[1][ft * NT + nt][r * 64 + lane]) + red[2][ft * NT + nt][r * 64 + lane]) +
+                          red[3][ft * NT + nt][r * 64 + lane];
           if (f < p.F && hh < p.H && n < p.N) p.dW[((size_t)f * p.H + hh) * p.N + n] = s;
         }
       }
@@ -461,7 +524,7 @@ extern "C" size_t rsx_cin_bf16_weight_elems(int F, int H, int N) {
 
 extern "C" size_t rsx_cin_bf16_bwd_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
-  const size_t dp = ((size_t)B * rup(N, 16) * CB_D * 2 + 15) & ~(size_t)15;
+  const size_t dp = (size_t)((B + 1) / 2) * 2 * rup(N, 16) * CB_D * 2;      // fragments of whole example pairs
   return dp + (size_t)((B + 1) / 2) * rup(N, 16) * sizeof(float);
 }
 
@@ -486,13 +549,13 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
   if (D != CB_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int H16 = rup(H, 16), N16 = rup(N, 16), Hp = rup(H, 32), Np = rup(N, 32);
   const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)F * H16 * Np;
-  CbFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, (B + 7) / 8, {}};
+  CbFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, (B + 1) / 2, {}};
   const int rcs = adam_build_slice(sweep_h, a.sweep);
   if (rcs != RSX_OK) return rcs;
   const unsigned gx = (unsigned)(N16 / 16);
   const unsigned extra = (a.sweep.n_blk + gx - 1) / gx;
   const dim3 grid(gx, (unsigned)a.nby + extra);
-  const size_t lds = (size_t)8 * F * CB_D * sizeof(float);
+  const size_t lds = ((size_t)2 * F * CB_D + 4 * 2 * 256) * sizeof(float);
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
   switch (Hp / 32) {
     case 1: hipLaunchKernelGGL(cin_fwd_bf16_k<1>, grid, dim3(256), lds, rsx_s(stream), a); break;
@@ -517,12 +580,21 @@ extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const vo
   const int H16 = rup(H, 16), N16 = rup(N, 16), Np = rup(N, 32);
   const int HT = H16 / 16;
   bf16_t* dpre16 = static_cast<bf16_t*>(ws);
-  float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (((size_t)B * N16 * CB_D * 2 + 15) & ~(size_t)15));
+  float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
+  const int PART = HT >= 8 ? 2 : (HT >= 4 ? 3 : (HT >= 3 ? 4 : (HT == 2 ? 6 : 8)));      // 8-16 waves per workgroup
   CbDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dX0, dpre16, dc_part, acc_dxk, acc_dx0,
-             B, F, H, N, H16, N16, Np, HT};
-  const size_t lds = (size_t)2 * 16 * (Np + 8) * 2 + ((size_t)2 * F * CB_D + (size_t)HT * 2 * F * CB_D) * sizeof(float);
-  if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
-  const dim3 grid((unsigned)((B + 1) / 2)), block((unsigned)(64 * HT));
+             B, F, H, N, H16, N16, Np, HT, PART};
+  const size_t lds = (size_t)2 * 16 * (Np + 8) * 2 +
+                     ((size_t)2 * F * CB_D + (size_t)HT * 2 * F * CB_D + (size_t)(PART - 1) * HT * 2 * 256) * sizeof(float);
+  if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
+  const dim3 grid((unsigned)((B + 1) / 2)), block((unsigned)(64 * HT * PART));
+  const void* fn = Np / 32 == 1 ? reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<1>)
+                 : Np / 32 == 2 ? reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<2>)
+                 : Np / 32 == 3 ? reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<3>)
+                                : reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<4>);
+  // gfx950 has 160 KiB of LDS per CU; above 64 KiB a kernel must opt in (host-side attribute, no stream work)
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return RSX_ELAUNCH;
   switch (Np / 32) {
     case 1: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<1>, grid, block, lds, rsx_s(stream), a); break;
     case 2: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<2>, grid, block, lds, rsx_s(stream), a); break;
@@ -530,15 +602,15 @@ extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const vo
     default: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<4>, grid, block, lds, rsx_s(stream), a); break;
   }
   RSX_CHECK_LAUNCH();
-  constexpr int FT = 3, NT = 4;
+  constexpr int FT = 3, NT = 2;
   CbDwArgs w{X0, Xk, dpre16, dc_part, dW, dc, B, F, H, N, N16, (F + FT - 1) / FT, {}};
   const int rcs = adam_build_slice(sweep_h, w.sweep);
   if (rcs != RSX_OK) return rcs;
   const unsigned gx = (unsigned)((N16 + 16 * NT - 1) / (16 * NT));
   const unsigned plane = gx * (unsigned)HT;
-  const unsigned zs = (1u + w.sweep.n_blk + plane - 1) / plane;       // extra z-planes: the dc block + the sweep slice
+  const unsigned zs = (1u + (w.sweep.n_blk + 1) / 2 + plane - 1) / plane;    // extra z-planes: the dc block + the sweep slice
   const dim3 gridw(gx, (unsigned)HT, (unsigned)w.FGn + zs);
-  hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT>), gridw, dim3(256), 0, rsx_s(stream), w);
+  hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT>), gridw, dim3(512), 0, rsx_s(stream), w);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

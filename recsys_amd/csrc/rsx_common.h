@@ -29,3 +29,19 @@ __device__ __forceinline__ float4 f4_scale(float s, float4 a) {
 __device__ __forceinline__ float4 f4_shfl_xor(float4 a, int m) {
   return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m), __shfl_xor(a.w, m));
 }
+
+// Profiling aid (NOT in the product build): -DRSX_STAMPS makes selected workgroups record the 100 MHz wall clock at phase
+// boundaries into a per-translation-unit device array, read back by rsx_dbg_stamps_<unit>(); scripts/stamp_probe.py
+// builds that variant into scripts/_build/ and prints where a latency-bound kernel spends its microseconds.
+#ifdef RSX_STAMPS
+#define RSX_STAMP_DECL static __device__ unsigned long long rsx_stamps_d[64];
+#define RSX_STAMP(slot, cond)                                                        \
+  do {                                                                               \
+    if ((cond) && threadIdx.x == 0) rsx_stamps_d[slot] = wall_clock64();             \
+  } while (0)
+#else
+#define RSX_STAMP_DECL
+#define RSX_STAMP(slot, cond) \
+  do {                        \
+  } while (0)
+#endif

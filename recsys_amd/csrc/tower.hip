@@ -23,6 +23,7 @@
 #include "drop_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+RSX_STAMP_DECL
 
 constexpr float TOWER_BN_EPS = 1e-3f;  // tf.layers.batch_normalization default epsilon
 constexpr int TM = 16;                 // rows per row tile
@@ -31,12 +32,27 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// fixed-order fp64 sum of the RT per-row-tile partials of one column; 8 loads in flight at a time
+// fixed-order fp64 sum of the RT per-row-tile partials of one column.  All loads of a 16-tile block are issued before the
+// first add (batch 256 = 16 row tiles = ONE memory round trip per consumer instead of two; every tower launch starts with
+// this reduction, so the round trip is on the step's critical path five times).
 __device__ __forceinline__ void col_partials(const double* __restrict__ st, int RT, int N, int col, double& s1,
                                              double& s2) {
   s1 = 0.0;
   s2 = 0.0;
   int r = 0;
+  for (; r + 16 <= RT; r += 16) {
+    double t1[16], t2[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      t1[u] = st[((size_t)(r + u) * 2 + 0) * N + col];
+      t2[u] = st[((size_t)(r + u) * 2 + 1) * N + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      s1 += t1[u];
+      s2 += t2[u];
+    }
+  }
   for (; r + 8 <= RT; r += 8) {
     double t1[8], t2[8];
 #pragma unroll
@@ -77,7 +93,26 @@ template <class Ld>
 __device__ __forceinline__ float tile_ksplit(int nsteps, float* part /* LDS [4][256] */, Ld ld) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  for (int ks = w; ks < nsteps; ks += 8) {
+  int ks = w;
+  // deep reductions (the first layer's K = 624: 10 k-steps per wave): the loads of FOUR k-steps are issued before their
+  // 16 MFMAs, so a wave needs 3 memory round trips instead of 5; the summation order (acc0: even, acc1: odd visits)
+  // is the one of the two-step loop below, which finishes the tail
+  for (; ks + 12 < nsteps; ks += 16) {
+    float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+    ld(ks, a0, b0);
+    ld(ks + 4, a1, b1);
+    ld(ks + 8, a2, b2);
+    ld(ks + 12, a3, b3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc0 = mfma16(a0[t], b0[t], acc0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc1 = mfma16(a1[t], b1[t], acc1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc0 = mfma16(a2[t], b2[t], acc0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc1 = mfma16(a3[t], b3[t], acc1);
+  }
+  for (; ks < nsteps; ks += 8) {
     float a0[4], b0[4], a1[4], b1[4];
     ld(ks, a0, b0);
     const bool two = ks + 4 < nsteps;
@@ -133,6 +168,8 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     return;
   }
   const int bx = blockIdx.x % p.ct, by = blockIdx.x / p.ct;
+  const int st0 = p.fstat_prev == nullptr ? 4 : 0;
+  RSX_STAMP(st0 + 0, blockIdx.x == 0);
   float* sc = lds;                    // [K] scale
   float* sh = lds + p.K;              // [K] shift
   float* part = lds + 2 * p.K;        // [4][256]
@@ -158,6 +195,7 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     }
     __syncthreads();
   }
+  RSX_STAMP(st0 + 1, blockIdx.x == 0);
   const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
   const int i = lane & 15, kq = lane >> 4;
   const int row = by * TM + i;
@@ -189,6 +227,7 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     }
     a[0] = av.x * okf; a[1] = av.y * okf; a[2] = av.z * okf; a[3] = av.w * okf;
   });
+  RSX_STAMP(st0 + 2, blockIdx.x == 0);
   // epilogue: thread t owns element (r = t/16, c = t%16)
   const int orow = by * TM + (tid >> 4), ocol = bx * 16 + (tid & 15);
   double s1 = 0.0, s2 = 0.0;
@@ -212,6 +251,7 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
       p.fstat_out[((size_t)by * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
     }
   }
+  RSX_STAMP(st0 + 3, blockIdx.x == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,6 +302,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
   __shared__ float redw[4][256];
   __shared__ double hred[4][8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  RSX_STAMP(8, blockIdx.x == 0);
   for (int c = tid; c < p.N; c += 256) {
     if (p.gamma == nullptr) {   // no batch-norm on the last layer: dy_last is the gradient wrt the dropout input
       sc[c] = 1.f; sh[c] = 0.f; mu[c] = 0.f; rs[c] = 0.f;
@@ -280,6 +321,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
     }
   }
   __syncthreads();
+  RSX_STAMP(9, blockIdx.x == 0);
   const DropRng dr = drop_make(p.rate, p.mask, p.rng_step, p.seed, p.layer);
   constexpr int CPL = 4;  // columns per lane (N <= 256)
   double sdy[CPL], sdx[CPL];
@@ -369,6 +411,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
       }
     }
   }
+  RSX_STAMP(10, blockIdx.x == 0);
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int c = lane + 64 * k;
@@ -385,6 +428,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
     p.dwd_part[(size_t)blockIdx.x * p.N + c] = redw[0][c] + redw[1][c] + redw[2][c] + redw[3][c];
   }
   if (tid < 8) p.hpart[(size_t)blockIdx.x * 8 + tid] = hred[0][tid] + hred[1][tid] + hred[2][tid] + hred[3][tid];
+  RSX_STAMP(11, blockIdx.x == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -479,13 +523,16 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   const bool first = p.bn_prev == nullptr;
   const bool nobn = p.gamma == nullptr;          // this layer has no batch-norm (uniform)
   const int i = lane & 15, kq = lane >> 4;
+  const int sb0 = first ? 16 : 24;
   if (bid < p.n_din) {
     // ---- d(input) tile: rows rt*16.., input columns kc*16.. ; reduction over the N outputs ----------
+    RSX_STAMP(sb0 + 0, bid == 0);
     for (int c = tid; c < p.N; c += 256) {
       const ColBwd cb = bwd_col(p, c);
       Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
     }
     __syncthreads();
+    RSX_STAMP(sb0 + 1, bid == 0);
     // large batches (SPLIT): one workgroup walks din_rtw consecutive row tiles of its column tile, so the column
     // constants above (and the launch's workgroup count) are amortised; small batches: one tile per workgroup
     const int rtw = SPLIT ? p.din_rtw : 1;
@@ -529,6 +576,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         b[t] = wr[t] * (cok ? nf : 0.f);
       }
     });
+    RSX_STAMP(sb0 + 2, bid == 0);
     double s1 = 0.0, s2 = 0.0;
     if (orow < p.B && ocol < p.K) {
       float o = v;
@@ -555,6 +603,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       }
     }
     }
+    RSX_STAMP(sb0 + 3, bid == 0);
     return;
   }
   if (bid < p.n_din + p.n_dw) {
@@ -565,6 +614,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     const int ks0 = SPLIT ? sbi * p.ksb : 0;
     const int ks_all = (p.B + 15) / 16;
     const int nks = SPLIT ? (ks0 + p.ksb < ks_all ? p.ksb : ks_all - ks0) : ks_all;
+    RSX_STAMP(sb0 + 4, bid == p.n_din);
     const int feat = kf * 16 + i;          // A-operand row (input feature)
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
@@ -581,6 +631,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       p.dbeta[ncol] = cb.sdy;
     }
     const int featc = fok ? feat : 0, ncolc = nok ? ncol : 0;
+    RSX_STAMP(sb0 + 5, bid == p.n_din);
     float v = tile_ksplit(nks, part, [&](int ks, float* a, float* b) {
       // operand loads unconditional on clamped indices, masked by multiplication afterwards (a guarded load is compiled
       // into a branch of its own, and the four k-steps' loads then complete one after the other)
@@ -604,6 +655,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         b[t] = da_of(ar[t], dyr[t], cb, Bf, nobn) * (nok ? vf : 0.f);
       }
     });
+    RSX_STAMP(sb0 + 6, bid == p.n_din);
     if (SPLIT) {      // partial tile; tower_reduce_dw_k adds the sb partials in ascending block order
       p.dwp[((size_t)tile * p.sb + sbi) * 256 + tid] = v;
       return;
@@ -613,6 +665,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       if (orow < p.K) p.dW[(size_t)orow * p.N + ocol] = v;
       else if (orow == p.K) p.db[ocol] = v;
     }
+    RSX_STAMP(sb0 + 7, bid == p.n_din);
     return;
   }
   if (bid >= p.n_din + p.n_dw + p.n_head + p.n_sort) {
@@ -966,3 +1019,10 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   }
   return RSX_OK;
 }
+
+#ifdef RSX_STAMPS
+// profiling build only: copy the tower kernels' phase stamps (100 MHz wall clock ticks) to the host
+extern "C" int rsx_dbg_stamps_tower(unsigned long long* out_h) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(rsx_stamps_d), sizeof(unsigned long long) * 64) == hipSuccess ? RSX_OK : RSX_ELAUNCH;
+}
+#endif

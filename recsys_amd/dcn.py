@@ -52,7 +52,12 @@ def build_variables(store, params, capacity):
     store.layout = layout
     store.cross = CrossLayers(dim, nL, capacity, store.device)
     store.tower = None
-    if params.get("tower", "hip") == "hip":
+    want_hip = params.get("tower", "hip") == "hip"
+    if want_hip and not FusedTower.supports(dim, layers):
+        print("INFO:deep_layers=%s is outside the fused tower's envelope (widths multiple of 4, last <= 256): using the "
+              "autograd tower (tower='torch')" % params["deep_layers"], flush=True)
+        want_hip = False
+    if want_hip:
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False

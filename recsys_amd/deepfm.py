@@ -63,8 +63,13 @@ def build_variables(store, params, capacity, with_dnn=True):
     store.build({"input_layer": arena}, shapes, init, params["learning_rate"])
     store.layout = layout
     store.tower = None
-    if with_dnn and params.get("tower", "hip") == "hip":
-        from .ops import FusedTower
+    from .ops import FusedTower
+    want_hip = with_dnn and params.get("tower", "hip") == "hip"
+    if want_hip and not FusedTower.supports(layout.F * D, layers):
+        print("INFO:deep_layers=%s is outside the fused tower's envelope (widths multiple of 4, last <= 256): using the "
+              "autograd tower (tower='torch')" % params["deep_layers"], flush=True)
+        want_hip = False
+    if want_hip:
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False

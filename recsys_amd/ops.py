@@ -421,12 +421,19 @@ class FusedTower:
     buffer; dX / gs0 / gs1 (gradients of the tower inputs) are returned for the embedding scatter.
     Mirrors deepfm/deepfm.py:100-112 (`dnn` scope + logits) with fm/fm.py:146-149 (loss)."""
 
+    @staticmethod
+    def supports(k0, widths):
+        """The fused kernels' envelope; model code checks it BEFORE creating any variable and otherwise takes the
+        autograd path (`tower='torch'`), so every --deep_layers the reference accepts still trains."""
+        widths = [int(w) for w in widths]
+        return bool(widths) and int(k0) % 4 == 0 and all(w % 4 == 0 for w in widths[:-1]) and widths[-1] <= 256
+
     def __init__(self, dense, pre, k0, widths, capacity, device="cuda", batch_norm=True):
         """batch_norm=False: L x [dense(relu) -> dropout] (din/din.py:132-137), no gamma/beta variables."""
         dev = _require_cuda(device)
         self.bn_on = bool(batch_norm)
         self.P, self.pre, self.k0, self.widths = dense, pre, int(k0), [int(w) for w in widths]
-        if self.k0 % 4 or any(w % 4 for w in self.widths[:-1]) or self.widths[-1] > 256:
+        if not FusedTower.supports(self.k0, self.widths):
             raise _lib.RsxError("FusedTower envelope: widths multiple of 4, last width <= 256 (use tower='torch')")
         self.cap = int(capacity)
         B, RT = self.cap, (self.cap + 15) // 16

@@ -24,6 +24,15 @@ def build_variables(store, params, capacity):
     D = params["embedding_size"]
     F = layout.F
     cin = list(map(int, params["cross_layers"].split(",")))
+    # the fused TRAIN step is the only xDeepFM path: check its envelope before any variable exists, so an unsupported
+    # configuration fails here with the reason instead of at the first step
+    _layers = list(map(int, params["deep_layers"].split(",")))
+    if params["embedding_size"] != 16 or max(cin) > 128:
+        raise _lib.RsxError("xdeepfm: the CIN kernels cover embedding_size 16 and cross_layers widths <= 128 "
+                       "(got embedding_size=%d, cross_layers=%s)" % (params["embedding_size"], params["cross_layers"]))
+    if not FusedTower.supports(F * D, _layers):
+        raise _lib.RsxError("xdeepfm: deep_layers=%s is outside the fused tower's envelope (widths multiple of 4, last <= 256)"
+                       % params["deep_layers"])
     layers = list(map(int, params["deep_layers"].split(",")))
     if store.dp is not None:
         capacity *= store.dp.world

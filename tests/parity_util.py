@@ -43,7 +43,7 @@ def load_oracle_weights(est, P):
 
 def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100), adam_mode="tf1_dense",
                       use_graph=False, return_all=False, tower="hip", dropout=0.0, kind="deepfm", cross_layers=3,
-                      data_parallel=False):
+                      data_parallel=False, oracle_dtype=None):
     """Train `steps` steps of `kind` in {deepfm, fm, dcn} on both sides from identical weights and batches (injected
     dropout masks).  Returns max |prob_gpu - prob_oracle| over all steps (and losses / final parameter errors)."""
     import torch
@@ -80,9 +80,13 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
     ids0 = torch.from_numpy(batches[0][0]).cuda()
     est._call_model_fn({"ids": ids0}, None, ModeKeys.PREDICT)        # creates the variables
     load_oracle_weights(est, P)
+    import os
+    odt = np.float64 if (oracle_dtype or os.environ.get("RSX_TEST_ORACLE_DTYPE", "f32")) == "f64" else np.float32
+    if odt is np.float64:      # fp64 oracle from the same fp32 initial values (what the large-batch cases compare with: an
+        P = {k: v.astype(np.float64) for k, v in P.items()}      # fp32 numpy BN / matmul over 4096 rows has its own 1e-5 noise)
     om = {"dcn": lambda: models.DCN(P, row_off, len(layers), dropout), "fm": lambda: models.FM(P, row_off),
           "deepfm": lambda: models.DeepFM(P, row_off, len(layers), dropout)}[kind]()
-    opt = nn.AdamTF1(dtype=np.float32)
+    opt = nn.AdamTF1(dtype=odt)
     err = 0.0
     losses = []
     for ids, y in batches:
@@ -96,7 +100,8 @@ def deepfm_parity_run(B=64, steps=2, seed=0, rows=None, D=16, layers=(100, 100),
             est.params["_dropout_masks"] = [torch.from_numpy(m).cuda() for m in mk]
         loss_g = est._train_step(f, lab)
         zo_eval = nn.sigmoid(om.forward(ids, train=False))
-        loss_o, _ = models.train_step(om, opt, (ids,), y, {"masks": mk} if mk else None, lazy=(adam_mode == "lazy_rows"))
+        loss_o, _ = models.train_step(om, opt, (ids,), y.astype(odt), {"masks": [m.astype(odt) for m in mk]} if mk else None,
+                                      lazy=(adam_mode == "lazy_rows"))
         err = max(err, float(np.abs(zg.cpu().numpy().reshape(-1) - zo_eval).max()))
         losses.append((float(loss_g), float(loss_o)))
     if not return_all:
