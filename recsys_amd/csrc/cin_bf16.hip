@@ -94,8 +94,10 @@ struct CbFwdArgs {
 // grid = (N16/16, ceil(B/2) [+ sweep rows]), block = 256.  The workgroup owns examples 2*blockIdx.y, +1 and the 16
 // outputs n0..; its 4 waves split the FIELDS (wave w takes f = w, w + 4, ...: ten dependent steps instead of 39, and 4096
 // waves for the latency-bound W stream to hide behind), their partial sums are added in wave order through LDS.
-// KS = Hp / 32 k-steps per field.  The W fragments of two fields are in flight while the previous two are multiplied.
-// LDS: 2*F*16 (X0 of the two examples) + 4*2*256 (partials) floats.
+// KS = Hp / 32 k-steps per field.  The W fragments of the next field(s) are in flight while the current ones are multiplied.
+// Xk of the two examples is read ONCE per workgroup (coalesced float4), rounded to bf16 and transposed through LDS to
+// [d][h], so that every wave builds its A fragments with ds_read_b128.
+// LDS: 2*F*16 (X0 of the two examples) + 4*2*256 (partials) floats + 2*16*(Hp+8) bf16.
 template <int KS>
 __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -105,8 +107,10 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
     return;
   }
   constexpr int FG = KS >= 4 ? 1 : 2;            // fields per load group (register budget: 128 per lane, 4 waves per SIMD)
+  constexpr int HPP = 32 * KS + 8;               // padded h-stride of the transposed Xk tile (conflict-free b128 reads)
   float* sX0 = lds;                              // [2][F*16]
   float* sR = lds + 2 * p.F * CB_D;              // [4 waves][2 examples][4][64]
+  bf16_t* sXk = reinterpret_cast<bf16_t*>(sR + 4 * 2 * 256);     // [2][16][HPP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 16;
@@ -116,24 +120,19 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
     reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : z4;
   }
-  // A operand: Xk[b][h = 32 ks + 8 kq + j][d = i], the same for every field -> registers for the whole kernel
-  bf16x8 a[2][KS];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int b = b0 + e;
-    const float* xk = p.Xk + (size_t)(b < p.B ? b : p.B - 1) * p.H * CB_D + i;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {               // unconditional loads on clamped rows, masked by multiplication
-        const int h = 32 * ks + 8 * kq + j;
-        v[j] = xk[(size_t)(h < p.H ? h : p.H - 1) * CB_D] * ((h < p.H && b < p.B) ? 1.f : 0.f);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[e][ks][j] = (bf16_t)v[j];
-    }
+  for (int e4 = tid; e4 < 2 * 32 * KS * 4; e4 += 256) {          // (example, h, d-quarter): float4 in, 4 bf16 out (h >= H: zero)
+    const int ex = e4 / (32 * KS * 4), r = e4 - ex * (32 * KS * 4);
+    const int h = r >> 2, dq = r & 3;
+    const float4 v = (b0 + ex < p.B && h < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)(b0 + ex) * p.H + h) * CB_D)[dq] : z4;
+    bf16_t* t = sXk + (size_t)ex * 16 * HPP + h;
+    t[(dq * 4 + 0) * HPP] = (bf16_t)v.x;
+    t[(dq * 4 + 1) * HPP] = (bf16_t)v.y;
+    t[(dq * 4 + 2) * HPP] = (bf16_t)v.z;
+    t[(dq * 4 + 3) * HPP] = (bf16_t)v.w;
   }
+  // A operand: Xk[b][h = 32 ks + 8 kq + j][d = i], the same for every field -> registers for the whole kernel (filled
+  // from the LDS tile after the barrier below)
+  bf16x8 a[2][KS];
   const bf16_t* wbase = p.Wt16 + ((size_t)blockIdx.x * KS * 64 + lane) * 8;
   const size_t fstride = (size_t)p.N16 * p.Hp;
   bf16x8 wa[FG][KS], wb[FG][KS];
@@ -168,7 +167,11 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   };
   const int ng = (p.F + 4 * FG - 1) / (4 * FG);   // load groups per wave
   load_group(0, wa);
-  __syncthreads();                                // X0 staged
+  __syncthreads();                                // X0 and Xk staged
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[e][ks] = ld_bf16x8(sXk + ((size_t)e * 16 + i) * HPP + 32 * ks + 8 * kq);
   for (int g0 = 0; g0 < ng * FG; g0 += 2 * FG) {
     load_group(g0 + FG, wb);                      // (clamped: a group past F is loaded but never used)
     run_group(g0, wa);
@@ -555,7 +558,7 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
   const unsigned gx = (unsigned)(N16 / 16);
   const unsigned extra = (a.sweep.n_blk + gx - 1) / gx;
   const dim3 grid(gx, (unsigned)a.nby + extra);
-  const size_t lds = ((size_t)2 * F * CB_D + 4 * 2 * 256) * sizeof(float);
+  const size_t lds = ((size_t)2 * F * CB_D + 4 * 2 * 256) * sizeof(float) + (size_t)2 * 16 * (Hp + 8) * 2;
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
   switch (Hp / 32) {
     case 1: hipLaunchKernelGGL(cin_fwd_bf16_k<1>, grid, dim3(256), lds, rsx_s(stream), a); break;
@@ -581,7 +584,7 @@ extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const vo
   const int HT = H16 / 16;
   bf16_t* dpre16 = static_cast<bf16_t*>(ws);
   float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
-  const int PART = HT >= 8 ? 2 : (HT >= 4 ? 3 : (HT >= 3 ? 4 : (HT == 2 ? 6 : 8)));      // 8-16 waves per workgroup
+  const int PART = 16 / HT;                            // HT * PART <= 16 waves (1024 threads) per workgroup, HT <= 8
   CbDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dX0, dpre16, dc_part, acc_dxk, acc_dx0,
              B, F, H, N, H16, N16, Np, HT, PART};
   const size_t lds = (size_t)2 * 16 * (Np + 8) * 2 +

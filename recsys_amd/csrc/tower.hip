@@ -292,6 +292,8 @@ struct HeadArgs {
   AdamSlice sweep;
 };
 
+// CPL: columns per lane = ceil(N / 16) rounded up to 4 / 8 / 16 (a compile-time bound keeps every load unconditional)
+template <int CPL>
 __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
   if ((int)blockIdx.x >= p.n_own) {
     adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
@@ -300,9 +302,31 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
   __shared__ float sc[256], sh[256], mu[256], rs[256];
   __shared__ double red[4][2][256];
   __shared__ float redw[4][256];
-  __shared__ double hred[4][8];
+  __shared__ double hrow[16][8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   RSX_STAMP(8, blockIdx.x == 0);
+  // (the row's loads are issued BEFORE the statistics reduction below: they do not depend on it)
+  // One row per 16-lane group: the wave's 4 rows go through the dot product, the loss and its backward SIDE BY SIDE (the
+  // per-row chain -- 16-lane reduction, exp / log1p / divide -- used to run 4 times in sequence per wave: 1.6 us per row,
+  // measured with the phase stamps).  Lane (g, li) holds columns c = li + 16 k of row 16*blockIdx.x + 4*w + g.
+  const int g = lane >> 4, li = lane & 15;
+  const int row = blockIdx.x * TM + w * 4 + g;
+  const bool rok = row < p.B;
+  const size_t rowc = (size_t)(rok ? row : p.B - 1);
+  float av[CPL], wdv[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {     // unconditional on clamped indices (rows past the batch / columns past N are masked below)
+    const int c = li + 16 * k;
+    const int cc = c < p.N ? c : p.N - 1;
+    av[k] = p.a_last[rowc * p.N + cc];
+    wdv[k] = p.wd[cc] * (c < p.N ? 1.f : 0.f);
+  }
+  const float s0v = p.s0 ? p.s0[rowc] : 0.f, s1v = p.s1 ? p.s1[rowc] : 0.f, y = p.labels[rowc];
+  const float bd = p.bd[0];
+  const float wo0 = p.wo ? p.wo[0] : 1.f, wo1 = p.wo ? p.wo[1] : 1.f, wo2 = p.wo ? p.wo[2] : 1.f;
+  const float bo = p.bo ? p.bo[0] : 0.f;
+  const float c0 = p.c0 ? p.c0[0] : 0.f;
+  const DropRng dr = drop_make(p.rate, p.mask, p.rng_step, p.seed, p.layer);
   for (int c = tid; c < p.N; c += 256) {
     if (p.gamma == nullptr) {   // no batch-norm on the last layer: dy_last is the gradient wrt the dropout input
       sc[c] = 1.f; sh[c] = 0.f; mu[c] = 0.f; rs[c] = 0.f;
@@ -322,112 +346,80 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
   }
   __syncthreads();
   RSX_STAMP(9, blockIdx.x == 0);
-  const DropRng dr = drop_make(p.rate, p.mask, p.rng_step, p.seed, p.layer);
-  constexpr int CPL = 4;  // columns per lane (N <= 256)
-  double sdy[CPL], sdx[CPL];
-  float swd[CPL], wdv[CPL];
+  float o[CPL], xh[CPL], mk[CPL];
+  float dot = 0.f;
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
-    sdy[k] = 0.0; sdx[k] = 0.0; swd[k] = 0.f;
-    const int c = lane + 64 * k;
-    wdv[k] = c < p.N ? p.wd[c] : 0.f;
-  }
-  double hp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const float bd = p.bd[0];
-  const float wo0 = p.wo ? p.wo[0] : 1.f, wo1 = p.wo ? p.wo[1] : 1.f, wo2 = p.wo ? p.wo[2] : 1.f;
-  const float bo = p.bo ? p.bo[0] : 0.f;
-  const float c0 = p.c0 ? p.c0[0] : 0.f;
-  const int row0 = blockIdx.x * TM + w * 4;
-  // issue every load of the wave's 4 rows first, then the dependent math
-  float av[4][CPL], s0v[4], s1v[4], yv[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    // unconditional on clamped indices (rows past the batch are skipped below, columns past N are masked there): a
-    // guarded load is compiled into a branch of its own
-    const size_t row = (size_t)(row0 + rr < p.B ? row0 + rr : p.B - 1);
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int c = lane + 64 * k;
-      av[rr][k] = p.a_last[row * p.N + (c < p.N ? c : p.N - 1)];
+    const int c = li + 16 * k;
+    o[k] = 0.f; xh[k] = 0.f; mk[k] = 0.f;
+    if (c < p.N) {
+      const float a = av[k];
+      mk[k] = drop_mul(dr, p.mask, rowc * p.N + c);
+      const float v = (a * sc[c] + sh[c]) * mk[k];
+      o[k] = v;
+      xh[k] = (a - mu[c]) * rs[c];
+      dot += v * wdv[k];
     }
-    s0v[rr] = p.s0 ? p.s0[row] : 0.f;
-    s1v[rr] = p.s1 ? p.s1[row] : 0.f;
-    yv[rr] = p.labels[row];
   }
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = row0 + rr;
-    if (row >= p.B) break;  // wave-uniform
-    float o[CPL], xh[CPL], mk[CPL];
-    float dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int c = lane + 64 * k;
-      o[k] = 0.f; xh[k] = 0.f; mk[k] = 0.f;
-      if (c < p.N) {
-        const float a = av[rr][k];
-        mk[k] = drop_mul(dr, p.mask, (size_t)row * p.N + c);
-        const float v = (a * sc[c] + sh[c]) * mk[k];
-        o[k] = v;
-        xh[k] = (a - mu[c]) * rs[c];
-        dot += v * wdv[k];
-      }
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) dot += __shfl_xor(dot, m);
-    const float u = dot + bd;
-    const float t2 = (p.relu2 && u <= 0.f) ? 0.f : u;
-    const float v0 = p.s0 ? s0v[rr] + c0 : 0.f;
-    const float t0 = (p.relu0 && v0 <= 0.f) ? 0.f : v0;
-    const float v1 = s1v[rr];
-    const float zz = wo0 * t0 + wo1 * v1 + wo2 * t2 + bo;
-    const float y = yv[rr];
-    const float pr = 1.f / (1.f + expf(-zz));
-    const float ce = fmaxf(zz, 0.f) - zz * y + log1pf(expf(-fabsf(zz)));
-    const float dz = (pr - y) * p.loss_scale;
-    const float g0 = (p.relu0 && v0 <= 0.f) ? 0.f : dz * wo0;   // d/d(s0 + c0)
-    const float g2 = (p.relu2 && u <= 0.f) ? 0.f : dz * wo2;    // d/du
-    if (lane == 0) {
+  for (int m = 1; m < 16; m <<= 1) dot += __shfl_xor(dot, m);      // over the row's 16 lanes (fixed tree)
+  RSX_STAMP(12, blockIdx.x == 0);
+  const float u = dot + bd;
+  const float t2 = (p.relu2 && u <= 0.f) ? 0.f : u;
+  const float v0 = p.s0 ? s0v + c0 : 0.f;
+  const float t0 = (p.relu0 && v0 <= 0.f) ? 0.f : v0;
+  const float zz = wo0 * t0 + wo1 * s1v + wo2 * t2 + bo;
+  const float pr = 1.f / (1.f + expf(-zz));
+  const float ce = fmaxf(zz, 0.f) - zz * y + log1pf(expf(-fabsf(zz)));
+  const float dz = (pr - y) * p.loss_scale;
+  const float g0 = (p.relu0 && v0 <= 0.f) ? 0.f : dz * wo0;   // d/d(s0 + c0)
+  const float g2 = (p.relu2 && u <= 0.f) ? 0.f : dz * wo2;    // d/du
+  if (li == 0) {
+    double* hr = hrow[w * 4 + g];
+    if (rok) {
       p.prob[row] = pr;
       if (p.gs0) p.gs0[row] = g0;
       if (p.gs1) p.gs1[row] = dz * wo1;
-      hp[0] += (double)ce;
-      hp[1] += (double)(dz * t0);
-      hp[2] += (double)(dz * v1);
-      hp[3] += (double)(dz * t2);
-      hp[4] += (double)dz;
-      hp[5] += (double)g0;
-      hp[6] += (double)g2;
-    }
+      hr[0] = (double)ce; hr[1] = (double)(dz * t0); hr[2] = (double)(dz * s1v); hr[3] = (double)(dz * t2);
+      hr[4] = (double)dz; hr[5] = (double)g0; hr[6] = (double)g2; hr[7] = 0.0;
+    } else {
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int c = lane + 64 * k;
-      if (c < p.N) {
-        const float dyv = g2 * wdv[k] * mk[k];    // d/d(BN output) after dropout backward
-        p.dy_last[(size_t)row * p.N + c] = dyv;
-        sdy[k] += (double)dyv;
-        sdx[k] += (double)dyv * (double)xh[k];
-        swd[k] += o[k] * g2;
+      for (int k = 0; k < 8; ++k) hr[k] = 0.0;
+    }
+  }
+  RSX_STAMP(13, blockIdx.x == 0);
+  // column partials of the wave's 4 rows: (r0 + r1) + (r2 + r3) by two cross-group steps, then one LDS slot per wave
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = li + 16 * k;
+    {
+      const bool ok = rok && c < p.N;
+      const float dyv = ok ? g2 * wdv[k] * mk[k] : 0.f;          // d/d(BN output) after dropout backward
+      if (ok) p.dy_last[(size_t)row * p.N + c] = dyv;
+      double sdy = (double)dyv, sdx = (double)dyv * (double)xh[k];
+      float swd = ok ? o[k] * g2 : 0.f;
+      sdy += __shfl_xor(sdy, 16); sdx += __shfl_xor(sdx, 16); swd += __shfl_xor(swd, 16);
+      sdy += __shfl_xor(sdy, 32); sdx += __shfl_xor(sdx, 32); swd += __shfl_xor(swd, 32);
+      if (g == 0 && c < p.N) {
+        red[w][0][c] = sdy;
+        red[w][1][c] = sdx;
+        redw[w][c] = swd;
       }
     }
   }
   RSX_STAMP(10, blockIdx.x == 0);
-#pragma unroll
-  for (int k = 0; k < CPL; ++k) {
-    const int c = lane + 64 * k;
-    red[w][0][c] = sdy[k];
-    red[w][1][c] = sdx[k];
-    redw[w][c] = swd[k];
-  }
-  if (lane == 0)
-    for (int k = 0; k < 8; ++k) hred[w][k] = hp[k];
   __syncthreads();
   for (int c = tid; c < p.N; c += 256) {
     p.bstat_last[((size_t)blockIdx.x * 2 + 0) * p.N + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
     p.bstat_last[((size_t)blockIdx.x * 2 + 1) * p.N + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
     p.dwd_part[(size_t)blockIdx.x * p.N + c] = redw[0][c] + redw[1][c] + redw[2][c] + redw[3][c];
   }
-  if (tid < 8) p.hpart[(size_t)blockIdx.x * 8 + tid] = hred[0][tid] + hred[1][tid] + hred[2][tid] + hred[3][tid];
+  if (tid < 8) {                                   // the 16 rows of the tile in ascending order
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += hrow[r][tid];
+    p.hpart[(size_t)blockIdx.x * 8 + tid] = s;
+  }
   RSX_STAMP(11, blockIdx.x == 0);
 }
 
@@ -476,6 +468,7 @@ struct BwdArgs {
   int sb, ksb;
   float* dwp;                // [tiles, sb, 256] partial tiles
   int din_rtw;               // row tiles per d(input) workgroup (1, or 4 for large batches)
+  int dxg;                   // small batches: column tiles per d(input) workgroup (4: grouped LDS-staged tiles; 0: one tile)
   int n_head;                // 1 when the head-partial reduce block is present
   int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
   SortArgs sort;
@@ -506,6 +499,158 @@ __device__ __forceinline__ float da_of(float a, float dy, const ColBwd& c, float
   return c.k1 * (Bf * dy - c.sdy - xh * c.sdx);
 }
 
+// d(input) tiles for small batches: one workgroup = one 16-row tile x FOUR 16-column tiles (wave w owns column tile
+// 4*grp + w with the full reduction over the N outputs).  The operands are staged through LDS with coalesced float4 loads
+// -- da = relu'(a) * BNbwd(dy) is formed ONCE per workgroup instead of once per column tile, W rows are read as rows --
+// and every load of the tile is issued before the column constants are waited for, so the tile costs one memory round
+// trip.  (The one-tile-per-workgroup form read its operands as 4-byte strided loads, 24 instructions touching up to 64
+// lines each, and 624 workgroups of the first layer each re-reduced the BN partials of all N columns: phase stamps
+// showed 2.0 us of constants + 2.8 us of k-loop per tile.)  LDS: 5*N + (16 + 64) * (NP + 4) floats, NP = N rounded to 16.
+__device__ __forceinline__ void bwd_dx_group_tile(const BwdArgs& p, const int bid, float* lds, const bool first,
+                                                  const bool nobn) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int NP = (p.N + 15) & ~15, LD = NP + 4, N4 = p.N >> 2;
+  float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
+  float* sA = lds + ((5 * p.N + 3) & ~3);          // [16][LD]  da tile
+  float* sW = sA + 16 * LD;                         // [64][LD]  W rows of the workgroup's 64 input features
+  const int ngrp = (p.ct_k + p.dxg - 1) / p.dxg;
+  const int grp = bid % ngrp, rt = bid / ngrp;
+  const float Bf = (float)p.B;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (1) tile loads first: a, dy rows (kept in registers until the constants are there) ...
+  float4 av[2], dv[2];                              // 16 * N/4 float4 over 256 threads: <= 2 each (N <= 128, host-checked)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u;
+    const int r = e / N4, c4 = e - r * N4;
+    const bool ok = e < 16 * N4;
+    const size_t row = (size_t)((ok && rt * TM + r < p.B) ? rt * TM + r : p.B - 1);
+    av[u] = reinterpret_cast<const float4*>(p.a + row * p.N)[ok ? c4 : 0];
+    dv[u] = reinterpret_cast<const float4*>(p.dy + row * p.N)[ok ? c4 : 0];
+  }
+  // ... the epilogue's operands (previous layer's activation / BN statistics of this lane's 4 output elements) ...
+  const int ocol = (grp * p.dxg + w) * 16 + i;
+  const int occ = ocol < p.K ? ocol : p.K - 1;
+  float xin[4] = {0.f, 0.f, 0.f, 0.f}, bnm = 0.f, bnr = 0.f;
+  if (!first) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = rt * TM + 4 * kq + r;
+      xin[r] = p.in[(size_t)(orow < p.B ? orow : p.B - 1) * p.K + occ];
+    }
+    bnm = p.bn_prev[occ];
+    bnr = p.bn_prev[p.K + occ];
+  }
+  // ... and the W rows into LDS (rows past K and the k-padding columns n >= N are zero): 4 loads per thread in flight
+  // before the first LDS store (a load -> store loop is one memory round trip per iteration: 7 of them measured 5 us)
+  {
+    const int LD4 = LD >> 2, tot = 64 * LD4;
+    auto wsrc = [&](int e) -> const float4* {
+      const int ec = e < tot ? e : tot - 1;
+      const int r = ec / LD4, c4 = ec - r * LD4;
+      const int kcol = grp * p.dxg * 16 + r;
+      return reinterpret_cast<const float4*>(p.W + (size_t)(kcol < p.K ? kcol : p.K - 1) * p.N) + (c4 < N4 ? c4 : 0);
+    };
+    auto wdst = [&](int e, const float4 v) {
+      if (e < tot) {
+        const int r = e / LD4, c4 = e - r * LD4;
+        const bool ok = grp * p.dxg * 16 + r < p.K && c4 < N4;
+        reinterpret_cast<float4*>(sW + r * LD)[c4] = ok ? v : z4;
+      }
+    };
+    for (int e0 = tid; e0 < tot; e0 += 256 * 4) {
+      const float4 t0 = *wsrc(e0), t1 = *wsrc(e0 + 256), t2 = *wsrc(e0 + 512), t3 = *wsrc(e0 + 768);
+      wdst(e0, t0);
+      wdst(e0 + 256, t1);
+      wdst(e0 + 512, t2);
+      wdst(e0 + 768, t3);
+    }
+  }
+  // (2) column constants of the N outputs
+  for (int c = tid; c < p.N; c += 256) {
+    const ColBwd cb = bwd_col(p, c);
+    Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
+  }
+  for (int e = tid; e < 16 * ((LD - p.N) >> 2) ; e += 256) {      // zero the k padding of the da tile
+    const int r = e / ((LD - p.N) >> 2), c4 = e - r * ((LD - p.N) >> 2);
+    reinterpret_cast<float4*>(sA + r * LD + p.N)[c4] = z4;
+  }
+  __syncthreads();
+  RSX_STAMP(first ? 17 : 25, bid == 0);
+  // (3) da tile -> LDS
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u;
+    if (e < 16 * N4) {
+      const int r = e / N4, c = 4 * (e - r * N4);
+      const float rokf = rt * TM + r < p.B ? 1.f : 0.f;
+      ColBwd c0, c1, c2, c3;
+      c0.mean = Lm[c]; c0.rstd = Lr[c]; c0.k1 = Lk[c]; c0.sdy = Ls[c]; c0.sdx = Lx[c];
+      c1.mean = Lm[c + 1]; c1.rstd = Lr[c + 1]; c1.k1 = Lk[c + 1]; c1.sdy = Ls[c + 1]; c1.sdx = Lx[c + 1];
+      c2.mean = Lm[c + 2]; c2.rstd = Lr[c + 2]; c2.k1 = Lk[c + 2]; c2.sdy = Ls[c + 2]; c2.sdx = Lx[c + 2];
+      c3.mean = Lm[c + 3]; c3.rstd = Lr[c + 3]; c3.k1 = Lk[c + 3]; c3.sdy = Ls[c + 3]; c3.sdx = Lx[c + 3];
+      float4 o;
+      o.x = da_of(av[u].x, dv[u].x, c0, Bf, nobn) * rokf;
+      o.y = da_of(av[u].y, dv[u].y, c1, Bf, nobn) * rokf;
+      o.z = da_of(av[u].z, dv[u].z, c2, Bf, nobn) * rokf;
+      o.w = da_of(av[u].w, dv[u].w, c3, Bf, nobn) * rokf;
+      *reinterpret_cast<float4*>(sA + r * LD + c) = o;
+    }
+  }
+  __syncthreads();
+  // (4) wave w: 16 x 16 tile, k-steps of 16 outputs; two accumulators cover the MFMA's dependent latency
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* ar = sA + i * LD + 4 * kq;
+  const float* br = sW + (w * 16 + i) * LD + 4 * kq;
+  const int nks = NP >> 4;
+  for (int ks = 0; ks < nks; ks += 2) {
+    const float4 a0 = *reinterpret_cast<const float4*>(ar + 16 * ks);
+    const float4 b0 = *reinterpret_cast<const float4*>(br + 16 * ks);
+    acc0 = mfma16(a0.x, b0.x, acc0);
+    acc0 = mfma16(a0.y, b0.y, acc0);
+    acc0 = mfma16(a0.z, b0.z, acc0);
+    acc0 = mfma16(a0.w, b0.w, acc0);
+    if (ks + 1 < nks) {
+      const float4 a1 = *reinterpret_cast<const float4*>(ar + 16 * (ks + 1));
+      const float4 b1 = *reinterpret_cast<const float4*>(br + 16 * (ks + 1));
+      acc1 = mfma16(a1.x, b1.x, acc1);
+      acc1 = mfma16(a1.y, b1.y, acc1);
+      acc1 = mfma16(a1.z, b1.z, acc1);
+      acc1 = mfma16(a1.w, b1.w, acc1);
+    }
+  }
+  RSX_STAMP(first ? 18 : 26, bid == 0);
+  // (5) epilogue: lane (i, kq) holds rows 4 kq + r, column ocol.  Dropout backward of the previous layer and the
+  // partial sums of ITS batch-norm backward over this tile's 16 rows (4 in-lane, then the 4 lane quarters in order)
+  const bool wok = w < p.dxg && ocol < p.K;
+  double s1 = 0.0, s2 = 0.0;
+  const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int orow = rt * TM + 4 * kq + r;
+    float o = acc0[r] + acc1[r];
+    if (orow < p.B && wok) {
+      if (!first) {
+        o *= drop_mul(dr, p.mask_prev, (size_t)orow * p.K + ocol);
+        const float xh = (xin[r] - bnm) * bnr;
+        s1 += (double)o;
+        s2 += (double)o * (double)xh;
+      }
+      p.dy_prev[(size_t)orow * p.K + ocol] = o;
+    }
+  }
+  if (!first) {
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kq == 0 && wok) {
+      p.bstat_prev[((size_t)rt * 2 + 0) * p.K + ocol] = s1;
+      p.bstat_prev[((size_t)rt * 2 + 1) * p.K + ocol] = s2;
+    }
+  }
+  RSX_STAMP(first ? 19 : 27, bid == 0);
+}
+
 // SPLIT: the dW tiles' batch reduction is cut into p.sb row blocks (large batches); false keeps the single-block code
 // path free of the block arithmetic
 template <bool SPLIT>
@@ -524,6 +669,11 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   const bool nobn = p.gamma == nullptr;          // this layer has no batch-norm (uniform)
   const int i = lane & 15, kq = lane >> 4;
   const int sb0 = first ? 16 : 24;
+  if (!SPLIT && p.dxg > 0 && bid < p.n_din) {
+    RSX_STAMP(sb0 + 0, bid == 0);
+    bwd_dx_group_tile(p, bid, lds, first, nobn);
+    return;
+  }
   if (bid < p.n_din) {
     // ---- d(input) tile: rows rt*16.., input columns kc*16.. ; reduction over the N outputs ----------
     RSX_STAMP(sb0 + 0, bid == 0);
@@ -618,7 +768,18 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     const int feat = kf * 16 + i;          // A-operand row (input feature)
     const int ncol = nt * 16 + i;          // B-operand column
     const bool fok = feat < p.K, ones = feat == p.K, nok = ncol < p.N;
-    const ColBwd cb = bwd_col(p, nok ? ncol : 0);     // unconditional (clamped column): no branch around its loads
+    // column constants of the tile's 16 columns: reduced from the row-tile partials by 16 threads and shared through LDS
+    // (all 256 threads used to repeat the 32-load reduction; with 280 such workgroups starting together that prologue
+    // measured 5 us under the L2 queueing it caused itself)
+    float* Lc = reinterpret_cast<float*>(cred);        // [5][16] (cred is not used by this tile family)
+    if (tid < 16) {
+      const int c = nt * 16 + tid;
+      const ColBwd t = bwd_col(p, c < p.N ? c : 0);
+      Lc[tid] = t.mean; Lc[16 + tid] = t.rstd; Lc[32 + tid] = t.k1; Lc[48 + tid] = t.sdy; Lc[64 + tid] = t.sdx;
+    }
+    __syncthreads();
+    ColBwd cb;
+    cb.mean = Lc[i]; cb.rstd = Lc[16 + i]; cb.k1 = Lc[32 + i]; cb.sdy = Lc[48 + i]; cb.sdx = Lc[64 + i];
     float fsc = 1.f, fsh = 0.f;
     if (!first && fok && p.gamma_prev != nullptr) {   // (previous layer without batch-norm: identity)
       const float inv = p.bn_prev[p.K + feat] * p.gamma_prev[feat];
@@ -872,7 +1033,10 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   p.n_own = (B + TM - 1) / TM;
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
-  hipLaunchKernelGGL(tower_head_k, dim3(p.n_own + p.sweep.n_blk), dim3(256), 0, rsx_s(stream), p);
+  const dim3 grid(p.n_own + p.sweep.n_blk);
+  if (N <= 64) hipLaunchKernelGGL(tower_head_k<4>, grid, dim3(256), 0, rsx_s(stream), p);
+  else if (N <= 128) hipLaunchKernelGGL(tower_head_k<8>, grid, dim3(256), 0, rsx_s(stream), p);
+  else hipLaunchKernelGGL(tower_head_k<16>, grid, dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -994,13 +1158,24 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.sb = rsx_tower_dw_blocks(B, dw_partials != nullptr);
   static const int rtw_env = getenv("RSX_TOWER_RTW") ? atoi(getenv("RSX_TOWER_RTW")) : 4;
   p.din_rtw = p.sb > 1 ? rtw_env : 1;
-  p.n_din = p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
+  static const int dxg_env = getenv("RSX_TOWER_DXG") ? atoi(getenv("RSX_TOWER_DXG")) : 4;
+  p.dxg = (p.sb > 1 || (N & 3) != 0 || N > 128) ? 0 : (dxg_env > 0 ? 4 : 0);      // grouped LDS-staged d(input) tiles
+  p.n_din = p.dxg > 0 ? ((p.ct_k + p.dxg - 1) / p.dxg) * p.RTh : p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
   p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
   p.dwp = dw_partials;
   p.n_dw = p.ct_k1 * p.ct_n * p.sb;
   p.n_head = hpart != nullptr ? 1 : 0;
   p.n_sort = 0;
   size_t lds = ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float);
+  if (p.dxg > 0) {
+    const size_t l2 = ((size_t)5 * N + 4 + (size_t)(16 + 64) * ((size_t)((N + 15) & ~15) + 4)) * sizeof(float);
+    if (l2 > lds) lds = l2;
+    if (lds > 64 * 1024) {       // very wide layers: the one-tile form
+      p.dxg = 0;
+      p.n_din = p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
+      lds = ((size_t)5 * N + 4 + 1024 + 256) * sizeof(float);
+    }
+  }
   if (sort_h != nullptr) {
     const int rc = sort_job_args(*sort_h, p.sort, &lds);
     if (rc != RSX_OK) return rc;

@@ -193,16 +193,38 @@ class DataParallel:
         return out
 
     def gather_send_block(self, b, fold_dense=False):
-        """All-gathers [dense | block(b)] in place (no pack copy) and returns (views of RANK 0's parts inside the gathered
-        buffer, blocks descriptor) for EmbeddingArena.segsum*(..., blocks=).  The dense arenas of the ranks are summed in rank
-        order: into the local arena by one launch here, or -- fold_dense -- inside the optimizer launch itself: a third return
-        value (else None) then replaces DenseArena.adam_segments() (RSX_ADAM_DENSE with B = world replicas `stride` floats apart)."""
+        """Exchanges [dense | block(b)] straight from the send block (no pack copy) and returns (views of RANK 0's parts
+        inside the gathered buffer, blocks descriptor) for EmbeddingArena.segsum*(..., blocks=).
+        Small dense arenas (< RSX_DP_ALLREDUCE_MIN_BYTES, default 256 KiB: DeepFM / DCN / FM, ~0.3 MB): the arena rides in
+        front of the per-example block in ONE all-gather and the ranks' arenas are summed in rank order -- into the local
+        arena by one launch here, or (fold_dense) inside the optimizer launch itself: a third return value (else None) then
+        replaces DenseArena.adam_segments() (RSX_ADAM_DENSE with B = world replicas `stride` floats apart).  The step is
+        latency-bound there, one collective beats two.
+        Large arenas (xDeepFM's CIN filters: 3.3 MB): an all-gather would deliver N x the bytes of an all-reduce (26 MB per
+        rank per step at N = 8), so the arena takes a true all-reduce(sum), issued ASYNCHRONOUSLY on RCCL's stream before the
+        example block's all-gather and awaited after it -- the two collectives overlap each other (and whatever the caller
+        launches before the optimizer)."""
         from . import _lib
         n0, n = self._send_n0, self._send_dense.n
         L = b * sum(self._send_widths)
+        d = self._send_dense
+        big = n * 4 >= int(os.environ.get("RSX_DP_ALLREDUCE_MIN_BYTES", str(256 * 1024)))
+        if big:
+            Lp = (L + 3) & ~3
+            x = self._send[n0:n0 + Lp].view(1, Lp)
+            out = torch.empty((self.world, Lp), dtype=x.dtype, device=x.device)
+            grad = self._send[:n]
+
+            graph_break(lambda: self._overlapped_allreduce_allgather(grad, out, x))
+            views, o = [], 0
+            for w in self._send_widths:
+                v = out[0, o:o + b * w]
+                views.append(v if w == 1 else v.view(b, w))
+                o += b * w
+            self._keep = out
+            return views, (b, Lp), None
         ln = (n0 + L + 3) & ~3                                   # rank blocks stay 16-byte aligned
         out = self.all_gather_rows(self._send[:ln].view(1, ln))  # [N, ln]
-        d = self._send_dense
         seg = None
         if fold_dense:
             seg = [dict(kind=_lib.RSX_ADAM_DENSE, n=d.n, var=d.flat, m=d.m, v=d.v, g=out[0, :n], B=self.world, stride=ln,
@@ -294,6 +316,11 @@ class DataParallel:
             return dX_g, S_g, gy1_g, gy2_g, gi[:, o:o + ids.shape[1]].contiguous()
         return dX_g, S_g, gy1_g, gy2_g
 
+    def _overlapped_allreduce_allgather(self, grad, out, x):
+        work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        work.wait()                     # stream-level wait: the host does not block
+
     # -- dense gradients ------------------------------------------------------------------------
     def all_reduce_sum(self, flat):
         graph_break(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
@@ -320,6 +347,10 @@ class EmulatedDataParallel(DataParallel):
 
     def all_reduce_sum(self, flat):
         return flat.mul_(self.world)
+
+    def _overlapped_allreduce_allgather(self, grad, out, x):
+        grad.mul_(self.world)
+        out.copy_(x.expand_as(out))
 
     def barrier(self):
         pass

@@ -105,6 +105,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     dp, P = store.dp, store.dense
     B = ids.shape[0]
     sweeps, hot, L = None, None, len(store.cin_sizes)
+    tower_sweeps, last_sweep = None, None
     zc = dp is not None and getattr(store, "dp_block", False)
     with torch.no_grad():
         # data-parallel: the optimizer sees the GLOBAL batch -- the dedup sort runs over the all-gathered ids (issued first:
@@ -119,10 +120,26 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 # and the dense variables follow the scatter in one small launch
                 c1, h1 = a1.adam_split_segments()
                 c2, h2 = a2.adam_split_segments()
+                # carriers, in launch order: [CIN fwd_0..fwd_{L-1} | tower fwd_0, fwd_1, head, bwd_1, bwd_0 | CIN dW_{L-1}..dW_0 |
+                # scatter].  Default shares: the fp32 CIN launches are long MFMA kernels and take the sweep by their flops;
+                # the bf16 CIN launches are a few microseconds each, so there the latency-bound tower / scatter launches
+                # carry most of it (weights measured on MI355X; RSX_XDFM_SWEEP_WEIGHTS overrides).
                 w = [float(store.cin_sizes[k]) * (a1.F if k == 0 else store.cin_sizes[k - 1]) for k in range(len(store.cin_sizes))]
-                share = 0.5                      # part of the sweep carried by the forward launches (measured best)
                 tw = sum(w)
-                sweeps = store.opt.cold_slices(c1 + c2, [share * x / tw for x in w] + [(1.0 - share) * x / tw for x in w])
+                nl = len(store.tower.widths)
+                env = os.environ.get("RSX_XDFM_SWEEP_WEIGHTS")
+                if env:
+                    wts = [float(x) for x in env.split(",")]
+                elif store.cin.bf16:
+                    wts = [x / tw for x in w] + [0.0] * nl + [1.0] + [1.5] * nl + [1.5 * x / tw for x in w][::-1] + [1.0]
+                else:
+                    wts = [0.5 * x / tw for x in w] + [0.0] * (2 * nl + 1) + [0.5 * x / tw for x in w][::-1] + [0.0]
+                assert len(wts) == 2 * L + 2 * nl + 2, "RSX_XDFM_SWEEP_WEIGHTS: %d weights expected" % (2 * L + 2 * nl + 2)
+                # (first-order vector first: the LAST slice, carried by the scatter launch, may hold table blocks only)
+                sl_all = store.opt.cold_slices(c1[::-1] + c2, wts)
+                sweeps = sl_all[:L] + sl_all[L + 2 * nl + 1:2 * L + 2 * nl + 1][::-1]          # CIN fwd_k ..., then dW_k in layer order
+                tower_sweeps = sl_all[L:L + 2 * nl + 1]
+                last_sweep = sl_all[-1]
                 hot = h1 + h2
         dX1v, dX2v, glv = dp.send_views(B) if zc else (None,) * 3          # per-example gradient block, written in place
         # both input_layer calls (:125,185) + the pre-activation of linear_net (one-hot weights + 13 numeric log-values, :127)
@@ -138,7 +155,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),       # replicas draw independent dropout patterns
-            outs=(dX2v, glv, None) if zc else None)
+            sweeps=tower_sweeps, outs=(dX2v, glv, None) if zc else None)
         dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:],
                                  dX0_out=dX1v.view(B, a1.F, a1.D) if zc else None).view(B, -1)   # cin.* grads land in the dense arena
         torch.mv(logx.t(), g_lin, out=P["lin.wnum"].grad)
@@ -151,7 +168,8 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 (dX1g, dX2g, glg), blocks, dense_segs = dp.gather_send_block(B, fold_dense=hot is not None)
                 Bg = B * dp.world
                 if hot is not None:
-                    a1.segsum_adam(Bg, None, dX1g, glg, None, store.opt, dense_segs, None, blocks=blocks, second=(a2, dX2g))
+                    a1.segsum_adam(Bg, None, dX1g, glg, None, store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
+                                   blocks=blocks, second=(a2, dX2g))
                 else:
                     a1.segsum(Bg, None, dX1g, glg, None, blocks=blocks)
                     a2.segsum(Bg, None, dX2g, None, None, blocks=blocks)
@@ -169,7 +187,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             elif hot is not None:
                 # scatter + touched-row Adam of BOTH table sets (one shared sort) in one launch, which also carries the
                 # dense variables and advances the beta powers
-                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, store.dense.adam_segments(), None, second=(a2, dX2))
+                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, store.dense.adam_segments(), last_sweep, second=(a2, dX2))
             else:
                 a1.segsum(B, None, dX1, g_lin, None)
                 a2.segsum(B, None, dX2, None, None)

@@ -20,7 +20,8 @@ from recsys_amd.feature_columns import CriteoLayout, build_feature_columns  # no
 
 NAMES = {0: "fwd1: entry", 1: "fwd1: BN stats of the previous layer reduced", 2: "fwd1: k-loop done", 3: "fwd1: end",
          4: "fwd0: entry", 5: "fwd0: (no prologue)", 6: "fwd0: k-loop done", 7: "fwd0: end",
-         8: "head: entry", 9: "head: BN stats reduced", 10: "head: rows done (loads + dot + loss + dy stores)", 11: "head: end",
+         8: "head: entry", 9: "head: BN stats reduced", 12: "head: activations + dot product reduced (incl. the wait for the row loads)",
+         13: "head: loss + dz", 10: "head: dy stored, column partials reduced", 11: "head: end",
          16: "bwd0 dX tile: entry", 17: "bwd0 dX: column constants", 18: "bwd0 dX: k-loop done", 19: "bwd0 dX: end",
          20: "bwd0 dW tile: entry", 21: "bwd0 dW: column constants", 22: "bwd0 dW: k-loop done", 23: "bwd0 dW: end",
          24: "bwd1 dX tile: entry", 25: "bwd1 dX: column constants", 26: "bwd1 dX: k-loop done", 27: "bwd1 dX: end",
@@ -54,8 +55,8 @@ def main():
         t = acc / reps * 0.01                              # us
         print("---- overlap_adam=%s: us since fwd0's entry; delta to the previous stamp of the same kernel" % overlap)
         prev = None
-        for k in sorted(NAMES):
-            d = "" if prev is None or (k % 4 == 0) else "  (+%.2f)" % (t[k] - t[prev])
+        for k in NAMES:
+            d = "" if prev is None or (k % 4 == 0 and k != 12) else "  (+%.2f)" % (t[k] - t[prev])
             print("%-58s %8.2f%s" % (NAMES[k], t[k], d))
             prev = k
 

@@ -167,6 +167,26 @@ def _send_block_worker(rank, world, port, out_dir):
         _, _, seg2 = dp.gather_send_block(b, fold_dense=False)
         assert seg2 is None
         assert torch.equal(dense.grad, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+    # large arenas (xDeepFM's CIN filters): a true all-reduce of the arena, overlapped with the all-gather of the example
+    # block alone -- forced here by dropping the threshold
+    os.environ["RSX_DP_ALLREDUCE_MIN_BYTES"] = "64"
+    b = 6
+    dense.grad.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    dX, S, gy2, gy1 = dp.send_views(b)
+    dX.copy_(1000.0 * (rank + 1) + torch.arange(b * 12, dtype=torch.float32).view(b, 12))
+    S.fill_(rank + 0.5)
+    gy2.fill_(rank + 0.25)
+    gy1.fill_(rank + 0.125)
+    views, (bb, stride), seg = dp.gather_send_block(b, fold_dense=True)
+    out = dp._keep
+    assert seg is None and bb == b and stride % 4 == 0 and stride >= b * 18 and out.shape == (world, stride)
+    assert torch.equal(dense.grad, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)))   # summed in place
+    for r in range(world):
+        assert torch.equal(out[r, :b * 12].view(b, 12), 1000.0 * (r + 1) + torch.arange(b * 12, dtype=torch.float32).view(b, 12))
+        assert torch.equal(out[r, b * 12:b * 16], torch.full((b * 4,), r + 0.5))
+        assert torch.equal(out[r, b * 17:b * 18], torch.full((b,), r + 0.125))
+    assert views[0].data_ptr() == out.data_ptr() and views[0].shape == (b, 12)
+    del os.environ["RSX_DP_ALLREDUCE_MIN_BYTES"]
     # the prefetchable ids all-gather: synchronous when nobody issued it, otherwise it waits for the asynchronous launch
     x = torch.full((3, 2), rank, dtype=torch.int32)
     outp = torch.empty(world * 3, 2, dtype=torch.int32)
