@@ -111,6 +111,11 @@ typedef struct {
   const int32_t* segid;
   float* P;
   float* P1;                  /* nullable when gy1 is NULL */
+  float* G;                   /* nullable [F*stride, D] (+ gw1 [F*stride], nullable): rsx_segsum_partials then also FINISHES
+                                 every segment that lies inside one 16-position chunk of the sorted order and writes its sum
+                                 here; the stage-B entry points pick those rows up (rsx_segsum_bwd with the same G: nothing
+                                 left to do for them).  NULL: stage A only produces the long segments' chunk partials.   */
+  float* gw1;
 } rsx_seg_partials;
 /* Layout of the per-example inputs (dX, S, gy1, gy2) when they are read in place from an all-gathered buffer (data
  * parallel): example e lives in rank block e / examples at local index e % examples; blocks are stride_floats apart
@@ -452,6 +457,24 @@ int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const void* w16, co
                            const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
                            float* dW, float* dc, void* ws, int B, int F, int H, int N, int D,
                            const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* The same backward in two parts, so that a net of several layers launches the data gradients layer by layer (each needs
+ * the previous one's output) and then ALL weight gradients together (they only depend on their own layer's dX launch:
+ * one launch instead of L latency-bound ones).  ws: one rsx_cin_bf16_bwd_workspace_bytes(B, N) buffer PER LAYER, written
+ * by the dx call and read by the dw call.  rsx_cin_prep_bf16_multi: the filters of all layers in one launch (<= 4).   */
+typedef struct {
+  const float* Xk;   /* [B, H, 16] input map of the layer */
+  const void* ws;    /* the layer's workspace, filled by rsx_cin_layer_bwd_dx_bf16 */
+  float* dW;         /* [F*H, N] */
+  float* dc;         /* [N] */
+  int32_t H, N;
+} rsx_cin_dw_job;
+int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                              const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
+                              void* ws, int B, int F, int H, int N, int D, rsx_stream_t stream);
+int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
+                        const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
+                            int F, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Streaming reader: the whole `input_fn` front end -- tf.data.TFRecordDataset(filenames)

@@ -9,8 +9,17 @@ The algorithm lives in a third-party dependency that is absent from
 /root/reference: TensorFlow 1.13/1.14 (unpinned by the reference) which
 vendors google/farmhash (`farmhashna::Hash64`).  This file restates the
 published FarmHash algorithm.  Pinned by the KATs 'a','b','c','d' from upstream
-TF's string_to_hash_bucket_op_test and the empty
-string (= k2); longer-length branches have no KAT in the reference.
+TF's string_to_hash_bucket_op_test, the empty string
+(= k2), and the usage example of upstream TF's documentation,
+``to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2]``, whose
+strings take the 4-7-byte and the 8-16-byte branches (bucket values only; every
+8-hex-character Criteo value takes the 8-16-byte branch).  The google/farmhash
+self-test table (farmhashna 64-bit outputs over its generated data buffer)
+could NOT be reproduced offline -- neither the table nor its generator is on
+this image and there is no network -- so the 17-32, 33-64 and > 64-byte branches
+are pinned only by two independently written implementations (this file and
+recsys_amd/csrc/host_ingest.cpp) agreeing on thousands of random strings
+(tests/test_cabi_cpu.py).  No Criteo feature value reaches those branches.
 
 Test infrastructure only (see oracle/__init__.py).
 """

@@ -34,11 +34,15 @@ class ExampleBlocks(C.Structure):
 
 
 class SegPartials(C.Structure):
-    _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p)]
+    _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p), ("G", C.c_void_p), ("gw1", C.c_void_p)]
 
 
 class TableSet(C.Structure):
     _fields_ = [("tables", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("dX", C.c_void_p), ("partials", C.c_void_p)]
+
+
+class CinDwJob(C.Structure):
+    _fields_ = [("Xk", C.c_void_p), ("ws", C.c_void_p), ("dW", C.c_void_p), ("dc", C.c_void_p), ("H", C.c_int32), ("N", C.c_int32)]
 
 
 class SortJob(C.Structure):
@@ -88,6 +92,9 @@ _SIGS = {
     "rsx_cin_prep_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "rsx_cin_layer_fwd_bf16": (_I, [_P] * 5 + [_I] * 5 + [_P, _P]),
     "rsx_cin_layer_bwd_bf16": (_I, [_P] * 8 + [_I, _P, _I, _P, _P, _P] + [_I] * 5 + [_P, _P]),
+    "rsx_cin_layer_bwd_dx_bf16": (_I, [_P] * 8 + [_I, _P, _I, _P] + [_I] * 5 + [_P]),
+    "rsx_cin_bwd_dw_bf16": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _P, _P]),
+    "rsx_cin_prep_bf16_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rsx_hash_fp64_h": (_I, [_P, _P, C.c_int64, _P]),

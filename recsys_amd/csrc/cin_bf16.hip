@@ -373,54 +373,72 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dW, dc
-struct CbDwArgs {
-  const float* X0;        // [B, F, 16]
+constexpr int CB_MAXJ = 4;
+struct CbDwJob {
   const float* Xk;        // [B, H, 16]
   const bf16_t* dpre16;   // fragments, see CbDxArgs
   const float* dc_part;   // [ceil(B/2), N16]
   float* dW;              // [F*H, N]
   float* dc;              // [N]
-  int B, F, H, N, N16;
-  int FGn;                // field groups = z planes of the tile grid
+  int H, N, N16;
+  int gx, HT;             // tile grid of the job: gx n-groups x HT h tiles x FGn field groups
+  int tile_end;           // exclusive prefix sum of the jobs' tile counts
+};
+struct CbDwArgs {
+  CbDwJob job[CB_MAXJ];   // the weight gradients of SEVERAL layers in one launch (they only depend on their layer's dX
+  int njobs;              // launch, not on each other: two latency-bound tile sets overlap instead of queueing)
+  const float* X0;        // [B, F, 16]
+  int B, F;
+  int FGn;                // field groups
   AdamSlice sweep;
 };
 
-// grid = (N16/(16 NT), H16/16, FGn + extra planes), block = 512 = 8 waves that split the k-steps (pairs of examples).
-// Plane FGn: block 0 adds the dc partials in order; the other blocks of that plane and of the following planes carry the
-// optimizer sweep slice (two 256-thread sweep blocks per workgroup).  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is
-// formed in fp32 and rounded once.  Partial tiles: waves 4..7 -> LDS, waves 0..3 add; waves 1..3 -> LDS, wave 0 adds.
+// grid = (sum of the jobs' tiles + njobs + sweep blocks / 2), block = 512 = 8 waves that split the k-steps (pairs of
+// examples).  After the tiles: one block per job adds its dc partials in order; the rest carry the optimizer sweep slice
+// (two 256-thread sweep blocks per workgroup).  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is formed in fp32 and rounded
+// once.  Partial tiles: waves 4..7 -> LDS, waves 0..3 add; waves 1..3 -> LDS, wave 0 adds.
 template <int FT, int NT>
 __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   __shared__ float red[4][FT * NT][256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if ((int)blockIdx.z >= p.FGn) {
-    const uint32_t lin = (((uint32_t)blockIdx.z - (uint32_t)p.FGn) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (lin == 0) {                               // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
+  const int total = p.job[p.njobs - 1].tile_end;
+  if ((int)blockIdx.x >= total) {
+    const int lin = (int)blockIdx.x - total;
+    if (lin < p.njobs) {                          // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
+      const CbDwJob& jb = p.job[lin];
       const int G = (p.B + 1) / 2;
-      for (int n = tid; n < p.N; n += 512) {
+      for (int n = tid; n < jb.N; n += 512) {
         float s = 0.f;
         int g = 0;
         for (; g + 8 <= G; g += 8) {
           float t[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = p.dc_part[(size_t)(g + u) * p.N16 + n];
+          for (int u = 0; u < 8; ++u) t[u] = jb.dc_part[(size_t)(g + u) * jb.N16 + n];
 #pragma unroll
           for (int u = 0; u < 8; ++u) s += t[u];
         }
-        for (; g < G; ++g) s += p.dc_part[(size_t)g * p.N16 + n];
-        p.dc[n] = s;
+        for (; g < G; ++g) s += jb.dc_part[(size_t)g * jb.N16 + n];
+        jb.dc[n] = s;
       }
     } else {
-      const uint32_t blk = 2 * (lin - 1) + (uint32_t)(tid >> 8);
+      const uint32_t blk = 2 * (uint32_t)(lin - p.njobs) + (uint32_t)(tid >> 8);
       if (blk < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + blk, tid & 255);
     }
     return;
   }
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < CB_MAXJ; ++k)
+    if (k < p.njobs && (int)blockIdx.x >= p.job[k - 1].tile_end) ji = k;
+  const CbDwJob& jb = p.job[ji];
+  const int local = (int)blockIdx.x - (ji ? p.job[ji - 1].tile_end : 0);
+  const int bx = local % jb.gx, by = (local / jb.gx) % jb.HT, bz = local / (jb.gx * jb.HT);
   const int i = lane & 15, kq = lane >> 4;
-  const int ntg = blockIdx.x * NT, ht = blockIdx.y, f0 = blockIdx.z * FT;
-  const int NT16 = p.N16 >> 4;
+  const int ntg = bx * NT, ht = by, f0 = bz * FT;
+  const int NT16 = jb.N16 >> 4;
+  const int H = jb.H;
   const int h = 16 * ht + i;
-  const int hc = h < p.H ? h : p.H - 1;
+  const int hc = h < H ? h : H - 1;
   const int d0 = (kq & 1) * 8, eb = kq >> 1;      // k = 8 kq + j  <->  example 2 ks + (kq >> 1), dims d0 .. d0 + 7
   const int nks = (p.B + 1) / 2;
   f32x4 acc[FT][NT];
@@ -438,8 +456,8 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
     const int b = 2 * ks + eb;
     const int bc = b < p.B ? b : p.B - 1;
     const int ksc = ks < nks ? ks : nks - 1;
-    L.m = (b < p.B && ks < nks && h < p.H) ? 1.f : 0.f;
-    const float4* xk = reinterpret_cast<const float4*>(p.Xk + ((size_t)bc * p.H + hc) * CB_D + d0);
+    L.m = (b < p.B && ks < nks && h < H) ? 1.f : 0.f;
+    const float4* xk = reinterpret_cast<const float4*>(jb.Xk + ((size_t)bc * H + hc) * CB_D + d0);
     L.xk[0] = xk[0];
     L.xk[1] = xk[1];
 #pragma unroll
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {             // n tiles past N16 re-read the last tile (never stored)
       const int t = ntg + nt < NT16 ? ntg + nt : NT16 - 1;
-      L.dp[nt] = ld_bf16x8(p.dpre16 + (((size_t)ksc * NT16 + t) * 64 + lane) * 8);
+      L.dp[nt] = ld_bf16x8(jb.dpre16 + (((size_t)ksc * NT16 + t) * 64 + lane) * 8);
     }
   };
   auto run = [&](const Ld& L) {
@@ -512,10 +530,39 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
           const int hh = 16 * ht + 4 * kq + r;
           const float s = ((acc[ft][nt][r] + red[1][ft * NT + nt][r * 64 + lane]) + red[2][ft * NT + nt][r * 64 + lane]) +
                           red[3][ft * NT + nt][r * 64 + lane];
-          if (f < p.F && hh < p.H && n < p.N) p.dW[((size_t)f * p.H + hh) * p.N + n] = s;
+          if (f < p.F && hh < H && n < jb.N) jb.dW[((size_t)f * H + hh) * jb.N + n] = s;
         }
       }
     }
+  }
+}
+
+// several layers' filters in one launch
+struct CbPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; int H, N, H16, N16, Hp, Np; long long end; };
+struct CbPrepArgs { CbPrepJob job[CB_MAXJ]; int njobs, F; };
+__global__ __launch_bounds__(256) void cin_prep_multi_k(const CbPrepArgs p) {
+  const long long total = p.job[p.njobs - 1].end;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < CB_MAXJ; ++k)
+      if (k < p.njobs && e >= p.job[k - 1].end) ji = k;
+    const CbPrepJob& jb = p.job[ji];
+    const long long le = e - (ji ? p.job[ji - 1].end : 0);
+    const long long n1 = (long long)p.F * jb.H16 * jb.Np;
+    const bool first = le < n1;
+    const long long q = first ? le : le - n1;
+    const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
+    long long r = q >> 9;
+    const int KS = first ? jb.Np >> 5 : jb.Hp >> 5;
+    const int ks = (int)(r % KS);
+    r /= KS;
+    const int T = first ? jb.H16 >> 4 : jb.N16 >> 4;
+    const int t = (int)(r % T), f = (int)(r / T);
+    const int h = first ? 16 * t + (lane & 15) : 32 * ks + 8 * (lane >> 4) + j;
+    const int n = first ? 32 * ks + 8 * (lane >> 4) + j : 16 * t + (lane & 15);
+    const bf16_t v = (bf16_t)((h < jb.H && n < jb.N) ? jb.W[((size_t)f * jb.H + h) * jb.N + n] : 0.f);
+    if (first) jb.W16[q] = v; else jb.Wt16[q] = v;
   }
 }
 
@@ -570,13 +617,12 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
   return RSX_OK;
 }
 
-extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
-                                      const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
-                                      float* dW, float* dc, void* ws, int B, int F, int H, int N, int D,
-                                      const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+static int cb_launch_dx(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                        const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0, void* ws,
+                        int B, int F, int H, int N, int D, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  if (!X0 || !Xk || !w16 || !out || !dXk || !dX0 || !dW || !dc || !ws) return RSX_EINVAL;
+  if (!X0 || !Xk || !w16 || !out || !dXk || !dX0 || !ws) return RSX_EINVAL;
   if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
   if (dXk == dX0 && !(Xk == X0 && acc_dx0)) return RSX_EINVAL;   // one buffer only for the first layer, accumulating
   if (D != CB_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
@@ -605,15 +651,84 @@ extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const vo
     default: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<4>, grid, block, lds, rsx_s(stream), a); break;
   }
   RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+static int cb_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
+                        const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0) return RSX_EINVAL;
+  if (njobs > CB_MAXJ || D != CB_D) return RSX_EUNSUPPORTED;
+  if (B == 0) return RSX_OK;
   constexpr int FT = 3, NT = 2;
-  CbDwArgs w{X0, Xk, dpre16, dc_part, dW, dc, B, F, H, N, N16, (F + FT - 1) / FT, {}};
+  CbDwArgs w{};
+  w.njobs = njobs; w.X0 = X0; w.B = B; w.F = F; w.FGn = (F + FT - 1) / FT;
+  int tiles = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const rsx_cin_dw_job& j = jobs_h[k];
+    if (!j.Xk || !j.ws || !j.dW || !j.dc || j.H <= 0 || j.N <= 0) return RSX_EINVAL;
+    if (j.H > 128 || j.N > 128) return RSX_EUNSUPPORTED;
+    const int H16 = rup(j.H, 16), N16 = rup(j.N, 16);
+    CbDwJob& d = w.job[k];
+    d.Xk = j.Xk;
+    d.dpre16 = static_cast<const bf16_t*>(j.ws);
+    d.dc_part = reinterpret_cast<const float*>(static_cast<const char*>(j.ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
+    d.dW = j.dW; d.dc = j.dc; d.H = j.H; d.N = j.N; d.N16 = N16;
+    d.gx = (N16 + 16 * NT - 1) / (16 * NT);
+    d.HT = H16 / 16;
+    tiles += d.gx * d.HT * w.FGn;
+    d.tile_end = tiles;
+  }
   const int rcs = adam_build_slice(sweep_h, w.sweep);
   if (rcs != RSX_OK) return rcs;
-  const unsigned gx = (unsigned)((N16 + 16 * NT - 1) / (16 * NT));
-  const unsigned plane = gx * (unsigned)HT;
-  const unsigned zs = (1u + (w.sweep.n_blk + 1) / 2 + plane - 1) / plane;    // extra z-planes: the dc block + the sweep slice
-  const dim3 gridw(gx, (unsigned)HT, (unsigned)w.FGn + zs);
-  hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT>), gridw, dim3(512), 0, rsx_s(stream), w);
+  const unsigned grid = (unsigned)tiles + (unsigned)njobs + (w.sweep.n_blk + 1) / 2;
+  hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT>), dim3(grid), dim3(512), 0, rsx_s(stream), w);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16, const float* out,
+                                         const float* dout, const float* gs, const float* wout, float* dXk, int acc_dxk,
+                                         float* dX0, int acc_dx0, void* ws, int B, int F, int H, int N, int D,
+                                         rsx_stream_t stream) {
+  return cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, stream);
+}
+
+extern "C" int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
+                                   const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  return cb_launch_dw(X0, jobs_h, njobs, B, F, D, sweep_h, stream);
+}
+
+extern "C" int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h,
+                                       int L, int F, rsx_stream_t stream) {
+  if (!W_h || !w16_h || !H_h || !N_h || L <= 0 || F <= 0) return RSX_EINVAL;
+  if (L > CB_MAXJ) return RSX_EUNSUPPORTED;
+  CbPrepArgs a{};
+  a.njobs = L; a.F = F;
+  long long tot = 0;
+  for (int k = 0; k < L; ++k) {
+    const int H = H_h[k], N = N_h[k];
+    if (!W_h[k] || !w16_h[k] || H <= 0 || N <= 0) return RSX_EINVAL;
+    if (H > 128 || N > 128) return RSX_EUNSUPPORTED;
+    CbPrepJob& j = a.job[k];
+    j.W = W_h[k]; j.H = H; j.N = N; j.H16 = rup(H, 16); j.N16 = rup(N, 16); j.Hp = rup(H, 32); j.Np = rup(N, 32);
+    j.W16 = static_cast<bf16_t*>(w16_h[k]);
+    j.Wt16 = j.W16 + (size_t)F * j.H16 * j.Np;
+    tot += (long long)F * j.H16 * j.Np + (long long)F * j.N16 * j.Hp;
+    j.end = tot;
+  }
+  const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cin_prep_multi_k, dim3(blocks), dim3(256), 0, rsx_s(stream), a);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                                      const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
+                                      float* dW, float* dc, void* ws, int B, int F, int H, int N, int D,
+                                      const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  if (!dW || !dc) return RSX_EINVAL;
+  const int rc = cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, stream);
+  if (rc != RSX_OK || B == 0) return rc;
+  const rsx_cin_dw_job job{Xk, ws, dW, dc, H, N};
+  return cb_launch_dw(X0, &job, 1, B, F, D, sweep_h, stream);
 }

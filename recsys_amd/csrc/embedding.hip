@@ -197,6 +197,8 @@ struct SegPartials {
   const int32_t* segid;   // [F, stride] then [F] long- and [F] huge-segment counters (reset by the sort)
   float* P;               // [F, nch, 2, D]
   float* P1;              // [F, nch, 2]
+  float* G;               // nullable [F*stride, D]: stage A also FINISHES every segment that lies inside one chunk and
+  float* gw1;             // writes its sum here (nullable [F*stride]); stage B picks those rows up instead of re-walking them
   // segid + F*stride: [F] long- and [F] huge-segment counts, then the long list [F, nch] (unique index j of the
   // field's long segments from the front, huge ones from the back) -- all written by the sort
   __host__ __device__ const int32_t* counts(int F, int stride) const { return segid + (size_t)F * stride; }
@@ -238,11 +240,13 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
                                              const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
                                              int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
-                                             float4& acc, float& a1, float4& e, int& row, bool& do1) {
+                                             float4& acc, float& a1, float4& e, int& row, bool& do1, bool& staged,
+                                             const bool load_staged) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
   const int q = lane % LPR, g = lane / LPR;
+  staged = false;
   const int wpf = seg_waves_per_field(B, GPW, true);
   const int f = wave / wpf;
   valid = false;
@@ -263,6 +267,18 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
     const int beg = own ? so[j] : 0;
     int end = own ? so[j + 1] : 0;
     row = own ? uniq_row[sl] : 0;
+    // a segment inside ONE chunk was finished by stage A (position-major: perm -> rows in two memory round trips with 16
+    // independent row loads per group, instead of this group's seg_off -> perm -> row chain): pick its sum up
+    if (part.G != nullptr && own && beg / SEG_CHUNK == (end - 1) / SEG_CHUNK) {
+      valid = true;
+      staged = true;
+      if (load_staged) {
+        acc = reinterpret_cast<const float4*>(part.G)[sl * LPR + q];
+        a1 = (do1 && part.gw1 != nullptr) ? part.gw1[sl] : 0.f;
+        if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+      }
+      return true;
+    }
     const bool is_null = own && null_row >= 0 && row == null_row;
     if (is_null) end = beg;
     valid = own && end - beg <= SEG_SHORT;        // long rows belong to their helper wave
@@ -345,10 +361,12 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
                                             const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
                                             int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
-                                            float4& acc, float& a1, float4& e, int& row, bool& do1) {
+                                            float4& acc, float& a1, float4& e, int& row, bool& do1, bool& staged,
+                                            const bool load_staged = true) {
+  staged = false;
   if (part.P != nullptr)
     return segsum_wave2<D>(wave, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride, null_row,
-                           part, xb, valid, sl, acc, a1, e, row, do1);
+                           part, xb, valid, sl, acc, a1, e, row, do1, staged, load_staged);
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -421,7 +439,7 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   return true;
 }
 
-template <int D>
+template <int D, bool FM>
 __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict__ tables, const float* __restrict__ S,
                                                          const float* __restrict__ dX, const float* __restrict__ gy1,
                                                          const float* __restrict__ gy2, const int32_t* __restrict__ perm,
@@ -429,6 +447,15 @@ __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict
                                                          const int32_t* __restrict__ uniq_row, const SegPartials ws,
                                                          uint64_t w1_mask, int B, int F, int stride, int null_row,
                                                          const ExBlocks xb) {
+  // Position-major stage: a group walks the 16 sorted positions of its chunk in ascending order.  Every load of the chunk
+  // -- example indices and segment ids first, then the 16 gradient rows (and, for the FM term, the 16 table rows) -- is
+  // independent of the others, so the group has 16 rows in flight per round trip however the ids are distributed.
+  //   * a segment that starts and ends inside the chunk is FINISHED here (sum in ascending example order, the oracle's
+  //     order) and written to ws.G / ws.gw1 when those are given;
+  //   * the chunk's overlap with a LONG segment (> SEG_SHORT entries) goes to the partial slots as before (slot 0: the
+  //     segment of the chunk's first position, slot 1: of its last);
+  //   * a short segment that straddles a chunk boundary is left to its row-owner group in stage B, which sums it entry by
+  //     entry -- so every segment of <= SEG_SHORT entries keeps the strictly sequential order.
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -441,76 +468,109 @@ __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict
   const bool active = ch < nch;
   const int p0 = active ? ch * SEG_CHUNK : 0;
   const int p1 = active ? (p0 + SEG_CHUNK < B ? p0 + SEG_CHUNK : B) : 1;
-  // the chunk's example indices do not depend on the segment structure: fetch them alongside it
   const int32_t* pf = perm + (size_t)f * stride;
-  int pb[SEG_CHUNK];
-#pragma unroll
-  for (int k = 0; k < SEG_CHUNK; ++k) pb[k] = p0 + k < p1 ? pf[p0 + k] : 0;
   const int32_t* sid = ws.segid + (size_t)f * stride;
   const int32_t* so = seg_off + (size_t)f * (stride + 1);
-  const int jf = sid[p0], jl = sid[p1 - 1];
+  const bool fin = ws.G != nullptr;
+  int pb[SEG_CHUNK], sj[SEG_CHUNK];
+#pragma unroll
+  for (int k = 0; k < SEG_CHUNK; ++k) {              // unconditional loads on clamped positions
+    const int pos = p0 + k < p1 ? p0 + k : p1 - 1;
+    pb[k] = pf[pos];
+    sj[k] = sid[pos];
+  }
+  const int jprev = sid[p0 > 0 ? p0 - 1 : 0], jnext = sid[p1 < B ? p1 : B - 1];
+  const int jf = sj[0], jl = sj[SEG_CHUNK - 1];      // (clamped positions repeat the last one)
+  const bool lopen = p0 > 0 && jprev == jf, ropen = p1 < B && jnext == jl;
   const int bf = so[jf], ef = so[jf + 1], bl = so[jl], el = so[jl + 1];
   const int rowf = uniq_row[(size_t)f * stride + jf], rowl = uniq_row[(size_t)f * stride + jl];
   const bool long0 = active && ef - bf > SEG_SHORT && !(null_row >= 0 && rowf == null_row);
   const bool long1 = active && jl != jf && el - bl > SEG_SHORT && !(null_row >= 0 && rowl == null_row);
-  if (!long0 && !long1) return;
-  const bool fm = gy2 != nullptr, has_x = dX != nullptr;
+  // what happens to the first / last segment of the chunk: partial slot, finished here, or left to stage B
+  const bool fin0 = fin && active && !long0 && !lopen && (jf != jl || !ropen);
+  const bool fin1 = fin && active && !long1 && jl != jf && !ropen;
+  if (!active || (!fin && !long0 && !long1)) return;
+  constexpr bool fm = FM;                     // FM term (gy2 / S / table row): a compile-time switch keeps its registers out
+  constexpr int NB = FM ? 4 : 8;              // entries whose loads are in flight together
+  const bool has_x = dX != nullptr;
   const bool do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* T4 = reinterpret_cast<const float4*>(tables);
   const float4* S4 = reinterpret_cast<const float4*>(S);
   const float4* X4 = reinterpret_cast<const float4*>(dX);
-  const float4 e0 = (fm && long0) ? T4[(size_t)rowf * LPR + q] : z;
-  const float4 e1 = (fm && long1) ? T4[(size_t)rowl * LPR + q] : z;
-  const int hi0 = long0 ? (ef < p1 ? ef : p1) : p0;   // positions [p0, hi0) -> slot 0
-  const int lo1 = long1 ? bl : p1;                     // positions [lo1, p1) -> slot 1
-  float4 acc0 = z, acc1 = z;
-  float a0 = 0.f, a1 = 0.f;
+  float4* P4 = reinterpret_cast<float4*>(ws.P);
+  float4* G4 = reinterpret_cast<float4*>(ws.G);
+  const size_t po = ((size_t)f * nch + ch) * 2;
+  int cur = -1;
+  float4 acc = z;
+  float a1 = 0.f;
+  bool cur_null = false;
+  auto flush = [&](const int j) {
+    if (j < 0) return;
+    if (j == jf) {
+      if (long0) {
+        P4[po * LPR + q] = acc;
+        if (do1) ws.P1[po] = a1;
+      } else if (fin0) {
+        G4[((size_t)f * stride + j) * LPR + q] = acc;
+        if (ws.gw1 != nullptr && q == 0) ws.gw1[(size_t)f * stride + j] = do1 ? a1 : 0.f;
+      }
+    } else if (j == jl) {
+      if (long1) {
+        P4[(po + 1) * LPR + q] = acc;
+        if (do1) ws.P1[po + 1] = a1;
+      } else if (fin1) {
+        G4[((size_t)f * stride + j) * LPR + q] = acc;
+        if (ws.gw1 != nullptr && q == 0) ws.gw1[(size_t)f * stride + j] = do1 ? a1 : 0.f;
+      }
+    } else if (fin) {
+      G4[((size_t)f * stride + j) * LPR + q] = acc;
+      if (ws.gw1 != nullptr && q == 0) ws.gw1[(size_t)f * stride + j] = do1 ? a1 : 0.f;
+    }
+  };
 #pragma unroll
-  for (int k0 = 0; k0 < SEG_CHUNK; k0 += 8) {          // 8 entries' loads in flight, summed in ascending position
-    float gg[8], hh[8];
-    float4 ss[8], xx[8];
+  for (int k0 = 0; k0 < SEG_CHUNK; k0 += NB) {         // NB entries' loads in flight, summed in ascending position
+    float gg[NB], hh[NB];
+    float4 ss[NB], xx[NB], ee[NB];
+    int rw[NB];
+    bool use[NB];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pos = p0 + k0 + k;
-      const bool use = pos < hi0 || (pos >= lo1 && pos < p1);
-      const int b = pb[k0 + k];
+    for (int k = 0; k < NB; ++k) {
+      const int pos = p0 + k0 + k, j = sj[k0 + k];
+      use[k] = pos < p1 && (j == jf ? (long0 || fin0) : (j == jl ? (long1 || fin1) : fin));
+      rw[k] = (fm || null_row >= 0) ? uniq_row[(size_t)f * stride + j] : 0;
       int bi;
       size_t bo;
-      ex_locate(xb, b, bi, bo);
-      gg[k] = (use && fm) ? gy2[bo + bi] : 0.f;
-      ss[k] = (use && fm) ? S4[bo / 4 + (size_t)bi * LPR + q] : z;
-      xx[k] = (use && has_x) ? X4[bo / 4 + ((size_t)bi * F + f) * LPR + q] : z;
-      hh[k] = (use && do1) ? gy1[bo + bi] : 0.f;
+      ex_locate(xb, pb[k0 + k], bi, bo);
+      gg[k] = fm ? gy2[bo + bi] : 0.f;
+      ss[k] = fm ? S4[bo / 4 + (size_t)bi * LPR + q] : z;
+      xx[k] = has_x ? X4[bo / 4 + ((size_t)bi * F + f) * LPR + q] : z;
+      hh[k] = do1 ? gy1[bo + bi] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pos = p0 + k0 + k;
-      const bool in0 = pos < hi0, in1 = pos >= lo1 && pos < p1;
-      if (in0 || in1) {
-        float4 t = z;
-        if (fm) t = f4_sub(f4_scale(gg[k], ss[k]), f4_scale(gg[k], in0 ? e0 : e1));
-        if (has_x) t = fm ? f4_add(t, xx[k]) : xx[k];
-        if (in0) {
-          acc0 = f4_add(acc0, t);
-          a0 += hh[k];
-        } else {
-          acc1 = f4_add(acc1, t);
+    for (int k = 0; k < NB; ++k) ee[k] = fm ? T4[(size_t)rw[k] * LPR + q] : z;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if (use[k]) {                                     // (group-uniform over the 4 lanes of a row)
+        const int j = sj[k0 + k];
+        if (j != cur) {
+          flush(cur);
+          cur = j;
+          acc = z;
+          a1 = 0.f;
+          cur_null = null_row >= 0 && rw[k] == null_row;
+        }
+        if (!cur_null) {
+          float4 t = z;
+          if (fm) t = f4_sub(f4_scale(gg[k], ss[k]), f4_scale(gg[k], ee[k]));
+          if (has_x) t = fm ? f4_add(t, xx[k]) : xx[k];
+          acc = f4_add(acc, t);
           a1 += hh[k];
         }
       }
     }
   }
-  float4* P4 = reinterpret_cast<float4*>(ws.P);
-  const size_t o = ((size_t)f * nch + ch) * 2;
-  if (long0) {
-    P4[o * LPR + q] = acc0;
-    if (do1) ws.P1[o] = a0;
-  }
-  if (long1) {
-    P4[(o + 1) * LPR + q] = acc1;
-    if (do1) ws.P1[o + 1] = a1;
-  }
+  flush(cur);
 }
 
 template <int D>
@@ -530,10 +590,13 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   float4 acc, e;
   float a1;
   int row;
+  bool staged;
+  // rows finished by stage A already sit in G / gw1 when stage A was given these buffers: nothing to load or store
+  const bool same = part.G == G;
   if (!segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                      nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1))
+                      nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same))
     return;
-  if (valid) {
+  if (valid && !(staged && same)) {
     reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
     if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
   }
@@ -582,8 +645,10 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float4 acc, e;
     float a1;
     int row;
+    bool staged;
     if (segsum_wave<D>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr, nullptr,
-                       perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1) &&
+                       perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1,
+                       staged) &&
         valid) {
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
@@ -603,8 +668,9 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float4 acc, e;
     float a1;
     int row;
+    bool staged;
     if (segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                       nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1) && valid) {
+                       nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1, staged) && valid) {
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
@@ -664,8 +730,12 @@ static void launch_partials(dim3 grid, dim3 block, hipStream_t st, const float* 
                             const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                             const int32_t* uniq_row, const SegPartials& ws, uint64_t mask, int B, int F, int stride,
                             int null_row, const ExBlocks& xb) {
-  segsum_partials_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F, stride,
-                                               null_row, xb);
+  if (gy2 != nullptr)
+    segsum_partials_k<D, true><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F, stride,
+                                                       null_row, xb);
+  else
+    segsum_partials_k<D, false><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F,
+                                                        stride, null_row, xb);
 }
 // host view of the rank-blocked input layout; nullptr -> contiguous
 static inline int ex_blocks(const rsx_example_blocks* h, int B, ExBlocks& out) {
@@ -678,10 +748,10 @@ static inline int ex_blocks(const rsx_example_blocks* h, int B, ExBlocks& out) {
 }
 // host view of the two-stage workspace; nullptr -> single-stage
 static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegPartials& out) {
-  out = SegPartials{nullptr, nullptr, nullptr};
+  out = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (h == nullptr) return RSX_OK;
   if (!h->segid || !h->P || (need_p1 && !h->P1)) return RSX_EINVAL;
-  out = SegPartials{h->segid, h->P, h->P1};
+  out = SegPartials{h->segid, h->P, h->P1, h->G, h->G ? h->gw1 : nullptr};
   return RSX_OK;
 }
 

@@ -79,10 +79,11 @@ def build_variables(store, params, capacity, with_dnn=True):
             store.dp.make_send_block(store.dense, capacity // store.dp.world, [layout.F * D, D, 1, 1])
             store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter] (measured: the
-        # latency-bound scatter + touched-row Adam launch hides 1/5 of the sweep for free: 98.9 -> 96.2 us per step)
+        # latency-bound scatter + touched-row Adam launch hides a quarter of the sweep; r02 grid over the shares with the faster
+        # head kernel: [0,0,2,3,3,2] 93.2 us, [0,0,1,3.5,3.5,2.5] 91.4 us per step)
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
         store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
-                                                              [0.0] * len(layers) + [2.0] + [3.0] * len(layers) + [2.0])
+                                                              [0.0] * len(layers) + [1.0] + [3.5] * len(layers) + [2.5])
 
 
 def model_fn(features, labels, mode, params):

@@ -81,7 +81,8 @@ class EmbeddingArena:
             self.segid = torch.zeros(F * st + 2 * F + F * nch, **i32)
             self.P = torch.zeros(F * nch * 2, D, device=dev)
             self.P1 = torch.zeros(F * nch * 2, device=dev) if with_w1 else None
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1))
+            # (G / gw1: stage A finishes the segments that lie inside one chunk straight into the scatter's outputs)
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1))
         # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
         self.hook = torch.zeros((), device=dev, requires_grad=True)
 
@@ -105,7 +106,7 @@ class EmbeddingArena:
             setattr(self, k, getattr(other, k))
         if self.partials is not None:
             self.segid = other.segid
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1))
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1))
 
     # -- kernels ---------------------------------------------------------------------------
     def field_sort(self, ids):
@@ -620,7 +621,7 @@ class SparseTable:
         nch = (self.cap + 15) // 16
         self.segid = torch.zeros(self.cap + 2 + nch, **i32)
         self.P = torch.zeros(nch * 2, self.K, device=dev)
-        self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), None)
+        self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), None, None, None)
         self.hook = torch.zeros((), device=dev, requires_grad=True)
         self.pending = []
         self._seq = 0
@@ -869,8 +870,12 @@ class CinNet:
             hs16 = [F] + self.sizes[:-1]
             self.w16 = [torch.empty(int(lib().rsx_cin_bf16_weight_elems(F, h, n)), dtype=torch.int16, device=dev)
                         for h, n in zip(hs16, self.sizes)]
-            self.ws16 = torch.empty(max(int(lib().rsx_cin_bf16_bwd_workspace_bytes(capacity, n)) for n in self.sizes),
-                                    dtype=torch.uint8, device=dev)
+            # one backward workspace PER LAYER: the dX launches fill them layer by layer, ONE launch then computes every
+            # layer's weight gradient from them
+            self.ws16 = [torch.empty(int(lib().rsx_cin_bf16_bwd_workspace_bytes(capacity, n)), dtype=torch.uint8, device=dev)
+                         for n in self.sizes]
+            self._w16_h = (C.c_void_p * self.L)(*[w.data_ptr() for w in self.w16])
+            self._H_h = (C.c_int32 * self.L)(*hs16)
         self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
         self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
         hs = [F] + self.sizes[:-1]
@@ -886,10 +891,13 @@ class CinNet:
         optimizer sweep carried by layer k's forward launch."""
         B = X0.shape[0]
         Xk, H = X0, self.F
+        if self.bf16:     # the bf16 operand images of all layers' filters: one launch
+            W_h = (C.c_void_p * self.L)(*[P[f"cin.W{k}"].data_ptr() for k in range(self.L)])
+            check(lib().rsx_cin_prep_bf16_multi(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, _stream()),
+                  "rsx_cin_prep_bf16_multi")
         for k, n in enumerate(self.sizes):
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             if self.bf16:
-                check(lib().rsx_cin_prep_bf16(_ptr(P[f"cin.W{k}"]), _ptr(self.w16[k]), self.F, H, n, _stream()), "rsx_cin_prep_bf16")
                 check(lib().rsx_cin_layer_fwd_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]),
                                                    B, self.F, H, n, self.D, sw, _stream()), "rsx_cin_layer_fwd_bf16")
                 Xk, H = self.outs[k], n
@@ -904,7 +912,8 @@ class CinNet:
     def backward(self, X0, P, gy, sweeps=None, dX0_out=None):
         """gy [B]: gradient wrt cin_y.  Writes the cin.* gradients into P[...].grad and returns dX0 [B,F,D] (internal
         buffer, or dX0_out: a caller-owned contiguous [B,F,D] buffer).  sweeps[k]: slice of the untouched-row optimizer sweep
-        carried by layer k's weight-gradient launch."""
+        carried by layer k's weight-gradient launch (bf16: ONE launch computes all layers' weight gradients, so at most one
+        slice may be given)."""
         B, L = X0.shape[0], self.L
         dX0 = self.dX0 if dX0_out is None else dX0_out
         check(lib().rsx_cin_out_bwd(self._outs_h, self._sizes_h, L, _ptr(self.y), _ptr(gy), _ptr(self.gs), _ptr(P["cin.Wout"].grad),
@@ -919,13 +928,25 @@ class CinNet:
                 dxk, acc_dxk, acc_dx0 = self.dmap[k - 1], 0, 0 if k == L - 1 else 1
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             if self.bf16:       # w16[k] was prepared by this step's forward (the filters do not change in between)
-                check(lib().rsx_cin_layer_bwd_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
-                                                   C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
-                                                   _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.ws16), B,
-                                                   self.F, H, self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd_bf16")
+                check(lib().rsx_cin_layer_bwd_dx_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
+                                                      C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
+                                                      _ptr(self.ws16[k]), B, self.F, H, self.sizes[k], self.D, _stream()),
+                      "rsx_cin_layer_bwd_dx_bf16")
                 continue
             check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
                                           self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
+        if self.bf16:           # every layer's weight gradient in ONE launch; it carries the sum of the dW sweep slices' first
+            jobs = (_lib.CinDwJob * L)()
+            for k in range(L):
+                Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])
+                jobs[k] = _lib.CinDwJob(Xk.data_ptr(), self.ws16[k].data_ptr(), P[f"cin.W{k}"].grad.data_ptr(),
+                                        P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k])
+            sw = None
+            if sweeps is not None:
+                live = [x for x in sweeps if x is not None]
+                assert len(live) <= 1, "bf16 CinNet: one weight-gradient launch carries ONE sweep slice"
+                sw = C.byref(live[0]) if live else None
+            check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
         return dX0[:B]

@@ -120,24 +120,25 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 # and the dense variables follow the scatter in one small launch
                 c1, h1 = a1.adam_split_segments()
                 c2, h2 = a2.adam_split_segments()
-                # carriers, in launch order: [CIN fwd_0..fwd_{L-1} | tower fwd_0, fwd_1, head, bwd_1, bwd_0 | CIN dW_{L-1}..dW_0 |
-                # scatter].  Default shares: the fp32 CIN launches are long MFMA kernels and take the sweep by their flops;
+                # carriers, in launch order: [CIN fwd_0..fwd_{L-1} | tower fwd_0, fwd_1, head, bwd_1, bwd_0 | CIN dW_{L-1}..dW_0 (ONE
+                # launch on the bf16 path) | scatter].  Default shares: the fp32 CIN launches are long MFMA kernels and take the sweep by their flops;
                 # the bf16 CIN launches are a few microseconds each, so there the latency-bound tower / scatter launches
                 # carry most of it (weights measured on MI355X; RSX_XDFM_SWEEP_WEIGHTS overrides).
                 w = [float(store.cin_sizes[k]) * (a1.F if k == 0 else store.cin_sizes[k - 1]) for k in range(len(store.cin_sizes))]
                 tw = sum(w)
                 nl = len(store.tower.widths)
                 env = os.environ.get("RSX_XDFM_SWEEP_WEIGHTS")
+                nd = 1 if store.cin.bf16 else L          # weight-gradient launches: bf16 computes all layers' dW in one
                 if env:
                     wts = [float(x) for x in env.split(",")]
                 elif store.cin.bf16:
-                    wts = [x / tw for x in w] + [0.0] * nl + [1.0] + [1.5] * nl + [1.5 * x / tw for x in w][::-1] + [1.0]
+                    wts = [0.0] * L + [0.0] * nl + [1.0] + [2.0] * nl + [2.0] + [2.0]
                 else:
                     wts = [0.5 * x / tw for x in w] + [0.0] * (2 * nl + 1) + [0.5 * x / tw for x in w][::-1] + [0.0]
-                assert len(wts) == 2 * L + 2 * nl + 2, "RSX_XDFM_SWEEP_WEIGHTS: %d weights expected" % (2 * L + 2 * nl + 2)
+                assert len(wts) == L + 2 * nl + 1 + nd + 1, "RSX_XDFM_SWEEP_WEIGHTS: %d weights expected" % (L + 2 * nl + 2 + nd)
                 # (first-order vector first: the LAST slice, carried by the scatter launch, may hold table blocks only)
                 sl_all = store.opt.cold_slices(c1[::-1] + c2, wts)
-                sweeps = sl_all[:L] + sl_all[L + 2 * nl + 1:2 * L + 2 * nl + 1][::-1]          # CIN fwd_k ..., then dW_k in layer order
+                sweeps = sl_all[:L] + sl_all[L + 2 * nl + 1:L + 2 * nl + 1 + nd][::-1]         # CIN fwd_k ..., then dW_k in layer order
                 tower_sweeps = sl_all[L:L + 2 * nl + 1]
                 last_sweep = sl_all[-1]
                 hot = h1 + h2

@@ -60,6 +60,9 @@ def test_fingerprint64_matches_oracle_all_lengths(L):
                              out.ctypes.data_as(C.c_void_p)) == 0
     assert [int(x) for x in out] == [hashing.fingerprint64(s) for s in strs]
     assert int(out[0]) == 12917804110809363939          # Appendix B-1 KAT straight through the C ABI
+    # TF documentation example of to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2], through the C ABI
+    for s_, want in ((b"Hello", 0), (b"TensorFlow", 2), (b"2.x", 2)):
+        assert int(L.rsx_fingerprint64_h(s_, len(s_))) % 3 == want
 
 
 def test_bucketize_and_crc_match_oracle(L):

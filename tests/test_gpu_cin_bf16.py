@@ -137,3 +137,35 @@ def test_xdeepfm_bf16_trajectory_stays_close_to_fp32():
     # drift apart on individual examples; the per-step loss stays within 1e-2 and the first steps within 1e-3)
     assert dl.max() < 3e-2 and dl[:10].max() < 2e-3 and dpv.max() < 0.3 and dpv.mean() < 3e-2
     assert res[True][0][-20:].mean() < res[True][0][:20].mean()          # it trains
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_xdeepfm_sweep_carriers_cover_the_whole_update(bf16):
+    """Exact split of the TF-1 Adam update over the carrier launches (CIN forward, tower, the ONE merged weight-gradient
+    launch of the bf16 path, scatter): every variable after 12 steps must be BIT-IDENTICAL to the plain path (stand-alone
+    sweep) -- a slice that no launch executes, or executes twice, would show here."""
+    from recsys_amd import synthetic, xdeepfm
+    from recsys_amd.estimator import Estimator, PackedBatch, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    lin, emb = build_feature_columns(16, "numeric+indicator")
+    layout = CriteoLayout.from_columns(emb)
+    host = synthetic.criteo_id_batches(layout, 4, 128, seed=9)
+    states = []
+    for overlap in (False, True):
+        params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+                  "dropout": 0.5, "deep_layers": "100,100", "cross_layers": "128,128", "max_batch_size": 128, "cin_bf16": bf16,
+                  "overlap_adam": overlap}
+        est = Estimator(xdeepfm.model_fn, None, params, RunConfig(use_hip_graph=False, seed=3))
+        feats = [PackedBatch({"ids": i, "cont_log": c}, y, device="cuda") for i, y, c in host]
+        with torch.no_grad():
+            est._call_model_fn(feats[0].views()[0], None, "infer")
+        for s in range(12):
+            est._train_step(*feats[s % 4].views())
+        torch.cuda.synchronize()
+        st = est.store
+        a1, a2 = st.embeddings["input_layer"], st.embeddings["input_layer_1"]
+        states.append([t.clone() for t in (a1.tables, a1.m_t, a1.v_t, a1.w1, a1.m_w, a1.v_w, a2.tables, a2.m_t, a2.v_t,
+                                          st.dense.flat, st.dense.m, st.dense.v)])
+    for name, x, y in zip(("t1", "m1", "v1", "w1", "mw", "vw", "t2", "m2", "v2", "dense", "dm", "dv"), *states):
+        assert torch.isfinite(x).all(), name
+        assert torch.equal(x, y), (name, float((x - y).abs().max()))

@@ -14,6 +14,12 @@ def test_fingerprint64_kats():
     assert [hashing.hash_bucket(s, 10) for s in (b"a", b"b", b"c", b"d")] == [9, 2, 2, 5]
     assert all(hashing.hash_bucket(s, 1) == 0 for s in (b"a", b"b", b"NULL", b"05db9164"))
     assert hashing.fingerprint64(b"") == 0x9AE16A3B2F90404F   # farmhashna: empty -> k2
+    # the usage example in upstream TF's documentation of tf.strings.to_hash_bucket_fast:
+    #   to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2]
+    # bucket values only (mod 3), but they reach the 4-7-byte branch ("Hello"), the 8-16-byte branch ("TensorFlow": the
+    # branch every 8-hex-character Criteo value takes) and the 1-3-byte branch -- the only externally held answers for
+    # the first two; the 17-32 / 33-64 / > 64-byte branches stay pinned by two independent implementations agreeing
+    assert [hashing.hash_bucket(s, 3) for s in (b"Hello", b"TensorFlow", b"2.x")] == [0, 2, 2]
 
 
 def test_fingerprint64_all_length_branches_are_total():
