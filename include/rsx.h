@@ -431,6 +431,12 @@ int rsx_criteo_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int
 int rsx_din_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n, int P,
                     int64_t* label_h, int64_t* i_id_h, int64_t* i_cate_h, int64_t* hist_i_h, int64_t* hist_c_h,
                     int threads);
+/* deepfm/deepfm.py:28-33,53-56 AS COMMITTED (two int64 features u_id / i_id + int64 label): first value of each named int64
+ * feature, out_h[k*n + r]; and categorical_column_with_hash_bucket(dtype=int64) deepfm/deepfm.py:41,46: the key is formatted
+ * as a decimal string (TF as_string) and hashed, id = Fingerprint64(str(key)) % buckets.                            */
+int rsx_int64_features_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n,
+                               const char* const* names_h, int k, int64_t* out_h, int threads);
+int rsx_hash_int64_keys_h(const int64_t* keys_h, int64_t n, uint64_t buckets, int32_t* out_h);
 /* Writers for synthetic shards of the two schemas (the reference's own sample shard is a missing blob).  Return bytes
  * written, or -(needed+16) when cap is too small.                                                               */
 int64_t rsx_criteo_encode_h(const float* label_h, const float* cont_h, const uint8_t* cat_bytes_h,

@@ -107,6 +107,8 @@ _SIGS = {
     "rsx_din_encode_h": (C.c_int64, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _P, C.c_int64]),
     "rsx_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
     "rsx_masked_crc32c_h": (C.c_uint32, [_P, C.c_size_t]),
+    "rsx_int64_features_parse_h": (_I, [_P, _P, _P, C.c_int64, _P, _I, _P, _I]),
+    "rsx_hash_int64_keys_h": (_I, [_P, C.c_int64, C.c_uint64, _P]),
     "rsx_crc32c_table_h": (C.c_uint32, [_P, C.c_size_t]),
     "rsx_criteo_reader_open_h": (_P, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "rsx_criteo_reader_next_h": (_I, [_P, _P, _P, _P]),

@@ -541,28 +541,46 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
 struct CbPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; int H, N, H16, N16, Hp, Np; long long end; };
 struct CbPrepArgs { CbPrepJob job[CB_MAXJ]; int njobs, F; };
 __global__ __launch_bounds__(256) void cin_prep_multi_k(const CbPrepArgs p) {
-  const long long total = p.job[p.njobs - 1].end;
+  // one thread = one 16-byte operand quad (8 bf16): the index arithmetic is paid once per 8 elements, the W16 quads read
+  // 32 contiguous bytes of W, the Wt16 quads 8 rows of one column
+  const long long total = p.job[p.njobs - 1].end >> 3;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     int ji = 0;
 #pragma unroll
     for (int k = 1; k < CB_MAXJ; ++k)
-      if (k < p.njobs && e >= p.job[k - 1].end) ji = k;
+      if (k < p.njobs && e >= (p.job[k - 1].end >> 3)) ji = k;
     const CbPrepJob& jb = p.job[ji];
-    const long long le = e - (ji ? p.job[ji - 1].end : 0);
-    const long long n1 = (long long)p.F * jb.H16 * jb.Np;
+    const long long le = e - (ji ? (p.job[ji - 1].end >> 3) : 0);
+    const long long n1 = ((long long)p.F * jb.H16 * jb.Np) >> 3;
     const bool first = le < n1;
     const long long q = first ? le : le - n1;
-    const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
-    long long r = q >> 9;
+    const int lane = (int)(q & 63);
+    int r = (int)(q >> 6);
     const int KS = first ? jb.Np >> 5 : jb.Hp >> 5;
-    const int ks = (int)(r % KS);
+    const int ks = r % KS;
     r /= KS;
     const int T = first ? jb.H16 >> 4 : jb.N16 >> 4;
-    const int t = (int)(r % T), f = (int)(r / T);
-    const int h = first ? 16 * t + (lane & 15) : 32 * ks + 8 * (lane >> 4) + j;
-    const int n = first ? 32 * ks + 8 * (lane >> 4) + j : 16 * t + (lane & 15);
-    const bf16_t v = (bf16_t)((h < jb.H && n < jb.N) ? jb.W[((size_t)f * jb.H + h) * jb.N + n] : 0.f);
-    if (first) jb.W16[q] = v; else jb.Wt16[q] = v;
+    const int t = r % T, f = r / T;
+    bf16x8 o;
+    if (first) {                                   // W16: h = 16 t + (lane & 15), n = 32 ks + 8 (lane >> 4) + j
+      const int h = 16 * t + (lane & 15), n0 = 32 * ks + 8 * (lane >> 4);
+      const float* src = jb.W + ((size_t)f * jb.H + (h < jb.H ? h : jb.H - 1)) * jb.N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = n0 + j;
+        o[j] = (bf16_t)(src[n < jb.N ? n : jb.N - 1] * ((h < jb.H && n < jb.N) ? 1.f : 0.f));
+      }
+      *reinterpret_cast<bf16x8*>(jb.W16 + q * 8) = o;
+    } else {                                       // Wt16: n = 16 t + (lane & 15), h = 32 ks + 8 (lane >> 4) + j
+      const int n = 16 * t + (lane & 15), h0 = 32 * ks + 8 * (lane >> 4);
+      const float* src = jb.W + (size_t)f * jb.H * jb.N + (n < jb.N ? n : jb.N - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = h0 + j;
+        o[j] = (bf16_t)(src[(size_t)(h < jb.H ? h : jb.H - 1) * jb.N] * ((h < jb.H && n < jb.N) ? 1.f : 0.f));
+      }
+      *reinterpret_cast<bf16x8*>(jb.Wt16 + q * 8) = o;
+    }
   }
 }
 
@@ -716,7 +734,8 @@ extern "C" int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16
     tot += (long long)F * j.H16 * j.Np + (long long)F * j.N16 * j.Hp;
     j.end = tot;
   }
-  const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+  const long long quads = tot >> 3;
+  const unsigned blocks = (unsigned)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
   hipLaunchKernelGGL(cin_prep_multi_k, dim3(blocks), dim3(256), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

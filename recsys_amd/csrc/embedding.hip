@@ -484,6 +484,10 @@ __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict
   const bool lopen = p0 > 0 && jprev == jf, ropen = p1 < B && jnext == jl;
   const int bf = so[jf], ef = so[jf + 1], bl = so[jl], el = so[jl + 1];
   const int rowf = uniq_row[(size_t)f * stride + jf], rowl = uniq_row[(size_t)f * stride + jl];
+  // rows of all 16 positions' segments, in the same round trip as the segment bounds (FM term / padding row only)
+  int rws[SEG_CHUNK];
+#pragma unroll
+  for (int k = 0; k < SEG_CHUNK; ++k) rws[k] = (FM || null_row >= 0) ? uniq_row[(size_t)f * stride + sj[k]] : 0;
   const bool long0 = active && ef - bf > SEG_SHORT && !(null_row >= 0 && rowf == null_row);
   const bool long1 = active && jl != jf && el - bl > SEG_SHORT && !(null_row >= 0 && rowl == null_row);
   // what happens to the first / last segment of the chunk: partial slot, finished here, or left to stage B
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict
     for (int k = 0; k < NB; ++k) {
       const int pos = p0 + k0 + k, j = sj[k0 + k];
       use[k] = pos < p1 && (j == jf ? (long0 || fin0) : (j == jl ? (long1 || fin1) : fin));
-      rw[k] = (fm || null_row >= 0) ? uniq_row[(size_t)f * stride + j] : 0;
+      rw[k] = rws[k0 + k];
       int bi;
       size_t bo;
       ex_locate(xb, pb[k0 + k], bi, bo);

@@ -313,6 +313,50 @@ extern "C" int rsx_din_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, c
   return status.load();
 }
 
+// deepfm/deepfm.py:28-33,53-56 (the script as committed): scalar int64 features by name.  out_h[k*n + r] = first value of
+// feature names_h[k] in record r; a missing feature is RSX_EDATA (FixedLenFeature without default).
+extern "C" int rsx_int64_features_parse_h(const uint8_t* buf_h, const int64_t* offsets_h, const int64_t* lengths_h, int64_t n,
+                                          const char* const* names_h, int k, int64_t* out_h, int threads) {
+  if (n < 0 || k <= 0 || k > 16) return RSX_EINVAL;
+  if (n == 0) return RSX_OK;
+  if (!buf_h || !offsets_h || !lengths_h || !names_h || !out_h) return RSX_EINVAL;
+  size_t nlen[16];
+  for (int i = 0; i < k; ++i) {
+    if (!names_h[i]) return RSX_EINVAL;
+    nlen[i] = std::strlen(names_h[i]);
+  }
+  std::atomic<int> status{RSX_OK};
+  parallel_for(n, threads, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; ++r) {
+      bool got[16] = {false};
+      const bool ok = for_each_feature(buf_h + offsets_h[r], (size_t)lengths_h[r], [&](Span key, Span feat) {
+        for (int i = 0; i < k; ++i)
+          if (key.n == nlen[i] && std::memcmp(key.p, names_h[i], nlen[i]) == 0) got[i] = feat_int64s(feat, out_h + (size_t)i * n + r, 1) >= 1;
+      });
+      bool all = ok;
+      for (int i = 0; i < k; ++i) all = all && got[i];
+      if (!all) status.store(RSX_EDATA);
+    }
+  });
+  return status.load();
+}
+
+// categorical_column_with_hash_bucket(key, buckets, dtype=int64) (deepfm/deepfm.py:41,46): TF formats the integer as a
+// decimal string (as_string) and hashes that: id = Fingerprint64(str(key)) % buckets  (SURVEY.md Appendix A-2).
+extern "C" int rsx_hash_int64_keys_h(const int64_t* keys_h, int64_t n, uint64_t buckets, int32_t* out_h) {
+  if (n < 0 || buckets == 0 || buckets > 0x7fffffffull || (n > 0 && (!keys_h || !out_h))) return RSX_EINVAL;
+  for (int64_t i = 0; i < n; ++i) {
+    char tmp[24];
+    int64_t v = keys_h[i];
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    int p = 24;
+    do { tmp[--p] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) tmp[--p] = '-';
+    out_h[i] = (int32_t)(rsx_fingerprint64_h(reinterpret_cast<const uint8_t*>(tmp + p), (size_t)(24 - p)) % buckets);
+  }
+  return RSX_OK;
+}
+
 static void frame_into(std::string& out, const std::string& ex) {
   uint64_t len = ex.size();
   char hdr[8];

@@ -200,16 +200,28 @@ def define_flags(p=None):
     p.add_argument("--mirror", type=lambda s: s.lower() in ("1", "true", "yes"), default=True)
     p.add_argument("--model_dir", default="./model/")
     p.add_argument("--adam_mode", default="tf1_dense")
+    p.add_argument("--feature_set", default="criteo", choices=["criteo", "uid_iid"],
+                   help="criteo: the 39-field pipeline of fm.py (BASELINE configs); uid_iid: deepfm.py as committed "
+                        "(int64 u_id / i_id hashed into 500000 / 100000 buckets, int64 label)")
     return p
 
 
 def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None, shard=None):
+    if layout is not None and layout.columns[0].key in ("i_id", "u_id"):     # --feature_set uid_iid (the script as committed)
+        from .input_pipeline import uid_iid_input_fn
+        assert shard is None or shard[1] == 1, "--feature_set uid_iid: single replica only"
+        return uid_iid_input_fn(filenames, batch_size, num_epochs, need_shuffle, layout)
     from .input_pipeline import criteo_input_fn
     return criteo_input_fn(filenames, batch_size, num_epochs, need_shuffle, num_parallel, layout, shard=shard)
 
 
 def make_params(FLAGS, linear="indicator_all"):
-    lin, emb = build_feature_columns(FLAGS.embedding_size, linear)
+    if getattr(FLAGS, "feature_set", "criteo") == "uid_iid":
+        # deepfm/deepfm.py AS COMMITTED (:28-51): two int64 id features u_id / i_id, hashed as decimal strings
+        from .feature_columns import build_model_columns
+        lin, emb = build_model_columns(FLAGS.embedding_size)
+    else:
+        lin, emb = build_feature_columns(FLAGS.embedding_size, linear)
     return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
             "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
             "max_batch_size": FLAGS.batch_size}

@@ -70,6 +70,17 @@ def build_feature_columns(embedding_size, linear="indicator_all"):
     return lin, emb
 
 
+def build_model_columns(embedding_size):
+    """deepfm/deepfm.py:37-51 AS COMMITTED: two int64 id features hashed into 500 000 / 100 000 buckets
+    (`categorical_column_with_hash_bucket(..., dtype=int64)`: the key is hashed as its decimal string), each with an
+    indicator (linear) and an embedding column.  input_layer's name order puts i_id before u_id."""
+    lin, emb = [], []
+    for key, rows in (("u_id", 500000), ("i_id", 100000)):
+        lin.append(Column(key + "_indicator", key, "hash_indicator", rows))
+        emb.append(Column(key + "_embedding", key, "hash_embedding", rows, embedding_size))
+    return lin, emb
+
+
 @dataclass
 class CriteoLayout:
     """input_layer's name-sorted slot order resolved for the concatenated table."""
@@ -93,6 +104,20 @@ class CriteoLayout:
             if c.key in keys:
                 m |= 1 << i
         return m
+
+    def transform_int64(self, features):
+        """Host transform for int64-keyed hash columns (deepfm/deepfm.py:41,46): features[key] int64 [B] (or [B,1]) ->
+        ids [B,F] int32 in slot order, id = Fingerprint64(str(key)) % rows."""
+        L = lib()
+        B = int(np.asarray(features[self.columns[0].key]).reshape(-1).shape[0])
+        ids = np.empty((B, self.F), np.int32)
+        tmp = np.empty(B, np.int32)
+        for slot, c in enumerate(self.columns):
+            keys = np.ascontiguousarray(np.asarray(features[c.key]).reshape(-1), np.int64)
+            check(L.rsx_hash_int64_keys_h(keys.ctypes.data_as(C.c_void_p), B, c.rows, tmp.ctypes.data_as(C.c_void_p)),
+                  "rsx_hash_int64_keys_h")
+            ids[:, slot] = tmp
+        return ids
 
     def transform(self, cont, cat_bytes, cat_offs):
         """Host transform of one batch.  cont [B,13] float32 raw _c1.._c13; categorical values as one

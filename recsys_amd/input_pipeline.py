@@ -267,6 +267,39 @@ def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_p
     return it
 
 
+def uid_iid_input_fn(filenames, batch_size=32, num_epochs=-1, need_shuffle=False, layout=None, shuffle_buffer=100, seed=0):
+    """deepfm/deepfm.py:53-70 AS COMMITTED: records {label int64, u_id int64, i_id int64} -> features {'ids' int32 [B,2]}
+    (hashed on the host like the Criteo categorical fields), labels float32 [B].  Small utility path (the BASELINE configs
+    are the Criteo marriage): whole shards are indexed and parsed at once."""
+    names = (C.c_char_p * 3)(b"label", b"u_id", b"i_id")
+
+    def gen():
+        epoch = 0
+        while num_epochs < 0 or epoch < num_epochs:
+            carry = None
+            for path in filenames:
+                buf, offs, lens = read_shard(path)
+                n = len(offs)
+                out = np.empty((3, n), np.int64)
+                check(lib().rsx_int64_features_parse_h(_p(buf), _p(offs), _p(lens), n, names, 3, _p(out), 4),
+                      "rsx_int64_features_parse_h")
+                if carry is not None:
+                    out = np.concatenate([carry, out], 1)
+                full = (out.shape[1] // batch_size) * batch_size
+                for b in range(0, full, batch_size):
+                    sl = out[:, b:b + batch_size]
+                    yield {"ids": layout.transform_int64({"u_id": sl[1], "i_id": sl[2]})}, sl[0].astype(np.float32)
+                carry = out[:, full:] if full < out.shape[1] else None
+            if carry is not None and carry.shape[1]:
+                yield {"ids": layout.transform_int64({"u_id": carry[1], "i_id": carry[2]})}, carry[0].astype(np.float32)
+            epoch += 1
+
+    it = gen()
+    if need_shuffle:
+        it = _shuffled(it, shuffle_buffer, seed)
+    return it
+
+
 # ---- serialized tf.train.Example entry (SURVEY.md 8f-4) -------------------------------------------------------------
 def _pack_serialized(serialized):
     """list of bytes -> (buf uint8, offsets int64 [n], lengths int64 [n])."""

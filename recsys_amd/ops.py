@@ -5,6 +5,7 @@ optimizer is a hand-written gfx950 kernel in librsx.so, called with raw device p
 CPU fallback: constructing these objects without a GPU + librsx.so raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -81,8 +82,11 @@ class EmbeddingArena:
             self.segid = torch.zeros(F * st + 2 * F + F * nch, **i32)
             self.P = torch.zeros(F * nch * 2, D, device=dev)
             self.P1 = torch.zeros(F * nch * 2, device=dev) if with_w1 else None
-            # (G / gw1: stage A finishes the segments that lie inside one chunk straight into the scatter's outputs)
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1))
+            # (G / gw1: stage A finishes the segments that lie inside one chunk straight into the scatter's outputs;
+            # RSX_STAGE_A_FINAL=0 restores the long-segment-partials-only stage A for A/B runs)
+            fin = os.environ.get("RSX_STAGE_A_FINAL", "1") != "0"
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G) if fin else None,
+                                             _ptr(self.gw1) if fin else None)
         # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
         self.hook = torch.zeros((), device=dev, requires_grad=True)
 
@@ -106,7 +110,9 @@ class EmbeddingArena:
             setattr(self, k, getattr(other, k))
         if self.partials is not None:
             self.segid = other.segid
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1))
+            fin = os.environ.get("RSX_STAGE_A_FINAL", "1") != "0"
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G) if fin else None,
+                                             _ptr(self.gw1) if fin else None)
 
     # -- kernels ---------------------------------------------------------------------------
     def field_sort(self, ids):
@@ -926,13 +932,13 @@ class CinNet:
                 dxk, acc_dxk, acc_dx0 = dX0, 1 if L > 1 else 0, 1
             else:
                 dxk, acc_dxk, acc_dx0 = self.dmap[k - 1], 0, 0 if k == L - 1 else 1
-            sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             if self.bf16:       # w16[k] was prepared by this step's forward (the filters do not change in between)
                 check(lib().rsx_cin_layer_bwd_dx_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                                       C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                                       _ptr(self.ws16[k]), B, self.F, H, self.sizes[k], self.D, _stream()),
                       "rsx_cin_layer_bwd_dx_bf16")
                 continue
+            sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,

@@ -168,4 +168,10 @@ def test_xdeepfm_sweep_carriers_cover_the_whole_update(bf16):
                                           st.dense.flat, st.dense.m, st.dense.v)])
     for name, x, y in zip(("t1", "m1", "v1", "w1", "mw", "vw", "t2", "m2", "v2", "dense", "dm", "dv"), *states):
         assert torch.isfinite(x).all(), name
-        assert torch.equal(x, y), (name, float((x - y).abs().max()))
+        if bf16:
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+        else:
+            # fp32 path: a weight-gradient launch that carries a sweep slice uses a smaller tile configuration
+            # (cin.hip: co-resident sweep workgroups inherit the kernel's footprint), i.e. another summation order of
+            # dW -- rounding-level differences, while a missing / doubled slice would be ~1e-3 (one Adam step)
+            assert float((x - y).abs().max()) < 2e-6, (name, float((x - y).abs().max()))

@@ -84,3 +84,25 @@ def test_din_main_train_eval_predict_resume(tmp_path):
     assert len(preds) == 10
     res2 = din.main(common + ["--task_type", "train", "--num_epochs", "1"])
     assert res2["global_step"] > res["global_step"]
+
+
+def test_deepfm_main_as_committed_uid_iid_feature_set(tmp_path):
+    """deepfm/deepfm.py AS COMMITTED (two int64 id features, :28-51) through the same fused TRAIN step (F = 2 fields)."""
+    from oracle import tfrecord
+    from recsys_amd import deepfm
+    rng = np.random.default_rng(0)
+    d = str(tmp_path) + "/"
+    for k in range(3):
+        n = 600
+        u, i = rng.integers(1, 40, n), rng.integers(1, 25, n)
+        lab = ((i % 3 == 0) ^ (rng.random(n) < 0.1)).astype(np.int64)
+        blob = b"".join(tfrecord.frame(tfrecord.encode_example({"label": [int(lab[r])], "u_id": [int(u[r])], "i_id": [int(i[r])]}))
+                        for r in range(n))
+        open(d + "part-r-%05d" % k, "wb").write(blob)
+    common = ["--train_path", d, "--train_parts", "3", "--eval_parts", "1", "--batch_size", "128", "--model_dir",
+              str(tmp_path / "model"), "--save_checkpoints_steps", "8", "--log_steps", "4", "--dropout", "0.1",
+              "--learning_rate", "0.01", "--feature_set", "uid_iid", "--embedding_size", "8"]
+    res = deepfm.main(common + ["--task_type", "train", "--num_epochs", "6"])
+    assert np.isfinite(res["loss"]) and res["AUC"] > 0.8, res
+    preds = deepfm.main(common + ["--task_type", "infer"])
+    assert len(preds) == 10

@@ -259,3 +259,37 @@ def test_parse_serialized_examples_like_a_serving_request(layout):
     ex = {"label": [1], "i_id": [7], "i_cate": [3], "u_iid_seq": [5, 6], "u_icat_seq": [2, 2]}
     f, y = parse_din_examples([tfrecord.encode_example(ex)], hist_len=4)
     assert f["u_iid_seq"].tolist() == [[5, 6, 0, 0]] and f["i_id"].tolist() == [7] and y.tolist() == [1]
+
+
+def test_int64_key_columns_of_deepfm_py_as_committed(tmp_path):
+    """deepfm/deepfm.py:28-51: u_id / i_id int64 features, categorical_column_with_hash_bucket(dtype=int64) = hash of the
+    decimal string.  Host functions vs the oracle's FarmHash + codec."""
+    import ctypes as C
+    from oracle import hashing
+    from recsys_amd._lib import RsxError, lib
+    from recsys_amd.feature_columns import CriteoLayout, build_model_columns
+    from recsys_amd.input_pipeline import uid_iid_input_fn
+    lin, emb = build_model_columns(8)
+    layout = CriteoLayout.from_columns(emb)
+    assert [c.key for c in layout.columns] == ["i_id", "u_id"]            # input_layer sorts by column name (A-1)
+    rng = np.random.default_rng(2)
+    keys = np.concatenate([rng.integers(0, 1 << 40, 50), [0, 7, -5, 2 ** 62, -(2 ** 63)]]).astype(np.int64)
+    out = np.empty(len(keys), np.int32)
+    assert lib().rsx_hash_int64_keys_h(keys.ctypes.data_as(C.c_void_p), len(keys), 100000, out.ctypes.data_as(C.c_void_p)) == 0
+    assert out.tolist() == [hashing.hash_bucket(str(int(k)).encode(), 100000) for k in keys]
+    n = 23
+    u, i, lab = rng.integers(1, 10 ** 9, n), rng.integers(1, 10 ** 6, n), rng.integers(0, 2, n)
+    blob = b"".join(tfrecord.frame(tfrecord.encode_example({"label": [int(lab[r])], "u_id": [int(u[r])], "i_id": [int(i[r])]}))
+                    for r in range(n))
+    p = tmp_path / "part-r-00000"
+    p.write_bytes(blob)
+    got = list(uid_iid_input_fn([str(p)], 10, num_epochs=1, layout=layout))
+    assert [g[1].shape[0] for g in got] == [10, 10, 3]
+    ids = np.concatenate([g[0]["ids"] for g in got])
+    assert ids[:, 0].tolist() == [hashing.hash_bucket(str(int(k)).encode(), 100000) for k in i]      # slot 0 = i_id
+    assert ids[:, 1].tolist() == [hashing.hash_bucket(str(int(k)).encode(), 500000) for k in u]
+    assert np.array_equal(np.concatenate([g[1] for g in got]), lab.astype(np.float32))
+    bad = tmp_path / "bad"
+    bad.write_bytes(tfrecord.frame(tfrecord.encode_example({"label": [1], "u_id": [3]})))       # i_id missing
+    with pytest.raises(RsxError):
+        list(uid_iid_input_fn([str(bad)], 4, num_epochs=1, layout=layout))
