@@ -98,6 +98,12 @@ typedef struct {
   int32_t* segid;             /* nullable */
   int32_t max_rows_per_field, B, F, stride;
 } rsx_sort_job;
+/* rsx_gather_fm_fwd with the step's dedup sort (`sort_h`, see rsx_sort_job above) riding along as F extra workgroups of
+ * the same launch: the sort only needs the ids, and once it sits in the step's first launch every later launch may carry
+ * a slice of the untouched-row optimizer sweep (which reads the sort's slot map).  sort_h == NULL: plain gather.       */
+int rsx_gather_fm_fwd_sort(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
+                           float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int B, int F, int D,
+                           const rsx_sort_job* sort_h, rsx_stream_t stream);
 
 /* Workspace of the two-stage segment-sum (large / skewed batches), caller-owned, host struct; nch = ceil(stride/16):
  *   segid  written by rsx_field_sort (see above);  P float [F, nch, 2, D];  P1 float [F, nch, 2].

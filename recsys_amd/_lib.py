@@ -56,6 +56,7 @@ _SIGS = {
     "rsx_version": (C.c_int, []),
     "rsx_strerror": (C.c_char_p, [_I]),
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
+    "rsx_gather_fm_fwd_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P, _P]),
     "rsx_gather_two_fwd": (_I, [_P] * 10 + [_U64, _I, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rsx_field_sort_large": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),

@@ -78,6 +78,76 @@ __global__ void gather_fm_fwd_k(const float* __restrict__ tables, const float* _
   if (y1 != nullptr && lane == 0) y1[b] = a1;
 }
 
+// The same gather with the step's dedup sort riding along: workgroups [0, n_gather) gather 4 examples each (one wave per
+// example), the next F workgroups sort one field each (field_sort_block, ids only).  The sort is the first consumer-free
+// work of a training step -- its slot map tells which table rows the step touches -- so with it in the FIRST launch every
+// later launch (both tower-forward layers included) may carry a slice of the untouched-row optimizer sweep.
+template <int D>
+__global__ __launch_bounds__(256) void gather_fm_sort_k(const float* __restrict__ tables, const float* __restrict__ w1,
+                                                        const int32_t* __restrict__ row_off, const int32_t* __restrict__ ids,
+                                                        float* __restrict__ E, float* __restrict__ S, float* __restrict__ y1,
+                                                        float* __restrict__ y2, uint64_t w1_mask, int B, int F, int n_gather,
+                                                        const SortArgs sort) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t gs_lds[];
+  if ((int)blockIdx.x >= n_gather) {
+    field_sort_block(sort, blockIdx.x - n_gather, gs_lds);
+    return;
+  }
+  constexpr int LPR = D / 4;
+  constexpr int PPP = RSX_WAVE / LPR;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int q = lane % LPR, j = lane / LPR;
+  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(tables);
+  float4* __restrict__ E4 = reinterpret_cast<float4*>(E);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), qq = s;
+  float a1 = 0.f;
+  const int32_t* idb = ids + (size_t)b * F;
+  for (int f0 = j; f0 < F; f0 += 4 * PPP) {          // (the body of gather_fm_fwd_k: same loads, same summation order)
+    int row[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * PPP;
+      ok[k] = f < F;
+      const int fc = ok[k] ? f : F - 1;
+      row[k] = row_off[fc] + idb[fc];
+    }
+    float4 e[4];
+    float wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k] = T4[(size_t)row[k] * LPR + q];
+      wv[k] = w1 != nullptr ? w1[row[k]] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = f0 + k * PPP;
+      if (ok[k]) {
+        E4[((size_t)b * F + f) * LPR + q] = e[k];
+        s = f4_add(s, e[k]);
+        qq = f4_add(qq, f4_mul(e[k], e[k]));
+        if (q == 0 && ((w1_mask >> f) & 1ull)) a1 += wv[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = LPR; m < RSX_WAVE; m <<= 1) {
+    s = f4_add(s, f4_shfl_xor(s, m));
+    qq = f4_add(qq, f4_shfl_xor(qq, m));
+    a1 += __shfl_xor(a1, m);
+  }
+  if (S != nullptr && j == 0) reinterpret_cast<float4*>(S)[(size_t)b * LPR + q] = s;
+  if (y2 != nullptr) {
+    float t = ((s.x * s.x - qq.x) + (s.y * s.y - qq.y)) + ((s.z * s.z - qq.z) + (s.w * s.w - qq.w));
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m);
+    if (lane == 0) y2[b] = 0.5f * t;
+  }
+  if (y1 != nullptr && lane == 0) y1[b] = a1;
+}
+
 // F = 1 (tf.nn.embedding_lookup of one table: DIN's item / category / history lookups, din/din.py:96-105): a plain row
 // gather.  The multi-field kernel would keep one wave per id with D/4 of its 64 lanes busy; here a wave serves 64/(D/4)
 // ids at once, one float4 per lane, fully coalesced on the output side.
@@ -784,6 +854,32 @@ extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
   RSX_DISPATCH_D(D, launch_gather, grid, block, rsx_s(stream), tables, w1, row_off, ids, E, S, y1, y2,
                  w1_field_mask, B, F);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+template <int D>
+static void launch_gather_sort(dim3 grid, size_t lds, hipStream_t st, const float* tables, const float* w1,
+                               const int32_t* row_off, const int32_t* ids, float* E, float* S, float* y1, float* y2,
+                               uint64_t mask, int B, int F, int n_gather, const SortArgs& sort) {
+  gather_fm_sort_k<D><<<grid, dim3(256), lds, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F, n_gather, sort);
+}
+
+extern "C" int rsx_gather_fm_fwd_sort(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
+                                      float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int B, int F,
+                                      int D, const rsx_sort_job* sort_h, rsx_stream_t stream) {
+  if (sort_h == nullptr) return rsx_gather_fm_fwd(tables, w1, row_off, ids, E, S, y1, y2, w1_field_mask, B, F, D, stream);
+  if (B <= 0 || F <= 0 || F > 64 || !d_ok(D)) return RSX_EINVAL;
+  if (!tables || !row_off || !ids || !E) return RSX_EINVAL;
+  if ((y1 != nullptr) != (w1 != nullptr)) return RSX_EINVAL;
+  if (y2 != nullptr && S == nullptr) return RSX_EINVAL;
+  SortArgs sa;
+  size_t lds = 0;
+  const int rc = sort_job_args(*sort_h, sa, &lds);
+  if (rc != RSX_OK) return rc;
+  const int n_gather = (B + 3) / 4;
+  RSX_DISPATCH_D(D, launch_gather_sort, dim3((unsigned)(n_gather + sort_h->F)), lds, rsx_s(stream), tables, w1, row_off, ids, E,
+                 S, y1, y2, w1_field_mask, B, F, n_gather, sa);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

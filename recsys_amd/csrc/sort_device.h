@@ -257,3 +257,19 @@ static inline size_t rsx_sort_lds_bytes(const SortArgs& a, int threads) {
   if (a.n <= 512 && a.n <= threads) return ((size_t)a.n + 32) * sizeof(uint32_t);
   return ((size_t)2 * a.n + 32 + (size_t)(threads / 64) * 256) * sizeof(uint32_t);
 }
+
+// host: a rsx_sort_job (the step's dedup sort carried by another launch as extra 256-thread workgroups) -> SortArgs;
+// raises *lds to what field_sort_block needs
+static inline int sort_job_args(const rsx_sort_job& j, SortArgs& out, size_t* lds) {
+  if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
+      j.stride < j.B || j.max_rows_per_field <= 0)
+    return RSX_EINVAL;
+  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.segid, j.B, j.F, j.stride, 0, 0};
+  const int rc = rsx_sort_args(out, j.max_rows_per_field, 256);
+  if (rc != RSX_OK) return rc;
+  const size_t need = rsx_sort_lds_bytes(out, 256);
+  if (need > 64 * 1024) return RSX_EUNSUPPORTED;         // carrier launches keep the default 64 KB window (B <= 4096)
+  if (need > *lds) *lds = need;
+  return RSX_OK;
+}
+

@@ -943,19 +943,6 @@ __global__ __launch_bounds__(1024) void tower_reduce_partials_k(double* __restri
 }
 
 // validates a piggy-backed sort job for a 256-thread carrier launch and grows the launch's dynamic LDS if needed
-static inline int sort_job_args(const rsx_sort_job& j, SortArgs& out, size_t* lds) {
-  if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
-      j.stride < j.B || j.max_rows_per_field <= 0)
-    return RSX_EINVAL;
-  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.segid, j.B, j.F, j.stride, 0, 0};
-  const int rc = rsx_sort_args(out, j.max_rows_per_field, 256);
-  if (rc != RSX_OK) return rc;
-  const size_t need = rsx_sort_lds_bytes(out, 256);
-  if (need > 64 * 1024) return RSX_EUNSUPPORTED;         // carrier launches keep the default 64 KB window (B <= 4096)
-  if (need > *lds) *lds = need;
-  return RSX_OK;
-}
-
 // consumers read pre-reduced statistics (1 row) when the batch is large: see rsx_tower_reduce_partials
 static inline int stat_rows(int B) { return B > 512 ? 1 : (B + TM - 1) / TM; }
 

@@ -138,11 +138,18 @@ def _train_fused(store, arena, ids, labels, params, masks):
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids
         zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)
         job = None
-        if ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in a tower launch; larger sorts are faster with 1024 threads of their own
+        if ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
             job = arena.sort_job(ids_sort)
-        else:
+        # RSX_SORT_IN_GATHER=1: the sort rides in the GATHER launch (the step's first) instead, so that both tower-forward
+        # launches may carry sweep slices too.  Measured (r02, MI355X): the same 93.4 us with the forward shares at 0, and
+        # 106-108 us with any share given to the forward launches ([1,1,1,3,3,2.5] ...): a forward launch is a pure chain of
+        # dependent L2 accesses and stretches by more than the slice it hides.  So the default stays the r01 form.
+        in_gather = job is not None and overlap and os.environ.get("RSX_SORT_IN_GATHER", "0") == "1"
+        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv, sort_job=job if in_gather else None)
+        if in_gather:
+            job = None
+        elif job is None:
             arena.field_sort(ids_sort)
         sweeps, hot, last_sweep = None, None, None
         if overlap:
@@ -154,7 +161,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             sweeps = store.opt.cold_slices(cold[::-1], store.sweep_weights)      # [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
             last_sweep = sweeps[-1] if len(sweeps) == 2 * len(store.tower.widths) + 2 else None
             sweeps = sweeps[:2 * len(store.tower.widths) + 1]
-            assert job is None or sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
+            assert job is None or sweeps[0] is None, "a forward launch that carries the sort cannot carry a sweep slice"
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,

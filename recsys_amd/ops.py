@@ -147,15 +147,21 @@ class EmbeddingArena:
         j.max_rows_per_field, j.B, j.F, j.stride = self.max_rows, B, self.F, self.stride
         return j
 
-    def gather(self, ids, fm=False, first_order=False, S_out=None):
+    def gather(self, ids, fm=False, first_order=False, S_out=None, sort_job=None):
         """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd).  S_out: caller-owned [B,D] buffer for S
-        (e.g. a view of the data-parallel send block)."""
+        (e.g. a view of the data-parallel send block).  sort_job: the step's dedup sort (EmbeddingArena.sort_job) rides in
+        this launch as extra workgroups (rsx_gather_fm_fwd_sort)."""
         B = ids.shape[0]
         dev = self.tables.device
         E = torch.empty(B, self.F * self.D, device=dev)
         S = (S_out if S_out is not None else torch.empty(B, self.D, device=dev)) if fm else None
         y2 = torch.empty(B, device=dev) if fm else None
         y1 = torch.empty(B, device=dev) if first_order else None
+        if sort_job is not None:
+            check(lib().rsx_gather_fm_fwd_sort(_ptr(self.tables), _ptr(self.w1) if first_order else None, _ptr(self.row_off),
+                                               _ptr(ids), _ptr(E), _ptr(S), _ptr(y1), _ptr(y2), self.w1_mask,
+                                               B, self.F, self.D, C.byref(sort_job), _stream()), "rsx_gather_fm_fwd_sort")
+            return E, S, y1, y2
         check(lib().rsx_gather_fm_fwd(_ptr(self.tables), _ptr(self.w1) if first_order else None, _ptr(self.row_off),
                                       _ptr(ids), _ptr(E), _ptr(S), _ptr(y1), _ptr(y2), self.w1_mask,
                                       B, self.F, self.D, _stream()), "rsx_gather_fm_fwd")

@@ -387,3 +387,28 @@ def test_overlapped_optimizer_is_bit_identical_to_the_plain_path():
     for name, x, y in zip(("tables", "m", "v", "w1", "dense"), *res):
         assert torch.isfinite(x).all(), name
         assert torch.equal(x, y), (name, float((x - y).abs().max()))
+
+
+def test_gather_with_the_sort_riding_along_equals_the_two_separate_launches():
+    """rsx_gather_fm_fwd_sort: gather outputs and every sort output identical to rsx_gather_fm_fwd + rsx_field_sort."""
+    from oracle import criteo
+    from recsys_amd.ops import EmbeddingArena
+    from tests.parity_util import synth_ids
+    row_off = criteo.row_offsets()
+    rng = np.random.default_rng(5)
+    for B in (256, 100, 1024):
+        a = EmbeddingArena(row_off, 16, 1024, "cuda", with_w1=True, w1_field_mask=(1 << 39) - 1)
+        b = EmbeddingArena(row_off, 16, 1024, "cuda", with_w1=True, w1_field_mask=(1 << 39) - 1)
+        with torch.no_grad():
+            a.tables.normal_(); a.w1.normal_()
+            b.tables.copy_(a.tables); b.w1.copy_(a.w1)
+        for rep in range(2):                                  # the second round also clears the first round's slot map
+            ids = torch.from_numpy(synth_ids(rng, B, row_off)).cuda()
+            ra = a.gather(ids, fm=True, first_order=True, sort_job=a.sort_job(ids))
+            rb = b.gather(ids, fm=True, first_order=True)
+            b.field_sort(ids)
+            torch.cuda.synchronize()
+            for x, y in zip(ra, rb):
+                assert torch.equal(x, y)
+            for k in ("perm", "seg_off", "uniq_row", "nuniq", "slot"):
+                assert torch.equal(getattr(a, k), getattr(b, k)), (B, rep, k)
