@@ -400,6 +400,12 @@ int rsx_cin_out_fwd(const float* const* outs_h, const int32_t* sizes_h, int L, c
  * sum_b gs[b] * sum_d out_k[b,n,d], dbout = sum_b gs[b]; fixed summation order.                                      */
 int rsx_cin_out_bwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy, float* gs,
                     float* dWout, float* dbout, int B, int D, rsx_stream_t stream);
+/* The same launch with one more workgroup that computes the gradient of the numeric part of xdeepfm.py's linear_net kernel
+ * (xdeepfm/xdeepfm.py:127,131): dwnum[j] = sum_b logx[b, j] * g_lin[b], j < nnum (fixed order) -- instead of a library
+ * gemv launch of its own.  dwnum == NULL: exactly rsx_cin_out_bwd.                                                    */
+int rsx_cin_out_bwd_lin(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy, float* gs,
+                        float* dWout, float* dbout, const float* logx, const float* g_lin, float* dwnum, int nnum, int B,
+                        int D, rsx_stream_t stream);
 /* xDeepFM's input side in one launch (xdeepfm/xdeepfm.py:125-131,185): the same ids gather the rows of TWO table sets
  * (E1 [B,F*D] for the CIN, E2 for the DNN: the script calls input_layer twice) and y1[b] = sum of the indicator weights
  * w1[row] over the fields of w1_field_mask + <num_x[b,:], num_w> -- the pre-activation of linear_net = dense([ND numeric

@@ -98,6 +98,7 @@ _SIGS = {
     "rsx_cin_prep_bf16_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "rsx_cin_out_bwd_lin": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rsx_hash_fp64_h": (_I, [_P, _P, C.c_int64, _P]),
     "rsx_fingerprint64_h": (C.c_uint64, [_P, C.c_size_t]),
     "rsx_bucketize_log_h": (_I, [_P, C.c_int64, _P, _I, _F, _P]),

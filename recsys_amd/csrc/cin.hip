@@ -782,6 +782,12 @@ struct CinOutArgs {
   float* gs;           // [B]  out: gy * relu'(y)
   float* dWout;        // [tot]
   float* dbout;        // [1]
+  // optional rider (xdeepfm/xdeepfm.py:127,131): gradient of the numeric part of the linear_net kernel,
+  // dwnum[j] = sum_b logx[b, j] * g_lin[b] -- one more workgroup of this launch instead of a library gemv launch
+  const float* logx;   // [B, nnum]
+  const float* g_lin;  // [B]
+  float* dwnum;        // [nnum]
+  int nnum;
 };
 
 // one wave per example: lane e walks the float4 of each map, fixed-order butterfly at the end
@@ -819,6 +825,27 @@ __global__ __launch_bounds__(256) void cin_out_fwd_k(const CinOutArgs p) {
 __global__ __launch_bounds__(1024) void cin_out_bwd_k(const CinOutArgs p) {
   __shared__ float red[16][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (p.dwnum != nullptr && blockIdx.x == gridDim.x - 2) {      // wave w: columns w, w + 16, ...; lanes stride the batch
+    for (int j = wv; j < p.nnum; j += 16) {
+      float s = 0.f;
+      for (int b0 = lane; b0 < p.B; b0 += 64 * 8) {
+        float x[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + 64 * u;
+          const int bc = b < p.B ? b : p.B - 1;
+          x[u] = p.logx[(size_t)bc * p.nnum + j];
+          g[u] = b < p.B ? p.g_lin[bc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u] * g[u];
+      }
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+      if (lane == 0) p.dwnum[j] = s;
+    }
+    return;
+  }
   if (blockIdx.x == gridDim.x - 1) {
     float s = 0.f;
     for (int b = tid; b < p.B; b += 1024) {
@@ -892,16 +919,24 @@ extern "C" int rsx_cin_out_fwd(const float* const* outs_h, const int32_t* sizes_
   return RSX_OK;
 }
 
-extern "C" int rsx_cin_out_bwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy,
-                               float* gs, float* dWout, float* dbout, int B, int D, rsx_stream_t stream) {
+extern "C" int rsx_cin_out_bwd_lin(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy,
+                                   float* gs, float* dWout, float* dbout, const float* logx, const float* g_lin,
+                                   float* dwnum, int nnum, int B, int D, rsx_stream_t stream) {
   CinOutArgs a{};
   const int rc = cin_out_args(a, outs_h, sizes_h, L, B, D);
   if (rc != RSX_OK) return rc;
   if (!y || !gy || !gs || !dWout || !dbout) return RSX_EINVAL;
+  if (dwnum != nullptr && (!logx || !g_lin || nnum <= 0)) return RSX_EINVAL;
   a.y = const_cast<float*>(y); a.gy = gy; a.gs = gs; a.dWout = dWout; a.dbout = dbout;
+  a.logx = logx; a.g_lin = g_lin; a.dwnum = dwnum; a.nnum = nnum;
   int tiles = 0;
   for (int k = 0; k < L; ++k) tiles += (sizes_h[k] + 15) / 16;
-  hipLaunchKernelGGL(cin_out_bwd_k, dim3(tiles + 1), dim3(1024), 0, rsx_s(stream), a);
+  hipLaunchKernelGGL(cin_out_bwd_k, dim3(tiles + 1 + (dwnum != nullptr ? 1 : 0)), dim3(1024), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_cin_out_bwd(const float* const* outs_h, const int32_t* sizes_h, int L, const float* y, const float* gy,
+                               float* gs, float* dWout, float* dbout, int B, int D, rsx_stream_t stream) {
+  return rsx_cin_out_bwd_lin(outs_h, sizes_h, L, y, gy, gs, dWout, dbout, nullptr, nullptr, nullptr, 0, B, D, stream);
 }

@@ -921,15 +921,18 @@ class CinNet:
                                     B, self.D, _stream()), "rsx_cin_out_fwd")
         return self.y[:B]
 
-    def backward(self, X0, P, gy, sweeps=None, dX0_out=None):
+    def backward(self, X0, P, gy, sweeps=None, dX0_out=None, lin=None):
         """gy [B]: gradient wrt cin_y.  Writes the cin.* gradients into P[...].grad and returns dX0 [B,F,D] (internal
         buffer, or dX0_out: a caller-owned contiguous [B,F,D] buffer).  sweeps[k]: slice of the untouched-row optimizer sweep
         carried by layer k's weight-gradient launch (bf16: ONE launch computes all layers' weight gradients, so at most one
         slice may be given)."""
         B, L = X0.shape[0], self.L
         dX0 = self.dX0 if dX0_out is None else dX0_out
-        check(lib().rsx_cin_out_bwd(self._outs_h, self._sizes_h, L, _ptr(self.y), _ptr(gy), _ptr(self.gs), _ptr(P["cin.Wout"].grad),
-                                    _ptr(P["cin.bout"].grad), B, self.D, _stream()), "rsx_cin_out_bwd")
+        # lin = (logx [B, n], g_lin [B], dwnum [n]): the numeric linear_net gradient rides in the head's backward launch
+        lx, gl, dwn = lin if lin is not None else (None, None, None)
+        check(lib().rsx_cin_out_bwd_lin(self._outs_h, self._sizes_h, L, _ptr(self.y), _ptr(gy), _ptr(self.gs),
+                                        _ptr(P["cin.Wout"].grad), _ptr(P["cin.bout"].grad), _ptr(lx), _ptr(gl), _ptr(dwn),
+                                        0 if lx is None else lx.shape[1], B, self.D, _stream()), "rsx_cin_out_bwd_lin")
         wout = P["cin.Wout"].data_ptr()
         for k in range(L - 1, -1, -1):
             Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])

@@ -111,9 +111,19 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         # data-parallel: the optimizer sees the GLOBAL batch -- the dedup sort runs over the all-gathered ids (issued first:
         # they depend on nothing of the step), so the same exact split of the TF-1 update applies as on one GPU
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if zc else ids
+        job = None
         if dp is None or zc:
-            a1.field_sort(ids_sort)                                         # serves a2 as well (share_sort_of)
             a2.last_B = ids_sort.shape[0]
+            split = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
+            # The sort (it serves a2 as well, share_sort_of) rides in the tower's first forward launch when no sweep slice is
+            # scheduled before that launch (slices read the sort's slot map) -- the bf16 default; otherwise it runs first.
+            ride = (split and store.cin.bf16 and not os.environ.get("RSX_XDFM_SWEEP_WEIGHTS")
+                    and ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048"))
+                    and os.environ.get("RSX_XDFM_SORT_RIDE", "1") == "1")
+            if ride:
+                job = a1.sort_job(ids_sort)
+            else:
+                a1.field_sort(ids_sort)
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
                 # (700 MB of streaming) rides in the CIN forward and weight-gradient launches (MFMA work, little HBM); the touched rows
@@ -156,10 +166,11 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),       # replicas draw independent dropout patterns
-            sweeps=tower_sweeps, outs=(dX2v, glv, None) if zc else None)
+            sort_job=job, sort_in_fwd=True, sweeps=tower_sweeps, outs=(dX2v, glv, None) if zc else None)
+        logx_c = logx.contiguous()
         dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:],
-                                 dX0_out=dX1v.view(B, a1.F, a1.D) if zc else None).view(B, -1)   # cin.* grads land in the dense arena
-        torch.mv(logx.t(), g_lin, out=P["lin.wnum"].grad)
+                                 dX0_out=dX1v.view(B, a1.F, a1.D) if zc else None,
+                                 lin=(logx_c, g_lin, P["lin.wnum"].grad)).view(B, -1)   # cin.* and lin.wnum grads land in the dense arena
 
     def train_op():
         with torch.no_grad():

@@ -39,6 +39,8 @@ def test_cin_entry_points_reject_bad_arguments(L):
     assert L.rsx_cin_out_fwd(outs, sizes, 2, None, P, P, 4, 16, None) == EINVAL
     assert L.rsx_cin_out_fwd(outs, sizes, 2, P, P, P, 0, 16, None) == OK                                  # empty batch
     assert L.rsx_cin_out_bwd(outs, sizes, 2, P, P, None, P, P, 4, 16, None) == EINVAL                     # no gs
+    assert L.rsx_cin_out_bwd_lin(outs, sizes, 2, P, P, P, P, P, None, P, P, 13, 4, 16, None) == EINVAL    # dwnum without logx
+    assert L.rsx_cin_out_bwd_lin(outs, sizes, 2, P, P, P, P, P, P, P, P, 0, 4, 16, None) == EINVAL        # dwnum with nnum 0
     assert L.rsx_cin_layer_fwd(P, P, P, P, P, 4, 39, 200, 16, 16, None, None) == EUNSUPPORTED             # H > 128
     # backward: neither dout nor the direct-connect pair
     assert L.rsx_cin_layer_bwd(P, P, P, P, None, None, None, P, 0, C.c_void_p(0x2000), 0, P, P, P, 4, 39, 39, 16, 16, None, None) == EINVAL
