@@ -488,7 +488,8 @@ typedef struct {
 } rsx_cin_dw_job;
 int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
                               const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
-                              void* ws, int B, int F, int H, int N, int D, rsx_stream_t stream);
+                              void* ws, int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h,
+                              rsx_stream_t stream);
 int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
                         const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,

@@ -289,6 +289,23 @@ struct AdamSlice {
   AdamArgs args;
   uint32_t blk_lo, n_blk;     // n_blk == 0: no slice
 };
+// Workgroup order of a carrier launch with T workgroups of its own and R riders.  Appending the riders after the carrier's
+// workgroups serialises the two when T alone fills the chip (every slot is taken by a latency/MFMA-bound tile until the
+// first ones retire; the HBM-bound riders then run alone: measured, cin_bwd_dw_bf16_k 35 us + 27 us = 62 us).  Dealing them
+// in alternating runs of 8 (consecutive workgroup ids go to the 8 XCDs round-robin, so both kinds land on every XCD) makes
+// both resident from the start.  -> rider? and the index within its kind.
+struct RiderSplit {
+  bool rider;
+  uint32_t idx;
+};
+__device__ __forceinline__ RiderSplit rider_split(const uint32_t lin, const uint32_t T, const uint32_t R) {
+  const uint32_t m8 = (T < R ? T : R) & ~7u;          // alternating part: m8 of each kind
+  if (lin < 2u * m8) return {(lin & 8u) != 0u, ((lin >> 4) << 3) | (lin & 7u)};
+  const uint32_t r = lin - 2u * m8;                   // the rest: the carrier's own first
+  if (r < T - m8) return {false, m8 + r};
+  return {true, m8 + (r - (T - m8))};
+}
+
 static inline int adam_build_slice(const rsx_adam_slice* sl_h, AdamSlice& out) {
   out.n_blk = 0;
   out.blk_lo = 0;

@@ -87,8 +87,8 @@ struct CbFwdArgs {
   const float* c;       // [N]
   float* out;           // [B, N, 16]
   int B, F, H, N, N16, Hp;
-  int nby;              // tile rows of the grid; rows >= nby carry the optimizer sweep slice
-  AdamSlice sweep;
+  int nby;              // tile rows: N16/16 * nby tiles, dealt together with the riders of the optimizer sweep slice
+  AdamSlice sweep;      // (rider_split) over the grid's linear workgroup index
 };
 
 // grid = (N16/16, ceil(B/2) [+ sweep rows]), block = 256.  The workgroup owns examples 2*blockIdx.y, +1 and the 16
@@ -101,11 +101,12 @@ struct CbFwdArgs {
 template <int KS>
 __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.y >= p.nby) {
-    const uint32_t lin = ((uint32_t)blockIdx.y - (uint32_t)p.nby) * gridDim.x + blockIdx.x;
-    if (lin < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + lin);
+  const RiderSplit rs = rider_split(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * (uint32_t)p.nby, p.sweep.n_blk);
+  if (rs.rider) {
+    if (rs.idx < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + rs.idx);
     return;
   }
+  const int tile_x = (int)(rs.idx % gridDim.x), tile_y = (int)(rs.idx / gridDim.x);
   constexpr int FG = KS >= 4 ? 1 : 2;            // fields per load group (register budget: 128 per lane, 4 waves per SIMD)
   constexpr int HPP = 32 * KS + 8;               // padded h-stride of the transposed Xk tile (conflict-free b128 reads)
   float* sX0 = lds;                              // [2][F*16]
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   bf16_t* sXk = reinterpret_cast<bf16_t*>(sR + 4 * 2 * 256);     // [2][16][HPP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  const int b0 = blockIdx.y * 2;
+  const int n0 = tile_x * 16;
+  const int b0 = tile_y * 2;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e = tid; e < 2 * p.F * 4; e += 256) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   // A operand: Xk[b][h = 32 ks + 8 kq + j][d = i], the same for every field -> registers for the whole kernel (filled
   // from the LDS tile after the barrier below)
   bf16x8 a[2][KS];
-  const bf16_t* wbase = p.Wt16 + ((size_t)blockIdx.x * KS * 64 + lane) * 8;
+  const bf16_t* wbase = p.Wt16 + ((size_t)tile_x * KS * 64 + lane) * 8;
   const size_t fstride = (size_t)p.N16 * p.Hp;
   bf16x8 wa[FG][KS], wb[FG][KS];
   auto load_group = [&](int g0, bf16x8 (*w)[KS]) {        // group g0: fields wv + 4*(g0 + g)
@@ -216,6 +217,8 @@ struct CbDxArgs {
   int acc_dxk, acc_dx0;
   int B, F, H, N, H16, N16, Np;
   int HT, PART;
+  int ntile;            // ceil(B/2) workgroups of the layer, dealt together with the riders of the optimizer sweep slice
+  AdamSlice sweep;      // (blockDim / 256 sweep blocks per rider workgroup)
 };
 
 // grid = ceil(B/2), block = 64 * HT * PART (HT = H16/16 h tiles; the fields are dealt to PART waves per tile so that the
@@ -233,9 +236,17 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
   float* sP = sX0 + 2 * p.F * CB_D;                              // [HT][2][F][16]
   float* sDx = sP + HT * 2 * p.F * CB_D;                         // [PART-1][HT][2][4][64] dXk partials of parts 1..
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const uint32_t per = (uint32_t)nthr >> 8;      // sweep blocks per rider workgroup
+  const RiderSplit rs = rider_split(blockIdx.x, (uint32_t)p.ntile, (p.sweep.n_blk + per - 1) / per);
+  if (rs.rider) {
+    const uint32_t blk = rs.idx * per + ((uint32_t)tid >> 8);
+    if (((uint32_t)tid >> 8) < per && blk < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + blk, tid & 255);
+    return;
+  }
+  const int tile = (int)rs.idx;
   const int ht = wave % HT, part = wave / HT;
   const int i = lane & 15, kq = lane >> 4;
-  const int b0 = blockIdx.x * 2;
+  const int b0 = tile * 2;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e = tid; e < 16 * NPP; e += nthr) reinterpret_cast<uint32_t*>(sDpT)[e] = 0u;     // k padding must read as zero
   __syncthreads();
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
       bf16x4 q;
       q[0] = (bf16_t)v.x; q[1] = (bf16_t)v.y; q[2] = (bf16_t)v.z; q[3] = (bf16_t)v.w;
       {   // fragment of the dW kernel: lane (i = n & 15, kq = 2 e + (d >> 3)), elements j = d & 7
-        const size_t fr = (((size_t)blockIdx.x * (p.N16 >> 4) + (n >> 4)) * 64 + (2 * e + (dq >> 1)) * 16 + (n & 15)) * 8 + (dq & 1) * 4;
+        const size_t fr = (((size_t)tile * (p.N16 >> 4) + (n >> 4)) * 64 + (2 * e + (dq >> 1)) * 16 + (n & 15)) * 8 + (dq & 1) * 4;
         *reinterpret_cast<bf16x4*>(p.dpre16 + fr) = q;
       }
       bf16_t* t = sDpT + (size_t)e * 16 * NPP + n;
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
     }
     s += __shfl_xor(s, 1);                        // the 4 d-quarters of column n sit in adjacent lanes
     s += __shfl_xor(s, 2);
-    if (dq == 0) p.dc_part[(size_t)blockIdx.x * p.N16 + n] = s;
+    if (dq == 0) p.dc_part[(size_t)tile * p.N16 + n] = s;
   }
   for (int e = tid; e < 2 * p.F * 4; e += nthr) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
@@ -393,45 +404,46 @@ struct CbDwArgs {
   AdamSlice sweep;
 };
 
-// grid = (sum of the jobs' tiles + njobs + sweep blocks / 2), block = 512 = 8 waves that split the k-steps (pairs of
-// examples).  After the tiles: one block per job adds its dc partials in order; the rest carry the optimizer sweep slice
-// (two 256-thread sweep blocks per workgroup).  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is formed in fp32 and rounded
+// grid = (njobs + sum of the jobs' tiles + sweep blocks / 2), block = 512 = 8 waves that split the k-steps (pairs of
+// examples).  First one block per job that adds its dc partials in order; then the tiles, dealt together (rider_split) with
+// the workgroups that carry the optimizer sweep slice (two 256-thread sweep blocks each).  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is formed in fp32 and rounded
 // once.  Partial tiles: waves 4..7 -> LDS, waves 0..3 add; waves 1..3 -> LDS, wave 0 adds.
 template <int FT, int NT>
 __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   __shared__ float red[4][FT * NT][256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int total = p.job[p.njobs - 1].tile_end;
-  if ((int)blockIdx.x >= total) {
-    const int lin = (int)blockIdx.x - total;
-    if (lin < p.njobs) {                          // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
-      const CbDwJob& jb = p.job[lin];
-      const int G = (p.B + 1) / 2;
-      for (int n = tid; n < jb.N; n += 512) {
-        float s = 0.f;
-        int g = 0;
-        for (; g + 8 <= G; g += 8) {
-          float t[8];
+  if ((int)blockIdx.x < p.njobs) {                // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
+    const CbDwJob& jb = p.job[blockIdx.x];
+    const int G = (p.B + 1) / 2;
+    for (int n = tid; n < jb.N; n += 512) {
+      float s = 0.f;
+      int g = 0;
+      for (; g + 8 <= G; g += 8) {
+        float t[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = jb.dc_part[(size_t)(g + u) * jb.N16 + n];
+        for (int u = 0; u < 8; ++u) t[u] = jb.dc_part[(size_t)(g + u) * jb.N16 + n];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) s += t[u];
-        }
-        for (; g < G; ++g) s += jb.dc_part[(size_t)g * jb.N16 + n];
-        jb.dc[n] = s;
+        for (int u = 0; u < 8; ++u) s += t[u];
       }
-    } else {
-      const uint32_t blk = 2 * (uint32_t)(lin - p.njobs) + (uint32_t)(tid >> 8);
-      if (blk < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + blk, tid & 255);
+      for (; g < G; ++g) s += jb.dc_part[(size_t)g * jb.N16 + n];
+      jb.dc[n] = s;
     }
     return;
   }
+  const RiderSplit rs = rider_split(blockIdx.x - (uint32_t)p.njobs, (uint32_t)total, (p.sweep.n_blk + 1) / 2);
+  if (rs.rider) {
+    const uint32_t blk = 2 * rs.idx + (uint32_t)(tid >> 8);
+    if (blk < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + blk, tid & 255);
+    return;
+  }
+  const int tile = (int)rs.idx;
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < CB_MAXJ; ++k)
-    if (k < p.njobs && (int)blockIdx.x >= p.job[k - 1].tile_end) ji = k;
+    if (k < p.njobs && tile >= p.job[k - 1].tile_end) ji = k;
   const CbDwJob& jb = p.job[ji];
-  const int local = (int)blockIdx.x - (ji ? p.job[ji - 1].tile_end : 0);
+  const int local = tile - (ji ? p.job[ji - 1].tile_end : 0);
   const int bx = local % jb.gx, by = (local / jb.gx) % jb.HT, bz = local / (jb.gx * jb.HT);
   const int i = lane & 15, kq = lane >> 4;
   const int ntg = bx * NT, ht = by, f0 = bz * FT;
@@ -637,7 +649,7 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
 
 static int cb_launch_dx(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
                         const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0, void* ws,
-                        int B, int F, int H, int N, int D, rsx_stream_t stream) {
+                        int B, int F, int H, int N, int D, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !w16 || !out || !dXk || !dX0 || !ws) return RSX_EINVAL;
@@ -650,11 +662,14 @@ static int cb_launch_dx(const float* X0, const float* Xk, const void* w16, const
   float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
   const int PART = 16 / HT;                            // HT * PART <= 16 waves (1024 threads) per workgroup, HT <= 8
   CbDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dX0, dpre16, dc_part, acc_dxk, acc_dx0,
-             B, F, H, N, H16, N16, Np, HT, PART};
+             B, F, H, N, H16, N16, Np, HT, PART, (B + 1) / 2, {}};
+  const int rcs = adam_build_slice(sweep_h, a.sweep);
+  if (rcs != RSX_OK) return rcs;
   const size_t lds = (size_t)2 * 16 * (Np + 8) * 2 +
                      ((size_t)2 * F * CB_D + (size_t)HT * 2 * F * CB_D + (size_t)(PART - 1) * HT * 2 * 256) * sizeof(float);
   if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
-  const dim3 grid((unsigned)((B + 1) / 2)), block((unsigned)(64 * HT * PART));
+  const unsigned per = (unsigned)(64 * HT * PART) / 256;                     // sweep blocks per rider workgroup (>= 3)
+  const dim3 grid((unsigned)a.ntile + (a.sweep.n_blk + per - 1) / per), block((unsigned)(64 * HT * PART));
   const void* fn = Np / 32 == 1 ? reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<1>)
                  : Np / 32 == 2 ? reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<2>)
                  : Np / 32 == 3 ? reinterpret_cast<const void*>(cin_bwd_dx_bf16_k<3>)
@@ -707,8 +722,8 @@ static int cb_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs
 extern "C" int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16, const float* out,
                                          const float* dout, const float* gs, const float* wout, float* dXk, int acc_dxk,
                                          float* dX0, int acc_dx0, void* ws, int B, int F, int H, int N, int D,
-                                         rsx_stream_t stream) {
-  return cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, stream);
+                                         const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  return cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, sweep_h, stream);
 }
 
 extern "C" int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
@@ -746,7 +761,7 @@ extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const vo
                                       float* dW, float* dc, void* ws, int B, int F, int H, int N, int D,
                                       const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (!dW || !dc) return RSX_EINVAL;
-  const int rc = cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, stream);
+  const int rc = cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, nullptr, stream);
   if (rc != RSX_OK || B == 0) return rc;
   const rsx_cin_dw_job job{Xk, ws, dW, dc, H, N};
   return cb_launch_dw(X0, &job, 1, B, F, D, sweep_h, stream);

@@ -924,8 +924,8 @@ class CinNet:
     def backward(self, X0, P, gy, sweeps=None, dX0_out=None, lin=None):
         """gy [B]: gradient wrt cin_y.  Writes the cin.* gradients into P[...].grad and returns dX0 [B,F,D] (internal
         buffer, or dX0_out: a caller-owned contiguous [B,F,D] buffer).  sweeps[k]: slice of the untouched-row optimizer sweep
-        carried by layer k's weight-gradient launch (bf16: ONE launch computes all layers' weight gradients, so at most one
-        slice may be given)."""
+        carried by layer k's backward launch; on the bf16 path (L data-gradient launches, then ONE launch with all layers'
+        weight gradients) sweeps has L + 1 entries: [dx of layer 0 .. L-1, the weight-gradient launch]."""
         B, L = X0.shape[0], self.L
         dX0 = self.dX0 if dX0_out is None else dX0_out
         # lin = (logx [B, n], g_lin [B], dwnum [n]): the numeric linear_net gradient rides in the head's backward launch
@@ -944,24 +944,22 @@ class CinNet:
             if self.bf16:       # w16[k] was prepared by this step's forward (the filters do not change in between)
                 check(lib().rsx_cin_layer_bwd_dx_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                                       C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
-                                                      _ptr(self.ws16[k]), B, self.F, H, self.sizes[k], self.D, _stream()),
-                      "rsx_cin_layer_bwd_dx_bf16")
+                                                      _ptr(self.ws16[k]), B, self.F, H, self.sizes[k], self.D,
+                                                      None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k]),
+                                                      _stream()), "rsx_cin_layer_bwd_dx_bf16")
                 continue
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
             check(lib().rsx_cin_layer_bwd(_ptr(X0), _ptr(Xk), _ptr(P[f"cin.W{k}"]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
                                           self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
-        if self.bf16:           # every layer's weight gradient in ONE launch; it carries the sum of the dW sweep slices' first
+        if self.bf16:           # every layer's weight gradient in ONE launch
             jobs = (_lib.CinDwJob * L)()
             for k in range(L):
                 Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])
                 jobs[k] = _lib.CinDwJob(Xk.data_ptr(), self.ws16[k].data_ptr(), P[f"cin.W{k}"].grad.data_ptr(),
                                         P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k])
-            sw = None
-            if sweeps is not None:
-                live = [x for x in sweeps if x is not None]
-                assert len(live) <= 1, "bf16 CinNet: one weight-gradient launch carries ONE sweep slice"
-                sw = C.byref(live[0]) if live else None
+            assert sweeps is None or len(sweeps) == L + 1, "bf16 CinNet.backward: L + 1 sweep slots"
+            sw = None if sweeps is None or sweeps[L] is None else C.byref(sweeps[L])
             check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
         return dX0[:B]

@@ -111,47 +111,49 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         # data-parallel: the optimizer sees the GLOBAL batch -- the dedup sort runs over the all-gathered ids (issued first:
         # they depend on nothing of the step), so the same exact split of the TF-1 update applies as on one GPU
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if zc else ids
-        job = None
+        job, ride = None, False
         if dp is None or zc:
             a2.last_B = ids_sort.shape[0]
-            split = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
             # The sort (it serves a2 as well, share_sort_of) rides in the tower's first forward launch when no sweep slice is
-            # scheduled before that launch (slices read the sort's slot map) -- the bf16 default; otherwise it runs first.
-            ride = (split and store.cin.bf16 and not os.environ.get("RSX_XDFM_SWEEP_WEIGHTS")
-                    and ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048"))
+            # scheduled before or in that launch (slices read the sort's slot map); otherwise it runs first.
+            ride = (ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048"))
                     and os.environ.get("RSX_XDFM_SORT_RIDE", "1") == "1")
-            if ride:
-                job = a1.sort_job(ids_sort)
-            else:
-                a1.field_sort(ids_sort)
+            job = a1.sort_job(ids_sort)
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
                 # (700 MB of streaming) rides in the CIN forward and weight-gradient launches (MFMA work, little HBM); the touched rows
                 # and the dense variables follow the scatter in one small launch
                 c1, h1 = a1.adam_split_segments()
                 c2, h2 = a2.adam_split_segments()
-                # carriers, in launch order: [CIN fwd_0..fwd_{L-1} | tower fwd_0, fwd_1, head, bwd_1, bwd_0 | CIN dW_{L-1}..dW_0 (ONE
-                # launch on the bf16 path) | scatter].  Default shares: the fp32 CIN launches are long MFMA kernels and take the sweep by their flops;
-                # the bf16 CIN launches are a few microseconds each, so there the latency-bound tower / scatter launches
-                # carry most of it (weights measured on MI355X; RSX_XDFM_SWEEP_WEIGHTS overrides).
+                # carriers, in launch order: [CIN fwd_0..fwd_{L-1} | tower fwd_0, fwd_1, head, bwd_1, bwd_0 | CIN backward:
+                # bf16 dx_{L-1}..dx_0 then ONE launch with every layer's dW (L + 1 launches); fp32 bwd_{L-1}..bwd_0 | scatter].
+                # Default shares: the fp32 CIN launches are long MFMA kernels and take the sweep by their flops; on the
+                # bf16 path every backward launch carries a share (weights measured on MI355X; RSX_XDFM_SWEEP_WEIGHTS
+                # overrides).
                 w = [float(store.cin_sizes[k]) * (a1.F if k == 0 else store.cin_sizes[k - 1]) for k in range(len(store.cin_sizes))]
                 tw = sum(w)
                 nl = len(store.tower.widths)
                 env = os.environ.get("RSX_XDFM_SWEEP_WEIGHTS")
-                nd = 1 if store.cin.bf16 else L          # weight-gradient launches: bf16 computes all layers' dW in one
+                nd = L + 1 if store.cin.bf16 else L
                 if env:
                     wts = [float(x) for x in env.split(",")]
                 elif store.cin.bf16:
-                    wts = [0.0] * L + [0.0] * nl + [1.0] + [2.0] * nl + [2.0] + [2.0]
+                    wts = [0.0] * L + [0.0] * nl + [1.0] + [2.0] * nl + [0.0] * L + [2.0] + [2.0]
                 else:
                     wts = [0.5 * x / tw for x in w] + [0.0] * (2 * nl + 1) + [0.5 * x / tw for x in w][::-1] + [0.0]
                 assert len(wts) == L + 2 * nl + 1 + nd + 1, "RSX_XDFM_SWEEP_WEIGHTS: %d weights expected" % (L + 2 * nl + 2 + nd)
                 # (first-order vector first: the LAST slice, carried by the scatter launch, may hold table blocks only)
                 sl_all = store.opt.cold_slices(c1[::-1] + c2, wts)
-                sweeps = sl_all[:L] + sl_all[L + 2 * nl + 1:L + 2 * nl + 1 + nd][::-1]         # CIN fwd_k ..., then dW_k in layer order
+                bw = sl_all[L + 2 * nl + 1:L + 2 * nl + 1 + nd]
+                # CinNet.forward: fwd_k; CinNet.backward: layer order (bf16: dx_0..dx_{L-1}, then the dW launch)
+                sweeps = sl_all[:L] + (bw[:L][::-1] + bw[L:] if store.cin.bf16 else bw[::-1])
                 tower_sweeps = sl_all[L:L + 2 * nl + 1]
                 last_sweep = sl_all[-1]
+                ride = ride and all(x is None for x in sl_all[:L + 1])    # no slice before the launch that carries the sort
                 hot = h1 + h2
+            if not ride:
+                job = None
+                a1.field_sort(ids_sort)
         dX1v, dX2v, glv = dp.send_views(B) if zc else (None,) * 3          # per-example gradient block, written in place
         # both input_layer calls (:125,185) + the pre-activation of linear_net (one-hot weights + 13 numeric log-values, :127)
         E1 = torch.empty(B, a1.F * a1.D, device=ids.device)
