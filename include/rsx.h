@@ -98,6 +98,9 @@ typedef struct {
   int32_t* segid;             /* nullable */
   int32_t max_rows_per_field, B, F, stride;
 } rsx_sort_job;
+/* njobs (<= 4) independent sorts of the same shape (B, F, stride) in ONE launch, F workgroups each: the k batches of an
+ * optimizer window (rsx_adam_window), each into its own workspace.  B <= 16384 (the rsx_field_sort range).              */
+int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_stream_t stream);
 /* rsx_gather_fm_fwd with the step's dedup sort (`sort_h`, see rsx_sort_job above) riding along as F extra workgroups of
  * the same launch: the sort only needs the ids, and once it sits in the step's first launch every later launch may carry
  * a slice of the untouched-row optimizer sweep (which reads the sort's slot map).  sort_h == NULL: plain gather.       */
@@ -184,6 +187,12 @@ typedef struct {
   int32_t stride;          /* *_ROWS: per-field capacity of the rsx_field_sort workspace.  DENSE with B > 1: floats
                               between the replicas' arenas inside g (an all-gathered buffer), summed in order r = 0.. */
   int32_t zero_grad;       /* DENSE */
+  /* *_COLD kinds, optimizer WINDOW of 1 + w steps (w = leading non-NULL entries, 0..3): the slot maps of the window's LATER
+   * steps (their batches' ids are known ahead: rsx_field_sort_multi).  A row / element that NO step of the window touches
+   * (slot and every slot_w < 0) receives the window's 1 + w untouched-row updates back to back in registers -- the same fp32
+   * operations, in the same order, as 1 + w single-step sweeps, for 1/(1 + w) of their HBM traffic; every other row is
+   * skipped and is brought up to date step by step by rsx_segsum_adam_rows (`win_h`).  All NULL: a one-step sweep.        */
+  const int32_t* slot_w[3];
 } rsx_adam_seg;
 
 #define RSX_ADAM_MAX_SEGS 12
@@ -217,13 +226,30 @@ typedef struct rsx_table_set {
  * rsx_segsum_bwd + rsx_adam_tf1_multi(TABLE_ROWS, VEC_ROWS_DENSE, DENSE) with identical arithmetic.  sweep_h
  * (nullable) may carry TABLE_TF1_COLD segments only: a VEC_COLD slice restores touched elements of its float4s and
  * would race with this launch's own update of them (RSX_EINVAL).                                                */
+/* Optimizer window: k <= RSX_ADAM_WINDOW_MAX consecutive steps whose batches' ids are known when the first one starts (the
+ * input pipeline runs ahead of the device).  All k dedup sorts run first (rsx_field_sort_multi, one workspace per step);
+ * the rows NO step of the window touches then need ONE pass over the optimizer state for the whole window
+ * (rsx_adam_seg.slot_w) instead of one per step -- TF-1's non-lazy Adam moves every row every step, and
+ * for an untouched row step t+1's update only needs step t's result, so k of them are applied back to back in registers.
+ * A row that some step of the window touches is kept exact step by step: step `cur`'s scatter launch updates the rows it
+ * touches with their gradient (as always) and walks the OTHER steps' unique-row lists to give the rows that it does not
+ * touch this step's zero-gradient update.  Between two windows the state equals that of k single steps, bit for bit. */
+#define RSX_ADAM_WINDOW_MAX 4
+typedef struct {
+  int32_t k;                 /* steps of the window (1: no window) */
+  int32_t cur;               /* this step's position, 0 .. k-1 */
+  int32_t max_unique;        /* upper bound of nuniq[i][f] (the batch size) */
+  const int32_t* uniq_row[RSX_ADAM_WINDOW_MAX];   /* the k sort workspaces (rsx_field_sort outputs), entry `cur` = this step's */
+  const int32_t* nuniq[RSX_ADAM_WINDOW_MAX];
+  const int32_t* slot[RSX_ADAM_WINDOW_MAX];
+} rsx_adam_window;
 int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w, const float* S,
                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
                          int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
                          const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
-                         const rsx_table_set* second_h, float* state, int advance_step, float lr, float beta1, float beta2,
-                         float eps, rsx_stream_t stream);
+                         const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state, int advance_step,
+                         float lr, float beta1, float beta2, float eps, rsx_stream_t stream);
 /* second_h (nullable): a second table set looked up with the SAME ids (one sort serves both: xDeepFM's two input_layer
  * calls, xdeepfm/xdeepfm.py:125,185); its row-owner workgroups run in the same launch.  It has no first-order vector and
  * no FM term; its gradient rows dX use the same example blocks.                                                      */

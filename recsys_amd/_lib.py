@@ -20,7 +20,7 @@ class AdamSeg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n", C.c_int64),
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
                 ("slot", C.c_void_p), ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p),
-                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32)]
+                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32), ("slot_w", C.c_void_p * 3)]
 
 
 class AdamSlice(C.Structure):
@@ -51,6 +51,14 @@ class SortJob(C.Structure):
                 ("max_rows_per_field", C.c_int32), ("B", C.c_int32), ("F", C.c_int32), ("stride", C.c_int32)]
 
 
+ADAM_WINDOW_MAX = 4
+
+
+class AdamWindow(C.Structure):
+    _fields_ = [("k", C.c_int32), ("cur", C.c_int32), ("max_unique", C.c_int32), ("uniq_row", C.c_void_p * ADAM_WINDOW_MAX),
+                ("nuniq", C.c_void_p * ADAM_WINDOW_MAX), ("slot", C.c_void_p * ADAM_WINDOW_MAX)]
+
+
 _P, _I, _U64, _F = C.c_void_p, C.c_int, C.c_uint64, C.c_float
 _SIGS = {
     "rsx_version": (C.c_int, []),
@@ -71,7 +79,8 @@ _SIGS = {
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
-    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),
+    "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),
+    "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),

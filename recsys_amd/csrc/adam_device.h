@@ -10,6 +10,12 @@ struct SegDev {
   const int32_t *slot, *uniq_row, *nuniq;
   int32_t B, stride, zero_grad;
   uint32_t blk_begin;
+  // *_COLD kinds of an optimizer WINDOW (rsx_adam_seg.slot_w): the fields those kinds do not use hold the extra slot maps
+  // (kernel arguments are limited to 4 KB and a launch may embed two AdamArgs): zero_grad = their number (0..3),
+  // uniq_row / nuniq / g = the maps.
+  __host__ __device__ const int32_t* slot_w(int i) const {
+    return i == 0 ? uniq_row : i == 1 ? nuniq : reinterpret_cast<const int32_t*>(g);
+  }
 };
 struct AdamArgs {
   SegDev seg[RSX_ADAM_MAX_SEGS];
@@ -73,13 +79,99 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   for (int k = 1; k < a.nseg; ++k)
     if (blk >= a.seg[k].blk_begin) si = k;
   const SegDev& s = a.seg[si];
+  // window of 1 + nw steps (COLD kinds only): step j of the window runs with the beta powers advanced j times -- the same
+  // fp32 products the per-step advance of the powers makes
+  const bool is_cold = s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD;
+  const int nw = is_cold ? s.zero_grad : 0;
+  float alpha_w[3] = {0.f, 0.f, 0.f};
+  if (nw > 0) {
+    float p1 = b1p, p2 = b2p;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      p1 *= a.b1;
+      p2 *= a.b2;
+      alpha_w[j] = a.lr * sqrtf(1.0f - p2) / (1.0f - p1);
+    }
+  }
+  const int32_t* __restrict__ sw0 = s.uniq_row;
+  const int32_t* __restrict__ sw1 = s.nuniq;
+  const int32_t* __restrict__ sw2 = reinterpret_cast<const int32_t*>(s.g);
   const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  if (s.kind == RSX_ADAM_TABLE_TF1 || s.kind == RSX_ADAM_TABLE_TF1_COLD) {
+  if (s.kind == RSX_ADAM_TABLE_TF1_COLD && nw > 0) {
+    // The untouched rows of a window of 1 + nw steps (stand-alone launches; the one-step sweep below is what rides in other
+    // kernels' launches, where its 61 registers matter): touched rows are left to the scatter launches.  Batches of HB float4
+    // per lane, each in phases so that every load of the batch is in flight before the first use: slot maps (clamped index),
+    // then var / m / v unconditionally (a skipped row costs its read, ~1 % of the traffic; a guarded load would serialise
+    // the batch), then the 1 + nw updates one float4 at a time (4 independent chains, few temporaries: riders inherit their
+    // carrier's register budget), then the stores of the rows that moved.
+    constexpr int HB = 4;
+    static_assert(ADAM_U % HB == 0, "ADAM_U");
+    const int lpr = s.d >> 2;
+    const long long n4 = s.n * lpr;
+    const bool pow2 = (lpr & (lpr - 1)) == 0;
+    const int lsh = 31 - __clz(lpr);
+    const float aw0 = alpha_w[0], aw1 = alpha_w[1], aw2 = alpha_w[2];
+#pragma unroll 1
+    for (int u0 = 0; u0 < ADAM_U; u0 += HB) {
+      bool live[HB];
+      long long ec[HB];
+      int t[HB];
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const long long e = base + (long long)(u0 + u) * ADAM_T + tid;
+        ec[u] = e < n4 ? e : n4 - 1;
+        live[u] = e < n4;
+        const long long row = pow2 ? (ec[u] >> lsh) : (ec[u] / lpr);
+        t[u] = s.slot[row];
+        if (nw > 0) t[u] &= sw0[row];           // (untouched = -1 = all ones: one value >= 0 clears the sign of the AND)
+        if (nw > 1) t[u] &= sw1[row];
+        if (nw > 2) t[u] &= sw2[row];
+      }
+      float4 var[HB], m[HB], v[HB];
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+#if RSX_ADAM_NT
+        var[u] = __builtin_nontemporal_load(&var4[ec[u]]);
+        m[u] = __builtin_nontemporal_load(&m4[ec[u]]);
+        v[u] = __builtin_nontemporal_load(&v4[ec[u]]);
+#else
+        var[u] = var4[ec[u]];
+        m[u] = m4[ec[u]];
+        v[u] = v4[ec[u]];
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        live[u] = live[u] && t[u] < 0;
+        F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, h);
+#pragma unroll 1
+        for (int j = 0; j < nw; ++j) {          // the later steps of the window, back to back in registers
+          Hp hj = h;
+          hj.alpha = j == 0 ? aw0 : j == 1 ? aw1 : aw2;
+          F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, hj);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        if (live[u]) {
+#if RSX_ADAM_NT
+          __builtin_nontemporal_store(var[u], &var4[ec[u]]);
+          __builtin_nontemporal_store(m[u], &m4[ec[u]]);
+          __builtin_nontemporal_store(v[u], &v4[ec[u]]);
+#else
+          var4[ec[u]] = var[u];
+          m4[ec[u]] = m[u];
+          v4[ec[u]] = v[u];
+#endif
+        }
+      }
+    }
+  } else if (s.kind == RSX_ADAM_TABLE_TF1 || s.kind == RSX_ADAM_TABLE_TF1_COLD) {
     const bool cold_only = s.kind == RSX_ADAM_TABLE_TF1_COLD;   // touched rows are left to the TABLE_ROWS launch
     const int lpr = s.d >> 2;
     const long long n4 = s.n * lpr;
@@ -150,7 +242,10 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
     for (int u = 0; u < ADAM_U; ++u) {
       const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
-        const int4 sl = reinterpret_cast<const int4*>(s.slot)[e];
+        int4 sl = reinterpret_cast<const int4*>(s.slot)[e];
+        if (nw > 0) { const int4 t = reinterpret_cast<const int4*>(sw0)[e]; sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w; }
+        if (nw > 1) { const int4 t = reinterpret_cast<const int4*>(sw1)[e]; sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w; }
+        if (nw > 2) { const int4 t = reinterpret_cast<const int4*>(sw2)[e]; sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w; }
         float4 g;
         g.x = (!cold_only && sl.x >= 0) ? s.g[sl.x] : 0.f;     // COLD: g is not provided (touched elements are restored below)
         g.y = (!cold_only && sl.y >= 0) ? s.g[sl.y] : 0.f;
@@ -159,6 +254,11 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         float4 var = var4[e], m = m4[e], v = v4[e];
         const float4 var0 = var, m0 = m, v0 = v;
         F4_APPLY(adam_dense1, var, m, v, g, h);
+        for (int j = 0; j < nw; ++j) {
+          Hp hj = h;
+          hj.alpha = j == 0 ? alpha_w[0] : j == 1 ? alpha_w[1] : alpha_w[2];
+          F4_APPLY(adam_dense1, var, m, v, z4, hj);
+        }
         if (cold_only) {   // element-wise: leave the touched elements exactly as they were
           if (sl.x >= 0) { var.x = var0.x; m.x = m0.x; v.x = v0.x; }
           if (sl.y >= 0) { var.y = var0.y; m.y = m0.y; v.y = v0.y; }
@@ -170,9 +270,17 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         v4[e] = v;
       } else if (e == n4) {
         for (long long i = n4 * 4; i < s.n; ++i) {
-          const int sl = s.slot[i];
+          int sl = s.slot[i];
+          if (nw > 0) sl &= sw0[i];
+          if (nw > 1) sl &= sw1[i];
+          if (nw > 2) sl &= sw2[i];
           if (cold_only && sl >= 0) continue;
           adam_dense1(s.var[i], s.m[i], s.v[i], sl >= 0 ? s.g[sl] : 0.f, h);
+          for (int j = 0; j < nw; ++j) {
+            Hp hj = h;
+            hj.alpha = j == 0 ? alpha_w[0] : j == 1 ? alpha_w[1] : alpha_w[2];
+            adam_dense1(s.var[i], s.m[i], s.v[i], 0.f, hj);
+          }
         }
       }
     }
@@ -237,11 +345,13 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
       case RSX_ADAM_TABLE_TF1:
       case RSX_ADAM_TABLE_TF1_COLD:
         if (!s.slot || (!s.g && s.kind == RSX_ADAM_TABLE_TF1) || s.d < 4 || (s.d & 3)) return RSX_EINVAL;
+        if (s.kind == RSX_ADAM_TABLE_TF1 && s.slot_w[0]) return RSX_EINVAL;          // windows: COLD kinds only
         work = s.n * (s.d >> 2);
         break;
       case RSX_ADAM_VEC_SLOT:
       case RSX_ADAM_VEC_COLD:
         if (!s.slot || (!s.g && s.kind == RSX_ADAM_VEC_SLOT)) return RSX_EINVAL;
+        if (s.kind == RSX_ADAM_VEC_SLOT && s.slot_w[0]) return RSX_EINVAL;
         work = (s.n >> 2) + 1;
         break;
       case RSX_ADAM_TABLE_ROWS:
@@ -270,6 +380,16 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
     d.B = s.B;
     d.stride = s.stride;
     d.zero_grad = s.zero_grad;
+    if (s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD) {     // see SegDev: the window's extra slot maps
+      int nw = 0;
+      while (nw < 3 && s.slot_w[nw] != nullptr) ++nw;
+      for (int j = nw; j < 3; ++j)
+        if (s.slot_w[j] != nullptr) return RSX_EINVAL;                          // a prefix, no holes
+      d.zero_grad = nw;
+      d.uniq_row = s.slot_w[0];
+      d.nuniq = s.slot_w[1];
+      d.g = const_cast<float*>(reinterpret_cast<const float*>(s.slot_w[2]));
+    }
     d.blk_begin = blocks;
     blocks += (uint32_t)((work + ADAM_Q - 1) / ADAM_Q);
   }

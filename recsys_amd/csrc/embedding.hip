@@ -171,6 +171,14 @@ __global__ __launch_bounds__(1024) void field_sort_k(const SortArgs a) {
   field_sort_block(a, blockIdx.x, lds);
 }
 
+struct SortMulti {
+  SortArgs a[4];
+};
+__global__ __launch_bounds__(1024) void field_sort_multi_k(const SortMulti m) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  field_sort_block(m.a[blockIdx.y], blockIdx.x, lds);
+}
+
 // ------------------------------------------------------------------ backward: sorted segment-sum -
 // A wave owns GPW = 64/LPR consecutive unique rows (f, j0..j0+GPW-1) of one field; LPR lanes (one float4
 // each) form the group of one row.  Per entry of a segment the contribution is
@@ -695,7 +703,16 @@ struct HotAdam {
   SegPartials part2;
   AdamSlice extra;                       // dense variables (any non-COLD kinds), n_blk may be 0
   AdamSlice cold;                        // optional slice of the untouched-row sweep (rows disjoint from the touched ones)
+  // optimizer window (rsx_adam_window): rows that ANOTHER step of the window touches and this one does not are skipped by
+  // the window's sweep and get this step's untouched-row update here, from the other steps' unique-row lists
+  int win_k, win_cur;
+  const int32_t* win_uniq[RSX_ADAM_WINDOW_MAX];
+  const int32_t* win_nuniq[RSX_ADAM_WINDOW_MAX];
+  const int32_t* win_slot[RSX_ADAM_WINDOW_MAX];
+  uint32_t win_blk, win_per_f;           // workgroups of the pass; per (list, field)
 };
+
+constexpr int WIN_NR = 4;      // rows per lane group in the window pass of segsum_adam_k
 
 template <int D>
 __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S, const float* __restrict__ dX,
@@ -708,10 +725,69 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
   constexpr int LPR = D / 4;
   const float b1p = h.state[0], b2p = h.state[1];
   const uint32_t n_rows = h.tables2 != nullptr ? 2u * h.n_own : h.n_own;
-  if (blockIdx.x >= n_rows + h.extra.n_blk) {
-    adam_block(h.cold.args, h.cold.blk_lo + (blockIdx.x - n_rows - h.extra.n_blk));
-  } else if (blockIdx.x >= n_rows) {
-    adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - n_rows));
+  if (blockIdx.x >= n_rows + h.win_blk + h.extra.n_blk) {
+    adam_block(h.cold.args, h.cold.blk_lo + (blockIdx.x - n_rows - h.win_blk - h.extra.n_blk));
+  } else if (blockIdx.x >= n_rows + h.win_blk) {
+    adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - n_rows - h.win_blk));
+  } else if (blockIdx.x >= n_rows) {      // window pass: list li (the window's other steps in order), field f, WIN_NR*256/LPR rows
+    // Every LPR-lane group takes WIN_NR rows; phase by phase (unique rows, slot maps, the rows' state, update, store) so that
+    // the loads of all its rows are in flight together -- the pass is a chain of 4 dependent accesses per row.
+    constexpr int RPW = 256 / LPR;
+    const uint32_t wb = blockIdx.x - n_rows;
+    const uint32_t per_l = (uint32_t)F * h.win_per_f;
+    const int li = (int)(wb / per_l);
+    const uint32_t rem = wb - (uint32_t)li * per_l;
+    const int f = (int)(rem / h.win_per_f);
+    const int j0 = (int)(rem - (uint32_t)f * h.win_per_f) * (RPW * WIN_NR) + (int)threadIdx.x / LPR;
+    const int q = (int)threadIdx.x % LPR;
+    const int o = li < h.win_cur ? li : li + 1;
+    const int nu = h.win_nuniq[o][f];
+    if (j0 < nu) {
+      const int32_t* __restrict__ ur = h.win_uniq[o] + (size_t)f * stride;
+      int row[WIN_NR], t[WIN_NR];
+#pragma unroll
+      for (int i = 0; i < WIN_NR; ++i) {
+        const int j = j0 + i * RPW;
+        row[i] = ur[j < nu ? j : nu - 1];
+      }
+      // this step's own scatter owns the rows it touches; a row on several lists belongs to the first of them
+#pragma unroll
+      for (int i = 0; i < WIN_NR; ++i) t[i] = h.win_slot[h.win_cur][row[i]];
+      for (int l = 0; l < o; ++l)
+        if (l != h.win_cur) {
+#pragma unroll
+          for (int i = 0; i < WIN_NR; ++i) t[i] &= h.win_slot[l][row[i]];
+        }
+      Hp hp;
+      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
+      hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int nset = h.tables2 != nullptr ? 2 : 1;
+      for (int set = 0; set < nset; ++set) {
+        float4* __restrict__ T4 = reinterpret_cast<float4*>(set ? h.tables2 : h.tables);
+        float4* __restrict__ M4 = reinterpret_cast<float4*>(set ? h.m_t2 : h.m_t);
+        float4* __restrict__ V4 = reinterpret_cast<float4*>(set ? h.v_t2 : h.v_t);
+        float4 var[WIN_NR], m[WIN_NR], v[WIN_NR];
+#pragma unroll
+        for (int i = 0; i < WIN_NR; ++i) {
+          const size_t o4 = (size_t)row[i] * LPR + q;
+          var[i] = T4[o4]; m[i] = M4[o4]; v[i] = V4[o4];
+        }
+#pragma unroll
+        for (int i = 0; i < WIN_NR; ++i) {
+          F4_APPLY(adam_sparse1, var[i], m[i], v[i], z4, false, hp);
+          if (t[i] < 0 && j0 + i * RPW < nu) {
+            const size_t o4 = (size_t)row[i] * LPR + q;
+            T4[o4] = var[i]; M4[o4] = m[i]; V4[o4] = v[i];
+          }
+        }
+      }
+      if (h.w1 != nullptr && q == 0) {
+#pragma unroll
+        for (int i = 0; i < WIN_NR; ++i)
+          if (t[i] < 0 && j0 + i * RPW < nu) adam_dense1(h.w1[row[i]], h.m_w[row[i]], h.v_w[row[i]], 0.f, hp);
+      }
+    }
   } else if (blockIdx.x >= h.n_own) {     // second table set
     const int q = (threadIdx.x & 63) % LPR;
     bool valid, do1;
@@ -907,6 +983,40 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
   return RSX_OK;
 }
 
+extern "C" int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_stream_t stream) {
+  if (!jobs_h || njobs <= 0 || njobs > 4) return RSX_EINVAL;
+  SortMulti m;
+  int T = 0;
+  size_t lds = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const rsx_sort_job& j = jobs_h[k];
+    if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
+        j.stride < j.B || j.max_rows_per_field <= 0)
+      return RSX_EINVAL;
+    if (j.B != jobs_h[0].B || j.F != jobs_h[0].F || j.stride != jobs_h[0].stride) return RSX_EINVAL;
+    for (int i = 0; i < k; ++i)
+      if (jobs_h[i].slot == j.slot || jobs_h[i].perm == j.perm) return RSX_EINVAL;       // one workspace per job
+    m.a[k] = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.segid, j.B, j.F, j.stride, 0, 0};
+    int n = 128;
+    while (n < j.B) n <<= 1;
+    T = n <= 512 ? n : ((n >> 1) < 1024 ? (n >> 1) : 1024);
+    const int rc = rsx_sort_args(m.a[k], j.max_rows_per_field, T);
+    if (rc != RSX_OK) return rc;
+    const size_t need = rsx_sort_lds_bytes(m.a[k], T);
+    if (need > lds) lds = need;
+  }
+  if (jobs_h[0].B == 0) return RSX_OK;
+  for (int k = njobs; k < 4; ++k) m.a[k] = m.a[0];
+  if (lds > 64 * 1024) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(field_sort_multi_k),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return RSX_EUNSUPPORTED;
+  }
+  hipLaunchKernelGGL(field_sort_multi_k, dim3((unsigned)jobs_h[0].F, (unsigned)njobs), dim3(T), lds, rsx_s(stream), m);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
 static int segsum_impl(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                        const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq, float* G,
                        float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
@@ -980,8 +1090,8 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
                                     const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
                                     const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
-                                    const rsx_table_set* second_h, float* state, int advance_step, float lr, float beta1,
-                                    float beta2, float eps, rsx_stream_t stream) {
+                                    const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state,
+                                    int advance_step, float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
@@ -1026,7 +1136,21 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
     const bool overlaps = b0 < h.cold.blk_lo + h.cold.n_blk && h.cold.blk_lo < b1;     // segment k has blocks in the slice
     if (overlaps && h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
   }
-  h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.extra.n_blk + h.cold.n_blk;
+  h.win_k = 0; h.win_cur = 0; h.win_blk = 0; h.win_per_f = 0;
+  for (int i = 0; i < RSX_ADAM_WINDOW_MAX; ++i) h.win_uniq[i] = h.win_nuniq[i] = h.win_slot[i] = nullptr;
+  if (win_h != nullptr && win_h->k > 1) {
+    if (win_h->k > RSX_ADAM_WINDOW_MAX || win_h->cur < 0 || win_h->cur >= win_h->k || win_h->max_unique <= 0) return RSX_EINVAL;
+    for (int i = 0; i < win_h->k; ++i) {
+      if (!win_h->uniq_row[i] || !win_h->nuniq[i] || !win_h->slot[i]) return RSX_EINVAL;
+      h.win_uniq[i] = win_h->uniq_row[i]; h.win_nuniq[i] = win_h->nuniq[i]; h.win_slot[i] = win_h->slot[i];
+    }
+    if (win_h->uniq_row[win_h->cur] != uniq_row) return RSX_EINVAL;              // entry `cur` is this step's own sort
+    h.win_k = win_h->k; h.win_cur = win_h->cur;
+    const int rpw = WIN_NR * 256 / (D / 4);
+    h.win_per_f = (uint32_t)((win_h->max_unique + rpw - 1) / rpw);
+    h.win_blk = (uint32_t)(win_h->k - 1) * (uint32_t)F * h.win_per_f;
+  }
+  h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.win_blk + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,
                  w1_field_mask, B, F, stride, h, part, xb);

@@ -9,6 +9,7 @@ import os
 
 import torch
 
+from . import _lib
 from . import layers as L
 from .deepfm import define_flags as _deepfm_flags
 from .deepfm import input_fn, run_main  # noqa: F401
@@ -59,6 +60,9 @@ def build_variables(store, params, capacity):
         want_hip = False
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
+        if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) \
+                and capacity <= 16384:
+            store.window_k = _lib.ADAM_WINDOW_MAX          # optimizer windows (include/rsx.h rsx_adam_window)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):      # zero-copy gradient exchange (see deepfm.py)
@@ -84,12 +88,25 @@ def _train_fused(store, arena, ids, labels, params, masks):
         zc = dp is not None and store.dp_block
         x0, _, _, _ = arena.gather(ids)
         job, sweeps, hot, last_sweep = None, None, None, None
-        if ids_sort.shape[0] <= 2048:                # the sort rides in the first tower-forward launch; larger ones run stand-alone
+        # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
+        # untouched rows ONCE for the whole window (a launch of its own); the other positions run neither
+        wk, wpos, wfeat = store.window_of_step()
+        if wk > 1 and not (overlap and dp is None):
+            raise _lib.RsxError("optimizer windows need the split TF-1 update on one GPU")
+        arena.select(wpos)
+        if wk > 1:
+            if wpos == 0:
+                arena.sort_window([f["ids"] for f in wfeat])
+                cold, _ = arena.adam_split_segments(window_k=wk)
+                store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
+            arena.last_B = ids.shape[0]
+            hot = ()
+        elif ids_sort.shape[0] <= 2048:              # the sort rides in the first tower-forward launch; larger ones run stand-alone
             # (a 256-thread carrier workgroup sorts 4096 keys in 55 us, the 1024-thread kernel in 26 us)
             job = arena.sort_job(ids_sort)
         else:
             arena.field_sort(ids_sort)
-        if overlap:
+        if overlap and wk == 1:
             cold, hot = arena.adam_split_segments()
             sweeps = store.opt.cold_slices(cold, store.sweep_weights)
             last_sweep = sweeps[-1] if len(sweeps) == 2 * nl + 2 else None
@@ -117,7 +134,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 dXg, _, _, _, blocks = dp.gather_example_grads(dX, dense=store.dense.grad, blocked=True)
                 Bg = dX.shape[0] * dp.world
             if hot is not None:
-                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, dense_segs or store.dense.adam_segments(), last_sweep, blocks=blocks)
+                arena.select(wpos)
+                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
+                                  blocks=blocks, window=(wk, wpos))
             else:
                 arena.segsum(Bg, None, dXg, None, None, blocks=blocks)
                 store.apply_gradients()

@@ -11,6 +11,7 @@ import os
 
 import torch
 
+from . import _lib
 from . import layers as L
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
@@ -71,6 +72,10 @@ def build_variables(store, params, capacity, with_dnn=True):
         want_hip = False
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
+        # optimizer windows (include/rsx.h rsx_adam_window): up to 4 consecutive steps share ONE sweep over the untouched rows
+        if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) \
+                and capacity <= 16384:
+            store.window_k = _lib.ADAM_WINDOW_MAX
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):
@@ -138,9 +143,22 @@ def _train_fused(store, arena, ids, labels, params, masks):
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids
         zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
+        # Optimizer window (estimator.Window, rsx_adam_window): this step is position wpos of wk consecutive steps whose
+        # batches are known; position 0 sorts all of them and carries ONE sweep for the whole window, the others none.
+        wk, wpos, wfeat = store.window_of_step()
+        if wk > 1 and not (overlap and dp is None):
+            raise _lib.RsxError("optimizer windows need the split TF-1 update on one GPU")
         job = None
-        if ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
+        if wk > 1:
+            arena.select(wpos)
+            if wpos == 0:
+                arena.sort_window([f["ids"] for f in wfeat])
+            arena.last_B = ids.shape[0]
+        elif ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
+            arena.select(0)
             job = arena.sort_job(ids_sort)
+        else:
+            arena.select(0)
         # RSX_SORT_IN_GATHER=1: the sort rides in the GATHER launch (the step's first) instead, so that both tower-forward
         # launches may carry sweep slices too.  Measured (r02, MI355X): the same 93.4 us with the forward shares at 0, and
         # 106-108 us with any share given to the forward launches ([1,1,1,3,3,2.5] ...): a forward launch is a pure chain of
@@ -149,10 +167,16 @@ def _train_fused(store, arena, ids, labels, params, masks):
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv, sort_job=job if in_gather else None)
         if in_gather:
             job = None
-        elif job is None:
+        elif job is None and wk == 1:
             arena.field_sort(ids_sort)
         sweeps, hot, last_sweep = None, None, None
-        if overlap:
+        if overlap and wk > 1 and wpos == 0:
+            # ONE sweep for the whole window, as a launch of its own: k updates per row in registers make the slices
+            # ALU-heavy, and as riders they inherit their carrier's occupancy (measured, DeepFM bs 256: carried 164 us per
+            # 4-step window, stand-alone 73 us = 18 us per step against 53-60 us for a one-step sweep)
+            cold, hot = arena.adam_split_segments(window_k=wk)
+            store.opt.run_slice(store.opt.cold_slices(cold[::-1], [1.0])[0])
+        elif overlap and wpos == 0:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
             # workgroups, filling the CUs the latency-bound tower leaves idle; touched rows + dense follow the scatter.
@@ -162,6 +186,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
             last_sweep = sweeps[-1] if len(sweeps) == 2 * len(store.tower.widths) + 2 else None
             sweeps = sweeps[:2 * len(store.tower.widths) + 1]
             assert job is None or sweeps[0] is None, "a forward launch that carries the sort cannot carry a sweep slice"
+        elif overlap:
+            hot = ()            # a later position of the window: the window's sweep already ran
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
@@ -180,7 +206,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 dXg, Sg, gy1g, gy2g, blocks = dp.gather_example_grads(dX, S, gy1, gy2, dense=store.dense.grad, blocked=True)
                 Bg = dX.shape[0] * dp.world
             if hot is not None:     # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
-                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, dense_segs or store.dense.adam_segments(), last_sweep, blocks=blocks)
+                arena.select(wpos)
+                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
+                                  blocks=blocks, window=(wk, wpos))
             else:
                 arena.segsum(Bg, Sg, dXg, gy1g, gy2g, blocks=blocks)
                 store.apply_gradients()

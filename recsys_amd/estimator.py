@@ -130,6 +130,15 @@ class VariableStore:
         self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
         self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
         self.graph_safe_dp = False   # set by model code whose DP collectives run outside autograd (segmentable)
+        # Optimizer window (include/rsx.h rsx_adam_window): window_k = the longest run of consecutive TRAIN steps the
+        # model's fused step can treat as one window (set by model code; 1 = every step on its own); `window` =
+        # (k, position, [features of the k batches]) while the Estimator runs a step that belongs to one.
+        self.window_k = 1
+        self.window = None
+
+    def window_of_step(self):
+        """-> (k, position, features of the window's batches) of the TRAIN step being built; (1, 0, None) without a window."""
+        return self.window if self.window is not None else (1, 0, None)
 
     def build(self, embeddings: Dict[str, EmbeddingArena], dense_shapes, dense_init, lr, storage_shapes=None):
         self.embeddings = embeddings
@@ -235,6 +244,30 @@ class Estimator:
         # detach: a live loss would keep this step's autograd graph (and its AccumulateGrad nodes, bound to
         # this stream) alive into the next step, which breaks HIP-graph capture on the capture stream
         return spec.loss.detach()
+
+    def _train_window(self, batches):
+        """len(batches) consecutive TRAIN steps as ONE optimizer window: the model's fused step sorts the ids of all of
+        them at the first step and sweeps the untouched rows of the optimizer state once for the whole window.  After the
+        last step the variables equal those of len(batches) single steps bit for bit; between two steps of a window they
+        are not a state any single-step run passes through, so nothing else (evaluate, checkpoint) may run in between.
+        -> the loss of every step."""
+        k = len(batches)
+        feats = [f for f, _ in batches]
+        losses = []
+        for pos, (f, l) in enumerate(batches):
+            self.store.window = (k, pos, feats) if k > 1 else None
+            try:
+                losses.append(self._train_eager(f, l))
+            finally:
+                self.store.window = None
+        return losses
+
+    def _window_len(self):
+        """Steps per optimizer window: what the model supports (store.window_k), RSX_ADAM_WINDOW overrides (1 = off)."""
+        if not self.store.built or self.store.dp is not None:
+            return 1
+        k = int(os.environ.get("RSX_ADAM_WINDOW", self.params.get("adam_window", self.store.window_k)))
+        return max(1, min(k, self.store.window_k))
 
     def _use_graph(self):
         """HIP graphs are on unless the step has data-parallel collectives issued from inside autograd's backward
@@ -379,9 +412,13 @@ class Estimator:
         def capture(first, count):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            K = self._window_len()
             with torch.cuda.graph(graph):
-                for k in range(count):
-                    loss = self._train_eager(*batches[first + k].views())
+                k = 0
+                while k < count:         # optimizer windows never cross a graph: the resident batches ARE the look-ahead
+                    w = min(K, count - k)
+                    loss = self._train_window([batches[first + k + j].views() for j in range(w)])[-1]
+                    k += w
             return graph, loss        # `loss`: the static output of the graph's last step
 
         def partial(first, count):
@@ -427,26 +464,81 @@ class Estimator:
         return self.store.opt.global_step if self.store.built else 0
 
     # -- public API --------------------------------------------------------------------------
+    def _train_window_packed(self, pbs):
+        """One optimizer window over len(pbs) host (or device) batches: len(pbs) copies into the graph's static input
+        buffers, ONE graph replay for all of its steps.  -> loss of the last step."""
+        key = ("packedwin", len(pbs)) + pbs[0].key()
+        g = self._graphs.setdefault(key, {"warm": 0})
+        if "graph" in g:
+            for st, pb in zip(g["static"], pbs):
+                st.flat.copy_(pb.flat, non_blocking=True)
+            g["graph"].replay()
+            return g["losses"][-1]
+        dev = [pb if pb.flat.device == self.store.device else pb.to(self.store.device) for pb in pbs]
+        if g["warm"] < 1:
+            g["warm"] += 1
+            return self._train_window([pb.views() for pb in dev])[-1]
+        g["static"] = [pb.clone() for pb in dev]
+        g["graph"], g["losses"] = self._capture(lambda: self._train_window([st.views() for st in g["static"]]))
+        g["graph"].replay()             # capture executes nothing: the static buffers already hold this window's batches
+        return g["losses"][-1]
+
     def train(self, input_fn, steps=None, max_steps=None):
         it = iter(input_fn())
         done = 0
         cfg = self.config
         self._log_t, log_step0 = time.time(), None
+        held = []                # batches pulled ahead that did not go into the last window
+        gs_host = None           # the global step, tracked on the host after one device read
+        exhausted = False
         while True:
             if steps is not None and done >= steps:
                 break
-            if max_steps is not None and self.store.built and self.global_step >= max_steps:
+            if max_steps is not None and self.store.built:
+                if gs_host is None:
+                    gs_host = self.global_step
+                if gs_host >= max_steps:
+                    break
+            # How many steps the next optimizer window may hold (look-ahead over the input pipeline, which runs ahead of
+            # the device anyway): never across the end of training, a log line or a checkpoint -- between the steps of a
+            # window the variables are not a state the step-by-step run passes through.
+            room = self._window_len() if self._use_graph() else 1
+            if steps is not None:
+                room = min(room, steps - done)
+            if max_steps is not None and gs_host is not None:
+                room = min(room, max_steps - gs_host)
+            for every in (cfg.log_step_count_steps, cfg.save_checkpoints_steps if self.model_dir else 0):
+                if every:
+                    room = min(room, every - done % every)
+            while len(held) < room and not exhausted:
+                try:
+                    held.append(next(it))
+                except StopIteration:
+                    exhausted = True
+            if not held:
                 break
-            try:
-                features, labels = next(it)
-            except StopIteration:
-                break
+            features, labels = held[0]
             if not self.store.built:          # variables are created by the first model_fn call
                 self._call_model_fn(self._to_device(features), self._to_device(labels), ModeKeys.PREDICT)
                 self._maybe_restore()
-            # one packed host buffer -> one H2D copy -> the HIP graph's static input
-            loss = self._train_step(PackedBatch(features, labels))
-            done += 1
+                room = 1
+            # one packed host buffer per batch -> one H2D copy each -> the HIP graph's static inputs
+            win = [PackedBatch(*held[0])]
+            while len(win) < room and len(win) < len(held):
+                pb = PackedBatch(*held[len(win)])
+                if pb.key() != win[0].key():   # e.g. the last, smaller batch of an epoch: a step of its own
+                    break
+                win.append(pb)
+            if len(win) < self._window_len() or len(win) == 1:
+                win = win[:1]                  # windows are captured at full length only; the rest runs step by step
+                loss = self._train_step(win[0])
+            else:
+                loss = self._train_window_packed(win)
+            features, labels = held[len(win) - 1]
+            del held[:len(win)]
+            done += len(win)
+            if gs_host is not None:
+                gs_host += len(win)
             gs = self.global_step if (done % cfg.log_step_count_steps == 0 or
                                       (cfg.save_checkpoints_steps and done % cfg.save_checkpoints_steps == 0)) else None
             if gs is not None and done % cfg.log_step_count_steps == 0:
@@ -468,6 +560,7 @@ class Estimator:
                 self._save_checkpoint(gs)
         if self.model_dir and self.store.built and done:
             self._save_checkpoint(self.global_step)
+        _close_iter(it)
         return self
 
     def evaluate(self, input_fn, steps=None):

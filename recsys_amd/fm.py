@@ -23,6 +23,8 @@ def model_fn(features, labels, mode, params):
     if not store.built:
         cap = max(int(params.get("max_batch_size", 0)), ids.shape[0])
         _build(store, params, capacity=cap, with_dnn=False)
+        if store.dp is None and store.adam_mode == "tf1_dense" and params.get("fused", True) and cap <= 16384:
+            store.window_k = _lib.ADAM_WINDOW_MAX          # optimizer windows (include/rsx.h rsx_adam_window)
         store.dp_block = False
         if store.dp is not None and params.get("fused", True):
             # data-parallel: [S | gy2 | gy1] of the local batch + the dense gradient arena in one persistent send block
@@ -58,13 +60,27 @@ def _train_fused(store, arena, ids, labels):
     with torch.no_grad():
         # data-parallel: the optimizer sees the GLOBAL batch -- dedup sort over the all-gathered ids, per-example gradient
         # block [S | gy2 | gy1] + dense arena exchanged by ONE all-gather straight from the send block (see deepfm.py)
-        arena.field_sort(dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids)
+        # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
+        # untouched rows ONCE for the whole window (a launch of its own); the other positions run neither
+        wk, wpos, wfeat = store.window_of_step()
+        if wk > 1 and dp is not None:
+            raise _lib.RsxError("optimizer windows run on one GPU")
+        arena.select(wpos)
+        sweep = sweep2 = None
+        if wk > 1:
+            if wpos == 0:
+                arena.sort_window([f["ids"] for f in wfeat])
+                cold, _ = arena.adam_split_segments(window_k=wk)
+                store.opt.run_slice(store.opt.cold_slices(cold[::-1], [1.0])[0])
+            arena.last_B = B
+        else:
+            arena.field_sort(dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids)
+            cold, hot = arena.adam_split_segments()
+            # 70 % of the untouched-row sweep rides in the head launch, 30 % (table blocks only: the first-order vector goes
+            # first) in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)
+            sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
         Sv, gy2v, gy1v = dp.send_views(B) if dp is not None else (None,) * 3
         E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)
-        cold, hot = arena.adam_split_segments()
-        # 70 % of the untouched-row sweep rides in the head launch, 30 % (table blocks only: the first-order vector goes first)
-        # in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)
-        sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
         prob = torch.empty(B, device=dev)
         gy1, gy2 = (gy1v, gy2v) if dp is not None else (torch.empty(B, device=dev) for _ in range(2))
         loss = torch.empty(1, device=dev)
@@ -81,7 +97,8 @@ def _train_fused(store, arena, ids, labels):
                 (Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(B, fold_dense=True)
                 arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs, sweep2, blocks=blocks)
             else:
-                arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2)
+                arena.select(wpos)
+                arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2, window=(wk, wpos))
 
     return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 

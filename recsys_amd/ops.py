@@ -63,11 +63,6 @@ class EmbeddingArena:
             self.w1 = None
         F, st = self.F, self.stride
         i32 = dict(dtype=torch.int32, device=dev)
-        self.perm = torch.zeros(F * st, **i32)
-        self.seg_off = torch.zeros(F * (st + 1), **i32)
-        self.uniq_row = torch.zeros(F * st, **i32)
-        self.nuniq = torch.zeros(F, **i32)
-        self.slot = torch.full((self.R + 4,), -1, **i32)       # +4: int4 tail reads of VEC_SLOT
         self.G = torch.zeros(F * st, D, device=dev)
         self.gw1 = torch.zeros(F * st, device=dev) if with_w1 else None
         self.last_B = 0
@@ -76,17 +71,15 @@ class EmbeddingArena:
         if st > self.LDS_SORT_MAX_B:
             self.sort_ws = torch.zeros(int(lib().rsx_field_sort_large_workspace_ints(st, F, st)), **i32)
         # two-stage segment-sum workspace (B > TWO_STAGE_MIN_B): segment index per sorted position + chunk partials
-        self.partials = None
-        if st > self.TWO_STAGE_MIN_B:
+        self.two_stage_ws = st > self.TWO_STAGE_MIN_B
+        if self.two_stage_ws:
             nch = (st + 15) // 16
-            self.segid = torch.zeros(F * st + 2 * F + F * nch, **i32)
             self.P = torch.zeros(F * nch * 2, D, device=dev)
             self.P1 = torch.zeros(F * nch * 2, device=dev) if with_w1 else None
-            # (G / gw1: stage A finishes the segments that lie inside one chunk straight into the scatter's outputs;
-            # RSX_STAGE_A_FINAL=0 restores the long-segment-partials-only stage A for A/B runs)
-            fin = os.environ.get("RSX_STAGE_A_FINAL", "1") != "0"
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G) if fin else None,
-                                             _ptr(self.gw1) if fin else None)
+        # Dedup-sort workspaces: sortbufs[0] is the step's own; an optimizer WINDOW of k steps (rsx_adam_window) sorts
+        # the k batches ahead into sortbufs[0..k-1] (allocated on first use) and select(i) makes entry i the current one.
+        self.sortbufs = [self._new_sortbuf()]
+        self.select(0)
         # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
         self.hook = torch.zeros((), device=dev, requires_grad=True)
 
@@ -98,6 +91,39 @@ class EmbeddingArena:
     LDS_SORT_MAX_B = 8192         # above: rsx_field_sort_large (multi-workgroup; measured crossover ~8192, scripts/sort_time.py;
                                   # rsx_field_sort itself reaches 16384)
 
+    def _new_sortbuf(self):
+        F, st = self.F, self.stride
+        i32 = dict(dtype=torch.int32, device=self.tables.device)
+        b = dict(perm=torch.zeros(F * st, **i32), seg_off=torch.zeros(F * (st + 1), **i32),
+                 uniq_row=torch.zeros(F * st, **i32), nuniq=torch.zeros(F, **i32),
+                 slot=torch.full((self.R + 4,), -1, **i32),       # +4: int4 tail reads of VEC_SLOT
+                 segid=torch.zeros(F * st + 2 * F + F * ((st + 15) // 16), **i32) if self.two_stage_ws else None)
+        return b
+
+    def _bind_partials(self):
+        # (G / gw1: stage A finishes the segments that lie inside one chunk straight into the scatter's outputs;
+        # RSX_STAGE_A_FINAL=0 restores the long-segment-partials-only stage A for A/B runs)
+        self.partials = None
+        if self.two_stage_ws:
+            fin = os.environ.get("RSX_STAGE_A_FINAL", "1") != "0"
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G) if fin else None,
+                                             _ptr(self.gw1) if fin else None)
+
+    def select(self, i):
+        """Makes sort workspace i (position i of the optimizer window) the one field_sort / sort_job / segsum* use."""
+        owner = getattr(self, "_sort_owner", None)
+        bufs = owner.window_bufs(i + 1) if owner is not None else self.window_bufs(i + 1)
+        for k, v in bufs[i].items():
+            setattr(self, k, v)
+        self.cur_buf = i
+        self._bind_partials()
+
+    def window_bufs(self, k):
+        assert 1 <= k <= _lib.ADAM_WINDOW_MAX
+        while len(self.sortbufs) < k:
+            self.sortbufs.append(self._new_sortbuf())
+        return self.sortbufs[:k]
+
     def _two_stage(self, B):
         return self.partials is not None and B > self.TWO_STAGE_MIN_B
 
@@ -106,13 +132,8 @@ class EmbeddingArena:
         xdeepfm/xdeepfm.py:125,185) have one dedup result: alias `other`'s sort outputs; field_sort here becomes a no-op."""
         assert np.array_equal(self.row_off_np, other.row_off_np) and self.stride == other.stride
         self._sort_owner = other
-        for k in ("perm", "seg_off", "uniq_row", "nuniq", "slot", "sort_ws"):
-            setattr(self, k, getattr(other, k))
-        if self.partials is not None:
-            self.segid = other.segid
-            fin = os.environ.get("RSX_STAGE_A_FINAL", "1") != "0"
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G) if fin else None,
-                                             _ptr(self.gw1) if fin else None)
+        self.sort_ws = other.sort_ws
+        self.select(other.cur_buf)
 
     # -- kernels ---------------------------------------------------------------------------
     def field_sort(self, ids):
@@ -134,6 +155,28 @@ class EmbeddingArena:
                                        _ptr(self.segid) if self._two_stage(B) else None, self.max_rows,
                                        B, self.F, self.stride, _stream()), "rsx_field_sort")
         self.last_B = B
+
+    def sort_window(self, ids_list):
+        """The dedup sorts of the k batches of an optimizer window in ONE launch (rsx_field_sort_multi), batch i into
+        sort workspace i; leaves workspace 0 selected."""
+        k = len(ids_list)
+        jobs = (_lib.SortJob * k)()
+        for i, ids in enumerate(ids_list):
+            self.select(i)
+            jobs[i] = self.sort_job(ids)
+        self.select(0)
+        check(lib().rsx_field_sort_multi(jobs, k, _stream()), "rsx_field_sort_multi")
+
+    def window(self, k, cur):
+        """rsx_adam_window of position `cur` in a window of k steps (sort_window ran at its start)."""
+        if k <= 1:
+            return None
+        w = _lib.AdamWindow()
+        w.k, w.cur, w.max_unique = k, cur, self.last_B
+        owner = getattr(self, "_sort_owner", None) or self
+        for i, b in enumerate(owner.window_bufs(k)):
+            w.uniq_row[i], w.nuniq[i], w.slot[i] = b["uniq_row"].data_ptr(), b["nuniq"].data_ptr(), b["slot"].data_ptr()
+        return w
 
     def sort_job(self, ids):
         """The rsx_field_sort call of this step as a job another launch can carry (FusedTower.train_step)."""
@@ -190,9 +233,12 @@ class EmbeddingArena:
                                    _ptr(self.gw1) if gy1 is not None else None, self.w1_mask, B, self.F, self.D,
                                    self.stride, part, blk, _stream()), "rsx_segsum_bwd")
 
-    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True, second=None):
+    def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True, second=None,
+                    window=None):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups).
-        second = (arena2, dX2): a table set sharing this arena's sort (share_sort_of), updated by the same launch."""
+        second = (arena2, dX2): a table set sharing this arena's sort (share_sort_of), updated by the same launch.
+        window = (k, cur): this step is position `cur` of an optimizer window of k steps (the current sort workspace must
+        be `cur`): the rows the window's other steps touch get this step's untouched-row update in the same launch."""
         blk = self._blocks(blocks)
         sec = None
         if second is not None:
@@ -204,6 +250,10 @@ class EmbeddingArena:
             sec = C.byref(sec_obj)
         arr, n = opt._seg_array(extra_segments)
         lr, b1, b2, eps = opt.hp
+        win = None
+        if window is not None and window[0] > 1:
+            assert self.cur_buf == window[1], "segsum_adam: select() the window position's sort workspace first"
+            win = self.window(*window)
         w = self.with_w1 and gy1 is not None
         part = self._stage_a(B, S, dX, gy1, gy2, blk)
         check(lib().rsx_segsum_adam_rows(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), _ptr(self.w1) if w else None,
@@ -211,18 +261,26 @@ class EmbeddingArena:
                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
                                          None if sweep is None else C.byref(sweep), part, blk, sec,
+                                         None if win is None else C.byref(win),
                                          _ptr(opt.state), 1 if advance else 0, lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
 
     # -- optimizer segments ----------------------------------------------------------------
-    def adam_split_segments(self):
+    def adam_split_segments(self, window_k=1):
         """(cold, hot): the exact TF-1 update split into the untouched-row sweep (depends only on the slot map, may
-        overlap the tower) and the touched rows (needs this step's gradients)."""
+        overlap the tower) and the touched rows (needs this step's gradients).  window_k > 1: the sweep of a whole optimizer
+        window (the rows none of its k steps touches, k updates in one pass; call at window position 0)."""
+        slot_w = None
+        if window_k > 1:
+            assert self.cur_buf == 0
+            owner = getattr(self, "_sort_owner", None) or self
+            slot_w = [b["slot"] for b in owner.window_bufs(window_k)[1:]]
         cold = [dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=self.D, n=self.R, var=self.tables, m=self.m_t, v=self.v_t,
-                     slot=self.slot)]
+                     slot=self.slot, slot_w=slot_w)]
         hot = [dict(kind=_lib.RSX_ADAM_TABLE_ROWS, d=self.D, n=self.F * self.last_B, var=self.tables, m=self.m_t,
                     v=self.v_t, g=self.G, uniq_row=self.uniq_row, nuniq=self.nuniq, B=self.last_B, stride=self.stride)]
         if self.with_w1:
-            cold.append(dict(kind=_lib.RSX_ADAM_VEC_COLD, n=self.R, var=self.w1, m=self.m_w, v=self.v_w, slot=self.slot))
+            cold.append(dict(kind=_lib.RSX_ADAM_VEC_COLD, n=self.R, var=self.w1, m=self.m_w, v=self.v_w, slot=self.slot,
+                             slot_w=slot_w))
             hot.append(dict(kind=_lib.RSX_ADAM_VEC_ROWS_DENSE, n=self.F * self.last_B, var=self.w1, m=self.m_w, v=self.v_w,
                             g=self.gw1, uniq_row=self.uniq_row, nuniq=self.nuniq, B=self.last_B, stride=self.stride))
         return cold, hot
@@ -388,6 +446,8 @@ class AdamTF1:
                 t = s.get(f)
                 setattr(a, f, None if t is None else t.data_ptr())
             a.B, a.stride, a.zero_grad = s.get("B", 0), s.get("stride", 0), s.get("zero_grad", 0)
+            for j, t in enumerate(s.get("slot_w") or ()):
+                a.slot_w[j] = t.data_ptr()
         return arr, n
 
     def step(self, segments):

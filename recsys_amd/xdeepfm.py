@@ -83,6 +83,8 @@ def build_variables(store, params, capacity):
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
+    if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
+        store.window_k = _lib.ADAM_WINDOW_MAX          # optimizer windows (include/rsx.h rsx_adam_window)
     store.dp_block = False
     if store.dp is not None and params.get("dp_send_block", True):          # zero-copy gradient exchange (see deepfm.py)
         store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])
@@ -112,7 +114,23 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         # they depend on nothing of the step), so the same exact split of the TF-1 update applies as on one GPU
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if zc else ids
         job, ride = None, False
-        if dp is None or zc:
+        # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
+        # untouched rows of BOTH table sets once for the whole window (a launch of its own); the other positions run neither
+        wk, wpos, wfeat = store.window_of_step()
+        split = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
+        if wk > 1 and not (split and dp is None):
+            raise _lib.RsxError("optimizer windows need the split TF-1 update on one GPU")
+        a1.select(wpos)
+        a2.select(wpos)
+        if wk > 1:
+            if wpos == 0:
+                a1.sort_window([f["ids"] for f in wfeat])
+                c1, _ = a1.adam_split_segments(window_k=wk)
+                c2, _ = a2.adam_split_segments(window_k=wk)
+                store.opt.run_slice(store.opt.cold_slices(c1[::-1] + c2, [1.0])[0])
+            a1.last_B = a2.last_B = B
+            hot = ()
+        elif dp is None or zc:
             a2.last_B = ids_sort.shape[0]
             # The sort (it serves a2 as well, share_sort_of) rides in the tower's first forward launch when no sweep slice is
             # scheduled before or in that launch (slices read the sort's slot map); otherwise it runs first.
@@ -201,7 +219,10 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
             elif hot is not None:
                 # scatter + touched-row Adam of BOTH table sets (one shared sort) in one launch, which also carries the
                 # dense variables and advances the beta powers
-                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, store.dense.adam_segments(), last_sweep, second=(a2, dX2))
+                a1.select(wpos)
+                a2.select(wpos)
+                a1.segsum_adam(B, None, dX1, g_lin, None, store.opt, store.dense.adam_segments(), last_sweep, second=(a2, dX2),
+                               window=(wk, wpos))
             else:
                 a1.segsum(B, None, dX1, g_lin, None)
                 a2.segsum(B, None, dX2, None, None)

@@ -1,0 +1,37 @@
+"""GPU box: stand-alone time of the untouched-row sweep (COLD kinds, DeepFM-size state) for windows of 1..4 steps."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from oracle import criteo
+from recsys_amd import _lib
+from recsys_amd.ops import AdamTF1, EmbeddingArena
+from tests.parity_util import synth_ids
+
+row_off = criteo.row_offsets()
+a = EmbeddingArena(row_off, 16, 256, "cuda", with_w1=True, w1_field_mask=(1 << 39) - 1)
+with torch.no_grad():
+    a.tables.normal_(); a.w1.normal_()
+    a.m_t.normal_().mul_(0.01); a.v_t.uniform_().mul_(1e-4)
+    a.m_w.normal_().mul_(0.01); a.v_w.uniform_().mul_(1e-4)
+rng = np.random.default_rng(0)
+a.sort_window([torch.from_numpy(synth_ids(rng, 256, row_off)).cuda() for _ in range(4)])
+opt = AdamTF1(device="cuda")
+for k in (1, 2, 3, 4):
+    cold, _ = a.adam_split_segments(window_k=k)
+    sl = opt.cold_slices(cold[::-1], [1.0])[0]
+    g = torch.cuda.CUDAGraph()
+    opt.run_slice(sl)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            opt.run_slice(sl)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print("window %d: %.1f us per sweep, %.1f us per step" % (k, e0.elapsed_time(e1) * 10, e0.elapsed_time(e1) * 10 / k))

@@ -88,12 +88,52 @@ def test_scatter_second_table_set_is_validated(L):
     from recsys_amd._lib import TableSet
     ts = TableSet(0x1000, 0x1000, 0, 0x1000, None)      # no v
     r = L.rsx_segsum_adam_rows(P, P, P, None, None, None, None, P, None, None, P, P, P, P, 0, 8, 4, 16, 8, None, 0, None, None,
-                               None, C.byref(ts), P, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+                               None, C.byref(ts), None, P, 1, 1e-3, 0.9, 0.999, 1e-8, None)
     assert r == EINVAL
     # first-order gradient without the first-order vector
     r = L.rsx_segsum_adam_rows(P, P, P, None, None, None, None, P, P, None, P, P, P, P, 0, 8, 4, 16, 8, None, 0, None, None,
-                               None, None, P, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+                               None, None, None, P, 1, 1e-3, 0.9, 0.999, 1e-8, None)
     assert r == EINVAL
+
+
+def test_optimizer_window_is_validated(L):
+    from recsys_amd._lib import AdamSeg, AdamWindow, SortJob, RSX_ADAM_TABLE_TF1, RSX_ADAM_TABLE_TF1_COLD
+    w = AdamWindow()
+    w.k, w.cur, w.max_unique = 2, 0, 8
+    for i in range(2):
+        w.uniq_row[i], w.nuniq[i], w.slot[i] = 0x1000 + 0x100 * i, 0x1000, 0x1000
+    call = lambda win: L.rsx_segsum_adam_rows(P, P, P, None, None, None, None, P, None, None, P, P, C.c_void_p(0x1000), P, 0, 8, 4,
+                                              16, 8, None, 0, None, None, None, None, C.byref(win), P, 1, 1e-3, 0.9, 0.999,
+                                              1e-8, None)
+    w.cur = 2
+    assert call(w) == EINVAL                                   # position outside the window
+    w.cur = 1
+    assert call(w) == EINVAL                                   # entry `cur` is not this step's sort workspace
+    w.cur, w.k = 0, 5
+    assert call(w) == EINVAL                                   # more than RSX_ADAM_WINDOW_MAX steps
+    w.k = 2
+    w.slot[1] = None
+    assert call(w) == EINVAL
+    # the extra slot maps are a prefix, and only the COLD kinds take them
+    seg = (AdamSeg * 1)()
+    seg[0].kind, seg[0].d, seg[0].n = RSX_ADAM_TABLE_TF1_COLD, 16, 64
+    seg[0].var = seg[0].m = seg[0].v = seg[0].slot = 0x1000
+    seg[0].slot_w[1] = 0x1000
+    assert L.rsx_adam_num_blocks(seg, 1) == EINVAL
+    seg[0].slot_w[0] = 0x1000
+    assert L.rsx_adam_num_blocks(seg, 1) > 0
+    seg[0].kind, seg[0].g = RSX_ADAM_TABLE_TF1, 0x1000
+    assert L.rsx_adam_num_blocks(seg, 1) == EINVAL
+    # multi-sort: 1..4 jobs of one shape, each with a workspace of its own
+    jobs = (SortJob * 2)()
+    for i in range(2):
+        j = jobs[i]
+        j.ids = j.row_off = j.perm = j.seg_off = j.uniq_row = j.nuniq = j.slot = 0x1000
+        j.max_rows_per_field, j.B, j.F, j.stride = 100, 8, 4, 8
+    assert L.rsx_field_sort_multi(jobs, 2, None) == EINVAL     # shared workspace
+    assert L.rsx_field_sort_multi(jobs, 5, None) == EINVAL
+    jobs[1].slot, jobs[1].perm, jobs[1].B = 0x2000, 0x2000, 4
+    assert L.rsx_field_sort_multi(jobs, 2, None) == EINVAL     # different shapes
 
 
 def test_attention_envelope(L):
