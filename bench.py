@@ -8,9 +8,11 @@ synthetic pre-hashed batch already resident in HBM.  Optimizer semantics are the
 (`adam_mode=tf1_dense`): nothing is skipped inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel (adam_multi_k, the TF-faithful dense Adam sweep): algorithmic bytes per
-                  launch / mean launch duration measured with HIP events on the launch stream.
-                  step_achieved / step_frac: the same bytes over the measured STEP time.
+  roofline     -- the kernel that moves the bytes: the TF-faithful dense Adam sweep.  With optimizer windows (the
+                  default: include/rsx.h rsx_adam_window) that is adam_slice_k, ONE pass over the optimizer state per
+                  window of k steps: bytes of the pass / mean launch duration, HIP events on the launch stream;
+                  `single_step_sweep` = adam_multi_k, the one-step sweep every non-windowed path runs.
+                  step_achieved / step_frac: a step-by-step TF-1 run's bytes (345 MB) over the measured STEP time.
   cpu_baseline -- the same step on PyTorch-CPU fp32 with every host core (oracle/torch_ref.py; N=1, rank 0 only).
 """
 import argparse
@@ -251,26 +253,77 @@ def main():
         adam_ms += e0.elapsed_time(e1)
     adam_ms /= reps * per
     roof = None
-    traffic = None        # PMC-derived HBM bytes per launch: collected offline (scripts/pmc.sh, separate --pmc passes) and committed
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_adam_multi_k.json")))
-        if pm.get("model") == a.model and a.adam_mode == "tf1_dense":
-            traffic = int((2 * pm["FETCH_SIZE_kb_per_launch"] + pm["WRITE_SIZE_kb_per_launch"]) * 1024)
-    except Exception:
-        traffic = None
+    wk = est._window_len() if (dp is None and emu is None and not a.no_graph and not a.no_overlap) else 1
+
+    def pmc_traffic(kernel):
+        """PMC-derived HBM bytes per launch: collected offline (scripts/pmc.sh, separate --pmc passes) and committed."""
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % kernel)))
+            if pm.get("model") == a.model and a.adam_mode == "tf1_dense":
+                return int((2 * pm["FETCH_SIZE_kb_per_launch"] + pm["WRITE_SIZE_kb_per_launch"]) * 1024)
+        except Exception:
+            pass
+        return None
+
+    src = ("offline: separate rocprofv3 --pmc passes of this command (scripts/pmc.sh), 2 x FETCH_SIZE + WRITE_SIZE, "
+           "committed as profiles/pmc_%s.json")
     if alg_bytes is not None:
         ach = alg_bytes / (adam_ms * 1e-3) / 1e9
-        # step-level figure beside the stand-alone kernel: in the timed step the sweep does not run as adam_multi_k
-        # but rides, slice by slice, in the tower / head / scatter launches (same per-workgroup code); the bytes it has
-        # to move per step are the same, so `step_achieved` = those bytes / the measured step time.
         step_ach = alg_bytes / (dt / a.steps) / 1e9
-        roof = {"bound": "hbm", "kernel": "adam_multi_k", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(ach / 8000.0, 4), "traffic": traffic,
-                "traffic_source": "offline: separate rocprofv3 --pmc passes of this command (scripts/pmc.sh), "
-                                  "2 x FETCH_SIZE + WRITE_SIZE, committed as profiles/pmc_adam_multi_k.json" if traffic else None,
-                "alg_bytes_per_launch": alg_bytes, "launch_ms": round(adam_ms, 5),
-                "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / 8000.0, 4),
-                "step_floor_ms": round(alg_bytes / 8e12 * 1e3, 5)}
+        traffic = pmc_traffic("adam_multi_k")
+        single = {"kernel": "adam_multi_k", "achieved": round(ach, 1), "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                  "traffic_source": src % "adam_multi_k" if traffic else None, "alg_bytes_per_launch": alg_bytes,
+                  "launch_ms": round(adam_ms, 5)}
+        from recsys_amd.ops import EmbeddingArena
+        arenas = [x for x in store.embeddings.values() if isinstance(x, EmbeddingArena)]
+        if wk > 1 and arenas:
+            # The timed step runs ONE sweep over the untouched rows per optimizer window of wk steps (include/rsx.h
+            # rsx_adam_window): the launch that moves the bytes.  Timed the same way, with the last window's slot maps live.
+            cold = []
+            for ar in arenas:
+                ar.select(0)
+                cold += ar.adam_split_segments(window_k=wk)[0][::-1]
+            sl = store.opt.cold_slices(cold, [1.0])[0]
+            gw = torch.cuda.CUDAGraph()
+            store.opt.run_slice(sl)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gw):
+                for _ in range(per):
+                    store.opt.run_slice(sl)
+            gw.replay()
+            torch.cuda.synchronize()
+            win_ms = 0.0
+            for r in range(reps):
+                e0.record()
+                gw.replay()
+                e1.record()
+                e1.synchronize()
+                win_ms += e0.elapsed_time(e1)
+            win_ms /= reps * per
+            # bytes of ONE pass: 24 B per table / first-order element + the wk slot maps (4 B per row each)
+            rows = sum(int(ar.R) for ar in arenas if getattr(ar, "_sort_owner", None) is None)
+            pass_bytes = 24 * n_sparse + 4 * wk * rows
+            wach = pass_bytes / (win_ms * 1e-3) / 1e9
+            traffic = pmc_traffic("adam_slice_k")
+            roof = {"bound": "hbm", "kernel": "adam_slice_k (ONE untouched-row sweep per optimizer window)", "window_steps": wk,
+                    "achieved": round(wach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(wach / 8000.0, 4),
+                    "traffic": traffic, "traffic_source": src % "adam_slice_k" if traffic else None,
+                    "alg_bytes_per_launch": pass_bytes, "launch_ms": round(win_ms, 5),
+                    "note": "achieved = the bytes this launch has to move (one pass over the optimizer state) / its duration; "
+                            "it applies wk TF-1 updates per element, i.e. SURVEY 8(d)'s 345 MB/step figure x wk steps = "
+                            "tf1_equivalent_bytes, moved in one pass",
+                    "tf1_equivalent_bytes": wk * alg_bytes,
+                    "tf1_equivalent_GBps": round(wk * alg_bytes / (win_ms * 1e-3) / 1e9, 1),
+                    "single_step_sweep": single,
+                    # the whole step against the bytes a step-by-step TF-1 run has to move (345 MB each)
+                    "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / 8000.0, 4),
+                    "step_floor_ms": round(pass_bytes / wk / 8e12 * 1e3, 5)}
+        else:
+            # step-level figure beside the stand-alone kernel: in the timed step the sweep does not run as adam_multi_k
+            # but rides, slice by slice, in the tower / head / scatter launches (same per-workgroup code); the bytes it has
+            # to move per step are the same, so `step_achieved` = those bytes / the measured step time.
+            roof = dict(single, bound="hbm", peak=8000.0, unit="GB/s", step_achieved=round(step_ach, 1),
+                        step_frac=round(step_ach / 8000.0, 4), step_floor_ms=round(alg_bytes / 8e12 * 1e3, 5))
 
     if dp is not None:
         dp.barrier()
@@ -293,6 +346,7 @@ def main():
                                      ("per-step graph segments, RCCL collectives %s" %
                                       ("captured" if os.environ.get("RSX_DP_CAPTURE") == "1" else "eager between segments"))),
                       "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5),
+                      "adam_window": wk,
                       "timed_repeats_ms_per_step": [round(x / a.steps * 1e3, 5) for x in dts], "reported": "median repeat"},
            "roofline": roof}
     if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":

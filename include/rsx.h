@@ -98,7 +98,7 @@ typedef struct {
   int32_t* segid;             /* nullable */
   int32_t max_rows_per_field, B, F, stride;
 } rsx_sort_job;
-/* njobs (<= 4) independent sorts of the same shape (B, F, stride) in ONE launch, F workgroups each: the k batches of an
+/* njobs (<= 8) independent sorts of the same shape (B, F, stride) in ONE launch, F workgroups each: the k batches of an
  * optimizer window (rsx_adam_window), each into its own workspace.  B <= 16384 (the rsx_field_sort range).              */
 int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_stream_t stream);
 /* rsx_gather_fm_fwd with the step's dedup sort (`sort_h`, see rsx_sort_job above) riding along as F extra workgroups of
@@ -187,12 +187,14 @@ typedef struct {
   int32_t stride;          /* *_ROWS: per-field capacity of the rsx_field_sort workspace.  DENSE with B > 1: floats
                               between the replicas' arenas inside g (an all-gathered buffer), summed in order r = 0.. */
   int32_t zero_grad;       /* DENSE */
-  /* *_COLD kinds, optimizer WINDOW of 1 + w steps (w = leading non-NULL entries, 0..3): the slot maps of the window's LATER
+  /* *_COLD kinds, optimizer WINDOW of 1 + w steps (w = leading non-NULL entries, 0..7): the slot maps of the window's LATER
    * steps (their batches' ids are known ahead: rsx_field_sort_multi).  A row / element that NO step of the window touches
    * (slot and every slot_w < 0) receives the window's 1 + w untouched-row updates back to back in registers -- the same fp32
    * operations, in the same order, as 1 + w single-step sweeps, for 1/(1 + w) of their HBM traffic; every other row is
-   * skipped and is brought up to date step by step by rsx_segsum_adam_rows (`win_h`).  All NULL: a one-step sweep.        */
-  const int32_t* slot_w[3];
+   * skipped and is brought up to date step by step by rsx_segsum_adam_rows (`win_h`).  All NULL: a one-step sweep.  Every
+   * COLD segment of one call / slice carries the same maps (tables that share a dedup sort), and the maps are equally spaced
+   * in memory (slot_w[j] = slot_w[0] + j * stride, 16-byte aligned: slices of one allocation), else RSX_EINVAL.             */
+  const int32_t* slot_w[7];
 } rsx_adam_seg;
 
 #define RSX_ADAM_MAX_SEGS 12
@@ -234,7 +236,7 @@ typedef struct rsx_table_set {
  * A row that some step of the window touches is kept exact step by step: step `cur`'s scatter launch updates the rows it
  * touches with their gradient (as always) and walks the OTHER steps' unique-row lists to give the rows that it does not
  * touch this step's zero-gradient update.  Between two windows the state equals that of k single steps, bit for bit. */
-#define RSX_ADAM_WINDOW_MAX 4
+#define RSX_ADAM_WINDOW_MAX 8
 typedef struct {
   int32_t k;                 /* steps of the window (1: no window) */
   int32_t cur;               /* this step's position, 0 .. k-1 */

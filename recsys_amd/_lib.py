@@ -20,7 +20,7 @@ class AdamSeg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n", C.c_int64),
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
                 ("slot", C.c_void_p), ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p),
-                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32), ("slot_w", C.c_void_p * 3)]
+                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32), ("slot_w", C.c_void_p * 7)]
 
 
 class AdamSlice(C.Structure):
@@ -51,7 +51,15 @@ class SortJob(C.Structure):
                 ("max_rows_per_field", C.c_int32), ("B", C.c_int32), ("F", C.c_int32), ("stride", C.c_int32)]
 
 
-ADAM_WINDOW_MAX = 4
+ADAM_WINDOW_MAX = 8
+
+
+def default_adam_window(capacity):
+    """Steps per optimizer window (include/rsx.h rsx_adam_window) for a sort workspace of `capacity` examples: the one
+    sweep per window costs ~56 us + 4.5 us per step (DeepFM-size state), every step walks the other steps' unique-row lists
+    (their length grows with the batch).  Measured on MI355X: 8 steps up to batch 1024, 4 above (dcn.py at 4096: the lists
+    of 3 other steps cost 22 us per step)."""
+    return ADAM_WINDOW_MAX if capacity <= 1024 else 4
 
 
 class AdamWindow(C.Structure):

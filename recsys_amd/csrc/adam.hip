@@ -61,12 +61,28 @@ extern "C" int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg) {
 // The COLD kinds do not advance the beta powers (no ticket): a sweep cut into slices by the caller, run stand-alone.
 __global__ __launch_bounds__(ADAM_T) void adam_slice_k(const AdamSlice s) { adam_block(s.args, s.blk_lo + blockIdx.x); }
 
+// The sweep of an optimizer window (rsx_adam_seg.slot_w): 1 + nw updates per untouched row in one pass.
+template <int NW>
+__global__ __launch_bounds__(ADAM_T, 4) void adam_window_k(const AdamSlice s) {
+  adam_window_block<NW>(s.args, s.blk_lo + blockIdx.x);
+}
+
 extern "C" int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream) {
   AdamSlice s;
   const int rc = adam_build_slice(slice_h, s);
   if (rc != RSX_OK) return rc;
   if (s.n_blk == 0) return RSX_OK;
-  hipLaunchKernelGGL(adam_slice_k, dim3(s.n_blk), dim3(ADAM_T), 0, rsx_s(stream), s);
+  const dim3 grid(s.n_blk), block(ADAM_T);
+  switch (s.args.nw) {
+    case 0: hipLaunchKernelGGL(adam_slice_k, grid, block, 0, rsx_s(stream), s); break;
+    case 1: hipLaunchKernelGGL(adam_window_k<1>, grid, block, 0, rsx_s(stream), s); break;
+    case 2: hipLaunchKernelGGL(adam_window_k<2>, grid, block, 0, rsx_s(stream), s); break;
+    case 3: hipLaunchKernelGGL(adam_window_k<3>, grid, block, 0, rsx_s(stream), s); break;
+    case 4: hipLaunchKernelGGL(adam_window_k<4>, grid, block, 0, rsx_s(stream), s); break;
+    case 5: hipLaunchKernelGGL(adam_window_k<5>, grid, block, 0, rsx_s(stream), s); break;
+    case 6: hipLaunchKernelGGL(adam_window_k<6>, grid, block, 0, rsx_s(stream), s); break;
+    default: hipLaunchKernelGGL(adam_window_k<7>, grid, block, 0, rsx_s(stream), s); break;
+  }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

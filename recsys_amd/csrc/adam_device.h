@@ -10,15 +10,16 @@ struct SegDev {
   const int32_t *slot, *uniq_row, *nuniq;
   int32_t B, stride, zero_grad;
   uint32_t blk_begin;
-  // *_COLD kinds of an optimizer WINDOW (rsx_adam_seg.slot_w): the fields those kinds do not use hold the extra slot maps
-  // (kernel arguments are limited to 4 KB and a launch may embed two AdamArgs): zero_grad = their number (0..3),
-  // uniq_row / nuniq / g = the maps.
-  __host__ __device__ const int32_t* slot_w(int i) const {
-    return i == 0 ? uniq_row : i == 1 ? nuniq : reinterpret_cast<const int32_t*>(g);
-  }
 };
+constexpr int ADAM_WMAX = RSX_ADAM_WINDOW_MAX - 1;     // extra slot maps of an optimizer window
 struct AdamArgs {
   SegDev seg[RSX_ADAM_MAX_SEGS];
+  // *_COLD kinds of an optimizer WINDOW (rsx_adam_seg.slot_w): the slot maps of the window's later steps, shared by every COLD
+  // segment of the launch (kernel arguments are limited to 4 KB and a launch may embed two AdamArgs)
+  // -- equally spaced (one allocation; base + stride keeps them out of the scalar registers)
+  const int32_t* slot_w0;
+  long long slot_w_stride;      // in int32 elements
+  int32_t nw;
   int32_t nseg;
   float lr, b1, b2, eps;
   float* state;
@@ -64,6 +65,28 @@ constexpr int ADAM_T = 256;         // threads per workgroup
 constexpr int ADAM_U = RSX_ADAM_U;  // float4 per lane
 constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
 
+// alpha of the window's later steps: step j of the window runs with the beta powers advanced j times -- the same fp32
+// products the per-step advance of the powers makes.  (Named scalars, no array: a dynamically indexed local array is
+// promoted to LDS / scratch by this toolchain.)
+struct AlphaW {
+  float a0, a1, a2, a3, a4, a5, a6;
+  __device__ __forceinline__ float get(int j) const {
+    return j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : j == 3 ? a3 : j == 4 ? a4 : j == 5 ? a5 : a6;
+  }
+};
+static_assert(ADAM_WMAX == 7, "AlphaW holds 7 steps");
+__device__ __forceinline__ AlphaW alpha_window(const AdamArgs& a, int nw, float b1p, float b2p) {
+  AlphaW aw = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (nw > 0) {
+    float p1 = b1p, p2 = b2p;
+#define RSX_ALPHA_NEXT(dst) p1 *= a.b1; p2 *= a.b2; dst = a.lr * sqrtf(1.0f - p2) / (1.0f - p1)
+    RSX_ALPHA_NEXT(aw.a0); RSX_ALPHA_NEXT(aw.a1); RSX_ALPHA_NEXT(aw.a2); RSX_ALPHA_NEXT(aw.a3);
+    RSX_ALPHA_NEXT(aw.a4); RSX_ALPHA_NEXT(aw.a5); RSX_ALPHA_NEXT(aw.a6);
+#undef RSX_ALPHA_NEXT
+  }
+  return aw;
+}
+
 // One workgroup (ADAM_T = 256 threads) of the sweep: block `blk` of the launch-wide block index space of `a`.
 __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk, const int tid = threadIdx.x) {
   const float b1p = a.state[0], b2p = a.state[1];
@@ -82,96 +105,18 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   // window of 1 + nw steps (COLD kinds only): step j of the window runs with the beta powers advanced j times -- the same
   // fp32 products the per-step advance of the powers makes
   const bool is_cold = s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD;
-  const int nw = is_cold ? s.zero_grad : 0;
-  float alpha_w[3] = {0.f, 0.f, 0.f};
-  if (nw > 0) {
-    float p1 = b1p, p2 = b2p;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      p1 *= a.b1;
-      p2 *= a.b2;
-      alpha_w[j] = a.lr * sqrtf(1.0f - p2) / (1.0f - p1);
-    }
-  }
-  const int32_t* __restrict__ sw0 = s.uniq_row;
-  const int32_t* __restrict__ sw1 = s.nuniq;
-  const int32_t* __restrict__ sw2 = reinterpret_cast<const int32_t*>(s.g);
+  const int nw = is_cold ? a.nw : 0;
+  const AlphaW aw = alpha_window(a, nw, b1p, b2p);
+  // the window's extra slot maps are equally spaced (one allocation): base + stride instead of 7 pointers in scalar registers
+  const int32_t* __restrict__ swb = a.slot_w0;
+  const long long sws = a.slot_w_stride;
   const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  if (s.kind == RSX_ADAM_TABLE_TF1_COLD && nw > 0) {
-    // The untouched rows of a window of 1 + nw steps (stand-alone launches; the one-step sweep below is what rides in other
-    // kernels' launches, where its 61 registers matter): touched rows are left to the scatter launches.  Batches of HB float4
-    // per lane, each in phases so that every load of the batch is in flight before the first use: slot maps (clamped index),
-    // then var / m / v unconditionally (a skipped row costs its read, ~1 % of the traffic; a guarded load would serialise
-    // the batch), then the 1 + nw updates one float4 at a time (4 independent chains, few temporaries: riders inherit their
-    // carrier's register budget), then the stores of the rows that moved.
-    constexpr int HB = 4;
-    static_assert(ADAM_U % HB == 0, "ADAM_U");
-    const int lpr = s.d >> 2;
-    const long long n4 = s.n * lpr;
-    const bool pow2 = (lpr & (lpr - 1)) == 0;
-    const int lsh = 31 - __clz(lpr);
-    const float aw0 = alpha_w[0], aw1 = alpha_w[1], aw2 = alpha_w[2];
-#pragma unroll 1
-    for (int u0 = 0; u0 < ADAM_U; u0 += HB) {
-      bool live[HB];
-      long long ec[HB];
-      int t[HB];
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        const long long e = base + (long long)(u0 + u) * ADAM_T + tid;
-        ec[u] = e < n4 ? e : n4 - 1;
-        live[u] = e < n4;
-        const long long row = pow2 ? (ec[u] >> lsh) : (ec[u] / lpr);
-        t[u] = s.slot[row];
-        if (nw > 0) t[u] &= sw0[row];           // (untouched = -1 = all ones: one value >= 0 clears the sign of the AND)
-        if (nw > 1) t[u] &= sw1[row];
-        if (nw > 2) t[u] &= sw2[row];
-      }
-      float4 var[HB], m[HB], v[HB];
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-#if RSX_ADAM_NT
-        var[u] = __builtin_nontemporal_load(&var4[ec[u]]);
-        m[u] = __builtin_nontemporal_load(&m4[ec[u]]);
-        v[u] = __builtin_nontemporal_load(&v4[ec[u]]);
-#else
-        var[u] = var4[ec[u]];
-        m[u] = m4[ec[u]];
-        v[u] = v4[ec[u]];
-#endif
-      }
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        live[u] = live[u] && t[u] < 0;
-        F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, h);
-#pragma unroll 1
-        for (int j = 0; j < nw; ++j) {          // the later steps of the window, back to back in registers
-          Hp hj = h;
-          hj.alpha = j == 0 ? aw0 : j == 1 ? aw1 : aw2;
-          F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, hj);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        if (live[u]) {
-#if RSX_ADAM_NT
-          __builtin_nontemporal_store(var[u], &var4[ec[u]]);
-          __builtin_nontemporal_store(m[u], &m4[ec[u]]);
-          __builtin_nontemporal_store(v[u], &v4[ec[u]]);
-#else
-          var4[ec[u]] = var[u];
-          m4[ec[u]] = m[u];
-          v4[ec[u]] = v[u];
-#endif
-        }
-      }
-    }
-  } else if (s.kind == RSX_ADAM_TABLE_TF1 || s.kind == RSX_ADAM_TABLE_TF1_COLD) {
+  if (s.kind == RSX_ADAM_TABLE_TF1 || s.kind == RSX_ADAM_TABLE_TF1_COLD) {
     const bool cold_only = s.kind == RSX_ADAM_TABLE_TF1_COLD;   // touched rows are left to the TABLE_ROWS launch
     const int lpr = s.d >> 2;
     const long long n4 = s.n * lpr;
@@ -182,7 +127,8 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
       if (e < n4) {
         const long long row = e / lpr;
         const int q = (int)(e - row * lpr);
-        const int sl = s.slot[row];
+        int sl = s.slot[row];
+        for (int l = 0; l < nw; ++l) sl &= swb[(long long)l * sws + row];      // window (see adam_window_block for the fast form)
         if (cold_only && sl >= 0) continue;
 #if RSX_ADAM_NT
         float4 var = __builtin_nontemporal_load(&var4[e]), m = __builtin_nontemporal_load(&m4[e]),
@@ -193,6 +139,12 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         const bool has = sl >= 0;
         const float4 g = has ? G4[(long long)sl * lpr + q] : z4;
         F4_APPLY(adam_sparse1, var, m, v, g, has, h);
+#pragma unroll 1
+        for (int j = 0; j < nw; ++j) {
+          Hp hj = h;
+          hj.alpha = aw.get(j);
+          F4_APPLY(adam_sparse1, var, m, v, z4, false, hj);
+        }
 #if RSX_ADAM_NT
         __builtin_nontemporal_store(var, &var4[e]);
         __builtin_nontemporal_store(m, &m4[e]);
@@ -243,9 +195,10 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
       const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         int4 sl = reinterpret_cast<const int4*>(s.slot)[e];
-        if (nw > 0) { const int4 t = reinterpret_cast<const int4*>(sw0)[e]; sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w; }
-        if (nw > 1) { const int4 t = reinterpret_cast<const int4*>(sw1)[e]; sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w; }
-        if (nw > 2) { const int4 t = reinterpret_cast<const int4*>(sw2)[e]; sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w; }
+        for (int l = 0; l < nw; ++l) {
+          const int4 t = reinterpret_cast<const int4*>(swb + (long long)l * sws)[e];
+          sl.x &= t.x; sl.y &= t.y; sl.z &= t.z; sl.w &= t.w;
+        }
         float4 g;
         g.x = (!cold_only && sl.x >= 0) ? s.g[sl.x] : 0.f;     // COLD: g is not provided (touched elements are restored below)
         g.y = (!cold_only && sl.y >= 0) ? s.g[sl.y] : 0.f;
@@ -256,7 +209,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         F4_APPLY(adam_dense1, var, m, v, g, h);
         for (int j = 0; j < nw; ++j) {
           Hp hj = h;
-          hj.alpha = j == 0 ? alpha_w[0] : j == 1 ? alpha_w[1] : alpha_w[2];
+          hj.alpha = aw.get(j);
           F4_APPLY(adam_dense1, var, m, v, z4, hj);
         }
         if (cold_only) {   // element-wise: leave the touched elements exactly as they were
@@ -271,14 +224,12 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
       } else if (e == n4) {
         for (long long i = n4 * 4; i < s.n; ++i) {
           int sl = s.slot[i];
-          if (nw > 0) sl &= sw0[i];
-          if (nw > 1) sl &= sw1[i];
-          if (nw > 2) sl &= sw2[i];
+          for (int l = 0; l < nw; ++l) sl &= swb[(long long)l * sws + i];
           if (cold_only && sl >= 0) continue;
           adam_dense1(s.var[i], s.m[i], s.v[i], sl >= 0 ? s.g[sl] : 0.f, h);
           for (int j = 0; j < nw; ++j) {
             Hp hj = h;
-            hj.alpha = j == 0 ? alpha_w[0] : j == 1 ? alpha_w[1] : alpha_w[2];
+            hj.alpha = aw.get(j);
             adam_dense1(s.var[i], s.m[i], s.v[i], 0.f, hj);
           }
         }
@@ -325,13 +276,117 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   }
 }
 
+// The untouched rows of a window of 1 + nw steps, fast form (its own kernel, adam_window_k: ~125 registers against the 61
+// of adam_block, whose footprint every carrier kernel and the one-step sweep inherit).  Blocks of other kinds -> adam_block.
+template <int NW>
+__device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint32_t blk, const int tid = threadIdx.x) {
+  int si = 0;
+#pragma unroll 1
+  for (int k = 1; k < a.nseg; ++k)
+    if (blk >= a.seg[k].blk_begin) si = k;
+  const SegDev& s = a.seg[si];
+  constexpr int nw = NW;        // == a.nw (the host picks the instantiation)
+  if (s.kind != RSX_ADAM_TABLE_TF1_COLD) {
+    adam_block(a, blk, tid);
+    return;
+  }
+  const float b1p = a.state[0], b2p = a.state[1];
+  Hp h;
+  h.b1 = a.b1;
+  h.b2 = a.b2;
+  h.omb1 = 1.0f - a.b1;
+  h.omb2 = 1.0f - a.b2;
+  h.eps = a.eps;
+  h.alpha = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  const AlphaW aw = alpha_window(a, nw, b1p, b2p);
+  const int32_t* __restrict__ swb = a.slot_w0;
+  const int sws = (int)a.slot_w_stride;           // (< 2^28: adam_build_args) 32-bit element offsets: scalar base + vector offset
+  const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
+  float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
+  float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
+  float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    // The untouched rows of a window of 1 + nw steps (stand-alone launches; the one-step sweep below is what rides in other
+    // kernels' launches, where its 61 registers matter): touched rows are left to the scatter launches.  Batches of HB float4
+    // per lane, each in phases so that every load of the batch is in flight before the first use: slot maps (clamped index),
+    // then var / m / v unconditionally (a skipped row costs its read, ~1 % of the traffic; a guarded load would serialise
+    // the batch), then the 1 + nw updates one float4 at a time (4 independent chains, few temporaries: riders inherit their
+    // carrier's register budget), then the stores of the rows that moved.
+    constexpr int HB = 4;
+    static_assert(ADAM_U % HB == 0, "ADAM_U");
+    const int lpr = s.d >> 2;
+    const long long n4 = s.n * lpr;
+    const bool pow2 = (lpr & (lpr - 1)) == 0;
+    const int lsh = 31 - __clz(lpr);
+#pragma unroll 1
+    for (int u0 = 0; u0 < ADAM_U; u0 += HB) {
+      bool live[HB];
+      long long ec[HB];
+      int t[HB];
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const long long e = base + (long long)(u0 + u) * ADAM_T + tid;
+        ec[u] = e < n4 ? e : n4 - 1;
+        live[u] = e < n4;
+        const long long row = pow2 ? (ec[u] >> lsh) : (ec[u] / lpr);
+        t[u] = s.slot[row];
+        // (untouched = -1 = all ones: one value >= 0 clears the sign of the AND.)  All of them in flight at once.
+#pragma unroll
+        for (int l = 0; l < NW; ++l) t[u] &= swb[l * sws + (int)row];
+      }
+      float4 var[HB], m[HB], v[HB];
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+#if RSX_ADAM_NT
+        var[u] = __builtin_nontemporal_load(&var4[ec[u]]);
+        m[u] = __builtin_nontemporal_load(&m4[ec[u]]);
+        v[u] = __builtin_nontemporal_load(&v4[ec[u]]);
+#else
+        var[u] = var4[ec[u]];
+        m[u] = m4[ec[u]];
+        v[u] = v4[ec[u]];
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        live[u] = live[u] && t[u] < 0;
+        F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, h);
+#pragma unroll 1
+        for (int j = 0; j < NW; ++j) {          // the later steps of the window, back to back in registers
+          Hp hj = h;
+          hj.alpha = aw.get(j);
+          F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, hj);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        if (live[u]) {
+#if RSX_ADAM_NT
+          __builtin_nontemporal_store(var[u], &var4[ec[u]]);
+          __builtin_nontemporal_store(m[u], &m4[ec[u]]);
+          __builtin_nontemporal_store(v[u], &v4[ec[u]]);
+#else
+          var4[ec[u]] = var[u];
+          m4[ec[u]] = m[u];
+          v4[ec[u]] = v[u];
+#endif
+        }
+      }
+    }
+  }
+}
+
 // Host: validates the segment list and lays the segments out over the launch-wide block index space.
 // Returns an rsx_status; *blocks_out = number of workgroups (0 when there is nothing to do).
 static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* state, float lr, float beta1, float beta2,
                                   float eps, AdamArgs& a, uint32_t* blocks_out) {
   if (!segs_h || !state || nseg <= 0 || nseg > RSX_ADAM_MAX_SEGS) return RSX_EINVAL;
   uint32_t blocks = 0;
-  int k = 0;
+  int k = 0, n_cold = 0;
+  a.nw = 0;
+  a.slot_w0 = nullptr;
+  a.slot_w_stride = 0;
   for (int i = 0; i < nseg; ++i) {
     const rsx_adam_seg& s = segs_h[i];
     if (s.n < 0 || !s.var || !s.m || !s.v) return RSX_EINVAL;
@@ -380,15 +435,23 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
     d.B = s.B;
     d.stride = s.stride;
     d.zero_grad = s.zero_grad;
-    if (s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD) {     // see SegDev: the window's extra slot maps
+    if (s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD) {     // the window's extra slot maps (AdamArgs)
       int nw = 0;
-      while (nw < 3 && s.slot_w[nw] != nullptr) ++nw;
-      for (int j = nw; j < 3; ++j)
+      while (nw < ADAM_WMAX && s.slot_w[nw] != nullptr) ++nw;
+      for (int j = nw; j < ADAM_WMAX; ++j)
         if (s.slot_w[j] != nullptr) return RSX_EINVAL;                          // a prefix, no holes
-      d.zero_grad = nw;
-      d.uniq_row = s.slot_w[0];
-      d.nuniq = s.slot_w[1];
-      d.g = const_cast<float*>(reinterpret_cast<const float*>(s.slot_w[2]));
+      const long long str = nw > 1 ? (long long)(s.slot_w[1] - s.slot_w[0]) : 0;
+      for (int j = 1; j < nw; ++j)
+        if (s.slot_w[j] != s.slot_w[0] + j * str) return RSX_EINVAL;           // equally spaced (see rsx.h)
+      if (nw > 0 && (reinterpret_cast<uintptr_t>(s.slot_w[0]) & 15u || (str & 3) || str < 0 || str >= (1ll << 28)))
+        return RSX_EINVAL;                                                      // int4 reads (VEC_COLD), 32-bit offsets
+      if (n_cold++ == 0) {
+        a.nw = nw;
+        a.slot_w0 = s.slot_w[0];
+        a.slot_w_stride = str;
+      } else if (nw != a.nw || (nw > 0 && (a.slot_w0 != s.slot_w[0] || a.slot_w_stride != str))) {
+        return RSX_EINVAL;                                                      // one window per launch
+      }
     }
     d.blk_begin = blocks;
     blocks += (uint32_t)((work + ADAM_Q - 1) / ADAM_Q);

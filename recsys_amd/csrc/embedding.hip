@@ -172,7 +172,7 @@ __global__ __launch_bounds__(1024) void field_sort_k(const SortArgs a) {
 }
 
 struct SortMulti {
-  SortArgs a[4];
+  SortArgs a[RSX_ADAM_WINDOW_MAX];
 };
 __global__ __launch_bounds__(1024) void field_sort_multi_k(const SortMulti m) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -984,7 +984,7 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
 }
 
 extern "C" int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_stream_t stream) {
-  if (!jobs_h || njobs <= 0 || njobs > 4) return RSX_EINVAL;
+  if (!jobs_h || njobs <= 0 || njobs > RSX_ADAM_WINDOW_MAX) return RSX_EINVAL;
   SortMulti m;
   int T = 0;
   size_t lds = 0;
@@ -1006,7 +1006,7 @@ extern "C" int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_s
     if (need > lds) lds = need;
   }
   if (jobs_h[0].B == 0) return RSX_OK;
-  for (int k = njobs; k < 4; ++k) m.a[k] = m.a[0];
+  for (int k = njobs; k < RSX_ADAM_WINDOW_MAX; ++k) m.a[k] = m.a[0];
   if (lds > 64 * 1024) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(field_sort_multi_k),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

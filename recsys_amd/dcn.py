@@ -62,7 +62,7 @@ def build_variables(store, params, capacity):
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
         if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) \
                 and capacity <= 16384:
-            store.window_k = _lib.ADAM_WINDOW_MAX          # optimizer windows (include/rsx.h rsx_adam_window)
+            store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):      # zero-copy gradient exchange (see deepfm.py)

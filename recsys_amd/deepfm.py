@@ -75,7 +75,7 @@ def build_variables(store, params, capacity, with_dnn=True):
         # optimizer windows (include/rsx.h rsx_adam_window): up to 4 consecutive steps share ONE sweep over the untouched rows
         if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) \
                 and capacity <= 16384:
-            store.window_k = _lib.ADAM_WINDOW_MAX
+            store.window_k = _lib.default_adam_window(capacity)
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):

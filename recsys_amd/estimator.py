@@ -529,11 +529,10 @@ class Estimator:
                 if pb.key() != win[0].key():   # e.g. the last, smaller batch of an epoch: a step of its own
                     break
                 win.append(pb)
-            if len(win) < self._window_len() or len(win) == 1:
-                win = win[:1]                  # windows are captured at full length only; the rest runs step by step
+            if len(win) == 1:
                 loss = self._train_step(win[0])
-            else:
-                loss = self._train_window_packed(win)
+            else:                              # (one graph per window length: the full one, and the shorter ones that
+                loss = self._train_window_packed(win)     # end at a log line / checkpoint / the end of training)
             features, labels = held[len(win) - 1]
             del held[:len(win)]
             done += len(win)

@@ -24,7 +24,7 @@ def model_fn(features, labels, mode, params):
         cap = max(int(params.get("max_batch_size", 0)), ids.shape[0])
         _build(store, params, capacity=cap, with_dnn=False)
         if store.dp is None and store.adam_mode == "tf1_dense" and params.get("fused", True) and cap <= 16384:
-            store.window_k = _lib.ADAM_WINDOW_MAX          # optimizer windows (include/rsx.h rsx_adam_window)
+            store.window_k = _lib.default_adam_window(cap)          # optimizer windows (include/rsx.h rsx_adam_window)
         store.dp_block = False
         if store.dp is not None and params.get("fused", True):
             # data-parallel: [S | gy2 | gy1] of the local batch + the dense gradient arena in one persistent send block

@@ -78,7 +78,11 @@ class EmbeddingArena:
             self.P1 = torch.zeros(F * nch * 2, device=dev) if with_w1 else None
         # Dedup-sort workspaces: sortbufs[0] is the step's own; an optimizer WINDOW of k steps (rsx_adam_window) sorts
         # the k batches ahead into sortbufs[0..k-1] (allocated on first use) and select(i) makes entry i the current one.
+        # (the slot maps of all window positions are slices of ONE allocation, equally spaced: rsx_adam_seg.slot_w)
+        self._slot_stride = (self.R + 4 + 3) // 4 * 4
+        self._slot_all = torch.full((_lib.ADAM_WINDOW_MAX, self._slot_stride), -1, **i32)
         self.sortbufs = [self._new_sortbuf()]
+        self.window_bufs(_lib.default_adam_window(st))      # all of them NOW: never inside a HIP-graph capture (see window_bufs)
         self.select(0)
         # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
         self.hook = torch.zeros((), device=dev, requires_grad=True)
@@ -96,7 +100,7 @@ class EmbeddingArena:
         i32 = dict(dtype=torch.int32, device=self.tables.device)
         b = dict(perm=torch.zeros(F * st, **i32), seg_off=torch.zeros(F * (st + 1), **i32),
                  uniq_row=torch.zeros(F * st, **i32), nuniq=torch.zeros(F, **i32),
-                 slot=torch.full((self.R + 4,), -1, **i32),       # +4: int4 tail reads of VEC_SLOT
+                 slot=self._slot_all[len(self.sortbufs) if hasattr(self, "sortbufs") else 0],   # [R + 4]: int4 tail reads of VEC_SLOT
                  segid=torch.zeros(F * st + 2 * F + F * ((st + 15) // 16), **i32) if self.two_stage_ws else None)
         return b
 
@@ -121,6 +125,11 @@ class EmbeddingArena:
     def window_bufs(self, k):
         assert 1 <= k <= _lib.ADAM_WINDOW_MAX
         while len(self.sortbufs) < k:
+            # A workspace created while a HIP graph is being captured would live in that graph's memory pool and its
+            # zero-fill would be replayed with the graph -- wiping the unique-row count the next sort needs to clear the
+            # previous slot-map entries (found the hard way: windows of 7-8 steps diverged on the second replay).
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.RsxError("EmbeddingArena.window_bufs(%d): allocate the window's sort workspaces before capture" % k)
             self.sortbufs.append(self._new_sortbuf())
         return self.sortbufs[:k]
 
@@ -165,6 +174,12 @@ class EmbeddingArena:
             self.select(i)
             jobs[i] = self.sort_job(ids)
         self.select(0)
+        if os.environ.get("RSX_WIN_SEPARATE_SORTS") == "1":      # debugging aid: k launches of the single-sort kernel
+            for i, ids in enumerate(ids_list):
+                self.select(i)
+                self.field_sort(ids)
+            self.select(0)
+            return
         check(lib().rsx_field_sort_multi(jobs, k, _stream()), "rsx_field_sort_multi")
 
     def window(self, k, cur):

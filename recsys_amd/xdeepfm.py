@@ -84,7 +84,7 @@ def build_variables(store, params, capacity):
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
     if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
-        store.window_k = _lib.ADAM_WINDOW_MAX          # optimizer windows (include/rsx.h rsx_adam_window)
+        store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
     store.dp_block = False
     if store.dp is not None and params.get("dp_send_block", True):          # zero-copy gradient exchange (see deepfm.py)
         store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])

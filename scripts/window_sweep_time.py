@@ -15,9 +15,9 @@ with torch.no_grad():
     a.m_t.normal_().mul_(0.01); a.v_t.uniform_().mul_(1e-4)
     a.m_w.normal_().mul_(0.01); a.v_w.uniform_().mul_(1e-4)
 rng = np.random.default_rng(0)
-a.sort_window([torch.from_numpy(synth_ids(rng, 256, row_off)).cuda() for _ in range(4)])
+a.sort_window([torch.from_numpy(synth_ids(rng, 256, row_off)).cuda() for _ in range(8)])
 opt = AdamTF1(device="cuda")
-for k in (1, 2, 3, 4):
+for k in (1, 2, 3, 4, 6, 8):
     cold, _ = a.adam_split_segments(window_k=k)
     sl = opt.cold_slices(cold[::-1], [1.0])[0]
     g = torch.cuda.CUDAGraph()

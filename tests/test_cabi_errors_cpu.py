@@ -109,7 +109,7 @@ def test_optimizer_window_is_validated(L):
     assert call(w) == EINVAL                                   # position outside the window
     w.cur = 1
     assert call(w) == EINVAL                                   # entry `cur` is not this step's sort workspace
-    w.cur, w.k = 0, 5
+    w.cur, w.k = 0, 9
     assert call(w) == EINVAL                                   # more than RSX_ADAM_WINDOW_MAX steps
     w.k = 2
     w.slot[1] = None
@@ -124,14 +124,14 @@ def test_optimizer_window_is_validated(L):
     assert L.rsx_adam_num_blocks(seg, 1) > 0
     seg[0].kind, seg[0].g = RSX_ADAM_TABLE_TF1, 0x1000
     assert L.rsx_adam_num_blocks(seg, 1) == EINVAL
-    # multi-sort: 1..4 jobs of one shape, each with a workspace of its own
+    # multi-sort: 1..8 jobs of one shape, each with a workspace of its own
     jobs = (SortJob * 2)()
     for i in range(2):
         j = jobs[i]
         j.ids = j.row_off = j.perm = j.seg_off = j.uniq_row = j.nuniq = j.slot = 0x1000
         j.max_rows_per_field, j.B, j.F, j.stride = 100, 8, 4, 8
     assert L.rsx_field_sort_multi(jobs, 2, None) == EINVAL     # shared workspace
-    assert L.rsx_field_sort_multi(jobs, 5, None) == EINVAL
+    assert L.rsx_field_sort_multi(jobs, 9, None) == EINVAL
     jobs[1].slot, jobs[1].perm, jobs[1].B = 0x2000, 0x2000, 4
     assert L.rsx_field_sort_multi(jobs, 2, None) == EINVAL     # different shapes
 

@@ -31,7 +31,7 @@ def _adam_np(var, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, dense=False):
     return var1, m1, v1
 
 
-@pytest.mark.parametrize("k", [2, 3, 4])
+@pytest.mark.parametrize("k", [2, 3, 4, 7, 8])
 def test_window_sweep_equals_k_single_sweeps(k):
     """rsx_adam_seg.slot_w: rows no step of the window touches get k updates in one pass, all others are left alone --
     against k stand-alone single-step sweeps of the same rows (which advance the beta powers between them)."""
@@ -42,12 +42,13 @@ def test_window_sweep_equals_k_single_sweeps(k):
     tab0, m0 = torch.randn(R, D, generator=g), torch.randn(R, D, generator=g) * 0.01
     v0 = torch.rand(R, D, generator=g) * 1e-4
     w0, mw0, vw0 = torch.randn(R, generator=g), torch.randn(R, generator=g) * 0.01, torch.rand(R, generator=g) * 1e-4
-    slots = []
+    # the window's slot maps: equally spaced slices of one allocation (rsx_adam_seg.slot_w)
+    slot_all = torch.full((k, R + 4), -1, dtype=torch.int32)
     for i in range(k):
-        s = torch.full((R + 4,), -1, dtype=torch.int32)
         idx = torch.randperm(R, generator=g)[:400]
-        s[idx] = torch.arange(400, dtype=torch.int32)
-        slots.append(s.cuda())
+        slot_all[i, idx] = torch.arange(400, dtype=torch.int32)
+    slot_all = slot_all.cuda()
+    slots = [slot_all[i] for i in range(k)]
     touched = torch.stack([s[:R] >= 0 for s in slots]).any(0)
 
     def run(window):
@@ -101,14 +102,15 @@ def test_multi_sort_equals_single_sorts():
         a = EmbeddingArena(row_off, 16, 2048, "cuda")
         b = EmbeddingArena(row_off, 16, 2048, "cuda")
         for rep in range(2):                                  # the second window also clears the first one's slot maps
-            ids = [torch.from_numpy(synth_ids(rng, B, row_off)).cuda() for _ in range(4)]
+            nj = 8 if B == 256 else 4
+            ids = [torch.from_numpy(synth_ids(rng, B, row_off)).cuda() for _ in range(nj)]
             a.sort_window(ids)
-            for i in range(4):
+            for i in range(nj):
                 b.select(i)
                 b.field_sort(ids[i])
             b.select(0)
             torch.cuda.synchronize()
-            for i in range(4):
+            for i in range(nj):
                 for key in ("perm", "seg_off", "uniq_row", "nuniq", "slot"):
                     x, y = a.sortbufs[i][key], b.sortbufs[i][key]
                     if key in ("perm", "uniq_row"):           # entries beyond the batch / the unique count are workspace
@@ -144,7 +146,7 @@ def _state(est):
             "opt": est.store.opt.state.clone()}
 
 
-@pytest.mark.parametrize("window,steps,spg", [(4, 131, 16), (3, 64, 8), (2, 37, 8)])
+@pytest.mark.parametrize("window,steps,spg", [(8, 131, 16), (8, 75, 8), (7, 60, 8), (4, 131, 16), (3, 64, 8), (2, 37, 8)])
 def test_windowed_resident_training_is_bit_identical_to_single_steps(window, steps, spg):
     """train_resident with optimizer windows of `window` steps inside its HIP graphs (head / tail graphs give shorter
     windows too) against the plain path: stand-alone sort, segment-sum, ONE full TF-1 sweep per step, eager."""
@@ -189,7 +191,7 @@ def test_windowed_streaming_train_is_bit_identical_and_respects_boundaries(tmp_p
     for win in ("4", "1"):
         os.environ["RSX_ADAM_WINDOW"] = win
         try:
-            est = _deepfm_est(4)
+            est = _deepfm_est(8)
             est.train(input_fn, steps=47)
             assert est.global_step == 47
             est.train(input_fn, max_steps=90)          # a second call: continues, stops exactly at max_steps

@@ -22,8 +22,9 @@ def _adversarial_predictions(rng, n):
     special = np.concatenate([th[1:-1], np.nextafter(th[1:-1], np.float32(2)), np.nextafter(th[1:-1], np.float32(-1)),
                               np.array([0.5, 0.0, 1.0, np.nextafter(np.float32(0.5), np.float32(1)), 1.5, 2.5], np.float32)])
     special = np.clip(special, 0, 1).astype(np.float32)
-    idx = rng.choice(n, len(special) * 4, replace=False)
-    p[idx] = np.tile(special, 4)
+    k = min(len(special) * 4, n // 2)                 # small batches: a random half of the batch gets special values
+    idx = rng.choice(n, k, replace=False)
+    p[idx] = rng.permutation(np.tile(special, 4))[:k] if k < len(special) * 4 else np.tile(special, 4)
     y = (rng.random(n) < 0.3 + 0.4 * p).astype(np.float32)       # informative labels: AUC well away from 0.5
     return p, y
 
