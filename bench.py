@@ -9,7 +9,7 @@ synthetic pre-hashed batch already resident in HBM.  Optimizer semantics are the
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the kernel that moves the bytes: the TF-faithful dense Adam sweep.  With optimizer windows (the
-                  default: include/rsx.h rsx_adam_window) that is adam_slice_k, ONE pass over the optimizer state per
+                  default: include/rsx.h rsx_adam_window) that is adam_window_k, ONE pass over the optimizer state per
                   window of k steps: bytes of the pass / mean launch duration, HIP events on the launch stream;
                   `single_step_sweep` = adam_multi_k, the one-step sweep every non-windowed path runs.
                   step_achieved / step_frac: a step-by-step TF-1 run's bytes (345 MB) over the measured STEP time.
@@ -304,10 +304,10 @@ def main():
             rows = sum(int(ar.R) for ar in arenas if getattr(ar, "_sort_owner", None) is None)
             pass_bytes = 24 * n_sparse + 4 * wk * rows
             wach = pass_bytes / (win_ms * 1e-3) / 1e9
-            traffic = pmc_traffic("adam_slice_k")
-            roof = {"bound": "hbm", "kernel": "adam_slice_k (ONE untouched-row sweep per optimizer window)", "window_steps": wk,
+            traffic = pmc_traffic("adam_window_k")
+            roof = {"bound": "hbm", "kernel": "adam_window_k<%d> (ONE untouched-row sweep per optimizer window)" % (wk - 1), "window_steps": wk,
                     "achieved": round(wach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(wach / 8000.0, 4),
-                    "traffic": traffic, "traffic_source": src % "adam_slice_k" if traffic else None,
+                    "traffic": traffic, "traffic_source": src % "adam_window_k" if traffic else None,
                     "alg_bytes_per_launch": pass_bytes, "launch_ms": round(win_ms, 5),
                     "note": "achieved = the bytes this launch has to move (one pass over the optimizer state) / its duration; "
                             "it applies wk TF-1 updates per element, i.e. SURVEY 8(d)'s 345 MB/step figure x wk steps = "
