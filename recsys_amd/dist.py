@@ -195,7 +195,7 @@ class DataParallel:
     def gather_send_block(self, b, fold_dense=False):
         """Exchanges [dense | block(b)] straight from the send block (no pack copy) and returns (views of RANK 0's parts
         inside the gathered buffer, blocks descriptor) for EmbeddingArena.segsum*(..., blocks=).
-        Small dense arenas (< RSX_DP_ALLREDUCE_MIN_BYTES, default 256 KiB: DeepFM / DCN / FM, ~0.3 MB): the arena rides in
+        Small dense arenas (< RSX_DP_ALLREDUCE_MIN_BYTES, default 1 MiB: DeepFM / DCN / FM, ~0.3 MB): the arena rides in
         front of the per-example block in ONE all-gather and the ranks' arenas are summed in rank order -- into the local
         arena by one launch here, or (fold_dense) inside the optimizer launch itself: a third return value (else None) then
         replaces DenseArena.adam_segments() (RSX_ADAM_DENSE with B = world replicas `stride` floats apart).  The step is
@@ -208,7 +208,7 @@ class DataParallel:
         n0, n = self._send_n0, self._send_dense.n
         L = b * sum(self._send_widths)
         d = self._send_dense
-        big = n * 4 >= int(os.environ.get("RSX_DP_ALLREDUCE_MIN_BYTES", str(256 * 1024)))
+        big = n * 4 >= int(os.environ.get("RSX_DP_ALLREDUCE_MIN_BYTES", str(1024 * 1024)))
         if big:
             Lp = (L + 3) & ~3
             x = self._send[n0:n0 + Lp].view(1, Lp)
