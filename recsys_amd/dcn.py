@@ -98,7 +98,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             if wpos == 0:
                 arena.sort_window([f["ids"] for f in wfeat])
                 cold, _ = arena.adam_split_segments(window_k=wk)
-                store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
+                store.opt.window_sweep(cold)
             arena.last_B = ids.shape[0]
             hot = ()
         elif ids_sort.shape[0] <= 2048:              # the sort rides in the first tower-forward launch; larger ones run stand-alone

@@ -175,7 +175,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             # ALU-heavy, and as riders they inherit their carrier's occupancy (measured, DeepFM bs 256: carried 164 us per
             # 4-step window, stand-alone 73 us = 18 us per step against 53-60 us for a one-step sweep)
             cold, hot = arena.adam_split_segments(window_k=wk)
-            store.opt.run_slice(store.opt.cold_slices(cold[::-1], [1.0])[0])
+            store.opt.window_sweep(cold[::-1])
         elif overlap and wpos == 0:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra

@@ -71,7 +71,7 @@ def _train_fused(store, arena, ids, labels):
             if wpos == 0:
                 arena.sort_window([f["ids"] for f in wfeat])
                 cold, _ = arena.adam_split_segments(window_k=wk)
-                store.opt.run_slice(store.opt.cold_slices(cold[::-1], [1.0])[0])
+                store.opt.window_sweep(cold[::-1])
             arena.last_B = B
         else:
             arena.field_sort(dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids)

@@ -497,6 +497,14 @@ class AdamTF1:
     def run_slice(self, sl):
         check(lib().rsx_adam_slice_run(C.byref(sl), _stream()), "rsx_adam_slice_run")
 
+    def window_sweep(self, cold_segments):
+        """The ONE untouched-row sweep of an optimizer window (COLD segments with slot_w), a launch of its own on the step's
+        stream.  (Measured and rejected, r02: the same launch on a forked stream inside the graph, concurrent with the
+        window's steps -- it only touches rows none of them touches.  At full width it stretches the concurrent tower
+        launches 5-9x (0.082 ms per step against 0.075); throttled to 128 workgroups it spreads over the whole window and
+        gains 3 %, within the box-to-box noise, for a second stream, a snapshot of the beta powers and a join per window.)"""
+        self.run_slice(self.cold_slices(cold_segments, [1.0])[0])
+
     @property
     def global_step(self):
         return int(self.state.view(torch.int32)[3].item()) - 1

@@ -127,7 +127,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 a1.sort_window([f["ids"] for f in wfeat])
                 c1, _ = a1.adam_split_segments(window_k=wk)
                 c2, _ = a2.adam_split_segments(window_k=wk)
-                store.opt.run_slice(store.opt.cold_slices(c1[::-1] + c2, [1.0])[0])
+                store.opt.window_sweep(c1[::-1] + c2)
             a1.last_B = a2.last_B = B
             hot = ()
         elif dp is None or zc:
