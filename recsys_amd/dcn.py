@@ -60,9 +60,9 @@ def build_variables(store, params, capacity):
         want_hip = False
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
-        if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) \
-                and capacity <= 16384:
+        if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
             store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
+            store.window_dp = True
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):      # zero-copy gradient exchange (see deepfm.py)
@@ -84,22 +84,23 @@ def _train_fused(store, arena, ids, labels, params, masks):
     oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
     with torch.no_grad():
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids       # first: see deepfm._train_fused
+        wk, wpos, wfeat = store.window_of_step()
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1) else ids   # first: see deepfm._train_fused
         zc = dp is not None and store.dp_block
         x0, _, _, _ = arena.gather(ids)
         job, sweeps, hot, last_sweep = None, None, None, None
         # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
         # untouched rows ONCE for the whole window (a launch of its own); the other positions run neither
-        wk, wpos, wfeat = store.window_of_step()
-        if wk > 1 and not (overlap and dp is None):
-            raise _lib.RsxError("optimizer windows need the split TF-1 update on one GPU")
+        if wk > 1 and not overlap:
+            raise _lib.RsxError("optimizer windows need the split TF-1 update (adam_mode=tf1_dense, overlap_adam)")
         arena.select(wpos)
         if wk > 1:
             if wpos == 0:
-                arena.sort_window([f["ids"] for f in wfeat])
+                from .dist import window_global_ids
+                arena.sort_window(window_global_ids(dp, wfeat))    # data-parallel: one all-gather for all wk batches' ids
                 cold, _ = arena.adam_split_segments(window_k=wk)
                 store.opt.window_sweep(cold)
-            arena.last_B = ids.shape[0]
+            arena.last_B = ids.shape[0] * (dp.world if dp is not None else 1)
             hot = ()
         elif ids_sort.shape[0] <= 2048:              # the sort rides in the first tower-forward launch; larger ones run stand-alone
             # (a 256-thread carrier workgroup sorts 4096 keys in 55 us, the 1024-thread kernel in 26 us)

@@ -73,9 +73,9 @@ def build_variables(store, params, capacity, with_dnn=True):
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
         # optimizer windows (include/rsx.h rsx_adam_window): up to 4 consecutive steps share ONE sweep over the untouched rows
-        if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) \
-                and capacity <= 16384:
-            store.window_k = _lib.default_adam_window(capacity)
+        if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
+            store.window_k = _lib.default_adam_window(capacity)      # (capacity = the GLOBAL batch under data parallelism)
+            store.window_dp = True
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):
@@ -140,20 +140,22 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # data-parallel: the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices), so the
         # dedup sort runs over the all-gathered ids -- a 40 KB collective issued FIRST (ids depend on nothing of this step),
         # so that every launch from the gather to the last backward layer is one graph segment
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids
-        zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
-        dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         # Optimizer window (estimator.Window, rsx_adam_window): this step is position wpos of wk consecutive steps whose
         # batches are known; position 0 sorts all of them and carries ONE sweep for the whole window, the others none.
         wk, wpos, wfeat = store.window_of_step()
-        if wk > 1 and not (overlap and dp is None):
-            raise _lib.RsxError("optimizer windows need the split TF-1 update on one GPU")
+        if wk > 1 and not overlap:
+            raise _lib.RsxError("optimizer windows need the split TF-1 update (adam_mode=tf1_dense, overlap_adam)")
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1) else ids
+        zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
+        dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         job = None
         if wk > 1:
             arena.select(wpos)
             if wpos == 0:
-                arena.sort_window([f["ids"] for f in wfeat])
-            arena.last_B = ids.shape[0]
+                from .dist import window_global_ids
+                win_ids = window_global_ids(dp, wfeat)   # data-parallel: ONE all-gather for the ids of all wk local batches
+                arena.sort_window(win_ids)
+            arena.last_B = ids.shape[0] * (dp.world if dp is not None else 1)
         elif ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
             arena.select(0)
             job = arena.sort_job(ids_sort)

@@ -356,6 +356,17 @@ class EmulatedDataParallel(DataParallel):
         pass
 
 
+def window_global_ids(dp, window_features, key="ids"):
+    """The ids of the k batches of an optimizer window (estimator.VariableStore.window) as the GLOBAL batches the optimizer
+    sees: dp None -> the local ones; else ONE all-gather of the stacked local ids, then k [N*b, F] tensors in rank order."""
+    ids = [f[key] for f in window_features]
+    if dp is None:
+        return ids
+    b = ids[0].shape[0]
+    allg = dp.all_gather_rows(torch.stack(ids).unsqueeze(0))               # [N, k, b, F]
+    return [allg[:, i].reshape(dp.world * b, -1).contiguous() for i in range(len(ids))]
+
+
 def attach_if_distributed(estimator):
     """`--mirror` (fm/fm.py:36,184-186): data-parallel when launched with WORLD_SIZE > 1."""
     if not is_distributed_env():

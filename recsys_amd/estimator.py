@@ -264,7 +264,7 @@ class Estimator:
 
     def _window_len(self):
         """Steps per optimizer window: what the model supports (store.window_k), RSX_ADAM_WINDOW overrides (1 = off)."""
-        if not self.store.built or self.store.dp is not None:
+        if not self.store.built or (self.store.dp is not None and not getattr(self.store, "window_dp", False)):
             return 1
         k = int(os.environ.get("RSX_ADAM_WINDOW", self.params.get("adam_window", self.store.window_k)))
         return max(1, min(k, self.store.window_k))
@@ -370,10 +370,26 @@ class Estimator:
                 for s in range(min(2, steps)):
                     self._train_eager(*batches[s % n].views())
                 done = min(2, steps)
-                g = {"steps": [self._capture_step(*b.views()) for b in batches]}
+                g = {"steps": [self._capture_step(*b.views()) for b in batches], "wins": {}}
+                # optimizer windows (model code that supports them under data parallelism sets store.window_dp): K consecutive
+                # resident batches as ONE segmented capture -- the ids of all K batches are all-gathered at its start
+                K = self._window_len()
+                if K > 1 and n % K == 0:
+                    for i in range(0, n, K):
+                        g["wins"][i] = self._capture(
+                            lambda i=i: self._train_window([batches[i + j].views() for j in range(K)]))
+                    g["K"] = K
                 self._graphs[key] = g
             loss = None
-            for s in range(done, steps):
+            s = done
+            while s < steps:
+                K = g.get("K", 0)
+                if K and (s % n) % K == 0 and steps - s >= K:
+                    seg, losses = g["wins"][s % n]
+                    seg.replay()
+                    loss = losses[-1]
+                    s += K
+                    continue
                 seg, loss = g["steps"][s % n]
                 # RSX_DP_PREFETCH=1: the next batch's ids all-gather is issued underneath this step (not after the last one:
                 # nothing would consume it before the buffers may be refilled).  Off by default: through RCCL at world 1 the
@@ -381,6 +397,7 @@ class Estimator:
                 # only be measured on a multi-GPU node.
                 nxt = g["steps"][(s + 1) % n][0] if (s + 1 < steps and os.environ.get("RSX_DP_PREFETCH", "0") == "1") else None
                 seg.replay(nxt)
+                s += 1
             return loss if loss is not None else g["steps"][0][1]
         if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
             for s in range(steps):

@@ -23,8 +23,11 @@ def model_fn(features, labels, mode, params):
     if not store.built:
         cap = max(int(params.get("max_batch_size", 0)), ids.shape[0])
         _build(store, params, capacity=cap, with_dnn=False)
-        if store.dp is None and store.adam_mode == "tf1_dense" and params.get("fused", True) and cap <= 16384:
-            store.window_k = _lib.default_adam_window(cap)          # optimizer windows (include/rsx.h rsx_adam_window)
+        if store.adam_mode == "tf1_dense" and params.get("fused", True):
+            gcap = cap * (store.dp.world if store.dp is not None else 1)
+            if gcap <= 16384:
+                store.window_k = _lib.default_adam_window(gcap)     # optimizer windows (include/rsx.h rsx_adam_window)
+                store.window_dp = True
         store.dp_block = False
         if store.dp is not None and params.get("fused", True):
             # data-parallel: [S | gy2 | gy1] of the local batch + the dense gradient arena in one persistent send block
@@ -63,16 +66,15 @@ def _train_fused(store, arena, ids, labels):
         # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
         # untouched rows ONCE for the whole window (a launch of its own); the other positions run neither
         wk, wpos, wfeat = store.window_of_step()
-        if wk > 1 and dp is not None:
-            raise _lib.RsxError("optimizer windows run on one GPU")
         arena.select(wpos)
         sweep = sweep2 = None
         if wk > 1:
             if wpos == 0:
-                arena.sort_window([f["ids"] for f in wfeat])
+                from .dist import window_global_ids
+                arena.sort_window(window_global_ids(dp, wfeat))    # data-parallel: one all-gather for all wk batches' ids
                 cold, _ = arena.adam_split_segments(window_k=wk)
                 store.opt.window_sweep(cold[::-1])
-            arena.last_B = B
+            arena.last_B = B * (dp.world if dp is not None else 1)
         else:
             arena.field_sort(dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids)
             cold, hot = arena.adam_split_segments()
@@ -95,7 +97,8 @@ def _train_fused(store, arena, ids, labels):
         with torch.no_grad():
             if dp is not None:
                 (Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(B, fold_dense=True)
-                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs, sweep2, blocks=blocks)
+                arena.select(wpos)
+                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs, sweep2, blocks=blocks, window=(wk, wpos))
             else:
                 arena.select(wpos)
                 arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2, window=(wk, wpos))

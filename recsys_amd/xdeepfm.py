@@ -83,8 +83,10 @@ def build_variables(store, params, capacity):
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
-    if store.dp is None and store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
+    if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384 and \
+            (store.dp is None or params.get("dp_send_block", True)):
         store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
+        store.window_dp = True
     store.dp_block = False
     if store.dp is not None and params.get("dp_send_block", True):          # zero-copy gradient exchange (see deepfm.py)
         store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])
@@ -112,23 +114,24 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     with torch.no_grad():
         # data-parallel: the optimizer sees the GLOBAL batch -- the dedup sort runs over the all-gathered ids (issued first:
         # they depend on nothing of the step), so the same exact split of the TF-1 update applies as on one GPU
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if zc else ids
-        job, ride = None, False
         # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
         # untouched rows of BOTH table sets once for the whole window (a launch of its own); the other positions run neither
         wk, wpos, wfeat = store.window_of_step()
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (zc and wk == 1) else ids
+        job, ride = None, False
         split = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        if wk > 1 and not (split and dp is None):
-            raise _lib.RsxError("optimizer windows need the split TF-1 update on one GPU")
+        if wk > 1 and not (split and (dp is None or zc)):
+            raise _lib.RsxError("optimizer windows need the split TF-1 update (and, data-parallel, the send block)")
         a1.select(wpos)
         a2.select(wpos)
         if wk > 1:
             if wpos == 0:
-                a1.sort_window([f["ids"] for f in wfeat])
+                from .dist import window_global_ids
+                a1.sort_window(window_global_ids(dp, wfeat))       # data-parallel: one all-gather for all wk batches' ids
                 c1, _ = a1.adam_split_segments(window_k=wk)
                 c2, _ = a2.adam_split_segments(window_k=wk)
                 store.opt.window_sweep(c1[::-1] + c2)
-            a1.last_B = a2.last_B = B
+            a1.last_B = a2.last_B = B * (dp.world if dp is not None else 1)
             hot = ()
         elif dp is None or zc:
             a2.last_B = ids_sort.shape[0]
@@ -200,8 +203,10 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 (dX1g, dX2g, glg), blocks, dense_segs = dp.gather_send_block(B, fold_dense=hot is not None)
                 Bg = B * dp.world
                 if hot is not None:
+                    a1.select(wpos)
+                    a2.select(wpos)
                     a1.segsum_adam(Bg, None, dX1g, glg, None, store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
-                                   blocks=blocks, second=(a2, dX2g))
+                                   blocks=blocks, second=(a2, dX2g), window=(wk, wpos))
                 else:
                     a1.segsum(Bg, None, dX1g, glg, None, blocks=blocks)
                     a2.segsum(Bg, None, dX2g, None, None, blocks=blocks)

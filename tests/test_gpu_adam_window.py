@@ -203,3 +203,63 @@ def test_windowed_streaming_train_is_bit_identical_and_respects_boundaries(tmp_p
         res.append(_state(est))
     for name in res[0]:
         assert torch.equal(res[0][name], res[1][name]), (name, float((res[0][name].float() - res[1][name].float()).abs().max()))
+
+
+def _est_for(kind, B):
+    from recsys_amd import dcn, deepfm, fm, xdeepfm
+    from recsys_amd.estimator import Estimator, RunConfig
+    from recsys_amd.feature_columns import build_feature_columns
+    linear = {"deepfm": "indicator_all", "fm": "indicator_all", "dcn": "numeric", "xdeepfm": "numeric+indicator"}[kind]
+    lin, emb = build_feature_columns(16, linear)
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+              "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
+              "cross_layers": {"dcn": 3, "xdeepfm": "32,16"}.get(kind)}
+    mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn}[kind]
+    return Estimator(mfn, None, params, RunConfig(use_hip_graph=True, adam_mode="tf1_dense", device="cuda", seed=5))
+
+
+def _model_state(est):
+    torch.cuda.synchronize()
+    out = {"dense": est.store.dense.flat.clone(), "dense_m": est.store.dense.m.clone(), "opt": est.store.opt.state.clone()}
+    for name, a in est.store.embeddings.items():
+        for k in ("tables", "m_t", "v_t", "w1", "m_w", "v_w"):
+            if getattr(a, k, None) is not None:
+                out[name + "." + k] = getattr(a, k).clone()
+    return out
+
+
+@pytest.mark.parametrize("kind,world", [("deepfm", 2), ("deepfm", 4), ("fm", 2), ("dcn", 2), ("xdeepfm", 2),
+                                        ("fm", 1), ("dcn", 1), ("xdeepfm", 1)])
+def test_windowed_step_of_every_model_is_bit_identical_to_its_single_steps(kind, world):
+    """Every model's fused step through optimizer windows against the same step run one by one (RSX_ADAM_WINDOW=1), on one
+    GPU (world 1) and as the data-parallel step of an emulated world (ids all-gather -- ONE for the window's 8 local batches --,
+    send block, replica-sum Adam): every variable bit-identical."""
+    from recsys_amd import synthetic
+    from recsys_amd.dist import EmulatedDataParallel
+    from recsys_amd.estimator import PackedBatch
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    B = 128
+    layout = CriteoLayout.from_columns(build_feature_columns(16, "indicator_all")[1])
+    host = synthetic.criteo_id_batches(layout, 16, B, seed=77)
+    rng = np.random.default_rng(3)
+    logx = [np.log(np.floor(np.exp(rng.normal(2, 1, (B, 13)))) + 1.0).astype(np.float32) for _ in host]
+    res = []
+    for win in ("8", "1"):
+        os.environ["RSX_ADAM_WINDOW"] = win
+        try:
+            est = _est_for(kind, B)
+            if world > 1:
+                est.store.dp = est.dist = EmulatedDataParallel(world)
+            feats = [PackedBatch({"ids": i, "cont_log": lx} if kind == "xdeepfm" else {"ids": i}, y, device="cuda")
+                     for (i, y, _), lx in zip(host, logx)]
+            with torch.no_grad():
+                est._call_model_fn(feats[0].views()[0], None, "infer")
+            assert est._window_len() == int(win), (est._window_len(), win)
+            est.train_resident(feats, 58, 8)
+            assert est.global_step == 58
+        finally:
+            os.environ.pop("RSX_ADAM_WINDOW", None)
+        res.append(_model_state(est))
+    for name in res[0]:
+        assert torch.isfinite(res[0][name].float()).all(), name
+        assert torch.equal(res[0][name], res[1][name]), (name, float((res[0][name].float() - res[1][name].float()).abs().max()))
