@@ -207,3 +207,29 @@ def test_send_block_layout_world2(tmp_path):
     """The zero-copy data-parallel exchange (DataParallel.make_send_block / send_views / gather_send_block) over a real
     2-process gloo group: block layout, rank stride, alignment, the replica-sum optimizer segment."""
     mp.spawn(_send_block_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _window_ids_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from recsys_amd import dist as rdist
+    rdist.init_process_group("gloo")
+    dp = rdist.DataParallel()
+    k, b, F = 4, 5, 3
+    # batch j of the window on rank r: ids = 1000*r + 100*j + (example, field)
+    local = [torch.arange(b * F, dtype=torch.int32).reshape(b, F) + 1000 * rank + 100 * j for j in range(k)]
+    got = rdist.window_global_ids(dp, [{"ids": x} for x in local])
+    assert len(got) == k
+    for j in range(k):       # global batch j = the ranks' batch j in rank order (what all_gather_rows gives step by step)
+        want = torch.cat([torch.arange(b * F, dtype=torch.int32).reshape(b, F) + 1000 * r + 100 * j for r in range(world)])
+        assert got[j].shape == (world * b, F) and got[j].is_contiguous() and torch.equal(got[j], want), j
+        assert torch.equal(got[j], dp.all_gather_rows(local[j]))
+    assert rdist.window_global_ids(None, [{"ids": x} for x in local])[2] is local[2]
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_ids_all_gather_world2(tmp_path):
+    """Optimizer windows under data parallelism: ONE all-gather of the stacked ids of the window's k local batches must give
+    the same k global batches (rank order) as k per-step all-gathers."""
+    mp.spawn(_window_ids_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
