@@ -52,6 +52,7 @@ class SortJob(C.Structure):
 
 
 ADAM_WINDOW_MAX = 8
+ADAM_STATE_WORDS = 4 + 32 * 32        # include/rsx.h RSX_ADAM_STATE_WORDS
 
 
 def default_adam_window(capacity):

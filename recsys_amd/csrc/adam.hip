@@ -16,15 +16,10 @@ __global__ __launch_bounds__(ADAM_T) void adam_multi_k(const AdamArgs a) {
   adam_block(a, blockIdx.x);
   // ticket: the last workgroup to finish advances the beta powers for the next step
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(a.state + 2);
-    const uint32_t t = atomicAdd(ticket, 1u);
-    if (t == a.total_blocks - 1u) {
-      a.state[0] = b1p * a.b1;
-      a.state[1] = b2p * a.b2;
-      *ticket = 0u;
-      reinterpret_cast<uint32_t*>(a.state)[3] += 1u;
-    }
+  if (threadIdx.x == 0 && adam_arrive_last(a.state, a.total_blocks)) {
+    a.state[0] = b1p * a.b1;
+    a.state[1] = b2p * a.b2;
+    reinterpret_cast<uint32_t*>(a.state)[3] += 1u;
   }
 }
 

@@ -65,6 +65,22 @@ constexpr int ADAM_T = 256;         // threads per workgroup
 constexpr int ADAM_U = RSX_ADAM_U;  // float4 per lane
 constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
 
+// "Am I the last workgroup of this launch?" for thread 0 of every workgroup, after its block's work (and a __syncthreads):
+// arrival counters by workgroup index modulo 32 (one 128-byte line each: state words 4 + 32 r), then the shared ticket
+// (state word 2) for the last arrival of each residue.  All counters are left at zero.  total = workgroups of the launch.
+__device__ __forceinline__ bool adam_arrive_last(float* state, const uint32_t total) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(state);
+  const uint32_t r = blockIdx.x & 31u;
+  const uint32_t n_r = (total + 31u - r) >> 5;                  // workgroups with this residue
+  uint32_t* sub = w + 4 + 32 * r;
+  if (atomicAdd(sub, 1u) != n_r - 1u) return false;
+  *sub = 0u;
+  const uint32_t n_top = total < 32u ? total : 32u;             // residues in use
+  if (atomicAdd(w + 2, 1u) != n_top - 1u) return false;
+  w[2] = 0u;
+  return true;
+}
+
 // alpha of the window's later steps: step j of the window runs with the beta powers advanced j times -- the same fp32
 // products the per-step advance of the powers makes.  (Named scalars, no array: a dynamically indexed local array is
 // promoted to LDS / scratch by this toolchain.)

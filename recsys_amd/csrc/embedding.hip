@@ -429,6 +429,16 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
   return true;
 }
 
+// Optional prefetch for the fused touched-row Adam (segsum_adam_k, single-stage form): the row's optimizer state is
+// requested as soon as the row is known, so that its latency hides behind the segment walk instead of following it.
+struct AdamRowPrefetch {
+  const float* tables;
+  const float* m_t;
+  const float* v_t;
+  float4 var, m, v;
+  bool loaded;
+};
+
 // The per-wave body of the segment-sum: returns false when the wave owns no unique row.  On return, for lanes with
 // `valid`: sl = slot index of the row, acc = summed gradient quarter, a1 = summed first-order gradient (q == 0 lanes),
 // e = the table row quarter (loaded only when the FM term is active), row = global row.
@@ -440,8 +450,9 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
                                             const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
                                             int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
                                             float4& acc, float& a1, float4& e, int& row, bool& do1, bool& staged,
-                                            const bool load_staged = true) {
+                                            const bool load_staged = true, AdamRowPrefetch* pre = nullptr) {
   staged = false;
+  if (pre != nullptr) pre->loaded = false;
   if (part.P != nullptr)
     return segsum_wave2<D>(wave, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride, null_row,
                            part, xb, valid, sl, acc, a1, e, row, do1, staged, load_staged);
@@ -455,13 +466,16 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   if (f >= F) return false;
   const int wf = wave - f * wpf;
   const int nu = nuniq[f];
-  // fields with few unique rows (tiny vocabularies: every segment is long) spread ONE row per wave over the
-  // field's wpf waves instead of 16 rows on the first wave; group 0 then owns the row, all groups cooperate
-  const bool spread = nu <= wpf;
-  const int j0 = spread ? wf : wf * GPW;
+  // The field's unique rows are dealt EVENLY to its wpf waves: rpw = ceil(nu / wpf) rows per wave (groups 0 .. rpw-1 own
+  // them), so a field with a mid-sized vocabulary (say 50 rows, each a long Zipf-skewed segment) keeps 13 waves busy with 4
+  // rows each instead of 4 waves with 16 -- the wave-cooperative walk of a long segment is sequential per wave.  rpw = 1
+  // (tiny vocabularies: every segment is long): group 0 owns the row and anything above 2 entries is walked by the whole wave.
+  const int rpw = nu <= wpf ? 1 : (nu + wpf - 1) / wpf;
+  const bool spread = rpw == 1;
+  const int j0 = wf * rpw;
   if (j0 >= nu) return false;  // wave-uniform
-  const int j = spread ? j0 : j0 + g;
-  valid = spread ? g == 0 : j < nu;
+  const int j = j0 + g;
+  valid = g < rpw && j < nu;
   sl = (size_t)f * stride + (valid ? j : j0);
   const int beg = valid ? seg_off[(size_t)f * (stride + 1) + j] : 0;
   int end = valid ? seg_off[(size_t)f * (stride + 1) + j + 1] : 0;
@@ -485,6 +499,13 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   e = z;
   if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+  if (pre != nullptr && valid) {
+    const size_t o = (size_t)row * LPR + q;
+    pre->var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(pre->tables)[o];
+    pre->m = reinterpret_cast<const float4*>(pre->m_t)[o];
+    pre->v = reinterpret_cast<const float4*>(pre->v_t)[o];
+    pre->loaded = true;
+  }
   acc = z;
   a1 = 0.f;
   const int short_len = spread ? 2 : SEG_SHORT;   // a spread wave has 15 idle groups: cooperate on anything > 2
@@ -796,16 +817,18 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float a1;
     int row;
     bool staged;
+    AdamRowPrefetch pre{h.tables2, h.m_t2, h.v_t2};
     if (segsum_wave<D>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr, nullptr,
                        perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1,
-                       staged) &&
+                       staged, true, &pre) &&
         valid) {
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
       const size_t o = (size_t)row * LPR + q;
-      float4 var = reinterpret_cast<const float4*>(h.tables2)[o];
-      float4 m = reinterpret_cast<const float4*>(h.m_t2)[o], v = reinterpret_cast<const float4*>(h.v_t2)[o];
+      float4 var = pre.loaded ? pre.var : reinterpret_cast<const float4*>(h.tables2)[o];
+      float4 m = pre.loaded ? pre.m : reinterpret_cast<const float4*>(h.m_t2)[o];
+      float4 v = pre.loaded ? pre.v : reinterpret_cast<const float4*>(h.v_t2)[o];
       F4_APPLY(adam_sparse1, var, m, v, acc, true, hp);
       reinterpret_cast<float4*>(h.tables2)[o] = var;
       reinterpret_cast<float4*>(h.m_t2)[o] = m;
@@ -819,14 +842,17 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float a1;
     int row;
     bool staged;
+    AdamRowPrefetch pre{h.tables, h.m_t, h.v_t};
     if (segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                       nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1, staged) && valid) {
+                       nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1, staged, true, &pre) &&
+        valid) {
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
       const size_t o = (size_t)row * LPR + q;
-      float4 var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(h.tables)[o];
-      float4 m = reinterpret_cast<const float4*>(h.m_t)[o], v = reinterpret_cast<const float4*>(h.v_t)[o];
+      float4 var = pre.loaded ? pre.var : (gy2 != nullptr ? e : reinterpret_cast<const float4*>(h.tables)[o]);
+      float4 m = pre.loaded ? pre.m : reinterpret_cast<const float4*>(h.m_t)[o];
+      float4 v = pre.loaded ? pre.v : reinterpret_cast<const float4*>(h.v_t)[o];
       F4_APPLY(adam_sparse1, var, m, v, acc, true, hp);
       reinterpret_cast<float4*>(h.tables)[o] = var;
       reinterpret_cast<float4*>(h.m_t)[o] = m;
@@ -835,17 +861,10 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(h.state + 2);
-    const uint32_t t = atomicAdd(ticket, 1u);
-    if (t == h.total_blocks - 1u) {
-      *ticket = 0u;
-      if (h.advance) {
-        h.state[0] = b1p * h.b1;
-        h.state[1] = b2p * h.b2;
-        reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
-      }
-    }
+  if (threadIdx.x == 0 && adam_arrive_last(h.state, h.total_blocks) && h.advance) {
+    h.state[0] = b1p * h.b1;
+    h.state[1] = b2p * h.b2;
+    reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
   }
 }
 

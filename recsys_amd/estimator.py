@@ -190,7 +190,7 @@ class VariableStore:
 
     def load_state_dict(self, sd):
         with torch.no_grad():
-            self.opt.state.copy_(sd["opt_state"])
+            self.opt.state[:4].copy_(sd["opt_state"][:4])      # (beta powers, ticket, step; the arrival counters stay zero)
             for k in ("flat", "m", "v"):
                 getattr(self.dense, k).copy_(sd["dense"][k])
             for name, a in self.embeddings.items():

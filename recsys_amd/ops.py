@@ -446,7 +446,7 @@ class AdamTF1:
     def __init__(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, device="cuda"):
         dev = _require_cuda(device)
         self.hp = (float(lr), float(beta1), float(beta2), float(eps))
-        st = np.zeros(4, np.float32)
+        st = np.zeros(_lib.ADAM_STATE_WORDS, np.float32)     # words 0..3 + the arrival counters (zero)
         check(lib().rsx_adam_state_init_h(st.ctypes.data_as(C.c_void_p), beta1, beta2))
         self.state = torch.from_numpy(st).to(dev)
 
