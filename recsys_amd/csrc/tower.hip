@@ -1100,7 +1100,8 @@ extern "C" int rsx_fm_head(const float* y1, const float* y2, const float* c0, co
 
 // row blocks a dW tile's batch reduction is split into (1 without workspace or for small batches)
 static inline int rsx_tower_dw_blocks(int B, bool have_ws) {
-  if (!have_ws || B < 1024) return 1;
+  static const int min_b = getenv("RSX_TOWER_SB_MIN_B") ? atoi(getenv("RSX_TOWER_SB_MIN_B")) : 1024;
+  if (!have_ws || B < min_b) return 1;
   // rows per dW row block: 512 measured 2-3 % faster than 256 on dcn.py bs 4096 (fewer partial tiles to write and re-add)
   static const int rows = getenv("RSX_TOWER_SB_ROWS") ? atoi(getenv("RSX_TOWER_SB_ROWS")) : 512;
   const int sb = (B + rows - 1) / rows;
