@@ -61,6 +61,9 @@ __device__ __forceinline__ void adam_dense1(float& var, float& m, float& v, floa
 #ifndef RSX_ADAM_NT
 #define RSX_ADAM_NT 0
 #endif
+#ifndef RSX_ADAM_WIN_HB
+#define RSX_ADAM_WIN_HB 2      // float4 per lane and pipeline stage of the window sweep (adam_window_block)
+#endif
 constexpr int ADAM_T = 256;         // threads per workgroup
 constexpr int ADAM_U = RSX_ADAM_U;  // float4 per lane
 constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
@@ -329,66 +332,78 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
     // then var / m / v unconditionally (a skipped row costs its read, ~1 % of the traffic; a guarded load would serialise
     // the batch), then the 1 + nw updates one float4 at a time (4 independent chains, few temporaries: riders inherit their
     // carrier's register budget), then the stores of the rows that moved.
-    constexpr int HB = 4;
+    // Software pipeline over batches of HB float4 per lane: the loads of batch b + 1 are issued before batch b is updated, so
+    // a wave's ALU phase (1 + NW correctly rounded div + sqrt per element) overlaps its own next memory phase.
+    constexpr int HB = RSX_ADAM_WIN_HB;
+    constexpr int NB = ADAM_U / HB;
     static_assert(ADAM_U % HB == 0, "ADAM_U");
     const int lpr = s.d >> 2;
     const long long n4 = s.n * lpr;
     const bool pow2 = (lpr & (lpr - 1)) == 0;
     const int lsh = 31 - __clz(lpr);
-#pragma unroll 1
-    for (int u0 = 0; u0 < ADAM_U; u0 += HB) {
-      bool live[HB];
+    struct Batch {
+      float4 var[HB], m[HB], v[HB];
       long long ec[HB];
       int t[HB];
+      bool live[HB];
+    };
+    auto issue = [&](const int b, Batch& B) {
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
-        const long long e = base + (long long)(u0 + u) * ADAM_T + tid;
-        ec[u] = e < n4 ? e : n4 - 1;
-        live[u] = e < n4;
-        const long long row = pow2 ? (ec[u] >> lsh) : (ec[u] / lpr);
-        t[u] = s.slot[row];
+        const long long e = base + (long long)(b * HB + u) * ADAM_T + tid;
+        B.ec[u] = e < n4 ? e : n4 - 1;
+        B.live[u] = e < n4;
+        const long long row = pow2 ? (B.ec[u] >> lsh) : (B.ec[u] / lpr);
+        B.t[u] = s.slot[row];
         // (untouched = -1 = all ones: one value >= 0 clears the sign of the AND.)  All of them in flight at once.
 #pragma unroll
-        for (int l = 0; l < NW; ++l) t[u] &= swb[l * sws + (int)row];
+        for (int l = 0; l < NW; ++l) B.t[u] &= swb[l * sws + (int)row];
       }
-      float4 var[HB], m[HB], v[HB];
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
 #if RSX_ADAM_NT
-        var[u] = __builtin_nontemporal_load(&var4[ec[u]]);
-        m[u] = __builtin_nontemporal_load(&m4[ec[u]]);
-        v[u] = __builtin_nontemporal_load(&v4[ec[u]]);
+        B.var[u] = __builtin_nontemporal_load(&var4[B.ec[u]]);
+        B.m[u] = __builtin_nontemporal_load(&m4[B.ec[u]]);
+        B.v[u] = __builtin_nontemporal_load(&v4[B.ec[u]]);
 #else
-        var[u] = var4[ec[u]];
-        m[u] = m4[ec[u]];
-        v[u] = v4[ec[u]];
+        B.var[u] = var4[B.ec[u]];
+        B.m[u] = m4[B.ec[u]];
+        B.v[u] = v4[B.ec[u]];
 #endif
       }
+    };
+    auto finish = [&](Batch& B) {
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
-        live[u] = live[u] && t[u] < 0;
-        F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, h);
+        F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], z4, false, h);
 #pragma unroll 1
         for (int j = 0; j < NW; ++j) {          // the later steps of the window, back to back in registers
           Hp hj = h;
           hj.alpha = aw.get(j);
-          F4_APPLY(adam_sparse1, var[u], m[u], v[u], z4, false, hj);
+          F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], z4, false, hj);
         }
       }
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
-        if (live[u]) {
+        if (B.live[u] && B.t[u] < 0) {
 #if RSX_ADAM_NT
-          __builtin_nontemporal_store(var[u], &var4[ec[u]]);
-          __builtin_nontemporal_store(m[u], &m4[ec[u]]);
-          __builtin_nontemporal_store(v[u], &v4[ec[u]]);
+          __builtin_nontemporal_store(B.var[u], &var4[B.ec[u]]);
+          __builtin_nontemporal_store(B.m[u], &m4[B.ec[u]]);
+          __builtin_nontemporal_store(B.v[u], &v4[B.ec[u]]);
 #else
-          var4[ec[u]] = var[u];
-          m4[ec[u]] = m[u];
-          v4[ec[u]] = v[u];
+          var4[B.ec[u]] = B.var[u];
+          m4[B.ec[u]] = B.m[u];
+          v4[B.ec[u]] = B.v[u];
 #endif
         }
       }
+    };
+    Batch bt[2];
+    issue(0, bt[0]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) issue(b + 1, bt[(b + 1) & 1]);
+      finish(bt[b & 1]);
     }
   }
 }

@@ -1146,11 +1146,12 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   p.sb = rsx_tower_dw_blocks(B, dw_partials != nullptr);
   static const int rtw_env = getenv("RSX_TOWER_RTW") ? atoi(getenv("RSX_TOWER_RTW")) : 4;
   p.din_rtw = p.sb > 1 ? rtw_env : 1;
-  // grouped LDS-staged d(input) tiles: measured better when a sweep slice rides in the launch (step-by-step optimizer: 93.5
-  // vs ~96 us per DeepFM step) and 1 % worse without riders (optimizer windows: 70.6 vs 69.9 us) -> used when a slice rides.
-  // RSX_TOWER_DXG = 0 / 1 forces it off / on.
-  static const int dxg_env = getenv("RSX_TOWER_DXG") ? atoi(getenv("RSX_TOWER_DXG")) : -1;
-  const bool dxg_want = dxg_env >= 0 ? dxg_env > 0 : sweep_h != nullptr;
+  // grouped LDS-staged d(input) tiles (RSX_TOWER_DXG=1): measured better when a sweep slice rides in the launch (step-by-step
+  // optimizer: 93.5 vs ~96 us per DeepFM step) and 1 % worse without riders (optimizer windows, the default: 70.6 vs 69.9 us).
+  // Off by default, and NOT chosen per launch: the two forms add the N products of an output in a different order, and the
+  // windowed, the step-by-step and the plain path must stay bit-identical to each other.
+  static const int dxg_env = getenv("RSX_TOWER_DXG") ? atoi(getenv("RSX_TOWER_DXG")) : 0;
+  const bool dxg_want = dxg_env > 0;
   p.dxg = (p.sb > 1 || (N & 3) != 0 || N > 128 || !dxg_want) ? 0 : 4;
   p.n_din = p.dxg > 0 ? ((p.ct_k + p.dxg - 1) / p.dxg) * p.RTh : p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
   p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
