@@ -184,7 +184,7 @@ def make_params(FLAGS):
     lin, emb = build_feature_columns(FLAGS.embedding_size, "numeric")
     return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
             "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
-            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size}
+            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size, **({"adam_window": FLAGS.adam_window} if getattr(FLAGS, "adam_window", 0) else {})}
 
 
 def main(argv=None):

@@ -72,7 +72,7 @@ def build_variables(store, params, capacity, with_dnn=True):
         want_hip = False
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
-        # optimizer windows (include/rsx.h rsx_adam_window): up to 4 consecutive steps share ONE sweep over the untouched rows
+        # optimizer windows (include/rsx.h rsx_adam_window): up to 8 consecutive steps share ONE sweep over the untouched rows
         if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
             store.window_k = _lib.default_adam_window(capacity)      # (capacity = the GLOBAL batch under data parallelism)
             store.window_dp = True
@@ -237,6 +237,9 @@ def define_flags(p=None):
     p.add_argument("--mirror", type=lambda s: s.lower() in ("1", "true", "yes"), default=True)
     p.add_argument("--model_dir", default="./model/")
     p.add_argument("--adam_mode", default="tf1_dense")
+    p.add_argument("--adam_window", type=int, default=0,
+                   help="steps per optimizer window (include/rsx.h rsx_adam_window; bit-identical to single steps): 0 = the "
+                        "model's default (8 up to batch 1024, 4 above), 1 = every step on its own")
     p.add_argument("--feature_set", default="criteo", choices=["criteo", "uid_iid"],
                    help="criteo: the 39-field pipeline of fm.py (BASELINE configs); uid_iid: deepfm.py as committed "
                         "(int64 u_id / i_id hashed into 500000 / 100000 buckets, int64 label)")
@@ -259,9 +262,12 @@ def make_params(FLAGS, linear="indicator_all"):
         lin, emb = build_model_columns(FLAGS.embedding_size)
     else:
         lin, emb = build_feature_columns(FLAGS.embedding_size, linear)
-    return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
-            "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
-            "max_batch_size": FLAGS.batch_size}
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
+              "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
+              "max_batch_size": FLAGS.batch_size}
+    if getattr(FLAGS, "adam_window", 0):
+        params["adam_window"] = FLAGS.adam_window
+    return params
 
 
 def run_main(model_fn, FLAGS, make_params_fn):
