@@ -129,7 +129,7 @@ def main():
     from recsys_amd import dist
     dp = None
     if world > 1 or os.environ.get("RSX_FORCE_DIST") == "1":
-        dist.init_process_group("nccl")
+        dist.init_process_group()            # nccl (= RCCL); RSX_DIST_BACKEND=gloo lets several ranks share ONE GPU (smoke runs)
         dp = dist.DataParallel()
     if rank == 0:
         _build.build(verbose=False)          # no-op when the in-tree librsx.so is current
@@ -138,7 +138,7 @@ def main():
     from recsys_amd import deepfm, synthetic
     from recsys_amd.estimator import Estimator, RunConfig
     from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     emu = None
     if a.emulate_world > 1 and dp is None:
