@@ -181,9 +181,15 @@ def main():
         host_pbs = [PackedBatch(*f.to("cpu").views(), pin=True) for f in feats]
 
     def run(nsteps):
-        if host_pbs is not None:
-            for s in range(nsteps):
-                loss = est._train_step(host_pbs[s % len(host_pbs)])
+        if host_pbs is not None:        # what Estimator.train does with host batches: K copies + ONE graph replay per optimizer window
+            K, s = est._window_len(), 0
+            while s < nsteps:
+                k = min(K, nsteps - s)
+                if k > 1:
+                    loss = est._train_window_packed([host_pbs[(s + j) % len(host_pbs)] for j in range(k)])
+                else:
+                    loss = est._train_step(host_pbs[s % len(host_pbs)])
+                s += k
             return loss
         if a.steps_per_graph > 1:
             return est.train_resident(feats, nsteps, a.steps_per_graph)

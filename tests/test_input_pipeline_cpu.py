@@ -293,3 +293,27 @@ def test_int64_key_columns_of_deepfm_py_as_committed(tmp_path):
     bad.write_bytes(tfrecord.frame(tfrecord.encode_example({"label": [1], "u_id": [3]})))       # i_id missing
     with pytest.raises(RsxError):
         list(uid_iid_input_fn([str(bad)], 4, num_epochs=1, layout=layout))
+
+
+def test_packed_batch_adopts_the_readers_flat_buffer(tmp_path, layout):
+    """The C++ reader assembles every batch in one flat host buffer laid out like estimator.PackedBatch's packing; the
+    Estimator must wrap that buffer (no 40 KB copy per step) and see exactly the bytes a packed copy would hold.  Arrays that
+    are not such views (copies, the last partial batch, torch tensors) take the copying path and give the same views."""
+    from recsys_amd.estimator import PackedBatch
+    from recsys_amd.input_pipeline import criteo_input_fn, write_criteo_shard
+    p = str(tmp_path / "part-r-00000")
+    label, cont, cat = _raw(100, seed=2)
+    write_criteo_shard(p, label, cont, cat)
+    batches = list(criteo_input_fn([p], 32, num_epochs=1, need_shuffle=False, layout=layout))
+    assert [b[1].shape[0] for b in batches] == [32, 32, 32, 4]
+    for feats, lab in batches:
+        pb = PackedBatch(feats, lab)
+        adopted = pb.flat.data_ptr() == lab.ctypes.data
+        assert adopted == (lab.shape[0] == 32)                  # full batches are adopted, the partial one is copied
+        ref = PackedBatch({k: v.copy() for k, v in feats.items()}, lab.copy())
+        assert ref.flat.data_ptr() != lab.ctypes.data and ref.key() == pb.key() and ref.nbytes == pb.nbytes
+        f1, l1 = pb.views()
+        f2, l2 = ref.views()
+        assert np.array_equal(l1.numpy(), lab) and np.array_equal(l2.numpy(), lab)
+        for k in feats:
+            assert np.array_equal(f1[k].numpy(), feats[k]) and np.array_equal(f2[k].numpy(), feats[k])
