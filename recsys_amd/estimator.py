@@ -73,7 +73,19 @@ class PackedBatch:
     """(features, labels) of one batch packed into ONE contiguous byte buffer, so a training step needs a single
     host->device (or device->device) copy into the HIP graph's static input buffer instead of one per tensor."""
 
+    _flat_layouts = {}      # (key of a FlatFeatures batch) -> (layout, nbytes): batches of one stream share them
+
     def __init__(self, features, labels, device=None, pin=False):
+        flat_np = getattr(features, "flat", None)
+        if flat_np is not None and device is None and not pin:
+            # the input pipeline's reader already assembled the batch in this packing (input_pipeline.FlatFeatures): O(1)
+            pkey = features.pack_key
+            hit = PackedBatch._flat_layouts.get(pkey)
+            if hit is not None and hit[1] == flat_np.nbytes and labels.shape[0] == hit[0][0][2][0] and \
+                    labels.__array_interface__["data"][0] == flat_np.__array_interface__["data"][0]:
+                self.layout, self.nbytes = hit
+                self.flat = torch.from_numpy(flat_np)
+                return
         items = [("__label__", labels)] + sorted(features.items())
         self.layout, off = [], 0
         arrs = []
@@ -85,6 +97,8 @@ class PackedBatch:
             off = (off + nb + 15) & ~15
         self.nbytes = off
         flat = self._adopt(items) if (device is None and not pin) else None
+        if flat is not None and flat_np is not None and flat.data_ptr() == flat_np.ctypes.data and off == flat_np.nbytes:
+            PackedBatch._flat_layouts[pkey] = (self.layout, self.nbytes)      # the next batch of this stream skips all of this
         if flat is None:
             flat = torch.zeros(off, dtype=torch.uint8)
             for (k, dt, sh, o, nb), t in zip(self.layout, arrs):
@@ -239,6 +253,7 @@ class Estimator:
         self.config = config or RunConfig()
         self.store = VariableStore(self.config.device, self.config.seed, self.config.adam_mode)
         self._graphs = {}
+        self._ring = {}        # pinned staging buffers for host batches (see _h2d)
         self._restored = False
         self._log_t = None
         self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
@@ -355,12 +370,37 @@ class Estimator:
         g["graph"].replay()
         return g["loss"]
 
+    def _h2d(self, static, pb):
+        """One batch -> the graph's static input buffer, ONE copy.  A pageable host batch (what an input pipeline hands over)
+        goes through a ring of pinned staging buffers first: the H2D copy of pageable memory is synchronous -- the host would
+        wait for the GPU to finish the previous window before it could even start packing the next one (measured end to end
+        over TFRecord shards: 185 us per DeepFM step against 70 us of GPU time)."""
+        src = pb.flat
+        if src.device.type == "cpu" and not src.is_pinned() and torch.cuda.is_available():
+            ring = self._ring.get(pb.nbytes)
+            if ring is None:
+                R = 4 * max(2, self.store.window_k)
+                bufs = [torch.empty(pb.nbytes, dtype=torch.uint8).pin_memory() for _ in range(R)]
+                ring = {"bufs": bufs, "np": [b.numpy() for b in bufs], "evs": [torch.cuda.Event() for _ in range(R)],
+                        "used": [False] * R, "i": 0}
+                self._ring[pb.nbytes] = ring
+            i = ring["i"]
+            ring["i"] = (i + 1) % len(ring["bufs"])
+            if ring["used"][i]:
+                ring["evs"][i].synchronize()         # the copy that last read this staging buffer has run (long ago)
+            np.copyto(ring["np"][i], src.numpy())    # (a plain memcpy: torch's CPU copy_ of > 32 KB wakes its thread pool, ~0.4 ms)
+            static.flat.copy_(ring["bufs"][i], non_blocking=True)
+            ring["evs"][i].record()
+            ring["used"][i] = True
+            return
+        static.flat.copy_(src, non_blocking=True)
+
     def _train_step_packed(self, pb):
         key = ("packed",) + pb.key()
         g = self._graphs.setdefault(key, {"warm": 0}) if self._use_graph() else None
         if g is not None and "graph" in g:
-            # ONE copy per step, host (pinned) or device -> the graph's static input buffer
-            g["static"].flat.copy_(pb.flat, non_blocking=True)
+            # ONE copy per step, host or device -> the graph's static input buffer
+            self._h2d(g["static"], pb)
             g["graph"].replay()
             return g["loss"]
         if pb.flat.device != self.store.device:
@@ -511,7 +551,7 @@ class Estimator:
         g = self._graphs.setdefault(key, {"warm": 0})
         if "graph" in g:
             for st, pb in zip(g["static"], pbs):
-                st.flat.copy_(pb.flat, non_blocking=True)
+                self._h2d(st, pb)
             g["graph"].replay()
             return g["losses"][-1]
         dev = [pb if pb.flat.device == self.store.device else pb.to(self.store.device) for pb in pbs]

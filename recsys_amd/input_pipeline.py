@@ -179,6 +179,12 @@ def _paths_array(filenames):
     return arr
 
 
+class FlatFeatures(dict):
+    """The features dict of one batch whose arrays (and labels) are views of ONE flat host buffer laid out like
+    estimator.PackedBatch's packing: `flat` is that buffer (np.uint8), so the Estimator wraps it instead of re-packing."""
+    __slots__ = ("flat", "pack_key")       # pack_key: one hashable per stream layout (batch size, fields)
+
+
 def _criteo_batches(filenames, batch_size, num_epochs, layout, threads, shard, verify_crc, queue_batches, drop_remainder):
     ps = _CriteoParser(layout, threads)
     rank, world = shard
@@ -187,25 +193,35 @@ def _criteo_batches(filenames, batch_size, num_epochs, layout, threads, shard, v
                                                 _p(ps.bnd_off), _p(ps.shift), ps.F, int(batch_size), int(num_epochs), rank,
                                                 world, int(drop_remainder), int(threads), int(verify_crc), int(queue_batches)))
     F, bs = ps.F, int(batch_size)
+    # ONE flat host buffer per batch, laid out like estimator.PackedBatch packs it (label | cont_log | ids, 16-byte aligned
+    # parts), so the Estimator's single H2D copy can take it as it is (PackedBatch adopts it without a copy).  The parts are
+    # handed to the reader by ADDRESS (one .ctypes.data per batch instead of three data_as casts: the Python side of a batch
+    # cost 70 us, more than a DeepFM step).
+    o_cont = (bs * 4 + 15) & ~15
+    o_ids = (o_cont + bs * 52 + 15) & ~15
+    nb = o_ids + bs * F * 4
+    next_h = lib().rsx_criteo_reader_next_h
+    VP = C.c_void_p
+    pack_key = ("criteo", bs, F)
     try:
         while True:
-            # ONE flat host buffer per batch, laid out like estimator.PackedBatch packs it (label | cont_log | ids, 16-byte
-            # aligned parts), so the Estimator's single H2D copy can take it as it is
-            o_cont = (bs * 4 + 15) & ~15
-            o_ids = (o_cont + bs * 52 + 15) & ~15
-            flat = np.empty(o_ids + bs * F * 4, np.uint8)
-            label = flat[:bs * 4].view(np.float32).reshape(bs, 1)
-            cont = flat[o_cont:o_cont + bs * 52].view(np.float32).reshape(bs, 13)
-            ids = flat[o_ids:o_ids + bs * F * 4].view(np.int32).reshape(bs, F)
-            n = lib().rsx_criteo_reader_next_h(rd.h, _p(label), _p(cont), _p(ids))
+            flat = np.empty(nb, np.uint8)
+            a = flat.ctypes.data
+            n = next_h(rd.h, VP(a), VP(a + o_cont), VP(a + o_ids))
             if n == 0:
                 return
             if n < 0:
                 raise RsxError("%s: %s" % (filenames[0] if len(filenames) == 1 else "TFRecord stream",
                                            lib().rsx_strerror(int(n)).decode()))
+            label = flat[:bs * 4].view(np.float32).reshape(bs, 1)
+            cont = flat[o_cont:o_cont + bs * 52].view(np.float32).reshape(bs, 13)
+            ids = flat[o_ids:o_ids + bs * F * 4].view(np.int32).reshape(bs, F)
+            feats = FlatFeatures(ids=ids, cont_log=cont)
+            feats.flat, feats.pack_key = flat, pack_key
             if n < bs:
-                label, cont, ids = label[:n], cont[:n], ids[:n]
-            yield {"ids": ids, "cont_log": cont}, label
+                label = label[:n]
+                feats = {"ids": ids[:n], "cont_log": cont[:n]}
+            yield feats, label
     finally:
         rd.close()
 
