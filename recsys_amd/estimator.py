@@ -254,6 +254,7 @@ class Estimator:
         self.store = VariableStore(self.config.device, self.config.seed, self.config.adam_mode)
         self._graphs = {}
         self._ring = {}        # pinned staging buffers for host batches (see _h2d)
+        self._copy_stream = None
         self._restored = False
         self._log_t = None
         self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
@@ -546,22 +547,37 @@ class Estimator:
     # -- public API --------------------------------------------------------------------------
     def _train_window_packed(self, pbs):
         """One optimizer window over len(pbs) host (or device) batches: len(pbs) copies into the graph's static input
-        buffers, ONE graph replay for all of its steps.  -> loss of the last step."""
+        buffers, ONE graph replay for all of its steps.  -> loss of the last step.
+        Two captured instances of the window (each with its own static inputs) take turns: the copies of window w + 1 run on
+        a copy stream while the graph of window w computes -- 8 H2D copies are ~80 us of a 640 us window otherwise."""
         key = ("packedwin", len(pbs)) + pbs[0].key()
-        g = self._graphs.setdefault(key, {"warm": 0})
-        if "graph" in g:
-            for st, pb in zip(g["static"], pbs):
-                self._h2d(st, pb)
-            g["graph"].replay()
-            return g["losses"][-1]
+        g = self._graphs.setdefault(key, {"warm": 0, "sets": [], "turn": 0})
+        if len(g["sets"]) == 2:
+            st = g["sets"][g["turn"]]
+            g["turn"] ^= 1
+            cur = torch.cuda.current_stream()
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream()
+            cs = self._copy_stream
+            cs.wait_event(st["done"])              # the replay that last read this instance's inputs has finished
+            with torch.cuda.stream(cs):
+                for sb, pb in zip(st["static"], pbs):
+                    self._h2d(sb, pb)
+                st["ready"].record(cs)
+            cur.wait_event(st["ready"])
+            st["graph"].replay()
+            st["done"].record(cur)
+            return st["losses"][-1]
         dev = [pb if pb.flat.device == self.store.device else pb.to(self.store.device) for pb in pbs]
         if g["warm"] < 1:
             g["warm"] += 1
             return self._train_window([pb.views() for pb in dev])[-1]
-        g["static"] = [pb.clone() for pb in dev]
-        g["graph"], g["losses"] = self._capture(lambda: self._train_window([st.views() for st in g["static"]]))
-        g["graph"].replay()             # capture executes nothing: the static buffers already hold this window's batches
-        return g["losses"][-1]
+        st = {"static": [pb.clone() for pb in dev], "ready": torch.cuda.Event(), "done": torch.cuda.Event()}
+        st["graph"], st["losses"] = self._capture(lambda: self._train_window([sb.views() for sb in st["static"]]))
+        st["graph"].replay()            # capture executes nothing: the static buffers already hold this window's batches
+        st["done"].record(torch.cuda.current_stream())
+        g["sets"].append(st)
+        return st["losses"][-1]
 
     def train(self, input_fn, steps=None, max_steps=None):
         it = iter(input_fn())
