@@ -546,6 +546,8 @@ class FusedTower:
         self.gs1 = torch.empty(B, device=dev)
         self.dwd_part = torch.zeros(RT, self.widths[-1], device=dev)
         self.hpart = torch.zeros(RT, 8, **f64)
+        self._eval_stats = {}                       # batch size -> per-layer statistics that put BN in inference form (infer)
+        self._zero_labels = torch.zeros(B, device=dev)
         self.loss = torch.zeros(1, device=dev)
         # large batches: every dW tile's reduction over the batch is split into row blocks (csrc/tower.hip)
         self.dwp = []
@@ -639,6 +641,48 @@ class FusedTower:
             if l and self.bn_on:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
         return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
+
+
+    def infer(self, X, rng_step, labels=None, s0=None, c0=None, s1=None,
+              head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True):
+        """EVAL / PREDICT forward through the same kernels as the TRAIN step (L forward launches + the head): dropout off and
+        batch-norm in inference form.  The reference never updates the moving statistics (EVAL uses mean 0 /
+        variance 1), so BN(x) = gamma * x / sqrt(1 + eps) + beta -- exactly what the kernels compute when the statistics they
+        are handed say sum(x) = 0, sum(x^2) = B.  -> (prob [B], loss [1] or None when labels is None)."""
+        L, P, pre = lib(), self.P, self.pre
+        B = X.shape[0]
+        assert B <= self.cap and X.is_contiguous() and X.shape[1] == self.k0
+        st = _stream()
+        nl = len(self.widths)
+        bnp = (lambda name: _ptr(P[name])) if self.bn_on else (lambda name: None)
+        es = self._eval_stats.get(B)
+        if es is None:             # (first call per batch size: eager, before any capture of this signature)
+            es = []
+            for n in self.widths:
+                t = torch.zeros(self.fstat[0].shape[0], 2, n, dtype=torch.float64, device=X.device)
+                t[0, 1] = float(B)
+                es.append(t)
+            self._eval_stats[B] = es
+        rs = _ptr(rng_step)
+        for l in range(nl):
+            K = self.k0 if l == 0 else self.widths[l - 1]
+            check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
+                                        _ptr(self.a[l]), _ptr(self.fstat[l]), _ptr(es[l - 1]) if l else None,
+                                        bnp(f"{pre}.gamma{l - 1}") if l else None, bnp(f"{pre}.beta{l - 1}") if l else None,
+                                        None, _ptr(self.bn[l - 1]) if (l and self.bn_on) else None, rs, 0, l, 0.0, B, K,
+                                        self.widths[l], None, None, st), "rsx_tower_fwd_layer")
+        pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
+        wd, bd, wo, bo = head
+        lab = labels if labels is not None else self._zero_labels[:B]
+        check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(es[-1]), bnp(f"{pre}.gamma{nl - 1}"), bnp(f"{pre}.beta{nl - 1}"), None,
+                               _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)), _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
+                               _ptr(pv(bo)), _ptr(lab), _ptr(self.prob), _ptr(self.dy[-1]), _ptr(self.bstat[-1]),
+                               _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1), rs, 0, nl - 1, 0.0,
+                               1.0 / B, int(relu0), int(relu2), B, self.widths[-1], None, st), "rsx_tower_head")
+        loss = None
+        if labels is not None:     # the head's per-row-tile partial sums of the CE terms (column 0), in fp64
+            loss = (self.hpart[:(B + 15) // 16, 0].sum() / B).to(torch.float32).reshape(1)
+        return self.prob[:B].clone(), loss          # (a copy: self.prob is the TRAIN step's output buffer as well)
 
 
 class CrossLayers:
