@@ -157,6 +157,20 @@ def model_fn(features, labels, mode, params):
     masks = params.get("_dropout_masks")
     if training and store.tower is not None:
         return _train_fused(store, arena, ids, labels, params, masks)
+    if not training and store.tower is not None and params.get("fused_infer", True) and not torch.is_grad_enabled() \
+            and ids.shape[0] <= store.tower.cap:
+        # EVAL / PREDICT through the TRAIN step's kernels (gather, fused cross layers, FusedTower.infer: see deepfm.py)
+        nh = store.tower.widths[-1]
+        oW = P["out.W"].detach().view(-1)
+        x0, _, _, _ = arena.gather(ids)
+        _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
+        lab = None if (labels is None or mode == ModeKeys.PREDICT) else labels.reshape(-1).to(torch.float32)
+        prob, loss = store.tower.infer(x0, store.opt.state.view(torch.int32)[3:4], lab, s0=cz,
+                                       head=((oW[:nh], None), "out.b", None, None), relu0=False, relu2=False)
+        predictions = {"prob": prob}
+        if mode == ModeKeys.PREDICT:
+            return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+        return EstimatorSpec(mode, predictions=predictions, loss=loss[0], eval_metric_ops={"AUC": None, "Accuracy": None})
     if training:
         store.sort_ids_for_backward(arena, ids)
     (x0,) = gather_fm(arena, ids, dp=store.dp if training else None)               # embedding_net (:123)

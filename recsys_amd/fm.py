@@ -38,6 +38,23 @@ def model_fn(features, labels, mode, params):
     training = mode == ModeKeys.TRAIN
     if training and store.adam_mode == "tf1_dense" and params.get("fused", True) and (store.dp is None or store.dp_block):
         return _train_fused(store, arena, ids, labels)
+    if not training and store.adam_mode == "tf1_dense" and params.get("fused", True) and params.get("fused_infer", True) \
+            and not torch.is_grad_enabled():
+        # EVAL / PREDICT: gather + the FM head kernel of the TRAIN step (its gradients go to scratch)
+        B = ids.shape[0]
+        dev = ids.device
+        _, _, y1p, y2 = arena.gather(ids, fm=True, first_order=True)
+        lab = torch.zeros(B, device=dev) if (labels is None or mode == ModeKeys.PREDICT) else labels.reshape(-1).to(torch.float32)
+        prob, loss = torch.empty(B, device=dev), torch.empty(1, device=dev)
+        scr = torch.empty(2 * B + 4, device=dev)
+        _lib.check(_lib.lib().rsx_fm_head(_ptr(y1p), _ptr(y2), _ptr(P["b1"]), _ptr(P["out.W"].detach().view(-1)), _ptr(P["out.b"]),
+                                          _ptr(lab), _ptr(prob), _ptr(scr[:B]), _ptr(scr[B:2 * B]), _ptr(scr[2 * B:2 * B + 2]),
+                                          _ptr(scr[2 * B + 2:2 * B + 3]), _ptr(scr[2 * B + 3:]), _ptr(loss), 1.0 / B, B, None,
+                                          _stream()), "rsx_fm_head")
+        predictions = {"prob": prob}
+        if mode == ModeKeys.PREDICT:
+            return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+        return EstimatorSpec(mode, predictions=predictions, loss=loss[0], eval_metric_ops={"AUC": None, "Accuracy": None})
     if training:
         store.sort_ids_for_backward(arena, ids)
     _, y1p, y2 = gather_fm(arena, ids, fm=True, first_order=True, dp=store.dp if training else None)

@@ -247,6 +247,22 @@ def model_fn(features, labels, mode, params):
     if mode == ModeKeys.TRAIN:
         return _train_fused(store, a1, a2, ids, logx, labels, params, masks)
     B = ids.shape[0]
+    if params.get("fused_infer", True) and not torch.is_grad_enabled() and B <= store.tower.cap:
+        # EVAL / PREDICT through the TRAIN step's kernels: both gathers + linear_net pre-activation, CIN forward (fp32 or bf16
+        # as configured), FusedTower.infer (see deepfm.py)
+        E1 = torch.empty(B, a1.F * a1.D, device=ids.device)
+        E2 = torch.empty(B, a1.F * a1.D, device=ids.device)
+        lin_pre = torch.empty(B, device=ids.device)
+        _lib.check(_lib.lib().rsx_gather_two_fwd(_ptr(a1.tables), _ptr(a1.w1), _ptr(a2.tables), _ptr(a1.row_off), _ptr(ids),
+                                                 _ptr(logx.contiguous()), _ptr(P["lin.wnum"]), _ptr(E1), _ptr(E2), _ptr(lin_pre),
+                                                 a1.w1_mask, B, a1.F, a1.D, logx.shape[1], _stream()), "rsx_gather_two_fwd")
+        cin_y = store.cin.forward(E1.view(B, a1.F, a1.D), P, None)
+        lab = None if (labels is None or mode == ModeKeys.PREDICT) else labels.reshape(-1).to(torch.float32)
+        prob, loss = store.tower.infer(E2, store.opt.state.view(torch.int32)[3:4], lab, s0=lin_pre, c0="lin.b", s1=cin_y)
+        predictions = {"prob": prob}
+        if mode == ModeKeys.PREDICT:
+            return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+        return EstimatorSpec(mode, predictions=predictions, loss=loss[0], eval_metric_ops={"AUC": None, "Accuracy": None})
     n_layers = len(params["deep_layers"].split(","))
     E1, _, y1cat, _ = a1.gather(ids, first_order=True)
     linear_y = torch.relu(torch.addmv(y1cat, logx, P["lin.wnum"]) + P["lin.b"])                 # (:131)
