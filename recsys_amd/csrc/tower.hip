@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   const bool nobn = p.gamma == nullptr;          // this layer has no batch-norm (uniform)
   const int i = lane & 15, kq = lane >> 4;
   const int sb0 = first ? 16 : 24;
-  if (!SPLIT && p.dxg > 0 && bid < p.n_din) {
+  if (p.dxg > 0 && bid < p.n_din) {
     RSX_STAMP(sb0 + 0, bid == 0);
     bwd_dx_group_tile(p, bid, lds, first, nobn);
     return;
@@ -1151,8 +1151,13 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   // Off by default, and NOT chosen per launch: the two forms add the N products of an output in a different order, and the
   // windowed, the step-by-step and the plain path must stay bit-identical to each other.
   static const int dxg_env = getenv("RSX_TOWER_DXG") ? atoi(getenv("RSX_TOWER_DXG")) : 0;
-  const bool dxg_want = dxg_env > 0;
-  p.dxg = (p.sb > 1 || (N & 3) != 0 || N > 128 || !dxg_want) ? 0 : 4;
+  // Large batches (SPLIT, B >= 1024) always take the grouped form (RSX_TOWER_DXG_SPLIT=0 for A/B runs): there the one-tile
+  // workgroups (4 row tiles x 1 column tile each, operands as 4-byte strided loads) are throughput-bound -- phase stamps at
+  // batch 4096: 12-15 us per workgroup, 2 496 of them over ~1 000 slots -- while a grouped workgroup stages da and W once
+  // for four column tiles.  Every path of one batch size makes the same choice, so they stay bit-identical to each other.
+  static const int dxg_split_env = getenv("RSX_TOWER_DXG_SPLIT") ? atoi(getenv("RSX_TOWER_DXG_SPLIT")) : 1;
+  const bool dxg_want = p.sb > 1 ? dxg_split_env > 0 : dxg_env > 0;
+  p.dxg = ((N & 3) != 0 || N > 128 || !dxg_want) ? 0 : 4;
   p.n_din = p.dxg > 0 ? ((p.ct_k + p.dxg - 1) / p.dxg) * p.RTh : p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
   p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
   p.dwp = dw_partials;
