@@ -261,6 +261,14 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
 /* advance_step = 0: this launch leaves the beta powers / step counter alone because a later launch of the SAME step advances
  * them (models with two table sets: xdeepfm.py); 1 otherwise.                                                      */
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
+/* The window sweep (nw > 0) applies its 1 + nw zero-gradient updates with packed square roots / divisions that are correctly
+ * rounded on a restricted operand domain (csrc/adam_fast.h; elements outside it take the IEEE form).  Self-test of those forms
+ * against the compiler's sqrtf and '/': EVERY float of the square root's domain; 2 * 4096 * 256 * div_iters pseudo-random
+ * pairs over the division's domain; with exhaustive_div != 0 also all 2^46 pairs of mantissas at exponents 0 / 0 (~30 s).
+ * counts (device, 4 x uint64): sqrt mismatches, random-division mismatches, random pairs tried, exhaustive-division
+ * mismatches.  Synchronises the stream.                                                                                   */
+int rsx_adam_fast_math_selftest(unsigned long long* counts, uint32_t seed, int div_iters, int exhaustive_div,
+                                rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused DNN tower + head, TRAIN step: per layer

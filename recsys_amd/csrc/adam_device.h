@@ -1,6 +1,7 @@
 // TF-1.x Adam sweep as device/host building blocks shared by adam.hip (the stand-alone launch) and tower.hip (where
 // slices of the untouched-row sweep ride along in the tower launches).  See adam.hip for the semantics.
 #pragma once
+#include "adam_fast.h"
 #include "rsx_common.h"
 
 struct SegDev {
@@ -295,16 +296,67 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   }
 }
 
-// The untouched rows of a window of 1 + nw steps, fast form (its own kernel, adam_window_k: ~125 registers against the 61
-// of adam_block, whose footprint every carrier kernel and the one-step sweep inherit).  Blocks of other kinds -> adam_block.
+// ---- window sweep: packed fast form of the zero-gradient update --------------------------------------------------------
+#ifndef RSX_ADAM_WIN_FAST
+#define RSX_ADAM_WIN_FAST 1
+#endif
+
+// One zero-gradient TF-1 update of two elements -- adam_sparse1(has = false) -- with the packed square root / division.
+__device__ __forceinline__ void adam_zero_grad2(rsx_f2& var, rsx_f2& m, rsx_f2& v, const float alpha, const Hp& h) {
+  m = m * h.b1;
+  v = v * h.b2;
+  const rsx_f2 n = m * alpha;
+  const rsx_f2 d = rsx_sqrt2_fast(v) + h.eps;
+  var = var - rsx_div2_fast(n, d);
+}
+// Does this element leave the domain on which the packed form returns the bits of the IEEE form, at any of the window's
+// 1 + NW updates?  (Evaluated once per window on the loaded state; m and v only decay inside a window.)
+//   v:  2^-86 <= v <= 2^40                            -> every v_j in [2^-94, 2^40], d_j = sqrt(v_j) + eps in [2^-30, 2^21]
+//       v == +0 with m == +0 (a row no gradient has reached yet): the sweep computes with 1 in place of v -- n_j = +0, so
+//       the quotient is +0 whatever the denominator -- and stores the zero back (adam_window_block)
+//   m:  m_lo <= |m| <= 2^30 (m_lo = 2^-90 / min alpha) -> every n_j = alpha_j m_j has 2^-92 <= |n_j| <= 2^34: inside both domains
+//       m == +0                                        -> n_j = +0, both forms return +0
+//       |m| < m_lo (denormals, -0: where the moments of a row end up ~900 steps after its last gradient) and |var| >= 2^-24
+//                                                      -> |n_j| < 2^-88, so |q_j| < 2^-56 in EITHER form (d_j >= 2^-30; the
+//                                                         fast chain's result is bounded by 3 |n_j| / d_j): var - q_j == var
+// Anything else (NaN / inf moments, a tiny moment under a tiny weight, v below 2^-86) sends the wave to the IEEE form.
+__device__ __forceinline__ bool adam_win_guard1(const float var, const float m, const float v, const uint32_t m_lo_bits) {
+  const uint32_t vb = __float_as_uint(v), mb = __float_as_uint(m), ma = mb & 0x7fffffffu;
+  const uint32_t va = __float_as_uint(var) & 0x7fffffffu;
+  constexpr uint32_t V_LO = (127u - 86u) << 23, V_HI = (127u + 40u) << 23, M_HI = (127u + 30u) << 23;
+  constexpr uint32_t VAR_LO = (127u - 24u) << 23;
+  const bool v_ok = (vb - V_LO) <= (V_HI - V_LO);
+  const bool m_mid = (ma - m_lo_bits) <= (M_HI - m_lo_bits);
+  const bool m_tiny = ma < m_lo_bits && va >= VAR_LO;
+  return !(mb == 0u ? (v_ok || vb == 0u) : (v_ok && (m_mid || m_tiny)));
+}
+__device__ __forceinline__ bool adam_win_guard4(const float4& var, const float4& m, const float4& v, const uint32_t m_lo_bits) {
+  return adam_win_guard1(var.x, m.x, v.x, m_lo_bits) | adam_win_guard1(var.y, m.y, v.y, m_lo_bits) |
+         adam_win_guard1(var.z, m.z, v.z, m_lo_bits) | adam_win_guard1(var.w, m.w, v.w, m_lo_bits);
+}
+
+// The untouched rows of a window of 1 + NW steps (its own kernel, adam_window_k: the packed forms' temporaries would
+// otherwise count against every carrier kernel and the one-step sweep, which inherit adam_block's 61 registers).
+//   - TABLE_TF1_COLD blocks: batches of HB float4 per lane in phases, so that every load of a batch is in flight before
+//     the first use: slot maps (clamped index), then var / m / v unconditionally (a skipped row costs its read, ~1 % of the
+//     traffic; a guarded load would serialise the batch), then the 1 + NW updates, then the stores of the rows that moved.
+//     Software pipeline over the block's NB batches: the loads of batch b + 1 are issued before batch b is updated.
+//     (Measured against it at 8 / 4 steps per window, us per sweep of the DeepFM state: this form 86.5 / 61.0; persistent
+//     workgroups walking batches with a stride of the grid 85.2 / 64.7 at 4 per CU, 81.0 / 59.9 at 8 per CU; one batch per
+//     workgroup without a pipeline 97.5 / 65.6.  With the state L2-resident the updates alone cost ~9 us per step of the
+//     window: from ~4 steps per window on the kernel is VALU-bound, not HBM-bound.)
+//   - blocks of the other kinds (the first-order vector, ...): adam_block.
 template <int NW>
 __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint32_t blk, const int tid = threadIdx.x) {
+  constexpr int nw = NW;        // == a.nw (the host picks the instantiation)
+  constexpr int HB = RSX_ADAM_WIN_HB;
+  constexpr int NB = ADAM_U / HB;
+  static_assert(ADAM_U % HB == 0, "ADAM_U");
   int si = 0;
 #pragma unroll 1
   for (int k = 1; k < a.nseg; ++k)
     if (blk >= a.seg[k].blk_begin) si = k;
   const SegDev& s = a.seg[si];
-  constexpr int nw = NW;        // == a.nw (the host picks the instantiation)
   if (s.kind != RSX_ADAM_TABLE_TF1_COLD) {
     adam_block(a, blk, tid);
     return;
@@ -318,63 +370,133 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
   h.eps = a.eps;
   h.alpha = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
   const AlphaW aw = alpha_window(a, nw, b1p, b2p);
+  // Packed fast form of the zero-gradient updates (adam_fast.h): usable when the hyper-parameters keep every operand of a
+  // guarded element inside the fast forms' domains for all 1 + NW updates (b1^8 >= 1/4, b2^8 >= 2^-8, alphas within 4x).
+  float amin = h.alpha, amax = h.alpha;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    amin = fminf(amin, aw.get(j));
+    amax = fmaxf(amax, aw.get(j));
+  }
+  const bool fast_ok = RSX_ADAM_WIN_FAST && a.b1 >= 0.85f && a.b1 < 1.f && a.b2 >= 0.5f && a.b2 < 1.f && a.eps >= 0x1p-30f &&
+                       a.eps <= 1.f && amin >= 0x1p-24f && amax <= 16.f && amax <= 4.f * amin;
+  const uint32_t m_lo_bits = __float_as_uint(fast_ok ? 0x1p-90f / amin : 1.f);
   const int32_t* __restrict__ swb = a.slot_w0;
   const int sws = (int)a.slot_w_stride;           // (< 2^28: adam_build_args) 32-bit element offsets: scalar base + vector offset
-  const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    // The untouched rows of a window of 1 + nw steps (stand-alone launches; the one-step sweep below is what rides in other
-    // kernels' launches, where its 61 registers matter): touched rows are left to the scatter launches.  Batches of HB float4
-    // per lane, each in phases so that every load of the batch is in flight before the first use: slot maps (clamped index),
-    // then var / m / v unconditionally (a skipped row costs its read, ~1 % of the traffic; a guarded load would serialise
-    // the batch), then the 1 + nw updates one float4 at a time (4 independent chains, few temporaries: riders inherit their
-    // carrier's register budget), then the stores of the rows that moved.
-    // Software pipeline over batches of HB float4 per lane: the loads of batch b + 1 are issued before batch b is updated, so
-    // a wave's ALU phase (1 + NW correctly rounded div + sqrt per element) overlaps its own next memory phase.
-    constexpr int HB = RSX_ADAM_WIN_HB;
-    constexpr int NB = ADAM_U / HB;
-    static_assert(ADAM_U % HB == 0, "ADAM_U");
-    const int lpr = s.d >> 2;
-    const long long n4 = s.n * lpr;
-    const bool pow2 = (lpr & (lpr - 1)) == 0;
-    const int lsh = 31 - __clz(lpr);
-    struct Batch {
-      float4 var[HB], m[HB], v[HB];
-      long long ec[HB];
-      int t[HB];
-      bool live[HB];
-    };
-    auto issue = [&](const int b, Batch& B) {
+  const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
+  const int lpr = s.d >> 2;
+  const long long n4 = s.n * lpr;
+  const bool pow2 = (lpr & (lpr - 1)) == 0;
+  const int lsh = 31 - __clz(lpr);
+  struct Batch {
+    float4 var[HB], m[HB], v[HB];
+    long long ec[HB];
+    int t[HB];
+    bool live[HB];
+  };
+  auto issue = [&](const int b, Batch& B) {
 #pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        const long long e = base + (long long)(b * HB + u) * ADAM_T + tid;
-        B.ec[u] = e < n4 ? e : n4 - 1;
-        B.live[u] = e < n4;
-        const long long row = pow2 ? (B.ec[u] >> lsh) : (B.ec[u] / lpr);
-        B.t[u] = s.slot[row];
-        // (untouched = -1 = all ones: one value >= 0 clears the sign of the AND.)  All of them in flight at once.
+    for (int u = 0; u < HB; ++u) {
+      const long long e = base + (long long)(b * HB + u) * ADAM_T + tid;
+      B.ec[u] = e < n4 ? e : n4 - 1;
+      B.live[u] = e < n4;
+      const long long row = pow2 ? (B.ec[u] >> lsh) : (B.ec[u] / lpr);
+      B.t[u] = s.slot[row];
+      // (untouched = -1 = all ones: one value >= 0 clears the sign of the AND.)  All of them in flight at once.
 #pragma unroll
-        for (int l = 0; l < NW; ++l) B.t[u] &= swb[l * sws + (int)row];
-      }
+      for (int l = 0; l < NW; ++l) B.t[u] &= swb[l * sws + (int)row];
+    }
 #pragma unroll
-      for (int u = 0; u < HB; ++u) {
+    for (int u = 0; u < HB; ++u) {
 #if RSX_ADAM_NT
-        B.var[u] = __builtin_nontemporal_load(&var4[B.ec[u]]);
-        B.m[u] = __builtin_nontemporal_load(&m4[B.ec[u]]);
-        B.v[u] = __builtin_nontemporal_load(&v4[B.ec[u]]);
+      B.var[u] = __builtin_nontemporal_load(&var4[B.ec[u]]);
+      B.m[u] = __builtin_nontemporal_load(&m4[B.ec[u]]);
+      B.v[u] = __builtin_nontemporal_load(&v4[B.ec[u]]);
 #else
-        B.var[u] = var4[B.ec[u]];
-        B.m[u] = m4[B.ec[u]];
-        B.v[u] = v4[B.ec[u]];
+      B.var[u] = var4[B.ec[u]];
+      B.m[u] = m4[B.ec[u]];
+      B.v[u] = v4[B.ec[u]];
+#endif
+    }
+  };
+  auto store = [&](const Batch& B) {
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+      if (B.live[u] && B.t[u] < 0) {
+#if RSX_ADAM_NT
+        __builtin_nontemporal_store(B.var[u], &var4[B.ec[u]]);
+        __builtin_nontemporal_store(B.m[u], &m4[B.ec[u]]);
+        __builtin_nontemporal_store(B.v[u], &v4[B.ec[u]]);
+#else
+        var4[B.ec[u]] = B.var[u];
+        m4[B.ec[u]] = B.m[u];
+        v4[B.ec[u]] = B.v[u];
 #endif
       }
-    };
-    auto finish = [&](Batch& B) {
+    }
+  };
+  // Batches in which some element of the wave leaves the packed forms' domain are left untouched by the pipeline and redone
+  // in the IEEE form after it, from memory (a wave-uniform decision; the hot loop then holds the packed form only).
+  uint32_t redo = fast_ok ? 0u : (1u << NB) - 1u;
+  auto finish = [&](const int b, Batch& B) {
+    if (!fast_ok) return;
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < HB; ++u) bad |= adam_win_guard4(B.var[u], B.m[u], B.v[u], m_lo_bits);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+      redo |= 1u << b;
+      return;
+    }
+    rsx_f2 var2[HB][2], m2[HB][2], v2[HB][2];
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+      var2[u][0] = (rsx_f2){B.var[u].x, B.var[u].y}; var2[u][1] = (rsx_f2){B.var[u].z, B.var[u].w};
+      m2[u][0] = (rsx_f2){B.m[u].x, B.m[u].y}; m2[u][1] = (rsx_f2){B.m[u].z, B.m[u].w};
+      // (v == +0, which the guard admits under m == +0 only: compute with 1, store the zero back)
+      v2[u][0] = (rsx_f2){B.v[u].x == 0.f ? 1.f : B.v[u].x, B.v[u].y == 0.f ? 1.f : B.v[u].y};
+      v2[u][1] = (rsx_f2){B.v[u].z == 0.f ? 1.f : B.v[u].z, B.v[u].w == 0.f ? 1.f : B.v[u].w};
+    }
+    auto step = [&](const float alpha) {
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
+        adam_zero_grad2(var2[u][0], m2[u][0], v2[u][0], alpha, h);
+        adam_zero_grad2(var2[u][1], m2[u][1], v2[u][1], alpha, h);
+      }
+    };
+    step(h.alpha);
+#pragma unroll 1
+    for (int j = 0; j < NW; ++j) step(aw.get(j));
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+      B.var[u] = make_float4(var2[u][0].x, var2[u][0].y, var2[u][1].x, var2[u][1].y);
+      B.m[u] = make_float4(m2[u][0].x, m2[u][0].y, m2[u][1].x, m2[u][1].y);
+      B.v[u] = make_float4(B.v[u].x == 0.f ? 0.f : v2[u][0].x, B.v[u].y == 0.f ? 0.f : v2[u][0].y,
+                           B.v[u].z == 0.f ? 0.f : v2[u][1].x, B.v[u].w == 0.f ? 0.f : v2[u][1].y);
+    }
+    store(B);
+  };
+  {
+    Batch bt[2];
+    issue(0, bt[0]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) issue(b + 1, bt[(b + 1) & 1]);
+      finish(b, bt[b & 1]);
+    }
+  }
+  redo = __builtin_amdgcn_readfirstlane(redo);
+  if (redo != 0u) {
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      if (!(redo >> b & 1u)) continue;
+      Batch B;
+      issue(b, B);
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {     // (unrolled: a dynamically indexed register array is demoted to scratch)
         F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], z4, false, h);
 #pragma unroll 1
         for (int j = 0; j < NW; ++j) {          // the later steps of the window, back to back in registers
@@ -383,27 +505,7 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
           F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], z4, false, hj);
         }
       }
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        if (B.live[u] && B.t[u] < 0) {
-#if RSX_ADAM_NT
-          __builtin_nontemporal_store(B.var[u], &var4[B.ec[u]]);
-          __builtin_nontemporal_store(B.m[u], &m4[B.ec[u]]);
-          __builtin_nontemporal_store(B.v[u], &v4[B.ec[u]]);
-#else
-          var4[B.ec[u]] = B.var[u];
-          m4[B.ec[u]] = B.m[u];
-          v4[B.ec[u]] = B.v[u];
-#endif
-        }
-      }
-    };
-    Batch bt[2];
-    issue(0, bt[0]);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b + 1 < NB) issue(b + 1, bt[(b + 1) & 1]);
-      finish(bt[b & 1]);
+      store(B);
     }
   }
 }

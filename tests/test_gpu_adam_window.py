@@ -92,6 +92,93 @@ def test_window_sweep_equals_k_single_sweeps(k):
     np.testing.assert_allclose(a[3].numpy()[cold.numpy()], wv, rtol=1e-6, atol=1e-9)
 
 
+def _bits(x):
+    return x.contiguous().view(torch.int32)
+
+
+@pytest.mark.parametrize("k,hyper", [(8, {}), (4, {}), (2, {}), (8, dict(lr=0.05)), (8, dict(eps=1e-7, b2=0.99)),
+                                     (8, dict(b1=0.5)), (5, dict(lr=3e-7)), (8, dict(eps=1e-12))])
+def test_window_sweep_with_adversarial_state_is_the_bits_of_k_single_sweeps(k, hyper):
+    """The window sweep applies its updates with packed square roots / divisions that are correctly rounded on a restricted
+    domain (csrc/adam_fast.h) and sends every wave holding an element outside it to the IEEE form.  State built from the
+    values that sit on and around the guard's edges -- zeros of both signs, denormals (where the moments of a row end up
+    ~900 steps after its last gradient), tiny and huge normals, inf, NaN -- in every combination of (var, m, v), compared BIT
+    FOR BIT (signs of zero and NaN payloads included) with k single-step sweeps, which always use the IEEE form.  The
+    hyper-parameter sets include ones that switch the packed form off altogether (b1 = 0.5, tiny lr, tiny eps)."""
+    from recsys_amd import _lib
+    from recsys_amd.ops import AdamTF1
+    f = np.float32
+    m_vals = [0.0, -0.0, 1e-45, -1e-45, 4e-45, -6e-42, 1e-39, -1.2e-38, 2.0 ** -100, -(2.0 ** -90), 2.0 ** -81, 2.0 ** -80,
+              -(2.0 ** -79), 1e-20, -3e-12, 1e-7, -2.5e-3, 0.3, -7.0, 2.0 ** 29, 2.0 ** 30, -(2.0 ** 31), np.inf, -np.inf, np.nan]
+    v_vals = [0.0, -0.0, 1e-45, 1e-40, 2.0 ** -126, 2.0 ** -100, 2.0 ** -96, 2.0 ** -87, 2.0 ** -86, 2.0 ** -85, 1e-20, 1e-15,
+              3e-9, 1e-4, 0.5, 100.0, 2.0 ** 39, 2.0 ** 40, 2.0 ** 41, 1e30, np.inf, np.nan]
+    var_vals = [0.0, -0.0, 1e-45, -1e-40, 2.0 ** -60, -(2.0 ** -25), 2.0 ** -24, -(2.0 ** -23), 1e-5, -0.013, 0.5, -3.0, 1e6,
+                np.inf, np.nan]
+    with np.errstate(over="ignore"):
+        mv, vv, xv = np.array(m_vals, dtype=f), np.array(v_vals, dtype=f), np.array(var_vals, dtype=f)
+    rng = np.random.default_rng(k)
+    # (1) the full grid, one combination per element; (2) rows of ordinary state with a single odd element in them;
+    # (3) ordinary rows (these waves must take the packed form)
+    grid = np.stack(np.meshgrid(xv, mv, vv, indexing="ij"), -1).reshape(-1, 3)
+    D = 16
+    n_grid_rows = (len(grid) + D - 1) // D
+    pad = np.zeros((n_grid_rows * D - len(grid), 3), dtype=f)
+    grid = np.concatenate([grid, pad]).reshape(n_grid_rows, D, 3)
+    n_ord = 1500
+    ordn = np.stack([rng.standard_normal((n_ord, D)).astype(f) * f(0.05),
+                     rng.standard_normal((n_ord, D)).astype(f) * f(1e-4) * (f(0.9) ** rng.integers(0, 700, (n_ord, D))).astype(f),
+                     (rng.random((n_ord, D)).astype(f) * f(1e-6)) ** 2], -1)
+    odd = ordn[:600].copy()
+    pick = rng.integers(0, len(grid.reshape(-1, 3)), 600)
+    odd[np.arange(600), rng.integers(0, D, 600)] = grid.reshape(-1, 3)[pick]
+    state = np.concatenate([grid, odd, ordn])
+    R = state.shape[0]
+    tab0, m0, v0 = (torch.from_numpy(np.ascontiguousarray(state[..., i])) for i in range(3))
+    slot_all = torch.full((k, R + 4), -1, dtype=torch.int32)
+    g = torch.Generator(device="cpu").manual_seed(k)
+    for i in range(k):
+        idx = torch.randperm(R, generator=g)[:R // 50]
+        slot_all[i, idx] = torch.arange(R // 50, dtype=torch.int32)
+    slot_all = slot_all.cuda()
+    slots = [slot_all[i] for i in range(k)]
+    touched = torch.stack([s[:R] >= 0 for s in slots]).any(0)
+    b1, b2 = hyper.get("b1", 0.9), hyper.get("b2", 0.999)
+
+    def run(window):
+        t, m, v = tab0.clone().cuda(), m0.clone().cuda(), v0.clone().cuda()
+        opt = AdamTF1(lr=hyper.get("lr", 1e-3), beta1=b1, beta2=b2, eps=hyper.get("eps", 1e-8), device="cuda")
+        if window:
+            segs = [dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=D, n=R, var=t, m=m, v=v, slot=slots[0], slot_w=slots[1:])]
+            for sl in opt.cold_slices(segs, [1.0, 2.0]):
+                opt.run_slice(sl)
+        else:
+            union = torch.where(touched.cuda(), torch.zeros(R, dtype=torch.int32, device="cuda"),
+                                torch.full((R,), -1, dtype=torch.int32, device="cuda"))
+            union = torch.cat([union, torch.full((4,), -1, dtype=torch.int32, device="cuda")])
+            segs = [dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=D, n=R, var=t, m=m, v=v, slot=union)]
+            for _ in range(k):
+                for sl in opt.cold_slices(segs, [1.0]):
+                    opt.run_slice(sl)
+                st = opt.state.cpu().numpy().copy()
+                st[0], st[1] = f(st[0] * f(b1)), f(st[1] * f(b2))
+                opt.state.copy_(torch.from_numpy(st))
+        torch.cuda.synchronize()
+        return [x.cpu() for x in (t, m, v)]
+
+    a, b = run(True), run(False)
+    for name, x, y in zip(("tables", "m", "v"), a, b):
+        diff = _bits(x) != _bits(y)
+        assert not bool(diff.any()), (name, int(diff.sum()), state[diff.any(1).numpy()][:3])
+    # the numbers are numpy's (IEEE, denormals on) for the ordinary rows no step touches
+    cold = (~touched[-n_ord:]).cpu().numpy()
+    var, m, v = (state[-n_ord:][cold][..., i] for i in range(3))
+    lr, eps = hyper.get("lr", 1e-3), hyper.get("eps", 1e-8)
+    for t_ in range(1, k + 1):
+        var, m, v = _adam_np(var, m, v, t_, lr=lr, b1=b1, b2=b2, eps=eps)
+    assert np.array_equal(a[0].numpy()[-n_ord:][cold].view(np.int32), var.view(np.int32))
+    assert np.array_equal(a[1].numpy()[-n_ord:][cold].view(np.int32), m.view(np.int32))
+
+
 def test_multi_sort_equals_single_sorts():
     from oracle import criteo
     from recsys_amd.ops import EmbeddingArena
