@@ -9,6 +9,7 @@
 // each wave accumulates its examples in order into a lane-private LDS slab, the per-wave partials are
 // summed in order by cross_reduce_k.  No atomics.
 #include <cstdlib>
+#include <type_traits>
 
 #include "rsx_common.h"
 
@@ -195,6 +196,123 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
   for (int e = lane; e < nvec * n4; e += 64) dst[e] = acc[e];
 }
 
+// Sum over the wave, the same value in every lane: two quad permutes and two row mirrors (DPP, no LDS crossbar: the six
+// ds_bpermute of the xor butterfly cost ~0.3 us per call in the backward's dependent chain), then the four row totals in
+// row order.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});    // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return ((r0 + r1) + r2) + r3;
+}
+
+// The same backward for L <= 3 known at compile time (dcn.py: 3; L = 4 would spill): 4 waves per workgroup, each walking `epw` examples into
+// its OWN slab; the four slabs are added in wave order into one partial per workgroup.  Against cross_bwd_k (one wave per
+// workgroup, loops unrolled to CROSS_MAX_L: 442 registers, one wave per SIMD, one partial per wave): ~190 registers and
+// 70 KB of LDS per workgroup -> two workgroups = 8 waves per CU, a quarter of the partials.
+// grid = ceil(B / (4 epw)), block = 256, dyn LDS: 4 (2L+1) dim floats.
+template <int L>
+__global__ __launch_bounds__(256, 2) void cross_bwd4_k(const CrossBwdArgs p, int epw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n4 = p.dim >> 2;
+  constexpr int nvec = 2 * L + 1;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* acc = reinterpret_cast<float4*>(lds) + (size_t)w * nvec * n4;     // this wave's slab (LDS operations of one wave are ordered)
+  for (int e = lane; e < nvec * n4; e += 64) acc[e] = z;
+  float4 wv[L][CROSS_NV];
+#pragma unroll
+  for (int l = 0; l < L; ++l)
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v)
+      wv[l][v] = cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, lane + 64 * v, n4);
+  for (int rr = 0; rr < epw; ++rr) {
+    const int b = (blockIdx.x * 4 + w) * epw + rr;
+    if (b >= p.B) break;
+    float4 x0[CROSS_NV], xs[L][CROSS_NV], x[CROSS_NV], dx[CROSS_NV], dx0[CROSS_NV];
+    float sl[L];
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, lane + 64 * v, n4);
+      x[v] = x0[v];
+      dx0[v] = z;
+    }
+    const float g = p.gz != nullptr ? p.gz[b] : 0.f;
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {          // (issued before the recomputation below needs anything)
+      float4 d = z;
+      if (p.dxL != nullptr) d = cross_ld(reinterpret_cast<const float4*>(p.dxL) + (size_t)b * n4, lane + 64 * v, n4);   // uniform
+      dx[v] = d;
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) sl[l] = p.s[(size_t)b * L + l];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {                 // recompute x_0 .. x_{L-1} (and x_L in `x`)
+#pragma unroll
+      for (int v = 0; v < CROSS_NV; ++v) {
+        xs[l][v] = x[v];
+        const float4 bb = cross_ld(reinterpret_cast<const float4*>(p.Bc) + (size_t)l * n4, lane + 64 * v, n4);
+        x[v] = f4_add(f4_add(f4_scale(sl[l], x0[v]), x[v]), bb);
+      }
+    }
+    if (p.gz != nullptr) {
+#pragma unroll
+      for (int v = 0; v < CROSS_NV; ++v) {
+        const int e = lane + 64 * v;
+        dx[v] = f4_add(dx[v], f4_scale(g, cross_ld(reinterpret_cast<const float4*>(p.wout), e, n4)));
+        if (e < n4) {
+          float4* o = acc + (size_t)(2 * L) * n4 + e;
+          *o = f4_add(*o, f4_scale(g, x[v]));                       // d wout += gz * x_L
+        }
+      }
+    }
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+      float part = 0.f;
+#pragma unroll
+      for (int v = 0; v < CROSS_NV; ++v) part += dot4(dx[v], x0[v]);
+      const float ds = wave_sum_dpp(part);
+#pragma unroll
+      for (int v = 0; v < CROSS_NV; ++v) {
+        const int e = lane + 64 * v;
+        if (e < n4) {
+          float4* db = acc + (size_t)(L + l) * n4 + e;
+          float4* dw = acc + (size_t)l * n4 + e;
+          *db = f4_add(*db, dx[v]);                                  // dB_l += dx_{l+1}
+          *dw = f4_add(*dw, f4_scale(ds, xs[l][v]));                 // dW_l += ds * x_l
+        }
+        dx0[v] = f4_add(dx0[v], f4_scale(sl[l], dx[v]));             // dx0 += s_l * dx_{l+1}
+        dx[v] = f4_add(dx[v], f4_scale(ds, wv[l][v]));               // dx_l = dx_{l+1} + ds * w_l
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < CROSS_NV; ++v) {
+      const int e = lane + 64 * v;
+      if (e < n4) {
+        float4 o = f4_add(dx0[v], dx[v]);
+        float4* dst = reinterpret_cast<float4*>(p.dX) + (size_t)b * n4 + e;
+        if (p.accumulate) o = f4_add(*dst, o);
+        *dst = o;
+      }
+    }
+  }
+  __syncthreads();
+  const float4* sl4 = reinterpret_cast<const float4*>(lds);
+  const int per = nvec * n4;
+  float4* dst = reinterpret_cast<float4*>(p.part) + (size_t)blockIdx.x * per;
+  for (int e = threadIdx.x; e < per; e += 256)
+    dst[e] = f4_add(f4_add(f4_add(sl4[e], sl4[per + e]), sl4[2 * per + e]), sl4[3 * per + e]);
+}
+
 // out[j] = sum over the RT per-wave partials.  16 threads per output: thread q sums partials q, q+16, ... in order,
 // then the 16 totals are added in ascending q through LDS (fixed order).  grid = ceil(n/16), block = 256.
 __global__ __launch_bounds__(256) void cross_reduce_k(const float* __restrict__ part, int RT, int n, float* __restrict__ dW,
@@ -245,7 +363,13 @@ static inline int cross_epw(int B) {   // examples per wave
   return B <= 512 ? 1 : (B <= 2048 ? 2 : 4);   // ~4 us of dependent latency per example: parallelism first (measured)
 }
 
-extern "C" size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L) {
+static inline int cross_epw4(int B) {   // examples per wave of cross_bwd4_k (a workgroup takes 4x that)
+  static const int forced = getenv("RSX_CROSS_EPW4") ? atoi(getenv("RSX_CROSS_EPW4")) : 0;   // tuning aid
+  if (forced > 0) return forced;
+  return B <= 1024 ? 1 : (B <= 8192 ? 2 : 4);
+}
+
+extern "C" size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L) {   // (the one-wave form's: never less than bwd4's)
   const int epw = cross_epw(B);
   return (size_t)((B + epw - 1) / epw) * (size_t)(2 * L + 1) * (size_t)dim;
 }
@@ -260,11 +384,32 @@ extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, c
   if (dxL == nullptr && gz == nullptr) return RSX_EINVAL;
   if (dim % 4 != 0 || dim > 256 * CROSS_NV || L > CROSS_MAX_L) return RSX_EUNSUPPORTED;
   CrossBwdArgs p{x0, W, Bc, s, dxL, gz, wout, dX, workspace, accumulate, B, dim, L};
-  const int epw = cross_epw(B);
-  const int RT = (B + epw - 1) / epw;
-  const size_t lds = (size_t)(2 * L + 1) * dim * sizeof(float);
-  if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
-  hipLaunchKernelGGL(cross_bwd_k, dim3(RT), dim3(64), lds, rsx_s(stream), p, epw);
+  int RT;
+  static const int bwd4 = getenv("RSX_CROSS_BWD4") ? atoi(getenv("RSX_CROSS_BWD4")) : 1;   // 0: the one-wave form for every L
+  const size_t lds4 = (size_t)4 * (2 * L + 1) * dim * sizeof(float);
+  if (bwd4 && L <= 3 && lds4 <= 80 * 1024) {
+    const int epw = cross_epw4(B);
+    RT = (B + 4 * epw - 1) / (4 * epw);
+    auto launch = [&](auto kern) {
+      static bool attr_set = false;      // (> 64 KB of dynamic LDS per workgroup)
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(RT), dim3(256), lds4, rsx_s(stream), p, epw);
+    };
+    switch (L) {
+      case 1: launch(cross_bwd4_k<1>); break;
+      case 2: launch(cross_bwd4_k<2>); break;
+      default: launch(cross_bwd4_k<3>); break;
+    }
+  } else {
+    const int epw = cross_epw(B);
+    RT = (B + epw - 1) / epw;
+    const size_t lds = (size_t)(2 * L + 1) * dim * sizeof(float);
+    if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
+    hipLaunchKernelGGL(cross_bwd_k, dim3(RT), dim3(64), lds, rsx_s(stream), p, epw);
+  }
   RSX_CHECK_LAUNCH();
   const int n = (2 * L + 1) * dim;
   hipLaunchKernelGGL(cross_reduce_k, dim3((n + 15) / 16), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,

@@ -286,7 +286,8 @@ def test_fm_train_parity_criteo_bs256():
     assert max(perr.values()) < 5e-5, perr
 
 
-@pytest.mark.parametrize("B,dim,L", [(33, 624, 3), (256, 624, 4), (5, 64, 1), (70, 1024, 7), (1500, 624, 3)])
+@pytest.mark.parametrize("B,dim,L", [(33, 624, 3), (256, 624, 4), (5, 64, 1), (70, 1024, 7), (1500, 624, 3), (4099, 624, 2),
+                                     (9001, 128, 3)])
 def test_cross_layers_op_parity(B, dim, L):
     from recsys_amd.ops import CrossFn, CrossLayers
     rng = np.random.default_rng(B + L)
@@ -303,8 +304,11 @@ def test_cross_layers_op_parity(B, dim, L):
     tol = dict(rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(out.detach().cpu().numpy(), xs[-1], **tol)
     np.testing.assert_allclose(tx.grad.cpu().numpy(), dx0, **tol)
-    np.testing.assert_allclose(tW.grad.cpu().numpy(), dW, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(tB.grad.cpu().numpy(), dB, rtol=1e-4, atol=1e-4)
+    # batch sums of B terms of magnitude ~2 (unit-variance upstream gradient): the fp32 summation-order noise between the
+    # kernel's per-wave partials and numpy's pairwise sum grows with B (~7e-8 x |partial sum| per add), so does the tolerance
+    bt = 1e-4 * max(1.0, B / 1500.0)
+    np.testing.assert_allclose(tW.grad.cpu().numpy(), dW, rtol=1e-4, atol=bt)
+    np.testing.assert_allclose(tB.grad.cpu().numpy(), dB, rtol=1e-4, atol=bt)
     assert tuple(models.cross_fwd(np.array([[1.0, 2.0, 0, 0]], np.float32), np.array([[1.0, 1, 0, 0]], np.float32),
                                   np.zeros((1, 4), np.float32))[0][-1][0][:2]) == (4.0, 8.0)   # Appendix B-6 KAT
 
