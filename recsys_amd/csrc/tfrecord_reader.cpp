@@ -214,9 +214,20 @@ struct rsx_reader {
             if (c != rsx_masked_crc32c_h(m->p + p, 8)) { finish_scan(RSX_EDATA); return; }
           }
           if (len > n - p - 12 || n - p - 12 - len < 4 || len > 0xFFFFFFFFull) { finish_scan(RSX_EDATA); return; }
+          // This walk is the one serial stage of the reader and it is a chain of cache misses (one header per record, the
+          // next address known only from this length): records of one dataset have nearly the same size, so the lines where
+          // the headers 4 and 5 records ahead will most likely sit are requested now.
+          {
+            const size_t step = 16 + (size_t)len, a4 = p + 4 * step, a5 = a4 + step;
+            if (a5 + 64 < n) {
+              __builtin_prefetch(m->p + a4);
+              __builtin_prefetch(m->p + a5);
+            }
+          }
           const bool mine = (batch_in_epoch % world) == rank;
           if (mine) {
             if (cur.keep.empty() || cur.keep.back().get() != m.get()) cur.keep.push_back(m);
+            if (cur.recs.empty()) cur.recs.reserve((size_t)bs);
             cur.recs.push_back({m->p + p + 12, (uint32_t)len});
           }
           p += 16 + len;

@@ -13,6 +13,8 @@ Differences that are deliberate (MI355X-first):
   * MirroredStrategy (fm/fm.py:184-194) becomes one process per GPU + RCCL (recsys_amd.dist).
 """
 import os
+import queue
+import threading
 import time
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Optional
@@ -259,6 +261,7 @@ class Estimator:
         self._graphs = {}
         self._ring = {}        # pinned staging buffers for host batches (see _h2d)
         self._copy_stream = None
+        self._overlap_h2d = os.environ.get("RSX_H2D_OVERLAP", "0") != "0"     # window inputs on a copy stream; default: in line
         self._restored = False
         self._log_t = None
         self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
@@ -549,42 +552,115 @@ class Estimator:
         return self.store.opt.global_step if self.store.built else 0
 
     # -- public API --------------------------------------------------------------------------
-    def _train_window_packed(self, pbs):
-        """One optimizer window over len(pbs) host (or device) batches: len(pbs) copies into the graph's static input
-        buffers, ONE graph replay for all of its steps.  -> loss of the last step.
-        Two captured instances of the window (each with its own static inputs) take turns: the copies of window w + 1 run on
-        a copy stream while the graph of window w computes -- 8 H2D copies are ~80 us of a 640 us window otherwise."""
+    def _train_window_packed(self, pbs, launcher=None):
+        """One optimizer window over len(pbs) host (or device) batches -> loss of the last step.  The window's static input
+        buffers are slices of ONE device allocation: host batches are memcpy'ed into one pinned staging buffer and go over in
+        ONE H2D copy per window (eight 54 KB copies cost the host ~10 us each and the copy engine a start-up each), in line on
+        the compute stream (a copy stream + two events measured 5 us per step SLOWER: 0.0749 vs 0.0696 ms, bench.py
+        --host_input), then ONE graph replay runs all of the window's steps.  Two captured instances of the window (each with
+        its own inputs and staging buffer) take turns, so that window w + 1 can be staged while window w is still queued.
+        launcher (Estimator.train): the copy + replay are handed to the launch thread; -> None (the loss is the launch's)."""
         key = ("packedwin", len(pbs)) + pbs[0].key()
         g = self._graphs.setdefault(key, {"warm": 0, "sets": [], "turn": 0})
         if len(g["sets"]) == 2:
+            host = all(pb.flat.device.type == "cpu" for pb in pbs)
+            if host and not self._overlap_h2d:
+                st = self._stage_window(g, pbs)
+                if launcher is not None:
+                    launcher.submit(lambda: self._launch_staged(st))
+                    return None
+                return self._launch_staged(st)
+            if launcher is not None:
+                launcher.drain()
             st = g["sets"][g["turn"]]
             g["turn"] ^= 1
             cur = torch.cuda.current_stream()
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream()
-            cs = self._copy_stream
-            cs.wait_event(st["done"])              # the replay that last read this instance's inputs has finished
+            cs = self._copy_stream if self._overlap_h2d else cur
+            if host:
+                st["pin_ev"].synchronize()
+                stride, pin = st["stride"], st["pin_np"]
+                for i, pb in enumerate(pbs):
+                    np.copyto(pin[i * stride:i * stride + pb.nbytes], pb.flat.numpy())
+            if cs is not cur:
+                cs.wait_event(st["done"])          # the replay that last read this instance's inputs has finished
             with torch.cuda.stream(cs):
-                for sb, pb in zip(st["static"], pbs):
-                    self._h2d(sb, pb)
-                st["ready"].record(cs)
-            cur.wait_event(st["ready"])
+                if host:
+                    st["all"].copy_(st["pin"], non_blocking=True)
+                    st["pin_ev"].record(cs)
+                else:
+                    for sb, pb in zip(st["static"], pbs):
+                        self._h2d(sb, pb)
+                if cs is not cur:
+                    st["ready"].record(cs)
+            if cs is not cur:
+                cur.wait_event(st["ready"])
             st["graph"].replay()
             st["done"].record(cur)
             return st["losses"][-1]
+        if launcher is not None:
+            launcher.drain()
         dev = [pb if pb.flat.device == self.store.device else pb.to(self.store.device) for pb in pbs]
         if g["warm"] < 1:
             g["warm"] += 1
             return self._train_window([pb.views() for pb in dev])[-1]
-        st = {"static": [pb.clone() for pb in dev], "ready": torch.cuda.Event(), "done": torch.cuda.Event()}
+        stride = (dev[0].nbytes + 255) & ~255
+        st = {"ready": torch.cuda.Event(), "done": torch.cuda.Event(), "pin_ev": torch.cuda.Event(), "stride": stride,
+              "free": threading.Event(), "all": torch.empty(len(dev) * stride, dtype=torch.uint8, device=self.store.device)}
+        st["free"].set()
+        st["pin"] = torch.empty(len(dev) * stride, dtype=torch.uint8).pin_memory()
+        st["pin_np"] = st["pin"].numpy()
+        st["static"] = []
+        for i, pb in enumerate(dev):
+            sb = PackedBatch.__new__(PackedBatch)
+            sb.layout, sb.nbytes, sb.flat = pb.layout, pb.nbytes, st["all"][i * stride:i * stride + pb.nbytes]
+            sb.flat.copy_(pb.flat)
+            st["static"].append(sb)
         st["graph"], st["losses"] = self._capture(lambda: self._train_window([sb.views() for sb in st["static"]]))
         st["graph"].replay()            # capture executes nothing: the static buffers already hold this window's batches
         st["done"].record(torch.cuda.current_stream())
         g["sets"].append(st)
         return st["losses"][-1]
 
+    def _stage_window(self, g, pbs):
+        """Host half of a window (the training thread): the next instance's staging buffer <- the window's batches."""
+        st = g["sets"][g["turn"]]
+        g["turn"] ^= 1
+        st["free"].wait()                  # the launch that last used this instance has queued its copy (and recorded pin_ev)
+        st["free"].clear()
+        st["pin_ev"].synchronize()         # ... and the GPU has run it (two windows ago)
+        stride, pin = st["stride"], st["pin_np"]
+        for i, pb in enumerate(pbs):       # (plain memcpys: torch's CPU copy_ of > 32 KB wakes its thread pool, ~0.4 ms)
+            np.copyto(pin[i * stride:i * stride + pb.nbytes], pb.flat.numpy())
+        return st
+
+    def _launch_staged(self, st):
+        """Device half of a window (the launch thread, or in line): ONE H2D copy, ONE graph replay -> loss of the last step."""
+        st["all"].copy_(st["pin"], non_blocking=True)
+        st["pin_ev"].record()
+        st["free"].set()
+        st["graph"].replay()
+        return st["losses"][-1]
+
     def train(self, input_fn, steps=None, max_steps=None):
         it = iter(input_fn())
+        if self._use_graph() and os.environ.get("RSX_INPUT_THREAD", "0") != "0":      # (measured: no gain next to the launch thread)
+            depth = max(16, 2 * self._window_len())
+            # (an iterator that outlives this call keeps its thread and whatever the thread has pulled ahead)
+            it = it.threaded(depth) if isinstance(it, _Resumable) else _InputThread(it, depth)
+        launcher = None          # thread that issues the staged windows (single replica, HIP graphs on)
+        if self._use_graph() and self.store.dp is None and os.environ.get("RSX_LAUNCH_THREAD", "1") != "0":
+            launcher = _LaunchThread(self.config.device)
+        try:
+            self._train_loop(it, steps, max_steps, launcher)
+        finally:
+            if launcher is not None:
+                launcher.close()
+            _close_iter(it)
+        return self
+
+    def _train_loop(self, it, steps, max_steps, launcher):
         done = 0
         cfg = self.config
         self._log_t, log_step0 = time.time(), None
@@ -630,16 +706,21 @@ class Estimator:
                     break
                 win.append(pb)
             if len(win) == 1:
+                if launcher is not None:
+                    launcher.drain()
                 loss = self._train_step(win[0])
             else:                              # (one graph per window length: the full one, and the shorter ones that
-                loss = self._train_window_packed(win)     # end at a log line / checkpoint / the end of training)
+                loss = self._train_window_packed(win, launcher)     # end at a log line / checkpoint / the end of training)
             features, labels = held[len(win) - 1]
             del held[:len(win)]
             done += len(win)
             if gs_host is not None:
                 gs_host += len(win)
-            gs = self.global_step if (done % cfg.log_step_count_steps == 0 or
-                                      (cfg.save_checkpoints_steps and done % cfg.save_checkpoints_steps == 0)) else None
+            gs = None
+            if done % cfg.log_step_count_steps == 0 or (cfg.save_checkpoints_steps and done % cfg.save_checkpoints_steps == 0):
+                if launcher is not None and loss is None:
+                    loss = launcher.drain()
+                gs = self.global_step
             if gs is not None and done % cfg.log_step_count_steps == 0:
                 now = time.time()
                 world = 1
@@ -657,10 +738,10 @@ class Estimator:
             if gs is not None and cfg.save_checkpoints_steps and self.model_dir and \
                     done % cfg.save_checkpoints_steps == 0:
                 self._save_checkpoint(gs)
+        if launcher is not None:
+            launcher.drain()
         if self.model_dir and self.store.built and done:
             self._save_checkpoint(self.global_step)
-        _close_iter(it)
-        return self
 
     def _infer_step(self, features, labels, mode):
         """One EVAL / PREDICT forward over a host (or device) batch -> (prob, loss or None, labels on the device).  With HIP
@@ -778,6 +859,137 @@ class Estimator:
         return {"prob": np.concatenate(out) if out else np.zeros(0, np.float32)}
 
 
+class _LaunchThread:
+    """Issues the staged windows of Estimator.train (ONE H2D copy + ONE graph replay each) in order, on a thread of its own.
+    Why: hipGraphLaunch keeps its caller for almost as long as the window runs on the GPU (rocprofv3 --hip-runtime-trace:
+    499 us for a DeepFM window of 8 steps / 58 kernel nodes that executes in 560 us) -- with everything on one thread the
+    ~200 us it takes to fetch and stage the next window's batches left the GPU idle for that long between windows (165 us
+    gaps in the kernel trace, 91-96 us per step against 70 for the same windows launched back to back).  torch releases the
+    GIL inside replay(); the training thread stages window w + 1 meanwhile."""
+
+    def __init__(self, device):
+        self._q = queue.Queue(maxsize=1)
+        self._err = None
+        self.last = None
+        self._dev = torch.cuda.current_device() if torch.device(device).type == "cuda" else None
+        self._t = threading.Thread(target=self._run, name="rsx-launch", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        while True:
+            fn = self._q.get()
+            try:
+                if fn is None:
+                    return
+                if self._err is None:
+                    if self._dev is not None and torch.cuda.current_device() != self._dev:
+                        torch.cuda.set_device(self._dev)
+                    self.last = fn()
+            except BaseException as e:             # surfaces at the next submit / drain
+                self._err = e
+            finally:
+                self._q.task_done()
+
+    def _check(self):
+        if not self._t.is_alive():
+            raise RuntimeError("rsx-launch thread is gone") from self._err
+
+    def submit(self, fn):
+        if self._err is not None:
+            self.drain()
+        while True:
+            self._check()
+            try:
+                self._q.put(fn, timeout=1.0)
+                return
+            except queue.Full:
+                continue
+
+    def drain(self):
+        """Everything submitted has been issued to the stream -> result of the last launch."""
+        with self._q.all_tasks_done:
+            while self._q.unfinished_tasks:
+                self._check()
+                self._q.all_tasks_done.wait(timeout=1.0)
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+        return self.last
+
+    def close(self):
+        try:
+            self.drain()
+        except BaseException:
+            pass
+        if self._t.is_alive():
+            self._q.put(None)
+            self._t.join(timeout=5.0)
+        self._err = None
+
+
+class _InputThread:
+    """Pulls batches from an input iterator on a thread of its own, a bounded number ahead of the consumer.
+    Why: launching a captured window (hipGraphLaunch) keeps the calling thread for almost as long as the window runs on the
+    GPU -- the runtime enqueues the graph's ~60 kernel nodes one by one, ~8 us each (rocprofv3 --hip-runtime-trace: 499 us
+    for a DeepFM window of 8 steps that executes in 560) -- so whatever else the training thread does per window (fetching 8
+    batches from the reader, wrapping them: ~200 us) used to leave the GPU idle for that long between windows.  torch releases
+    the GIL inside replay(), the reader's `next` is a C call: this thread's work fits into the launch."""
+
+    _END = object()
+
+    def __init__(self, it, depth):
+        self._it = it
+        self._q = queue.Queue(maxsize=max(2, int(depth)))
+        self._stop = False
+        self._t = threading.Thread(target=self._run, name="rsx-input", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        try:
+            for item in self._it:
+                if self._stop:
+                    break
+                while not self._stop:
+                    try:
+                        self._q.put((item, None), timeout=0.05)
+                        break
+                    except queue.Full:
+                        continue
+                if self._stop:
+                    break
+            item = (self._END, None)
+        except BaseException as e:                 # surfaces in the consumer
+            item = (self._END, e)
+        _close_iter(self._it)                      # (by the thread that runs the generator)
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.05)
+                return
+            except queue.Full:
+                continue
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item, extra = self._q.get()
+        if item is self._END:
+            self._q.put((item, extra))             # (stay exhausted)
+            if extra is not None:
+                raise extra
+            raise StopIteration
+        return item
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._t.join(timeout=5.0)
+
+
 def _close_iter(it):
     """Stop a prefetching input iterator whose consumer leaves early (evaluate(steps=...), predict's caller breaking
     out): generators get close(), which runs their `finally` and stops the producer thread."""
@@ -817,6 +1029,12 @@ class _Resumable:
         return self
 
     def __iter__(self):
+        return self
+
+    def threaded(self, depth):
+        """Move the underlying iterator behind an input thread (once): batches pulled ahead stay queued between calls."""
+        if not isinstance(self.it, _InputThread):
+            self.it = _InputThread(self.it, depth)
         return self
 
     def __next__(self):
