@@ -260,6 +260,11 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
  * no FM term; its gradient rows dX use the same example blocks.                                                      */
 /* advance_step = 0: this launch leaves the beta powers / step counter alone because a later launch of the SAME step advances
  * them (models with two table sets: xdeepfm.py); 1 otherwise.                                                      */
+/* dst[0 .. nbytes) = src[0 .. nbytes) by a kernel (16-byte aligned, nbytes % 16 == 0); src may be pinned HOST memory (it is
+ * mapped into the device's address space): the captured windows of the streaming TRAIN path fetch their staged batches with
+ * this launch as their first graph node instead of a hipMemcpyAsync in front of the graph launch -- which made
+ * hipGraphLaunch hold its caller until the previous window had finished on the GPU.                                        */
+int rsx_copy_bytes(void* dst, const void* src, size_t nbytes, rsx_stream_t stream);
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
 /* The window sweep (nw > 0) applies its 1 + nw zero-gradient updates with packed square roots / divisions that are correctly
  * rounded on a restricted operand domain (csrc/adam_fast.h; elements outside it take the IEEE form).  Self-test of those forms

@@ -92,6 +92,7 @@ _SIGS = {
     "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
+    "rsx_copy_bytes": (_I, [_P, _P, C.c_size_t, _P]),
     "rsx_adam_fast_math_selftest": (_I, [_P, C.c_uint32, _I, _I, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),

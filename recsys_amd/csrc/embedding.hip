@@ -1183,3 +1183,24 @@ extern "C" int rsx_segsum_rows(const float* vals, const int32_t* perm, const int
   return segsum_impl(nullptr, nullptr, vals, nullptr, nullptr, perm, seg_off, uniq_row, nuniq, G, nullptr, 0, N, 1, K,
                      stride, null_row, partials_h, nullptr, stream);
 }
+
+// ---- staged host batches -> the step's static input buffers, as a KERNEL -----------------------------------------------------
+// The window graphs of the streaming TRAIN path (estimator.py _train_window_packed) read their 8 packed host batches (432 KB)
+// straight from the pinned staging buffer with this launch, captured as the graph's first node.  A hipMemcpyAsync in front of
+// the graph launch made hipGraphLaunch hold its calling thread until the copy had run, i.e. until the PREVIOUS window had
+// finished on the GPU (rocprofv3 --hip-runtime-trace: 499 us per launch instead of 24-39): the host could no longer stage
+// window w + 1 while window w computed.  Pinned host memory is mapped into the device's address space; 16-byte loads.
+__global__ __launch_bounds__(256) void copy_bytes_k(uint4* __restrict__ dst, const uint4* __restrict__ src, const size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int rsx_copy_bytes(void* dst, const void* src, size_t nbytes, rsx_stream_t stream) {
+  if (nbytes == 0) return RSX_OK;
+  if (!dst || !src || (nbytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return RSX_EINVAL;
+  const size_t n16 = nbytes >> 4;
+  const size_t blocks = (n16 + 255) / 256;
+  hipLaunchKernelGGL(copy_bytes_k, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, rsx_s(stream),
+                     static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}

@@ -22,6 +22,7 @@ from typing import Any, Callable, Dict, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from . import metrics as _metrics
 from .ops import AdamTF1, DenseArena, EmbeddingArena
 
@@ -260,8 +261,9 @@ class Estimator:
         self.store = VariableStore(self.config.device, self.config.seed, self.config.adam_mode)
         self._graphs = {}
         self._ring = {}        # pinned staging buffers for host batches (see _h2d)
-        self._copy_stream = None
-        self._overlap_h2d = os.environ.get("RSX_H2D_OVERLAP", "0") != "0"     # window inputs on a copy stream; default: in line
+        # captured instances of a streaming window that take turns (_train_window_packed): with 2 the training thread blocks
+        # on the GPU once per window (the instance it wants next finished only just now); 3 keep it a window ahead
+        self._window_sets = max(2, int(os.environ.get("RSX_WINDOW_SETS", "3")))
         self._restored = False
         self._log_t = None
         self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
@@ -553,18 +555,22 @@ class Estimator:
 
     # -- public API --------------------------------------------------------------------------
     def _train_window_packed(self, pbs, launcher=None):
-        """One optimizer window over len(pbs) host (or device) batches -> loss of the last step.  The window's static input
-        buffers are slices of ONE device allocation: host batches are memcpy'ed into one pinned staging buffer and go over in
-        ONE H2D copy per window (eight 54 KB copies cost the host ~10 us each and the copy engine a start-up each), in line on
-        the compute stream (a copy stream + two events measured 5 us per step SLOWER: 0.0749 vs 0.0696 ms, bench.py
-        --host_input), then ONE graph replay runs all of the window's steps.  Two captured instances of the window (each with
-        its own inputs and staging buffer) take turns, so that window w + 1 can be staged while window w is still queued.
-        launcher (Estimator.train): the copy + replay are handed to the launch thread; -> None (the loss is the launch's)."""
-        key = ("packedwin", len(pbs)) + pbs[0].key()
+        """One optimizer window over len(pbs) host (or device) batches -> loss of the last step: ONE graph replay.
+        Host batches are memcpy'ed into one pinned staging buffer, and the captured window's FIRST NODE is a kernel that
+        fetches that buffer into the window's static inputs (slices of one device allocation; csrc/embedding.hip
+        rsx_copy_bytes).  Tried before it: one hipMemcpyAsync per batch on a copy stream + two events per window (0.0786 ms
+        per DeepFM step, bench.py --host_input), one copy per window on the copy stream (0.0749), the same copy in line
+        (0.0696) -- but a hipMemcpyAsync in front of hipGraphLaunch makes the launch hold its caller until the copy has run,
+        i.e. until the previous window has finished on the GPU (499 us per launch instead of 24-39), and Estimator.train,
+        which has the next window's batches to fetch meanwhile, ran at 91-96 us per step with 165 us idle gaps between
+        windows.  Three captured instances of the window (each with its own inputs and staging buffer) take turns, so that
+        window w + 1 is staged while window w is queued or running.
+        launcher (Estimator.train): the replay is handed to the launch thread; -> None (the loss is the launch's result)."""
+        host = all(pb.flat.device.type == "cpu" for pb in pbs)
+        key = ("packedwin", len(pbs), host) + pbs[0].key()
         g = self._graphs.setdefault(key, {"warm": 0, "sets": [], "turn": 0})
-        if len(g["sets"]) == 2:
-            host = all(pb.flat.device.type == "cpu" for pb in pbs)
-            if host and not self._overlap_h2d:
+        if len(g["sets"]) == self._window_sets:
+            if host:
                 st = self._stage_window(g, pbs)
                 if launcher is not None:
                     launcher.submit(lambda: self._launch_staged(st))
@@ -573,31 +579,10 @@ class Estimator:
             if launcher is not None:
                 launcher.drain()
             st = g["sets"][g["turn"]]
-            g["turn"] ^= 1
-            cur = torch.cuda.current_stream()
-            if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream()
-            cs = self._copy_stream if self._overlap_h2d else cur
-            if host:
-                st["pin_ev"].synchronize()
-                stride, pin = st["stride"], st["pin_np"]
-                for i, pb in enumerate(pbs):
-                    np.copyto(pin[i * stride:i * stride + pb.nbytes], pb.flat.numpy())
-            if cs is not cur:
-                cs.wait_event(st["done"])          # the replay that last read this instance's inputs has finished
-            with torch.cuda.stream(cs):
-                if host:
-                    st["all"].copy_(st["pin"], non_blocking=True)
-                    st["pin_ev"].record(cs)
-                else:
-                    for sb, pb in zip(st["static"], pbs):
-                        self._h2d(sb, pb)
-                if cs is not cur:
-                    st["ready"].record(cs)
-            if cs is not cur:
-                cur.wait_event(st["ready"])
+            g["turn"] = (g["turn"] + 1) % len(g["sets"])
+            for sb, pb in zip(st["static"], pbs):          # device-resident batches: one D2D copy each, in stream order
+                self._h2d(sb, pb)
             st["graph"].replay()
-            st["done"].record(cur)
             return st["losses"][-1]
         if launcher is not None:
             launcher.drain()
@@ -606,19 +591,29 @@ class Estimator:
             g["warm"] += 1
             return self._train_window([pb.views() for pb in dev])[-1]
         stride = (dev[0].nbytes + 255) & ~255
-        st = {"ready": torch.cuda.Event(), "done": torch.cuda.Event(), "pin_ev": torch.cuda.Event(), "stride": stride,
-              "free": threading.Event(), "all": torch.empty(len(dev) * stride, dtype=torch.uint8, device=self.store.device)}
+        st = {"done": torch.cuda.Event(), "stride": stride, "free": threading.Event(),
+              "all": torch.empty(len(dev) * stride, dtype=torch.uint8, device=self.store.device)}
         st["free"].set()
-        st["pin"] = torch.empty(len(dev) * stride, dtype=torch.uint8).pin_memory()
-        st["pin_np"] = st["pin"].numpy()
         st["static"] = []
         for i, pb in enumerate(dev):
             sb = PackedBatch.__new__(PackedBatch)
             sb.layout, sb.nbytes, sb.flat = pb.layout, pb.nbytes, st["all"][i * stride:i * stride + pb.nbytes]
             sb.flat.copy_(pb.flat)
             st["static"].append(sb)
-        st["graph"], st["losses"] = self._capture(lambda: self._train_window([sb.views() for sb in st["static"]]))
-        st["graph"].replay()            # capture executes nothing: the static buffers already hold this window's batches
+        if host:
+            st["pin"] = torch.empty(len(dev) * stride, dtype=torch.uint8).pin_memory()
+            st["pin_np"] = st["pin"].numpy()
+            st["pin"].copy_(st["all"])  # (the staging buffer starts as this window's batches: the graph's first node reads it)
+            torch.cuda.synchronize()
+
+        def window():
+            if host:                    # first node: the staged batches, fetched from pinned host memory by a kernel
+                _lib.check(_lib.lib().rsx_copy_bytes(st["all"].data_ptr(), st["pin"].data_ptr(), st["all"].numel(),
+                                                     torch.cuda.current_stream().cuda_stream), "rsx_copy_bytes")
+            return self._train_window([sb.views() for sb in st["static"]])
+
+        st["graph"], st["losses"] = self._capture(window)
+        st["graph"].replay()            # capture executes nothing: the inputs already hold this window's batches
         st["done"].record(torch.cuda.current_stream())
         g["sets"].append(st)
         return st["losses"][-1]
@@ -626,21 +621,21 @@ class Estimator:
     def _stage_window(self, g, pbs):
         """Host half of a window (the training thread): the next instance's staging buffer <- the window's batches."""
         st = g["sets"][g["turn"]]
-        g["turn"] ^= 1
-        st["free"].wait()                  # the launch that last used this instance has queued its copy (and recorded pin_ev)
+        g["turn"] = (g["turn"] + 1) % len(g["sets"])
+        st["free"].wait()                  # the launch that last used this instance has been issued (and `done` recorded)
         st["free"].clear()
-        st["pin_ev"].synchronize()         # ... and the GPU has run it (two windows ago)
+        st["done"].synchronize()           # ... and the GPU has finished it (two windows ago): its first node read the buffer
         stride, pin = st["stride"], st["pin_np"]
         for i, pb in enumerate(pbs):       # (plain memcpys: torch's CPU copy_ of > 32 KB wakes its thread pool, ~0.4 ms)
             np.copyto(pin[i * stride:i * stride + pb.nbytes], pb.flat.numpy())
         return st
 
     def _launch_staged(self, st):
-        """Device half of a window (the launch thread, or in line): ONE H2D copy, ONE graph replay -> loss of the last step."""
-        st["all"].copy_(st["pin"], non_blocking=True)
-        st["pin_ev"].record()
-        st["free"].set()
+        """Device half of a window (the launch thread, or in line): ONE graph replay -- staged batches in, all steps -> loss of
+        the last step."""
         st["graph"].replay()
+        st["done"].record()
+        st["free"].set()
         return st["losses"][-1]
 
     def train(self, input_fn, steps=None, max_steps=None):

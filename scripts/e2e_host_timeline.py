@@ -27,11 +27,20 @@ with tempfile.TemporaryDirectory() as d:
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
               "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": 256}
     est = Estimator(deepfm.model_fn, None, params, RunConfig(device="cuda", seed=1, log_step_count_steps=1000000))
-    fn = lambda: ip.criteo_input_fn(files, 256, num_epochs=-1, need_shuffle=True, layout=layout, num_parallel=32)
+    workers = int(os.environ.get("WORKERS", "32"))
+    fn = lambda: ip.criteo_input_fn(files, 256, num_epochs=-1, need_shuffle=True, layout=layout, num_parallel=workers)
     est.train(fn, steps=304)
     torch.cuda.synchronize()
     K = est._window_len()
     it = iter(fn())
+    if os.environ.get("POOL"):            # no reader threads during the timed loop: a pool of batches fetched beforehand
+        pool = []
+        while len(pool) < 512:
+            h = next(it)
+            if h[1].shape[0] == 256:
+                pool.append(h)
+            it.close()
+        it = iter(pool[i % 512] for i in range(10 ** 9))
     waits = []
     orig = torch.cuda.Event.synchronize
 
@@ -41,6 +50,18 @@ with tempfile.TemporaryDirectory() as d:
         waits.append(time.perf_counter() - t)
 
     torch.cuda.Event.synchronize = timed_sync
+    gpu_ev = []
+    orig_launch = est._launch_staged
+
+    def timed_launch(st):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_launch(st)
+        e1.record()
+        gpu_ev.append((e0, e1))
+        return r
+
+    est._launch_staged = timed_launch
     T = {"read": 0.0, "pack": 0.0, "window": 0.0}
     nwin = 300
     torch.cuda.synchronize()
@@ -65,4 +86,13 @@ with tempfile.TemporaryDirectory() as d:
           "for the staging buffer %.1f), drained after %.1f us per window" %
           (K, t_host / nwin * 1e6, T["read"] / nwin * 1e6, T["pack"] / nwin * 1e6, T["window"] / nwin * 1e6,
            sum(waits) / nwin * 1e6, t_tot / nwin * 1e6))
-    it.close()
+    torch.cuda.Event.synchronize = orig
+    durs = [a.elapsed_time(b) * 1e3 for a, b in gpu_ev[20:]]
+    gaps = [gpu_ev[i][1].elapsed_time(gpu_ev[i + 1][0]) * 1e3 for i in range(20, len(gpu_ev) - 1)]
+    span = gpu_ev[0][0].elapsed_time(gpu_ev[-1][1]) * 1e3
+    print("GPU side: %d windows launched, first start -> last end %.1f us = %.1f us per window" % (len(gpu_ev), span, span / len(gpu_ev)))
+    print("GPU side: window durations mean %.1f us, p90 %.1f, the 6 longest %s" % (float(np.mean(durs)), float(np.percentile(durs, 90)), [int(x) for x in sorted(durs)[-6:]]))
+    print("GPU side: window %.1f us (median), idle between windows %.1f us (median; p90 %.1f; mean %.1f; the 6 longest: %s at windows %s)" %
+          (float(np.median(durs)), float(np.median(gaps)), float(np.percentile(gaps, 90)), float(np.mean(gaps)),
+           [int(x) for x in sorted(gaps)[-6:]], [int(i) + 20 for i in np.argsort(gaps)[-6:]]))
+    getattr(it, 'close', lambda: None)()
