@@ -13,8 +13,14 @@ done
 timeout 900 python scripts/kernel_roofline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r02_z_kernel_roofline_table.txt
 timeout 600 python scripts/ingest_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r02_z_ingest_bench.txt
 python scripts/window_sweep_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r02_z_window_sweep_time.txt
+timeout 600 python scripts/e2e_train_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r02_z_e2e_train_bench.txt
+timeout 300 python scripts/e2e_host_timeline.py 2>&1 | grep -v amdgpu.ids | tail -4 >> gpurun_out/r02_z_e2e_train_bench.txt
+timeout 300 python scripts/graph_launch_cost.py 2>&1 | grep -v amdgpu.ids | tail -3 >> gpurun_out/r02_z_e2e_train_bench.txt
+timeout 300 python scripts/ingest_layers.py 600000 32 2>&1 | grep -v amdgpu.ids > gpurun_out/r02_z_ingest_layers.txt
+timeout 600 python scripts/eval_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r02_z_eval_bench.txt
+timeout 300 python bench.py --host_input --steps 800 --warmup 96 --no_cpu_baseline 2>&1 | tail -1 > gpurun_out/r02_z_bench_host_input.json
 timeout 900 python bench.py 2>&1 | tail -1 > gpurun_out/r02_z_bench_default.json
 timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/r02_z_bench_steps20.json
 for f in deepfm fm dcn xdeepfm_f32 xdeepfm_bf16 din; do head -14 gpurun_out/r02_z_${f}_kernel_stats.txt | cut -c1-120; done
 cat gpurun_out/pmc_r02_z_FETCH_SIZE_deepfm.txt gpurun_out/pmc_r02_z_WRITE_SIZE_deepfm.txt | cut -c1-150
-cat gpurun_out/r02_z_window_sweep_time.txt; tail -12 gpurun_out/r02_z_ingest_bench.txt | cut -c1-150
+cat gpurun_out/r02_z_window_sweep_time.txt; tail -12 gpurun_out/r02_z_ingest_bench.txt | cut -c1-150; cat gpurun_out/r02_z_e2e_train_bench.txt gpurun_out/r02_z_ingest_layers.txt gpurun_out/r02_z_eval_bench.txt | cut -c1-220

@@ -77,7 +77,7 @@ for B in (256, 4096):
     dW, dB, dX, g = torch.empty_like(W), torch.empty_like(Bc), torch.empty_like(x0), torch.randn(B, 624, device=dev)
     op.forward(x0, W, Bc, None, want_xL=True)
     us = timeit(lambda: op.backward(x0, W, Bc, dW, dB, dX, False, dxL=g))
-    rec("cross_bwd_k + cross_reduce_k", "B=%d dim=624" % B, us, nbytes=B * 3 * 2496 + 4 * 3 * 624 * 4)
+    rec("cross_bwd4_k + cross_reduce_k", "B=%d dim=624" % B, us, nbytes=B * 3 * 2496 + 4 * 3 * 624 * 4)
 # CIN
 for (B, H, N) in ((256, 39, 128), (256, 128, 128)):
     X0 = torch.randn(B, 39, 16, device=dev) * 0.3; Xk = torch.randn(B, H, 16, device=dev) * 0.3

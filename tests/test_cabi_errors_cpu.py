@@ -147,3 +147,17 @@ def test_attention_envelope(L):
     assert L.rsx_din_valid_rows(None, 4, 10, P, P, None, None) == EINVAL
     assert L.rsx_din_valid_rows(P, 1 << 20, 1 << 10, P, P, None, None) == EUNSUPPORTED
     assert L.rsx_din_attn_bwd_workspace_floats(4, 10, 32, 80, 40) > 0
+
+
+def test_copy_and_selftest_entry_points_reject_bad_arguments(L):
+    """rsx_copy_bytes (the streaming windows' first graph node) moves whole 16-byte words between 16-byte aligned buffers."""
+    buf = (C.c_char * 64)()
+    a = C.addressof(buf)
+    a16 = (a + 15) & ~15
+    assert L.rsx_copy_bytes(None, a16, 16, None) == EINVAL
+    assert L.rsx_copy_bytes(a16, None, 16, None) == EINVAL
+    assert L.rsx_copy_bytes(a16, a16 + 16, 8, None) == EINVAL          # not a multiple of 16 bytes
+    assert L.rsx_copy_bytes(a16 + 4, a16 + 16, 16, None) == EINVAL     # misaligned destination
+    assert L.rsx_copy_bytes(a16, a16 + 20, 16, None) == EINVAL         # misaligned source
+    assert L.rsx_copy_bytes(a16, a16 + 16, 0, None) == OK              # nothing to do
+    assert L.rsx_adam_fast_math_selftest(None, 1, 1, 0, None) == EINVAL
