@@ -261,9 +261,9 @@ class Estimator:
         self.store = VariableStore(self.config.device, self.config.seed, self.config.adam_mode)
         self._graphs = {}
         self._ring = {}        # pinned staging buffers for host batches (see _h2d)
-        # captured instances of a streaming window that take turns (_train_window_packed): with 2 the training thread blocks
-        # on the GPU once per window (the instance it wants next finished only just now); 3 keep it a window ahead
-        self._window_sets = max(2, int(os.environ.get("RSX_WINDOW_SETS", "3")))
+        # captured instances of a streaming window that take turns (_train_window_packed): window w + 1 is staged into the
+        # other instance while window w is queued or running (3 measured the same as 2: the stream is GPU-bound)
+        self._window_sets = max(2, int(os.environ.get("RSX_WINDOW_SETS", "2")))
         self._restored = False
         self._log_t = None
         self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
@@ -563,7 +563,7 @@ class Estimator:
         (0.0696) -- but a hipMemcpyAsync in front of hipGraphLaunch makes the launch hold its caller until the copy has run,
         i.e. until the previous window has finished on the GPU (499 us per launch instead of 24-39), and Estimator.train,
         which has the next window's batches to fetch meanwhile, ran at 91-96 us per step with 165 us idle gaps between
-        windows.  Three captured instances of the window (each with its own inputs and staging buffer) take turns, so that
+        windows.  Two captured instances of the window (each with its own inputs and staging buffer) take turns, so that
         window w + 1 is staged while window w is queued or running.
         launcher (Estimator.train): the replay is handed to the launch thread; -> None (the loss is the launch's result)."""
         host = all(pb.flat.device.type == "cpu" for pb in pbs)
@@ -644,8 +644,11 @@ class Estimator:
             depth = max(16, 2 * self._window_len())
             # (an iterator that outlives this call keeps its thread and whatever the thread has pulled ahead)
             it = it.threaded(depth) if isinstance(it, _Resumable) else _InputThread(it, depth)
-        launcher = None          # thread that issues the staged windows (single replica, HIP graphs on)
-        if self._use_graph() and self.store.dp is None and os.environ.get("RSX_LAUNCH_THREAD", "1") != "0":
+        # optional thread that issues the staged windows (single replica, HIP graphs on).  Off by default: a window launch
+        # costs the training thread 22-45 us per 8 steps (scripts/graph_launch_cost.py) and the stream is GPU-bound without
+        # it; with a slow input pipeline it takes the launch off the fetching thread (e2e A/B: within the box-to-box noise)
+        launcher = None
+        if self._use_graph() and self.store.dp is None and os.environ.get("RSX_LAUNCH_THREAD", "0") != "0":
             launcher = _LaunchThread(self.config.device)
         try:
             self._train_loop(it, steps, max_steps, launcher)
@@ -855,12 +858,11 @@ class Estimator:
 
 
 class _LaunchThread:
-    """Issues the staged windows of Estimator.train (ONE H2D copy + ONE graph replay each) in order, on a thread of its own.
-    Why: hipGraphLaunch keeps its caller for almost as long as the window runs on the GPU (rocprofv3 --hip-runtime-trace:
-    499 us for a DeepFM window of 8 steps / 58 kernel nodes that executes in 560 us) -- with everything on one thread the
-    ~200 us it takes to fetch and stage the next window's batches left the GPU idle for that long between windows (165 us
-    gaps in the kernel trace, 91-96 us per step against 70 for the same windows launched back to back).  torch releases the
-    GIL inside replay(); the training thread stages window w + 1 meanwhile."""
+    """Issues the staged windows of Estimator.train (ONE graph replay each) in order, on a thread of its own (opt-in,
+    RSX_LAUNCH_THREAD=1): torch releases the GIL inside replay(), so the training thread fetches and stages window w + 1
+    meanwhile.  (It was written when a rocprofv3 --hip-runtime-trace showed hipGraphLaunch holding its caller for 499 us per
+    window -- which turned out to be the profiler's own interception of the graph's 58 dispatches; unprofiled the launch
+    costs 22-45 us, and the stream is GPU-bound either way.)"""
 
     def __init__(self, device):
         self._q = queue.Queue(maxsize=1)
