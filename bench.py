@@ -259,7 +259,7 @@ def main():
         adam_ms += e0.elapsed_time(e1)
     adam_ms /= reps * per
     roof = None
-    wk = est._window_len() if (dp is None and emu is None and not a.no_graph and not a.no_overlap) else 1
+    wk = est._window_len() if (not a.no_graph and not a.no_overlap) else 1      # (data-parallel runs use windows too)
 
     def pmc_traffic(kernel):
         """PMC-derived HBM bytes per launch: collected offline (scripts/pmc.sh, separate --pmc passes) and committed."""
@@ -349,7 +349,8 @@ def main():
                                                "din": "Amazon-Electronics-shaped hist_len=100 K=32"}[a.model], B,
                                      a.adam_mode, not a.no_graph,
                                      ("steps_per_graph=%d" % a.steps_per_graph) if (dp is None and emu is None) else
-                                     ("per-step graph segments, RCCL collectives %s" %
+                                     ("one graph-segment chain per optimizer window (one ids all-gather per window, one gradient "
+                                      "all-gather per step), RCCL collectives %s" %
                                       ("captured" if os.environ.get("RSX_DP_CAPTURE") == "1" else "eager between segments"))),
                       "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5),
                       "adam_window": wk,
