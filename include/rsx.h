@@ -262,8 +262,8 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
  * them (models with two table sets: xdeepfm.py); 1 otherwise.                                                      */
 /* dst[0 .. nbytes) = src[0 .. nbytes) by a kernel (16-byte aligned, nbytes % 16 == 0); src may be pinned HOST memory (it is
  * mapped into the device's address space): the captured windows of the streaming TRAIN path fetch their staged batches with
- * this launch as their first graph node instead of a hipMemcpyAsync in front of the graph launch -- which made
- * hipGraphLaunch hold its caller until the previous window had finished on the GPU.                                        */
+ * this launch as their first graph node, so that a window is one graph launch with no hipMemcpyAsync / copy-engine start-up /
+ * cross-stream event in front of it.                                                                                      */
 int rsx_copy_bytes(void* dst, const void* src, size_t nbytes, rsx_stream_t stream);
 int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream);
 /* The window sweep (nw > 0) applies its 1 + nw zero-gradient updates with packed square roots / divisions that are correctly

@@ -558,14 +558,12 @@ class Estimator:
         """One optimizer window over len(pbs) host (or device) batches -> loss of the last step: ONE graph replay.
         Host batches are memcpy'ed into one pinned staging buffer, and the captured window's FIRST NODE is a kernel that
         fetches that buffer into the window's static inputs (slices of one device allocation; csrc/embedding.hip
-        rsx_copy_bytes).  Tried before it: one hipMemcpyAsync per batch on a copy stream + two events per window (0.0786 ms
-        per DeepFM step, bench.py --host_input), one copy per window on the copy stream (0.0749), the same copy in line
-        (0.0696) -- but a hipMemcpyAsync in front of hipGraphLaunch makes the launch hold its caller until the copy has run,
-        i.e. until the previous window has finished on the GPU (499 us per launch instead of 24-39), and Estimator.train,
-        which has the next window's batches to fetch meanwhile, ran at 91-96 us per step with 165 us idle gaps between
-        windows.  Two captured instances of the window (each with its own inputs and staging buffer) take turns, so that
-        window w + 1 is staged while window w is queued or running.
-        launcher (Estimator.train): the replay is handed to the launch thread; -> None (the loss is the launch's result)."""
+        rsx_copy_bytes), so that a window is one hipGraphLaunch (22-45 us of host time) and nothing else on the stream.
+        Measured before it (ms per DeepFM step, bench.py --host_input, unprofiled): one hipMemcpyAsync per batch on a copy
+        stream + two events per window 0.0786, one copy per window on the copy stream 0.0749, the same copy in line 0.0696,
+        the kernel node 0.0680 (resident batches: 0.0655).  Two captured instances of the window (each with its own inputs
+        and staging buffer) take turns, so that window w + 1 is staged while window w is queued or running.
+        launcher (Estimator.train, opt-in): the replay is handed to the launch thread; -> None (the loss is the launch's)."""
         host = all(pb.flat.device.type == "cpu" for pb in pbs)
         key = ("packedwin", len(pbs), host) + pbs[0].key()
         g = self._graphs.setdefault(key, {"warm": 0, "sets": [], "turn": 0})
@@ -925,12 +923,10 @@ class _LaunchThread:
 
 
 class _InputThread:
-    """Pulls batches from an input iterator on a thread of its own, a bounded number ahead of the consumer.
-    Why: launching a captured window (hipGraphLaunch) keeps the calling thread for almost as long as the window runs on the
-    GPU -- the runtime enqueues the graph's ~60 kernel nodes one by one, ~8 us each (rocprofv3 --hip-runtime-trace: 499 us
-    for a DeepFM window of 8 steps that executes in 560) -- so whatever else the training thread does per window (fetching 8
-    batches from the reader, wrapping them: ~200 us) used to leave the GPU idle for that long between windows.  torch releases
-    the GIL inside replay(), the reader's `next` is a C call: this thread's work fits into the launch."""
+    """Pulls batches from an input iterator on a thread of its own, a bounded number ahead of the consumer (opt-in,
+    RSX_INPUT_THREAD=1).  The reader's `next` is a C call that releases the GIL, but the generator code around it and the
+    training thread's own Python share the GIL: end to end it measured within the noise of the default (the C++ reader already
+    runs `prefetch` batches ahead on its own threads), so it stays a knob for input_fns that do real Python work per batch."""
 
     _END = object()
 
