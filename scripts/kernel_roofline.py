@@ -4,11 +4,12 @@ BASELINE sizes and at larger batches, against its bounding roofline (HBM 8 TB/s 
 Algorithmic bytes / flops follow SURVEY.md section 8d.  Output: a text table (commit under profiles/)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from recsys_amd import _lib
 from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
 from recsys_amd.ops import AdamTF1, CinLayerFn, CrossLayers, DinPoolFn, EmbeddingArena, _ptr, _stream, check, lib
-from tests.parity_util import synth_ids
+from kernel_roofline_util import synth_ids
 
 HBM, MFMA32 = 8000.0, 157.3
 dev = "cuda"

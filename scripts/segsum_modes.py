@@ -4,12 +4,11 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-from oracle import criteo
 from recsys_amd.ops import AdamTF1, EmbeddingArena
 from scripts.kernel_roofline_util import timeit
-from tests.parity_util import synth_ids
+from kernel_roofline_util import criteo_row_off, synth_ids
 
-row_off = criteo.row_offsets()
+row_off = criteo_row_off()
 rng = np.random.default_rng(0)
 for B in (512, 1024, 2048, 4096):
     ids = torch.from_numpy(synth_ids(rng, B, row_off)).cuda()

@@ -4,12 +4,11 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-from oracle import criteo
 from recsys_amd.ops import EmbeddingArena
-from tests.parity_util import synth_ids
+from kernel_roofline_util import criteo_row_off, synth_ids
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-row_off = criteo.row_offsets()
+row_off = criteo_row_off()
 rng = np.random.default_rng(0)
 a = EmbeddingArena(row_off, 16, B, "cuda", with_w1=True)
 a.tables.normal_(); a.w1.normal_()

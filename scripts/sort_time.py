@@ -1,12 +1,12 @@
 """GPU box: field-sort timings, LDS path (one workgroup per field) vs the multi-workgroup global radix path."""
+import os
 import sys
 import numpy as np
 import torch
 sys.path.insert(0, '.')
-from oracle import criteo
 from recsys_amd.ops import EmbeddingArena
-from tests.parity_util import synth_ids
-row_off = criteo.row_offsets()
+from kernel_roofline_util import criteo_row_off, synth_ids
+row_off = criteo_row_off()
 rng = np.random.default_rng(0)
 for B in (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
     res = []

@@ -1,14 +1,15 @@
 """GPU box: stand-alone time of the untouched-row sweep (COLD kinds, DeepFM-size state) for windows of 1..4 steps."""
+import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
-from oracle import criteo
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from recsys_amd import _lib
 from recsys_amd.ops import AdamTF1, EmbeddingArena
-from tests.parity_util import synth_ids
+from kernel_roofline_util import criteo_row_off, synth_ids
 
-row_off = criteo.row_offsets()
+row_off = criteo_row_off()
 a = EmbeddingArena(row_off, 16, 256, "cuda", with_w1=True, w1_field_mask=(1 << 39) - 1)
 with torch.no_grad():
     a.tables.normal_(); a.w1.normal_()
