@@ -57,10 +57,12 @@ ADAM_STATE_WORDS = 4 + 32 * 32        # include/rsx.h RSX_ADAM_STATE_WORDS
 
 def default_adam_window(capacity):
     """Steps per optimizer window (include/rsx.h rsx_adam_window) for a sort workspace of `capacity` examples: the one
-    sweep per window costs ~56 us + 4.5 us per step (DeepFM-size state), every step walks the other steps' unique-row lists
-    (their length grows with the batch).  Measured on MI355X: 8 steps up to batch 1024, 4 above (dcn.py at 4096: the lists
-    of 3 other steps cost 22 us per step)."""
-    return ADAM_WINDOW_MAX if capacity <= 1024 else 4
+    sweep per window costs 57-79 us for 1-8 steps (DeepFM-size state), every step walks the other steps' unique-row lists
+    (their length grows with the batch).  Measured on MI355X: 8 steps up to batch 1024, 4 above (dcn.py at 4096 with the
+    packed sweep: 0.229 / 0.231 / 0.239 ms per step with windows of 4 / 6 / 8, scripts/gpu_round2_ax.sh)."""
+    if capacity <= 1024:
+        return ADAM_WINDOW_MAX
+    return max(1, min(ADAM_WINDOW_MAX, int(os.environ.get("RSX_ADAM_WINDOW_LARGE", "4"))))     # (A/B knob for the large-batch choice)
 
 
 class AdamWindow(C.Structure):
