@@ -923,12 +923,19 @@ __global__ __launch_bounds__(1024) void tower_reduce_partials_k(double* __restri
   double s = 0.0;
   if (c < N2) {
     int r = r0;
-    for (; r + 8 <= r1; r += 8) {
-      double t[8];
+    for (; r + 16 <= r1; r += 16) {      // (batch 4 096: exactly one such batch per wave -- one memory round trip)
+      double t[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
+      for (int u = 0; u < 16; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += t[u];
+      for (int u = 0; u < 16; ++u) s += t[u];
+    }
+    for (; r + 4 <= r1; r += 4) {
+      double t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += t[u];
     }
     for (; r < r1; ++r) s += st[(size_t)r * N2 + c];
   }
