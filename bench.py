@@ -12,7 +12,14 @@ Prints ONE JSON line (rank 0).  Extra objects:
                   default: include/rsx.h rsx_adam_window) that is adam_window_k, ONE pass over the optimizer state per
                   window of k steps: bytes of the pass / mean launch duration, HIP events on the launch stream;
                   `single_step_sweep` = adam_multi_k, the one-step sweep every non-windowed path runs.
-                  step_achieved / step_frac: a step-by-step TF-1 run's bytes (345 MB) over the measured STEP time.
+                  Step-level fractions, named for what they divide: tf1_equivalent_step_frac = the bytes a
+                  step-by-step TF-1 run has to move (345 MB) / measured step time / peak; moved_bytes_step_frac = the bytes
+                  THIS path moves per step (one window pass / window length + the model's per-example traffic) / step time /
+                  peak -- the honest traffic fraction of the latency-bound step.
+  configs      -- (N = 1) the other BASELINE.json configs timed in the same process, a few seconds each: fm bs 256,
+                  dcn bs 4096, xdeepfm fp32 and bf16-CIN bs 256, din bs 1024: ms_per_step, examples_per_sec, the dominant
+                  kernel by name (rocprofv3 tables under profiles/) and the same two step-level fractions (+ the MFMA
+                  fraction of the CIN flops for xdeepfm).
   cpu_baseline -- the same step on PyTorch-CPU fp32 with every host core (oracle/torch_ref.py; N=1, rank 0 only).
 """
 import argparse
@@ -52,6 +59,8 @@ def parse():
                    "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
     p.add_argument("--no_overlap", action="store_true", help="profiling aid: plain path (stand-alone sort, segment-sum, ONE full "
                    "optimizer sweep) instead of sweep slices riding in the tower launches -- shows every kernel's own duration")
+    p.add_argument("--no_configs", action="store_true", help="skip the `configs` list (the other BASELINE configs)")
+    p.add_argument("--config_steps", type=int, default=320, help="timed steps per entry of the `configs` list (x 3 repeats)")
     p.add_argument("--steps_per_graph", type=int, default=16, help="training steps captured per HIP graph (1: per-step "
                    "graph fed by one D2D copy of the batch)")
     return p.parse_args()
@@ -118,52 +127,75 @@ def cpu_baseline(batches, layout, seconds):
                       "TensorFlow itself is not installable here" % (B, best_t, host_cores, w_e, r_e, w_l, r_l)}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
-    from recsys_amd import build as _build
-    from recsys_amd import dist
-    dp = None
-    if world > 1 or os.environ.get("RSX_FORCE_DIST") == "1":
-        dist.init_process_group()            # nccl (= RCCL); RSX_DIST_BACKEND=gloo lets several ranks share ONE GPU (smoke runs)
-        dp = dist.DataParallel()
-    if rank == 0:
-        _build.build(verbose=False)          # no-op when the in-tree librsx.so is current
-    if dp is not None:
-        dp.barrier()                         # the other ranks load the library only after rank 0's build check
-    from recsys_amd import deepfm, synthetic
-    from recsys_amd.estimator import Estimator, RunConfig
-    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(dev)
-    emu = None
-    if a.emulate_world > 1 and dp is None:
-        emu = dist.EmulatedDataParallel(a.emulate_world)
+WORKLOADS = {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16", "dcn": "Criteo-39 d=16 3 cross layers DNN 100-100",
+             "xdeepfm": "Criteo-39 d=16 CIN 128,128 DNN 100-100", "din": "Amazon-Electronics-shaped hist_len=100 K=32"}
+# the launch that takes the largest share of the step in the committed rocprofv3 tables (profiles/r03_*_kernel_stats.txt)
+DOMINANT = {"deepfm": "segsum_adam_k (scatter + touched-row Adam; latency-bound) / adam_window_k per window",
+            "fm": "segsum_adam_k / adam_window_k per window", "dcn": "tower_bwd_k<true> (fp32 MFMA dW/dX tiles at bs 4096)",
+            "xdeepfm": "cin_bwd_dw_k / cin_bwd_dx2_k (fp32 MFMA)", "xdeepfm_bf16": "cin_bwd_dw_bf16_k (bf16 MFMA)",
+            "din": "din_attn_bwd_k (fp32 MFMA attention MLP backward)"}
 
-    from recsys_amd import dcn, din, fm, xdeepfm
-    from recsys_amd.estimator import PackedBatch
-    B = a.batch_size
-    if a.model != "deepfm" and a.batch_size == 256:
-        B = {"dcn": 4096, "din": 1024}.get(a.model, 256)
-    linear = {"deepfm": "indicator_all", "fm": "indicator_all", "dcn": "numeric", "xdeepfm": "numeric+indicator"}.get(a.model)
+
+def per_example_bytes(model):
+    """Algorithmic HBM bytes per example and step outside the optimizer sweep: gather 5 148 B +
+    scatter 5 148 B per Criteo example (x 2 table sets for xdeepfm), + 2 x 2 x 2 496 B for dcn's cross layers (fwd, bwd),
+    DIN pool 27 456 B fwd + the same backward."""
+    return {"deepfm": 2 * 5148, "fm": 2 * 5148, "dcn": 2 * 5148 + 4 * 2496, "xdeepfm": 4 * 5148, "din": 2 * 27456}[model]
+
+
+def sweep_bytes(est, wk):
+    """(tf1_equivalent bytes per step, bytes of ONE window pass): 24 B per table / first-order element, 32 B per dense
+    element; a window pass adds the wk slot maps (4 B per row each)."""
+    from recsys_amd.ops import EmbeddingArena
+    store = est.store
+    segs = store.adam_segments()
+    n_sparse = sum(int(sg["n"]) * int(sg.get("d", 1) or 1) for sg in segs if sg["kind"] in (1, 2))
+    alg = 24 * n_sparse + 32 * store.dense.n
+    arenas = [x for x in store.embeddings.values() if isinstance(x, EmbeddingArena)]
+    rows = sum(int(ar.R) for ar in arenas if getattr(ar, "_sort_owner", None) is None)
+    return alg, 24 * n_sparse + 4 * wk * rows, n_sparse, arenas
+
+
+def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
+    alg, pass_bytes, _, arenas = sweep_bytes(est, wk)
+    windowed = wk > 1 and bool(arenas)
+    moved = (pass_bytes / wk if windowed else alg) + B * per_example_bytes(model)
+    out = {"tf1_equivalent_step_frac": round(alg / (ms_per_step * 1e-3) / 8e12, 4),
+           "moved_bytes_step_frac": round(moved / (ms_per_step * 1e-3) / 8e12, 4),
+           "moved_bytes_per_step": int(moved), "tf1_equivalent_bytes_per_step": int(alg)}
+    if model == "xdeepfm":
+        flops = 3 * 2 * B * 16 * (39 * 39 * 128 + 39 * 128 * 128)          # SURVEY 8(d): fwd x 3 with backward
+        peak = 2.5e15 if cin_bf16 else 157.3e12
+        out["cin_mfma_step_frac"] = round(flops / (ms_per_step * 1e-3) / peak, 4)
+        out["cin_flops_per_step"] = flops
+        out["mfma_peak"] = "2.5 PF dense bf16" if cin_bf16 else "157.3 TF fp32"
+    return out
+
+
+def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmup, repeats):
+    """Builds the Estimator of one BASELINE config over HBM-resident synthetic batches, runs `warmup` untimed steps (graph
+    capture included) and `repeats` timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize."""
+    from recsys_amd import dcn, deepfm, din, fm, synthetic, xdeepfm
+    from recsys_amd.estimator import Estimator, PackedBatch, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    B = batch_size
+    if model != "deepfm" and batch_size == 256:
+        B = {"dcn": 4096, "din": 1024}.get(model, 256)
+    linear = {"deepfm": "indicator_all", "fm": "indicator_all", "dcn": "numeric", "xdeepfm": "numeric+indicator"}.get(model)
     lin, emb = build_feature_columns(16, linear) if linear else (None, None)
-    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if a.model == "din" else 16,
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if model == "din" else 16,
               "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
-              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(a.model), "cin_bf16": a.cin_bf16}
+              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(model), "cin_bf16": cin_bf16}
     if a.no_overlap:
         params["overlap_adam"] = False
-    mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[a.model]
+    mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[model]
     cfg = RunConfig(use_hip_graph=not a.no_graph, adam_mode=a.adam_mode, device=str(dev), seed=1234)
     est = Estimator(mfn, None, params, cfg)
     if dp is not None or emu is not None:
         est.store.dp = dp or emu
         est.dist = dp or emu
     layout = CriteoLayout.from_columns(emb) if emb else None
-    if a.model == "din":
+    if model == "din":
         rng = np.random.default_rng(synthetic.SEED + rank)
         raw = [synthetic.din_batch(rng, B) for _ in range(a.n_batches)]
         host = None
@@ -172,7 +204,7 @@ def main():
     else:
         host = synthetic.criteo_id_batches(layout, a.n_batches, B, seed=synthetic.SEED + rank)
         # one packed HBM-resident buffer per batch (ids [+ log-values] + labels): no per-step input copy
-        feats = [PackedBatch({"ids": i, "cont_log": c} if a.model == "xdeepfm" else {"ids": i}, y, device=dev) for i, y, c in host]
+        feats = [PackedBatch({"ids": i, "cont_log": c} if model == "xdeepfm" else {"ids": i}, y, device=dev) for i, y, c in host]
     # variables are created on the first call; then W untimed warm-up steps (includes graph capture)
     with torch.no_grad():
         est._call_model_fn(feats[0].views()[0], None, "infer")
@@ -197,11 +229,11 @@ def main():
             loss = est._train_step(feats[s % len(feats)])
         return loss
 
-    run(a.warmup)
+    run(warmup)
     if host_pbs is None and a.steps_per_graph > 1:
         # every HIP graph the timed schedule replays is captured HERE (capturing executes nothing), so the timed
         # region below is pure replay whatever `steps % steps_per_graph` is
-        est.prepare_resident(feats, a.steps, a.steps_per_graph)
+        est.prepare_resident(feats, steps, a.steps_per_graph)
 
     def sync():
         torch.cuda.synchronize()
@@ -213,10 +245,10 @@ def main():
     # region is repeated `--repeats` times back to back and the MEDIAN repeat is reported (a 20-step region is 2 ms:
     # one repeat is at the mercy of a single clock ramp or host hiccup).  All repeats are listed in config.
     dts = []
-    for _ in range(max(1, a.repeats)):
+    for _ in range(max(1, repeats)):
         sync()
         t0 = time.perf_counter()
-        loss = run(a.steps)
+        loss = run(steps)
         torch.cuda.synchronize()
         if dp is not None:
             dp.barrier()
@@ -228,7 +260,64 @@ def main():
             dt = float(t.item())
         dts.append(dt)
     dt = sorted(dts)[len(dts) // 2]
-    final_loss = float(loss)
+    return {"est": est, "B": B, "dt": dt, "dts": dts, "final_loss": float(loss), "host": host, "layout": layout, "feats": feats}
+
+
+def other_configs(a, rank, dev):
+    """The remaining BASELINE.json configs, each timed in this process: `config_steps` steps x 3 repeats after a warm-up
+    that includes every graph capture (median repeat)."""
+    import gc
+    out = []
+    for model, bf16 in (("fm", False), ("dcn", False), ("xdeepfm", False), ("xdeepfm", True), ("din", False)):
+        if model == a.model and bf16 == a.cin_bf16:
+            continue
+        steps = a.config_steps if model != "din" else max(64, a.config_steps // 2)
+        try:
+            t = time_config(a, model, 256, bf16, None, None, rank, dev, steps, 64, 3)
+        except Exception as e:                                   # a config that fails must not take the headline line with it
+            out.append({"workload": "%s.py%s" % (model, " --cin_bf16" if bf16 else ""), "error": repr(e)[:300]})
+            continue
+        ms = t["dt"] / steps * 1e3
+        wk = t["est"]._window_len() if (not a.no_graph and not a.no_overlap) else 1
+        e = {"workload": "%s.py %s bs=%d%s, full train step (fwd+bwd+TF1 Adam), adam_mode=%s" %
+                         (model, WORKLOADS[model], t["B"], ", bf16 CIN operands / f32 accumulate" if bf16 else "", a.adam_mode),
+             "dtype": "f32" if not bf16 else "bf16 CIN operands / f32 accumulate, f32 elsewhere",
+             "ms_per_step": round(ms, 5), "examples_per_sec": round(t["B"] * steps / t["dt"], 1), "steps": steps,
+             "timed_repeats_ms_per_step": [round(x / steps * 1e3, 5) for x in t["dts"]], "adam_window": wk,
+             "final_loss": round(t["final_loss"], 5), "dominant_kernel": DOMINANT[model + ("_bf16" if bf16 else "")]}
+        e.update(step_fractions(t["est"], model, t["B"], ms, wk, bf16))
+        out.append(e)
+        del t
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    from recsys_amd import build as _build
+    from recsys_amd import dist
+    dp = None
+    if world > 1 or os.environ.get("RSX_FORCE_DIST") == "1":
+        dist.init_process_group()            # nccl (= RCCL); RSX_DIST_BACKEND=gloo lets several ranks share ONE GPU (smoke runs)
+        dp = dist.DataParallel()
+    if rank == 0:
+        _build.build(verbose=False)          # no-op when the in-tree librsx.so is current
+    if dp is not None:
+        dp.barrier()                         # the other ranks load the library only after rank 0's build check
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    emu = None
+    if a.emulate_world > 1 and dp is None:
+        emu = dist.EmulatedDataParallel(a.emulate_world)
+
+    t = time_config(a, a.model, a.batch_size, a.cin_bf16, dp, emu, rank, dev, a.steps, a.warmup, a.repeats)
+    est, B, dt, dts, final_loss, host, layout = t["est"], t["B"], t["dt"], t["dts"], t["final_loss"], t["host"], t["layout"]
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
     store = est.store
@@ -322,15 +411,17 @@ def main():
                     "tf1_equivalent_GBps": round(wk * alg_bytes / (win_ms * 1e-3) / 1e9, 1),
                     "single_step_sweep": single,
                     # the whole step against the bytes a step-by-step TF-1 run has to move (345 MB each)
-                    "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / 8000.0, 4),
-                    "step_floor_ms": round(pass_bytes / wk / 8e12 * 1e3, 5)}
+                    "tf1_equivalent_step_GBps": round(step_ach, 1), "step_floor_ms": round(pass_bytes / wk / 8e12 * 1e3, 5)}
         else:
             # step-level figure beside the stand-alone kernel: in the timed step the sweep does not run as adam_multi_k
             # but rides, slice by slice, in the tower / head / scatter launches (same per-workgroup code); the bytes it has
-            # to move per step are the same, so `step_achieved` = those bytes / the measured step time.
-            roof = dict(single, bound="hbm", peak=8000.0, unit="GB/s", step_achieved=round(step_ach, 1),
-                        step_frac=round(step_ach / 8000.0, 4), step_floor_ms=round(alg_bytes / 8e12 * 1e3, 5))
+            # to move per step are the same, so `tf1_equivalent_step_GBps` = those bytes / the measured step time.
+            roof = dict(single, bound="hbm", peak=8000.0, unit="GB/s", tf1_equivalent_step_GBps=round(step_ach, 1),
+                        step_floor_ms=round(alg_bytes / 8e12 * 1e3, 5))
 
+    if roof is not None:
+        # step-level fractions, named for what they divide (see the module docstring)
+        roof.update(step_fractions(est, a.model, B, dt / a.steps * 1e3, wk, a.cin_bf16))
     if dp is not None:
         dp.barrier()
         torch.distributed.destroy_process_group()
@@ -343,10 +434,7 @@ def main():
            "dtype": "f32" if not (a.cin_bf16 and a.model == "xdeepfm") else "bf16 CIN operands / f32 accumulate, f32 elsewhere (max |dlogit| vs f32 path: see DESIGN.md)", "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
            "config": {"workload": "%s.py %s bs=%d/replica, full train step "
                                   "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, %s"
-                                  % (a.model, {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16",
-                                               "dcn": "Criteo-39 d=16 3 cross layers DNN 100-100",
-                                               "xdeepfm": "Criteo-39 d=16 CIN 128,128 DNN 100-100",
-                                               "din": "Amazon-Electronics-shaped hist_len=100 K=32"}[a.model], B,
+                                  % (a.model, WORKLOADS[a.model], B,
                                      a.adam_mode, not a.no_graph,
                                      ("steps_per_graph=%d" % a.steps_per_graph) if (dp is None and emu is None) else
                                      ("one graph-segment chain per optimizer window (one ids all-gather per window, one gradient "
@@ -356,6 +444,9 @@ def main():
                       "adam_window": wk,
                       "timed_repeats_ms_per_step": [round(x / a.steps * 1e3, 5) for x in dts], "reported": "median repeat"},
            "roofline": roof}
+    if N == 1 and emu is None and not a.no_configs and a.model == "deepfm" and not a.host_input and a.adam_mode == "tf1_dense":
+        del t, est, store
+        out["configs"] = other_configs(a, rank, dev)
     if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":
         out["cpu_baseline"] = cpu_baseline(host, layout, a.cpu_seconds)
     print(json.dumps(out), flush=True)
