@@ -8,18 +8,31 @@ deepfm/deepfm.py:41,46): `string_to_hash_bucket_fast` =
 The algorithm lives in a third-party dependency that is absent from
 /root/reference: TensorFlow 1.13/1.14 (unpinned by the reference) which
 vendors google/farmhash (`farmhashna::Hash64`).  This file restates the
-published FarmHash algorithm.  Pinned by the KATs 'a','b','c','d' from upstream
-TF's string_to_hash_bucket_op_test, the empty string
-(= k2), and the usage example of upstream TF's documentation,
-``to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2]``, whose
-strings take the 4-7-byte and the 8-16-byte branches (bucket values only; every
-8-hex-character Criteo value takes the 8-16-byte branch).  The google/farmhash
-self-test table (farmhashna 64-bit outputs over its generated data buffer)
-could NOT be reproduced offline -- neither the table nor its generator is on
-this image and there is no network -- so the 17-32, 33-64 and > 64-byte branches
-are pinned only by two independently written implementations (this file and
-recsys_amd/csrc/host_ingest.cpp) agreeing on thousands of random strings
-(tests/test_cabi_cpu.py).  No Criteo feature value reaches those branches.
+published FarmHash algorithm.
+
+What pins each length branch (tests/test_oracle_kats.py, tests/test_hash_external_cpu.py):
+
+  branch        external known answers                                        in-repo cross-check
+  0-16 bytes    upstream TF's string_to_hash_bucket_op_test ('a','b','c','d'), 10^6 random strings,
+                the empty string (= k2), TF's documentation example (mod 3),  C++ product == this file
+                AND Google's own CityHash64 (abseil, as shipped inside
+                pyarrow's libarrow_compute.so on this image): 481 committed
+                vectors (tests/golden/cityhash_abseil_kats.json) + 10^6 live
+  17-32 bytes   the same abseil CityHash64 vectors / live run                 same
+  33-64 bytes   NONE                                                           same (digest committed)
+  > 64 bytes    NONE                                                           same (digest committed)
+
+CityHash64 v1.1 and farmhashna::Hash64 are the same function up to 32 bytes
+(HashLen0to16 and HashLen17to32 are shared verbatim) and different functions
+beyond (FarmHash redesigned HashLen33to64 and the long loop) -- observed here
+too: 6 602 of 6 602 random strings of <= 32 bytes agree with abseil, none of
+the longer ones does.  The 0-32 range holds every value the reference's
+pipelines hash: 8-hex-character Criteo categoricals (8-16 branch), the 'NULL'
+default (4-7), int64 ids as decimal strings (<= 20 characters).  The
+google/farmhash self-test table for the longer branches could NOT be reproduced
+offline (neither the table nor its generator is on this image): those two
+branches rest on two independently written implementations (this file and
+recsys_amd/csrc/host_ingest.cpp) agreeing on 10^6 random strings.
 
 Test infrastructure only (see oracle/__init__.py).
 """

@@ -134,7 +134,6 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   if (s.kind == RSX_ADAM_TABLE_TF1 || s.kind == RSX_ADAM_TABLE_TF1_COLD) {
     const bool cold_only = s.kind == RSX_ADAM_TABLE_TF1_COLD;   // touched rows are left to the TABLE_ROWS launch
@@ -157,13 +156,13 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         float4 var = var4[e], m = m4[e], v = v4[e];
 #endif
         const bool has = sl >= 0;
-        const float4 g = has ? G4[(long long)sl * lpr + q] : z4;
+        const float4 g = has ? G4[(long long)sl * lpr + q] : F4Z;
         F4_APPLY(adam_sparse1, var, m, v, g, has, h);
 #pragma unroll 1
         for (int j = 0; j < nw; ++j) {
           Hp hj = h;
           hj.alpha = aw.get(j);
-          F4_APPLY(adam_sparse1, var, m, v, z4, false, hj);
+          F4_APPLY(adam_sparse1, var, m, v, F4Z, false, hj);
         }
 #if RSX_ADAM_NT
         __builtin_nontemporal_store(var, &var4[e]);
@@ -197,7 +196,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         var4[e] = var;
         m4[e] = m;
         v4[e] = v;
-        if (s.zero_grad) g4[e] = z4;
+        if (s.zero_grad) g4[e] = F4Z;
       } else if (e == n4) {  // scalar tail (n not a multiple of 4)
         for (long long i = n4 * 4; i < s.n; ++i) {
           float g = s.g[i];
@@ -230,7 +229,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         for (int j = 0; j < nw; ++j) {
           Hp hj = h;
           hj.alpha = aw.get(j);
-          F4_APPLY(adam_dense1, var, m, v, z4, hj);
+          F4_APPLY(adam_dense1, var, m, v, F4Z, hj);
         }
         if (cold_only) {   // element-wise: leave the touched elements exactly as they were
           if (sl.x >= 0) { var.x = var0.x; m.x = m0.x; v.x = v0.x; }
@@ -383,7 +382,6 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
   const uint32_t m_lo_bits = __float_as_uint(fast_ok ? 0x1p-90f / amin : 1.f);
   const int32_t* __restrict__ swb = a.slot_w0;
   const int sws = (int)a.slot_w_stride;           // (< 2^28: adam_build_args) 32-bit element offsets: scalar base + vector offset
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
@@ -497,12 +495,12 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
       issue(b, B);
 #pragma unroll
       for (int u = 0; u < HB; ++u) {     // (unrolled: a dynamically indexed register array is demoted to scratch)
-        F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], z4, false, h);
+        F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], F4Z, false, h);
 #pragma unroll 1
         for (int j = 0; j < NW; ++j) {          // the later steps of the window, back to back in registers
           Hp hj = h;
           hj.alpha = aw.get(j);
-          F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], z4, false, hj);
+          F4_APPLY(adam_sparse1, B.var[u], B.m[u], B.v[u], F4Z, false, hj);
         }
       }
       store(B);

@@ -64,12 +64,11 @@ __global__ __launch_bounds__(256) void cin_fwd_k(const CinFwdArgs p) {
   const int n0 = blockIdx.x * 16;
   const int b = blockIdx.y * 4 + wv;
   const bool bok = b < p.B, nok = n0 + i < p.N;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e = tid; e < 2 * 16 * HP; e += 256) sW[e] = 0.f;          // rows h >= H must read as zero
   for (int e = tid; e < 4 * p.F * 4; e += 256) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
     const int bb = blockIdx.y * 4 + ex;
-    reinterpret_cast<float4*>(sX0)[e] = bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[r] : z4;
+    reinterpret_cast<float4*>(sX0)[e] = bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[r] : F4Z;
   }
   float areg[HSMAX];
   {
@@ -91,7 +90,7 @@ __global__ __launch_bounds__(256) void cin_fwd_k(const CinFwdArgs p) {
       if ((p.N & 3) == 0) {                      // aligned rows: one float4
         const bool ok = h < p.H && nn < p.N;
         wreg[r] = *reinterpret_cast<const float4*>(p.W + ((size_t)f * p.H + (ok ? h : 0)) * p.N + (ok ? nn : 0));
-        if (!ok) wreg[r] = z4;
+        if (!ok) wreg[r] = F4Z;
       } else {                                   // odd widths (tests, tiny models): element-wise
         const float* w = p.W + ((size_t)f * p.H + (h < p.H ? h : 0)) * p.N;
         const bool hok = h < p.H;
@@ -188,14 +187,13 @@ __global__ __launch_bounds__(768) void cin_bwd_dx_k(const CinBwdDxArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ht = wave % HT, part = wave / HT;
   const int b0 = blockIdx.x * CIN_BT;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int bt = 0; bt < CIN_BT; ++bt) {
     const int b = b0 + bt;
     for (int e = tid; e < p.N * 4; e += blockDim.x) {
-      float4 v = z4;
+      float4 v = F4Z;
       if (b < p.B) {
         const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)b * p.N * CIN_D)[e];
-        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CIN_D)[e] : z4;
+        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CIN_D)[e] : F4Z;
         if (p.gs) {
           const float a = p.gs[b] * p.wout[e >> 2];
           g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
@@ -207,10 +205,10 @@ __global__ __launch_bounds__(768) void cin_bwd_dx_k(const CinBwdDxArgs p) {
     }
     for (int e = tid; e < p.F * 4; e += blockDim.x)
       reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e] =
-          b < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)b * p.F * CIN_D)[e] : z4;
+          b < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)b * p.F * CIN_D)[e] : F4Z;
     for (int e = tid; e < p.H * 4; e += blockDim.x)
       reinterpret_cast<float4*>(sXk + bt * p.H * CIN_D)[e] =
-          b < p.B ? reinterpret_cast<const float4*>(p.Xk + (size_t)b * p.H * CIN_D)[e] : z4;
+          b < p.B ? reinterpret_cast<const float4*>(p.Xk + (size_t)b * p.H * CIN_D)[e] : F4Z;
   }
   __syncthreads();
   const int i = lane & 15, kq = lane >> 4;
@@ -254,7 +252,7 @@ __global__ __launch_bounds__(768) void cin_bwd_dx_k(const CinBwdDxArgs p) {
 #pragma unroll
       for (int u = 0; u < NSMAX; ++u) {
         const int nn = 16 * u + 4 * kq;
-        float4 t = z4;
+        float4 t = F4Z;
         if (hok && nn < p.N) {
           t.x = Wr[nn];
           t.y = nn + 1 < p.N ? Wr[nn + 1] : 0.f;
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(768) void cin_bwd_dx_k(const CinBwdDxArgs p) {
     const int bt = e / (p.F * 4), r = e - bt * p.F * 4;
     const int b = b0 + bt;
     if (b >= p.B) continue;
-    float4 s = z4;
+    float4 s = F4Z;
     for (int w = 0; w < HT; ++w) s = f4_add(s, reinterpret_cast<const float4*>(sP + (w * CIN_BT + bt) * p.F * CIN_D)[r]);
     float4* dst = reinterpret_cast<float4*>(p.dX0 + (size_t)b * p.F * CIN_D) + r;
     if (p.acc_dx0) s = f4_add(*dst, s);
@@ -363,14 +361,13 @@ __global__ __launch_bounds__(64 * EB * FS) void cin_bwd_dx2_k(const CinBwdDxArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int e = wave % EB, part = wave / EB;
   const int ht = blockIdx.x, b0 = blockIdx.y * EB, b = b0 + e;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int bt = 0; bt < EB; ++bt) {
     const int bb = b0 + bt;
     for (int e4 = tid; e4 < p.N * 4; e4 += NTHR) {
-      float4 v = z4;
+      float4 v = F4Z;
       if (bb < p.B) {
         const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)bb * p.N * CIN_D)[e4];
-        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)bb * p.N * CIN_D)[e4] : z4;
+        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)bb * p.N * CIN_D)[e4] : F4Z;
         if (p.gs) {
           const float a = p.gs[bb] * p.wout[e4 >> 2];
           g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
@@ -382,11 +379,11 @@ __global__ __launch_bounds__(64 * EB * FS) void cin_bwd_dx2_k(const CinBwdDxArgs
     }
     for (int e4 = tid; e4 < p.F * 4; e4 += NTHR)
       reinterpret_cast<float4*>(sX0 + bt * p.F * CIN_D)[e4] =
-          bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[e4] : z4;
+          bb < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)bb * p.F * CIN_D)[e4] : F4Z;
     for (int e4 = tid; e4 < 64; e4 += NTHR) {
       const int hh = ht * 16 + (e4 >> 2);
       reinterpret_cast<float4*>(sXk + bt * 256)[e4] =
-          (bb < p.B && hh < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)bb * p.H + hh) * CIN_D)[e4 & 3] : z4;
+          (bb < p.B && hh < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)bb * p.H + hh) * CIN_D)[e4 & 3] : F4Z;
     }
   }
   __syncthreads();
@@ -423,7 +420,7 @@ __global__ __launch_bounds__(64 * EB * FS) void cin_bwd_dx2_k(const CinBwdDxArgs
   const float4* W4 = reinterpret_cast<const float4*>(p.W);
   const size_t fstride4 = (size_t)p.H * N4;
   // the double buffer starts as zeros: the row pads and the columns past N that the fixed NSMAX reads touch must be finite
-  for (int e4 = tid; e4 < (2 * FS * 16 * NP) / 4; e4 += NTHR) reinterpret_cast<float4*>(sW)[e4] = z4;
+  for (int e4 = tid; e4 < (2 * FS * 16 * NP) / 4; e4 += NTHR) reinterpret_cast<float4*>(sW)[e4] = F4Z;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < RMAX; ++k) {
@@ -435,7 +432,7 @@ __global__ __launch_bounds__(64 * EB * FS) void cin_bwd_dx2_k(const CinBwdDxArgs
   for (int s_ = 0; s_ < steps; ++s_) {
     // next step's slices: global loads in flight during this step's MFMAs (clamped step: the last one reloads itself)
     const int sn = s_ + 1 < steps ? s_ + 1 : s_;
-    float4 st0 = z4, st1 = z4, st2 = z4, st3 = z4;
+    float4 st0 = F4Z, st1 = F4Z, st2 = F4Z, st3 = F4Z;
     {
       const int f0_ = sn * FS + cp_pf[0] < p.F ? sn * FS + cp_pf[0] : p.F - 1;
       st0 = W4[(size_t)f0_ * fstride4 + cp_g[0]];

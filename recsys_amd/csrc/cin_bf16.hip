@@ -116,15 +116,14 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   const int i = lane & 15, kq = lane >> 4;
   const int n0 = tile_x * 16;
   const int b0 = tile_y * 2;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e = tid; e < 2 * p.F * 4; e += 256) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
-    reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : z4;
+    reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : F4Z;
   }
   for (int e4 = tid; e4 < 2 * 32 * KS * 4; e4 += 256) {          // (example, h, d-quarter): float4 in, 4 bf16 out (h >= H: zero)
     const int ex = e4 / (32 * KS * 4), r = e4 - ex * (32 * KS * 4);
     const int h = r >> 2, dq = r & 3;
-    const float4 v = (b0 + ex < p.B && h < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)(b0 + ex) * p.H + h) * CB_D)[dq] : z4;
+    const float4 v = (b0 + ex < p.B && h < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)(b0 + ex) * p.H + h) * CB_D)[dq] : F4Z;
     bf16_t* t = sXk + (size_t)ex * 16 * HPP + h;
     t[(dq * 4 + 0) * HPP] = (bf16_t)v.x;
     t[(dq * 4 + 1) * HPP] = (bf16_t)v.y;
@@ -247,7 +246,6 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
   const int ht = wave % HT, part = wave / HT;
   const int i = lane & 15, kq = lane >> 4;
   const int b0 = tile * 2;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e = tid; e < 16 * NPP; e += nthr) reinterpret_cast<uint32_t*>(sDpT)[e] = 0u;     // k padding must read as zero
   __syncthreads();
   // dpre = relu'(out) * (dout + gs*wout): fp32 column sums -> dc_part, bf16 copy -> global (dW fragments) and LDS (transposed)
@@ -257,10 +255,10 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int b = b0 + e;
-      float4 v = z4;
+      float4 v = F4Z;
       if (b < p.B && n < p.N) {
         const float4 o = reinterpret_cast<const float4*>(p.out + (size_t)b * p.N * CB_D)[e4];
-        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CB_D)[e4] : z4;
+        float4 g = p.dout ? reinterpret_cast<const float4*>(p.dout + (size_t)b * p.N * CB_D)[e4] : F4Z;
         if (p.gs) {
           const float a = p.gs[b] * p.wout[n];
           g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
   }
   for (int e = tid; e < 2 * p.F * 4; e += nthr) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
-    reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : z4;
+    reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : F4Z;
   }
   __syncthreads();
   bf16x8 bd[2][KSN];                              // dpre[b][n = 32 ks + 8 kq + j][d = i]
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(1024) void cin_bwd_dx_bf16_k(const CbDxArgs p) {
     const int ex = e4 / (p.F * 4), r = e4 - ex * p.F * 4;
     const int b = b0 + ex;
     if (b >= p.B) continue;
-    float4 s = z4;
+    float4 s = F4Z;
     for (int w = 0; w < HT; ++w) s = f4_add(s, reinterpret_cast<const float4*>(sP + (size_t)(w * 2 + ex) * p.F * CB_D)[r]);
     float4* dst = reinterpret_cast<float4*>(p.dX0 + (size_t)b * p.F * CB_D) + r;
     if (p.acc_dx0) s = f4_add(*dst, s);

@@ -47,7 +47,6 @@ __global__ __launch_bounds__(256) void cross_fwd_k(const CrossFwdArgs p) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= p.B) return;
   const int n4 = p.dim >> 2;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 x0[CROSS_NV], x[CROSS_NV];
 #pragma unroll
   for (int v = 0; v < CROSS_NV; ++v) {
@@ -107,9 +106,8 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
   const int lane = threadIdx.x;
   const int n4 = p.dim >> 2;
   const int nvec = 2 * p.L + 1;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   float4* acc = reinterpret_cast<float4*>(lds);
-  for (int e = lane; e < nvec * n4; e += 64) acc[e] = z;
+  for (int e = lane; e < nvec * n4; e += 64) acc[e] = F4Z;
   __syncthreads();   // single wave: orders the zero fill before the per-lane read-modify-writes below
   float4 wv[CROSS_MAX_L][CROSS_NV];
 #pragma unroll
@@ -117,7 +115,7 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
 #pragma unroll
     for (int v = 0; v < CROSS_NV; ++v) {
       const int e = lane + 64 * v;
-      wv[l][v] = l < p.L ? cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, e, n4) : z;   // l: uniform
+      wv[l][v] = l < p.L ? cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, e, n4) : F4Z;   // l: uniform
     }
   for (int rr = 0; rr < epw; ++rr) {
     const int b = blockIdx.x * epw + rr;
@@ -129,7 +127,7 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
       const int e = lane + 64 * v;
       x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, e, n4);
       x[v] = x0[v];
-      dx0[v] = z;
+      dx0[v] = F4Z;
     }
 #pragma unroll
     for (int l = 0; l < CROSS_MAX_L; ++l) {   // recompute x_0 .. x_{L-1} (and x_L in `x`)
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
 #pragma unroll
     for (int v = 0; v < CROSS_NV; ++v) {
       const int e = lane + 64 * v;
-      float4 d = z;
+      float4 d = F4Z;
       if (p.dxL != nullptr) d = cross_ld(reinterpret_cast<const float4*>(p.dxL) + (size_t)b * n4, e, n4);   // uniform
       if (p.gz != nullptr) {
         d = f4_add(d, f4_scale(g, cross_ld(reinterpret_cast<const float4*>(p.wout), e, n4)));
@@ -226,9 +224,8 @@ __global__ __launch_bounds__(256, 2) void cross_bwd4_k(const CrossBwdArgs p, int
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n4 = p.dim >> 2;
   constexpr int nvec = 2 * L + 1;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   float4* acc = reinterpret_cast<float4*>(lds) + (size_t)w * nvec * n4;     // this wave's slab (LDS operations of one wave are ordered)
-  for (int e = lane; e < nvec * n4; e += 64) acc[e] = z;
+  for (int e = lane; e < nvec * n4; e += 64) acc[e] = F4Z;
   float4 wv[L][CROSS_NV];
 #pragma unroll
   for (int l = 0; l < L; ++l)
@@ -244,12 +241,12 @@ __global__ __launch_bounds__(256, 2) void cross_bwd4_k(const CrossBwdArgs p, int
     for (int v = 0; v < CROSS_NV; ++v) {
       x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, lane + 64 * v, n4);
       x[v] = x0[v];
-      dx0[v] = z;
+      dx0[v] = F4Z;
     }
     const float g = p.gz != nullptr ? p.gz[b] : 0.f;
 #pragma unroll
     for (int v = 0; v < CROSS_NV; ++v) {          // (issued before the recomputation below needs anything)
-      float4 d = z;
+      float4 d = F4Z;
       if (p.dxL != nullptr) d = cross_ld(reinterpret_cast<const float4*>(p.dxL) + (size_t)b * n4, lane + 64 * v, n4);   // uniform
       dx[v] = d;
     }

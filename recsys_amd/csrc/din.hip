@@ -50,7 +50,6 @@ __global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ 
   if (b >= B) return;
   const int q = lane % LPR, j = lane / LPR;
   const float4 g = reinterpret_cast<const float4*>(dout)[(size_t)b * LPR + q];
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int p0 = 0; p0 < P; p0 += RPW) {   // wave-uniform trip count: the shuffles below need every lane
     const int p = p0 + j;
     const bool in = p < P;

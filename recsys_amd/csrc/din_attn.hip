@@ -86,12 +86,11 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
   int mrow[4];                                   // original indices of this lane's C-layout rows 4*kq + r
 #pragma unroll
   for (int r = 0; r < 4; ++r) mrow[r] = __shfl(mc, 4 * kq + r);   // lane 4*kq + r (kq' = 0) holds that row's index
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 h4[KB], q4[KB];
 #pragma unroll
   for (int c = 0; c < KB; ++c) {
-    h4[c] = mok ? *reinterpret_cast<const float4*>(p.H + (size_t)mc * K + 16 * c + 4 * kq) : z4;
-    q4[c] = mok ? *reinterpret_cast<const float4*>(p.q + (size_t)(mc / p.P) * K + 16 * c + 4 * kq) : z4;
+    h4[c] = mok ? *reinterpret_cast<const float4*>(p.H + (size_t)mc * K + 16 * c + 4 * kq) : F4Z;
+    q4[c] = mok ? *reinterpret_cast<const float4*>(p.q + (size_t)(mc / p.P) * K + 16 * c + 4 * kq) : F4Z;
   }
   // ---- layer 0: z1 = [h, q, h*q, h-q] . W0 ----------------------------------------------------------------------
   f32x4 acc1[NT1];
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
   for (int e = tid; e < N2P; e += 512) sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
   const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
   const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
   // weight-gradient accumulators, alive across all blocks: wave w owns row tile w of dW0 (w < 4*KB) and of dW1 (w < NT1)
   f32x4 accW0[NT1], accW1[NT2];
@@ -355,8 +353,8 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
       for (int c = 0; c < KB; ++c) {
         const float4 hr = *reinterpret_cast<const float4*>(p.H + mcl * K + 16 * c + 4 * kq);
         const float4 qr = *reinterpret_cast<const float4*>(p.q + (mcl / p.P) * K + 16 * c + 4 * kq);
-        const float4 hv = mok ? hr : z4;
-        const float4 qv = mok ? qr : z4;
+        const float4 hv = mok ? hr : F4Z;
+        const float4 qv = mok ? qr : F4Z;
         const int cc = 16 * c + 4 * kq, rr = 16 * rt + i;
         sH[(cc + 0) * LDR + rr] = hv.x; sH[(cc + 1) * LDR + rr] = hv.y; sH[(cc + 2) * LDR + rr] = hv.z; sH[(cc + 3) * LDR + rr] = hv.w;
         sQ[(cc + 0) * LDR + rr] = qv.x; sQ[(cc + 1) * LDR + rr] = qv.y; sQ[(cc + 2) * LDR + rr] = qv.z; sQ[(cc + 3) * LDR + rr] = qv.w;

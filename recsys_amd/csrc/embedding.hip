@@ -11,6 +11,13 @@
 #include "sort_device.h"
 #include "adam_device.h"
 
+RSX_STAMP_DECL
+// (profiling build only) which workgroup of a launch stamps slots [16 g, 16 g + 16): g = 0 -> workgroup 0, g = 1 -> workgroup 24
+#define RSX_STAMP2(slot) do { RSX_STAMP(slot, blockIdx.x == 0); RSX_STAMP(16 + (slot), blockIdx.x == 24); } while (0)
+// segsum_adam_k: workgroup 0 (field 0's helpers of huge segments at B = 4096) -> slots 32.., workgroup 432 (row owners of a
+// 100 000-row field at B = 4096) -> slots 48..
+#define RSX_STAMP3(slot) do { RSX_STAMP(32 + (slot), blockIdx.x == 0); RSX_STAMP(48 + (slot), blockIdx.x == 432); } while (0)
+
 // ------------------------------------------------------------------ forward --------------------
 // One wave per example b.  lane = (j, q): q = float4 quarter of the row, j = pair slot; the wave
 // walks fields f = j, j+PPP, ...  The field reductions (S, sum of squares, first-order sum) are
@@ -225,7 +232,6 @@ struct SegCtx {
 template <int LPR>
 __device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4 e, int i0, int i1, float4& acc,
                                               float& a1) {
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = i0; i < i1; i += 4) {
     int bb[4];
     float g[4], h[4];
@@ -240,14 +246,14 @@ __device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4
       size_t bo;
       ex_locate(c.xb, b, bi, bo);
       g[k] = (ok && c.gy2 != nullptr) ? c.gy2[bo + bi] : 0.f;
-      s[k] = (ok && c.gy2 != nullptr) ? c.S4[bo / 4 + (size_t)bi * LPR + c.q] : z;
-      x[k] = (ok && c.X4 != nullptr) ? c.X4[bo / 4 + ((size_t)bi * c.F + c.f) * LPR + c.q] : z;
+      s[k] = (ok && c.gy2 != nullptr) ? c.S4[bo / 4 + (size_t)bi * LPR + c.q] : F4Z;
+      x[k] = (ok && c.X4 != nullptr) ? c.X4[bo / 4 + ((size_t)bi * c.F + c.f) * LPR + c.q] : F4Z;
       h[k] = (ok && c.do1) ? c.gy1[bo + bi] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (bb[k] >= 0) {
-        float4 t = z;
+        float4 t = F4Z;
         if (c.gy2 != nullptr) t = f4_sub(f4_scale(g[k], s[k]), f4_scale(g[k], e));
         if (c.X4 != nullptr) t = c.gy2 != nullptr ? f4_add(t, x[k]) : x[k];
         acc = f4_add(acc, t);
@@ -288,7 +294,6 @@ template <int LPR>
 __device__ __forceinline__ void partial_range_sum(const float4* __restrict__ P4, const float* __restrict__ P1, size_t base,
                                                   bool first_slot1, int q, bool do1, int t0, int t1, float4& acc,
                                                   float& a1) {
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = t0; t < t1; t += 8) {
     float4 v[8];
     float h[8];
@@ -296,7 +301,7 @@ __device__ __forceinline__ void partial_range_sum(const float4* __restrict__ P4,
     for (int k = 0; k < 8; ++k) {
       const bool ok = t + k < t1;
       const size_t idx = (base + (size_t)(ok ? t + k : t0)) * 2 + ((t + k) == 0 && first_slot1 ? 1 : 0);
-      v[k] = ok ? P4[idx * LPR + q] : z;
+      v[k] = ok ? P4[idx * LPR + q] : F4Z;
       h[k] = (ok && do1) ? P1[idx] : 0.f;
     }
 #pragma unroll
@@ -309,35 +314,91 @@ __device__ __forceinline__ void partial_range_sum(const float4* __restrict__ P4,
   }
 }
 
-// Stage B wave body (same contract as segsum_wave).  Waves [0, nact) of a field own GPW unique rows each and sum the
-// short ones; wave nact + k is the helper of the field's k-th long segment.
+// Optional prefetch for the fused touched-row Adam (segsum_adam_k): the row's optimizer state is
+// requested as soon as the row is known, so that its latency hides behind the segment walk instead of following it.
+struct AdamRowPrefetch {
+  const float* tables;
+  const float* m_t;
+  const float* v_t;
+  float4 var, m, v;
+  bool loaded;
+};
+
+// Stage B's work as a COMPACT list of wave-sized units: field f contributes ceil(nu_f / GPW) row-owner units, ceil(nlong_f
+// / GPW) long-segment units and nhuge_f huge-segment units, in that order, fields in order.  (A grid sized for the worst
+// case -- B unique rows in every field -- launched 2 808 workgroups at 4 096 examples x 39 fields of which ~690 had work;
+// each of the others still cost a dispatch slot, a barrier and a returning atomic on the arrival counter: the launch took
+// 15 us while no single workgroup lived longer than 7.)  Every wave derives the list from the F-entry count arrays with
+// one load per lane and a wave scan; waves walk it with a grid stride.
+struct SegUnits {
+  int incl;          // lane f: units of fields 0 .. f
+  int nu, nl, nh;    // lane f: unique rows / long / huge segments of field f
+  int total;
+};
+template <int GPW>
+__device__ __forceinline__ SegUnits seg_units(const int32_t* __restrict__ nuniq, const SegPartials& part, int F, int stride) {
+  const int lane = threadIdx.x & 63;
+  const int lc = lane < F ? lane : F - 1;
+  SegUnits u;
+  u.nu = nuniq[lc];
+  u.nl = part.counts(F, stride)[lc];
+  u.nh = part.counts(F, stride)[F + lc];
+  int incl = lane < F ? (u.nu + GPW - 1) / GPW + (u.nl + GPW - 1) / GPW + u.nh : 0;
+#pragma unroll
+  for (int d = 1; d < RSX_WAVE; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  u.incl = incl;
+  u.total = __shfl(incl, RSX_WAVE - 1);
+  return u;
+}
+// unit (wave-uniform, < u.total) -> field, unit within the field, the field's counts
+__device__ __forceinline__ void seg_unit_locate(const SegUnits& u, int unit, int& f, int& wf, int& nu, int& nl, int& nh) {
+  f = __popcll(__ballot(u.incl <= unit));
+  const int below = __shfl(u.incl, f > 0 ? f - 1 : 0);
+  wf = unit - (f > 0 ? below : 0);
+  nu = __shfl(u.nu, f);
+  nl = __shfl(u.nl, f);
+  nh = __shfl(u.nh, f);
+}
+constexpr int SEG_STAGE_B_MAX_WG = 1024;   // stage-B workgroups of a launch at most (4 waves each, grid stride over the units)
+
+// Stage B wave body (same contract as segsum_wave) for unit wf of field f: units [0, nact) own GPW unique rows each (the
+// short ones were summed by stage A: their sums are picked up); the next ceil(nlong / GPW) units are the helpers of the
+// field's long segments (a group each), the last nhuge units those of its huge segments (a wave each).
 template <int D>
-__device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__ tables, const float* __restrict__ S,
+__device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, int nhuge, const float* __restrict__ tables,
+                                             const float* __restrict__ S,
                                              const float* __restrict__ dX, const float* __restrict__ gy1,
                                              const float* __restrict__ gy2, const int32_t* __restrict__ perm,
                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
                                              const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
                                              int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
                                              float4& acc, float& a1, float4& e, int& row, bool& do1, bool& staged,
-                                             const bool load_staged) {
+                                             const bool load_staged, AdamRowPrefetch* pre) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
   const int q = lane % LPR, g = lane / LPR;
   staged = false;
-  const int wpf = seg_waves_per_field(B, GPW, true);
-  const int f = wave / wpf;
+  // the row's optimizer state, requested as soon as the row is known (segsum_adam_k): one round trip less per row
+  auto prefetch = [&](const int r) {
+    if (pre != nullptr) {
+      const size_t o = (size_t)r * LPR + q;
+      pre->var = reinterpret_cast<const float4*>(pre->tables)[o];
+      pre->m = reinterpret_cast<const float4*>(pre->m_t)[o];
+      pre->v = reinterpret_cast<const float4*>(pre->v_t)[o];
+      pre->loaded = true;
+    }
+  };
   valid = false;
-  if (f >= F) return false;
-  const int wf = wave - f * wpf;
-  const int nu = nuniq[f];
   const int nact = (nu + GPW - 1) / GPW;
   const int32_t* so = seg_off + (size_t)f * (stride + 1);
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
-  acc = z;
+  acc = F4Z;
   a1 = 0.f;
-  e = z;
+  e = F4Z;
   if (wf < nact) {
     const int j = wf * GPW + g;
     const bool own = j < nu;
@@ -345,15 +406,22 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
     const int beg = own ? so[j] : 0;
     int end = own ? so[j + 1] : 0;
     row = own ? uniq_row[sl] : 0;
-    // a segment inside ONE chunk was finished by stage A (position-major: perm -> rows in two memory round trips with 16
-    // independent row loads per group, instead of this group's seg_off -> perm -> row chain): pick its sum up
-    if (part.G != nullptr && own && beg / SEG_CHUNK == (end - 1) / SEG_CHUNK) {
+    // every segment of <= SEG_SHORT entries was finished by stage A (segsum_tiles_k): pick its sum up.  The loads do not
+    // depend on the row, so they share the round trip of the segment bounds.
+    float4 gs = F4Z;
+    float g1s = 0.f;
+    if (load_staged) {
+      gs = reinterpret_cast<const float4*>(part.G)[sl * LPR + q];
+      g1s = (do1 && part.gw1 != nullptr) ? part.gw1[sl] : 0.f;
+    }
+    if (own && end - beg <= SEG_SHORT) {
       valid = true;
       staged = true;
       if (load_staged) {
-        acc = reinterpret_cast<const float4*>(part.G)[sl * LPR + q];
-        a1 = (do1 && part.gw1 != nullptr) ? part.gw1[sl] : 0.f;
-        if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+        acc = gs;
+        a1 = g1s;
+        prefetch(row);
+        if (gy2 != nullptr) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
       }
       return true;
     }
@@ -377,7 +445,6 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
     return true;
   }
   const size_t nch = (size_t)(B + SEG_CHUNK - 1) / SEG_CHUNK;
-  const int nlong = part.counts(F, stride)[f], nhuge = part.counts(F, stride)[F + f];
   const int32_t* ll = part.long_list(F, stride) + (size_t)f * nch;
   const int nlw = (nlong + GPW - 1) / GPW;
   const float4* P4 = reinterpret_cast<const float4*>(part.P);
@@ -394,7 +461,8 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
       valid = false;
       return true;
     }
-    if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+    prefetch(row);
+    if (gy2 != nullptr) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
     const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
     partial_range_sum<LPR>(P4, part.P1, (size_t)f * nch + c0, sb % SEG_CHUNK != 0, q, do1, 0, nt, acc, a1);
     return true;
@@ -408,12 +476,13 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
   row = uniq_row[sl];
   if (null_row >= 0 && row == null_row) return false;   // the padding row is written (as zero) by its row-owner group
   valid = g == 0;
-  if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+  if (valid) prefetch(row);
+  if (gy2 != nullptr && valid) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
   const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
   const int per = (nt + GPW - 1) / GPW;
   const int t0 = g * per;
   const int t1 = t0 + per < nt ? t0 + per : nt;
-  float4 p = z;
+  float4 p = F4Z;
   float p1 = 0.f;
   if (t0 < t1) partial_range_sum<LPR>(P4, part.P1, (size_t)f * nch + c0, sb % SEG_CHUNK != 0, q, do1, t0, t1, p, p1);
   float4 tot = make_float4(__shfl(p.x, q), __shfl(p.y, q), __shfl(p.z, q), __shfl(p.w, q));
@@ -429,16 +498,6 @@ __device__ __forceinline__ bool segsum_wave2(int wave, const float* __restrict__
   return true;
 }
 
-// Optional prefetch for the fused touched-row Adam (segsum_adam_k, single-stage form): the row's optimizer state is
-// requested as soon as the row is known, so that its latency hides behind the segment walk instead of following it.
-struct AdamRowPrefetch {
-  const float* tables;
-  const float* m_t;
-  const float* v_t;
-  float4 var, m, v;
-  bool loaded;
-};
-
 // The per-wave body of the segment-sum: returns false when the wave owns no unique row.  On return, for lanes with
 // `valid`: sl = slot index of the row, acc = summed gradient quarter, a1 = summed first-order gradient (q == 0 lanes),
 // e = the table row quarter (loaded only when the FM term is active), row = global row.
@@ -453,9 +512,6 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
                                             const bool load_staged = true, AdamRowPrefetch* pre = nullptr) {
   staged = false;
   if (pre != nullptr) pre->loaded = false;
-  if (part.P != nullptr)
-    return segsum_wave2<D>(wave, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride, null_row,
-                           part, xb, valid, sl, acc, a1, e, row, do1, staged, load_staged);
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -496,8 +552,7 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   c.q = q;
   c.do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
   do1 = c.do1;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  e = z;
+  e = F4Z;
   if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
   if (pre != nullptr && valid) {
     const size_t o = (size_t)row * LPR + q;
@@ -506,7 +561,7 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
     pre->v = reinterpret_cast<const float4*>(pre->v_t)[o];
     pre->loaded = true;
   }
-  acc = z;
+  acc = F4Z;
   a1 = 0.f;
   const int short_len = spread ? 2 : SEG_SHORT;   // a spread wave has 15 idle groups: cooperate on anything > 2
   if (valid && L <= short_len) seg_range_sum<LPR>(c, e, beg, end, acc, a1);
@@ -519,7 +574,7 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
     const int per = (se - sb + GPW - 1) / GPW;
     const int r0 = sb + g * per;
     const int r1 = r0 + per < se ? r0 + per : se;
-    float4 p = z;
+    float4 p = F4Z;
     float p1 = 0.f;
     if (r0 < r1) seg_range_sum<LPR>(c, es, r0, r1, p, p1);
     float4 tot = make_float4(__shfl(p.x, q), __shfl(p.y, q), __shfl(p.z, q), __shfl(p.w, q));
@@ -538,142 +593,265 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   return true;
 }
 
-template <int D, bool FM>
-__global__ __launch_bounds__(256) void segsum_partials_k(const float* __restrict__ tables, const float* __restrict__ S,
-                                                         const float* __restrict__ dX, const float* __restrict__ gy1,
-                                                         const float* __restrict__ gy2, const int32_t* __restrict__ perm,
-                                                         const int32_t* __restrict__ seg_off,
-                                                         const int32_t* __restrict__ uniq_row, const SegPartials ws,
-                                                         uint64_t w1_mask, int B, int F, int stride, int null_row,
-                                                         const ExBlocks xb) {
-  // Position-major stage: a group walks the 16 sorted positions of its chunk in ascending order.  Every load of the chunk
-  // -- example indices and segment ids first, then the 16 gradient rows (and, for the FM term, the 16 table rows) -- is
-  // independent of the others, so the group has 16 rows in flight per round trip however the ids are distributed.
-  //   * a segment that starts and ends inside the chunk is FINISHED here (sum in ascending example order, the oracle's
-  //     order) and written to ws.G / ws.gw1 when those are given;
-  //   * the chunk's overlap with a LONG segment (> SEG_SHORT entries) goes to the partial slots as before (slot 0: the
-  //     segment of the chunk's first position, slot 1: of its last);
-  //   * a short segment that straddles a chunk boundary is left to its row-owner group in stage B, which sums it entry by
-  //     entry -- so every segment of <= SEG_SHORT entries keeps the strictly sequential order.
+// Stage A of the two-stage scatter (B > 1024): TILES of the sorted order.  A 256-thread workgroup takes 256/LPR * 16
+// consecutive sorted positions of one field (1024 at D = 16), its LPR-lane group g the 16-position chunk g.  The index
+// side -- segment index and example index of every position of the tile, plus 16 positions of halo on either side --
+// arrives with ONE coalesced round trip into LDS; from it a group knows, without touching seg_off, where the segments
+// of its chunk begin and end (a count of equal neighbours, capped at 16 = "long"), so the 16 gradient rows of the chunk
+// are requested at once, one round trip later.  Then, in ascending position (the oracle's order):
+//   * every segment of <= SEG_SHORT entries is FINISHED here by the group of the chunk it starts in -- a segment that
+//     crosses into the next chunk is followed there (at most 15 more entries) -- and its sum written to ws.G / ws.gw1;
+//     stage B never walks the permutation or a gradient row again;
+//   * the chunk's overlap with a LONG segment goes to the partial slots (slot 0: the segment of the chunk's first
+//     position, slot 1: of its last); stage B adds them in ascending chunk order.
+// The previous form (one group = one chunk with its own 34 scalar index loads, then seg_off / uniq_row, then the rows in
+// two batches: 5-6 dependent round trips, short segments crossing a chunk boundary left to stage B) measured 12 us at
+// 4 096 examples x 39 fields on 156 workgroups -- a pure latency chain.
+template <int LPR>
+struct SegTile {
+  static constexpr int GPB = 256 / LPR;          // groups (= chunks) per workgroup
+  static constexpr int POS = GPB * SEG_CHUNK;    // sorted positions per workgroup
+  static constexpr int SID = POS + 2 * SEG_CHUNK;
+  static constexpr int PRM = POS + SEG_CHUNK;
+  static constexpr size_t lds_bytes = (size_t)(SID + PRM) * sizeof(int32_t);
+};
+
+// W1: the first-order sums ride along (compile-time, so that the gy1 loads are as unconditional as the row loads: behind a
+// per-lane condition the first of them is waited for alone, ahead of the whole batch)
+template <int D, bool FM, bool W1>
+__global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ tables, const float* __restrict__ S,
+                                                      const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                      const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ uniq_row, const SegPartials ws,
+                                                      uint64_t w1_mask, int B, int F, int stride, int null_row,
+                                                      const ExBlocks xb) {
   constexpr int LPR = D / 4;
-  constexpr int GPW = RSX_WAVE / LPR;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  const int q = lane % LPR, g = lane / LPR;
-  const int nch = (B + SEG_CHUNK - 1) / SEG_CHUNK;
-  const int wpf = (nch + GPW - 1) / GPW;
-  const int f = wave / wpf;
-  if (f >= F) return;
-  const int ch = (wave - f * wpf) * GPW + g;
-  const bool active = ch < nch;
-  const int p0 = active ? ch * SEG_CHUNK : 0;
-  const int p1 = active ? (p0 + SEG_CHUNK < B ? p0 + SEG_CHUNK : B) : 1;
+  using T = SegTile<LPR>;
+  extern __shared__ __attribute__((aligned(16))) int32_t tile_lds[];
+  int32_t* sid_l = tile_lds;                       // [SID]: segment index of positions base - 16 ..; -1 before 0, -2 from B on
+  int32_t* prm_l = tile_lds + T::SID;              // [PRM]: example index of positions base ..
+  const int tid = threadIdx.x;
+  const int tiles = (B + T::POS - 1) / T::POS;
+  const int f = blockIdx.x / tiles;
+  const int base = (blockIdx.x - f * tiles) * T::POS;
   const int32_t* pf = perm + (size_t)f * stride;
   const int32_t* sid = ws.segid + (size_t)f * stride;
-  const int32_t* so = seg_off + (size_t)f * (stride + 1);
-  const bool fin = ws.G != nullptr;
-  int pb[SEG_CHUNK], sj[SEG_CHUNK];
+  RSX_STAMP2(0);
+  // the padding row (DIN's history id 0, exactly-zero gradients): table-local id 0 sorts first, so it is segment 0
+  int row0 = -1;
+  if (null_row >= 0) row0 = uniq_row[(size_t)f * stride];
+  {
+    constexpr int NI = (T::SID + 255) / 256;
+    int32_t a[NI], b[NI];
 #pragma unroll
-  for (int k = 0; k < SEG_CHUNK; ++k) {              // unconditional loads on clamped positions
-    const int pos = p0 + k < p1 ? p0 + k : p1 - 1;
-    pb[k] = pf[pos];
-    sj[k] = sid[pos];
+    for (int u = 0; u < NI; ++u) {                 // every load of the tile before the first LDS store
+      const int i = tid + 256 * u, pos = base - SEG_CHUNK + i;
+      a[u] = sid[pos < 0 ? 0 : (pos < B ? pos : B - 1)];
+      const int pp = base + i;
+      b[u] = pf[pp < B ? pp : B - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int i = tid + 256 * u, pos = base - SEG_CHUNK + i;
+      if (i < T::SID) sid_l[i] = pos < 0 ? -1 : (pos < B ? a[u] : -2);
+      if (i < T::PRM) prm_l[i] = b[u];
+    }
   }
-  const int jprev = sid[p0 > 0 ? p0 - 1 : 0], jnext = sid[p1 < B ? p1 : B - 1];
-  const int jf = sj[0], jl = sj[SEG_CHUNK - 1];      // (clamped positions repeat the last one)
-  const bool lopen = p0 > 0 && jprev == jf, ropen = p1 < B && jnext == jl;
-  const int bf = so[jf], ef = so[jf + 1], bl = so[jl], el = so[jl + 1];
-  const int rowf = uniq_row[(size_t)f * stride + jf], rowl = uniq_row[(size_t)f * stride + jl];
-  // rows of all 16 positions' segments, in the same round trip as the segment bounds (FM term / padding row only)
-  int rws[SEG_CHUNK];
+  __syncthreads();
+  RSX_STAMP2(1);
+  const int g = tid / LPR, q = tid % LPR;
+  const int p0 = base + g * SEG_CHUNK;
+  if (p0 >= B) return;
+  const int n_in = B - p0 < SEG_CHUNK ? B - p0 : SEG_CHUNK;
+  // the chunk's window of segment indices: 16 before, the chunk, 16 after
+  int sw[3 * SEG_CHUNK];
+  {
+    const int4* w4 = reinterpret_cast<const int4*>(sid_l + g * SEG_CHUNK);
 #pragma unroll
-  for (int k = 0; k < SEG_CHUNK; ++k) rws[k] = (FM || null_row >= 0) ? uniq_row[(size_t)f * stride + sj[k]] : 0;
-  const bool long0 = active && ef - bf > SEG_SHORT && !(null_row >= 0 && rowf == null_row);
-  const bool long1 = active && jl != jf && el - bl > SEG_SHORT && !(null_row >= 0 && rowl == null_row);
-  // what happens to the first / last segment of the chunk: partial slot, finished here, or left to stage B
-  const bool fin0 = fin && active && !long0 && !lopen && (jf != jl || !ropen);
-  const bool fin1 = fin && active && !long1 && jl != jf && !ropen;
-  if (!active || (!fin && !long0 && !long1)) return;
-  constexpr bool fm = FM;                     // FM term (gy2 / S / table row): a compile-time switch keeps its registers out
-  constexpr int NB = FM ? 4 : 8;              // entries whose loads are in flight together
+    for (int u = 0; u < 3 * SEG_CHUNK / 4; ++u) {
+      const int4 v = w4[u];
+      sw[4 * u] = v.x; sw[4 * u + 1] = v.y; sw[4 * u + 2] = v.z; sw[4 * u + 3] = v.w;
+    }
+  }
+  int pb[SEG_CHUNK];
+  {
+    const int4* p4 = reinterpret_cast<const int4*>(prm_l + g * SEG_CHUNK);
+#pragma unroll
+    for (int u = 0; u < SEG_CHUNK / 4; ++u) {
+      const int4 v = p4[u];
+      pb[4 * u] = v.x; pb[4 * u + 1] = v.y; pb[4 * u + 2] = v.z; pb[4 * u + 3] = v.w;
+    }
+  }
+  const int jf = sw[SEG_CHUNK], jl = sid_l[(g + 1) * SEG_CHUNK + n_in - 1];
+  uint32_t mb = 0, ma = 0, mf = 0, ml = 0;
+#pragma unroll
+  for (int k = 0; k < SEG_CHUNK; ++k) {
+    mb |= (uint32_t)(sw[SEG_CHUNK - 1 - k] == jf) << k;
+    ma |= (uint32_t)(sw[2 * SEG_CHUNK + k] == jl) << k;
+    mf |= (uint32_t)(sw[SEG_CHUNK + k] == jf) << k;
+    ml |= (uint32_t)(sw[SEG_CHUNK + k] == jl) << k;
+  }
+  const int cb = __builtin_ctz(~mb);                               // equal neighbours before the chunk (16: "16 or more")
+  const int ca = n_in == SEG_CHUNK ? __builtin_ctz(~ma) : 0;       // ... after it
+  const int cf = __builtin_ctz(~mf);                               // entries of the first segment inside the chunk
+  const bool one = jf == jl;
+  const int cl = one ? 0 : n_in - __builtin_ctz(ml);               // ... of the last one
+  const bool null0 = null_row >= 0 && row0 == null_row;
+  const bool nullf = null0 && jf == 0, nulll = null0 && jl == 0;
+  bool long0, own0, long1 = false, own1 = false;
+  int next;                                                        // entries of the last owned segment beyond the chunk
+  if (one) {
+    long0 = cb == SEG_CHUNK || ca == SEG_CHUNK || cb + n_in + ca > SEG_SHORT;
+    own0 = !long0 && cb == 0;
+    next = own0 ? ca : 0;
+  } else {
+    long0 = cb == SEG_CHUNK || cb + cf > SEG_SHORT;
+    own0 = !long0 && cb == 0;
+    long1 = ca == SEG_CHUNK || cl + ca > SEG_SHORT;
+    own1 = !long1;
+    next = own1 ? ca : 0;
+  }
+  if (nullf) long0 = false;                                        // never walked: stage B writes its zero
+  if (nulll && !one) long1 = false;
+  // dX may be absent with the FM term alone (fm.py): the row loads then read S instead and are multiplied by 0 -- a load
+  // behind even a uniform condition is waited for on its own, one position after the other
   const bool has_x = dX != nullptr;
-  const bool do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float xm = has_x ? 1.f : 0.f;
+  const size_t xrow = has_x ? (size_t)F * LPR : (size_t)LPR, xoff = has_x ? (size_t)f * LPR + q : (size_t)q;
+  const bool do1 = W1 && q == 0 && ((w1_mask >> f) & 1ull);
   const float4* T4 = reinterpret_cast<const float4*>(tables);
   const float4* S4 = reinterpret_cast<const float4*>(S);
-  const float4* X4 = reinterpret_cast<const float4*>(dX);
+  const float4* X4 = reinterpret_cast<const float4*>(has_x ? dX : S);
   float4* P4 = reinterpret_cast<float4*>(ws.P);
   float4* G4 = reinterpret_cast<float4*>(ws.G);
-  const size_t po = ((size_t)f * nch + ch) * 2;
-  int cur = -1;
-  float4 acc = z;
+  const size_t fs = (size_t)f * stride;
+  const size_t po = ((size_t)f * ((B + SEG_CHUNK - 1) / SEG_CHUNK) + (size_t)(p0 / SEG_CHUNK)) * 2;
+  constexpr int NB = FM ? 8 : 16;                                  // entries whose loads are in flight together
+  RSX_STAMP2(2);
+  float4 acc = F4Z;
   float a1 = 0.f;
-  bool cur_null = false;
-  auto flush = [&](const int j) {
-    if (j < 0) return;
-    if (j == jf) {
-      if (long0) {
-        P4[po * LPR + q] = acc;
-        if (do1) ws.P1[po] = a1;
-      } else if (fin0) {
-        G4[((size_t)f * stride + j) * LPR + q] = acc;
-        if (ws.gw1 != nullptr && q == 0) ws.gw1[(size_t)f * stride + j] = do1 ? a1 : 0.f;
-      }
-    } else if (j == jl) {
-      if (long1) {
-        P4[(po + 1) * LPR + q] = acc;
-        if (do1) ws.P1[po + 1] = a1;
-      } else if (fin1) {
-        G4[((size_t)f * stride + j) * LPR + q] = acc;
-        if (ws.gw1 != nullptr && q == 0) ws.gw1[(size_t)f * stride + j] = do1 ? a1 : 0.f;
-      }
-    } else if (fin) {
-      G4[((size_t)f * stride + j) * LPR + q] = acc;
-      if (ws.gw1 != nullptr && q == 0) ws.gw1[(size_t)f * stride + j] = do1 ? a1 : 0.f;
-    }
+  // The first XE entries of the owned short segment that runs on into the next chunk are requested NOW, with the chunk's
+  // own rows: a load issued after the sums below have been stored could only be waited for together with those stores
+  // (loads and stores share one in-order counter), and most such tails are 1-3 entries long.
+  constexpr int XE = 4;
+  float xg[XE], xh[XE];
+  float4 xs[XE], xx0[XE];
+  const bool nullx = one ? nullf : nulll;
+  const int rowx = FM ? uniq_row[fs + jl] : 0;                     // (unconditional: a guarded load is waited for alone)
+#pragma unroll
+  for (int k = 0; k < XE; ++k) {
+    int bi;
+    size_t bo;
+    ex_locate(xb, prm_l[(g + 1) * SEG_CHUNK + (k < next ? k : 0)], bi, bo);
+    xg[k] = FM ? gy2[bo + bi] : 0.f;
+    xs[k] = FM ? S4[bo / 4 + (size_t)bi * LPR + q] : F4Z;
+    xx0[k] = X4[bo / 4 + (size_t)bi * xrow + xoff];
+    xh[k] = W1 ? gy1[bo + bi] : 0.f;
+  }
+  auto to_G = [&](const int j) {
+    G4[(fs + j) * LPR + q] = acc;
+    if (ws.gw1 != nullptr && q == 0) ws.gw1[fs + j] = do1 ? a1 : 0.f;
+  };
+  auto to_P = [&](const int slot) {
+    P4[(po + slot) * LPR + q] = acc;
+    if (do1) ws.P1[po + slot] = a1;
   };
 #pragma unroll
-  for (int k0 = 0; k0 < SEG_CHUNK; k0 += NB) {         // NB entries' loads in flight, summed in ascending position
+  for (int k0 = 0; k0 < SEG_CHUNK; k0 += NB) {
     float gg[NB], hh[NB];
     float4 ss[NB], xx[NB], ee[NB];
     int rw[NB];
-    bool use[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-      const int pos = p0 + k0 + k, j = sj[k0 + k];
-      use[k] = pos < p1 && (j == jf ? (long0 || fin0) : (j == jl ? (long1 || fin1) : fin));
-      rw[k] = rws[k0 + k];
       int bi;
       size_t bo;
-      ex_locate(xb, pb[k0 + k], bi, bo);
-      gg[k] = fm ? gy2[bo + bi] : 0.f;
-      ss[k] = fm ? S4[bo / 4 + (size_t)bi * LPR + q] : z;
-      xx[k] = has_x ? X4[bo / 4 + ((size_t)bi * F + f) * LPR + q] : z;
-      hh[k] = do1 ? gy1[bo + bi] : 0.f;
+      ex_locate(xb, pb[k0 + k], bi, bo);                           // (positions past B hold the last example: valid, unused)
+      rw[k] = FM ? uniq_row[fs + (sw[SEG_CHUNK + k0 + k] >= 0 ? sw[SEG_CHUNK + k0 + k] : 0)] : 0;
+      gg[k] = FM ? gy2[bo + bi] : 0.f;
+      ss[k] = FM ? S4[bo / 4 + (size_t)bi * LPR + q] : F4Z;
+      xx[k] = X4[bo / 4 + (size_t)bi * xrow + xoff];
+      hh[k] = W1 ? gy1[bo + bi] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < NB; ++k) ee[k] = fm ? T4[(size_t)rw[k] * LPR + q] : z;
+    for (int k = 0; k < NB; ++k) ee[k] = FM ? T4[(size_t)rw[k] * LPR + q] : F4Z;
+    // every load above has landed before the first sum is stored: after a store, the compiler's per-block waits for a
+    // loaded value become "wait for everything", i.e. for the stores (measured: 5.6 us for the 16 positions of a chunk)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+    RSX_STAMP2(3 + (k0 ? 3 : 0));
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-      if (use[k]) {                                     // (group-uniform over the 4 lanes of a row)
-        const int j = sj[k0 + k];
-        if (j != cur) {
-          flush(cur);
-          cur = j;
-          acc = z;
+      const int kp = k0 + k;
+      if (kp < n_in) {                                              // (group-uniform over the LPR lanes of a row)
+        const int j = sw[SEG_CHUNK + kp];
+        const bool isf = j == jf, isl = !one && j == jl;
+        const bool use = isf ? ((long0 || own0) && !nullf) : (isl ? !nulll : true);
+        const bool head = kp == 0 || j != sw[SEG_CHUNK + kp - 1];
+        const bool tail = kp == n_in - 1 || j != sw[SEG_CHUNK + kp + 1];
+        if (head) {
+          acc = F4Z;
           a1 = 0.f;
-          cur_null = null_row >= 0 && rw[k] == null_row;
         }
-        if (!cur_null) {
-          float4 t = z;
-          if (fm) t = f4_sub(f4_scale(gg[k], ss[k]), f4_scale(gg[k], ee[k]));
-          if (has_x) t = fm ? f4_add(t, xx[k]) : xx[k];
+        if (use) {
+          float4 t = F4Z;
+          if (FM) t = f4_sub(f4_scale(gg[k], ss[k]), f4_scale(gg[k], ee[k]));
+          t = FM ? f4_add(t, f4_scale(xm, xx[k])) : xx[k];
           acc = f4_add(acc, t);
-          a1 += hh[k];
+          if (W1) a1 += hh[k];
+        }
+        if (tail) {
+          if (isf) {
+            if (long0) to_P(0);
+            else if (own0 && !(one && next > 0)) to_G(j);          // (a null segment that starts here: its zero)
+          } else if (isl) {
+            if (long1) to_P(1);
+            else if (own1 && next == 0) to_G(j);
+          } else {
+            to_G(j);
+          }
         }
       }
     }
   }
-  flush(cur);
+  RSX_STAMP2(4);
+  // the owned short segment that runs on into the next chunk: its remaining <= 15 entries, in order
+  const float4 ex = FM ? T4[(size_t)rowx * LPR + q] : F4Z;
+#pragma unroll
+  for (int k = 0; k < XE; ++k) {
+    if (k < next && !nullx) {
+      float4 t = F4Z;
+      if (FM) t = f4_sub(f4_scale(xg[k], xs[k]), f4_scale(xg[k], ex));
+      t = FM ? f4_add(t, f4_scale(xm, xx0[k])) : xx0[k];
+      acc = f4_add(acc, t);
+      if (W1) a1 += xh[k];
+    }
+  }
+  for (int k0 = XE; __ballot(k0 < next) != 0ull; k0 += 4) {
+    float gg[4], hh[4];
+    float4 ss[4], xx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int kk = k0 + k < next ? k0 + k : 0;
+      int bi;
+      size_t bo;
+      ex_locate(xb, prm_l[(g + 1) * SEG_CHUNK + kk], bi, bo);
+      gg[k] = FM ? gy2[bo + bi] : 0.f;
+      ss[k] = FM ? S4[bo / 4 + (size_t)bi * LPR + q] : F4Z;
+      xx[k] = X4[bo / 4 + (size_t)bi * xrow + xoff];
+      hh[k] = W1 ? gy1[bo + bi] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k0 + k < next && !nullx) {
+        float4 t = F4Z;
+        if (FM) t = f4_sub(f4_scale(gg[k], ss[k]), f4_scale(gg[k], ex));
+        t = FM ? f4_add(t, f4_scale(xm, xx[k])) : xx[k];
+        acc = f4_add(acc, t);
+        if (W1) a1 += hh[k];
+      }
+    }
+  }
+  if (next > 0) to_G(jl);
+  RSX_STAMP2(5);
 }
 
 template <int D>
@@ -696,6 +874,22 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   bool staged;
   // rows finished by stage A already sit in G / gw1 when stage A was given these buffers: nothing to load or store
   const bool same = part.G == G;
+  if (part.P != nullptr) {     // two-stage: the compact unit list, grid stride
+    constexpr int GPW = RSX_WAVE / LPR;
+    const SegUnits su = seg_units<GPW>(nuniq, part, F, stride);
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; unit < su.total; unit += nwaves) {
+      int f, wf, nu, nl, nh;
+      seg_unit_locate(su, unit, f, wf, nu, nl, nh);
+      if (segsum_wave2<D>(f, wf, nu, nl, nh, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride,
+                          null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same, nullptr) &&
+          valid && !(staged && same)) {
+        reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
+        if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
+      }
+    }
+    return;
+  }
   if (!segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
                       nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same))
     return;
@@ -744,6 +938,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
                                                      int stride, const HotAdam h, const SegPartials part,
                                                      const ExBlocks xb) {
   constexpr int LPR = D / 4;
+  RSX_STAMP3(0);
   const float b1p = h.state[0], b2p = h.state[1];
   const uint32_t n_rows = h.tables2 != nullptr ? 2u * h.n_own : h.n_own;
   if (blockIdx.x >= n_rows + h.win_blk + h.extra.n_blk) {
@@ -818,13 +1013,10 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     int row;
     bool staged;
     AdamRowPrefetch pre{h.tables2, h.m_t2, h.v_t2};
-    if (segsum_wave<D>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr, nullptr,
-                       perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1,
-                       staged, true, &pre) &&
-        valid) {
-      Hp hp;
-      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
-      hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    Hp hp;
+    hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
+    hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    auto update2 = [&]() {
       const size_t o = (size_t)row * LPR + q;
       float4 var = pre.loaded ? pre.var : reinterpret_cast<const float4*>(h.tables2)[o];
       float4 m = pre.loaded ? pre.m : reinterpret_cast<const float4*>(h.m_t2)[o];
@@ -833,6 +1025,24 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       reinterpret_cast<float4*>(h.tables2)[o] = var;
       reinterpret_cast<float4*>(h.m_t2)[o] = m;
       reinterpret_cast<float4*>(h.v_t2)[o] = v;
+    };
+    if (h.part2.P != nullptr) {           // two-stage: the compact unit list, grid stride over this set's workgroups
+      constexpr int GPW = RSX_WAVE / LPR;
+      const SegUnits su = seg_units<GPW>(nuniq, h.part2, F, stride);
+      for (int unit = ((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6; unit < su.total; unit += (int)h.n_own * 4) {
+        int f, wf, nu, nl, nh;
+        seg_unit_locate(su, unit, f, wf, nu, nl, nh);
+        pre.loaded = false;
+        if (segsum_wave2<D>(f, wf, nu, nl, nh, h.tables2, nullptr, h.dX2, nullptr, nullptr, perm, seg_off, uniq_row, nuniq, 0, B,
+                            F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1, staged, true, &pre) &&
+            valid)
+          update2();
+      }
+    } else if (segsum_wave<D>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr,
+                              nullptr, perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e,
+                              row, do1, staged, true, &pre) &&
+               valid) {
+      update2();
     }
   } else {
     const int q = (threadIdx.x & 63) % LPR;
@@ -843,12 +1053,10 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     int row;
     bool staged;
     AdamRowPrefetch pre{h.tables, h.m_t, h.v_t};
-    if (segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                       nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1, staged, true, &pre) &&
-        valid) {
-      Hp hp;
-      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
-      hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    Hp hp;
+    hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
+    hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    auto update1 = [&]() {
       const size_t o = (size_t)row * LPR + q;
       float4 var = pre.loaded ? pre.var : (gy2 != nullptr ? e : reinterpret_cast<const float4*>(h.tables)[o]);
       float4 m = pre.loaded ? pre.m : reinterpret_cast<const float4*>(h.m_t)[o];
@@ -858,14 +1066,37 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       reinterpret_cast<float4*>(h.m_t)[o] = m;
       reinterpret_cast<float4*>(h.v_t)[o] = v;
       if (h.w1 != nullptr && q == 0) adam_dense1(h.w1[row], h.m_w[row], h.v_w[row], do1 ? a1 : 0.f, hp);
+    };
+    if (part.P != nullptr) {              // two-stage: the compact unit list, grid stride over the row workgroups
+      constexpr int GPW = RSX_WAVE / LPR;
+      const SegUnits su = seg_units<GPW>(nuniq, part, F, stride);
+      for (int unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; unit < su.total; unit += (int)h.n_own * 4) {
+        int f, wf, nu, nl, nh;
+        seg_unit_locate(su, unit, f, wf, nu, nl, nh);
+        pre.loaded = false;
+        if (segsum_wave2<D>(f, wf, nu, nl, nh, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride,
+                            -1, part, xb, valid, sl, acc, a1, e, row, do1, staged, true, &pre) &&
+            valid)
+          update1();
+      }
+      RSX_STAMP3(1);
+    } else {
+      const bool any = segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off,
+                                      uniq_row, nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1,
+                                      staged, true, &pre);
+      RSX_STAMP3(1);
+      if (any && valid) update1();
     }
   }
+  RSX_STAMP3(2);
   __syncthreads();
+  RSX_STAMP3(3);
   if (threadIdx.x == 0 && adam_arrive_last(h.state, h.total_blocks) && h.advance) {
     h.state[0] = b1p * h.b1;
     h.state[1] = b2p * h.b2;
     reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
   }
+  RSX_STAMP3(4);
 }
 
 // ------------------------------------------------------------------ C ABI ----------------------
@@ -895,16 +1126,18 @@ static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* ta
                                           stride, null_row, part, xb);
 }
 template <int D>
-static void launch_partials(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
-                            const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
-                            const int32_t* uniq_row, const SegPartials& ws, uint64_t mask, int B, int F, int stride,
-                            int null_row, const ExBlocks& xb) {
-  if (gy2 != nullptr)
-    segsum_partials_k<D, true><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F, stride,
-                                                       null_row, xb);
-  else
-    segsum_partials_k<D, false><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws, mask, B, F,
-                                                        stride, null_row, xb);
+static void launch_tiles(dim3 grid, hipStream_t st, const float* tables, const float* S, const float* dX,
+                         const float* gy1, const float* gy2, const int32_t* perm, const int32_t* uniq_row,
+                         const SegPartials& ws, uint64_t mask, int B, int F, int stride, int null_row, const ExBlocks& xb) {
+  constexpr size_t lds = SegTile<D / 4>::lds_bytes;
+#define RSX_TILES(FM, W1) \
+  segsum_tiles_k<D, FM, W1><<<grid, dim3(256), lds, st>>>(tables, S, dX, gy1, gy2, perm, uniq_row, ws, mask, B, F, stride, null_row, xb)
+  if (gy2 != nullptr) {
+    if (gy1 != nullptr) RSX_TILES(true, true); else RSX_TILES(true, false);
+  } else {
+    if (gy1 != nullptr) RSX_TILES(false, true); else RSX_TILES(false, false);
+  }
+#undef RSX_TILES
 }
 // host view of the rank-blocked input layout; nullptr -> contiguous
 static inline int ex_blocks(const rsx_example_blocks* h, int B, ExBlocks& out) {
@@ -1053,7 +1286,9 @@ static int segsum_impl(const float* tables, const float* S, const float* dX, con
   if (rcb != RSX_OK) return rcb;
   const int gpw = 64 / (D / 4);                                   // unique rows per wave
   const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);   // two-stage: + helpers
-  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  long long wgs = (waves + 3) / 4;
+  if (part.P != nullptr && wgs > SEG_STAGE_B_MAX_WG) wgs = SEG_STAGE_B_MAX_WG;   // (grid stride over the compact unit list)
+  const dim3 grid((unsigned)wgs), block(256);
   RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
                  nuniq, G, gw1, w1_field_mask, B, F, stride, null_row, part, xb);
   RSX_CHECK_LAUNCH();
@@ -1084,12 +1319,12 @@ extern "C" int rsx_segsum_partials(const float* tables, const float* S, const fl
   ExBlocks xb;
   const int rcb = ex_blocks(blocks_h, B, xb);
   if (rcb != RSX_OK) return rcb;
-  const int gpw = 64 / (D / 4);                                   // chunks per wave
-  const int nch = (B + SEG_CHUNK - 1) / SEG_CHUNK;
-  const long long waves = (long long)F * ((nch + gpw - 1) / gpw);
-  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  RSX_DISPATCH_D(D, launch_partials, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws,
-                 w1_field_mask, B, F, stride, null_row, xb);
+  if (ws.G == nullptr) return RSX_EINVAL;                          // stage A finishes the short segments into G (/ gw1)
+  if (gy2 == nullptr && dX == nullptr) return RSX_EINVAL;          // nothing to sum
+  const int pos = (256 / (D / 4)) * SEG_CHUNK;                     // sorted positions per workgroup
+  const dim3 grid((unsigned)((size_t)F * ((B + pos - 1) / pos)));
+  RSX_DISPATCH_D(D, launch_tiles, grid, rsx_s(stream), tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F,
+                 stride, null_row, xb);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1145,6 +1380,7 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   const int gpw = 64 / (D / 4);
   const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);
   h.n_own = (uint32_t)((waves + 3) / 4);
+  if (part.P != nullptr && h.n_own > (uint32_t)SEG_STAGE_B_MAX_WG) h.n_own = SEG_STAGE_B_MAX_WG;   // (grid stride, compact units)
   const int rcs = adam_build_slice(sweep_h, h.cold);
   if (rcs != RSX_OK) return rcs;
   // A VEC_COLD slice rewrites (restores) the touched elements of its float4s: racing with this launch's own update of
@@ -1204,3 +1440,10 @@ extern "C" int rsx_copy_bytes(void* dst, const void* src, size_t nbytes, rsx_str
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
+
+#ifdef RSX_STAMPS
+// profiling build only: copy this unit's phase stamps (100 MHz wall clock ticks) to the host
+extern "C" int rsx_dbg_stamps_embedding(unsigned long long* out_h) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(rsx_stamps_d), sizeof(unsigned long long) * 64) == hipSuccess ? RSX_OK : RSX_ELAUNCH;
+}
+#endif

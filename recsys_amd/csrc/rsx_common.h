@@ -14,6 +14,12 @@
 
 static inline hipStream_t rsx_s(rsx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A zero float4 is always this literal.  A NAMED zero (`const float4 z = make_float4(0, 0, 0, 0)`) that is selected against
+// (`ok ? load : z`) is placed in scratch memory by this toolchain; every use reloads it and waits with `s_waitcnt
+// vmcnt(0)` -- i.e. for every load AND store in flight (found with phase stamps in segsum_tiles_k: 5.6 us for 16
+// position sums; the literal is rematerialised in registers).
+#define F4Z make_float4(0.f, 0.f, 0.f, 0.f)
+
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }

@@ -517,7 +517,6 @@ __device__ __forceinline__ void bwd_dx_group_tile(const BwdArgs& p, const int bi
   const int ngrp = (p.ct_k + p.dxg - 1) / p.dxg;
   const int grp = bid % ngrp, rt = bid / ngrp;
   const float Bf = (float)p.B;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // (1) tile loads first: a, dy rows (kept in registers until the constants are there) ...
   float4 av[2], dv[2];                              // 16 * N/4 float4 over 256 threads: <= 2 each (N <= 128, host-checked)
 #pragma unroll
@@ -556,7 +555,7 @@ __device__ __forceinline__ void bwd_dx_group_tile(const BwdArgs& p, const int bi
       if (e < tot) {
         const int r = e / LD4, c4 = e - r * LD4;
         const bool ok = grp * p.dxg * 16 + r < p.K && c4 < N4;
-        reinterpret_cast<float4*>(sW + r * LD)[c4] = ok ? v : z4;
+        reinterpret_cast<float4*>(sW + r * LD)[c4] = ok ? v : F4Z;
       }
     };
     for (int e0 = tid; e0 < tot; e0 += 256 * 4) {
@@ -574,7 +573,7 @@ __device__ __forceinline__ void bwd_dx_group_tile(const BwdArgs& p, const int bi
   }
   for (int e = tid; e < 16 * ((LD - p.N) >> 2) ; e += 256) {      // zero the k padding of the da tile
     const int r = e / ((LD - p.N) >> 2), c4 = e - r * ((LD - p.N) >> 2);
-    reinterpret_cast<float4*>(sA + r * LD + p.N)[c4] = z4;
+    reinterpret_cast<float4*>(sA + r * LD + p.N)[c4] = F4Z;
   }
   __syncthreads();
   RSX_STAMP(first ? 17 : 25, bid == 0);

@@ -105,13 +105,10 @@ class EmbeddingArena:
         return b
 
     def _bind_partials(self):
-        # (G / gw1: stage A finishes the segments that lie inside one chunk straight into the scatter's outputs;
-        # RSX_STAGE_A_FINAL=0 restores the long-segment-partials-only stage A for A/B runs)
+        # (G / gw1: stage A finishes every segment of <= 16 entries straight into the scatter's outputs)
         self.partials = None
         if self.two_stage_ws:
-            fin = os.environ.get("RSX_STAGE_A_FINAL", "1") != "0"
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G) if fin else None,
-                                             _ptr(self.gw1) if fin else None)
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1))
 
     def select(self, i):
         """Makes sort workspace i (position i of the optimizer window) the one field_sort / sort_job / segsum* use."""
@@ -760,7 +757,7 @@ class SparseTable:
         nch = (self.cap + 15) // 16
         self.segid = torch.zeros(self.cap + 2 + nch, **i32)
         self.P = torch.zeros(nch * 2, self.K, device=dev)
-        self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), None, None, None)
+        self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), None, _ptr(self.G), None)
         self.hook = torch.zeros((), device=dev, requires_grad=True)
         self.pending = []
         self._seq = 0
