@@ -125,7 +125,16 @@ typedef struct {
                                  here; the stage-B entry points pick those rows up (rsx_segsum_bwd with the same G: nothing
                                  left to do for them).  NULL: stage A only produces the long segments' chunk partials.   */
   float* gw1;
+  /* Padding rows (DIN's history padding, din/din.py:56-57,107: their entries carry exactly-zero gradients by construction, so
+   * their -- huge -- segments need not be walked).  null_row >= 0: that global row; RSX_NULL_LAST_ROW: the LAST row of every
+   * field, row_off[f + 1] - 1 (row_off required then: a dummy row appended to each table, to which the padding entries' keys
+   * are mapped -- this keeps a real row 0 usable by ordinary lookups); RSX_NULL_NONE: none.  Read by the stage-A / stage-B
+   * entry points that take this struct (the explicit null_row arguments of rsx_segsum_partials / _rows still work).    */
+  const int32_t* row_off;
+  int32_t null_row;
 } rsx_seg_partials;
+#define RSX_NULL_NONE (-1)
+#define RSX_NULL_LAST_ROW (-2)
 /* Layout of the per-example inputs (dX, S, gy1, gy2) when they are read in place from an all-gathered buffer (data
  * parallel): example e lives in rank block e / examples at local index e % examples; blocks are stride_floats apart
  * (a multiple of 4) and each pointer names its array inside block 0.  NULL = contiguous over the batch.            */
@@ -255,6 +264,19 @@ int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
                          const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
                          const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state, int advance_step,
                          float lr, float beta1, float beta2, float eps, rsx_stream_t stream);
+/* The same with two options for the first-order vector: its elements w1_stride floats apart (4: column 0 of a 4-wide table,
+ * as DIN's item bias is stored), and w1_sparse_formula != 0: the sparse (IndexedSlices) Adam formula -- the vector is a 1-D
+ * variable read through tf.gather (din/din.py:96,139), not the kernel of a dense layer on one-hot input (fm/fm.py:121) --
+ * applied to the rows of the fields in w1_field_mask only.                                                            */
+int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w, const float* S,
+                          const float* dX, const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                          const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D,
+                          int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
+                          const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
+                          const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state, int advance_step,
+                          float lr, float beta1, float beta2, float eps, int w1_stride, int w1_sparse_formula,
+                          rsx_stream_t stream);
+
 /* second_h (nullable): a second table set looked up with the SAME ids (one sort serves both: xDeepFM's two input_layer
  * calls, xdeepfm/xdeepfm.py:125,185); its row-owner workgroups run in the same launch.  It has no first-order vector and
  * no FM term; its gradient rows dX use the same example blocks.                                                      */
@@ -333,6 +355,28 @@ int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const f
  * dW tile's reduction over the batch into up to 32 row blocks; a second small launch adds the partial tiles in ascending
  * block order (deterministic).  Without it one workgroup per tile walks the whole batch.                               */
 size_t rsx_tower_bwd_workspace_floats(int B, int K, int N);
+/* Large batches: a layer's weight gradient leaves rsx_tower_bwd_layer as partial sums over blocks of batch rows, added in
+ * block order by a small second launch.  rsx_tower_bwd_layer_defer hands that reduction back as a job instead (reduce_out->sb
+ * == 0: nothing to do); rsx_tower_reduce_dw_jobs runs the jobs of ALL layers in one launch at the end of the backward pass
+ * (dW is first read by the optimizer).  Same arithmetic, same order per layer.                                          */
+#define RSX_DW_REDUCE_MAX_JOBS 4
+typedef struct {
+  const float* partials;
+  float* dW;
+  float* db;
+  int32_t sb, K, N;
+  int32_t layout;            /* 0: [tiles][sb][256] tile-major, 1: [sb][K+1 rounded to 16][N rounded to 16] */
+} rsx_dw_reduce_job;
+int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, const float* dy, const double* bstat,
+                              const float* bn, const float* gamma, float* dW, float* db, float* dgamma, float* dbeta,
+                              const float* bn_prev, const float* gamma_prev, const float* beta_prev, const float* mask_prev,
+                              float* dy_prev, double* bstat_prev, const double* hpart, const float* dwd_part, float* dwd,
+                              float* dbd, float* dwo, float* dbo, float* dc0, float* loss, const uint32_t* rng_step,
+                              uint32_t seed, int layer, float dropout_rate, int B, int K, int N, const rsx_sort_job* sort_h,
+                              const rsx_adam_slice* sweep_h, float* dw_partials, rsx_dw_reduce_job* reduce_out,
+                              rsx_stream_t stream);
+int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njobs, rsx_stream_t stream);
+
 /* sweep_h (host pointer, nullable, on all three tower entry points): a slice of the untouched-row optimizer sweep
  * (see rsx_adam_slice) executed by extra workgroups appended after the launch's own ones -- the HBM-bound stream fills the
  * CUs the latency-bound tower workgroups leave idle.
@@ -366,6 +410,39 @@ int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* ids, float* 
 /* dH[b,p,:] (+)= dout[b,:] * w[b,p] * mask ;  dw[b,p] = <H[b,p,:], dout[b,:]> * mask                              */
 int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH, float* dw,
                      int accumulate, int B, int P, int K, rsx_stream_t stream);
+/* The same two with row strides (floats, multiples of 4): `out` / `dout` may be column slices of a wider [B, ld] matrix (the
+ * 'mlp_layer' concat din/din.py:131 and its gradient, never materialised as copies), dH rows may be interleaved with another
+ * table's gradient rows (the [entries, 2, K] value block of the two-table scatter).                                       */
+int rsx_din_pool_fwd_ld(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K, int ld_out,
+                        rsx_stream_t stream);
+int rsx_din_pool_bwd_ld(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH, float* dw,
+                        int accumulate, int B, int P, int K, int ld_dout, int ld_dH, rsx_stream_t stream);
+
+/* Several plain row gathers (tf.gather / tf.nn.embedding_lookup of one table each, din/din.py:96-105) in ONE launch:
+ * out[e, 0:K] = table[row_base + ids[e], 0:K], e < n, `out` rows ld_out floats apart.  Host array of <= 8 jobs.             */
+#define RSX_GATHER_MAX_JOBS 8
+typedef struct {
+  const float* table;
+  const int32_t* ids;
+  float* out;
+  int64_t n;
+  int32_t K, ld_out, row_base;
+} rsx_gather_job;
+int rsx_gather_rows_multi(const rsx_gather_job* jobs_h, int njobs, rsx_stream_t stream);
+
+/* Sort keys of DIN's two id tables (item, category) for one step: keys2 [B*(P+1), 2] int32; entry e < B = the target lookup
+ * of example e (i_id, i_cate: din/din.py:100-101), entry B + b*P + p = history position (b, p) (:105) with padding ids (<= 0,
+ * :107) mapped to the table's dummy last row (see rsx_seg_partials.null_row).                                               */
+int rsx_din_keys(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B, int P,
+                 int dummy_item_row, int dummy_cate_row, int32_t* keys2, rsx_stream_t stream);
+/* rsx_din_keys + rsx_din_valid_rows of BOTH histories in two launches (the fused TRAIN step of din.py): keys2 as above;
+ * rows_x / count_x / w_x as rsx_din_valid_rows (ascending list of the positions of history x that are not padding, its length
+ * in count_x[0], count_x + 1: ceil(B*P/1024) ints of scratch, w_x nullable: zeroed at the padded positions).              */
+int rsx_din_prepare(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B, int P,
+                    int dummy_item_row, int dummy_cate_row, int32_t* keys2, int32_t* rows_i, int32_t* count_i, float* w_i,
+                    int32_t* rows_c, int32_t* count_c, float* w_c, rsx_stream_t stream);
+
+
 /* Fused attention MLP of `_attention` (din/din.py:111-121): for every history position m = (b, p)
  *   w[m] = W2 . drop(relu(W1^T . drop(relu(W0^T . [h, q, h*q, h-q] + b0)) + b1)) + b2,   h = H[m,:], q = q[b,:]
  * without materialising the [B*P, 4K] concat; a1 [M,N1] / a2 [M,N2] (relu outputs before dropout) are saved for the
@@ -397,6 +474,16 @@ int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const floa
                      const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
                      float dropout_rate, int accumulate_dH, const int32_t* rows, const int32_t* count, const int32_t* ids,
                      int B, int P, int K, int N1, int N2, rsx_stream_t stream);
+/* The same with row strides (floats): dH rows ld_dH apart (interleaved with another table's gradient rows), dq rows ld_dq
+ * apart, and optionally dq = dq_add (rows ld_dq_add apart) + the attention's query gradient -- the target item embedding
+ * also feeds the final MLP directly (din/din.py:131), so its two gradients leave as one row of the scatter's value block.  */
+int rsx_din_attn_bwd_ld(const float* H, const float* q, const float* W0, const float* W1, const float* W2, const float* a1,
+                        const float* a2, const float* dw, float* dH, float* dq, float* grads, float* workspace,
+                        const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
+                        float dropout_rate, int accumulate_dH, const int32_t* rows, const int32_t* count, const int32_t* ids,
+                        int B, int P, int K, int N1, int N2, int ld_dH, int ld_dq, const float* dq_add, int ld_dq_add,
+                        rsx_stream_t stream);
+
 /* accumulate_dH != 0: dH += (rsx_din_pool_bwd has already written its share of the gradient of H into the same buffer).
  * rows / count / ids (nullable together): the forward's row list and the [B*P] ids it came from; only listed positions get
  * their dH written (accumulated) and contribute to dq.                                                                   */

@@ -34,7 +34,24 @@ class ExampleBlocks(C.Structure):
 
 
 class SegPartials(C.Structure):
-    _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p), ("G", C.c_void_p), ("gw1", C.c_void_p)]
+    _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p), ("G", C.c_void_p), ("gw1", C.c_void_p),
+                ("row_off", C.c_void_p), ("null_row", C.c_int32)]
+
+    def __init__(self, segid=None, P=None, P1=None, G=None, gw1=None, row_off=None, null_row=-1):
+        super().__init__(segid, P, P1, G, gw1, row_off, null_row)
+
+
+NULL_NONE, NULL_LAST_ROW = -1, -2          # include/rsx.h RSX_NULL_*
+
+
+class DwReduceJob(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("sb", C.c_int32), ("K", C.c_int32),
+                ("N", C.c_int32), ("layout", C.c_int32)]
+
+
+class GatherJob(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("ids", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("K", C.c_int32),
+                ("ld_out", C.c_int32), ("row_base", C.c_int32)]
 
 
 class TableSet(C.Structure):
@@ -89,8 +106,12 @@ _SIGS = {
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P, _P]),
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
+    "rsx_tower_bwd_layer_defer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "rsx_tower_reduce_dw_jobs": (_I, [_P, _I, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),
+    "rsx_segsum_adam_rows2": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F,
+                                   _I, _I, _P]),
     "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
@@ -100,6 +121,12 @@ _SIGS = {
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_fwd": (_I, [_P] * 4 + [_I, _I, _I, _P]),
+    "rsx_din_pool_fwd_ld": (_I, [_P] * 4 + [_I, _I, _I, _I, _P]),
+    "rsx_din_pool_bwd_ld": (_I, [_P] * 6 + [_I, _I, _I, _I, _I, _I, _P]),
+    "rsx_gather_rows_multi": (_I, [_P, _I, _P]),
+    "rsx_din_keys": (_I, [_P] * 4 + [_I, _I, _I, _I, _P, _P]),
+    "rsx_din_prepare": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P] * 8),
+    "rsx_din_attn_bwd_ld": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P, _P]),
     "rsx_din_attn_fwd": (_I, [_P] * 14 + [C.c_uint32, _I, _F, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -9,7 +9,7 @@
 template <int K>
 __global__ __launch_bounds__(256) void din_pool_fwd_k(const float* __restrict__ H, const float* __restrict__ w,
                                                       const int32_t* __restrict__ ids, float* __restrict__ out, int B,
-                                                      int P) {
+                                                      int P, int ldo) {
   constexpr int LPR = K / 4, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void din_pool_fwd_k(const float* __restrict__ 
   }
 #pragma unroll
   for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
-  if (j == 0) reinterpret_cast<float4*>(out)[(size_t)b * LPR + q] = acc;
+  if (j == 0) *reinterpret_cast<float4*>(out + (size_t)b * ldo + 4 * q) = acc;   // (ldo: row stride of `out`, floats)
 }
 
 // dH[b,p,:] (+)= dout[b,:] * w[b,p] * mask ;  dw[b,p] = <H[b,p,:], dout[b,:]> * mask.
@@ -43,13 +43,13 @@ template <int K>
 __global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ H, const float* __restrict__ w,
                                                       const int32_t* __restrict__ ids, const float* __restrict__ dout,
                                                       float* __restrict__ dH, float* __restrict__ dw, int accumulate,
-                                                      int B, int P) {
+                                                      int B, int P, int ldg, int ldh) {
   constexpr int LPR = K / 4, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int q = lane % LPR, j = lane / LPR;
-  const float4 g = reinterpret_cast<const float4*>(dout)[(size_t)b * LPR + q];
+  const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)b * ldg + 4 * q);     // (ldg / ldh: row strides, floats)
   for (int p0 = 0; p0 < P; p0 += RPW) {   // wave-uniform trip count: the shuffles below need every lane
     const int p = p0 + j;
     const bool in = p < P;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ 
 #pragma unroll
     for (int m = 1; m < LPR; m <<= 1) d += __shfl_xor(d, m);
     if (in) {
-      float4* dst = reinterpret_cast<float4*>(dH) + e * LPR + q;
+      float4* dst = reinterpret_cast<float4*>(dH + e * ldh + 4 * q);
       *dst = accumulate ? f4_add(*dst, o) : o;
       if (q == 0) dw[e] = d;
     }
@@ -178,45 +178,135 @@ __global__ __launch_bounds__(256) void sorted_long_lists_k(const int32_t* __rest
 }
 
 template <int K>
-static void launch_pool_fwd(hipStream_t st, const float* H, const float* w, const int32_t* ids, float* out, int B, int P) {
-  din_pool_fwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, out, B, P);
+static void launch_pool_fwd(hipStream_t st, const float* H, const float* w, const int32_t* ids, float* out, int B, int P,
+                            int ldo) {
+  din_pool_fwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, out, B, P, ldo);
 }
 template <int K>
 static void launch_pool_bwd(hipStream_t st, const float* H, const float* w, const int32_t* ids, const float* dout,
-                            float* dH, float* dw, int acc, int B, int P) {
-  din_pool_bwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, dout, dH, dw, acc, B, P);
+                            float* dH, float* dw, int acc, int B, int P, int ldg, int ldh) {
+  din_pool_bwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, dout, dH, dw, acc, B, P, ldg, ldh);
 }
 
-extern "C" int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K,
-                                rsx_stream_t stream) {
+extern "C" int rsx_din_pool_fwd_ld(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K,
+                                   int ld_out, rsx_stream_t stream) {
   if (B < 0 || P <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  if (!H || !w || !ids || !out) return RSX_EINVAL;
+  if (!H || !w || !ids || !out || ld_out < K || (ld_out & 3)) return RSX_EINVAL;
   switch (K) {
-    case 4: launch_pool_fwd<4>(rsx_s(stream), H, w, ids, out, B, P); break;
-    case 8: launch_pool_fwd<8>(rsx_s(stream), H, w, ids, out, B, P); break;
-    case 16: launch_pool_fwd<16>(rsx_s(stream), H, w, ids, out, B, P); break;
-    case 32: launch_pool_fwd<32>(rsx_s(stream), H, w, ids, out, B, P); break;
-    case 64: launch_pool_fwd<64>(rsx_s(stream), H, w, ids, out, B, P); break;
+    case 4: launch_pool_fwd<4>(rsx_s(stream), H, w, ids, out, B, P, ld_out); break;
+    case 8: launch_pool_fwd<8>(rsx_s(stream), H, w, ids, out, B, P, ld_out); break;
+    case 16: launch_pool_fwd<16>(rsx_s(stream), H, w, ids, out, B, P, ld_out); break;
+    case 32: launch_pool_fwd<32>(rsx_s(stream), H, w, ids, out, B, P, ld_out); break;
+    case 64: launch_pool_fwd<64>(rsx_s(stream), H, w, ids, out, B, P, ld_out); break;
     default: return RSX_EUNSUPPORTED;
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
+extern "C" int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K,
+                                rsx_stream_t stream) {
+  return rsx_din_pool_fwd_ld(H, w, ids, out, B, P, K, K, stream);
+}
 
-extern "C" int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH,
-                                float* dw, int accumulate, int B, int P, int K, rsx_stream_t stream) {
+extern "C" int rsx_din_pool_bwd_ld(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH,
+                                   float* dw, int accumulate, int B, int P, int K, int ld_dout, int ld_dH,
+                                   rsx_stream_t stream) {
   if (B < 0 || P <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
-  if (!H || !w || !ids || !dout || !dH || !dw) return RSX_EINVAL;
+  if (!H || !w || !ids || !dout || !dH || !dw || ld_dout < K || (ld_dout & 3) || ld_dH < K || (ld_dH & 3)) return RSX_EINVAL;
+#define RSX_POOL_BWD(KK) launch_pool_bwd<KK>(rsx_s(stream), H, w, ids, dout, dH, dw, accumulate, B, P, ld_dout, ld_dH)
   switch (K) {
-    case 4: launch_pool_bwd<4>(rsx_s(stream), H, w, ids, dout, dH, dw, accumulate, B, P); break;
-    case 8: launch_pool_bwd<8>(rsx_s(stream), H, w, ids, dout, dH, dw, accumulate, B, P); break;
-    case 16: launch_pool_bwd<16>(rsx_s(stream), H, w, ids, dout, dH, dw, accumulate, B, P); break;
-    case 32: launch_pool_bwd<32>(rsx_s(stream), H, w, ids, dout, dH, dw, accumulate, B, P); break;
-    case 64: launch_pool_bwd<64>(rsx_s(stream), H, w, ids, dout, dH, dw, accumulate, B, P); break;
+    case 4: RSX_POOL_BWD(4); break;
+    case 8: RSX_POOL_BWD(8); break;
+    case 16: RSX_POOL_BWD(16); break;
+    case 32: RSX_POOL_BWD(32); break;
+    case 64: RSX_POOL_BWD(64); break;
     default: return RSX_EUNSUPPORTED;
   }
+#undef RSX_POOL_BWD
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+extern "C" int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH,
+                                float* dw, int accumulate, int B, int P, int K, rsx_stream_t stream) {
+  return rsx_din_pool_bwd_ld(H, w, ids, dout, dH, dw, accumulate, B, P, K, K, K, stream);
+}
+
+// ---- several row gathers in ONE launch (din/din.py:96-105: i_item / i_id / i_cate looked up by the target ids and by the
+// two id histories: five tf.gather / embedding_lookup calls per step) ----------------------------------------------------------
+struct GatherJobs {
+  rsx_gather_job j[RSX_GATHER_MAX_JOBS];
+  uint32_t blk_end[RSX_GATHER_MAX_JOBS];     // workgroups of jobs 0 .. i
+};
+__global__ __launch_bounds__(256) void gather_rows_multi_k(const GatherJobs g) {
+  // (job selection by an unrolled chain of compile-time indices: a dynamically indexed by-value struct lives in scratch)
+  rsx_gather_job jb = g.j[0];
+  uint32_t b0 = 0;
+#pragma unroll
+  for (int k = 1; k < RSX_GATHER_MAX_JOBS; ++k) {
+    if (blockIdx.x >= g.blk_end[k - 1]) {
+      jb = g.j[k];
+      b0 = g.blk_end[k - 1];
+    }
+  }
+  const int lpr = jb.K >> 2;
+  const long long t = (long long)(blockIdx.x - b0) * 256 + threadIdx.x;
+  const long long e = t / lpr;
+  if (e >= jb.n) return;
+  const int q = (int)(t - e * lpr);
+  const long long row = (long long)jb.row_base + jb.ids[e];
+  *reinterpret_cast<float4*>(jb.out + e * jb.ld_out + 4 * q) = reinterpret_cast<const float4*>(jb.table)[row * lpr + q];
+}
+
+extern "C" int rsx_gather_rows_multi(const rsx_gather_job* jobs_h, int njobs, rsx_stream_t stream) {
+  if (!jobs_h || njobs <= 0 || njobs > RSX_GATHER_MAX_JOBS) return RSX_EINVAL;
+  GatherJobs g;
+  uint32_t end = 0;
+  for (int k = 0; k < RSX_GATHER_MAX_JOBS; ++k) {
+    const rsx_gather_job& j = jobs_h[k < njobs ? k : njobs - 1];
+    if (k < njobs) {
+      if (!j.table || !j.ids || !j.out || j.n < 0 || j.K <= 0 || (j.K & 3) || j.ld_out < j.K || (j.ld_out & 3)) return RSX_EINVAL;
+      end += (uint32_t)((j.n * (j.K >> 2) + 255) / 256);
+    }
+    g.j[k] = j;
+    g.blk_end[k] = end;
+  }
+  if (end == 0) return RSX_OK;
+  hipLaunchKernelGGL(gather_rows_multi_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+// ---- the sort keys of DIN's two id tables in one launch: entry e < B = the target lookup of example e, entry B + b*P + p =
+// history position (b, p); a padding position (id <= 0, din/din.py:107) gets the field's DUMMY row (the table's last row:
+// never looked up, zero gradient), so that a real row 0 stays an ordinary row.  keys2 [B + B*P, 2] (item, category). ---------
+__global__ __launch_bounds__(256) void din_keys_k(const int32_t* __restrict__ i_id, const int32_t* __restrict__ i_cate,
+                                                  const int32_t* __restrict__ hist_i, const int32_t* __restrict__ hist_c, int B,
+                                                  long long BP, int dummy_i, int dummy_c, int32_t* __restrict__ keys2) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= B + BP) return;
+  int a, c;
+  if (e < B) {
+    a = i_id[e];
+    c = i_cate[e];
+  } else {
+    a = hist_i[e - B];
+    c = hist_c[e - B];
+    a = a > 0 ? a : dummy_i;
+    c = c > 0 ? c : dummy_c;
+  }
+  reinterpret_cast<int2*>(keys2)[e] = make_int2(a, c);
+}
+
+extern "C" int rsx_din_keys(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
+                            int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, rsx_stream_t stream) {
+  if (B < 0 || P < 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!i_id || !i_cate || !hist_i || !hist_c || !keys2) return RSX_EINVAL;
+  const long long n = (long long)B * (P + 1);
+  hipLaunchKernelGGL(din_keys_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, rsx_s(stream), i_id, i_cate, hist_i, hist_c, B,
+                     (long long)B * P, dummy_item_row, dummy_cate_row, keys2);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

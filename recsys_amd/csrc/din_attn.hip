@@ -222,13 +222,13 @@ extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0,
 //   dW1 += a1d^T . g2,  dW0 += [h,q,h*q,h-q]^T . g1   reduction over the block's 64 rows, operands from the block's LDS
 //                                                     tiles, output tiles split over the 4 waves and kept in registers
 //                                                     across ALL blocks of the workgroup
-// Every workgroup writes ONE partial of all weight gradients; din_attn_reduce_k adds the partials in workgroup order.
+// Every workgroup writes ONE partial of all weight gradients; din_attn_finish_k adds the partials in workgroup order.
 // =====================================================================================================================
 struct AttnBwdArgs {
   const float* H; const float* q; const float* W0; const float* W1; const float* W2;
   const float* a1; const float* a2; const float* dw;     // dw [M]: gradient of the logits
   float* dH;            // [M, K]
-  float* dqr;           // [M, K] per-row query gradient (summed over p by din_attn_dq_k)
+  float* dqr;           // [M, K] per-row query gradient (summed over p by din_attn_finish_k)
   float* part;          // [G, NPART] weight-gradient partials
   const float* mask1; const float* mask2;
   const uint32_t* rng_step;
@@ -236,6 +236,7 @@ struct AttnBwdArgs {
   float rate;
   int M, P, N1, N2, nblk;
   int acc_dH;           // dH += (the pooling backward already wrote its part of the same gradient)
+  int ldh;              // row stride of dH (floats; K when dense)
   const int32_t* rows;  // optional row list, as in the forward: only rows[0 .. count[0]) are walked (their dH / dqr written)
   const int32_t* count;
 };
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
           if (blk * 64 + row < Mv) {
             const float hv = sH[col * LDR + row], qv = sQ[col * LDR + row];
             const float dh = (dx[0][r] + dx[2][r] * qv) + dx[3][r];
-            p.dH[mm * K + col] = p.acc_dH ? p.dH[mm * K + col] + dh : dh;
+            p.dH[mm * p.ldh + col] = p.acc_dH ? p.dH[mm * p.ldh + col] + dh : dh;
             p.dqr[mm * K + col] = (dx[1][r] + dx[2][r] * hv) - dx[3][r];
           }
         }
@@ -548,69 +549,78 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
   }
 }
 
-// grads[j] = sum over the G workgroup partials.  block = 1024 = 16 waves x 64 elements: wave w adds the contiguous
-// partial range [w*per, (w+1)*per) (8 loads in flight), the 16 sub-sums are then added in ascending wave order -- a fixed
-// association with 16x shorter dependent chains than one thread walking all G partials.
-__global__ __launch_bounds__(1024) void din_attn_reduce_k(const float* __restrict__ part, int G, int n,
-                                                          float* __restrict__ grads) {
+// Two small jobs that only need the backward kernel's outputs, as ONE launch of 1024-thread workgroups:
+//   * grads[j] = sum over the G workgroup partials: 16 waves x 64 elements, wave w adds the contiguous partial range
+//     [w*per, (w+1)*per) (8 loads in flight), the 16 sub-sums are then added in ascending wave order -- a fixed association
+//     with 16x shorter dependent chains than one thread walking all G partials;
+//   * dq[b, c] = sum_p dqr[b*P + p, c] (+ add[b, c]): 256 threads per example = (256/K) position groups x K columns; group g
+//     adds positions g, g+G', ... (ascending), the groups are then added in ascending order.  valid (nullable, [B*P] ids):
+//     with a row list only the positions whose id is > 0 were written to dqr -- the others are selected away (never
+//     multiplied: they may hold anything).  dq rows ld_dq floats apart; add (nullable, rows ld_add apart): a second gradient of
+//     the same query added on the way out (din/din.py:131: the target item embedding also feeds the final MLP directly).
+// workgroups [0, nr) reduce 64 weight-gradient elements each, the rest take 4 examples each.
+__global__ __launch_bounds__(1024) void din_attn_finish_k(const float* __restrict__ part, int G, int n, float* __restrict__ grads,
+                                                          int nr, const float* __restrict__ dqr, float* __restrict__ dq, int B,
+                                                          int P, int K, const int32_t* __restrict__ valid, int ld_dq,
+                                                          const float* __restrict__ add, int ld_add) {
   __shared__ float sub[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + lane;
-  const int per = (G + 15) / 16;
-  const int g0 = w * per, g1 = g0 + per < G ? g0 + per : G;
-  float s = 0.f;
-  if (j < n) {
-    int g = g0;
-    for (; g + 8 <= g1; g += 8) {
-      float t[8];
+  if ((int)blockIdx.x < nr) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int per = (G + 15) / 16;
+    const int g0 = w * per, g1 = g0 + per < G ? g0 + per : G;
+    float s = 0.f;
+    if (j < n) {
+      int g = g0;
+      for (; g + 8 <= g1; g += 8) {
+        float t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(g + u) * n + j];
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(g + u) * n + j];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += t[u];
+        for (int u = 0; u < 8; ++u) s += t[u];
+      }
+      for (; g < g1; ++g) s += part[(size_t)g * n + j];
     }
-    for (; g < g1; ++g) s += part[(size_t)g * n + j];
-  }
-  sub[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && j < n) {
-    float t = sub[0][lane];
+    sub[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && j < n) {
+      float t = sub[0][lane];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) t += sub[k][lane];
-    grads[j] = t;
-  }
-}
-
-// dq[b, c] = sum_p dqr[b*P + p, c].  One workgroup per example: 256 threads = (256/K) position groups x K columns; group g
-// adds positions g, g+G', ... (ascending), the groups are then added in ascending order.
-// valid (nullable, [B*P] ids): with a row list only the positions whose id is > 0 were written to dqr -- the others are skipped
-// (selected away, never multiplied: they may hold anything).
-__global__ __launch_bounds__(256) void din_attn_dq_k(const float* __restrict__ dqr, float* __restrict__ dq, int B, int P,
-                                                     int K, const int32_t* __restrict__ valid) {
-  __shared__ float sub[256];
-  const int b = blockIdx.x, c = threadIdx.x % K, g = threadIdx.x / K, ng = 256 / K;
-  const float* src = dqr + (size_t)b * P * K + c;
-  const int32_t* vid = valid ? valid + (size_t)b * P : nullptr;
-  float s = 0.f;
-  int pp = g;
-  for (; pp + 3 * ng < P; pp += 4 * ng) {
-    float t0 = src[(size_t)pp * K], t1 = src[(size_t)(pp + ng) * K], t2 = src[(size_t)(pp + 2 * ng) * K],
-          t3 = src[(size_t)(pp + 3 * ng) * K];
-    if (vid) {
-      const int v0 = vid[pp], v1 = vid[pp + ng], v2 = vid[pp + 2 * ng], v3 = vid[pp + 3 * ng];
-      t0 = v0 > 0 ? t0 : 0.f; t1 = v1 > 0 ? t1 : 0.f; t2 = v2 > 0 ? t2 : 0.f; t3 = v3 > 0 ? t3 : 0.f;
+      for (int k = 1; k < 16; ++k) t += sub[k][lane];
+      grads[j] = t;
     }
-    s += t0; s += t1; s += t2; s += t3;
+    return;
   }
-  for (; pp < P; pp += ng) {
-    const float t = src[(size_t)pp * K];
-    s += (vid == nullptr || vid[pp] > 0) ? t : 0.f;
+  float* sb = &sub[0][0] + (threadIdx.x >> 8) * 256;           // this example's 256 slots
+  const int lt = threadIdx.x & 255;
+  const int b = ((int)blockIdx.x - nr) * 4 + (threadIdx.x >> 8);
+  const int c = lt % K, g = lt / K, ng = 256 / K;
+  float s = 0.f;
+  if (b < B) {
+    const float* src = dqr + (size_t)b * P * K + c;
+    const int32_t* vid = valid ? valid + (size_t)b * P : nullptr;
+    int pp = g;
+    for (; pp + 3 * ng < P; pp += 4 * ng) {
+      float t0 = src[(size_t)pp * K], t1 = src[(size_t)(pp + ng) * K], t2 = src[(size_t)(pp + 2 * ng) * K],
+            t3 = src[(size_t)(pp + 3 * ng) * K];
+      if (vid) {
+        const int v0 = vid[pp], v1 = vid[pp + ng], v2 = vid[pp + 2 * ng], v3 = vid[pp + 3 * ng];
+        t0 = v0 > 0 ? t0 : 0.f; t1 = v1 > 0 ? t1 : 0.f; t2 = v2 > 0 ? t2 : 0.f; t3 = v3 > 0 ? t3 : 0.f;
+      }
+      s += t0; s += t1; s += t2; s += t3;
+    }
+    for (; pp < P; pp += ng) {
+      const float t = src[(size_t)pp * K];
+      s += (vid == nullptr || vid[pp] > 0) ? t : 0.f;
+    }
   }
-  sub[threadIdx.x] = s;
+  sb[lt] = s;
   __syncthreads();
-  if (g == 0) {
-    float t = sub[c];
-    for (int k = 1; k < ng; ++k) t += sub[k * K + c];
-    dq[(size_t)b * K + c] = t;
+  if (b < B && g == 0) {
+    float t = sb[c];
+    for (int k = 1; k < ng; ++k) t += sb[k * K + c];
+    if (add != nullptr) t = add[(size_t)b * ld_add + c] + t;
+    dq[(size_t)b * ld_dq + c] = t;
   }
 }
 
@@ -667,6 +677,96 @@ __global__ __launch_bounds__(256) void din_valid_rows_k(const int32_t* __restric
   if (blockIdx.x == gridDim.x - 1 && tid == 0) count[0] = base;
 }
 
+// ---- both histories' row lists AND the sort keys of both id tables in two launches (fused TRAIN step of din.py) ---------------
+// launch 1, grid (tiles, 2): valid positions per 1024-position tile of history y; the y = 0 blocks also write the tile's sort
+// keys (entry B + position: the history ids with padding mapped to the tables' dummy rows, rsx_din_keys) and block (0, 0) the B
+// target entries' keys.  launch 2, grid (tiles, 2): din_valid_rows_k's body per history.
+struct DinPrep {
+  const int32_t* hist[2];
+  int32_t* rows[2];
+  int32_t* count[2];          // count[h][0] = valid rows, count[h] + 1: per-tile scratch
+  float* w[2];                // nullable: zeroed at the padded positions
+  const int32_t* i_id;
+  const int32_t* i_cate;
+  int32_t* keys2;             // [B + M, 2]
+  int B, M, dummy[2];
+};
+__global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = blockIdx.y;
+  const int32_t* ids = h ? p.hist[1] : p.hist[0];
+  int32_t* tcnt = (h ? p.count[1] : p.count[0]) + 1;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = blockIdx.x * 1024 + 256 * k + tid;
+    const int v = e < p.M ? ids[e] : 0;
+    c += v > 0 ? 1 : 0;
+    if (h == 0 && e < p.M) {
+      const int vc = p.hist[1][e];
+      reinterpret_cast<int2*>(p.keys2)[(size_t)p.B + e] = make_int2(v > 0 ? v : p.dummy[0], vc > 0 ? vc : p.dummy[1]);
+    }
+  }
+  if (h == 0 && blockIdx.x == 0)
+    for (int e = tid; e < p.B; e += 256) reinterpret_cast<int2*>(p.keys2)[e] = make_int2(p.i_id[e], p.i_cate[e]);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
+  if (lane == 0) wsum[wv] = c;
+  __syncthreads();
+  if (tid == 0) tcnt[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+__global__ __launch_bounds__(256) void din_prep_rows_k(const DinPrep p) {
+  __shared__ int wsum[4];
+  __shared__ int sbase;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = blockIdx.y;
+  const int32_t* ids = h ? p.hist[1] : p.hist[0];
+  int32_t* rows = h ? p.rows[1] : p.rows[0];
+  int32_t* count = h ? p.count[1] : p.count[0];
+  const int32_t* tcnt = count + 1;
+  float* w = h ? p.w[1] : p.w[0];
+  const int M = p.M, t0 = blockIdx.x * 1024;
+  int before = 0;
+  for (int t = tid; t < (int)blockIdx.x; t += 256) before += tcnt[t];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) before += __shfl_xor(before, m);
+  if (lane == 0) wsum[wv] = before;
+  __syncthreads();
+  if (tid == 0) sbase = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  __syncthreads();
+  int base = sbase;
+  for (int k = 0; k < 4; ++k) {
+    const int e = t0 + 256 * k + tid;
+    const bool ok = e < M && ids[e] > 0;
+    if (e < M && !ok && w != nullptr) w[e] = 0.f;
+    const uint64_t bal = __ballot(ok);
+    __syncthreads();
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int ww = 0; ww < wv; ++ww) off += wsum[ww];
+    if (ok) rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+    base += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) count[0] = base;
+}
+
+extern "C" int rsx_din_prepare(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
+                               int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int32_t* rows_i,
+                               int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
+                               rsx_stream_t stream) {
+  if (B <= 0 || P <= 0) return (B == 0 && P > 0) ? RSX_OK : RSX_EINVAL;
+  if (!i_id || !i_cate || !hist_i || !hist_c || !keys2 || !rows_i || !count_i || !rows_c || !count_c) return RSX_EINVAL;
+  const long long M = (long long)B * P;
+  if (M > (1ll << 24)) return RSX_EUNSUPPORTED;
+  DinPrep p{{hist_i, hist_c}, {rows_i, rows_c}, {count_i, count_c}, {w_i, w_c}, i_id, i_cate, keys2, B, (int)M,
+            {dummy_item_row, dummy_cate_row}};
+  const int nt = (int)((M + 1023) / 1024);
+  hipLaunchKernelGGL(din_prep_counts_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
+  hipLaunchKernelGGL(din_prep_rows_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
 extern "C" int rsx_din_valid_rows(const int32_t* ids, int B, int P, int32_t* rows, int32_t* count, float* w_zero_padded,
                                   rsx_stream_t stream) {
   if (B < 0 || P <= 0) return RSX_EINVAL;
@@ -703,28 +803,44 @@ static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
   return RSX_OK;
 }
 
+extern "C" int rsx_din_attn_bwd_ld(const float*, const float*, const float*, const float*, const float*, const float*,
+                                   const float*, const float*, float*, float*, float*, float*, const float*, const float*,
+                                   const uint32_t*, uint32_t, int, float, int, const int32_t*, const int32_t*, const int32_t*, int,
+                                   int, int, int, int, int, int, const float*, int, rsx_stream_t);
 extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
                                 const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
                                 float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
                                 uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, const int32_t* rows,
                                 const int32_t* count, const int32_t* ids, int B, int P, int K, int N1, int N2,
                                 rsx_stream_t stream) {
+  return rsx_din_attn_bwd_ld(H, q, W0, W1, W2, a1, a2, dw, dH, dq, grads, workspace, mask1, mask2, rng_step, seed, layer0,
+                             dropout_rate, accumulate_dH, rows, count, ids, B, P, K, N1, N2, K, K, nullptr, 0, stream);
+}
+
+extern "C" int rsx_din_attn_bwd_ld(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
+                                   const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
+                                   float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
+                                   uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, const int32_t* rows,
+                                   const int32_t* count, const int32_t* ids, int B, int P, int K, int N1, int N2, int ld_dH,
+                                   int ld_dq, const float* dq_add, int ld_dq_add, rsx_stream_t stream) {
   if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!H || !q || !W0 || !W1 || !W2 || !a1 || !a2 || !dw || !dH || !dq || !grads || !workspace) return RSX_EINVAL;
+  if (ld_dH < K || ld_dq < K || (dq_add != nullptr && ld_dq_add < K)) return RSX_EINVAL;
   if ((rows == nullptr) != (count == nullptr) || (rows != nullptr && ids == nullptr)) return RSX_EINVAL;
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;
   const int M = B * P, G = attn_bwd_groups(M);
   AttnBwdArgs p{H, q, W0, W1, W2, a1, a2, dw, dH, workspace, workspace + (size_t)M * K, mask1, mask2, rng_step, seed,
-                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64, accumulate_dH != 0, rows, count};
+                (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64, accumulate_dH != 0, ld_dH, rows, count};
   hipStream_t st = rsx_s(stream);
   const int rc = K == 32 ? launch_attn_bwd<2, 5, 3>(p, G, st) : launch_attn_bwd<1, 5, 3>(p, G, st);
   if (rc != RSX_OK) return rc;
   RSX_CHECK_LAUNCH();
   const int n = (int)attn_npart(K, N1, N2);
-  hipLaunchKernelGGL(din_attn_reduce_k, dim3((n + 63) / 64), dim3(1024), 0, st, p.part, G, n, grads);
-  hipLaunchKernelGGL(din_attn_dq_k, dim3(B), dim3(256), 0, st, p.dqr, dq, B, P, K, rows ? ids : nullptr);
+  const int nr = (n + 63) / 64;
+  hipLaunchKernelGGL(din_attn_finish_k, dim3(nr + (B + 3) / 4), dim3(1024), 0, st, p.part, G, n, grads, nr, p.dqr, dq, B, P, K,
+                     rows ? ids : nullptr, ld_dq, dq_add, ld_dq_add);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

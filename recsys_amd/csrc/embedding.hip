@@ -281,12 +281,19 @@ struct SegPartials {
   const int32_t* segid;   // [F, stride] then [F] long- and [F] huge-segment counters (reset by the sort)
   float* P;               // [F, nch, 2, D]
   float* P1;              // [F, nch, 2]
-  float* G;               // nullable [F*stride, D]: stage A also FINISHES every segment that lies inside one chunk and
-  float* gw1;             // writes its sum here (nullable [F*stride]); stage B picks those rows up instead of re-walking them
+  float* G;               // [F*stride, D]: stage A FINISHES every segment of <= SEG_SHORT entries and writes its sum here
+  float* gw1;             // (gw1: nullable [F*stride]); stage B picks those rows up
+  const int32_t* row_off; // [F + 1], needed for null_row == RSX_NULL_LAST_ROW only
+  int null_row;           // padding row: >= 0 a global row, RSX_NULL_LAST_ROW the last row of every field, RSX_NULL_NONE
   // segid + F*stride: [F] long- and [F] huge-segment counts, then the long list [F, nch] (unique index j of the
   // field's long segments from the front, huge ones from the back) -- all written by the sort
   __host__ __device__ const int32_t* counts(int F, int stride) const { return segid + (size_t)F * stride; }
   __host__ __device__ const int32_t* long_list(int F, int stride) const { return segid + (size_t)F * stride + 2 * F; }
+  // the padding row of field f (or -1): wave-uniform
+  __device__ __forceinline__ int null_of(int f, int explicit_row) const {
+    const int nr = explicit_row != RSX_NULL_NONE ? explicit_row : null_row;
+    return nr == RSX_NULL_LAST_ROW ? row_off[f + 1] - 1 : nr;
+  }
 };
 
 // sequential ascending sum of chunk partials t in [t0, t1) of one long segment whose first chunk is `base`
@@ -393,6 +400,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
     }
   };
   valid = false;
+  const int nrow = part.null_of(f, null_row);                       // this field's padding row, or -1
   const int nact = (nu + GPW - 1) / GPW;
   const int32_t* so = seg_off + (size_t)f * (stride + 1);
   do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
@@ -425,7 +433,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
       }
       return true;
     }
-    const bool is_null = own && null_row >= 0 && row == null_row;
+    const bool is_null = own && nrow >= 0 && row == nrow;
     if (is_null) end = beg;
     valid = own && end - beg <= SEG_SHORT;        // long rows belong to their helper wave
     if (!valid) return true;
@@ -457,7 +465,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
     const int sb = so[j], se = so[j + 1];
     sl = (size_t)f * stride + j;
     row = uniq_row[sl];
-    if (null_row >= 0 && row == null_row) {   // the padding row is written (as zero) by its row-owner group
+    if (nrow >= 0 && row == nrow) {   // the padding row is written (as zero) by its row-owner group
       valid = false;
       return true;
     }
@@ -474,7 +482,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
   const int sb = so[j], se = so[j + 1];
   sl = (size_t)f * stride + j;
   row = uniq_row[sl];
-  if (null_row >= 0 && row == null_row) return false;   // the padding row is written (as zero) by its row-owner group
+  if (nrow >= 0 && row == nrow) return false;   // the padding row is written (as zero) by its row-owner group
   valid = g == 0;
   if (valid) prefetch(row);
   if (gy2 != nullptr && valid) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
@@ -637,9 +645,8 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
   const int32_t* pf = perm + (size_t)f * stride;
   const int32_t* sid = ws.segid + (size_t)f * stride;
   RSX_STAMP2(0);
-  // the padding row (DIN's history id 0, exactly-zero gradients): table-local id 0 sorts first, so it is segment 0
-  int row0 = -1;
-  if (null_row >= 0) row0 = uniq_row[(size_t)f * stride];
+  // the padding row of this field (exactly-zero gradients by construction: never walked), or -1
+  const int nrow = ws.null_of(f, null_row);
   {
     constexpr int NI = (T::SID + 255) / 256;
     int32_t a[NI], b[NI];
@@ -696,8 +703,12 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
   const int cf = __builtin_ctz(~mf);                               // entries of the first segment inside the chunk
   const bool one = jf == jl;
   const int cl = one ? 0 : n_in - __builtin_ctz(ml);               // ... of the last one
-  const bool null0 = null_row >= 0 && row0 == null_row;
-  const bool nullf = null0 && jf == 0, nulll = null0 && jl == 0;
+  // (the rows of the chunk's first / last segment: only looked at inside the sum loop, after the wait for the row loads)
+  int rowf = -1, rowl = -1;
+  if (nrow >= 0) {
+    rowf = uniq_row[(size_t)f * stride + jf];
+    rowl = uniq_row[(size_t)f * stride + jl];
+  }
   bool long0, own0, long1 = false, own1 = false;
   int next;                                                        // entries of the last owned segment beyond the chunk
   if (one) {
@@ -711,8 +722,6 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
     own1 = !long1;
     next = own1 ? ca : 0;
   }
-  if (nullf) long0 = false;                                        // never walked: stage B writes its zero
-  if (nulll && !one) long1 = false;
   // dX may be absent with the FM term alone (fm.py): the row loads then read S instead and are multiplied by 0 -- a load
   // behind even a uniform condition is waited for on its own, one position after the other
   const bool has_x = dX != nullptr;
@@ -736,7 +745,6 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
   constexpr int XE = 4;
   float xg[XE], xh[XE];
   float4 xs[XE], xx0[XE];
-  const bool nullx = one ? nullf : nulll;
   const int rowx = FM ? uniq_row[fs + jl] : 0;                     // (unconditional: a guarded load is waited for alone)
 #pragma unroll
   for (int k = 0; k < XE; ++k) {
@@ -778,6 +786,7 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
     // loaded value become "wait for everything", i.e. for the stores (measured: 5.6 us for the 16 positions of a chunk)
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
     RSX_STAMP2(3 + (k0 ? 3 : 0));
+    const bool nullf = nrow >= 0 && rowf == nrow, nulll = nrow >= 0 && rowl == nrow;   // a padding segment: never walked,
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int kp = k0 + k;
@@ -799,11 +808,11 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
           if (W1) a1 += hh[k];
         }
         if (tail) {
-          if (isf) {
-            if (long0) to_P(0);
-            else if (own0 && !(one && next > 0)) to_G(j);          // (a null segment that starts here: its zero)
+          if (isf) {                                               // no partials (a short one that starts here: its zero)
+            if (long0) { if (!nullf) to_P(0); }
+            else if (own0 && !(one && next > 0)) to_G(j);
           } else if (isl) {
-            if (long1) to_P(1);
+            if (long1) { if (!nulll) to_P(1); }
             else if (own1 && next == 0) to_G(j);
           } else {
             to_G(j);
@@ -815,6 +824,7 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
   RSX_STAMP2(4);
   // the owned short segment that runs on into the next chunk: its remaining <= 15 entries, in order
   const float4 ex = FM ? T4[(size_t)rowx * LPR + q] : F4Z;
+  const bool nullx = nrow >= 0 && (one ? rowf : rowl) == nrow;
 #pragma unroll
   for (int k = 0; k < XE; ++k) {
     if (k < next && !nullx) {
@@ -907,6 +917,9 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
 struct HotAdam {
   float* tables; float* m_t; float* v_t;
   float* w1; float* m_w; float* v_w;     // nullable
+  int w1_stride;                         // floats between the elements of w1 / m_w / v_w (1; 4: column 0 of a 4-wide table)
+  int w1_sparse;                         // != 0: the sparse (IndexedSlices) formula for w1 -- a 1-D variable read through
+                                         // tf.gather (din/din.py:96) -- instead of the dense-kernel formula (fm/fm.py:121)
   float lr, b1, b2, eps;
   float* state;
   uint32_t n_own, total_blocks;
@@ -1001,7 +1014,11 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       if (h.w1 != nullptr && q == 0) {
 #pragma unroll
         for (int i = 0; i < WIN_NR; ++i)
-          if (t[i] < 0 && j0 + i * RPW < nu) adam_dense1(h.w1[row[i]], h.m_w[row[i]], h.v_w[row[i]], 0.f, hp);
+          if (t[i] < 0 && j0 + i * RPW < nu) {
+            const size_t wi = (size_t)row[i] * h.w1_stride;
+            if (h.w1_sparse) adam_sparse1(h.w1[wi], h.m_w[wi], h.v_w[wi], 0.f, false, hp);
+            else adam_dense1(h.w1[wi], h.m_w[wi], h.v_w[wi], 0.f, hp);
+          }
       }
     }
   } else if (blockIdx.x >= h.n_own) {     // second table set
@@ -1065,7 +1082,14 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       reinterpret_cast<float4*>(h.tables)[o] = var;
       reinterpret_cast<float4*>(h.m_t)[o] = m;
       reinterpret_cast<float4*>(h.v_t)[o] = v;
-      if (h.w1 != nullptr && q == 0) adam_dense1(h.w1[row], h.m_w[row], h.v_w[row], do1 ? a1 : 0.f, hp);
+      if (h.w1 != nullptr && q == 0) {
+        const size_t wi = (size_t)row * h.w1_stride;
+        if (h.w1_sparse) {
+          if (do1) adam_sparse1(h.w1[wi], h.m_w[wi], h.v_w[wi], a1, true, hp);       // (fields outside the mask: not its rows)
+        } else {
+          adam_dense1(h.w1[wi], h.m_w[wi], h.v_w[wi], do1 ? a1 : 0.f, hp);
+        }
+      }
     };
     if (part.P != nullptr) {              // two-stage: the compact unit list, grid stride over the row workgroups
       constexpr int GPW = RSX_WAVE / LPR;
@@ -1150,10 +1174,12 @@ static inline int ex_blocks(const rsx_example_blocks* h, int B, ExBlocks& out) {
 }
 // host view of the two-stage workspace; nullptr -> single-stage
 static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegPartials& out) {
-  out = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr};
+  out = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE};
   if (h == nullptr) return RSX_OK;
   if (!h->segid || !h->P || (need_p1 && !h->P1)) return RSX_EINVAL;
-  out = SegPartials{h->segid, h->P, h->P1, h->G, h->G ? h->gw1 : nullptr};
+  if (h->null_row == RSX_NULL_LAST_ROW && !h->row_off) return RSX_EINVAL;
+  if (h->null_row < RSX_NULL_LAST_ROW) return RSX_EINVAL;
+  out = SegPartials{h->segid, h->P, h->P1, h->G, h->G ? h->gw1 : nullptr, h->row_off, h->null_row};
   return RSX_OK;
 }
 
@@ -1346,6 +1372,21 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
                                     const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
                                     const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state,
                                     int advance_step, float lr, float beta1, float beta2, float eps, rsx_stream_t stream) {
+  return rsx_segsum_adam_rows2(tables, m_t, v_t, w1, m_w, v_w, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_field_mask, B,
+                               F, D, stride, extra_segs_h, n_extra, sweep_h, partials_h, blocks_h, second_h, win_h, state,
+                               advance_step, lr, beta1, beta2, eps, 1, 0, stream);
+}
+
+extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w,
+                                     const float* S, const float* dX, const float* gy1, const float* gy2,
+                                     const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                                     const int32_t* nuniq, uint64_t w1_field_mask, int B, int F, int D, int stride,
+                                     const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
+                                     const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h,
+                                     const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state,
+                                     int advance_step, float lr, float beta1, float beta2, float eps, int w1_stride,
+                                     int w1_sparse_formula, rsx_stream_t stream) {
+  if (w1_stride < 1) return RSX_EINVAL;
   if (!tables || !m_t || !v_t || !perm || !seg_off || !uniq_row || !nuniq || !state || B <= 0 || F <= 0 || F > 64 ||
       stride < B || !d_ok(D))
     return RSX_EINVAL;
@@ -1360,9 +1401,10 @@ extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float
   if (rcb != RSX_OK) return rcb;
   HotAdam h;
   h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
+  h.w1_stride = w1_stride; h.w1_sparse = w1_sparse_formula != 0;
   h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state; h.advance = advance_step != 0;
   h.tables2 = nullptr; h.m_t2 = nullptr; h.v_t2 = nullptr; h.dX2 = nullptr;
-  h.part2.segid = nullptr; h.part2.P = nullptr; h.part2.P1 = nullptr;
+  h.part2 = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE};
   if (second_h != nullptr) {
     if (!second_h->tables || !second_h->m || !second_h->v || !second_h->dX) return RSX_EINVAL;
     h.tables2 = second_h->tables; h.m_t2 = second_h->m; h.v_t2 = second_h->v; h.dX2 = second_h->dX;

@@ -650,6 +650,59 @@ __device__ __forceinline__ void bwd_dx_group_tile(const BwdArgs& p, const int bi
   RSX_STAMP(first ? 19 : 27, bid == 0);
 }
 
+// the last layer's backward launch also folds the head's per-row-tile partials (one workgroup): dWd, dbd, dwo, dbo, dc0, loss
+__device__ __forceinline__ void tower_head_reduce(const BwdArgs& p, float* part /* LDS [256] */, double* cred /* LDS [32] */) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (p.hpart != nullptr) {
+    // RTh row-tile partials per column: the 4 waves take contiguous quarter ranges of the rows (8 loads in flight),
+    // lane = column; the quarters are then added in ascending order -- fixed association, short dependent chains
+    const int w = tid >> 6;
+    const int per = (p.RTh + 3) / 4;
+    const int r0 = w * per, r1 = r0 + per < p.RTh ? r0 + per : p.RTh;
+    for (int c0 = 0; c0 < p.N; c0 += 64) {
+      const int c = c0 + lane;
+      float s = 0.f;
+      if (c < p.N) {
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = p.dwd_part[(size_t)(r + u) * p.N + c];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; r < r1; ++r) s += p.dwd_part[(size_t)r * p.N + c];
+      }
+      __syncthreads();
+      part[w * 64 + lane] = s;
+      __syncthreads();
+      if (w == 0 && c < p.N) p.dwd[c] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+    }
+    double hs = 0.0;
+    if (lane < 8) {
+      int r = r0;
+      for (; r + 8 <= r1; r += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p.hpart[(size_t)(r + u) * 8 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hs += t[u];
+      }
+      for (; r < r1; ++r) hs += p.hpart[(size_t)r * 8 + lane];
+      cred[w * 8 + lane] = hs;
+    }
+    __syncthreads();
+    if (tid < 8) {
+      const double s = ((cred[tid] + cred[8 + tid]) + cred[16 + tid]) + cred[24 + tid];
+      if (tid == 0) p.loss[0] = (float)(s / (double)p.B);
+      if (p.has_wo && tid >= 1 && tid <= 3) p.dwo[tid - 1] = (float)s;
+      if (p.has_wo && tid == 4) p.dbo[0] = (float)s;
+      if (p.dc0 != nullptr && tid == 5) p.dc0[0] = (float)s;
+      if (tid == 6) p.dbd[0] = (float)s;
+    }
+  }
+}
+
 // SPLIT: the dW tiles' batch reduction is cut into p.sb row blocks (large batches); false keeps the single-block code
 // path free of the block arithmetic
 template <bool SPLIT>
@@ -838,54 +891,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     return;
   }
   // ---- head partial reduce (last layer only) ---------------------------------------------------------
-  if (p.hpart != nullptr) {
-    // RTh row-tile partials per column: the 4 waves take contiguous quarter ranges of the rows (8 loads in flight),
-    // lane = column; the quarters are then added in ascending order -- fixed association, short dependent chains
-    const int w = tid >> 6;
-    const int per = (p.RTh + 3) / 4;
-    const int r0 = w * per, r1 = r0 + per < p.RTh ? r0 + per : p.RTh;
-    for (int c0 = 0; c0 < p.N; c0 += 64) {
-      const int c = c0 + lane;
-      float s = 0.f;
-      if (c < p.N) {
-        int r = r0;
-        for (; r + 8 <= r1; r += 8) {
-          float t[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = p.dwd_part[(size_t)(r + u) * p.N + c];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) s += t[u];
-        }
-        for (; r < r1; ++r) s += p.dwd_part[(size_t)r * p.N + c];
-      }
-      __syncthreads();
-      part[w * 64 + lane] = s;
-      __syncthreads();
-      if (w == 0 && c < p.N) p.dwd[c] = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
-    }
-    double hs = 0.0;
-    if (lane < 8) {
-      int r = r0;
-      for (; r + 8 <= r1; r += 8) {
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p.hpart[(size_t)(r + u) * 8 + lane];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) hs += t[u];
-      }
-      for (; r < r1; ++r) hs += p.hpart[(size_t)r * 8 + lane];
-      cred[w * 8 + lane] = hs;
-    }
-    __syncthreads();
-    if (tid < 8) {
-      const double s = ((cred[tid] + cred[8 + tid]) + cred[16 + tid]) + cred[24 + tid];
-      if (tid == 0) p.loss[0] = (float)(s / (double)p.B);
-      if (p.has_wo && tid >= 1 && tid <= 3) p.dwo[tid - 1] = (float)s;
-      if (p.has_wo && tid == 4) p.dbo[0] = (float)s;
-      if (p.dc0 != nullptr && tid == 5) p.dc0[0] = (float)s;
-      if (tid == 6) p.dbd[0] = (float)s;
-    }
-  }
+  tower_head_reduce(p, part, cred);
 }
 
 // Large batches: dW[tile] = sum of the tile's sb partials in ascending row-block order.  grid = tiles, block = 256.
@@ -948,6 +954,645 @@ __global__ __launch_bounds__(1024) void tower_reduce_partials_k(double* __restri
   }
 }
 
+// =============================================================================================
+// LARGE BATCHES (B >= TOWER_BIG_MIN_B).  The tiles above are built for batch 256: one 16x16 output tile per workgroup,
+// its reduction split over the 4 waves, operands straight from global memory -- 1 792 workgroups of 7.5 us each for
+// dcn.py's first layer at batch 4 096 (phase stamps), 19 us per launch with 7 of them per CU competing for the memory
+// pipeline, every one re-reading its 40 KB of input rows and 40 KB of weights.  Here ONE workgroup owns a 16-row tile
+// across ALL output columns: the input rows are read once (coalesced float4, all in flight) into LDS with the previous
+// layer's batch-norm + dropout applied on the way, each wave takes column tiles w, w + 4, .. with its own accumulators
+// and streams its weight columns with the loads of two k-steps in flight.  256 workgroups at batch 4 096 = one per CU.
+// =============================================================================================
+constexpr int TOWER_BIG_MIN_B = 1024;
+constexpr int TOWER_BIG_MIN_K = 256;     // input width from which the large-batch kernels are used (see rsx_tower_fwd_layer)
+// LDS row stride of a 16-row operand tile read with ds_read_b128 by lane (row = lane & 15, k-quarter = lane >> 4): a stride
+// == 8 (mod 64) floats puts the 16 lanes of every hardware lane group on distinct banks
+__host__ __device__ inline int big_stride(int K) { return (K + 127) / 128 * 128 + 8; }     // (>= K rounded up to 128 floats)
+
+// NTW: column tiles per wave (N <= 64 * NTW).  RID: the launch carries riders (the step's dedup sort / a slice of the
+// optimizer sweep as extra workgroups) -- a compile-time switch, because their ~100 KB of code and their registers would
+// otherwise sit in the rider-free launches of the windowed step as well; the tiles themselves are the same code.
+template <int NTW, bool RID>
+__global__ __launch_bounds__(256) void tower_fwd_big_k(const FwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (RID) {
+    if ((int)blockIdx.x >= p.n_own + p.n_sort) {
+      adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
+      return;
+    }
+    if ((int)blockIdx.x >= p.n_own) {
+      field_sort_block(p.sort, blockIdx.x - p.n_own, reinterpret_cast<uint32_t*>(lds));
+      return;
+    }
+  }
+  const int stb = p.fstat_prev == nullptr ? 36 : 32;      // (profiling build) stamp slots: first layer 36.., others 32..
+  RSX_STAMP(stb + 0, blockIdx.x == 0);
+  const int KP = big_stride(p.K);
+  float* sA = lds;                    // [16][KP]
+  float* sc = lds + 16 * KP;          // [K] scale, [K] shift of the previous layer's batch-norm
+  float* sh = sc + p.K;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int rt = blockIdx.x;
+  const bool first = p.fstat_prev == nullptr;
+  const int K4 = p.K >> 2, nks = ((p.K + 127) >> 7) << 3;      // k-steps of 16, padded to a multiple of 8 (A is zero there)
+  if (!first) {
+    for (int k = tid; k < p.K; k += 256) {
+      if (p.gamma_prev == nullptr) {   // previous layer without batch-norm (din/din.py MLP): dropout only
+        sc[k] = 1.f;
+        sh[k] = 0.f;
+        continue;
+      }
+      float mean, rstd;
+      bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.B, mean, rstd);
+      const float inv = rstd * p.gamma_prev[k];
+      sc[k] = inv;
+      sh[k] = p.beta_prev[k] - mean * inv;
+      if (rt == 0) {
+        p.bn_prev_out[k] = mean;
+        p.bn_prev_out[p.K + k] = rstd;
+      }
+    }
+    __syncthreads();
+  }
+  // (1) the tile's 16 input rows -> LDS (previous layer's batch-norm + dropout applied), zero beyond K and beyond the batch
+  {
+    const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+    const int tot = 16 * K4;
+    constexpr int NLD = 12;                      // float4 per thread and batch: K = 624 is 9.75 -> ONE batch, all in flight
+    for (int e0 = tid; e0 < tot; e0 += 256 * NLD) {
+      float4 v[NLD];
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int e = e0 + 256 * u < tot ? e0 + 256 * u : tot - 1;
+        const int r = e / K4, c4 = e - r * K4;
+        const int row = rt * TM + r < p.B ? rt * TM + r : p.B - 1;
+        v[u] = reinterpret_cast<const float4*>(p.in + (size_t)row * p.K)[c4];
+      }
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < tot) {
+          const int r = e / K4, c4 = e - r * K4, k = 4 * c4;
+          const int row = rt * TM + r;
+          float4 a = v[u];
+          if (!first) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sc + k);
+            const float4 h4 = *reinterpret_cast<const float4*>(sh + k);
+            const size_t ei = (size_t)(row < p.B ? row : p.B - 1) * p.K + k;
+            a.x = (a.x * s4.x + h4.x) * drop_mul(dr, p.mask_prev, ei);
+            a.y = (a.y * s4.y + h4.y) * drop_mul(dr, p.mask_prev, ei + 1);
+            a.z = (a.z * s4.z + h4.z) * drop_mul(dr, p.mask_prev, ei + 2);
+            a.w = (a.w * s4.w + h4.w) * drop_mul(dr, p.mask_prev, ei + 3);
+          }
+          if (row >= p.B) a = F4Z;
+          *reinterpret_cast<float4*>(sA + r * KP + k) = a;
+        }
+      }
+    }
+    const int padw = nks * 16 - p.K;               // 0 .. 60 floats per row (a multiple of 4)
+    for (int e = tid; e < 16 * (padw >> 2); e += 256) {
+      const int r = e / (padw >> 2), c4 = e - r * (padw >> 2);
+      *reinterpret_cast<float4*>(sA + r * KP + p.K + 4 * c4) = F4Z;
+    }
+  }
+  __syncthreads();
+  RSX_STAMP(stb + 1, blockIdx.x == 0);
+  // (2) wave w: column tiles w, w + 4, ...; k = 16 ks + 4 kq + t on both operands
+  const int i = lane & 15, kq = lane >> 4;
+  const int NT = (p.N + 15) >> 4;
+  int colc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int col = (w + 4 * j) * 16 + i;
+    colc[j] = col < p.N ? col : p.N - 1;           // (columns past N: computed on a valid address, never stored)
+  }
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto ldb = [&](const int ks, float (&b)[NTW][4]) {
+    const int kk = ks * 16 + 4 * kq;
+    const int kc = kk < p.K ? kk : p.K - 4;        // (a k-step past K: A is zero there)
+    const float* wr = p.W + (size_t)kc * p.N;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[j][t] = wr[(size_t)t * p.N + colc[j]];
+    }
+  };
+  // four k-steps of weight loads in flight (one k-step of MFMAs is 256-320 cycles, an L2 round trip under load more than
+  // twice that: with two in flight every k-step waited for its operands); the column tiles of a wave alternate inside a
+  // k-step so that consecutive MFMAs never share an accumulator (40-cycle dependent latency against a 32-cycle issue)
+  float bq[4][NTW][4];
+  // (every load of the loop is UNCONDITIONAL, on a clamped k-step: behind a condition the compiler can no longer count the
+  // loads in flight and waits for all of them -- vmcnt(0) -- at the head of every iteration, which is no prefetch at all)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) ldb(u, bq[u]);
+  const float* ar = sA + i * KP + 4 * kq;
+  // (8 k-steps per trip: at the loop's back edge the compiler falls back to "wait for everything", so a trip should be long)
+  float4 an = *reinterpret_cast<const float4*>(ar);               // (the A fragment one k-step ahead: its LDS latency hides too)
+  for (int ks = 0; ks < nks; ks += 8) {
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const int u = uu & 3;
+      const float4 a = an;
+      an = *reinterpret_cast<const float4*>(ar + 16 * (ks + uu + 1 < nks ? ks + uu + 1 : ks + uu));
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = mfma16(av[t], bq[u][j][t], acc[j]);
+      }
+      // (a scheduling fence: left alone, the compiler sinks these loads towards their use four k-steps later and the
+      // loop runs with ~1 k-step of loads in flight instead of 4)
+      __builtin_amdgcn_sched_barrier(0);
+      ldb(ks + uu + 4 < nks ? ks + uu + 4 : nks - 1, bq[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // (3) epilogue: lane (i, kq) holds rows 4 kq + r of column tile j's column i; bias + relu, the per-row-tile column sums
+  // for the batch-norm statistics (4 rows in-lane, then the 4 lane quarters in order)
+  RSX_STAMP(stb + 2, blockIdx.x == 0);
+  float biasv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) biasv[j] = p.bias[colc[j]];
+  __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) BEFORE the first store: afterwards a wait for a load waits for the stores
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int ct = w + 4 * j;
+    const int col = ct * 16 + i;
+    const bool cok = ct < NT && col < p.N;
+    const float bias = biasv[j];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * TM + 4 * kq + r;
+      float o = acc[j][r] + bias;
+      o = o > 0.f ? o : 0.f;
+      if (cok && row < p.B) {
+        p.a_out[(size_t)row * p.N + col] = o;
+        s1 += (double)o;
+        s2 += (double)o * (double)o;
+      }
+    }
+    if (p.fstat_out != nullptr) {
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (kq == 0 && cok) {
+        p.fstat_out[((size_t)rt * 2 + 0) * p.N + col] = s1;
+        p.fstat_out[((size_t)rt * 2 + 1) * p.N + col] = s2;
+      }
+    }
+  }
+  RSX_STAMP(stb + 3, blockIdx.x == 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward layer, large batches.  Workgroup families of one launch (256 threads each):
+//   [0, n_din)        d(input): ONE workgroup per 16-row tile across ALL K input columns.  da = relu'(a) * BNbwd(dy) of the
+//                     tile is formed once into LDS; wave w takes column tiles w, w + 4, .. (NTX accumulators per pass) and
+//                     streams the W rows of its columns as float4 (the reduction index n is contiguous in W[k, :]), the
+//                     loads of the next k-step in flight.
+//   [n_din, +n_dw)    dW: workgroup = (64 input features, one block of p.ksb * 16 batch rows); wave w owns 16 features x
+//                     ALL N outputs.  Both MFMA operands are indexed [batch row][feature / output], i.e. "transposed": 32
+//                     rows at a time are staged in LDS (in' with batch-norm + dropout, da, coalesced float4 loads) and read
+//                     back column-wise with ds_read_b32.  Row K of the feature range is the ones-row (-> db).  Partial
+//                     result [sb][K + 1 rounded to 16][N rounded to 16] -> tower_reduce_dw_big_k adds the blocks in order.
+//   then              the head-partial reduce, the riding sort, the sweep slice -- as in tower_bwd_k.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIG_DW_ROWS = 32;        // batch rows per LDS stage of a dW workgroup
+__host__ __device__ inline int big_ld32(int n) { return ((n + 15) & ~15) + 4; }   // row stride == 4 (mod 8): ds_read_b32 columns
+
+// NTX: d(input) column tiles per wave and pass; NTD: column tiles of the dW family (N <= 16 * NTD); RID: riders present
+template <int NTX, int NTD, bool RID>
+__global__ __launch_bounds__(256) void tower_bwd_big_k(const BwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int bid = blockIdx.x;
+  const float Bf = (float)p.B;
+  const bool first = p.bn_prev == nullptr;
+  const bool nobn = p.gamma == nullptr;
+  const int N4 = p.N >> 2, NP = (p.N + 15) & ~15;
+  float* Lm = lds; float* Lr = lds + NP; float* Lk = lds + 2 * NP; float* Ls = lds + 3 * NP; float* Lx = lds + 4 * NP;
+  float* tile = lds + 5 * NP;                                   // 16-byte aligned (NP % 16 == 0)
+  if (bid < p.n_din) {
+    // ================= d(input): rows rt*16 .., all K columns =================
+    const int rt = bid;
+    const int sx = first ? 40 : 48;                              // (profiling build) stamp slots
+    RSX_STAMP(sx + 0, bid == 0);
+    const int LD = big_stride(p.N);
+    float* sA = tile;                                           // [16][LD]
+    float4 av[4], dv[4];                                        // 16 * N/4 float4 over 256 threads: <= 4 each (N <= 256)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      const int ec = e < 16 * N4 ? e : 16 * N4 - 1;
+      const int r = ec / N4, c4 = ec - r * N4;
+      const size_t row = (size_t)(rt * TM + r < p.B ? rt * TM + r : p.B - 1);
+      av[u] = reinterpret_cast<const float4*>(p.a + row * p.N)[c4];
+      dv[u] = reinterpret_cast<const float4*>(p.dy + row * p.N)[c4];
+    }
+    for (int c = tid; c < NP; c += 256) {
+      const ColBwd cb = bwd_col(p, c < p.N ? c : p.N - 1);
+      Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      if (e < 16 * N4) {
+        const int r = e / N4, c = 4 * (e - r * N4);
+        const float rokf = rt * TM + r < p.B ? 1.f : 0.f;
+        ColBwd c0, c1, c2, c3;
+        c0.mean = Lm[c]; c0.rstd = Lr[c]; c0.k1 = Lk[c]; c0.sdy = Ls[c]; c0.sdx = Lx[c];
+        c1.mean = Lm[c + 1]; c1.rstd = Lr[c + 1]; c1.k1 = Lk[c + 1]; c1.sdy = Ls[c + 1]; c1.sdx = Lx[c + 1];
+        c2.mean = Lm[c + 2]; c2.rstd = Lr[c + 2]; c2.k1 = Lk[c + 2]; c2.sdy = Ls[c + 2]; c2.sdx = Lx[c + 2];
+        c3.mean = Lm[c + 3]; c3.rstd = Lr[c + 3]; c3.k1 = Lk[c + 3]; c3.sdy = Ls[c + 3]; c3.sdx = Lx[c + 3];
+        float4 o;
+        o.x = da_of(av[u].x, dv[u].x, c0, Bf, nobn) * rokf;
+        o.y = da_of(av[u].y, dv[u].y, c1, Bf, nobn) * rokf;
+        o.z = da_of(av[u].z, dv[u].z, c2, Bf, nobn) * rokf;
+        o.w = da_of(av[u].w, dv[u].w, c3, Bf, nobn) * rokf;
+        *reinterpret_cast<float4*>(sA + r * LD + c) = o;
+      }
+    }
+    const int nks = ((p.N + 31) >> 5) << 1;                      // k-steps of 16, padded to an even count (da is zero there)
+    for (int e = tid; e < 16 * ((nks * 16 - p.N) >> 2); e += 256) {    // zero the k padding
+      const int r = e / ((nks * 16 - p.N) >> 2), c4 = e - r * ((nks * 16 - p.N) >> 2);
+      *reinterpret_cast<float4*>(sA + r * LD + p.N + 4 * c4) = F4Z;
+    }
+    __syncthreads();
+    RSX_STAMP(sx + 1, bid == 0);
+    const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+    const float* ar = sA + i * LD + 4 * kq;
+    const int tpw = (p.ct_k - w + 3) / 4;                        // column tiles of this wave: w, w + 4, ...
+    for (int j0 = 0; j0 < tpw; j0 += NTX) {
+      int kcol[NTX];
+      const float* wrow[NTX];
+#pragma unroll
+      for (int j = 0; j < NTX; ++j) {
+        const int ct = w + 4 * (j0 + j);
+        kcol[j] = ct * 16 + i;
+        const int kc = (j0 + j < tpw && kcol[j] < p.K) ? kcol[j] : p.K - 1;
+        wrow[j] = p.W + (size_t)kc * p.N + 4 * kq;
+      }
+      f32x4 acc[NTX];
+#pragma unroll
+      for (int j = 0; j < NTX; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto ldw = [&](const int ks, float4 (&b)[NTX]) {
+        const int off = 16 * ks + 4 * kq < p.N ? 16 * ks : p.N - 4 - 4 * kq;     // (past N: A is zero there)
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) b[j] = *reinterpret_cast<const float4*>(wrow[j] + off);
+      };
+      float4 b0[NTX], b1[NTX];
+      ldw(0, b0);
+      ldw(1, b1);
+      for (int ks = 0; ks < nks; ks += 2) {                       // (loads unconditional on clamped k-steps: see tower_fwd_big_k)
+        const float4 a0 = *reinterpret_cast<const float4*>(ar + 16 * ks);
+        const float4 a1 = *reinterpret_cast<const float4*>(ar + 16 * (ks + 1));
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a0.x, b0[j].x, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a0.y, b0[j].y, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a0.z, b0[j].z, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a0.w, b0[j].w, acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        ldw(ks + 2 < nks ? ks + 2 : nks - 1, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a1.x, b1[j].x, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a1.y, b1[j].y, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a1.z, b1[j].z, acc[j]);
+#pragma unroll
+        for (int j = 0; j < NTX; ++j) acc[j] = mfma16(a1.w, b1[j].w, acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        ldw(ks + 3 < nks ? ks + 3 : nks - 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      RSX_STAMP(sx + 2, bid == 0 && j0 == 0);
+      // epilogue: lane (i, kq) holds rows 4 kq + r of column kcol[j]: dropout backward of the previous layer and the
+      // partial sums of ITS batch-norm backward over the tile's 16 rows (4 in-lane, then the 4 lane quarters in order)
+#pragma unroll
+      for (int j = 0; j < NTX; ++j) {
+        const bool cok = j0 + j < tpw && kcol[j] < p.K;
+        const int kc = cok ? kcol[j] : p.K - 1;
+        float xin[4] = {0.f, 0.f, 0.f, 0.f}, bnm = 0.f, bnr = 0.f;
+        if (!first) {     // (uniform)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int orow = rt * TM + 4 * kq + r;
+            xin[r] = p.in[(size_t)(orow < p.B ? orow : p.B - 1) * p.K + kc];
+          }
+          bnm = p.bn_prev[kc];
+          bnr = p.bn_prev[p.K + kc];
+        }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = rt * TM + 4 * kq + r;
+          float o = acc[j][r];
+          if (orow < p.B && cok) {
+            if (!first) {
+              o *= drop_mul(dr, p.mask_prev, (size_t)orow * p.K + kc);
+              const float xh = (xin[r] - bnm) * bnr;
+              s1 += (double)o;
+              s2 += (double)o * (double)xh;
+            }
+            p.dy_prev[(size_t)orow * p.K + kc] = o;
+          }
+        }
+        if (!first) {
+          s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          if (kq == 0 && cok) {
+            p.bstat_prev[((size_t)rt * 2 + 0) * p.K + kc] = s1;
+            p.bstat_prev[((size_t)rt * 2 + 1) * p.K + kc] = s2;
+          }
+        }
+      }
+    }
+    RSX_STAMP(sx + 3, bid == 0);
+    return;
+  }
+  if (bid < p.n_din + p.n_dw) {
+    // ================= dW: features fg*64 .. +64 (wave w: 16 of them), batch rows sbi * ksb * 16 .. =================
+    const int t_id = bid - p.n_din;
+    const int sbi = t_id % p.sb, fg = t_id / p.sb;
+    const int sw = first ? 44 : 52;
+    RSX_STAMP(sw + 0, t_id == 0);
+    const int LDI = big_ld32(64), LDD = big_ld32(p.N);
+    float* sI = tile;                                            // [2][32][LDI]
+    float* sD = tile + 2 * BIG_DW_ROWS * LDI;                    // [2][32][LDD]
+    float* fS = sD + 2 * BIG_DW_ROWS * LDD;                      // [64] scale, [64] shift of the workgroup's features
+    for (int c = tid; c < NP; c += 256) {
+      const ColBwd cb = bwd_col(p, c < p.N ? c : p.N - 1);
+      Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
+      if (fg == 0 && sbi == 0 && c < p.N && !nobn) {
+        p.dgamma[c] = cb.sdx;
+        p.dbeta[c] = cb.sdy;
+      }
+    }
+    if (tid < 64) {
+      const int feat = fg * 64 + tid;
+      float fsc = 1.f, fsh = 0.f;
+      if (!first && feat < p.K && p.gamma_prev != nullptr) {
+        const float inv = p.bn_prev[p.K + feat] * p.gamma_prev[feat];
+        fsc = inv;
+        fsh = p.beta_prev[feat] - p.bn_prev[feat] * inv;
+      }
+      fS[tid] = fsc;
+      fS[64 + tid] = fsh;
+    }
+    const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+    const int row0 = sbi * p.ksb * 16;
+    const int row1 = row0 + p.ksb * 16 < p.B ? row0 + p.ksb * 16 : p.B;
+    const int NT = NP >> 4;
+    f32x4 acc[NTD];                                              // every wave: all NT <= NTD column tiles
+    // in' tile: 32 rows x 64 features = 512 float4, 2 per thread; a, dy: 32 x N/4 float4 each, <= 4 per thread (N <= 128)
+#pragma unroll
+    for (int j = 0; j < NTD; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nst = (row1 - row0 + BIG_DW_ROWS - 1) / BIG_DW_ROWS;
+    __syncthreads();
+    float4 xv[2], avv[4], dvv[4];                    // (N <= 128, host-checked: 32 * N / 4 float4 over 256 threads)
+    // global loads of one 32-row stage (unconditional, rows clamped into the block) ...
+    auto ld_stage = [&](const int st) {
+      const int rb = row0 + st * BIG_DW_ROWS;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, r = e >> 4, c4 = e & 15;
+        const int row = rb + r < row1 ? rb + r : row1 - 1;
+        const int feat = fg * 64 + 4 * c4;
+        xv[u] = *reinterpret_cast<const float4*>(p.in + (size_t)row * p.K + (feat + 3 < p.K ? feat : p.K - 4));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u;
+        const int ec = e < BIG_DW_ROWS * N4 ? e : BIG_DW_ROWS * N4 - 1;
+        const int r = ec / N4, c4 = ec - r * N4;
+        const size_t row = (size_t)(rb + r < row1 ? rb + r : row1 - 1);
+        avv[u] = reinterpret_cast<const float4*>(p.a + row * p.N)[c4];
+        dvv[u] = reinterpret_cast<const float4*>(p.dy + row * p.N)[c4];
+      }
+    };
+    // ... and their way into the stage's LDS buffer: in' = dropout(BN(in)) (feature K: the ones-row), da = relu' * BNbwd(dy)
+    auto put_stage = [&](const int st) {
+      float* cI = sI + (st & 1) * BIG_DW_ROWS * LDI;
+      float* cD = sD + (st & 1) * BIG_DW_ROWS * LDD;
+      const int rb = row0 + st * BIG_DW_ROWS;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, r = e >> 4, c4 = e & 15;
+        const int row = rb + r;
+        const int feat = fg * 64 + 4 * c4;
+        const float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};      // (K % 4 == 0: a float4 is all inside K or all outside)
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ft = feat + t;
+          float x = v[t];
+          if (!first) x = (x * fS[4 * c4 + t] + fS[64 + 4 * c4 + t]) *
+                          drop_mul(dr, p.mask_prev, (size_t)(row < row1 ? row : row1 - 1) * p.K + (ft < p.K ? ft : p.K - 1));
+          x = ft < p.K ? x : (ft == p.K ? 1.f : 0.f);            // feature K: the ones-row that yields db
+          o[t] = row < row1 ? x : 0.f;
+        }
+        *reinterpret_cast<float4*>(cI + r * LDI + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u;
+        if (e < BIG_DW_ROWS * N4) {
+          const int r = e / N4, c = 4 * (e - r * N4);
+          const float rokf = rb + r < row1 ? 1.f : 0.f;
+          ColBwd c0, c1, c2, c3;
+          c0.mean = Lm[c]; c0.rstd = Lr[c]; c0.k1 = Lk[c]; c0.sdy = Ls[c]; c0.sdx = Lx[c];
+          c1.mean = Lm[c + 1]; c1.rstd = Lr[c + 1]; c1.k1 = Lk[c + 1]; c1.sdy = Ls[c + 1]; c1.sdx = Lx[c + 1];
+          c2.mean = Lm[c + 2]; c2.rstd = Lr[c + 2]; c2.k1 = Lk[c + 2]; c2.sdy = Ls[c + 2]; c2.sdx = Lx[c + 2];
+          c3.mean = Lm[c + 3]; c3.rstd = Lr[c + 3]; c3.k1 = Lk[c + 3]; c3.sdy = Ls[c + 3]; c3.sdx = Lx[c + 3];
+          float4 o;
+          o.x = da_of(avv[u].x, dvv[u].x, c0, Bf, nobn) * rokf;
+          o.y = da_of(avv[u].y, dvv[u].y, c1, Bf, nobn) * rokf;
+          o.z = da_of(avv[u].z, dvv[u].z, c2, Bf, nobn) * rokf;
+          o.w = da_of(avv[u].w, dvv[u].w, c3, Bf, nobn) * rokf;
+          *reinterpret_cast<float4*>(cD + r * LDD + c) = o;
+        }
+      }
+    };
+    for (int e = tid; e < 2 * BIG_DW_ROWS * (NP - p.N); e += 256) {   // the k padding of the da tiles (both buffers), once
+      const int r = e / (NP - p.N), c = e - r * (NP - p.N);
+      sD[r * LDD + p.N + c] = 0.f;
+    }
+    RSX_STAMP(sw + 1, t_id == 0);
+    ld_stage(0);
+    for (int st = 0; st < nst; ++st) {
+      const float* cI = sI + (st & 1) * BIG_DW_ROWS * LDI;
+      const float* cD = sD + (st & 1) * BIG_DW_ROWS * LDD;
+      put_stage(st);
+      ld_stage(st + 1 < nst ? st + 1 : st);          // the next stage's rows are in flight under this stage's MFMAs
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < BIG_DW_ROWS / 16; ++ks) {
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = cI[(16 * ks + 4 * kq + t) * LDI + 16 * w + i];
+        float b[NTD][4];
+#pragma unroll
+        for (int j = 0; j < NTD; ++j) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) b[j][t] = cD[(16 * ks + 4 * kq + t) * LDD + 16 * (j < NT ? j : NT - 1) + i];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int j = 0; j < NTD; ++j)
+            if (j < NT) acc[j] = mfma16(a[t], b[j][t], acc[j]);
+        }
+      }
+      // (the next stage writes the other LDS buffer; the barrier at its end also orders this stage's reads before the
+      // stage after next overwrites this buffer)
+    }
+    RSX_STAMP(sw + 2, t_id == 0);
+    // partial tile: lane (i, kq) holds features fg*64 + 16 w + 4 kq + r, column 16 j + i
+    const int KR = p.ct_k1 * 16;
+    float* out = p.dwp + (size_t)sbi * KR * NP;
+#pragma unroll
+    for (int j = 0; j < NTD; ++j) {
+      if (j < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int feat = fg * 64 + 16 * w + 4 * kq + r;
+          if (feat < KR) out[(size_t)feat * NP + 16 * j + i] = acc[j][r];
+        }
+      }
+    }
+    return;
+  }
+  if (RID) {
+    if (bid >= p.n_din + p.n_dw + p.n_head + p.n_sort) {
+      adam_block(p.sweep.args, p.sweep.blk_lo + (bid - (p.n_din + p.n_dw + p.n_head + p.n_sort)));
+      return;
+    }
+    if (bid >= p.n_din + p.n_dw + p.n_head) {
+      field_sort_block(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
+      return;
+    }
+  }
+  tower_head_reduce(p, tile, reinterpret_cast<double*>(tile + 1024));
+}
+
+// dW[k, n] = sum over the sb row blocks (ascending) of the partial [sb][KR][NP]; row K -> db.  grid = KR * NP / 1024 floats
+__global__ __launch_bounds__(256) void tower_reduce_dw_big_k(const float* __restrict__ dwp, float* __restrict__ dW,
+                                                             float* __restrict__ db, int sb, int K, int N, int KR, int NP) {
+  const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;       // float4 index into [KR][NP]
+  const size_t tot4 = (size_t)KR * NP / 4;
+  if (e4 >= tot4) return;
+  const float4* src = reinterpret_cast<const float4*>(dwp);
+  float4 s = F4Z;
+  for (int q = 0; q < sb; q += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(q + u < sb ? q + u : sb - 1) * tot4 + e4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q + u < sb) s = f4_add(s, t[u]);
+  }
+  const int k = (int)((e4 * 4) / NP), n = (int)((e4 * 4) - (size_t)k * NP);
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (n + t < N) {
+      if (k < K) dW[(size_t)k * N + n + t] = v[t];
+      else if (k == K) db[n + t] = v[t];
+    }
+  }
+}
+
+// The dW reductions of ALL layers of a backward pass in one launch (a layer's reduce is first needed by the optimizer: one
+// launch at the end of the backward pass instead of one per layer; every job keeps its own fixed summation order).
+struct DwReduceJobs {
+  rsx_dw_reduce_job j[RSX_DW_REDUCE_MAX_JOBS];
+  uint32_t blk_end[RSX_DW_REDUCE_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void tower_reduce_dw_jobs_k(const DwReduceJobs g) {
+  rsx_dw_reduce_job jb = g.j[0];
+  uint32_t b0 = 0;
+#pragma unroll
+  for (int k = 1; k < RSX_DW_REDUCE_MAX_JOBS; ++k) {     // (compile-time indices: see gather_rows_multi_k)
+    if (blockIdx.x >= g.blk_end[k - 1]) {
+      jb = g.j[k];
+      b0 = g.blk_end[k - 1];
+    }
+  }
+  const uint32_t blk = blockIdx.x - b0;
+  const int tid = threadIdx.x;
+  if (jb.layout == 0) {            // tile-major partials [tiles][sb][256] (tower_bwd_k<true>): one workgroup per tile
+    const int tile = (int)blk;
+    const float* all = jb.partials + (size_t)tile * jb.sb * 256;
+    float s = 0.f;
+    for (int q = 0; q < jb.sb; q += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = q + u < jb.sb ? all[(size_t)(q + u) * 256 + tid] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    const int ct_n = (jb.N + 15) / 16;
+    const int nt = tile % ct_n, kf = tile / ct_n;
+    const int orow = kf * 16 + (tid >> 4), ocol = nt * 16 + (tid & 15);
+    if (ocol < jb.N) {
+      if (orow < jb.K) jb.dW[(size_t)orow * jb.N + ocol] = s;
+      else if (orow == jb.K) jb.db[ocol] = s;
+    }
+    return;
+  }
+  // row-block partials [sb][KR][NP] (tower_bwd_big_k)
+  const int KR = (jb.K + 1 + 15) / 16 * 16, NP = (jb.N + 15) / 16 * 16;
+  const size_t e4 = (size_t)blk * 256 + tid, tot4 = (size_t)KR * NP / 4;
+  if (e4 >= tot4) return;
+  const float4* src = reinterpret_cast<const float4*>(jb.partials);
+  float4 s = F4Z;
+  for (int q = 0; q < jb.sb; q += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(q + u < jb.sb ? q + u : jb.sb - 1) * tot4 + e4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q + u < jb.sb) s = f4_add(s, t[u]);
+  }
+  const int kk = (int)((e4 * 4) / NP), n = (int)((e4 * 4) - (size_t)kk * NP);
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (n + t < jb.N) {
+      if (kk < jb.K) jb.dW[(size_t)kk * jb.N + n + t] = v[t];
+      else if (kk == jb.K) jb.db[n + t] = v[t];
+    }
+  }
+}
+
+extern "C" int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njobs, rsx_stream_t stream) {
+  if (njobs == 0) return RSX_OK;
+  if (!jobs_h || njobs < 0 || njobs > RSX_DW_REDUCE_MAX_JOBS) return RSX_EINVAL;
+  DwReduceJobs g;
+  uint32_t end = 0;
+  for (int k = 0; k < RSX_DW_REDUCE_MAX_JOBS; ++k) {
+    const rsx_dw_reduce_job& j = jobs_h[k < njobs ? k : njobs - 1];
+    if (k < njobs) {
+      if (!j.partials || !j.dW || !j.db || j.sb <= 0 || j.K <= 0 || j.N <= 0 || (j.layout != 0 && j.layout != 1)) return RSX_EINVAL;
+      if (j.layout == 0) end += (uint32_t)(((j.K + 1 + 15) / 16) * ((j.N + 15) / 16));
+      else end += (uint32_t)((((size_t)(j.K + 1 + 15) / 16 * 16) * ((size_t)(j.N + 15) / 16 * 16) / 4 + 255) / 256);
+    }
+    g.j[k] = j;
+    g.blk_end[k] = end;
+  }
+  hipLaunchKernelGGL(tower_reduce_dw_jobs_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
 // validates a piggy-backed sort job for a 256-thread carrier launch and grows the launch's dynamic LDS if needed
 // consumers read pre-reduced statistics (1 row) when the batch is large: see rsx_tower_reduce_partials
 static inline int stat_rows(int B) { return B > 512 ? 1 : (B + TM - 1) / TM; }
@@ -994,6 +1639,31 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
     const int rc = sort_job_args(*sort_h, p.sort, &lds);
     if (rc != RSX_OK) return rc;
     p.n_sort = sort_h->F;
+  }
+  static const int big_env = getenv("RSX_TOWER_BIG") ? atoi(getenv("RSX_TOWER_BIG")) : 1;   // (0: the small-batch tiles, A/B runs)
+  const size_t lds_big = ((size_t)16 * big_stride(K) + 2 * (size_t)K) * sizeof(float);
+  // (A/B on one box, r03: the large-batch kernels win on the WIDE first layer -- dcn.py K = 624: forward 19 -> 16 us, backward
+  // 48 -> 41 us incl. the reduce -- and lose on 100-wide layers, whose launches are latency chains either way: DIN's 96 /
+  // 100 / 52-wide MLP at batch 1 024 ran 22 us per step slower through them.  The choice is a function of the layer shape
+  // only, so every path of one model and batch size takes the same kernels.)
+  if (big_env && B >= TOWER_BIG_MIN_B && K >= TOWER_BIG_MIN_K && N <= 256 && lds_big <= 64 * 1024) {
+    // one workgroup per 16-row tile across all N columns (see tower_fwd_big_k)
+    p.n_own = (B + TM - 1) / TM;
+    size_t l2 = lds_big > lds ? lds_big : lds;                     // (lds: what a riding sort needs)
+    const dim3 grid(p.n_own + p.n_sort + p.sweep.n_blk);
+    const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
+#define RSX_FWD_BIG(NTW)                                                                                      \
+  do {                                                                                                        \
+    if (rid) hipLaunchKernelGGL((tower_fwd_big_k<NTW, true>), grid, dim3(256), l2, rsx_s(stream), p);         \
+    else hipLaunchKernelGGL((tower_fwd_big_k<NTW, false>), grid, dim3(256), l2, rsx_s(stream), p);            \
+  } while (0)
+    if (N <= 64) RSX_FWD_BIG(1);
+    else if (N <= 128) RSX_FWD_BIG(2);
+    else if (N <= 192) RSX_FWD_BIG(3);
+    else RSX_FWD_BIG(4);
+#undef RSX_FWD_BIG
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
   }
   hipLaunchKernelGGL(tower_fwd_k, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
@@ -1115,9 +1785,20 @@ static inline int rsx_tower_dw_blocks(int B, bool have_ws) {
 }
 
 extern "C" size_t rsx_tower_bwd_workspace_floats(int B, int K, int N) {
-  return (size_t)((K + 1 + 15) / 16) * ((N + 15) / 16) * rsx_tower_dw_blocks(B, true) * 256;
+  const size_t small = (size_t)((K + 1 + 15) / 16) * ((N + 15) / 16) * rsx_tower_dw_blocks(B, true) * 256;
+  // large-batch layout (tower_bwd_big_k): up to min(32, 320 / feature groups) row blocks of the whole [K + 1 rounded to
+  // 16][N rounded to 16] gradient
+  const int nfg = (K + 1 + 63) / 64;
+  const int sbmax = 320 / nfg < 1 ? 1 : (320 / nfg > 32 ? 32 : 320 / nfg);
+  const size_t big = (size_t)sbmax * (((size_t)K + 1 + 15) / 16 * 16) * (((size_t)N + 15) / 16 * 16);
+  return B >= TOWER_BIG_MIN_B && big > small ? big : small;
 }
 
+extern "C" int rsx_tower_bwd_layer_defer(const float*, const float*, const float*, const float*, const double*, const float*,
+                                         const float*, float*, float*, float*, float*, const float*, const float*, const float*,
+                                         const float*, float*, double*, const double*, const float*, float*, float*, float*,
+                                         float*, float*, float*, const uint32_t*, uint32_t, int, float, int, int, int,
+                                         const rsx_sort_job*, const rsx_adam_slice*, float*, rsx_dw_reduce_job*, rsx_stream_t);
 extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const float* dy,
                                    const double* bstat, const float* bn, const float* gamma, float* dW, float* db,
                                    float* dgamma, float* dbeta, const float* bn_prev, const float* gamma_prev,
@@ -1127,6 +1808,21 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
                                    int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
                                    float* dw_partials, rsx_stream_t stream) {
+  return rsx_tower_bwd_layer_defer(in, W, a, dy, bstat, bn, gamma, dW, db, dgamma, dbeta, bn_prev, gamma_prev, beta_prev, mask_prev,
+                                   dy_prev, bstat_prev, hpart, dwd_part, dwd, dbd, dwo, dbo, dc0, loss, rng_step, seed, layer,
+                                   dropout_rate, B, K, N, sort_h, sweep_h, dw_partials, nullptr, stream);
+}
+
+extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, const float* dy,
+                                         const double* bstat, const float* bn, const float* gamma, float* dW, float* db,
+                                         float* dgamma, float* dbeta, const float* bn_prev, const float* gamma_prev,
+                                         const float* beta_prev, const float* mask_prev, float* dy_prev,
+                                         double* bstat_prev, const double* hpart, const float* dwd_part, float* dwd,
+                                         float* dbd, float* dwo, float* dbo, float* dc0, float* loss,
+                                         const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
+                                         int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
+                                         float* dw_partials, rsx_dw_reduce_job* reduce_out, rsx_stream_t stream) {
+  if (reduce_out != nullptr) reduce_out->sb = 0;          // (0: nothing left to reduce for this layer)
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !a || !dy || !bstat || !bn || !dW || !db || !dy_prev) return RSX_EINVAL;
@@ -1187,11 +1883,56 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
   }
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
+  static const int big_env = getenv("RSX_TOWER_BIG") ? atoi(getenv("RSX_TOWER_BIG")) : 1;   // (0: the small-batch tiles, A/B runs)
+  if (big_env && B >= TOWER_BIG_MIN_B && K >= TOWER_BIG_MIN_K && dw_partials != nullptr && (N & 3) == 0 && N <= 128 &&
+      (K & 3) == 0) {
+    // one workgroup per 16-row tile for d(input), (64 features x row block) workgroups for dW (see tower_bwd_big_k)
+    const int NP = (N + 15) & ~15;
+    p.n_din = p.RTh;
+    const int nfg = (K + 1 + 63) / 64;
+    int sbw = 320 / nfg < 1 ? 1 : (320 / nfg > 32 ? 32 : 320 / nfg);                 // row blocks wanted (more, shorter blocks
+                                                                                      // measured slower: the reduce grows with them)
+    int rows = ((B + sbw - 1) / sbw + BIG_DW_ROWS - 1) / BIG_DW_ROWS * BIG_DW_ROWS;  // rows per block: a multiple of the LDS stage
+    p.ksb = rows / 16;
+    p.sb = (B + rows - 1) / rows;
+    p.n_dw = nfg * p.sb;
+    size_t lb = (size_t)5 * NP + 16 * (size_t)big_stride(N);
+    const size_t ldw = (size_t)5 * NP + 2 * BIG_DW_ROWS * ((size_t)big_ld32(64) + big_ld32(N)) + 128;
+    if (ldw > lb) lb = ldw;
+    if ((size_t)5 * NP + 1024 + 64 > lb) lb = (size_t)5 * NP + 1024 + 64;
+    lb *= sizeof(float);
+    if (lb > lds) lds = lb;                                       // (lds: what a riding sort needs)
+    const dim3 grid(p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk);
+    const bool wide = K > 128;                                    // d(input) column tiles per wave and pass: 5 (K = 624: two passes), else 2
+    const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
+#define RSX_BWD_BIG(NTX, NTD)                                                                                 \
+  do {                                                                                                        \
+    if (rid) hipLaunchKernelGGL((tower_bwd_big_k<NTX, NTD, true>), grid, dim3(256), lds, rsx_s(stream), p);   \
+    else hipLaunchKernelGGL((tower_bwd_big_k<NTX, NTD, false>), grid, dim3(256), lds, rsx_s(stream), p);      \
+  } while (0)
+    if (N <= 64) { if (wide) RSX_BWD_BIG(5, 4); else RSX_BWD_BIG(2, 4); }
+    else { if (wide) RSX_BWD_BIG(5, 8); else RSX_BWD_BIG(2, 8); }
+#undef RSX_BWD_BIG
+    RSX_CHECK_LAUNCH();
+    const int KR = p.ct_k1 * 16;
+    if (reduce_out != nullptr) {
+      *reduce_out = rsx_dw_reduce_job{dw_partials, dW, db, p.sb, K, N, 1};
+      return RSX_OK;
+    }
+    hipLaunchKernelGGL(tower_reduce_dw_big_k, dim3((unsigned)(((size_t)KR * NP / 4 + 255) / 256)), dim3(256), 0, rsx_s(stream),
+                       dw_partials, dW, db, p.sb, K, N, KR, NP);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+  }
   const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
   if (p.sb > 1) hipLaunchKernelGGL(tower_bwd_k<true>, dim3(total), dim3(256), lds, rsx_s(stream), p);
   else hipLaunchKernelGGL(tower_bwd_k<false>, dim3(total), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   if (p.sb > 1) {
+    if (reduce_out != nullptr) {
+      *reduce_out = rsx_dw_reduce_job{dw_partials, dW, db, p.sb, K, N, 0};
+      return RSX_OK;
+    }
     hipLaunchKernelGGL(tower_reduce_dw_k, dim3(p.ct_k1 * p.ct_n), dim3(256), 0, rsx_s(stream), dw_partials, dW, db, p.sb,
                        p.ct_n, K, N);
     RSX_CHECK_LAUNCH();

@@ -14,7 +14,8 @@ import torch
 from . import layers as L
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
-from .ops import DinAttnFn, DinAttnPoolFn, DinPoolFn, FusedTower, SparseTable
+from . import _lib
+from .ops import DinAttnFn, DinAttnPoolFn, DinPoolFn, EmbeddingArena, FusedTower, SparseTable, _ptr, _stream
 
 ATTENTION_LAYERS = [80, 40]      # din/din.py:85 (the din_layers flag is ignored by the reference)
 MLP_LAYERS = [100, 50, 20]       # din/din.py:86 (the deep_layers flag is ignored by the reference)
@@ -40,10 +41,30 @@ def build_variables(store, params, B, P):
     world = store.dp.world if store.dp is not None else 1
     cap = (B * (P + 1)) * world
     # id 0 is the history padding (din/din.py:56-57,107): its gradient entries are exactly zero (masked sum), so the
-    # sparse path may skip that one huge segment; direct lookups never use id 0
-    item = SparseTable(n_item, K, cap, store.device, null_row=0)
-    cate = SparseTable(n_cate, K, cap, store.device, null_row=0)
-    bias = SparseTable(n_item, 4, B * world, store.device)     # i_item [n_item] stored as column 0 of a 4-wide table
+    # sparse path may skip that one huge segment -- but ONLY the histories' entries: a target item / category with id 0
+    # (tf.gather / embedding_lookup train row 0 like any other) keeps its gradient.
+    # Storage: ONE two-field arena [item rows + 1 | category rows + 1, K] (+ both Adam slots) and a one-field arena for the
+    # item bias, stored as column 0 of a 4-wide table.  The extra last row of every field is a DUMMY row: the fused step
+    # maps the history padding entries' sort keys to it (their gradients are exactly zero), so that row 0 stays an ordinary
+    # row for the target lookups (din/din.py:95-107 masks id 0 in the histories only).  The SparseTable objects the
+    # autograd path, the checkpoints and the tests see are VIEWS of the same memory.
+    dev = store.device
+    row_off = [0, n_item + 1, n_item + 1 + n_cate + 1]
+    arena = EmbeddingArena(row_off, K, cap, dev, with_w1=True, w1_field_mask=1)    # (first-order path = the item bias, field 0)
+    barena = EmbeddingArena([0, n_item], 4, B * world, dev, with_w1=False)
+    with torch.no_grad():
+        arena.tables.zero_()
+        barena.tables.zero_()
+
+    def view(tbl_arena, lo, rows, Kw, capacity, null_row):
+        t = SparseTable(rows, Kw, capacity, dev, table=tbl_arena.tables[lo:lo + rows], null_row=null_row)
+        assert t.table.data_ptr() == tbl_arena.tables[lo:lo + rows].data_ptr()
+        t.m, t.v = tbl_arena.m_t[lo:lo + rows], tbl_arena.v_t[lo:lo + rows]
+        return t
+
+    item = view(arena, 0, n_item, K, cap, n_item)              # null_row == rows: the dummy key of the history padding
+    cate = view(arena, n_item + 1, n_cate, K, cap, n_cate)
+    bias = view(barena, 0, n_item, 4, B * world, -1)           # i_item [n_item] stored as column 0 of a 4-wide table
     with torch.no_grad():
         for tbl, rows in ((item, n_item), (cate, n_cate)):
             t = torch.empty(rows, K)
@@ -79,6 +100,146 @@ def build_variables(store, params, B, P):
     store.tower = None
     if (3 * K) % 4 == 0 and widths[-1] <= 256:
         store.tower = FusedTower(store.dense, "mlp", 3 * K, widths, B, store.device, batch_norm=False)
+    store.din = None
+    if store.tower is not None and len(ATTENTION_LAYERS) == 2 and DinAttnFn.supported(K, *ATTENTION_LAYERS) and \
+            store.adam_mode == "tf1_dense":
+        store.din = DinFused(store, arena, barena, n_item, n_cate, K, B, P)
+
+
+class DinFused:
+    """din/din.py:83-173 TRAIN as a fixed launch sequence, no autograd (what _train_fused is to deepfm.py):
+      keys of both id tables (1 launch) -> ONE dedup sort for both (csrc/sort_large.hip, F = 2) -> the untouched-row sweep
+      -> ONE launch for the six lookups (:96-105) -> per history: row list of the non-padding positions, fused attention MLP,
+      masked weighted sum written straight into its slice of the 'mlp_layer' input (:131, never concatenated) -> MLP + loss
+      forward / backward (FusedTower, no batch-norm) -> per history: pooling backward + attention backward, both writing
+      their share of d(history rows) into the scatter's value block [entries, 2, K]; the target rows' gradients (the
+      attention's dq + the MLP input slice) land in the same block -> the bias rows -> two scatter + Adam launches.
+    The autograd path (`fused_step=False`) needed 68 launches, ~17 of them framework glue (cat / copy / fill)."""
+
+    def __init__(self, store, arena, barena, n_item, n_cate, K, B, P):
+        import ctypes as C
+        self.C = C
+        dev = store.device
+        self.arena, self.barena = arena, barena
+        self.n_item, self.n_cate, self.K, self.cap_B, self.P = n_item, n_cate, K, B, P
+        N = B * (P + 1)
+        f32 = dict(device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.keys2 = torch.zeros(N, 2, **i32)
+        self.X = torch.empty(B, 3 * K, **f32)                 # [q_item | pooled item history | pooled category history]
+        self.qi, self.qc = torch.empty(B, K, **f32), torch.empty(B, K, **f32)
+        self.ib = torch.empty(B, **f32)
+        self.H = [torch.empty(B * P, K, **f32) for _ in range(2)]
+        self.vals = torch.zeros(N, 2 * K, **f32)              # the scatter's value block: entry e -> [item grad | category grad]
+        self.gbias = torch.zeros(N, **f32)                    # d loss / d i_item[i_id] of the target entries, 0 for history entries
+        n1, n2 = ATTENTION_LAYERS
+        self.a1 = [torch.empty(B * P, n1, **f32) for _ in range(2)]
+        self.a2 = [torch.empty(B * P, n2, **f32) for _ in range(2)]
+        self.w = [torch.empty(B, P, **f32) for _ in range(2)]
+        self.dw = [torch.empty(B, P, **f32) for _ in range(2)]
+        self.rows = [torch.empty(B * P + 2 + (B * P + 1023) // 1024, **i32) for _ in range(2)]
+        self.ws = torch.empty(int(_lib.lib().rsx_din_attn_bwd_workspace_floats(B, P, K, n1, n2)), **f32)
+        # padding rows of the two-field arena: the last row of every field (include/rsx.h RSX_NULL_LAST_ROW)
+        arena.null_last = True
+        arena._bind_partials()
+
+    def _gather(self, B, i_id, i_cate, hist):
+        C, a = self.C, self.arena
+        K, P = self.K, self.P
+        cate_tab = a.tables[self.n_item + 1:]
+        jobs = (_lib.GatherJob * 6)()
+        spec = [(a.tables, i_id, self.X, B, K, 3 * K), (a.tables, i_id, self.qi, B, K, K), (cate_tab, i_cate, self.qc, B, K, K),
+                (a.tables, hist[0], self.H[0], B * P, K, K), (cate_tab, hist[1], self.H[1], B * P, K, K)]
+        for j, (tab, ids, out, n, k, ld) in zip(jobs, spec):
+            j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base = tab.data_ptr(), ids.data_ptr(), out.data_ptr(), n, k, ld, 0
+        _lib.check(_lib.lib().rsx_gather_rows_multi(jobs, 5, _stream()), "rsx_gather_rows_multi")
+        # tf.gather(i_item, i_id) (:96): column 0 of the 4-wide bias table
+        torch.index_select(self.barena.tables[:, 0], 0, i_id, out=self.ib[:B])
+
+    def train_step(self, store, features, labels, params, masks):
+        L = _lib.lib()
+        C, a, K, P = self.C, self.arena, self.K, self.P
+        i_id = features["i_id"].to(torch.int32).contiguous()
+        i_cate = features["i_cate"].to(torch.int32).contiguous()
+        hist = [features["u_iid_seq"].to(torch.int32).contiguous(), features["u_icat_seq"].to(torch.int32).contiguous()]
+        B = i_id.shape[0]
+        assert B <= self.cap_B and hist[0].shape[1] == P
+        N = B * (P + 1)
+        st = _stream()
+        P_ = store.dense
+        rate = params["dropout"]
+        step = store.opt.state.view(torch.int32)[3:4]
+        n1, n2 = ATTENTION_LAYERS
+        with torch.no_grad():
+            # ---- ids only: keys, ONE sort for both tables, the bias rows' sort, then the sweep over the untouched rows ----
+            # (sort keys of both tables + both histories' lists of non-padding positions: two launches)
+            keys2 = self.keys2[:N]
+            cnts = [self.rows[t][B * P:] for t in range(2)]
+            _lib.check(L.rsx_din_prepare(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item, self.n_cate,
+                                         _ptr(keys2), _ptr(self.rows[0]), _ptr(cnts[0]), _ptr(self.w[0]), _ptr(self.rows[1]),
+                                         _ptr(cnts[1]), _ptr(self.w[1]), st), "rsx_din_prepare")
+            a.select(0)
+            a.field_sort(keys2)
+            # The item bias (i_item, tf.gather by the target ids: :96,139) rides with the item table: its rows ARE item rows, so the
+            # item field's dedup serves it; rows that only a history touches get a zero-gradient update from the same launch.
+            cold = [a.adam_split_segments()[0][0],
+                    dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=4, n=self.n_item, var=self.barena.tables, m=self.barena.m_t,
+                         v=self.barena.v_t, slot=a.slot, slot_w=None)]
+            store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
+            # ---- forward --------------------------------------------------------------------------------------------
+            self._gather(B, i_id, i_cate, hist)
+            q = (self.qi[:B], self.qc[:B])
+            att_m = []
+            att_mk = [None, None]
+            if masks is not None:
+                att_mk = [masks.get("att_i"), masks.get("att_c")]
+            for t, pre in enumerate(("att_i", "att_c")):
+                Ws = [P_[f"{pre}.{v}{i}"] for i in range(3) for v in ("W", "b")]
+                mk = att_mk[t] if rate > 0.0 else None
+                m1, m2 = (None, None) if mk is None else (mk[0].contiguous(), mk[1].contiguous())
+                rows, cnt = self.rows[t], cnts[t]
+                _lib.check(L.rsx_din_attn_fwd(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]), _ptr(self.a2[t]),
+                                              _ptr(self.w[t]), _ptr(m1), _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, _ptr(rows),
+                                              _ptr(cnt), B, P, K, n1, n2, st), "rsx_din_attn_fwd")
+                _lib.check(L.rsx_din_pool_fwd_ld(_ptr(self.H[t]), _ptr(self.w[t]), _ptr(hist[t]),
+                                                 C.c_void_p(self.X.data_ptr() + 4 * K * (t + 1)), B, P, K, 3 * K, st),
+                           "rsx_din_pool_fwd_ld")
+                att_m.append((m1, m2))
+            tw = store.tower
+            mlp_mk = None if masks is None or "mlp" not in masks else \
+                [torch.nn.functional.pad(m, (0, w - m.shape[1]), value=1.0) for m, w in zip(masks["mlp"], tw.widths)]
+            loss, prob, dX, gs0, _ = tw.train_step(
+                self.X[:B], labels.reshape(-1).to(torch.float32), rate, step, s0=self.ib[:B],
+                head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=1, masks=mlp_mk, seed=0xD1AD,
+                outs=(None, self.gbias[:B], None))               # d loss / d bias lands in the scatter's first-order input
+            # ---- backward of the two attention blocks, straight into the scatter's value block --------------------------
+            vals = self.vals[:N]
+            vbase = vals.data_ptr()
+            for t, pre in enumerate(("att_i", "att_c")):
+                Ws = [P_[f"{pre}.W{i}"] for i in range(3)]
+                names = [f"{pre}.{v}{i}" for i in range(3) for v in ("W", "b")]
+                gout = P_.packed_grad(names)
+                assert gout is not None
+                m1, m2 = att_m[t]
+                rows, cnt = self.rows[t], self.rows[t][B * P:]
+                dH = C.c_void_p(vbase + 4 * (B * 2 * K + t * K))            # rows B.. of column block t
+                dout = C.c_void_p(dX.data_ptr() + 4 * K * (t + 1))           # d(pooled history t) = dX[:, (t+1)K : (t+2)K]
+                _lib.check(L.rsx_din_pool_bwd_ld(_ptr(self.H[t]), _ptr(self.w[t]), _ptr(hist[t]), dout, dH, _ptr(self.dw[t]), 0,
+                                                 B, P, K, 3 * K, 2 * K, st), "rsx_din_pool_bwd_ld")
+                dq = C.c_void_p(vbase + 4 * t * K)                           # rows 0 .. B-1 of column block t
+                _lib.check(L.rsx_din_attn_bwd_ld(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]),
+                                                 _ptr(self.a2[t]), _ptr(self.dw[t]), dH, dq, _ptr(gout), _ptr(self.ws), _ptr(m1),
+                                                 _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, 1, _ptr(rows), _ptr(cnt),
+                                                 _ptr(hist[t]), B, P, K, n1, n2, 2 * K, 2 * K,
+                                                 _ptr(dX) if t == 0 else None, 3 * K, st), "rsx_din_attn_bwd_ld")
+
+        def train_op():                                                    # AdamOptimizer.minimize (:172-173)
+            with torch.no_grad():
+                ba = self.barena
+                a.segsum_adam(N, None, vals, self.gbias[:N], None, store.opt, store.dense.adam_segments(),
+                              w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
+
+        return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 
 
 class DinHeadFn(torch.autograd.Function):
@@ -110,7 +271,7 @@ def _attention(tbl, hist, q, P_, pre, training, rate, masks, store=None, layer0=
     """din/din.py:103-125."""
     B, Pn = hist.shape
     K = tbl.K
-    H = tbl.lookup(hist)                                                   # dense_emb [B,P,K] (:105)
+    H = tbl.lookup(hist, pad_id=0)                                         # dense_emb [B,P,K] (:105); id 0 = padding (:107)
     n1, n2 = P_[f"{pre}.W0"].shape[1], P_[f"{pre}.W1"].shape[1]
     if len(ATTENTION_LAYERS) == 2 and DinAttnFn.supported(K, n1, n2) and store is not None:
         # fused MFMA kernel: the [B*P, 4K] concat, the tiled query and the layer outputs never round-trip through HBM;
@@ -149,6 +310,9 @@ def model_fn(features, labels, mode, params):
     training = mode == ModeKeys.TRAIN
     rate = params["dropout"]
     mk = params.get("_dropout_masks") or {}
+    if training and store.din is not None and store.dp is None and params.get("fused_step", True) and \
+            params.get("fused_attention", True) and params.get("fused_head", True):
+        return store.din.train_step(store, features, labels, params, params.get("_dropout_masks"))
 
     i_b = bias.lookup(i_id)[:, 0]                                          # tf.gather(pkg_w, i_id) (:96)
     pkg_emb = item.lookup(i_id)                                            # (:100)
@@ -172,6 +336,16 @@ def model_fn(features, labels, mode, params):
                 store.apply_gradients()
 
         return EstimatorSpec(mode, predictions={"prob": pred}, loss=loss, train_op=train_op_fused)
+    if not training and store.tower is not None and params.get("fused_infer", True) and not torch.is_grad_enabled() \
+            and net.shape[0] <= store.tower.cap:
+        # EVAL / PREDICT head through the TRAIN step's kernels (FusedTower.infer: 3 forward launches + the head, dropout off)
+        lab = None if (labels is None or mode == ModeKeys.PREDICT) else labels.reshape(-1).to(torch.float32)
+        prob, loss = store.tower.infer(net.contiguous(), store.opt.state.view(torch.int32)[3:4], lab, s0=i_b.contiguous(),
+                                       head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False)
+        predictions = {"prob": prob}
+        if mode == ModeKeys.PREDICT:
+            return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
+        return EstimatorSpec(mode, predictions=predictions, loss=loss[0], eval_metric_ops={"AUC": None, "Accuracy": None})
     for i in range(len(MLP_LAYERS)):
         net = L.dense(net, P_[f"mlp.W{i}"], P_[f"mlp.b{i}"], relu=True)
         net = L.dropout(net, rate, training, mk["mlp"][i] if "mlp" in mk else None)

@@ -253,7 +253,10 @@ def get_variable_store() -> VariableStore:
 
 
 class Estimator:
+    MAX_INFER_GRAPHS = 32      # EVAL / PREDICT input signatures that get a captured graph (and an entry in _graphs) at most
+
     def __init__(self, model_fn, model_dir=None, params=None, config: Optional[RunConfig] = None):
+        self._n_infer_graphs = 0
         self.model_fn = model_fn
         self.model_dir = model_dir
         self.params = dict(params or {})
@@ -306,9 +309,20 @@ class Estimator:
             self.store.window = (k, pos, feats) if k > 1 else None
             try:
                 losses.append(self._train_eager(f, l))
+            except BaseException:
+                if k > 1:
+                    # the rows no step of the window touches are already k steps ahead, the touched ones and global_step only
+                    # `pos`: not a state any run passes through.  Poison the store: evaluate / predict / checkpoint refuse.
+                    self.store.window_broken = True
+                raise
             finally:
                 self.store.window = None
         return losses
+
+    def _check_consistent(self, what):
+        if getattr(self.store, "window_broken", False):
+            raise _lib.RsxError("Estimator.%s: an optimizer window was interrupted by an exception; the variables are between two "
+                           "window boundaries (untouched rows ahead of the touched ones).  Restore from a checkpoint." % what)
 
     def _window_len(self):
         """Steps per optimizer window: what the model supports (store.window_k), RSX_ADAM_WINDOW overrides (1 = off)."""
@@ -532,7 +546,9 @@ class Estimator:
         return sched
 
     def prepare_resident(self, batches, steps, steps_per_graph=8):
-        """Capture (without running) every HIP graph train_resident(batches, steps, steps_per_graph) will replay."""
+        """Capture every HIP graph train_resident(batches, steps, steps_per_graph) will replay, so that a timed region
+        afterwards is pure replay.  Capturing itself executes nothing -- but when the resident graphs are still cold this runs
+        the TWO eager warm-up training steps first (lazy initialisation, allocator warm-up): real optimizer steps."""
         n = len(batches)
         if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
             return
@@ -604,8 +620,15 @@ class Estimator:
             st["pin"].copy_(st["all"])  # (the staging buffer starts as this window's batches: the graph's first node reads it)
             torch.cuda.synchronize()
 
+        # The kernel node reads the pinned staging buffer through the device's mapping of host memory, right after plain host
+        # stores: that needs coherent (fine-grained) pinned allocations, torch's default.  RSX_WINDOW_STAGE=memcpy (automatic
+        # under HIP_HOST_COHERENT=0) makes the first node a hipMemcpyAsync instead (0.0696 vs 0.0680 ms per DeepFM step).
+        stage_memcpy = os.environ.get("RSX_WINDOW_STAGE", "") == "memcpy" or os.environ.get("HIP_HOST_COHERENT", "1") == "0"
+
         def window():
-            if host:                    # first node: the staged batches, fetched from pinned host memory by a kernel
+            if host and stage_memcpy:
+                st["all"].copy_(st["pin"], non_blocking=True)
+            elif host:                  # first node: the staged batches, fetched from pinned host memory by a kernel
                 _lib.check(_lib.lib().rsx_copy_bytes(st["all"].data_ptr(), st["pin"].data_ptr(), st["all"].numel(),
                                                      torch.cuda.current_stream().cuda_stream), "rsx_copy_bytes")
             return self._train_window([sb.views() for sb in st["static"]])
@@ -753,7 +776,16 @@ class Estimator:
             return spec.predictions["prob"], spec.loss, l
         pb = PackedBatch(features, labels if has_lab else np.zeros(0, np.float32))
         key = ("infer", mode, has_lab) + pb.key()
-        g = self._graphs.setdefault(key, {"warm": 0})
+        g = self._graphs.get(key)
+        if g is None:
+            if self._n_infer_graphs >= self.MAX_INFER_GRAPHS:
+                # a serving loop with ever-new request sizes: stop capturing (and stop remembering signatures), stay eager
+                dev = pb if pb.flat.device == self.store.device else pb.to(self.store.device)
+                f, l = dev.views()
+                spec = self._call_model_fn(f, l if mode == ModeKeys.EVAL else None, mode)
+                return spec.predictions["prob"], spec.loss, (l if has_lab else None)
+            g = self._graphs[key] = {"warm": 0}
+            self._n_infer_graphs += 1
         if "graph" in g:
             self._h2d(g["static"], pb)
             g["graph"].replay()
@@ -762,10 +794,6 @@ class Estimator:
         if g["warm"] < 1:                 # first batch of this signature: eager (lazy initialisation, allocator warm-up)
             g["warm"] += 1
             f, l = dev.views()
-            spec = self._call_model_fn(f, l if mode == ModeKeys.EVAL else None, mode)
-            return spec.predictions["prob"], spec.loss, (l if has_lab else None)
-        if sum(1 for k in self._graphs if k[0] == "infer" and "graph" in self._graphs[k]) >= 32:
-            f, l = dev.views()          # (a serving loop with ever-new request sizes: stop capturing, stay eager)
             spec = self._call_model_fn(f, l if mode == ModeKeys.EVAL else None, mode)
             return spec.predictions["prob"], spec.loss, (l if has_lab else None)
         g["static"] = dev.clone()
@@ -783,6 +811,7 @@ class Estimator:
         """Estimator.evaluate (fm/fm.py:216-221): AUC-200 / Accuracy / mean batch loss accumulated ON DEVICE by one
         launch per batch (metrics.EvalMetrics); the host synchronises once, when the counters are read back.
         Data-parallel: every rank evaluates its own shard of the eval stream and the integer counters are summed."""
+        self._check_consistent("evaluate")
         met = _metrics.EvalMetrics(self.store.device)
         n = 0
         it = input_fn()
@@ -811,6 +840,7 @@ class Estimator:
     def _save_checkpoint(self, step):
         """Replicas are bit-identical by construction: rank 0 writes, everybody waits (MirroredStrategy: the chief saves)."""
         from . import checkpoint
+        self._check_consistent("checkpoint")
         if self._is_chief():
             checkpoint.save(self.model_dir, self.store, step, self.config.keep_checkpoint_max)
         if self.store.dp is not None:

@@ -266,11 +266,8 @@ def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_p
                     raise RsxError("DIN TFRecord stream: %s" % lib().rsx_strerror(int(n)).decode())
                 if n < bs:
                     lab, iid, icat, hi, hc = lab[:n], iid[:n], icat[:n], hi[:n], hc[:n]
-                # id 0 is the history padding (din/din.py:56-57,107): the device tables skip gradient entries of row 0, so a
-                # TARGET item / category with id 0 would silently lose its gradient (tf.gather / embedding_lookup do update
-                # it) -- refuse such data instead of diverging from the reference
-                if (iid <= 0).any() or (icat <= 0).any():
-                    raise RsxError("DIN input: i_id / i_cate must be > 0 (0 is reserved for history padding)")
+                # (id 0 is the history padding (din/din.py:56-57,107) AND an ordinary row for the target lookups, as in the
+                # reference: the device side keys the padding entries to a dummy row, so a target id 0 trains normally)
                 if ids_int32:
                     iid, icat, hi, hc = (x.astype(np.int32) for x in (iid, icat, hi, hc))
                 yield {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab

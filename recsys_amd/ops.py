@@ -108,7 +108,9 @@ class EmbeddingArena:
         # (G / gw1: stage A finishes every segment of <= 16 entries straight into the scatter's outputs)
         self.partials = None
         if self.two_stage_ws:
-            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1))
+            nl = getattr(self, "null_last", False)     # padding entries keyed to every field's last (dummy) row: never walked
+            self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1),
+                                             _ptr(self.row_off) if nl else None, _lib.NULL_LAST_ROW if nl else _lib.NULL_NONE)
 
     def select(self, i):
         """Makes sort workspace i (position i of the optimizer window) the one field_sort / sort_job / segsum* use."""
@@ -246,7 +248,7 @@ class EmbeddingArena:
                                    self.stride, part, blk, _stream()), "rsx_segsum_bwd")
 
     def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True, second=None,
-                    window=None):
+                    window=None, w1_ext=None):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups).
         second = (arena2, dX2): a table set sharing this arena's sort (share_sort_of), updated by the same launch.
         window = (k, cur): this step is position `cur` of an optimizer window of k steps (the current sort workspace must
@@ -267,14 +269,18 @@ class EmbeddingArena:
             assert self.cur_buf == window[1], "segsum_adam: select() the window position's sort workspace first"
             win = self.window(*window)
         w = self.with_w1 and gy1 is not None
+        w1p, mwp, vwp, w1s, w1sp = (_ptr(self.w1), _ptr(self.m_w), _ptr(self.v_w), 1, 0) if w else (None, None, None, 1, 0)
+        if w1_ext is not None:          # (w1, m, v, stride, sparse formula): a first-order vector stored outside this arena
+            w1p, mwp, vwp, w1s, w1sp = _ptr(w1_ext[0]), _ptr(w1_ext[1]), _ptr(w1_ext[2]), int(w1_ext[3]), int(w1_ext[4])
+            assert gy1 is not None
         part = self._stage_a(B, S, dX, gy1, gy2, blk)
-        check(lib().rsx_segsum_adam_rows(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), _ptr(self.w1) if w else None,
-                                         _ptr(self.m_w) if w else None, _ptr(self.v_w) if w else None, _ptr(S), _ptr(dX),
-                                         _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
-                                         _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
-                                         None if sweep is None else C.byref(sweep), part, blk, sec,
-                                         None if win is None else C.byref(win),
-                                         _ptr(opt.state), 1 if advance else 0, lr, b1, b2, eps, _stream()), "rsx_segsum_adam_rows")
+        check(lib().rsx_segsum_adam_rows2(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), w1p, mwp, vwp, _ptr(S), _ptr(dX),
+                                          _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
+                                          _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
+                                          None if sweep is None else C.byref(sweep), part, blk, sec,
+                                          None if win is None else C.byref(win),
+                                          _ptr(opt.state), 1 if advance else 0, lr, b1, b2, eps, w1s, w1sp, _stream()),
+              "rsx_segsum_adam_rows2")
 
     # -- optimizer segments ----------------------------------------------------------------
     def adam_split_segments(self, window_k=1):
@@ -618,10 +624,13 @@ class FusedTower:
               "rsx_tower_head")
         if self.bn_on:
             check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
+        # (large batches: the layers' dW reductions are handed back as jobs and run as ONE launch after the last layer)
+        jobs = (_lib.DwReduceJob * max(nl, 1))()
+        defer = nl <= 4
         for l in reversed(range(nl)):
             K = self.k0 if l == 0 else self.widths[l - 1]
             last = l == nl - 1
-            check(L.rsx_tower_bwd_layer(
+            check(L.rsx_tower_bwd_layer_defer(
                 _ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(self.a[l]), _ptr(self.dy[l]),
                 _ptr(self.bstat[l]), _ptr(self.bn[l]), bnp(f"{pre}.gamma{l}"),
                 _ptr(g(f"{pre}.W{l}")), _ptr(g(f"{pre}.b{l}")), bng(f"{pre}.gamma{l}"), bng(f"{pre}.beta{l}"),
@@ -634,9 +643,15 @@ class FusedTower:
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
                 rs, seed, l, rate, B, K, self.widths[l],
                 C.byref(sort_job) if (last and sort_job is not None and not sort_in_fwd) else None,
-                ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), st), "rsx_tower_bwd_layer")
+                ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), C.byref(jobs[l]) if defer else None, st),
+                "rsx_tower_bwd_layer_defer")
             if l and self.bn_on:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
+        if defer:
+            todo = [jobs[l] for l in range(nl) if jobs[l].sb > 0]
+            if todo:
+                arr = (_lib.DwReduceJob * len(todo))(*todo)
+                check(L.rsx_tower_reduce_dw_jobs(arr, len(todo), st), "rsx_tower_reduce_dw_jobs")
         return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
 
 
@@ -737,18 +752,22 @@ class SparseTable:
     def __init__(self, rows, K, capacity, device="cuda", table=None, null_row=-1):
         dev = _require_cuda(device)
         self.R, self.K, self.cap = int(rows), int(K), int(capacity)
-        self.null_row = int(null_row)     # padding id whose entries carry exactly-zero gradients (DIN: 0), or -1
+        # null_row: the key whose entries carry exactly-zero gradients and need not be summed, or -1.  null_row == rows is a
+        # DUMMY key one past the table: lookups declared with `pad_id` (DIN's histories, padding id 0: din/din.py:107) map their
+        # padding entries to it, so that the real row `pad_id` stays an ordinary row for every other lookup of the table
+        self.null_row = int(null_row)
+        self.key_rows = self.R + 1 if self.null_row == self.R else self.R
         self.table = torch.zeros(self.R, self.K, device=dev) if table is None else \
             torch.as_tensor(table, dtype=torch.float32).to(dev).contiguous()
         self.m = torch.zeros_like(self.table)
         self.v = torch.zeros_like(self.table)
         i32 = dict(dtype=torch.int32, device=dev)
         self.row_off = torch.zeros(2, **i32)
-        self.row_off[1] = self.R
+        self.row_off[1] = self.key_rows
         self.uniq_row = torch.zeros(self.cap, **i32)
         self.seg_off = torch.zeros(self.cap + 1, **i32)
         self.nuniq = torch.zeros(1, **i32)
-        self.slot = torch.full((self.R + 4,), -1, **i32)
+        self.slot = torch.full((self.R + 8,), -1, **i32)          # (+ the dummy key, + int4 tail reads)
         self.G = torch.zeros(self.cap, self.K, device=dev)
         self.perm = torch.zeros(self.cap, **i32)
         self.sort_ws = torch.zeros(int(lib().rsx_field_sort_large_workspace_ints(self.cap, 1, self.cap)), **i32) \
@@ -770,8 +789,10 @@ class SparseTable:
                                       0, flat.shape[0], 1, self.K, _stream()), "rsx_gather_fm_fwd")
         return out.view(*ids.shape, self.K)
 
-    def lookup(self, ids):
-        return _LookupFn.apply(self.hook, self, ids)
+    def lookup(self, ids, pad_id=None):
+        """pad_id: this lookup's padding id (its entries are masked downstream and carry exactly-zero gradients): keyed to
+        the table's dummy row in the sparse gradient when the table was built with null_row == rows."""
+        return _LookupFn.apply(self.hook, self, ids, pad_id)
 
     def finalize(self, dp=None):
         """Dedup + ordered segment-sum of everything registered since the last call (forward lookup order, which is
@@ -793,11 +814,11 @@ class SparseTable:
         perm = self.perm
         if N > EmbeddingArena.LDS_SORT_MAX_B:
             check(lib().rsx_field_sort_large(_ptr(ids2), _ptr(self.row_off), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row),
-                                             _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid), _ptr(self.sort_ws), self.R,
+                                             _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid), _ptr(self.sort_ws), self.key_rows,
                                              N, 1, self.cap, _stream()), "rsx_field_sort_large")
         else:
             check(lib().rsx_field_sort(_ptr(ids2), _ptr(self.row_off), _ptr(perm), _ptr(self.seg_off), _ptr(self.uniq_row),
-                                       _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid) if two else None, self.R, N, 1,
+                                       _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid) if two else None, self.key_rows, N, 1,
                                        self.cap, _stream()), "rsx_field_sort")
         part = None
         if two:
@@ -819,15 +840,18 @@ class SparseTable:
 
 class _LookupFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hook, tbl, ids):
-        ctx.tbl, ctx.ids, ctx.seq = tbl, ids, tbl._seq
+    def forward(ctx, hook, tbl, ids, pad_id=None):
+        ctx.tbl, ctx.ids, ctx.seq, ctx.pad_id = tbl, ids, tbl._seq, pad_id
         tbl._seq += 1
         return tbl.gather(ids)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.tbl.pending.append((ctx.seq, ctx.ids, g.contiguous()))
-        return None, None, None
+        ids = ctx.ids
+        if ctx.pad_id is not None and ctx.tbl.null_row == ctx.tbl.R:
+            ids = torch.where(ids == ctx.pad_id, torch.full_like(ids, ctx.tbl.null_row), ids)
+        ctx.tbl.pending.append((ctx.seq, ids, g.contiguous()))
+        return None, None, None, None
 
 
 class DinPoolFn(torch.autograd.Function):

@@ -62,7 +62,7 @@ def test_sparse_table_segments_and_ordered_sums():
         np.testing.assert_allclose(Gg, G, rtol=2e-5, atol=1e-6)
 
 
-def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False):
+def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False, zero_targets=0, extra_params=None):
     from recsys_amd import din, synthetic
     from recsys_amd.estimator import ModeKeys
     from tests.parity_util import make_estimator
@@ -71,8 +71,12 @@ def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False):
     P["item_bias"] += (rng.standard_normal(n_item) * 0.01).astype(np.float32)
     params = {"embedding_size": K, "learning_rate": 1e-3, "dropout": dropout, "max_batch_size": B, "n_item": n_item,
               "n_cate": n_cate}
+    params.update(extra_params or {})
     est = make_estimator(din.model_fn, params, use_graph=use_graph)
     batches = [synthetic.din_batch(rng, B, Pn, n_item, n_cate) for _ in range(steps)]
+    for b in batches:              # target item / category id 0: an ordinary row for tf.gather (din/din.py:96-101)
+        b["i_id"][:zero_targets] = 0
+        b["i_cate"][:max(zero_targets - 1, 0)] = 0
 
     def feats(b):
         return {k: torch.from_numpy(b[k]).cuda() for k in ("i_id", "i_cate", "u_iid_seq", "u_icat_seq")}
@@ -114,6 +118,18 @@ def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False):
 @pytest.mark.parametrize("dropout", [0.0, 0.5])
 def test_din_train_parity_small(dropout):
     err, losses, perr = _din_run(B=24, Pn=12, K=16, n_item=200, n_cate=20, steps=4, seed=3, dropout=dropout)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_din_target_id_zero_trains_like_any_other_row(fused):
+    """din/din.py:95-107 masks id 0 in the HISTORIES only; a target item / category 0 gets its gradient (both the fused step
+    and the autograd path key the history padding to a dummy row instead of skipping row 0)."""
+    err, losses, perr = _din_run(B=24, Pn=12, K=16, n_item=200, n_cate=20, steps=4, seed=7, dropout=0.0, zero_targets=5,
+                                 extra_params={"fused_step": fused})
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5, losses
@@ -249,3 +265,91 @@ def test_attention_over_the_valid_rows_equals_attention_over_all_rows():
         res.append((out.detach().cpu().numpy(), tH.grad.cpu().numpy(), tq.grad.cpu().numpy(), wg))
     for a, b, name in zip(res[0], res[1], ("out", "dH", "dq", "weights")):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5, err_msg=name)
+
+
+def test_gather_rows_multi_equals_indexing():
+    """rsx_gather_rows_multi: several tf.gather / embedding_lookup calls (din/din.py:96-105) in one launch, with output row
+    strides (a lookup written straight into its column slice of the 'mlp_layer' input)."""
+    import ctypes as C
+    from recsys_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    t32 = torch.randn(500, 32, device="cuda")
+    t16 = torch.randn(70, 16, device="cuda")
+    ids_a = torch.from_numpy(rng.integers(0, 500, 130).astype(np.int32)).cuda()
+    ids_b = torch.from_numpy(rng.integers(0, 70, 999).astype(np.int32)).cuda()
+    ids_c = torch.from_numpy(rng.integers(0, 400, 57).astype(np.int32)).cuda()
+    X = torch.full((130, 96), -7.0, device="cuda")
+    o_b = torch.empty(999, 16, device="cuda")
+    o_c = torch.empty(57, 32, device="cuda")
+    jobs = (_lib.GatherJob * 3)()
+    for j, (tab, ids, out, k, ld, base) in zip(jobs, ((t32, ids_a, X[:, 32:], 32, 96, 0), (t16, ids_b, o_b, 16, 16, 0),
+                                                     (t32, ids_c, o_c, 32, 32, 100))):
+        j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base = tab.data_ptr(), ids.data_ptr(), out.data_ptr(), ids.shape[0], k, ld, base
+    assert L.rsx_gather_rows_multi(jobs, 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(X[:, 32:64], t32[ids_a.long()]) and bool((X[:, :32] == -7).all()) and bool((X[:, 64:] == -7).all())
+    assert torch.equal(o_b, t16[ids_b.long()])
+    assert torch.equal(o_c, t32[ids_c.long() + 100])
+
+
+@pytest.mark.parametrize("B,P", [(3, 5), (64, 100), (1024, 100)])
+def test_din_prepare_keys_and_row_lists_are_exact(B, P):
+    """rsx_din_prepare: the sort keys of both id tables (history padding -> the tables' dummy rows, target ids untouched -- a
+    target id 0 stays row 0) and both histories' ascending lists of non-padding positions, against numpy."""
+    import ctypes as C
+    from recsys_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(B)
+    i_id = rng.integers(0, 50, B).astype(np.int32)
+    i_cate = rng.integers(0, 9, B).astype(np.int32)
+    hi = rng.integers(1, 50, (B, P)).astype(np.int32)
+    hc = rng.integers(1, 9, (B, P)).astype(np.int32)
+    for b in range(B):
+        n = rng.integers(0, P + 1)
+        hi[b, n:] = 0
+        hc[b, rng.integers(0, P + 1):] = 0          # (the two histories' masks need not agree)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    d = [dev(x) for x in (i_id, i_cate, hi, hc)]
+    M, N = B * P, B * (P + 1)
+    keys2 = torch.zeros(N, 2, dtype=torch.int32, device="cuda")
+    rows = [torch.zeros(M + 2 + (M + 1023) // 1024, dtype=torch.int32, device="cuda") for _ in range(2)]
+    w = [torch.ones(B, P, device="cuda") for _ in range(2)]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert L.rsx_din_prepare(p(d[0]), p(d[1]), p(d[2]), p(d[3]), B, P, 50, 9, p(keys2), p(rows[0]), p(rows[0][M:]), p(w[0]),
+                             p(rows[1]), p(rows[1][M:]), p(w[1]), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    want = np.zeros((N, 2), np.int32)
+    want[:B, 0], want[:B, 1] = i_id, i_cate
+    want[B:, 0] = np.where(hi.reshape(-1) > 0, hi.reshape(-1), 50)
+    want[B:, 1] = np.where(hc.reshape(-1) > 0, hc.reshape(-1), 9)
+    assert np.array_equal(keys2.cpu().numpy(), want)
+    for t, h in enumerate((hi, hc)):
+        valid = np.flatnonzero(h.reshape(-1) > 0)
+        r = rows[t].cpu().numpy()
+        assert r[M] == len(valid) and np.array_equal(r[:len(valid)], valid)
+        assert np.array_equal(w[t].cpu().numpy().reshape(-1) == 0, h.reshape(-1) <= 0)
+
+
+def test_din_eval_head_through_the_fused_tower_equals_the_torch_path():
+    """EVAL / PREDICT of din.py: the MLP head through FusedTower.infer (dropout off, no batch-norm) against the torch layers."""
+    from recsys_amd import din, synthetic
+    from recsys_amd.estimator import ModeKeys
+    from tests.parity_util import make_estimator
+    rng = np.random.default_rng(2)
+    B, Pn, K = 48, 20, 32
+    out = []
+    for fused in (True, False):
+        params = {"embedding_size": K, "learning_rate": 1e-2, "dropout": 0.5, "max_batch_size": B, "n_item": 300, "n_cate": 20,
+                  "fused_infer": fused}
+        est = make_estimator(din.model_fn, params)
+        r2 = np.random.default_rng(5)
+        bs = [synthetic.din_batch(r2, B, Pn, 300, 20) for _ in range(4)]
+        feats = lambda b: {k: torch.from_numpy(b[k]).cuda() for k in ("i_id", "i_cate", "u_iid_seq", "u_icat_seq")}
+        for b in bs[:3]:
+            est._train_step(feats(b), torch.from_numpy(b["label"]).cuda())
+        with torch.no_grad():
+            sp = est._call_model_fn(feats(bs[3]), torch.from_numpy(bs[3]["label"]).cuda(), ModeKeys.EVAL)
+        out.append((sp.predictions["prob"].cpu().numpy().reshape(-1), float(sp.loss)))
+    (p1, l1), (p2, l2) = out
+    assert np.abs(p1 - p2).max() < 2e-6 and abs(l1 - l2) < 2e-6, (np.abs(p1 - p2).max(), l1, l2)

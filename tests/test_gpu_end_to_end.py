@@ -147,3 +147,37 @@ def test_fused_inference_equals_the_framework_path(kind):
         (e1, p1), (e2, p2) = res
         assert p1.shape == (3 * B,) and np.abs(p1 - p2).max() < 2e-6, (B, np.abs(p1 - p2).max())
         assert abs(e1["loss"] - e2["loss"]) < 2e-6 and abs(e1["AUC"] - e2["AUC"]) < 1e-6 and e1["Accuracy"] == e2["Accuracy"], (e1, e2)
+
+
+@pytest.mark.gpu
+def test_an_interrupted_optimizer_window_poisons_the_store():
+    """Inside an optimizer window the variables are not a state any step-by-step run passes through; if a step of a window
+    raises, evaluate / checkpoints must refuse instead of persisting that state."""
+    import torch
+    from recsys_amd import _lib, deepfm, synthetic
+    from recsys_amd.estimator import Estimator, PackedBatch, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    lin, emb = build_feature_columns(16, "indicator_all")
+    layout = CriteoLayout.from_columns(emb)
+    host = synthetic.criteo_id_batches(layout, 4, 64, seed=1)
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+              "dropout": 0.0, "deep_layers": "100,100", "max_batch_size": 64}
+    est = Estimator(deepfm.model_fn, None, params, RunConfig(device="cuda", seed=3, use_hip_graph=False))
+    pbs = [PackedBatch({"ids": i}, y, device="cuda") for i, y, _ in host]
+    est._train_step(pbs[0])                                        # builds the variables
+    est._train_window([pb.views() for pb in pbs])                  # a complete window: fine
+    est.evaluate(lambda: iter([({"ids": host[0][0]}, host[0][1].reshape(-1, 1))]), steps=1)
+    real, calls = est._train_eager, []
+
+    def flaky(f, l):
+        calls.append(1)
+        if len(calls) == 3:
+            raise RuntimeError("injected failure in the third step of the window")
+        return real(f, l)
+
+    est._train_eager = flaky
+    with pytest.raises(RuntimeError):
+        est._train_window([pb.views() for pb in pbs])
+    est._train_eager = real
+    with pytest.raises(_lib.RsxError):
+        est.evaluate(lambda: iter([({"ids": host[0][0]}, host[0][1].reshape(-1, 1))]), steps=1)
