@@ -419,7 +419,8 @@ int rsx_din_pool_bwd_ld(const float* H, const float* w, const int32_t* ids, cons
                         int accumulate, int B, int P, int K, int ld_dout, int ld_dH, rsx_stream_t stream);
 
 /* Several plain row gathers (tf.gather / tf.nn.embedding_lookup of one table each, din/din.py:96-105) in ONE launch:
- * out[e, 0:K] = table[row_base + ids[e], 0:K], e < n, `out` rows ld_out floats apart.  Host array of <= 8 jobs.             */
+ * out[e, 0:K] = table[row_base + ids[e], 0:K], e < n, `out` rows ld_out floats apart (K a multiple of 4, or K == 1: see
+ * ld_table).  Host array of <= 8 jobs.                                                                                    */
 #define RSX_GATHER_MAX_JOBS 8
 typedef struct {
   const float* table;
@@ -427,6 +428,7 @@ typedef struct {
   float* out;
   int64_t n;
   int32_t K, ld_out, row_base;
+  int32_t ld_table;          /* K == 1 only (scalar rows of a 1-D variable): floats between its elements in `table` */
 } rsx_gather_job;
 int rsx_gather_rows_multi(const rsx_gather_job* jobs_h, int njobs, rsx_stream_t stream);
 

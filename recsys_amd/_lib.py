@@ -51,7 +51,7 @@ class DwReduceJob(C.Structure):
 
 class GatherJob(C.Structure):
     _fields_ = [("table", C.c_void_p), ("ids", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("K", C.c_int32),
-                ("ld_out", C.c_int32), ("row_base", C.c_int32)]
+                ("ld_out", C.c_int32), ("row_base", C.c_int32), ("ld_table", C.c_int32)]
 
 
 class TableSet(C.Structure):

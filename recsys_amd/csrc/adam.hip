@@ -57,8 +57,11 @@ extern "C" int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg) {
 __global__ __launch_bounds__(ADAM_T) void adam_slice_k(const AdamSlice s) { adam_block(s.args, s.blk_lo + blockIdx.x); }
 
 // The sweep of an optimizer window (rsx_adam_seg.slot_w): 1 + nw updates per untouched row in one pass.
+#ifndef RSX_ADAM_WIN_OCC
+#define RSX_ADAM_WIN_OCC 4      // waves per SIMD the window sweep is compiled for (A/B knob: 3 = 168 registers, no spills at NW = 7)
+#endif
 template <int NW>
-__global__ __launch_bounds__(ADAM_T, 4) void adam_window_k(const AdamSlice s) {
+__global__ __launch_bounds__(ADAM_T, RSX_ADAM_WIN_OCC) void adam_window_k(const AdamSlice s) {
   adam_window_block<NW>(s.args, s.blk_lo + blockIdx.x);
 }
 template <int NW>

@@ -148,13 +148,14 @@ class DinFused:
         K, P = self.K, self.P
         cate_tab = a.tables[self.n_item + 1:]
         jobs = (_lib.GatherJob * 6)()
-        spec = [(a.tables, i_id, self.X, B, K, 3 * K), (a.tables, i_id, self.qi, B, K, K), (cate_tab, i_cate, self.qc, B, K, K),
-                (a.tables, hist[0], self.H[0], B * P, K, K), (cate_tab, hist[1], self.H[1], B * P, K, K)]
-        for j, (tab, ids, out, n, k, ld) in zip(jobs, spec):
-            j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base = tab.data_ptr(), ids.data_ptr(), out.data_ptr(), n, k, ld, 0
-        _lib.check(_lib.lib().rsx_gather_rows_multi(jobs, 5, _stream()), "rsx_gather_rows_multi")
-        # tf.gather(i_item, i_id) (:96): column 0 of the 4-wide bias table
-        torch.index_select(self.barena.tables[:, 0], 0, i_id, out=self.ib[:B])
+        spec = [(a.tables, i_id, self.X, B, K, 3 * K, 0), (a.tables, i_id, self.qi, B, K, K, 0),
+                (cate_tab, i_cate, self.qc, B, K, K, 0), (a.tables, hist[0], self.H[0], B * P, K, K, 0),
+                (cate_tab, hist[1], self.H[1], B * P, K, K, 0),
+                (self.barena.tables, i_id, self.ib, B, 1, 1, 4)]       # tf.gather(i_item, i_id) (:96): column 0 of the 4-wide table
+        for j, (tab, ids, out, n, k, ld, ldt) in zip(jobs, spec):
+            j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base, j.ld_table = \
+                tab.data_ptr(), ids.data_ptr(), out.data_ptr(), n, k, ld, 0, ldt
+        _lib.check(_lib.lib().rsx_gather_rows_multi(jobs, 6, _stream()), "rsx_gather_rows_multi")
 
     def train_step(self, store, features, labels, params, masks):
         L = _lib.lib()

@@ -27,12 +27,14 @@ def build_variables(store, params, capacity):
     # the fused TRAIN step is the only xDeepFM path: check its envelope before any variable exists, so an unsupported
     # configuration fails here with the reason instead of at the first step
     _layers = list(map(int, params["deep_layers"].split(",")))
-    if params["embedding_size"] != 16 or max(cin) > 128:
-        raise _lib.RsxError("xdeepfm: the CIN kernels cover embedding_size 16 and cross_layers widths <= 128 "
-                       "(got embedding_size=%d, cross_layers=%s)" % (params["embedding_size"], params["cross_layers"]))
-    if not FusedTower.supports(F * D, _layers):
-        raise _lib.RsxError("xdeepfm: deep_layers=%s is outside the fused tower's envelope (widths multiple of 4, last <= 256)"
-                       % params["deep_layers"])
+    if D not in (4, 8, 16, 32, 64):
+        raise _lib.RsxError("xdeepfm: embedding_size must be 4, 8, 16, 32 or 64 (rows are moved as float4 lanes); got %d" % D)
+    # The hand-written CIN kernels cover embedding_size 16 and layer widths <= 128 (BASELINE's [128,128], the script's default
+    # 20,10,10), the fused tower widths that are multiples of 4.  Every other value the reference's flags accept
+    # (xdeepfm/xdeepfm.py:12-19) trains through the GENERIC path: the same gather / scatter / Adam kernels under autograd, the
+    # CIN layer and the tower as library GEMMs (`_cin_layer_generic`, layers.py) -- slower, same arithmetic.
+    store.generic = bool(params.get("force_generic", False)) or D != 16 or max(cin) > 128 or \
+        not FusedTower.supports(F * D, _layers)
     layers = list(map(int, params["deep_layers"].split(",")))
     if store.dp is not None:
         capacity *= store.dp.world
@@ -80,6 +82,10 @@ def build_variables(store, params, capacity):
     store.build({"input_layer": a1, "input_layer_1": a2}, shapes, init, params["learning_rate"])
     store.layout = layout
     store.cin_sizes = cin
+    store.dp_block = False
+    if store.generic:
+        store.tower = store.cin = None
+        return
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
@@ -94,12 +100,24 @@ def build_variables(store, params, capacity):
     store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
 
-def _cin(X0, P, sizes, sweeps=None):
+def _cin_layer_generic(X0, Xk, W, c):
+    """One CIN layer for ANY embedding size / width (xdeepfm/xdeepfm.py:145-172) as library ops under autograd:
+    Z[b,d,f*H+h] = X0[b,f,d] * Xk[b,h,d] ((f major, h minor)), out[b,n,d] = relu(Z[b,d,:] . W[:,n] + c[n])."""
+    B, F, D = X0.shape
+    H = Xk.shape[1]
+    Z = torch.einsum("bfd,bhd->bdfh", X0, Xk).reshape(B, D, F * H)
+    return torch.relu(Z @ W + c).transpose(1, 2)
+
+
+def _cin(X0, P, sizes, sweeps=None, generic=False):
     """'cin_net' (:135-182): every layer's full map is both the next hidden state and a direct output.
     sweeps[k]: slice of the untouched-row optimizer sweep carried by layer k's weight-gradient launch."""
     outs, Xk = [], X0
     for k in range(len(sizes)):
-        Xk = CinLayerFn.apply(X0, Xk, P[f"cin.W{k}"], P[f"cin.c{k}"], None if sweeps is None else sweeps[k])
+        if generic:
+            Xk = _cin_layer_generic(X0, Xk, P[f"cin.W{k}"], P[f"cin.c{k}"])
+        else:
+            Xk = CinLayerFn.apply(X0, Xk, P[f"cin.W{k}"], P[f"cin.c{k}"], None if sweeps is None else sweeps[k])
         outs.append(Xk)
     res = torch.cat(outs, 1).sum(-1)                                        # (:180-181)
     return L.dense(res, P["cin.Wout"], P["cin.bout"], relu=True)            # cin_y [B,1] (:182)
@@ -244,10 +262,11 @@ def model_fn(features, labels, mode, params):
         build_variables(store, params, capacity=max(int(params.get("max_batch_size", 0)), ids.shape[0]))
     a1, a2, P = store.embeddings["input_layer"], store.embeddings["input_layer_1"], store.dense
     masks = params.get("_dropout_masks")
-    if mode == ModeKeys.TRAIN:
+    generic = getattr(store, "generic", False)
+    if mode == ModeKeys.TRAIN and not generic:
         return _train_fused(store, a1, a2, ids, logx, labels, params, masks)
     B = ids.shape[0]
-    if params.get("fused_infer", True) and not torch.is_grad_enabled() and B <= store.tower.cap:
+    if not generic and params.get("fused_infer", True) and not torch.is_grad_enabled() and B <= store.tower.cap:
         # EVAL / PREDICT through the TRAIN step's kernels: both gathers + linear_net pre-activation, CIN forward (fp32 or bf16
         # as configured), FusedTower.infer (see deepfm.py)
         E1 = torch.empty(B, a1.F * a1.D, device=ids.device)
@@ -264,11 +283,20 @@ def model_fn(features, labels, mode, params):
             return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
         return EstimatorSpec(mode, predictions=predictions, loss=loss[0], eval_metric_ops={"AUC": None, "Accuracy": None})
     n_layers = len(params["deep_layers"].split(","))
-    E1, _, y1cat, _ = a1.gather(ids, first_order=True)
+    training = mode == ModeKeys.TRAIN
+    if training:                 # generic TRAIN: the gathers are autograd nodes whose backward is the sorted segment-sum
+        from .ops import gather_fm
+        ids_s = ids if store.dp is None else store.dp.all_gather_rows(ids)     # the optimizer sees the global batch
+        a1.field_sort(ids_s)                                     # one dedup sort serves both table sets
+        a2.field_sort(ids_s)                                     # (a2 aliases a1's sort outputs: bookkeeping only)
+        E1, y1cat = gather_fm(a1, ids, fm=False, first_order=True, dp=store.dp)
+        (E2,) = gather_fm(a2, ids, fm=False, first_order=False, dp=store.dp)
+    else:
+        E1, _, y1cat, _ = a1.gather(ids, first_order=True)
+        E2, _, _, _ = a2.gather(ids)
     linear_y = torch.relu(torch.addmv(y1cat, logx, P["lin.wnum"]) + P["lin.b"])                 # (:131)
-    cin_y = _cin(E1.view(B, a1.F, a1.D), P, store.cin_sizes)
-    E2, _, _, _ = a2.gather(ids)
-    dnn_net = L.tower(E2, P, "dnn", n_layers, False, params["dropout"])
+    cin_y = _cin(E1.view(B, a1.F, a1.D), P, store.cin_sizes, generic=generic)
+    dnn_net = L.tower(E2, P, "dnn", n_layers, training, params["dropout"], masks)
     dnn_y = L.dense(dnn_net, P["dnn.Wout"], P["dnn.bout"], relu=True)                          # (:192)
     logits = L.dense(torch.cat([linear_y[:, None], cin_y, dnn_y], -1), P["out.W"], P["out.b"])  # (:194-195) [B,1]
     pred = torch.sigmoid(logits)
@@ -276,6 +304,10 @@ def model_fn(features, labels, mode, params):
     if mode == ModeKeys.PREDICT:
         return EstimatorSpec(mode, predictions=predictions, export_outputs={"serving_default": predictions})
     loss = L.sigmoid_ce_mean(logits, labels)
+    if training:
+        def train_op():                                            # AdamOptimizer.minimize (:225-226)
+            store.minimize(loss)
+        return EstimatorSpec(mode, predictions=predictions, loss=loss, train_op=train_op)
     return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
 
 

@@ -282,12 +282,16 @@ def test_gather_rows_multi_equals_indexing():
     X = torch.full((130, 96), -7.0, device="cuda")
     o_b = torch.empty(999, 16, device="cuda")
     o_c = torch.empty(57, 32, device="cuda")
-    jobs = (_lib.GatherJob * 3)()
-    for j, (tab, ids, out, k, ld, base) in zip(jobs, ((t32, ids_a, X[:, 32:], 32, 96, 0), (t16, ids_b, o_b, 16, 16, 0),
-                                                     (t32, ids_c, o_c, 32, 32, 100))):
-        j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base = tab.data_ptr(), ids.data_ptr(), out.data_ptr(), ids.shape[0], k, ld, base
-    assert L.rsx_gather_rows_multi(jobs, 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    t4 = torch.randn(500, 4, device="cuda")                      # a 1-D variable stored as column 0 of a 4-wide table
+    o_s = torch.empty(130, device="cuda")
+    jobs = (_lib.GatherJob * 4)()
+    for j, (tab, ids, out, k, ld, base, ldt) in zip(jobs, ((t32, ids_a, X[:, 32:], 32, 96, 0, 0), (t16, ids_b, o_b, 16, 16, 0, 0),
+                                                          (t32, ids_c, o_c, 32, 32, 100, 0), (t4, ids_a, o_s, 1, 1, 0, 4))):
+        j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base, j.ld_table = \
+            tab.data_ptr(), ids.data_ptr(), out.data_ptr(), ids.shape[0], k, ld, base, ldt
+    assert L.rsx_gather_rows_multi(jobs, 4, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     torch.cuda.synchronize()
+    assert torch.equal(o_s, t4[ids_a.long(), 0])
     assert torch.equal(X[:, 32:64], t32[ids_a.long()]) and bool((X[:, :32] == -7).all()) and bool((X[:, 64:] == -7).all())
     assert torch.equal(o_b, t16[ids_b.long()])
     assert torch.equal(o_c, t32[ids_c.long() + 100])

@@ -52,20 +52,20 @@ def test_cin_first_layer_aliasing_x0():
     np.testing.assert_allclose(tx.grad.cpu().numpy(), d0 + dk, rtol=1e-4, atol=1e-4)
 
 
-def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False):
+def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16):
     from recsys_amd import xdeepfm
     from recsys_amd.estimator import ModeKeys
     from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
     from tests.parity_util import make_estimator
     rng = np.random.default_rng(seed)
-    lin, emb = build_feature_columns(16, "numeric+indicator")
+    lin, emb = build_feature_columns(D, "numeric+indicator")
     lay = CriteoLayout.from_columns(emb)
     row_off = criteo.row_offsets()
     cat_slot, cat_off = init.xdeepfm_layout()
-    P = init.xdeepfm_params(seed, 16, layers, cin, np.float32, row_off)
+    P = init.xdeepfm_params(seed, D, layers, cin, np.float32, row_off)
     for k in ("lin.b", "cin.bout", "dnn.bout"):
         P[k] += np.float32(0.05)
-    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D, "learning_rate": 1e-3,
               "dropout": dropout, "deep_layers": ",".join(map(str, layers)), "cross_layers": ",".join(map(str, cin)),
               "max_batch_size": B}
     est = make_estimator(xdeepfm.model_fn, params, use_graph=use_graph)
@@ -127,6 +127,18 @@ def test_xdeepfm_train_parity(cin, dropout, B):
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5, losses
     assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("D,cin,layers", [(8, (12, 6), (20, 10)), (16, (136, 8), (24, 12)), (32, (10, 10), (30, 18))])
+def test_xdeepfm_generic_path_covers_the_flag_envelope(D, cin, layers):
+    """--embedding_size != 16, a CIN width above 128 or a tower width that is no multiple of 4 (xdeepfm/xdeepfm.py:12-19 accepts
+    them all) train through the generic path -- the same gather / scatter / TF-1 Adam kernels under autograd, the CIN layer and
+    the tower as library GEMMs -- with the same parity bar against the fp64 oracle."""
+    err, losses, perr = _xdeepfm_run(B=16, steps=3, seed=21 + D, cin=cin, layers=layers, dropout=0.5, D=D)
+    assert err < 2e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 2e-5, losses
+    assert max(perr.values()) < 1e-4, perr
 
 
 def test_xdeepfm_train_parity_config3():
