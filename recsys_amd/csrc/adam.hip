@@ -58,7 +58,7 @@ __global__ __launch_bounds__(ADAM_T) void adam_slice_k(const AdamSlice s) { adam
 
 // The sweep of an optimizer window (rsx_adam_seg.slot_w): 1 + nw updates per untouched row in one pass.
 #ifndef RSX_ADAM_WIN_OCC
-#define RSX_ADAM_WIN_OCC 4      // waves per SIMD the window sweep is compiled for (A/B knob: 3 = 168 registers, no spills at NW = 7)
+#define RSX_ADAM_WIN_OCC 3      // waves per SIMD the window sweep is compiled for.  3 = 168 registers, no spills at NW = 7; 4 (128 registers, spills at NW = 7) measured equal up to 6-step windows and 3 us slower per 8-step sweep (76.6 vs 73.5 us; DeepFM step 0.0668 -> 0.0659 ms; scripts/ab_window_occ.sh, profiles/r03_q_ab_window_occ.txt)
 #endif
 template <int NW>
 __global__ __launch_bounds__(ADAM_T, RSX_ADAM_WIN_OCC) void adam_window_k(const AdamSlice s) {

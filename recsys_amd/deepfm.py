@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 from . import layers as L
+from .dist import dp_overlap_enabled as dist_overlap_enabled, overlap_ranges as dist_overlap_ranges
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
 from .feature_columns import CAT_FEATURE, CONT_FEATURE, CriteoLayout, build_feature_columns
@@ -201,18 +202,33 @@ def _train_fused(store, arena, ids, labels, params, masks):
             assert job is None or sweeps[0] is None, "a forward launch that carries the sort cannot carry a sweep slice"
         elif overlap:
             hot = ()            # a later position of the window: the window's sweep already ran
+        # RSX_DP_OVERLAP=1 (opt-in): the dense arena is all-reduced per tower layer from inside backward, on RCCL's stream
+        pending, layer_done = [], None
+        if zc and dist_overlap_enabled():
+            nl = len(store.tower.widths)
+            per_layer, rest = dist_overlap_ranges(
+                store.dense, [[f"dnn.{v}{l}" for v in ("W", "b", "gamma", "beta")] for l in range(nl)])
+            g = store.dense.grad
+
+            def layer_done(l):
+                for lo, hi in ([per_layer[l]] + (rest if l == nl - 1 else [])):
+                    pending.append(dp.all_reduce_async(g[lo:hi]))
         loss, prob, dX, gy1, gy2 = store.tower.train_step(
             E, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=y1p, c0="b1", s1=y2,
             replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
-            sort_job=job, sweeps=sweeps, sort_in_fwd=overlap, outs=(dXv, gy1v, gy2v) if zc else None)
+            sort_job=job, sweeps=sweeps, sort_in_fwd=overlap, outs=(dXv, gy1v, gy2v) if zc else None,
+            layer_done=layer_done)
 
     def train_op():
         with torch.no_grad():
             Sg, dXg, gy1g, gy2g, blocks, Bg, dense_segs = S, dX, gy1, gy2, None, dX.shape[0], None
             if zc:                  # ONE collective straight from the send block (dense arena + per-example block)
-                (dXg, Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(dX.shape[0], fold_dense=hot is not None)
+                if layer_done is not None:
+                    dp.wait_all(pending)
+                (dXg, Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(
+                    dX.shape[0], fold_dense=hot is not None, dense_done=layer_done is not None)
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer

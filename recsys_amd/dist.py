@@ -111,6 +111,61 @@ class SegmentedGraph:
                     next_seg.prefetch.issue()
 
 
+class _AsyncAllReduce:
+    def __init__(self, t, group):
+        self.t, self.group, self.work = t, group, None
+
+    def issue(self):
+        self.work = dist.all_reduce(self.t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
+def dp_overlap_enabled():
+    """RSX_DP_OVERLAP=1 (opt-in, default off): the dense-gradient all-reduce is issued per tower layer from inside
+    backward instead of riding in the step's single all-gather.  At DeepFM's size the step is latency-bound and one
+    collective beats several, so this exists to be A/B-ed on a multi-GPU node, not as a default."""
+    return os.environ.get("RSX_DP_OVERLAP", "0") == "1"
+
+
+def overlap_ranges(dense, layer_names):
+    """Splits a DenseArena into the float ranges that become final after each backward launch.
+    layer_names: per tower layer l, the names of its variables (W, b, gamma, beta).  Returns (per_layer [(lo, hi)],
+    rest [(lo, hi), ...]): layer l's covering range, and the maximal ranges covered by no layer (head, first-order
+    bias, ...), which are final after the LAST layer's backward launch (the first one issued).  A layer whose variables
+    interleave with another's makes the split impossible -> RsxError (the caller then keeps the default exchange)."""
+    from . import _lib
+    names = list(dense.names)
+    end = {k: (dense.offsets[names[i + 1]] if i + 1 < len(names) else dense.n) for i, k in enumerate(names)}
+    owner = {}
+    per_layer = []
+    for l, ks in enumerate(layer_names):
+        ks = [k for k in ks if k in dense.offsets]
+        lo, hi = min(dense.offsets[k] for k in ks), max(end[k] for k in ks)
+        for k in names:
+            if lo <= dense.offsets[k] < hi:
+                if k not in ks:
+                    raise _lib.RsxError(f"RSX_DP_OVERLAP: dense variable {k} lies inside tower layer {l}'s range")
+                owner[k] = l
+        per_layer.append((lo, hi))
+    rest, cur = [], None
+    for k in names:
+        if k in owner:
+            if cur is not None:
+                rest.append(tuple(cur))
+                cur = None
+        elif cur is None:
+            cur = [dense.offsets[k], end[k]]
+        else:
+            cur[1] = end[k]
+    if cur is not None:
+        rest.append(tuple(cur))
+    return per_layer, rest
+
+
 class _PrefetchableAllGather:
     """An all-gather whose input is ready before the step starts (the batch ids).  As a SegmentedGraph item it either waits
     for the asynchronous launch a previous step issued for it (`issue`) or runs synchronously."""
@@ -192,7 +247,7 @@ class DataParallel:
             o += b * w
         return out
 
-    def gather_send_block(self, b, fold_dense=False):
+    def gather_send_block(self, b, fold_dense=False, dense_done=False):
         """Exchanges [dense | block(b)] straight from the send block (no pack copy) and returns (views of RANK 0's parts
         inside the gathered buffer, blocks descriptor) for EmbeddingArena.segsum*(..., blocks=).
         Small dense arenas (< RSX_DP_ALLREDUCE_MIN_BYTES, default 1 MiB: DeepFM / DCN / FM, ~0.3 MB): the arena rides in
@@ -203,19 +258,24 @@ class DataParallel:
         Large arenas (xDeepFM's CIN filters: 3.3 MB): an all-gather would deliver N x the bytes of an all-reduce (26 MB per
         rank per step at N = 8), so the arena takes a true all-reduce(sum), issued ASYNCHRONOUSLY on RCCL's stream before the
         example block's all-gather and awaited after it -- the two collectives overlap each other (and whatever the caller
-        launches before the optimizer)."""
+        launches before the optimizer).
+        dense_done (RSX_DP_OVERLAP, see overlap_ranges / all_reduce_async): the arena was already summed in place by
+        all-reduces issued from inside backward; only the example block is exchanged and the third value is None."""
         from . import _lib
         n0, n = self._send_n0, self._send_dense.n
         L = b * sum(self._send_widths)
         d = self._send_dense
         big = n * 4 >= int(os.environ.get("RSX_DP_ALLREDUCE_MIN_BYTES", str(1024 * 1024)))
-        if big:
+        if big or dense_done:
             Lp = (L + 3) & ~3
             x = self._send[n0:n0 + Lp].view(1, Lp)
             out = torch.empty((self.world, Lp), dtype=x.dtype, device=x.device)
             grad = self._send[:n]
 
-            graph_break(lambda: self._overlapped_allreduce_allgather(grad, out, x))
+            if dense_done:
+                graph_break(lambda: self._all_gather_into(out, x))
+            else:
+                graph_break(lambda: self._overlapped_allreduce_allgather(grad, out, x))
             views, o = [], 0
             for w in self._send_widths:
                 v = out[0, o:o + b * w]
@@ -321,7 +381,24 @@ class DataParallel:
         dist.all_gather_into_tensor(out, x, group=self.group)
         work.wait()                     # stream-level wait: the host does not block
 
+    def _all_gather_into(self, out, x):
+        dist.all_gather_into_tensor(out, x, group=self.group)
+
     # -- dense gradients ------------------------------------------------------------------------
+    def all_reduce_async(self, flat):
+        """RSX_DP_OVERLAP: all-reduce(sum) of `flat` (a slice of the dense gradient arena whose producers have all been
+        launched) issued NOW on RCCL's stream, asynchronously -- it runs underneath whatever the caller launches next
+        (the lower layers' backward).  Returns a handle for wait_all().  Under a SegmentedGraph capture the issue is a
+        segment break like every other collective, so this mode trades one graph segment for one per tower layer."""
+        h = _AsyncAllReduce(flat, self.group)
+        graph_break(h.issue)
+        return h
+
+    def wait_all(self, handles):
+        """The current stream waits for the collectives of all_reduce_async (no host block)."""
+        hs = list(handles)
+        graph_break(lambda: [h.wait() for h in hs])
+
     def all_reduce_sum(self, flat):
         graph_break(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
         return flat
@@ -347,6 +424,16 @@ class EmulatedDataParallel(DataParallel):
 
     def all_reduce_sum(self, flat):
         return flat.mul_(self.world)
+
+    def all_reduce_async(self, flat):
+        flat.mul_(self.world)
+        return None
+
+    def wait_all(self, handles):
+        pass
+
+    def _all_gather_into(self, out, x):
+        out.copy_(x.expand_as(out))
 
     def _overlapped_allreduce_allgather(self, grad, out, x):
         grad.mul_(self.world)

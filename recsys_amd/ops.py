@@ -574,7 +574,7 @@ class FusedTower:
 
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
-                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None):
+                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None, layer_done=None):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
@@ -583,6 +583,9 @@ class FusedTower:
         untouched-row optimizer sweep that ride along as extra workgroups (AdamTF1.cold_slices).
         outs = (dX [B,k0], gs0 [B], gs1 [B]): caller-owned contiguous output buffers (views of the data-parallel send block)
         instead of the tower's own.
+        layer_done(l): called after layer l's backward launch (l = L-1 .. 0), when that layer's dW/db (and, for l = L-1,
+        the head's gradients) have been launched in full -- the hook of the RSX_DP_OVERLAP all-reduces.  The layers' dW
+        reductions are then NOT deferred to the end.
         Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
         L, P, pre = lib(), self.P, self.pre
         o_dX, o_gs0, o_gs1 = [o if o is not None else d for o, d in zip(outs or (None,) * 3, (self.dX, self.gs0, self.gs1))]
@@ -626,7 +629,7 @@ class FusedTower:
             check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
         # (large batches: the layers' dW reductions are handed back as jobs and run as ONE launch after the last layer)
         jobs = (_lib.DwReduceJob * max(nl, 1))()
-        defer = nl <= 4
+        defer = nl <= 4 and layer_done is None
         for l in reversed(range(nl)):
             K = self.k0 if l == 0 else self.widths[l - 1]
             last = l == nl - 1
@@ -647,6 +650,8 @@ class FusedTower:
                 "rsx_tower_bwd_layer_defer")
             if l and self.bn_on:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
+            if layer_done is not None:
+                layer_done(l)
         if defer:
             todo = [jobs[l] for l in range(nl) if jobs[l].sb > 0]
             if todo:

@@ -187,6 +187,28 @@ def _send_block_worker(rank, world, port, out_dir):
         assert torch.equal(out[r, b * 17:b * 18], torch.full((b,), r + 0.125))
     assert views[0].data_ptr() == out.data_ptr() and views[0].shape == (b, 12)
     del os.environ["RSX_DP_ALLREDUCE_MIN_BYTES"]
+    # RSX_DP_OVERLAP: slices of the arena all-reduced asynchronously (per tower layer), then the example block alone
+    dense.names = ["b1", "dnn.W0", "dnn.b0", "dnn.W1", "dnn.b1", "dnn.Wout", "out.W"]
+    dense.offsets = dict(zip(dense.names, (0, 4, 16, 20, 28, 32, 36)))
+    per_layer, rest = rdist.overlap_ranges(dense, [["dnn.W0", "dnn.b0", "dnn.gamma0"], ["dnn.W1", "dnn.b1"]])
+    assert per_layer == [(4, 20), (20, 32)] and rest == [(0, 4), (32, 37)]
+    try:
+        rdist.overlap_ranges(dense, [["dnn.W0", "dnn.W1"], ["dnn.b0"]])
+        raise AssertionError("interleaved layers must be refused")
+    except _lib.RsxError:
+        pass
+    dense.grad.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    dX, S, gy2, gy1 = dp.send_views(b)
+    dX.fill_(rank + 1.0)
+    hs = [dp.all_reduce_async(dense.grad[lo:hi]) for lo, hi in [per_layer[1]] + rest + [per_layer[0]]]
+    dp.wait_all(hs)
+    views, (bb, stride), seg = dp.gather_send_block(b, fold_dense=True, dense_done=True)
+    assert seg is None and all(h.work is None for h in hs)
+    assert torch.equal(dense.grad, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+    out = dp._keep
+    assert out.shape == (world, stride) and views[0].data_ptr() == out.data_ptr()
+    for r in range(world):
+        assert torch.equal(out[r, :b * 12], torch.full((b * 12,), r + 1.0))
     # the prefetchable ids all-gather: synchronous when nobody issued it, otherwise it waits for the asynchronous launch
     x = torch.full((3, 2), rank, dtype=torch.int32)
     outp = torch.empty(world * 3, 2, dtype=torch.int32)

@@ -27,21 +27,26 @@ print("DP_OK")
 """ % ROOT
 
 
-@pytest.mark.parametrize("capture_collectives", ["0", "1"])
-def test_dp_world1_rccl_matches_oracle(capture_collectives):
-    """'0': graph SEGMENTS with eager RCCL calls between them (default); '1': collectives captured into the graph."""
+@pytest.mark.parametrize("capture_collectives,overlap", [("0", "0"), ("1", "0"), ("0", "1")])
+def test_dp_world1_rccl_matches_oracle(capture_collectives, overlap):
+    """'0': graph SEGMENTS with eager RCCL calls between them (default); '1': collectives captured into the graph.
+    overlap '1' = RSX_DP_OVERLAP: DeepFM's dense arena all-reduced per tower layer from inside backward (asynchronous RCCL
+    launches between graph segments, awaited in train_op) instead of riding in the step's all-gather."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               RSX_DP_CAPTURE=capture_collectives)
+               RSX_DP_CAPTURE=capture_collectives, RSX_DP_OVERLAP=overlap)
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("kind,B,world", [("deepfm", 48, 3), ("dcn", 40, 2), ("deepfm", 300, 4), ("deepfm", 600, 4), ("fm", 56, 3)])
-def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world):
+@pytest.mark.parametrize("kind,B,world,overlap", [("deepfm", 48, 3, 0), ("dcn", 40, 2, 0), ("deepfm", 300, 4, 0),
+                                                  ("deepfm", 600, 4, 0), ("fm", 56, 3, 0), ("deepfm", 48, 3, 1)])
+def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world, overlap, monkeypatch):
     """Multi-block data-parallel compute on one GPU: `world` identical replicas of a batch b (collectives replaced by
     local tiling) must train exactly like ONE process on the batch repeated `world` times -- same BN statistics, same
     mean loss, gradients summed over replicas with the 1/N loss scale.  Exercises the global dedup sort, the scatter
-    reading rank blocks in place from the gathered buffer, and (B*world > 1024) its two-stage form."""
+    reading rank blocks in place from the gathered buffer, and (B*world > 1024) its two-stage form.
+    overlap = 1: the RSX_DP_OVERLAP exchange (per-layer dense all-reduce, example block alone in the all-gather)."""
+    monkeypatch.setenv("RSX_DP_OVERLAP", str(overlap))
     import numpy as np
     import torch
     from oracle import init
