@@ -16,7 +16,10 @@ RSX_STAMP_DECL
 #define RSX_STAMP2(slot) do { RSX_STAMP(slot, blockIdx.x == 0); RSX_STAMP(16 + (slot), blockIdx.x == 24); } while (0)
 // segsum_adam_k: workgroup 0 (field 0's helpers of huge segments at B = 4096) -> slots 32.., workgroup 432 (row owners of a
 // 100 000-row field at B = 4096) -> slots 48..
-#define RSX_STAMP3(slot) do { RSX_STAMP(32 + (slot), blockIdx.x == 0); RSX_STAMP(48 + (slot), blockIdx.x == 432); } while (0)
+#ifndef RSX_STAMP_BLK2
+#define RSX_STAMP_BLK2 432      // (-DRSX_STAMP_BLK2=100: a row-owner workgroup of a hashed field at B = 256)
+#endif
+#define RSX_STAMP3(slot) do { RSX_STAMP(32 + (slot), blockIdx.x == 0); RSX_STAMP(48 + (slot), blockIdx.x == RSX_STAMP_BLK2); } while (0)
 
 // ------------------------------------------------------------------ forward --------------------
 // One wave per example b.  lane = (j, q): q = float4 quarter of the row, j = pair slot; the wave
@@ -228,38 +231,63 @@ struct SegCtx {
   bool do1;
 };
 
-// sequential ascending sum over sorted positions [i0, i1) of one field; 4 entries' loads in flight
-template <int LPR>
-__device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4 e, int i0, int i1, float4& acc,
-                                              float& a1) {
+// sequential ascending sum over sorted positions [i0, i1) of one field; 4 entries' loads in flight.
+// Every load is UNCONDITIONAL (positions past the end re-read the last one, absent inputs are compiled out by FM / XG, the
+// first-order scalar comes through a pointer that always names a valid [B] array) and the tail is masked on the VALUES: a
+// load behind a condition costs a branch and ends the compiler's counting of the loads in flight.
+template <int LPR, bool FM, bool XG, bool BLK>
+__device__ __forceinline__ void seg_range_sum_t(const SegCtx<LPR>& c, const float4 e, int i0, int i1, float4& acc,
+                                                float& a1) {
+  const float* __restrict__ h1 = c.gy1 != nullptr ? c.gy1 : (FM ? c.gy2 : reinterpret_cast<const float*>(c.X4));
   for (int i = i0; i < i1; i += 4) {
     int bb[4];
     float g[4], h[4];
     float4 s[4], x[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bb[k] = (i + k < i1) ? c.pf[i + k] : -1;
+    for (int k = 0; k < 4; ++k) bb[k] = c.pf[i + k < i1 ? i + k : i1 - 1];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const bool ok = bb[k] >= 0;
-      const int b = ok ? bb[k] : 0;
-      int bi;
-      size_t bo;
-      ex_locate(c.xb, b, bi, bo);
-      g[k] = (ok && c.gy2 != nullptr) ? c.gy2[bo + bi] : 0.f;
-      s[k] = (ok && c.gy2 != nullptr) ? c.S4[bo / 4 + (size_t)bi * LPR + c.q] : F4Z;
-      x[k] = (ok && c.X4 != nullptr) ? c.X4[bo / 4 + ((size_t)bi * c.F + c.f) * LPR + c.q] : F4Z;
-      h[k] = (ok && c.do1) ? c.gy1[bo + bi] : 0.f;
+      int bi = bb[k];
+      size_t bo = 0;
+      if constexpr (BLK) ex_locate(c.xb, bb[k], bi, bo);      // (the uniform "rank-blocked?" branch stays outside the loop)
+      if constexpr (FM) {
+        g[k] = c.gy2[bo + bi];
+        s[k] = c.S4[bo / 4 + (size_t)bi * LPR + c.q];
+      }
+      if constexpr (XG) x[k] = c.X4[bo / 4 + ((size_t)bi * c.F + c.f) * LPR + c.q];
+      h[k] = h1[bo + bi];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (bb[k] >= 0) {
-        float4 t = F4Z;
-        if (c.gy2 != nullptr) t = f4_sub(f4_scale(g[k], s[k]), f4_scale(g[k], e));
-        if (c.X4 != nullptr) t = c.gy2 != nullptr ? f4_add(t, x[k]) : x[k];
+      if (i + k < i1) {
+        float4 t;
+        if constexpr (FM) {
+          t = f4_sub(f4_scale(g[k], s[k]), f4_scale(g[k], e));
+          if constexpr (XG) t = f4_add(t, x[k]);
+        } else {
+          t = x[k];
+        }
         acc = f4_add(acc, t);
         if (c.do1) a1 += h[k];
       }
     }
+  }
+}
+template <int LPR>
+__device__ __forceinline__ void seg_range_sum(const SegCtx<LPR>& c, const float4 e, int i0, int i1, float4& acc,
+                                              float& a1) {
+  if (c.xb.b > 0) {                       // all kernel-uniform
+    if (c.gy2 != nullptr) {
+      if (c.X4 != nullptr) seg_range_sum_t<LPR, true, true, true>(c, e, i0, i1, acc, a1);
+      else seg_range_sum_t<LPR, true, false, true>(c, e, i0, i1, acc, a1);
+    } else {
+      seg_range_sum_t<LPR, false, true, true>(c, e, i0, i1, acc, a1);
+    }
+  } else if (c.gy2 != nullptr) {
+    if (c.X4 != nullptr) seg_range_sum_t<LPR, true, true, false>(c, e, i0, i1, acc, a1);
+    else seg_range_sum_t<LPR, true, false, false>(c, e, i0, i1, acc, a1);
+  } else {
+    seg_range_sum_t<LPR, false, true, false>(c, e, i0, i1, acc, a1);
   }
 }
 
@@ -323,12 +351,14 @@ __device__ __forceinline__ void partial_range_sum(const float4* __restrict__ P4,
 
 // Optional prefetch for the fused touched-row Adam (segsum_adam_k): the row's optimizer state is
 // requested as soon as the row is known, so that its latency hides behind the segment walk instead of following it.
+// (PRE template flag of segsum_wave / segsum_wave2; whenever they return `valid`, the state is loaded.  A nullable pointer to
+// this struct with a `loaded` flag kept the whole struct in SCRATCH memory on this toolchain -- 57 scratch instructions in
+// segsum_adam_k, each store sharing the in-order vmcnt counter with the loads that matter.)
 struct AdamRowPrefetch {
   const float* tables;
   const float* m_t;
   const float* v_t;
   float4 var, m, v;
-  bool loaded;
 };
 
 // Stage B's work as a COMPACT list of wave-sized units: field f contributes ceil(nu_f / GPW) row-owner units, ceil(nlong_f
@@ -374,7 +404,7 @@ constexpr int SEG_STAGE_B_MAX_WG = 1024;   // stage-B workgroups of a launch at 
 // Stage B wave body (same contract as segsum_wave) for unit wf of field f: units [0, nact) own GPW unique rows each (the
 // short ones were summed by stage A: their sums are picked up); the next ceil(nlong / GPW) units are the helpers of the
 // field's long segments (a group each), the last nhuge units those of its huge segments (a wave each).
-template <int D>
+template <int D, bool PRE>
 __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, int nhuge, const float* __restrict__ tables,
                                              const float* __restrict__ S,
                                              const float* __restrict__ dX, const float* __restrict__ gy1,
@@ -383,7 +413,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
                                              const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
                                              int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
                                              float4& acc, float& a1, float4& e, int& row, bool& do1, bool& staged,
-                                             const bool load_staged, AdamRowPrefetch* pre) {
+                                             const bool load_staged, AdamRowPrefetch& pre) {
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -391,13 +421,16 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
   staged = false;
   // the row's optimizer state, requested as soon as the row is known (segsum_adam_k): one round trip less per row
   auto prefetch = [&](const int r) {
-    if (pre != nullptr) {
+    if constexpr (PRE) {
       const size_t o = (size_t)r * LPR + q;
-      pre->var = reinterpret_cast<const float4*>(pre->tables)[o];
-      pre->m = reinterpret_cast<const float4*>(pre->m_t)[o];
-      pre->v = reinterpret_cast<const float4*>(pre->v_t)[o];
-      pre->loaded = true;
+      pre.var = reinterpret_cast<const float4*>(pre.tables)[o];
+      pre.m = reinterpret_cast<const float4*>(pre.m_t)[o];
+      pre.v = reinterpret_cast<const float4*>(pre.v_t)[o];
     }
+  };
+  auto table_row = [&](const int r) -> float4 {     // the FM term's row: the prefetched variable where there is one
+    if constexpr (PRE) return pre.var;
+    else return reinterpret_cast<const float4*>(tables)[(size_t)r * LPR + q];
   };
   valid = false;
   const int nrow = part.null_of(f, null_row);                       // this field's padding row, or -1
@@ -429,7 +462,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
         acc = gs;
         a1 = g1s;
         prefetch(row);
-        if (gy2 != nullptr) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+        if (gy2 != nullptr) e = table_row(row);
       }
       return true;
     }
@@ -448,7 +481,8 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
     c.f = f;
     c.q = q;
     c.do1 = do1;
-    if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+    prefetch(row);
+    if (gy2 != nullptr) e = table_row(row);
     seg_range_sum<LPR>(c, e, beg, end, acc, a1);
     return true;
   }
@@ -470,7 +504,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
       return true;
     }
     prefetch(row);
-    if (gy2 != nullptr) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+    if (gy2 != nullptr) e = table_row(row);
     const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
     partial_range_sum<LPR>(P4, part.P1, (size_t)f * nch + c0, sb % SEG_CHUNK != 0, q, do1, 0, nt, acc, a1);
     return true;
@@ -485,7 +519,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
   if (nrow >= 0 && row == nrow) return false;   // the padding row is written (as zero) by its row-owner group
   valid = g == 0;
   if (valid) prefetch(row);
-  if (gy2 != nullptr && valid) e = pre != nullptr ? pre->var : reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+  if (gy2 != nullptr && valid) e = table_row(row);
   const int c0 = sb / SEG_CHUNK, nt = (se - 1) / SEG_CHUNK - c0 + 1;
   const int per = (nt + GPW - 1) / GPW;
   const int t0 = g * per;
@@ -509,7 +543,7 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
 // The per-wave body of the segment-sum: returns false when the wave owns no unique row.  On return, for lanes with
 // `valid`: sl = slot index of the row, acc = summed gradient quarter, a1 = summed first-order gradient (q == 0 lanes),
 // e = the table row quarter (loaded only when the FM term is active), row = global row.
-template <int D>
+template <int D, bool PRE>
 __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ tables, const float* __restrict__ S,
                                             const float* __restrict__ dX, const float* __restrict__ gy1,
                                             const float* __restrict__ gy2, const int32_t* __restrict__ perm,
@@ -517,9 +551,8 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
                                             const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
                                             int null_row, const SegPartials& part, const ExBlocks& xb, bool& valid, size_t& sl,
                                             float4& acc, float& a1, float4& e, int& row, bool& do1, bool& staged,
-                                            const bool load_staged = true, AdamRowPrefetch* pre = nullptr) {
+                                            const bool load_staged, AdamRowPrefetch& pre) {
   staged = false;
-  if (pre != nullptr) pre->loaded = false;
   constexpr int LPR = D / 4;
   constexpr int GPW = RSX_WAVE / LPR;
   const int lane = threadIdx.x & 63;
@@ -562,12 +595,13 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
   do1 = c.do1;
   e = F4Z;
   if (gy2 != nullptr && valid) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
-  if (pre != nullptr && valid) {
-    const size_t o = (size_t)row * LPR + q;
-    pre->var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(pre->tables)[o];
-    pre->m = reinterpret_cast<const float4*>(pre->m_t)[o];
-    pre->v = reinterpret_cast<const float4*>(pre->v_t)[o];
-    pre->loaded = true;
+  if constexpr (PRE) {
+    if (valid) {
+      const size_t o = (size_t)row * LPR + q;
+      pre.var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(pre.tables)[o];
+      pre.m = reinterpret_cast<const float4*>(pre.m_t)[o];
+      pre.v = reinterpret_cast<const float4*>(pre.v_t)[o];
+    }
   }
   acc = F4Z;
   a1 = 0.f;
@@ -884,6 +918,7 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   bool staged;
   // rows finished by stage A already sit in G / gw1 when stage A was given these buffers: nothing to load or store
   const bool same = part.G == G;
+  AdamRowPrefetch nopre;
   if (part.P != nullptr) {     // two-stage: the compact unit list, grid stride
     constexpr int GPW = RSX_WAVE / LPR;
     const SegUnits su = seg_units<GPW>(nuniq, part, F, stride);
@@ -891,8 +926,8 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
     for (int unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; unit < su.total; unit += nwaves) {
       int f, wf, nu, nl, nh;
       seg_unit_locate(su, unit, f, wf, nu, nl, nh);
-      if (segsum_wave2<D>(f, wf, nu, nl, nh, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride,
-                          null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same, nullptr) &&
+      if (segsum_wave2<D, false>(f, wf, nu, nl, nh, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F,
+                                 stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same, nopre) &&
           valid && !(staged && same)) {
         reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
         if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
@@ -900,8 +935,9 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
     }
     return;
   }
-  if (!segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                      nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same))
+  if (!segsum_wave<D, false>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
+                             nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same,
+                             nopre))
     return;
   if (valid && !(staged && same)) {
     reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
@@ -963,6 +999,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     // the loads of all its rows are in flight together -- the pass is a chain of 4 dependent accesses per row.
     constexpr int RPW = 256 / LPR;
     const uint32_t wb = blockIdx.x - n_rows;
+    RSX_STAMP(40, wb == 0);
     const uint32_t per_l = (uint32_t)F * h.win_per_f;
     const int li = (int)(wb / per_l);
     const uint32_t rem = wb - (uint32_t)li * per_l;
@@ -987,6 +1024,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
 #pragma unroll
           for (int i = 0; i < WIN_NR; ++i) t[i] &= h.win_slot[l][row[i]];
         }
+      RSX_STAMP(41, wb == 0 && t[0] != 12345);
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
@@ -1011,6 +1049,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
           }
         }
       }
+      RSX_STAMP(42, wb == 0);
       if (h.w1 != nullptr && q == 0) {
 #pragma unroll
         for (int i = 0; i < WIN_NR; ++i)
@@ -1035,9 +1074,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
     auto update2 = [&]() {
       const size_t o = (size_t)row * LPR + q;
-      float4 var = pre.loaded ? pre.var : reinterpret_cast<const float4*>(h.tables2)[o];
-      float4 m = pre.loaded ? pre.m : reinterpret_cast<const float4*>(h.m_t2)[o];
-      float4 v = pre.loaded ? pre.v : reinterpret_cast<const float4*>(h.v_t2)[o];
+      float4 var = pre.var, m = pre.m, v = pre.v;
       F4_APPLY(adam_sparse1, var, m, v, acc, true, hp);
       reinterpret_cast<float4*>(h.tables2)[o] = var;
       reinterpret_cast<float4*>(h.m_t2)[o] = m;
@@ -1049,15 +1086,14 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       for (int unit = ((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6; unit < su.total; unit += (int)h.n_own * 4) {
         int f, wf, nu, nl, nh;
         seg_unit_locate(su, unit, f, wf, nu, nl, nh);
-        pre.loaded = false;
-        if (segsum_wave2<D>(f, wf, nu, nl, nh, h.tables2, nullptr, h.dX2, nullptr, nullptr, perm, seg_off, uniq_row, nuniq, 0, B,
-                            F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1, staged, true, &pre) &&
+        if (segsum_wave2<D, true>(f, wf, nu, nl, nh, h.tables2, nullptr, h.dX2, nullptr, nullptr, perm, seg_off, uniq_row, nuniq,
+                                  0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e, row, do1, staged, true, pre) &&
             valid)
           update2();
       }
-    } else if (segsum_wave<D>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr,
-                              nullptr, perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl, acc, a1, e,
-                              row, do1, staged, true, &pre) &&
+    } else if (segsum_wave<D, true>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2,
+                                    nullptr, nullptr, perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl,
+                                    acc, a1, e, row, do1, staged, true, pre) &&
                valid) {
       update2();
     }
@@ -1075,9 +1111,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
     auto update1 = [&]() {
       const size_t o = (size_t)row * LPR + q;
-      float4 var = pre.loaded ? pre.var : (gy2 != nullptr ? e : reinterpret_cast<const float4*>(h.tables)[o]);
-      float4 m = pre.loaded ? pre.m : reinterpret_cast<const float4*>(h.m_t)[o];
-      float4 v = pre.loaded ? pre.v : reinterpret_cast<const float4*>(h.v_t)[o];
+      float4 var = pre.var, m = pre.m, v = pre.v;
       F4_APPLY(adam_sparse1, var, m, v, acc, true, hp);
       reinterpret_cast<float4*>(h.tables)[o] = var;
       reinterpret_cast<float4*>(h.m_t)[o] = m;
@@ -1097,22 +1131,23 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       for (int unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; unit < su.total; unit += (int)h.n_own * 4) {
         int f, wf, nu, nl, nh;
         seg_unit_locate(su, unit, f, wf, nu, nl, nh);
-        pre.loaded = false;
-        if (segsum_wave2<D>(f, wf, nu, nl, nh, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F, stride,
-                            -1, part, xb, valid, sl, acc, a1, e, row, do1, staged, true, &pre) &&
+        if (segsum_wave2<D, true>(f, wf, nu, nl, nh, h.tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F,
+                                  stride, -1, part, xb, valid, sl, acc, a1, e, row, do1, staged, true, pre) &&
             valid)
           update1();
       }
       RSX_STAMP3(1);
     } else {
-      const bool any = segsum_wave<D>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm, seg_off,
-                                      uniq_row, nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1, e, row, do1,
-                                      staged, true, &pre);
+      const bool any = segsum_wave<D, true>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm,
+                                            seg_off, uniq_row, nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1,
+                                            e, row, do1, staged, true, pre);
       RSX_STAMP3(1);
       if (any && valid) update1();
     }
   }
   RSX_STAMP3(2);
+  RSX_STAMP(43, blockIdx.x == n_rows);
+  RSX_STAMP(56, blockIdx.x == gridDim.x - 1);
   __syncthreads();
   RSX_STAMP3(3);
   if (threadIdx.x == 0 && adam_arrive_last(h.state, h.total_blocks) && h.advance) {
@@ -1121,6 +1156,8 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
   }
   RSX_STAMP3(4);
+  RSX_STAMP(44, blockIdx.x == n_rows);
+  RSX_STAMP(57, blockIdx.x == gridDim.x - 1);
 }
 
 // ------------------------------------------------------------------ C ABI ----------------------

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RSX_LIB_PATH"] = os.path.join(ROOT, "scripts", "_build", "librsx_stamps.so")
+os.environ["RSX_LIB_PATH"] = os.path.join(ROOT, "scripts", "_build", os.environ.get("RSX_STAMP_LIB", "librsx_stamps.so"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from recsys_amd.ops import EmbeddingArena  # noqa: E402
@@ -29,9 +29,18 @@ from recsys_amd.ops import AdamTF1  # noqa: E402
 opt = AdamTF1(device="cuda")
 acc = np.zeros(64)
 reps = 0
+win = None
+dense_segs = []
+if os.environ.get("RSX_STAMP_WINDOW"):       # the DeepFM launch: window pass over 7 other lists + the dense arena
+    from recsys_amd.ops import DenseArena  # noqa: E402
+    nb = min(8 if B <= 1024 else 4, len(a.sortbufs))
+    a.sort_window([ids] + [torch.from_numpy(synth_ids(rng, B, row_off)).cuda() for _ in range(nb - 1)])
+    a.select(0)
+    win = (nb, 0)
+    dense_segs = DenseArena({"w": (73100,)}, "cuda").adam_segments()
 for s in range(30):
     if fm:
-        a.segsum_adam(B, S, dX, g1, g2, opt, [], None)
+        a.segsum_adam(B, S, dX, g1, g2, opt, dense_segs, None, window=win)
     else:
         a.segsum_adam(B, None, dX, None, None, opt, [], None)
     torch.cuda.synchronize()
@@ -55,3 +64,8 @@ for g, what in ((32, "workgroup 0 (helpers of field 0's huge segments)"), (48, "
     print("---- stage B + Adam (segsum_adam_k), B = %d, %s: us since workgroup 0's entry" % (B, what))
     for k, n in enumerate(names):
         print("%-55s %8.2f" % (n, t[g + k]))
+
+if os.environ.get("RSX_STAMP_WINDOW"):
+    print("---- first window-pass workgroup: entry %.2f, slot maps read %.2f, table rows stored %.2f, first-order done %.2f, "
+          "counter done %.2f | last workgroup of the grid: work done %.2f, counter done %.2f" %
+          (t[40], t[41], t[42], t[43], t[44], t[56], t[57]))
