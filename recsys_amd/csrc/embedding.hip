@@ -358,7 +358,13 @@ struct AdamRowPrefetch {
   const float* tables;
   const float* m_t;
   const float* v_t;
+  // first-order vector riding in the same launch (or any valid arrays with stride 0: the loads are unconditional)
+  const float* w1;
+  const float* m_w;
+  const float* v_w;
+  int w1_stride;
   float4 var, m, v;
+  float w, mw, vw;
 };
 
 // Stage B's work as a COMPACT list of wave-sized units: field f contributes ceil(nu_f / GPW) row-owner units, ceil(nlong_f
@@ -426,6 +432,10 @@ __device__ __forceinline__ bool segsum_wave2(int f, int wf, int nu, int nlong, i
       pre.var = reinterpret_cast<const float4*>(pre.tables)[o];
       pre.m = reinterpret_cast<const float4*>(pre.m_t)[o];
       pre.v = reinterpret_cast<const float4*>(pre.v_t)[o];
+      const size_t wi = (size_t)r * pre.w1_stride;
+      pre.w = pre.w1[wi];
+      pre.mw = pre.m_w[wi];
+      pre.vw = pre.v_w[wi];
     }
   };
   auto table_row = [&](const int r) -> float4 {     // the FM term's row: the prefetched variable where there is one
@@ -601,6 +611,10 @@ __device__ __forceinline__ bool segsum_wave(int wave, const float* __restrict__ 
       pre.var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(pre.tables)[o];
       pre.m = reinterpret_cast<const float4*>(pre.m_t)[o];
       pre.v = reinterpret_cast<const float4*>(pre.v_t)[o];
+      const size_t wi = (size_t)row * pre.w1_stride;
+      pre.w = pre.w1[wi];
+      pre.mw = pre.m_w[wi];
+      pre.vw = pre.v_w[wi];
     }
   }
   acc = F4Z;
@@ -1016,19 +1030,33 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
         const int j = j0 + i * RPW;
         row[i] = ur[j < nu ? j : nu - 1];
       }
-      // this step's own scatter owns the rows it touches; a row on several lists belongs to the first of them
+      // this step's own scatter owns the rows it touches; a row on several lists belongs to the first of them.  All 8 slot
+      // maps are read unconditionally (a list that does not take part is replaced by this step's own map: a loop with a
+      // dynamic trip count drains the loads at every back-edge), together with the rows' state -- ONE round trip after the rows.
+      const int32_t* __restrict__ scur = h.win_slot[h.win_cur];
 #pragma unroll
-      for (int i = 0; i < WIN_NR; ++i) t[i] = h.win_slot[h.win_cur][row[i]];
-      for (int l = 0; l < o; ++l)
-        if (l != h.win_cur) {
+      for (int i = 0; i < WIN_NR; ++i) t[i] = scur[row[i]];
 #pragma unroll
-          for (int i = 0; i < WIN_NR; ++i) t[i] &= h.win_slot[l][row[i]];
-        }
-      RSX_STAMP(41, wb == 0 && t[0] != 12345);
+      for (int l = 0; l < RSX_ADAM_WINDOW_MAX; ++l) {
+        const int32_t* __restrict__ sp = (l < o && l != h.win_cur) ? h.win_slot[l] : scur;
+#pragma unroll
+        for (int i = 0; i < WIN_NR; ++i) t[i] &= sp[row[i]];
+      }
       Hp hp;
       hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
       hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool hw1 = h.w1 != nullptr;
+      const float* __restrict__ w1p = hw1 ? h.w1 : h.tables;
+      const float* __restrict__ mwp = hw1 ? h.m_w : h.m_t;
+      const float* __restrict__ vwp = hw1 ? h.v_w : h.v_t;
+      const size_t wst = hw1 ? (size_t)h.w1_stride : 0;
+      float w[WIN_NR], mw[WIN_NR], vw[WIN_NR];
+#pragma unroll
+      for (int i = 0; i < WIN_NR; ++i) {
+        w[i] = w1p[(size_t)row[i] * wst];
+        mw[i] = mwp[(size_t)row[i] * wst];
+        vw[i] = vwp[(size_t)row[i] * wst];
+      }
       const int nset = h.tables2 != nullptr ? 2 : 1;
       for (int set = 0; set < nset; ++set) {
         float4* __restrict__ T4 = reinterpret_cast<float4*>(set ? h.tables2 : h.tables);
@@ -1040,9 +1068,10 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
           const size_t o4 = (size_t)row[i] * LPR + q;
           var[i] = T4[o4]; m[i] = M4[o4]; v[i] = V4[o4];
         }
+        RSX_STAMP(41, wb == 0 && set == 0 && t[0] != 12345);
 #pragma unroll
         for (int i = 0; i < WIN_NR; ++i) {
-          F4_APPLY(adam_sparse1, var[i], m[i], v[i], z4, false, hp);
+          F4_APPLY(adam_sparse1, var[i], m[i], v[i], F4Z, false, hp);
           if (t[i] < 0 && j0 + i * RPW < nu) {
             const size_t o4 = (size_t)row[i] * LPR + q;
             T4[o4] = var[i]; M4[o4] = m[i]; V4[o4] = v[i];
@@ -1050,14 +1079,16 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
         }
       }
       RSX_STAMP(42, wb == 0);
-      if (h.w1 != nullptr && q == 0) {
+      if (hw1 && q == 0) {
 #pragma unroll
-        for (int i = 0; i < WIN_NR; ++i)
+        for (int i = 0; i < WIN_NR; ++i) {
+          if (h.w1_sparse) adam_sparse1(w[i], mw[i], vw[i], 0.f, false, hp);
+          else adam_dense1(w[i], mw[i], vw[i], 0.f, hp);
           if (t[i] < 0 && j0 + i * RPW < nu) {
-            const size_t wi = (size_t)row[i] * h.w1_stride;
-            if (h.w1_sparse) adam_sparse1(h.w1[wi], h.m_w[wi], h.v_w[wi], 0.f, false, hp);
-            else adam_dense1(h.w1[wi], h.m_w[wi], h.v_w[wi], 0.f, hp);
+            const size_t wi = (size_t)row[i] * wst;
+            h.w1[wi] = w[i]; h.m_w[wi] = mw[i]; h.v_w[wi] = vw[i];
           }
+        }
       }
     }
   } else if (blockIdx.x >= h.n_own) {     // second table set
@@ -1068,7 +1099,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float a1;
     int row;
     bool staged;
-    AdamRowPrefetch pre{h.tables2, h.m_t2, h.v_t2};
+    AdamRowPrefetch pre{h.tables2, h.m_t2, h.v_t2, h.tables2, h.m_t2, h.v_t2, 0};
     Hp hp;
     hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
     hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
@@ -1105,7 +1136,9 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     float a1;
     int row;
     bool staged;
-    AdamRowPrefetch pre{h.tables, h.m_t, h.v_t};
+    const bool hw1 = h.w1 != nullptr;
+    AdamRowPrefetch pre{h.tables, h.m_t, h.v_t, hw1 ? h.w1 : h.tables, hw1 ? h.m_w : h.m_t, hw1 ? h.v_w : h.v_t,
+                        hw1 ? h.w1_stride : 0};
     Hp hp;
     hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
     hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
@@ -1116,12 +1149,20 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
       reinterpret_cast<float4*>(h.tables)[o] = var;
       reinterpret_cast<float4*>(h.m_t)[o] = m;
       reinterpret_cast<float4*>(h.v_t)[o] = v;
-      if (h.w1 != nullptr && q == 0) {
+      if (h.w1 != nullptr && q == 0) {       // (state prefetched with the row's: no round trip of its own)
         const size_t wi = (size_t)row * h.w1_stride;
+        float w = pre.w, mw = pre.mw, vw = pre.vw;
+        bool st = true;
         if (h.w1_sparse) {
-          if (do1) adam_sparse1(h.w1[wi], h.m_w[wi], h.v_w[wi], a1, true, hp);       // (fields outside the mask: not its rows)
+          st = do1;                             // (fields outside the mask: not its rows)
+          adam_sparse1(w, mw, vw, a1, true, hp);
         } else {
-          adam_dense1(h.w1[wi], h.m_w[wi], h.v_w[wi], do1 ? a1 : 0.f, hp);
+          adam_dense1(w, mw, vw, do1 ? a1 : 0.f, hp);
+        }
+        if (st) {
+          h.w1[wi] = w;
+          h.m_w[wi] = mw;
+          h.v_w[wi] = vw;
         }
       }
     };
