@@ -68,6 +68,11 @@ __device__ __forceinline__ void adam_dense1(float& var, float& m, float& v, floa
 constexpr int ADAM_T = 256;         // threads per workgroup
 constexpr int ADAM_U = RSX_ADAM_U;  // float4 per lane
 constexpr long long ADAM_Q = (long long)ADAM_T * ADAM_U;  // float4 per workgroup
+// DENSE segments take 2 float4 per lane: a dense arena is small (0.3 MB for DeepFM) and rides in the latency-bound scatter
+// launch, where 8 sequential IEEE div + sqrt updates per lane (~1 900 instructions of one wave) made its 9 workgroups the
+// LAST ones to finish (stamps: 8.6 us after the launch's first workgroup, against 4.8 for the window pass).
+constexpr int ADAM_U_DENSE = 2;
+constexpr long long ADAM_Q_DENSE = (long long)ADAM_T * ADAM_U_DENSE;
 
 // "Am I the last workgroup of this launch?" for thread 0 of every workgroup, after its block's work (and a __syncthreads):
 // arrival counters by workgroup index modulo 32 (one 128-byte line each: state words 4 + 32 r), then the shared ticket
@@ -130,7 +135,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   // the window's extra slot maps are equally spaced (one allocation): base + stride instead of 7 pointers in scalar registers
   const int32_t* __restrict__ swb = a.slot_w0;
   const long long sws = a.slot_w_stride;
-  const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
+  const long long base = (long long)(blk - s.blk_begin) * (s.kind == RSX_ADAM_DENSE ? ADAM_Q_DENSE : ADAM_Q);
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
@@ -183,7 +188,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
     const int nrep = s.B > 1 ? s.B : 1;
     const long long rs4 = (long long)s.stride >> 2;
 #pragma unroll
-    for (int u = 0; u < ADAM_U; ++u) {
+    for (int u = 0; u < ADAM_U_DENSE; ++u) {
       const long long e = base + (long long)u * ADAM_T + tid;
       if (e < n4) {
         float4 var = var4[e], m = m4[e], v = v4[e];
@@ -585,7 +590,8 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
       }
     }
     d.blk_begin = blocks;
-    blocks += (uint32_t)((work + ADAM_Q - 1) / ADAM_Q);
+    const long long quantum = s.kind == RSX_ADAM_DENSE ? ADAM_Q_DENSE : ADAM_Q;
+    blocks += (uint32_t)((work + quantum - 1) / quantum);
   }
   a.nseg = k;
   a.lr = lr;

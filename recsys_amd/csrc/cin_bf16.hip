@@ -406,9 +406,14 @@ struct CbDwArgs {
 // examples).  First one block per job that adds its dc partials in order; then the tiles, dealt together (rider_split) with
 // the workgroups that carry the optimizer sweep slice (two 256-thread sweep blocks each).  A[i = h][k = (b, d)] = X0[b,f,d] * Xk[b,h,d] is formed in fp32 and rounded
 // once.  Partial tiles: waves 4..7 -> LDS, waves 0..3 add; waves 1..3 -> LDS, wave 0 adds.
-template <int FT, int NT>
+// X0L: the workgroup's X0 slab [FT fields][B examples][16] is staged in LDS once and the A-operand factor comes from there
+// (two broadcast ds_read_b128 per field and k-step).  Read from global memory it was 2 * FT of the 2 + 2 * FT + NT 1-KiB
+// vector loads of a k-step -- 16 lanes of a wave share each address, but the texture path still moves a full 1 KiB per
+// instruction, and with 16 waves per CU at 10 KiB per k-step that path (64 B / clk / CU) is what bounded the launch.
+template <int FT, int NT, bool X0L>
 __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
-  __shared__ float red[4][FT * NT][256];
+  extern __shared__ float4 dw_lds[];
+  float (*red)[FT * NT][256] = reinterpret_cast<float (*)[FT * NT][256]>(dw_lds);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int total = p.job[p.njobs - 1].tile_end;
   if ((int)blockIdx.x < p.njobs) {                // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
@@ -456,6 +461,15 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (X0L) {                            // X0[b, f0 + ft, :] -> x0s[(ft * B + b) * 4 + quarter]
+    const int n4 = FT * p.B * 4;
+    for (int e = tid; e < n4; e += 512) {
+      const int qd = e & 3, b = (e >> 2) % p.B, ft = (e >> 2) / p.B;
+      const int f = f0 + ft < p.F ? f0 + ft : p.F - 1;
+      dw_lds[e] = reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f) * CB_D)[qd];
+    }
+    __syncthreads();
+  }
   struct Ld {
     float4 xk[2];
     float4 x0[FT][2];
@@ -472,10 +486,16 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
     L.xk[1] = xk[1];
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
-      const int f = f0 + ft < p.F ? f0 + ft : p.F - 1;
-      const float4* x0 = reinterpret_cast<const float4*>(p.X0 + ((size_t)bc * p.F + f) * CB_D + d0);
-      L.x0[ft][0] = x0[0];
-      L.x0[ft][1] = x0[1];
+      if constexpr (X0L) {
+        const float4* x0 = dw_lds + ((size_t)ft * p.B + bc) * 4 + (d0 >> 2);
+        L.x0[ft][0] = x0[0];
+        L.x0[ft][1] = x0[1];
+      } else {
+        const int f = f0 + ft < p.F ? f0 + ft : p.F - 1;
+        const float4* x0 = reinterpret_cast<const float4*>(p.X0 + ((size_t)bc * p.F + f) * CB_D + d0);
+        L.x0[ft][0] = x0[0];
+        L.x0[ft][1] = x0[1];
+      }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {             // n tiles past N16 re-read the last tile (never stored)
@@ -492,6 +512,8 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
       for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = mfma_bf16(a, L.dp[nt], acc[ft][nt]);
     }
   };
+  // (A ring of 4 stages in flight was measured: 254 registers, one workgroup per CU instead of two, 7 % SLOWER -- the launch
+  // lives on thread-level parallelism, and is bound by the CU's vector-memory path: see X0L above.)
   Ld La, Lb;
   load(wv, La);
   for (int ks = wv; ks < nks; ks += 16) {         // this wave's k-steps: wv, wv + 8, ...
@@ -500,6 +522,7 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
     load(ks + 16, La);
     run(Lb);
   }
+  if constexpr (X0L) __syncthreads();             // (the reduce buffer aliases the X0 slab)
   // partial tiles, fixed order: ((w0 + w4) + (w1 + w5) ... ) as two rounds through one 4-slot LDS buffer
   if (wv >= 4) {
 #pragma unroll
@@ -685,12 +708,9 @@ static int cb_launch_dx(const float* X0, const float* Xk, const void* w16, const
   return RSX_OK;
 }
 
-static int cb_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
-                        const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
-  if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0) return RSX_EINVAL;
-  if (njobs > CB_MAXJ || D != CB_D) return RSX_EUNSUPPORTED;
-  if (B == 0) return RSX_OK;
-  constexpr int FT = 3, NT = 2;
+template <int FT, int NT>
+static int cb_launch_dw_t(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F,
+                          const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   CbDwArgs w{};
   w.njobs = njobs; w.X0 = X0; w.B = B; w.F = F; w.FGn = (F + FT - 1) / FT;
   int tiles = 0;
@@ -712,9 +732,36 @@ static int cb_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs
   const int rcs = adam_build_slice(sweep_h, w.sweep);
   if (rcs != RSX_OK) return rcs;
   const unsigned grid = (unsigned)tiles + (unsigned)njobs + (w.sweep.n_blk + 1) / 2;
-  hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT>), dim3(grid), dim3(512), 0, rsx_s(stream), w);
+  const size_t red_bytes = (size_t)4 * FT * NT * 256 * 4, x0_bytes = (size_t)FT * B * CB_D * 4;
+  static const int x0l_env = getenv("RSX_CIN_DW16_X0L") ? atoi(getenv("RSX_CIN_DW16_X0L")) : 1;
+  if (x0l_env != 0 && x0_bytes <= 64 * 1024) {
+    const size_t lds = red_bytes > x0_bytes ? red_bytes : x0_bytes;
+    hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT, true>), dim3(grid), dim3(512), lds, rsx_s(stream), w);
+  } else {
+    hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT, false>), dim3(grid), dim3(512), red_bytes, rsx_s(stream), w);
+  }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+// Wave tile = FT fields x 16 h x NT n-tiles.  Every k-step forms FT A fragments on the VALU (8 fp32 products + 4 packing
+// conversions each) and issues FT * NT MFMAs: NT sets how many MFMAs amortise one A fragment, FT how many share one B
+// (dpre) fragment load.  The sums over the batch do not depend on the choice (same wave split of the k-steps, same LDS
+// reduce order): every configuration produces the same bits.  RSX_CIN_DW16_CFG = 10 * FT + NT overrides (A/B runs).
+static int cb_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
+                        const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0) return RSX_EINVAL;
+  if (njobs > CB_MAXJ || D != CB_D) return RSX_EUNSUPPORTED;
+  if (B == 0) return RSX_OK;
+  static const int cfg = getenv("RSX_CIN_DW16_CFG") ? atoi(getenv("RSX_CIN_DW16_CFG")) : 32;
+  switch (cfg) {
+    case 24: return cb_launch_dw_t<2, 4>(X0, jobs_h, njobs, B, F, sweep_h, stream);
+    case 34: return cb_launch_dw_t<3, 4>(X0, jobs_h, njobs, B, F, sweep_h, stream);
+    case 44: return cb_launch_dw_t<4, 4>(X0, jobs_h, njobs, B, F, sweep_h, stream);
+    case 18: return cb_launch_dw_t<1, 8>(X0, jobs_h, njobs, B, F, sweep_h, stream);
+    case 28: return cb_launch_dw_t<2, 8>(X0, jobs_h, njobs, B, F, sweep_h, stream);
+    default: return cb_launch_dw_t<3, 2>(X0, jobs_h, njobs, B, F, sweep_h, stream);
+  }
 }
 
 extern "C" int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16, const float* out,

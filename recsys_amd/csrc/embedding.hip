@@ -313,6 +313,7 @@ struct SegPartials {
   float* gw1;             // (gw1: nullable [F*stride]); stage B picks those rows up
   const int32_t* row_off; // [F + 1], needed for null_row == RSX_NULL_LAST_ROW only
   int null_row;           // padding row: >= 0 a global row, RSX_NULL_LAST_ROW the last row of every field, RSX_NULL_NONE
+  int lds_mode;           // single stage only: the workgroup-cooperative form through LDS (segsum_wave_lds; set by the host)
   // segid + F*stride: [F] long- and [F] huge-segment counts, then the long list [F, nch] (unique index j of the
   // field's long segments from the front, huge ones from the back) -- all written by the sort
   __host__ __device__ const int32_t* counts(int F, int stride) const { return segid + (size_t)F * stride; }
@@ -912,6 +913,207 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
   RSX_STAMP2(5);
 }
 
+// ---- single stage through LDS (B <= SEG_LDS_MAX_B entries per field, 4 | waves per field) ---------------------------------
+// segsum_wave is a chain of dependent global accesses: field count -> segment bounds + row -> permutation -> the entries'
+// rows (-> further batches of 4 for longer segments): 4-5 round trips of 0.3-1 us each in a launch whose other work is
+// nothing.  Here the WORKGROUP (4 consecutive waves of one field) does it in two: (1) the field's index arrays -- segment
+// offsets, unique rows, permutation: 3 B ints -- go to LDS whole, needing no count; (2) with them, every address is known:
+// the rows' own loads (table row, Adam state) and ALL entries of the workgroup's position range [plo, phi) are requested at
+// once, the entries staged in LDS; the sums then walk LDS.  Same association as segsum_wave, entry for entry (short segments
+// sequentially in ascending position, long ones in 16 sub-ranges whose partials are added in ascending order): bit-identical.
+constexpr int SEG_LDS_MAX_B = 512;
+__host__ __device__ inline size_t seg_lds_idx4(int B) { return ((size_t)3 * B + 4 + 3) / 4; }      // index arrays, float4 units
+__host__ __device__ inline size_t seg_lds_bytes(int B, int D) {
+  return (seg_lds_idx4(B) * 4 + (size_t)2 * B * D + (size_t)2 * B) * 4;
+}
+static inline bool seg_lds_ok(int B, int D, bool two_stage) {
+  const int gpw = 64 / (D / 4), wpf = (B + gpw - 1) / gpw;
+  static const int env = getenv("RSX_SEG_LDS") ? atoi(getenv("RSX_SEG_LDS")) : 1;      // (0: the per-wave form, A/B runs)
+  return env != 0 && !two_stage && B <= SEG_LDS_MAX_B && wpf % 4 == 0 && seg_lds_bytes(B, D) <= 64 * 1024;
+}
+
+template <int LPR, bool FM, bool XG>
+__device__ __forceinline__ void lds_range_sum(const float4* __restrict__ Xs, const float4* __restrict__ Ss,
+                                              const float* __restrict__ g2s, const float* __restrict__ g1s, int plo, int q,
+                                              bool do1, const float4 e, int i0, int i1, float4& acc, float& a1) {
+  for (int i = i0; i < i1; ++i) {
+    const int p = i - plo;
+    float4 t;
+    if constexpr (FM) {
+      const float g = g2s[p];
+      t = f4_sub(f4_scale(g, Ss[(size_t)p * LPR + q]), f4_scale(g, e));
+      if constexpr (XG) t = f4_add(t, Xs[(size_t)p * LPR + q]);
+    } else {
+      t = Xs[(size_t)p * LPR + q];
+    }
+    acc = f4_add(acc, t);
+    if (do1) a1 += g1s[p];
+  }
+}
+
+template <int D, bool PRE>
+__device__ __forceinline__ bool segsum_wave_lds(int wave, const float* __restrict__ tables, const float* __restrict__ S,
+                                                const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                const int32_t* __restrict__ seg_off, const int32_t* __restrict__ uniq_row,
+                                                const int32_t* __restrict__ nuniq, uint64_t w1_mask, int B, int F, int stride,
+                                                int null_row, const ExBlocks& xb, bool& valid, size_t& sl, float4& acc,
+                                                float& a1, float4& e, int& row, bool& do1, bool& staged, AdamRowPrefetch& pre,
+                                                float4* __restrict__ lds) {
+  staged = false;
+  valid = false;
+  constexpr int LPR = D / 4;
+  constexpr int GPW = RSX_WAVE / LPR;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int q = lane % LPR, g = lane / LPR;
+  const int wpf = (B + GPW - 1) / GPW;          // a multiple of 4: the workgroup's 4 waves belong to ONE field
+  const int f = wave / wpf;
+  if (f >= F) return false;                     // workgroup-uniform
+  const int wf = wave - f * wpf;
+  const int wf0 = wf - w;
+  int32_t* __restrict__ so_l = reinterpret_cast<int32_t*>(lds);
+  int32_t* __restrict__ ur_l = so_l + (B + 1);
+  int32_t* __restrict__ pf_l = ur_l + B;
+  float4* __restrict__ Xs = lds + seg_lds_idx4(B);
+  float4* __restrict__ Ss = Xs + (size_t)B * LPR;
+  float* __restrict__ g2s = reinterpret_cast<float*>(Ss + (size_t)B * LPR);
+  float* __restrict__ g1s = g2s + B;
+  // (1) the field's index arrays, whole (entries past the field's counts are stale and never used)
+  {
+    const int32_t* __restrict__ so = seg_off + (size_t)f * (stride + 1);
+    const int32_t* __restrict__ ur = uniq_row + (size_t)f * stride;
+    const int32_t* __restrict__ pf = perm + (size_t)f * stride;
+    int a[SEG_LDS_MAX_B / 256 + 1], b[SEG_LDS_MAX_B / 256], c[SEG_LDS_MAX_B / 256];
+#pragma unroll
+    for (int k = 0; k <= SEG_LDS_MAX_B / 256; ++k) a[k] = so[min(k * 256 + tid, B)];
+#pragma unroll
+    for (int k = 0; k < SEG_LDS_MAX_B / 256; ++k) {
+      b[k] = ur[min(k * 256 + tid, B - 1)];
+      c[k] = pf[min(k * 256 + tid, B - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k <= SEG_LDS_MAX_B / 256; ++k)
+      if (k * 256 + tid <= B) so_l[k * 256 + tid] = a[k];
+#pragma unroll
+    for (int k = 0; k < SEG_LDS_MAX_B / 256; ++k)
+      if (k * 256 + tid < B) {
+        ur_l[k * 256 + tid] = b[k];
+        pf_l[k * 256 + tid] = c[k];
+      }
+  }
+  const int nu = nuniq[f];
+  __syncthreads();
+  const int rpw = nu <= wpf ? 1 : (nu + wpf - 1) / wpf;      // (the dealing of segsum_wave)
+  const bool spread = rpw == 1;
+  const int jlo = wf0 * rpw;
+  if (jlo >= nu) return false;                  // workgroup-uniform: none of its waves owns a row
+  const int jhi = (wf0 + 4) * rpw < nu ? (wf0 + 4) * rpw : nu;
+  const int plo = so_l[jlo], phi = so_l[jhi];
+  const int j0 = wf * rpw;
+  const int j = j0 + g;
+  valid = g < rpw && j < nu;
+  sl = (size_t)f * stride + (valid ? j : jlo);
+  const int beg = valid ? so_l[j] : 0;
+  int end = valid ? so_l[j + 1] : 0;
+  row = valid ? ur_l[j] : 0;
+  if (valid && null_row >= 0 && row == null_row) end = beg;
+  const int L = end - beg;
+  do1 = gy1 != nullptr && q == 0 && ((w1_mask >> f) & 1ull);
+  // (2) the rows' own loads ...
+  e = F4Z;
+  if (gy2 != nullptr) e = reinterpret_cast<const float4*>(tables)[(size_t)row * LPR + q];
+  if constexpr (PRE) {
+    const size_t o = (size_t)row * LPR + q;
+    pre.var = gy2 != nullptr ? e : reinterpret_cast<const float4*>(pre.tables)[o];
+    pre.m = reinterpret_cast<const float4*>(pre.m_t)[o];
+    pre.v = reinterpret_cast<const float4*>(pre.v_t)[o];
+    const size_t wi = (size_t)row * pre.w1_stride;
+    pre.w = pre.w1[wi];
+    pre.mw = pre.m_w[wi];
+    pre.vw = pre.v_w[wi];
+  }
+  // ... and every entry of the position range, 4 per thread in flight.  Absent inputs are read through a pointer to a
+  // present one (loads stay unconditional; the values are never used).
+  {
+    const float4* __restrict__ X4 = reinterpret_cast<const float4*>(dX != nullptr ? dX : S);
+    const float4* __restrict__ S4 = reinterpret_cast<const float4*>(gy2 != nullptr ? S : dX);
+    const float* __restrict__ h2 = gy2 != nullptr ? gy2 : dX;
+    const float* __restrict__ h1 = gy1 != nullptr ? gy1 : h2;
+    const int xF = dX != nullptr ? F : 1, xf = dX != nullptr ? f : 0;     // (S rows have no field index)
+    const int ntask = (phi - plo) * LPR;
+    for (int base = 0; base < ntask; base += 1024) {
+      float4 xv[4], sv[4];
+      float gv[4], hv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = base + k * 256 + tid;
+        const int tc = t < ntask ? t : ntask - 1;
+        const int p = tc / LPR, qq = tc % LPR;
+        int bi;
+        size_t bo;
+        ex_locate(xb, pf_l[plo + p], bi, bo);
+        xv[k] = X4[bo / 4 + ((size_t)bi * xF + xf) * LPR + qq];
+        sv[k] = S4[bo / 4 + (gy2 != nullptr ? (size_t)bi * LPR : ((size_t)bi * xF + xf) * LPR) + qq];
+        gv[k] = h2[bo + bi];
+        hv[k] = h1[bo + bi];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = base + k * 256 + tid;
+        if (t < ntask) {
+          Xs[t] = xv[k];
+          Ss[t] = sv[k];
+          if (t % LPR == 0) {
+            g2s[t / LPR] = gv[k];
+            g1s[t / LPR] = hv[k];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (j0 >= nu) return false;                   // (a wave without rows leaves after the barriers)
+  acc = F4Z;
+  a1 = 0.f;
+  const bool fm = gy2 != nullptr, xg = dX != nullptr;
+  auto range = [&](const float4 es, int i0, int i1, float4& ac, float& a) {
+    if (fm) {
+      if (xg) lds_range_sum<LPR, true, true>(Xs, Ss, g2s, g1s, plo, q, do1, es, i0, i1, ac, a);
+      else lds_range_sum<LPR, true, false>(Xs, Ss, g2s, g1s, plo, q, do1, es, i0, i1, ac, a);
+    } else {
+      lds_range_sum<LPR, false, true>(Xs, Ss, g2s, g1s, plo, q, do1, es, i0, i1, ac, a);
+    }
+  };
+  const int short_len = spread ? 2 : SEG_SHORT;
+  if (valid && L <= short_len) range(e, beg, end, acc, a1);
+  unsigned long long todo = __ballot(valid && L > short_len && q == 0);
+  while (todo) {  // wave-uniform loop over the long segments owned by this wave (as in segsum_wave)
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int sb = __shfl(beg, src), se = __shfl(end, src);
+    const float4 es = make_float4(__shfl(e.x, src + q), __shfl(e.y, src + q), __shfl(e.z, src + q), __shfl(e.w, src + q));
+    const int per = (se - sb + GPW - 1) / GPW;
+    const int r0 = sb + g * per;
+    const int r1 = r0 + per < se ? r0 + per : se;
+    float4 p = F4Z;
+    float p1 = 0.f;
+    if (r0 < r1) range(es, r0, r1, p, p1);
+    float4 tot = make_float4(__shfl(p.x, q), __shfl(p.y, q), __shfl(p.z, q), __shfl(p.w, q));
+    float t1 = __shfl(p1, 0);
+#pragma unroll
+    for (int k = 1; k < GPW; ++k) {  // ascending sub-range order
+      const int ln = k * LPR + q;
+      tot = f4_add(tot, make_float4(__shfl(p.x, ln), __shfl(p.y, ln), __shfl(p.z, ln), __shfl(p.w, ln)));
+      t1 += __shfl(p1, k * LPR);
+    }
+    if (g == src / LPR) {
+      acc = tot;
+      a1 = t1;
+    }
+  }
+  return true;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ tables, const float* __restrict__ S,
                                                     const float* __restrict__ dX, const float* __restrict__ gy1,
@@ -949,9 +1151,15 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
     }
     return;
   }
-  if (!segsum_wave<D, false>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                             nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same,
-                             nopre))
+  if (part.lds_mode) {
+    extern __shared__ float4 seg_dyn_lds[];
+    if (!segsum_wave_lds<D, false>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off,
+                                   uniq_row, nuniq, w1_mask, B, F, stride, null_row, xb, valid, sl, acc, a1, e, row, do1, staged,
+                                   nopre, seg_dyn_lds))
+      return;
+  } else if (!segsum_wave<D, false>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, tables, S, dX, gy1, gy2, perm, seg_off,
+                                    uniq_row, nuniq, w1_mask, B, F, stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1,
+                                    staged, !same, nopre))
     return;
   if (valid && !(staged && same)) {
     reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
@@ -1002,6 +1210,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
                                                      const ExBlocks xb) {
   constexpr int LPR = D / 4;
   RSX_STAMP3(0);
+  RSX_STAMP(58, blockIdx.x == gridDim.x - 1);
   const float b1p = h.state[0], b2p = h.state[1];
   const uint32_t n_rows = h.tables2 != nullptr ? 2u * h.n_own : h.n_own;
   if (blockIdx.x >= n_rows + h.win_blk + h.extra.n_blk) {
@@ -1122,6 +1331,13 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
             valid)
           update2();
       }
+    } else if (part.lds_mode) {
+      extern __shared__ float4 seg_dyn_lds[];
+      if (segsum_wave_lds<D, true>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2, nullptr,
+                                   nullptr, perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, xb, valid, sl, acc, a1, e, row,
+                                   do1, staged, pre, seg_dyn_lds) &&
+          valid)
+        update2();
     } else if (segsum_wave<D, true>(((blockIdx.x - h.n_own) * blockDim.x + threadIdx.x) >> 6, h.tables2, nullptr, h.dX2,
                                     nullptr, nullptr, perm, seg_off, uniq_row, nuniq, 0, B, F, stride, -1, h.part2, xb, valid, sl,
                                     acc, a1, e, row, do1, staged, true, pre) &&
@@ -1178,6 +1394,13 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
           update1();
       }
       RSX_STAMP3(1);
+    } else if (part.lds_mode) {
+      extern __shared__ float4 seg_dyn_lds[];
+      const bool any = segsum_wave_lds<D, true>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm,
+                                                seg_off, uniq_row, nuniq, w1_mask, B, F, stride, -1, xb, valid, sl, acc, a1, e,
+                                                row, do1, staged, pre, seg_dyn_lds);
+      RSX_STAMP3(1);
+      if (any && valid) update1();
     } else {
       const bool any = segsum_wave<D, true>((blockIdx.x * blockDim.x + threadIdx.x) >> 6, h.tables, S, dX, gy1, gy2, perm,
                                             seg_off, uniq_row, nuniq, w1_mask, B, F, stride, -1, part, xb, valid, sl, acc, a1,
@@ -1224,8 +1447,9 @@ static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* ta
                           const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                           const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
                           int F, int stride, int null_row, const SegPartials& part, const ExBlocks& xb) {
-  segsum_bwd_k<D><<<grid, block, 0, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
-                                          stride, null_row, part, xb);
+  const size_t lds = part.lds_mode ? seg_lds_bytes(B, D) : 0;
+  segsum_bwd_k<D><<<grid, block, lds, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
+                                            stride, null_row, part, xb);
 }
 template <int D>
 static void launch_tiles(dim3 grid, hipStream_t st, const float* tables, const float* S, const float* dX,
@@ -1252,12 +1476,12 @@ static inline int ex_blocks(const rsx_example_blocks* h, int B, ExBlocks& out) {
 }
 // host view of the two-stage workspace; nullptr -> single-stage
 static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegPartials& out) {
-  out = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE};
+  out = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE, 0};
   if (h == nullptr) return RSX_OK;
   if (!h->segid || !h->P || (need_p1 && !h->P1)) return RSX_EINVAL;
   if (h->null_row == RSX_NULL_LAST_ROW && !h->row_off) return RSX_EINVAL;
   if (h->null_row < RSX_NULL_LAST_ROW) return RSX_EINVAL;
-  out = SegPartials{h->segid, h->P, h->P1, h->G, h->G ? h->gw1 : nullptr, h->row_off, h->null_row};
+  out = SegPartials{h->segid, h->P, h->P1, h->G, h->G ? h->gw1 : nullptr, h->row_off, h->null_row, 0};
   return RSX_OK;
 }
 
@@ -1385,6 +1609,7 @@ static int segsum_impl(const float* tables, const float* S, const float* dX, con
   SegPartials part;
   const int rcp = seg_partials(partials_h, gy1 != nullptr, part);
   if (rcp != RSX_OK) return rcp;
+  part.lds_mode = seg_lds_ok(B, D, part.P != nullptr) ? 1 : 0;
   ExBlocks xb;
   const int rcb = ex_blocks(blocks_h, B, xb);
   if (rcb != RSX_OK) return rcb;
@@ -1438,8 +1663,9 @@ static void launch_segsum_adam(dim3 grid, dim3 block, hipStream_t st, const floa
                                const float* gy2, const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
                                const int32_t* nuniq, uint64_t mask, int B, int F, int stride, const HotAdam& h,
                                const SegPartials& part, const ExBlocks& xb) {
-  segsum_adam_k<D><<<grid, block, 0, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h, part,
-                                           xb);
+  const size_t lds = part.lds_mode ? seg_lds_bytes(B, D) : 0;
+  segsum_adam_k<D><<<grid, block, lds, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h, part,
+                                             xb);
 }
 
 extern "C" int rsx_segsum_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w,
@@ -1474,6 +1700,7 @@ extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, floa
   SegPartials part;
   const int rcp = seg_partials(partials_h, gy1 != nullptr, part);
   if (rcp != RSX_OK) return rcp;
+  part.lds_mode = seg_lds_ok(B, D, part.P != nullptr) ? 1 : 0;
   ExBlocks xb;
   const int rcb = ex_blocks(blocks_h, B, xb);
   if (rcb != RSX_OK) return rcb;
@@ -1482,7 +1709,7 @@ extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, floa
   h.w1_stride = w1_stride; h.w1_sparse = w1_sparse_formula != 0;
   h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state; h.advance = advance_step != 0;
   h.tables2 = nullptr; h.m_t2 = nullptr; h.v_t2 = nullptr; h.dX2 = nullptr;
-  h.part2 = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE};
+  h.part2 = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE, 0};
   if (second_h != nullptr) {
     if (!second_h->tables || !second_h->m || !second_h->v || !second_h->dX) return RSX_EINVAL;
     h.tables2 = second_h->tables; h.m_t2 = second_h->m; h.v_t2 = second_h->v; h.dX2 = second_h->dX;

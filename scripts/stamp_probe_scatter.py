@@ -67,5 +67,5 @@ for g, what in ((32, "workgroup 0 (helpers of field 0's huge segments)"), (48, "
 
 if os.environ.get("RSX_STAMP_WINDOW"):
     print("---- first window-pass workgroup: entry %.2f, slot maps read %.2f, table rows stored %.2f, first-order done %.2f, "
-          "counter done %.2f | last workgroup of the grid: work done %.2f, counter done %.2f" %
-          (t[40], t[41], t[42], t[43], t[44], t[56], t[57]))
+          "counter done %.2f | last workgroup of the grid: entry %.2f, work done %.2f, counter done %.2f" %
+          (t[40], t[41], t[42], t[43], t[44], t[58], t[56], t[57]))
