@@ -753,7 +753,7 @@ static int cb_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs
   if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0) return RSX_EINVAL;
   if (njobs > CB_MAXJ || D != CB_D) return RSX_EUNSUPPORTED;
   if (B == 0) return RSX_OK;
-  static const int cfg = getenv("RSX_CIN_DW16_CFG") ? atoi(getenv("RSX_CIN_DW16_CFG")) : 32;
+  static const int cfg = getenv("RSX_CIN_DW16_CFG") ? atoi(getenv("RSX_CIN_DW16_CFG")) : 24;
   switch (cfg) {
     case 24: return cb_launch_dw_t<2, 4>(X0, jobs_h, njobs, B, F, sweep_h, stream);
     case 34: return cb_launch_dw_t<3, 4>(X0, jobs_h, njobs, B, F, sweep_h, stream);
