@@ -638,10 +638,13 @@ int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const i
  * num_epochs < 0 repeats forever.  Data-parallel sharding (MirroredStrategy gives successive batches of the stream to
  * successive replicas, fm/fm.py:184-194): batch b of an epoch belongs to rank b % shard_world; only complete rounds of
  * shard_world FULL batches are delivered, so every rank runs the same number of equal-size steps.
+ * drop_remainder == RSX_SHARD_TAIL (evaluation: no collective inside the loop): every batch goes to rank b % shard_world,
+ * leftover full batches and the final partial one included -- the ranks together see every record exactly once.
  * next(): fills the caller's arrays (host; pinned on the training path) with the next batch of THIS rank, in stream
  * order; returns the number of rows (batch_size, or fewer for a final partial batch), 0 at the end of the data, or a
  * negative status code (RSX_EDATA: truncated file, crc mismatch, malformed Example, missing required feature --
  * TF raises DataLossError / InvalidArgument there).  open() returns NULL on invalid arguments.  One consumer thread. */
+#define RSX_SHARD_TAIL 2            /* value of drop_remainder: sharded evaluation covers every record (see above) */
 typedef struct rsx_reader rsx_reader;
 rsx_reader* rsx_criteo_reader_open_h(const char* const* paths_h, int n_paths, const int32_t* slot_src_h,
                                      const int32_t* slot_rows_h, const float* bnd_h, const int32_t* bnd_off_h,

@@ -13,7 +13,10 @@
 //     SURVEY.md 8e "replica r gets records r, r+N, ..."): batch b of an epoch belongs to rank b % world; a rank
 //     neither verifies nor parses the other ranks' records.  Only complete rounds of `world` full batches are
 //     delivered, so every rank runs the same number of equal-size steps (the collectives need that); the < world*bs
-//     records left at the end of an epoch are dropped.
+//     records left at the end of an epoch are dropped.  drop_remainder == RSX_SHARD_TAIL (2) lifts that for EVALUATION
+//     (no collective inside the loop, the metric counters are summed at the end): every batch goes to rank b % world as
+//     soon as it is full, the leftover full batches and the final partial one included, so the ranks together cover every
+//     record exactly once -- the same examples a single-replica evaluation of the files sees.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -234,7 +237,7 @@ struct rsx_reader {
           ++total_records;
           if (++in_batch == bs) {            // batch `batch_in_epoch` is complete
             if (mine) {
-              if (world == 1) { if (!push_job(std::move(cur))) return; }
+              if (world == 1 || drop_remainder == RSX_SHARD_TAIL) { if (!push_job(std::move(cur))) return; }
               else { held = std::move(cur); have_held = true; }
               cur = Job();
             }
@@ -254,7 +257,8 @@ struct rsx_reader {
       }
       // end of the epoch: the final partial batch is kept on a single replica (batch before repeat, fm/fm.py:108-111);
       // data-parallel runs deliver complete rounds only (see the header).
-      if (world == 1 && in_batch > 0 && !drop_remainder) {
+      if (in_batch > 0 && ((world == 1 && !drop_remainder) ||
+                           (drop_remainder == RSX_SHARD_TAIL && (batch_in_epoch % world) == rank))) {
         if (!push_job(std::move(cur))) return;
       }
       if (total_records == 0) break;         // nothing to repeat

@@ -226,24 +226,38 @@ def _criteo_batches(filenames, batch_size, num_epochs, layout, threads, shard, v
         rd.close()
 
 
+RSX_SHARD_TAIL = 2      # include/rsx.h: value of drop_remainder
+
+
+def _shard_tail(shard_tail, num_epochs, need_shuffle):
+    """Sharded EVALUATION (one pass, no shuffle: how run_main builds its eval / predict input_fn) has no collective inside
+    its loop, so the ranks need not run equal step counts: deliver the leftover batches of the last round and the final
+    partial batch too (csrc/tfrecord_reader.cpp RSX_SHARD_TAIL) -- together the ranks then evaluate exactly the examples
+    a single replica would.  TRAIN keeps complete rounds only."""
+    if shard_tail is None:
+        shard_tail = int(num_epochs) == 1 and not need_shuffle
+    return RSX_SHARD_TAIL if shard_tail else 0
+
+
 def criteo_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None,
-                    shuffle_buffer=1000, prefetch=16, seed=0, shard=None, verify_crc=True):
+                    shuffle_buffer=1000, prefetch=16, seed=0, shard=None, verify_crc=True, shard_tail=None):
     """fm/fm.py:106-112.  Returns an iterator of (features, labels).
     shard=(rank, world): this replica's share of the batch stream (see csrc/tfrecord_reader.cpp); each replica then
-    shuffles its own sub-stream with its own seed.  `prefetch` = batches the C++ reader keeps in flight."""
+    shuffles its own sub-stream with its own seed.  `prefetch` = batches the C++ reader keeps in flight.
+    shard_tail (default: num_epochs == 1 and not need_shuffle, i.e. evaluation): see _shard_tail."""
     if layout is None:
         from .feature_columns import CriteoLayout, build_feature_columns
         layout = CriteoLayout.from_columns(build_feature_columns(16)[1])
     rank, world = _shard_from_env(shard)
     it = _criteo_batches(list(filenames), batch_size, num_epochs, layout, num_parallel, (rank, world), verify_crc,
-                         max(2, prefetch), drop_remainder=False)
+                         max(2, prefetch), drop_remainder=_shard_tail(shard_tail, num_epochs, need_shuffle) if world > 1 else 0)
     if need_shuffle:
         it = _shuffled(it, shuffle_buffer, seed + 7919 * rank)
     return it
 
 
 def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=6, hist_len=100,
-                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False, shard=None, verify_crc=True):
+                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False, shard=None, verify_crc=True, shard_tail=None):
     """din/din.py:61-80: features {'i_id','i_cate' int64 [B]; 'u_iid_seq','u_icat_seq' int64 [B,P]}, labels int64 [B].
     ids_int32: narrow the id features to int32 on the HOST (the device kernels index with int32; like the Criteo parse,
     which emits int32 row ids) so that the training step has no per-feature cast launches."""
@@ -253,7 +267,8 @@ def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_p
 
     def gen():
         paths = _paths_array(filenames)
-        rd = _Reader(lib().rsx_din_reader_open_h(paths, len(filenames), P, bs, int(num_epochs), rank, world, 0,
+        tail = _shard_tail(shard_tail, num_epochs, need_shuffle) if world > 1 else 0
+        rd = _Reader(lib().rsx_din_reader_open_h(paths, len(filenames), P, bs, int(num_epochs), rank, world, tail,
                                                  int(num_parallel), int(verify_crc), max(2, int(prefetch))))
         try:
             while True:
