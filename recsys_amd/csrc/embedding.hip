@@ -1199,6 +1199,9 @@ struct HotAdam {
 };
 
 constexpr int WIN_NR = 4;      // rows per lane group in the window pass of segsum_adam_k
+#ifndef RSX_WIN_PASS_NT
+#define RSX_WIN_PASS_NT 0      // (A/B knob: streaming stores in the window pass)
+#endif
 
 template <int D>
 __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S, const float* __restrict__ dX,
@@ -1223,6 +1226,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     constexpr int RPW = 256 / LPR;
     const uint32_t wb = blockIdx.x - n_rows;
     RSX_STAMP(40, wb == 0);
+    RSX_STAMP_MAX(62, true);                                                           // latest ENTRY of a window-pass workgroup
     const uint32_t per_l = (uint32_t)F * h.win_per_f;
     const int li = (int)(wb / per_l);
     const uint32_t rem = wb - (uint32_t)li * per_l;
@@ -1283,7 +1287,14 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
           F4_APPLY(adam_sparse1, var[i], m[i], v[i], F4Z, false, hp);
           if (t[i] < 0 && j0 + i * RPW < nu) {
             const size_t o4 = (size_t)row[i] * LPR + q;
+#if RSX_WIN_PASS_NT
+            typedef float nt4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((nt4){var[i].x, var[i].y, var[i].z, var[i].w}, reinterpret_cast<nt4*>(&T4[o4]));
+            __builtin_nontemporal_store((nt4){m[i].x, m[i].y, m[i].z, m[i].w}, reinterpret_cast<nt4*>(&M4[o4]));
+            __builtin_nontemporal_store((nt4){v[i].x, v[i].y, v[i].z, v[i].w}, reinterpret_cast<nt4*>(&V4[o4]));
+#else
             T4[o4] = var[i]; M4[o4] = m[i]; V4[o4] = v[i];
+#endif
           }
         }
       }
@@ -1421,6 +1432,9 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
   }
   RSX_STAMP3(4);
   RSX_STAMP(44, blockIdx.x == n_rows);
+  RSX_STAMP_MAX(59, blockIdx.x < n_rows);                                            // last exit: row owners
+  RSX_STAMP_MAX(60, blockIdx.x >= n_rows && blockIdx.x < n_rows + h.win_blk);        //            window pass
+  RSX_STAMP_MAX(61, blockIdx.x >= n_rows + h.win_blk);                               //            dense / cold riders
   RSX_STAMP(57, blockIdx.x == gridDim.x - 1);
 }
 
@@ -1790,6 +1804,10 @@ extern "C" int rsx_copy_bytes(void* dst, const void* src, size_t nbytes, rsx_str
 
 #ifdef RSX_STAMPS
 // profiling build only: copy this unit's phase stamps (100 MHz wall clock ticks) to the host
+extern "C" int rsx_dbg_stamps_embedding_zero() {
+  static const unsigned long long z[64] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(rsx_stamps_d), z, sizeof(z)) == hipSuccess ? RSX_OK : RSX_ELAUNCH;
+}
 extern "C" int rsx_dbg_stamps_embedding(unsigned long long* out_h) {
   return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(rsx_stamps_d), sizeof(unsigned long long) * 64) == hipSuccess ? RSX_OK : RSX_ELAUNCH;
 }

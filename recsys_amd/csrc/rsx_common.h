@@ -45,9 +45,17 @@ __device__ __forceinline__ float4 f4_shfl_xor(float4 a, int m) {
   do {                                                                               \
     if ((cond) && threadIdx.x == 0) rsx_stamps_d[slot] = wall_clock64();             \
   } while (0)
+// latest time any workgroup passed this point (the probe zeroes the slot before the launch)
+#define RSX_STAMP_MAX(slot, cond)                                                                 \
+  do {                                                                                            \
+    if ((cond) && threadIdx.x == 0) atomicMax(&rsx_stamps_d[slot], (unsigned long long)wall_clock64()); \
+  } while (0)
 #else
 #define RSX_STAMP_DECL
 #define RSX_STAMP(slot, cond) \
   do {                        \
+  } while (0)
+#define RSX_STAMP_MAX(slot, cond) \
+  do {                            \
   } while (0)
 #endif

@@ -38,7 +38,10 @@ if os.environ.get("RSX_STAMP_WINDOW"):       # the DeepFM launch: window pass ov
     a.select(0)
     win = (nb, 0)
     dense_segs = DenseArena({"w": (73100,)}, "cuda").adam_segments()
+fz = C.CDLL(os.environ["RSX_LIB_PATH"]).rsx_dbg_stamps_embedding_zero
+last = np.zeros(4)
 for s in range(30):
+    fz()
     if fm:
         a.segsum_adam(B, S, dX, g1, g2, opt, dense_segs, None, window=win)
     else:
@@ -50,6 +53,7 @@ for s in range(30):
         t = np.array(list(buf), np.float64)
         acc[:32] += np.where(t[:32] > 0, t[:32] - t[0], 0)
         acc[32:] += np.where(t[32:] > 0, t[32:] - t[32], 0)
+        last += np.where(t[59:63] > 0, t[59:63] - t[32], 0) * 0.01
         reps += 1
 t = acc / reps * 0.01
 names = ["entry", "tile indices in LDS", "chunk classified (LDS reads, masks)", "first batch of rows arrived",
@@ -65,6 +69,8 @@ for g, what in ((32, "workgroup 0 (helpers of field 0's huge segments)"), (48, "
     for k, n in enumerate(names):
         print("%-55s %8.2f" % (n, t[g + k]))
 
+print("---- LAST exit per role (us since workgroup 0's entry): row owners %.2f, window pass %.2f, dense / riders %.2f | latest "
+      "ENTRY of a window-pass workgroup %.2f" % tuple(last / reps))
 if os.environ.get("RSX_STAMP_WINDOW"):
     print("---- first window-pass workgroup: entry %.2f, slot maps read %.2f, table rows stored %.2f, first-order done %.2f, "
           "counter done %.2f | last workgroup of the grid: entry %.2f, work done %.2f, counter done %.2f" %
