@@ -300,10 +300,57 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   }
 }
 
-// ---- window sweep: packed fast form of the zero-gradient update --------------------------------------------------------
 #ifndef RSX_ADAM_WIN_FAST
 #define RSX_ADAM_WIN_FAST 1
 #endif
+
+// ---- scalar zero-gradient update (the first-order vector's rows in the lazy window pass of segsum_adam_k) ----------------
+// adam_fast.h's sequences on ONE element, behind a guard on the operands themselves (checked after they have been computed):
+// v1 in the square root's domain -- or +0 together with a +0 numerator, where both forms give var - (+0) --, numerator and
+// denominator in the division's.  A wave with an active element outside takes the IEEE form for this update.
+__device__ __forceinline__ float rsx_sqrt1_fast(const float x) {
+  const float r = __builtin_amdgcn_rsqf(x), g = x * r, hh = r * 0.5f;
+  return __builtin_fmaf(__builtin_fmaf(-g, g, x), hh, g);
+}
+__device__ __forceinline__ float rsx_div1_fast(const float n, const float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+  const float q = n * r;
+  return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+template <bool DENSE>
+__device__ __forceinline__ void adam_zero_grad1(float& var, float& m, float& v, const bool active, const Hp& h) {
+  float m1, v1, n;
+  if constexpr (DENSE) {                      // adam_dense1 with g = 0, operation by operation
+    m1 = m + (0.f - m) * h.omb1;
+    v1 = v + (0.f * 0.f - v) * h.omb2;
+    n = m1 * h.alpha;
+  } else {                                    // adam_sparse1 with has = false
+    m1 = m * h.b1;
+    v1 = v * h.b2;
+    n = h.alpha * m1;
+  }
+  const bool vz = __float_as_uint(v1) == 0u && __float_as_uint(n) == 0u;
+  const float d = (vz ? 0.f : rsx_sqrt1_fast(vz ? 1.f : v1)) + h.eps;
+  const uint32_t vb = __float_as_uint(v1), nb = __float_as_uint(n), na = nb & 0x7fffffffu, db = __float_as_uint(d);
+  constexpr uint32_t V_LO = (127u - 96u) << 23, V_HI = (127u + 41u) << 23;      // rsx_sqrt2_fast: 2^-96 <= v1 < 2^41
+  constexpr uint32_t D_LO = (127u - 30u) << 23, D_HI = (127u + 21u) << 23;      // rsx_div2_fast:  2^-30 <= d <= 2^21
+  constexpr uint32_t N_LO = (127u - 94u) << 23, N_HI = (127u + 34u) << 23;      //                 n == +0 or 2^-94 <= |n| <= 2^34
+  const bool ok = (vz || (vb - V_LO) < (V_HI - V_LO)) && (db - D_LO) <= (D_HI - D_LO) &&
+                  (nb == 0u || (na - N_LO) <= (N_HI - N_LO));
+  if (RSX_ADAM_WIN_FAST && __builtin_amdgcn_ballot_w64(active && !ok) == 0ull) {
+    if (active) {
+      var = var - rsx_div1_fast(n, d);
+      m = m1;
+      v = v1;
+    }
+  } else if (active) {
+    if constexpr (DENSE) adam_dense1(var, m, v, 0.f, h);
+    else adam_sparse1(var, m, v, 0.f, false, h);
+  }
+}
+
+// ---- window sweep: packed fast form of the zero-gradient update --------------------------------------------------------
 
 // One zero-gradient TF-1 update of two elements -- adam_sparse1(has = false) -- with the packed square root / division.
 __device__ __forceinline__ void adam_zero_grad2(rsx_f2& var, rsx_f2& m, rsx_f2& v, const float alpha, const Hp& h) {

@@ -1198,7 +1198,8 @@ struct HotAdam {
   uint32_t win_blk, win_per_f;           // workgroups of the pass; per (list, field)
 };
 
-constexpr int WIN_NR = 4;      // rows per lane group in the window pass of segsum_adam_k
+constexpr int WIN_NR = 1;      // rows per lane group in the window pass of segsum_adam_k (round 2's one-update pass took 4; the
+                               // lazy pass applies up to 8 updates per row back to back: more workgroups, shorter chains)
 #ifndef RSX_WIN_PASS_NT
 #define RSX_WIN_PASS_NT 0      // (A/B knob: streaming stores in the window pass)
 #endif
@@ -1220,9 +1221,19 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     adam_block(h.cold.args, h.cold.blk_lo + (blockIdx.x - n_rows - h.win_blk - h.extra.n_blk));
   } else if (blockIdx.x >= n_rows + h.win_blk) {
     adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - n_rows - h.win_blk));
-  } else if (blockIdx.x >= n_rows) {      // window pass: list li (the window's other steps in order), field f, WIN_NR*256/LPR rows
-    // Every LPR-lane group takes WIN_NR rows; phase by phase (unique rows, slot maps, the rows' state, update, store) so that
-    // the loads of all its rows are in flight together -- the pass is a chain of 4 dependent accesses per row.
+  } else if (blockIdx.x >= n_rows) {
+    // LAZY window pass.  A row that some step of the window touches is skipped by the window's sweep; its zero-gradient
+    // updates of the steps that do NOT touch it are caught up right before they are needed instead of step by step:
+    //   * step cur < k - 1 walks the NEXT step's unique-row list: a row that this step does not touch itself receives the
+    //     updates of the steps (its last touch, cur] back to back in registers -- so the next step's gather reads, and its
+    //     scatter updates, a row that is current;
+    //   * the window's last step walks every earlier list: a row whose LAST touch was step o receives the updates of the
+    //     steps (o, k - 1].
+    // Every row thus gets the same updates in the same order as with a pass over all other lists in every step (round 2:
+    // k (k - 1) list walks per window, 11 MB of traffic and 273 workgroups per DeepFM step) -- with 2 (k - 1) walks.  The
+    // step size of step s comes from state[8 + s], written by step s's launch (the expression every update of that step used).
+    // Inside a window the tables are not a state any step-by-step run passes through (that was already so).
+    // Every LPR-lane group takes WIN_NR rows, phase by phase (unique rows; all slot maps + the rows' state; updates; stores).
     constexpr int RPW = 256 / LPR;
     const uint32_t wb = blockIdx.x - n_rows;
     RSX_STAMP(40, wb == 0);
@@ -1233,31 +1244,30 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     const int f = (int)(rem / h.win_per_f);
     const int j0 = (int)(rem - (uint32_t)f * h.win_per_f) * (RPW * WIN_NR) + (int)threadIdx.x / LPR;
     const int q = (int)threadIdx.x % LPR;
-    const int o = li < h.win_cur ? li : li + 1;
+    const int cur = h.win_cur, wk = h.win_k;
+    const bool tail = cur == wk - 1;
+    const int o = tail ? li : cur + 1;                   // the list this workgroup walks
     const int nu = h.win_nuniq[o][f];
     if (j0 < nu) {
       const int32_t* __restrict__ ur = h.win_uniq[o] + (size_t)f * stride;
-      int row[WIN_NR], t[WIN_NR];
+      int row[WIN_NR];
 #pragma unroll
       for (int i = 0; i < WIN_NR; ++i) {
         const int j = j0 + i * RPW;
         row[i] = ur[j < nu ? j : nu - 1];
       }
-      // this step's own scatter owns the rows it touches; a row on several lists belongs to the first of them.  All 8 slot
-      // maps are read unconditionally (a list that does not take part is replaced by this step's own map: a loop with a
-      // dynamic trip count drains the loads at every back-edge), together with the rows' state -- ONE round trip after the rows.
-      const int32_t* __restrict__ scur = h.win_slot[h.win_cur];
+      // which steps of the window touch the row: all slot maps in ONE round trip (maps past the window re-read this step's)
+      uint32_t touch[WIN_NR];
 #pragma unroll
-      for (int i = 0; i < WIN_NR; ++i) t[i] = scur[row[i]];
+      for (int i = 0; i < WIN_NR; ++i) touch[i] = 0u;
+      const int32_t* __restrict__ scur = h.win_slot[cur];
 #pragma unroll
       for (int l = 0; l < RSX_ADAM_WINDOW_MAX; ++l) {
-        const int32_t* __restrict__ sp = (l < o && l != h.win_cur) ? h.win_slot[l] : scur;
+        const int32_t* __restrict__ sp = l < wk ? h.win_slot[l] : scur;
+        const uint32_t bit = l < wk ? (1u << l) : 0u;
 #pragma unroll
-        for (int i = 0; i < WIN_NR; ++i) t[i] &= sp[row[i]];
+        for (int i = 0; i < WIN_NR; ++i) touch[i] |= sp[row[i]] >= 0 ? bit : 0u;
       }
-      Hp hp;
-      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
-      hp.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
       const bool hw1 = h.w1 != nullptr;
       const float* __restrict__ w1p = hw1 ? h.w1 : h.tables;
       const float* __restrict__ mwp = hw1 ? h.m_w : h.m_t;
@@ -1270,6 +1280,45 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
         mw[i] = mwp[(size_t)row[i] * wst];
         vw[i] = vwp[(size_t)row[i] * wst];
       }
+      // owner + first pending step of every row
+      bool own[WIN_NR];
+      int p0[WIN_NR];
+#pragma unroll
+      for (int i = 0; i < WIN_NR; ++i) {
+        const uint32_t m = touch[i];
+        if (tail) {
+          own[i] = (m >> (o + 1)) == 0u;                 // no later step touches it: step o was its last
+          p0[i] = o + 1;
+        } else {
+          own[i] = ((m >> cur) & 1u) == 0u;              // (touched now: the row owners bring it up to date)
+          const uint32_t below = m & ((1u << cur) - 1u);
+          p0[i] = below != 0u ? 32 - __clz(below) : 0;   // the step after its last touch
+        }
+        own[i] = own[i] && j0 + i * RPW < nu;
+      }
+      // (wave-uniform, by ballot: groups past the list's end are inactive here) does any row of the wave wait for step st?
+      auto any_pending = [&](const int st) -> bool {
+        bool need = false;
+#pragma unroll
+        for (int i = 0; i < WIN_NR; ++i) need |= own[i] && st >= p0[i];
+        return __builtin_amdgcn_ballot_w64(need) != 0ull;
+      };
+      Hp hp;
+      hp.b1 = h.b1; hp.b2 = h.b2; hp.omb1 = 1.0f - h.b1; hp.omb2 = 1.0f - h.b2; hp.eps = h.eps;
+      const float alpha_now = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      // the step size of window step st (uniform): state[8 + st] for st < cur, this step's own for st == cur.  (Read in
+      // place: a register array of them indexed by the loop counter goes to scratch memory on this toolchain.)
+      auto alpha_of = [&](const int st) -> float { return st < cur ? h.state[8 + st] : alpha_now; };
+      float amin = alpha_now, amax = alpha_now;
+#pragma unroll
+      for (int l = 0; l < RSX_ADAM_WINDOW_MAX; ++l) {
+        const float a = l < cur ? h.state[8 + l] : alpha_now;
+        amin = fminf(amin, a);
+        amax = fmaxf(amax, a);
+      }
+      const bool fast_ok = RSX_ADAM_WIN_FAST && h.b1 >= 0.85f && h.b1 < 1.f && h.b2 >= 0.5f && h.b2 < 1.f && h.eps >= 0x1p-30f &&
+                           h.eps <= 1.f && amin >= 0x1p-24f && amax <= 16.f && amax <= 4.f * amin;
+      const uint32_t m_lo_bits = __float_as_uint(fast_ok ? 0x1p-90f / amin : 1.f);
       const int nset = h.tables2 != nullptr ? 2 : 1;
       for (int set = 0; set < nset; ++set) {
         float4* __restrict__ T4 = reinterpret_cast<float4*>(set ? h.tables2 : h.tables);
@@ -1281,30 +1330,74 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
           const size_t o4 = (size_t)row[i] * LPR + q;
           var[i] = T4[o4]; m[i] = M4[o4]; v[i] = V4[o4];
         }
-        RSX_STAMP(41, wb == 0 && set == 0 && t[0] != 12345);
+        RSX_STAMP(41, wb == 0 && set == 0 && touch[0] != 12345u);
+        bool bad = !fast_ok;
+#pragma unroll
+        for (int i = 0; i < WIN_NR; ++i) bad |= own[i] && adam_win_guard4(var[i], m[i], v[i], m_lo_bits);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+          // packed fast form (adam_fast.h; the guard keeps every operand of <= 8 updates inside its domains)
+          rsx_f2 var2[WIN_NR][2], m2[WIN_NR][2], v2[WIN_NR][2];
+#pragma unroll
+          for (int i = 0; i < WIN_NR; ++i) {
+            var2[i][0] = (rsx_f2){var[i].x, var[i].y}; var2[i][1] = (rsx_f2){var[i].z, var[i].w};
+            m2[i][0] = (rsx_f2){m[i].x, m[i].y}; m2[i][1] = (rsx_f2){m[i].z, m[i].w};
+            // (v == +0, which the guard admits under m == +0 only: compute with 1, store the zero back)
+            v2[i][0] = (rsx_f2){v[i].x == 0.f ? 1.f : v[i].x, v[i].y == 0.f ? 1.f : v[i].y};
+            v2[i][1] = (rsx_f2){v[i].z == 0.f ? 1.f : v[i].z, v[i].w == 0.f ? 1.f : v[i].w};
+          }
+#pragma unroll 1
+          for (int st = 0; st <= cur; ++st) {
+            if (!any_pending(st)) continue;
+            const float a = alpha_of(st);
+#pragma unroll
+            for (int i = 0; i < WIN_NR; ++i) {
+              if (st >= p0[i]) {
+                adam_zero_grad2(var2[i][0], m2[i][0], v2[i][0], a, hp);
+                adam_zero_grad2(var2[i][1], m2[i][1], v2[i][1], a, hp);
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < WIN_NR; ++i) {
+            var[i] = make_float4(var2[i][0].x, var2[i][0].y, var2[i][1].x, var2[i][1].y);
+            m[i] = make_float4(m2[i][0].x, m2[i][0].y, m2[i][1].x, m2[i][1].y);
+            v[i] = make_float4(v[i].x == 0.f ? 0.f : v2[i][0].x, v[i].y == 0.f ? 0.f : v2[i][0].y,
+                               v[i].z == 0.f ? 0.f : v2[i][1].x, v[i].w == 0.f ? 0.f : v2[i][1].y);
+          }
+        } else {
+#pragma unroll 1
+          for (int st = 0; st <= cur; ++st) {
+            if (!any_pending(st)) continue;
+            hp.alpha = alpha_of(st);
+#pragma unroll
+            for (int i = 0; i < WIN_NR; ++i) {
+              if (st >= p0[i]) { F4_APPLY(adam_sparse1, var[i], m[i], v[i], F4Z, false, hp); }
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < WIN_NR; ++i) {
-          F4_APPLY(adam_sparse1, var[i], m[i], v[i], F4Z, false, hp);
-          if (t[i] < 0 && j0 + i * RPW < nu) {
+          if (own[i]) {
             const size_t o4 = (size_t)row[i] * LPR + q;
-#if RSX_WIN_PASS_NT
-            typedef float nt4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store((nt4){var[i].x, var[i].y, var[i].z, var[i].w}, reinterpret_cast<nt4*>(&T4[o4]));
-            __builtin_nontemporal_store((nt4){m[i].x, m[i].y, m[i].z, m[i].w}, reinterpret_cast<nt4*>(&M4[o4]));
-            __builtin_nontemporal_store((nt4){v[i].x, v[i].y, v[i].z, v[i].w}, reinterpret_cast<nt4*>(&V4[o4]));
-#else
             T4[o4] = var[i]; M4[o4] = m[i]; V4[o4] = v[i];
-#endif
           }
         }
       }
       RSX_STAMP(42, wb == 0);
       if (hw1 && q == 0) {
+#pragma unroll 1
+        for (int st = 0; st <= cur; ++st) {
+          if (!any_pending(st)) continue;
+          hp.alpha = alpha_of(st);
+#pragma unroll
+          for (int i = 0; i < WIN_NR; ++i) {
+            if (h.w1_sparse) adam_zero_grad1<false>(w[i], mw[i], vw[i], st >= p0[i], hp);
+            else adam_zero_grad1<true>(w[i], mw[i], vw[i], st >= p0[i], hp);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < WIN_NR; ++i) {
-          if (h.w1_sparse) adam_sparse1(w[i], mw[i], vw[i], 0.f, false, hp);
-          else adam_dense1(w[i], mw[i], vw[i], 0.f, hp);
-          if (t[i] < 0 && j0 + i * RPW < nu) {
+          if (own[i]) {
             const size_t wi = (size_t)row[i] * wst;
             h.w1[wi] = w[i]; h.m_w[wi] = mw[i]; h.v_w[wi] = vw[i];
           }
@@ -1425,10 +1518,14 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
   RSX_STAMP(56, blockIdx.x == gridDim.x - 1);
   __syncthreads();
   RSX_STAMP3(3);
-  if (threadIdx.x == 0 && adam_arrive_last(h.state, h.total_blocks) && h.advance) {
-    h.state[0] = b1p * h.b1;
-    h.state[1] = b2p * h.b2;
-    reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
+  if (threadIdx.x == 0 && adam_arrive_last(h.state, h.total_blocks)) {
+    // (the lazy window pass of the window's later steps reads this step's step size from here)
+    if (h.win_k > 1) h.state[8 + h.win_cur] = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    if (h.advance) {
+      h.state[0] = b1p * h.b1;
+      h.state[1] = b2p * h.b2;
+      reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
+    }
   }
   RSX_STAMP3(4);
   RSX_STAMP(44, blockIdx.x == n_rows);
@@ -1764,7 +1861,8 @@ extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, floa
     h.win_k = win_h->k; h.win_cur = win_h->cur;
     const int rpw = WIN_NR * 256 / (D / 4);
     h.win_per_f = (uint32_t)((win_h->max_unique + rpw - 1) / rpw);
-    h.win_blk = (uint32_t)(win_h->k - 1) * (uint32_t)F * h.win_per_f;
+    // lazy pass: the next step's list, or -- the window's last step -- every earlier list
+    h.win_blk = (uint32_t)(win_h->cur == win_h->k - 1 ? win_h->k - 1 : 1) * (uint32_t)F * h.win_per_f;
   }
   h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.win_blk + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);

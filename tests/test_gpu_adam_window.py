@@ -230,7 +230,7 @@ def _state(est):
     torch.cuda.synchronize()
     return {"tables": a.tables.clone(), "m": a.m_t.clone(), "v": a.v_t.clone(), "w1": a.w1.clone(), "m_w": a.m_w.clone(),
             "v_w": a.v_w.clone(), "dense": est.store.dense.flat.clone(), "dense_m": est.store.dense.m.clone(),
-            "opt": est.store.opt.state.clone()}
+            "opt": est.store.opt.state[:4].clone()}      # (beta powers, step counter; words 8.. hold a window's step sizes)
 
 
 @pytest.mark.parametrize("window,steps,spg", [(8, 131, 16), (8, 75, 8), (7, 60, 8), (4, 131, 16), (3, 64, 8), (2, 37, 8)])
@@ -307,7 +307,7 @@ def _est_for(kind, B):
 
 def _model_state(est):
     torch.cuda.synchronize()
-    out = {"dense": est.store.dense.flat.clone(), "dense_m": est.store.dense.m.clone(), "opt": est.store.opt.state.clone()}
+    out = {"dense": est.store.dense.flat.clone(), "dense_m": est.store.dense.m.clone(), "opt": est.store.opt.state[:4].clone()}
     for name, a in est.store.embeddings.items():
         for k in ("tables", "m_t", "v_t", "w1", "m_w", "v_w"):
             if getattr(a, k, None) is not None:

@@ -232,6 +232,6 @@ def test_two_table_sets_in_one_scatter_launch_is_bit_identical(B):
                 a1.segsum_adam(B, None, dX1, g1, None, opt, [], None, advance=False)
                 a2.segsum_adam(B, None, dX2, None, None, opt, dense.adam_segments(), None)
             dense.grad.copy_(torch.arange(dense.n, device="cuda") * 0.01)
-        res.append([x.cpu().numpy().copy() for x in (a1.tables, a1.m_t, a1.v_t, a1.w1, a2.tables, a2.m_t, a2.v_t, dense.flat, opt.state)])
+        res.append([x.cpu().numpy().copy() for x in (a1.tables, a1.m_t, a1.v_t, a1.w1, a2.tables, a2.m_t, a2.v_t, dense.flat, opt.state[:4])])
     for x, y in zip(*res):
         np.testing.assert_array_equal(x, y)
