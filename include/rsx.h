@@ -161,7 +161,8 @@ int rsx_segsum_bwd(const float* tables, const float* S, const float* dX, const f
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: tf.train.AdamOptimizer(lr).minimize(...) fm/fm.py:162-163.
  * One launch sweeps any number of variable segments.  state (device, RSX_ADAM_STATE_WORDS 32-bit words) =
- * {beta1^t, beta2^t, <uint32 blocks-done ticket>, <uint32 step t>, then 32 arrival counters one 128-byte line apart};
+ * {beta1^t, beta2^t, <uint32 blocks-done ticket>, <uint32 step t>, then 32 arrival counters one 128-byte line apart;
+ *  words 8 .. 15: the step sizes of the current optimizer window's steps (rsx_adam_window)};
  * initialise words 0..3 with rsx_adam_state_init_h and the rest with zeros.  The last workgroup to finish advances the
  * powers, so the sweep is replayable from a hipGraph with no per-step host arguments.  (Every workgroup announces its
  * arrival on the counter of its index modulo 32 and only the last of each residue touches the shared ticket: one
@@ -245,9 +246,18 @@ typedef struct rsx_table_set {
  * the rows NO step of the window touches then need ONE pass over the optimizer state for the whole window
  * (rsx_adam_seg.slot_w) instead of one per step -- TF-1's non-lazy Adam moves every row every step, and
  * for an untouched row step t+1's update only needs step t's result, so k of them are applied back to back in registers.
- * A row that some step of the window touches is kept exact step by step: step `cur`'s scatter launch updates the rows it
- * touches with their gradient (as always) and walks the OTHER steps' unique-row lists to give the rows that it does not
- * touch this step's zero-gradient update.  Between two windows the state equals that of k single steps, bit for bit. */
+ * A row that some step of the window touches receives exactly the updates of k single steps, in order, but its
+ * zero-gradient updates are applied LAZILY (round 3): step `cur`'s scatter launch updates the rows it touches with their
+ * gradient (as always); for cur < k - 1 it also walks the NEXT step's unique-row list and brings the rows that it does not
+ * touch itself up to date -- the updates of the steps (last touch, cur] back to back in registers -- so the next step's
+ * gather and scatter see current rows; the window's last step walks every earlier list and finishes the rows whose last touch
+ * was that list's step.  (Round 2 walked all other lists in every step: k (k - 1) walks per window instead of 2 (k - 1).)
+ * The step sizes of the window's steps are kept in state words 8 .. 8 + k - 1 (written by the window's sweep, rsx_adam_slice_run
+ * over COLD segments with slot_w, which therefore has to run before the window's first step; each step's launch also
+ * leaves its own there).  Between two windows the state equals
+ * that of k single steps, bit for bit; INSIDE a window neither the untouched rows (already k steps ahead) nor the touched
+ * ones (possibly behind) are a state a step-by-step run passes through: the caller must not read, evaluate or checkpoint
+ * the variables there, and must run the window's steps 0 .. k-1 in order. */
 #define RSX_ADAM_WINDOW_MAX 8
 typedef struct {
   int32_t k;                 /* steps of the window (1: no window) */

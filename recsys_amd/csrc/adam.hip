@@ -62,6 +62,16 @@ __global__ __launch_bounds__(ADAM_T) void adam_slice_k(const AdamSlice s) { adam
 #endif
 template <int NW>
 __global__ __launch_bounds__(ADAM_T, RSX_ADAM_WIN_OCC) void adam_window_k(const AdamSlice s) {
+  // The step sizes of the window's 1 + NW steps, for the lazy window pass of segsum_adam_k (csrc/embedding.hip), which applies
+  // a row's zero-gradient updates of several steps -- also FUTURE ones -- in one go: state word 8 + j = the step size of
+  // window step j, from the products the per-step advance of the beta powers will make (alpha_window: what this sweep uses).
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const float b1p = s.args.state[0], b2p = s.args.state[1];
+    const AlphaW aw = alpha_window(s.args, NW, b1p, b2p);
+    s.args.state[8] = s.args.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) s.args.state[9 + j] = aw.get(j);
+  }
   adam_window_block<NW>(s.args, s.blk_lo + blockIdx.x);
 }
 template <int NW>

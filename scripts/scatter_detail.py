@@ -28,6 +28,7 @@ for B in Bs:
         dense = DenseArena({"w": (73100,)}, "cuda")
         a.sort_window(ids[:nb])
         a.select(0)
+        opt.window_sweep(a.adam_split_segments(window_k=nb)[0])     # (leaves the window's step sizes in the optimizer state)
         win = (nb, 0)
         res = {}
         if not w1:
@@ -39,6 +40,11 @@ for B in Bs:
             res["dX + FM + w1, no window (w1 swept in the launch)"] = timeit(lambda: a.segsum_adam(B, S, dX, g1, g2, opt, [], None))
             res["dX + FM + w1 + window pass"] = timeit(lambda: a.segsum_adam(B, S, dX, g1, g2, opt, [], None, window=win))
             res["dX + FM + w1 + dense + window pass (the DeepFM launch)"] = timeit(lambda: a.segsum_adam(B, S, dX, g1, g2, opt, dense.adam_segments(), None, window=win))
+            for pos in (nb // 2, nb - 1):      # a middle position and the window's LAST step (the lazy pass finishes every earlier list there)
+                a.select(pos)
+                res["the same at window position %d of %d" % (pos, nb)] = timeit(
+                    lambda: a.segsum_adam(B, S, dX, g1, g2, opt, dense.adam_segments(), None, window=(nb, pos)))
+            a.select(0)
             if B > 1024:
                 res["stage A alone (FM + w1)"] = timeit(lambda: a._stage_a(B, S, dX, g1, g2))
         for k, v in res.items():

@@ -36,6 +36,7 @@ if os.environ.get("RSX_STAMP_WINDOW"):       # the DeepFM launch: window pass ov
     nb = min(8 if B <= 1024 else 4, len(a.sortbufs))
     a.sort_window([ids] + [torch.from_numpy(synth_ids(rng, B, row_off)).cuda() for _ in range(nb - 1)])
     a.select(0)
+    opt.window_sweep(a.adam_split_segments(window_k=nb)[0])     # (leaves the window's step sizes in the optimizer state)
     win = (nb, 0)
     dense_segs = DenseArena({"w": (73100,)}, "cuda").adam_segments()
 fz = C.CDLL(os.environ["RSX_LIB_PATH"]).rsx_dbg_stamps_embedding_zero
