@@ -73,12 +73,14 @@ __device__ __forceinline__ void col_partials(const double* __restrict__ st, int 
 }
 
 // mean / rstd of one column from the per-row-tile partial sums (sum a, sum a^2)
-__device__ __forceinline__ void bn_col_stats(const double* __restrict__ fstat, int RT, int N, int col, int B,
+// (inv_B = 1.0 / B from the host: the two fp64 divisions cost ~80 instructions on the critical path of every workgroup of
+// every launch that consumes batch-norm statistics -- a lone wave issues ~270 per microsecond)
+__device__ __forceinline__ void bn_col_stats(const double* __restrict__ fstat, int RT, int N, int col, double inv_B,
                                              float& mean, float& rstd) {
   double s1, s2;
   col_partials(fstat, RT, N, col, s1, s2);
-  const double mu = s1 / B;
-  double var = s2 / B - mu * mu;
+  const double mu = s1 * inv_B;
+  double var = s2 * inv_B - mu * mu;
   if (var < 0.0) var = 0.0;
   mean = (float)mu;
   rstd = 1.0f / sqrtf((float)var + TOWER_BN_EPS);
@@ -151,6 +153,7 @@ struct FwdArgs {
   uint32_t seed, layer_prev;
   float rate;
   int B, K, N, RT;
+  double inv_B;            // 1.0 / B
   int ct, n_own;          // column tiles; ct * row tiles = workgroups of the layer itself
   int n_sort;             // extra workgroups running the step's per-field dedup sort (0: none), before the sweep slice
   SortArgs sort;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
         continue;
       }
       float mean, rstd;
-      bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.B, mean, rstd);
+      bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.inv_B, mean, rstd);
       const float inv = rstd * p.gamma_prev[k];
       sc[k] = inv;
       sh[k] = p.beta_prev[k] - mean * inv;
@@ -288,6 +291,7 @@ struct HeadArgs {
   float rate, loss_scale;    // loss_scale = 1/(B * replicas)
   int relu0, relu2;
   int B, N, RT;
+  double inv_B;              // 1.0 / B
   int n_own;
   AdamSlice sweep;
 };
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
       continue;
     }
     float mean, rstd;
-    bn_col_stats(p.fstat_last, p.RT, p.N, c, p.B, mean, rstd);
+    bn_col_stats(p.fstat_last, p.RT, p.N, c, p.inv_B, mean, rstd);
     const float inv = rstd * p.gamma[c];
     sc[c] = inv;
     sh[c] = p.beta[c] - mean * inv;
@@ -1003,7 +1007,7 @@ __global__ __launch_bounds__(256) void tower_fwd_big_k(const FwdArgs p) {
         continue;
       }
       float mean, rstd;
-      bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.B, mean, rstd);
+      bn_col_stats(p.fstat_prev, p.RT, p.K, k, p.inv_B, mean, rstd);
       const float inv = rstd * p.gamma_prev[k];
       sc[k] = inv;
       sh[k] = p.beta_prev[k] - mean * inv;
@@ -1629,6 +1633,7 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
   p.rate = dropout_rate;
   p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B);
+  p.inv_B = 1.0 / (double)B;
   p.ct = (N + 15) / 16;
   p.n_own = p.ct * ((B + TM - 1) / TM);
   const int rcs = adam_build_slice(sweep_h, p.sweep);
@@ -1693,6 +1698,7 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   p.loss_scale = loss_scale;
   p.relu0 = relu0; p.relu2 = relu2;
   p.B = B; p.N = N; p.RT = stat_rows(B);
+  p.inv_B = 1.0 / (double)B;
   p.n_own = (B + TM - 1) / TM;
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
