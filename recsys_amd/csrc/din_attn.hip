@@ -42,6 +42,36 @@ struct AttnFwdArgs {
   const int32_t* count;
 };
 
+// Stages a row-major global matrix src[R][C] (C a run-time count) into LDS -- as it is (dst[r * ld + c]) or transposed
+// (dst[c * ld + r]) -- with T threads: 8 unconditional loads in flight per thread and trip, the (row, column) of an element
+// advanced incrementally.  (The per-element loops this replaces divided by C and waited for one conditional load per trip:
+// 40 + 13 dependent round trips in the forward kernel's prologue, ~a quarter of the launch.)
+template <int T, bool TRANS>
+__device__ __forceinline__ void stage_matrix(float* __restrict__ dst, const float* __restrict__ src, const int R, const int C,
+                                             const int ld, const int tid) {
+  const int total = R * C;
+  if (total <= 0) return;
+  const int dc = T % C, dr = T / C;
+  int c = tid % C, r = tid / C;
+  for (int base = 0; base < total; base += 8 * T) {
+    float v[8];
+    int rr[8], cc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = base + j * T + tid;
+      v[j] = src[e < total ? e : total - 1];
+      rr[j] = r;
+      cc[j] = c;
+      c += dc;
+      r += dr;
+      if (c >= C) { c -= C; ++r; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (base + j * T + tid < total) dst[TRANS ? cc[j] * ld + rr[j] : rr[j] * ld + cc[j]] = v[j];
+  }
+}
+
 // KB = K/16, NT1 = ceil(N1/16), NT2 = ceil(N2/16).  grid = ceil(M/64), block = 256.
 // dyn LDS (floats): 16*NT1*(64*KB+4) + 16*NT2*(16*NT1+4) + 4*16*(16*NT1+4) + 16*NT1 + 2*16*NT2
 template <int KB, int NT1, int NT2>
@@ -57,16 +87,10 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   // weights: zero fill (padding rows / columns), then coalesced global reads scattered into the transposed layout
-  for (int e = tid; e < N1P * LD0 + N2P * LD1; e += 256) sW0[e] = 0.f;
+  for (int e = tid; e < (N1P * LD0 + N2P * LD1) / 4; e += 256) reinterpret_cast<float4*>(sW0)[e] = F4Z;
   __syncthreads();
-  for (int e = tid; e < K4 * p.N1; e += 256) {
-    const int k = e / p.N1, n = e - k * p.N1;
-    sW0[n * LD0 + k] = p.W0[e];
-  }
-  for (int e = tid; e < p.N1 * p.N2; e += 256) {
-    const int k = e / p.N2, n = e - k * p.N2;
-    sW1[n * LD1 + k] = p.W1[e];
-  }
+  stage_matrix<256, true>(sW0, p.W0, K4, p.N1, LD0, tid);       // sW0[n][k] = W0[k][n]
+  stage_matrix<256, true>(sW1, p.W1, p.N1, p.N2, LD1, tid);     // sW1[n2][n1] = W1[n1][n2]
   for (int e = tid; e < N1P; e += 256) sb0[e] = e < p.N1 ? p.b0[e] : 0.f;
   for (int e = tid; e < N2P; e += 256) {
     sb1[e] = e < p.N2 ? p.b1[e] : 0.f;
@@ -273,14 +297,10 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
   const int rt = wave & 3, hf = wave >> 2;
   const int i = lane & 15, kq = lane >> 4;
   const int nt0 = hf * NH1;                // this half's first g1 column tile
-  for (int e = tid; e < K4 * LD1; e += 512) {
-    const int k = e / LD1, n = e - k * LD1;
-    sW0[e] = n < p.N1 ? p.W0[(size_t)k * p.N1 + n] : 0.f;
-  }
-  for (int e = tid; e < N1P * LD2; e += 512) {
-    const int k = e / LD2, n = e - k * LD2;
-    sW1[e] = (k < p.N1 && n < p.N2) ? p.W1[(size_t)k * p.N2 + n] : 0.f;
-  }
+  for (int e = tid; e < (K4 * LD1 + N1P * LD2) / 4; e += 512) reinterpret_cast<float4*>(sW0)[e] = F4Z;   // (padding columns / rows)
+  __syncthreads();
+  stage_matrix<512, false>(sW0, p.W0, K4, p.N1, LD1, tid);      // W0 row-major
+  stage_matrix<512, false>(sW1, p.W1, p.N1, p.N2, LD2, tid);    // W1 row-major
   for (int e = tid; e < N2P; e += 512) sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
   const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
   const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
