@@ -72,27 +72,33 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ dst, const floa
   }
 }
 
-// KB = K/16, NT1 = ceil(N1/16), NT2 = ceil(N2/16).  grid = ceil(M/64), block = 256.
-// dyn LDS (floats): 16*NT1*(64*KB+4) + 16*NT2*(16*NT1+4) + 4*16*(16*NT1+4) + 16*NT1 + 2*16*NT2
+// KB = K/16, NT1 = ceil(N1/16), NT2 = ceil(N2/16).  grid = ceil(M / (16 FWD_WAVES)), block = 64 FWD_WAVES.
+// dyn LDS (floats): 16*NT1*(64*KB+4) + 16*NT2*(16*NT1+4) + FWD_WAVES*16*(16*NT1+4) + 16*NT1 + 2*16*NT2
+// 16 waves per workgroup (round 3; 4 before): the kernel issues about as many VALU cycles (operand construction, layer
+// transitions, dropout hash) as MFMA cycles per wave -- SQ counters: 9.6 k against 11.2 k of a 62 k-cycle wave life -- and
+// two workgroups of 4 waves per CU (LDS-limited: 58 KB of staged weights + 5.4 KB of transposition scratch per wave) left 2
+// waves per SIMD to overlap them; 16 waves share ONE copy of the weights (144 KB in all), so 4 waves per SIMD fit.
+constexpr int FWD_WAVES = 16;
 template <int KB, int NT1, int NT2>
-__global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
+__global__ __launch_bounds__(64 * FWD_WAVES) void din_attn_fwd_k(const AttnFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int K = 16 * KB, K4 = 4 * K, LD0 = K4 + 4, N1P = 16 * NT1, LD1 = N1P + 4, N2P = 16 * NT2;
   float* sW0 = lds;                       // [N1P][LD0]  W0 transposed: sW0[n][k]
   float* sW1 = sW0 + N1P * LD0;           // [N2P][LD1]  W1 transposed: sW1[n2][n1]
-  float* sS = sW1 + N2P * LD1;            // [4 waves][16][LD1]  a1 (after dropout) in row-major for the A layout
-  float* sb0 = sS + 4 * 16 * LD1;         // [N1P]
+  float* sS = sW1 + N2P * LD1;            // [FWD_WAVES][16][LD1]  a1 (after dropout) in row-major for the A layout
+  float* sb0 = sS + FWD_WAVES * 16 * LD1; // [N1P]
   float* sb1 = sb0 + N1P;                 // [N2P]
   float* sw2 = sb1 + N2P;                 // [N2P]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   // weights: zero fill (padding rows / columns), then coalesced global reads scattered into the transposed layout
-  for (int e = tid; e < (N1P * LD0 + N2P * LD1) / 4; e += 256) reinterpret_cast<float4*>(sW0)[e] = F4Z;
+  constexpr int FT = 64 * FWD_WAVES;
+  for (int e = tid; e < (N1P * LD0 + N2P * LD1) / 4; e += FT) reinterpret_cast<float4*>(sW0)[e] = F4Z;
   __syncthreads();
-  stage_matrix<256, true>(sW0, p.W0, K4, p.N1, LD0, tid);       // sW0[n][k] = W0[k][n]
-  stage_matrix<256, true>(sW1, p.W1, p.N1, p.N2, LD1, tid);     // sW1[n2][n1] = W1[n1][n2]
-  for (int e = tid; e < N1P; e += 256) sb0[e] = e < p.N1 ? p.b0[e] : 0.f;
-  for (int e = tid; e < N2P; e += 256) {
+  stage_matrix<FT, true>(sW0, p.W0, K4, p.N1, LD0, tid);        // sW0[n][k] = W0[k][n]
+  stage_matrix<FT, true>(sW1, p.W1, p.N1, p.N2, LD1, tid);      // sW1[n2][n1] = W1[n1][n2]
+  for (int e = tid; e < N1P; e += FT) sb0[e] = e < p.N1 ? p.b0[e] : 0.f;
+  for (int e = tid; e < N2P; e += FT) {
     sb1[e] = e < p.N2 ? p.b1[e] : 0.f;
     sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
   }
@@ -100,9 +106,9 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
   const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
   const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
   const int Mv = p.count ? p.count[0] : p.M;     // rows to evaluate (valid history positions, or all)
-  const int nblk = (Mv + 63) / 64;
+  const int nblk = (Mv + 16 * FWD_WAVES - 1) / (16 * FWD_WAVES);
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {    // persistent: the weights are staged once per workgroup
-  const int m0 = (blk * 4 + wv) * 16;            // position in the (possibly compacted) row list
+  const int m0 = (blk * FWD_WAVES + wv) * 16;    // position in the (possibly compacted) row list
   const bool mok = m0 + i < Mv;
   const int jc = mok ? m0 + i : 0;
   const int m = p.rows ? p.rows[jc] : jc;        // A-layout row of this lane (original row index)
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void din_attn_fwd_k(const AttnFwdArgs p) {
 
 static inline size_t attn_fwd_lds_floats(int KB, int NT1, int NT2) {
   const size_t LD0 = 64 * KB + 4, N1P = 16 * NT1, LD1 = N1P + 4, N2P = 16 * NT2;
-  return N1P * LD0 + N2P * LD1 + 4 * 16 * LD1 + N1P + 2 * N2P;
+  return N1P * LD0 + N2P * LD1 + FWD_WAVES * 16 * LD1 + N1P + 2 * N2P;
 }
 
 extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0, const float* b0, const float* W1,
@@ -218,8 +224,8 @@ extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0,
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;     // instantiated envelope (din/din.py:85)
   AttnFwdArgs p{H, q, W0, b0, W1, b1, W2, b2, a1, a2, w, mask1, mask2, rng_step, seed, (uint32_t)layer0, dropout_rate,
                 B * P, P, N1, N2, rows, count};
-  const int nblk = (p.M + 63) / 64;
-  const dim3 grid((unsigned)(nblk < 512 ? nblk : 512)), block(256);    // <= 2 workgroups per CU (80 KB of LDS each)
+  const int nblk = (p.M + 16 * FWD_WAVES - 1) / (16 * FWD_WAVES);
+  const dim3 grid((unsigned)(nblk < 256 ? nblk : 256)), block(64 * FWD_WAVES);    // one workgroup per CU (144 KB of LDS)
   if (K == 32) {
     const size_t lds = attn_fwd_lds_floats(2, 5, 3) * sizeof(float);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_k<2, 5, 3>),
