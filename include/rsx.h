@@ -86,6 +86,11 @@ size_t rsx_field_sort_large_workspace_ints(int B, int F, int stride);
 int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
                          int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace,
                          int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream);
+/* The same for keys that are already field-major: ids_t [F, stride] int32 (field f's B keys at ids_t + f * stride).  No
+ * transpose launch; ids_t is CLOBBERED (it ends up holding the sorted keys).                                            */
+int rsx_field_sort_large_t(int32_t* ids_t, const int32_t* row_off, int32_t* perm, int32_t* seg_off, int32_t* uniq_row,
+                           int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace, int max_rows_per_field, int B,
+                           int F, int stride, rsx_stream_t stream);
 /* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
 typedef struct {
   const int32_t* ids;
@@ -453,6 +458,13 @@ int rsx_din_keys(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist
 int rsx_din_prepare(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B, int P,
                     int dummy_item_row, int dummy_cate_row, int32_t* keys2, int32_t* rows_i, int32_t* count_i, float* w_i,
                     int32_t* rows_c, int32_t* count_c, float* w_c, rsx_stream_t stream);
+/* The same with two options: keys_field_stride > 0 -- the keys are written FIELD-MAJOR ([2, keys_field_stride]: item keys,
+ * then category keys), the layout rsx_field_sort_large_t takes without a transpose launch; labels_i64 / labels_f32 (both or
+ * neither): the model_fn's cast of the labels to float32 (din/din.py:146) done by the same launch.                       */
+int rsx_din_prepare2(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B, int P,
+                     int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride, int32_t* rows_i,
+                     int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c, const int64_t* labels_i64,
+                     float* labels_f32, rsx_stream_t stream);
 
 
 /* Fused attention MLP of `_attention` (din/din.py:111-121): for every history position m = (b, p)

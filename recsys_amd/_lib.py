@@ -96,6 +96,7 @@ _SIGS = {
     "rsx_gather_two_fwd": (_I, [_P] * 10 + [_U64, _I, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rsx_field_sort_large": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
+    "rsx_field_sort_large_t": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
     "rsx_field_sort_large_workspace_ints": (C.c_size_t, [_I, _I, _I]),
     "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P, _P, _P]),
     "rsx_segsum_partials": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P, _P]),
@@ -126,6 +127,7 @@ _SIGS = {
     "rsx_gather_rows_multi": (_I, [_P, _I, _P]),
     "rsx_din_keys": (_I, [_P] * 4 + [_I, _I, _I, _I, _P, _P]),
     "rsx_din_prepare": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P] * 8),
+    "rsx_din_prepare2": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P, _I] + [_P] * 6 + [_P, _P, _P]),
     "rsx_din_attn_bwd_ld": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P, _P]),

@@ -714,8 +714,11 @@ struct DinPrep {
   float* w[2];                // nullable: zeroed at the padded positions
   const int32_t* i_id;
   const int32_t* i_cate;
-  int32_t* keys2;             // [B + M, 2]
+  int32_t* keys2;             // [B + M, 2], or field-major [2, kt_stride] when kt_stride > 0
   int B, M, dummy[2];
+  int kt_stride;
+  const int64_t* labels_i64;  // nullable: labels_f32[e] = (float)labels_i64[e] (the model_fn's tf.cast, din/din.py:146)
+  float* labels_f32;
 };
 __global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
   __shared__ int wsum[4];
@@ -730,11 +733,25 @@ __global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
     c += v > 0 ? 1 : 0;
     if (h == 0 && e < p.M) {
       const int vc = p.hist[1][e];
-      reinterpret_cast<int2*>(p.keys2)[(size_t)p.B + e] = make_int2(v > 0 ? v : p.dummy[0], vc > 0 ? vc : p.dummy[1]);
+      const int k0 = v > 0 ? v : p.dummy[0], k1 = vc > 0 ? vc : p.dummy[1];
+      if (p.kt_stride > 0) {
+        p.keys2[(size_t)p.B + e] = k0;
+        p.keys2[(size_t)p.kt_stride + p.B + e] = k1;
+      } else {
+        reinterpret_cast<int2*>(p.keys2)[(size_t)p.B + e] = make_int2(k0, k1);
+      }
     }
   }
   if (h == 0 && blockIdx.x == 0)
-    for (int e = tid; e < p.B; e += 256) reinterpret_cast<int2*>(p.keys2)[e] = make_int2(p.i_id[e], p.i_cate[e]);
+    for (int e = tid; e < p.B; e += 256) {
+      if (p.kt_stride > 0) {
+        p.keys2[e] = p.i_id[e];
+        p.keys2[(size_t)p.kt_stride + e] = p.i_cate[e];
+      } else {
+        reinterpret_cast<int2*>(p.keys2)[e] = make_int2(p.i_id[e], p.i_cate[e]);
+      }
+      if (p.labels_i64 != nullptr) p.labels_f32[e] = (float)p.labels_i64[e];
+    }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
   if (lane == 0) wsum[wv] = c;
@@ -776,21 +793,31 @@ __global__ __launch_bounds__(256) void din_prep_rows_k(const DinPrep p) {
   if (blockIdx.x == gridDim.x - 1 && tid == 0) count[0] = base;
 }
 
-extern "C" int rsx_din_prepare(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
-                               int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int32_t* rows_i,
-                               int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
-                               rsx_stream_t stream) {
+extern "C" int rsx_din_prepare2(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
+                                int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride,
+                                int32_t* rows_i, int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
+                                const int64_t* labels_i64, float* labels_f32, rsx_stream_t stream) {
   if (B <= 0 || P <= 0) return (B == 0 && P > 0) ? RSX_OK : RSX_EINVAL;
   if (!i_id || !i_cate || !hist_i || !hist_c || !keys2 || !rows_i || !count_i || !rows_c || !count_c) return RSX_EINVAL;
+  if ((labels_i64 != nullptr) != (labels_f32 != nullptr)) return RSX_EINVAL;
   const long long M = (long long)B * P;
   if (M > (1ll << 24)) return RSX_EUNSUPPORTED;
+  if (keys_field_stride != 0 && keys_field_stride < B + M) return RSX_EINVAL;
   DinPrep p{{hist_i, hist_c}, {rows_i, rows_c}, {count_i, count_c}, {w_i, w_c}, i_id, i_cate, keys2, B, (int)M,
-            {dummy_item_row, dummy_cate_row}};
+            {dummy_item_row, dummy_cate_row}, keys_field_stride, labels_i64, labels_f32};
   const int nt = (int)((M + 1023) / 1024);
   hipLaunchKernelGGL(din_prep_counts_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
   hipLaunchKernelGGL(din_prep_rows_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_din_prepare(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
+                               int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int32_t* rows_i,
+                               int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
+                               rsx_stream_t stream) {
+  return rsx_din_prepare2(i_id, i_cate, hist_i, hist_c, B, P, dummy_item_row, dummy_cate_row, keys2, 0, rows_i, count_i, w_i,
+                          rows_c, count_c, w_c, nullptr, nullptr, stream);
 }
 
 extern "C" int rsx_din_valid_rows(const int32_t* ids, int B, int P, int32_t* rows, int32_t* count, float* w_zero_padded,

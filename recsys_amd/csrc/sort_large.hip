@@ -370,9 +370,10 @@ extern "C" size_t rsx_field_sort_large_workspace_ints(int B, int F, int stride) 
   return (size_t)3 * F * stride + (size_t)F * LS_BINS * nT + (size_t)F * nblk + (size_t)2 * F * LS_BINS;
 }
 
-extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
-                                    int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace,
-                                    int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream) {
+static int field_sort_large_impl(const int32_t* ids, int32_t* idsT_caller, const int32_t* row_off, int32_t* perm,
+                                 int32_t* seg_off, int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid,
+                                 int32_t* workspace, int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream) {
+  if (idsT_caller != nullptr) ids = idsT_caller;
   if (!ids || !row_off || !perm || !seg_off || !uniq_row || !nuniq || !slot || !workspace || B <= 0 || F <= 0 ||
       stride < B || max_rows_per_field <= 0)
     return RSX_EINVAL;
@@ -381,7 +382,9 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   LargeSort a;
   a.ids = ids; a.row_off = row_off; a.perm = perm;
   a.B = B; a.F = F; a.stride = stride; a.nT = (B + LS_TILE - 1) / LS_TILE;
-  a.idsT = workspace;
+  // keys already field-major ([F, stride], rsx_field_sort_large_t): the caller's buffer takes the place of the transposed
+  // copy -- no transpose launch -- and, like it, ends up holding the sorted keys
+  a.idsT = idsT_caller != nullptr ? idsT_caller : workspace;
   a.keyA = workspace + (size_t)F * stride;
   a.valA = workspace + (size_t)2 * F * stride;
   a.hist = workspace + (size_t)3 * F * stride;
@@ -389,7 +392,8 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   a.dtot = F >= 16 ? nullptr : a.hist + (size_t)F * LS_BINS * nT_cap + (size_t)F * (((size_t)stride + SG_BLK - 1) / SG_BLK);
   a.src0 = F == 1 ? ids : a.idsT;
   a.fuse_scan = a.dtot != nullptr && a.nT <= 64;
-  if (F > 1) hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
+  if (idsT_caller != nullptr) a.src0 = idsT_caller;
+  else if (F > 1) hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     hipLaunchKernelGGL(ls_hist_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
     if (a.fuse_scan) {}      // the scatter workgroups derive their offsets themselves
@@ -410,4 +414,19 @@ extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, 
   if (segid != nullptr) hipLaunchKernelGGL(ls_long_lists_k, dim3((B + 255) / 256, F), dim3(256), 0, st, g);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
+                                    int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace,
+                                    int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream) {
+  return field_sort_large_impl(ids, nullptr, row_off, perm, seg_off, uniq_row, nuniq, slot, segid, workspace,
+                               max_rows_per_field, B, F, stride, stream);
+}
+
+extern "C" int rsx_field_sort_large_t(int32_t* ids_t, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
+                                      int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace,
+                                      int max_rows_per_field, int B, int F, int stride, rsx_stream_t stream) {
+  if (!ids_t) return RSX_EINVAL;
+  return field_sort_large_impl(nullptr, ids_t, row_off, perm, seg_off, uniq_row, nuniq, slot, segid, workspace,
+                               max_rows_per_field, B, F, stride, stream);
 }

@@ -126,6 +126,8 @@ class DinFused:
         f32 = dict(device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.keys2 = torch.zeros(N, 2, **i32)
+        self.keys_t = torch.zeros(2, arena.stride, **i32)     # the same keys field-major (large sorts: no transpose launch)
+        self.labels_f = torch.zeros(B, **f32)
         self.X = torch.empty(B, 3 * K, **f32)                 # [q_item | pooled item history | pooled category history]
         self.qi, self.qc = torch.empty(B, K, **f32), torch.empty(B, K, **f32)
         self.ib = torch.empty(B, **f32)
@@ -176,11 +178,19 @@ class DinFused:
             # (sort keys of both tables + both histories' lists of non-padding positions: two launches)
             keys2 = self.keys2[:N]
             cnts = [self.rows[t][B * P:] for t in range(2)]
-            _lib.check(L.rsx_din_prepare(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item, self.n_cate,
-                                         _ptr(keys2), _ptr(self.rows[0]), _ptr(cnts[0]), _ptr(self.w[0]), _ptr(self.rows[1]),
-                                         _ptr(cnts[1]), _ptr(self.w[1]), st), "rsx_din_prepare")
+            big = N > a.LDS_SORT_MAX_B                  # the large sort takes field-major keys as they are
+            lab64 = labels.reshape(-1) if labels.dtype == torch.int64 and labels.is_contiguous() else None
+            _lib.check(L.rsx_din_prepare2(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item, self.n_cate,
+                                          _ptr(self.keys_t) if big else _ptr(keys2), a.stride if big else 0, _ptr(self.rows[0]),
+                                          _ptr(cnts[0]), _ptr(self.w[0]), _ptr(self.rows[1]), _ptr(cnts[1]), _ptr(self.w[1]),
+                                          _ptr(lab64), _ptr(self.labels_f) if lab64 is not None else None, st),
+                       "rsx_din_prepare2")
+            labels_f = self.labels_f[:B] if lab64 is not None else labels.reshape(-1).to(torch.float32)
             a.select(0)
-            a.field_sort(keys2)
+            if big:
+                a.field_sort_t(self.keys_t, N)
+            else:
+                a.field_sort(keys2)
             # The item bias (i_item, tf.gather by the target ids: :96,139) rides with the item table: its rows ARE item rows, so the
             # item field's dedup serves it; rows that only a history touches get a zero-gradient update from the same launch.
             cold = [a.adam_split_segments()[0][0],
@@ -210,7 +220,7 @@ class DinFused:
             mlp_mk = None if masks is None or "mlp" not in masks else \
                 [torch.nn.functional.pad(m, (0, w - m.shape[1]), value=1.0) for m, w in zip(masks["mlp"], tw.widths)]
             loss, prob, dX, gs0, _ = tw.train_step(
-                self.X[:B], labels.reshape(-1).to(torch.float32), rate, step, s0=self.ib[:B],
+                self.X[:B], labels_f, rate, step, s0=self.ib[:B],
                 head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=1, masks=mlp_mk, seed=0xD1AD,
                 outs=(None, self.gbias[:B], None))               # d loss / d bias lands in the scatter's first-order input
             # ---- backward of the two attention blocks, straight into the scatter's value block --------------------------

@@ -144,6 +144,17 @@ class EmbeddingArena:
         self.select(other.cur_buf)
 
     # -- kernels ---------------------------------------------------------------------------
+    def field_sort_t(self, ids_t, B):
+        """field_sort for keys that are already FIELD-MAJOR: ids_t int32 [F, stride] (field f's B keys in row f), large sorts
+        only (rsx_field_sort_large_t: no transpose launch); ids_t is clobbered."""
+        assert ids_t.dtype == torch.int32 and ids_t.is_contiguous() and tuple(ids_t.shape) == (self.F, self.stride)
+        assert self.LDS_SORT_MAX_B < B <= self.stride and getattr(self, "_sort_owner", None) is None
+        check(lib().rsx_field_sort_large_t(_ptr(ids_t), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
+                                           _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid),
+                                           _ptr(self.sort_ws), self.max_rows, B, self.F, self.stride, _stream()),
+              "rsx_field_sort_large_t")
+        self.last_B = B
+
     def field_sort(self, ids):
         B = ids.shape[0]
         assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and B <= self.stride

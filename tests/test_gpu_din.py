@@ -333,6 +333,48 @@ def test_din_prepare_keys_and_row_lists_are_exact(B, P):
         r = rows[t].cpu().numpy()
         assert r[M] == len(valid) and np.array_equal(r[:len(valid)], valid)
         assert np.array_equal(w[t].cpu().numpy().reshape(-1) == 0, h.reshape(-1) <= 0)
+    # rsx_din_prepare2: the same keys FIELD-MAJOR (what rsx_field_sort_large_t takes) + the labels' cast to float32
+    stride = N + 5
+    keys_t = torch.zeros(2, stride, dtype=torch.int32, device="cuda")
+    lab = torch.from_numpy(rng.integers(0, 2, B).astype(np.int64)).cuda()
+    lab_f = torch.full((B,), -1.0, device="cuda")
+    assert L.rsx_din_prepare2(p(d[0]), p(d[1]), p(d[2]), p(d[3]), B, P, 50, 9, p(keys_t), stride, p(rows[0]), p(rows[0][M:]),
+                              p(w[0]), p(rows[1]), p(rows[1][M:]), p(w[1]), p(lab), p(lab_f),
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(keys_t[:, :N].cpu().numpy(), want.T)
+    assert np.array_equal(lab_f.cpu().numpy(), lab.cpu().numpy().astype(np.float32))
+
+
+def test_large_sort_of_field_major_keys_equals_the_transposing_entry():
+    """rsx_field_sort_large_t (keys already [F, stride]: no transpose launch, the buffer is clobbered) against
+    rsx_field_sort_large on the same keys: every output of the dedup sort identical."""
+    from recsys_amd.ops import EmbeddingArena
+    rng = np.random.default_rng(3)
+    rows_per = (700, 90)
+    row_off = np.concatenate([[0], np.cumsum(rows_per)]).astype(np.int32)
+    N = 20000
+    outs = []
+    keys = np.stack([rng.integers(0, r, N) for r in rows_per], 1).astype(np.int32)
+    for transposed in (False, True):
+        a = EmbeddingArena(row_off, 32, N + 7, "cuda")
+        assert N > a.LDS_SORT_MAX_B
+        if transposed:
+            kt = torch.zeros(2, a.stride, dtype=torch.int32, device="cuda")
+            kt[:, :N] = torch.from_numpy(np.ascontiguousarray(keys.T)).cuda()
+            a.field_sort_t(kt, N)
+        else:
+            a.field_sort(torch.from_numpy(keys).cuda())
+        torch.cuda.synchronize()
+        nu = a.nuniq.cpu().numpy()
+        outs.append((nu, a.perm.view(2, -1)[:, :N].cpu().numpy(), a.seg_off.view(2, -1).cpu().numpy(),
+                     a.uniq_row.view(2, -1).cpu().numpy(), a.slot.cpu().numpy()))
+    nu = outs[0][0]
+    assert np.array_equal(nu, outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][4], outs[1][4])
+    for f in range(2):
+        assert np.array_equal(outs[0][2][f, :nu[f] + 1], outs[1][2][f, :nu[f] + 1])
+        assert np.array_equal(outs[0][3][f, :nu[f]], outs[1][3][f, :nu[f]])
 
 
 def test_din_eval_head_through_the_fused_tower_equals_the_torch_path():
