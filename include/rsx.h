@@ -432,6 +432,14 @@ int rsx_din_pool_fwd_ld(const float* H, const float* w, const int32_t* ids, floa
                         rsx_stream_t stream);
 int rsx_din_pool_bwd_ld(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH, float* dw,
                         int accumulate, int B, int P, int K, int ld_dout, int ld_dH, rsx_stream_t stream);
+/* Both histories of din.py (item ids, category ids) in ONE launch each way: the arguments of two rsx_din_pool_fwd_ld /
+ * rsx_din_pool_bwd_ld calls that share B, P, K and the leading dimensions.                                            */
+int rsx_din_pool_fwd_pair(const float* H0, const float* w0, const int32_t* ids0, float* out0, const float* H1,
+                          const float* w1, const int32_t* ids1, float* out1, int B, int P, int K, int ld_out,
+                          rsx_stream_t stream);
+int rsx_din_pool_bwd_pair(const float* H0, const float* w0, const int32_t* ids0, const float* dout0, float* dH0, float* dw0,
+                          const float* H1, const float* w1, const int32_t* ids1, const float* dout1, float* dH1, float* dw1,
+                          int accumulate, int B, int P, int K, int ld_dout, int ld_dH, rsx_stream_t stream);
 
 /* Several plain row gathers (tf.gather / tf.nn.embedding_lookup of one table each, din/din.py:96-105) in ONE launch:
  * out[e, 0:K] = table[row_base + ids[e], 0:K], e < n, `out` rows ld_out floats apart (K a multiple of 4, or K == 1: see

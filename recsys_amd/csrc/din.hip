@@ -7,9 +7,9 @@
 
 // out[b,:] = sum_p H[b,p,:] * w[b,p] * (ids[b,p] > 0).   One wave per example; LPR = K/4 lanes per row.
 template <int K>
-__global__ __launch_bounds__(256) void din_pool_fwd_k(const float* __restrict__ H, const float* __restrict__ w,
-                                                      const int32_t* __restrict__ ids, float* __restrict__ out, int B,
-                                                      int P, int ldo) {
+__device__ __forceinline__ void pool_fwd_wave(const float* __restrict__ H, const float* __restrict__ w,
+                                              const int32_t* __restrict__ ids, float* __restrict__ out, int B, int P,
+                                              int ldo) {
   constexpr int LPR = K / 4, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -37,13 +37,26 @@ __global__ __launch_bounds__(256) void din_pool_fwd_k(const float* __restrict__ 
   for (int m = LPR; m < 64; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
   if (j == 0) *reinterpret_cast<float4*>(out + (size_t)b * ldo + 4 * q) = acc;   // (ldo: row stride of `out`, floats)
 }
+template <int K>
+__global__ __launch_bounds__(256) void din_pool_fwd_k(const float* __restrict__ H, const float* __restrict__ w,
+                                                      const int32_t* __restrict__ ids, float* __restrict__ out, int B,
+                                                      int P, int ldo) {
+  pool_fwd_wave<K>(H, w, ids, out, B, P, ldo);
+}
+// both histories of din.py in one launch (grid.y = history): the two launches were 6.7 us each for 13 MB of traffic
+struct PoolFwdSet { const float* H; const float* w; const int32_t* ids; float* out; };
+template <int K>
+__global__ __launch_bounds__(256) void din_pool_fwd_pair_k(const PoolFwdSet s0, const PoolFwdSet s1, int B, int P, int ldo) {
+  if (blockIdx.y == 0) pool_fwd_wave<K>(s0.H, s0.w, s0.ids, s0.out, B, P, ldo);
+  else pool_fwd_wave<K>(s1.H, s1.w, s1.ids, s1.out, B, P, ldo);
+}
 
 // dH[b,p,:] (+)= dout[b,:] * w[b,p] * mask ;  dw[b,p] = <H[b,p,:], dout[b,:]> * mask.
 template <int K>
-__global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ H, const float* __restrict__ w,
-                                                      const int32_t* __restrict__ ids, const float* __restrict__ dout,
-                                                      float* __restrict__ dH, float* __restrict__ dw, int accumulate,
-                                                      int B, int P, int ldg, int ldh) {
+__device__ __forceinline__ void pool_bwd_wave(const float* __restrict__ H, const float* __restrict__ w,
+                                              const int32_t* __restrict__ ids, const float* __restrict__ dout,
+                                              float* __restrict__ dH, float* __restrict__ dw, int accumulate, int B, int P,
+                                              int ldg, int ldh) {
   constexpr int LPR = K / 4, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -80,6 +93,20 @@ __global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ 
       }
     }
   }
+}
+template <int K>
+__global__ __launch_bounds__(256) void din_pool_bwd_k(const float* __restrict__ H, const float* __restrict__ w,
+                                                      const int32_t* __restrict__ ids, const float* __restrict__ dout,
+                                                      float* __restrict__ dH, float* __restrict__ dw, int accumulate,
+                                                      int B, int P, int ldg, int ldh) {
+  pool_bwd_wave<K>(H, w, ids, dout, dH, dw, accumulate, B, P, ldg, ldh);
+}
+struct PoolBwdSet { const float* H; const float* w; const int32_t* ids; const float* dout; float* dH; float* dw; };
+template <int K>
+__global__ __launch_bounds__(256) void din_pool_bwd_pair_k(const PoolBwdSet s0, const PoolBwdSet s1, int accumulate, int B,
+                                                           int P, int ldg, int ldh) {
+  if (blockIdx.y == 0) pool_bwd_wave<K>(s0.H, s0.w, s0.ids, s0.dout, s0.dH, s0.dw, accumulate, B, P, ldg, ldh);
+  else pool_bwd_wave<K>(s1.H, s1.w, s1.ids, s1.dout, s1.dH, s1.dw, accumulate, B, P, ldg, ldh);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -220,6 +247,55 @@ extern "C" int rsx_din_pool_fwd_ld(const float* H, const float* w, const int32_t
 extern "C" int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K,
                                 rsx_stream_t stream) {
   return rsx_din_pool_fwd_ld(H, w, ids, out, B, P, K, K, stream);
+}
+
+template <int K>
+static void launch_pool_fwd_pair(hipStream_t st, const PoolFwdSet& a, const PoolFwdSet& b, int B, int P, int ldo) {
+  din_pool_fwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, B, P, ldo);
+}
+template <int K>
+static void launch_pool_bwd_pair(hipStream_t st, const PoolBwdSet& a, const PoolBwdSet& b, int acc, int B, int P, int ldg,
+                                 int ldh) {
+  din_pool_bwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, acc, B, P, ldg, ldh);
+}
+extern "C" int rsx_din_pool_fwd_pair(const float* H0, const float* w0, const int32_t* ids0, float* out0, const float* H1,
+                                     const float* w1, const int32_t* ids1, float* out1, int B, int P, int K, int ld_out,
+                                     rsx_stream_t stream) {
+  if (B < 0 || P <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!H0 || !w0 || !ids0 || !out0 || !H1 || !w1 || !ids1 || !out1 || ld_out < K || (ld_out & 3)) return RSX_EINVAL;
+  const PoolFwdSet a{H0, w0, ids0, out0}, b{H1, w1, ids1, out1};
+  switch (K) {
+    case 4: launch_pool_fwd_pair<4>(rsx_s(stream), a, b, B, P, ld_out); break;
+    case 8: launch_pool_fwd_pair<8>(rsx_s(stream), a, b, B, P, ld_out); break;
+    case 16: launch_pool_fwd_pair<16>(rsx_s(stream), a, b, B, P, ld_out); break;
+    case 32: launch_pool_fwd_pair<32>(rsx_s(stream), a, b, B, P, ld_out); break;
+    case 64: launch_pool_fwd_pair<64>(rsx_s(stream), a, b, B, P, ld_out); break;
+    default: return RSX_EUNSUPPORTED;
+  }
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+extern "C" int rsx_din_pool_bwd_pair(const float* H0, const float* w0, const int32_t* ids0, const float* dout0, float* dH0,
+                                     float* dw0, const float* H1, const float* w1, const int32_t* ids1, const float* dout1,
+                                     float* dH1, float* dw1, int accumulate, int B, int P, int K, int ld_dout, int ld_dH,
+                                     rsx_stream_t stream) {
+  if (B < 0 || P <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!H0 || !w0 || !ids0 || !dout0 || !dH0 || !dw0 || !H1 || !w1 || !ids1 || !dout1 || !dH1 || !dw1 || ld_dout < K ||
+      (ld_dout & 3) || ld_dH < K || (ld_dH & 3))
+    return RSX_EINVAL;
+  const PoolBwdSet a{H0, w0, ids0, dout0, dH0, dw0}, b{H1, w1, ids1, dout1, dH1, dw1};
+  switch (K) {
+    case 4: launch_pool_bwd_pair<4>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
+    case 8: launch_pool_bwd_pair<8>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
+    case 16: launch_pool_bwd_pair<16>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
+    case 32: launch_pool_bwd_pair<32>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
+    case 64: launch_pool_bwd_pair<64>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
+    default: return RSX_EUNSUPPORTED;
+  }
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
 }
 
 extern "C" int rsx_din_pool_bwd_ld(const float* H, const float* w, const int32_t* ids, const float* dout, float* dH,

@@ -212,10 +212,12 @@ class DinFused:
                 _lib.check(L.rsx_din_attn_fwd(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]), _ptr(self.a2[t]),
                                               _ptr(self.w[t]), _ptr(m1), _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, _ptr(rows),
                                               _ptr(cnt), B, P, K, n1, n2, st), "rsx_din_attn_fwd")
-                _lib.check(L.rsx_din_pool_fwd_ld(_ptr(self.H[t]), _ptr(self.w[t]), _ptr(hist[t]),
-                                                 C.c_void_p(self.X.data_ptr() + 4 * K * (t + 1)), B, P, K, 3 * K, st),
-                           "rsx_din_pool_fwd_ld")
                 att_m.append((m1, m2))
+            # masked weighted sums of both histories in one launch, written into their slices of the MLP input
+            _lib.check(L.rsx_din_pool_fwd_pair(_ptr(self.H[0]), _ptr(self.w[0]), _ptr(hist[0]),
+                                               C.c_void_p(self.X.data_ptr() + 4 * K), _ptr(self.H[1]), _ptr(self.w[1]),
+                                               _ptr(hist[1]), C.c_void_p(self.X.data_ptr() + 8 * K), B, P, K, 3 * K, st),
+                       "rsx_din_pool_fwd_pair")
             tw = store.tower
             mlp_mk = None if masks is None or "mlp" not in masks else \
                 [torch.nn.functional.pad(m, (0, w - m.shape[1]), value=1.0) for m, w in zip(masks["mlp"], tw.widths)]
@@ -226,6 +228,11 @@ class DinFused:
             # ---- backward of the two attention blocks, straight into the scatter's value block --------------------------
             vals = self.vals[:N]
             vbase = vals.data_ptr()
+            dHp = [C.c_void_p(vbase + 4 * (B * 2 * K + t * K)) for t in range(2)]        # rows B.. of column block t
+            doutp = [C.c_void_p(dX.data_ptr() + 4 * K * (t + 1)) for t in range(2)]       # d(pooled history t) = dX[:, (t+1)K : (t+2)K]
+            _lib.check(L.rsx_din_pool_bwd_pair(_ptr(self.H[0]), _ptr(self.w[0]), _ptr(hist[0]), doutp[0], dHp[0], _ptr(self.dw[0]),
+                                               _ptr(self.H[1]), _ptr(self.w[1]), _ptr(hist[1]), doutp[1], dHp[1], _ptr(self.dw[1]),
+                                               0, B, P, K, 3 * K, 2 * K, st), "rsx_din_pool_bwd_pair")
             for t, pre in enumerate(("att_i", "att_c")):
                 Ws = [P_[f"{pre}.W{i}"] for i in range(3)]
                 names = [f"{pre}.{v}{i}" for i in range(3) for v in ("W", "b")]
@@ -233,10 +240,7 @@ class DinFused:
                 assert gout is not None
                 m1, m2 = att_m[t]
                 rows, cnt = self.rows[t], self.rows[t][B * P:]
-                dH = C.c_void_p(vbase + 4 * (B * 2 * K + t * K))            # rows B.. of column block t
-                dout = C.c_void_p(dX.data_ptr() + 4 * K * (t + 1))           # d(pooled history t) = dX[:, (t+1)K : (t+2)K]
-                _lib.check(L.rsx_din_pool_bwd_ld(_ptr(self.H[t]), _ptr(self.w[t]), _ptr(hist[t]), dout, dH, _ptr(self.dw[t]), 0,
-                                                 B, P, K, 3 * K, 2 * K, st), "rsx_din_pool_bwd_ld")
+                dH = dHp[t]
                 dq = C.c_void_p(vbase + 4 * t * K)                           # rows 0 .. B-1 of column block t
                 _lib.check(L.rsx_din_attn_bwd_ld(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]),
                                                  _ptr(self.a2[t]), _ptr(self.dw[t]), dH, dq, _ptr(gout), _ptr(self.ws), _ptr(m1),
