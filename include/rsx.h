@@ -515,6 +515,19 @@ int rsx_din_attn_bwd_ld(const float* H, const float* q, const float* W0, const f
                         float dropout_rate, int accumulate_dH, const int32_t* rows, const int32_t* count, const int32_t* ids,
                         int B, int P, int K, int N1, int N2, int ld_dH, int ld_dq, const float* dq_add, int ld_dq_add,
                         rsx_stream_t stream);
+/* din.py runs two attention blocks per step (item ids, category ids): the backward launch alone, leaving its per-row query
+ * gradients and weight-gradient partials in `workspace` (rsx_din_attn_bwd_workspace_floats floats, ONE PER BLOCK) ...      */
+int rsx_din_attn_bwd_nofinish(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
+                              const float* a1, const float* a2, const float* dw, float* dH, float* workspace,
+                              const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
+                              float dropout_rate, int accumulate_dH, const int32_t* rows, const int32_t* count,
+                              const int32_t* ids, int B, int P, int K, int N1, int N2, int ld_dH, rsx_stream_t stream);
+/* ... and ONE launch that finishes both: grads_x (the packed [W0 | b0 | W1 | b1 | W2 | b2] gradient of block x) = the sum of its
+ * partials in workgroup order, dq_x[b, :] = dq_add_x[b, :] (nullable) + sum over p of the per-row query gradients (padded
+ * positions skipped through ids_x when the backward ran over a row list, else ids_x = NULL).                              */
+int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0, const float* dq_add0,
+                             const float* workspace1, float* grads1, float* dq1, const int32_t* ids1, const float* dq_add1,
+                             int B, int P, int K, int N1, int N2, int ld_dq, int ld_dq_add, rsx_stream_t stream);
 
 /* accumulate_dH != 0: dH += (rsx_din_pool_bwd has already written its share of the gradient of H into the same buffer).
  * rows / count / ids (nullable together): the forward's row list and the [B*P] ids it came from; only listed positions get

@@ -127,6 +127,8 @@ _SIGS = {
     "rsx_gather_rows_multi": (_I, [_P, _I, _P]),
     "rsx_din_keys": (_I, [_P] * 4 + [_I, _I, _I, _I, _P, _P]),
     "rsx_din_prepare": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P] * 8),
+    "rsx_din_attn_bwd_nofinish": (_I, [_P] * 13 + [C.c_uint32, _I, C.c_float, _I] + [_P] * 3 + [_I] * 6 + [_P]),
+    "rsx_din_attn_finish_pair": (_I, [_P] * 10 + [_I] * 7 + [_P]),
     "rsx_din_pool_fwd_pair": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "rsx_din_pool_bwd_pair": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, _P]),
     "rsx_din_prepare2": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P, _I] + [_P] * 6 + [_P, _P, _P]),

@@ -585,11 +585,11 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
 //     multiplied: they may hold anything).  dq rows ld_dq floats apart; add (nullable, rows ld_add apart): a second gradient of
 //     the same query added on the way out (din/din.py:131: the target item embedding also feeds the final MLP directly).
 // workgroups [0, nr) reduce 64 weight-gradient elements each, the rest take 4 examples each.
-__global__ __launch_bounds__(1024) void din_attn_finish_k(const float* __restrict__ part, int G, int n, float* __restrict__ grads,
-                                                          int nr, const float* __restrict__ dqr, float* __restrict__ dq, int B,
-                                                          int P, int K, const int32_t* __restrict__ valid, int ld_dq,
-                                                          const float* __restrict__ add, int ld_add) {
-  __shared__ float sub[16][64];
+__device__ __forceinline__ void attn_finish_block(float (*sub)[64], const float* __restrict__ part, int G, int n,
+                                                  float* __restrict__ grads, int nr, const float* __restrict__ dqr,
+                                                  float* __restrict__ dq, int B, int P, int K,
+                                                  const int32_t* __restrict__ valid, int ld_dq, const float* __restrict__ add,
+                                                  int ld_add) {
   if ((int)blockIdx.x < nr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
@@ -648,6 +648,21 @@ __global__ __launch_bounds__(1024) void din_attn_finish_k(const float* __restric
     if (add != nullptr) t = add[(size_t)b * ld_add + c] + t;
     dq[(size_t)b * ld_dq + c] = t;
   }
+}
+__global__ __launch_bounds__(1024) void din_attn_finish_k(const float* __restrict__ part, int G, int n, float* __restrict__ grads,
+                                                          int nr, const float* __restrict__ dqr, float* __restrict__ dq, int B,
+                                                          int P, int K, const int32_t* __restrict__ valid, int ld_dq,
+                                                          const float* __restrict__ add, int ld_add) {
+  __shared__ float sub[16][64];
+  attn_finish_block(sub, part, G, n, grads, nr, dqr, dq, B, P, K, valid, ld_dq, add, ld_add);
+}
+// the finish of BOTH attention blocks of din.py in one launch (grid.y = block)
+struct AttnFinishSet { const float* part; float* grads; const float* dqr; float* dq; const int32_t* valid; const float* add; };
+__global__ __launch_bounds__(1024) void din_attn_finish_pair_k(const AttnFinishSet s0, const AttnFinishSet s1, int G, int n, int nr,
+                                                               int B, int P, int K, int ld_dq, int ld_add) {
+  __shared__ float sub[16][64];
+  if (blockIdx.y == 0) attn_finish_block(sub, s0.part, G, n, s0.grads, nr, s0.dqr, s0.dq, B, P, K, s0.valid, ld_dq, s0.add, ld_add);
+  else attn_finish_block(sub, s1.part, G, n, s1.grads, nr, s1.dqr, s1.dq, B, P, K, s1.valid, ld_dq, s1.add, ld_add);
 }
 
 // ---- row list of the history positions that are not padding (id > 0), din/din.py:118-124 -------------------------------
@@ -870,12 +885,12 @@ extern "C" int rsx_din_attn_bwd(const float* H, const float* q, const float* W0,
                              dropout_rate, accumulate_dH, rows, count, ids, B, P, K, N1, N2, K, K, nullptr, 0, stream);
 }
 
-extern "C" int rsx_din_attn_bwd_ld(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
-                                   const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
-                                   float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
-                                   uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, const int32_t* rows,
-                                   const int32_t* count, const int32_t* ids, int B, int P, int K, int N1, int N2, int ld_dH,
-                                   int ld_dq, const float* dq_add, int ld_dq_add, rsx_stream_t stream) {
+static int attn_bwd_impl(const float* H, const float* q, const float* W0, const float* W1, const float* W2, const float* a1,
+                         const float* a2, const float* dw, float* dH, float* dq, float* grads, float* workspace,
+                         const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed, int layer0,
+                         float dropout_rate, int accumulate_dH, const int32_t* rows, const int32_t* count, const int32_t* ids,
+                         int B, int P, int K, int N1, int N2, int ld_dH, int ld_dq, const float* dq_add, int ld_dq_add,
+                         bool finish, rsx_stream_t stream) {
   if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!H || !q || !W0 || !W1 || !W2 || !a1 || !a2 || !dw || !dH || !dq || !grads || !workspace) return RSX_EINVAL;
@@ -890,10 +905,54 @@ extern "C" int rsx_din_attn_bwd_ld(const float* H, const float* q, const float* 
   const int rc = K == 32 ? launch_attn_bwd<2, 5, 3>(p, G, st) : launch_attn_bwd<1, 5, 3>(p, G, st);
   if (rc != RSX_OK) return rc;
   RSX_CHECK_LAUNCH();
+  if (!finish) return RSX_OK;
   const int n = (int)attn_npart(K, N1, N2);
   const int nr = (n + 63) / 64;
   hipLaunchKernelGGL(din_attn_finish_k, dim3(nr + (B + 3) / 4), dim3(1024), 0, st, p.part, G, n, grads, nr, p.dqr, dq, B, P, K,
                      rows ? ids : nullptr, ld_dq, dq_add, ld_dq_add);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_din_attn_bwd_ld(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
+                                   const float* a1, const float* a2, const float* dw, float* dH, float* dq, float* grads,
+                                   float* workspace, const float* mask1, const float* mask2, const uint32_t* rng_step,
+                                   uint32_t seed, int layer0, float dropout_rate, int accumulate_dH, const int32_t* rows,
+                                   const int32_t* count, const int32_t* ids, int B, int P, int K, int N1, int N2, int ld_dH,
+                                   int ld_dq, const float* dq_add, int ld_dq_add, rsx_stream_t stream) {
+  return attn_bwd_impl(H, q, W0, W1, W2, a1, a2, dw, dH, dq, grads, workspace, mask1, mask2, rng_step, seed, layer0, dropout_rate,
+                       accumulate_dH, rows, count, ids, B, P, K, N1, N2, ld_dH, ld_dq, dq_add, ld_dq_add, true, stream);
+}
+
+// The backward launch alone: the weight-gradient partials and the per-row query gradients stay in `workspace` until
+// rsx_din_attn_finish_pair reduces them (din.py has two attention blocks per step: one finish launch instead of two).
+extern "C" int rsx_din_attn_bwd_nofinish(const float* H, const float* q, const float* W0, const float* W1, const float* W2,
+                                         const float* a1, const float* a2, const float* dw, float* dH, float* workspace,
+                                         const float* mask1, const float* mask2, const uint32_t* rng_step, uint32_t seed,
+                                         int layer0, float dropout_rate, int accumulate_dH, const int32_t* rows,
+                                         const int32_t* count, const int32_t* ids, int B, int P, int K, int N1, int N2, int ld_dH,
+                                         rsx_stream_t stream) {
+  // (dq / grads are written by the finish: any non-null pointers pass the argument check)
+  return attn_bwd_impl(H, q, W0, W1, W2, a1, a2, dw, dH, workspace, workspace, workspace, mask1, mask2, rng_step, seed, layer0,
+                       dropout_rate, accumulate_dH, rows, count, ids, B, P, K, N1, N2, ld_dH, K, nullptr, 0, false, stream);
+}
+
+extern "C" int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0,
+                                        const float* dq_add0, const float* workspace1, float* grads1, float* dq1,
+                                        const int32_t* ids1, const float* dq_add1, int B, int P, int K, int N1, int N2, int ld_dq,
+                                        int ld_dq_add, rsx_stream_t stream) {
+  if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!workspace0 || !grads0 || !dq0 || !workspace1 || !grads1 || !dq1 || ld_dq < K) return RSX_EINVAL;
+  if ((dq_add0 != nullptr || dq_add1 != nullptr) && ld_dq_add < K) return RSX_EINVAL;
+  const int M = B * P, G = attn_bwd_groups(M);
+  const int n = (int)attn_npart(K, N1, N2);
+  const int nr = (n + 63) / 64;
+  // workspace layout of the backward launch: [M, K] per-row query gradients, then the G partials
+  const AttnFinishSet s0{workspace0 + (size_t)M * K, grads0, workspace0, dq0, ids0, dq_add0};
+  const AttnFinishSet s1{workspace1 + (size_t)M * K, grads1, workspace1, dq1, ids1, dq_add1};
+  hipLaunchKernelGGL(din_attn_finish_pair_k, dim3(nr + (B + 3) / 4, 2), dim3(1024), 0, rsx_s(stream), s0, s1, G, n, nr, B, P, K,
+                     ld_dq, ld_dq_add);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -140,7 +140,7 @@ class DinFused:
         self.w = [torch.empty(B, P, **f32) for _ in range(2)]
         self.dw = [torch.empty(B, P, **f32) for _ in range(2)]
         self.rows = [torch.empty(B * P + 2 + (B * P + 1023) // 1024, **i32) for _ in range(2)]
-        self.ws = torch.empty(int(_lib.lib().rsx_din_attn_bwd_workspace_floats(B, P, K, n1, n2)), **f32)
+        self.ws = [torch.empty(int(_lib.lib().rsx_din_attn_bwd_workspace_floats(B, P, K, n1, n2)), **f32) for _ in range(2)]
         # padding rows of the two-field arena: the last row of every field (include/rsx.h RSX_NULL_LAST_ROW)
         arena.null_last = True
         arena._bind_partials()
@@ -233,20 +233,24 @@ class DinFused:
             _lib.check(L.rsx_din_pool_bwd_pair(_ptr(self.H[0]), _ptr(self.w[0]), _ptr(hist[0]), doutp[0], dHp[0], _ptr(self.dw[0]),
                                                _ptr(self.H[1]), _ptr(self.w[1]), _ptr(hist[1]), doutp[1], dHp[1], _ptr(self.dw[1]),
                                                0, B, P, K, 3 * K, 2 * K, st), "rsx_din_pool_bwd_pair")
+            gouts = []
             for t, pre in enumerate(("att_i", "att_c")):
                 Ws = [P_[f"{pre}.W{i}"] for i in range(3)]
                 names = [f"{pre}.{v}{i}" for i in range(3) for v in ("W", "b")]
                 gout = P_.packed_grad(names)
                 assert gout is not None
+                gouts.append(gout)
                 m1, m2 = att_m[t]
                 rows, cnt = self.rows[t], self.rows[t][B * P:]
-                dH = dHp[t]
-                dq = C.c_void_p(vbase + 4 * t * K)                           # rows 0 .. B-1 of column block t
-                _lib.check(L.rsx_din_attn_bwd_ld(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]),
-                                                 _ptr(self.a2[t]), _ptr(self.dw[t]), dH, dq, _ptr(gout), _ptr(self.ws), _ptr(m1),
-                                                 _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, 1, _ptr(rows), _ptr(cnt),
-                                                 _ptr(hist[t]), B, P, K, n1, n2, 2 * K, 2 * K,
-                                                 _ptr(dX) if t == 0 else None, 3 * K, st), "rsx_din_attn_bwd_ld")
+                _lib.check(L.rsx_din_attn_bwd_nofinish(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]),
+                                                       _ptr(self.a2[t]), _ptr(self.dw[t]), dHp[t], _ptr(self.ws[t]), _ptr(m1),
+                                                       _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, 1, _ptr(rows), _ptr(cnt),
+                                                       _ptr(hist[t]), B, P, K, n1, n2, 2 * K, st), "rsx_din_attn_bwd_nofinish")
+            # weight gradients + the target rows' gradients (dq, plus the MLP input slice for the item block) of both blocks
+            dqp = [C.c_void_p(vbase + 4 * t * K) for t in range(2)]         # rows 0 .. B-1 of column block t
+            _lib.check(L.rsx_din_attn_finish_pair(_ptr(self.ws[0]), _ptr(gouts[0]), dqp[0], _ptr(hist[0]), _ptr(dX),
+                                                  _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,
+                                                  B, P, K, n1, n2, 2 * K, 3 * K, st), "rsx_din_attn_finish_pair")
 
         def train_op():                                                    # AdamOptimizer.minimize (:172-173)
             with torch.no_grad():
