@@ -98,8 +98,11 @@ struct CbFwdArgs {
 // Xk of the two examples is read ONCE per workgroup (coalesced float4), rounded to bf16 and transposed through LDS to
 // [d][h], so that every wave builds its A fragments with ds_read_b128.
 // LDS: 2*F*16 (X0 of the two examples) + 4*2*256 (partials) floats + 2*16*(Hp+8) bf16.
-template <int KS>
-__global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
+// E examples per workgroup: every 1-KiB W fragment a wave loads feeds E MFMAs.  E = 4 (RSX_CIN_FWD16_EX=4) halves the
+// fragment traffic per MFMA and measured the same as 2 (xdeepfm.py --cin_bf16 0.1780 / 0.1774 ms against 0.1782 / 0.1772):
+// the launch is not bound by the CU's vector-memory path; the default stays 2.
+template <int KS, int E>
+__global__ __launch_bounds__(256, E == 4 ? 3 : 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const RiderSplit rs = rider_split(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * (uint32_t)p.nby, p.sweep.n_blk);
   if (rs.rider) {
@@ -109,18 +112,18 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   const int tile_x = (int)(rs.idx % gridDim.x), tile_y = (int)(rs.idx / gridDim.x);
   constexpr int FG = KS >= 4 ? 1 : 2;            // fields per load group (register budget: 128 per lane, 4 waves per SIMD)
   constexpr int HPP = 32 * KS + 8;               // padded h-stride of the transposed Xk tile (conflict-free b128 reads)
-  float* sX0 = lds;                              // [2][F*16]
-  float* sR = lds + 2 * p.F * CB_D;              // [4 waves][2 examples][4][64]
-  bf16_t* sXk = reinterpret_cast<bf16_t*>(sR + 4 * 2 * 256);     // [2][16][HPP]
+  float* sX0 = lds;                              // [E][F*16]
+  float* sR = lds + E * p.F * CB_D;              // [4 waves][E examples][4][64]
+  bf16_t* sXk = reinterpret_cast<bf16_t*>(sR + 4 * E * 256);     // [E][16][HPP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int n0 = tile_x * 16;
-  const int b0 = tile_y * 2;
-  for (int e = tid; e < 2 * p.F * 4; e += 256) {
+  const int b0 = tile_y * E;
+  for (int e = tid; e < E * p.F * 4; e += 256) {
     const int ex = e / (p.F * 4), r = e - ex * (p.F * 4);
     reinterpret_cast<float4*>(sX0)[e] = b0 + ex < p.B ? reinterpret_cast<const float4*>(p.X0 + (size_t)(b0 + ex) * p.F * CB_D)[r] : F4Z;
   }
-  for (int e4 = tid; e4 < 2 * 32 * KS * 4; e4 += 256) {          // (example, h, d-quarter): float4 in, 4 bf16 out (h >= H: zero)
+  for (int e4 = tid; e4 < E * 32 * KS * 4; e4 += 256) {          // (example, h, d-quarter): float4 in, 4 bf16 out (h >= H: zero)
     const int ex = e4 / (32 * KS * 4), r = e4 - ex * (32 * KS * 4);
     const int h = r >> 2, dq = r & 3;
     const float4 v = (b0 + ex < p.B && h < p.H) ? reinterpret_cast<const float4*>(p.Xk + ((size_t)(b0 + ex) * p.H + h) * CB_D)[dq] : F4Z;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   }
   // A operand: Xk[b][h = 32 ks + 8 kq + j][d = i], the same for every field -> registers for the whole kernel (filled
   // from the LDS tile after the barrier below)
-  bf16x8 a[2][KS];
+  bf16x8 a[E][KS];
   const bf16_t* wbase = p.Wt16 + ((size_t)tile_x * KS * 64 + lane) * 8;
   const size_t fstride = (size_t)p.N16 * p.Hp;
   bf16x8 wa[FG][KS], wb[FG][KS];
@@ -145,14 +148,16 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
       for (int ks = 0; ks < KS; ++ks) w[g][ks] = ld_bf16x8(wbase + (size_t)f * fstride + (size_t)ks * 512);
     }
   };
-  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto run_group = [&](int g0, bf16x8 (*w)[KS]) {
 #pragma unroll
     for (int g = 0; g < FG; ++g) {
       const int f = wv + 4 * (g0 + g);
       if (f < p.F) {                              // wave-uniform
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < E; ++e) {
           f32x4 T = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) T = mfma_bf16(a[e][ks], w[g][ks], T);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
   load_group(0, wa);
   __syncthreads();                                // X0 and Xk staged
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
+  for (int e = 0; e < E; ++e)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[e][ks] = ld_bf16x8(sXk + ((size_t)e * 16 + i) * HPP + 32 * ks + 8 * kq);
   for (int g0 = 0; g0 < ng * FG; g0 += 2 * FG) {
@@ -179,19 +184,20 @@ __global__ __launch_bounds__(256, 4) void cin_fwd_bf16_k(const CbFwdArgs p) {
     run_group(g0 + FG, wb);
   }
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
+  for (int e = 0; e < E; ++e)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = acc[e][r];
+    for (int r = 0; r < 4; ++r) sR[((wv * E + e) * 4 + r) * 64 + lane] = acc[e][r];
   __syncthreads();
-  if (wv < 2) {                                   // wave e finishes example e: partials in wave (= field residue) order
+  static_assert(E <= 4, "one finishing wave per example");
+  if (wv < E) {                                   // wave e finishes example e: partials in wave (= field residue) order
     const int e = wv, b = b0 + e;
     const bool nok = n0 + i < p.N;
     const float cv = p.c[nok ? n0 + i : 0];
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float s = ((sR[((0 * 2 + e) * 4 + r) * 64 + lane] + sR[((1 * 2 + e) * 4 + r) * 64 + lane]) +
-                       sR[((2 * 2 + e) * 4 + r) * 64 + lane]) + sR[((3 * 2 + e) * 4 + r) * 64 + lane];
+      const float s = ((sR[((0 * E + e) * 4 + r) * 64 + lane] + sR[((1 * E + e) * 4 + r) * 64 + lane]) +
+                       sR[((2 * E + e) * 4 + r) * 64 + lane]) + sR[((3 * E + e) * 4 + r) * 64 + lane];
       o[r] = fmaxf(s + cv, 0.f);
     }
     if (nok && b < p.B)
@@ -650,20 +656,26 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
   if (D != CB_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int H16 = rup(H, 16), N16 = rup(N, 16), Hp = rup(H, 32), Np = rup(N, 32);
   const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)F * H16 * Np;
-  CbFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, (B + 1) / 2, {}};
+  static const int ex_env = getenv("RSX_CIN_FWD16_EX") ? atoi(getenv("RSX_CIN_FWD16_EX")) : 2;     // examples per workgroup
+  const int E = ex_env == 4 ? 4 : 2;
+  CbFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, (B + E - 1) / E, {}};
   const int rcs = adam_build_slice(sweep_h, a.sweep);
   if (rcs != RSX_OK) return rcs;
   const unsigned gx = (unsigned)(N16 / 16);
   const unsigned extra = (a.sweep.n_blk + gx - 1) / gx;
   const dim3 grid(gx, (unsigned)a.nby + extra);
-  const size_t lds = ((size_t)2 * F * CB_D + 4 * 2 * 256) * sizeof(float) + (size_t)2 * 16 * (Hp + 8) * 2;
+  const size_t lds = ((size_t)E * F * CB_D + 4 * E * 256) * sizeof(float) + (size_t)E * 16 * (Hp + 8) * 2;
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
+#define RSX_CIN_FWD16(KS)                                                                                    \
+  if (E == 2) hipLaunchKernelGGL((cin_fwd_bf16_k<KS, 2>), grid, dim3(256), lds, rsx_s(stream), a);          \
+  else hipLaunchKernelGGL((cin_fwd_bf16_k<KS, 4>), grid, dim3(256), lds, rsx_s(stream), a)
   switch (Hp / 32) {
-    case 1: hipLaunchKernelGGL(cin_fwd_bf16_k<1>, grid, dim3(256), lds, rsx_s(stream), a); break;
-    case 2: hipLaunchKernelGGL(cin_fwd_bf16_k<2>, grid, dim3(256), lds, rsx_s(stream), a); break;
-    case 3: hipLaunchKernelGGL(cin_fwd_bf16_k<3>, grid, dim3(256), lds, rsx_s(stream), a); break;
-    default: hipLaunchKernelGGL(cin_fwd_bf16_k<4>, grid, dim3(256), lds, rsx_s(stream), a); break;
+    case 1: RSX_CIN_FWD16(1); break;
+    case 2: RSX_CIN_FWD16(2); break;
+    case 3: RSX_CIN_FWD16(3); break;
+    default: RSX_CIN_FWD16(4); break;
   }
+#undef RSX_CIN_FWD16
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
