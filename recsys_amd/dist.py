@@ -68,7 +68,11 @@ class SegmentedGraph:
 
     def _begin(self):
         self._graph = torch.cuda.CUDAGraph()
-        self._ctx = torch.cuda.graph(self._graph, pool=self._pool)
+        # capture_error_mode "thread_local": ProcessGroupNCCL's watchdog thread polls the events of collectives that are still
+        # in flight (hipEventQuery) -- legal while THIS thread captures only in that mode.  With the default ("global") an
+        # asynchronous all-reduce left pending across a segment boundary (RSX_DP_OVERLAP) aborted the process from the
+        # watchdog: "operation not permitted when stream is capturing".
+        self._ctx = torch.cuda.graph(self._graph, pool=self._pool, capture_error_mode="thread_local")
         self._ctx.__enter__()
 
     def _end(self):
