@@ -1298,6 +1298,11 @@ __device__ __forceinline__ void window_pass(const HotAdam& h, const uint32_t wb,
     const float alpha_now = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
     // the step size of window step st (uniform): state[8 + st] for st < cur, this step's own for st == cur.  (Read in
     // place: a register array of them indexed by the loop counter goes to scratch memory on this toolchain.)
+    // ORDER DEPENDENCE: words 8 + j are written by the window's sweep (adam_window_k, rsx_adam_slice_run with slot_w) and by
+    // every step's own launch (word 8 + cur, end of this kernel); a window pass therefore needs the sweep of ITS window to
+    // have run at position 0 -- the only order the host issues (deepfm._train_fused: window_sweep before the first step).
+    // Without it the words hold the previous window's values or zeros: the step sizes of steps < cur would be WRONG, not
+    // merely slow, so rsx_segsum_adam_rows2 documents the sweep as a precondition of window != NULL (include/rsx.h).
     auto alpha_of = [&](const int st) -> float { return st == cur ? alpha_now : h.state[8 + st]; };
     float amin = alpha_now, amax = alpha_now;
 #pragma unroll

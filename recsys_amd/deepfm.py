@@ -273,13 +273,15 @@ def define_flags(p=None):
     return p
 
 
-def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None, shard=None):
+def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None, shard=None,
+             shard_tail=False):
     if layout is not None and layout.columns[0].key in ("i_id", "u_id"):     # --feature_set uid_iid (the script as committed)
         from .input_pipeline import uid_iid_input_fn
         assert shard is None or shard[1] == 1, "--feature_set uid_iid: single replica only"
         return uid_iid_input_fn(filenames, batch_size, num_epochs, need_shuffle, layout)
     from .input_pipeline import criteo_input_fn
-    return criteo_input_fn(filenames, batch_size, num_epochs, need_shuffle, num_parallel, layout, shard=shard)
+    return criteo_input_fn(filenames, batch_size, num_epochs, need_shuffle, num_parallel, layout, shard=shard,
+                           shard_tail=shard_tail)
 
 
 def make_params(FLAGS, linear="indicator_all"):
@@ -317,10 +319,10 @@ def run_main(model_fn, FLAGS, make_params_fn):
     layout = CriteoLayout.from_columns(params["embedding_feature_columns"])
     if FLAGS.task_type == "train":
         tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.num_parallel, layout, shard))
-        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout, shard), steps=200)
+        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout, shard, True), steps=200)
         return train_and_evaluate(est, tr, ev)
     if FLAGS.task_type == "eval":
-        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout, shard), steps=200)
+        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout, shard, True), steps=200)
     if FLAGS.task_type == "infer":
         out = []
         for i, p in enumerate(est.predict(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.num_parallel, layout))):

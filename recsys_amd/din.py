@@ -51,7 +51,10 @@ def build_variables(store, params, B, P):
     dev = store.device
     row_off = [0, n_item + 1, n_item + 1 + n_cate + 1]
     arena = EmbeddingArena(row_off, K, cap, dev, with_w1=True, w1_field_mask=1)    # (first-order path = the item bias, field 0)
-    barena = EmbeddingArena([0, n_item], 4, B * world, dev, with_w1=False)
+    # The bias rides through the item field's scatter as its "first-order vector" and is therefore indexed by GLOBAL rows of the
+    # two-field arena (the item field's dummy row n_item is written by its row owner, the category field's rows are prefetched):
+    # it is allocated over the arena's whole row space; the variable i_item [n_item] is the leading slice.
+    barena = EmbeddingArena([0, arena.R], 4, B * world, dev, with_w1=False)
     with torch.no_grad():
         arena.tables.zero_()
         barena.tables.zero_()
@@ -225,6 +228,11 @@ class DinFused:
                 self.X[:B], labels_f, rate, step, s0=self.ib[:B],
                 head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=1, masks=mlp_mk, seed=0xD1AD,
                 outs=(None, self.gbias[:B], None))               # d loss / d bias lands in the scatter's first-order input
+            if B < self.cap_B:
+                # a batch smaller than an earlier one (the final partial batch of an epoch): entries B.. are HISTORY entries now,
+                # whose bias gradient is zero -- not what a larger batch's head left there.  Unconditional for this batch size,
+                # so that a captured graph of the step carries it.
+                self.gbias[B:self.cap_B].zero_()
             # ---- backward of the two attention blocks, straight into the scatter's value block --------------------------
             vals = self.vals[:N]
             vbase = vals.data_ptr()
@@ -412,9 +420,10 @@ def define_flags():
     return p
 
 
-def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, hist_len=100, shard=None):
+def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, hist_len=100, shard=None, shard_tail=False):
     from .input_pipeline import din_input_fn
-    return din_input_fn(filenames, batch_size, num_epochs, need_shuffle, hist_len=hist_len, ids_int32=True, shard=shard)
+    return din_input_fn(filenames, batch_size, num_epochs, need_shuffle, hist_len=hist_len, ids_int32=True, shard=shard,
+                        shard_tail=shard_tail)
 
 
 def main(argv=None):
@@ -433,10 +442,10 @@ def main(argv=None):
             shard = (dp.rank, dp.world)
     if FLAGS.task_type == "train":
         tr = TrainSpec(lambda: input_fn(train_files, FLAGS.batch_size, FLAGS.num_epochs, True, FLAGS.hist_len, shard))
-        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len, shard), steps=FLAGS.eval_steps)
+        ev = EvalSpec(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len, shard, True), steps=FLAGS.eval_steps)
         return train_and_evaluate(est, tr, ev)
     if FLAGS.task_type == "eval":
-        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len, shard), steps=FLAGS.eval_steps)
+        return est.evaluate(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len, shard, True), steps=FLAGS.eval_steps)
     return list(zip(range(10), est.predict(lambda: input_fn(eval_files, FLAGS.batch_size, 1, False, FLAGS.hist_len))))
 
 

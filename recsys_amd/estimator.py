@@ -660,6 +660,7 @@ class Estimator:
         return st["losses"][-1]
 
     def train(self, input_fn, steps=None, max_steps=None):
+        self._check_consistent("train")       # (a poisoned store must be restored from a checkpoint, not trained on)
         it = iter(input_fn())
         if self._use_graph() and os.environ.get("RSX_INPUT_THREAD", "0") != "0":      # (measured: no gain next to the launch thread)
             depth = max(16, 2 * self._window_len())
@@ -847,6 +848,7 @@ class Estimator:
             self.store.dp.barrier()
 
     def predict(self, input_fn):
+        self._check_consistent("predict")
         it = input_fn()
         try:
             with torch.no_grad():
@@ -866,6 +868,7 @@ class Estimator:
         parse_fn(list[bytes]) -> (features, labels); default: the Criteo parse spec of the params' embedding columns, or
         the DIN spec (din/din.py:44-57) when the params hold no feature columns."""
         from . import input_pipeline as ip
+        self._check_consistent("predict_examples")
         if parse_fn is None:
             cols = self.params.get("embedding_feature_columns")
             if cols is not None:

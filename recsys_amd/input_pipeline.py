@@ -230,21 +230,21 @@ RSX_SHARD_TAIL = 2      # include/rsx.h: value of drop_remainder
 
 
 def _shard_tail(shard_tail, num_epochs, need_shuffle):
-    """Sharded EVALUATION (one pass, no shuffle: how run_main builds its eval / predict input_fn) has no collective inside
-    its loop, so the ranks need not run equal step counts: deliver the leftover batches of the last round and the final
-    partial batch too (csrc/tfrecord_reader.cpp RSX_SHARD_TAIL) -- together the ranks then evaluate exactly the examples
-    a single replica would.  TRAIN keeps complete rounds only."""
-    if shard_tail is None:
-        shard_tail = int(num_epochs) == 1 and not need_shuffle
+    """Sharded EVALUATION has no collective inside its loop, so the ranks need not run equal step counts: with shard_tail=True
+    (what run_main's eval input_fns pass) the leftover batches of the last round and the final partial batch are delivered
+    too (csrc/tfrecord_reader.cpp RSX_SHARD_TAIL) -- together the ranks then evaluate exactly the examples a single replica
+    would.  An explicit opt-in (default False): a data-parallel TRAIN stream that happened to be built with
+    num_epochs=1 and no shuffle must keep complete rounds only, or its ranks run unequal step counts and deadlock in the
+    step's collectives."""
     return RSX_SHARD_TAIL if shard_tail else 0
 
 
 def criteo_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=8, layout=None,
-                    shuffle_buffer=1000, prefetch=16, seed=0, shard=None, verify_crc=True, shard_tail=None):
+                    shuffle_buffer=1000, prefetch=16, seed=0, shard=None, verify_crc=True, shard_tail=False):
     """fm/fm.py:106-112.  Returns an iterator of (features, labels).
     shard=(rank, world): this replica's share of the batch stream (see csrc/tfrecord_reader.cpp); each replica then
     shuffles its own sub-stream with its own seed.  `prefetch` = batches the C++ reader keeps in flight.
-    shard_tail (default: num_epochs == 1 and not need_shuffle, i.e. evaluation): see _shard_tail."""
+    shard_tail (default False; evaluation passes True): see _shard_tail."""
     if layout is None:
         from .feature_columns import CriteoLayout, build_feature_columns
         layout = CriteoLayout.from_columns(build_feature_columns(16)[1])
@@ -257,7 +257,7 @@ def criteo_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, nu
 
 
 def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_parallel=6, hist_len=100,
-                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False, shard=None, verify_crc=True, shard_tail=None):
+                 shuffle_buffer=1000, prefetch=16, seed=0, ids_int32=False, shard=None, verify_crc=True, shard_tail=False):
     """din/din.py:61-80: features {'i_id','i_cate' int64 [B]; 'u_iid_seq','u_icat_seq' int64 [B,P]}, labels int64 [B].
     ids_int32: narrow the id features to int32 on the HOST (the device kernels index with int32; like the Criteo parse,
     which emits int32 row ids) so that the training step has no per-feature cast launches."""
@@ -283,6 +283,9 @@ def din_input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, num_p
                     lab, iid, icat, hi, hc = lab[:n], iid[:n], icat[:n], hi[:n], hc[:n]
                 # (id 0 is the history padding (din/din.py:56-57,107) AND an ordinary row for the target lookups, as in the
                 # reference: the device side keys the padding entries to a dummy row, so a target id 0 trains normally)
+                # Negative ids would index in front of the tables (tf.gather raises InvalidArgument on CPU): refuse them here.
+                if min(int(iid.min()), int(icat.min()), int(hi.min()), int(hc.min())) < 0:
+                    raise RsxError("DIN TFRecord stream: negative id in i_id / i_cate / u_iid_seq / u_icat_seq")
                 if ids_int32:
                     iid, icat, hi, hc = (x.astype(np.int32) for x in (iid, icat, hi, hc))
                 yield {"i_id": iid, "i_cate": icat, "u_iid_seq": hi, "u_icat_seq": hc}, lab

@@ -62,7 +62,8 @@ def test_sparse_table_segments_and_ordered_sums():
         np.testing.assert_allclose(Gg, G, rtol=2e-5, atol=1e-6)
 
 
-def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False, zero_targets=0, extra_params=None):
+def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False, zero_targets=0, extra_params=None,
+             batch_sizes=None):
     from recsys_amd import din, synthetic
     from recsys_amd.estimator import ModeKeys
     from tests.parity_util import make_estimator
@@ -73,7 +74,8 @@ def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False, ze
               "n_cate": n_cate}
     params.update(extra_params or {})
     est = make_estimator(din.model_fn, params, use_graph=use_graph)
-    batches = [synthetic.din_batch(rng, B, Pn, n_item, n_cate) for _ in range(steps)]
+    sizes = list(batch_sizes) if batch_sizes is not None else [B] * steps      # (B = the capacity, sizes[i] <= B)
+    batches = [synthetic.din_batch(rng, bs, Pn, n_item, n_cate) for bs in sizes]
     for b in batches:              # target item / category id 0: an ordinary row for tf.gather (din/din.py:96-101)
         b["i_id"][:zero_targets] = 0
         b["i_cate"][:max(zero_targets - 1, 0)] = 0
@@ -94,9 +96,10 @@ def _din_run(B, Pn, K, n_item, n_cate, steps, seed, dropout, use_graph=False, ze
     for b in batches:
         mk = None
         if dropout > 0:
-            mk = {"att_i": [(rng.random((B * Pn, n)) >= dropout).astype(np.float32) for n in (80, 40)],
-                  "att_c": [(rng.random((B * Pn, n)) >= dropout).astype(np.float32) for n in (80, 40)],
-                  "mlp": [(rng.random((B, n)) >= dropout).astype(np.float32) for n in (100, 50, 20)]}
+            nb = len(b["i_id"])
+            mk = {"att_i": [(rng.random((nb * Pn, n)) >= dropout).astype(np.float32) for n in (80, 40)],
+                  "att_c": [(rng.random((nb * Pn, n)) >= dropout).astype(np.float32) for n in (80, 40)],
+                  "mlp": [(rng.random((nb, n)) >= dropout).astype(np.float32) for n in (100, 50, 20)]}
             est.params["_dropout_masks"] = {k: [torch.from_numpy(m).cuda() for m in v] for k, v in mk.items()}
         f = feats(b)
         with torch.no_grad():
@@ -130,6 +133,20 @@ def test_din_target_id_zero_trains_like_any_other_row(fused):
     and the autograd path key the history padding to a dummy row instead of skipping row 0)."""
     err, losses, perr = _din_run(B=24, Pn=12, K=16, n_item=200, n_cate=20, steps=4, seed=7, dropout=0.0, zero_targets=5,
                                  extra_params={"fused_step": fused})
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < 1e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_din_vocabulary_multiple_of_32_and_shrinking_batches(use_graph):
+    """(a) the item bias rides through the item field's scatter indexed by GLOBAL arena rows (the dummy row n_item
+    and the category rows included): with n_item % 32 == 0 an n_item-row allocation has no slack and the dummy row's update
+    landed in the first-moment slot of bias row 0; (b) a batch smaller than an earlier one (the last batch of an epoch) must
+    not pick up the larger batch's bias gradients at its history entries.  Every step is held against the oracle."""
+    err, losses, perr = _din_run(B=32, Pn=12, K=16, n_item=256, n_cate=32, steps=6, seed=11, dropout=0.0, use_graph=use_graph,
+                                 batch_sizes=[32, 20, 32, 7, 20, 32])
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5, losses

@@ -163,7 +163,8 @@ def test_reader_shards_the_batch_stream_by_rank(tmp_path, layout):
     # EVALUATION under sharding (one pass, no shuffle): nothing is dropped -- leftover full batches of the last
     # round and the final partial batch go to rank b % world, and the ranks together cover every record exactly once
     for world in (2, 3, 4):
-        per_rank = [list(criteo_input_fn(files, bs, num_epochs=1, layout=layout, shard=(rank, world), num_parallel=3))
+        per_rank = [list(criteo_input_fn(files, bs, num_epochs=1, layout=layout, shard=(rank, world), num_parallel=3,
+                                         shard_tail=True))
                     for rank in range(world)]
         nbatches = (total + bs - 1) // bs
         for rank in range(world):
@@ -174,8 +175,8 @@ def test_reader_shards_the_batch_stream_by_rank(tmp_path, layout):
                 assert np.array_equal(got[1].reshape(-1).astype(np.int64), want), (world, rank, b)
         seen = np.concatenate([g[1].reshape(-1) for x in per_rank for g in x]).astype(np.int64)
         assert sorted(seen.tolist()) == list(range(total))
-        # TRAIN-style call of the same files (shard_tail off): complete rounds only
-        t0 = list(criteo_input_fn(files, bs, num_epochs=1, layout=layout, shard=(0, world), shard_tail=False))
+        # TRAIN-style call of the same files (shard_tail off = the DEFAULT, also for one unshuffled epoch): complete rounds only
+        t0 = list(criteo_input_fn(files, bs, num_epochs=1, layout=layout, shard=(0, world)))
         assert len(t0) == total // (bs * world)
     # world 1 keeps the partial batch, drop handled by the caller's choice
     got = list(criteo_input_fn(files, bs, num_epochs=1, layout=layout, shard=(0, 1)))
@@ -248,15 +249,15 @@ def test_din_reader_shards_and_keeps_order(tmp_path):
     b["label"] = np.arange(50)
     p = tmp_path / "train2"
     write_din_shard(str(p), b)
-    r0 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(0, 2), ids_int32=True, shard_tail=False))
-    r1 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(1, 2), shard_tail=False))
+    r0 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(0, 2), ids_int32=True))        # default: complete rounds
+    r1 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(1, 2)))
     assert [g[1].tolist() for g in r0] == [list(range(0, 8)), list(range(16, 24)), list(range(32, 40))]
     assert [g[1].tolist() for g in r1] == [list(range(8, 16)), list(range(24, 32)), list(range(40, 48))]
     assert r0[0][0]["u_iid_seq"].dtype == np.int32 and r1[0][0]["u_iid_seq"].dtype == np.int64
     assert np.array_equal(r1[1][0]["u_iid_seq"], b["u_iid_seq"][24:32])
-    # evaluation (one pass, no shuffle): the tail is delivered -- batch 6 (records 48, 49) belongs to rank 6 % 2 = 0
-    e0 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(0, 2)))
-    e1 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(1, 2)))
+    # evaluation (shard_tail=True): the tail is delivered -- batch 6 (records 48, 49) belongs to rank 6 % 2 = 0
+    e0 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(0, 2), shard_tail=True))
+    e1 = list(din_input_fn([str(p)], 8, num_epochs=1, hist_len=12, shard=(1, 2), shard_tail=True))
     assert [g[1].tolist() for g in e0] == [list(range(0, 8)), list(range(16, 24)), list(range(32, 40)), [48, 49]]
     assert [g[1].tolist() for g in e1] == [list(range(8, 16)), list(range(24, 32)), list(range(40, 48))]
 
