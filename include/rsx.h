@@ -338,6 +338,17 @@ int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, floa
                         const float* mask_prev, float* bn_prev_out, const uint32_t* rng_step, uint32_t seed,
                         int layer, float dropout_rate, int B, int K, int N, const rsx_sort_job* sort_h,
                         const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* rsx_gather_fm_fwd + the FIRST rsx_tower_fwd_layer in ONE launch (round 4): the input_layer lookup, first-order sum and FM
+ * term of deepfm/deepfm.py:85-98 (= fm/fm.py:117-129) and a_0 = relu(E . W_0 + b_0) of deepfm/deepfm.py:103-104, K = F * D.
+ * Every tile workgroup gathers its 16 examples' rows into LDS and feeds the MFMA A operand from there; E / S / y1 / y2 are
+ * still written (backward and the head read them) and are bit-identical to rsx_gather_fm_fwd's, a_out / fstat_out to
+ * rsx_tower_fwd_layer's.  Envelope (rsx_gather_tower_fwd0_supported): D == 16, F <= 64, B < 1024 -- RSX_EUNSUPPORTED outside,
+ * where the caller runs the two entries above one after the other.  S / y1 / y2 / w1 may be NULL as in rsx_gather_fm_fwd. */
+int rsx_gather_tower_fwd0(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids, float* E,
+                          float* S, float* y1, float* y2, uint64_t w1_field_mask, int F, int D, const float* W,
+                          const float* bias, float* a_out, double* fstat_out, int B, int N, const rsx_sort_job* sort_h,
+                          const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+int rsx_gather_tower_fwd0_supported(int B, int F, int D);
 /* o = dropout(BN(a_last)); u = o.wd + bd; z = wo[0]*act0(s0+c0) + wo[1]*s1 + wo[2]*act2(u) + bo (wo NULL: plain sum);
  * prob = sigmoid(z); per-row-tile partials of the loss and of every head gradient; dy_last / bstat_last = gradient
  * wrt the last BN output; gs0 / gs1 = d loss / d s0, d s1.  loss_scale = 1/(B*replicas).                    */

@@ -21,6 +21,7 @@
 #include "sort_device.h"
 #include "adam_device.h"
 #include "drop_device.h"
+#include "gather_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 RSX_STAMP_DECL
@@ -160,6 +161,34 @@ struct FwdArgs {
   AdamSlice sweep;        // optional slice of the untouched-row optimizer sweep carried as extra workgroups
 };
 
+// epilogue of a forward tile: thread t owns element (r = t/16, c = t%16) of the 16x16 tile (bx, by): bias + relu, the store,
+// and the tile's column sums (sum a, sum a^2) for the batch-norm statistics
+__device__ __forceinline__ void fwd_tile_epilogue(const FwdArgs& p, const float v, const int bx, const int by, double* cred) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int orow = by * TM + (tid >> 4), ocol = bx * 16 + (tid & 15);
+  double s1 = 0.0, s2 = 0.0;
+  if (orow < p.B && ocol < p.N) {
+    float o = v + p.bias[ocol];
+    o = o > 0.f ? o : 0.f;
+    p.a_out[(size_t)orow * p.N + ocol] = o;
+    s1 = (double)o;
+    s2 = (double)o * (double)o;
+  }
+  if (p.fstat_out != nullptr) {   // column sums over the tile's 16 rows: 4 rows per wave, then 4 waves
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lane < 16) {
+      cred[((tid >> 6) * 2 + 0) * 16 + lane] = s1;
+      cred[((tid >> 6) * 2 + 1) * 16 + lane] = s2;
+    }
+    __syncthreads();
+    if (tid < 16 && ocol < p.N) {
+      p.fstat_out[((size_t)by * 2 + 0) * p.N + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
+      p.fstat_out[((size_t)by * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= p.n_own + p.n_sort) {
@@ -231,30 +260,153 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     a[0] = av.x * okf; a[1] = av.y * okf; a[2] = av.z * okf; a[3] = av.w * okf;
   });
   RSX_STAMP(st0 + 2, blockIdx.x == 0);
-  // epilogue: thread t owns element (r = t/16, c = t%16)
-  const int orow = by * TM + (tid >> 4), ocol = bx * 16 + (tid & 15);
-  double s1 = 0.0, s2 = 0.0;
-  if (orow < p.B && ocol < p.N) {
-    float o = v + p.bias[ocol];
-    o = o > 0.f ? o : 0.f;
-    p.a_out[(size_t)orow * p.N + ocol] = o;
-    s1 = (double)o;
-    s2 = (double)o * (double)o;
-  }
-  if (p.fstat_out != nullptr) {   // column sums over the tile's 16 rows: 4 rows per wave, then 4 waves
-    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    if (lane < 16) {
-      cred[((tid >> 6) * 2 + 0) * 16 + lane] = s1;
-      cred[((tid >> 6) * 2 + 1) * 16 + lane] = s2;
-    }
-    __syncthreads();
-    if (tid < 16 && ocol < p.N) {
-      p.fstat_out[((size_t)by * 2 + 0) * p.N + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
-      p.fstat_out[((size_t)by * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
-    }
-  }
+  fwd_tile_epilogue(p, v, bx, by, cred);
   RSX_STAMP(st0 + 3, blockIdx.x == 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather + FIRST forward layer in one launch (round 4; deepfm.py at batch < 1024, D = 16): the input_layer lookup
+// (fm/fm.py:118 = deepfm/deepfm.py:85), the first-order sum and the FM term (deepfm/deepfm.py:88-98) and
+// a_0 = relu(E . W_0 + b_0) (deepfm/deepfm.py:103-104).  Workgroup roles by blockIdx.x:
+//   [0, n_own)       tile (bx, by): gathers the rows of its 16 examples STRAIGHT INTO LDS (wave w the examples 16 by + 4 w +
+//                    {0..3}, 16 row loads per lane in flight) and feeds the MFMA A operand from there.  The wave's B operands
+//                    (its k-steps of W_0) are requested first and stay in registers, so nothing behind the gather touches
+//                    global memory.  E never makes the HBM round trip on the step's critical path.
+//   [.., + n_gout)   the stand-alone gather (gather_device.h, one wave per example): E for backward's dW, S, y1, y2 -- off
+//                    the tile workgroups' path (phase stamps: as part of the column-tile-0 workgroups these outputs made
+//                    them 2.7 us longer than the other tiles, and the launch as long as the two it replaces).
+//   then the riders every tower launch takes: the step's dedup sort, a slice of the untouched-row optimizer sweep.
+// The 7 column tiles gather the same rows: 7 x 0.64 MB of L2 reads -- what a kernel boundary costs in time many times over.
+// dyn LDS: 16 * (K + 4) + 1024 + 256 floats.
+// ---------------------------------------------------------------------------------------------
+struct GatherFwdArgs {
+  FwdArgs f;                 // in unused, fstat_prev == nullptr, K = F * 16
+  const float* tables; const float* w1; const int32_t* row_off; const int32_t* ids;
+  float* E; float* S; float* y1; float* y2;
+  uint64_t w1_mask;
+  int F, n_gout;
+};
+
+// NS = k-steps per wave (K / 16 = F k-steps dealt to the 4 waves); RID = false: no sort / sweep workgroups in the launch (the
+// optimizer-window form of the step), their code -- and its registers -- compiled out
+template <int NS, bool RID>
+__global__ __launch_bounds__(256, 1) void tower_gather_fwd_k(const GatherFwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const FwdArgs& p = g.f;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if ((int)blockIdx.x >= p.n_own) {
+    const int r = blockIdx.x - p.n_own;
+    if (r < g.n_gout) {
+      const int b = r * 4 + w;
+      if (b < p.B) gather_fm_example<16>(g.tables, g.w1, g.row_off, g.ids, g.E, g.S, g.y1, g.y2, g.w1_mask, b, g.F, lane);
+    } else if (RID) {
+      if (r < g.n_gout + p.n_sort) field_sort_block(p.sort, r - g.n_gout, reinterpret_cast<uint32_t*>(lds));     // (ids only)
+      else adam_block(p.sweep.args, p.sweep.blk_lo + (r - g.n_gout - p.n_sort));
+    }
+    return;
+  }
+  constexpr int D = 16, LPR = 4, PPP = 16;
+  const int bx = blockIdx.x % p.ct, by = blockIdx.x / p.ct;
+  RSX_STAMP(4, blockIdx.x == 0);
+  const int ES = p.K + 4;              // row stride of the LDS tile: 16-byte aligned, the 16 rows of an A-operand read start
+  float* et = lds;                     // in 16 different 4-bank groups (K = 624: stride 628 = 52 mod 64)
+  float* part = lds + 16 * ES;         // [4][256]
+  double* cred = reinterpret_cast<double*>(part + 1024);
+  const int F = g.F;                   // = the number of k-steps (K = 16 F)
+  // ---- B operands of this wave's k-steps ks = w, w + 4, ... (operand t <-> k = 16 ks + 4 (lane >> 4) + t) ----
+  const int i = lane & 15, kq = lane >> 4;
+  const int col = bx * 16 + i;
+  const int colc = col < p.N ? col : 0;
+  // (32-bit element offsets from the uniform base: one v_add per load -- the launch is bound by instruction issue, every
+  // 64-bit address costs 3-4 instructions of a lone wave's ~270 per microsecond)
+  float bw[NS][4];
+  const float* __restrict__ Wg = p.W;
+  const uint32_t Nn = (uint32_t)p.N;
+  const uint32_t woff = (uint32_t)(w * 16 + 4 * kq) * Nn + (uint32_t)colc;
+#pragma unroll
+  for (int sI = 0; sI < NS; ++sI) {
+    const uint32_t o = w + 4 * sI < F ? woff + (uint32_t)(sI * 64) * Nn : woff;   // (a k-step past K is loaded from a valid
+    bw[sI][0] = Wg[o];                                                           // address and never multiplied)
+    bw[sI][1] = Wg[o + Nn];
+    bw[sI][2] = Wg[o + 2u * Nn];
+    bw[sI][3] = Wg[o + 3u * Nn];
+  }
+  __builtin_amdgcn_sched_barrier(0);      // (pins the loads here: the scheduler sinks a prefetch to its first use)
+  RSX_STAMP(32, blockIdx.x == 0);
+  // ---- rows of the tile's examples: lane = (pair slot j, float4 quarter q), fields j, j + 16, ... ----
+  const int q = lane % LPR, j = lane / LPR;
+  const f32x4* __restrict__ TV = reinterpret_cast<const f32x4*>(g.tables);
+  // (F <= 64 = 4 * PPP: ONE pass, straight-line -- the lane's fields are j + 16 k, k = 0..3, clamped to F - 1)
+  const int32_t* __restrict__ idg = g.ids;
+  const int32_t* __restrict__ rog = g.row_off;
+  {
+    int row[4][4];
+    uint32_t fc[4];
+    int ro[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = j + k * PPP;
+      fc[k] = (uint32_t)(f < F ? f : F - 1);
+      ro[k] = rog[fc[k]];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int b = by * TM + 4 * w + e;
+      const uint32_t ib = (uint32_t)(b < p.B ? b : p.B - 1) * (uint32_t)F;     // (B * F < 2^31: the sort's own bound)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) row[e][k] = ro[k] + idg[ib + fc[k]];
+    }
+    RSX_STAMP(33, blockIdx.x == 0);
+    f32x4 ev[4][4];                       // (the native vector type: an array of HIP's float4 STRUCT stayed in scratch memory here)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ev[e][k] = TV[(size_t)row[e][k] * LPR + q];
+    __builtin_amdgcn_sched_barrier(0);    // (all 16 row loads in flight before the first store)
+    RSX_STAMP(34, blockIdx.x == 0);
+    // (unconditional stores on the clamped field index -- a field past F rewrites field F - 1's row with the same bytes: behind
+    // a guard the compiler sinks every row load to its store and the 16 round trips run one after the other)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<f32x4*>(et + (4 * w + e) * ES + (int)fc[k] * D + q * 4) = ev[e][k];
+  }
+  RSX_STAMP(35, blockIdx.x == 0);
+  __syncthreads();
+  RSX_STAMP(5, blockIdx.x == 0);
+  // ---- the tile: acc0 takes this wave's even visits, acc1 the odd ones, each in ascending k (tile_ksplit's order); the two
+  // chains are issued interleaved (fp32 MFMA 16x16x4 has a ~32-cycle dependent latency) ----
+  // (rows past the batch hold a copy of the last example: an A row only reaches its own output row, which is never stored)
+  const float* arow = et + i * ES + 4 * kq;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sI = 0; sI < NS; sI += 2) {
+    const int ks0 = w + 4 * sI, ks1 = ks0 + 4;
+    if (ks0 < F) {                                          // (wave-uniform)
+      const float4 x0 = *reinterpret_cast<const float4*>(arow + ks0 * 16);
+      const float4 x1 = *reinterpret_cast<const float4*>(arow + (ks1 < F ? ks1 : ks0) * 16);
+      const float a0[4] = {x0.x, x0.y, x0.z, x0.w};
+      const float a1v[4] = {x1.x, x1.y, x1.z, x1.w};
+      if (sI + 1 < NS && ks1 < F) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc0 = mfma16(a0[t], bw[sI][t], acc0);
+          acc1 = mfma16(a1v[t], bw[sI + 1 < NS ? sI + 1 : sI][t], acc1);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0 = mfma16(a0[t], bw[sI][t], acc0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[w * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+  RSX_STAMP(6, blockIdx.x == 0);
+  __syncthreads();
+  const float v = ((part[tid] + part[256 + tid]) + part[512 + tid]) + part[768 + tid];
+  fwd_tile_epilogue(p, v, bx, by, cred);
+  RSX_STAMP(7, blockIdx.x == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1673,6 +1825,54 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   hipLaunchKernelGGL(tower_fwd_k, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_gather_tower_fwd0(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
+                                     float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int F, int D,
+                                     const float* W, const float* bias, float* a_out, double* fstat_out, int B, int N,
+                                     const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || D <= 0 || N <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!tables || !row_off || !ids || !E || !W || !bias || !a_out) return RSX_EINVAL;
+  // the envelope (rsx_gather_tower_fwd0_supported): rows of 16 floats, a batch the small-batch tiles serve, an LDS tile that
+  // leaves room for 3 workgroups per CU
+  if (D != 16 || F > 64 || B >= TOWER_BIG_MIN_B) return RSX_EUNSUPPORTED;
+  GatherFwdArgs g;
+  FwdArgs& p = g.f;
+  p.in = nullptr; p.W = W; p.bias = bias; p.a_out = a_out; p.fstat_out = fstat_out;
+  p.fstat_prev = nullptr; p.gamma_prev = nullptr; p.beta_prev = nullptr; p.mask_prev = nullptr; p.bn_prev_out = nullptr;
+  p.rng_step = nullptr; p.seed = 0; p.layer_prev = 0u; p.rate = 0.f;
+  p.B = B; p.K = F * D; p.N = N; p.RT = stat_rows(B);
+  p.inv_B = 1.0 / (double)B;
+  p.ct = (N + 15) / 16;
+  p.n_own = p.ct * ((B + TM - 1) / TM);
+  const int rcs = adam_build_slice(sweep_h, p.sweep);
+  if (rcs != RSX_OK) return rcs;
+  size_t lds = ((size_t)16 * (p.K + 4) + 1024 + 256) * sizeof(float);
+  p.n_sort = 0;
+  if (sort_h != nullptr) {
+    const int rc = sort_job_args(*sort_h, p.sort, &lds);
+    if (rc != RSX_OK) return rc;
+    p.n_sort = sort_h->F;
+  }
+  g.tables = tables; g.w1 = w1; g.row_off = row_off; g.ids = ids; g.E = E; g.S = S; g.y1 = y1; g.y2 = y2;
+  g.w1_mask = w1_field_mask; g.F = F;
+  g.n_gout = (B + 3) / 4;
+  const dim3 grid(p.n_own + g.n_gout + p.n_sort + p.sweep.n_blk);
+  const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
+  if (F <= 40) {
+    if (rid) hipLaunchKernelGGL((tower_gather_fwd_k<10, true>), grid, dim3(256), lds, rsx_s(stream), g);
+    else hipLaunchKernelGGL((tower_gather_fwd_k<10, false>), grid, dim3(256), lds, rsx_s(stream), g);
+  } else {
+    if (rid) hipLaunchKernelGGL((tower_gather_fwd_k<16, true>), grid, dim3(256), lds, rsx_s(stream), g);
+    else hipLaunchKernelGGL((tower_gather_fwd_k<16, false>), grid, dim3(256), lds, rsx_s(stream), g);
+  }
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_gather_tower_fwd0_supported(int B, int F, int D) {
+  return D == 16 && F > 0 && F <= 64 && B > 0 && B < TOWER_BIG_MIN_B;
 }
 
 extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, const float* gamma, const float* beta,

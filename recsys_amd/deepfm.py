@@ -178,7 +178,13 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # 106-108 us with any share given to the forward launches ([1,1,1,3,3,2.5] ...): a forward launch is a pure chain of
         # dependent L2 accesses and stretches by more than the slice it hides.  So the default stays the r01 form.
         in_gather = job is not None and overlap and os.environ.get("RSX_SORT_IN_GATHER", "0") == "1"
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv, sort_job=job if in_gather else None)
+        # round 4: the gather itself rides in the first tower-forward launch (E tiles gathered straight into LDS as the MFMA
+        # A operand, rsx_gather_tower_fwd0): one launch less on the step's dependent chain
+        fuse_gather = not in_gather and store.tower.fused_gather_ok(arena, ids.shape[0])
+        if fuse_gather:
+            E, S, y1p, y2 = arena.gather_outputs(ids.shape[0], fm=True, first_order=True, S_out=Sv)
+        else:
+            E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv, sort_job=job if in_gather else None)
         if in_gather:
             job = None
         elif job is None and wk == 1:
@@ -219,7 +225,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
             sort_job=job, sweeps=sweeps, sort_in_fwd=overlap, outs=(dXv, gy1v, gy2v) if zc else None,
-            layer_done=layer_done)
+            layer_done=layer_done, gather=(arena, ids, S, y1p, y2) if fuse_gather else None)
 
     def train_op():
         with torch.no_grad():

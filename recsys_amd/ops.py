@@ -215,16 +215,21 @@ class EmbeddingArena:
         j.max_rows_per_field, j.B, j.F, j.stride = self.max_rows, B, self.F, self.stride
         return j
 
-    def gather(self, ids, fm=False, first_order=False, S_out=None, sort_job=None):
-        """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd).  S_out: caller-owned [B,D] buffer for S
-        (e.g. a view of the data-parallel send block).  sort_job: the step's dedup sort (EmbeddingArena.sort_job) rides in
-        this launch as extra workgroups (rsx_gather_fm_fwd_sort)."""
-        B = ids.shape[0]
+    def gather_outputs(self, B, fm=False, first_order=False, S_out=None):
+        """The output buffers of gather(): E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None."""
         dev = self.tables.device
         E = torch.empty(B, self.F * self.D, device=dev)
         S = (S_out if S_out is not None else torch.empty(B, self.D, device=dev)) if fm else None
         y2 = torch.empty(B, device=dev) if fm else None
         y1 = torch.empty(B, device=dev) if first_order else None
+        return E, S, y1, y2
+
+    def gather(self, ids, fm=False, first_order=False, S_out=None, sort_job=None):
+        """-> E [B, F*D], S [B,D]|None, y1 [B]|None, y2 [B]|None (no autograd).  S_out: caller-owned [B,D] buffer for S
+        (e.g. a view of the data-parallel send block).  sort_job: the step's dedup sort (EmbeddingArena.sort_job) rides in
+        this launch as extra workgroups (rsx_gather_fm_fwd_sort)."""
+        B = ids.shape[0]
+        E, S, y1, y2 = self.gather_outputs(B, fm, first_order, S_out)
         if sort_job is not None:
             check(lib().rsx_gather_fm_fwd_sort(_ptr(self.tables), _ptr(self.w1) if first_order else None, _ptr(self.row_off),
                                                _ptr(ids), _ptr(E), _ptr(S), _ptr(y1), _ptr(y2), self.w1_mask,
@@ -570,6 +575,12 @@ class FusedTower:
             self.dwp.append(torch.empty(int(lib().rsx_tower_bwd_workspace_floats(self.cap, K, n)), device=dev)
                             if self.cap >= 1024 else None)
 
+    @staticmethod
+    def fused_gather_ok(arena, B):
+        """The envelope of the gather riding in the first forward launch (RSX_FUSE_GATHER=0: the two launches, A/B runs)."""
+        return os.environ.get("RSX_FUSE_GATHER", "1") != "0" and \
+            bool(lib().rsx_gather_tower_fwd0_supported(int(B), int(arena.F), int(arena.D)))
+
     def _masks(self, B, rate, masks):
         """Injected keep-masks (parity tests) as contiguous [B, N_l] views; None -> the kernels derive the mask
         from the counter-based hash (seed, step, layer, element), no buffer and no launch."""
@@ -585,7 +596,7 @@ class FusedTower:
 
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
-                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None, layer_done=None):
+                   seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None, layer_done=None, gather=None):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
@@ -594,6 +605,8 @@ class FusedTower:
         untouched-row optimizer sweep that ride along as extra workgroups (AdamTF1.cold_slices).
         outs = (dX [B,k0], gs0 [B], gs1 [B]): caller-owned contiguous output buffers (views of the data-parallel send block)
         instead of the tower's own.
+        gather = (arena, ids, S, y1, y2): X is the arena's (still empty) E buffer and the FIRST forward launch fills it -- the
+        input_layer lookup + first-order sum + FM term ride in that launch (rsx_gather_tower_fwd0; fused_gather_ok says when).
         layer_done(l): called after layer l's backward launch (l = L-1 .. 0), when that layer's dW/db (and, for l = L-1,
         the head's gradients) have been launched in full -- the hook of the RSX_DP_OVERLAP all-reduces.  The layers' dW
         reductions are then NOT deferred to the end.
@@ -613,6 +626,17 @@ class FusedTower:
         ref = lambda x: None if x is None else C.byref(x)
         for l in range(nl):
             K = self.k0 if l == 0 else self.widths[l - 1]
+            if l == 0 and gather is not None:
+                ar, ids, gS, gy1, gy2 = gather
+                assert ar.F * ar.D == self.k0 and ids.shape[0] == B
+                check(L.rsx_gather_tower_fwd0(_ptr(ar.tables), _ptr(ar.w1) if gy1 is not None else None, _ptr(ar.row_off),
+                                              _ptr(ids), _ptr(X), _ptr(gS), _ptr(gy1), _ptr(gy2), ar.w1_mask, ar.F, ar.D,
+                                              _ptr(P[f"{pre}.W0"]), _ptr(P[f"{pre}.b0"]), _ptr(self.a[0]), _ptr(self.fstat[0]),
+                                              B, self.widths[0], ref(sort_job) if sort_in_fwd else None, ref(sw[0]), st),
+                      "rsx_gather_tower_fwd0")
+                if self.bn_on:
+                    check(L.rsx_tower_reduce_partials(_ptr(self.fstat[0]), B, self.widths[0], st))
+                continue
             check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
                                         _ptr(self.a[l]), _ptr(self.fstat[l]),
                                         _ptr(self.fstat[l - 1]) if l else None,

@@ -19,7 +19,9 @@ from recsys_amd.estimator import Estimator, PackedBatch, RunConfig  # noqa: E402
 from recsys_amd.feature_columns import CriteoLayout, build_feature_columns  # noqa: E402
 
 NAMES = {0: "fwd1: entry", 1: "fwd1: BN stats of the previous layer reduced", 2: "fwd1: k-loop done", 3: "fwd1: end",
-         4: "fwd0: entry", 5: "fwd0: (no prologue)", 6: "fwd0: k-loop done", 7: "fwd0: end",
+         4: "fwd0: entry", 32: "gfwd0: W operand loads issued", 33: "gfwd0: ids + offsets arrived (rows computed)",
+         34: "gfwd0: rows arrived", 35: "gfwd0: LDS tile written", 5: "fwd0: (no prologue) / gfwd0: workgroup barrier",
+         6: "fwd0: k-loop done", 7: "fwd0: end",
          8: "head: entry", 9: "head: BN stats reduced", 12: "head: activations + dot product reduced (incl. the wait for the row loads)",
          13: "head: loss + dz", 10: "head: dy stored, column partials reduced", 11: "head: end",
          16: "bwd0 dX tile: entry", 17: "bwd0 dX: column constants", 18: "bwd0 dX: k-loop done", 19: "bwd0 dX: end",
@@ -56,7 +58,7 @@ def main():
         print("---- overlap_adam=%s: us since fwd0's entry; delta to the previous stamp of the same kernel" % overlap)
         prev = None
         for k in NAMES:
-            d = "" if prev is None or (k % 4 == 0 and k != 12) else "  (+%.2f)" % (t[k] - t[prev])
+            d = "" if prev is None or (k % 4 == 0 and k not in (12, 32, 36)) else "  (+%.2f)" % (t[k] - t[prev])
             print("%-58s %8.2f%s" % (NAMES[k], t[k], d))
             prev = k
 
