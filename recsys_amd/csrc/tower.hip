@@ -26,6 +26,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 RSX_STAMP_DECL
 
+// The riders of a tower launch (a slice of the untouched-row optimizer sweep, the step's dedup sort).  -DRSX_ISA_PROBE compiles
+// them out, so that scripts/isa_probe.sh can read a kernel's own instruction stream (never part of the product build).
+#ifdef RSX_ISA_PROBE
+#define RSX_RIDE_SWEEP(...) do { } while (0)
+#define RSX_RIDE_SORT(...) do { } while (0)
+#else
+#define RSX_RIDE_SWEEP(...) adam_block(__VA_ARGS__)
+#define RSX_RIDE_SORT(...) field_sort_block(__VA_ARGS__)
+#endif
+
 constexpr float TOWER_BN_EPS = 1e-3f;  // tf.layers.batch_normalization default epsilon
 constexpr int TM = 16;                 // rows per row tile
 
@@ -189,14 +199,17 @@ __device__ __forceinline__ void fwd_tile_epilogue(const FwdArgs& p, const float 
   }
 }
 
+// RID = false: a launch without riders (the optimizer-window form of the step): their code -- most of the kernel's
+// instructions and registers -- is compiled out
+template <bool RID>
 __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x >= p.n_own + p.n_sort) {
-    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
+  if (RID && (int)blockIdx.x >= p.n_own + p.n_sort) {
+    RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
     return;
   }
-  if ((int)blockIdx.x >= p.n_own) {   // piggy-backed dedup sort (ids only; first consumed by later launches)
-    field_sort_block(p.sort, blockIdx.x - p.n_own, reinterpret_cast<uint32_t*>(lds));
+  if (RID && (int)blockIdx.x >= p.n_own) {   // piggy-backed dedup sort (ids only; first consumed by later launches)
+    RSX_RIDE_SORT(p.sort, blockIdx.x - p.n_own, reinterpret_cast<uint32_t*>(lds));
     return;
   }
   const int bx = blockIdx.x % p.ct, by = blockIdx.x / p.ct;
@@ -300,8 +313,8 @@ __global__ __launch_bounds__(256, 1) void tower_gather_fwd_k(const GatherFwdArgs
       const int b = r * 4 + w;
       if (b < p.B) gather_fm_example<16>(g.tables, g.w1, g.row_off, g.ids, g.E, g.S, g.y1, g.y2, g.w1_mask, b, g.F, lane);
     } else if (RID) {
-      if (r < g.n_gout + p.n_sort) field_sort_block(p.sort, r - g.n_gout, reinterpret_cast<uint32_t*>(lds));     // (ids only)
-      else adam_block(p.sweep.args, p.sweep.blk_lo + (r - g.n_gout - p.n_sort));
+      if (r < g.n_gout + p.n_sort) RSX_RIDE_SORT(p.sort, r - g.n_gout, reinterpret_cast<uint32_t*>(lds));     // (ids only)
+      else RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (r - g.n_gout - p.n_sort));
     }
     return;
   }
@@ -449,10 +462,10 @@ struct HeadArgs {
 };
 
 // CPL: columns per lane = ceil(N / 16) rounded up to 4 / 8 / 16 (a compile-time bound keeps every load unconditional)
-template <int CPL>
+template <int CPL, bool RID>
 __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
-  if ((int)blockIdx.x >= p.n_own) {
-    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
+  if (RID && (int)blockIdx.x >= p.n_own) {
+    RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
     return;
   }
   __shared__ float sc[256], sh[256], mu[256], rs[256];
@@ -861,7 +874,7 @@ __device__ __forceinline__ void tower_head_reduce(const BwdArgs& p, float* part 
 
 // SPLIT: the dW tiles' batch reduction is cut into p.sb row blocks (large batches); false keeps the single-block code
 // path free of the block arithmetic
-template <bool SPLIT>
+template <bool SPLIT, bool RID>
 __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
@@ -1037,13 +1050,13 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     RSX_STAMP(sb0 + 7, bid == p.n_din);
     return;
   }
-  if (bid >= p.n_din + p.n_dw + p.n_head + p.n_sort) {
-    adam_block(p.sweep.args, p.sweep.blk_lo + (bid - (p.n_din + p.n_dw + p.n_head + p.n_sort)));
+  if (RID && bid >= p.n_din + p.n_dw + p.n_head + p.n_sort) {
+    RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (bid - (p.n_din + p.n_dw + p.n_head + p.n_sort)));
     return;
   }
-  if (bid >= p.n_din + p.n_dw + p.n_head) {
+  if (RID && bid >= p.n_din + p.n_dw + p.n_head) {
     // ---- piggy-backed dedup sort: independent of the tower, first needed by the segment-sum -----------
-    field_sort_block(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
+    RSX_RIDE_SORT(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
     return;
   }
   // ---- head partial reduce (last layer only) ---------------------------------------------------------
@@ -1133,11 +1146,11 @@ __global__ __launch_bounds__(256) void tower_fwd_big_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (RID) {
     if ((int)blockIdx.x >= p.n_own + p.n_sort) {
-      adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
+      RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
       return;
     }
     if ((int)blockIdx.x >= p.n_own) {
-      field_sort_block(p.sort, blockIdx.x - p.n_own, reinterpret_cast<uint32_t*>(lds));
+      RSX_RIDE_SORT(p.sort, blockIdx.x - p.n_own, reinterpret_cast<uint32_t*>(lds));
       return;
     }
   }
@@ -1628,11 +1641,11 @@ __global__ __launch_bounds__(256) void tower_bwd_big_k(const BwdArgs p) {
   }
   if (RID) {
     if (bid >= p.n_din + p.n_dw + p.n_head + p.n_sort) {
-      adam_block(p.sweep.args, p.sweep.blk_lo + (bid - (p.n_din + p.n_dw + p.n_head + p.n_sort)));
+      RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (bid - (p.n_din + p.n_dw + p.n_head + p.n_sort)));
       return;
     }
     if (bid >= p.n_din + p.n_dw + p.n_head) {
-      field_sort_block(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
+      RSX_RIDE_SORT(p.sort, bid - (p.n_din + p.n_dw + p.n_head), reinterpret_cast<uint32_t*>(lds));
       return;
     }
   }
@@ -1822,7 +1835,10 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
     RSX_CHECK_LAUNCH();
     return RSX_OK;
   }
-  hipLaunchKernelGGL(tower_fwd_k, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
+  if (p.n_sort + (int)p.sweep.n_blk > 0)
+    hipLaunchKernelGGL(tower_fwd_k<true>, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
+  else
+    hipLaunchKernelGGL(tower_fwd_k<false>, dim3(p.n_own), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1903,9 +1919,16 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
   const dim3 grid(p.n_own + p.sweep.n_blk);
-  if (N <= 64) hipLaunchKernelGGL(tower_head_k<4>, grid, dim3(256), 0, rsx_s(stream), p);
-  else if (N <= 128) hipLaunchKernelGGL(tower_head_k<8>, grid, dim3(256), 0, rsx_s(stream), p);
-  else hipLaunchKernelGGL(tower_head_k<16>, grid, dim3(256), 0, rsx_s(stream), p);
+  const bool rid = p.sweep.n_blk > 0;
+#define RSX_HEAD(CPL)                                                                                   \
+  do {                                                                                                  \
+    if (rid) hipLaunchKernelGGL((tower_head_k<CPL, true>), grid, dim3(256), 0, rsx_s(stream), p);      \
+    else hipLaunchKernelGGL((tower_head_k<CPL, false>), grid, dim3(256), 0, rsx_s(stream), p);         \
+  } while (0)
+  if (N <= 64) RSX_HEAD(4);
+  else if (N <= 128) RSX_HEAD(8);
+  else RSX_HEAD(16);
+#undef RSX_HEAD
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1926,7 +1949,7 @@ struct FmHeadArgs {
 
 __global__ __launch_bounds__(256) void fm_head_k(const FmHeadArgs p) {
   if (blockIdx.x > 0) {
-    adam_block(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - 1));
+    RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - 1));
     return;
   }
   __shared__ double red[4][5];
@@ -2131,8 +2154,14 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
     return RSX_OK;
   }
   const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
-  if (p.sb > 1) hipLaunchKernelGGL(tower_bwd_k<true>, dim3(total), dim3(256), lds, rsx_s(stream), p);
-  else hipLaunchKernelGGL(tower_bwd_k<false>, dim3(total), dim3(256), lds, rsx_s(stream), p);
+  const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;        // (no riders: the variant with their code compiled out)
+  if (p.sb > 1) {
+    if (rid) hipLaunchKernelGGL((tower_bwd_k<true, true>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+    else hipLaunchKernelGGL((tower_bwd_k<true, false>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+  } else {
+    if (rid) hipLaunchKernelGGL((tower_bwd_k<false, true>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+    else hipLaunchKernelGGL((tower_bwd_k<false, false>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+  }
   RSX_CHECK_LAUNCH();
   if (p.sb > 1) {
     if (reduce_out != nullptr) {
