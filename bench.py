@@ -148,7 +148,7 @@ def sweep_bytes(est, wk):
     element; a window pass adds the wk slot maps (4 B per row each)."""
     from recsys_amd.ops import EmbeddingArena
     store = est.store
-    segs = store.adam_segments()
+    segs = store.adam_segments(timing_only=True)
     n_sparse = sum(int(sg["n"]) * int(sg.get("d", 1) or 1) for sg in segs if sg["kind"] in (1, 2))
     alg = 24 * n_sparse + 32 * store.dense.n
     arenas = [x for x in store.embeddings.values() if isinstance(x, EmbeddingArena)]
@@ -293,6 +293,18 @@ def other_configs(a, rank, dev):
     return out
 
 
+def dp_exchange_info(store, B):
+    """What one rank contributes to the step's gradient collective (data parallel / emulated): bytes, and how many fields /
+    rows travel as dense per-row buckets instead of through the per-example block (recsys_amd/dist.py)."""
+    d = getattr(store, "dp", None)
+    if d is None or not hasattr(d, "_send"):
+        return {}
+    a = getattr(d, "_bucket_arena", None)
+    return {"dp_send_bytes_per_rank_per_step": int(d.send_bytes(B)),
+            "dp_bucket_fields": len(a.bucket_fields) if a is not None else 0,
+            "dp_bucket_rows": int(a.bucket_rows) if a is not None else 0}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -321,7 +333,7 @@ def main():
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
     store = est.store
-    segs = store.adam_segments()
+    segs = store.adam_segments(timing_only=True)     # (with gradient buckets on: over a slot map that marks no row)
     n_dense = store.dense.n
     # algorithmic bytes of the TF-faithful sweep: 24 B per table / first-order element (var, m, v read + written),
     # 32 B per dense element (+ gradient read and zeroed)
@@ -442,6 +454,7 @@ def main():
                                       ("captured" if os.environ.get("RSX_DP_CAPTURE") == "1" else "eager between segments"))),
                       "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5),
                       "adam_window": wk,
+                      **dp_exchange_info(store, B),
                       "timed_repeats_ms_per_step": [round(x / a.steps * 1e3, 5) for x in dts], "reported": "median repeat"},
            "roofline": roof}
     if N == 1 and emu is None and not a.no_configs and a.model == "deepfm" and not a.host_input and a.adam_mode == "tf1_dense":

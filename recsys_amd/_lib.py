@@ -20,7 +20,8 @@ class AdamSeg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n", C.c_int64),
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
                 ("slot", C.c_void_p), ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p),
-                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32), ("slot_w", C.c_void_p * 7)]
+                ("B", C.c_int32), ("stride", C.c_int32), ("zero_grad", C.c_int32), ("slot_w", C.c_void_p * 7),
+                ("g_replicas", C.c_int32), ("g_replica_stride", C.c_int64)]
 
 
 class AdamSlice(C.Structure):
@@ -35,10 +36,10 @@ class ExampleBlocks(C.Structure):
 
 class SegPartials(C.Structure):
     _fields_ = [("segid", C.c_void_p), ("P", C.c_void_p), ("P1", C.c_void_p), ("G", C.c_void_p), ("gw1", C.c_void_p),
-                ("row_off", C.c_void_p), ("null_row", C.c_int32)]
+                ("row_off", C.c_void_p), ("null_row", C.c_int32), ("skip_mask", C.c_uint64)]
 
-    def __init__(self, segid=None, P=None, P1=None, G=None, gw1=None, row_off=None, null_row=-1):
-        super().__init__(segid, P, P1, G, gw1, row_off, null_row)
+    def __init__(self, segid=None, P=None, P1=None, G=None, gw1=None, row_off=None, null_row=-1, skip_mask=0):
+        super().__init__(segid, P, P1, G, gw1, row_off, null_row, skip_mask)
 
 
 NULL_NONE, NULL_LAST_ROW = -1, -2          # include/rsx.h RSX_NULL_*
@@ -65,7 +66,8 @@ class CinDwJob(C.Structure):
 class SortJob(C.Structure):
     _fields_ = [("ids", C.c_void_p), ("row_off", C.c_void_p), ("perm", C.c_void_p), ("seg_off", C.c_void_p),
                 ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p), ("segid", C.c_void_p),
-                ("max_rows_per_field", C.c_int32), ("B", C.c_int32), ("F", C.c_int32), ("stride", C.c_int32)]
+                ("max_rows_per_field", C.c_int32), ("B", C.c_int32), ("F", C.c_int32), ("stride", C.c_int32),
+                ("skip_mask", C.c_uint64)]
 
 
 ADAM_WINDOW_MAX = 8
@@ -94,6 +96,7 @@ _SIGS = {
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
     "rsx_gather_fm_fwd_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P, _P]),
     "rsx_gather_two_fwd": (_I, [_P] * 10 + [_U64, _I, _I, _I, _I, _P]),
+    "rsx_bucket_scatter": (_I, [_P] * 11 + [_U64, _I, _I, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rsx_field_sort_large": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
     "rsx_field_sort_large_t": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),

@@ -11,6 +11,7 @@ struct SegDev {
   const int32_t *slot, *uniq_row, *nuniq;
   int32_t B, stride, zero_grad;
   uint32_t blk_begin;
+  int32_t g_rep, g_rep_stride4;      // *_ROWS kinds: replicas of g summed in order, float4 units apart (rsx_adam_seg.g_replicas)
 };
 constexpr int ADAM_WMAX = RSX_ADAM_WINDOW_MAX - 1;     // extra slot maps of an optimizer window
 struct AdamArgs {
@@ -275,7 +276,8 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
           const long long sl = (long long)f * s.stride + j;
           const long long r = (long long)s.uniq_row[sl] * lpr + q;
           float4 var = var4[r], m = m4[r], v = v4[r];
-          const float4 g = G4[sl * lpr + q];
+          float4 g = G4[sl * lpr + q];
+          for (int rr = 1; rr < s.g_rep; ++rr) g = f4_add(g, G4[(long long)rr * s.g_rep_stride4 + sl * lpr + q]);   // replicas, in rank order
           F4_APPLY(adam_sparse1, var, m, v, g, true, h);
           var4[r] = var;
           m4[r] = m;
@@ -292,8 +294,10 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
         if (j < s.nuniq[f]) {
           const long long sl = (long long)f * s.stride + j;
           const int r = s.uniq_row[sl];
-          if (s.kind == RSX_ADAM_VEC_ROWS_DENSE) adam_dense1(s.var[r], s.m[r], s.v[r], s.g[sl], h);
-          else adam_sparse1(s.var[r], s.m[r], s.v[r], s.g[sl], true, h);
+          float g = s.g[sl];
+          for (int rr = 1; rr < s.g_rep; ++rr) g += s.g[(long long)rr * 4 * s.g_rep_stride4 + sl];
+          if (s.kind == RSX_ADAM_VEC_ROWS_DENSE) adam_dense1(s.var[r], s.m[r], s.v[r], g, h);
+          else adam_sparse1(s.var[r], s.m[r], s.v[r], g, true, h);
         }
       }
     }
@@ -594,11 +598,13 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
         break;
       case RSX_ADAM_TABLE_ROWS:
         if (!s.g || !s.uniq_row || !s.nuniq || s.B <= 0 || s.d < 4 || (s.d & 3)) return RSX_EINVAL;
+        if (s.g_replicas > 1 && (s.g_replica_stride <= 0 || (s.g_replica_stride & 3) || s.g_replica_stride >= (1ll << 33))) return RSX_EINVAL;
         work = s.n * (s.d >> 2);
         break;
       case RSX_ADAM_VEC_ROWS:
       case RSX_ADAM_VEC_ROWS_DENSE:
         if (!s.g || !s.uniq_row || !s.nuniq || s.B <= 0) return RSX_EINVAL;
+        if (s.g_replicas > 1 && (s.g_replica_stride <= 0 || (s.g_replica_stride & 3) || s.g_replica_stride >= (1ll << 33))) return RSX_EINVAL;
         work = s.n;
         break;
       default: return RSX_EINVAL;
@@ -618,6 +624,9 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
     d.B = s.B;
     d.stride = s.stride;
     d.zero_grad = s.zero_grad;
+    const bool rows_kind = s.kind == RSX_ADAM_TABLE_ROWS || s.kind == RSX_ADAM_VEC_ROWS || s.kind == RSX_ADAM_VEC_ROWS_DENSE;
+    d.g_rep = rows_kind && s.g_replicas > 1 ? s.g_replicas : 1;
+    d.g_rep_stride4 = d.g_rep > 1 ? (int32_t)(s.g_replica_stride >> 2) : 0;
     if (s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD) {     // the window's extra slot maps (AdamArgs)
       int nw = 0;
       while (nw < ADAM_WMAX && s.slot_w[nw] != nullptr) ++nw;

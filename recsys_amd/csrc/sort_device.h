@@ -16,6 +16,10 @@ struct SortArgs {
   // then [F] long- and [F] huge-segment counts, then [F, ceil(B/16)] the long list (long from the front, huge from the back)
   int32_t* segid;
   int B, F, stride, n, bbits;
+  // fields whose bit is set are NOT sorted (their workspace rows keep nuniq = 0: every consumer then finds nothing to do).
+  // The data-parallel step sets it for the small-vocabulary fields, whose gradients travel as dense per-row buckets
+  // (rsx_bucket_scatter) instead of through the global sort + scatter.  A field must be skipped always or never.
+  uint64_t skip;
 };
 
 // lanes of this wave whose `digit` equals mine (all 64 lanes must call it): nbits ballots
@@ -38,6 +42,7 @@ __device__ __forceinline__ uint64_t rsx_match_digit(uint32_t digit, int nbits) {
 //   ordered by a (digit-major, wave-minor) scan of per-wave counters: ~4 barriers per pass instead of the
 //   log2(n)*(log2(n)+1)/2 = 66..105 barrier-separated stages of a bitonic network.  lds: 2n + 256*waves + 32 words
 __device__ __forceinline__ void field_sort_block(const SortArgs& a, int f, uint32_t* lds) {
+  if ((a.skip >> f) & 1ull) return;                     // (workgroup-uniform)
   const int tid = threadIdx.x, T = blockDim.x;
   const int B = a.B, n = a.n, bbits = a.bbits, stride = a.stride;
   const bool small = n <= 512 && n <= T;
@@ -264,7 +269,7 @@ static inline int sort_job_args(const rsx_sort_job& j, SortArgs& out, size_t* ld
   if (!j.ids || !j.row_off || !j.perm || !j.seg_off || !j.uniq_row || !j.nuniq || !j.slot || j.B < 0 || j.F <= 0 ||
       j.stride < j.B || j.max_rows_per_field <= 0)
     return RSX_EINVAL;
-  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.segid, j.B, j.F, j.stride, 0, 0};
+  out = SortArgs{j.ids, j.row_off, j.perm, j.seg_off, j.uniq_row, j.nuniq, j.slot, j.segid, j.B, j.F, j.stride, 0, 0, j.skip_mask};
   const int rc = rsx_sort_args(out, j.max_rows_per_field, 256);
   if (rc != RSX_OK) return rc;
   const size_t need = rsx_sort_lds_bytes(out, 256);

@@ -66,7 +66,10 @@ def build_variables(store, params, capacity):
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
         if store.dp is not None and params.get("dp_send_block", True):      # zero-copy gradient exchange (see deepfm.py)
-            store.dp.make_send_block(store.dense, capacity // store.dp.world, [dim])
+            if os.environ.get("RSX_DP_BUCKETS", "0") == "1" and store.adam_mode == "tf1_dense" and \
+                    bool(params.get("overlap_adam", True)):
+                arena.enable_buckets()          # small-vocabulary fields as dense gradient buckets (deepfm.py; needs the LDS sort)
+            store.dp.make_send_block(store.dense, capacity // store.dp.world, [dim], arena=arena)
             store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
@@ -127,8 +130,13 @@ def _train_fused(store, arena, ids, labels, params, masks):
     def train_op():
         with torch.no_grad():
             dXg, blocks, Bg, dense_segs = dX, None, dX.shape[0], None
-            if zc:                  # ONE collective straight from the send block (dense arena + dX)
+            bsegs = []
+            if zc:                  # ONE collective straight from the send block (dense arena + buckets + dX)
+                bv = dp.bucket_views()
+                if bv is not None:
+                    arena.bucket_scatter(ids, None, dX, None, None, bv[0], bv[1])
                 (dXg,), blocks, dense_segs = dp.gather_send_block(dX.shape[0], fold_dense=hot is not None)
+                bsegs = dp.bucket_segments()
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
@@ -136,9 +144,10 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 Bg = dX.shape[0] * dp.world
             if hot is not None:
                 arena.select(wpos)
-                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
-                                  blocks=blocks, window=(wk, wpos))
+                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, (dense_segs or store.dense.adam_segments()) + bsegs,
+                                  last_sweep, blocks=blocks, window=(wk, wpos))
             else:
+                assert not bsegs
                 arena.segsum(Bg, None, dXg, None, None, blocks=blocks)
                 store.apply_gradients()
 

@@ -82,7 +82,15 @@ def build_variables(store, params, capacity, with_dnn=True):
         if store.dp is not None and params.get("dp_send_block", True):
             # zero-copy gradient exchange: the dense gradient arena and the tower / gather outputs of the per-example block
             # live inside ONE persistent send buffer (no pack launch before the all-gather)
-            store.dp.make_send_block(store.dense, capacity // store.dp.world, [layout.F * D, D, 1, 1])
+            # round 4, RSX_DP_BUCKETS=1 (opt-in): the small-vocabulary fields leave the global sort + scatter and travel as dense
+            # per-row gradient buckets that ride the dense gradients' collective (EmbeddingArena.enable_buckets).  Measured on one
+            # GPU with N emulated replicas (profiles/r04_*emulate*): it does NOT shorten the step -- the global scatter's time is
+            # set by the LARGE fields' long segments and the window pass (13.8 + 35.8 us at N = 8 with or without the 25 small
+            # fields), and the bucket launch adds its own 16 us -- so the default stays the per-example block.
+            if os.environ.get("RSX_DP_BUCKETS", "0") == "1" and store.adam_mode == "tf1_dense" and \
+                    bool(params.get("overlap_adam", True)):
+                arena.enable_buckets()
+            store.dp.make_send_block(store.dense, capacity // store.dp.world, [layout.F * D, D, 1, 1], arena=arena)
             store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter] (measured: the
         # latency-bound scatter + touched-row Adam launch hides a quarter of the sweep; r02 grid over the shares with the faster
@@ -230,11 +238,16 @@ def _train_fused(store, arena, ids, labels, params, masks):
     def train_op():
         with torch.no_grad():
             Sg, dXg, gy1g, gy2g, blocks, Bg, dense_segs = S, dX, gy1, gy2, None, dX.shape[0], None
-            if zc:                  # ONE collective straight from the send block (dense arena + per-example block)
+            bsegs = []
+            if zc:                  # ONE collective straight from the send block (dense arena + buckets + per-example block)
                 if layer_done is not None:
                     dp.wait_all(pending)
+                bv = dp.bucket_views()
+                if bv is not None:  # the bucket fields' local gradients, summed per row without a sort (rsx_bucket_scatter)
+                    arena.bucket_scatter(ids, S, dX, gy1, gy2, bv[0], bv[1])
                 (dXg, Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(
                     dX.shape[0], fold_dense=hot is not None, dense_done=layer_done is not None)
+                bsegs = dp.bucket_segments()
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
@@ -242,9 +255,10 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 Bg = dX.shape[0] * dp.world
             if hot is not None:     # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
                 arena.select(wpos)
-                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
-                                  blocks=blocks, window=(wk, wpos))
+                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, (dense_segs or store.dense.adam_segments()) + bsegs,
+                                  last_sweep, blocks=blocks, window=(wk, wpos))
             else:
+                assert not bsegs
                 arena.segsum(Bg, Sg, dXg, gy1g, gy2g, blocks=blocks)
                 store.apply_gradients()
 

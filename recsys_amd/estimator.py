@@ -195,11 +195,11 @@ class VariableStore:
         self.opt = AdamTF1(lr=lr, device=self.device)
         self.built = True
 
-    def adam_segments(self):
+    def adam_segments(self, timing_only=False):
         lazy = self.adam_mode == "lazy_rows"
         segs = []
         for a in self.embeddings.values():
-            segs += a.adam_segments(lazy)
+            segs += a.adam_segments(lazy, timing_only) if hasattr(a, "skip_mask") else a.adam_segments(lazy)
         segs += self.extra_segments
         segs += self.dense.adam_segments()
         return segs

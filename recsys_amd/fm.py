@@ -31,7 +31,11 @@ def model_fn(features, labels, mode, params):
         store.dp_block = False
         if store.dp is not None and params.get("fused", True):
             # data-parallel: [S | gy2 | gy1] of the local batch + the dense gradient arena in one persistent send block
-            store.dp.make_send_block(store.dense, cap, [store.embeddings["input_layer"].D, 1, 1])
+            import os
+            a0 = store.embeddings["input_layer"]
+            if os.environ.get("RSX_DP_BUCKETS", "0") == "1":        # small-vocabulary fields as dense gradient buckets (deepfm.py)
+                a0.enable_buckets()
+            store.dp.make_send_block(store.dense, cap, [a0.D, 1, 1], arena=a0)
             store.dp_block = True
             store.graph_safe_dp = True       # the fused step issues its collectives outside autograd
     arena, P = store.embeddings["input_layer"], store.dense
@@ -113,9 +117,13 @@ def _train_fused(store, arena, ids, labels):
     def train_op():
         with torch.no_grad():
             if dp is not None:
+                bv = dp.bucket_views()
+                if bv is not None:
+                    arena.bucket_scatter(ids, S, None, gy1, gy2, bv[0], bv[1])
                 (Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(B, fold_dense=True)
                 arena.select(wpos)
-                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs, sweep2, blocks=blocks, window=(wk, wpos))
+                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs + dp.bucket_segments(), sweep2,
+                                  blocks=blocks, window=(wk, wpos))
             else:
                 arena.select(wpos)
                 arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2, window=(wk, wpos))

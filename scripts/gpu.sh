@@ -47,7 +47,7 @@ PY
                timeout 600 python bench.py --model $m $e --no_cpu_baseline --no_configs "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('emulated per-rank compute: model $m world $n  ms_per_step', d['ms_per_step'], ' adam_window', d['config']['adam_window'], ' global_batch', $n * int(d['config']['global_batch']))"
+print('emulated per-rank compute: model $m world $n  ms_per_step', d['ms_per_step'], ' adam_window', d['config']['adam_window'], ' global_batch', $n * int(d['config']['global_batch']), ' send_bytes/rank', d['config'].get('dp_send_bytes_per_rank_per_step'), ' bucket_fields', d['config'].get('dp_bucket_fields'))"
              done | tee gpurun_out/emulate_$m.txt ;;
     roofline) timeout 1200 python scripts/kernel_roofline.py 2>&1 | tee gpurun_out/kernel_roofline_table.txt | tail -40 ;;
     *) echo "unknown task $task"; return 1 ;;
