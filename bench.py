@@ -300,7 +300,7 @@ def dp_exchange_info(store, B):
     if d is None or not hasattr(d, "_send"):
         return {}
     a = getattr(d, "_bucket_arena", None)
-    return {"dp_send_bytes_per_rank_per_step": int(d.send_bytes(B)),
+    return {"dp_send_bytes_per_rank_per_step": int(d.send_bytes()),
             "dp_bucket_fields": len(a.bucket_fields) if a is not None else 0,
             "dp_bucket_rows": int(a.bucket_rows) if a is not None else 0}
 

@@ -107,6 +107,9 @@ def build_variables(store, params, B, P):
     if store.tower is not None and len(ATTENTION_LAYERS) == 2 and DinAttnFn.supported(K, *ATTENTION_LAYERS) and \
             store.adam_mode == "tf1_dense":
         store.din = DinFused(store, arena, barena, n_item, n_cate, K, B, P)
+        if store.dp is not None:
+            # data parallel (round 4): the fused step's collectives are plain calls between graph segments (deepfm.py)
+            store.graph_safe_dp = True
 
 
 class DinFused:
@@ -137,6 +140,13 @@ class DinFused:
         self.H = [torch.empty(B * P, K, **f32) for _ in range(2)]
         self.vals = torch.zeros(N, 2 * K, **f32)              # the scatter's value block: entry e -> [item grad | category grad]
         self.gbias = torch.zeros(N, **f32)                    # d loss / d i_item[i_id] of the target entries, 0 for history entries
+        self.dp = store.dp
+        if self.dp is not None:
+            # data parallel: value block and bias gradients live in the persistent send block behind the dense gradient arena
+            # ([dense | vals (2K per entry) | gbias (1 per entry)]): ONE all-gather straight from it, no pack copy; the global
+            # scatter reads every rank's block in place (dist.DataParallel.gather_send_block)
+            self.dp.make_send_block(store.dense, N, [2 * K, 1])
+            self.vals = self.gbias = None
         n1, n2 = ATTENTION_LAYERS
         self.a1 = [torch.empty(B * P, n1, **f32) for _ in range(2)]
         self.a2 = [torch.empty(B * P, n2, **f32) for _ in range(2)]
@@ -181,7 +191,9 @@ class DinFused:
             # (sort keys of both tables + both histories' lists of non-padding positions: two launches)
             keys2 = self.keys2[:N]
             cnts = [self.rows[t][B * P:] for t in range(2)]
-            big = N > a.LDS_SORT_MAX_B                  # the large sort takes field-major keys as they are
+            dp = self.dp
+            world = dp.world if dp is not None else 1
+            big = N > a.LDS_SORT_MAX_B and dp is None   # the large sort takes field-major keys as they are (single replica)
             lab64 = labels.reshape(-1) if labels.dtype == torch.int64 and labels.is_contiguous() else None
             _lib.check(L.rsx_din_prepare2(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item, self.n_cate,
                                           _ptr(self.keys_t) if big else _ptr(keys2), a.stride if big else 0, _ptr(self.rows[0]),
@@ -190,7 +202,12 @@ class DinFused:
                        "rsx_din_prepare2")
             labels_f = self.labels_f[:B] if lab64 is not None else labels.reshape(-1).to(torch.float32)
             a.select(0)
-            if big:
+            if dp is not None:
+                # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
+                # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
+                a.field_sort(dp.all_gather_rows(keys2))
+                vals_full, gbias_full = dp.send_views(N)
+            elif big:
                 a.field_sort_t(self.keys_t, N)
             else:
                 a.field_sort(keys2)
@@ -204,6 +221,7 @@ class DinFused:
             self._gather(B, i_id, i_cate, hist)
             q = (self.qi[:B], self.qc[:B])
             att_m = []
+            att_seed = 0xD1A77 + 7919 * (dp.rank if dp is not None else 0)
             att_mk = [None, None]
             if masks is not None:
                 att_mk = [masks.get("att_i"), masks.get("att_c")]
@@ -213,7 +231,7 @@ class DinFused:
                 m1, m2 = (None, None) if mk is None else (mk[0].contiguous(), mk[1].contiguous())
                 rows, cnt = self.rows[t], cnts[t]
                 _lib.check(L.rsx_din_attn_fwd(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]), _ptr(self.a2[t]),
-                                              _ptr(self.w[t]), _ptr(m1), _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, _ptr(rows),
+                                              _ptr(self.w[t]), _ptr(m1), _ptr(m2), _ptr(step), att_seed, 2 * t, rate, _ptr(rows),
                                               _ptr(cnt), B, P, K, n1, n2, st), "rsx_din_attn_fwd")
                 att_m.append((m1, m2))
             # masked weighted sums of both histories in one launch, written into their slices of the MLP input
@@ -224,17 +242,20 @@ class DinFused:
             tw = store.tower
             mlp_mk = None if masks is None or "mlp" not in masks else \
                 [torch.nn.functional.pad(m, (0, w - m.shape[1]), value=1.0) for m, w in zip(masks["mlp"], tw.widths)]
+            gbias = self.gbias[:N] if dp is None else gbias_full
+            rank = dp.rank if dp is not None else 0
             loss, prob, dX, gs0, _ = tw.train_step(
                 self.X[:B], labels_f, rate, step, s0=self.ib[:B],
-                head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=1, masks=mlp_mk, seed=0xD1AD,
-                outs=(None, self.gbias[:B], None))               # d loss / d bias lands in the scatter's first-order input
+                head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=world, masks=mlp_mk,
+                seed=0xD1AD + 7919 * rank,                       # replicas draw independent dropout patterns
+                outs=(None, gbias[:B], None))                    # d loss / d bias lands in the scatter's first-order input
             if B < self.cap_B:
                 # a batch smaller than an earlier one (the final partial batch of an epoch): entries B.. are HISTORY entries now,
-                # whose bias gradient is zero -- not what a larger batch's head left there.  Unconditional for this batch size,
-                # so that a captured graph of the step carries it.
-                self.gbias[B:self.cap_B].zero_()
+                # whose bias gradient is zero -- not what a larger batch's head (or, in the send block, a larger batch's value
+                # block) left there.  Unconditional for this batch size, so that a captured graph of the step carries it.
+                gbias[B:(self.cap_B if dp is None else N)].zero_()
             # ---- backward of the two attention blocks, straight into the scatter's value block --------------------------
-            vals = self.vals[:N]
+            vals = self.vals[:N] if dp is None else vals_full
             vbase = vals.data_ptr()
             dHp = [C.c_void_p(vbase + 4 * (B * 2 * K + t * K)) for t in range(2)]        # rows B.. of column block t
             doutp = [C.c_void_p(dX.data_ptr() + 4 * K * (t + 1)) for t in range(2)]       # d(pooled history t) = dX[:, (t+1)K : (t+2)K]
@@ -252,7 +273,7 @@ class DinFused:
                 rows, cnt = self.rows[t], self.rows[t][B * P:]
                 _lib.check(L.rsx_din_attn_bwd_nofinish(_ptr(self.H[t]), _ptr(q[t]), *[_ptr(x) for x in Ws], _ptr(self.a1[t]),
                                                        _ptr(self.a2[t]), _ptr(self.dw[t]), dHp[t], _ptr(self.ws[t]), _ptr(m1),
-                                                       _ptr(m2), _ptr(step), 0xD1A77, 2 * t, rate, 1, _ptr(rows), _ptr(cnt),
+                                                       _ptr(m2), _ptr(step), att_seed, 2 * t, rate, 1, _ptr(rows), _ptr(cnt),
                                                        _ptr(hist[t]), B, P, K, n1, n2, 2 * K, st), "rsx_din_attn_bwd_nofinish")
             # weight gradients + the target rows' gradients (dq, plus the MLP input slice for the item block) of both blocks
             dqp = [C.c_void_p(vbase + 4 * t * K) for t in range(2)]         # rows 0 .. B-1 of column block t
@@ -263,8 +284,15 @@ class DinFused:
         def train_op():                                                    # AdamOptimizer.minimize (:172-173)
             with torch.no_grad():
                 ba = self.barena
-                a.segsum_adam(N, None, vals, self.gbias[:N], None, store.opt, store.dense.adam_segments(),
-                              w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
+                if dp is None:
+                    a.segsum_adam(N, None, vals, gbias, None, store.opt, store.dense.adam_segments(),
+                                  w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
+                else:
+                    # ONE collective: [dense gradient arena | value block | bias gradients] of every rank; the dense arenas are
+                    # summed in rank order inside the optimizer launch, the scatter reads the rank blocks in place
+                    (vg, gbg), blocks, dense_segs = dp.gather_send_block(N, fold_dense=True)
+                    a.segsum_adam(N * world, None, vg, gbg, None, store.opt, dense_segs, blocks=blocks,
+                                  w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
 
         return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
 
@@ -337,7 +365,7 @@ def model_fn(features, labels, mode, params):
     training = mode == ModeKeys.TRAIN
     rate = params["dropout"]
     mk = params.get("_dropout_masks") or {}
-    if training and store.din is not None and store.dp is None and params.get("fused_step", True) and \
+    if training and store.din is not None and params.get("fused_step", True) and \
             params.get("fused_attention", True) and params.get("fused_head", True):
         return store.din.train_step(store, features, labels, params, params.get("_dropout_masks"))
 

@@ -270,8 +270,10 @@ class DataParallel:
         gw = out_row0[bucket_off + nb * a.D:bucket_off + nb * a.D + nb] if a.with_w1 else None
         self._bucket_segs = a.bucket_adam_segments(g, gw, replicas=self.world, stride=stride)
 
-    def send_bytes(self, b):
-        """Bytes one rank contributes to the step's gradient collective for a batch of b examples (reported by bench.py)."""
+    def send_bytes(self, b=None):
+        """Bytes one rank contributes to the step's gradient collective (reported by bench.py); b = units of the per-example
+        block (examples; din.py: entries = examples x (1 + history length)), default: those of the last exchange."""
+        b = getattr(self, "_last_b", 0) if b is None else b
         return 4 * (self._send_n0 + self._send_nbk + b * sum(self._send_widths))
 
     def send_views(self, b):
@@ -299,6 +301,7 @@ class DataParallel:
         all-reduces issued from inside backward; only the example block is exchanged and the third value is None."""
         from . import _lib
         n0, n, nbk = self._send_n0, self._send_dense.n, self._send_nbk
+        self._last_b = b
         L = b * sum(self._send_widths)
         d = self._send_dense
         big = n * 4 >= int(os.environ.get("RSX_DP_ALLREDUCE_MIN_BYTES", str(1024 * 1024)))

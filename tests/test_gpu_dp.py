@@ -186,3 +186,55 @@ def test_xdeepfm_blocked_data_parallel_equals_single_batch():
         assert float((ta - tb).abs().max()) < 2e-6, name
     assert float((a.store.embeddings["input_layer"].w1 - b.store.embeddings["input_layer"].w1).abs().max()) < 2e-6
     assert float((a.store.dense.flat - b.store.dense.flat).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("B,Pn,world,use_graph", [(24, 12, 2, False), (24, 12, 3, True), (96, 100, 2, False)])
+def test_din_fused_step_data_parallel_equals_single_batch(B, Pn, world, use_graph):
+    """din.py's fused TRAIN step under data parallelism (round 4; din/din.py:204-206 MirroredStrategy): `world` emulated
+    replicas of a batch -- keys all-gathered for ONE global dedup sort, [dense arena | value block | bias gradients] exchanged
+    straight from the send block, the scatter reading rank blocks in place -- must train like one process on the batch
+    repeated `world` times (entries are summed in rank-block order instead of targets-then-histories order: 2e-6).
+    (96, 100): 9 696 entries per rank, the multi-launch sort and the two-stage scatter."""
+    import numpy as np
+    import torch
+    from oracle import init
+    from recsys_amd import din, synthetic
+    from recsys_amd.dist import EmulatedDataParallel
+    from tests.parity_util import make_estimator
+    K, n_item, n_cate = 16, 300, 20
+    rng = np.random.default_rng(5)
+    P = init.din_params(2, K, n_item, n_cate, np.float32)
+    P["item_bias"] += (rng.standard_normal(n_item) * 0.01).astype(np.float32)
+    base = {"embedding_size": K, "learning_rate": 1e-3, "dropout": 0.0, "n_item": n_item, "n_cate": n_cate}
+    ests = []
+    for w in (world, 1):
+        est = make_estimator(din.model_fn, dict(base, max_batch_size=B * (1 if w > 1 else world)), use_graph=use_graph)
+        if w > 1:
+            est.store.dp = EmulatedDataParallel(w)
+        ests.append(est)
+    keys = ("i_id", "i_cate", "u_iid_seq", "u_icat_seq")
+    for step in range(3):
+        b = synthetic.din_batch(rng, B, Pn, n_item, n_cate)
+        b["i_id"][:2] = 0                                        # target id 0 trains like any row; the histories' 0 is padding
+        losses = []
+        for est, rep in zip(ests, (1, world)):
+            f = {k: torch.from_numpy(np.tile(b[k], (rep,) + (1,) * (b[k].ndim - 1))).cuda() for k in keys}
+            y = torch.from_numpy(np.tile(b["label"], rep)).cuda()
+            if not est.store.built:
+                with torch.no_grad():
+                    est._call_model_fn(f, None, "infer")
+                st = est.store
+                with torch.no_grad():
+                    st.embeddings["i_id"].table.copy_(torch.from_numpy(P["item_emb"]))
+                    st.embeddings["i_cate"].table.copy_(torch.from_numpy(P["cate_emb"]))
+                    st.embeddings["i_item"].table[:, 0].copy_(torch.from_numpy(P["item_bias"]))
+                st.dense.load({k: v for k, v in P.items() if k in st.dense.params})
+                assert st.din is not None
+            losses.append(float(est._train_step(f, y)))
+        assert abs(losses[0] - losses[1]) < 1e-6, losses
+    a, b2 = ests
+    for name in ("i_id", "i_cate", "i_item"):
+        ta, tb = a.store.embeddings[name], b2.store.embeddings[name]
+        assert float((ta.table - tb.table).abs().max()) < 2e-6, name
+        assert float((ta.m - tb.m).abs().max()) < 2e-6 and float((ta.v - tb.v).abs().max()) < 2e-6, name
+    assert float((a.store.dense.flat - b2.store.dense.flat).abs().max()) < 2e-6
