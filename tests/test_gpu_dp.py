@@ -21,6 +21,39 @@ for kind, graph, drop in (("deepfm", False, 0.5), ("deepfm", True, 0.0), ("dcn",
     assert err < 1e-5, (kind, err)
     assert all(abs(a - b) < 1e-5 for a, b in losses), (kind, losses)
     assert max(perr.values()) < 5e-5, (kind, perr)
+# din.py: the fused step through RCCL at world 1 (keys all-gather, send block, blocked scatter) against the single-replica step
+import numpy as np, torch
+from oracle import init
+from recsys_amd import din, synthetic, dist as rdist
+from tests.parity_util import make_estimator
+K, n_item, n_cate, B, Pn = 16, 300, 20, 24, 12
+rng = np.random.default_rng(5)
+P = init.din_params(2, K, n_item, n_cate, np.float32)
+base = {"embedding_size": K, "learning_rate": 1e-3, "dropout": 0.0, "n_item": n_item, "n_cate": n_cate, "max_batch_size": B}
+ests = []
+for use_dp in (True, False):
+    est = make_estimator(din.model_fn, dict(base), use_graph=use_dp)
+    if use_dp:
+        est.store.dp = est.dist = rdist.DataParallel()
+    ests.append(est)
+for step in range(3):
+    b = synthetic.din_batch(rng, B, Pn, n_item, n_cate)
+    losses = []
+    for est in ests:
+        f = {k: torch.from_numpy(b[k]).cuda() for k in ("i_id", "i_cate", "u_iid_seq", "u_icat_seq")}
+        if not est.store.built:
+            with torch.no_grad():
+                est._call_model_fn(f, None, "infer")
+            st = est.store
+            with torch.no_grad():
+                st.embeddings["i_id"].table.copy_(torch.from_numpy(P["item_emb"]))
+                st.embeddings["i_cate"].table.copy_(torch.from_numpy(P["cate_emb"]))
+            st.dense.load({k: v for k, v in P.items() if k in st.dense.params})
+        losses.append(float(est._train_step(f, torch.from_numpy(b["label"]).cuda())))
+    assert abs(losses[0] - losses[1]) < 1e-6, losses
+for name in ("i_id", "i_cate", "i_item"):
+    assert float((ests[0].store.embeddings[name].table - ests[1].store.embeddings[name].table).abs().max()) < 2e-6, name
+assert float((ests[0].store.dense.flat - ests[1].store.dense.flat).abs().max()) < 2e-6
 import torch.distributed as dist
 dist.destroy_process_group()
 print("DP_OK")
