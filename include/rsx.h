@@ -35,6 +35,8 @@ typedef enum {
 } rsx_status;
 
 int rsx_version(void);
+/* Kernel launches issued by this library in this process so far (a relaxed counter; bench.py derives launches per step). */
+unsigned long long rsx_dbg_launch_count(void);
 const char* rsx_strerror(int status);
 
 /* ---------------------------------------------------------------------------------------------

@@ -92,6 +92,7 @@ class AdamWindow(C.Structure):
 _P, _I, _U64, _F = C.c_void_p, C.c_int, C.c_uint64, C.c_float
 _SIGS = {
     "rsx_version": (C.c_int, []),
+    "rsx_dbg_launch_count": (C.c_uint64, []),
     "rsx_strerror": (C.c_char_p, [_I]),
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
     "rsx_gather_fm_fwd_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P, _P]),

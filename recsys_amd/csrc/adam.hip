@@ -39,7 +39,7 @@ extern "C" int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* s
   const int rc = adam_build_args(segs_h, nseg, state, lr, beta1, beta2, eps, a, &blocks);
   if (rc != RSX_OK) return rc;
   if (blocks == 0) return RSX_OK;
-  hipLaunchKernelGGL(adam_multi_k, dim3(blocks), dim3(ADAM_T), 0, rsx_s(stream), a);
+  RSX_LAUNCH(adam_multi_k, dim3(blocks), dim3(ADAM_T), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(ADAM_T, RSX_ADAM_WIN_OCC) void adam_window_k(const 
 }
 template <int NW>
 static void launch_window(const AdamSlice& s, hipStream_t st) {
-  hipLaunchKernelGGL(adam_window_k<NW>, dim3(s.n_blk), dim3(ADAM_T), 0, st, s);
+  RSX_LAUNCH(adam_window_k<NW>, dim3(s.n_blk), dim3(ADAM_T), 0, st, s);
 }
 
 extern "C" int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t stream) {
@@ -86,7 +86,7 @@ extern "C" int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t st
   if (s.n_blk == 0) return RSX_OK;
   const dim3 grid(s.n_blk), block(ADAM_T);
   switch (s.args.nw) {
-    case 0: hipLaunchKernelGGL(adam_slice_k, grid, block, 0, rsx_s(stream), s); break;
+    case 0: RSX_LAUNCH(adam_slice_k, grid, block, 0, rsx_s(stream), s); break;
     case 1: launch_window<1>(s, rsx_s(stream)); break;
     case 2: launch_window<2>(s, rsx_s(stream)); break;
     case 3: launch_window<3>(s, rsx_s(stream)); break;
@@ -168,14 +168,14 @@ extern "C" int rsx_adam_fast_math_selftest(unsigned long long* counts, uint32_t 
   if (!counts || div_iters < 0) return RSX_EINVAL;
   hipStream_t st = rsx_s(stream);
   if (hipMemsetAsync(counts, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return RSX_ELAUNCH;
-  hipLaunchKernelGGL(st_sqrt_k, dim3(4096), dim3(256), 0, st, (127u - 96u) << 23, (127u + 41u) << 23, counts);
+  RSX_LAUNCH(st_sqrt_k, dim3(4096), dim3(256), 0, st, (127u - 96u) << 23, (127u + 41u) << 23, counts);
   const int grid = 4096, block = 256;
-  if (div_iters > 0) hipLaunchKernelGGL(st_div_k, dim3(grid), dim3(block), 0, st, seed, div_iters, counts + 1);
+  if (div_iters > 0) RSX_LAUNCH(st_div_k, dim3(grid), dim3(block), 0, st, seed, div_iters, counts + 1);
   const unsigned long long pairs = 2ull * grid * block * (unsigned long long)div_iters;
   if (hipMemcpyAsync(counts + 2, &pairs, sizeof(pairs), hipMemcpyHostToDevice, st) != hipSuccess) return RSX_ELAUNCH;
   if (exhaustive_div) {
     for (uint32_t lo = 0; lo < (1u << 23); lo += (1u << 18)) {      // 32 launches of 2^18 denominators (~1 s each)
-      hipLaunchKernelGGL(st_div_all_k, dim3(1u << 18), dim3(256), 0, st, lo, counts + 3);
+      RSX_LAUNCH(st_div_all_k, dim3(1u << 18), dim3(256), 0, st, lo, counts + 3);
       if (hipStreamSynchronize(st) != hipSuccess) return RSX_ELAUNCH;
     }
   }

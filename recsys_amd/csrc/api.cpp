@@ -13,3 +13,6 @@ extern "C" const char* rsx_strerror(int status) {
     default: return "unknown rsx status";
   }
 }
+
+#include "rsx_launch_count.h"
+extern "C" unsigned long long rsx_dbg_launch_count(void) { return rsx_launches_g.load(std::memory_order_relaxed); }

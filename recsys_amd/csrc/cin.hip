@@ -672,8 +672,8 @@ extern "C" int rsx_cin_layer_fwd(const float* X0, const float* Xk, const float* 
   if (rcs != RSX_OK) return rcs;
   const unsigned gx = (unsigned)((N + 15) / 16);
   const dim3 grid(gx, p.nby + (p.sweep.n_blk + gx - 1) / gx);
-  if (H <= 48) hipLaunchKernelGGL(cin_fwd_k<12>, grid, dim3(256), lds, rsx_s(stream), p);
-  else hipLaunchKernelGGL(cin_fwd_k<32>, grid, dim3(256), lds, rsx_s(stream), p);
+  if (H <= 48) RSX_LAUNCH(cin_fwd_k<12>, grid, dim3(256), lds, rsx_s(stream), p);
+  else RSX_LAUNCH(cin_fwd_k<32>, grid, dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -706,11 +706,11 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
     if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
     float* part_ws = dpre_ws + (size_t)B * N * CIN_D;
     const dim3 grid(HT, (B + EB - 1) / EB), block(64 * EB * FS);
-    if (N <= 32) hipLaunchKernelGGL((cin_bwd_dx2_k<2, 4, 1>), grid, block, lds, rsx_s(stream), a, part_ws);
-    else hipLaunchKernelGGL((cin_bwd_dx2_k<8, 4, 1>), grid, block, lds, rsx_s(stream), a, part_ws);
+    if (N <= 32) RSX_LAUNCH((cin_bwd_dx2_k<2, 4, 1>), grid, block, lds, rsx_s(stream), a, part_ws);
+    else RSX_LAUNCH((cin_bwd_dx2_k<8, 4, 1>), grid, block, lds, rsx_s(stream), a, part_ws);
     RSX_CHECK_LAUNCH();
     const long long n4 = (long long)B * F * 4;
-    hipLaunchKernelGGL(cin_dx0_reduce_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, rsx_s(stream), part_ws, dX0, HT, n4,
+    RSX_LAUNCH(cin_dx0_reduce_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, rsx_s(stream), part_ws, dX0, HT, n4,
                        acc_dx0);
     RSX_CHECK_LAUNCH();
   } else {
@@ -725,8 +725,8 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
         return RSX_ELAUNCH;
     }
     const dim3 grid((B + CIN_BT - 1) / CIN_BT), block(64 * HT * FS);
-    if (N <= 32) hipLaunchKernelGGL(cin_bwd_dx_k<2>, grid, block, lds, rsx_s(stream), a);
-    else hipLaunchKernelGGL(cin_bwd_dx_k<8>, grid, block, lds, rsx_s(stream), a);
+    if (N <= 32) RSX_LAUNCH(cin_bwd_dx_k<2>, grid, block, lds, rsx_s(stream), a);
+    else RSX_LAUNCH(cin_bwd_dx_k<8>, grid, block, lds, rsx_s(stream), a);
     RSX_CHECK_LAUNCH();
   }
   // Wave tile = FT fields x 16 h x (NT x 16) n, NW waves split the batch.  The configuration is chosen for BALANCE first
@@ -754,11 +754,11 @@ extern "C" int rsx_cin_layer_bwd(const float* X0, const float* Xk, const float* 
   const unsigned zs = (w.sweep.n_blk + plane - 1) / plane;           // extra z-planes that carry the sweep
   const dim3 grid(gx, HT, w.FG + zs);
   switch (best) {
-    case 0: hipLaunchKernelGGL((cin_bwd_dw_k<5, 2, 8>), grid, dim3(512), 0, rsx_s(stream), w); break;
-    case 1: hipLaunchKernelGGL((cin_bwd_dw_k<5, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
-    case 2: hipLaunchKernelGGL((cin_bwd_dw_k<3, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
-    case 3: hipLaunchKernelGGL((cin_bwd_dw_k<2, 2, 8>), grid, dim3(512), 0, rsx_s(stream), w); break;
-    default: hipLaunchKernelGGL((cin_bwd_dw_k<2, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
+    case 0: RSX_LAUNCH((cin_bwd_dw_k<5, 2, 8>), grid, dim3(512), 0, rsx_s(stream), w); break;
+    case 1: RSX_LAUNCH((cin_bwd_dw_k<5, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
+    case 2: RSX_LAUNCH((cin_bwd_dw_k<3, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
+    case 3: RSX_LAUNCH((cin_bwd_dw_k<2, 2, 8>), grid, dim3(512), 0, rsx_s(stream), w); break;
+    default: RSX_LAUNCH((cin_bwd_dw_k<2, 1, 4>), grid, dim3(256), 0, rsx_s(stream), w); break;
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -911,7 +911,7 @@ extern "C" int rsx_cin_out_fwd(const float* const* outs_h, const int32_t* sizes_
   if (B == 0) return RSX_OK;
   if (!Wout || !bout || !y) return RSX_EINVAL;
   a.Wout = Wout; a.bout = bout; a.y = y;
-  hipLaunchKernelGGL(cin_out_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), a);
+  RSX_LAUNCH(cin_out_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -928,7 +928,7 @@ extern "C" int rsx_cin_out_bwd_lin(const float* const* outs_h, const int32_t* si
   a.logx = logx; a.g_lin = g_lin; a.dwnum = dwnum; a.nnum = nnum;
   int tiles = 0;
   for (int k = 0; k < L; ++k) tiles += (sizes_h[k] + 15) / 16;
-  hipLaunchKernelGGL(cin_out_bwd_k, dim3(tiles + 1 + (dwnum != nullptr ? 1 : 0)), dim3(1024), 0, rsx_s(stream), a);
+  RSX_LAUNCH(cin_out_bwd_k, dim3(tiles + 1 + (dwnum != nullptr ? 1 : 0)), dim3(1024), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -643,7 +643,7 @@ extern "C" int rsx_cin_prep_bf16(const float* W, void* w16, int F, int H, int N,
   bf16_t* b = a + (size_t)F * H16 * Np;
   const long long tot = (long long)F * H16 * Np + (long long)F * N16 * Hp;
   const unsigned blocks = (unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
-  hipLaunchKernelGGL(cin_prep_bf16_k, dim3(blocks), dim3(256), 0, rsx_s(stream), W, a, b, F, H, N, H16, N16, Hp, Np);
+  RSX_LAUNCH(cin_prep_bf16_k, dim3(blocks), dim3(256), 0, rsx_s(stream), W, a, b, F, H, N, H16, N16, Hp, Np);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -667,8 +667,8 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
   const size_t lds = ((size_t)E * F * CB_D + 4 * E * 256) * sizeof(float) + (size_t)E * 16 * (Hp + 8) * 2;
   if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
 #define RSX_CIN_FWD16(KS)                                                                                    \
-  if (E == 2) hipLaunchKernelGGL((cin_fwd_bf16_k<KS, 2>), grid, dim3(256), lds, rsx_s(stream), a);          \
-  else hipLaunchKernelGGL((cin_fwd_bf16_k<KS, 4>), grid, dim3(256), lds, rsx_s(stream), a)
+  if (E == 2) RSX_LAUNCH((cin_fwd_bf16_k<KS, 2>), grid, dim3(256), lds, rsx_s(stream), a);          \
+  else RSX_LAUNCH((cin_fwd_bf16_k<KS, 4>), grid, dim3(256), lds, rsx_s(stream), a)
   switch (Hp / 32) {
     case 1: RSX_CIN_FWD16(1); break;
     case 2: RSX_CIN_FWD16(2); break;
@@ -711,10 +711,10 @@ static int cb_launch_dx(const float* X0, const float* Xk, const void* w16, const
   if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return RSX_ELAUNCH;
   switch (Np / 32) {
-    case 1: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<1>, grid, block, lds, rsx_s(stream), a); break;
-    case 2: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<2>, grid, block, lds, rsx_s(stream), a); break;
-    case 3: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<3>, grid, block, lds, rsx_s(stream), a); break;
-    default: hipLaunchKernelGGL(cin_bwd_dx_bf16_k<4>, grid, block, lds, rsx_s(stream), a); break;
+    case 1: RSX_LAUNCH(cin_bwd_dx_bf16_k<1>, grid, block, lds, rsx_s(stream), a); break;
+    case 2: RSX_LAUNCH(cin_bwd_dx_bf16_k<2>, grid, block, lds, rsx_s(stream), a); break;
+    case 3: RSX_LAUNCH(cin_bwd_dx_bf16_k<3>, grid, block, lds, rsx_s(stream), a); break;
+    default: RSX_LAUNCH(cin_bwd_dx_bf16_k<4>, grid, block, lds, rsx_s(stream), a); break;
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -748,9 +748,9 @@ static int cb_launch_dw_t(const float* X0, const rsx_cin_dw_job* jobs_h, int njo
   static const int x0l_env = getenv("RSX_CIN_DW16_X0L") ? atoi(getenv("RSX_CIN_DW16_X0L")) : 1;
   if (x0l_env != 0 && x0_bytes <= 64 * 1024) {
     const size_t lds = red_bytes > x0_bytes ? red_bytes : x0_bytes;
-    hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT, true>), dim3(grid), dim3(512), lds, rsx_s(stream), w);
+    RSX_LAUNCH((cin_bwd_dw_bf16_k<FT, NT, true>), dim3(grid), dim3(512), lds, rsx_s(stream), w);
   } else {
-    hipLaunchKernelGGL((cin_bwd_dw_bf16_k<FT, NT, false>), dim3(grid), dim3(512), red_bytes, rsx_s(stream), w);
+    RSX_LAUNCH((cin_bwd_dw_bf16_k<FT, NT, false>), dim3(grid), dim3(512), red_bytes, rsx_s(stream), w);
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -808,7 +808,7 @@ extern "C" int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16
   }
   const long long quads = tot >> 3;
   const unsigned blocks = (unsigned)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
-  hipLaunchKernelGGL(cin_prep_multi_k, dim3(blocks), dim3(256), 0, rsx_s(stream), a);
+  RSX_LAUNCH(cin_prep_multi_k, dim3(blocks), dim3(256), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

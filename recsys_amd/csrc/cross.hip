@@ -349,7 +349,7 @@ extern "C" int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, c
   if (!x0 || !W || !Bc || !s || (cz != nullptr && wout == nullptr)) return RSX_EINVAL;
   if (dim % 4 != 0 || dim > 256 * CROSS_NV || L > CROSS_MAX_L) return RSX_EUNSUPPORTED;
   CrossFwdArgs p{x0, W, Bc, wout, s, xL, cz, B, dim, L};
-  hipLaunchKernelGGL(cross_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), p);
+  RSX_LAUNCH(cross_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -393,7 +393,7 @@ extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(RT), dim3(256), lds4, rsx_s(stream), p, epw);
+      RSX_LAUNCH(kern, dim3(RT), dim3(256), lds4, rsx_s(stream), p, epw);
     };
     switch (L) {
       case 1: launch(cross_bwd4_k<1>); break;
@@ -405,11 +405,11 @@ extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, c
     RT = (B + epw - 1) / epw;
     const size_t lds = (size_t)(2 * L + 1) * dim * sizeof(float);
     if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
-    hipLaunchKernelGGL(cross_bwd_k, dim3(RT), dim3(64), lds, rsx_s(stream), p, epw);
+    RSX_LAUNCH(cross_bwd_k, dim3(RT), dim3(64), lds, rsx_s(stream), p, epw);
   }
   RSX_CHECK_LAUNCH();
   const int n = (2 * L + 1) * dim;
-  hipLaunchKernelGGL(cross_reduce_k, dim3((n + 15) / 16), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,
+  RSX_LAUNCH(cross_reduce_k, dim3((n + 15) / 16), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,
                      L, dim);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

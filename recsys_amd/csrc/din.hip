@@ -220,12 +220,12 @@ __global__ __launch_bounds__(256) void sorted_long_lists_k(const int32_t* __rest
 template <int K>
 static void launch_pool_fwd(hipStream_t st, const float* H, const float* w, const int32_t* ids, float* out, int B, int P,
                             int ldo) {
-  din_pool_fwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, out, B, P, ldo);
+  RSX_COUNT_LAUNCH(); din_pool_fwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, out, B, P, ldo);
 }
 template <int K>
 static void launch_pool_bwd(hipStream_t st, const float* H, const float* w, const int32_t* ids, const float* dout,
                             float* dH, float* dw, int acc, int B, int P, int ldg, int ldh) {
-  din_pool_bwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, dout, dH, dw, acc, B, P, ldg, ldh);
+  RSX_COUNT_LAUNCH(); din_pool_bwd_k<K><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(H, w, ids, dout, dH, dw, acc, B, P, ldg, ldh);
 }
 
 extern "C" int rsx_din_pool_fwd_ld(const float* H, const float* w, const int32_t* ids, float* out, int B, int P, int K,
@@ -251,12 +251,12 @@ extern "C" int rsx_din_pool_fwd(const float* H, const float* w, const int32_t* i
 
 template <int K>
 static void launch_pool_fwd_pair(hipStream_t st, const PoolFwdSet& a, const PoolFwdSet& b, int B, int P, int ldo) {
-  din_pool_fwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, B, P, ldo);
+  RSX_COUNT_LAUNCH(); din_pool_fwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, B, P, ldo);
 }
 template <int K>
 static void launch_pool_bwd_pair(hipStream_t st, const PoolBwdSet& a, const PoolBwdSet& b, int acc, int B, int P, int ldg,
                                  int ldh) {
-  din_pool_bwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, acc, B, P, ldg, ldh);
+  RSX_COUNT_LAUNCH(); din_pool_bwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, acc, B, P, ldg, ldh);
 }
 extern "C" int rsx_din_pool_fwd_pair(const float* H0, const float* w0, const int32_t* ids0, float* out0, const float* H1,
                                      const float* w1, const int32_t* ids1, float* out1, int B, int P, int K, int ld_out,
@@ -368,7 +368,7 @@ extern "C" int rsx_gather_rows_multi(const rsx_gather_job* jobs_h, int njobs, rs
     g.blk_end[k] = end;
   }
   if (end == 0) return RSX_OK;
-  hipLaunchKernelGGL(gather_rows_multi_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
+  RSX_LAUNCH(gather_rows_multi_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -400,7 +400,7 @@ extern "C" int rsx_din_keys(const int32_t* i_id, const int32_t* i_cate, const in
   if (B == 0) return RSX_OK;
   if (!i_id || !i_cate || !hist_i || !hist_c || !keys2) return RSX_EINVAL;
   const long long n = (long long)B * (P + 1);
-  hipLaunchKernelGGL(din_keys_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, rsx_s(stream), i_id, i_cate, hist_i, hist_c, B,
+  RSX_LAUNCH(din_keys_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, rsx_s(stream), i_id, i_cate, hist_i, hist_c, B,
                      (long long)B * P, dummy_item_row, dummy_cate_row, keys2);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -414,14 +414,14 @@ extern "C" int rsx_sorted_segments(const int32_t* sorted_keys, int N, int32_t* u
   if (segid != nullptr && stride < N) return RSX_EINVAL;
   const int nblk = N > 0 ? (N + SS_BLK - 1) / SS_BLK : 1;
   int32_t* cnt = segid != nullptr ? segid + stride : nullptr;       // [2] counts, then the list [ceil(N/16)]
-  hipLaunchKernelGGL(sorted_heads_k, dim3(nblk), dim3(SS_T), 0, rsx_s(stream), sorted_keys, N, uniq_row, nuniq, slot,
+  RSX_LAUNCH(sorted_heads_k, dim3(nblk), dim3(SS_T), 0, rsx_s(stream), sorted_keys, N, uniq_row, nuniq, slot,
                      scratch, cnt);
   RSX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sorted_emit_k, dim3(nblk), dim3(SS_T), 0, rsx_s(stream), sorted_keys, N, uniq_row, seg_off, nuniq,
+  RSX_LAUNCH(sorted_emit_k, dim3(nblk), dim3(SS_T), 0, rsx_s(stream), sorted_keys, N, uniq_row, seg_off, nuniq,
                      slot, segid, scratch);
   RSX_CHECK_LAUNCH();
   if (segid != nullptr && N > 0) {
-    hipLaunchKernelGGL(sorted_long_lists_k, dim3((N + 255) / 256), dim3(256), 0, rsx_s(stream), seg_off, nuniq, cnt,
+    RSX_LAUNCH(sorted_long_lists_k, dim3((N + 255) / 256), dim3(256), 0, rsx_s(stream), seg_off, nuniq, cnt,
                        cnt + 2, (N + 15) / 16);
     RSX_CHECK_LAUNCH();
   }

@@ -231,13 +231,13 @@ extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0,
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_k<2, 5, 3>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return RSX_EUNSUPPORTED;
-    hipLaunchKernelGGL((din_attn_fwd_k<2, 5, 3>), grid, block, lds, rsx_s(stream), p);
+    RSX_LAUNCH((din_attn_fwd_k<2, 5, 3>), grid, block, lds, rsx_s(stream), p);
   } else {
     const size_t lds = attn_fwd_lds_floats(1, 5, 3) * sizeof(float);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_k<1, 5, 3>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return RSX_EUNSUPPORTED;
-    hipLaunchKernelGGL((din_attn_fwd_k<1, 5, 3>), grid, block, lds, rsx_s(stream), p);
+    RSX_LAUNCH((din_attn_fwd_k<1, 5, 3>), grid, block, lds, rsx_s(stream), p);
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -821,8 +821,8 @@ extern "C" int rsx_din_prepare2(const int32_t* i_id, const int32_t* i_cate, cons
   DinPrep p{{hist_i, hist_c}, {rows_i, rows_c}, {count_i, count_c}, {w_i, w_c}, i_id, i_cate, keys2, B, (int)M,
             {dummy_item_row, dummy_cate_row}, keys_field_stride, labels_i64, labels_f32};
   const int nt = (int)((M + 1023) / 1024);
-  hipLaunchKernelGGL(din_prep_counts_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
-  hipLaunchKernelGGL(din_prep_rows_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
+  RSX_LAUNCH(din_prep_counts_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
+  RSX_LAUNCH(din_prep_rows_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -842,8 +842,8 @@ extern "C" int rsx_din_valid_rows(const int32_t* ids, int B, int P, int32_t* row
   const long long M = (long long)B * P;
   if (M > (1ll << 24)) return RSX_EUNSUPPORTED;
   const int nt = M == 0 ? 1 : (int)((M + 1023) / 1024);
-  hipLaunchKernelGGL(din_tile_counts_k, dim3(nt), dim3(256), 0, rsx_s(stream), ids, (int)M, count + 1);
-  hipLaunchKernelGGL(din_valid_rows_k, dim3(nt), dim3(256), 0, rsx_s(stream), ids, (int)M, rows, count, count + 1,
+  RSX_LAUNCH(din_tile_counts_k, dim3(nt), dim3(256), 0, rsx_s(stream), ids, (int)M, count + 1);
+  RSX_LAUNCH(din_valid_rows_k, dim3(nt), dim3(256), 0, rsx_s(stream), ids, (int)M, rows, count, count + 1,
                      w_zero_padded);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -867,7 +867,7 @@ static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_k<KB, NT1, NT2>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess || fl * sizeof(float) > 160 * 1024) return RSX_EUNSUPPORTED;
-  hipLaunchKernelGGL((din_attn_bwd_k<KB, NT1, NT2>), dim3(G), dim3(512), fl * sizeof(float), st, p);
+  RSX_LAUNCH((din_attn_bwd_k<KB, NT1, NT2>), dim3(G), dim3(512), fl * sizeof(float), st, p);
   return RSX_OK;
 }
 
@@ -908,7 +908,7 @@ static int attn_bwd_impl(const float* H, const float* q, const float* W0, const 
   if (!finish) return RSX_OK;
   const int n = (int)attn_npart(K, N1, N2);
   const int nr = (n + 63) / 64;
-  hipLaunchKernelGGL(din_attn_finish_k, dim3(nr + (B + 3) / 4), dim3(1024), 0, st, p.part, G, n, grads, nr, p.dqr, dq, B, P, K,
+  RSX_LAUNCH(din_attn_finish_k, dim3(nr + (B + 3) / 4), dim3(1024), 0, st, p.part, G, n, grads, nr, p.dqr, dq, B, P, K,
                      rows ? ids : nullptr, ld_dq, dq_add, ld_dq_add);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -951,7 +951,7 @@ extern "C" int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, 
   // workspace layout of the backward launch: [M, K] per-row query gradients, then the G partials
   const AttnFinishSet s0{workspace0 + (size_t)M * K, grads0, workspace0, dq0, ids0, dq_add0};
   const AttnFinishSet s1{workspace1 + (size_t)M * K, grads1, workspace1, dq1, ids1, dq_add1};
-  hipLaunchKernelGGL(din_attn_finish_pair_k, dim3(nr + (B + 3) / 4, 2), dim3(1024), 0, rsx_s(stream), s0, s1, G, n, nr, B, P, K,
+  RSX_LAUNCH(din_attn_finish_pair_k, dim3(nr + (B + 3) / 4, 2), dim3(1024), 0, rsx_s(stream), s0, s1, G, n, nr, B, P, K,
                      ld_dq, ld_dq_add);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -1549,7 +1549,7 @@ template <int D>
 static void launch_gather(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* w1,
                           const int32_t* row_off, const int32_t* ids, float* E, float* S, float* y1, float* y2,
                           uint64_t mask, int B, int F) {
-  gather_fm_fwd_k<D><<<grid, block, 0, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F);
+  RSX_COUNT_LAUNCH(); gather_fm_fwd_k<D><<<grid, block, 0, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F);
 }
 template <int D>
 static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
@@ -1557,7 +1557,7 @@ static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* ta
                           const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
                           int F, int stride, int null_row, const SegPartials& part, const ExBlocks& xb) {
   const size_t lds = part.lds_mode ? seg_lds_bytes(B, D) : 0;
-  segsum_bwd_k<D><<<grid, block, lds, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
+  RSX_COUNT_LAUNCH(); segsum_bwd_k<D><<<grid, block, lds, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
                                             stride, null_row, part, xb);
 }
 template <int D>
@@ -1567,6 +1567,7 @@ static void launch_tiles(dim3 grid, hipStream_t st, const float* tables, const f
   constexpr size_t lds = SegTile<D / 4>::lds_bytes;
 #define RSX_TILES(FM, W1) \
   segsum_tiles_k<D, FM, W1><<<grid, dim3(256), lds, st>>>(tables, S, dX, gy1, gy2, perm, uniq_row, ws, mask, B, F, stride, null_row, xb)
+  RSX_COUNT_LAUNCH();
   if (gy2 != nullptr) {
     if (gy1 != nullptr) RSX_TILES(true, true); else RSX_TILES(true, false);
   } else {
@@ -1597,7 +1598,7 @@ static inline int seg_partials(const rsx_seg_partials* h, bool need_p1, SegParti
 template <int D>
 static void launch_gather_rows(dim3 grid, dim3 block, hipStream_t st, const float* tables, const int32_t* row_off,
                                const int32_t* ids, float* E, long long n) {
-  gather_rows_k<D><<<grid, block, 0, st>>>(tables, row_off, ids, E, n);
+  RSX_COUNT_LAUNCH(); gather_rows_k<D><<<grid, block, 0, st>>>(tables, row_off, ids, E, n);
 }
 
 extern "C" int rsx_gather_fm_fwd(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
@@ -1627,7 +1628,7 @@ template <int D>
 static void launch_gather_sort(dim3 grid, size_t lds, hipStream_t st, const float* tables, const float* w1,
                                const int32_t* row_off, const int32_t* ids, float* E, float* S, float* y1, float* y2,
                                uint64_t mask, int B, int F, int n_gather, const SortArgs& sort) {
-  gather_fm_sort_k<D><<<grid, dim3(256), lds, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F, n_gather, sort);
+  RSX_COUNT_LAUNCH(); gather_fm_sort_k<D><<<grid, dim3(256), lds, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F, n_gather, sort);
 }
 
 extern "C" int rsx_gather_fm_fwd_sort(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
@@ -1651,7 +1652,7 @@ extern "C" int rsx_gather_fm_fwd_sort(const float* tables, const float* w1, cons
 
 template <int D>
 static void launch_bucket(dim3 grid, hipStream_t st, const BucketArgs& a) {
-  bucket_scatter_k<D><<<grid, dim3(256), 0, st>>>(a);
+  RSX_COUNT_LAUNCH(); bucket_scatter_k<D><<<grid, dim3(256), 0, st>>>(a);
 }
 
 extern "C" int rsx_bucket_scatter(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
@@ -1689,7 +1690,7 @@ extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_
         hipFuncSetAttribute(reinterpret_cast<const void*>(field_sort_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return RSX_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL(field_sort_k, dim3(F), dim3(T), lds, rsx_s(stream), a);
+  RSX_LAUNCH(field_sort_k, dim3(F), dim3(T), lds, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1723,7 +1724,7 @@ extern "C" int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_s
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return RSX_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL(field_sort_multi_k, dim3((unsigned)jobs_h[0].F, (unsigned)njobs), dim3(T), lds, rsx_s(stream), m);
+  RSX_LAUNCH(field_sort_multi_k, dim3((unsigned)jobs_h[0].F, (unsigned)njobs), dim3(T), lds, rsx_s(stream), m);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1797,6 +1798,7 @@ static void launch_segsum_adam(dim3 grid, dim3 block, hipStream_t st, const floa
   const size_t lds = part.lds_mode ? seg_lds_bytes(B, D) : 0;
   // (the window pass's rows per lane group as a template parameter: one instantiation holding both forms ran at 199
   // registers instead of 159 and DeepFM's step 3 % slower)
+  RSX_COUNT_LAUNCH();
   if (h.win_nr == 4)
     segsum_adam_k<D, 4><<<grid, block, lds, st>>>(S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, mask, B, F, stride, h, part,
                                                   xb);
@@ -1923,7 +1925,7 @@ extern "C" int rsx_copy_bytes(void* dst, const void* src, size_t nbytes, rsx_str
   if (!dst || !src || (nbytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return RSX_EINVAL;
   const size_t n16 = nbytes >> 4;
   const size_t blocks = (n16 + 255) / 256;
-  hipLaunchKernelGGL(copy_bytes_k, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, rsx_s(stream),
+  RSX_LAUNCH(copy_bytes_k, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, rsx_s(stream),
                      static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -77,7 +77,7 @@ extern "C" int rsx_eval_metrics_update(const float* prob, const float* labels, c
   if (B == 0) return RSX_OK;
   int blocks = (B + MET_T - 1) / MET_T;
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(eval_metrics_k, dim3(blocks), dim3(MET_T), 0, rsx_s(stream), prob, labels, thresholds,
+  RSX_LAUNCH(eval_metrics_k, dim3(blocks), dim3(MET_T), 0, rsx_s(stream), prob, labels, thresholds,
                      num_thresholds, batch_loss, reinterpret_cast<unsigned long long*>(state), B);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

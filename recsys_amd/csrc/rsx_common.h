@@ -14,6 +14,16 @@
 
 static inline hipStream_t rsx_s(rsx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Every kernel launch of the library is counted (a relaxed process-wide counter, read by rsx_dbg_launch_count): bench.py
+// reports launches per step from it -- at batch 256 the step IS the sum of its dependent launches.
+#include "rsx_launch_count.h"
+#define RSX_COUNT_LAUNCH() rsx_launches_g.fetch_add(1ull, std::memory_order_relaxed)
+#define RSX_LAUNCH(...)                \
+  do {                                 \
+    RSX_COUNT_LAUNCH();                \
+    hipLaunchKernelGGL(__VA_ARGS__);   \
+  } while (0)
+
 // A zero float4 is always this literal.  A NAMED zero (`const float4 z = make_float4(0, 0, 0, 0)`) that is selected against
 // (`ok ? load : z`) is placed in scratch memory by this toolchain; every use reloads it and waits with `s_waitcnt
 // vmcnt(0)` -- i.e. for every load AND store in flight (found with phase stamps in segsum_tiles_k: 5.6 us for 16

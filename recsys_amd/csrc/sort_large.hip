@@ -393,13 +393,13 @@ static int field_sort_large_impl(const int32_t* ids, int32_t* idsT_caller, const
   a.src0 = F == 1 ? ids : a.idsT;
   a.fuse_scan = a.dtot != nullptr && a.nT <= 64;
   if (idsT_caller != nullptr) a.src0 = idsT_caller;
-  else if (F > 1) hipLaunchKernelGGL(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
+  else if (F > 1) RSX_LAUNCH(ls_transpose_k, dim3((B + 31) / 32, (F + 31) / 32), dim3(1024), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
-    hipLaunchKernelGGL(ls_hist_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
+    RSX_LAUNCH(ls_hist_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
     if (a.fuse_scan) {}      // the scatter workgroups derive their offsets themselves
-    else if (F >= 16) hipLaunchKernelGGL(ls_scan_field_k, dim3(F), dim3(LS_BINS), 0, st, a);
-    else hipLaunchKernelGGL(ls_scan_k, dim3((unsigned)((F * LS_BINS + 3) / 4)), dim3(256), 0, st, a, pass);
-    hipLaunchKernelGGL(ls_scatter_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
+    else if (F >= 16) RSX_LAUNCH(ls_scan_field_k, dim3(F), dim3(LS_BINS), 0, st, a);
+    else RSX_LAUNCH(ls_scan_k, dim3((unsigned)((F * LS_BINS + 3) / 4)), dim3(256), 0, st, a, pass);
+    RSX_LAUNCH(ls_scatter_k, dim3(a.nT, F), dim3(LS_T), 0, st, a, pass);
   }
   RSX_CHECK_LAUNCH();
   LargeSeg g;
@@ -409,9 +409,9 @@ static int field_sort_large_impl(const int32_t* ids, int32_t* idsT_caller, const
   g.blk_cnt = a.hist + (size_t)F * LS_BINS * nT_cap;
   // (a.dtot sits after blk_cnt's F * nblk ints)
   g.B = B; g.F = F; g.stride = stride; g.nblk = (B + SG_BLK - 1) / SG_BLK;
-  hipLaunchKernelGGL(ls_heads_k, dim3(g.nblk, F), dim3(SG_T), 0, st, g);
-  hipLaunchKernelGGL(ls_emit_k, dim3(g.nblk, F), dim3(SG_T), 0, st, g);
-  if (segid != nullptr) hipLaunchKernelGGL(ls_long_lists_k, dim3((B + 255) / 256, F), dim3(256), 0, st, g);
+  RSX_LAUNCH(ls_heads_k, dim3(g.nblk, F), dim3(SG_T), 0, st, g);
+  RSX_LAUNCH(ls_emit_k, dim3(g.nblk, F), dim3(SG_T), 0, st, g);
+  if (segid != nullptr) RSX_LAUNCH(ls_long_lists_k, dim3((B + 255) / 256, F), dim3(256), 0, st, g);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -1757,7 +1757,7 @@ extern "C" int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njo
     g.j[k] = j;
     g.blk_end[k] = end;
   }
-  hipLaunchKernelGGL(tower_reduce_dw_jobs_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
+  RSX_LAUNCH(tower_reduce_dw_jobs_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1771,7 +1771,7 @@ extern "C" int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_
   if (B <= 512) return RSX_OK;   // small batches: consumers sum the <= 32 partials themselves
   if (!stat) return RSX_EINVAL;
   const int RT = (B + TM - 1) / TM;
-  hipLaunchKernelGGL(tower_reduce_partials_k, dim3((2 * N + 63) / 64), dim3(1024), 0, rsx_s(stream), stat, RT, 2 * N);
+  RSX_LAUNCH(tower_reduce_partials_k, dim3((2 * N + 63) / 64), dim3(1024), 0, rsx_s(stream), stat, RT, 2 * N);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1824,8 +1824,8 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
     const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
 #define RSX_FWD_BIG(NTW)                                                                                      \
   do {                                                                                                        \
-    if (rid) hipLaunchKernelGGL((tower_fwd_big_k<NTW, true>), grid, dim3(256), l2, rsx_s(stream), p);         \
-    else hipLaunchKernelGGL((tower_fwd_big_k<NTW, false>), grid, dim3(256), l2, rsx_s(stream), p);            \
+    if (rid) RSX_LAUNCH((tower_fwd_big_k<NTW, true>), grid, dim3(256), l2, rsx_s(stream), p);         \
+    else RSX_LAUNCH((tower_fwd_big_k<NTW, false>), grid, dim3(256), l2, rsx_s(stream), p);            \
   } while (0)
     if (N <= 64) RSX_FWD_BIG(1);
     else if (N <= 128) RSX_FWD_BIG(2);
@@ -1836,9 +1836,9 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
     return RSX_OK;
   }
   if (p.n_sort + (int)p.sweep.n_blk > 0)
-    hipLaunchKernelGGL(tower_fwd_k<true>, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
+    RSX_LAUNCH(tower_fwd_k<true>, dim3(p.n_own + p.n_sort + p.sweep.n_blk), dim3(256), lds, rsx_s(stream), p);
   else
-    hipLaunchKernelGGL(tower_fwd_k<false>, dim3(p.n_own), dim3(256), lds, rsx_s(stream), p);
+    RSX_LAUNCH(tower_fwd_k<false>, dim3(p.n_own), dim3(256), lds, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1877,11 +1877,11 @@ extern "C" int rsx_gather_tower_fwd0(const float* tables, const float* w1, const
   const dim3 grid(p.n_own + g.n_gout + p.n_sort + p.sweep.n_blk);
   const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
   if (F <= 40) {
-    if (rid) hipLaunchKernelGGL((tower_gather_fwd_k<10, true>), grid, dim3(256), lds, rsx_s(stream), g);
-    else hipLaunchKernelGGL((tower_gather_fwd_k<10, false>), grid, dim3(256), lds, rsx_s(stream), g);
+    if (rid) RSX_LAUNCH((tower_gather_fwd_k<10, true>), grid, dim3(256), lds, rsx_s(stream), g);
+    else RSX_LAUNCH((tower_gather_fwd_k<10, false>), grid, dim3(256), lds, rsx_s(stream), g);
   } else {
-    if (rid) hipLaunchKernelGGL((tower_gather_fwd_k<16, true>), grid, dim3(256), lds, rsx_s(stream), g);
-    else hipLaunchKernelGGL((tower_gather_fwd_k<16, false>), grid, dim3(256), lds, rsx_s(stream), g);
+    if (rid) RSX_LAUNCH((tower_gather_fwd_k<16, true>), grid, dim3(256), lds, rsx_s(stream), g);
+    else RSX_LAUNCH((tower_gather_fwd_k<16, false>), grid, dim3(256), lds, rsx_s(stream), g);
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -1922,8 +1922,8 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   const bool rid = p.sweep.n_blk > 0;
 #define RSX_HEAD(CPL)                                                                                   \
   do {                                                                                                  \
-    if (rid) hipLaunchKernelGGL((tower_head_k<CPL, true>), grid, dim3(256), 0, rsx_s(stream), p);      \
-    else hipLaunchKernelGGL((tower_head_k<CPL, false>), grid, dim3(256), 0, rsx_s(stream), p);         \
+    if (rid) RSX_LAUNCH((tower_head_k<CPL, true>), grid, dim3(256), 0, rsx_s(stream), p);      \
+    else RSX_LAUNCH((tower_head_k<CPL, false>), grid, dim3(256), 0, rsx_s(stream), p);         \
   } while (0)
   if (N <= 64) RSX_HEAD(4);
   else if (N <= 128) RSX_HEAD(8);
@@ -1998,7 +1998,7 @@ extern "C" int rsx_fm_head(const float* y1, const float* y2, const float* c0, co
   FmHeadArgs p{y1, y2, c0, wo, bo, labels, prob, gy1, gy2, dwo, dbo, dc0, loss, loss_scale, B, {}};
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
-  hipLaunchKernelGGL(fm_head_k, dim3(1 + p.sweep.n_blk), dim3(256), 0, rsx_s(stream), p);
+  RSX_LAUNCH(fm_head_k, dim3(1 + p.sweep.n_blk), dim3(256), 0, rsx_s(stream), p);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -2136,8 +2136,8 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
     const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
 #define RSX_BWD_BIG(NTX, NTD)                                                                                 \
   do {                                                                                                        \
-    if (rid) hipLaunchKernelGGL((tower_bwd_big_k<NTX, NTD, true>), grid, dim3(256), lds, rsx_s(stream), p);   \
-    else hipLaunchKernelGGL((tower_bwd_big_k<NTX, NTD, false>), grid, dim3(256), lds, rsx_s(stream), p);      \
+    if (rid) RSX_LAUNCH((tower_bwd_big_k<NTX, NTD, true>), grid, dim3(256), lds, rsx_s(stream), p);   \
+    else RSX_LAUNCH((tower_bwd_big_k<NTX, NTD, false>), grid, dim3(256), lds, rsx_s(stream), p);      \
   } while (0)
     if (N <= 64) { if (wide) RSX_BWD_BIG(5, 4); else RSX_BWD_BIG(2, 4); }
     else { if (wide) RSX_BWD_BIG(5, 8); else RSX_BWD_BIG(2, 8); }
@@ -2148,7 +2148,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
       *reduce_out = rsx_dw_reduce_job{dw_partials, dW, db, p.sb, K, N, 1};
       return RSX_OK;
     }
-    hipLaunchKernelGGL(tower_reduce_dw_big_k, dim3((unsigned)(((size_t)KR * NP / 4 + 255) / 256)), dim3(256), 0, rsx_s(stream),
+    RSX_LAUNCH(tower_reduce_dw_big_k, dim3((unsigned)(((size_t)KR * NP / 4 + 255) / 256)), dim3(256), 0, rsx_s(stream),
                        dw_partials, dW, db, p.sb, K, N, KR, NP);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -2156,11 +2156,11 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
   const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;        // (no riders: the variant with their code compiled out)
   if (p.sb > 1) {
-    if (rid) hipLaunchKernelGGL((tower_bwd_k<true, true>), dim3(total), dim3(256), lds, rsx_s(stream), p);
-    else hipLaunchKernelGGL((tower_bwd_k<true, false>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+    if (rid) RSX_LAUNCH((tower_bwd_k<true, true>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+    else RSX_LAUNCH((tower_bwd_k<true, false>), dim3(total), dim3(256), lds, rsx_s(stream), p);
   } else {
-    if (rid) hipLaunchKernelGGL((tower_bwd_k<false, true>), dim3(total), dim3(256), lds, rsx_s(stream), p);
-    else hipLaunchKernelGGL((tower_bwd_k<false, false>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+    if (rid) RSX_LAUNCH((tower_bwd_k<false, true>), dim3(total), dim3(256), lds, rsx_s(stream), p);
+    else RSX_LAUNCH((tower_bwd_k<false, false>), dim3(total), dim3(256), lds, rsx_s(stream), p);
   }
   RSX_CHECK_LAUNCH();
   if (p.sb > 1) {
@@ -2168,7 +2168,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
       *reduce_out = rsx_dw_reduce_job{dw_partials, dW, db, p.sb, K, N, 0};
       return RSX_OK;
     }
-    hipLaunchKernelGGL(tower_reduce_dw_k, dim3(p.ct_k1 * p.ct_n), dim3(256), 0, rsx_s(stream), dw_partials, dW, db, p.sb,
+    RSX_LAUNCH(tower_reduce_dw_k, dim3(p.ct_k1 * p.ct_n), dim3(256), 0, rsx_s(stream), dw_partials, dW, db, p.sb,
                        p.ct_n, K, N);
     RSX_CHECK_LAUNCH();
   }

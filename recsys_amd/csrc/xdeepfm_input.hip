@@ -67,7 +67,7 @@ template <int D>
 static void launch_two(dim3 grid, dim3 block, hipStream_t st, const float* t1, const float* w1, const float* t2,
                        const int32_t* row_off, const int32_t* ids, const float* nx, const float* nw, float* E1, float* E2,
                        float* y1, uint64_t mask, int B, int F, int ND) {
-  gather_two_fwd_k<D><<<grid, block, 0, st>>>(t1, w1, t2, row_off, ids, nx, nw, E1, E2, y1, mask, B, F, ND);
+  RSX_COUNT_LAUNCH(); gather_two_fwd_k<D><<<grid, block, 0, st>>>(t1, w1, t2, row_off, ids, nx, nw, E1, E2, y1, mask, B, F, ND);
 }
 
 extern "C" int rsx_gather_two_fwd(const float* tables1, const float* w1, const float* tables2, const int32_t* row_off,
