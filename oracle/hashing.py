@@ -34,6 +34,11 @@ offline (neither the table nor its generator is on this image): those two
 branches rest on two independently written implementations (this file and
 recsys_amd/csrc/host_ingest.cpp) agreeing on 10^6 random strings.
 
+Round 4: every shared object on the image (site-packages, /usr/lib, /opt/rocm, 400+ files over 1 MB)
+was scanned once more -- `nm -D` for exported Fingerprint64 / farmhash / Hash64 symbols and `strings` for "farmhash" -- and
+nothing but this repository's own librsx.so carries one.  There is no external vector for the 33-64 and > 64-byte branches to
+be had here; the question is closed until a TensorFlow or google/farmhash build is available.
+
 Test infrastructure only (see oracle/__init__.py).
 """
 import struct
