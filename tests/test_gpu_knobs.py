@@ -1,0 +1,67 @@
+"""Every RSX_* A/B knob of the training step flipped ONCE against the default schedule: a knob that only
+changes how the same arithmetic is scheduled (which launch carries the sort, how long a window is, fused or separate gather,
+LDS or register staging ...) must leave every variable and optimizer slot BIT-identical; a knob that changes a summation
+order (tile shapes of the MFMA kernels) must stay within fp32 rounding of it.  One subprocess per setting: most knobs are read
+once per process."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_cache = {}
+
+
+def _run(model, B, steps, env_extra, bf16=False):
+    key = (model, B, steps, bf16, tuple(sorted(env_extra.items())))
+    if key not in _cache:
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_worker.py"), model, str(B), str(steps), "1" if bf16 else "0"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        _cache[key] = json.loads(r.stdout.strip().splitlines()[-1])
+    return _cache[key]
+
+
+BIT_IDENTICAL = [
+    ("deepfm", 256, {"RSX_FUSE_GATHER": "0"}),                # gather as its own launch
+    ("deepfm", 256, {"RSX_ADAM_WINDOW": "1"}),                # no optimizer windows: every step sorts and carries its sweep slices
+    ("deepfm", 256, {"RSX_ADAM_WINDOW": "4"}),
+    ("deepfm", 256, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_IN_GATHER": "1", "RSX_FUSE_GATHER": "0"}),   # the sort rides in the gather launch
+    ("deepfm", 256, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_RIDE_MAX": "0"}),                            # stand-alone sort launch
+    ("deepfm", 256, {"RSX_ADAM_WINDOW": "1", "RSX_SWEEP_WEIGHTS": "0,1,1,2,2,1"}),                  # other shares of the sweep per launch
+    ("deepfm", 256, {"RSX_WIN_SEPARATE_SORTS": "1"}),         # k single sorts instead of the multi-sort
+    ("deepfm", 256, {"RSX_SEG_LDS": "0"}),                    # the scatter's register form
+    ("fm", 256, {"RSX_ADAM_WINDOW": "1"}),
+    ("dcn", 1024, {"RSX_ADAM_WINDOW": "1"}),
+    ("dcn", 1024, {"RSX_TOWER_RTW": "1"}),                    # row tiles per d(input) workgroup
+    ("xdeepfm", 128, {"RSX_ADAM_WINDOW": "1"}),
+    ("xdeepfm", 128, {"RSX_XDFM_SORT_RIDE": "0"}),
+]
+ROUNDING = [
+    ("dcn", 1024, {"RSX_CROSS_BWD4": "0"}),                   # one-wave cross backward: its partials are added in another order
+    ("deepfm", 256, {"RSX_TOWER_DXG": "1"}),                  # grouped d(input) tiles: another order over the N outputs
+    ("dcn", 1024, {"RSX_TOWER_BIG": "0"}),                    # the batch-256 tiles for the wide first layer
+    ("dcn", 1024, {"RSX_TOWER_DXG_SPLIT": "0"}),
+    ("dcn", 1024, {"RSX_TOWER_SB_ROWS": "256"}),              # dW row blocks of 256 instead of 512 rows
+    ("xdeepfm", 128, {"RSX_CIN_DX": "1"}),                    # register form of the CIN dX kernel
+]
+
+
+@pytest.mark.parametrize("model,B,env", BIT_IDENTICAL, ids=lambda x: "+".join("%s=%s" % kv for kv in x.items()) if isinstance(x, dict) else str(x))
+def test_scheduling_knobs_leave_every_bit_unchanged(model, B, env):
+    base = _run(model, B, 12, {})
+    got = _run(model, B, 12, env)
+    assert got["digest"] == base["digest"], (env, got["loss"], base["loss"], got["dense_abs_sum"], base["dense_abs_sum"])
+
+
+@pytest.mark.parametrize("model,B,env", ROUNDING, ids=lambda x: "+".join("%s=%s" % kv for kv in x.items()) if isinstance(x, dict) else str(x))
+def test_tiling_knobs_stay_within_fp32_rounding(model, B, env):
+    base = _run(model, B, 12, {})
+    got = _run(model, B, 12, env)
+    assert abs(got["loss"] - base["loss"]) < 1e-5, (env, got["loss"], base["loss"])
+    np.testing.assert_allclose(np.array(got["dense"]), np.array(base["dense"]), rtol=1e-4, atol=2e-6)
