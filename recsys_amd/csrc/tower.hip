@@ -469,8 +469,11 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
     return;
   }
   __shared__ float sc[256], sh[256], mu[256], rs[256];
-  __shared__ double red[4][2][256];
-  __shared__ float redw[4][256];
+  // per (row of the tile, column): dy, xhat and o * g2 -- the column partials are summed from here by one thread per column
+  // (round 4; they used to travel through 80 cross-lane fp64 / fp32 shuffles per wave, a third of the kernel's instructions).
+  // Row stride = 16 mod 64 floats: the 4 rows a wave writes at once land in 4 different bank groups.
+  constexpr int LDC = 16 * CPL + 16;
+  __shared__ float ldy[16][LDC], lxh[16][LDC], log2_[16][LDC];
   __shared__ double hrow[16][8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   RSX_STAMP(8, blockIdx.x == 0);
@@ -557,31 +560,37 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
     }
   }
   RSX_STAMP(13, blockIdx.x == 0);
-  // column partials of the wave's 4 rows: (r0 + r1) + (r2 + r3) by two cross-group steps, then one LDS slot per wave
+  // column partials over the tile's 16 rows, in the order the shuffles used to produce: per wave (r0 + r1) + (r2 + r3), then the
+  // waves in order -- the same bits
+  {
+    const int r = w * 4 + g;
 #pragma unroll
-  for (int k = 0; k < CPL; ++k) {
-    const int c = li + 16 * k;
-    {
+    for (int k = 0; k < CPL; ++k) {
+      const int c = li + 16 * k;
       const bool ok = rok && c < p.N;
       const float dyv = ok ? g2 * wdv[k] * mk[k] : 0.f;          // d/d(BN output) after dropout backward
       if (ok) p.dy_last[(size_t)row * p.N + c] = dyv;
-      double sdy = (double)dyv, sdx = (double)dyv * (double)xh[k];
-      float swd = ok ? o[k] * g2 : 0.f;
-      sdy += __shfl_xor(sdy, 16); sdx += __shfl_xor(sdx, 16); swd += __shfl_xor(swd, 16);
-      sdy += __shfl_xor(sdy, 32); sdx += __shfl_xor(sdx, 32); swd += __shfl_xor(swd, 32);
-      if (g == 0 && c < p.N) {
-        red[w][0][c] = sdy;
-        red[w][1][c] = sdx;
-        redw[w][c] = swd;
-      }
+      ldy[r][c] = dyv;
+      lxh[r][c] = xh[k];
+      log2_[r][c] = ok ? o[k] * g2 : 0.f;
     }
   }
   RSX_STAMP(10, blockIdx.x == 0);
   __syncthreads();
   for (int c = tid; c < p.N; c += 256) {
-    p.bstat_last[((size_t)blockIdx.x * 2 + 0) * p.N + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-    p.bstat_last[((size_t)blockIdx.x * 2 + 1) * p.N + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
-    p.dwd_part[(size_t)blockIdx.x * p.N + c] = redw[0][c] + redw[1][c] + redw[2][c] + redw[3][c];
+    double sdy[4], sdx[4];
+    float swd[4];
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const float d0 = ldy[4 * ww][c], d1 = ldy[4 * ww + 1][c], d2 = ldy[4 * ww + 2][c], d3 = ldy[4 * ww + 3][c];
+      const float x0 = lxh[4 * ww][c], x1 = lxh[4 * ww + 1][c], x2 = lxh[4 * ww + 2][c], x3 = lxh[4 * ww + 3][c];
+      sdy[ww] = ((double)d0 + (double)d1) + ((double)d2 + (double)d3);
+      sdx[ww] = ((double)d0 * (double)x0 + (double)d1 * (double)x1) + ((double)d2 * (double)x2 + (double)d3 * (double)x3);
+      swd[ww] = (log2_[4 * ww][c] + log2_[4 * ww + 1][c]) + (log2_[4 * ww + 2][c] + log2_[4 * ww + 3][c]);
+    }
+    p.bstat_last[((size_t)blockIdx.x * 2 + 0) * p.N + c] = sdy[0] + sdy[1] + sdy[2] + sdy[3];
+    p.bstat_last[((size_t)blockIdx.x * 2 + 1) * p.N + c] = sdx[0] + sdx[1] + sdx[2] + sdx[3];
+    p.dwd_part[(size_t)blockIdx.x * p.N + c] = swd[0] + swd[1] + swd[2] + swd[3];
   }
   if (tid < 8) {                                   // the 16 rows of the tile in ascending order
     double s = 0.0;
