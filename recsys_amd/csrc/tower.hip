@@ -936,15 +936,28 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
       bnr_e = p.bn_prev[p.K + oc];
     }
     const size_t arow = (size_t)(rok ? row : p.B - 1) * p.N, wrow = (size_t)(cok ? kcol : 0) * p.N;
+    const bool n4 = (p.N & 3) == 0;                    // (uniform) rows of a / dy / W are 16-byte aligned: one float4 per operand
     const float v = tile_ksplit((p.N + 15) / 16, part, [&](int ks, float* a, float* b) {
       const int nn = ks * 16 + 4 * kq;
       float ar[4], dyr[4], wr[4];
+      if (n4) {
+        // the lane's 4 consecutive outputs as ONE 16-byte load per operand (3 instead of 12 load instructions per k-step, each
+        // touching the same 16 lines; a k-step past N reads the last 4 columns and is masked below like a clamped scalar)
+        const int nb = nn < p.N ? nn : p.N - 4;
+        const float4 a4 = *reinterpret_cast<const float4*>(p.a + arow + nb);
+        const float4 d4 = *reinterpret_cast<const float4*>(p.dy + arow + nb);
+        const float4 w4 = *reinterpret_cast<const float4*>(p.W + wrow + nb);
+        ar[0] = a4.x; ar[1] = a4.y; ar[2] = a4.z; ar[3] = a4.w;
+        dyr[0] = d4.x; dyr[1] = d4.y; dyr[2] = d4.z; dyr[3] = d4.w;
+        wr[0] = w4.x; wr[1] = w4.y; wr[2] = w4.z; wr[3] = w4.w;
+      } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {                    // unconditional loads on clamped indices (see the dW tiles)
         const int nc = nn + t < p.N ? nn + t : p.N - 1;
         ar[t] = p.a[arow + nc];
         dyr[t] = p.dy[arow + nc];
         wr[t] = p.W[wrow + nc];
+      }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
