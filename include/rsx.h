@@ -257,8 +257,20 @@ typedef struct {
   float lr, beta1, beta2, eps;
   float* state;               /* device state (see above), read only                        */
   uint32_t blk_lo, blk_hi;    /* workgroup range [lo, hi) out of rsx_adam_num_blocks(segs)  */
+  /* A WINDOW sweep (segments with slot_w) cut into one slice per step of its window, each riding in that step's head launch
+   * (rsx_tower_head, round 4): a row that no step of the window touches is read by none of them, so its 1 + w updates may be
+   * applied at any time inside the window.
+   *   window_block_u      float4 per lane of a TABLE_TF1_COLD block: 0 (= 8, the stand-alone sweep's) or 2 / 4 -- smaller
+   *                       blocks spread a slice over the CUs a latency-bound launch leaves idle; blk_lo / blk_hi then count
+   *                       blocks of rsx_adam_num_blocks_u(segs, nseg, window_block_u).
+   *   alphas_from_state   0: the step sizes come from the beta powers (state words 0, 1) -- the slice of the window's FIRST
+   *                       step, whose block 0 also leaves them in state words 8.. --; 1: they are read from there (later steps:
+   *                       the powers have been advanced since).                                                              */
+  int32_t window_block_u;
+  int32_t alphas_from_state;
 } rsx_adam_slice;
 int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg);
+int64_t rsx_adam_num_blocks_u(const rsx_adam_seg* segs_h, int nseg, int window_block_u);
 typedef struct rsx_table_set {
   float* tables; float* m; float* v;        /* [R, D] each */
   const float* dX;                           /* [B, F*D] */

@@ -27,7 +27,7 @@ class AdamSeg(C.Structure):
 class AdamSlice(C.Structure):
     _fields_ = [("segs", C.POINTER(AdamSeg)), ("nseg", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("state", C.c_void_p), ("blk_lo", C.c_uint32),
-                ("blk_hi", C.c_uint32)]
+                ("blk_hi", C.c_uint32), ("window_block_u", C.c_int32), ("alphas_from_state", C.c_int32)]
 
 
 class ExampleBlocks(C.Structure):
@@ -121,6 +121,7 @@ _SIGS = {
                                    _I, _I, _P]),
     "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
+    "rsx_adam_num_blocks_u": (C.c_int64, [C.POINTER(AdamSeg), _I, _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_copy_bytes": (_I, [_P, _P, C.c_size_t, _P]),
     "rsx_adam_fast_math_selftest": (_I, [_P, C.c_uint32, _I, _I, _P]),

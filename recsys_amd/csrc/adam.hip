@@ -46,10 +46,13 @@ extern "C" int rsx_adam_tf1_multi(const rsx_adam_seg* segs_h, int nseg, float* s
 
 // Number of workgroups the given segment list occupies (to cut a COLD sweep into slices).
 extern "C" int64_t rsx_adam_num_blocks(const rsx_adam_seg* segs_h, int nseg) {
+  return rsx_adam_num_blocks_u(segs_h, nseg, 0);
+}
+extern "C" int64_t rsx_adam_num_blocks_u(const rsx_adam_seg* segs_h, int nseg, int window_block_u) {
   AdamArgs a;
   uint32_t blocks = 0;
   float dummy;
-  const int rc = adam_build_args(segs_h, nseg, &dummy, 0.f, 0.f, 0.f, 0.f, a, &blocks);
+  const int rc = adam_build_args(segs_h, nseg, &dummy, 0.f, 0.f, 0.f, 0.f, a, &blocks, window_block_u);
   return rc != RSX_OK ? (int64_t)rc : (int64_t)blocks;
 }
 
@@ -62,16 +65,8 @@ __global__ __launch_bounds__(ADAM_T) void adam_slice_k(const AdamSlice s) { adam
 #endif
 template <int NW>
 __global__ __launch_bounds__(ADAM_T, RSX_ADAM_WIN_OCC) void adam_window_k(const AdamSlice s) {
-  // The step sizes of the window's 1 + NW steps, for the lazy window pass of segsum_adam_k (csrc/embedding.hip), which applies
-  // a row's zero-gradient updates of several steps -- also FUTURE ones -- in one go: state word 8 + j = the step size of
-  // window step j, from the products the per-step advance of the beta powers will make (alpha_window: what this sweep uses).
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const float b1p = s.args.state[0], b2p = s.args.state[1];
-    const AlphaW aw = alpha_window(s.args, NW, b1p, b2p);
-    s.args.state[8] = s.args.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-#pragma unroll
-    for (int j = 0; j < NW; ++j) s.args.state[9 + j] = aw.get(j);
-  }
+  // (the window's step sizes for the lazy window pass: state words 8.., adam_device.h)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && s.blk_lo == 0 && !s.args.alpha_src) adam_publish_step_sizes<NW>(s.args);
   adam_window_block<NW>(s.args, s.blk_lo + blockIdx.x);
 }
 template <int NW>
@@ -84,6 +79,7 @@ extern "C" int rsx_adam_slice_run(const rsx_adam_slice* slice_h, rsx_stream_t st
   const int rc = adam_build_slice(slice_h, s);
   if (rc != RSX_OK) return rc;
   if (s.n_blk == 0) return RSX_OK;
+  if (s.args.win_u != 0) return RSX_EUNSUPPORTED;      // small window blocks exist as riders only (rsx_tower_head)
   const dim3 grid(s.n_blk), block(ADAM_T);
   switch (s.args.nw) {
     case 0: RSX_LAUNCH(adam_slice_k, grid, block, 0, rsx_s(stream), s); break;

@@ -26,6 +26,11 @@ struct AdamArgs {
   float lr, b1, b2, eps;
   float* state;
   uint32_t total_blocks;
+  // Window sweeps that RIDE in the steps' launches, a slice per step (round 4, rsx_adam_slice.window_block_u / alphas_from_state):
+  // win_u = float4 per lane of a TABLE_TF1_COLD block (0: ADAM_U) -- smaller blocks spread a slice over the idle CUs of a
+  // latency-bound launch --; alpha_src != 0: the window's step sizes are READ from state words 8.. (the slice of the window's
+  // first step computed them from the beta powers, which later steps have advanced since).
+  int32_t win_u, alpha_src;
 };
 
 struct Hp {
@@ -113,16 +118,39 @@ __device__ __forceinline__ AlphaW alpha_window(const AdamArgs& a, int nw, float 
   return aw;
 }
 
+// The step sizes of a sweep over 1 + nw steps: from the beta powers (state words 0, 1), or -- a slice of a window sweep that runs
+// at a LATER step of its window -- the values the window's first slice left in state words 8.. (the same floats).
+__device__ __forceinline__ void adam_step_sizes(const AdamArgs& a, int nw, float& alpha0, AlphaW& aw) {
+  if (a.alpha_src) {
+    alpha0 = a.state[8];
+    aw = AlphaW{a.state[9], a.state[10], a.state[11], a.state[12], a.state[13], a.state[14], a.state[15]};
+    return;
+  }
+  const float b1p = a.state[0], b2p = a.state[1];
+  alpha0 = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  aw = alpha_window(a, nw, b1p, b2p);
+}
+// The step sizes of the window's 1 + NW steps, for the lazy window pass of segsum_adam_k (csrc/embedding.hip), which applies
+// a row's zero-gradient updates of several steps -- also FUTURE ones -- in one go: state word 8 + j = the step size of
+// window step j, from the products the per-step advance of the beta powers will make.  ONE thread of the window's first sweep
+// launch (or first slice) calls this.
+template <int NW>
+__device__ __forceinline__ void adam_publish_step_sizes(const AdamArgs& a) {
+  const float b1p = a.state[0], b2p = a.state[1];
+  const AlphaW aw = alpha_window(a, NW, b1p, b2p);
+  a.state[8] = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+#pragma unroll
+  for (int j = 0; j < NW; ++j) a.state[9 + j] = aw.get(j);
+}
+
 // One workgroup (ADAM_T = 256 threads) of the sweep: block `blk` of the launch-wide block index space of `a`.
 __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk, const int tid = threadIdx.x) {
-  const float b1p = a.state[0], b2p = a.state[1];
   Hp h;
   h.b1 = a.b1;
   h.b2 = a.b2;
   h.omb1 = 1.0f - a.b1;
   h.omb2 = 1.0f - a.b2;
   h.eps = a.eps;
-  h.alpha = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
   int si = 0;
 #pragma unroll 1
   for (int k = 1; k < a.nseg; ++k)
@@ -132,7 +160,8 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
   // fp32 products the per-step advance of the powers makes
   const bool is_cold = s.kind == RSX_ADAM_TABLE_TF1_COLD || s.kind == RSX_ADAM_VEC_COLD;
   const int nw = is_cold ? a.nw : 0;
-  const AlphaW aw = alpha_window(a, nw, b1p, b2p);
+  AlphaW aw;
+  adam_step_sizes(a, nw, h.alpha, aw);
   // the window's extra slot maps are equally spaced (one allocation): base + stride instead of 7 pointers in scalar registers
   const int32_t* __restrict__ swb = a.slot_w0;
   const long long sws = a.slot_w_stride;
@@ -401,12 +430,13 @@ __device__ __forceinline__ bool adam_win_guard4(const float4& var, const float4&
 //     workgroup without a pipeline 97.5 / 65.6.  With the state L2-resident the updates alone cost ~9 us per step of the
 //     window: from ~4 steps per window on the kernel is VALU-bound, not HBM-bound.)
 //   - blocks of the other kinds (the first-order vector, ...): adam_block.
-template <int NW>
+// U = float4 per lane of a block (== a.win_u, or ADAM_U when that is 0: the host picks the instantiation)
+template <int NW, int U = ADAM_U>
 __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint32_t blk, const int tid = threadIdx.x) {
   constexpr int nw = NW;        // == a.nw (the host picks the instantiation)
   constexpr int HB = RSX_ADAM_WIN_HB;
-  constexpr int NB = ADAM_U / HB;
-  static_assert(ADAM_U % HB == 0, "ADAM_U");
+  constexpr int NB = U / HB;
+  static_assert(U % HB == 0 && U <= ADAM_U, "U");
   int si = 0;
 #pragma unroll 1
   for (int k = 1; k < a.nseg; ++k)
@@ -416,15 +446,14 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
     adam_block(a, blk, tid);
     return;
   }
-  const float b1p = a.state[0], b2p = a.state[1];
   Hp h;
   h.b1 = a.b1;
   h.b2 = a.b2;
   h.omb1 = 1.0f - a.b1;
   h.omb2 = 1.0f - a.b2;
   h.eps = a.eps;
-  h.alpha = a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-  const AlphaW aw = alpha_window(a, nw, b1p, b2p);
+  AlphaW aw;
+  adam_step_sizes(a, nw, h.alpha, aw);
   // Packed fast form of the zero-gradient updates (adam_fast.h): usable when the hyper-parameters keep every operand of a
   // guarded element inside the fast forms' domains for all 1 + NW updates (b1^8 >= 1/4, b2^8 >= 2^-8, alphas within 4x).
   float amin = h.alpha, amax = h.alpha;
@@ -441,7 +470,7 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
   float4* __restrict__ var4 = reinterpret_cast<float4*>(s.var);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(s.m);
   float4* __restrict__ v4 = reinterpret_cast<float4*>(s.v);
-  const long long base = (long long)(blk - s.blk_begin) * ADAM_Q;
+  const long long base = (long long)(blk - s.blk_begin) * ((long long)ADAM_T * U);
   const int lpr = s.d >> 2;
   const long long n4 = s.n * lpr;
   const bool pow2 = (lpr & (lpr - 1)) == 0;
@@ -567,8 +596,11 @@ __device__ __forceinline__ void adam_window_block(const AdamArgs& a, const uint3
 // Host: validates the segment list and lays the segments out over the launch-wide block index space.
 // Returns an rsx_status; *blocks_out = number of workgroups (0 when there is nothing to do).
 static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* state, float lr, float beta1, float beta2,
-                                  float eps, AdamArgs& a, uint32_t* blocks_out) {
+                                  float eps, AdamArgs& a, uint32_t* blocks_out, int win_u = 0, int alpha_src = 0) {
   if (!segs_h || !state || nseg <= 0 || nseg > RSX_ADAM_MAX_SEGS) return RSX_EINVAL;
+  if (win_u != 0 && win_u != 2 && win_u != 4 && win_u != ADAM_U) return RSX_EINVAL;
+  a.win_u = win_u == ADAM_U ? 0 : win_u;
+  a.alpha_src = alpha_src ? 1 : 0;
   uint32_t blocks = 0;
   int k = 0, n_cold = 0;
   a.nw = 0;
@@ -646,7 +678,8 @@ static inline int adam_build_args(const rsx_adam_seg* segs_h, int nseg, float* s
       }
     }
     d.blk_begin = blocks;
-    const long long quantum = s.kind == RSX_ADAM_DENSE ? ADAM_Q_DENSE : ADAM_Q;
+    const long long quantum = s.kind == RSX_ADAM_DENSE ? ADAM_Q_DENSE
+                              : (s.kind == RSX_ADAM_TABLE_TF1_COLD && a.win_u > 0 ? (long long)ADAM_T * a.win_u : ADAM_Q);
     blocks += (uint32_t)((work + quantum - 1) / quantum);
   }
   a.nseg = k;
@@ -688,7 +721,7 @@ static inline int adam_build_slice(const rsx_adam_slice* sl_h, AdamSlice& out) {
   if (sl_h == nullptr) return RSX_OK;
   uint32_t blocks = 0;
   const int rc = adam_build_args(sl_h->segs, sl_h->nseg, sl_h->state, sl_h->lr, sl_h->beta1, sl_h->beta2, sl_h->eps,
-                                 out.args, &blocks);
+                                 out.args, &blocks, sl_h->window_block_u, sl_h->alphas_from_state);
   if (rc != RSX_OK) return rc;
   if (sl_h->blk_hi < sl_h->blk_lo || sl_h->blk_hi > blocks) return RSX_EINVAL;
   out.blk_lo = sl_h->blk_lo;

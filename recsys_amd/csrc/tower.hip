@@ -31,9 +31,12 @@ RSX_STAMP_DECL
 #ifdef RSX_ISA_PROBE
 #define RSX_RIDE_SWEEP(...) do { } while (0)
 #define RSX_RIDE_SORT(...) do { } while (0)
+#define RSX_RIDE_WINDOW(...) do { } while (0)
 #else
 #define RSX_RIDE_SWEEP(...) adam_block(__VA_ARGS__)
 #define RSX_RIDE_SORT(...) field_sort_block(__VA_ARGS__)
+// a slice of a full optimizer window's sweep (1 + 7 updates per untouched row) in small blocks (rsx_adam_slice.window_block_u = 2)
+#define RSX_RIDE_WINDOW(...) adam_window_block<ADAM_WMAX, 2>(__VA_ARGS__)
 #endif
 
 constexpr float TOWER_BN_EPS = 1e-3f;  // tf.layers.batch_normalization default epsilon
@@ -462,10 +465,19 @@ struct HeadArgs {
 };
 
 // CPL: columns per lane = ceil(N / 16) rounded up to 4 / 8 / 16 (a compile-time bound keeps every load unconditional)
-template <int CPL, bool RID>
+// RID: 0 = no riders; 1 = a slice of the one-step untouched-row sweep; 2 = a slice of a full optimizer WINDOW's sweep (round 4:
+// the 16 head workgroups leave 240 CUs idle for ~7 us -- 1/8 of the window's sweep per step fits there, and the stand-alone
+// 70 us launch per window disappears from the step's chain)
+template <int CPL, int RID>
 __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
-  if (RID && (int)blockIdx.x >= p.n_own) {
-    RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own));
+  if (RID != 0 && (int)blockIdx.x >= p.n_own) {
+    const uint32_t blk = p.sweep.blk_lo + (blockIdx.x - p.n_own);
+    if (RID == 2) {
+      if (blk == 0 && threadIdx.x == 0 && !p.sweep.args.alpha_src) adam_publish_step_sizes<ADAM_WMAX>(p.sweep.args);
+      RSX_RIDE_WINDOW(p.sweep.args, blk);
+    } else {
+      RSX_RIDE_SWEEP(p.sweep.args, blk);
+    }
     return;
   }
   __shared__ float sc[256], sh[256], mu[256], rs[256];
@@ -1941,11 +1953,15 @@ extern "C" int rsx_tower_head(const float* a_last, const double* fstat_last, con
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
   const dim3 grid(p.n_own + p.sweep.n_blk);
-  const bool rid = p.sweep.n_blk > 0;
+  // riders: none / a slice of the one-step sweep / a slice of a full window's sweep in small blocks
+  const int rid = p.sweep.n_blk == 0 ? 0 : (p.sweep.args.nw == 0 && p.sweep.args.win_u == 0 ? 1 :
+                                            (p.sweep.args.nw == ADAM_WMAX && p.sweep.args.win_u == 2 ? 2 : -1));
+  if (rid < 0) return RSX_EUNSUPPORTED;      // (partial windows / other block sizes: the stand-alone sweep, rsx_adam_slice_run)
 #define RSX_HEAD(CPL)                                                                                   \
   do {                                                                                                  \
-    if (rid) RSX_LAUNCH((tower_head_k<CPL, true>), grid, dim3(256), 0, rsx_s(stream), p);      \
-    else RSX_LAUNCH((tower_head_k<CPL, false>), grid, dim3(256), 0, rsx_s(stream), p);         \
+    if (rid == 2) RSX_LAUNCH((tower_head_k<CPL, 2>), grid, dim3(256), 0, rsx_s(stream), p);             \
+    else if (rid == 1) RSX_LAUNCH((tower_head_k<CPL, 1>), grid, dim3(256), 0, rsx_s(stream), p);        \
+    else RSX_LAUNCH((tower_head_k<CPL, 0>), grid, dim3(256), 0, rsx_s(stream), p);                      \
   } while (0)
   if (N <= 64) RSX_HEAD(4);
   else if (N <= 128) RSX_HEAD(8);

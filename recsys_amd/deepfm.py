@@ -198,7 +198,21 @@ def _train_fused(store, arena, ids, labels, params, masks):
         elif job is None and wk == 1:
             arena.field_sort(ids_sort)
         sweeps, hot, last_sweep = None, None, None
-        if overlap and wk > 1 and wpos == 0:
+        # RSX_WINDOW_RIDE=1 (round 4, opt-in; measured and NOT the default): a FULL window's sweep (8 steps) rides in the steps' head
+        # launches, one eighth per step in small blocks (rsx_adam_slice.window_block_u) -- a row no step of the window touches is
+        # read by none of them, so its 8 updates may land at any time inside the window.  Bit-identical (tests/test_gpu_knobs.py),
+        # but the sweep is bandwidth-bound, not idle-CU-bound: a slice moves 43 MB (8.6 us at 5 TB/s) and the head launch grew
+        # from 7.1 to 18.6 us -- more than the 8.8 us per step the stand-alone launch costs (0.0625 vs 0.0600 ms per step,
+        # profiles/r04_e_window_ride_ab.txt).
+        ride = overlap and wk == _lib.ADAM_WINDOW_MAX and os.environ.get("RSX_WINDOW_RIDE", "0") == "1"
+        if ride:
+            if wpos == 0:
+                cold, hot = arena.adam_split_segments(window_k=wk)
+                store._win_slices = store.opt.cold_slices(cold[::-1], [1.0] * wk, window_block_u=2)
+            hot = ()
+            sweeps = [None] * (2 * len(store.tower.widths) + 1)
+            sweeps[len(store.tower.widths)] = store._win_slices[wpos]
+        elif overlap and wk > 1 and wpos == 0:
             # ONE sweep for the whole window, as a launch of its own: k updates per row in registers make the slices
             # ALU-heavy, and as riders they inherit their carrier's occupancy (measured, DeepFM bs 256: carried 164 us per
             # 4-step window, stand-alone 73 us = 18 us per step against 53-60 us for a one-step sweep)

@@ -569,11 +569,14 @@ class AdamTF1:
         lr, b1, b2, eps = self.hp
         check(lib().rsx_adam_tf1_multi(arr, n, _ptr(self.state), lr, b1, b2, eps, _stream()), "rsx_adam_tf1_multi")
 
-    def cold_slices(self, cold_segments, weights):
+    def cold_slices(self, cold_segments, weights, window_block_u=0):
         """Cuts the untouched-row sweep (COLD kinds) into len(weights) consecutive workgroup ranges, proportional to
-        `weights`, as rsx_adam_slice structs for the tower launches.  Returns a list (entries may be None)."""
+        `weights`, as rsx_adam_slice structs for the tower launches.  Returns a list (entries may be None).
+        window_block_u (2 / 4): a WINDOW sweep (segments with slot_w) in smaller table blocks, one slice per step of the
+        window -- slice i is meant to ride in step i's head launch; slices after the first read the window's step sizes from the
+        optimizer state (rsx_adam_slice.alphas_from_state)."""
         arr, n = self._seg_array(cold_segments)
-        nb = int(lib().rsx_adam_num_blocks(arr, n))
+        nb = int(lib().rsx_adam_num_blocks_u(arr, n, int(window_block_u)))
         if nb < 0:
             check(nb, "rsx_adam_num_blocks")
         lr, b1, b2, eps = self.hp
@@ -586,6 +589,8 @@ class AdamTF1:
                 sl = _lib.AdamSlice()
                 sl.segs, sl.nseg, sl.lr, sl.beta1, sl.beta2, sl.eps = arr, n, lr, b1, b2, eps
                 sl.state, sl.blk_lo, sl.blk_hi = self.state.data_ptr(), lo, hi
+                sl.window_block_u = int(window_block_u)
+                sl.alphas_from_state = 1 if (window_block_u and lo > 0) else 0
                 sl._keep = arr
                 out.append(sl)
             else:

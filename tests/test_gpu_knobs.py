@@ -29,6 +29,7 @@ def _run(model, B, steps, env_extra, bf16=False):
 
 BIT_IDENTICAL = [
     ("deepfm", 256, {"RSX_FUSE_GATHER": "0"}),                # gather as its own launch
+    ("deepfm", 256, {"RSX_WINDOW_RIDE": "1"}),                # the window's sweep as 8 slices riding in the head launches
     ("deepfm", 256, {"RSX_ADAM_WINDOW": "1"}),                # no optimizer windows: every step sorts and carries its sweep slices
     ("deepfm", 256, {"RSX_ADAM_WINDOW": "4"}),
     ("deepfm", 256, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_IN_GATHER": "1", "RSX_FUSE_GATHER": "0"}),   # the sort rides in the gather launch
