@@ -224,6 +224,9 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   double* cred = reinterpret_cast<double*>(part + 1024);   // [4][2][16] column-sum exchange (8-byte aligned: K%4==0)
   const int tid = threadIdx.x, lane = tid & 63;
   const bool first = p.fstat_prev == nullptr;
+  // (before the statistics reduction: the step counter it reads is one more memory round trip, and behind the barrier below it
+  // used to start only when the reduction's had finished)
+  const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
   if (!first) {
     for (int k = tid; k < p.K; k += 256) {
       if (p.gamma_prev == nullptr) {   // previous layer without batch-norm (din/din.py MLP): dropout only
@@ -244,7 +247,6 @@ __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
     __syncthreads();
   }
   RSX_STAMP(st0 + 1, blockIdx.x == 0);
-  const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
   const int i = lane & 15, kq = lane >> 4;
   const int row = by * TM + i;
   const int col = bx * 16 + i;
@@ -919,6 +921,8 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   if (bid < p.n_din) {
     // ---- d(input) tile: rows rt*16.., input columns kc*16.. ; reduction over the N outputs ----------
     RSX_STAMP(sb0 + 0, bid == 0);
+    // (the epilogue's dropout key: its step-counter load starts here, not behind the k-loop)
+    const DropRng dr_e = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
     for (int c = tid; c < p.N; c += 256) {
       const ColBwd cb = bwd_col(p, c);
       Lm[c] = cb.mean; Lr[c] = cb.rstd; Lk[c] = cb.k1; Ls[c] = cb.sdy; Lx[c] = cb.sdx;
@@ -986,8 +990,7 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     if (orow < p.B && ocol < p.K) {
       float o = v;
       if (!first) {
-        const DropRng dr = drop_make(p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
-        o *= drop_mul(dr, p.mask_prev, (size_t)orow * p.K + ocol);
+        o *= drop_mul(dr_e, p.mask_prev, (size_t)orow * p.K + ocol);
         const float xh = (xin_e - bnm_e) * bnr_e;
         s1 = (double)o;
         s2 = (double)o * (double)xh;
@@ -1027,6 +1030,16 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     // (all 256 threads used to repeat the 32-load reduction; with 280 such workgroups starting together that prologue
     // measured 5 us under the L2 queueing it caused itself)
     float* Lc = reinterpret_cast<float*>(cred);        // [5][16] (cred is not used by this tile family)
+    // (the dropout key's step counter and the previous layer's batch-norm constants are requested BEFORE the column constants:
+    // behind the barrier below they were a second memory round trip on the launch's longest chain -- phase stamps: 3.7 us from
+    // the tile's entry to its k-loop against 1.8 us in the d(input) tiles)
+    const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
+    float fsc = 1.f, fsh = 0.f;
+    if (!first && fok && p.gamma_prev != nullptr) {   // (previous layer without batch-norm: identity)
+      const float inv = p.bn_prev[p.K + feat] * p.gamma_prev[feat];
+      fsc = inv;
+      fsh = p.beta_prev[feat] - p.bn_prev[feat] * inv;
+    }
     if (tid < 16) {
       const int c = nt * 16 + tid;
       const ColBwd t = bwd_col(p, c < p.N ? c : 0);
@@ -1035,13 +1048,6 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
     __syncthreads();
     ColBwd cb;
     cb.mean = Lc[i]; cb.rstd = Lc[16 + i]; cb.k1 = Lc[32 + i]; cb.sdy = Lc[48 + i]; cb.sdx = Lc[64 + i];
-    float fsc = 1.f, fsh = 0.f;
-    if (!first && fok && p.gamma_prev != nullptr) {   // (previous layer without batch-norm: identity)
-      const float inv = p.bn_prev[p.K + feat] * p.gamma_prev[feat];
-      fsc = inv;
-      fsh = p.beta_prev[feat] - p.bn_prev[feat] * inv;
-    }
-    const DropRng dr = drop_make(first ? 0.f : p.rate, p.mask_prev, p.rng_step, p.seed, p.layer_prev);
     if (kf == 0 && sbi == 0 && nok && tid < 16 && !nobn) {   // lanes 0..15 of wave 0 hold the column constants
       p.dgamma[ncol] = cb.sdx;
       p.dbeta[ncol] = cb.sdy;
