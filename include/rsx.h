@@ -93,6 +93,18 @@ int rsx_field_sort_large(const int32_t* ids, const int32_t* row_off, int32_t* pe
 int rsx_field_sort_large_t(int32_t* ids_t, const int32_t* row_off, int32_t* perm, int32_t* seg_off, int32_t* uniq_row,
                            int32_t* nuniq, int32_t* slot, int32_t* segid, int32_t* workspace, int max_rows_per_field, int B,
                            int F, int stride, rsx_stream_t stream);
+/* fm.py's forward AND head in one launch (round 4; fm/fm.py:117-133,146-149): rsx_gather_fm_fwd (without E: fm.py's backward
+ * recomputes the FM term from the table row) followed, in the same wave, by rsx_fm_head's arithmetic for that example --
+ * prob, gy1 = d loss / d y1, gy2 = d loss / d y2 -- and the head's dense gradients as rows of `terms` [ceil(B/16), term_stride]
+ * laid out like the caller's dense gradient arena: row g = the sum, in example order, over examples 16 g .. 16 g + 15 of the
+ * example's d/d c0 at [off_c0], d/d wo at [off_wo], [off_wo + 1], d/d bo at [off_bo], zeros elsewhere below n_dense, and of
+ * its cross-entropy term at [n_dense].  The optimizer sums the rows in order (an RSX_ADAM_DENSE segment with g = terms,
+ * B = ceil(batch/16), stride = term_stride); the mean loss is sum(terms[:, n_dense]) / batch.  term_stride: a multiple of 4,
+ * n_dense < term_stride <= 64.                                                                                           */
+int rsx_gather_fm_head(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids, float* S,
+                       uint64_t w1_field_mask, const float* c0, const float* wo, const float* bo, const float* labels,
+                       float* prob, float* gy1, float* gy2, float* terms, int term_stride, int n_dense, int off_c0,
+                       int off_wo, int off_bo, float loss_scale, int B, int F, int D, rsx_stream_t stream);
 /* Dense gradient buckets of the SMALL-VOCABULARY fields (data parallel, round 4): TF's MirroredStrategy sums the replicas'
  * IndexedSlices of every embedding variable (fm/fm.py:184-194, SURVEY A-4/A-12); for a field of a few hundred rows that sum
  * is cheapest as a dense [rows, D] array that rides the dense gradients' collective -- no sort, no ragged counts.
@@ -402,6 +414,13 @@ int rsx_tower_head(const float* a_last, const double* fstat_last, const float* g
 int rsx_fm_head(const float* y1, const float* y2, const float* c0, const float* wo, const float* bo,
                 const float* labels, float* prob, float* gy1, float* gy2, float* dwo, float* dbo, float* dc0,
                 float* loss, float loss_scale, int B, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* The same with the reduction left to the optimizer launch (round 4): terms != NULL -> terms [ceil(B/16), term_stride] receives
+ * the rows of rsx_gather_fm_head's contract -- the same additions in the same order, so the two schedules train the same bits
+ * (dwo / dbo / dc0 / loss are not written and may be NULL).  terms == NULL: rsx_fm_head.                                   */
+int rsx_fm_head_terms(const float* y1, const float* y2, const float* c0, const float* wo, const float* bo,
+                      const float* labels, float* prob, float* gy1, float* gy2, float* dwo, float* dbo, float* dc0,
+                      float* loss, float* terms, int term_stride, int n_dense, int off_c0, int off_wo, int off_bo,
+                      float loss_scale, int B, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 /* Backward of layer l: BN backward + relu mask on load; writes dW, db, dgamma, dbeta, and dy_prev = gradient wrt
  * the previous layer's BN output (+ its bstat_prev partials), or dX for the first layer (bn_prev == NULL).
  * With hpart != NULL (last layer) one extra workgroup reduces the head partials into dwd, dbd, dwo[3], dbo, dc0, loss. */

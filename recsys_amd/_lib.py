@@ -97,6 +97,7 @@ _SIGS = {
     "rsx_gather_fm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P]),
     "rsx_gather_fm_fwd_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P, _P]),
     "rsx_gather_two_fwd": (_I, [_P] * 10 + [_U64, _I, _I, _I, _I, _P]),
+    "rsx_gather_fm_head": (_I, [_P] * 5 + [_U64] + [_P] * 8 + [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P]),
     "rsx_bucket_scatter": (_I, [_P] * 11 + [_U64, _I, _I, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rsx_field_sort_large": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
@@ -112,6 +113,7 @@ _SIGS = {
     "rsx_tower_reduce_partials": (_I, [_P, _I, _I, _P]),
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P, _P]),
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
+    "rsx_fm_head_terms": (_I, [_P] * 14 + [_I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
     "rsx_tower_bwd_layer_defer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
     "rsx_tower_reduce_dw_jobs": (_I, [_P, _I, _P]),

@@ -223,7 +223,16 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a, const uint32_t blk
       if (e < n4) {
         float4 var = var4[e], m = m4[e], v = v4[e];
         float4 g = g4[e];
-        for (int r = 1; r < nrep; ++r) {
+        int r = 1;
+        // (many replicas -- fm.py's per-example head gradients, round 4: 16 loads in flight per trip; the same ascending order)
+        for (; r + 15 < nrep; r += 16) {
+          float4 t[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) t[q] = g4[e + (long long)(r + q) * rs4];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { g.x += t[q].x; g.y += t[q].y; g.z += t[q].z; g.w += t[q].w; }
+        }
+        for (; r < nrep; ++r) {
           const float4 gr = g4[e + r * rs4];
           g.x += gr.x; g.y += gr.y; g.z += gr.z; g.w += gr.w;
         }

@@ -55,6 +55,69 @@ __global__ __launch_bounds__(256) void gather_fm_sort_k(const float* __restrict_
   gather_fm_example<D>(tables, w1, row_off, ids, E, S, y1, y2, w1_mask, b, F, threadIdx.x & 63);
 }
 
+// fm.py's whole forward + head in ONE launch (round 4; fm/fm.py:117-133,146-149): one wave per example gathers the rows (no
+// E: fm.py's backward recomputes the FM term from the table row), forms the first-order sum and the FM term, and goes on to
+//   z = wo[0] relu(y1 + c0) + wo[1] y2 + bo,  prob = sigmoid(z),  ce,  dz = (prob - label) loss_scale
+// and the head's backward: gy1 = d loss / d y1, gy2 = d loss / d y2 for the scatter, and this EXAMPLE's contribution to the
+// four dense gradients, written as one row of `terms` in the dense arena's own layout (terms[b, off_c0] = dc0, [off_wo + 0 / 1]
+// = dwo, [off_bo] = dbo, every other element of the row's first `n_dense` floats 0) + its cross-entropy term at [b, n_dense].
+// Rows of 16 consecutive examples are pre-added in example order (terms [ceil(B/16), stride]); the optimizer launch sums the
+// group rows in order (an RSX_ADAM_DENSE segment with B = ceil(batch/16) "replicas" `stride` floats apart), the host reads the
+// loss from column n_dense when somebody asks for it: no separate head launch, no cross-workgroup reduction here.
+struct FmHeadFused {
+  const float* c0; const float* wo; const float* bo; const float* labels;
+  float* prob; float* gy1; float* gy2; float* terms;
+  int stride, n_dense, off_c0, off_wo, off_bo;
+  float loss_scale;
+};
+// One workgroup = 16 waves = 16 consecutive examples; their rows of dense-gradient terms are added in example order by the
+// lanes of wave 0 (one per column) and leave as ONE row of `terms` per workgroup: the optimizer launch then adds B / 16 rows
+// instead of B (its 3-thread dense segment walked 256 rows in 16 dependent trips: 4 us at the tail of the scatter launch).
+template <int D>
+__global__ __launch_bounds__(1024) void gather_fm_head_k(const float* __restrict__ tables, const float* __restrict__ w1,
+                                                         const int32_t* __restrict__ row_off, const int32_t* __restrict__ ids,
+                                                         float* __restrict__ S, uint64_t w1_mask, int B, int F,
+                                                         const FmHeadFused h) {
+  __shared__ float rows[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 16 + w;
+  const bool live = b < B;
+  const int bc = live ? b : B - 1;                  // (a wave past the batch repeats the last example and contributes nothing)
+  const float c0 = h.c0[0], w0 = h.wo[0], w1o = h.wo[1], bo = h.bo[0], y = h.labels[bc];     // (before the gather's chain)
+  float y1v, y2v;
+  gather_fm_example<D>(tables, w1, row_off, ids, nullptr, live ? S : nullptr, nullptr, nullptr, w1_mask, bc, F, lane, &y1v, &y2v);
+  y1v = __shfl(y1v, 0);          // (the first-order sum is complete in the lanes of quarter 0 only)
+  // the arithmetic of fm_head_k, one example per wave (every lane computes it)
+  const float v0 = y1v + c0, v1 = y2v;
+  const float t0 = v0 > 0.f ? v0 : 0.f;
+  const float z = w0 * t0 + w1o * v1 + bo;
+  const float pr = 1.f / (1.f + expf(-z));
+  const float ce = fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+  const float dz = (pr - y) * h.loss_scale;
+  const float g0 = v0 > 0.f ? dz * w0 : 0.f;
+  if (lane == 0 && live) {
+    h.prob[b] = pr;
+    h.gy1[b] = g0;
+    h.gy2[b] = dz * w1o;
+  }
+  {
+    float t = 0.f;
+    t = lane == h.off_c0 ? g0 : t;
+    t = lane == h.off_wo ? dz * t0 : t;
+    t = lane == h.off_wo + 1 ? dz * v1 : t;
+    t = lane == h.off_bo ? dz : t;
+    t = lane == h.n_dense ? ce : t;
+    rows[w][lane] = t;
+  }
+  __syncthreads();
+  if (w == 0 && lane < h.stride) {
+    const int n = B - blockIdx.x * 16 < 16 ? B - blockIdx.x * 16 : 16;     // examples of this group (>= 1)
+    float t = rows[0][lane];
+    for (int i = 1; i < n; ++i) t += rows[i][lane];                       // ascending example order: fm_head_k's terms mode adds the same way
+    h.terms[(size_t)blockIdx.x * h.stride + lane] = t;
+  }
+}
+
 // F = 1 (tf.nn.embedding_lookup of one table: DIN's item / category / history lookups, din/din.py:96-105): a plain row
 // gather.  The multi-field kernel would keep one wave per id with D/4 of its 64 lanes busy; here a wave serves 64/(D/4)
 // ids at once, one float4 per lane, fully coalesced on the output side.
@@ -1646,6 +1709,31 @@ extern "C" int rsx_gather_fm_fwd_sort(const float* tables, const float* w1, cons
   const int n_gather = (B + 3) / 4;
   RSX_DISPATCH_D(D, launch_gather_sort, dim3((unsigned)(n_gather + sort_h->F)), lds, rsx_s(stream), tables, w1, row_off, ids, E,
                  S, y1, y2, w1_field_mask, B, F, n_gather, sa);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+template <int D>
+static void launch_gather_fm_head(dim3 grid, hipStream_t st, const float* tables, const float* w1, const int32_t* row_off,
+                                  const int32_t* ids, float* S, uint64_t mask, int B, int F, const FmHeadFused& h) {
+  RSX_COUNT_LAUNCH(); gather_fm_head_k<D><<<grid, dim3(1024), 0, st>>>(tables, w1, row_off, ids, S, mask, B, F, h);
+}
+
+extern "C" int rsx_gather_fm_head(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids, float* S,
+                                  uint64_t w1_field_mask, const float* c0, const float* wo, const float* bo,
+                                  const float* labels, float* prob, float* gy1, float* gy2, float* terms, int term_stride,
+                                  int n_dense, int off_c0, int off_wo, int off_bo, float loss_scale, int B, int F, int D,
+                                  rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || !d_ok(D)) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!tables || !w1 || !row_off || !ids || !S || !c0 || !wo || !bo || !labels || !prob || !gy1 || !gy2 || !terms)
+    return RSX_EINVAL;
+  if (term_stride < n_dense + 1 || term_stride > 64 || (term_stride & 3) || n_dense <= 0 || off_c0 < 0 || off_wo < 0 ||
+      off_bo < 0 || off_c0 >= n_dense || off_wo + 1 >= n_dense || off_bo >= n_dense)
+    return RSX_EINVAL;
+  const FmHeadFused h{c0, wo, bo, labels, prob, gy1, gy2, terms, term_stride, n_dense, off_c0, off_wo, off_bo, loss_scale};
+  RSX_DISPATCH_D(D, launch_gather_fm_head, dim3((unsigned)((B + 15) / 16)), rsx_s(stream), tables, w1, row_off, ids, S,
+                 w1_field_mask, B, F, h);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

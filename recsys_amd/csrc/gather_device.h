@@ -7,12 +7,14 @@
 
 // lane = (j, q): q = float4 quarter of the row, j = pair slot; the wave walks fields f = j, j + PPP, ...  The field
 // reductions (S, sum of squares, first-order sum) are xor-butterflies over the j bits.
+// y1v (valid in the lanes of quarter q == 0, e.g. lane 0) / y2v (valid in every lane): the first-order sum and the FM term, for
+// a caller that goes on with them (gather_fm_head_k); E may be NULL (fm.py's TRAIN step never reads it).
 template <int D>
 __device__ __forceinline__ void gather_fm_example(const float* __restrict__ tables, const float* __restrict__ w1,
                                                   const int32_t* __restrict__ row_off, const int32_t* __restrict__ ids,
                                                   float* __restrict__ E, float* __restrict__ S, float* __restrict__ y1,
                                                   float* __restrict__ y2, const uint64_t w1_mask, const int b, const int F,
-                                                  const int lane) {
+                                                  const int lane, float* y1v = nullptr, float* y2v = nullptr) {
   constexpr int LPR = D / 4;
   constexpr int PPP = RSX_WAVE / LPR;
   const int q = lane % LPR, j = lane / LPR;
@@ -45,7 +47,7 @@ __device__ __forceinline__ void gather_fm_example(const float* __restrict__ tabl
     for (int k = 0; k < 4; ++k) {
       const int f = f0 + k * PPP;
       if (ok[k]) {
-        E4[((size_t)b * F + f) * LPR + q] = e[k];
+        if (E != nullptr) E4[((size_t)b * F + f) * LPR + q] = e[k];
         s = f4_add(s, e[k]);
         qq = f4_add(qq, f4_mul(e[k], e[k]));
         if (q == 0 && ((w1_mask >> f) & 1ull)) a1 += wv[k];
@@ -59,11 +61,13 @@ __device__ __forceinline__ void gather_fm_example(const float* __restrict__ tabl
     a1 += __shfl_xor(a1, m);
   }
   if (S != nullptr && j == 0) reinterpret_cast<float4*>(S)[(size_t)b * LPR + q] = s;
-  if (y2 != nullptr) {
+  if (y2 != nullptr || y2v != nullptr) {
     float t = ((s.x * s.x - qq.x) + (s.y * s.y - qq.y)) + ((s.z * s.z - qq.z) + (s.w * s.w - qq.w));
 #pragma unroll
     for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m);
-    if (lane == 0) y2[b] = 0.5f * t;
+    if (y2 != nullptr && lane == 0) y2[b] = 0.5f * t;
+    if (y2v != nullptr) *y2v = 0.5f * t;
   }
   if (y1 != nullptr && lane == 0) y1[b] = a1;
+  if (y1v != nullptr) *y1v = a1;
 }

@@ -1988,6 +1988,11 @@ struct FmHeadArgs {
   float* prob; float* gy1; float* gy2; float* dwo; float* dbo; float* dc0; float* loss;
   float loss_scale;
   int B;
+  // terms != null (round 4): no reduction here -- every example's contribution to the dense gradients goes to row b of
+  // terms [B, stride] in the dense arena's layout, its cross-entropy term to column n_dense (rsx_gather_fm_head's contract: the
+  // optimizer launch sums the rows in example order, so this launch and the fused one leave the same bits)
+  float* terms;
+  int stride, n_dense, off_c0, off_wo, off_bo;
   AdamSlice sweep;
 };
 
@@ -1997,9 +2002,45 @@ __global__ __launch_bounds__(256) void fm_head_k(const FmHeadArgs p) {
     return;
   }
   __shared__ double red[4][5];
+  __shared__ float tv[256][5];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float c0 = p.c0[0], w0 = p.wo[0], w1 = p.wo[1], bo = p.bo[0];
   double acc[5] = {0, 0, 0, 0, 0};                   // loss, dwo0, dwo1, dbo, dc0
+  if (p.terms != nullptr) {
+    // terms mode: groups of 16 consecutive examples added in example order into ONE row each (rsx_gather_fm_head's contract,
+    // the same additions in the same order as gather_fm_head_k)
+    for (int b0 = 0; b0 < p.B; b0 += 256) {
+      const int b = b0 + tid;
+      if (b < p.B) {
+        const float v0 = p.y1[b] + c0, v1 = p.y2[b], y = p.labels[b];
+        const float t0 = v0 > 0.f ? v0 : 0.f;
+        const float z = w0 * t0 + w1 * v1 + bo;
+        const float pr = 1.f / (1.f + expf(-z));
+        const float ce = fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+        const float dz = (pr - y) * p.loss_scale;
+        const float g0 = v0 > 0.f ? dz * w0 : 0.f;
+        p.prob[b] = pr;
+        p.gy1[b] = g0;
+        p.gy2[b] = dz * w1;
+        tv[tid][0] = g0; tv[tid][1] = dz * t0; tv[tid][2] = dz * v1; tv[tid][3] = dz; tv[tid][4] = ce;
+      }
+      __syncthreads();
+      for (int gi = tid; gi < 16 * p.stride; gi += 256) {             // (group of this chunk, column of its row)
+        const int g = gi / p.stride, col = gi - g * p.stride;
+        if (b0 + 16 * g >= p.B) continue;
+        const int n = p.B - (b0 + 16 * g) < 16 ? p.B - (b0 + 16 * g) : 16;
+        const int src = col == p.off_c0 ? 0 : col == p.off_wo ? 1 : col == p.off_wo + 1 ? 2 : col == p.off_bo ? 3 : col == p.n_dense ? 4 : -1;
+        float t = 0.f;
+        if (src >= 0) {
+          t = tv[16 * g][src];
+          for (int i = 1; i < n; ++i) t += tv[16 * g + i][src];
+        }
+        p.terms[(size_t)(b0 / 16 + g) * p.stride + col] = t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int b = tid; b < p.B; b += 256) {
     const float v0 = p.y1[b] + c0, v1 = p.y2[b], y = p.labels[b];
     const float t0 = v0 > 0.f ? v0 : 0.f;
@@ -2036,10 +2077,22 @@ __global__ __launch_bounds__(256) void fm_head_k(const FmHeadArgs p) {
 extern "C" int rsx_fm_head(const float* y1, const float* y2, const float* c0, const float* wo, const float* bo,
                            const float* labels, float* prob, float* gy1, float* gy2, float* dwo, float* dbo, float* dc0,
                            float* loss, float loss_scale, int B, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+  return rsx_fm_head_terms(y1, y2, c0, wo, bo, labels, prob, gy1, gy2, dwo, dbo, dc0, loss, nullptr, 0, 0, 0, 0, 0, loss_scale,
+                           B, sweep_h, stream);
+}
+
+extern "C" int rsx_fm_head_terms(const float* y1, const float* y2, const float* c0, const float* wo, const float* bo,
+                                 const float* labels, float* prob, float* gy1, float* gy2, float* dwo, float* dbo, float* dc0,
+                                 float* loss, float* terms, int term_stride, int n_dense, int off_c0, int off_wo, int off_bo,
+                                 float loss_scale, int B, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   if (B <= 0) return B == 0 ? RSX_OK : RSX_EINVAL;
-  if (!y1 || !y2 || !c0 || !wo || !bo || !labels || !prob || !gy1 || !gy2 || !dwo || !dbo || !dc0 || !loss)
+  if (!y1 || !y2 || !c0 || !wo || !bo || !labels || !prob || !gy1 || !gy2) return RSX_EINVAL;
+  if (terms == nullptr && (!dwo || !dbo || !dc0 || !loss)) return RSX_EINVAL;
+  if (terms != nullptr && (term_stride < n_dense + 1 || term_stride > 64 || (term_stride & 3) || n_dense <= 0 || off_c0 < 0 ||
+                           off_wo < 0 || off_bo < 0 || off_c0 >= n_dense || off_wo + 1 >= n_dense || off_bo >= n_dense))
     return RSX_EINVAL;
-  FmHeadArgs p{y1, y2, c0, wo, bo, labels, prob, gy1, gy2, dwo, dbo, dc0, loss, loss_scale, B, {}};
+  FmHeadArgs p{y1, y2, c0, wo, bo, labels, prob, gy1, gy2, dwo, dbo, dc0, loss, loss_scale, B,
+               terms, term_stride, n_dense, off_c0, off_wo, off_bo, {}};
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
   RSX_LAUNCH(fm_head_k, dim3(1 + p.sweep.n_blk), dim3(256), 0, rsx_s(stream), p);

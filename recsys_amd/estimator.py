@@ -159,6 +159,37 @@ class PackedBatch:
         return feats, labels
 
 
+class LazyMeanLoss:
+    """A TRAIN step's mean loss that nobody has asked for yet: the per-example terms sit in a device buffer (column `col` of
+    `terms` [n, stride], written by the step's kernels) and are summed when the value is read -- float(), .item(), .tensor().
+    The Estimator only touches a step's loss at log lines, so a step that would need a launch of its own just to reduce 256
+    numbers (fm.py's fused forward + head, csrc/embedding.hip gather_fm_head_k) does not pay for it."""
+
+    def __init__(self, terms, col, n):
+        self.terms, self.col, self.n = terms, int(col), int(n)       # n = examples (the rows may be pre-added groups)
+
+    def detach(self):
+        return self
+
+    def tensor(self):
+        return (self.terms[:, self.col].double().sum() / self.n).to(torch.float32)
+
+    def clone(self):
+        return self.tensor()
+
+    def reshape(self, *shape):
+        return self.tensor().reshape(*shape)
+
+    def item(self):
+        return float(self.tensor().item())
+
+    def __float__(self):
+        return self.item()
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+
 class VariableStore:
     """The variables of one model: named embedding arenas + one flat dense arena + the optimizer."""
 

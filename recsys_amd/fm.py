@@ -5,6 +5,7 @@ logits = dense([relu(first_order), fm_second_order], 1).  The whole model is the
 (gather + first-order + FM forward, sorted segment-sum backward) plus a 2->1 dense head.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -103,16 +104,40 @@ def _train_fused(store, arena, ids, labels):
             # first) in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)
             sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
         Sv, gy2v, gy1v = dp.send_views(B) if dp is not None else (None,) * 3
-        E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)
         prob = torch.empty(B, device=dev)
         gy1, gy2 = (gy1v, gy2v) if dp is not None else (torch.empty(B, device=dev) for _ in range(2))
-        loss = torch.empty(1, device=dev)
         oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
         world = dp.world if dp is not None else 1
-        _lib.check(_lib.lib().rsx_fm_head(_ptr(y1p), _ptr(y2), _ptr(P["b1"]), _ptr(oW), _ptr(P["out.b"]),
-                                          _ptr(labels.reshape(-1).to(torch.float32)), _ptr(prob), _ptr(gy1), _ptr(gy2),
-                                          _ptr(oG), _ptr(P["out.b"].grad), _ptr(P["b1"].grad), _ptr(loss), 1.0 / (B * world), B,
-                                          None if sweep is None else C.byref(sweep), _stream()), "rsx_fm_head")
+        lab = labels.reshape(-1).to(torch.float32)
+        # round 4: forward AND head in ONE launch (rsx_gather_fm_head: 3.25 -> 2.25 launches per step).  Every example leaves its
+        # contribution to the four dense gradients as a row of `terms` in the dense arena's layout; the optimizer launch adds
+        # the rows in example order (an RSX_ADAM_DENSE segment with B = batch "replicas"), the loss is read from the terms when
+        # somebody asks (estimator.LazyMeanLoss).  Single replica, windows on (no sweep slice to carry); RSX_FM_FUSE=0: two launches.
+        terms_on = dp is None and os.environ.get("RSX_FM_FUSE", "1") != "0" and P.n + 1 <= 64
+        fuse = terms_on and sweep is None
+        terms, loss = None, None
+        if terms_on:
+            stride = (P.n + 1 + 3) & ~3
+            terms = torch.empty((B + 15) // 16, stride, device=dev)      # rows of 16 examples, pre-added in example order
+            from .estimator import LazyMeanLoss
+            loss = LazyMeanLoss(terms, P.n, B)
+        if fuse:
+            S = torch.empty(B, arena.D, device=dev)
+            _lib.check(_lib.lib().rsx_gather_fm_head(
+                _ptr(arena.tables), _ptr(arena.w1), _ptr(arena.row_off), _ptr(ids), _ptr(S), arena.w1_mask, _ptr(P["b1"]), _ptr(oW),
+                _ptr(P["out.b"]), _ptr(lab), _ptr(prob), _ptr(gy1), _ptr(gy2), _ptr(terms), stride, P.n, P.offsets["b1"],
+                P.offsets["out.W"], P.offsets["out.b"], 1.0 / (B * world), B, arena.F, arena.D, _stream()), "rsx_gather_fm_head")
+        else:
+            # two launches: a sweep slice rides in the head launch (every step on its own), or data parallel.  Single replica:
+            # the head leaves the same per-example terms as the fused launch, so both schedules train the same bits.
+            E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv)
+            if terms is None:
+                loss = torch.empty(1, device=dev)
+            _lib.check(_lib.lib().rsx_fm_head_terms(
+                _ptr(y1p), _ptr(y2), _ptr(P["b1"]), _ptr(oW), _ptr(P["out.b"]), _ptr(lab), _ptr(prob), _ptr(gy1), _ptr(gy2),
+                _ptr(oG), _ptr(P["out.b"].grad), _ptr(P["b1"].grad), _ptr(loss) if terms is None else None, _ptr(terms),
+                stride if terms is not None else 0, P.n, P.offsets["b1"], P.offsets["out.W"], P.offsets["out.b"],
+                1.0 / (B * world), B, None if sweep is None else C.byref(sweep), _stream()), "rsx_fm_head_terms")
 
     def train_op():
         with torch.no_grad():
@@ -126,9 +151,14 @@ def _train_fused(store, arena, ids, labels):
                                   blocks=blocks, window=(wk, wpos))
             else:
                 arena.select(wpos)
-                arena.segsum_adam(B, S, None, gy1, gy2, store.opt, store.dense.adam_segments(), sweep2, window=(wk, wpos))
+                dense_segs = store.dense.adam_segments()
+                if terms is not None:       # the head's dense gradients: the examples' rows, summed in example order by the launch
+                    dense_segs = [dict(kind=_lib.RSX_ADAM_DENSE, n=P.n, var=P.flat, m=P.m, v=P.v, g=terms, B=terms.shape[0],
+                                       stride=terms.shape[1], zero_grad=0)]
+                arena.segsum_adam(B, S, None, gy1, gy2, store.opt, dense_segs, sweep2, window=(wk, wpos))
 
-    return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
+    return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss if terms is not None else loss[0],
+                         train_op=train_op)
 
 
 def main(argv=None):

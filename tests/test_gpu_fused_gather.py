@@ -119,3 +119,47 @@ def test_deepfm_train_parity_with_and_without_the_fused_gather(fuse, monkeypatch
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5, losses
     assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("B", [256, 37, 1])
+def test_fm_fused_forward_and_head_is_the_bits_of_the_two_launches(B):
+    """rsx_gather_fm_head (fm.py's forward + head in one launch, round 4) against rsx_gather_fm_fwd + rsx_fm_head_terms: S,
+    prob, gy1, gy2 and the rows of dense-gradient terms (16 examples each, pre-added in example order) bit for bit; the rows' column
+    sums against rsx_fm_head's own fp64 reduction (1e-6: fp32 additions in example order)."""
+    from recsys_amd import _lib
+    from recsys_amd.ops import _ptr, _stream
+    a, tables, w1, row_off, ids, W, b = _setup(B, None, 4, seed=B)
+    L = _lib.lib()
+    ids_t = torch.from_numpy(ids).cuda()
+    rng = np.random.default_rng(B)
+    c0 = torch.tensor([0.05], device="cuda")
+    wo = torch.from_numpy(rng.standard_normal(2).astype(np.float32)).cuda()
+    bo = torch.tensor([-0.1], device="cuda")
+    lab = torch.from_numpy((rng.random(B) < 0.4).astype(np.float32)).cuda()
+    stride, nd, offs = 16, 12, (0, 4, 8)
+    f = lambda *shape: torch.full(shape, 7.0, device="cuda")
+    # two launches
+    E, S, y1, y2 = a.gather(ids_t, fm=True, first_order=True)
+    prob0, g10, g20, terms0 = f(B), f(B), f(B), f((B + 15) // 16, stride)
+    _lib.check(L.rsx_fm_head_terms(_ptr(y1), _ptr(y2), _ptr(c0), _ptr(wo), _ptr(bo), _ptr(lab), _ptr(prob0), _ptr(g10), _ptr(g20),
+                                   None, None, None, None, _ptr(terms0), stride, nd, *offs, 1.0 / B, B, None, _stream()))
+    # the reducing form (reference for the sums)
+    prob1, g11, g21 = f(B), f(B), f(B)
+    dwo, dbo, dc0, loss = f(2), f(1), f(1), f(1)
+    _lib.check(L.rsx_fm_head(_ptr(y1), _ptr(y2), _ptr(c0), _ptr(wo), _ptr(bo), _ptr(lab), _ptr(prob1), _ptr(g11), _ptr(g21),
+                             _ptr(dwo), _ptr(dbo), _ptr(dc0), _ptr(loss), 1.0 / B, B, None, _stream()))
+    # one launch
+    S2, prob2, g12, g22, terms2 = f(B, 16), f(B), f(B), f(B), f((B + 15) // 16, stride)
+    _lib.check(L.rsx_gather_fm_head(_ptr(a.tables), _ptr(a.w1), _ptr(a.row_off), _ptr(ids_t), _ptr(S2), a.w1_mask, _ptr(c0), _ptr(wo),
+                                    _ptr(bo), _ptr(lab), _ptr(prob2), _ptr(g12), _ptr(g22), _ptr(terms2), stride, nd, *offs, 1.0 / B,
+                                    B, a.F, a.D, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(S2, S) and torch.equal(prob2, prob0) and torch.equal(g12, g10) and torch.equal(g22, g20)
+    assert torch.equal(prob1, prob0) and torch.equal(g11, g10)
+    assert torch.equal(terms2, terms0), (terms2 - terms0).abs().max()
+    t = terms0.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose([t[4], t[5]], dwo.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(t[8], dbo.item(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(t[0], dc0.item(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(t[12] / B, loss.item(), rtol=1e-6)
+    assert float(terms0[:, [1, 2, 3, 6, 7, 9, 10, 11, 13, 14, 15]].abs().max()) == 0.0
