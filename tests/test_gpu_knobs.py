@@ -44,6 +44,7 @@ BIT_IDENTICAL = [
     ("xdeepfm", 128, {"RSX_XDFM_SORT_RIDE": "0"}),
 ]
 ROUNDING = [
+    ("fm", 256, {"RSX_FM_FUSE": "0"}),                        # fp64 reduction of the head's dense gradients instead of the grouped fp32 rows
     ("dcn", 1024, {"RSX_CROSS_BWD4": "0"}),                   # one-wave cross backward: its partials are added in another order
     ("deepfm", 256, {"RSX_TOWER_DXG": "1"}),                  # grouped d(input) tiles: another order over the N outputs
     ("dcn", 1024, {"RSX_TOWER_BIG": "0"}),                    # the batch-256 tiles for the wide first layer
