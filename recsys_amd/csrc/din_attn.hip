@@ -11,7 +11,9 @@
 //   * dropout is the counter hash of the fused tower (drop_device.h) or an injected mask (parity tests).
 // One wave = one 16-row tile; k-permutation as in tower.hip / cin.hip: k-step 4*kb + t uses k = 16*kb + 4*(lane>>4) + t.
 #include "drop_device.h"
+#include <type_traits>
 #include "rsx_common.h"
+RSX_STAMP_DECL
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 att_mfma(float a, float b, f32x4 c) {
@@ -69,6 +71,32 @@ __device__ __forceinline__ void stage_matrix(float* __restrict__ dst, const floa
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (base + j * T + tid < total) dst[TRANS ? cc[j] * ld + rr[j] : rr[j] * ld + cc[j]] = v[j];
+  }
+}
+
+// The same, untransposed, in 16-byte pieces (C % 4 == 0, src 16-byte aligned, ld % 4 == 0): a quarter of the load and LDS-store
+// instructions, up to 8 loads in flight per thread -- the backward kernel's 13 440 weights arrive in one trip instead of four.
+template <int T>
+__device__ __forceinline__ void stage_matrix4(float* __restrict__ dst, const float* __restrict__ src, const int R, const int C,
+                                              const int ld, const int tid) {
+  const int C4 = C >> 2, total = R * C4;
+  if (total <= 0) return;
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+  for (int base = 0; base < total; base += 8 * T) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = base + j * T + tid;
+      v[j] = s4[e < total ? e : total - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = base + j * T + tid;
+      if (e < total) {
+        const int r = e / C4, c = e - r * C4;
+        *reinterpret_cast<float4*>(dst + r * ld + 4 * c) = v[j];
+      }
+    }
   }
 }
 
@@ -281,13 +309,24 @@ struct AttnDims {
 // columns of every per-row stage (g1 columns, dx columns), the 8 waves split the weight-gradient tiles; per wave that is
 // ~170 registers, so two waves share a SIMD and one's VALU / LDS work overlaps the other's MFMAs (with 4 waves of 417
 // registers the kernel was instruction-issue bound: 13 non-MFMA instructions per MFMA, one wave per SIMD).
-template <int KB, int NT1, int NT2>
+// element `idx` of a per-row array through a 32-bit BYTE offset from the (uniform) base: the load / store takes the
+// scalar-base + 32-bit-offset form -- one address register per access instead of a 64-bit pair and its arithmetic
+template <class T>
+__device__ __forceinline__ T* at32(T* base, uint32_t idx) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + idx * (uint32_t)sizeof(T));
+}
+// VEC (N1 and N2 multiples of 4 -- din.py's 80 / 40): a2 and a1 arrive as ONE 16-byte load per 16-column tile and lane in the A
+// layout (row = lane & 15) instead of four 4-byte loads -- 7 instead of 25 load instructions per wave and block for them: the
+// CU's address path, not HBM, bounded the loads --; a1 goes through its transposed LDS tile (which S6 needs anyway) to reach
+// the C layout S4 wants, dropout applied on the way.
+template <int KB, int NT1, int NT2, bool VEC>
 __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
   using D = AttnDims<KB, NT1, NT2>;
   constexpr int K = D::K, K4 = D::K4, N1P = D::N1P, N2P = D::N2P, LD1 = D::LD1, LD2 = D::LD2;
   constexpr int NH1 = (NT1 + 1) / 2;       // g1 column tiles per half
   constexpr int CH = (KB + 1) / 2;         // dx column blocks (of each of the 4 segments) per half
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  RSX_STAMP(0, blockIdx.x == 0);
   float* sW0 = lds;                        // [K4][LD1]   W0 row-major
   float* sW1 = sW0 + K4 * LD1;             // [N1P][LD2]  W1 row-major
   float* sw2 = sW1 + N1P * LD2;            // [N2P]
@@ -299,64 +338,132 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
   float* sG2 = sA1 + N1P * LDR;            // [N2P][LDR]  g2^T
   float* sH = sG2 + N2P * LDR;             // [K][LDR]    h^T
   float* sQ = sH + K * LDR;                // [K][LDR]    q^T
+  float* sA2 = sQ + K * LDR;               // [N2P][LDR]  (a2 after dropout * dw)^T: db1 / dW2 are column sums of sG2 / sA2,
+                                           //             taken by the matrix cores with an all-ones A operand (waves NT1, NT1+1)
+  static_assert(NT1 + 2 <= 8, "two spare waves for the ones-row tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rt = wave & 3, hf = wave >> 2;
   const int i = lane & 15, kq = lane >> 4;
   const int nt0 = hf * NH1;                // this half's first g1 column tile
   for (int e = tid; e < (K4 * LD1 + N1P * LD2) / 4; e += 512) reinterpret_cast<float4*>(sW0)[e] = F4Z;   // (padding columns / rows)
   __syncthreads();
-  stage_matrix<512, false>(sW0, p.W0, K4, p.N1, LD1, tid);      // W0 row-major
-  stage_matrix<512, false>(sW1, p.W1, p.N1, p.N2, LD2, tid);    // W1 row-major
+  if (VEC && (((uintptr_t)p.W0 | (uintptr_t)p.W1) & 15) == 0) {
+    stage_matrix4<512>(sW0, p.W0, K4, p.N1, LD1, tid);          // W0 row-major
+    stage_matrix4<512>(sW1, p.W1, p.N1, p.N2, LD2, tid);        // W1 row-major
+  } else {
+    stage_matrix<512, false>(sW0, p.W0, K4, p.N1, LD1, tid);
+    stage_matrix<512, false>(sW1, p.W1, p.N1, p.N2, LD2, tid);
+  }
   for (int e = tid; e < N2P; e += 512) sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
   const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
   const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
   const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
-  // weight-gradient accumulators, alive across all blocks: wave w owns row tile w of dW0 (w < 4*KB) and of dW1 (w < NT1)
+  // weight-gradient accumulators, alive across all blocks: wave w owns row tile w of dW0 (w < 4*KB) and of dW1 (w < NT1);
+  // waves NT1 / NT1 + 1 keep ones^T . g2 = db1 and ones^T . (a2d * dw) = dW2 in accW1 (every row of the tile is the sum)
   f32x4 accW0[NT1], accW1[NT2];
 #pragma unroll
   for (int b = 0; b < NT1; ++b) accW0[b] = zf;
 #pragma unroll
   for (int b = 0; b < NT2; ++b) accW1[b] = zf;
-  float db0acc[NH1], db1acc[NT2][4], dw2acc[NT2][4], db2acc = 0.f;
+  float db0acc[NH1], db2acc = 0.f;
 #pragma unroll
   for (int a = 0; a < NH1; ++a) db0acc[a] = 0.f;
-#pragma unroll
-  for (int a = 0; a < NT2; ++a)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) db1acc[a][t] = dw2acc[a][t] = 0.f;
   __syncthreads();
 
   const int Mv = p.count ? p.count[0] : p.M;       // rows to walk (valid history positions, or all)
   const int nblk = (Mv + 63) / 64;
+  // the row-list entry of the NEXT block is requested one block ahead (one dependent HBM round trip less per block)
+  auto row_of = [&](const int blk_) -> int {
+    const int jr = blk_ * 64 + 16 * rt + i;
+    const int jcl = jr < Mv ? jr : 0;
+    return p.rows ? p.rows[jcl] : jcl;
+  };
+  int mci_next = row_of((int)blockIdx.x);
+  // The per-row global operands of a block (dw, a2, a1, h, q, the dH to add to) are requested ONE BLOCK AHEAD, right before the
+  // previous block's weight-gradient MFMAs (S6): that phase needs only the LDS tiles and the accumulators, the ~45 registers the
+  // operands land in are free there, and the ~4 us the loads took at the top of every block (stamps: 30 % of it) are covered by
+  // S6 and the barrier behind it.  All loads are unconditional on clamped addresses (rows past the end read row 0).
+  int n_mci;
+  float n_dz, n_a2[NT2][4], n_a1[NH1][4], n_dh[CH][4];
+  float4 n_h[KB], n_q[KB];
+  auto issue = [&](const int blk_) {
+    const int jr = blk_ * 64 + 16 * rt + i;
+    n_mci = jr < Mv ? mci_next : 0;                // A-layout row (original index; 0 when past the end)
+    mci_next = row_of(blk_ + (int)gridDim.x);      // (the row-list entry of the block after: one dependent round trip less)
+    const uint32_t mcu = (uint32_t)n_mci;          // (32-bit element offsets: the host refuses shapes whose arrays reach 4 GB)
+    uint32_t mr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mr[r] = (uint32_t)__shfl(n_mci, 4 * kq + r);
+    n_dz = *at32(p.dw, mcu);
+    if constexpr (VEC) {
+#pragma unroll
+      for (int kb = 0; kb < NT2; ++kb) {
+        const int n0 = 16 * kb + 4 * kq;
+        const float4 v = *reinterpret_cast<const float4*>(at32(p.a2, mcu * (uint32_t)p.N2 + (uint32_t)(n0 < p.N2 ? n0 : p.N2 - 4)));
+        n_a2[kb][0] = v.x; n_a2[kb][1] = v.y; n_a2[kb][2] = v.z; n_a2[kb][3] = v.w;
+      }
+#pragma unroll
+      for (int u = 0; u < NH1; ++u) {                // A layout: row i, columns 16*(nt0+u) + 4*kq + t
+        const int n0 = 16 * (nt0 + u) + 4 * kq;
+        const float4 v = *reinterpret_cast<const float4*>(at32(p.a1, mcu * (uint32_t)p.N1 + (uint32_t)(n0 < p.N1 ? n0 : p.N1 - 4)));
+        n_a1[u][0] = v.x; n_a1[u][1] = v.y; n_a1[u][2] = v.z; n_a1[u][3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NT2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int n = 16 * kb + 4 * kq + t;
+          n_a2[kb][t] = *at32(p.a2, mcu * (uint32_t)p.N2 + (uint32_t)(n < p.N2 ? n : p.N2 - 1));
+        }
+#pragma unroll
+      for (int u = 0; u < NH1; ++u) {                // C layout: rows 4*kq + r, column 16*(nt0+u) + i
+        const int n = 16 * (nt0 + u) + i, nc = n < p.N1 ? n : p.N1 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n_a1[u][r] = *at32(p.a1, mr[r] * (uint32_t)p.N1 + (uint32_t)nc);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {                 // (half 1 does not use them: wave-uniform)
+      n_h[c] = hf == 0 ? *reinterpret_cast<const float4*>(at32(p.H, mcu * (uint32_t)K + (uint32_t)(16 * c + 4 * kq))) : F4Z;
+      n_q[c] = hf == 0 ? *reinterpret_cast<const float4*>(at32(p.q, (mcu / (uint32_t)p.P) * (uint32_t)K + (uint32_t)(16 * c + 4 * kq)))
+                       : F4Z;
+    }
+#pragma unroll
+    for (int cu = 0; cu < CH; ++cu) {
+      const int c = hf * CH + cu, cc = c < KB ? c : KB - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        n_dh[cu][r] = p.acc_dH ? *at32(p.dH, mr[r] * (uint32_t)p.ldh + (uint32_t)(16 * cc + i)) : 0.f;
+    }
+  };
+  issue((int)blockIdx.x);
+  RSX_STAMP(1, blockIdx.x == 0);
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const bool stamp_ = blockIdx.x == 0 && blk == (int)gridDim.x;        // (profiling build) the workgroup's SECOND block
+    RSX_STAMP(2, stamp_);
     const int jrow = blk * 64 + 16 * rt + i;       // position in the (possibly compacted) row list
     const bool mok = jrow < Mv;
-    const int jc = mok ? jrow : 0;
-    const size_t mc = mok ? (size_t)(p.rows ? p.rows[jc] : jc) : 0;     // A-layout row (original index; 0 when past the end)
-    const size_t mcl = mc;
-    size_t mrow[4];                                // original indices of this lane's C-layout rows 16*rt + 4*kq + r
+    const int mci = n_mci;
+    const size_t mc = (size_t)mci;
+    int mrow[4];                                   // original indices of this lane's C-layout rows 16*rt + 4*kq + r
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mrow[r] = (size_t)__shfl((int)mc, 4 * kq + r);
+    for (int r = 0; r < 4; ++r) mrow[r] = __shfl(mci, 4 * kq + r);
     // ---- S1/S2: g2 (A layout, registers; both halves), the h / q / g2 tiles of the block (half 0) -----------------
-    // global operands: unconditional on clamped addresses (no branch per load); with two waves per SIMD the other wave's
-    // MFMAs cover their latency, so nothing is prefetched across blocks (that cost 41 registers and spilled)
-    const float dz = mok ? p.dw[mcl] : 0.f;
-    float a2N[NT2][4], a1N[NH1][4];
+    const float dz = mok ? n_dz : 0.f;
+    float a2N[NT2][4], a1N[NH1][4], dh_old[CH][4];
 #pragma unroll
     for (int kb = 0; kb < NT2; ++kb)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int n = 16 * kb + 4 * kq + t;
-        a2N[kb][t] = p.a2[mcl * p.N2 + (n < p.N2 ? n : p.N2 - 1)];
-      }
+      for (int t = 0; t < 4; ++t) a2N[kb][t] = n_a2[kb][t];
 #pragma unroll
-    for (int u = 0; u < NH1; ++u) {
-      const int n = 16 * (nt0 + u) + i, nc = n < p.N1 ? n : p.N1 - 1;
+    for (int u = 0; u < NH1; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a1N[u][r] = p.a1[mrow[r] * p.N1 + nc];
-      }
-    }
+      for (int r = 0; r < 4; ++r) a1N[u][r] = n_a1[u][r];
+#pragma unroll
+    for (int cu = 0; cu < CH; ++cu)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh_old[cu][r] = n_dh[cu][r];
     float g2[NT2][4];
 #pragma unroll
     for (int kb = 0; kb < NT2; ++kb)
@@ -369,17 +476,30 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
         const float gv = av > 0.f ? dz * sw2[n] * mul : 0.f;
         g2[kb][t] = gv;
         if (hf == 0) {
-          dw2acc[kb][t] += av * mul * dz;
-          db1acc[kb][t] += gv;
+          sA2[n * LDR + 16 * rt + i] = av * mul * dz;
           sG2[n * LDR + 16 * rt + i] = gv;
         }
       }
+    if constexpr (VEC) {                           // a1 after dropout -> its transposed tile (this wave's rows and column tiles)
+#pragma unroll
+      for (int u = 0; u < NH1; ++u) {
+        if (nt0 + u < NT1) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int n = 16 * (nt0 + u) + 4 * kq + t;
+            const bool ok = mok && n < p.N1;
+            const float av = a1N[u][t] * (ok ? 1.f : 0.f);
+            const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mc * p.N1 + n) : 0.f);
+            sA1[n * LDR + 16 * rt + i] = av * mul;
+          }
+        }
+      }
+    }
     if (hf == 0) {
       if (kq == 0) db2acc += dz;
 #pragma unroll
       for (int c = 0; c < KB; ++c) {
-        const float4 hr = *reinterpret_cast<const float4*>(p.H + mcl * K + 16 * c + 4 * kq);
-        const float4 qr = *reinterpret_cast<const float4*>(p.q + (mcl / p.P) * K + 16 * c + 4 * kq);
+        const float4 hr = n_h[c], qr = n_q[c];
         const float4 hv = mok ? hr : F4Z;
         const float4 qv = mok ? qr : F4Z;
         const int cc = 16 * c + 4 * kq, rr = 16 * rt + i;
@@ -387,6 +507,7 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
         sQ[(cc + 0) * LDR + rr] = qv.x; sQ[(cc + 1) * LDR + rr] = qv.y; sQ[(cc + 2) * LDR + rr] = qv.z; sQ[(cc + 3) * LDR + rr] = qv.w;
       }
     }
+    RSX_STAMP(3, stamp_ && g2[0][0] != 12345.f);
     // ---- S3: dg1 = g2 . W1^T for this half's column tiles (C layout: rows 4*kq + r, column n1 = 16*nt + i) ----------
     f32x4 dg1[NH1];
 #pragma unroll
@@ -403,29 +524,46 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
           dg1[u] = att_mfma(g2[kb][3], b.w, dg1[u]);
         }
       }
+    RSX_STAMP(4, stamp_ && dg1[0][0] != 12345.f);
     // ---- S4: g1 = dg1 * drop1 * (a1 > 0); tiles g1^T / a1d^T --------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < NH1; ++u) {
       if (nt0 + u < NT1) {
         const int n = 16 * (nt0 + u) + i;
         float gq[4], aq[4];
+        if constexpr (VEC) {
+          // (a1 * drop1)[rows 4*kq + r][n] back from the tile this wave wrote above (zero where dropped, relu'd away or past
+          // the end): positive <=> kept and a1 > 0
+          const float4 ad = *reinterpret_cast<const float4*>(sA1 + n * LDR + 16 * rt + 4 * kq);
+          const float mulc = d1.mode == 0 ? 1.f : d1.inv_keep;
+          const float adr[4] = {ad.x, ad.y, ad.z, ad.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * rt + 4 * kq + r;
-          const size_t mm = mrow[r];
-          const bool ok = blk * 64 + row < Mv && n < p.N1;
-          const float av = a1N[u][r] * (ok ? 1.f : 0.f);
-          const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mm * p.N1 + n) : 0.f);
-          const float gv = av > 0.f ? dg1[u][r] * mul : 0.f;
-          db0acc[u] += gv;
-          gq[r] = gv;
-          aq[r] = av * mul;
+          for (int r = 0; r < 4; ++r) {
+            const float gv = adr[r] > 0.f ? dg1[u][r] * mulc : 0.f;
+            db0acc[u] += gv;
+            gq[r] = gv;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * kq + r;
+            const size_t mm = (size_t)mrow[r];
+            const bool ok = blk * 64 + row < Mv && n < p.N1;
+            const float av = a1N[u][r] * (ok ? 1.f : 0.f);
+            const float mul = d1.mode == 0 ? 1.f : (ok ? drop_mul(d1, p.mask1, mm * p.N1 + n) : 0.f);
+            const float gv = av > 0.f ? dg1[u][r] * mul : 0.f;
+            db0acc[u] += gv;
+            gq[r] = gv;
+            aq[r] = av * mul;
+          }
+          *reinterpret_cast<float4*>(sA1 + n * LDR + 16 * rt + 4 * kq) = make_float4(aq[0], aq[1], aq[2], aq[3]);
         }
         *reinterpret_cast<float4*>(sG1 + n * LDR + 16 * rt + 4 * kq) = make_float4(gq[0], gq[1], gq[2], gq[3]);
-        *reinterpret_cast<float4*>(sA1 + n * LDR + 16 * rt + 4 * kq) = make_float4(aq[0], aq[1], aq[2], aq[3]);
       }
     }
+    RSX_STAMP(5, stamp_);
     __syncthreads();
+    RSX_STAMP(6, stamp_);
     // ---- S5: dx = g1 . W0^T for this half's column blocks of the 4 segments -> dH, per-row dq ---------------------------
 #pragma unroll
     for (int cu = 0; cu < CH; ++cu) {
@@ -449,26 +587,30 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * rt + 4 * kq + r, col = 16 * c + i;
-          const size_t mm = mrow[r];
           if (blk * 64 + row < Mv) {
             const float hv = sH[col * LDR + row], qv = sQ[col * LDR + row];
             const float dh = (dx[0][r] + dx[2][r] * qv) + dx[3][r];
-            p.dH[mm * p.ldh + col] = p.acc_dH ? p.dH[mm * p.ldh + col] + dh : dh;
-            p.dqr[mm * K + col] = (dx[1][r] + dx[2][r] * hv) - dx[3][r];
+            *at32(p.dH, (uint32_t)mrow[r] * (uint32_t)p.ldh + (uint32_t)col) = p.acc_dH ? dh_old[cu][r] + dh : dh;
+            *at32(p.dqr, (uint32_t)mrow[r] * (uint32_t)K + (uint32_t)col) = (dx[1][r] + dx[2][r] * hv) - dx[3][r];
           }
         }
       }
     }
+    RSX_STAMP(7, stamp_);
+    issue(blk + (int)gridDim.x);                       // the NEXT block's operands, in flight during S6
     // ---- S6: weight gradients over the block's 64 rows (k-step (kb, t) <-> row 16*kb + 4*kq + t) --------------------
-    if (wave < NT1) {                                  // dW1 row tile `wave`
+    if (wave < NT1 + 2) {                              // dW1 row tile `wave`; waves NT1 / NT1 + 1: the ones rows (db1 / dW2)
       float4 av[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) av[kb] = *reinterpret_cast<const float4*>(sA1 + (16 * wave + i) * LDR + 16 * kb + 4 * kq);
+      for (int kb = 0; kb < 4; ++kb)
+        av[kb] = wave < NT1 ? *reinterpret_cast<const float4*>(sA1 + (16 * wave + i) * LDR + 16 * kb + 4 * kq)
+                            : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float* __restrict__ sB = wave == NT1 + 1 ? sA2 : sG2;
 #pragma unroll
       for (int jt = 0; jt < NT2; ++jt) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          const float4 bv = *reinterpret_cast<const float4*>(sG2 + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
+          const float4 bv = *reinterpret_cast<const float4*>(sB + (16 * jt + i) * LDR + 16 * kb + 4 * kq);
           accW1[jt] = att_mfma(av[kb].x, bv.x, accW1[jt]);
           accW1[jt] = att_mfma(av[kb].y, bv.y, accW1[jt]);
           accW1[jt] = att_mfma(av[kb].z, bv.z, accW1[jt]);
@@ -500,8 +642,11 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
         }
       }
     }
+    RSX_STAMP(8, stamp_ && accW0[0][0] != 12345.f);
     __syncthreads();                                   // the tiles are rewritten by the next block
+    RSX_STAMP(9, stamp_);
   }
+  RSX_STAMP(10, blockIdx.x == 0);
 
   // ---- this workgroup's partial of every weight gradient: [dW0 | db0 | dW1 | db1 | dW2 | db2] --------------------------
   float* out = p.part + (size_t)blockIdx.x * ((size_t)K4 * p.N1 + p.N1 + (size_t)p.N1 * p.N2 + 2 * p.N2 + 1);
@@ -529,22 +674,23 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
         if (k1 < p.N1 && n < p.N2) o_dW1[(size_t)k1 * p.N2 + n] = accW1[jt][r];
       }
   }
+  if ((wave == NT1 || wave == NT1 + 1) && kq == 0) {   // db1 / dW2: row 0 of the ones-row tiles
+    float* o_ = wave == NT1 ? o_db1 : o_dW2;
+#pragma unroll
+    for (int jt = 0; jt < NT2; ++jt) {
+      const int n = 16 * jt + i;
+      if (n < p.N2) o_[n] = accW1[jt][0];
+    }
+  }
   // bias-like sums: per-lane partials -> fixed-order sums over lanes and waves through LDS (the tiles are idle now)
   float* red = sG1;                                    // [8 waves][64 lanes][NR], spans the g1 / a1 / g2 tiles
-  constexpr int NR = NH1 + 8 * NT2 + 1;
+  constexpr int NR = NH1 + 1;
   static_assert(8 * 64 * NR <= 68 * (2 * N1P + N2P + 2 * K), "reduction scratch must fit the block tiles");
   {
     float* r_ = red + (wave * 64 + lane) * NR;
 #pragma unroll
     for (int a = 0; a < NH1; ++a) r_[a] = db0acc[a];
-#pragma unroll
-    for (int a = 0; a < NT2; ++a)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        r_[NH1 + 4 * a + t] = db1acc[a][t];
-        r_[NH1 + 4 * NT2 + 4 * a + t] = dw2acc[a][t];
-      }
-    r_[NH1 + 8 * NT2] = db2acc;
+    r_[NH1] = db2acc;
   }
   __syncthreads();
   // db0[n1 = 16*nt + i]: nt belongs to half nt / NH1; sum over that half's 4 row-tile waves and the 4 kq lanes of column i
@@ -555,24 +701,14 @@ __global__ __launch_bounds__(512) void din_attn_bwd_k(const AttnBwdArgs p) {
       for (int k4 = 0; k4 < 4; ++k4) s_ += red[((h_ * 4 + w) * 64 + 16 * k4 + ii) * NR + u];
     o_db0[n] = s_;
   }
-  // db1 / dW2 [n2 = 16*kb + 4*kq + t]: accumulated by half 0; sum over its 4 waves and the 16 row lanes of group kq
-  for (int n = tid; n < p.N2; n += 512) {
-    const int kb = n >> 4, k4 = (n >> 2) & 3, t = n & 3;
-    float s1 = 0.f, s2 = 0.f;
-    for (int w = 0; w < 4; ++w)
-      for (int ii = 0; ii < 16; ++ii) {
-        s1 += red[(w * 64 + 16 * k4 + ii) * NR + NH1 + 4 * kb + t];
-        s2 += red[(w * 64 + 16 * k4 + ii) * NR + NH1 + 4 * NT2 + 4 * kb + t];
-      }
-    o_db1[n] = s1;
-    o_dW2[n] = s2;
-  }
   if (tid == 0) {
     float s_ = 0.f;
     for (int w = 0; w < 4; ++w)
-      for (int ii = 0; ii < 16; ++ii) s_ += red[(w * 64 + ii) * NR + NH1 + 8 * NT2];
+      for (int ii = 0; ii < 16; ++ii) s_ += red[(w * 64 + ii) * NR + NH1];
     o_db2[0] = s_;
   }
+  RSX_STAMP(11, blockIdx.x == 0);
+  RSX_STAMP_MAX(12, true);
 }
 
 // Two small jobs that only need the backward kernel's outputs, as ONE launch of 1024-thread workgroups:
@@ -860,14 +996,14 @@ extern "C" size_t rsx_din_attn_bwd_workspace_floats(int B, int P, int K, int N1,
   return M * K + (size_t)attn_bwd_groups((int)M) * attn_npart(K, N1, N2);
 }
 
-template <int KB, int NT1, int NT2>
+template <int KB, int NT1, int NT2, bool VEC>
 static int launch_attn_bwd(const AttnBwdArgs& p, int G, hipStream_t st) {
   using D = AttnDims<KB, NT1, NT2>;
-  const size_t fl = (size_t)D::K4 * D::LD1 + (size_t)D::N1P * D::LD2 + D::N2P + (size_t)68 * (2 * D::N1P + D::N2P + 2 * D::K);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_k<KB, NT1, NT2>),
+  const size_t fl = (size_t)D::K4 * D::LD1 + (size_t)D::N1P * D::LD2 + D::N2P + (size_t)68 * (2 * D::N1P + 2 * D::N2P + 2 * D::K);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_k<KB, NT1, NT2, VEC>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess || fl * sizeof(float) > 160 * 1024) return RSX_EUNSUPPORTED;
-  RSX_LAUNCH((din_attn_bwd_k<KB, NT1, NT2>), dim3(G), dim3(512), fl * sizeof(float), st, p);
+  RSX_LAUNCH((din_attn_bwd_k<KB, NT1, NT2, VEC>), dim3(G), dim3(512), fl * sizeof(float), st, p);
   return RSX_OK;
 }
 
@@ -898,11 +1034,17 @@ static int attn_bwd_impl(const float* H, const float* q, const float* W0, const 
   if ((rows == nullptr) != (count == nullptr) || (rows != nullptr && ids == nullptr)) return RSX_EINVAL;
   if (dropout_rate < 0.f || dropout_rate >= 1.f) return RSX_EINVAL;
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;
+  {   // the backward kernel addresses its per-row arrays with 32-bit element offsets
+    const size_t widest = (size_t)(N1 > ld_dH ? N1 : ld_dH);
+    if ((size_t)B * P * widest >= (1ull << 30)) return RSX_EUNSUPPORTED;
+  }
   const int M = B * P, G = attn_bwd_groups(M);
   AttnBwdArgs p{H, q, W0, W1, W2, a1, a2, dw, dH, workspace, workspace + (size_t)M * K, mask1, mask2, rng_step, seed,
                 (uint32_t)layer0, dropout_rate, M, P, N1, N2, (M + 63) / 64, accumulate_dH != 0, ld_dH, rows, count};
   hipStream_t st = rsx_s(stream);
-  const int rc = K == 32 ? launch_attn_bwd<2, 5, 3>(p, G, st) : launch_attn_bwd<1, 5, 3>(p, G, st);
+  const bool vec = N1 % 4 == 0 && N2 % 4 == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)a2 & 15) == 0;
+  const int rc = K == 32 ? (vec ? launch_attn_bwd<2, 5, 3, true>(p, G, st) : launch_attn_bwd<2, 5, 3, false>(p, G, st))
+                         : (vec ? launch_attn_bwd<1, 5, 3, true>(p, G, st) : launch_attn_bwd<1, 5, 3, false>(p, G, st));
   if (rc != RSX_OK) return rc;
   RSX_CHECK_LAUNCH();
   if (!finish) return RSX_OK;
@@ -956,3 +1098,14 @@ extern "C" int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, 
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
+
+#ifdef RSX_STAMPS
+// profiling build only: the attention kernels' phase stamps (100 MHz wall clock ticks)
+extern "C" int rsx_dbg_stamps_attn_zero() {
+  static const unsigned long long z[64] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(rsx_stamps_d), z, sizeof(z)) == hipSuccess ? RSX_OK : RSX_ELAUNCH;
+}
+extern "C" int rsx_dbg_stamps_attn(unsigned long long* out_h) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(rsx_stamps_d), sizeof(unsigned long long) * 64) == hipSuccess ? RSX_OK : RSX_ELAUNCH;
+}
+#endif
