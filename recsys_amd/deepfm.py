@@ -169,12 +169,21 @@ def _train_fused(store, arena, ids, labels, params, masks):
         zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         job = None
+        side, main = None, torch.cuda.current_stream()
         if wk > 1:
             arena.select(wpos)
             if wpos == 0:
                 from .dist import window_global_ids
                 win_ids = window_global_ids(dp, wfeat)   # data-parallel: ONE all-gather for the ids of all wk local batches
-                arena.sort_window(win_ids)
+                # RSX_WINDOW_SIDE=1 (single replica, opt-in; dcn.py has the note): the window's sort + sweep on a side stream
+                if dp is None and os.environ.get("RSX_WINDOW_SIDE", "0") == "1" and \
+                        os.environ.get("RSX_WINDOW_RIDE", "0") != "1":
+                    if getattr(store, "_side_stream", None) is None:
+                        store._side_stream = torch.cuda.Stream()
+                    side = store._side_stream
+                    side.wait_stream(main)
+                with torch.cuda.stream(side if side is not None else main):
+                    arena.sort_window(win_ids)
             arena.last_B = ids.shape[0] * (dp.world if dp is not None else 1)
         elif ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
             arena.select(0)
@@ -217,7 +226,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
             # ALU-heavy, and as riders they inherit their carrier's occupancy (measured, DeepFM bs 256: carried 164 us per
             # 4-step window, stand-alone 73 us = 18 us per step against 53-60 us for a one-step sweep)
             cold, hot = arena.adam_split_segments(window_k=wk)
-            store.opt.window_sweep(cold[::-1])
+            with torch.cuda.stream(side if side is not None else main):
+                store.opt.window_sweep(cold[::-1])
         elif overlap and wpos == 0:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
@@ -248,6 +258,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
             sort_job=job, sweeps=sweeps, sort_in_fwd=overlap, outs=(dXv, gy1v, gy2v) if zc else None,
             layer_done=layer_done, gather=(arena, ids, S, y1p, y2) if fuse_gather else None)
+        if side is not None:
+            main.wait_stream(side)
 
     def train_op():
         with torch.no_grad():

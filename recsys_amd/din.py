@@ -8,6 +8,7 @@ Hand kernels: row gathers, the attention-weighted masked history sum (fwd/bwd), 
 the non-lazy TF-1 Adam sweep.  The attention / head MLP GEMMs (M = B*P rows) are library GEMMs via torch.
 """
 import argparse
+import os
 
 import torch
 
@@ -158,6 +159,13 @@ class DinFused:
         arena.null_last = True
         arena._bind_partials()
 
+    def _side_stream(self):
+        if os.environ.get("RSX_DIN_SIDE_SORT", "1") != "1":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def _gather(self, B, i_id, i_cate, hist):
         C, a = self.C, self.arena
         K, P = self.K, self.P
@@ -202,21 +210,31 @@ class DinFused:
                        "rsx_din_prepare2")
             labels_f = self.labels_f[:B] if lab64 is not None else labels.reshape(-1).to(torch.float32)
             a.select(0)
-            if dp is not None:
-                # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
-                # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
-                a.field_sort(dp.all_gather_rows(keys2))
-                vals_full, gbias_full = dp.send_views(N)
-            elif big:
-                a.field_sort_t(self.keys_t, N)
-            else:
-                a.field_sort(keys2)
-            # The item bias (i_item, tf.gather by the target ids: :96,139) rides with the item table: its rows ARE item rows, so the
-            # item field's dedup serves it; rows that only a history touches get a zero-gradient update from the same launch.
-            cold = [a.adam_split_segments()[0][0],
-                    dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=4, n=self.n_item, var=self.barena.tables, m=self.barena.m_t,
-                         v=self.barena.v_t, slot=a.slot, slot_w=None)]
-            store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
+            # Round 4: the ids-only branch of the step -- the dedup sort (7 launches on 52 workgroups: a chain of launch latencies)
+            # and the sweep over the rows it leaves untouched -- runs on a SIDE stream beside the forward / backward launches
+            # (which read and write touched rows only) and joins the step's stream before the scatter.  Captured, the fork and
+            # the join are two edges of the step's graph.  Single replica only: under data parallelism the sort waits for the
+            # keys' all-gather, which is ordered with the other collectives on the step's stream.  RSX_DIN_SIDE_SORT=0: in line.
+            side = self._side_stream() if dp is None else None
+            main = torch.cuda.current_stream()
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                if dp is not None:
+                    # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
+                    # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
+                    a.field_sort(dp.all_gather_rows(keys2))
+                    vals_full, gbias_full = dp.send_views(N)
+                elif big:
+                    a.field_sort_t(self.keys_t, N)
+                else:
+                    a.field_sort(keys2)
+                # The item bias (i_item, tf.gather by the target ids: :96,139) rides with the item table: its rows ARE item rows, so the
+                # item field's dedup serves it; rows that only a history touches get a zero-gradient update from the same launch.
+                cold = [a.adam_split_segments()[0][0],
+                        dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=4, n=self.n_item, var=self.barena.tables, m=self.barena.m_t,
+                             v=self.barena.v_t, slot=a.slot, slot_w=None)]
+                store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
             # ---- forward --------------------------------------------------------------------------------------------
             self._gather(B, i_id, i_cate, hist)
             q = (self.qi[:B], self.qc[:B])
@@ -280,6 +298,8 @@ class DinFused:
             _lib.check(L.rsx_din_attn_finish_pair(_ptr(self.ws[0]), _ptr(gouts[0]), dqp[0], _ptr(hist[0]), _ptr(dX),
                                                   _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,
                                                   B, P, K, n1, n2, 2 * K, 3 * K, st), "rsx_din_attn_finish_pair")
+            if side is not None:
+                main.wait_stream(side)            # the scatter (train_op) needs the sort; the sweep must precede its Adam state advance
 
         def train_op():                                                    # AdamOptimizer.minimize (:172-173)
             with torch.no_grad():
