@@ -50,7 +50,8 @@ __device__ __forceinline__ float4 f4_shfl_xor(float4 a, int m) {
 // boundaries into a per-translation-unit device array, read back by rsx_dbg_stamps_<unit>(); scripts/stamp_probe.py
 // builds that variant into scripts/_build/ and prints where a latency-bound kernel spends its microseconds.
 #ifdef RSX_STAMPS
-#define RSX_STAMP_DECL static __device__ unsigned long long rsx_stamps_d[64];
+static __device__ unsigned long long rsx_stamps_d[64];     // one array per translation unit
+#define RSX_STAMP_DECL
 #define RSX_STAMP(slot, cond)                                                        \
   do {                                                                               \
     if ((cond) && threadIdx.x == 0) rsx_stamps_d[slot] = wall_clock64();             \

@@ -238,6 +238,284 @@ __device__ __forceinline__ void field_sort_block(const SortArgs& a, int f, uint3
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: SEVERAL workgroups per field (stand-alone sort launches, 1 024 <= B <= 8 192).  The one-workgroup form above leaves
+// 217 of 256 CUs idle and its critical path is the 17-bit fields' three 8-bit passes over all B keys (26 us at 4 096 x 39).
+// Here field f is cut into G id ranges [lo, hi) of equal width; workgroup (f, g)
+//   * reads the WHOLE id column (cheap: B ints), marks every id in an LDS presence bitmap (rows <= 131 072 -> 16 KB), counts
+//     the keys below its range and compacts the keys inside it in ascending example order (stable);
+//   * sorts ITS keys only (~B / G of them, id bits of the range only: two 8-bit passes at most for 2^16-row ranges);
+//   * knows every output index without talking to the other workgroups: sorted position = keys below + local rank, unique
+//     index j of id r = popcount of the bitmap below r (a prefix popcount per word + one masked popcount) -- heads, segment
+//     ids and the slot map follow; a segment never crosses a range, so the long / huge classification is local too.
+// No workgroup waits for another one (no spin, no co-residency requirement).  What the old form did by being alone:
+//   * forgetting the previous step's rows: a workgroup owns the slot-map entries of its row range and nobody else reads or
+//     writes them during the sort, so it sweeps that range of the map itself (entries >= 0 -> -1) while its ids are in flight
+//     (the previous unique-row list cannot be used: other workgroups overwrite it at their own pace);
+//   * the long / huge lists of the two-stage segment-sum: a workgroup reserves list space with ONE atomic per class on a
+//     per-(job, field) running counter; the last workgroup of the field to arrive (a ticket) publishes the totals and zeroes
+//     the three words for the next launch.  List order is arrival order, as before (it only assigns work).
+// The result arrays are bit-identical to field_sort_block's except for the order of those two lists.
+struct SortSplitScratch {
+  int32_t w[RSX_ADAM_WINDOW_MAX][64][4];     // [job][field]{running long, running huge, ticket, -}: zero between launches
+};
+
+__device__ __forceinline__ void field_sort_split_block(const SortArgs& a, int f, int g, int G, int W, uint32_t* lds,
+                                                        int32_t* scr /* [4] of (job, f) */) {
+  if ((a.skip >> f) & 1ull) return;                     // (workgroup-uniform)
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+  const int B = a.B, n = a.n, bbits = a.bbits, stride = a.stride;
+  const int roff = a.row_off[f];
+  const int rows = a.row_off[f + 1] - roff;
+  const int Gw = rows < G ? rows : G;
+  const int span = (rows + Gw - 1) / Gw;
+  const int lo = g * span;
+  if (lo >= rows) return;
+  const int hi = lo + span < rows ? lo + span : rows;
+  const bool last_range = hi == rows;
+  const int Gf = (rows + span - 1) / span;              // ranges that hold rows (the others returned)
+  uint32_t* keyA = lds;                                 // [n]
+  uint32_t* keyB = lds + n;                             // [n]
+  uint32_t* cnt = lds + 2 * n;                          // [nw * 256]
+  uint32_t* bm = cnt + nw * 256;                        // [W]   presence bitmap of the field's ids
+  uint32_t* pre = bm + W;                               // [W]   distinct ids in the words before this one
+  uint32_t* wsum = pre + W;                             // [64]
+  const int Wf = (rows + 31) >> 5;
+  RSX_STAMP(0, blockIdx.x == 0 && blockIdx.y == 0);
+  const int wpt = (Wf + T - 1) / T;                     // bitmap words per thread (contiguous)
+  for (int i = tid; i < wpt * T; i += T)
+    if (i < W) bm[i] = 0;
+  // the column: thread t holds examples t*ipt .. t*ipt + ipt - 1 (ascending: the compaction below is stable)
+  const int ipt = n / T;                                // 2, 4 or 8
+  uint32_t v[8];
+  {
+    const int32_t* col = a.ids + f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = tid * ipt + u;
+      v[u] = (u < ipt) ? (uint32_t)col[(size_t)(b < B ? b : B - 1) * a.F] : 0u;
+    }
+  }
+  // forget the previous sort's rows of MY range (see above): 16-byte loads, 8 in flight -- a 25 000-row range is ONE round trip
+  {
+    int32_t* sl = a.slot + roff;                          // (hipMalloc'ed base: 16-byte aligned where roff + r is a multiple of 4)
+    const int mis = (int)((reinterpret_cast<uintptr_t>(sl + lo) >> 2) & 3u);
+    const int a0 = lo + ((4 - mis) & 3) < hi ? lo + ((4 - mis) & 3) : hi;      // first 16-byte aligned row of the range
+    const int a1 = a0 + ((hi - a0) & ~3);                                     // end of the aligned body
+    if (tid < a0 - lo && sl[lo + tid] >= 0) sl[lo + tid] = -1;
+    if (tid < hi - a1 && sl[a1 + tid] >= 0) sl[a1 + tid] = -1;
+    int4* s4 = reinterpret_cast<int4*>(sl + a0);
+    const int n4 = (a1 - a0) >> 2;
+    for (int q = tid; q < n4; q += 8 * T) {
+      int4 sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sv[u] = s4[q + u * T < n4 ? q + u * T : n4 - 1];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (q + u * T < n4 && (sv[u].x >= 0 || sv[u].y >= 0 || sv[u].z >= 0 || sv[u].w >= 0))
+          s4[q + u * T] = make_int4(-1, -1, -1, -1);
+      }
+    }
+  }
+  __syncthreads();                                      // bitmap zeroed
+  RSX_STAMP_MAX(1, true);
+  int mine = 0, below = 0;
+  int fbits = 0;
+  while ((1 << fbits) < rows) ++fbits;
+  // Marking: an LDS atomic serialises over the lanes (and waves) that hit the same word.  A field of <= 256 rows has <= 8
+  // words and every wave instruction would queue 64 lanes on them (measured: rows = 3 -> 27 us for the 4 096 marks of one
+  // workgroup); there ONE lane per distinct id and wave instruction marks (ballot match over the id bits).
+  const bool few = fbits <= 8;                           // (workgroup-uniform)
+  const uint64_t ltm = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (u < ipt) {                                       // (uniform)
+      const bool ok = tid * ipt + u < B;
+      bool mark = ok;
+      if (few) {
+        uint64_t m = __ballot(ok);
+        m = ok ? m : ~m;
+        m &= rsx_match_digit(v[u], fbits);
+        mark = ok && (m & ltm) == 0ull;
+      }
+      if (mark) atomicOr(&bm[v[u] >> 5], 1u << (v[u] & 31u));
+      if (ok) {
+        mine += ((int)v[u] >= lo && (int)v[u] < hi) ? 1 : 0;
+        below += (int)v[u] < lo ? 1 : 0;
+      }
+    }
+  }
+  __syncthreads();                                      // bitmap complete
+  RSX_STAMP_MAX(2, true);
+  // three block scans at once: my keys (exclusive -> compaction offset), keys below (total), distinct ids per word group
+  int pc = 0;
+  for (int k = 0; k < wpt; ++k) {
+    const int i = tid * wpt + k;
+    pc += i < Wf ? __popc(bm[i]) : 0;
+  }
+  int i_m = mine, i_b = below, i_p = pc;
+#pragma unroll
+  for (int d = 1; d < RSX_WAVE; d <<= 1) {
+    const int om = __shfl_up(i_m, d), ob = __shfl_up(i_b, d), op = __shfl_up(i_p, d);
+    if (lane >= d) { i_m += om; i_b += ob; i_p += op; }
+  }
+  if (lane == 63) { wsum[w] = (uint32_t)i_m; wsum[16 + w] = (uint32_t)i_b; wsum[32 + w] = (uint32_t)i_p; }
+  __syncthreads();
+  int off = i_m - mine, n_own = 0, n_below = 0, pbase = i_p - pc, total_u = 0;
+  for (int ww = 0; ww < nw; ++ww) {
+    const int vm = (int)wsum[ww], vb = (int)wsum[16 + ww], vp = (int)wsum[32 + ww];
+    if (ww < w) { off += vm; pbase += vp; }
+    n_own += vm; n_below += vb; total_u += vp;
+  }
+  {
+    int run = pbase;
+    for (int k = 0; k < wpt; ++k) {
+      const int i = tid * wpt + k;
+      if (i < Wf) { pre[i] = (uint32_t)run; run += __popc(bm[i]); }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (u < ipt && tid * ipt + u < B && (int)v[u] >= lo && (int)v[u] < hi)
+      keyA[off++] = ((v[u] - (uint32_t)lo) << bbits) | (uint32_t)(tid * ipt + u);
+  }
+  // keys per wave of the radix passes: a contiguous range, a multiple of 64; all-ones padding sorts last
+  int ipw = ((n_own + nw - 1) / nw + 63) & ~63;
+  if (ipw == 0) ipw = 64;
+  for (int i = n_own + tid; i < nw * ipw; i += T) keyA[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  RSX_STAMP_MAX(3, true);
+  uint32_t* src = keyA;
+  uint32_t* dst = keyB;
+  {
+    int idbits = 0;
+    while ((1 << idbits) < hi - lo) ++idbits;
+    const int npass = (idbits + 7) >> 3;
+    const int width = npass ? (idbits + npass - 1) / npass : 0;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int sh = 0; sh < idbits; sh += width) {
+      const int nb = idbits - sh < width ? idbits - sh : width;
+      const uint32_t dmask = (1u << nb) - 1u;
+      for (int i = tid; i < nw * 256; i += T) cnt[i] = 0;
+      __syncthreads();
+      for (int j = 0; j < ipw; j += 64) atomicAdd(&cnt[w * 256 + ((src[w * ipw + j + lane] >> (bbits + sh)) & dmask)], 1u);
+      __syncthreads();
+      // exclusive scan in (digit-major, wave-minor) order over the 256 * nw counters as ONE linear array: thread t owns the four
+      // consecutive entries 4t .. 4t + 3 = digit 4t / nw, waves 4t % nw .. + 3 (nw is a multiple of 4; T = 64 nw threads cover it)
+      {
+        const int d0 = (4 * tid) / nw, w0 = (4 * tid) - d0 * nw;
+        int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = (int)cnt[(w0 + q) * 256 + d0];
+        const int tot = (c[0] + c[1]) + (c[2] + c[3]);
+        int incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < RSX_WAVE; dd <<= 1) {
+          const int o = __shfl_up(incl, dd);
+          if (lane >= dd) incl += o;
+        }
+        if (lane == 63) wsum[w] = (uint32_t)incl;
+        __syncthreads();
+        int run = incl - tot;
+        for (int ww = 0; ww < w; ++ww) run += (int)wsum[ww];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          cnt[(w0 + q) * 256 + d0] = (uint32_t)run;
+          run += c[q];
+        }
+      }
+      __syncthreads();
+      for (int j = 0; j < ipw; j += 64) {
+        const uint32_t k = src[w * ipw + j + lane];
+        const uint32_t d = (k >> (bbits + sh)) & dmask;
+        const uint64_t m = rsx_match_digit(d, nb);
+        const uint32_t old = cnt[w * 256 + d];
+        const int r = __popcll(m & lt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (r == 0) cnt[w * 256 + d] = old + (uint32_t)__popcll(m);
+        dst[old + r] = k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      __syncthreads();
+      uint32_t* t = src;
+      src = dst;
+      dst = t;
+    }
+  }
+  // emit: sorted position = n_below + i; unique index from the bitmap
+  const uint32_t bmask = (1u << bbits) - 1u;
+  auto rank_of = [&](const int id) -> int {             // distinct ids of the field below `id` (id < rows)
+    return (int)pre[id >> 5] + __popc(bm[id >> 5] & ((1u << (id & 31)) - 1u));
+  };
+  const int jlo = rank_of(lo);
+  const int jhi = last_range ? total_u : rank_of(hi);
+  const int U = jhi - jlo;                              // my distinct ids
+  // Segment starts, the long / huge classification and the list reservations first (LDS only + two atomics whose round trip
+  // hides behind the stores below); then every global store; then the ticket.  No fence: the only cross-workgroup traffic
+  // of this launch are the atomics on the three scratch words, and the lists are read by LATER launches.
+  uint32_t* hs = dst;                                   // [U] local position of every segment start (the idle key buffer)
+  uint32_t* lst = cnt;                                  // [<= n/17] long from the front, huge from the back of cnt's nw*256 words
+  const int lcap = nw * 256;
+  const bool lists = a.segid != nullptr;
+  if (lists) {
+    for (int i = tid; i < n_own; i += T) {
+      const uint32_t kk = src[i];
+      if (i == 0 || (src[i - 1] >> bbits) != (kk >> bbits)) hs[rank_of(lo + (int)(kk >> bbits)) - jlo] = (uint32_t)i;
+    }
+    if (tid == 0) { wsum[0] = 0; wsum[1] = 0; }
+    __syncthreads();
+    for (int jl = tid; jl < U; jl += T) {
+      const int L = (jl + 1 < U ? (int)hs[jl + 1] : n_own) - (int)hs[jl];
+      if (L > 256) lst[lcap - 1 - (int)atomicAdd(&wsum[1], 1u)] = (uint32_t)(jlo + jl);
+      else if (L > 16) lst[atomicAdd(&wsum[0], 1u)] = (uint32_t)(jlo + jl);
+    }
+    __syncthreads();
+    if (tid < 2) {                                      // lane 0: long, lane 1: huge -- both reservations in flight together
+      const int cnum = (int)wsum[tid];
+      wsum[2 + tid] = cnum ? (uint32_t)atomicAdd(&scr[tid], cnum) : 0u;
+    }
+  }
+  RSX_STAMP_MAX(4, true);
+  for (int i = tid; i < n_own; i += T) {
+    const uint32_t kk = src[i];
+    const int id = lo + (int)(kk >> bbits);
+    const int pos = n_below + i;
+    const int j = rank_of(id);
+    a.perm[(size_t)f * stride + pos] = (int32_t)(kk & bmask);
+    if (lists) a.segid[(size_t)f * stride + pos] = j;
+    if (i == 0 || (src[i - 1] >> bbits) != (kk >> bbits)) {
+      const int row = roff + id;
+      a.uniq_row[(size_t)f * stride + j] = row;
+      a.seg_off[(size_t)f * (stride + 1) + j] = pos;
+      a.slot[row] = f * stride + j;
+    }
+  }
+  if (last_range && tid == 0) {
+    a.seg_off[(size_t)f * (stride + 1) + total_u] = B;
+    a.nuniq[f] = total_u;
+  }
+  if (!lists) return;
+  RSX_STAMP_MAX(5, true);
+  __syncthreads();                                      // the reservations' results (and every wave's stores issued)
+  const int nl = (int)wsum[0], nh = (int)wsum[1];
+  const int nch = (B + 15) >> 4;
+  int32_t* cn = a.segid + (size_t)a.F * stride;
+  int32_t* ll = cn + 2 * a.F + (size_t)f * nch;
+  const int bl = (int)wsum[2], bh = (int)wsum[3];
+  RSX_STAMP_MAX(6, true);
+  for (int k = tid; k < nl; k += T) ll[bl + k] = (int32_t)lst[k];
+  for (int k = tid; k < nh; k += T) ll[nch - 1 - (bh + k)] = (int32_t)lst[lcap - 1 - k];
+  if (tid == 0) {
+    const int t = atomicAdd(&scr[2], 1);
+    if (t == Gf - 1) {                                  // every range of the field has reserved: the totals are final
+      cn[f] = atomicExch(&scr[0], 0);
+      cn[a.F + f] = atomicExch(&scr[1], 0);
+      atomicExch(&scr[2], 0);
+    }
+  }
+  RSX_STAMP_MAX(7, true);
+}
+
 static inline int rsx_ceil_log2(int x) {
   int b = 0;
   while ((1 << b) < x) ++b;
@@ -261,6 +539,19 @@ static inline int rsx_sort_args(SortArgs& a, int max_rows_per_field, int threads
 static inline size_t rsx_sort_lds_bytes(const SortArgs& a, int threads) {
   if (a.n <= 512 && a.n <= threads) return ((size_t)a.n + 32) * sizeof(uint32_t);
   return ((size_t)2 * a.n + 32 + (size_t)(threads / 64) * 256) * sizeof(uint32_t);
+}
+
+// the split form: applicability and launch geometry (stand-alone launches only; RSX_SORT_SPLIT=0 switches it off for A/B runs)
+static inline int rsx_sort_split_parts(const SortArgs& a, int max_rows_per_field) {
+  // (measured, 39 Criteo fields: 1 024 keys 16.6 vs 12.7 us, 2 048: 23.8 vs 18.8 -- the one-workgroup form wins; 4 096: 24.6 vs 26.7,
+  // 8 192: 41.3 vs 43.6.  Every workgroup pulls the whole [B, F] id matrix through its L1 to read one column -- ~4-7 us that no
+  // split shortens; profiles/r04_g_sort_split_stamps.txt)
+  if (a.n < 4096 || a.n > 8192 || max_rows_per_field > 131072 || a.F > 64) return 0;
+  return a.n <= 4096 ? 4 : 8;
+}
+static inline int rsx_sort_split_words(int max_rows_per_field) { return (((max_rows_per_field + 31) >> 5) + 3) & ~3; }
+static inline size_t rsx_sort_split_lds_bytes(const SortArgs& a, int threads, int W) {
+  return ((size_t)2 * a.n + (size_t)(threads / 64) * 256 + 2 * (size_t)W + 64) * sizeof(uint32_t);
 }
 
 // host: a rsx_sort_job (the step's dedup sort carried by another launch as extra 256-thread workgroups) -> SortArgs;

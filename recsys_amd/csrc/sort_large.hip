@@ -11,6 +11,7 @@
 // Replaces the same TF ops as rsx_field_sort (unique() in safe_embedding_lookup_sparse).
 #include "rsx_common.h"
 #include "sort_device.h"
+RSX_STAMP_DECL
 
 namespace {
 constexpr int LS_TILE = 4096;   // keys per workgroup

@@ -1174,6 +1174,16 @@ __global__ __launch_bounds__(1024) void tower_reduce_partials_k(double* __restri
 // =============================================================================================
 constexpr int TOWER_BIG_MIN_B = 1024;
 constexpr int TOWER_BIG_MIN_K = 256;     // input width from which the large-batch kernels are used (see rsx_tower_fwd_layer)
+// Round 4: at batch >= 4096 the BACKWARD of a 100-wide layer also wins through the large-batch kernel (dcn.py's second layer:
+// step 0.2094 -> 0.2052 ms, A/B on one box; the forward does not: 0.2077 with it alone, 0.2053 with both) -- the rule stays a
+// function of the layer shape and batch only.  RSX_TOWER_BIG_MIN_K_FWD / _BWD override the width threshold (A/B runs).
+constexpr int TOWER_BIG_MIN_K_BWD_4096 = 64;
+static inline int tower_big_min_k(bool bwd, int B) {
+  static const int f = getenv("RSX_TOWER_BIG_MIN_K_FWD") ? atoi(getenv("RSX_TOWER_BIG_MIN_K_FWD")) : 0;
+  static const int b = getenv("RSX_TOWER_BIG_MIN_K_BWD") ? atoi(getenv("RSX_TOWER_BIG_MIN_K_BWD")) : 0;
+  if (bwd) return b > 0 ? b : (B >= 4096 ? TOWER_BIG_MIN_K_BWD_4096 : TOWER_BIG_MIN_K);
+  return f > 0 ? f : TOWER_BIG_MIN_K;
+}
 // LDS row stride of a 16-row operand tile read with ds_read_b128 by lane (row = lane & 15, k-quarter = lane >> 4): a stride
 // == 8 (mod 64) floats puts the 16 lanes of every hardware lane group on distinct banks
 __host__ __device__ inline int big_stride(int K) { return (K + 127) / 128 * 128 + 8; }     // (>= K rounded up to 128 floats)
@@ -1856,7 +1866,7 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   // 48 -> 41 us incl. the reduce -- and lose on 100-wide layers, whose launches are latency chains either way: DIN's 96 /
   // 100 / 52-wide MLP at batch 1 024 ran 22 us per step slower through them.  The choice is a function of the layer shape
   // only, so every path of one model and batch size takes the same kernels.)
-  if (big_env && B >= TOWER_BIG_MIN_B && K >= TOWER_BIG_MIN_K && N <= 256 && lds_big <= 64 * 1024) {
+  if (big_env && B >= TOWER_BIG_MIN_B && K >= tower_big_min_k(false, B) && N <= 256 && lds_big <= 64 * 1024) {
     // one workgroup per 16-row tile across all N columns (see tower_fwd_big_k)
     p.n_own = (B + TM - 1) / TM;
     size_t l2 = lds_big > lds ? lds_big : lds;                     // (lds: what a riding sort needs)
@@ -2210,7 +2220,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   const int rcs = adam_build_slice(sweep_h, p.sweep);
   if (rcs != RSX_OK) return rcs;
   static const int big_env = getenv("RSX_TOWER_BIG") ? atoi(getenv("RSX_TOWER_BIG")) : 1;   // (0: the small-batch tiles, A/B runs)
-  if (big_env && B >= TOWER_BIG_MIN_B && K >= TOWER_BIG_MIN_K && dw_partials != nullptr && (N & 3) == 0 && N <= 128 &&
+  if (big_env && B >= TOWER_BIG_MIN_B && K >= tower_big_min_k(true, B) && dw_partials != nullptr && (N & 3) == 0 && N <= 128 &&
       (K & 3) == 0) {
     // one workgroup per 16-row tile for d(input), (64 features x row block) workgroups for dW (see tower_bwd_big_k)
     const int NP = (N + 15) & ~15;

@@ -81,6 +81,53 @@ def test_field_sort_is_exact(B, rows):
         assert np.array_equal(slot, want_slot)
 
 
+@pytest.mark.parametrize("B,rows", [(4096, None), (1024, (3, 100000, 40)), (3000, (1, 2, 131072, 17)), (8192, (5, 93145, 1460)),
+                                    (4096, (100000,) * 3)])
+def test_field_sort_split_lists_and_repeat(B, rows):
+    """The several-workgroups-per-field sort (sort_device.h field_sort_split_block, 1024 <= B <= 8192): every output exact
+    over three calls on fresh ids (slot-map entries of the previous call forgotten, the per-field list counters reset by the
+    last range), and the long / huge segment lists of the two-stage segment-sum hold exactly the segments of 17..256 /
+    > 256 entries (list ORDER is arrival order: compared as sets)."""
+    rng = np.random.default_rng(7 * B)
+    row_off = criteo.row_offsets() if rows is None else np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    a, _, _ = _arena(row_off, 16, B + 5, rng)
+    F = len(row_off) - 1
+    st = a.stride
+    for rep in range(3):
+        ids = synth_ids(rng, B, row_off)
+        if rep == 1:                                   # skew: half of the batch on one id per field
+            ids[: B // 2] = ids[0]
+        a.field_sort(torch.from_numpy(ids).cuda())
+        torch.cuda.synchronize()
+        perm = a.perm.cpu().numpy().reshape(F, st)
+        seg = a.seg_off.cpu().numpy().reshape(F, st + 1)
+        uniq = a.uniq_row.cpu().numpy().reshape(F, st)
+        nu = a.nuniq.cpu().numpy()
+        slot = a.slot.cpu().numpy()[:a.R]
+        sid = a.segid.cpu().numpy()
+        nch = (B + 15) // 16
+        cnts = sid[F * st: F * st + 2 * F]
+        lists = sid[F * st + 2 * F: F * st + 2 * F + F * nch].reshape(F, nch)
+        want_slot = np.full(a.R, -1, np.int64)
+        for f in range(F):
+            order = np.lexsort((np.arange(B), ids[:, f]))
+            assert np.array_equal(perm[f, :B], order)
+            u, first, counts = np.unique(ids[order, f], return_index=True, return_counts=True)
+            assert nu[f] == len(u)
+            assert np.array_equal(uniq[f, :len(u)], u + row_off[f])
+            assert np.array_equal(seg[f, :len(u)], first) and seg[f, len(u)] == B
+            want_slot[u + row_off[f]] = f * st + np.arange(len(u))
+            if not a._two_stage(B):                    # (B <= 1024: no two-stage workspace, the sort gets no segid pointer)
+                continue
+            assert np.array_equal(sid[f * st: f * st + B], np.repeat(np.arange(len(u)), counts))
+            long_j = set(np.nonzero((counts > 16) & (counts <= 256))[0].tolist())
+            huge_j = set(np.nonzero(counts > 256)[0].tolist())
+            assert cnts[f] == len(long_j) and cnts[F + f] == len(huge_j)
+            assert set(lists[f, :len(long_j)].tolist()) == long_j
+            assert set(lists[f, nch - len(huge_j):].tolist()) == huge_j if huge_j else True
+        assert np.array_equal(slot, want_slot)
+
+
 @pytest.mark.parametrize("B,rows,D", [(256, None, 16), (300, (3, 7, 4, 11, 6), 4), (2048, (2, 500), 16),
                                       (2048, None, 16), (4099, (3, 1000, 50, 100000, 1), 16), (1500, (7, 300), 8),
                                       (16384, (3, 40000), 32), (30000, (3, 100000, 40), 16)])
