@@ -466,6 +466,47 @@ int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njobs, rsx_str
  * instead of occupying its own slot on the critical path (same results as a separate rsx_field_sort call).        */
 
 /* ---------------------------------------------------------------------------------------------
+ * A tower WITHOUT batch-norm as ONE launch, din/din.py:130-147: 'mlp_layer' =
+ * L x [tf.layers.dense(relu) -> tf.layers.dropout] -> dense(1); logit = that + s0 (din.py:139: the target item's bias);
+ * loss = mean sigmoid cross-entropy (:146-147); forward AND backward of a 16-row tile by one workgroup with every layer's
+ * weights in LDS, weight gradients as per-workgroup partials summed in workgroup order by a second launch (deterministic).
+ * Replaces the 2L + 2 launches of rsx_tower_fwd_layer / rsx_tower_head / rsx_tower_bwd_layer for such a tower; the dropout
+ * masks are the same counter-based hash (layer index l, element b * widths[l] + c), sums are associated differently.
+ * Envelope (rsx_mlp_nobn_supported): 1 <= L <= 3, K0 and widths multiples of 4 and <= 112, 16-byte aligned arrays.
+ * dW[l] [K_l, widths[l]], db[l] [widths[l]], dwout [widths[L-1]], dbout [1], loss [1] = sum(ce) / B, prob [B],
+ * dX [B, K0] = d loss / d X, gs0 (nullable) [B] = d loss / d s0; loss_scale = 1 / (B * replicas) scales every gradient.
+ * workspace: rsx_mlp_nobn_workspace_floats(B, K0, widths, L) floats.
+ * ------------------------------------------------------------------------------------------- */
+#define RSX_MLP_MAX_LAYERS 3
+typedef struct {
+  const float* X;                          /* [B, K0] */
+  const float* W[RSX_MLP_MAX_LAYERS];
+  const float* b[RSX_MLP_MAX_LAYERS];
+  const float* masks[RSX_MLP_MAX_LAYERS];  /* nullable entries: explicit keep masks [B, widths[l]] (parity tests) */
+  const float* wout;
+  const float* bout;
+  const float* s0;                         /* nullable [B] */
+  const float* labels;                     /* [B] float */
+  const uint32_t* rng_step;                /* device: the optimizer's step counter (dropout key) */
+  float* prob;
+  float* dX;
+  float* gs0;                              /* nullable */
+  float* workspace;
+  float* dW[RSX_MLP_MAX_LAYERS];
+  float* db[RSX_MLP_MAX_LAYERS];
+  float* dwout;
+  float* dbout;
+  float* loss;
+  uint32_t seed;
+  float dropout_rate, loss_scale;
+  int32_t B, K0, L;
+  int32_t widths[RSX_MLP_MAX_LAYERS];
+} rsx_mlp_step;
+int rsx_mlp_nobn_supported(int K0, const int32_t* widths, int L);
+size_t rsx_mlp_nobn_workspace_floats(int B, int K0, const int32_t* widths, int L);
+int rsx_mlp_nobn_train_step(const rsx_mlp_step* step_h, rsx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * DCN cross layers, dcn/dcn.py:132-142: x_{l+1} = (x_l . w_l) * x0 + x_l + b_l, all L
  * layers fused per example.  dim % 4 == 0, dim <= 1024, L <= 8.
  * ------------------------------------------------------------------------------------------- */

@@ -45,6 +45,15 @@ class SegPartials(C.Structure):
 NULL_NONE, NULL_LAST_ROW = -1, -2          # include/rsx.h RSX_NULL_*
 
 
+class MlpStep(C.Structure):               # include/rsx.h rsx_mlp_step
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p * 3), ("b", C.c_void_p * 3), ("masks", C.c_void_p * 3),
+                ("wout", C.c_void_p), ("bout", C.c_void_p), ("s0", C.c_void_p), ("labels", C.c_void_p),
+                ("rng_step", C.c_void_p), ("prob", C.c_void_p), ("dX", C.c_void_p), ("gs0", C.c_void_p),
+                ("workspace", C.c_void_p), ("dW", C.c_void_p * 3), ("db", C.c_void_p * 3), ("dwout", C.c_void_p),
+                ("dbout", C.c_void_p), ("loss", C.c_void_p), ("seed", C.c_uint32), ("dropout_rate", C.c_float),
+                ("loss_scale", C.c_float), ("B", C.c_int32), ("K0", C.c_int32), ("L", C.c_int32), ("widths", C.c_int32 * 3)]
+
+
 class DwReduceJob(C.Structure):
     _fields_ = [("partials", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("sb", C.c_int32), ("K", C.c_int32),
                 ("N", C.c_int32), ("layout", C.c_int32)]
@@ -182,6 +191,9 @@ _SIGS = {
     "rsx_din_reader_next_h": (_I, [_P, _P, _P, _P, _P, _P]),
     "rsx_reader_records_parsed_h": (C.c_int64, [_P]),
     "rsx_reader_close_h": (None, [_P]),
+    "rsx_mlp_nobn_supported": (_I, [_I, _P, _I]),
+    "rsx_mlp_nobn_workspace_floats": (C.c_size_t, [_I, _I, _P, _I]),
+    "rsx_mlp_nobn_train_step": (_I, [C.POINTER(MlpStep), _P]),
     "rsx_eval_metrics_state_words": (_I, [_I]),
     "rsx_eval_metrics_update": (_I, [_P, _P, _P, _I, _P, _P, _I, _P]),
 }

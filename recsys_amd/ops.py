@@ -703,6 +703,28 @@ class FusedTower:
         st = _stream()
         mk = self._masks(B, rate, masks)
         nl = len(self.widths)
+        # Round 4: a tower WITHOUT batch-norm (din.py's 'mlp_layer') runs forward + loss + backward as ONE launch + one reduce
+        # (csrc/mlp_fused.hip, rsx_mlp_nobn_train_step) instead of 2L + 2 launches; RSX_MLP_FUSE=0: the launch-per-layer form
+        if (not self.bn_on and self._mlp_fused_ok() and sort_job is None and sweeps is None and gather is None
+                and layer_done is None and s1 is None and c0 is None and not relu0 and not relu2
+                and head[2] is None and head[3] is None and isinstance(head[0], str) and isinstance(head[1], str)):
+            ms = _lib.MlpStep()
+            ms.X, ms.B, ms.K0, ms.L = X.data_ptr(), B, self.k0, nl
+            for l in range(nl):
+                ms.W[l], ms.b[l] = P[f"{pre}.W{l}"].data_ptr(), P[f"{pre}.b{l}"].data_ptr()
+                ms.dW[l], ms.db[l] = P[f"{pre}.W{l}"].grad.data_ptr(), P[f"{pre}.b{l}"].grad.data_ptr()
+                ms.masks[l] = None if mk[l] is None else mk[l].data_ptr()
+                ms.widths[l] = self.widths[l]
+            ms.wout, ms.bout = P[head[0]].data_ptr(), P[head[1]].data_ptr()
+            ms.dwout, ms.dbout = P[head[0]].grad.data_ptr(), P[head[1]].grad.data_ptr()
+            ms.s0 = None if s0 is None else s0.data_ptr()
+            ms.labels, ms.rng_step = labels.data_ptr(), rng_step.data_ptr()
+            ms.prob, ms.dX, ms.gs0 = self.prob.data_ptr(), o_dX.data_ptr(), None if s0 is None else o_gs0.data_ptr()
+            ms.workspace, ms.loss = self._mlp_ws.data_ptr(), self.loss.data_ptr()
+            ms.seed, ms.dropout_rate, ms.loss_scale = seed, rate, 1.0 / (B * replicas)
+            assert labels.is_contiguous() and o_dX.is_contiguous() and (s0 is None or s0.is_contiguous())
+            check(L.rsx_mlp_nobn_train_step(C.byref(ms), st), "rsx_mlp_nobn_train_step")
+            return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
         g = lambda name: P[name].grad
         bnp = (lambda name: _ptr(P[name])) if self.bn_on else (lambda name: None)        # gamma / beta (None: no batch-norm)
         bng = (lambda name: _ptr(P[name].grad)) if self.bn_on else (lambda name: None)
@@ -779,6 +801,19 @@ class FusedTower:
                 check(L.rsx_tower_reduce_dw_jobs(arr, len(todo), st), "rsx_tower_reduce_dw_jobs")
         return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
 
+
+    def _mlp_fused_ok(self):
+        """The one-launch form of a batch-norm-free tower applies (envelope of csrc/mlp_fused.hip); allocates its workspace."""
+        ok = getattr(self, "_mlp_ok", None)
+        if ok is None:
+            w = (C.c_int32 * len(self.widths))(*self.widths)
+            ok = os.environ.get("RSX_MLP_FUSE", "1") == "1" and len(self.widths) <= 3 and \
+                bool(lib().rsx_mlp_nobn_supported(self.k0, w, len(self.widths)))
+            if ok:
+                n = int(lib().rsx_mlp_nobn_workspace_floats(self.cap, self.k0, w, len(self.widths)))
+                self._mlp_ws = torch.empty(n, device=self.prob.device)
+            self._mlp_ok = ok
+        return ok
 
     def infer(self, X, rng_step, labels=None, s0=None, c0=None, s1=None,
               head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True):
