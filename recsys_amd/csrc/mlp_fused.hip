@@ -55,60 +55,129 @@ struct MlpArgs {
   long long poffL;
 };
 
-__global__ __launch_bounds__(256) void mlp_nobn_step_k(const MlpArgs p) {
+constexpr int MLP_T = 512, MLP_NW = MLP_T / 64;     // 8 waves = 2 per SIMD: one wave's LDS / MFMA latency hides behind the other's
+
+// one 16x16 output tile, A rows from an LDS tile (float4 along k), B = W[k][col] read down a column (forward).  Even and odd
+// k-steps go to two accumulators: consecutive MFMAs never depend on each other (a dependent 16x16x4 fp32 MFMA waits ~40 cycles)
+__device__ __forceinline__ f32x4 tile_fwd(const float* __restrict__ arow /* in + i*ldi + 4*kq */,
+                                          const float* __restrict__ bcol /* W + 4*kq*ld + col */, const int ld, const int nks) {
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int ks = 0;
+  for (; ks + 1 < nks; ks += 2) {
+    const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+    const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 16);
+    const float* b0 = bcol + 16 * ks * ld;
+    const float* b1 = b0 + 16 * ld;
+    const float b00 = b0[0], b01 = b0[ld], b02 = b0[2 * ld], b03 = b0[3 * ld];
+    const float b10 = b1[0], b11 = b1[ld], b12 = b1[2 * ld], b13 = b1[3 * ld];
+    acc0 = mfma16(a0.x, b00, acc0);
+    acc1 = mfma16(a1.x, b10, acc1);
+    acc0 = mfma16(a0.y, b01, acc0);
+    acc1 = mfma16(a1.y, b11, acc1);
+    acc0 = mfma16(a0.z, b02, acc0);
+    acc1 = mfma16(a1.z, b12, acc1);
+    acc0 = mfma16(a0.w, b03, acc0);
+    acc1 = mfma16(a1.w, b13, acc1);
+  }
+  if (ks < nks) {
+    const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+    const float* b0 = bcol + 16 * ks * ld;
+    acc0 = mfma16(a0.x, b0[0], acc0);
+    acc0 = mfma16(a0.y, b0[ld], acc0);
+    acc0 = mfma16(a0.z, b0[2 * ld], acc0);
+    acc0 = mfma16(a0.w, b0[3 * ld], acc0);
+  }
+  return acc0 + acc1;
+}
+// the same with B = W[col][k] read along a row as float4 (d(input) = da . W^T)
+__device__ __forceinline__ f32x4 tile_bwd(const float* __restrict__ arow /* da + i*ldda + 4*kq */,
+                                          const float* __restrict__ brow /* W + col*ld + 4*kq */, const int nks) {
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int ks = 0;
+  for (; ks + 1 < nks; ks += 2) {
+    const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+    const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 16);
+    const float4 b0 = *reinterpret_cast<const float4*>(brow + 16 * ks);
+    const float4 b1 = *reinterpret_cast<const float4*>(brow + 16 * ks + 16);
+    acc0 = mfma16(a0.x, b0.x, acc0);
+    acc1 = mfma16(a1.x, b1.x, acc1);
+    acc0 = mfma16(a0.y, b0.y, acc0);
+    acc1 = mfma16(a1.y, b1.y, acc1);
+    acc0 = mfma16(a0.z, b0.z, acc0);
+    acc1 = mfma16(a1.z, b1.z, acc1);
+    acc0 = mfma16(a0.w, b0.w, acc0);
+    acc1 = mfma16(a1.w, b1.w, acc1);
+  }
+  if (ks < nks) {
+    const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+    const float4 b0 = *reinterpret_cast<const float4*>(brow + 16 * ks);
+    acc0 = mfma16(a0.x, b0.x, acc0);
+    acc0 = mfma16(a0.y, b0.y, acc0);
+    acc0 = mfma16(a0.z, b0.z, acc0);
+    acc0 = mfma16(a0.w, b0.w, acc0);
+  }
+  return acc0 + acc1;
+}
+
+__global__ __launch_bounds__(MLP_T) void mlp_nobn_step_k(const MlpArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
   const int wg = blockIdx.x, row0 = wg * 16;
   const int L = p.L;
   RSX_STAMP(0, wg == 0);
-  // ---- the tile's input rows are requested first; LDS zeroed; weights in ---------------------------------------------
+  // ---- every global input of the tile is requested first (input rows: <= 1 float4 per thread; weights: <= 8), the LDS is
+  // zeroed while they fly ------------------------------------------------------------------------------------------------
   const int K04 = p.K0 >> 2;
-  float4 xv[2];                                                   // 16 * K0/4 float4 over 256 threads: <= 2 each (K0 <= 112)
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = tid + 256 * u, ec = e < 16 * K04 ? e : 16 * K04 - 1;
+  float4 xv;
+  {
+    const int ec = tid < 16 * K04 ? tid : 16 * K04 - 1;
     const int r = ec / K04, c4 = ec - r * K04;
     const int row = row0 + r < p.B ? row0 + r : p.B - 1;
-    xv[u] = reinterpret_cast<const float4*>(p.X + (size_t)row * p.K0)[c4];
+    xv = reinterpret_cast<const float4*>(p.X + (size_t)row * p.K0)[c4];
   }
-  for (int e = tid; e < (p.lds_floats >> 2); e += 256) reinterpret_cast<float4*>(lds)[e] = F4Z;
+  // (the dropout key's step counter, the row's label / extra logit and the output bias too: a global load costs ~1 us of
+  // latency wherever it sits, and the phases below are a fraction of that)
+  const uint32_t rng_st = p.rng_step != nullptr ? p.rng_step[0] : 0u;
+  const int hrow = row0 + (tid >> 5) < p.B ? row0 + (tid >> 5) : p.B - 1;
+  const float s0r = p.s0 ? p.s0[hrow] : 0.f, yr = p.labels[hrow], boutv = p.bout[0];
+  constexpr int WPT = (MLP_MAX_W * MLP_MAX_W / 4 + MLP_T - 1) / MLP_T;      // float4 of the widest layer per thread: 7
+  float4 wv[MLP_MAX_L][WPT];
+#pragma unroll
+  for (int l = 0; l < MLP_MAX_L; ++l) {
+    const int K = l == 0 ? p.K0 : p.N[l > 0 ? l - 1 : 0], tot = l < L ? K * (p.N[l] >> 2) : 0;
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      const int e = tid + MLP_T * u;
+      wv[l][u] = l < L ? reinterpret_cast<const float4*>(p.W[l])[e < tot ? e : tot - 1] : F4Z;
+    }
+  }
+  for (int e = tid; e < (p.lds_floats >> 2); e += MLP_T) reinterpret_cast<float4*>(lds)[e] = F4Z;
   __syncthreads();
   RSX_STAMP(1, wg == 0);
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = tid + 256 * u;
-    if (e < 16 * K04) {
-      const int r = e / K04, c4 = e - r * K04;
-      *reinterpret_cast<float4*>(lds + p.oIn[0] + r * p.ldin[0] + 4 * c4) = xv[u];
-    }
+  if (tid < 16 * K04) {
+    const int r = tid / K04, c4 = tid - r * K04;
+    *reinterpret_cast<float4*>(lds + p.oIn[0] + r * p.ldin[0] + 4 * c4) = xv;
   }
 #pragma unroll
   for (int l = 0; l < MLP_MAX_L; ++l) {
     if (l < L) {
-      const int K = l == 0 ? p.K0 : p.N[l > 0 ? l - 1 : 0], N = p.N[l], N4 = N >> 2;
-      const float* Wl = p.W[l];
+      const int K = l == 0 ? p.K0 : p.N[l > 0 ? l - 1 : 0], N = p.N[l], N4 = N >> 2, tot = K * N4;
       float* dst = lds + p.oW[l];
       const int ld = p.ldw[l];
-      int e = tid;
-      for (; e + 7 * 256 < K * N4; e += 8 * 256) {                 // 8 x 16-byte loads in flight
-        float4 v[8];
+      int r = tid / N4, c4 = tid - r * N4;                         // (one division; then stepped)
+      const int dr = MLP_T / N4, dc = MLP_T - dr * N4;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(Wl)[e + 256 * u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ee = e + 256 * u, r = ee / N4, c4 = ee - r * N4;
-          *reinterpret_cast<float4*>(dst + r * ld + 4 * c4) = v[u];
-        }
+      for (int u = 0; u < WPT; ++u) {
+        if (tid + MLP_T * u < tot) *reinterpret_cast<float4*>(dst + r * ld + 4 * c4) = wv[l][u];
+        r += dr;
+        c4 += dc;
+        if (c4 >= N4) { c4 -= N4; ++r; }
       }
-      for (; e < K * N4; e += 256) {
-        const int r = e / N4, c4 = e - r * N4;
-        *reinterpret_cast<float4*>(dst + r * ld + 4 * c4) = reinterpret_cast<const float4*>(Wl)[e];
-      }
-      for (int c = tid; c < N; c += 256) lds[p.oB[l] + c] = p.b[l][c];
+      for (int c = tid; c < N; c += MLP_T) lds[p.oB[l] + c] = p.b[l][c];
     }
   }
   const int NL = p.NL;
-  for (int c = tid; c < NL; c += 256) lds[p.oWout + c] = p.wout[c];
+  for (int c = tid; c < NL; c += MLP_T) lds[p.oWout + c] = p.wout[c];
   __syncthreads();
   RSX_STAMP(2, wg == 0);
   // ---- forward --------------------------------------------------------------------------------------------------------
@@ -124,19 +193,14 @@ __global__ __launch_bounds__(256) void mlp_nobn_step_k(const MlpArgs p) {
     float* out = lds + p.oIn[l + 1];
     float* gm = lds + p.oG[l];
     const int ldo = p.ldin[l + 1];
-    const DropRng dr = drop_make(p.rate, p.mask[l], p.rng_step, p.seed, (uint32_t)l);
-    for (int j = w; j < ntj; j += 4) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < nks; ++ks) {
-        const float4 a = *reinterpret_cast<const float4*>(in + i * ldi + 16 * ks + 4 * kq);
-        const float* br = Wl + (16 * ks + 4 * kq) * ld + 16 * j + i;
-        const float b0 = br[0], b1 = br[ld], b2 = br[2 * ld], b3 = br[3 * ld];
-        acc = mfma16(a.x, b0, acc);
-        acc = mfma16(a.y, b1, acc);
-        acc = mfma16(a.z, b2, acc);
-        acc = mfma16(a.w, b3, acc);
-      }
+    DropRng dr;                                                   // = drop_make(rate, mask, rng_step, seed, l) on the preloaded step
+    dr.inv_keep = 1.0f / (1.0f - p.rate);
+    dr.mode = p.rate == 0.f ? 0 : (p.mask[l] != nullptr ? 1 : 2);
+    dr.thresh = (uint32_t)((double)p.rate * 4294967296.0);
+    dr.key = rsx_hash32(p.seed ^ (rng_st * 0x9E3779B9u) ^ ((uint32_t)l * 0x85EBCA6Bu + 0x27220A95u));
+    for (int j = w; j < ntj; j += MLP_NW) {
       const int col = 16 * j + i;
+      const f32x4 acc = tile_fwd(in + i * ldi + 4 * kq, Wl + 4 * kq * ld + col, ld, nks);
       const float bias = col < N ? lds[p.oB[l] + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -154,52 +218,63 @@ __global__ __launch_bounds__(256) void mlp_nobn_step_k(const MlpArgs p) {
     __syncthreads();
     RSX_STAMP(3 + l, wg == 0);
   }
-  // ---- logit, loss and its gradient: one thread per row (din/din.py:138-147) ----------------------------------------
+  // ---- logit, loss and its gradient (din/din.py:138-147): 32 lanes per row, columns li, li + 32, .. -------------------
   float* rowb = lds + p.oRow;                                     // [16] dz, [16] ce
-  if (tid < 16) {
-    const int grow = row0 + tid;
+  {
+    const int row = tid >> 5, li = tid & 31, grow = row0 + row;
     const bool rok = grow < p.B;
-    const float* inL = lds + p.oInL + tid * p.ldinL;
+    const float* inL = lds + p.oInL + row * p.ldinL;
     float dot = 0.f;
-    for (int c = 0; c < NL; ++c) dot += inL[c] * lds[p.oWout + c];
-    const size_t rc = (size_t)(rok ? grow : p.B - 1);
-    const float zz = (p.s0 ? p.s0[rc] : 0.f) + (dot + p.bout[0]);
-    const float y = p.labels[rc];
-    const float pr = 1.f / (1.f + expf(-zz));
-    const float ce = fmaxf(zz, 0.f) - zz * y + log1pf(expf(-fabsf(zz)));
-    const float dz = rok ? (pr - y) * p.loss_scale : 0.f;
-    if (rok) {
-      p.prob[grow] = pr;
-      if (p.gs0) p.gs0[grow] = dz;
+#pragma unroll
+    for (int k = 0; k < (MLP_MAX_W + 31) / 32; ++k) {
+      const int c = li + 32 * k;
+      dot += c < NL ? inL[c] * lds[p.oWout + c] : 0.f;
     }
-    rowb[tid] = dz;
-    rowb[16 + tid] = rok ? ce : 0.f;
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) dot += __shfl_xor(dot, m);   // (fixed tree over the row's 32 lanes)
+    if (li == 0) {
+      const float zz = s0r + (dot + boutv);
+      const float y = yr;
+      const float pr = 1.f / (1.f + expf(-zz));
+      const float ce = fmaxf(zz, 0.f) - zz * y + log1pf(expf(-fabsf(zz)));
+      const float dz = rok ? (pr - y) * p.loss_scale : 0.f;
+      if (rok) {
+        p.prob[grow] = pr;
+        if (p.gs0) p.gs0[grow] = dz;
+      }
+      rowb[row] = dz;
+      rowb[16 + row] = rok ? ce : 0.f;
+    }
   }
   __syncthreads();
-  // output layer's gradients and the loss term of this tile: rows in ascending order
+  // output layer's gradients and the loss term of this tile: rows in ascending order (all 16 operands requested first)
   {
     float* po = p.part + p.poffL + (size_t)wg * p.NPo;
     if (tid < NL) {
+      float a[16], d[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { a[r] = lds[p.oInL + r * p.ldinL + tid]; d[r] = rowb[r]; }
       float s = 0.f;
-      for (int r = 0; r < 16; ++r) s += rowb[r] * lds[p.oInL + r * p.ldinL + tid];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += d[r] * a[r];
       po[tid] = s;
     } else if (tid == NL || tid == NL + 1) {
       float s = 0.f;
+#pragma unroll
       for (int r = 0; r < 16; ++r) s += rowb[(tid - NL) * 16 + r];
       po[tid] = s;
     } else if (tid < p.NPo) {
       po[tid] = 0.f;
     }
   }
-  // da of the last hidden layer: dz * wout * g
+  // da of the last hidden layer: dz * wout * g (thread = (row, 32-lane column group))
   {
     float* da = lds + p.oDa[0];
     const float* gm = lds + p.oGL;
     const int ldg = p.ldinL;
-    for (int e = tid; e < 16 * p.ldda; e += 256) {
-      const int r = e / p.ldda, c = e - r * p.ldda;
-      da[e] = c < NL ? rowb[r] * lds[p.oWout + c] * gm[r * ldg + c] : 0.f;
-    }
+    const int row = tid >> 5, li = tid & 31;
+    const float dzr = rowb[row];
+    for (int c = li; c < p.ldda; c += 32) da[row * p.ldda + c] = c < NL ? dzr * lds[p.oWout + c] * gm[row * ldg + c] : 0.f;
   }
   __syncthreads();
   RSX_STAMP(6, wg == 0);
@@ -217,19 +292,11 @@ __global__ __launch_bounds__(256) void mlp_nobn_step_k(const MlpArgs p) {
     const int ldi = p.ldin[l];
     const float* Wl = lds + p.oW[l];
     const int ld = p.ldw[l];
-    // (a) d(input) = da . W^T: column tiles over K; wave w: tiles w, w + 4, ..
+    // (a) d(input) = da . W^T: column tiles over K; wave w: tiles w, w + 8, ..
     const int ntk = (K + 15) >> 4, nkn = NP >> 4;
-    for (int j = w; j < ntk; j += 4) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < nkn; ++ks) {
-        const float4 a = *reinterpret_cast<const float4*>(da + i * p.ldda + 16 * ks + 4 * kq);
-        const float4 bq = *reinterpret_cast<const float4*>(Wl + (16 * j + i) * ld + 16 * ks + 4 * kq);
-        acc = mfma16(a.x, bq.x, acc);
-        acc = mfma16(a.y, bq.y, acc);
-        acc = mfma16(a.z, bq.z, acc);
-        acc = mfma16(a.w, bq.w, acc);
-      }
+    for (int j = w; j < ntk; j += MLP_NW) {
       const int col = 16 * j + i;
+      const f32x4 acc = tile_bwd(da + i * p.ldda + 4 * kq, Wl + col * ld + 4 * kq, nkn);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * kq + r, grow = row0 + row;
@@ -241,30 +308,42 @@ __global__ __launch_bounds__(256) void mlp_nobn_step_k(const MlpArgs p) {
       }
     }
     if (l > 0) {                                                  // the next da tile's columns beyond K: zero
-      const int padw = p.ldda - K;
-      for (int e = tid; e < 16 * padw; e += 256) {
-        const int r = e / padw, c = e - r * padw;
-        dan[r * p.ldda + K + c] = 0.f;
-      }
+      const int row = tid >> 5, li = tid & 31;
+      for (int c = K + li; c < p.ldda; c += 32) dan[row * p.ldda + c] = 0.f;
     }
-    // (b) dW partial [KR][NP] = [in' | 1]^T . da over the tile's 16 rows (one k-step); tiles dealt from wave 3 downwards
+    // (b) dW partial [KR][NP] = [in' | 1]^T . da over the tile's 16 rows (one k-step); tiles dealt from the last wave downwards
+    // (the first waves hold the d(input) tiles), TWO tiles at a time: their MFMA chains interleave
     {
-      const int ntm = KR >> 4, ntn = NP >> 4;
+      const int ntm = KR >> 4, ntn = NP >> 4, ntt = ntm * ntn;
+      const int rcp = 65536 / ntn + 1;
       float* po = p.part + p.poff[l] + (size_t)wg * KR * NP;
-      for (int tt = 3 - w; tt < ntm * ntn; tt += 4) {
-        const int m = tt / ntn, jn = tt - m * ntn;
-        const int feat = 16 * m + i;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int tt = MLP_NW - 1 - w; tt < ntt; tt += 2 * MLP_NW) {
+        const int t2 = tt + MLP_NW < ntt ? tt + MLP_NW : tt;      // (second tile; the last odd one is computed twice, stored once)
+        // (tt < 64 and ntn <= 7: an exact multiply-shift instead of two integer divisions -- ~50 instructions per tile pair)
+        const int m0 = (tt * rcp) >> 16, j0 = tt - m0 * ntn, m1 = (t2 * rcp) >> 16, j1 = t2 - m1 * ntn;
+        const int f0 = 16 * m0 + i, f1 = 16 * m1 + i;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = 4 * kq + t;
           // (feature K: the ones-row that yields the bias gradient; in' tiles are zero beyond K, and their stride covers KR)
-          const float a = feat == K ? 1.f : in[row * ldi + feat];
-          const float bv = da[row * p.ldda + 16 * jn + i];
-          acc = mfma16(a, bv, acc);
+          a0[t] = f0 == K ? 1.f : in[row * ldi + f0];
+          a1[t] = f1 == K ? 1.f : in[row * ldi + f1];
+          b0[t] = da[row * p.ldda + 16 * j0 + i];
+          b1[t] = da[row * p.ldda + 16 * j1 + i];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) po[(size_t)(16 * m + 4 * kq + r) * NP + 16 * jn + i] = acc[r];
+        for (int t = 0; t < 4; ++t) {
+          acc0 = mfma16(a0[t], b0[t], acc0);
+          acc1 = mfma16(a1[t], b1[t], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) po[(16 * m0 + 4 * kq + r) * NP + 16 * j0 + i] = acc0[r];
+        if (t2 != tt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) po[(16 * m1 + 4 * kq + r) * NP + 16 * j1 + i] = acc1[r];
+        }
       }
     }
     RSX_STAMP(7 + 2 * lr, wg == 0);
@@ -287,9 +366,11 @@ struct MlpRed {
   int L, nwg, NPo, NL;
   double inv_B;
 };
-// one thread per float4 of a region: the nwg partials in ascending workgroup order, 16 loads in flight
-__global__ __launch_bounds__(256) void mlp_reduce_k(const MlpRed r) {
-  const unsigned e = blockIdx.x * 256 + threadIdx.x;
+// one thread per float4 of a region: the nwg partials in ascending workgroup order, 32 loads in flight
+// (64-thread workgroups: the 5.6 MB of partials were written by 64 other CUs a moment ago and come back from memory --
+// 85 small workgroups pull them through 85 CUs' L1s instead of 22)
+__global__ __launch_bounds__(64) void mlp_reduce_k(const MlpRed r) {
+  const unsigned e = blockIdx.x * 64 + threadIdx.x;
   int q = 0;
   unsigned base = 0;
 #pragma unroll
@@ -308,12 +389,12 @@ __global__ __launch_bounds__(256) void mlp_reduce_k(const MlpRed r) {
   const float4* src = reinterpret_cast<const float4*>(r.part + pq) + e4;
   float4 s = F4Z;
   double sl = 0.0;
-  for (int g = 0; g < r.nwg; g += 16) {
-    float4 t[16];
+  for (int g = 0; g < r.nwg; g += 32) {
+    float4 t[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = src[(size_t)(g + u < r.nwg ? g + u : r.nwg - 1) * reg4];
+    for (int u = 0; u < 32; ++u) t[u] = src[(size_t)(g + u < r.nwg ? g + u : r.nwg - 1) * reg4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       if (g + u < r.nwg) {
         s = f4_add(s, t[u]);
         // (the loss term is summed in fp64: 1 024 terms of ~0.7 in fp32 would cost the reported loss its last digits)
@@ -446,8 +527,8 @@ extern "C" int rsx_mlp_nobn_train_step(const rsx_mlp_step* s, rsx_stream_t strea
   }
   r.part = s->workspace; r.dwout = s->dwout; r.dbout = s->dbout; r.loss = s->loss;
   r.L = L; r.nwg = nwg; r.NPo = p.NPo; r.NL = NL; r.inv_B = 1.0 / (double)B;
-  RSX_LAUNCH(mlp_nobn_step_k, dim3(nwg), dim3(256), lds, rsx_s(stream), p);
-  RSX_LAUNCH(mlp_reduce_k, dim3((e4 + 255) / 256), dim3(256), 0, rsx_s(stream), r);
+  RSX_LAUNCH(mlp_nobn_step_k, dim3(nwg), dim3(MLP_T), lds, rsx_s(stream), p);
+  RSX_LAUNCH(mlp_reduce_k, dim3((e4 + 63) / 64), dim3(64), 0, rsx_s(stream), r);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
