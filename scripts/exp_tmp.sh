@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_mlp_fused.py -x -q 2>&1 | tail -3
-python scripts/stamp_probe_mlp.py 2>&1 | tail -14
-b() { python bench.py --no_cpu_baseline --no_configs "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config'].get('launches_per_step'), d['config']['timed_repeats_ms_per_step'])"; }
-echo "din fused mlp"; b --model din
+timeout 900 python -m pytest tests/test_gpu_din.py -x -q 2>&1 | tail -3
+scripts/gpu.sh prof din_mlp3 --model din --no_cpu_baseline --no_configs --steps 160 --warmup 16 > /dev/null; grep -E "pool|finish|calls" gpurun_out/din_mlp3.txt | head -5 | cut -c1-130
+python bench.py --model din --no_cpu_baseline --no_configs 2>/dev/null | tail -1 | cut -c1-150

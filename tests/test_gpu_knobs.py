@@ -42,6 +42,12 @@ BIT_IDENTICAL = [
     ("dcn", 1024, {"RSX_TOWER_RTW": "1"}),                    # row tiles per d(input) workgroup
     ("xdeepfm", 128, {"RSX_ADAM_WINDOW": "1"}),
     ("xdeepfm", 128, {"RSX_XDFM_SORT_RIDE": "0"}),
+    # round 4
+    ("deepfm", 256, {"RSX_WINDOW_SIDE": "1"}),                # the window's sort + sweep on a side stream (opt-in: measured slower)
+    ("dcn", 1024, {"RSX_WINDOW_SIDE": "1"}),
+    ("dcn", 4096, {"RSX_ADAM_WINDOW": "1"}),                  # stand-alone sort launches of 4 096 keys: several workgroups per field ..
+    ("dcn", 4096, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_SPLIT": "0"}),    # .. and one workgroup per field: the same bits
+    ("din", 64, {"RSX_DIN_SIDE_SORT": "0"}),                  # din.py: the ids-only branch (sort + sweep) in line instead of on a side stream
 ]
 ROUNDING = [
     ("fm", 256, {"RSX_FM_FUSE": "0"}),                        # fp64 reduction of the head's dense gradients instead of the grouped fp32 rows
@@ -51,6 +57,9 @@ ROUNDING = [
     ("dcn", 1024, {"RSX_TOWER_DXG_SPLIT": "0"}),
     ("dcn", 1024, {"RSX_TOWER_SB_ROWS": "256"}),              # dW row blocks of 256 instead of 512 rows
     ("xdeepfm", 128, {"RSX_CIN_DX": "1"}),                    # register form of the CIN dX kernel
+    # round 4
+    ("din", 64, {"RSX_MLP_FUSE": "0"}),                       # din.py's 'mlp_layer' as 8 launches instead of the one-launch form
+    ("dcn", 4096, {"RSX_TOWER_BIG_MIN_K_BWD": "256"}),        # the batch-256 backward tiles for the 100-wide layer at batch 4 096
 ]
 
 
