@@ -893,8 +893,12 @@ __global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
       }
     }
   }
-  if (h == 0 && blockIdx.x == 0)
-    for (int e = tid; e < p.B; e += 256) {
+  // the B target entries' keys (+ the labels' cast), a slice per tile workgroup of history 0 (round 4: block (0, 0) used to walk
+  // all of them in B / 256 dependent trips -- 4 us longer than every other workgroup of the launch at batch 1 024)
+  if (h == 0) {
+    const int per = (p.B + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int e0 = (int)blockIdx.x * per, e1 = e0 + per < p.B ? e0 + per : p.B;
+    for (int e = e0 + tid; e < e1; e += 256) {
       if (p.kt_stride > 0) {
         p.keys2[e] = p.i_id[e];
         p.keys2[(size_t)p.kt_stride + e] = p.i_cate[e];
@@ -903,6 +907,7 @@ __global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
       }
       if (p.labels_i64 != nullptr) p.labels_f32[e] = (float)p.labels_i64[e];
     }
+  }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m);
   if (lane == 0) wsum[wv] = c;
