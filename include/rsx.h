@@ -501,10 +501,31 @@ typedef struct {
   float dropout_rate, loss_scale;
   int32_t B, K0, L;
   int32_t widths[RSX_MLP_MAX_LAYERS];
+  int32_t defer_reduce;                    /* 1: rsx_mlp_nobn_train_step leaves the weight-gradient reduce to a later
+                                            * rsx_mlp_nobn_reduce(step_h) -- on any stream ordered after the step's launch */
+  int32_t reserved;
 } rsx_mlp_step;
 int rsx_mlp_nobn_supported(int K0, const int32_t* widths, int L);
 size_t rsx_mlp_nobn_workspace_floats(int B, int K0, const int32_t* widths, int L);
 int rsx_mlp_nobn_train_step(const rsx_mlp_step* step_h, rsx_stream_t stream);
+int rsx_mlp_nobn_reduce(const rsx_mlp_step* step_h, rsx_stream_t stream);
+/* The same reduce as a JOB another launch of the step carries as extra workgroups (rsx_din_pool_bwd_pair_ride): filled by
+ * rsx_mlp_nobn_reduce_job from a step with defer_reduce = 1; plain data, valid while the step's buffers are.               */
+typedef struct {
+  const float* part;
+  long long poff[RSX_MLP_MAX_LAYERS + 1];
+  float* dW[RSX_MLP_MAX_LAYERS];
+  float* db[RSX_MLP_MAX_LAYERS];
+  float* dwout;
+  float* dbout;
+  float* loss;
+  int32_t K[RSX_MLP_MAX_LAYERS], N[RSX_MLP_MAX_LAYERS];
+  uint32_t e4_end[RSX_MLP_MAX_LAYERS];     /* float4 elements of the layer regions 0 .. q */
+  uint32_t e4_last;                        /* float4 elements in all (0: nothing to do) */
+  int32_t L, nwg, NPo, NL;
+  double inv_B;
+} rsx_mlp_reduce_job;
+int rsx_mlp_nobn_reduce_job(const rsx_mlp_step* step_h, rsx_mlp_reduce_job* job_out);
 
 /* ---------------------------------------------------------------------------------------------
  * DCN cross layers, dcn/dcn.py:132-142: x_{l+1} = (x_l . w_l) * x0 + x_l + b_l, all L
@@ -547,6 +568,11 @@ int rsx_din_pool_fwd_pair(const float* H0, const float* w0, const int32_t* ids0,
 int rsx_din_pool_bwd_pair(const float* H0, const float* w0, const int32_t* ids0, const float* dout0, float* dH0, float* dw0,
                           const float* H1, const float* w1, const int32_t* ids1, const float* dout1, float* dH1, float* dw1,
                           int accumulate, int B, int P, int K, int ld_dout, int ld_dH, rsx_stream_t stream);
+/* the same launch carrying `rider` (nullable: then exactly rsx_din_pool_bwd_pair) as extra workgroups */
+int rsx_din_pool_bwd_pair_ride(const float* H0, const float* w0, const int32_t* ids0, const float* dout0, float* dH0, float* dw0,
+                               const float* H1, const float* w1, const int32_t* ids1, const float* dout1, float* dH1, float* dw1,
+                               int accumulate, int B, int P, int K, int ld_dout, int ld_dH, const rsx_mlp_reduce_job* rider,
+                               rsx_stream_t stream);
 
 /* Several plain row gathers (tf.gather / tf.nn.embedding_lookup of one table each, din/din.py:96-105) in ONE launch:
  * out[e, 0:K] = table[row_base + ids[e], 0:K], e < n, `out` rows ld_out floats apart (K a multiple of 4, or K == 1: see

@@ -51,7 +51,15 @@ class MlpStep(C.Structure):               # include/rsx.h rsx_mlp_step
                 ("rng_step", C.c_void_p), ("prob", C.c_void_p), ("dX", C.c_void_p), ("gs0", C.c_void_p),
                 ("workspace", C.c_void_p), ("dW", C.c_void_p * 3), ("db", C.c_void_p * 3), ("dwout", C.c_void_p),
                 ("dbout", C.c_void_p), ("loss", C.c_void_p), ("seed", C.c_uint32), ("dropout_rate", C.c_float),
-                ("loss_scale", C.c_float), ("B", C.c_int32), ("K0", C.c_int32), ("L", C.c_int32), ("widths", C.c_int32 * 3)]
+                ("loss_scale", C.c_float), ("B", C.c_int32), ("K0", C.c_int32), ("L", C.c_int32), ("widths", C.c_int32 * 3),
+                ("defer_reduce", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MlpReduceJob(C.Structure):          # include/rsx.h rsx_mlp_reduce_job
+    _fields_ = [("part", C.c_void_p), ("poff", C.c_longlong * 4), ("dW", C.c_void_p * 3), ("db", C.c_void_p * 3),
+                ("dwout", C.c_void_p), ("dbout", C.c_void_p), ("loss", C.c_void_p), ("K", C.c_int32 * 3), ("N", C.c_int32 * 3),
+                ("e4_end", C.c_uint32 * 3), ("e4_last", C.c_uint32), ("L", C.c_int32), ("nwg", C.c_int32), ("NPo", C.c_int32),
+                ("NL", C.c_int32), ("inv_B", C.c_double)]
 
 
 class DwReduceJob(C.Structure):
@@ -149,6 +157,7 @@ _SIGS = {
     "rsx_din_attn_finish_pair": (_I, [_P] * 10 + [_I] * 7 + [_P]),
     "rsx_din_pool_fwd_pair": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "rsx_din_pool_bwd_pair": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, _P]),
+    "rsx_din_pool_bwd_pair_ride": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, C.POINTER(MlpReduceJob), _P]),
     "rsx_din_prepare2": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P, _I] + [_P] * 6 + [_P, _P, _P]),
     "rsx_din_attn_bwd_ld": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
@@ -194,6 +203,8 @@ _SIGS = {
     "rsx_mlp_nobn_supported": (_I, [_I, _P, _I]),
     "rsx_mlp_nobn_workspace_floats": (C.c_size_t, [_I, _I, _P, _I]),
     "rsx_mlp_nobn_train_step": (_I, [C.POINTER(MlpStep), _P]),
+    "rsx_mlp_nobn_reduce": (_I, [C.POINTER(MlpStep), _P]),
+    "rsx_mlp_nobn_reduce_job": (_I, [C.POINTER(MlpStep), C.POINTER(MlpReduceJob)]),
     "rsx_eval_metrics_state_words": (_I, [_I]),
     "rsx_eval_metrics_update": (_I, [_P, _P, _P, _I, _P, _P, _I, _P]),
 }

@@ -4,6 +4,7 @@
 // the gather and the weighted masked sum are the hand-kernel part, the attention
 // MLP GEMMs (M = B*P rows) are library GEMMs.  HBM-bound: per history P*(4 + K*4 + 4) B read, K*4 written.
 #include "rsx_common.h"
+#include "mlp_reduce_device.h"
 
 // out[b,:] = sum_p H[b,p,:] * w[b,p] * (ids[b,p] > 0).   One wave per example; LPR = K/4 lanes per row.
 template <int K>
@@ -258,6 +259,25 @@ static void launch_pool_bwd_pair(hipStream_t st, const PoolBwdSet& a, const Pool
                                  int ldh) {
   RSX_COUNT_LAUNCH(); din_pool_bwd_pair_k<K><<<dim3((B + 3) / 4, 2), dim3(256), 0, st>>>(a, b, acc, B, P, ldg, ldh);
 }
+// the same launch with a rider (round 4): the weight-gradient reduce of din.py's one-launch 'mlp_layer' (mlp_reduce_device.h) as
+// extra workgroups behind history 0's -- first needed by the optimizer, so its 9 us launch leaves the step's chain
+template <int K>
+__global__ __launch_bounds__(256) void din_pool_bwd_pair_ride_k(const PoolBwdSet s0, const PoolBwdSet s1, int accumulate, int B,
+                                                                int P, int ldg, int ldh, const MlpRed red, int n_own) {
+  if ((int)blockIdx.x >= n_own) {
+    if (blockIdx.y == 0) mlp_reduce_body<16>(red, (blockIdx.x - n_own) * 256 + threadIdx.x);
+    return;
+  }
+  if (blockIdx.y == 0) pool_bwd_wave<K>(s0.H, s0.w, s0.ids, s0.dout, s0.dH, s0.dw, accumulate, B, P, ldg, ldh);
+  else pool_bwd_wave<K>(s1.H, s1.w, s1.ids, s1.dout, s1.dH, s1.dw, accumulate, B, P, ldg, ldh);
+}
+template <int K>
+static void launch_pool_bwd_pair_ride(hipStream_t st, const PoolBwdSet& a, const PoolBwdSet& b, int acc, int B, int P, int ldg,
+                                      int ldh, const MlpRed& red) {
+  const int n_own = (B + 3) / 4;
+  RSX_COUNT_LAUNCH();
+  din_pool_bwd_pair_ride_k<K><<<dim3(n_own + (red.e4_last + 255) / 256, 2), dim3(256), 0, st>>>(a, b, acc, B, P, ldg, ldh, red, n_own);
+}
 extern "C" int rsx_din_pool_fwd_pair(const float* H0, const float* w0, const int32_t* ids0, float* out0, const float* H1,
                                      const float* w1, const int32_t* ids1, float* out1, int B, int P, int K, int ld_out,
                                      rsx_stream_t stream) {
@@ -292,6 +312,30 @@ extern "C" int rsx_din_pool_bwd_pair(const float* H0, const float* w0, const int
     case 16: launch_pool_bwd_pair<16>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
     case 32: launch_pool_bwd_pair<32>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
     case 64: launch_pool_bwd_pair<64>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH); break;
+    default: return RSX_EUNSUPPORTED;
+  }
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_din_pool_bwd_pair_ride(const float* H0, const float* w0, const int32_t* ids0, const float* dout0, float* dH0,
+                                          float* dw0, const float* H1, const float* w1, const int32_t* ids1, const float* dout1,
+                                          float* dH1, float* dw1, int accumulate, int B, int P, int K, int ld_dout, int ld_dH,
+                                          const rsx_mlp_reduce_job* rider, rsx_stream_t stream) {
+  if (rider == nullptr || rider->e4_last == 0)
+    return rsx_din_pool_bwd_pair(H0, w0, ids0, dout0, dH0, dw0, H1, w1, ids1, dout1, dH1, dw1, accumulate, B, P, K, ld_dout, ld_dH,
+                                 stream);
+  if (B <= 0 || P <= 0) return RSX_EINVAL;            // (a rider needs a launch to ride in)
+  if (!H0 || !w0 || !ids0 || !dout0 || !dH0 || !dw0 || !H1 || !w1 || !ids1 || !dout1 || !dH1 || !dw1 || ld_dout < K ||
+      (ld_dout & 3) || ld_dH < K || (ld_dH & 3) || !rider->part || rider->nwg <= 0)
+    return RSX_EINVAL;
+  const PoolBwdSet a{H0, w0, ids0, dout0, dH0, dw0}, b{H1, w1, ids1, dout1, dH1, dw1};
+  switch (K) {
+    case 4: launch_pool_bwd_pair_ride<4>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH, *rider); break;
+    case 8: launch_pool_bwd_pair_ride<8>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH, *rider); break;
+    case 16: launch_pool_bwd_pair_ride<16>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH, *rider); break;
+    case 32: launch_pool_bwd_pair_ride<32>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH, *rider); break;
+    case 64: launch_pool_bwd_pair_ride<64>(rsx_s(stream), a, b, accumulate, B, P, ld_dout, ld_dH, *rider); break;
     default: return RSX_EUNSUPPORTED;
   }
   RSX_CHECK_LAUNCH();

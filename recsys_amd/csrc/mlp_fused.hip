@@ -14,12 +14,12 @@
 // the four MFMAs t of a 16-wide k-step (same convention as tower.hip); the accumulator holds rows 4 kq + r of column i.
 #include "rsx_common.h"
 #include "drop_device.h"
+#include "mlp_reduce_device.h"
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-constexpr int MLP_MAX_L = 3;          // hidden layers
 constexpr int MLP_MAX_W = 112;        // widest layer / input (a multiple of 16): 7 column tiles
 
 struct MlpArgs {
@@ -352,81 +352,10 @@ __global__ __launch_bounds__(MLP_T) void mlp_nobn_step_k(const MlpArgs p) {
   }
 }
 
-struct MlpRed {
-  const float* part;
-  long long poff[MLP_MAX_L + 1];
-  float* dW[MLP_MAX_L];
-  float* db[MLP_MAX_L];
-  float* dwout;
-  float* dbout;
-  float* loss;
-  int K[MLP_MAX_L], N[MLP_MAX_L];
-  unsigned e4_end[MLP_MAX_L];         // float4 elements of the layer regions 0 .. q (unused layers: never reached)
-  unsigned e4_last;
-  int L, nwg, NPo, NL;
-  double inv_B;
-};
-// one thread per float4 of a region: the nwg partials in ascending workgroup order, 32 loads in flight
+// one thread per float4 of a region, 32 loads in flight (mlp_reduce_device.h)
 // (64-thread workgroups: the 5.6 MB of partials were written by 64 other CUs a moment ago and come back from memory --
 // 85 small workgroups pull them through 85 CUs' L1s instead of 22)
-__global__ __launch_bounds__(64) void mlp_reduce_k(const MlpRed r) {
-  const unsigned e = blockIdx.x * 64 + threadIdx.x;
-  int q = 0;
-  unsigned base = 0;
-#pragma unroll
-  for (int k = 0; k < MLP_MAX_L; ++k) {
-    if (k < r.L && e >= r.e4_end[k]) {
-      q = k + 1;
-      base = r.e4_end[k];
-    }
-  }
-  if (e >= r.e4_last) return;
-  const unsigned e4 = e - base;
-  const int K = q == 0 ? r.K[0] : (q == 1 ? r.K[1] : r.K[2]), N = q == 0 ? r.N[0] : (q == 1 ? r.N[1] : r.N[2]);
-  const int KR = (K + 1 + 15) & ~15, NP = (N + 15) & ~15;
-  const size_t reg4 = q < r.L ? (size_t)KR * NP / 4 : (size_t)r.NPo / 4;
-  const long long pq = q == r.L ? r.poff[MLP_MAX_L] : (q == 0 ? r.poff[0] : (q == 1 ? r.poff[1] : r.poff[2]));
-  const float4* src = reinterpret_cast<const float4*>(r.part + pq) + e4;
-  float4 s = F4Z;
-  double sl = 0.0;
-  for (int g = 0; g < r.nwg; g += 32) {
-    float4 t[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) t[u] = src[(size_t)(g + u < r.nwg ? g + u : r.nwg - 1) * reg4];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      if (g + u < r.nwg) {
-        s = f4_add(s, t[u]);
-        // (the loss term is summed in fp64: 1 024 terms of ~0.7 in fp32 would cost the reported loss its last digits)
-        if (q == r.L) {
-          const int c0 = (int)e4 * 4, cl = r.NL + 1 - c0;
-          if (cl >= 0 && cl < 4) sl += (double)(cl == 0 ? t[u].x : cl == 1 ? t[u].y : cl == 2 ? t[u].z : t[u].w);
-        }
-      }
-    }
-  }
-  const float v[4] = {s.x, s.y, s.z, s.w};
-  if (q < r.L) {
-    const int kk = (int)(((size_t)e4 * 4) / NP), n = (int)(((size_t)e4 * 4) - (size_t)kk * NP);
-    float* dW = q == 0 ? r.dW[0] : (q == 1 ? r.dW[1] : r.dW[2]);
-    float* db = q == 0 ? r.db[0] : (q == 1 ? r.db[1] : r.db[2]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (n + t < N) {
-        if (kk < K) dW[(size_t)kk * N + n + t] = v[t];
-        else if (kk == K) db[n + t] = v[t];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int c = (int)e4 * 4 + t;
-      if (c < r.NL) r.dwout[c] = v[t];
-      else if (c == r.NL) r.dbout[0] = v[t];
-      else if (c == r.NL + 1) r.loss[0] = (float)(sl * r.inv_B);
-    }
-  }
-}
+__global__ __launch_bounds__(64) void mlp_reduce_k(const MlpRed r) { mlp_reduce_body<32>(r, blockIdx.x * 64 + threadIdx.x); }
 
 inline int up16(int x) { return (x + 15) & ~15; }
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
@@ -452,18 +381,16 @@ extern "C" int rsx_mlp_nobn_supported(int K0, const int32_t* widths, int L) {
   return 1;
 }
 
-extern "C" int rsx_mlp_nobn_train_step(const rsx_mlp_step* s, rsx_stream_t stream) {
+static int mlp_build(const rsx_mlp_step* s, MlpArgs& p, MlpRed& r, size_t& lds_bytes, unsigned& e4_total) {
   if (!s) return RSX_EINVAL;
   const int L = s->L, B = s->B, K0 = s->K0;
   if (B < 0 || L <= 0 || L > MLP_MAX_L) return RSX_EINVAL;
   if (!rsx_mlp_nobn_supported(K0, s->widths, L)) return RSX_EUNSUPPORTED;
-  if (B == 0) return RSX_OK;
+  if (B == 0) { e4_total = 0; return RSX_OK; }
   if (!s->X || !s->wout || !s->bout || !s->labels || !s->prob || !s->dX || !s->workspace || !s->dwout || !s->dbout || !s->loss)
     return RSX_EINVAL;
   if (s->dropout_rate < 0.f || s->dropout_rate >= 1.f) return RSX_EINVAL;
   if (!al16(s->X) || !al16(s->dX) || !al16(s->workspace)) return RSX_EUNSUPPORTED;
-  MlpArgs p;
-  MlpRed r;
   p.X = s->X; p.wout = s->wout; p.bout = s->bout; p.s0 = s->s0; p.labels = s->labels; p.rng_step = s->rng_step;
   p.prob = s->prob; p.dX = s->dX; p.gs0 = s->gs0; p.part = s->workspace;
   p.seed = s->seed; p.rate = s->dropout_rate; p.loss_scale = s->loss_scale;
@@ -527,11 +454,47 @@ extern "C" int rsx_mlp_nobn_train_step(const rsx_mlp_step* s, rsx_stream_t strea
   }
   r.part = s->workspace; r.dwout = s->dwout; r.dbout = s->dbout; r.loss = s->loss;
   r.L = L; r.nwg = nwg; r.NPo = p.NPo; r.NL = NL; r.inv_B = 1.0 / (double)B;
-  RSX_LAUNCH(mlp_nobn_step_k, dim3(nwg), dim3(MLP_T), lds, rsx_s(stream), p);
+  lds_bytes = lds;
+  e4_total = e4;
+  return RSX_OK;
+}
+
+extern "C" int rsx_mlp_nobn_train_step(const rsx_mlp_step* s, rsx_stream_t stream) {
+  MlpArgs p;
+  MlpRed r;
+  size_t lds = 0;
+  unsigned e4 = 0;
+  const int rc = mlp_build(s, p, r, lds, e4);
+  if (rc != RSX_OK || e4 == 0) return rc;
+  RSX_LAUNCH(mlp_nobn_step_k, dim3((s->B + 15) / 16), dim3(MLP_T), lds, rsx_s(stream), p);
+  // (defer_reduce: the caller issues rsx_mlp_nobn_reduce itself -- on another stream, or later: the weight gradients are
+  // first needed by the optimizer)
+  if (!s->defer_reduce) RSX_LAUNCH(mlp_reduce_k, dim3((e4 + 63) / 64), dim3(64), 0, rsx_s(stream), r);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_mlp_nobn_reduce_job(const rsx_mlp_step* s, rsx_mlp_reduce_job* job_out) {
+  if (!job_out) return RSX_EINVAL;
+  MlpArgs p;
+  size_t lds = 0;
+  unsigned e4 = 0;
+  job_out->e4_last = 0;
+  return mlp_build(s, p, *job_out, lds, e4);
+}
+
+extern "C" int rsx_mlp_nobn_reduce(const rsx_mlp_step* s, rsx_stream_t stream) {
+  MlpArgs p;
+  MlpRed r;
+  size_t lds = 0;
+  unsigned e4 = 0;
+  const int rc = mlp_build(s, p, r, lds, e4);
+  if (rc != RSX_OK || e4 == 0) return rc;
   RSX_LAUNCH(mlp_reduce_k, dim3((e4 + 63) / 64), dim3(64), 0, rsx_s(stream), r);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
+
 
 #ifdef RSX_STAMPS
 extern "C" int rsx_dbg_stamps_mlp(unsigned long long* out_h) {

@@ -266,7 +266,13 @@ class DinFused:
                 self.X[:B], labels_f, rate, step, s0=self.ib[:B],
                 head=("mlp.Wout", "mlp.bout", None, None), relu0=False, relu2=False, replicas=world, masks=mlp_mk,
                 seed=0xD1AD + 7919 * rank,                       # replicas draw independent dropout patterns
-                outs=(None, gbias[:B], None))                    # d loss / d bias lands in the scatter's first-order input
+                outs=(None, gbias[:B], None),                    # d loss / d bias lands in the scatter's first-order input
+                # the weight-gradient reduce of the one-launch mlp_layer rides in the pooling-backward launch below
+                # (RSX_MLP_REDUCE_RIDE=0: its own launch; RSX_MLP_REDUCE_SIDE=1: on the side stream -- measured slower, §4c-15)
+                reduce_rider=os.environ.get("RSX_MLP_REDUCE_RIDE", "1") == "1",
+                reduce_stream=side if os.environ.get("RSX_MLP_REDUCE_SIDE", "0") == "1" and
+                os.environ.get("RSX_MLP_REDUCE_RIDE", "1") != "1" else None)
+            rider = getattr(tw, "mlp_reduce_job", None)
             if B < self.cap_B:
                 # a batch smaller than an earlier one (the final partial batch of an epoch): entries B.. are HISTORY entries now,
                 # whose bias gradient is zero -- not what a larger batch's head (or, in the send block, a larger batch's value
@@ -277,9 +283,10 @@ class DinFused:
             vbase = vals.data_ptr()
             dHp = [C.c_void_p(vbase + 4 * (B * 2 * K + t * K)) for t in range(2)]        # rows B.. of column block t
             doutp = [C.c_void_p(dX.data_ptr() + 4 * K * (t + 1)) for t in range(2)]       # d(pooled history t) = dX[:, (t+1)K : (t+2)K]
-            _lib.check(L.rsx_din_pool_bwd_pair(_ptr(self.H[0]), _ptr(self.w[0]), _ptr(hist[0]), doutp[0], dHp[0], _ptr(self.dw[0]),
-                                               _ptr(self.H[1]), _ptr(self.w[1]), _ptr(hist[1]), doutp[1], dHp[1], _ptr(self.dw[1]),
-                                               0, B, P, K, 3 * K, 2 * K, st), "rsx_din_pool_bwd_pair")
+            _lib.check(L.rsx_din_pool_bwd_pair_ride(_ptr(self.H[0]), _ptr(self.w[0]), _ptr(hist[0]), doutp[0], dHp[0], _ptr(self.dw[0]),
+                                                    _ptr(self.H[1]), _ptr(self.w[1]), _ptr(hist[1]), doutp[1], dHp[1], _ptr(self.dw[1]),
+                                                    0, B, P, K, 3 * K, 2 * K, None if rider is None else C.byref(rider), st),
+                       "rsx_din_pool_bwd_pair_ride")
             gouts = []
             for t, pre in enumerate(("att_i", "att_c")):
                 Ws = [P_[f"{pre}.W{i}"] for i in range(3)]
