@@ -606,6 +606,14 @@ int rsx_din_prepare2(const int32_t* i_id, const int32_t* i_cate, const int32_t* 
                      int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride, int32_t* rows_i,
                      int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c, const int64_t* labels_i64,
                      float* labels_f32, rsx_stream_t stream);
+/* The same two launches carrying the step's row gathers (rsx_gather_rows_multi's jobs; din/din.py:96-105) as extra workgroups:
+ * jobs [0, njobs_first) ride in the first launch, the others in the second -- the lookups depend on the batch's ids only, like
+ * the prepare kernels, so the bandwidth-bound gather runs beside those two latency-bound launches instead of after them.    */
+int rsx_din_prepare2_gather(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B, int P,
+                            int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride, int32_t* rows_i,
+                            int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
+                            const int64_t* labels_i64, float* labels_f32, const rsx_gather_job* jobs_h, int njobs, int njobs_first,
+                            rsx_stream_t stream);
 
 
 /* Fused attention MLP of `_attention` (din/din.py:111-121): for every history position m = (b, p)

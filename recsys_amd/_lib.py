@@ -159,6 +159,7 @@ _SIGS = {
     "rsx_din_pool_bwd_pair": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, _P]),
     "rsx_din_pool_bwd_pair_ride": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, C.POINTER(MlpReduceJob), _P]),
     "rsx_din_prepare2": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P, _I] + [_P] * 6 + [_P, _P, _P]),
+    "rsx_din_prepare2_gather": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P, _I] + [_P] * 6 + [_P, _P, C.POINTER(GatherJob), _I, _I, _P]),
     "rsx_din_attn_bwd_ld": (_I, [_P] * 15 + [C.c_uint32, _I, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "rsx_din_pool_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "rsx_segsum_rows": (_I, [_P] * 6 + [_I, _I, _I, _I, _P, _P]),

@@ -5,6 +5,7 @@
 // MLP GEMMs (M = B*P rows) are library GEMMs.  HBM-bound: per history P*(4 + K*4 + 4) B read, K*4 written.
 #include "rsx_common.h"
 #include "mlp_reduce_device.h"
+#include "gather_rows_device.h"
 
 // out[b,:] = sum_p H[b,p,:] * w[b,p] * (ids[b,p] > 0).   One wave per example; LPR = K/4 lanes per row.
 template <int K>
@@ -368,49 +369,14 @@ extern "C" int rsx_din_pool_bwd(const float* H, const float* w, const int32_t* i
 
 // ---- several row gathers in ONE launch (din/din.py:96-105: i_item / i_id / i_cate looked up by the target ids and by the
 // two id histories: five tf.gather / embedding_lookup calls per step) ----------------------------------------------------------
-struct GatherJobs {
-  rsx_gather_job j[RSX_GATHER_MAX_JOBS];
-  uint32_t blk_end[RSX_GATHER_MAX_JOBS];     // workgroups of jobs 0 .. i
-};
-__global__ __launch_bounds__(256) void gather_rows_multi_k(const GatherJobs g) {
-  // (job selection by an unrolled chain of compile-time indices: a dynamically indexed by-value struct lives in scratch)
-  rsx_gather_job jb = g.j[0];
-  uint32_t b0 = 0;
-#pragma unroll
-  for (int k = 1; k < RSX_GATHER_MAX_JOBS; ++k) {
-    if (blockIdx.x >= g.blk_end[k - 1]) {
-      jb = g.j[k];
-      b0 = g.blk_end[k - 1];
-    }
-  }
-  if (jb.K == 1) {           // scalar rows (tf.gather of a 1-D variable stored with a row stride: DIN's item bias)
-    const long long e = (long long)(blockIdx.x - b0) * 256 + threadIdx.x;
-    if (e < jb.n) jb.out[e * jb.ld_out] = jb.table[((long long)jb.row_base + jb.ids[e]) * jb.ld_table];
-    return;
-  }
-  const int lpr = jb.K >> 2;
-  const long long t = (long long)(blockIdx.x - b0) * 256 + threadIdx.x;
-  const long long e = t / lpr;
-  if (e >= jb.n) return;
-  const int q = (int)(t - e * lpr);
-  const long long row = (long long)jb.row_base + jb.ids[e];
-  *reinterpret_cast<float4*>(jb.out + e * jb.ld_out + 4 * q) = reinterpret_cast<const float4*>(jb.table)[row * lpr + q];
-}
+__global__ __launch_bounds__(256) void gather_rows_multi_k(const GatherJobs g) { RSX_GATHER_ROWS_BLOCK(g, blockIdx.x); }
 
 extern "C" int rsx_gather_rows_multi(const rsx_gather_job* jobs_h, int njobs, rsx_stream_t stream) {
   if (!jobs_h || njobs <= 0 || njobs > RSX_GATHER_MAX_JOBS) return RSX_EINVAL;
   GatherJobs g;
   uint32_t end = 0;
-  for (int k = 0; k < RSX_GATHER_MAX_JOBS; ++k) {
-    const rsx_gather_job& j = jobs_h[k < njobs ? k : njobs - 1];
-    if (k < njobs) {
-      if (!j.table || !j.ids || !j.out || j.n < 0 || j.K <= 0 || j.ld_out < j.K) return RSX_EINVAL;
-      if (j.K == 1 ? j.ld_table < 1 : ((j.K & 3) || (j.ld_out & 3))) return RSX_EINVAL;
-      end += (uint32_t)((j.n * (j.K == 1 ? 1 : (j.K >> 2)) + 255) / 256);
-    }
-    g.j[k] = j;
-    g.blk_end[k] = end;
-  }
+  const int rc = gather_jobs_pack(jobs_h, 0, njobs, g, &end);
+  if (rc != RSX_OK) return rc;
   if (end == 0) return RSX_OK;
   RSX_LAUNCH(gather_rows_multi_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
   RSX_CHECK_LAUNCH();

@@ -13,6 +13,7 @@
 #include "drop_device.h"
 #include <type_traits>
 #include "rsx_common.h"
+#include "gather_rows_device.h"
 RSX_STAMP_DECL
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -871,7 +872,14 @@ struct DinPrep {
   const int64_t* labels_i64;  // nullable: labels_f32[e] = (float)labels_i64[e] (the model_fn's tf.cast, din/din.py:146)
   float* labels_f32;
 };
-__global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
+// RID: the launch carries row gathers of the same step as extra workgroups (gather_rows_device.h): x >= n_tiles, two per x
+template <bool RID>
+__global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p, const GatherJobs gj, const int n_tiles, const uint32_t n_gather) {
+  if (RID && (int)blockIdx.x >= n_tiles) {
+    const uint32_t r = (blockIdx.x - n_tiles) * 2 + blockIdx.y;
+    if (r < n_gather) RSX_GATHER_ROWS_BLOCK(gj, r);
+    return;
+  }
   __shared__ int wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = blockIdx.y;
   const int32_t* ids = h ? p.hist[1] : p.hist[0];
@@ -896,7 +904,7 @@ __global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
   // the B target entries' keys (+ the labels' cast), a slice per tile workgroup of history 0 (round 4: block (0, 0) used to walk
   // all of them in B / 256 dependent trips -- 4 us longer than every other workgroup of the launch at batch 1 024)
   if (h == 0) {
-    const int per = (p.B + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int per = (p.B + n_tiles - 1) / n_tiles;
     const int e0 = (int)blockIdx.x * per, e1 = e0 + per < p.B ? e0 + per : p.B;
     for (int e = e0 + tid; e < e1; e += 256) {
       if (p.kt_stride > 0) {
@@ -914,7 +922,13 @@ __global__ __launch_bounds__(256) void din_prep_counts_k(const DinPrep p) {
   __syncthreads();
   if (tid == 0) tcnt[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
-__global__ __launch_bounds__(256) void din_prep_rows_k(const DinPrep p) {
+template <bool RID>
+__global__ __launch_bounds__(256) void din_prep_rows_k(const DinPrep p, const GatherJobs gj, const int n_tiles, const uint32_t n_gather) {
+  if (RID && (int)blockIdx.x >= n_tiles) {
+    const uint32_t r = (blockIdx.x - n_tiles) * 2 + blockIdx.y;
+    if (r < n_gather) RSX_GATHER_ROWS_BLOCK(gj, r);
+    return;
+  }
   __shared__ int wsum[4];
   __shared__ int sbase;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = blockIdx.y;
@@ -946,26 +960,48 @@ __global__ __launch_bounds__(256) void din_prep_rows_k(const DinPrep p) {
     if (ok) rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = e;
     base += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
   }
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) count[0] = base;
+  if ((int)blockIdx.x == n_tiles - 1 && tid == 0) count[0] = base;
 }
 
-extern "C" int rsx_din_prepare2(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
-                                int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride,
-                                int32_t* rows_i, int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
-                                const int64_t* labels_i64, float* labels_f32, rsx_stream_t stream) {
+extern "C" int rsx_din_prepare2_gather(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c,
+                                       int B, int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride,
+                                       int32_t* rows_i, int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
+                                       const int64_t* labels_i64, float* labels_f32, const rsx_gather_job* jobs_h, int njobs,
+                                       int njobs_first, rsx_stream_t stream) {
   if (B <= 0 || P <= 0) return (B == 0 && P > 0) ? RSX_OK : RSX_EINVAL;
   if (!i_id || !i_cate || !hist_i || !hist_c || !keys2 || !rows_i || !count_i || !rows_c || !count_c) return RSX_EINVAL;
   if ((labels_i64 != nullptr) != (labels_f32 != nullptr)) return RSX_EINVAL;
+  if (njobs < 0 || njobs > RSX_GATHER_MAX_JOBS || njobs_first < 0 || njobs_first > njobs || (njobs > 0 && !jobs_h)) return RSX_EINVAL;
   const long long M = (long long)B * P;
   if (M > (1ll << 24)) return RSX_EUNSUPPORTED;
   if (keys_field_stride != 0 && keys_field_stride < B + M) return RSX_EINVAL;
   DinPrep p{{hist_i, hist_c}, {rows_i, rows_c}, {count_i, count_c}, {w_i, w_c}, i_id, i_cate, keys2, B, (int)M,
             {dummy_item_row, dummy_cate_row}, keys_field_stride, labels_i64, labels_f32};
   const int nt = (int)((M + 1023) / 1024);
-  RSX_LAUNCH(din_prep_counts_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
-  RSX_LAUNCH(din_prep_rows_k, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p);
+  GatherJobs g1{}, g2{};
+  uint32_t n1 = 0, n2 = 0;
+  if (njobs_first > 0) {
+    const int rc = gather_jobs_pack(jobs_h, 0, njobs_first, g1, &n1);
+    if (rc != RSX_OK) return rc;
+  }
+  if (njobs - njobs_first > 0) {
+    const int rc = gather_jobs_pack(jobs_h, njobs_first, njobs - njobs_first, g2, &n2);
+    if (rc != RSX_OK) return rc;
+  }
+  if (n1 > 0) RSX_LAUNCH(din_prep_counts_k<true>, dim3(nt + (n1 + 1) / 2, 2), dim3(256), 0, rsx_s(stream), p, g1, nt, n1);
+  else RSX_LAUNCH(din_prep_counts_k<false>, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p, g1, nt, 0u);
+  if (n2 > 0) RSX_LAUNCH(din_prep_rows_k<true>, dim3(nt + (n2 + 1) / 2, 2), dim3(256), 0, rsx_s(stream), p, g2, nt, n2);
+  else RSX_LAUNCH(din_prep_rows_k<false>, dim3(nt, 2), dim3(256), 0, rsx_s(stream), p, g2, nt, 0u);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
+}
+
+extern "C" int rsx_din_prepare2(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,
+                                int P, int dummy_item_row, int dummy_cate_row, int32_t* keys2, int keys_field_stride,
+                                int32_t* rows_i, int32_t* count_i, float* w_i, int32_t* rows_c, int32_t* count_c, float* w_c,
+                                const int64_t* labels_i64, float* labels_f32, rsx_stream_t stream) {
+  return rsx_din_prepare2_gather(i_id, i_cate, hist_i, hist_c, B, P, dummy_item_row, dummy_cate_row, keys2, keys_field_stride, rows_i,
+                                 count_i, w_i, rows_c, count_c, w_c, labels_i64, labels_f32, nullptr, 0, 0, stream);
 }
 
 extern "C" int rsx_din_prepare(const int32_t* i_id, const int32_t* i_cate, const int32_t* hist_i, const int32_t* hist_c, int B,

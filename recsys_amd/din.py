@@ -166,19 +166,24 @@ class DinFused:
             self._side = torch.cuda.Stream()
         return self._side
 
-    def _gather(self, B, i_id, i_cate, hist):
-        C, a = self.C, self.arena
+    def _gather_jobs(self, B, i_id, i_cate, hist):
+        """The step's six lookups (din/din.py:96-105) as rsx_gather_job structs; the category history LAST (the fused step lets
+        the first five ride in its first prepare launch and that one in the second)."""
+        a = self.arena
         K, P = self.K, self.P
         cate_tab = a.tables[self.n_item + 1:]
         jobs = (_lib.GatherJob * 6)()
         spec = [(a.tables, i_id, self.X, B, K, 3 * K, 0), (a.tables, i_id, self.qi, B, K, K, 0),
-                (cate_tab, i_cate, self.qc, B, K, K, 0), (a.tables, hist[0], self.H[0], B * P, K, K, 0),
-                (cate_tab, hist[1], self.H[1], B * P, K, K, 0),
-                (self.barena.tables, i_id, self.ib, B, 1, 1, 4)]       # tf.gather(i_item, i_id) (:96): column 0 of the 4-wide table
+                (cate_tab, i_cate, self.qc, B, K, K, 0),
+                (self.barena.tables, i_id, self.ib, B, 1, 1, 4),       # tf.gather(i_item, i_id) (:96): column 0 of the 4-wide table
+                (a.tables, hist[0], self.H[0], B * P, K, K, 0), (cate_tab, hist[1], self.H[1], B * P, K, K, 0)]
         for j, (tab, ids, out, n, k, ld, ldt) in zip(jobs, spec):
             j.table, j.ids, j.out, j.n, j.K, j.ld_out, j.row_base, j.ld_table = \
                 tab.data_ptr(), ids.data_ptr(), out.data_ptr(), n, k, ld, 0, ldt
-        _lib.check(_lib.lib().rsx_gather_rows_multi(jobs, 6, _stream()), "rsx_gather_rows_multi")
+        return jobs
+
+    def _gather(self, B, i_id, i_cate, hist):
+        _lib.check(_lib.lib().rsx_gather_rows_multi(self._gather_jobs(B, i_id, i_cate, hist), 6, _stream()), "rsx_gather_rows_multi")
 
     def train_step(self, store, features, labels, params, masks):
         L = _lib.lib()
@@ -203,11 +208,17 @@ class DinFused:
             world = dp.world if dp is not None else 1
             big = N > a.LDS_SORT_MAX_B and dp is None   # the large sort takes field-major keys as they are (single replica)
             lab64 = labels.reshape(-1) if labels.dtype == torch.int64 and labels.is_contiguous() else None
-            _lib.check(L.rsx_din_prepare2(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item, self.n_cate,
-                                          _ptr(self.keys_t) if big else _ptr(keys2), a.stride if big else 0, _ptr(self.rows[0]),
-                                          _ptr(cnts[0]), _ptr(self.w[0]), _ptr(self.rows[1]), _ptr(cnts[1]), _ptr(self.w[1]),
-                                          _ptr(lab64), _ptr(self.labels_f) if lab64 is not None else None, st),
-                       "rsx_din_prepare2")
+            # Round 4: the six lookups ride in the two prepare launches as extra workgroups (they depend on the ids only, like the
+            # prepare kernels: the 11 us bandwidth-bound gather runs beside two latency-bound launches); RSX_DIN_GATHER_RIDE=0: its
+            # own launch after them
+            gride = os.environ.get("RSX_DIN_GATHER_RIDE", "1") == "1"
+            gjobs = self._gather_jobs(B, i_id, i_cate, hist) if gride else None
+            _lib.check(L.rsx_din_prepare2_gather(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item,
+                                                 self.n_cate, _ptr(self.keys_t) if big else _ptr(keys2), a.stride if big else 0,
+                                                 _ptr(self.rows[0]), _ptr(cnts[0]), _ptr(self.w[0]), _ptr(self.rows[1]),
+                                                 _ptr(cnts[1]), _ptr(self.w[1]), _ptr(lab64),
+                                                 _ptr(self.labels_f) if lab64 is not None else None, gjobs, 6 if gride else 0,
+                                                 5 if gride else 0, st), "rsx_din_prepare2_gather")
             labels_f = self.labels_f[:B] if lab64 is not None else labels.reshape(-1).to(torch.float32)
             a.select(0)
             # Round 4: the ids-only branch of the step -- the dedup sort (7 launches on 52 workgroups: a chain of launch latencies)
@@ -236,7 +247,8 @@ class DinFused:
                              v=self.barena.v_t, slot=a.slot, slot_w=None)]
                 store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
             # ---- forward --------------------------------------------------------------------------------------------
-            self._gather(B, i_id, i_cate, hist)
+            if not gride:
+                self._gather(B, i_id, i_cate, hist)
             q = (self.qi[:B], self.qc[:B])
             att_m = []
             att_seed = 0xD1A77 + 7919 * (dp.rank if dp is not None else 0)

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_din.py tests/test_gpu_mlp_fused.py tests/test_gpu_dp.py -x -q 2>&1 | tail -2
 b() { python bench.py --no_cpu_baseline --no_configs "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config'].get('launches_per_step'))"; }
-for i in 1 2 3; do echo -n "din reduce rides: "; b --model din; echo -n "din reduce own launch: "; RSX_MLP_REDUCE_RIDE=0 b --model din; done
+for i in 1 2; do for j in end mlp poolbwd; do echo -n "din join at $j: "; RSX_DIN_JOIN_AT=$j b --model din; done; done
