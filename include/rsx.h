@@ -183,6 +183,7 @@ int rsx_segsum_partials(const float* tables, const float* S, const float* dX, co
                         const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B, int F, int D, int stride,
                         int null_row, const rsx_example_blocks* blocks_h, rsx_stream_t stream);
 
+
 /* Row-wise gradient "scatter" as a sorted segment-sum (replaces the IndexedSlices gradient of the
  * gather + tf.unsorted_segment_sum, Appendix A-4): for unique row (f, j)
  *   G[f*B+j, :]  = sum over its examples b, ascending:  (gy2[b]*S[b,:] - gy2[b]*T[row,:]) + dX[b, f*D:(f+1)*D]
@@ -541,6 +542,36 @@ size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L);
 int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, const float* s, const float* dxL, const float* gz,
                   const float* wout, float* dX, int accumulate, float* dW, float* dB, float* dwout, float* workspace,
                   int B, int dim, int L, rsx_stream_t stream);
+/* The backward's second launch (the sum of the per-wave gradient partials into dW / dB / dwout) as a job: rsx_cross_bwd_defer
+ * hands it back instead of launching it (reduce_out nullable: then exactly rsx_cross_bwd); rsx_cross_reduce_run runs it, or the
+ * scatter's stage-A launch carries it as extra workgroups (rsx_segsum_partials_ride) -- only the optimizer needs these sums. */
+typedef struct {
+  const float* part;
+  float* dW;
+  float* dB;
+  float* dwout;            /* nullable */
+  int32_t RT, n, L, dim;   /* n == 0: nothing to do */
+} rsx_cross_reduce_job;
+int rsx_cross_bwd_defer(const float* x0, const float* W, const float* Bc, const float* s, const float* dxL, const float* gz,
+                        const float* wout, float* dX, int accumulate, float* dW, float* dB, float* dwout, float* workspace,
+                        int B, int dim, int L, rsx_cross_reduce_job* reduce_out, rsx_stream_t stream);
+int rsx_cross_reduce_run(const rsx_cross_reduce_job* job_h, rsx_stream_t stream);
+/* Reductions of other launches of the TRAIN step that only the optimizer reads, carried by the scatter's stage-A launch
+ * (rsx_segsum_partials_ride) as extra 256-thread workgroups beside its position tiles: the tower's dW partial-tile reductions
+ * (the jobs rsx_tower_bwd_layer_defer hands back) and the cross layers' gradient reduce.  dcn.py at batch 4 096: two launches
+ * (6.4 + 4.9 us) leave the step's dependent chain.                                                                       */
+typedef struct {
+  rsx_dw_reduce_job dw[RSX_DW_REDUCE_MAX_JOBS];
+  int32_t n_dw;
+  int32_t reserved;
+  rsx_cross_reduce_job cross;    /* cross.n == 0: none */
+} rsx_scatter_riders;
+/* rsx_segsum_partials (the scatter's stage A, above) -- the same launch carrying `riders` (nullable / empty: exactly rsx_segsum_partials).  Where the launch's kernel variant has no
+ * rider form (it has for D = 16 dX-only and D = 32 dX + first order: dcn.py, din.py) the riders run as their own launches first. */
+int rsx_segsum_partials_ride(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
+                             const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row,
+                             const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
+                             const rsx_example_blocks* blocks_h, const rsx_scatter_riders* riders, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DIN: attention-weighted masked history sum din/din.py:118-124 and the generic

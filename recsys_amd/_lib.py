@@ -67,6 +67,15 @@ class DwReduceJob(C.Structure):
                 ("N", C.c_int32), ("layout", C.c_int32)]
 
 
+class CrossReduceJob(C.Structure):        # include/rsx.h rsx_cross_reduce_job
+    _fields_ = [("part", C.c_void_p), ("dW", C.c_void_p), ("dB", C.c_void_p), ("dwout", C.c_void_p), ("RT", C.c_int32),
+                ("n", C.c_int32), ("L", C.c_int32), ("dim", C.c_int32)]
+
+
+class ScatterRiders(C.Structure):         # include/rsx.h rsx_scatter_riders
+    _fields_ = [("dw", DwReduceJob * 4), ("n_dw", C.c_int32), ("reserved", C.c_int32), ("cross", CrossReduceJob)]
+
+
 class GatherJob(C.Structure):
     _fields_ = [("table", C.c_void_p), ("ids", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("K", C.c_int32),
                 ("ld_out", C.c_int32), ("row_base", C.c_int32), ("ld_table", C.c_int32)]
@@ -122,6 +131,7 @@ _SIGS = {
     "rsx_field_sort_large_workspace_ints": (C.c_size_t, [_I, _I, _I]),
     "rsx_segsum_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P, _P, _P]),
     "rsx_segsum_partials": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P, _P]),
+    "rsx_segsum_partials_ride": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P, C.POINTER(ScatterRiders), _P]),
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
     "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
     "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P]),
@@ -147,6 +157,8 @@ _SIGS = {
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),
+    "rsx_cross_bwd_defer": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, C.POINTER(CrossReduceJob), _P]),
+    "rsx_cross_reduce_run": (_I, [C.POINTER(CrossReduceJob), _P]),
     "rsx_din_pool_fwd": (_I, [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_din_pool_fwd_ld": (_I, [_P] * 4 + [_I, _I, _I, _I, _P]),
     "rsx_din_pool_bwd_ld": (_I, [_P] * 6 + [_I, _I, _I, _I, _I, _I, _P]),

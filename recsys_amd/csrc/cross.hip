@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "rsx_common.h"
+#include "step_riders_device.h"
 
 constexpr int CROSS_MAX_L = 8;
 constexpr int CROSS_NV = 4;   // float4 per lane -> dim <= 1024
@@ -310,36 +311,11 @@ __global__ __launch_bounds__(256, 2) void cross_bwd4_k(const CrossBwdArgs p, int
     dst[e] = f4_add(f4_add(f4_add(sl4[e], sl4[per + e]), sl4[2 * per + e]), sl4[3 * per + e]);
 }
 
-// out[j] = sum over the RT per-wave partials.  16 threads per output: thread q sums partials q, q+16, ... in order,
-// then the 16 totals are added in ascending q through LDS (fixed order).  grid = ceil(n/16), block = 256.
+// out[j] = sum over the RT per-wave partials (step_riders_device.h cross_reduce_block).  grid = ceil(n/16), block = 256.
 __global__ __launch_bounds__(256) void cross_reduce_k(const float* __restrict__ part, int RT, int n, float* __restrict__ dW,
                                                       float* __restrict__ dB, float* __restrict__ dwout, int L, int dim) {
-  __shared__ float red[16][16];
-  const int jl = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + jl;
-  float s = 0.f;
-  if (j < n) {   // row group q takes rows q, q+16, ...: 8 loads in flight, fixed order
-    int r = q;
-    for (; r + 7 * 16 < RT; r += 8 * 16) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(r + 16 * u) * n + j];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += t[u];
-    }
-    for (; r < RT; r += 16) s += part[(size_t)r * n + j];
-  }
-  red[q][jl] = s;
-  __syncthreads();
-  if (q == 0 && j < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][jl];
-    const int vec = j / dim, e = j - vec * dim;
-    if (vec < L) dW[(size_t)vec * dim + e] = t;
-    else if (vec < 2 * L) dB[(size_t)(vec - L) * dim + e] = t;
-    else if (dwout != nullptr) dwout[e] = t;
-  }
+  __shared__ float red[256];
+  cross_reduce_block(part, RT, n, dW, dB, dwout, L, dim, blockIdx.x, red);
 }
 
 extern "C" int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, const float* wout, float* s, float* xL,
@@ -371,9 +347,20 @@ extern "C" size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L) {   // (
   return (size_t)((B + epw - 1) / epw) * (size_t)(2 * L + 1) * (size_t)dim;
 }
 
+extern "C" int rsx_cross_bwd_defer(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                                   float*, int, float*, float*, float*, float*, int, int, int, rsx_cross_reduce_job*, rsx_stream_t);
 extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, const float* s, const float* dxL,
                              const float* gz, const float* wout, float* dX, int accumulate, float* dW, float* dB,
                              float* dwout, float* workspace, int B, int dim, int L, rsx_stream_t stream) {
+  return rsx_cross_bwd_defer(x0, W, Bc, s, dxL, gz, wout, dX, accumulate, dW, dB, dwout, workspace, B, dim, L, nullptr, stream);
+}
+// reduce_out (nullable): the second launch (the sum of the per-wave gradient partials) is handed back as a job instead of
+// launched -- rsx_cross_reduce_run runs it, or another launch of the step carries it (rsx_segsum_partials_ride)
+extern "C" int rsx_cross_bwd_defer(const float* x0, const float* W, const float* Bc, const float* s, const float* dxL,
+                                   const float* gz, const float* wout, float* dX, int accumulate, float* dW, float* dB,
+                                   float* dwout, float* workspace, int B, int dim, int L, rsx_cross_reduce_job* reduce_out,
+                                   rsx_stream_t stream) {
+  if (reduce_out != nullptr) reduce_out->n = 0;
   if (B < 0 || dim <= 0 || L <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!x0 || !W || !Bc || !s || !dX || !dW || !dB || !workspace) return RSX_EINVAL;
@@ -409,8 +396,22 @@ extern "C" int rsx_cross_bwd(const float* x0, const float* W, const float* Bc, c
   }
   RSX_CHECK_LAUNCH();
   const int n = (2 * L + 1) * dim;
+  if (reduce_out != nullptr) {
+    *reduce_out = rsx_cross_reduce_job{workspace, dW, dB, dwout, RT, n, L, dim};
+    return RSX_OK;
+  }
   RSX_LAUNCH(cross_reduce_k, dim3((n + 15) / 16), dim3(256), 0, rsx_s(stream), workspace, RT, n, dW, dB, dwout,
                      L, dim);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_cross_reduce_run(const rsx_cross_reduce_job* j, rsx_stream_t stream) {
+  if (!j) return RSX_EINVAL;
+  if (j->n == 0) return RSX_OK;
+  if (!j->part || !j->dW || !j->dB || j->RT <= 0 || j->n < 0 || j->L <= 0 || j->dim <= 0) return RSX_EINVAL;
+  RSX_LAUNCH(cross_reduce_k, dim3((j->n + 15) / 16), dim3(256), 0, rsx_s(stream), j->part, j->RT, j->n, j->dW, j->dB, j->dwout,
+                     j->L, j->dim);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -11,6 +11,7 @@
 #include "sort_device.h"
 #include "adam_device.h"
 #include "gather_device.h"
+#include "step_riders_device.h"
 
 RSX_STAMP_DECL
 // (profiling build only) which workgroup of a launch stamps slots [16 g, 16 g + 16): g = 0 -> workgroup 0, g = 1 -> workgroup 24
@@ -750,12 +751,12 @@ struct SegTile {
 // W1: the first-order sums ride along (compile-time, so that the gy1 loads are as unconditional as the row loads: behind a
 // per-lane condition the first of them is waited for alone, ahead of the whole batch)
 template <int D, bool FM, bool W1>
-__global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ tables, const float* __restrict__ S,
-                                                      const float* __restrict__ dX, const float* __restrict__ gy1,
-                                                      const float* __restrict__ gy2, const int32_t* __restrict__ perm,
-                                                      const int32_t* __restrict__ uniq_row, const SegPartials ws,
-                                                      uint64_t w1_mask, int B, int F, int stride, int null_row,
-                                                      const ExBlocks xb) {
+__device__ __forceinline__ void segsum_tiles_body(const float* __restrict__ tables, const float* __restrict__ S,
+                                                  const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                  const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                  const int32_t* __restrict__ uniq_row, const SegPartials& ws,
+                                                  uint64_t w1_mask, int B, int F, int stride, int null_row,
+                                                  const ExBlocks& xb) {
   constexpr int LPR = D / 4;
   using T = SegTile<LPR>;
   extern __shared__ __attribute__((aligned(16))) int32_t tile_lds[];
@@ -986,6 +987,39 @@ __global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ 
   }
   if (next > 0) to_G(jl);
   RSX_STAMP2(5);
+}
+
+template <int D, bool FM, bool W1>
+__global__ __launch_bounds__(256) void segsum_tiles_k(const float* __restrict__ tables, const float* __restrict__ S,
+                                                      const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                      const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ uniq_row, const SegPartials ws,
+                                                      uint64_t w1_mask, int B, int F, int stride, int null_row,
+                                                      const ExBlocks xb) {
+  segsum_tiles_body<D, FM, W1>(tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_mask, B, F, stride, null_row, xb);
+}
+// the same launch carrying reductions of the step's other launches that only the optimizer reads (step_riders_device.h): its
+// own n_own position-tile workgroups, then the tower's dW partial-tile reductions, then the cross layers' gradient reduce
+template <int D, bool FM, bool W1>
+__global__ __launch_bounds__(256) void segsum_tiles_ride_k(const float* __restrict__ tables, const float* __restrict__ S,
+                                                           const float* __restrict__ dX, const float* __restrict__ gy1,
+                                                           const float* __restrict__ gy2, const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ uniq_row, const SegPartials ws,
+                                                           uint64_t w1_mask, int B, int F, int stride, int null_row,
+                                                           const ExBlocks xb, const DwReduceJobs dwj, const rsx_cross_reduce_job cr,
+                                                           const uint32_t n_own, const uint32_t n_dw) {
+  if (blockIdx.x >= n_own) {
+    const uint32_t r = blockIdx.x - n_own;
+    if (r < n_dw) {
+      RSX_DW_REDUCE_SELECT(dwj, r, jb, blk)
+      dw_reduce_job_block(jb, blk);
+    } else {
+      extern __shared__ __attribute__((aligned(16))) int32_t tile_lds[];
+      cross_reduce_block(cr.part, cr.RT, cr.n, cr.dW, cr.dB, cr.dwout, cr.L, cr.dim, r - n_dw, reinterpret_cast<float*>(tile_lds));
+    }
+    return;
+  }
+  segsum_tiles_body<D, FM, W1>(tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_mask, B, F, stride, null_row, xb);
 }
 
 // ---- single stage through LDS (B <= SEG_LDS_MAX_B entries per field, 4 | waves per field) ---------------------------------
@@ -1925,6 +1959,54 @@ extern "C" int rsx_segsum_partials(const float* tables, const float* S, const fl
   const dim3 grid((unsigned)((size_t)F * ((B + pos - 1) / pos)));
   RSX_DISPATCH_D(D, launch_tiles, grid, rsx_s(stream), tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F,
                  stride, null_row, xb);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_segsum_partials_ride(const float* tables, const float* S, const float* dX, const float* gy1,
+                                        const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                                        const int32_t* uniq_row, const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B,
+                                        int F, int D, int stride, int null_row, const rsx_example_blocks* blocks_h,
+                                        const rsx_scatter_riders* riders, rsx_stream_t stream) {
+  const bool any = riders != nullptr && (riders->n_dw > 0 || riders->cross.n > 0);
+  // the rider forms that exist: dcn.py's scatter (D = 16, dX only) and din.py's (D = 32, dX + first order)
+  const bool form = (D == 16 && gy2 == nullptr && gy1 == nullptr) || (D == 32 && gy2 == nullptr && gy1 != nullptr);
+  if (any && (!form || B == 0)) {        // no rider form for this launch: the riders' own launches, then the plain stage A
+    if (riders->n_dw > 0) {
+      const int rc = rsx_tower_reduce_dw_jobs(riders->dw, riders->n_dw, stream);
+      if (rc != RSX_OK) return rc;
+    }
+    const int rc = rsx_cross_reduce_run(&riders->cross, stream);
+    if (rc != RSX_OK) return rc;
+  }
+  if (!any || !form || B == 0)
+    return rsx_segsum_partials(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws_h, w1_field_mask, B, F, D, stride, null_row,
+                               blocks_h, stream);
+  if (!perm || !seg_off || !uniq_row || !ws_h || B < 0 || F <= 0 || F > 64 || stride < B || !dX) return RSX_EINVAL;
+  SegPartials ws;
+  const int rc = seg_partials(ws_h, gy1 != nullptr, ws);
+  if (rc != RSX_OK) return rc;
+  ExBlocks xb;
+  const int rcb = ex_blocks(blocks_h, B, xb);
+  if (rcb != RSX_OK) return rcb;
+  if (ws.G == nullptr) return RSX_EINVAL;
+  DwReduceJobs dwj;
+  uint32_t n_dw = 0;
+  const int rcd = dw_reduce_pack(riders->dw, riders->n_dw, dwj, &n_dw);
+  if (rcd != RSX_OK) return rcd;
+  const rsx_cross_reduce_job cr = riders->cross;
+  if (cr.n > 0 && (!cr.part || !cr.dW || !cr.dB || cr.RT <= 0 || cr.L <= 0 || cr.dim <= 0)) return RSX_EINVAL;
+  const uint32_t n_cross = cr.n > 0 ? (uint32_t)((cr.n + 15) / 16) : 0u;
+  const int pos = (256 / (D / 4)) * SEG_CHUNK;
+  const uint32_t n_own = (uint32_t)((size_t)F * ((B + pos - 1) / pos));
+  const dim3 grid(n_own + n_dw + n_cross);
+  RSX_COUNT_LAUNCH();
+  if (D == 16)
+    segsum_tiles_ride_k<16, false, false><<<grid, dim3(256), SegTile<4>::lds_bytes, rsx_s(stream)>>>(
+        tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F, stride, null_row, xb, dwj, cr, n_own, n_dw);
+  else
+    segsum_tiles_ride_k<32, false, true><<<grid, dim3(256), SegTile<8>::lds_bytes, rsx_s(stream)>>>(
+        tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F, stride, null_row, xb, dwj, cr, n_own, n_dw);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -22,6 +22,7 @@
 #include "adam_device.h"
 #include "drop_device.h"
 #include "gather_device.h"
+#include "step_riders_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 RSX_STAMP_DECL
@@ -1731,82 +1732,17 @@ __global__ __launch_bounds__(256) void tower_reduce_dw_big_k(const float* __rest
 
 // The dW reductions of ALL layers of a backward pass in one launch (a layer's reduce is first needed by the optimizer: one
 // launch at the end of the backward pass instead of one per layer; every job keeps its own fixed summation order).
-struct DwReduceJobs {
-  rsx_dw_reduce_job j[RSX_DW_REDUCE_MAX_JOBS];
-  uint32_t blk_end[RSX_DW_REDUCE_MAX_JOBS];
-};
 __global__ __launch_bounds__(256) void tower_reduce_dw_jobs_k(const DwReduceJobs g) {
-  rsx_dw_reduce_job jb = g.j[0];
-  uint32_t b0 = 0;
-#pragma unroll
-  for (int k = 1; k < RSX_DW_REDUCE_MAX_JOBS; ++k) {     // (compile-time indices: see gather_rows_multi_k)
-    if (blockIdx.x >= g.blk_end[k - 1]) {
-      jb = g.j[k];
-      b0 = g.blk_end[k - 1];
-    }
-  }
-  const uint32_t blk = blockIdx.x - b0;
-  const int tid = threadIdx.x;
-  if (jb.layout == 0) {            // tile-major partials [tiles][sb][256] (tower_bwd_k<true>): one workgroup per tile
-    const int tile = (int)blk;
-    const float* all = jb.partials + (size_t)tile * jb.sb * 256;
-    float s = 0.f;
-    for (int q = 0; q < jb.sb; q += 8) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = q + u < jb.sb ? all[(size_t)(q + u) * 256 + tid] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += t[u];
-    }
-    const int ct_n = (jb.N + 15) / 16;
-    const int nt = tile % ct_n, kf = tile / ct_n;
-    const int orow = kf * 16 + (tid >> 4), ocol = nt * 16 + (tid & 15);
-    if (ocol < jb.N) {
-      if (orow < jb.K) jb.dW[(size_t)orow * jb.N + ocol] = s;
-      else if (orow == jb.K) jb.db[ocol] = s;
-    }
-    return;
-  }
-  // row-block partials [sb][KR][NP] (tower_bwd_big_k)
-  const int KR = (jb.K + 1 + 15) / 16 * 16, NP = (jb.N + 15) / 16 * 16;
-  const size_t e4 = (size_t)blk * 256 + tid, tot4 = (size_t)KR * NP / 4;
-  if (e4 >= tot4) return;
-  const float4* src = reinterpret_cast<const float4*>(jb.partials);
-  float4 s = F4Z;
-  for (int q = 0; q < jb.sb; q += 8) {
-    float4 t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(q + u < jb.sb ? q + u : jb.sb - 1) * tot4 + e4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (q + u < jb.sb) s = f4_add(s, t[u]);
-  }
-  const int kk = (int)((e4 * 4) / NP), n = (int)((e4 * 4) - (size_t)kk * NP);
-  const float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (n + t < jb.N) {
-      if (kk < jb.K) jb.dW[(size_t)kk * jb.N + n + t] = v[t];
-      else if (kk == jb.K) jb.db[n + t] = v[t];
-    }
-  }
+  RSX_DW_REDUCE_SELECT(g, blockIdx.x, jb, blk)
+  dw_reduce_job_block(jb, blk);
 }
 
 extern "C" int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njobs, rsx_stream_t stream) {
   if (njobs == 0) return RSX_OK;
-  if (!jobs_h || njobs < 0 || njobs > RSX_DW_REDUCE_MAX_JOBS) return RSX_EINVAL;
   DwReduceJobs g;
   uint32_t end = 0;
-  for (int k = 0; k < RSX_DW_REDUCE_MAX_JOBS; ++k) {
-    const rsx_dw_reduce_job& j = jobs_h[k < njobs ? k : njobs - 1];
-    if (k < njobs) {
-      if (!j.partials || !j.dW || !j.db || j.sb <= 0 || j.K <= 0 || j.N <= 0 || (j.layout != 0 && j.layout != 1)) return RSX_EINVAL;
-      if (j.layout == 0) end += (uint32_t)(((j.K + 1 + 15) / 16) * ((j.N + 15) / 16));
-      else end += (uint32_t)((((size_t)(j.K + 1 + 15) / 16 * 16) * ((size_t)(j.N + 15) / 16 * 16) / 4 + 255) / 256);
-    }
-    g.j[k] = j;
-    g.blk_end[k] = end;
-  }
+  const int rc = dw_reduce_pack(jobs_h, njobs, g, &end);
+  if (rc != RSX_OK) return rc;
   RSX_LAUNCH(tower_reduce_dw_jobs_k, dim3(end), dim3(256), 0, rsx_s(stream), g);
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -15,7 +15,7 @@ from .deepfm import define_flags as _deepfm_flags
 from .deepfm import input_fn, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
 from .feature_columns import CriteoLayout, build_feature_columns
-from .ops import CrossFn, CrossLayers, EmbeddingArena, FusedTower, gather_fm
+from .ops import make_scatter_riders, CrossFn, CrossLayers, EmbeddingArena, FusedTower, gather_fm
 
 
 def build_variables(store, params, capacity):
@@ -127,15 +127,21 @@ def _train_fused(store, arena, ids, labels, params, masks):
             sweeps = sweeps[:2 * nl + 1]
             if job is not None:
                 assert sweeps[0] is None, "the first forward launch carries the sort: no sweep slice may ride with it"
+        # Round 4 (single replica, fused optimizer launch): the tower's dW partial-tile reductions and the cross layers' gradient
+        # reduce -- two launches whose results only the optimizer reads -- ride in the scatter's stage-A launch as extra
+        # workgroups (rsx_segsum_partials_ride).  Data parallel: the dense gradients go into a collective first, so they stay.
+        ride = dp is None and hot is not None and os.environ.get("RSX_SCATTER_RIDERS", "1") == "1"
         _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
         loss, prob, dX, gz, _ = store.tower.train_step(
             x0, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,
             replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
-            sort_job=job, sweeps=sweeps, sort_in_fwd=True, outs=(dp.send_views(ids.shape[0])[0], None, None) if zc else None)
-        store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
-                             gz=gz, wout=oW[nh:], dwout=oG[nh:])
+            sort_job=job, sweeps=sweeps, sort_in_fwd=True, outs=(dp.send_views(ids.shape[0])[0], None, None) if zc else None,
+            defer_dw_reduce=ride)
+        cross_job = store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
+                                         gz=gz, wout=oW[nh:], dwout=oG[nh:], defer_reduce=ride)
+        riders = make_scatter_riders(store.tower.dw_jobs_pending, cross_job) if ride else None
         if side is not None:
             main.wait_stream(side)
 
@@ -157,7 +163,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             if hot is not None:
                 arena.select(wpos)
                 arena.segsum_adam(Bg, None, dXg, None, None, store.opt, (dense_segs or store.dense.adam_segments()) + bsegs,
-                                  last_sweep, blocks=blocks, window=(wk, wpos))
+                                  last_sweep, blocks=blocks, window=(wk, wpos), riders=riders)
             else:
                 assert not bsegs
                 arena.segsum(Bg, None, dXg, None, None, blocks=blocks)

@@ -22,6 +22,31 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def make_scatter_riders(dw_jobs=None, cross_job=None):
+    """_lib.ScatterRiders from the tower's deferred dW reduce jobs (FusedTower.train_step(defer_dw_reduce=True) ->
+    tower.dw_jobs_pending) and the cross layers' deferred reduce (CrossLayers.backward(defer_reduce=True)); None if neither."""
+    dw_jobs = list(dw_jobs or ())
+    if not dw_jobs and (cross_job is None or cross_job.n == 0):
+        return None
+    r = _lib.ScatterRiders()
+    for i, j in enumerate(dw_jobs):
+        r.dw[i] = j
+    r.n_dw = len(dw_jobs)
+    if cross_job is not None:
+        r.cross = cross_job
+    return r
+
+
+def run_scatter_riders(riders):
+    """The riders as their own launches (a scatter without a stage A to carry them)."""
+    if riders is None:
+        return
+    if riders.n_dw > 0:
+        check(lib().rsx_tower_reduce_dw_jobs(riders.dw, riders.n_dw, _stream()), "rsx_tower_reduce_dw_jobs")
+    if riders.cross.n > 0:
+        check(lib().rsx_cross_reduce_run(C.byref(riders.cross), _stream()), "rsx_cross_reduce_run")
+
+
 def _require_cuda(dev):
     if not torch.cuda.is_available():
         raise _lib.RsxError("recsys_amd hot path needs an MI355X (torch.cuda.is_available() is False); "
@@ -316,13 +341,17 @@ class EmbeddingArena:
         (dist.DataParallel.gather_example_grads(blocked=True)); None = contiguous."""
         return None if blocks is None else C.byref(_lib.ExampleBlocks(int(blocks[0]), int(blocks[1])))
 
-    def _stage_a(self, B, S, dX, gy1, gy2, blk=None):
-        """Stage A of the two-stage scatter; returns the partials handle stage B takes (None: single stage)."""
+    def _stage_a(self, B, S, dX, gy1, gy2, blk=None, riders=None):
+        """Stage A of the two-stage scatter; returns the partials handle stage B takes (None: single stage).
+        riders (_lib.ScatterRiders or None): reductions of the step's other launches that only the optimizer reads, carried by
+        this launch as extra workgroups (rsx_segsum_partials_ride); without a stage A they run as their own launches here."""
         if not self._two_stage(B):
+            run_scatter_riders(riders)
             return None
-        check(lib().rsx_segsum_partials(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
-                                        _ptr(self.seg_off), _ptr(self.uniq_row), C.byref(self.partials), self.w1_mask,
-                                        B, self.F, self.D, self.stride, -1, blk, _stream()), "rsx_segsum_partials")
+        check(lib().rsx_segsum_partials_ride(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1), _ptr(gy2), _ptr(self.perm),
+                                             _ptr(self.seg_off), _ptr(self.uniq_row), C.byref(self.partials), self.w1_mask,
+                                             B, self.F, self.D, self.stride, -1, blk,
+                                             None if riders is None else C.byref(riders), _stream()), "rsx_segsum_partials_ride")
         return C.byref(self.partials)
 
     def segsum(self, B, S, dX, gy1, gy2, blocks=None):
@@ -334,7 +363,7 @@ class EmbeddingArena:
                                    self.stride, part, blk, _stream()), "rsx_segsum_bwd")
 
     def segsum_adam(self, B, S, dX, gy1, gy2, opt, extra_segments, sweep=None, blocks=None, advance=True, second=None,
-                    window=None, w1_ext=None):
+                    window=None, w1_ext=None, riders=None):
         """Segment-sum + touched-row Adam in one launch (+ `extra_segments`, e.g. the dense arena, as extra workgroups).
         second = (arena2, dX2): a table set sharing this arena's sort (share_sort_of), updated by the same launch.
         window = (k, cur): this step is position `cur` of an optimizer window of k steps (the current sort workspace must
@@ -359,7 +388,7 @@ class EmbeddingArena:
         if w1_ext is not None:          # (w1, m, v, stride, sparse formula): a first-order vector stored outside this arena
             w1p, mwp, vwp, w1s, w1sp = _ptr(w1_ext[0]), _ptr(w1_ext[1]), _ptr(w1_ext[2]), int(w1_ext[3]), int(w1_ext[4])
             assert gy1 is not None
-        part = self._stage_a(B, S, dX, gy1, gy2, blk)
+        part = self._stage_a(B, S, dX, gy1, gy2, blk, riders)
         check(lib().rsx_segsum_adam_rows2(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), w1p, mwp, vwp, _ptr(S), _ptr(dX),
                                           _ptr(gy1), _ptr(gy2), _ptr(self.perm), _ptr(self.seg_off), _ptr(self.uniq_row),
                                           _ptr(self.nuniq), self.w1_mask, B, self.F, self.D, self.stride, arr, n,
@@ -682,7 +711,7 @@ class FusedTower:
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
                    seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None, layer_done=None, gather=None,
-                   reduce_stream=None, reduce_rider=False):
+                   reduce_stream=None, reduce_rider=False, defer_dw_reduce=False):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
@@ -809,9 +838,13 @@ class FusedTower:
                 check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
             if layer_done is not None:
                 layer_done(l)
+        self.dw_jobs_pending = []
         if defer:
             todo = [jobs[l] for l in range(nl) if jobs[l].sb > 0]
-            if todo:
+            if todo and defer_dw_reduce:
+                # (the caller hands them to the scatter's stage-A launch: make_scatter_riders / segsum_adam(riders=...))
+                self.dw_jobs_pending = todo
+            elif todo:
                 arr = (_lib.DwReduceJob * len(todo))(*todo)
                 check(L.rsx_tower_reduce_dw_jobs(arr, len(todo), st), "rsx_tower_reduce_dw_jobs")
         return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
@@ -891,11 +924,15 @@ class CrossLayers:
               "rsx_cross_fwd")
         return self.s[:B], xL, (self.cz[:B] if wout is not None else None)
 
-    def backward(self, x0, W, Bc, dW, dB, dX, accumulate, dxL=None, gz=None, wout=None, dwout=None):
+    def backward(self, x0, W, Bc, dW, dB, dX, accumulate, dxL=None, gz=None, wout=None, dwout=None, defer_reduce=False):
+        """defer_reduce: the second launch (the gradient partials' sum) comes back as a _lib.CrossReduceJob for the scatter's
+        stage-A launch to carry (make_scatter_riders) instead of being launched here."""
         B = x0.shape[0]
-        check(lib().rsx_cross_bwd(_ptr(x0), _ptr(W), _ptr(Bc), _ptr(self.s), _ptr(dxL), _ptr(gz), _ptr(wout), _ptr(dX),
-                                  int(accumulate), _ptr(dW), _ptr(dB), _ptr(dwout), _ptr(self.ws), B, self.dim, self.L,
-                                  _stream()), "rsx_cross_bwd")
+        job = _lib.CrossReduceJob() if defer_reduce else None
+        check(lib().rsx_cross_bwd_defer(_ptr(x0), _ptr(W), _ptr(Bc), _ptr(self.s), _ptr(dxL), _ptr(gz), _ptr(wout), _ptr(dX),
+                                        int(accumulate), _ptr(dW), _ptr(dB), _ptr(dwout), _ptr(self.ws), B, self.dim, self.L,
+                                        None if job is None else C.byref(job), _stream()), "rsx_cross_bwd_defer")
+        return job
 
 
 class CrossFn(torch.autograd.Function):
