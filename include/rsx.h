@@ -560,11 +560,21 @@ int rsx_cross_reduce_run(const rsx_cross_reduce_job* job_h, rsx_stream_t stream)
  * (rsx_segsum_partials_ride) as extra 256-thread workgroups beside its position tiles: the tower's dW partial-tile reductions
  * (the jobs rsx_tower_bwd_layer_defer hands back) and the cross layers' gradient reduce.  dcn.py at batch 4 096: two launches
  * (6.4 + 4.9 us) leave the step's dependent chain.                                                                       */
+/* out[j] = sum over g < G of part[g * n + j] (the G partial gradient vectors of a persistent launch, in workgroup order:
+ * 16 contiguous ranges of ceil(G / 16) partials summed one after the other, the 16 sub-sums then added in ascending order --
+ * the association of rsx_din_attn_finish's reduce) */
+typedef struct {
+  const float* part;
+  float* out;
+  int32_t G, n;
+} rsx_vec_reduce_job;
+#define RSX_VEC_REDUCE_MAX_JOBS 2
 typedef struct {
   rsx_dw_reduce_job dw[RSX_DW_REDUCE_MAX_JOBS];
   int32_t n_dw;
-  int32_t reserved;
+  int32_t n_vec;
   rsx_cross_reduce_job cross;    /* cross.n == 0: none */
+  rsx_vec_reduce_job vec[RSX_VEC_REDUCE_MAX_JOBS];   /* din.py: the two attention blocks' weight-gradient partials */
 } rsx_scatter_riders;
 /* rsx_segsum_partials (the scatter's stage A, above) -- the same launch carrying `riders` (nullable / empty: exactly rsx_segsum_partials).  Where the launch's kernel variant has no
  * rider form (it has for D = 16 dX-only and D = 32 dX + first order: dcn.py, din.py) the riders run as their own launches first. */
@@ -700,6 +710,14 @@ int rsx_din_attn_bwd_nofinish(const float* H, const float* q, const float* W0, c
 int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0, const float* dq_add0,
                              const float* workspace1, float* grads1, float* dq1, const int32_t* ids1, const float* dq_add1,
                              int B, int P, int K, int N1, int N2, int ld_dq, int ld_dq_add, rsx_stream_t stream);
+/* the same with the two weight-gradient reduces handed back as jobs (reduce_out[2], nullable: then exactly the entry above)
+ * instead of run by the launch -- only the optimizer reads grads_x, so the scatter's stage-A launch can carry them
+ * (rsx_scatter_riders.vec) and this launch is left with the query-gradient sums the scatter waits for.                    */
+int rsx_din_attn_finish_pair_defer(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0, const float* dq_add0,
+                                   const float* workspace1, float* grads1, float* dq1, const int32_t* ids1, const float* dq_add1,
+                                   int B, int P, int K, int N1, int N2, int ld_dq, int ld_dq_add, rsx_vec_reduce_job* reduce_out,
+                                   rsx_stream_t stream);
+int rsx_vec_reduce_run(const rsx_vec_reduce_job* jobs_h, int njobs, rsx_stream_t stream);
 
 /* accumulate_dH != 0: dH += (rsx_din_pool_bwd has already written its share of the gradient of H into the same buffer).
  * rows / count / ids (nullable together): the forward's row list and the [B*P] ids it came from; only listed positions get

@@ -72,8 +72,13 @@ class CrossReduceJob(C.Structure):        # include/rsx.h rsx_cross_reduce_job
                 ("n", C.c_int32), ("L", C.c_int32), ("dim", C.c_int32)]
 
 
+class VecReduceJob(C.Structure):          # include/rsx.h rsx_vec_reduce_job
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("G", C.c_int32), ("n", C.c_int32)]
+
+
 class ScatterRiders(C.Structure):         # include/rsx.h rsx_scatter_riders
-    _fields_ = [("dw", DwReduceJob * 4), ("n_dw", C.c_int32), ("reserved", C.c_int32), ("cross", CrossReduceJob)]
+    _fields_ = [("dw", DwReduceJob * 4), ("n_dw", C.c_int32), ("n_vec", C.c_int32), ("cross", CrossReduceJob),
+                ("vec", VecReduceJob * 2)]
 
 
 class GatherJob(C.Structure):
@@ -167,6 +172,8 @@ _SIGS = {
     "rsx_din_prepare": (_I, [_P] * 4 + [_I, _I, _I, _I] + [_P] * 8),
     "rsx_din_attn_bwd_nofinish": (_I, [_P] * 13 + [C.c_uint32, _I, C.c_float, _I] + [_P] * 3 + [_I] * 6 + [_P]),
     "rsx_din_attn_finish_pair": (_I, [_P] * 10 + [_I] * 7 + [_P]),
+    "rsx_din_attn_finish_pair_defer": (_I, [_P] * 10 + [_I] * 7 + [_P, _P]),
+    "rsx_vec_reduce_run": (_I, [_P, _I, _P]),
     "rsx_din_pool_fwd_pair": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
     "rsx_din_pool_bwd_pair": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, _P]),
     "rsx_din_pool_bwd_pair_ride": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _I, C.POINTER(MlpReduceJob), _P]),

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "rsx_common.h"
 #include "gather_rows_device.h"
+#include "step_riders_device.h"
 RSX_STAMP_DECL
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1120,22 +1121,56 @@ extern "C" int rsx_din_attn_bwd_nofinish(const float* H, const float* q, const f
                        dropout_rate, accumulate_dH, rows, count, ids, B, P, K, N1, N2, ld_dH, K, nullptr, 0, false, stream);
 }
 
-extern "C" int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0,
-                                        const float* dq_add0, const float* workspace1, float* grads1, float* dq1,
-                                        const int32_t* ids1, const float* dq_add1, int B, int P, int K, int N1, int N2, int ld_dq,
-                                        int ld_dq_add, rsx_stream_t stream) {
+extern "C" int rsx_din_attn_finish_pair_defer(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0,
+                                              const float* dq_add0, const float* workspace1, float* grads1, float* dq1,
+                                              const int32_t* ids1, const float* dq_add1, int B, int P, int K, int N1, int N2,
+                                              int ld_dq, int ld_dq_add, rsx_vec_reduce_job* reduce_out, rsx_stream_t stream) {
+  if (reduce_out != nullptr) reduce_out[0].n = reduce_out[1].n = 0;
   if (B < 0 || P <= 0 || K <= 0 || N1 <= 0 || N2 <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!workspace0 || !grads0 || !dq0 || !workspace1 || !grads1 || !dq1 || ld_dq < K) return RSX_EINVAL;
   if ((dq_add0 != nullptr || dq_add1 != nullptr) && ld_dq_add < K) return RSX_EINVAL;
   const int M = B * P, G = attn_bwd_groups(M);
   const int n = (int)attn_npart(K, N1, N2);
-  const int nr = (n + 63) / 64;
+  // reduce_out: the launch keeps the query-gradient sums only (nr = 0 reduce workgroups); the two reduces go back as jobs
+  const int nr = reduce_out != nullptr ? 0 : (n + 63) / 64;
   // workspace layout of the backward launch: [M, K] per-row query gradients, then the G partials
   const AttnFinishSet s0{workspace0 + (size_t)M * K, grads0, workspace0, dq0, ids0, dq_add0};
   const AttnFinishSet s1{workspace1 + (size_t)M * K, grads1, workspace1, dq1, ids1, dq_add1};
+  if (reduce_out != nullptr) {
+    reduce_out[0] = rsx_vec_reduce_job{s0.part, grads0, G, n};
+    reduce_out[1] = rsx_vec_reduce_job{s1.part, grads1, G, n};
+  }
   RSX_LAUNCH(din_attn_finish_pair_k, dim3(nr + (B + 3) / 4, 2), dim3(1024), 0, rsx_s(stream), s0, s1, G, n, nr, B, P, K,
                      ld_dq, ld_dq_add);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+extern "C" int rsx_din_attn_finish_pair(const float* workspace0, float* grads0, float* dq0, const int32_t* ids0,
+                                        const float* dq_add0, const float* workspace1, float* grads1, float* dq1,
+                                        const int32_t* ids1, const float* dq_add1, int B, int P, int K, int N1, int N2, int ld_dq,
+                                        int ld_dq_add, rsx_stream_t stream) {
+  return rsx_din_attn_finish_pair_defer(workspace0, grads0, dq0, ids0, dq_add0, workspace1, grads1, dq1, ids1, dq_add1, B, P, K, N1,
+                                        N2, ld_dq, ld_dq_add, nullptr, stream);
+}
+
+// the deferred reduces as a launch of their own (grid.y = job)
+__global__ __launch_bounds__(256) void vec_reduce_k(const rsx_vec_reduce_job a, const rsx_vec_reduce_job b) {
+  __shared__ float sub[1024];
+  if (blockIdx.y == 0) vec_reduce_block(a.part, a.G, a.n, a.out, blockIdx.x, sub);
+  else vec_reduce_block(b.part, b.G, b.n, b.out, blockIdx.x, sub);
+}
+extern "C" int rsx_vec_reduce_run(const rsx_vec_reduce_job* jobs_h, int njobs, rsx_stream_t stream) {
+  if (njobs == 0) return RSX_OK;
+  if (!jobs_h || njobs < 0 || njobs > RSX_VEC_REDUCE_MAX_JOBS) return RSX_EINVAL;
+  const rsx_vec_reduce_job a = jobs_h[0], b = jobs_h[njobs > 1 ? 1 : 0];
+  int nmax = 0;
+  for (int k = 0; k < njobs; ++k) {
+    if (jobs_h[k].n < 0 || (jobs_h[k].n > 0 && (!jobs_h[k].part || !jobs_h[k].out || jobs_h[k].G <= 0))) return RSX_EINVAL;
+    nmax = jobs_h[k].n > nmax ? jobs_h[k].n : nmax;
+  }
+  if (nmax == 0) return RSX_OK;
+  RSX_LAUNCH(vec_reduce_k, dim3((nmax + 63) / 64, njobs), dim3(256), 0, rsx_s(stream), a, b);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -1007,15 +1007,21 @@ __global__ __launch_bounds__(256) void segsum_tiles_ride_k(const float* __restri
                                                            const int32_t* __restrict__ uniq_row, const SegPartials ws,
                                                            uint64_t w1_mask, int B, int F, int stride, int null_row,
                                                            const ExBlocks xb, const DwReduceJobs dwj, const rsx_cross_reduce_job cr,
-                                                           const uint32_t n_own, const uint32_t n_dw) {
+                                                           const rsx_vec_reduce_job v0, const rsx_vec_reduce_job v1,
+                                                           const uint32_t n_own, const uint32_t n_dw, const uint32_t n_cross,
+                                                           const uint32_t n_v0) {
   if (blockIdx.x >= n_own) {
+    extern __shared__ __attribute__((aligned(16))) int32_t tile_lds[];      // (>= 4 KB: the host sizes the launch for the riders)
     const uint32_t r = blockIdx.x - n_own;
     if (r < n_dw) {
       RSX_DW_REDUCE_SELECT(dwj, r, jb, blk)
       dw_reduce_job_block(jb, blk);
-    } else {
-      extern __shared__ __attribute__((aligned(16))) int32_t tile_lds[];
+    } else if (r < n_dw + n_cross) {
       cross_reduce_block(cr.part, cr.RT, cr.n, cr.dW, cr.dB, cr.dwout, cr.L, cr.dim, r - n_dw, reinterpret_cast<float*>(tile_lds));
+    } else if (r < n_dw + n_cross + n_v0) {
+      vec_reduce_block(v0.part, v0.G, v0.n, v0.out, r - n_dw - n_cross, reinterpret_cast<float*>(tile_lds));
+    } else {
+      vec_reduce_block(v1.part, v1.G, v1.n, v1.out, r - n_dw - n_cross - n_v0, reinterpret_cast<float*>(tile_lds));
     }
     return;
   }
@@ -1968,7 +1974,8 @@ extern "C" int rsx_segsum_partials_ride(const float* tables, const float* S, con
                                         const int32_t* uniq_row, const rsx_seg_partials* ws_h, uint64_t w1_field_mask, int B,
                                         int F, int D, int stride, int null_row, const rsx_example_blocks* blocks_h,
                                         const rsx_scatter_riders* riders, rsx_stream_t stream) {
-  const bool any = riders != nullptr && (riders->n_dw > 0 || riders->cross.n > 0);
+  const bool any = riders != nullptr && (riders->n_dw > 0 || riders->cross.n > 0 || riders->n_vec > 0);
+  if (riders != nullptr && (riders->n_vec < 0 || riders->n_vec > RSX_VEC_REDUCE_MAX_JOBS)) return RSX_EINVAL;
   // the rider forms that exist: dcn.py's scatter (D = 16, dX only) and din.py's (D = 32, dX + first order)
   const bool form = (D == 16 && gy2 == nullptr && gy1 == nullptr) || (D == 32 && gy2 == nullptr && gy1 != nullptr);
   if (any && (!form || B == 0)) {        // no rider form for this launch: the riders' own launches, then the plain stage A
@@ -1978,6 +1985,8 @@ extern "C" int rsx_segsum_partials_ride(const float* tables, const float* S, con
     }
     const int rc = rsx_cross_reduce_run(&riders->cross, stream);
     if (rc != RSX_OK) return rc;
+    const int rcv = rsx_vec_reduce_run(riders->vec, riders->n_vec, stream);
+    if (rcv != RSX_OK) return rcv;
   }
   if (!any || !form || B == 0)
     return rsx_segsum_partials(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, ws_h, w1_field_mask, B, F, D, stride, null_row,
@@ -1997,16 +2006,23 @@ extern "C" int rsx_segsum_partials_ride(const float* tables, const float* S, con
   const rsx_cross_reduce_job cr = riders->cross;
   if (cr.n > 0 && (!cr.part || !cr.dW || !cr.dB || cr.RT <= 0 || cr.L <= 0 || cr.dim <= 0)) return RSX_EINVAL;
   const uint32_t n_cross = cr.n > 0 ? (uint32_t)((cr.n + 15) / 16) : 0u;
+  rsx_vec_reduce_job v0{nullptr, nullptr, 0, 0}, v1{nullptr, nullptr, 0, 0};
+  if (riders->n_vec > 0) v0 = riders->vec[0];
+  if (riders->n_vec > 1) v1 = riders->vec[1];
+  if ((v0.n > 0 && (!v0.part || !v0.out || v0.G <= 0)) || (v1.n > 0 && (!v1.part || !v1.out || v1.G <= 0))) return RSX_EINVAL;
+  const uint32_t n_v0 = v0.n > 0 ? (uint32_t)((v0.n + 63) / 64) : 0u, n_v1 = v1.n > 0 ? (uint32_t)((v1.n + 63) / 64) : 0u;
   const int pos = (256 / (D / 4)) * SEG_CHUNK;
   const uint32_t n_own = (uint32_t)((size_t)F * ((B + pos - 1) / pos));
-  const dim3 grid(n_own + n_dw + n_cross);
+  const dim3 grid(n_own + n_dw + n_cross + n_v0 + n_v1);
+  const size_t lds_own = D == 16 ? SegTile<4>::lds_bytes : SegTile<8>::lds_bytes;
+  const size_t lds = lds_own > 4096 ? lds_own : 4096;                  // (the riders' LDS: 256 / 1 024 floats)
   RSX_COUNT_LAUNCH();
   if (D == 16)
-    segsum_tiles_ride_k<16, false, false><<<grid, dim3(256), SegTile<4>::lds_bytes, rsx_s(stream)>>>(
-        tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F, stride, null_row, xb, dwj, cr, n_own, n_dw);
+    segsum_tiles_ride_k<16, false, false><<<grid, dim3(256), lds, rsx_s(stream)>>>(
+        tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F, stride, null_row, xb, dwj, cr, v0, v1, n_own, n_dw, n_cross, n_v0);
   else
-    segsum_tiles_ride_k<32, false, true><<<grid, dim3(256), SegTile<8>::lds_bytes, rsx_s(stream)>>>(
-        tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F, stride, null_row, xb, dwj, cr, n_own, n_dw);
+    segsum_tiles_ride_k<32, false, true><<<grid, dim3(256), lds, rsx_s(stream)>>>(
+        tables, S, dX, gy1, gy2, perm, uniq_row, ws, w1_field_mask, B, F, stride, null_row, xb, dwj, cr, v0, v1, n_own, n_dw, n_cross, n_v0);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -121,3 +121,38 @@ __device__ __forceinline__ void cross_reduce_block(const float* __restrict__ par
     else if (dwout != nullptr) dwout[e] = t;
   }
 }
+
+// ---- out[j] = sum of G partial vectors (rsx_vec_reduce_job; din_attn.hip attn_finish_block's weight-gradient reduce with the SAME
+// association: sub-sum w = partials [w * per, (w + 1) * per), per = ceil(G / 16), 8 loads in flight; then the 16 sub-sums in
+// ascending order).  A 256-thread workgroup: 4 waves x 4 sub-sums each, lane = column blk * 64 + lane.  sub: 1024 floats of LDS.
+__device__ __forceinline__ void vec_reduce_block(const float* __restrict__ part, const int G, const int n, float* __restrict__ out,
+                                                 const uint32_t blk, float* sub /* [16][64] */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = (int)blk * 64 + lane;
+  const int per = (G + 15) / 16;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int w = 4 * wv + k;
+    const int g0 = w * per, g1 = g0 + per < G ? g0 + per : G;
+    float s = 0.f;
+    if (j < n) {
+      int g = g0;
+      for (; g + 8 <= g1; g += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(g + u) * n + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+      }
+      for (; g < g1; ++g) s += part[(size_t)g * n + j];
+    }
+    sub[w * 64 + lane] = s;
+  }
+  __syncthreads();
+  if (wv == 0 && j < n) {
+    float t = sub[lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sub[k * 64 + lane];
+    out[j] = t;
+  }
+}

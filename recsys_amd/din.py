@@ -16,7 +16,7 @@ from . import layers as L
 from .estimator import Estimator, EstimatorSpec, EvalSpec, ModeKeys, RunConfig, TrainSpec, get_variable_store, \
     train_and_evaluate
 from . import _lib
-from .ops import DinAttnFn, DinAttnPoolFn, DinPoolFn, EmbeddingArena, FusedTower, SparseTable, _ptr, _stream
+from .ops import make_scatter_riders, DinAttnFn, DinAttnPoolFn, DinPoolFn, EmbeddingArena, FusedTower, SparseTable, _ptr, _stream
 
 ATTENTION_LAYERS = [80, 40]      # din/din.py:85 (the din_layers flag is ignored by the reference)
 MLP_LAYERS = [100, 50, 20]       # din/din.py:86 (the deep_layers flag is ignored by the reference)
@@ -314,9 +314,14 @@ class DinFused:
                                                        _ptr(hist[t]), B, P, K, n1, n2, 2 * K, st), "rsx_din_attn_bwd_nofinish")
             # weight gradients + the target rows' gradients (dq, plus the MLP input slice for the item block) of both blocks
             dqp = [C.c_void_p(vbase + 4 * t * K) for t in range(2)]         # rows 0 .. B-1 of column block t
-            _lib.check(L.rsx_din_attn_finish_pair(_ptr(self.ws[0]), _ptr(gouts[0]), dqp[0], _ptr(hist[0]), _ptr(dX),
-                                                  _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,
-                                                  B, P, K, n1, n2, 2 * K, 3 * K, st), "rsx_din_attn_finish_pair")
+            # (round 4, single replica: the two weight-gradient reduces -- 28 of the launch's 54 MB, read by the optimizer only --
+            # come back as jobs and ride in the scatter's stage-A launch; RSX_SCATTER_RIDERS=0: inside this launch)
+            ride_fin = dp is None and os.environ.get("RSX_SCATTER_RIDERS", "1") == "1"
+            vjobs = (_lib.VecReduceJob * 2)() if ride_fin else None
+            _lib.check(L.rsx_din_attn_finish_pair_defer(_ptr(self.ws[0]), _ptr(gouts[0]), dqp[0], _ptr(hist[0]), _ptr(dX),
+                                                        _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,
+                                                        B, P, K, n1, n2, 2 * K, 3 * K, vjobs, st), "rsx_din_attn_finish_pair_defer")
+            riders = make_scatter_riders(vec_jobs=list(vjobs)) if ride_fin else None
             if side is not None:
                 main.wait_stream(side)            # the scatter (train_op) needs the sort; the sweep must precede its Adam state advance
 
@@ -325,7 +330,7 @@ class DinFused:
                 ba = self.barena
                 if dp is None:
                     a.segsum_adam(N, None, vals, gbias, None, store.opt, store.dense.adam_segments(),
-                                  w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
+                                  w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1), riders=riders)
                 else:
                     # ONE collective: [dense gradient arena | value block | bias gradients] of every rank; the dense arenas are
                     # summed in rank order inside the optimizer launch, the scatter reads the rank blocks in place

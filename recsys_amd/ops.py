@@ -22,11 +22,13 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_scatter_riders(dw_jobs=None, cross_job=None):
+def make_scatter_riders(dw_jobs=None, cross_job=None, vec_jobs=None):
     """_lib.ScatterRiders from the tower's deferred dW reduce jobs (FusedTower.train_step(defer_dw_reduce=True) ->
-    tower.dw_jobs_pending) and the cross layers' deferred reduce (CrossLayers.backward(defer_reduce=True)); None if neither."""
+    tower.dw_jobs_pending), the cross layers' deferred reduce (CrossLayers.backward(defer_reduce=True)) and deferred
+    partial-vector reduces (din.py: rsx_din_attn_finish_pair_defer); None if there is none."""
     dw_jobs = list(dw_jobs or ())
-    if not dw_jobs and (cross_job is None or cross_job.n == 0):
+    vec_jobs = [v for v in (vec_jobs or ()) if v.n > 0]
+    if not dw_jobs and (cross_job is None or cross_job.n == 0) and not vec_jobs:
         return None
     r = _lib.ScatterRiders()
     for i, j in enumerate(dw_jobs):
@@ -34,6 +36,9 @@ def make_scatter_riders(dw_jobs=None, cross_job=None):
     r.n_dw = len(dw_jobs)
     if cross_job is not None:
         r.cross = cross_job
+    for i, v in enumerate(vec_jobs):
+        r.vec[i] = v
+    r.n_vec = len(vec_jobs)
     return r
 
 
@@ -45,6 +50,8 @@ def run_scatter_riders(riders):
         check(lib().rsx_tower_reduce_dw_jobs(riders.dw, riders.n_dw, _stream()), "rsx_tower_reduce_dw_jobs")
     if riders.cross.n > 0:
         check(lib().rsx_cross_reduce_run(C.byref(riders.cross), _stream()), "rsx_cross_reduce_run")
+    if riders.n_vec > 0:
+        check(lib().rsx_vec_reduce_run(riders.vec, riders.n_vec, _stream()), "rsx_vec_reduce_run")
 
 
 def _require_cuda(dev):
