@@ -536,6 +536,11 @@ int rsx_mlp_nobn_reduce_job(const rsx_mlp_step* step_h, rsx_mlp_reduce_job* job_
  * the logit contribution <x_L, wout> of tf.layers.dense(concat[deep, x_L], 1) dcn/dcn.py:151-152.                  */
 int rsx_cross_fwd(const float* x0, const float* W, const float* Bc, const float* wout, float* s, float* xL, float* cz,
                   int B, int dim, int L, rsx_stream_t stream);
+/* The input_layer lookup (rsx_gather_fm_fwd without first-order / FM outputs; dcn/dcn.py:125-127) and rsx_cross_fwd in ONE launch:
+ * a wave gathers an example's rows and runs the cross layers on the registers it holds (D = 16, F <= 64).  E [B, F*D] as the
+ * gather writes it, s / cz as rsx_cross_fwd; the same bits as the two launches.                                             */
+int rsx_gather_cross_fwd(const float* tables, const int32_t* row_off, const int32_t* ids, float* E, const float* W, const float* Bc,
+                         const float* wout, float* s, float* cz, int B, int F, int D, int L, rsx_stream_t stream);
 size_t rsx_cross_bwd_workspace_floats(int B, int dim, int L);
 /* Given dxL [B,dim] and/or gz [B] (gradient of cz): dX (+)= d loss/d x0, dW[L,dim], dB[L,dim], dwout[dim].
  * x_1..x_L are recomputed from s.  workspace: rsx_cross_bwd_workspace_floats() floats.                             */

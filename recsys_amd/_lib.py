@@ -161,6 +161,7 @@ _SIGS = {
     "rsx_adam_fast_math_selftest": (_I, [_P, C.c_uint32, _I, _I, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
+    "rsx_gather_cross_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
     "rsx_cross_bwd": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_defer": (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I, _I, _I, C.POINTER(CrossReduceJob), _P]),
     "rsx_cross_reduce_run": (_I, [C.POINTER(CrossReduceJob), _P]),

@@ -13,17 +13,8 @@
 
 #include "rsx_common.h"
 #include "step_riders_device.h"
+#include "cross_device.h"
 
-constexpr int CROSS_MAX_L = 8;
-constexpr int CROSS_NV = 4;   // float4 per lane -> dim <= 1024
-
-// float4 #e of a row of n4 float4s; lanes past the row read the last element (in range) and get zero by multiplication:
-// a guarded load is compiled into a branch of its own and the vectors of a lane then load one after the other
-__device__ __forceinline__ float4 cross_ld(const float4* __restrict__ row, int e, int n4) {
-  const float4 v = row[e < n4 ? e : n4 - 1];
-  const float f = e < n4 ? 1.f : 0.f;
-  return make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
-}
 
 struct CrossFwdArgs {
   const float* x0;     // [B, dim]
@@ -36,53 +27,16 @@ struct CrossFwdArgs {
   int B, dim, L;
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-  return v;
-}
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
-
 __global__ __launch_bounds__(256) void cross_fwd_k(const CrossFwdArgs p) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= p.B) return;
   const int n4 = p.dim >> 2;
-  float4 x0[CROSS_NV], x[CROSS_NV];
+  float4 x0[CROSS_NV];
 #pragma unroll
-  for (int v = 0; v < CROSS_NV; ++v) {
-    const int e = lane + 64 * v;
-    x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, e, n4);
-    x[v] = x0[v];
-  }
-  for (int l = 0; l < p.L; ++l) {
-    float4 w[CROSS_NV], bb[CROSS_NV];
-    float part = 0.f;
-#pragma unroll
-    for (int v = 0; v < CROSS_NV; ++v) {
-      const int e = lane + 64 * v;
-      w[v] = cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, e, n4);
-      bb[v] = cross_ld(reinterpret_cast<const float4*>(p.Bc) + (size_t)l * n4, e, n4);
-      part += dot4(x[v], w[v]);
-    }
-    const float s = wave_sum(part);
-    if (lane == 0) p.s[(size_t)b * p.L + l] = s;
-#pragma unroll
-    for (int v = 0; v < CROSS_NV; ++v) x[v] = f4_add(f4_add(f4_scale(s, x0[v]), x[v]), bb[v]);
-  }
-  float part = 0.f;
-#pragma unroll
-  for (int v = 0; v < CROSS_NV; ++v) {
-    const int e = lane + 64 * v;
-    if (e < n4) {
-      if (p.xL != nullptr) reinterpret_cast<float4*>(p.xL)[(size_t)b * n4 + e] = x[v];
-      if (p.wout != nullptr) part += dot4(x[v], reinterpret_cast<const float4*>(p.wout)[e]);
-    }
-  }
-  if (p.cz != nullptr) {
-    const float c = wave_sum(part);
-    if (lane == 0) p.cz[b] = c;
-  }
+  for (int v = 0; v < CROSS_NV; ++v) x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, lane + 64 * v, n4);
+  cross_fwd_wave(x0, p.W, p.Bc, p.wout, p.s + (size_t)b * p.L, p.xL != nullptr ? p.xL + (size_t)b * p.dim : nullptr,
+                 p.cz != nullptr ? p.cz + b : nullptr, p.dim, p.L, lane);
 }
 
 struct CrossBwdArgs {

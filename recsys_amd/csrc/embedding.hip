@@ -12,6 +12,7 @@
 #include "adam_device.h"
 #include "gather_device.h"
 #include "step_riders_device.h"
+#include "cross_device.h"
 
 RSX_STAMP_DECL
 // (profiling build only) which workgroup of a launch stamps slots [16 g, 16 g + 16): g = 0 -> workgroup 0, g = 1 -> workgroup 24
@@ -122,6 +123,44 @@ __global__ __launch_bounds__(1024) void gather_fm_head_k(const float* __restrict
 // F = 1 (tf.nn.embedding_lookup of one table: DIN's item / category / history lookups, din/din.py:96-105): a plain row
 // gather.  The multi-field kernel would keep one wave per id with D/4 of its 64 lanes busy; here a wave serves 64/(D/4)
 // ids at once, one float4 per lane, fully coalesced on the output side.
+// dcn.py's input_layer lookup AND its cross layers' forward in ONE launch (round 4; dcn/dcn.py:125-142): a wave gathers the 39 rows
+// of one example -- lane (j, q) holds quarter q of fields j, j + 16, j + 32: float4 #(lane + 64 v) of the example's row, which is
+// exactly the lane layout of cross_fwd_wave (cross_device.h) -- writes E as the gather does and runs the cross layers on the
+// registers it already holds.  Replaces gather_fm_fwd_k + cross_fwd_k (the second re-read the 10 MB the first had just written and
+// was a launch of its own on the step's chain); same bits as the two launches.  D = 16, F <= 64.
+__global__ __launch_bounds__(256) void gather_cross_fwd_k(const float* __restrict__ tables, const int32_t* __restrict__ row_off,
+                                                          const int32_t* __restrict__ ids, float* __restrict__ E,
+                                                          const float* __restrict__ W, const float* __restrict__ Bc,
+                                                          const float* __restrict__ wout, float* __restrict__ s,
+                                                          float* __restrict__ cz, int B, int F, int L) {
+  constexpr int LPR = 4, PPP = 16;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int q = lane % LPR, j = lane / LPR;
+  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(tables);
+  float4* __restrict__ E4 = reinterpret_cast<float4*>(E);
+  const int32_t* idb = ids + (size_t)b * F;
+  int row[CROSS_NV];
+  bool ok[CROSS_NV];
+#pragma unroll
+  for (int k = 0; k < CROSS_NV; ++k) {     // fields j, j + 16, j + 32, j + 48: ids and offsets first, then the row loads, all unconditional
+    const int f = j + k * PPP;
+    ok[k] = f < F;
+    const int fc = ok[k] ? f : F - 1;
+    row[k] = row_off[fc] + idb[fc];
+  }
+  float4 x0[CROSS_NV];
+#pragma unroll
+  for (int k = 0; k < CROSS_NV; ++k) x0[k] = T4[(size_t)row[k] * LPR + q];
+#pragma unroll
+  for (int k = 0; k < CROSS_NV; ++k) {
+    if (ok[k]) E4[((size_t)b * F + j + k * PPP) * LPR + q] = x0[k];
+    else x0[k] = F4Z;
+  }
+  cross_fwd_wave(x0, W, Bc, wout, s + (size_t)b * L, nullptr, cz != nullptr ? cz + b : nullptr, F * 16, L, lane);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ table, const int32_t* __restrict__ row_off,
                                                      const int32_t* __restrict__ ids, float* __restrict__ out,
@@ -1765,6 +1804,18 @@ static void launch_gather_sort(dim3 grid, size_t lds, hipStream_t st, const floa
                                const int32_t* row_off, const int32_t* ids, float* E, float* S, float* y1, float* y2,
                                uint64_t mask, int B, int F, int n_gather, const SortArgs& sort) {
   RSX_COUNT_LAUNCH(); gather_fm_sort_k<D><<<grid, dim3(256), lds, st>>>(tables, w1, row_off, ids, E, S, y1, y2, mask, B, F, n_gather, sort);
+}
+
+extern "C" int rsx_gather_cross_fwd(const float* tables, const int32_t* row_off, const int32_t* ids, float* E, const float* W,
+                                    const float* Bc, const float* wout, float* s, float* cz, int B, int F, int D, int L,
+                                    rsx_stream_t stream) {
+  if (!tables || !row_off || !ids || !E || !W || !Bc || !s || B < 0 || F <= 0 || L <= 0) return RSX_EINVAL;
+  if ((cz != nullptr) != (wout != nullptr)) return RSX_EINVAL;
+  if (D != 16 || F > 64 || L > CROSS_MAX_L) return RSX_EUNSUPPORTED;
+  if (B == 0) return RSX_OK;
+  RSX_LAUNCH(gather_cross_fwd_k, dim3((B + 3) / 4), dim3(256), 0, rsx_s(stream), tables, row_off, ids, E, W, Bc, wout, s, cz, B, F, L);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
 }
 
 extern "C" int rsx_gather_fm_fwd_sort(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,

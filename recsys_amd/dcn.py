@@ -90,7 +90,13 @@ def _train_fused(store, arena, ids, labels, params, masks):
         wk, wpos, wfeat = store.window_of_step()
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1) else ids   # first: see deepfm._train_fused
         zc = dp is not None and store.dp_block
-        x0, _, _, _ = arena.gather(ids)
+        # Round 4: the lookup and the cross layers' forward in ONE launch (rsx_gather_cross_fwd: the gather's lanes already hold the
+        # example's row in the cross kernel's layout); RSX_GATHER_CROSS=0: two launches
+        gcross = store.cross.fused_gather_ok(arena)
+        if gcross:
+            x0, _, cz = store.cross.gather_forward(arena, ids, P["cross.W"], P["cross.b"], oW[nh:])
+        else:
+            x0, _, _, _ = arena.gather(ids)
         job, sweeps, hot, last_sweep = None, None, None, None
         # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
         # untouched rows ONCE for the whole window (a launch of its own); the other positions run neither
@@ -131,7 +137,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # reduce -- two launches whose results only the optimizer reads -- ride in the scatter's stage-A launch as extra
         # workgroups (rsx_segsum_partials_ride).  Data parallel: the dense gradients go into a collective first, so they stay.
         ride = dp is None and hot is not None and os.environ.get("RSX_SCATTER_RIDERS", "1") == "1"
-        _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
+        if not gcross:
+            _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
         loss, prob, dX, gz, _ = store.tower.train_step(
             x0, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,

@@ -931,6 +931,20 @@ class CrossLayers:
               "rsx_cross_fwd")
         return self.s[:B], xL, (self.cz[:B] if wout is not None else None)
 
+    def gather_forward(self, arena, ids, W, Bc, wout):
+        """The arena's input_layer lookup AND the cross layers' forward in ONE launch (rsx_gather_cross_fwd, round 4): -> x0 [B, dim],
+        s [B, L], cz [B].  Applies when arena.D == 16 and arena.F * 16 == dim (fused_gather_ok)."""
+        B = ids.shape[0]
+        E, _, _, _ = arena.gather_outputs(B, False, False, None)
+        check(lib().rsx_gather_cross_fwd(_ptr(arena.tables), _ptr(arena.row_off), _ptr(ids), _ptr(E), _ptr(W), _ptr(Bc), _ptr(wout),
+                                         _ptr(self.s), _ptr(self.cz), B, arena.F, arena.D, self.L, _stream()),
+              "rsx_gather_cross_fwd")
+        return E, self.s[:B], self.cz[:B]
+
+    def fused_gather_ok(self, arena):
+        return arena.D == 16 and arena.F <= 64 and arena.F * arena.D == self.dim and self.L <= 8 and \
+            os.environ.get("RSX_GATHER_CROSS", "1") == "1"
+
     def backward(self, x0, W, Bc, dW, dB, dX, accumulate, dxL=None, gz=None, wout=None, dwout=None, defer_reduce=False):
         """defer_reduce: the second launch (the gradient partials' sum) comes back as a _lib.CrossReduceJob for the scatter's
         stage-A launch to carry (make_scatter_riders) instead of being launched here."""
