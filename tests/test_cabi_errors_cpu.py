@@ -161,3 +161,51 @@ def test_copy_and_selftest_entry_points_reject_bad_arguments(L):
     assert L.rsx_copy_bytes(a16, a16 + 20, 16, None) == EINVAL         # misaligned source
     assert L.rsx_copy_bytes(a16, a16 + 16, 0, None) == OK              # nothing to do
     assert L.rsx_adam_fast_math_selftest(None, 1, 1, 0, None) == EINVAL
+
+
+def test_round4_entry_points_reject_bad_arguments(L):
+    """The one-launch batch-norm-free tower, the riders and the fused lookup + cross forward (include/rsx.h, round 4)."""
+    from recsys_amd import _lib
+    w = (C.c_int32 * 3)(100, 52, 20)
+    assert L.rsx_mlp_nobn_supported(96, w, 3) == 1
+    assert L.rsx_mlp_nobn_supported(96, w, 4) == 0                                   # > 3 hidden layers
+    assert L.rsx_mlp_nobn_supported(98, w, 3) == 0                                   # input width not a multiple of 4
+    assert L.rsx_mlp_nobn_supported(96, (C.c_int32 * 3)(128, 52, 20), 3) == 0        # a layer wider than 112
+    assert L.rsx_mlp_nobn_workspace_floats(1024, 96, w, 3) == 64 * (112 * 112 + 112 * 64 + 64 * 32 + 24)
+    assert L.rsx_mlp_nobn_train_step(None, None) == EINVAL
+    ms = _lib.MlpStep()
+    ms.B, ms.K0, ms.L = 16, 96, 3
+    for i, n in enumerate((100, 52, 20)):
+        ms.widths[i] = n
+    assert L.rsx_mlp_nobn_train_step(C.byref(ms), None) == EINVAL                    # no buffers
+    ms.L = 4
+    assert L.rsx_mlp_nobn_train_step(C.byref(ms), None) == EINVAL
+    ms.L, ms.B = 3, 0
+    assert L.rsx_mlp_nobn_train_step(C.byref(ms), None) == OK                        # empty batch
+    job = _lib.MlpReduceJob()
+    assert L.rsx_mlp_nobn_reduce_job(C.byref(ms), None) == EINVAL
+    assert L.rsx_mlp_nobn_reduce_job(C.byref(ms), C.byref(job)) == OK and job.e4_last == 0
+    # riders
+    assert L.rsx_vec_reduce_run(None, 1, None) == EINVAL
+    assert L.rsx_vec_reduce_run(None, 0, None) == OK
+    vj = (_lib.VecReduceJob * 2)()
+    assert L.rsx_vec_reduce_run(vj, 3, None) == EINVAL                               # > 2 jobs
+    assert L.rsx_vec_reduce_run(vj, 2, None) == OK                                   # both empty (n == 0)
+    vj[0].n, vj[0].G = 64, 4
+    assert L.rsx_vec_reduce_run(vj, 1, None) == EINVAL                               # no partials / output
+    cj = _lib.CrossReduceJob()
+    assert L.rsx_cross_reduce_run(None, None) == EINVAL
+    assert L.rsx_cross_reduce_run(C.byref(cj), None) == OK                           # n == 0: nothing to do
+    cj.n = 10
+    assert L.rsx_cross_reduce_run(C.byref(cj), None) == EINVAL
+    # the fused lookup + cross forward: D = 16 only, wout and cz together
+    assert L.rsx_gather_cross_fwd(P, P, P, P, P, P, P, P, P, 8, 39, 8, 3, None) == EUNSUPPORTED
+    assert L.rsx_gather_cross_fwd(P, P, P, P, P, P, P, P, P, 8, 39, 16, 9, None) == EUNSUPPORTED       # > 8 layers
+    assert L.rsx_gather_cross_fwd(P, P, P, P, P, P, None, P, P, 8, 39, 16, 3, None) == EINVAL         # cz without wout
+    assert L.rsx_gather_cross_fwd(None, P, P, P, P, P, P, P, P, 8, 39, 16, 3, None) == EINVAL
+    assert L.rsx_gather_cross_fwd(P, P, P, P, P, P, P, P, P, 0, 39, 16, 3, None) == OK                 # empty batch
+    # din.py's prepare launches carrying lookups: the job split must lie inside the job list
+    gj = (_lib.GatherJob * 2)()
+    assert L.rsx_din_prepare2_gather(P, P, P, P, 4, 10, 100, 10, P, 0, P, P, None, P, P, None, None, None, gj, 2, 3, None) == EINVAL
+    assert L.rsx_din_prepare2_gather(P, P, P, P, 4, 10, 100, 10, P, 0, P, P, None, P, P, None, None, None, None, 2, 1, None) == EINVAL
+    assert L.rsx_din_prepare2_gather(P, P, P, P, 4, 10, 100, 10, P, 0, P, P, None, P, P, None, None, None, gj, 2, 1, None) == EINVAL   # empty jobs: no table
