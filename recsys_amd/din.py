@@ -224,18 +224,22 @@ class DinFused:
             # Round 4: the ids-only branch of the step -- the dedup sort (7 launches on 52 workgroups: a chain of launch latencies)
             # and the sweep over the rows it leaves untouched -- runs on a SIDE stream beside the forward / backward launches
             # (which read and write touched rows only) and joins the step's stream before the scatter.  Captured, the fork and
-            # the join are two edges of the step's graph.  Single replica only: under data parallelism the sort waits for the
-            # keys' all-gather, which is ordered with the other collectives on the step's stream.  RSX_DIN_SIDE_SORT=0: in line.
-            side = self._side_stream() if dp is None else None
+            # the join are two edges of the step's graph.  Data parallel: the keys' all-gather stays on the step's stream (it is
+            # ordered with the other collectives there, and ends a graph segment); the fork follows it, inside the next segment
+            # (RSX_DIN_SIDE_SORT_DP=0: in line).  RSX_DIN_SIDE_SORT=0: in line.
+            keys_g = None
+            if dp is not None:
+                # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
+                # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
+                keys_g = dp.all_gather_rows(keys2)
+                vals_full, gbias_full = dp.send_views(N)
+            side = self._side_stream() if (dp is None or os.environ.get("RSX_DIN_SIDE_SORT_DP", "1") == "1") else None
             main = torch.cuda.current_stream()
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
                 if dp is not None:
-                    # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
-                    # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
-                    a.field_sort(dp.all_gather_rows(keys2))
-                    vals_full, gbias_full = dp.send_views(N)
+                    a.field_sort(keys_g)
                 elif big:
                     a.field_sort_t(self.keys_t, N)
                 else:
