@@ -418,3 +418,45 @@ def train_step(model, opt, fwd_args, labels, fwd_kwargs=None, lazy=False):
             opt.apply_sparse(name, P[name], uniq, G, lazy=lazy)
     opt.finish_step()
     return loss, z
+
+
+def train_step_dp(model, opt, rank_fwd_args, rank_labels, rank_fwd_kwargs=None, lazy=False):
+    """One SYNCHRONOUS data-parallel TRAIN step of N replicas on N different batches, as tf.distribute.MirroredStrategy
+    runs it (fm/fm.py:184-194, deepfm/readme.md:24 "each step runs two batches"): every replica runs
+    forward / backward on ITS batch with the shared variables (batch-norm statistics and dropout per replica), the replica
+    losses are scaled by 1/N, dense gradients are SUMMED over the replicas, the replicas' IndexedSlices are concatenated in
+    replica order and de-duplicated by the optimizer (one segment-sum over the global batch), then ONE TF-1 Adam update.
+    rank_fwd_args[r]: the forward arguments of replica r; rank_labels[r]; rank_fwd_kwargs[r] (e.g. its dropout masks).
+    Returns (per-replica mean losses, per-replica logits)."""
+    P = model.P
+    N = len(rank_fwd_args)
+    g_sum, s_cat, losses, zs = {}, {}, [], []
+    for r in range(N):
+        kw = (rank_fwd_kwargs[r] if rank_fwd_kwargs is not None else None) or {}
+        z = model.forward(*rank_fwd_args[r], train=True, **kw)
+        loss, dz = nn.sigmoid_ce_mean(z, rank_labels[r])
+        g, s = model.backward(dz / N)
+        losses.append(loss)
+        zs.append(z)
+        for name, grad in g.items():
+            grad = grad.reshape(P[name].shape)
+            g_sum[name] = grad.copy() if name not in g_sum else g_sum[name] + grad
+        for name, (rows, vals) in s.items():
+            s_cat.setdefault(name, []).append((rows, vals))
+    for name, grad in g_sum.items():
+        opt.apply_dense(name, P[name], grad.astype(P[name].dtype))
+    for name, parts in s_cat.items():
+        rows = np.concatenate([p[0] for p in parts])
+        vals = np.concatenate([p[1] for p in parts])
+        uniq, G = nn.segment_sum_rows(rows, vals)
+        if name in ("w1", "lin.wcat"):
+            if lazy:
+                opt.apply_sparse(name, P[name], uniq, G, lazy=True)
+            else:
+                dense = np.zeros_like(P[name])
+                dense[uniq] = G
+                opt.apply_dense(name, P[name], dense)
+        else:
+            opt.apply_sparse(name, P[name], uniq, G, lazy=lazy)
+    opt.finish_step()
+    return losses, zs

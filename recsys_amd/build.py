@@ -92,9 +92,16 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 4))) as ex:
         list(ex.map(compile_one, todo))
     keep = set(objs)
-    for f in glob.glob(os.path.join(OBJ_DIR, "*.o")):          # objects of older source versions
+    # objects of older source versions.  Several ranks may build at once: another process may have removed the same stale file
+    # already, and an object younger than an hour may be one a concurrent build (of another source version) is about to link
+    import time
+    for f in glob.glob(os.path.join(OBJ_DIR, "*.o")):
         if f not in keep:
-            os.remove(f)
+            try:
+                if time.time() - os.path.getmtime(f) > 3600:
+                    os.remove(f)
+            except FileNotFoundError:
+                pass
     tmp = LIB + ".tmp.%d" % os.getpid()      # link to a private name, then rename: a concurrent loader (another rank)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]   # never sees a half-written library
     if verbose:

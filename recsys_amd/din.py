@@ -339,7 +339,10 @@ class DinFused:
                     # ONE collective: [dense gradient arena | value block | bias gradients] of every rank; the dense arenas are
                     # summed in rank order inside the optimizer launch, the scatter reads the rank blocks in place
                     (vg, gbg), blocks, dense_segs = dp.gather_send_block(N, fold_dense=True)
-                    a.segsum_adam(N * world, None, vg, gbg, None, store.opt, dense_segs, blocks=blocks,
+                    # (dense_segs is None when the arena took the all-reduce branch -- RSX_DP_ALLREDUCE_MIN_BYTES, a large
+                    # embedding_size: the gradients were then summed in place and the arena's own segments apply them)
+                    a.segsum_adam(N * world, None, vg, gbg, None, store.opt, dense_segs or store.dense.adam_segments(),
+                                  blocks=blocks,
                                   w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
 
         return EstimatorSpec(ModeKeys.TRAIN, predictions={"prob": prob}, loss=loss[0], train_op=train_op)
@@ -461,11 +464,12 @@ def model_fn(features, labels, mode, params):
     if mode == ModeKeys.EVAL:
         return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
     dp = store.dp
-    if dp is not None:          # MirroredStrategy scales the replica loss by 1/N (the fused head does the same inside)
-        loss = loss / dp.world
+    # MirroredStrategy scales the replica loss by 1/N for the GRADIENTS (the fused head does the same inside); the spec carries
+    # the replica's own mean loss like every other TRAIN path -- the Estimator's log line averages over the replicas
+    loss_bwd = loss / dp.world if dp is not None else loss
 
     def train_op():                                                        # AdamOptimizer.minimize (:172-173)
-        loss.backward()
+        loss_bwd.backward()
         with torch.no_grad():
             for tbl in (item, cate, bias):
                 tbl.finalize(dp)

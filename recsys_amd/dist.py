@@ -484,6 +484,124 @@ class EmulatedDataParallel(DataParallel):
         pass
 
 
+class LoopbackDataParallel(DataParallel):
+    """TEST HARNESS (tests/test_gpu_dp_loopback.py): ONE process plays the N ranks of a synchronous
+    data-parallel step ONE AFTER THE OTHER on N DIFFERENT batches -- shared variables, per-rank batch-norm statistics and
+    dropout seeds, exactly the kernels and the send / gathered buffer layouts of a real N-rank run -- so that a wrong rank
+    stride, block offset or replica sum FAILS against the oracle (EmulatedDataParallel tiles one batch N times: its N rank
+    blocks are byte-identical and cannot).
+
+    Protocol (loopback_train_step below): ranks 0 .. N-2 run model_fn as SHADOW passes -- forward and backward write the
+    rank's send block, which is stashed; everything that changes optimizer state before train_op (untouched-row sweeps,
+    AdamTF1.shadow) is skipped -- then rank N-1 runs model_fn with every collective seeing all N ranks' real inputs (its
+    dedup sort is the global one) and its train_op runs the optimizer stage once over the N real send blocks.
+    Collectives are matched by their call order inside model_fn, which is the same on every rank.  Fused steps with the
+    zero-copy send block only (what the data-parallel product path runs)."""
+
+    def __init__(self, world):
+        self.group, self.rank, self.world = None, 0, int(world)
+        self.shadow = False
+        self._calls, self._ci, self._stash, self._phase = [], 0, [], "model"
+
+    # -- driver side --------------------------------------------------------------------------------------
+    def begin_step(self):
+        self._calls, self._stash = [], []
+
+    def enter_rank(self, r, store):
+        self.rank, self._ci, self._phase = r, 0, "model"
+        self.shadow = r < self.world - 1
+        store.opt.shadow = self.shadow
+
+    def leave_rank(self, store):
+        """After model_fn of a shadow rank: keep its send block (dense gradient arena | per-unit gradient block)."""
+        if self.shadow:
+            self._stash.append(self._send.clone())
+        else:
+            self._phase = "train_op"
+        store.opt.shadow = False
+
+    # -- collectives ----------------------------------------------------------------------------------------
+    def _send_offset(self, x):
+        s = getattr(self, "_send", None)
+        if s is None:
+            return None
+        o = (x.data_ptr() - s.data_ptr()) // 4
+        return o if (0 <= o and o + x.numel() <= s.numel() and x.dtype == s.dtype) else None
+
+    def _gather_from_send(self, x):
+        o = self._send_offset(x)
+        assert len(self._stash) == self.world - 1 and self.rank == self.world - 1, "loopback: train_op of the LAST rank only"
+        rows = [st[o:o + x.numel()].view(x.shape) for st in self._stash] + [x]
+        return torch.cat(rows, 0)
+
+    def all_gather_rows(self, x, prefetchable=False):
+        x = x.contiguous()
+        if self._send_offset(x) is not None:
+            return self._gather_from_send(x)
+        if self._phase != "model":
+            raise RuntimeError("LoopbackDataParallel: a collective outside the send block inside train_op -- the shadow ranks' "
+                               "inputs of it do not exist (zero-copy send block paths only)")
+        c = self._ci
+        self._ci += 1
+        if c == len(self._calls):
+            self._calls.append([None] * self.world)
+        self._calls[c][self.rank] = x.clone()
+        # (shadow passes see their own block in place of the ranks that have not run yet: their sort results are overwritten
+        # by the last rank's, whose gathered buffer holds every rank's real block)
+        return torch.cat([t if t is not None else x for t in self._calls[c]], 0)
+
+    def _all_gather_into(self, out, x):
+        out.copy_(self._gather_from_send(x).view_as(out))
+
+    def _overlapped_allreduce_allgather(self, grad, out, x):
+        o = self._send_offset(grad)
+        tot = self._stash[0][o:o + grad.numel()].clone()
+        for st in self._stash[1:]:
+            tot += st[o:o + grad.numel()]
+        tot += grad                                  # rank order: the live block is the last rank's
+        grad.copy_(tot)
+        self._all_gather_into(out, x)
+
+    def all_reduce_sum(self, flat):
+        raise RuntimeError("LoopbackDataParallel: fused steps only (no autograd-path all-reduce)")
+
+    def all_reduce_async(self, flat):
+        raise RuntimeError("LoopbackDataParallel does not play RSX_DP_OVERLAP")
+
+    def wait_all(self, handles):
+        pass
+
+    def barrier(self):
+        pass
+
+
+def loopback_train_step(est, rank_features, rank_labels, window=None, before_rank=None):
+    """One data-parallel TRAIN step of est.store.dp.world ranks on ONE GPU (LoopbackDataParallel): rank r trains on
+    (rank_features[r], rank_labels[r]).  window = (k, pos, rank_window_features) with rank_window_features[r] = the features
+    of rank r's k batches: the step is position pos of an optimizer window.  before_rank(r): called before rank r's model_fn
+    (e.g. to inject that rank's dropout masks into est.params).  Eager (no HIP graphs).
+    -> the ranks' mean losses (floats)."""
+    from .estimator import ModeKeys
+    st, dp = est.store, est.store.dp
+    assert isinstance(dp, LoopbackDataParallel) and len(rank_features) == dp.world
+    dp.begin_step()
+    losses, spec = [], None
+    for r in range(dp.world):
+        dp.enter_rank(r, st)
+        if before_rank is not None:
+            before_rank(r)
+        st.window = (window[0], window[1], window[2][r]) if (window is not None and window[0] > 1) else None
+        try:
+            spec = est._call_model_fn(rank_features[r], rank_labels[r], ModeKeys.TRAIN)
+        finally:
+            st.window = None
+        losses.append(float(spec.loss))
+        dp.leave_rank(st)
+    spec.train_op()
+    dp.rank, dp._phase = 0, "model"
+    return losses
+
+
 def window_global_ids(dp, window_features, key="ids"):
     """The ids of the k batches of an optimizer window (estimator.VariableStore.window) as the GLOBAL batches the optimizer
     sees: dp None -> the local ones; else ONE all-gather of the stacked local ids, then k [N*b, F] tensors in rank order."""

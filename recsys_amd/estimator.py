@@ -776,10 +776,10 @@ class Estimator:
                 now = time.time()
                 world = 1
                 if self.store.dp is not None:
-                    # every TRAIN step returns its replica's mean loss / N (MirroredStrategy's loss scaling): the sum over
-                    # replicas is the mean loss of the global batch, which is what gets logged
-                    loss = self.store.dp.all_reduce_sum(loss.detach().clone().reshape(1))
+                    # every TRAIN step returns its REPLICA's mean loss (only the gradients carry MirroredStrategy's 1/N): the
+                    # mean over replicas is the mean loss of the global batch, which is what gets logged
                     world = self.store.dp.world
+                    loss = self.store.dp.all_reduce_sum(loss.detach().clone().reshape(1)) / world
                 if self._is_chief():
                     if log_step0 is not None:
                         rate = (gs - log_step0) / max(now - self._log_t, 1e-9)

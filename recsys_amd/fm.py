@@ -147,7 +147,8 @@ def _train_fused(store, arena, ids, labels):
                     arena.bucket_scatter(ids, S, None, gy1, gy2, bv[0], bv[1])
                 (Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(B, fold_dense=True)
                 arena.select(wpos)
-                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs + dp.bucket_segments(), sweep2,
+                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt,
+                                  (dense_segs or store.dense.adam_segments()) + dp.bucket_segments(), sweep2,
                                   blocks=blocks, window=(wk, wpos))
             else:
                 arena.select(wpos)

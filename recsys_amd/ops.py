@@ -31,10 +31,14 @@ def make_scatter_riders(dw_jobs=None, cross_job=None, vec_jobs=None):
     if not dw_jobs and (cross_job is None or cross_job.n == 0) and not vec_jobs:
         return None
     r = _lib.ScatterRiders()
+    # (the job tables are fixed-size C arrays: refuse here, before a backward launch has deferred a reduce nobody would run)
+    if len(dw_jobs) > len(r.dw) or len(vec_jobs) > len(r.vec):
+        raise _lib.RsxError("make_scatter_riders: %d dW / %d vector reduce jobs exceed the rider tables (%d / %d)"
+                            % (len(dw_jobs), len(vec_jobs), len(r.dw), len(r.vec)))
     for i, j in enumerate(dw_jobs):
         r.dw[i] = j
     r.n_dw = len(dw_jobs)
-    if cross_job is not None:
+    if cross_job is not None and cross_job.n > 0:
         r.cross = cross_job
     for i, v in enumerate(vec_jobs):
         r.vec[i] = v
@@ -611,6 +615,8 @@ class AdamTF1:
         window_block_u (2 / 4): a WINDOW sweep (segments with slot_w) in smaller table blocks, one slice per step of the
         window -- slice i is meant to ride in step i's head launch; slices after the first read the window's step sizes from the
         optimizer state (rsx_adam_slice.alphas_from_state)."""
+        if getattr(self, "shadow", False):      # dist.LoopbackDataParallel: a shadow rank's pass changes no optimizer state
+            return [None] * len(weights)
         arr, n = self._seg_array(cold_segments)
         nb = int(lib().rsx_adam_num_blocks_u(arr, n, int(window_block_u)))
         if nb < 0:
@@ -635,6 +641,8 @@ class AdamTF1:
         return out
 
     def run_slice(self, sl):
+        if sl is None:
+            return
         check(lib().rsx_adam_slice_run(C.byref(sl), _stream()), "rsx_adam_slice_run")
 
     def window_sweep(self, cold_segments):
@@ -741,6 +749,7 @@ class FusedTower:
         mk = self._masks(B, rate, masks)
         nl = len(self.widths)
         self.mlp_reduce_job = None
+        self.dw_jobs_pending = []         # (every path: a caller that defers reads it after ANY step, the one-launch form included)
         # Round 4: a tower WITHOUT batch-norm (din.py's 'mlp_layer') runs forward + loss + backward as ONE launch + one reduce
         # (csrc/mlp_fused.hip, rsx_mlp_nobn_train_step) instead of 2L + 2 launches; RSX_MLP_FUSE=0: the launch-per-layer form
         if (not self.bn_on and self._mlp_fused_ok() and sort_job is None and sweeps is None and gather is None
