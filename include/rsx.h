@@ -346,6 +346,65 @@ int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, float* w1, floa
  * no FM term; its gradient rows dX use the same example blocks.                                                      */
 /* advance_step = 0: this launch leaves the beta powers / step counter alone because a later launch of the SAME step advances
  * them (models with two table sets: xdeepfm.py); 1 otherwise.                                                      */
+/* ---- data parallel: the exchange of per-rank UNIQUE-ROW lists (round 5) -------------------------------------------------
+ * tf.distribute.MirroredStrategy (fm/fm.py:184-194, deepfm/deepfm.py:202-204, xdeepfm/xdeepfm.py:249-251, dcn/dcn.py:235-237,
+ * din/din.py:204-206; deepfm/readme.md:24 "each step runs two batches") hands AdamOptimizer the replicas' IndexedSlices of
+ * every embedding variable, one (row, gradient) pair per looked-up id, concatenated in replica order; _apply_sparse
+ * de-duplicates them.  Each rank here reduces ITS slices first (its own dedup sort + sorted
+ * segment-sum: what a single replica runs) and the ranks exchange unique (row, sum) lists in two fixed-size collectives:
+ *   ids phase (once per optimizer window):  keys = [nuniq[F] | unique rows, field f's at goff[f] .. goff[f] + nuniq[f])
+ *   after backward:                         G[capT, D] (+ a second table set's, + gw1[capT]) laid out the same way
+ * goff [F + 1] (device): cap_f = goff[f+1] - goff[f] >= the unique rows ONE rank can have in field f -- min(batch, rows of the
+ * field) -- and capT = goff[F].                                                                                          */
+#define RSX_UNIQ_MAX_RANKS 8
+/* The same sorted segment-sum as rsx_segsum_bwd, unique row j of field f written at row goff[f] + j of G / gw1 (the rank's
+ * block of the exchange) instead of f * stride + j.  Two-stage (partials_h): stage A must have been given its own full-stride
+ * G / gw1 scratch (RSX_EINVAL when partials_h->G == G).  null_row as in rsx_segsum_partials.                               */
+int rsx_segsum_bwd_packed(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
+                          const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq,
+                          float* G, float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
+                          const rsx_seg_partials* partials_h, const int32_t* goff, rsx_stream_t stream);
+/* keys[0 .. F) = nuniq, keys[F + goff[f] + j] = uniq_row[f, j] (j < nuniq[f]; -1 up to cap_f) for the LOCAL sort outputs of
+ * up to RSX_ADAM_WINDOW_MAX batches (an optimizer window) in one launch.                                                 */
+typedef struct {
+  const int32_t* uniq_row;    /* [F, stride]: rsx_field_sort's output for the rank's own batch */
+  const int32_t* nuniq;       /* [F] */
+  int32_t* keys;              /* out: [F + capT] */
+} rsx_uniq_pack_job;
+int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, int F, int stride, rsx_stream_t stream);
+/* The N ranks' key blocks -> what rsx_field_sort leaves for the GLOBAL batch, without a global sort: per job (a batch of
+ * the window) the global unique rows of every field in ascending order (uniq_row [F, stride], nuniq [F]), the slot map (row
+ * -> f * stride + j for touched rows; the entries of the workspace's PREVIOUS contents are reset to -1 first, so uniq_row /
+ * nuniq must hold what the last call -- or zero-initialisation -- left), and src [N][F, stride]: src[r][f, j] = position of
+ * global unique row j in rank r's list, or -1.  keys: rank r's block of job k at keys + r * rank_stride + k * job_stride
+ * (int32 units), as an all-gather of the ranks' packed blocks leaves them.  stride >= the global unique rows of any field
+ * (min(N * batch, rows of the field)).  max_rows_per_field: the largest field's row count (a presence bitmap of it lives
+ * in LDS: RSX_EUNSUPPORTED beyond ~650 000 rows); max_entries: N * the largest cap_f (launch shape only).
+ * N <= RSX_UNIQ_MAX_RANKS.  Deterministic.                                                                              */
+typedef struct {
+  int32_t* uniq_row;          /* in/out [F, stride] */
+  int32_t* nuniq;             /* in/out [F] */
+  int32_t* slot;              /* in/out [R + 4] */
+  int32_t* src;               /* out [N][F, stride] */
+} rsx_uniq_merge_job;
+int rsx_uniq_merge(const int32_t* keys, long long rank_stride, int job_stride, const rsx_uniq_merge_job* jobs_h, int njobs,
+                   const int32_t* goff, const int32_t* row_off, int max_rows_per_field, int max_entries, int F, int N,
+                   int stride, rsx_stream_t stream);
+/* The optimizer launch of the exchange: rsx_segsum_adam_rows2 with the gradient of global unique row (f, j) taken from the
+ * ranks' lists -- sum over r = 0 .. N-1, IN RANK ORDER (every replica adds the same numbers in the same order: replicas stay
+ * bit-identical), of G_r[goff[f] + src[r][f, j]] over the ranks with src >= 0; G_r = G + r * rank_stride floats (rank 0's
+ * block inside the gathered buffer; rank_stride % 4 == 0, G 16-byte aligned), gw1 likewise (nullable with w1).  The per-rank
+ * sums already carry the FM term (rsx_segsum_bwd_packed).  uniq_row / nuniq / src: rsx_uniq_merge's outputs for this step;
+ * max_units: sum over fields of ceil(min(N * batch, rows_f) / (256 / D)) (the launch's row-owner grid, capped inside).
+ * second_h: rsx_table_set with dX = rank 0's [capT, D] block of the second table set's sums in the same buffer (partials
+ * ignored).  extra segments, sweep slice, window, state, advance_step, w1_stride / w1_sparse_formula: as rsx_segsum_adam_rows2. */
+int rsx_merged_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w, const float* G,
+                         const float* gw1, long long rank_stride, int N, const int32_t* src, const int32_t* goff,
+                         const int32_t* uniq_row, const int32_t* nuniq, uint64_t w1_field_mask, int max_units, int F, int D,
+                         int stride, const rsx_adam_seg* extra_segs_h, int n_extra, const rsx_adam_slice* sweep_h,
+                         const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state, int advance_step,
+                         float lr, float beta1, float beta2, float eps, int w1_stride, int w1_sparse_formula,
+                         rsx_stream_t stream);
 /* dst[0 .. nbytes) = src[0 .. nbytes) by a kernel (16-byte aligned, nbytes % 16 == 0); src may be pinned HOST memory (it is
  * mapped into the device's address space): the captured windows of the streaming TRAIN path fetch their staged batches with
  * this launch as their first graph node, so that a window is one graph launch with no hipMemcpyAsync / copy-engine start-up /

@@ -94,6 +94,17 @@ class CinDwJob(C.Structure):
     _fields_ = [("Xk", C.c_void_p), ("ws", C.c_void_p), ("dW", C.c_void_p), ("dc", C.c_void_p), ("H", C.c_int32), ("N", C.c_int32)]
 
 
+class UniqPackJob(C.Structure):           # include/rsx.h rsx_uniq_pack_job
+    _fields_ = [("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("keys", C.c_void_p)]
+
+
+class UniqMergeJob(C.Structure):          # include/rsx.h rsx_uniq_merge_job
+    _fields_ = [("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p), ("src", C.c_void_p)]
+
+
+UNIQ_MAX_RANKS = 8
+
+
 class SortJob(C.Structure):
     _fields_ = [("ids", C.c_void_p), ("row_off", C.c_void_p), ("perm", C.c_void_p), ("seg_off", C.c_void_p),
                 ("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p), ("segid", C.c_void_p),
@@ -154,6 +165,11 @@ _SIGS = {
     "rsx_segsum_adam_rows2": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F,
                                    _I, _I, _P]),
     "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
+    "rsx_segsum_bwd_packed": (_I, [_P] * 11 + [_U64, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "rsx_uniq_pack": (_I, [C.POINTER(UniqPackJob), _I, _P, _I, _I, _P]),
+    "rsx_uniq_merge": (_I, [_P, C.c_longlong, _I, C.POINTER(UniqMergeJob), _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rsx_merged_adam_rows": (_I, [_P] * 8 + [C.c_longlong, _I, _P, _P, _P, _P, _U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I,
+                                  _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _I, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
     "rsx_adam_num_blocks_u": (C.c_int64, [C.POINTER(AdamSeg), _I, _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),

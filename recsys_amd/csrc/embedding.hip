@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
                                                     const int32_t* __restrict__ nuniq, float* __restrict__ G,
                                                     float* __restrict__ gw1, uint64_t w1_mask, int B, int F,
                                                     int stride, int null_row, const SegPartials part,
-                                                    const ExBlocks xb) {
+                                                    const ExBlocks xb, const int32_t* __restrict__ goff) {
   constexpr int LPR = D / 4;
   const int q = (threadIdx.x & 63) % LPR;
   bool valid, do1;
@@ -1269,6 +1269,14 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
   bool staged;
   // rows finished by stage A already sit in G / gw1 when stage A was given these buffers: nothing to load or store
   const bool same = part.G == G;
+  // goff (nullable, [F + 1]; rsx_segsum_bwd_packed): unique row j of field f is written at row goff[f] + j of G / gw1 instead
+  // of f * stride + j -- the per-rank block of the data-parallel unique-list exchange, packed to cap_f = goff[f+1] - goff[f]
+  // rows per field (min(batch, rows of the field): nuniq[f] can never exceed it)
+  auto out_of = [&](const size_t s_l) -> size_t {
+    if (goff == nullptr) return s_l;
+    const int f = (int)(s_l / (size_t)stride);
+    return (size_t)goff[f] + (s_l - (size_t)f * stride);
+  };
   AdamRowPrefetch nopre;
   if (part.P != nullptr) {     // two-stage: the compact unit list, grid stride
     constexpr int GPW = RSX_WAVE / LPR;
@@ -1280,8 +1288,9 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
       if (segsum_wave2<D, false>(f, wf, nu, nl, nh, tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, w1_mask, B, F,
                                  stride, null_row, part, xb, valid, sl, acc, a1, e, row, do1, staged, !same, nopre) &&
           valid && !(staged && same)) {
-        reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
-        if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
+        const size_t so = out_of(sl);
+        reinterpret_cast<float4*>(G)[so * LPR + q] = acc;
+        if (gw1 != nullptr && q == 0) gw1[so] = do1 ? a1 : 0.f;
       }
     }
     return;
@@ -1297,8 +1306,9 @@ __global__ __launch_bounds__(256) void segsum_bwd_k(const float* __restrict__ ta
                                     staged, !same, nopre))
     return;
   if (valid && !(staged && same)) {
-    reinterpret_cast<float4*>(G)[sl * LPR + q] = acc;
-    if (gw1 != nullptr && q == 0) gw1[sl] = do1 ? a1 : 0.f;
+    const size_t so = out_of(sl);
+    reinterpret_cast<float4*>(G)[so * LPR + q] = acc;
+    if (gw1 != nullptr && q == 0) gw1[so] = do1 ? a1 : 0.f;
   }
 }
 
@@ -1477,10 +1487,11 @@ template <int D>
 static void launch_segsum(dim3 grid, dim3 block, hipStream_t st, const float* tables, const float* S, const float* dX,
                           const float* gy1, const float* gy2, const int32_t* perm, const int32_t* seg_off,
                           const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1, uint64_t mask, int B,
-                          int F, int stride, int null_row, const SegPartials& part, const ExBlocks& xb) {
+                          int F, int stride, int null_row, const SegPartials& part, const ExBlocks& xb,
+                          const int32_t* goff) {
   const size_t lds = part.lds_mode ? seg_lds_bytes(B, D) : 0;
   RSX_COUNT_LAUNCH(); segsum_bwd_k<D><<<grid, block, lds, st>>>(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, mask, B, F,
-                                            stride, null_row, part, xb);
+                                            stride, null_row, part, xb, goff);
 }
 template <int D>
 static void launch_tiles(dim3 grid, hipStream_t st, const float* tables, const float* S, const float* dX,
@@ -1709,7 +1720,8 @@ extern "C" int rsx_field_sort_multi(const rsx_sort_job* jobs_h, int njobs, rsx_s
 static int segsum_impl(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
                        const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq, float* G,
                        float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
-                       const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, rsx_stream_t stream) {
+                       const rsx_seg_partials* partials_h, const rsx_example_blocks* blocks_h, rsx_stream_t stream,
+                       const int32_t* goff = nullptr) {
   if (!perm || !seg_off || !uniq_row || !nuniq || !G || B < 0 || F <= 0 || F > 64 || stride < B || !d_ok(D))
     return RSX_EINVAL;
   if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
@@ -1727,8 +1739,9 @@ static int segsum_impl(const float* tables, const float* S, const float* dX, con
   long long wgs = (waves + 3) / 4;
   if (part.P != nullptr && wgs > SEG_STAGE_B_MAX_WG) wgs = SEG_STAGE_B_MAX_WG;   // (grid stride over the compact unit list)
   const dim3 grid((unsigned)wgs), block(256);
+  if (goff != nullptr && part.G == G) return RSX_EINVAL;     // packed output: stage A's G is the full-stride scratch, not the output
   RSX_DISPATCH_D(D, launch_segsum, grid, block, rsx_s(stream), tables, S, dX, gy1, gy2, perm, seg_off, uniq_row,
-                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row, part, xb);
+                 nuniq, G, gw1, w1_field_mask, B, F, stride, null_row, part, xb, goff);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1741,6 +1754,16 @@ extern "C" int rsx_segsum_bwd(const float* tables, const float* S, const float* 
                               rsx_stream_t stream) {
   return segsum_impl(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, w1_field_mask, B, F, D, stride, -1,
                      partials_h, blocks_h, stream);
+}
+
+extern "C" int rsx_segsum_bwd_packed(const float* tables, const float* S, const float* dX, const float* gy1,
+                                     const float* gy2, const int32_t* perm, const int32_t* seg_off,
+                                     const int32_t* uniq_row, const int32_t* nuniq, float* G, float* gw1,
+                                     uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
+                                     const rsx_seg_partials* partials_h, const int32_t* goff, rsx_stream_t stream) {
+  if (!goff) return RSX_EINVAL;
+  return segsum_impl(tables, S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq, G, gw1, w1_field_mask, B, F, D, stride, null_row,
+                     partials_h, nullptr, stream, goff);
 }
 
 extern "C" int rsx_segsum_partials(const float* tables, const float* S, const float* dX, const float* gy1,
@@ -1879,11 +1902,9 @@ extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, floa
   const int rcb = ex_blocks(blocks_h, B, xb);
   if (rcb != RSX_OK) return rcb;
   HotAdam h;
-  h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
-  h.w1_stride = w1_stride; h.w1_sparse = w1_sparse_formula != 0;
-  h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state; h.advance = advance_step != 0;
-  h.tables2 = nullptr; h.m_t2 = nullptr; h.v_t2 = nullptr; h.dX2 = nullptr;
-  h.part2 = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE, 0};
+  const int rch = hot_adam_init(h, tables, m_t, v_t, w1, m_w, v_w, w1_stride, w1_sparse_formula, extra_segs_h, n_extra, sweep_h,
+                                win_h, uniq_row, state, advance_step, lr, beta1, beta2, eps, F, D);
+  if (rch != RSX_OK) return rch;
   if (second_h != nullptr) {
     if (!second_h->tables || !second_h->m || !second_h->v || !second_h->dX) return RSX_EINVAL;
     h.tables2 = second_h->tables; h.m_t2 = second_h->m; h.v_t2 = second_h->v; h.dX2 = second_h->dX;
@@ -1891,45 +1912,10 @@ extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, floa
     if (rc2 != RSX_OK) return rc2;
     if ((h.part2.P != nullptr) != (part.P != nullptr)) return RSX_EINVAL;   // both sets one- or two-stage
   }
-  h.extra.n_blk = 0; h.extra.blk_lo = 0;
-  if (n_extra > 0) {
-    uint32_t blocks = 0;
-    const int rc = adam_build_args(extra_segs_h, n_extra, state, lr, beta1, beta2, eps, h.extra.args, &blocks);
-    if (rc != RSX_OK) return rc;
-    h.extra.n_blk = blocks;
-  }
   const int gpw = 64 / (D / 4);
   const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);
   h.n_own = (uint32_t)((waves + 3) / 4);
   if (part.P != nullptr && h.n_own > (uint32_t)SEG_STAGE_B_MAX_WG) h.n_own = SEG_STAGE_B_MAX_WG;   // (grid stride, compact units)
-  const int rcs = adam_build_slice(sweep_h, h.cold);
-  if (rcs != RSX_OK) return rcs;
-  // A VEC_COLD slice rewrites (restores) the touched elements of its float4s: racing with this launch's own update of
-  // those elements.  Only table slices (whole touched rows are skipped, never written) may ride here.
-  for (int k = 0; h.cold.n_blk != 0 && k < h.cold.args.nseg; ++k) {
-    const uint32_t b0 = h.cold.args.seg[k].blk_begin;
-    const uint32_t b1 = k + 1 < h.cold.args.nseg ? h.cold.args.seg[k + 1].blk_begin : h.cold.args.total_blocks;
-    const bool overlaps = b0 < h.cold.blk_lo + h.cold.n_blk && h.cold.blk_lo < b1;     // segment k has blocks in the slice
-    if (overlaps && h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
-  }
-  h.win_k = 0; h.win_cur = 0; h.win_blk = 0; h.win_per_f = 0; h.win_nr = 1;
-  for (int i = 0; i < RSX_ADAM_WINDOW_MAX; ++i) h.win_uniq[i] = h.win_nuniq[i] = h.win_slot[i] = nullptr;
-  if (win_h != nullptr && win_h->k > 1) {
-    if (win_h->k > RSX_ADAM_WINDOW_MAX || win_h->cur < 0 || win_h->cur >= win_h->k || win_h->max_unique <= 0) return RSX_EINVAL;
-    for (int i = 0; i < win_h->k; ++i) {
-      if (!win_h->uniq_row[i] || !win_h->nuniq[i] || !win_h->slot[i]) return RSX_EINVAL;
-      h.win_uniq[i] = win_h->uniq_row[i]; h.win_nuniq[i] = win_h->nuniq[i]; h.win_slot[i] = win_h->slot[i];
-    }
-    if (win_h->uniq_row[win_h->cur] != uniq_row) return RSX_EINVAL;              // entry `cur` is this step's own sort
-    h.win_k = win_h->k; h.win_cur = win_h->cur;
-    // rows per lane group: the lazy pass applies up to 8 updates per row back to back -- one row per group (more workgroups,
-    // shorter chains) where the launch is latency-bound, four at large batches
-    h.win_nr = win_h->max_unique > 1024 ? 4 : 1;
-    const int rpw = h.win_nr * 256 / (D / 4);
-    h.win_per_f = (uint32_t)((win_h->max_unique + rpw - 1) / rpw);
-    // lists walked: the next step's, or -- the window's last step -- every earlier one
-    h.win_blk = (uint32_t)(win_h->cur == win_h->k - 1 ? win_h->k - 1 : 1) * (uint32_t)F * h.win_per_f;
-  }
   h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.win_blk + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,

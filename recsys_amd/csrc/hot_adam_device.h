@@ -262,3 +262,69 @@ __device__ __forceinline__ void window_pass(const HotAdam& h, const uint32_t wb,
   }
 }
 
+
+// Host side: everything of a HotAdam that does not depend on how the launch obtains its row gradients -- the variables, the
+// hyper-parameters, the riders (dense-variable segments, an optional slice of the untouched-row sweep) and the lazy window
+// pass.  The caller sets n_own (+ the second table set) and total_blocks.  uniq_row: this step's unique-row list (must be
+// entry `cur` of the window).
+static inline int hot_adam_init(HotAdam& h, float* tables, float* m_t, float* v_t, float* w1, float* m_w, float* v_w,
+                                int w1_stride, int w1_sparse_formula, const rsx_adam_seg* extra_segs_h, int n_extra,
+                                const rsx_adam_slice* sweep_h, const rsx_adam_window* win_h, const int32_t* uniq_row,
+                                float* state, int advance_step, float lr, float beta1, float beta2, float eps, int F, int D) {
+  h.tables = tables; h.m_t = m_t; h.v_t = v_t; h.w1 = w1; h.m_w = m_w; h.v_w = v_w;
+  h.w1_stride = w1_stride; h.w1_sparse = w1_sparse_formula != 0;
+  h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.state = state; h.advance = advance_step != 0;
+  h.tables2 = nullptr; h.m_t2 = nullptr; h.v_t2 = nullptr; h.dX2 = nullptr;
+  h.part2 = SegPartials{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, RSX_NULL_NONE, 0};
+  h.n_own = 0; h.total_blocks = 0;
+  h.extra.n_blk = 0; h.extra.blk_lo = 0;
+  if (n_extra > 0) {
+    uint32_t blocks = 0;
+    const int rc = adam_build_args(extra_segs_h, n_extra, state, lr, beta1, beta2, eps, h.extra.args, &blocks);
+    if (rc != RSX_OK) return rc;
+    h.extra.n_blk = blocks;
+  }
+  const int rcs = adam_build_slice(sweep_h, h.cold);
+  if (rcs != RSX_OK) return rcs;
+  // A VEC_COLD slice rewrites (restores) the touched elements of its float4s: racing with this launch's own update of
+  // those elements.  Only table slices (whole touched rows are skipped, never written) may ride here.
+  for (int k = 0; h.cold.n_blk != 0 && k < h.cold.args.nseg; ++k) {
+    const uint32_t b0 = h.cold.args.seg[k].blk_begin;
+    const uint32_t b1 = k + 1 < h.cold.args.nseg ? h.cold.args.seg[k + 1].blk_begin : h.cold.args.total_blocks;
+    const bool overlaps = b0 < h.cold.blk_lo + h.cold.n_blk && h.cold.blk_lo < b1;     // segment k has blocks in the slice
+    if (overlaps && h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
+  }
+  h.win_k = 0; h.win_cur = 0; h.win_blk = 0; h.win_per_f = 0; h.win_nr = 1;
+  for (int i = 0; i < RSX_ADAM_WINDOW_MAX; ++i) h.win_uniq[i] = h.win_nuniq[i] = h.win_slot[i] = nullptr;
+  if (win_h != nullptr && win_h->k > 1) {
+    if (win_h->k > RSX_ADAM_WINDOW_MAX || win_h->cur < 0 || win_h->cur >= win_h->k || win_h->max_unique <= 0) return RSX_EINVAL;
+    for (int i = 0; i < win_h->k; ++i) {
+      if (!win_h->uniq_row[i] || !win_h->nuniq[i] || !win_h->slot[i]) return RSX_EINVAL;
+      h.win_uniq[i] = win_h->uniq_row[i]; h.win_nuniq[i] = win_h->nuniq[i]; h.win_slot[i] = win_h->slot[i];
+    }
+    if (win_h->uniq_row[win_h->cur] != uniq_row) return RSX_EINVAL;              // entry `cur` is this step's own sort
+    h.win_k = win_h->k; h.win_cur = win_h->cur;
+    // rows per lane group: the lazy pass applies up to 8 updates per row back to back -- one row per group (more workgroups,
+    // shorter chains) where the launch is latency-bound, four at large batches
+    h.win_nr = win_h->max_unique > 1024 ? 4 : 1;
+    const int rpw = h.win_nr * 256 / (D / 4);
+    h.win_per_f = (uint32_t)((win_h->max_unique + rpw - 1) / rpw);
+    // lists walked: the next step's, or -- the window's last step -- every earlier one
+    h.win_blk = (uint32_t)(win_h->cur == win_h->k - 1 ? win_h->k - 1 : 1) * (uint32_t)F * h.win_per_f;
+  }
+  return RSX_OK;
+}
+
+// The tail every launch that carries a HotAdam ends with: the last workgroup to arrive publishes this step's step size (read
+// by the lazy window pass of the window's later steps) and advances the beta powers / step counter.
+__device__ __forceinline__ void hot_adam_finish(const HotAdam& h, const float b1p, const float b2p) {
+  __syncthreads();
+  if (threadIdx.x == 0 && adam_arrive_last(h.state, h.total_blocks)) {
+    if (h.win_k > 1) h.state[8 + h.win_cur] = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    if (h.advance) {
+      h.state[0] = b1p * h.b1;
+      h.state[1] = b2p * h.b2;
+      reinterpret_cast<uint32_t*>(h.state)[3] += 1u;
+    }
+  }
+}

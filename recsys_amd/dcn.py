@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from . import layers as L
-from .deepfm import define_flags as _deepfm_flags
+from .deepfm import define_flags as _deepfm_flags, dp_unique_wanted
 from .deepfm import input_fn, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
 from .feature_columns import CriteoLayout, build_feature_columns
@@ -60,16 +60,23 @@ def build_variables(store, params, capacity):
         want_hip = False
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", dim, layers, capacity, store.device)
-        if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
+        want_ux = store.dp is not None and params.get("dp_send_block", True) and dp_unique_wanted(store, params) and \
+            EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world)
+        # (unique-list exchange: the window's sorts are the ranks' LOCAL ones -- dcn.py at 8 x 4 096 keeps its windows)
+        sort_cap = capacity // store.dp.world if want_ux else capacity
+        if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and sort_cap <= 16384:
             store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
             store.window_dp = True
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
+        store.dp_unique = False
         if store.dp is not None and params.get("dp_send_block", True):      # zero-copy gradient exchange (see deepfm.py)
-            if os.environ.get("RSX_DP_BUCKETS", "0") == "1" and store.adam_mode == "tf1_dense" and \
-                    bool(params.get("overlap_adam", True)):
-                arena.enable_buckets()          # small-vocabulary fields as dense gradient buckets (deepfm.py; needs the LDS sort)
-            store.dp.make_send_block(store.dense, capacity // store.dp.world, [dim], arena=arena)
+            if want_ux:         # round 5: the ranks exchange unique (row, sum) lists; send block [dense | G [capT, D]]
+                ux = arena.enable_unique_exchange(store.dp.world, capacity // store.dp.world)
+                store.dp.make_send_block(store.dense, ux.capT, [D])
+                store.dp_unique = True
+            else:               # RSX_DP_EXCHANGE=examples: [dense | dX of the local batch]
+                store.dp.make_send_block(store.dense, capacity // store.dp.world, [dim])
             store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter]
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
@@ -88,8 +95,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
     with torch.no_grad():
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
         wk, wpos, wfeat = store.window_of_step()
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1) else ids   # first: see deepfm._train_fused
-        zc = dp is not None and store.dp_block
+        ux = dp is not None and store.dp_unique
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1 and not ux) else ids   # first: see deepfm._train_fused
+        zc = dp is not None and store.dp_block and not ux
         # Round 4: the lookup and the cross layers' forward in ONE launch (rsx_gather_cross_fwd: the gather's lanes already hold the
         # example's row in the cross kernel's layout); RSX_GATHER_CROSS=0: two launches
         gcross = store.cross.fused_gather_ok(arena)
@@ -104,7 +112,19 @@ def _train_fused(store, arena, ids, labels, params, masks):
             raise _lib.RsxError("optimizer windows need the split TF-1 update (adam_mode=tf1_dense, overlap_adam)")
         arena.select(wpos)
         side, main = None, torch.cuda.current_stream()
-        if wk > 1:
+        if ux:
+            # ids phase of the unique-list exchange (deepfm._train_fused): local sorts -> key blocks -> one all-gather -> merge
+            if wpos == 0:
+                idl = [f["ids"] for f in wfeat] if wk > 1 else [ids]
+                arena.ux_merge(dp.all_gather_keys(arena.ux_sort_pack(idl), arena, idl), wk)
+            arena.select(wpos)
+            arena.last_B = arena.ux.max_unique
+            if wk > 1:
+                if wpos == 0:
+                    cold, _ = arena.adam_split_segments(window_k=wk)
+                    store.opt.window_sweep(cold)
+                hot = ()
+        elif wk > 1:
             if wpos == 0:
                 from .dist import window_global_ids
                 # RSX_WINDOW_SIDE=1 (single replica): the window's ids-only launches -- the dedup sort of its wk batches and the ONE
@@ -151,17 +171,21 @@ def _train_fused(store, arena, ids, labels, params, masks):
         riders = make_scatter_riders(store.tower.dw_jobs_pending, cross_job) if ride else None
         if side is not None:
             main.wait_stream(side)
+        if ux:      # the rank's own sorted segment-sum, written as its block of the send buffer (deepfm._train_fused)
+            (Gv,) = dp.send_views(arena.ux.capT)
+            arena.ux_segsum_local(dX.shape[0], None, dX, None, None, Gv, None, wpos)
 
     def train_op():
         with torch.no_grad():
             dXg, blocks, Bg, dense_segs = dX, None, dX.shape[0], None
-            bsegs = []
-            if zc:                  # ONE collective straight from the send block (dense arena + buckets + dX)
-                bv = dp.bucket_views()
-                if bv is not None:
-                    arena.bucket_scatter(ids, None, dX, None, None, bv[0], bv[1])
+            if ux:                  # ONE collective [dense | G], then the touched-row Adam off the merged lists
+                (G0,), blocks, dense_segs = dp.gather_send_block(arena.ux.capT, fold_dense=True)
+                arena.select(wpos)
+                arena.ux_merged_adam(G0, None, blocks[1], store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
+                                     window=(wk, wpos))
+                return
+            if zc:                  # ONE collective straight from the send block (dense arena + dX)
                 (dXg,), blocks, dense_segs = dp.gather_send_block(dX.shape[0], fold_dense=hot is not None)
-                bsegs = dp.bucket_segments()
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
@@ -169,10 +193,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 Bg = dX.shape[0] * dp.world
             if hot is not None:
                 arena.select(wpos)
-                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, (dense_segs or store.dense.adam_segments()) + bsegs,
+                arena.segsum_adam(Bg, None, dXg, None, None, store.opt, dense_segs or store.dense.adam_segments(),
                                   last_sweep, blocks=blocks, window=(wk, wpos), riders=riders)
             else:
-                assert not bsegs
                 arena.segsum(Bg, None, dXg, None, None, blocks=blocks)
                 store.apply_gradients()
 

@@ -74,23 +74,28 @@ def build_variables(store, params, capacity, with_dnn=True):
     if want_hip:
         store.tower = FusedTower(store.dense, "dnn", layout.F * D, layers, capacity, store.device)
         # optimizer windows (include/rsx.h rsx_adam_window): up to 8 consecutive steps share ONE sweep over the untouched rows
-        if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384:
-            store.window_k = _lib.default_adam_window(capacity)      # (capacity = the GLOBAL batch under data parallelism)
+        # (capacity = the GLOBAL batch under data parallelism; the window's sorts are the ranks' LOCAL ones under the unique-list
+        # exchange, so only the local batch has to fit the one-launch multi-sort)
+        sort_cap = capacity // store.dp.world if (store.dp is not None and dp_unique_wanted(store, params)) else capacity
+        if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and sort_cap <= 16384:
+            store.window_k = _lib.default_adam_window(capacity)
             store.window_dp = True
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
+        store.dp_unique = False
         if store.dp is not None and params.get("dp_send_block", True):
-            # zero-copy gradient exchange: the dense gradient arena and the tower / gather outputs of the per-example block
-            # live inside ONE persistent send buffer (no pack launch before the all-gather)
-            # round 4, RSX_DP_BUCKETS=1 (opt-in): the small-vocabulary fields leave the global sort + scatter and travel as dense
-            # per-row gradient buckets that ride the dense gradients' collective (EmbeddingArena.enable_buckets).  Measured on one
-            # GPU with N emulated replicas (profiles/r04_*emulate*): it does NOT shorten the step -- the global scatter's time is
-            # set by the LARGE fields' long segments and the window pass (13.8 + 35.8 us at N = 8 with or without the 25 small
-            # fields), and the bucket launch adds its own 16 us -- so the default stays the per-example block.
-            if os.environ.get("RSX_DP_BUCKETS", "0") == "1" and store.adam_mode == "tf1_dense" and \
-                    bool(params.get("overlap_adam", True)):
-                arena.enable_buckets()
-            store.dp.make_send_block(store.dense, capacity // store.dp.world, [layout.F * D, D, 1, 1], arena=arena)
+            # zero-copy gradient exchange: the dense gradient arena and the rank's block of the sparse exchange live inside ONE
+            # persistent send buffer (no pack launch before the all-gather).
+            # Round 5 (default; RSX_DP_EXCHANGE=examples keeps the round-1..4 exchange of the pre-dedup per-example block): every
+            # rank de-duplicates and sums ITS batch, the ranks exchange unique (row, sum) lists (EmbeddingArena.enable_unique_exchange,
+            # csrc/uniq_exchange.hip) -- the send block is [dense | G [capT, D] | gw1 [capT]]
+            b_local = capacity // store.dp.world
+            if dp_unique_wanted(store, params) and EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world):
+                ux = arena.enable_unique_exchange(store.dp.world, b_local)
+                store.dp.make_send_block(store.dense, ux.capT, [D, 1])
+                store.dp_unique = True
+            else:
+                store.dp.make_send_block(store.dense, b_local, [layout.F * D, D, 1, 1])
             store.dp_block = True
         # share of the untouched-row Adam sweep carried by [fwd_0.., head, bwd_{L-1}..bwd_0, scatter] (measured: the
         # latency-bound scatter + touched-row Adam launch hides a quarter of the sweep; r02 grid over the shares with the faster
@@ -98,6 +103,13 @@ def build_variables(store, params, capacity, with_dnn=True):
         env = os.environ.get("RSX_SWEEP_WEIGHTS")
         store.sweep_weights = params.get("sweep_weights") or ([float(x) for x in env.split(",")] if env else
                                                               [0.0] * len(layers) + [1.0] + [3.5] * len(layers) + [2.5])
+
+
+def dp_unique_wanted(store, params):
+    """The data-parallel sparse exchange of this run: unique-row lists (round 5, default) need the split TF-1 update (the
+    optimizer launch that owns the touched rows); RSX_DP_EXCHANGE=examples: the pre-dedup per-example block of rounds 1-4."""
+    return os.environ.get("RSX_DP_EXCHANGE", "unique") == "unique" and store.adam_mode == "tf1_dense" and \
+        bool(params.get("overlap_adam", True)) and params.get("dp_send_block", True)
 
 
 def model_fn(features, labels, mode, params):
@@ -165,12 +177,26 @@ def _train_fused(store, arena, ids, labels, params, masks):
         wk, wpos, wfeat = store.window_of_step()
         if wk > 1 and not overlap:
             raise _lib.RsxError("optimizer windows need the split TF-1 update (adam_mode=tf1_dense, overlap_adam)")
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1) else ids
-        zc = dp is not None and store.dp_block       # outputs of the per-example gradient block written in place
+        ux = dp is not None and store.dp_unique      # the exchange of per-rank unique-row lists (round 5)
+        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1 and not ux) else ids
+        zc = dp is not None and store.dp_block and not ux     # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         job = None
         side, main = None, torch.cuda.current_stream()
-        if wk > 1:
+        if ux:
+            # ids phase of the unique-list exchange: the rank's OWN dedup sorts (the window's wk batches in one launch) -> key
+            # blocks -> ONE all-gather -> the global lists / slot maps / src of all wk positions (rsx_uniq_merge): 3 launches
+            # and a collective per WINDOW, no global sort
+            if wpos == 0:
+                keys_g = dp.all_gather_keys(arena.ux_sort_pack([f["ids"] for f in wfeat] if wk > 1 else [ids]), arena,
+                                            [f["ids"] for f in wfeat] if wk > 1 else [ids])
+                arena.ux_merge(keys_g, wk)
+            arena.select(wpos)
+            arena.last_B = arena.ux.max_unique
+            if wk > 1 and wpos == 0 and overlap:
+                cold, hot = arena.adam_split_segments(window_k=wk)
+                store.opt.window_sweep(cold[::-1])
+        elif wk > 1:
             arena.select(wpos)
             if wpos == 0:
                 from .dist import window_global_ids
@@ -204,7 +230,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             E, S, y1p, y2 = arena.gather(ids, fm=True, first_order=True, S_out=Sv, sort_job=job if in_gather else None)
         if in_gather:
             job = None
-        elif job is None and wk == 1:
+        elif job is None and wk == 1 and not ux:
             arena.field_sort(ids_sort)
         sweeps, hot, last_sweep = None, None, None
         # RSX_WINDOW_RIDE=1 (round 4, opt-in; measured and NOT the default): a FULL window's sweep (8 steps) rides in the steps' head
@@ -213,7 +239,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # but the sweep is bandwidth-bound, not idle-CU-bound: a slice moves 43 MB (8.6 us at 5 TB/s) and the head launch grew
         # from 7.1 to 18.6 us -- more than the 8.8 us per step the stand-alone launch costs (0.0625 vs 0.0600 ms per step,
         # profiles/r04_e_window_ride_ab.txt).
-        ride = overlap and wk == _lib.ADAM_WINDOW_MAX and os.environ.get("RSX_WINDOW_RIDE", "0") == "1"
+        ride = overlap and not ux and wk == _lib.ADAM_WINDOW_MAX and os.environ.get("RSX_WINDOW_RIDE", "0") == "1"
         if ride:
             if wpos == 0:
                 cold, hot = arena.adam_split_segments(window_k=wk)
@@ -221,6 +247,8 @@ def _train_fused(store, arena, ids, labels, params, masks):
             hot = ()
             sweeps = [None] * (2 * len(store.tower.widths) + 1)
             sweeps[len(store.tower.widths)] = store._win_slices[wpos]
+        elif ux and overlap and wk > 1:
+            hot = ()            # (the window's sweep ran with the ids phase above)
         elif overlap and wk > 1 and wpos == 0:
             # ONE sweep for the whole window, as a launch of its own: k updates per row in registers make the slices
             # ALU-heavy, and as riders they inherit their carrier's occupancy (measured, DeepFM bs 256: carried 164 us per
@@ -260,20 +288,30 @@ def _train_fused(store, arena, ids, labels, params, masks):
             layer_done=layer_done, gather=(arena, ids, S, y1p, y2) if fuse_gather else None)
         if side is not None:
             main.wait_stream(side)
+        if ux:
+            # the rank's own sorted segment-sum (what a single replica's scatter does), written as its block of the send buffer
+            Gv, gw1v = dp.send_views(arena.ux.capT)
+            arena.ux_segsum_local(dX.shape[0], S, dX, gy1, gy2, Gv, gw1v, wpos)
 
     def train_op():
         with torch.no_grad():
             Sg, dXg, gy1g, gy2g, blocks, Bg, dense_segs = S, dX, gy1, gy2, None, dX.shape[0], None
-            bsegs = []
-            if zc:                  # ONE collective straight from the send block (dense arena + buckets + per-example block)
+            if ux:
+                # ONE collective [dense | G | gw1], then the touched-row Adam off the merged lists: N looked-up rows per global
+                # unique row, summed in rank order
                 if layer_done is not None:
                     dp.wait_all(pending)
-                bv = dp.bucket_views()
-                if bv is not None:  # the bucket fields' local gradients, summed per row without a sort (rsx_bucket_scatter)
-                    arena.bucket_scatter(ids, S, dX, gy1, gy2, bv[0], bv[1])
+                (G0, gw10), blocks, dense_segs = dp.gather_send_block(arena.ux.capT, fold_dense=True,
+                                                                      dense_done=layer_done is not None)
+                arena.select(wpos)
+                arena.ux_merged_adam(G0, gw10, blocks[1], store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
+                                     window=(wk, wpos))
+                return
+            if zc:                  # ONE collective straight from the send block (dense arena + per-example block)
+                if layer_done is not None:
+                    dp.wait_all(pending)
                 (dXg, Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(
                     dX.shape[0], fold_dense=hot is not None, dense_done=layer_done is not None)
-                bsegs = dp.bucket_segments()
                 Bg = dX.shape[0] * dp.world
             elif dp is not None:    # ONE collective: per-example gradient block + dense arena (summed in rank order);
                 # the scatter then reads every rank's block in place from the gathered buffer
@@ -281,10 +319,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 Bg = dX.shape[0] * dp.world
             if hot is not None:     # scatter + touched-row Adam + dense Adam in ONE launch; advances the beta powers
                 arena.select(wpos)
-                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, (dense_segs or store.dense.adam_segments()) + bsegs,
+                arena.segsum_adam(Bg, Sg, dXg, gy1g, gy2g, store.opt, dense_segs or store.dense.adam_segments(),
                                   last_sweep, blocks=blocks, window=(wk, wpos))
             else:
-                assert not bsegs
                 arena.segsum(Bg, Sg, dXg, gy1g, gy2g, blocks=blocks)
                 store.apply_gradients()
 

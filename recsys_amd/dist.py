@@ -222,6 +222,12 @@ class DataParallel:
             graph_break(lambda: dist.all_gather_into_tensor(out, x, group=self.group))
         return out
 
+    def all_gather_keys(self, keys, arena=None, ids_list=None):
+        """The ids-phase collective of the unique-list exchange: keys [1, k * KS] int32 (EmbeddingArena.ux_sort_pack: the rank's
+        packed unique-row lists of the k batches of an optimizer window) -> [N, k * KS].  (arena / ids_list: what the key block
+        was made from -- EmulatedDataParallel derives its peers' blocks from other batches with them.)"""
+        return self.all_gather_rows(keys)
+
     # -- sparse gradient block ----------------------------------------------------------------
     @staticmethod
     def pack_widths(F, D, has_fm, has_w1):
@@ -511,6 +517,14 @@ class LoopbackDataParallel(DataParallel):
         self.rank, self._ci, self._phase = r, 0, "model"
         self.shadow = r < self.world - 1
         store.opt.shadow = self.shadow
+        # rank-LOCAL state of the unique-list exchange (the rank's own sort workspaces and key blocks live across the steps of an
+        # optimizer window): one set per played rank
+        for a in store.embeddings.values():
+            ux = getattr(a, "ux", None)
+            if ux is not None:
+                if not hasattr(ux, "rank_locals"):
+                    ux.rank_locals = [(ux.local, ux.keys)] + [ux.new_local() for _ in range(self.world - 1)]
+                ux.local, ux.keys = ux.rank_locals[r]
 
     def leave_rank(self, store):
         """After model_fn of a shadow rank: keep its send block (dense gradient arena | per-unit gradient block)."""

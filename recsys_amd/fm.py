@@ -12,9 +12,9 @@ import torch
 from . import _lib
 from . import layers as L
 from .deepfm import build_variables as _build
-from .deepfm import define_flags, input_fn, make_params, run_main  # noqa: F401
+from .deepfm import define_flags, dp_unique_wanted, input_fn, make_params, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
-from .ops import _ptr, _stream, gather_fm
+from .ops import EmbeddingArena, _ptr, _stream, gather_fm
 
 
 def model_fn(features, labels, mode, params):
@@ -24,19 +24,26 @@ def model_fn(features, labels, mode, params):
     if not store.built:
         cap = max(int(params.get("max_batch_size", 0)), ids.shape[0])
         _build(store, params, capacity=cap, with_dnn=False)
+        a0 = store.embeddings["input_layer"]
+        want_ux = store.dp is not None and params.get("fused", True) and dp_unique_wanted(store, params) and \
+            EmbeddingArena.unique_exchange_ok(a0.row_off_np, store.dp.world)
         if store.adam_mode == "tf1_dense" and params.get("fused", True):
             gcap = cap * (store.dp.world if store.dp is not None else 1)
-            if gcap <= 16384:
+            if (cap if want_ux else gcap) <= 16384:      # (unique-list exchange: the window's sorts are the ranks' local ones)
                 store.window_k = _lib.default_adam_window(gcap)     # optimizer windows (include/rsx.h rsx_adam_window)
                 store.window_dp = True
         store.dp_block = False
+        store.dp_unique = False
         if store.dp is not None and params.get("fused", True):
-            # data-parallel: [S | gy2 | gy1] of the local batch + the dense gradient arena in one persistent send block
-            import os
-            a0 = store.embeddings["input_layer"]
-            if os.environ.get("RSX_DP_BUCKETS", "0") == "1":        # small-vocabulary fields as dense gradient buckets (deepfm.py)
-                a0.enable_buckets()
-            store.dp.make_send_block(store.dense, cap, [a0.D, 1, 1], arena=a0)
+            # data-parallel: the dense gradient arena + the rank's block of the sparse exchange in one persistent send block --
+            # [G [capT, D] | gw1 [capT]] (unique-row lists, round 5: deepfm.py) or, RSX_DP_EXCHANGE=examples, [S | gy2 | gy1] of
+            # the local batch
+            if want_ux:
+                ux = a0.enable_unique_exchange(store.dp.world, cap)
+                store.dp.make_send_block(store.dense, ux.capT, [a0.D, 1])
+                store.dp_unique = True
+            else:
+                store.dp.make_send_block(store.dense, cap, [a0.D, 1, 1])
             store.dp_block = True
             store.graph_safe_dp = True       # the fused step issues its collectives outside autograd
     arena, P = store.embeddings["input_layer"], store.dense
@@ -90,7 +97,22 @@ def _train_fused(store, arena, ids, labels):
         wk, wpos, wfeat = store.window_of_step()
         arena.select(wpos)
         sweep = sweep2 = None
-        if wk > 1:
+        ux = dp is not None and store.dp_unique
+        if ux:
+            # ids phase of the unique-list exchange (deepfm._train_fused): local sorts -> key blocks -> one all-gather -> merge
+            if wpos == 0:
+                idl = [f["ids"] for f in wfeat] if wk > 1 else [ids]
+                arena.ux_merge(dp.all_gather_keys(arena.ux_sort_pack(idl), arena, idl), wk)
+            arena.select(wpos)
+            arena.last_B = arena.ux.max_unique
+            if wk > 1:
+                if wpos == 0:
+                    cold, _ = arena.adam_split_segments(window_k=wk)
+                    store.opt.window_sweep(cold[::-1])
+            else:
+                cold, hot = arena.adam_split_segments()
+                sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
+        elif wk > 1:
             if wpos == 0:
                 from .dist import window_global_ids
                 arena.sort_window(window_global_ids(dp, wfeat))    # data-parallel: one all-gather for all wk batches' ids
@@ -103,9 +125,9 @@ def _train_fused(store, arena, ids, labels):
             # 70 % of the untouched-row sweep rides in the head launch, 30 % (table blocks only: the first-order vector goes
             # first) in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)
             sweep, sweep2 = store.opt.cold_slices(cold[::-1], [0.7, 0.3])
-        Sv, gy2v, gy1v = dp.send_views(B) if dp is not None else (None,) * 3
+        Sv, gy2v, gy1v = dp.send_views(B) if (dp is not None and not ux) else (None,) * 3
         prob = torch.empty(B, device=dev)
-        gy1, gy2 = (gy1v, gy2v) if dp is not None else (torch.empty(B, device=dev) for _ in range(2))
+        gy1, gy2 = (gy1v, gy2v) if (dp is not None and not ux) else (torch.empty(B, device=dev) for _ in range(2))
         oW, oG = P["out.W"].detach().view(-1), P["out.W"].grad.view(-1)
         world = dp.world if dp is not None else 1
         lab = labels.reshape(-1).to(torch.float32)
@@ -139,16 +161,21 @@ def _train_fused(store, arena, ids, labels):
                 stride if terms is not None else 0, P.n, P.offsets["b1"], P.offsets["out.W"], P.offsets["out.b"],
                 1.0 / (B * world), B, None if sweep is None else C.byref(sweep), _stream()), "rsx_fm_head_terms")
 
+        if ux:      # the rank's own sorted segment-sum, written as its block of the send buffer (deepfm._train_fused)
+            Gv, gw1v = dp.send_views(arena.ux.capT)
+            arena.ux_segsum_local(B, S, None, gy1, gy2, Gv, gw1v, wpos)
+
     def train_op():
         with torch.no_grad():
-            if dp is not None:
-                bv = dp.bucket_views()
-                if bv is not None:
-                    arena.bucket_scatter(ids, S, None, gy1, gy2, bv[0], bv[1])
+            if ux:
+                (G0, gw10), blocks, dense_segs = dp.gather_send_block(arena.ux.capT, fold_dense=True)
+                arena.select(wpos)
+                arena.ux_merged_adam(G0, gw10, blocks[1], store.opt, dense_segs or store.dense.adam_segments(), sweep2,
+                                     window=(wk, wpos))
+            elif dp is not None:
                 (Sg, gy2g, gy1g), blocks, dense_segs = dp.gather_send_block(B, fold_dense=True)
                 arena.select(wpos)
-                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt,
-                                  (dense_segs or store.dense.adam_segments()) + dp.bucket_segments(), sweep2,
+                arena.segsum_adam(B * world, Sg, None, gy1g, gy2g, store.opt, dense_segs or store.dense.adam_segments(), sweep2,
                                   blocks=blocks, window=(wk, wpos))
             else:
                 arena.select(wpos)

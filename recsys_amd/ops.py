@@ -74,7 +74,7 @@ class EmbeddingArena:
     tf.layers.dense(linear_net, 1) (fm/fm.py:121)."""
 
     def __init__(self, row_off, D, capacity, device="cuda", with_w1=False, w1_field_mask=None,
-                 tables=None, w1=None):
+                 tables=None, w1=None, workspace_only=False):
         dev = _require_cuda(device)
         self.row_off_np = np.asarray(row_off, np.int64)
         self.F = len(self.row_off_np) - 1
@@ -86,15 +86,17 @@ class EmbeddingArena:
         self.tables = torch.empty(self.R, D, device=dev) if tables is None else \
             torch.as_tensor(tables, dtype=torch.float32).to(dev).contiguous()
         assert self.tables.shape == (self.R, D)
-        self.m_t = torch.zeros_like(self.tables)
-        self.v_t = torch.zeros_like(self.tables)
+        # workspace_only: the sort / segment-sum workspace of ANOTHER arena's variables (the rank-local half of the data-parallel
+        # unique-list exchange, enable_unique_exchange): `tables` / `w1` alias the owner's, there are no Adam slots
+        self.m_t = None if workspace_only else torch.zeros_like(self.tables)
+        self.v_t = None if workspace_only else torch.zeros_like(self.tables)
         self.with_w1 = with_w1
         self.w1_mask = (1 << self.F) - 1 if w1_field_mask is None else int(w1_field_mask)
         if with_w1:
             self.w1 = torch.empty(self.R, device=dev) if w1 is None else \
                 torch.as_tensor(w1, dtype=torch.float32).to(dev).contiguous().reshape(-1)
-            self.m_w = torch.zeros_like(self.w1)
-            self.v_w = torch.zeros_like(self.w1)
+            self.m_w = None if workspace_only else torch.zeros_like(self.w1)
+            self.v_w = None if workspace_only else torch.zeros_like(self.w1)
         else:
             self.w1 = None
         F, st = self.F, self.stride
@@ -241,6 +243,132 @@ class EmbeddingArena:
                              uniq_row=self._browmap, nuniq=self._bcount, B=nb, stride=nb, g_replicas=replicas,
                              g_replica_stride=stride))
         return segs
+
+    # -- data parallel: exchange of per-rank unique-row lists (csrc/uniq_exchange.hip) ----------------------
+    @staticmethod
+    def unique_exchange_ok(row_off, world):
+        """rsx_uniq_merge keeps a presence bitmap + prefix counts of a field's rows in LDS (rows / 4 bytes of 160 KB) and the
+        optimizer launch unrolls over at most RSX_UNIQ_MAX_RANKS ranks."""
+        rows = np.diff(np.asarray(row_off, np.int64))
+        return world <= _lib.UNIQ_MAX_RANKS and int(rows.max()) <= 640000 and len(rows) <= 64
+
+    def enable_unique_exchange(self, world, b_local, sort_capacity=None):
+        """Data parallel, round 5 (include/rsx.h "exchange of per-rank UNIQUE-ROW lists"): this arena (capacity = the GLOBAL
+        batch) keeps the global unique-row lists, slot maps and optimizer state; `self.ux.local` -- a workspace-only arena of
+        capacity b_local over the SAME variables -- runs the rank's own dedup sort and segment-sum.  goff: field f's rows of a
+        rank's block start at goff[f]; cap_f = min(b_local, rows_f) bounds the unique rows one rank can have in field f."""
+        from types import SimpleNamespace
+        assert self.unique_exchange_ok(self.row_off_np, world) and b_local * world <= self.stride
+        dev = self.tables.device
+        rows = np.diff(self.row_off_np)
+        caps = np.minimum(rows, b_local)
+        goff = np.concatenate([[0], np.cumsum(caps)]).astype(np.int32)
+        capT = int(goff[-1])
+        i32 = dict(dtype=torch.int32, device=dev)
+        KS = (self.F + capT + 3) & ~3
+
+        def new_local():
+            loc = EmbeddingArena(self.row_off_np, self.D, int(sort_capacity or b_local), dev, with_w1=self.with_w1,
+                                 w1_field_mask=self.w1_mask, tables=self.tables, w1=self.w1, workspace_only=True)
+            assert loc.tables.data_ptr() == self.tables.data_ptr()
+            return loc, torch.zeros(_lib.ADAM_WINDOW_MAX, KS, **i32)
+
+        local, keys = new_local()
+        gpw = 256 // self.D
+        gmax = np.minimum(rows, b_local * world)
+        self.ux = SimpleNamespace(
+            world=int(world), b=int(b_local), goff_np=goff, goff=torch.tensor(goff, **i32), capT=capT, KS=KS, local=local,
+            keys=keys, src=[], new_local=new_local,
+            max_units=int(((gmax + gpw - 1) // gpw).sum()), max_unique=int(gmax.max()), max_entries=int(caps.max()) * int(world))
+        self.ux_src_bufs(len(self.sortbufs))
+        return self.ux
+
+    def ux_src_bufs(self, k):
+        """src [N][F, stride] of window positions 0 .. k-1 (allocated outside graph capture, like the sort workspaces)."""
+        ux = self.ux
+        while len(ux.src) < k:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.RsxError("EmbeddingArena.ux_src_bufs(%d): allocate before capture" % k)
+            ux.src.append(torch.full((ux.world, self.F * self.stride), -1, dtype=torch.int32, device=self.tables.device))
+        return ux.src[:k]
+
+    def ux_sort_pack(self, ids_list):
+        """The rank's OWN dedup sorts of the k batches of an optimizer window (k = 1: a single step) + their key blocks
+        [nuniq | unique rows packed at goff] -> keys [1, k * KS] int32, the input of the ids-phase all-gather."""
+        ux, k = self.ux, len(ids_list)
+        loc = ux.local
+        if k == 1 and ids_list[0].shape[0] > loc.LDS_SORT_MAX_B:
+            loc.select(0)
+            loc.field_sort(ids_list[0])
+        else:
+            loc.sort_window(ids_list)
+        return self.ux_pack(k)
+
+    def ux_pack(self, k):
+        ux, loc = self.ux, self.ux.local
+        jobs = (_lib.UniqPackJob * k)()
+        for i, b in enumerate(loc.window_bufs(k)):
+            jobs[i].uniq_row, jobs[i].nuniq, jobs[i].keys = b["uniq_row"].data_ptr(), b["nuniq"].data_ptr(), ux.keys[i].data_ptr()
+        check(lib().rsx_uniq_pack(jobs, k, _ptr(ux.goff), self.F, loc.stride, _stream()), "rsx_uniq_pack")
+        return ux.keys[:k].view(1, k * ux.KS)
+
+    def ux_merge(self, keys_g, k):
+        """keys_g [N, k * KS] (the all-gathered key blocks) -> window positions 0 .. k-1 of THIS arena's sort workspaces:
+        global unique rows, slot maps, src (rsx_uniq_merge).  Leaves what rsx_field_sort would leave for the global batch,
+        minus the per-example permutation nobody needs any more."""
+        ux = self.ux
+        assert keys_g.dtype == torch.int32 and keys_g.is_contiguous() and tuple(keys_g.shape) == (ux.world, k * ux.KS)
+        jobs = (_lib.UniqMergeJob * k)()
+        srcs = self.ux_src_bufs(k)
+        for i, b in enumerate(self.window_bufs(k)):
+            jobs[i].uniq_row, jobs[i].nuniq, jobs[i].slot = b["uniq_row"].data_ptr(), b["nuniq"].data_ptr(), b["slot"].data_ptr()
+            jobs[i].src = srcs[i].data_ptr()
+        check(lib().rsx_uniq_merge(_ptr(keys_g), k * ux.KS, ux.KS, jobs, k, _ptr(ux.goff), _ptr(self.row_off), self.max_rows,
+                                   ux.max_entries, self.F, ux.world, self.stride, _stream()), "rsx_uniq_merge")
+        self.last_B = ux.max_unique
+
+    def ux_segsum_local(self, B, S, dX, gy1, gy2, G_out, gw1_out, pos=0, null_row=-1):
+        """The rank's own sorted segment-sum (window position pos of the LOCAL workspace) written as its block of the
+        exchange: G_out [capT, D], gw1_out [capT] (views of the send block)."""
+        loc = self.ux.local
+        loc.select(pos)
+        assert G_out.is_contiguous() and G_out.shape[0] >= self.ux.capT
+        part = loc._stage_a(B, S, dX, gy1, gy2)
+        w = gy1 is not None and gw1_out is not None
+        check(lib().rsx_segsum_bwd_packed(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1) if w else None, _ptr(gy2),
+                                          _ptr(loc.perm), _ptr(loc.seg_off), _ptr(loc.uniq_row), _ptr(loc.nuniq), _ptr(G_out),
+                                          _ptr(gw1_out) if w else None, self.w1_mask, B, self.F, self.D, loc.stride, null_row,
+                                          part, _ptr(self.ux.goff), _stream()), "rsx_segsum_bwd_packed")
+
+    def ux_merged_adam(self, G0, gw10, rank_stride, opt, extra_segments, sweep=None, advance=True, second=None, window=None,
+                       w1_ext=None):
+        """The optimizer launch of the exchange (rsx_merged_adam_rows): G0 / gw10 = rank 0's blocks inside the gathered buffer,
+        rank r's rank_stride floats further.  second = (arena2, G2_0): a table set sharing this arena's lists.
+        window = (k, cur) as segsum_adam."""
+        ux = self.ux
+        arr, n = opt._seg_array(extra_segments)
+        lr, b1, b2, eps = opt.hp
+        win = None
+        if window is not None and window[0] > 1:
+            assert self.cur_buf == window[1]
+            win = self.window(*window)
+        sec = None
+        if second is not None:
+            a2, G20 = second
+            sec_obj = _lib.TableSet(a2.tables.data_ptr(), a2.m_t.data_ptr(), a2.v_t.data_ptr(), G20.data_ptr(), None)
+            sec = C.byref(sec_obj)
+        w = self.with_w1 and gw10 is not None
+        w1p, mwp, vwp, w1s, w1sp = (_ptr(self.w1), _ptr(self.m_w), _ptr(self.v_w), 1, 0) if w else (None, None, None, 1, 0)
+        if w1_ext is not None:
+            w1p, mwp, vwp, w1s, w1sp = _ptr(w1_ext[0]), _ptr(w1_ext[1]), _ptr(w1_ext[2]), int(w1_ext[3]), int(w1_ext[4])
+            assert gw10 is not None
+        check(lib().rsx_merged_adam_rows(_ptr(self.tables), _ptr(self.m_t), _ptr(self.v_t), w1p, mwp, vwp, _ptr(G0),
+                                         _ptr(gw10) if w1p is not None else None, int(rank_stride), ux.world,
+                                         _ptr(ux.src[self.cur_buf]), _ptr(ux.goff), _ptr(self.uniq_row), _ptr(self.nuniq),
+                                         self.w1_mask, ux.max_units, self.F, self.D, self.stride, arr, n,
+                                         None if sweep is None else C.byref(sweep), sec, None if win is None else C.byref(win),
+                                         _ptr(opt.state), 1 if advance else 0, lr, b1, b2, eps, w1s, w1sp, _stream()),
+              "rsx_merged_adam_rows")
 
     # -- kernels ---------------------------------------------------------------------------
     def field_sort_t(self, ids_t, B):

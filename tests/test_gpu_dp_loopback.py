@@ -56,7 +56,8 @@ def _param_err(est, P64):
 
 @pytest.mark.parametrize("exchange", ["examples", "unique"])
 @pytest.mark.parametrize("kind,world,B,dropout", [("deepfm", 2, 48, 0.5), ("deepfm", 3, 40, 0.0), ("dcn", 2, 56, 0.5),
-                                                  ("fm", 3, 64, 0.0), ("deepfm", 4, 300, 0.0), ("dcn", 4, 600, 0.0)])
+                                                  ("fm", 3, 64, 0.0), ("deepfm", 4, 300, 0.0), ("dcn", 4, 600, 0.0),
+                                                  ("deepfm", 2, 1100, 0.0), ("dcn", 2, 2200, 0.0)])
 def test_loopback_dp_with_distinct_batches_matches_the_oracle(kind, world, B, dropout, exchange, monkeypatch):
     import torch
     from oracle import models, nn
