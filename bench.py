@@ -148,7 +148,7 @@ def sweep_bytes(est, wk):
     element; a window pass adds the wk slot maps (4 B per row each)."""
     from recsys_amd.ops import EmbeddingArena
     store = est.store
-    segs = store.adam_segments(timing_only=True)
+    segs = store.adam_segments()
     n_sparse = sum(int(sg["n"]) * int(sg.get("d", 1) or 1) for sg in segs if sg["kind"] in (1, 2))
     alg = 24 * n_sparse + 32 * store.dense.n
     arenas = [x for x in store.embeddings.values() if isinstance(x, EmbeddingArena)]
@@ -302,15 +302,22 @@ def other_configs(a, rank, dev):
 
 
 def dp_exchange_info(store, B):
-    """What one rank contributes to the step's gradient collective (data parallel / emulated): bytes, and how many fields /
-    rows travel as dense per-row buckets instead of through the per-example block (recsys_amd/dist.py)."""
+    """What one rank contributes to the step's collectives (data parallel / emulated), bytes per step: the gradient collective
+    [dense | the rank's block of the sparse exchange] + the ids-phase collective (the packed unique-row lists of the unique-list
+    exchange, or the batch ids of the per-example one), and which exchange runs (recsys_amd/dist.py)."""
     d = getattr(store, "dp", None)
     if d is None or not hasattr(d, "_send"):
         return {}
-    a = getattr(d, "_bucket_arena", None)
-    return {"dp_send_bytes_per_rank_per_step": int(d.send_bytes()),
-            "dp_bucket_fields": len(a.bucket_fields) if a is not None else 0,
-            "dp_bucket_rows": int(a.bucket_rows) if a is not None else 0}
+    ux = bool(getattr(store, "dp_unique", False))
+    ids_bytes = 0
+    for ar in store.embeddings.values():
+        if getattr(ar, "ux", None) is not None and getattr(ar, "_sort_owner", None) is None:
+            ids_bytes += 4 * ar.ux.KS
+        elif not ux and hasattr(ar, "F") and getattr(ar, "_sort_owner", None) is None:
+            ids_bytes += 4 * B * ar.F
+    return {"dp_exchange": "unique_rows" if ux else "examples",
+            "dp_send_bytes_per_rank_per_step": int(d.send_bytes()) + ids_bytes,
+            "dp_gradient_bytes": int(d.send_bytes()), "dp_ids_phase_bytes": ids_bytes}
 
 
 def launches_per_step(est, feats, wk):
@@ -391,7 +398,7 @@ def main():
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
     store = est.store
-    segs = store.adam_segments(timing_only=True)     # (with gradient buckets on: over a slot map that marks no row)
+    segs = store.adam_segments()
     n_dense = store.dense.n
     # algorithmic bytes of the TF-faithful sweep: 24 B per table / first-order element (var, m, v read + written),
     # 32 B per dense element (+ gradient read and zeroed)

@@ -142,12 +142,27 @@ class DinFused:
         self.vals = torch.zeros(N, 2 * K, **f32)              # the scatter's value block: entry e -> [item grad | category grad]
         self.gbias = torch.zeros(N, **f32)                    # d loss / d i_item[i_id] of the target entries, 0 for history entries
         self.dp = store.dp
+        self.ux = None
+        # padding rows of the two-field arena: the last row of every field (include/rsx.h RSX_NULL_LAST_ROW)
+        arena.null_last = True
+        arena._bind_partials()
         if self.dp is not None:
-            # data parallel: value block and bias gradients live in the persistent send block behind the dense gradient arena
-            # ([dense | vals (2K per entry) | gbias (1 per entry)]): ONE all-gather straight from it, no pack copy; the global
-            # scatter reads every rank's block in place (dist.DataParallel.gather_send_block)
-            self.dp.make_send_block(store.dense, N, [2 * K, 1])
-            self.vals = self.gbias = None
+            from .deepfm import dp_unique_wanted
+            if dp_unique_wanted(store, {}) and EmbeddingArena.unique_exchange_ok(arena.row_off_np, self.dp.world):
+                # round 5: every rank de-duplicates and sums ITS entries (the single replica's sort + scatter), the ranks exchange
+                # unique (row, sum) lists: send block [dense | G [capT, K] | bias sums [capT]], capT = min(entries, item rows + 1)
+                # + min(entries, category rows + 1) instead of 2K + 1 floats per ENTRY (8.4 MB instead of 27 MB per rank and step
+                # at batch 1 024 x 100)
+                self.ux = arena.enable_unique_exchange(self.dp.world, N)
+                self.keys_t = torch.zeros(2, self.ux.local.stride, **i32)
+                self.dp.make_send_block(store.dense, self.ux.capT, [K, 1])
+                store.dp_unique = True
+            else:
+                # RSX_DP_EXCHANGE=examples: value block and bias gradients live in the persistent send block behind the dense
+                # gradient arena ([dense | vals (2K per entry) | gbias (1 per entry)]): ONE all-gather straight from it, no pack
+                # copy; the global scatter reads every rank's block in place (dist.DataParallel.gather_send_block)
+                self.dp.make_send_block(store.dense, N, [2 * K, 1])
+                self.vals = self.gbias = None
         n1, n2 = ATTENTION_LAYERS
         self.a1 = [torch.empty(B * P, n1, **f32) for _ in range(2)]
         self.a2 = [torch.empty(B * P, n2, **f32) for _ in range(2)]
@@ -155,9 +170,6 @@ class DinFused:
         self.dw = [torch.empty(B, P, **f32) for _ in range(2)]
         self.rows = [torch.empty(B * P + 2 + (B * P + 1023) // 1024, **i32) for _ in range(2)]
         self.ws = [torch.empty(int(_lib.lib().rsx_din_attn_bwd_workspace_floats(B, P, K, n1, n2)), **f32) for _ in range(2)]
-        # padding rows of the two-field arena: the last row of every field (include/rsx.h RSX_NULL_LAST_ROW)
-        arena.null_last = True
-        arena._bind_partials()
 
     def _side_stream(self):
         if os.environ.get("RSX_DIN_SIDE_SORT", "1") != "1":
@@ -205,8 +217,10 @@ class DinFused:
             keys2 = self.keys2[:N]
             cnts = [self.rows[t][B * P:] for t in range(2)]
             dp = self.dp
+            ux = self.ux is not None
             world = dp.world if dp is not None else 1
-            big = N > a.LDS_SORT_MAX_B and dp is None   # the large sort takes field-major keys as they are (single replica)
+            # the large sort takes field-major keys as they are (single replica, and the rank's OWN sort of the unique-list exchange)
+            big = N > a.LDS_SORT_MAX_B and (dp is None or ux)
             lab64 = labels.reshape(-1) if labels.dtype == torch.int64 and labels.is_contiguous() else None
             # Round 4: the six lookups ride in the two prepare launches as extra workgroups (they depend on the ids only, like the
             # prepare kernels: the 11 us bandwidth-bound gather runs beside two latency-bound launches); RSX_DIN_GATHER_RIDE=0: its
@@ -214,7 +228,7 @@ class DinFused:
             gride = os.environ.get("RSX_DIN_GATHER_RIDE", "1") == "1"
             gjobs = self._gather_jobs(B, i_id, i_cate, hist) if gride else None
             _lib.check(L.rsx_din_prepare2_gather(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item,
-                                                 self.n_cate, _ptr(self.keys_t) if big else _ptr(keys2), a.stride if big else 0,
+                                                 self.n_cate, _ptr(self.keys_t) if big else _ptr(keys2), self.keys_t.shape[1] if big else 0,
                                                  _ptr(self.rows[0]), _ptr(cnts[0]), _ptr(self.w[0]), _ptr(self.rows[1]),
                                                  _ptr(cnts[1]), _ptr(self.w[1]), _ptr(lab64),
                                                  _ptr(self.labels_f) if lab64 is not None else None, gjobs, 6 if gride else 0,
@@ -228,7 +242,7 @@ class DinFused:
             # ordered with the other collectives there, and ends a graph segment); the fork follows it, inside the next segment
             # (RSX_DIN_SIDE_SORT_DP=0: in line).  RSX_DIN_SIDE_SORT=0: in line.
             keys_g = None
-            if dp is not None:
+            if dp is not None and not ux:
                 # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
                 # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
                 keys_g = dp.all_gather_rows(keys2)
@@ -238,7 +252,17 @@ class DinFused:
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
-                if dp is not None:
+                if ux:
+                    # unique-list exchange: the rank's OWN dedup sort + its key block, beside the forward; the all-gather of the key
+                    # blocks, the merge into global lists and the sweep follow the forward (below)
+                    loc = self.ux.local
+                    loc.select(0)
+                    if big:
+                        loc.field_sort_t(self.keys_t, N)
+                    else:
+                        loc.field_sort(keys2)
+                    keys_l = a.ux_pack(1)
+                elif dp is not None:
                     a.field_sort(keys_g)
                 elif big:
                     a.field_sort_t(self.keys_t, N)
@@ -246,10 +270,13 @@ class DinFused:
                     a.field_sort(keys2)
                 # The item bias (i_item, tf.gather by the target ids: :96,139) rides with the item table: its rows ARE item rows, so the
                 # item field's dedup serves it; rows that only a history touches get a zero-gradient update from the same launch.
-                cold = [a.adam_split_segments()[0][0],
-                        dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=4, n=self.n_item, var=self.barena.tables, m=self.barena.m_t,
-                             v=self.barena.v_t, slot=a.slot, slot_w=None)]
-                store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
+                def cold_sweep():
+                    cold = [a.adam_split_segments()[0][0],
+                            dict(kind=_lib.RSX_ADAM_TABLE_TF1_COLD, d=4, n=self.n_item, var=self.barena.tables, m=self.barena.m_t,
+                                 v=self.barena.v_t, slot=a.slot, slot_w=None)]
+                    store.opt.run_slice(store.opt.cold_slices(cold, [1.0])[0])
+                if not ux:
+                    cold_sweep()
             # ---- forward --------------------------------------------------------------------------------------------
             if not gride:
                 self._gather(B, i_id, i_cate, hist)
@@ -276,7 +303,7 @@ class DinFused:
             tw = store.tower
             mlp_mk = None if masks is None or "mlp" not in masks else \
                 [torch.nn.functional.pad(m, (0, w - m.shape[1]), value=1.0) for m, w in zip(masks["mlp"], tw.widths)]
-            gbias = self.gbias[:N] if dp is None else gbias_full
+            gbias = self.gbias[:N] if (dp is None or ux) else gbias_full
             rank = dp.rank if dp is not None else 0
             loss, prob, dX, gs0, _ = tw.train_step(
                 self.X[:B], labels_f, rate, step, s0=self.ib[:B],
@@ -293,9 +320,17 @@ class DinFused:
                 # a batch smaller than an earlier one (the final partial batch of an epoch): entries B.. are HISTORY entries now,
                 # whose bias gradient is zero -- not what a larger batch's head (or, in the send block, a larger batch's value
                 # block) left there.  Unconditional for this batch size, so that a captured graph of the step carries it.
-                gbias[B:(self.cap_B if dp is None else N)].zero_()
+                gbias[B:(self.cap_B if (dp is None or ux) else N)].zero_()
             # ---- backward of the two attention blocks, straight into the scatter's value block --------------------------
-            vals = self.vals[:N] if dp is None else vals_full
+            if ux:
+                # ids phase, second half: the key blocks' all-gather (the local sort ran beside the forward), the merge into the
+                # global unique-row lists / slot map / src, and the untouched-row sweep, which needs that slot map
+                if side is not None:
+                    main.wait_stream(side)
+                a.select(0)
+                a.ux_merge(dp.all_gather_keys(keys_l, a, None), 1)
+                cold_sweep()
+            vals = self.vals[:N] if (dp is None or ux) else vals_full
             vbase = vals.data_ptr()
             dHp = [C.c_void_p(vbase + 4 * (B * 2 * K + t * K)) for t in range(2)]        # rows B.. of column block t
             doutp = [C.c_void_p(dX.data_ptr() + 4 * K * (t + 1)) for t in range(2)]       # d(pooled history t) = dX[:, (t+1)K : (t+2)K]
@@ -326,8 +361,11 @@ class DinFused:
                                                         _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,
                                                         B, P, K, n1, n2, 2 * K, 3 * K, vjobs, st), "rsx_din_attn_finish_pair_defer")
             riders = make_scatter_riders(vec_jobs=list(vjobs)) if ride_fin else None
-            if side is not None:
+            if side is not None and not ux:
                 main.wait_stream(side)            # the scatter (train_op) needs the sort; the sweep must precede its Adam state advance
+            if ux:      # the rank's own segment-sum (stage A + packed stage B), written as its block of the send buffer
+                Gv, gbv = dp.send_views(self.ux.capT)
+                a.ux_segsum_local(N, None, vals, gbias, None, Gv, gbv, 0)
 
         def train_op():                                                    # AdamOptimizer.minimize (:172-173)
             with torch.no_grad():
@@ -335,6 +373,12 @@ class DinFused:
                 if dp is None:
                     a.segsum_adam(N, None, vals, gbias, None, store.opt, store.dense.adam_segments(),
                                   w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1), riders=riders)
+                elif ux:
+                    # ONE collective [dense | G | bias sums], then the touched-row Adam of both tables + the bias off the merged lists
+                    (G0, gb0), blocks, dense_segs = dp.gather_send_block(self.ux.capT, fold_dense=True)
+                    a.select(0)
+                    a.ux_merged_adam(G0, gb0, blocks[1], store.opt, dense_segs or store.dense.adam_segments(),
+                                     w1_ext=(ba.tables, ba.m_t, ba.v_t, 4, 1))
                 else:
                     # ONE collective: [dense gradient arena | value block | bias gradients] of every rank; the dense arenas are
                     # summed in rank order inside the optimizer launch, the scatter reads the rank blocks in place

@@ -239,52 +239,26 @@ class DataParallel:
         return w
 
     # -- zero-copy send block -------------------------------------------------------------------
-    def make_send_block(self, dense, b_max, widths, arena=None):
-        """One persistent buffer [dense gradient arena | pad | gradient buckets | per-example block of up to b_max examples]; the
-        dense arena's grad views are moved into it.  widths: per-example float counts of the parts in block order (e.g. F*D,
-        D, 1, 1).  arena: an EmbeddingArena with enable_buckets() on -- its small-vocabulary fields' dense gradient buckets
-        ([rows, D] then [rows]) sit between the arena and the example block and ride the same collective (round 4)."""
+    def make_send_block(self, dense, b_max, widths):
+        """One persistent buffer [dense gradient arena | pad | the rank's block of the sparse exchange: up to b_max units]; the
+        dense arena's grad views are moved into it.  widths: per-unit float counts of the block's parts in block order -- the
+        unique-list exchange (round 5): units = the capT packed unique rows, parts G [capT, D] (, a second table set's), gw1
+        [capT]; the per-example exchange: units = examples, parts e.g. dX F*D, S D, gy2 1, gy1 1."""
         n0 = (dense.n + 3) & ~3
-        self._bucket_arena = arena if (arena is not None and getattr(arena, "skip_mask", 0)) else None
-        nbk = self._bucket_arena.bucket_floats() if self._bucket_arena is not None else 0
-        self._send = torch.zeros(n0 + nbk + b_max * sum(widths) + 4, device=dense.grad.device)
-        self._send_n0, self._send_nbk, self._send_widths, self._send_dense = n0, nbk, list(widths), dense
-        self._bucket_segs = []
+        self._send = torch.zeros(n0 + b_max * sum(widths) + 4, device=dense.grad.device)
+        self._send_n0, self._send_widths, self._send_dense = n0, list(widths), dense
         dense.rebind_grad(self._send)
         return self._send
-
-    def bucket_views(self):
-        """This replica's buckets inside the send block: (G [rows, D], gw1 [rows] | None); None without buckets."""
-        a = self._bucket_arena
-        if a is None:
-            return None
-        o, nb = self._send_n0, a.bucket_rows
-        G = self._send[o:o + nb * a.D].view(nb, a.D)
-        return G, (self._send[o + nb * a.D:o + nb * a.D + nb] if a.with_w1 else None)
-
-    def bucket_segments(self):
-        """The optimizer segments of the LAST gather_send_block's buckets (replica sums in rank order); [] without buckets."""
-        return list(self._bucket_segs)
-
-    def _bind_buckets(self, out_row0, bucket_off, stride):
-        a = self._bucket_arena
-        self._bucket_segs = []
-        if a is None:
-            return
-        nb = a.bucket_rows
-        g = out_row0[bucket_off:bucket_off + nb * a.D]
-        gw = out_row0[bucket_off + nb * a.D:bucket_off + nb * a.D + nb] if a.with_w1 else None
-        self._bucket_segs = a.bucket_adam_segments(g, gw, replicas=self.world, stride=stride)
 
     def send_bytes(self, b=None):
         """Bytes one rank contributes to the step's gradient collective (reported by bench.py); b = units of the per-example
         block (examples; din.py: entries = examples x (1 + history length)), default: those of the last exchange."""
         b = getattr(self, "_last_b", 0) if b is None else b
-        return 4 * (self._send_n0 + self._send_nbk + b * sum(self._send_widths))
+        return 4 * (self._send_n0 + b * sum(self._send_widths))
 
     def send_views(self, b):
         """The parts of the example block for a batch of b examples, as views of the send block: [b, w] each (w = 1: [b])."""
-        out, o = [], self._send_n0 + self._send_nbk
+        out, o = [], self._send_n0
         for w in self._send_widths:
             v = self._send[o:o + b * w]
             out.append(v if w == 1 else v.view(b, w))
@@ -306,13 +280,13 @@ class DataParallel:
         dense_done (RSX_DP_OVERLAP, see overlap_ranges / all_reduce_async): the arena was already summed in place by
         all-reduces issued from inside backward; only the example block is exchanged and the third value is None."""
         from . import _lib
-        n0, n, nbk = self._send_n0, self._send_dense.n, self._send_nbk
+        n0, n = self._send_n0, self._send_dense.n
         self._last_b = b
         L = b * sum(self._send_widths)
         d = self._send_dense
         big = n * 4 >= int(os.environ.get("RSX_DP_ALLREDUCE_MIN_BYTES", str(1024 * 1024)))
         if big or dense_done:
-            Lp = nbk + ((L + 3) & ~3)                              # (the buckets sit right in front of the example block)
+            Lp = (L + 3) & ~3
             x = self._send[n0:n0 + Lp].view(1, Lp)
             out = torch.empty((self.world, Lp), dtype=x.dtype, device=x.device)
             grad = self._send[:n]
@@ -321,15 +295,14 @@ class DataParallel:
                 graph_break(lambda: self._all_gather_into(out, x))
             else:
                 graph_break(lambda: self._overlapped_allreduce_allgather(grad, out, x))
-            views, o = [], nbk
+            views, o = [], 0
             for w in self._send_widths:
                 v = out[0, o:o + b * w]
                 views.append(v if w == 1 else v.view(b, w))
                 o += b * w
             self._keep = out
-            self._bind_buckets(out[0], 0, Lp)
             return views, (b, Lp), None
-        ln = (n0 + nbk + L + 3) & ~3                             # rank blocks stay 16-byte aligned
+        ln = (n0 + L + 3) & ~3                             # rank blocks stay 16-byte aligned
         out = self.all_gather_rows(self._send[:ln].view(1, ln))  # [N, ln]
         seg = None
         if fold_dense:
@@ -337,13 +310,12 @@ class DataParallel:
                         zero_grad=0)]
         else:
             torch.sum(out[:, :n], 0, out=d.grad)
-        views, o = [], n0 + nbk
+        views, o = [], n0
         for w in self._send_widths:
             v = out[0, o:o + b * w]
             views.append(v if w == 1 else v.view(b, w))
             o += b * w
         self._keep = out
-        self._bind_buckets(out[0], n0, ln)
         return views, (b, ln), seg
 
     def gather_example_grads(self, dX, S=None, gy1=None, gy2=None, ids=None, dense=None, blocked=False):
@@ -519,7 +491,10 @@ class LoopbackDataParallel(DataParallel):
         store.opt.shadow = self.shadow
         # rank-LOCAL state of the unique-list exchange (the rank's own sort workspaces and key blocks live across the steps of an
         # optimizer window): one set per played rank
-        for a in store.embeddings.values():
+        arenas = list(store.embeddings.values())
+        if getattr(store, "din", None) is not None:
+            arenas.append(store.din.arena)           # (din.py: the two-field arena behind its SparseTable views)
+        for a in arenas:
             ux = getattr(a, "ux", None)
             if ux is not None:
                 if not hasattr(ux, "rank_locals"):

@@ -205,6 +205,7 @@ class VariableStore:
         self.extra_segments = []     # model-specific optimizer segments (e.g. DIN tables)
         self.dp = None               # recsys_amd.dist.DataParallel when training data-parallel
         self.graph_safe_dp = False   # set by model code whose DP collectives run outside autograd (segmentable)
+        self.dp_unique = False       # data parallel: the sparse exchange carries per-rank unique-row lists (dist.py, round 5)
         # Optimizer window (include/rsx.h rsx_adam_window): window_k = the longest run of consecutive TRAIN steps the
         # model's fused step can treat as one window (set by model code; 1 = every step on its own); `window` =
         # (k, position, [features of the k batches]) while the Estimator runs a step that belongs to one.
@@ -226,11 +227,11 @@ class VariableStore:
         self.opt = AdamTF1(lr=lr, device=self.device)
         self.built = True
 
-    def adam_segments(self, timing_only=False):
+    def adam_segments(self):
         lazy = self.adam_mode == "lazy_rows"
         segs = []
         for a in self.embeddings.values():
-            segs += a.adam_segments(lazy, timing_only) if hasattr(a, "skip_mask") else a.adam_segments(lazy)
+            segs += a.adam_segments(lazy)
         segs += self.extra_segments
         segs += self.dense.adam_segments()
         return segs

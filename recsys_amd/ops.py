@@ -148,8 +148,7 @@ class EmbeddingArena:
         if self.two_stage_ws:
             nl = getattr(self, "null_last", False)     # padding entries keyed to every field's last (dummy) row: never walked
             self.partials = _lib.SegPartials(_ptr(self.segid), _ptr(self.P), _ptr(self.P1), _ptr(self.G), _ptr(self.gw1),
-                                             _ptr(self.row_off) if nl else None, _lib.NULL_LAST_ROW if nl else _lib.NULL_NONE,
-                                             getattr(self, "skip_mask", 0))
+                                             _ptr(self.row_off) if nl else None, _lib.NULL_LAST_ROW if nl else _lib.NULL_NONE, 0)
 
     def select(self, i):
         """Makes sort workspace i (position i of the optimizer window) the one field_sort / sort_job / segsum* use."""
@@ -182,68 +181,6 @@ class EmbeddingArena:
         self.sort_ws = other.sort_ws
         self.select(other.cur_buf)
 
-    # -- dense gradient buckets of the small-vocabulary fields (data parallel) ---------------------
-    BUCKET_MARK = 0x40000000      # slot-map value of a bucket row: "touched" for every sweep, never an index
-
-    def enable_buckets(self, max_rows=None):
-        """Data parallel (round 4): the fields of <= max_rows rows (RSX_DP_BUCKET_MAX_ROWS, default 1500:
-        25 of Criteo's 39, 3 291 rows) leave the global dedup sort + scatter.  Each rank sums its LOCAL batch into a dense
-        [rows, D] (+ first-order) bucket without sorting (rsx_bucket_scatter); the buckets ride the dense gradients' collective
-        and the optimizer adds them in rank order and updates EVERY bucket row with the touched-row formula -- for a row no
-        replica touched the gradient is an exact zero and that formula IS the untouched-row update, so TF-1's non-lazy Adam is
-        reproduced without knowing which rows were touched.  Returns False (nothing changes) when no field qualifies or the
-        sort workspace is beyond the LDS sort (the multi-launch sort has no skip mask)."""
-        if max_rows is None:
-            max_rows = int(os.environ.get("RSX_DP_BUCKET_MAX_ROWS", "1500"))
-        rows = np.diff(self.row_off_np)
-        small = [f for f in range(self.F) if rows[f] <= max_rows]
-        if not small or self.stride > self.LDS_SORT_MAX_B or self.F > 64 or getattr(self, "_sort_owner", None) is not None:
-            return False
-        dev = self.tables.device
-        boff = np.concatenate([[0], np.cumsum(rows[small])]).astype(np.int32)
-        self.bucket_fields = small
-        self.bucket_rows = int(boff[-1])
-        rowmap = np.concatenate([np.arange(self.row_off_np[f], self.row_off_np[f + 1]) for f in small]).astype(np.int32)
-        i32 = dict(dtype=torch.int32, device=dev)
-        self._bfield = torch.tensor(small, **i32)
-        self._boff = torch.tensor(boff, **i32)
-        self._browmap = torch.tensor(rowmap, **i32)
-        self._bcount = torch.tensor([self.bucket_rows], **i32)
-        self.skip_mask = sum(1 << f for f in small)
-        # permanent marks in EVERY slot map: the untouched-row sweeps (single steps and windows) pass over the bucket rows; the
-        # sorts never write them (skipped fields)
-        self._slot_all[:, self._browmap.long()] = self.BUCKET_MARK
-        for o in [self] + list(getattr(self, "_sort_sharers", [])):
-            o._bind_partials()
-        return True
-
-    def bucket_floats(self):
-        """Floats of one replica's buckets inside the send block: [rows, D] then [rows] (first order), padded to 4."""
-        n = self.bucket_rows * self.D + (self.bucket_rows if self.with_w1 else 0)
-        return (n + 3) & ~3
-
-    def bucket_scatter(self, ids, S, dX, gy1, gy2, G, gw1):
-        """The LOCAL batch's gradients of the bucket fields -> G [rows, D], gw1 [rows] (every row written)."""
-        B = ids.shape[0]
-        assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape[1] == self.F and G.is_contiguous()
-        w = self.with_w1 and gy1 is not None and gw1 is not None
-        check(lib().rsx_bucket_scatter(_ptr(self.tables), _ptr(S), _ptr(dX), _ptr(gy1) if w else None, _ptr(gy2), _ptr(ids),
-                                       _ptr(self.row_off), _ptr(self._bfield), _ptr(self._boff), _ptr(G), _ptr(gw1) if w else None,
-                                       self.w1_mask, B, self.F, self.D, len(self.bucket_fields), self.bucket_rows, _stream()),
-              "rsx_bucket_scatter")
-
-    def bucket_adam_segments(self, G, gw1, replicas=1, stride=0):
-        """Optimizer segments that apply the (replica-summed) buckets to every bucket row: the table rows with TF-1's sparse
-        formula, the first-order weights with ApplyAdam's, exactly as the scatter launch treats touched rows."""
-        nb = self.bucket_rows
-        segs = [dict(kind=_lib.RSX_ADAM_TABLE_ROWS, d=self.D, n=nb, var=self.tables, m=self.m_t, v=self.v_t, g=G,
-                     uniq_row=self._browmap, nuniq=self._bcount, B=nb, stride=nb, g_replicas=replicas, g_replica_stride=stride)]
-        if self.with_w1 and gw1 is not None:
-            segs.append(dict(kind=_lib.RSX_ADAM_VEC_ROWS_DENSE, n=nb, var=self.w1, m=self.m_w, v=self.v_w, g=gw1,
-                             uniq_row=self._browmap, nuniq=self._bcount, B=nb, stride=nb, g_replicas=replicas,
-                             g_replica_stride=stride))
-        return segs
-
     # -- data parallel: exchange of per-rank unique-row lists (csrc/uniq_exchange.hip) ----------------------
     @staticmethod
     def unique_exchange_ok(row_off, world):
@@ -271,6 +208,9 @@ class EmbeddingArena:
             loc = EmbeddingArena(self.row_off_np, self.D, int(sort_capacity or b_local), dev, with_w1=self.with_w1,
                                  w1_field_mask=self.w1_mask, tables=self.tables, w1=self.w1, workspace_only=True)
             assert loc.tables.data_ptr() == self.tables.data_ptr()
+            if getattr(self, "null_last", False):         # (din.py: the padding entries' dummy rows, never walked)
+                loc.null_last = True
+                loc._bind_partials()
             return loc, torch.zeros(_lib.ADAM_WINDOW_MAX, KS, **i32)
 
         local, keys = new_local()
@@ -390,12 +330,6 @@ class EmbeddingArena:
             assert owner.last_B == B, "shared sort: sort the owning arena first"
             self.last_B = B
             return
-        if getattr(self, "skip_mask", 0):          # bucket fields are not sorted (rsx_sort_job.skip_mask): the job entry point
-            assert B <= self.LDS_SORT_MAX_B
-            jobs = (_lib.SortJob * 1)(self.sort_job(ids))
-            check(lib().rsx_field_sort_multi(jobs, 1, _stream()), "rsx_field_sort_multi")
-            self.last_B = B
-            return
         if B > self.LDS_SORT_MAX_B:
             check(lib().rsx_field_sort_large(_ptr(ids), _ptr(self.row_off), _ptr(self.perm), _ptr(self.seg_off),
                                              _ptr(self.uniq_row), _ptr(self.nuniq), _ptr(self.slot), _ptr(self.segid),
@@ -446,7 +380,7 @@ class EmbeddingArena:
         j.uniq_row, j.nuniq, j.slot = self.uniq_row.data_ptr(), self.nuniq.data_ptr(), self.slot.data_ptr()
         j.segid = self.segid.data_ptr() if self._two_stage(B) else None
         j.max_rows_per_field, j.B, j.F, j.stride = self.max_rows, B, self.F, self.stride
-        j.skip_mask = getattr(self, "skip_mask", 0)
+        j.skip_mask = 0
         return j
 
     def gather_outputs(self, B, fm=False, first_order=False, S_out=None):
@@ -557,16 +491,8 @@ class EmbeddingArena:
                             g=self.gw1, uniq_row=self.uniq_row, nuniq=self.nuniq, B=self.last_B, stride=self.stride))
         return cold, hot
 
-    def adam_segments(self, lazy=False, timing_only=False):
-        """timing_only: the same sweep over a slot map that marks NO row (bench.py's stand-alone roofline leg when gradient
-        buckets are on: the live maps then carry the bucket rows' marks, which are not gradient indices)."""
+    def adam_segments(self, lazy=False):
         slot = self.slot
-        if getattr(self, "skip_mask", 0):
-            if not timing_only:
-                raise _lib.RsxError("EmbeddingArena.adam_segments: gradient buckets are enabled (data-parallel fused step only)")
-            if not hasattr(self, "_clean_slot"):
-                self._clean_slot = torch.full_like(self.slot, -1)
-            slot = self._clean_slot
         segs = []
         if lazy:
             segs.append(dict(kind=_lib.RSX_ADAM_TABLE_ROWS, d=self.D, n=self.F * self.last_B, var=self.tables,

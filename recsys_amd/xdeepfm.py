@@ -89,13 +89,26 @@ def build_variables(store, params, capacity):
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
-    if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and capacity <= 16384 and \
+    from .deepfm import dp_unique_wanted
+    want_ux = store.dp is not None and dp_unique_wanted(store, params) and \
+        EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world)
+    sort_cap = capacity // store.dp.world if want_ux else capacity      # (unique-list exchange: the ranks sort their own batches)
+    if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and sort_cap <= 16384 and \
             (store.dp is None or params.get("dp_send_block", True)):
         store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
         store.window_dp = True
     store.dp_block = False
+    store.dp_unique = False
     if store.dp is not None and params.get("dp_send_block", True):          # zero-copy gradient exchange (see deepfm.py)
-        store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])
+        if want_ux:
+            # round 5: the ranks exchange unique (row, sum) lists of BOTH table sets (one dedup serves both):
+            # send block [dense | G1 [capT, D] | G2 [capT, D] | g_lin sums [capT]]
+            ux = a1.enable_unique_exchange(store.dp.world, capacity // store.dp.world)
+            a2.ux = ux
+            store.dp.make_send_block(store.dense, ux.capT, [D, D, 1])
+            store.dp_unique = True
+        else:
+            store.dp.make_send_block(store.dense, capacity // store.dp.world, [F * D, F * D, 1])
         store.dp_block = True
     store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
 
@@ -128,7 +141,8 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
     B = ids.shape[0]
     sweeps, hot, L = None, None, len(store.cin_sizes)
     tower_sweeps, last_sweep = None, None
-    zc = dp is not None and getattr(store, "dp_block", False)
+    ux = dp is not None and getattr(store, "dp_unique", False)      # exchange of per-rank unique-row lists (deepfm._train_fused)
+    zc = dp is not None and getattr(store, "dp_block", False) and not ux
     with torch.no_grad():
         # data-parallel: the optimizer sees the GLOBAL batch -- the dedup sort runs over the all-gathered ids (issued first:
         # they depend on nothing of the step), so the same exact split of the TF-1 update applies as on one GPU
@@ -138,26 +152,35 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (zc and wk == 1) else ids
         job, ride = None, False
         split = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
-        if wk > 1 and not (split and (dp is None or zc)):
+        if wk > 1 and not (split and (dp is None or zc or ux)):
             raise _lib.RsxError("optimizer windows need the split TF-1 update (and, data-parallel, the send block)")
+        if ux and wpos == 0:
+            # ids phase of the unique-list exchange: local sorts -> key blocks -> one all-gather -> global lists / slot maps / src
+            idl = [f["ids"] for f in wfeat] if wk > 1 else [ids]
+            a1.ux_merge(dp.all_gather_keys(a1.ux_sort_pack(idl), a1, idl), wk)
         a1.select(wpos)
         a2.select(wpos)
+        if ux:
+            a1.last_B = a2.last_B = a1.ux.max_unique
         if wk > 1:
             if wpos == 0:
-                from .dist import window_global_ids
-                a1.sort_window(window_global_ids(dp, wfeat))       # data-parallel: one all-gather for all wk batches' ids
+                if not ux:
+                    from .dist import window_global_ids
+                    a1.sort_window(window_global_ids(dp, wfeat))       # data-parallel: one all-gather for all wk batches' ids
                 c1, _ = a1.adam_split_segments(window_k=wk)
                 c2, _ = a2.adam_split_segments(window_k=wk)
                 store.opt.window_sweep(c1[::-1] + c2)
-            a1.last_B = a2.last_B = B * (dp.world if dp is not None else 1)
+            if not ux:
+                a1.last_B = a2.last_B = B * (dp.world if dp is not None else 1)
             hot = ()
-        elif dp is None or zc:
-            a2.last_B = ids_sort.shape[0]
+        elif dp is None or zc or ux:
+            if not ux:
+                a2.last_B = ids_sort.shape[0]
             # The sort (it serves a2 as well, share_sort_of) rides in the tower's first forward launch when no sweep slice is
             # scheduled before or in that launch (slices read the sort's slot map); otherwise it runs first.
-            ride = (ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048"))
+            ride = (not ux and ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048"))
                     and os.environ.get("RSX_XDFM_SORT_RIDE", "1") == "1")
-            job = a1.sort_job(ids_sort)
+            job = a1.sort_job(ids_sort) if not ux else None
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets
                 # (700 MB of streaming) rides in the CIN forward and weight-gradient launches (MFMA work, little HBM); the touched rows
@@ -192,7 +215,8 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 hot = h1 + h2
             if not ride:
                 job = None
-                a1.field_sort(ids_sort)
+                if not ux:
+                    a1.field_sort(ids_sort)
         dX1v, dX2v, glv = dp.send_views(B) if zc else (None,) * 3          # per-example gradient block, written in place
         # both input_layer calls (:125,185) + the pre-activation of linear_net (one-hot weights + 13 numeric log-values, :127)
         E1 = torch.empty(B, a1.F * a1.D, device=ids.device)
@@ -212,10 +236,23 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         dX1 = store.cin.backward(X0, P, g_cin.reshape(-1), None if sweeps is None else sweeps[L:],
                                  dX0_out=dX1v.view(B, a1.F, a1.D) if zc else None,
                                  lin=(logx_c, g_lin, P["lin.wnum"].grad)).view(B, -1)   # cin.* and lin.wnum grads land in the dense arena
+        if ux:
+            # the rank's own sorted segment-sums of both table sets, written as its block of the send buffer
+            G1v, G2v, gw1v = dp.send_views(a1.ux.capT)
+            a1.ux_segsum_local(B, None, dX1, g_lin, None, G1v, gw1v, wpos)
+            a2.ux_segsum_local(B, None, dX2, None, None, G2v, None, wpos)
 
     def train_op():
         with torch.no_grad():
-            if zc:
+            if ux:
+                # ONE collective [dense | G1 | G2 | g_lin sums] (the 3.3 MB of CIN filters through an all-reduce beside it), then
+                # both table sets' touched-row Adam off the merged lists + the dense update in one launch
+                (G10, G20, gw10), blocks, dense_segs = dp.gather_send_block(a1.ux.capT, fold_dense=True)
+                a1.select(wpos)
+                a2.select(wpos)
+                a1.ux_merged_adam(G10, gw10, blocks[1], store.opt, dense_segs or store.dense.adam_segments(), last_sweep,
+                                  second=(a2, G20), window=(wk, wpos))
+            elif zc:
                 # ONE collective straight from the send block [dense arena | dX1 | dX2 | g_lin]; both table sets' scatter +
                 # touched-row Adam + the dense update (replica arenas summed in rank order) in one launch
                 (dX1g, dX2g, glg), blocks, dense_segs = dp.gather_send_block(B, fold_dense=hot is not None)

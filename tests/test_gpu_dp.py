@@ -71,22 +71,21 @@ def test_dp_world1_rccl_matches_oracle(capture_collectives, overlap):
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("buckets", ["0", "50", "1500"])
+@pytest.mark.parametrize("exchange", ["examples", "unique"])
 @pytest.mark.parametrize("kind,B,world,overlap", [("deepfm", 48, 3, 0), ("dcn", 40, 2, 0), ("deepfm", 300, 4, 0),
                                                   ("deepfm", 600, 4, 0), ("fm", 56, 3, 0), ("deepfm", 48, 3, 1)])
-def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world, overlap, buckets, monkeypatch):
+def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world, overlap, exchange, monkeypatch):
     """Multi-block data-parallel compute on one GPU: `world` identical replicas of a batch b (collectives replaced by
     local tiling) must train exactly like ONE process on the batch repeated `world` times -- same BN statistics, same
     mean loss, gradients summed over replicas with the 1/N loss scale.  Exercises the global dedup sort, the scatter
     reading rank blocks in place from the gathered buffer, and (B*world > 1024) its two-stage form.
     overlap = 1: the RSX_DP_OVERLAP exchange (per-layer dense all-reduce, example block alone in the all-gather).
-    buckets (round 4): "0" = every field through the global sort + per-example block (the round-3 exchange); "50" = the fields
-    of <= 50 rows (3, 7, 40, 11) as dense per-row gradient buckets summed over the replicas in rank order, the 600-row field
-    through the global sort; "1500" = all five fields as buckets (the global sort has nothing to do).  The replicas' partial
-    sums are added in a different association than the single process adds the examples: 2e-6."""
+    exchange: "examples" = the pre-dedup per-example block + one global dedup sort (rounds 1-4); "unique" (round 5, default) =
+    every replica's own dedup + segment-sum, unique (row, sum) lists exchanged and merged in rank order (the replicas' partial
+    sums are added in another association than the single process adds the examples: 2e-6).  Identical replicas cannot catch a
+    wrong rank stride -- tests/test_gpu_dp_loopback.py runs DISTINCT batches against the oracle."""
     monkeypatch.setenv("RSX_DP_OVERLAP", str(overlap))
-    monkeypatch.setenv("RSX_DP_BUCKETS", "0" if buckets == "0" else "1")
-    monkeypatch.setenv("RSX_DP_BUCKET_MAX_ROWS", buckets)
+    monkeypatch.setenv("RSX_DP_EXCHANGE", exchange)
     import numpy as np
     import torch
     from oracle import init
@@ -123,7 +122,7 @@ def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world,
             losses.append(float(est._train_step({"ids": i}, y)))
         assert abs(losses[0] - losses[1]) < 1e-6, losses
     a, b = ests
-    assert bool(getattr(a.store.embeddings["input_layer"], "skip_mask", 0)) == (buckets != "0")
+    assert bool(getattr(a.store, "dp_unique", False)) == (exchange == "unique")
     for name in a.store.embeddings:
         ta, tb = a.store.embeddings[name].tables, b.store.embeddings[name].tables
         assert float((ta - tb).abs().max()) < 2e-6, name
@@ -132,54 +131,6 @@ def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world,
         if a.store.embeddings[name].with_w1:
             assert float((a.store.embeddings[name].w1 - b.store.embeddings[name].w1).abs().max()) < 2e-6, name
     assert float((a.store.dense.flat - b.store.dense.flat).abs().max()) < 2e-6
-
-
-def test_bucket_scatter_is_the_dense_form_of_the_segment_sum():
-    """rsx_bucket_scatter (round 4): for every row of the bucket fields the sum, over the LOCAL batch's examples with that
-    id, of (gy2 S - gy2 T[row]) + dX[:, f] and of gy1 -- against a float64 numpy scatter (1e-5) and, for rows that one or
-    no example names, exactly."""
-    import numpy as np
-    import torch
-    from recsys_amd.ops import EmbeddingArena
-    from tests.parity_util import synth_ids
-    rng = np.random.default_rng(3)
-    rows = (3, 1000, 7, 40, 2000, 11, 600, 1)
-    row_off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-    F, D, B = len(rows), 16, 300
-    tables = rng.standard_normal((int(row_off[-1]), D)).astype(np.float32) * 0.25
-    a = EmbeddingArena(row_off, D, B, "cuda", with_w1=True, w1_field_mask=0b10111101, tables=tables,
-                       w1=np.zeros(int(row_off[-1]), np.float32))
-    assert a.enable_buckets(700)
-    small = [0, 2, 3, 5, 6, 7]
-    assert a.bucket_fields == small and a.skip_mask == sum(1 << f for f in small)
-    ids = synth_ids(rng, B, row_off)
-    dX = rng.standard_normal((B, F * D)).astype(np.float32)
-    S = rng.standard_normal((B, D)).astype(np.float32)
-    gy1, gy2 = rng.standard_normal(B).astype(np.float32), rng.standard_normal(B).astype(np.float32)
-    t = lambda x: torch.from_numpy(x).cuda()
-    for fm, xg in ((True, True), (False, True), (True, False)):
-        G = torch.full((a.bucket_rows, D), 7.0, device="cuda")
-        gw = torch.full((a.bucket_rows,), 7.0, device="cuda")
-        a.bucket_scatter(t(ids), t(S) if fm else None, t(dX) if xg else None, t(gy1), t(gy2) if fm else None, G, gw)
-        torch.cuda.synchronize()
-        Gw = np.zeros((a.bucket_rows, D)); gww = np.zeros(a.bucket_rows); cnt = np.zeros(a.bucket_rows, np.int64)
-        k0 = 0
-        for f in small:
-            for b in range(B):
-                k = k0 + ids[b, f]
-                v = np.zeros(D)
-                if fm:
-                    v = v + (gy2[b] * S[b] - gy2[b] * tables[row_off[f] + ids[b, f]]).astype(np.float64)
-                if xg:
-                    v = v + dX[b, f * D:(f + 1) * D]
-                Gw[k] += v
-                cnt[k] += 1
-                if (0b10111101 >> f) & 1:
-                    gww[k] += gy1[b]
-            k0 += rows[f]
-        np.testing.assert_allclose(G.cpu().numpy(), Gw, rtol=1e-5, atol=2e-5)
-        np.testing.assert_allclose(gw.cpu().numpy(), gww, rtol=1e-5, atol=2e-5)
-        assert np.all(G.cpu().numpy()[cnt == 0] == 0.0) and np.all(gw.cpu().numpy()[cnt == 0] == 0.0)     # every row is written
 
 
 def test_xdeepfm_blocked_data_parallel_equals_single_batch():

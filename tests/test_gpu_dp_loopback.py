@@ -185,3 +185,125 @@ def test_the_loopback_comparison_fails_when_two_rank_blocks_are_swapped(monkeypa
         models.train_step_dp(om, opt, [(i,) for i in ids], [y.astype(np.float64) for y in ys])
     perr = _param_err(est, P64)
     assert perr["tables"] > 1e-4, perr
+
+
+@pytest.mark.parametrize("exchange", ["examples", "unique"])
+@pytest.mark.parametrize("world,B,cin,window", [(2, 24, (8, 4), 1), (3, 16, (20, 10, 10), 1), (2, 16, (8, 4), 3)])
+def test_loopback_dp_xdeepfm_matches_the_oracle(world, B, cin, window, exchange, monkeypatch):
+    """xdeepfm.py (two table sets behind one dedup, the first-order weights of the indicator columns, 3.3 MB-class dense arena
+    through its own all-reduce when large): distinct batches per rank against oracle.models.train_step_dp."""
+    import torch
+    from oracle import criteo, init, models, nn
+    from recsys_amd import xdeepfm
+    from recsys_amd.dist import LoopbackDataParallel, loopback_train_step
+    from recsys_amd.feature_columns import build_feature_columns
+    from tests.parity_util import make_estimator, synth_ids
+    monkeypatch.setenv("RSX_DP_EXCHANGE", exchange)
+    D, layers, seed = 16, (32, 16), 21
+    rng = np.random.default_rng(seed)
+    lin, emb = build_feature_columns(D, "numeric+indicator")
+    row_off = criteo.row_offsets()
+    cat_slot, cat_off = init.xdeepfm_layout()
+    P = init.xdeepfm_params(seed, D, layers, cin, np.float32, row_off)
+    for k in ("lin.b", "cin.bout", "dnn.bout"):
+        P[k] += np.float32(0.05)
+    params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D, "learning_rate": 1e-3,
+              "dropout": 0.0, "deep_layers": ",".join(map(str, layers)), "cross_layers": ",".join(map(str, cin)),
+              "max_batch_size": B}
+    est = make_estimator(xdeepfm.model_fn, params)
+    est.store.dp = LoopbackDataParallel(world)
+
+    def feats(ids, logx):
+        return {"ids": torch.from_numpy(ids).cuda(), "cont_log": torch.from_numpy(logx).cuda()}
+
+    def batch():
+        return (synth_ids(rng, B, row_off), np.log(np.floor(np.exp(rng.normal(2, 1, (B, 13)))) + 1.0).astype(np.float32),
+                rng.integers(0, 2, B).astype(np.float32))
+
+    b0 = batch()
+    with torch.no_grad():
+        est._call_model_fn(feats(*b0[:2]), None, "infer")
+    st = est.store
+    assert st.dp_unique == (exchange == "unique")
+    w1 = np.zeros(int(row_off[-1]), np.float32)
+    for j in range(26):
+        s_ = int(cat_slot[j])
+        w1[row_off[s_]:row_off[s_ + 1]] = P["lin.wcat"][cat_off[j]:cat_off[j + 1]]
+    with torch.no_grad():
+        st.embeddings["input_layer"].tables.copy_(torch.from_numpy(P["tables"]))
+        st.embeddings["input_layer"].w1.copy_(torch.from_numpy(w1))
+        st.embeddings["input_layer_1"].tables.copy_(torch.from_numpy(P["tables2"]))
+    st.dense.load({k: v for k, v in P.items() if k in st.dense.params})
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    om = models.XDeepFM(P64, row_off, cat_slot, cat_off, cin, len(layers), 0.0)
+    opt = nn.AdamTF1(dtype=np.float64)
+    for w in range(2):
+        bs = [[batch() for _ in range(window)] for _ in range(world)]            # [rank][position]
+        fs = [[feats(*b[:2]) for b in bs[r]] for r in range(world)]
+        for pos in range(window):
+            lg = loopback_train_step(est, [fs[r][pos] for r in range(world)],
+                                     [torch.from_numpy(bs[r][pos][2]).cuda() for r in range(world)],
+                                     window=(window, pos, fs) if window > 1 else None)
+            lo, _ = models.train_step_dp(om, opt, [(bs[r][pos][0], bs[r][pos][1].astype(np.float64)) for r in range(world)],
+                                         [bs[r][pos][2].astype(np.float64) for r in range(world)])
+            assert all(abs(a - b) < 2e-5 for a, b in zip(lg, lo)), (w, pos, lg, lo)
+    a1 = st.embeddings["input_layer"]
+    w1g = a1.w1.cpu().numpy()
+    wcat = np.concatenate([w1g[row_off[int(cat_slot[j])]:row_off[int(cat_slot[j]) + 1]] for j in range(26)])
+    perr = {"tables": float(np.abs(a1.tables.cpu().numpy() - P64["tables"]).max()),
+            "tables2": float(np.abs(st.embeddings["input_layer_1"].tables.cpu().numpy() - P64["tables2"]).max()),
+            "lin.wcat": float(np.abs(wcat - P64["lin.wcat"]).max())}
+    for k, p in st.dense.params.items():
+        perr[k] = float(np.abs(p.detach().cpu().numpy() - P64[k].reshape(p.shape)).max())
+    assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("exchange", ["examples", "unique"])
+@pytest.mark.parametrize("world,B,Pn", [(2, 24, 12), (3, 16, 20), (2, 96, 100)])
+def test_loopback_dp_din_matches_the_oracle(world, B, Pn, exchange, monkeypatch):
+    """din.py's fused step (din/din.py:204-206 MirroredStrategy): per-rank batches with ragged histories, target ids 0, the item
+    bias riding as the item field's first-order vector, history padding mapped to the dummy rows.  (96, 100): 9 696 entries per
+    rank -- the multi-launch sort and the two-stage scatter (global or, under the unique-list exchange, the rank's own)."""
+    import torch
+    from oracle import init, models, nn
+    from recsys_amd import din, synthetic
+    from recsys_amd.dist import LoopbackDataParallel, loopback_train_step
+    from tests.parity_util import make_estimator
+    monkeypatch.setenv("RSX_DP_EXCHANGE", exchange)
+    K, n_item, n_cate = 16, 300, 20
+    rng = np.random.default_rng(5)
+    P = init.din_params(2, K, n_item, n_cate, np.float32)
+    P["item_bias"] += (rng.standard_normal(n_item) * 0.01).astype(np.float32)
+    est = make_estimator(din.model_fn, {"embedding_size": K, "learning_rate": 1e-3, "dropout": 0.0, "n_item": n_item,
+                                        "n_cate": n_cate, "max_batch_size": B})
+    est.store.dp = LoopbackDataParallel(world)
+    keys = ("i_id", "i_cate", "u_iid_seq", "u_icat_seq")
+
+    def feats(b):
+        return {k: torch.from_numpy(b[k]).cuda() for k in keys}
+
+    b0 = synthetic.din_batch(rng, B, Pn, n_item, n_cate)
+    with torch.no_grad():
+        est._call_model_fn(feats(b0), None, "infer")
+    st = est.store
+    assert st.din is not None and st.dp_unique == (exchange == "unique")
+    with torch.no_grad():
+        st.embeddings["i_id"].table.copy_(torch.from_numpy(P["item_emb"]))
+        st.embeddings["i_cate"].table.copy_(torch.from_numpy(P["cate_emb"]))
+        st.embeddings["i_item"].table[:, 0].copy_(torch.from_numpy(P["item_bias"]))
+    st.dense.load({k: v for k, v in P.items() if k in st.dense.params})
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    om = models.DIN(P64, 0.0)
+    opt = nn.AdamTF1(dtype=np.float64)
+    for step in range(3):
+        bs = [synthetic.din_batch(rng, B, Pn, n_item, n_cate) for _ in range(world)]
+        bs[0]["i_id"][:2] = 0                                    # target id 0 trains like any row; the histories' 0 is padding
+        lg = loopback_train_step(est, [feats(b) for b in bs], [torch.from_numpy(b["label"]).cuda() for b in bs])
+        lo, _ = models.train_step_dp(om, opt, [tuple(b[k] for k in keys) for b in bs], [b["label"].astype(np.float64) for b in bs])
+        assert all(abs(a - b_) < 1e-5 for a, b_ in zip(lg, lo)), (step, lg, lo)
+    perr = {"item_emb": float(np.abs(st.embeddings["i_id"].table.cpu().numpy() - P64["item_emb"]).max()),
+            "cate_emb": float(np.abs(st.embeddings["i_cate"].table.cpu().numpy() - P64["cate_emb"]).max()),
+            "item_bias": float(np.abs(st.embeddings["i_item"].table[:, 0].cpu().numpy() - P64["item_bias"]).max())}
+    for k, p in st.dense.params.items():
+        perr[k] = float(np.abs(p.detach().cpu().numpy() - P64[k].reshape(p.shape)).max())
+    assert max(perr.values()) < 2e-5, perr
