@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--batch_size", type=int, default=256)
     p.add_argument("--adam_mode", default="tf1_dense", choices=["tf1_dense", "lazy_rows"])
     p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--emulate_identical", action="store_true", help="--emulate_world with N IDENTICAL replicas (one batch tiled N "
+                   "times: rounds 1-4's emulation; the global batch then has a single replica's unique rows)")
     p.add_argument("--emulate_world", type=int, default=0, help="profiling aid: time the per-rank COMPUTE of an N-GPU "
                    "data-parallel step on one GPU (collectives replaced by local tiling; not a throughput claim)")
     p.add_argument("--host_input", action="store_true", help="measurement aid: every step's batch starts in pinned HOST "
@@ -208,6 +210,25 @@ def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmu
     # variables are created on the first call; then W untimed warm-up steps (includes graph capture)
     with torch.no_grad():
         est._call_model_fn(feats[0].views()[0], None, "infer")
+    if emu is not None and not a.emulate_identical:
+        # the peers of resident batch i are REAL other batches (i + r n / N) -- the global step then touches the rows N
+        # different batches touch, not one batch's rows N times; their packed unique-row lists are
+        # computed here, once, outside the timed region
+        n = len(feats)
+        tok = "i_id" if model == "din" else "ids"
+        views = [f.views()[0] for f in feats]
+        peers = {views[i][tok].data_ptr(): [views[(i + (r + 1) * max(1, n // emu.world)) % n] for r in range(emu.world - 1)]
+                 for i in range(n)}
+        key_fn = None
+        if getattr(est.store, "dp_unique", False):
+            if model == "din":
+                key_fn = est.store.din.ux_peer_keys
+            else:
+                ar = est.store.embeddings["input_layer"]
+                key_fn = lambda pf, ar=ar: ar.ux_peer_keys(pf["ids"])
+        emu.set_peers(peers, key_fn)
+        emu.warm_keys()
+        torch.cuda.synchronize()
     host_pbs = None
     if a.host_input:
         host_pbs = [PackedBatch(*f.to("cpu").views(), pin=True) for f in feats]

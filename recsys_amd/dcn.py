@@ -96,7 +96,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         overlap = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
         wk, wpos, wfeat = store.window_of_step()
         ux = dp is not None and store.dp_unique
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1 and not ux) else ids   # first: see deepfm._train_fused
+        ids_sort = dp.all_gather_id_list([ids], prefetchable=True)[0] if (dp is not None and wk == 1 and not ux) else ids   # first: see deepfm._train_fused
         zc = dp is not None and store.dp_block and not ux
         # Round 4: the lookup and the cross layers' forward in ONE launch (rsx_gather_cross_fwd: the gather's lanes already hold the
         # example's row in the cross kernel's layout); RSX_GATHER_CROSS=0: two launches

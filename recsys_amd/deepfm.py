@@ -178,7 +178,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         if wk > 1 and not overlap:
             raise _lib.RsxError("optimizer windows need the split TF-1 update (adam_mode=tf1_dense, overlap_adam)")
         ux = dp is not None and store.dp_unique      # the exchange of per-rank unique-row lists (round 5)
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (dp is not None and wk == 1 and not ux) else ids
+        ids_sort = dp.all_gather_id_list([ids], prefetchable=True)[0] if (dp is not None and wk == 1 and not ux) else ids
         zc = dp is not None and store.dp_block and not ux     # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         job = None

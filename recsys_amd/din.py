@@ -171,6 +171,30 @@ class DinFused:
         self.rows = [torch.empty(B * P + 2 + (B * P + 1023) // 1024, **i32) for _ in range(2)]
         self.ws = [torch.empty(int(_lib.lib().rsx_din_attn_bwd_workspace_floats(B, P, K, n1, n2)), **f32) for _ in range(2)]
 
+    def ux_peer_keys(self, features):
+        """EmulatedDataParallel: the packed key block a PEER rank holding `features` would send -- its sort keys (rsx_din_keys), its
+        own dedup sort and pack, on scratch workspaces."""
+        a, ux = self.arena, self.ux
+        i_id = features["i_id"].to(torch.int32).contiguous()
+        i_cate = features["i_cate"].to(torch.int32).contiguous()
+        hist = [features["u_iid_seq"].to(torch.int32).contiguous(), features["u_icat_seq"].to(torch.int32).contiguous()]
+        B = i_id.shape[0]
+        N = B * (self.P + 1)
+        if not hasattr(ux, "scratch"):
+            ux.scratch = ux.new_local()
+            self._peer_keys2 = torch.zeros_like(self.keys2)
+        _lib.check(_lib.lib().rsx_din_keys(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, self.P, self.n_item,
+                                          self.n_cate, _ptr(self._peer_keys2), _stream()), "rsx_din_keys")
+        own = (ux.local, ux.keys)
+        ux.local, ux.keys = ux.scratch
+        try:
+            ux.local.select(0)
+            ux.local.field_sort(self._peer_keys2[:N])
+            out = a.ux_pack(1).reshape(-1).clone()
+        finally:
+            ux.local, ux.keys = own
+        return out
+
     def _side_stream(self):
         if os.environ.get("RSX_DIN_SIDE_SORT", "1") != "1":
             return None
@@ -328,7 +352,7 @@ class DinFused:
                 if side is not None:
                     main.wait_stream(side)
                 a.select(0)
-                a.ux_merge(dp.all_gather_keys(keys_l, a, None), 1)
+                a.ux_merge(dp.all_gather_keys(keys_l, a, [features["i_id"]]), 1)
                 cold_sweep()
             vals = self.vals[:N] if (dp is None or ux) else vals_full
             vbase = vals.data_ptr()

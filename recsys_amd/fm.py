@@ -120,7 +120,7 @@ def _train_fused(store, arena, ids, labels):
                 store.opt.window_sweep(cold[::-1])
             arena.last_B = B * (dp.world if dp is not None else 1)
         else:
-            arena.field_sort(dp.all_gather_rows(ids, prefetchable=True) if dp is not None else ids)
+            arena.field_sort(dp.all_gather_id_list([ids], prefetchable=True)[0] if dp is not None else ids)
             cold, hot = arena.adam_split_segments()
             # 70 % of the untouched-row sweep rides in the head launch, 30 % (table blocks only: the first-order vector goes
             # first) in the scatter + touched-row Adam launch (measured: 76.4 -> 72.2 us per step)

@@ -244,6 +244,20 @@ class EmbeddingArena:
             loc.sort_window(ids_list)
         return self.ux_pack(k)
 
+    def ux_peer_keys(self, ids):
+        """EmulatedDataParallel: the packed key block [KS] a PEER rank holding batch `ids` would send (its dedup sort + pack, run
+        on a scratch workspace so that this rank's own sort state is untouched)."""
+        ux = self.ux
+        if not hasattr(ux, "scratch"):
+            ux.scratch = ux.new_local()
+        own = (ux.local, ux.keys)
+        ux.local, ux.keys = ux.scratch
+        try:
+            out = self.ux_sort_pack([ids]).reshape(-1).clone()
+        finally:
+            ux.local, ux.keys = own
+        return out
+
     def ux_pack(self, k):
         ux, loc = self.ux, self.ux.local
         jobs = (_lib.UniqPackJob * k)()

@@ -149,7 +149,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         # optimizer window (deepfm.py, include/rsx.h rsx_adam_window): position 0 sorts the ids of all wk batches and sweeps the
         # untouched rows of BOTH table sets once for the whole window (a launch of its own); the other positions run neither
         wk, wpos, wfeat = store.window_of_step()
-        ids_sort = dp.all_gather_rows(ids, prefetchable=True) if (zc and wk == 1) else ids
+        ids_sort = dp.all_gather_id_list([ids], prefetchable=True)[0] if (zc and wk == 1) else ids
         job, ride = None, False
         split = store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True))
         if wk > 1 and not (split and (dp is None or zc or ux)):

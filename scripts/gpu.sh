@@ -44,11 +44,15 @@ PY
     emulate) local m=$1; shift
              for n in 1 2 4 8; do
                if [ $n -eq 1 ]; then e=""; else e="--emulate_world $n"; fi
-               timeout 600 python bench.py --model $m $e --no_cpu_baseline --no_configs "$@" 2>/dev/null | tail -1 | python -c "
+               timeout 600 python bench.py --model $m $e --no_cpu_baseline --no_configs "$@" 2>gpurun_out/emulate_$m.err | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read())
-print('emulated per-rank compute: model $m world $n  ms_per_step', d['ms_per_step'], ' adam_window', d['config']['adam_window'], ' global_batch', $n * int(d['config']['global_batch']), ' send_bytes/rank', d['config'].get('dp_send_bytes_per_rank_per_step'), ' bucket_fields', d['config'].get('dp_bucket_fields'))"
-             done | tee gpurun_out/emulate_$m.txt ;;
+try:
+    d = json.loads(sys.stdin.read())
+except Exception as ex:
+    print('emulate $m world $n: no JSON line', ex); print(open('gpurun_out/emulate_$m.err').read()[-2500:]); sys.exit(0)
+c = d['config']
+print('emulated per-rank compute: model $m world $n exchange', c.get('dp_exchange', '-'), 'RSX_DP_EXCHANGE=${RSX_DP_EXCHANGE:-unique} peers', '$*' if '$*' else 'distinct batches', ' ms_per_step', d['ms_per_step'], ' adam_window', c['adam_window'], ' global_batch', $n * int(c['global_batch']), ' gradient bytes/rank', c.get('dp_gradient_bytes'), ' ids-phase bytes/rank', c.get('dp_ids_phase_bytes'), ' launches/step', c.get('launches_per_step'))"
+             done | tee gpurun_out/emulate_$m${TAG:+_$TAG}.txt ;;
     roofline) timeout 1200 python scripts/kernel_roofline.py 2>&1 | tee gpurun_out/kernel_roofline_table.txt | tail -40 ;;
     *) echo "unknown task $task"; return 1 ;;
   esac

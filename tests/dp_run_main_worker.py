@@ -19,7 +19,7 @@ def main():
     m = importlib.import_module("recsys_amd." + mod)
     from recsys_amd import deepfm as driver
     rank = int(os.environ["RANK"])
-    seen = []
+    seen, trained = [], []
     real_input_fn = driver.input_fn
 
     def spy(filenames, batch_size, num_epochs=-1, need_shuffle=False, *a, **kw):
@@ -28,6 +28,7 @@ def main():
         for feats, lab in it:
             if train:            # c13's log value is unique per record in the synthetic shards: a record fingerprint
                 seen.append(np.round(feats["cont_log"][:, 12].astype(np.float64) * 1e6).astype(np.int64))
+                trained.append((np.array(feats["ids"]), np.array(lab)))      # what this rank's step len(trained) - 1 trains on
             yield feats, lab
 
     driver.input_fn = spy
@@ -40,9 +41,21 @@ def main():
         made.append(self)
 
     E.Estimator.__init__ = init_spy
+    # the variables as model_fn creates them (before the first step): the parent replays the run through the oracle from here
+    init_vars = {}
+    real_build = E.VariableStore.build
+
+    def build_spy(self, embeddings, *a, **kw):
+        real_build(self, embeddings, *a, **kw)
+        if mod == "deepfm" and not init_vars:
+            ar = embeddings["input_layer"]
+            init_vars.update(tables=ar.tables.cpu().numpy().copy(), w1=ar.w1.cpu().numpy().copy(),
+                             **{k: p.detach().cpu().numpy().copy() for k, p in self.dense.params.items()})
+
+    E.VariableStore.build = build_spy
     res = m.main(["--train_path", data_dir, "--train_parts", "4", "--eval_parts", "1", "--batch_size", "64", "--model_dir",
                   model_dir, "--save_checkpoints_steps", "6", "--log_steps", "3", "--dropout", "0.0", "--learning_rate",
-                  "0.01", "--task_type", "train", "--num_epochs", "2", "--mirror", "true"])
+                  "0.001", "--task_type", "train", "--num_epochs", "2", "--mirror", "true"])
     # digest of every variable of this replica
     est = made[-1]
     h = hashlib.sha256()
@@ -53,6 +66,13 @@ def main():
         for kk, t in items:
             h.update(k.encode() + kk.encode())
             h.update(t.detach().cpu().contiguous().numpy().tobytes())
+    if mod == "deepfm":
+        ar = est.store.embeddings["input_layer"]
+        np.savez(os.path.join(out_dir, "vars_rank%d.npz" % rank),
+                 **{"init." + k: v for k, v in init_vars.items()},
+                 **{"final.tables": ar.tables.cpu().numpy(), "final.w1": ar.w1.cpu().numpy()},
+                 **{"final." + k: p.detach().cpu().numpy() for k, p in est.store.dense.params.items()},
+                 ids=np.stack([t[0] for t in trained]), labels=np.stack([t[1] for t in trained]))
     json.dump({"rank": rank, "digest": h.hexdigest(), "seen": np.concatenate(seen).tolist() if seen else [],
                "batches": len(seen), "res": {k: float(v) for k, v in res.items()}, "global_step": int(est.global_step)},
               open(os.path.join(out_dir, "rank%d.json" % rank), "w"))

@@ -68,3 +68,26 @@ def test_run_main_world2_disjoint_records_identical_replicas(tmp_path, mod):
     assert glob.glob(model_dir + "/model.ckpt-*.pt") and not glob.glob(model_dir + "/*.tmp*")
     # rank 1 stayed quiet
     assert "INFO:loss" in logs[0] and "INFO:loss" not in logs[1]
+    if mod != "deepfm":
+        return
+    # ... and the two real processes trained what the ORACLE trains from the same initial variables on the same per-rank batches
+    # (oracle.models.train_step_dp: MirroredStrategy's step -- per-replica batch-norm, losses scaled 1/N, dense gradients summed,
+    # IndexedSlices concatenated in replica order).  Two ranks that are identically WRONG pass the digest comparison above;
+    # they do not pass this one.
+    from oracle import criteo, models, nn
+    v = [np.load(out / ("vars_rank%d.npz" % k)) for k in range(2)]
+    for k in v[0].files:
+        if k.startswith("init."):
+            assert np.array_equal(v[0][k], v[1][k]), k            # same seed -> same initial variables on both ranks
+    steps = v[0]["ids"].shape[0]
+    assert steps == v[1]["ids"].shape[0] == r[0]["global_step"] and not np.array_equal(v[0]["ids"], v[1]["ids"])
+    P = {k[5:]: v[0][k].astype(np.float64) for k in v[0].files if k.startswith("init.")}
+    om = models.DeepFM(P, criteo.row_offsets(), 2, 0.0)
+    opt = nn.AdamTF1(lr=1e-3, dtype=np.float64)
+    for i in range(steps):
+        models.train_step_dp(om, opt, [(v[0]["ids"][i],), (v[1]["ids"][i],)],
+                             [v[0]["labels"][i].astype(np.float64).reshape(-1), v[1]["labels"][i].astype(np.float64).reshape(-1)])
+    err = {k: float(np.abs(v[0]["final." + k].astype(np.float64).reshape(P[k].shape) - P[k]).max()) for k in P}
+    assert max(err.values()) < 1e-4, err
+    moved = float(np.abs(v[0]["final.tables"] - v[0]["init.tables"]).max())
+    assert moved > 5e-3, moved                                     # (the variables did move: 18 steps at lr 1e-3)
