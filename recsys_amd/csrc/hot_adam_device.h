@@ -6,6 +6,7 @@
 #pragma once
 #include "rsx_common.h"
 #include "adam_device.h"
+#include <stdlib.h>
 
 struct SegPartials {
   const int32_t* segid;   // [F, stride] then [F] long- and [F] huge-segment counters (reset by the sort)
@@ -82,17 +83,87 @@ struct HotAdam {
 // run passes through (that was already so).
 // NR rows per LPR-lane group (1: batches up to 1024, where the launch is latency-bound -- more workgroups, shorter chains; 4
 // above), phase by phase (unique rows; all slot maps + the rows' state; the pending updates; stores).
+// window_pass_rows: the workgroup's rows are jbase + thread / LPR (+ i * 256 / LPR, i < NR) of field f in list li (tail step)
+// or in the next step's list.  Two ways of dealing the (list, field, row block) units to workgroups:
+//   window_pass          a dense grid sized for `max_unique` rows in EVERY field of every walked list (segsum_adam_k: lists of a
+//                        few hundred rows, the workgroups past a list's end leave at once);
+//   window_pass_compact  a fixed number of workgroups walk the COMPACT unit list with a grid stride (merged_adam_k, round 5:
+//                        the GLOBAL lists of a data-parallel step are bounded by min(N b, rows of the field) -- 2 048 at
+//                        8 x 256 -- while 25 of Criteo's 39 fields hold fewer than 1 500 rows: the dense grid of a window's
+//                        last step was 7 lists x 39 fields x 32 = 8 736 workgroups, most of them empty).
+template <int D, int NR>
+__device__ __forceinline__ void window_pass_rows(const HotAdam& h, const int li, const int f, const int jbase, const float b1p,
+                                                 const float b2p, const int stride);
+
 template <int D, int NR>
 __device__ __forceinline__ void window_pass(const HotAdam& h, const uint32_t wb, const float b1p, const float b2p,
-                                                 const int F, const int stride) {
-  constexpr int LPR = D / 4;
-  constexpr int WIN_NR = NR;
-  constexpr int RPW = 256 / LPR;
+                                            const int F, const int stride) {
+  constexpr int RPW = 256 / (D / 4);
   const uint32_t per_l = (uint32_t)F * h.win_per_f;
   const int li = (int)(wb / per_l);
   const uint32_t rem = wb - (uint32_t)li * per_l;
   const int f = (int)(rem / h.win_per_f);
-  const int j0 = (int)(rem - (uint32_t)f * h.win_per_f) * (RPW * WIN_NR) + (int)threadIdx.x / LPR;
+  window_pass_rows<D, NR>(h, li, f, (int)(rem - (uint32_t)f * h.win_per_f) * (RPW * NR), b1p, b2p, stride);
+}
+
+template <int D, int NR>
+__device__ __forceinline__ void window_pass_compact(const HotAdam& h, const uint32_t wb, const float b1p, const float b2p,
+                                                    const int F, const int stride) {
+  constexpr int RPB = (256 / (D / 4)) * NR;            // rows per workgroup unit
+  const int lane = threadIdx.x & 63;
+  const int cur = h.win_cur, wk = h.win_k;
+  const bool tail = cur == wk - 1;
+  const int nlists = tail ? wk - 1 : 1;
+  // lane f: inclusive unit count of fields 0 .. f of list l (all lists' counts in ONE round trip), and the lists' totals
+  int incl[RSX_ADAM_WINDOW_MAX - 1];
+  int ltot[RSX_ADAM_WINDOW_MAX - 1];
+  const int lc = lane < F ? lane : F - 1;
+#pragma unroll
+  for (int l = 0; l < RSX_ADAM_WINDOW_MAX - 1; ++l) {
+    const int o = tail ? (l < nlists ? l : 0) : cur + 1;
+    const int nu = h.win_nuniq[o][lc];
+    incl[l] = (lane < F && l < nlists) ? (nu + RPB - 1) / RPB : 0;
+  }
+#pragma unroll
+  for (int l = 0; l < RSX_ADAM_WINDOW_MAX - 1; ++l) {
+#pragma unroll
+    for (int d = 1; d < RSX_WAVE; d <<= 1) {
+      const int t = __shfl_up(incl[l], d);
+      if (lane >= d) incl[l] += t;
+    }
+    ltot[l] = __shfl(incl[l], RSX_WAVE - 1);
+  }
+  int total = 0;
+#pragma unroll
+  for (int l = 0; l < RSX_ADAM_WINDOW_MAX - 1; ++l) total += ltot[l];
+  for (int u = (int)wb; u < total; u += (int)h.win_blk) {          // (block-uniform)
+    int li = 0, base = 0, inc_l = incl[0];
+#pragma unroll
+    for (int l = 1; l < RSX_ADAM_WINDOW_MAX - 1; ++l) {
+      int below = 0;
+#pragma unroll
+      for (int m = 0; m < l; ++m) below += ltot[m];
+      if (u >= below && l < nlists) {
+        li = l;
+        base = below;
+        inc_l = incl[l];
+      }
+    }
+    const int v = u - base;
+    const int f = __popcll(__ballot(inc_l <= v));      // (lanes >= F hold the list's total, which v never reaches)
+    const int bf = __shfl(inc_l, f > 0 ? f - 1 : 0);
+    window_pass_rows<D, NR>(h, li, f, (v - (f > 0 ? bf : 0)) * RPB, b1p, b2p, stride);
+  }
+}
+
+template <int D, int NR>
+__device__ __forceinline__ void window_pass_rows(const HotAdam& h, const int li, const int f, const int jbase, const float b1p,
+                                                 const float b2p, const int stride) {
+  constexpr int LPR = D / 4;
+  constexpr int WIN_NR = NR;
+  constexpr int RPW = 256 / LPR;
+  const uint32_t wb = (uint32_t)jbase;                 // (profiling stamps only)
+  const int j0 = jbase + (int)threadIdx.x / LPR;
   const int q = (int)threadIdx.x % LPR;
   const int cur = h.win_cur, wk = h.win_k;
   const bool tail = cur == wk - 1;
@@ -306,7 +377,12 @@ static inline int hot_adam_init(HotAdam& h, float* tables, float* m_t, float* v_
     h.win_k = win_h->k; h.win_cur = win_h->cur;
     // rows per lane group: the lazy pass applies up to 8 updates per row back to back -- one row per group (more workgroups,
     // shorter chains) where the launch is latency-bound, four at large batches
-    h.win_nr = win_h->max_unique > 1024 ? 4 : 1;
+    {
+      // (measured, round 5: deepfm.py as 8 emulated ranks -- lists of up to 2 048 rows -- 0.0977 ms per step with four rows
+      // per group, 0.0911 with one; dcn.py at 8 x 4 096 -- up to 32 768 -- 0.311 with four, 0.337 with one.  RSX_WIN_NR4_MIN: A/B knob)
+      static const int nr4_min = getenv("RSX_WIN_NR4_MIN") ? atoi(getenv("RSX_WIN_NR4_MIN")) : 2048;
+      h.win_nr = win_h->max_unique > nr4_min ? 4 : 1;
+    }
     const int rpw = h.win_nr * 256 / (D / 4);
     h.win_per_f = (uint32_t)((win_h->max_unique + rpw - 1) / rpw);
     // lists walked: the next step's, or -- the window's last step -- every earlier one

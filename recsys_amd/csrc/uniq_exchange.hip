@@ -121,15 +121,22 @@ __global__ __launch_bounds__(T) void uniq_merge_k(const UxMerge a) {
   const int g0 = a.goff[f];
   const int32_t* kb = a.keys + (size_t)job * a.job_stride;
   for (int w = tid; w < W; w += T) bm[w] = 0u;
+  // the N lists as ONE index space (entry e of the concatenation): every load of the marking pass is independent of the others
+  // -- a loop over the ranks around it made 8 dependent round trips of it
+  int cum[UX_MAX_RANKS + 1];
+  cum[0] = 0;
+#pragma unroll
+  for (int rr = 0; rr < UX_MAX_RANKS; ++rr) cum[rr + 1] = cum[rr] + (rr < a.N ? kb[(size_t)rr * a.rank_stride + f] : 0);
   __syncthreads();
-  for (int rr = 0; rr < a.N; ++rr) {
-    const int32_t* kr = kb + (size_t)rr * a.rank_stride;
-    const int nu = kr[f];
-    const int32_t* xr = kr + a.F + g0;
-    for (int i = tid; i < nu; i += T) {
-      const uint32_t x = (uint32_t)(xr[i] - row0);
-      atomicOr(&bm[x >> 5], 1u << (x & 31u));
-    }
+  for (int e = tid; e < cum[UX_MAX_RANKS]; e += T) {
+    int rr = 0;
+#pragma unroll
+    for (int k = 1; k < UX_MAX_RANKS; ++k) rr += e >= cum[k] ? 1 : 0;
+    int base = 0;
+#pragma unroll
+    for (int k = 1; k < UX_MAX_RANKS; ++k) base = k == rr ? cum[k] : base;
+    const uint32_t x = (uint32_t)(kb[(size_t)rr * a.rank_stride + a.F + g0 + (e - base)] - row0);
+    atomicOr(&bm[x >> 5], 1u << (x & 31u));
   }
   __syncthreads();
   // exclusive prefix of the words' popcounts: a contiguous run of words per thread, then a block scan of the run totals
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256) void merged_adam_k(const UxSrc ms, const int32
   } else if (blockIdx.x >= n_rows + h.win_blk) {
     adam_block(h.extra.args, h.extra.blk_lo + (blockIdx.x - n_rows - h.win_blk));
   } else if (blockIdx.x >= n_rows) {
-    window_pass<D, NR>(h, blockIdx.x - n_rows, b1p, b2p, F, stride);
+    window_pass_compact<D, NR>(h, blockIdx.x - n_rows, b1p, b2p, F, stride);
   } else if (blockIdx.x >= h.n_own) {
     merged_rows<D, true>(ms, h, uniq_row, nuniq, 0ull, F, stride, blockIdx.x - h.n_own, b1p, b2p);
   } else {
@@ -399,6 +406,9 @@ extern "C" int rsx_merged_adam_rows(float* tables, float* m_t, float* v_t, float
     h.tables2 = second_h->tables; h.m_t2 = second_h->m; h.v_t2 = second_h->v; h.dX2 = second_h->dX;
     ms.G2 = second_h->dX;
   }
+  // the window pass walks the COMPACT unit list of the lists it visits with a grid stride (window_pass_compact): at most as
+  // many workgroups as the dense grid would have, and never more than a launch-full
+  if (h.win_blk > 768u) h.win_blk = 768u;
   const long long wgs = ((long long)max_units + 3) / 4;
   h.n_own = (uint32_t)(wgs < 1024 ? wgs : 1024);                 // (grid stride over the compact unit list)
   h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.win_blk + h.extra.n_blk + h.cold.n_blk;
