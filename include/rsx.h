@@ -357,6 +357,7 @@ int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, float* w1, floa
  * goff [F + 1] (device): cap_f = goff[f+1] - goff[f] >= the unique rows ONE rank can have in field f -- min(batch, rows of the
  * field) -- and capT = goff[F].                                                                                          */
 #define RSX_UNIQ_MAX_RANKS 8
+#define RSX_UNIQ_MAX_PARTS 64     /* row-range parts per field of the merge (one bitmap word range each; one lane each) */
 /* The same sorted segment-sum as rsx_segsum_bwd, unique row j of field f written at row goff[f] + j of G / gw1 (the rank's
  * block of the exchange) instead of f * stride + j.  Two-stage (partials_h): stage A must have been given its own full-stride
  * G / gw1 scratch (RSX_EINVAL when partials_h->G == G).  null_row as in rsx_segsum_partials.                               */
@@ -364,14 +365,19 @@ int rsx_segsum_bwd_packed(const float* tables, const float* S, const float* dX, 
                           const int32_t* perm, const int32_t* seg_off, const int32_t* uniq_row, const int32_t* nuniq,
                           float* G, float* gw1, uint64_t w1_field_mask, int B, int F, int D, int stride, int null_row,
                           const rsx_seg_partials* partials_h, const int32_t* goff, rsx_stream_t stream);
-/* keys[0 .. F) = nuniq, keys[F + goff[f] + j] = uniq_row[f, j] (j < nuniq[f]; -1 up to cap_f) for the LOCAL sort outputs of
- * up to RSX_ADAM_WINDOW_MAX batches (an optimizer window) in one launch.                                                 */
+/* The key block of a rank's batch, [F + F (parts + 1) + capT] int32:  keys[0 .. F) = nuniq;  keys[F + f (parts + 1) + p] = the
+ * first position of field f's (ascending) list whose row lies in row-range part p or above, p = 0 .. parts (part p = rows
+ * [p rpp, (p + 1) rpp) of the field, rpp = ceil(rows_f / parts) rounded up to 32; entry `parts` = nuniq[f]) -- the merge's part
+ * workgroups go straight to their sub-range of every rank's list;  then keys[F + F (parts + 1) + goff[f] + j] = uniq_row[f, j]
+ * (j < nuniq[f]; -1 up to cap_f).  For the LOCAL sort outputs of up to RSX_ADAM_WINDOW_MAX batches (an optimizer window) in one
+ * launch.  parts: 1 .. RSX_UNIQ_MAX_PARTS, the same value rsx_uniq_merge is given.                                        */
 typedef struct {
   const int32_t* uniq_row;    /* [F, stride]: rsx_field_sort's output for the rank's own batch */
   const int32_t* nuniq;       /* [F] */
   int32_t* keys;              /* out: [F + capT] */
 } rsx_uniq_pack_job;
-int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, int F, int stride, rsx_stream_t stream);
+int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, const int32_t* row_off, int F, int stride,
+                  int parts, rsx_stream_t stream);
 /* The N ranks' key blocks -> what rsx_field_sort leaves for the GLOBAL batch, without a global sort: per job (a batch of
  * the window) the global unique rows of every field in ascending order (uniq_row [F, stride], nuniq [F]), the slot map (row
  * -> f * stride + j for touched rows; the entries of the workspace's PREVIOUS contents are reset to -1 first, so uniq_row /
@@ -379,7 +385,10 @@ int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* gof
  * global unique row j in rank r's list, or -1.  keys: rank r's block of job k at keys + r * rank_stride + k * job_stride
  * (int32 units), as an all-gather of the ranks' packed blocks leaves them.  stride >= the global unique rows of any field
  * (min(N * batch, rows of the field)).  max_rows_per_field: the largest field's row count (a presence bitmap of it lives
- * in LDS: RSX_EUNSUPPORTED beyond ~650 000 rows); max_entries: N * the largest cap_f (launch shape only).
+ * in LDS: RSX_EUNSUPPORTED beyond ~650 000 rows per part); max_entries: N * the largest cap_f (launch shape only).
+ * parts > 1 (long lists: dcn.py at 8 x 4 096, din.py's item table): every field's row range is cut into `parts` ranges merged by
+ * their own workgroups -- a count pass (distinct rows per part -> part_counts [njobs][F * parts] int32, caller-owned; it also
+ * resets the previous slot entries) and an emit pass, two launches; parts == 1: one launch, part_counts unused.
  * N <= RSX_UNIQ_MAX_RANKS.  Deterministic.                                                                              */
 typedef struct {
   int32_t* uniq_row;          /* in/out [F, stride] */
@@ -388,8 +397,8 @@ typedef struct {
   int32_t* src;               /* out [N][F, stride] */
 } rsx_uniq_merge_job;
 int rsx_uniq_merge(const int32_t* keys, long long rank_stride, int job_stride, const rsx_uniq_merge_job* jobs_h, int njobs,
-                   const int32_t* goff, const int32_t* row_off, int max_rows_per_field, int max_entries, int F, int N,
-                   int stride, rsx_stream_t stream);
+                   const int32_t* goff, const int32_t* row_off, int32_t* part_counts, int parts, int max_rows_per_field,
+                   int max_entries, int F, int N, int stride, rsx_stream_t stream);
 /* The optimizer launch of the exchange: rsx_segsum_adam_rows2 with the gradient of global unique row (f, j) taken from the
  * ranks' lists -- sum over r = 0 .. N-1, IN RANK ORDER (every replica adds the same numbers in the same order: replicas stay
  * bit-identical), of G_r[goff[f] + src[r][f, j]] over the ranks with src >= 0; G_r = G + r * rank_stride floats (rank 0's
@@ -922,6 +931,14 @@ int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16,
                               rsx_stream_t stream);
 int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
                         const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+/* The weight gradients as a K-split GEMM tile (round 5): workgroup = 2 fields x 64 h x all n-tiles x one of S slices of the batch,
+ * the dpre fragments staged through LDS once per workgroup, the S partial tiles written to part_h[k] (one
+ * rsx_cin_bf16_dw_split_floats(F, H, N, S) buffer per job) and added in slice order by a second small launch.  Same contract as
+ * rsx_cin_bwd_dw_bf16 otherwise; the batch sum is associated differently (slices), within the bf16 path's tolerance.
+ * F * H * N must be a multiple of 4 (RSX_EUNSUPPORTED otherwise: use rsx_cin_bwd_dw_bf16).  1 <= S <= 8.                 */
+size_t rsx_cin_bf16_dw_split_floats(int F, int H, int N, int S);
+int rsx_cin_bwd_dw_bf16_split(const float* X0, const rsx_cin_dw_job* jobs_h, float* const* part_h, int njobs, int B, int F,
+                              int D, int S, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
                             int F, rsx_stream_t stream);
 

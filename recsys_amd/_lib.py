@@ -102,7 +102,7 @@ class UniqMergeJob(C.Structure):          # include/rsx.h rsx_uniq_merge_job
     _fields_ = [("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("slot", C.c_void_p), ("src", C.c_void_p)]
 
 
-UNIQ_MAX_RANKS = 8
+UNIQ_MAX_RANKS, UNIQ_MAX_PARTS = 8, 64
 
 
 class SortJob(C.Structure):
@@ -166,8 +166,8 @@ _SIGS = {
                                    _I, _I, _P]),
     "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
     "rsx_segsum_bwd_packed": (_I, [_P] * 11 + [_U64, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "rsx_uniq_pack": (_I, [C.POINTER(UniqPackJob), _I, _P, _I, _I, _P]),
-    "rsx_uniq_merge": (_I, [_P, C.c_longlong, _I, C.POINTER(UniqMergeJob), _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rsx_uniq_pack": (_I, [C.POINTER(UniqPackJob), _I, _P, _P, _I, _I, _I, _P]),
+    "rsx_uniq_merge": (_I, [_P, C.c_longlong, _I, C.POINTER(UniqMergeJob), _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rsx_merged_adam_rows": (_I, [_P] * 8 + [C.c_longlong, _I, _P, _P, _P, _P, _U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I,
                                   _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _I, _P]),
     "rsx_adam_num_blocks": (C.c_int64, [C.POINTER(AdamSeg), _I]),
@@ -215,6 +215,8 @@ _SIGS = {
     "rsx_cin_layer_bwd_dx_bf16": (_I, [_P] * 8 + [_I, _P, _I, _P] + [_I] * 5 + [_P, _P]),
     "rsx_cin_bwd_dw_bf16": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _P, _P]),
     "rsx_cin_prep_bf16_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "rsx_cin_bf16_dw_split_floats": (C.c_size_t, [_I, _I, _I, _I]),
+    "rsx_cin_bwd_dw_bf16_split": (_I, [_P, C.POINTER(CinDwJob), _P, _I, _I, _I, _I, _I, _P, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd_lin": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -59,6 +59,7 @@ struct HotAdam {
   const int32_t* win_slot[RSX_ADAM_WINDOW_MAX];
   uint32_t win_blk, win_per_f;           // workgroups of the pass; per (list, field)
   int win_nr;                            // rows per lane group in the pass: 1 (batches up to 1024) or 4
+  int win_compact;                       // window_pass_compact (grid stride over the compact unit list) instead of the dense grid
 };
 
 #ifndef RSX_WIN_PASS_NT
@@ -365,7 +366,7 @@ static inline int hot_adam_init(HotAdam& h, float* tables, float* m_t, float* v_
     const bool overlaps = b0 < h.cold.blk_lo + h.cold.n_blk && h.cold.blk_lo < b1;     // segment k has blocks in the slice
     if (overlaps && h.cold.args.seg[k].kind != RSX_ADAM_TABLE_TF1_COLD) return RSX_EINVAL;
   }
-  h.win_k = 0; h.win_cur = 0; h.win_blk = 0; h.win_per_f = 0; h.win_nr = 1;
+  h.win_k = 0; h.win_cur = 0; h.win_blk = 0; h.win_per_f = 0; h.win_nr = 1; h.win_compact = 0;
   for (int i = 0; i < RSX_ADAM_WINDOW_MAX; ++i) h.win_uniq[i] = h.win_nuniq[i] = h.win_slot[i] = nullptr;
   if (win_h != nullptr && win_h->k > 1) {
     if (win_h->k > RSX_ADAM_WINDOW_MAX || win_h->cur < 0 || win_h->cur >= win_h->k || win_h->max_unique <= 0) return RSX_EINVAL;

@@ -36,9 +36,16 @@ struct UxPack {
   const int32_t* nuniq[UX_MAX_JOBS];
   int32_t* keys[UX_MAX_JOBS];
   const int32_t* goff;
-  int F, stride;
+  const int32_t* row_off;
+  int F, stride, P;
 };
 
+// rows of field f owned by one of the P row-range PARTS of the merge (a multiple of 32: parts own whole bitmap words)
+__host__ __device__ __forceinline__ int ux_rows_per_part(int rows, int P) { return ((rows + P - 1) / P + 31) & ~31; }
+
+// key block = [nuniq[F] | rstart[F][P + 1] | rows packed at goff]: rstart[f][p] = first position of the (ascending) list whose
+// row lies in part p or above (rstart[f][P] = nuniq[f]) -- the rank that owns the list finds these boundaries for free while it
+// copies it, so that the merge's part workgroups go straight to their sub-ranges of every rank's list.
 __global__ __launch_bounds__(256) void uniq_pack_k(const UxPack a) {
   const int f = blockIdx.x, job = blockIdx.y, tid = threadIdx.x;
   const int32_t* ur = a.uniq_row[0];
@@ -53,26 +60,37 @@ __global__ __launch_bounds__(256) void uniq_pack_k(const UxPack a) {
     }
   }
   const int g0 = a.goff[f], cap = a.goff[f + 1] - g0;
-  const int nu = nq[f];
-  if (tid == 0) keys[f] = nu < cap ? nu : cap;
+  const int nu0 = nq[f];
+  const int nu = nu0 < cap ? nu0 : cap;
+  if (tid == 0) keys[f] = nu;
   ur += (size_t)f * a.stride;
-  keys += a.F + g0;
-  for (int j = tid; j < cap; j += 256) {
+  const int row0 = a.row_off[f];
+  const int rpp = ux_rows_per_part(a.row_off[f + 1] - row0, a.P);
+  int32_t* rs = keys + a.F + f * (a.P + 1);
+  int32_t* out = keys + a.F + a.F * (a.P + 1) + g0;
+  for (int j = tid; j < cap + 1; j += 256) {
     const int32_t r = ur[j < nu ? j : 0];
-    keys[j] = j < nu ? r : -1;
+    if (j < cap) out[j] = j < nu ? r : -1;
+    if (j <= nu) {                                // boundaries crossed between entries j - 1 and j (j == nu: the list's end)
+      const int pj = j < nu ? (r - row0) / rpp : a.P;
+      const int pp = j > 0 ? (ur[j - 1] - row0) / rpp : -1;
+      for (int q = pp + 1; q <= pj; ++q) rs[q] = j;
+    }
   }
 }
 
-extern "C" int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, int F, int stride,
-                             rsx_stream_t stream) {
-  if (!jobs_h || njobs < 1 || njobs > UX_MAX_JOBS || !goff || F <= 0 || F > 64 || stride <= 0) return RSX_EINVAL;
+extern "C" int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, const int32_t* row_off, int F,
+                             int stride, int parts, rsx_stream_t stream) {
+  if (!jobs_h || njobs < 1 || njobs > UX_MAX_JOBS || !goff || !row_off || F <= 0 || F > 64 || stride <= 0 || parts < 1 ||
+      parts > RSX_UNIQ_MAX_PARTS)
+    return RSX_EINVAL;
   UxPack a;
   for (int k = 0; k < UX_MAX_JOBS; ++k) {
     const rsx_uniq_pack_job& j = jobs_h[k < njobs ? k : 0];
     if (!j.uniq_row || !j.nuniq || !j.keys) return RSX_EINVAL;
     a.uniq_row[k] = j.uniq_row; a.nuniq[k] = j.nuniq; a.keys[k] = j.keys;
   }
-  a.goff = goff; a.F = F; a.stride = stride;
+  a.goff = goff; a.row_off = row_off; a.F = F; a.stride = stride; a.P = parts;
   RSX_LAUNCH(uniq_pack_k, dim3((unsigned)F, (unsigned)njobs), dim3(256), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
@@ -89,7 +107,9 @@ struct UxMerge {
   int32_t* src[UX_MAX_JOBS];    // [N][F * stride]
   const int32_t* goff;
   const int32_t* row_off;
-  int F, N, stride, wmax;       // wmax: bitmap words of the largest field (the LDS layout)
+  int32_t* cnt;                 // [jobs][F * P]: distinct rows per (field, part) -- written by the count pass (P > 1)
+  int F, N, stride, wmax;       // wmax: bitmap words of the largest field (or part: the LDS layout)
+  int P;                        // row-range parts per field (1: uniq_merge_k alone; > 1: uniq_merge_count_k + uniq_merge_part_k)
 };
 
 // Workgroup (f, r, job): builds the union bitmap of field f over all N lists (every workgroup of the field does -- N x the
@@ -128,6 +148,7 @@ __global__ __launch_bounds__(T) void uniq_merge_k(const UxMerge a) {
 #pragma unroll
   for (int rr = 0; rr < UX_MAX_RANKS; ++rr) cum[rr + 1] = cum[rr] + (rr < a.N ? kb[(size_t)rr * a.rank_stride + f] : 0);
   __syncthreads();
+  const int roff = a.F + a.F * (a.P + 1) + g0;     // this field's rows inside a key block
   for (int e = tid; e < cum[UX_MAX_RANKS]; e += T) {
     int rr = 0;
 #pragma unroll
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(T) void uniq_merge_k(const UxMerge a) {
     int base = 0;
 #pragma unroll
     for (int k = 1; k < UX_MAX_RANKS; ++k) base = k == rr ? cum[k] : base;
-    const uint32_t x = (uint32_t)(kb[(size_t)rr * a.rank_stride + a.F + g0 + (e - base)] - row0);
+    const uint32_t x = (uint32_t)(kb[(size_t)rr * a.rank_stride + roff + (e - base)] - row0);
     atomicOr(&bm[x >> 5], 1u << (x & 31u));
   }
   __syncthreads();
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(T) void uniq_merge_k(const UxMerge a) {
   {
     const int32_t* kr = kb + (size_t)r * a.rank_stride;
     const int nu = kr[f];
-    const int32_t* xr = kr + a.F + g0;
+    const int32_t* xr = kr + roff;
     for (int i = tid; i < nu; i += T) {
       const uint32_t x = (uint32_t)(xr[i] - row0);
       const uint32_t g = pre[x >> 5] + (uint32_t)__popc(bm[x >> 5] & ((1u << (x & 31u)) - 1u));
@@ -201,11 +222,190 @@ __global__ __launch_bounds__(T) void uniq_merge_k(const UxMerge a) {
   if (tid == 0) nq[f] = (int)total;
 }
 
+// ---- the merge with P row-range parts per field (long lists: dcn.py at 8 x 4 096 -- 32 768 entries per hashed field -- and
+// din.py's item table: 8 x ~45 000 entries in ONE field, which a single workgroup per (field, rank) marks in ~100 us) ---------
+// Part p of field f owns rows [p rpp, (p + 1) rpp) and finds its entries of every rank's list through rstart (uniq_pack_k).
+//   uniq_merge_count_k   workgroup (f, p, job): marks its range from all N lists, counts the distinct rows -> cnt[job][f P + p];
+//                        also resets this workspace's PREVIOUS slot entries (its share of the old list): the emit pass of another
+//                        part may write a new entry for the same row, so the reset cannot live in the emit launch
+//   uniq_merge_part_k    workgroup (f P + p, r, job): marks again, prefix of its range + the counts of the parts below = global
+//                        unique index; writes rank r's column of src for its range; r == 0 publishes the range's rows + slots
+template <int T>
+__device__ __forceinline__ uint32_t ux_mark_part(const UxMerge& a, const int32_t* kb, const int f, const int p, const int row0,
+                                                 const int rlo, uint32_t* bm, const int W) {
+  const int tid = threadIdx.x;
+  for (int w = tid; w < W; w += T) bm[w] = 0u;
+  int cum[UX_MAX_RANKS + 1], lo[UX_MAX_RANKS];
+  cum[0] = 0;
+#pragma unroll
+  for (int rr = 0; rr < UX_MAX_RANKS; ++rr) {
+    const int32_t* rs = kb + (size_t)(rr < a.N ? rr : 0) * a.rank_stride + a.F + f * (a.P + 1) + p;
+    const int b0 = rs[0], b1 = rs[1];
+    lo[rr] = b0;
+    cum[rr + 1] = cum[rr] + (rr < a.N ? b1 - b0 : 0);
+  }
+  __syncthreads();
+  const int roff = a.F + a.F * (a.P + 1) + a.goff[f];
+  for (int e = tid; e < cum[UX_MAX_RANKS]; e += T) {
+    int rr = 0;
+#pragma unroll
+    for (int k = 1; k < UX_MAX_RANKS; ++k) rr += e >= cum[k] ? 1 : 0;
+    int base = 0, l0 = lo[0];
+#pragma unroll
+    for (int k = 1; k < UX_MAX_RANKS; ++k) {
+      base = k == rr ? cum[k] : base;
+      l0 = k == rr ? lo[k] : l0;
+    }
+    const uint32_t x = (uint32_t)(kb[(size_t)rr * a.rank_stride + roff + l0 + (e - base)] - row0 - rlo);
+    atomicOr(&bm[x >> 5], 1u << (x & 31u));
+  }
+  __syncthreads();
+  return (uint32_t)cum[UX_MAX_RANKS];
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void uniq_merge_count_k(const UxMerge a) {
+  extern __shared__ uint32_t ux_lds[];
+  uint32_t* bm = ux_lds;
+  uint32_t* wsum = ux_lds + a.wmax;
+  const int f = blockIdx.x, p = blockIdx.y, job = blockIdx.z, tid = threadIdx.x;
+  int32_t* ur = a.uniq_row[0];
+  int32_t* nq = a.nuniq[0];
+  int32_t* slot = a.slot[0];
+#pragma unroll
+  for (int k = 1; k < UX_MAX_JOBS; ++k) {
+    if (k == job) {
+      ur = a.uniq_row[k];
+      nq = a.nuniq[k];
+      slot = a.slot[k];
+    }
+  }
+  const int row0 = a.row_off[f], rows = a.row_off[f + 1] - row0;
+  const int rpp = ux_rows_per_part(rows, a.P);
+  const int rlo = p * rpp;
+  const int rn = rows - rlo < rpp ? (rows - rlo > 0 ? rows - rlo : 0) : rpp;
+  const int W = (rn + 31) >> 5;
+  // the previous list's slot entries, this part's share of it
+  {
+    const int prev = nq[f];
+    const int32_t* uf = ur + (size_t)f * a.stride;
+    const int j0 = (int)((long long)prev * p / a.P), j1 = (int)((long long)prev * (p + 1) / a.P);
+    for (int j = j0 + tid; j < j1; j += T) slot[uf[j]] = -1;
+  }
+  const int32_t* kb = a.keys + (size_t)job * a.job_stride;
+  ux_mark_part<T>(a, kb, f, p, row0, rlo, bm, W);
+  uint32_t c = 0;
+  for (int w = tid; w < W; w += T) c += (uint32_t)__popc(bm[w]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+  if ((tid & 63) == 0) wsum[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t t = 0;
+    for (int k = 0; k < T / 64; ++k) t += wsum[k];
+    a.cnt[(size_t)job * a.F * a.P + f * a.P + p] = (int32_t)t;
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void uniq_merge_part_k(const UxMerge a) {
+  extern __shared__ uint32_t ux_lds[];
+  uint32_t* bm = ux_lds;
+  uint32_t* pre = ux_lds + a.wmax;
+  uint32_t* wsum = pre + a.wmax;
+  const int f = blockIdx.x / a.P, p = blockIdx.x - f * a.P, r = blockIdx.y, job = blockIdx.z, tid = threadIdx.x;
+  int32_t* ur = a.uniq_row[0];
+  int32_t* nq = a.nuniq[0];
+  int32_t* slot = a.slot[0];
+  int32_t* src = a.src[0];
+#pragma unroll
+  for (int k = 1; k < UX_MAX_JOBS; ++k) {
+    if (k == job) {
+      ur = a.uniq_row[k];
+      nq = a.nuniq[k];
+      slot = a.slot[k];
+      src = a.src[k];
+    }
+  }
+  const int row0 = a.row_off[f], rows = a.row_off[f + 1] - row0;
+  const int rpp = ux_rows_per_part(rows, a.P);
+  const int rlo = p * rpp;
+  const int rn = rows - rlo < rpp ? (rows - rlo > 0 ? rows - rlo : 0) : rpp;
+  const int W = (rn + 31) >> 5;
+  const int32_t* kb = a.keys + (size_t)job * a.job_stride;
+  // distinct rows of the parts below (and of the whole field): one load per lane of the first wave's worth, every wave alike
+  const int lane = tid & 63, wave = tid >> 6;
+  const int32_t* cf = a.cnt + (size_t)job * a.F * a.P + f * a.P;
+  const int cv = lane < a.P ? cf[lane] : 0;
+  int below = lane < p ? cv : 0, all = cv;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    below += __shfl_xor(below, d);
+    all += __shfl_xor(all, d);
+  }
+  ux_mark_part<T>(a, kb, f, p, row0, rlo, bm, W);
+  const int per = (W + T - 1) / T;
+  const int w0 = tid * per, w1 = w0 + per < W ? w0 + per : W;
+  uint32_t run = 0;
+  for (int w = w0; w < w1; ++w) run += (uint32_t)__popc(bm[w]);
+  uint32_t incl = run;
+#pragma unroll
+  for (int d = 1; d < RSX_WAVE; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == RSX_WAVE - 1) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < T / 64; ++k) {
+    const uint32_t sv = wsum[k];
+    base += k < wave ? sv : 0u;
+    total += sv;
+  }
+  uint32_t q = base + incl - run;
+  for (int w = w0; w < w1; ++w) {
+    pre[w] = q;
+    q += (uint32_t)__popc(bm[w]);
+  }
+  __syncthreads();
+  int32_t* sr = src + ((size_t)r * a.F + f) * a.stride + below;
+  for (uint32_t j = tid; j < total; j += T) sr[j] = -1;
+  __syncthreads();
+  {
+    const int32_t* kr = kb + (size_t)r * a.rank_stride;
+    const int32_t* rs = kr + a.F + f * (a.P + 1) + p;
+    const int i0 = rs[0], i1 = rs[1];
+    const int32_t* xr = kr + a.F + a.F * (a.P + 1) + a.goff[f];
+    for (int i = i0 + tid; i < i1; i += T) {
+      const uint32_t x = (uint32_t)(xr[i] - row0 - rlo);
+      const uint32_t g = pre[x >> 5] + (uint32_t)__popc(bm[x >> 5] & ((1u << (x & 31u)) - 1u));
+      sr[g] = i;
+    }
+  }
+  if (r != 0) return;
+  int32_t* uf = ur + (size_t)f * a.stride + below;
+  for (int w = tid; w < W; w += T) {
+    uint32_t bits = bm[w];
+    uint32_t g = pre[w];
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      const int row = row0 + rlo + (w << 5) + b;
+      uf[g] = row;
+      slot[row] = f * a.stride + below + (int)g;
+      ++g;
+    }
+  }
+  if (p == 0 && tid == 0) nq[f] = all;
+}
+
 extern "C" int rsx_uniq_merge(const int32_t* keys, long long rank_stride, int job_stride, const rsx_uniq_merge_job* jobs_h,
-                              int njobs, const int32_t* goff, const int32_t* row_off, int max_rows_per_field, int max_entries,
-                              int F, int N, int stride, rsx_stream_t stream) {
+                              int njobs, const int32_t* goff, const int32_t* row_off, int32_t* part_counts, int parts,
+                              int max_rows_per_field, int max_entries, int F, int N, int stride, rsx_stream_t stream) {
   if (!keys || !jobs_h || njobs < 1 || njobs > UX_MAX_JOBS || !goff || !row_off || F <= 0 || F > 64 || N < 1 ||
-      N > UX_MAX_RANKS || stride <= 0 || max_rows_per_field <= 0 || rank_stride < (long long)njobs * job_stride)
+      N > UX_MAX_RANKS || stride <= 0 || max_rows_per_field <= 0 || rank_stride < (long long)njobs * job_stride || parts < 1 ||
+      parts > RSX_UNIQ_MAX_PARTS || (parts > 1 && !part_counts))
     return RSX_EINVAL;
   UxMerge a;
   a.keys = keys; a.rank_stride = rank_stride; a.job_stride = job_stride;
@@ -214,29 +414,44 @@ extern "C" int rsx_uniq_merge(const int32_t* keys, long long rank_stride, int jo
     if (!j.uniq_row || !j.nuniq || !j.slot || !j.src) return RSX_EINVAL;
     a.uniq_row[k] = j.uniq_row; a.nuniq[k] = j.nuniq; a.slot[k] = j.slot; a.src[k] = j.src;
   }
-  a.goff = goff; a.row_off = row_off; a.F = F; a.N = N; a.stride = stride;
-  a.wmax = (max_rows_per_field + 31) / 32;
-  // few entries per field (small batches): 256 threads; else 1024
-  const bool big = max_entries > 2048;
+  a.goff = goff; a.row_off = row_off; a.cnt = part_counts; a.F = F; a.N = N; a.stride = stride; a.P = parts;
+  a.wmax = (ux_rows_per_part(max_rows_per_field, parts) + 31) / 32;
+  // few entries per workgroup (small batches): 256 threads; else 1024
+  const bool big = max_entries / parts > 2048;
   const int T = big ? 1024 : 256;
   const size_t lds = ((size_t)2 * a.wmax + T / 64) * sizeof(uint32_t);
-  if (lds > 160 * 1024) return RSX_EUNSUPPORTED;          // a field of more than ~650 000 rows: the caller keeps the example exchange
-  const dim3 grid((unsigned)F, (unsigned)N, (unsigned)njobs);
-  if (big) {
-    if (lds > 64 * 1024) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(uniq_merge_k<1024>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (attr != hipSuccess) return RSX_EUNSUPPORTED;
-    }
-    RSX_LAUNCH(uniq_merge_k<1024>, grid, dim3(1024), lds, rsx_s(stream), a);
-  } else {
-    if (lds > 64 * 1024) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(uniq_merge_k<256>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (attr != hipSuccess) return RSX_EUNSUPPORTED;
-    }
-    RSX_LAUNCH(uniq_merge_k<256>, grid, dim3(256), lds, rsx_s(stream), a);
+  if (lds > 160 * 1024) return RSX_EUNSUPPORTED;          // a field of more than ~650 000 rows per part: the caller keeps the example exchange
+#define UX_BIG_LDS(K)                                                                                                   \
+  if (lds > 64 * 1024) {                                                                                                \
+    static const hipError_t attr =                                                                                      \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    if (attr != hipSuccess) return RSX_EUNSUPPORTED;                                                                    \
   }
+  if (parts == 1) {
+    const dim3 grid((unsigned)F, (unsigned)N, (unsigned)njobs);
+    if (big) {
+      UX_BIG_LDS(uniq_merge_k<1024>)
+      RSX_LAUNCH(uniq_merge_k<1024>, grid, dim3(1024), lds, rsx_s(stream), a);
+    } else {
+      UX_BIG_LDS(uniq_merge_k<256>)
+      RSX_LAUNCH(uniq_merge_k<256>, grid, dim3(256), lds, rsx_s(stream), a);
+    }
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+  }
+  const dim3 gc((unsigned)F, (unsigned)parts, (unsigned)njobs), gp((unsigned)(F * parts), (unsigned)N, (unsigned)njobs);
+  if (big) {
+    UX_BIG_LDS(uniq_merge_count_k<1024>)
+    UX_BIG_LDS(uniq_merge_part_k<1024>)
+    RSX_LAUNCH(uniq_merge_count_k<1024>, gc, dim3(1024), lds, rsx_s(stream), a);
+    RSX_LAUNCH(uniq_merge_part_k<1024>, gp, dim3(1024), lds, rsx_s(stream), a);
+  } else {
+    UX_BIG_LDS(uniq_merge_count_k<256>)
+    UX_BIG_LDS(uniq_merge_part_k<256>)
+    RSX_LAUNCH(uniq_merge_count_k<256>, gc, dim3(256), lds, rsx_s(stream), a);
+    RSX_LAUNCH(uniq_merge_part_k<256>, gp, dim3(256), lds, rsx_s(stream), a);
+  }
+#undef UX_BIG_LDS
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -409,6 +624,7 @@ extern "C" int rsx_merged_adam_rows(float* tables, float* m_t, float* v_t, float
   // the window pass walks the COMPACT unit list of the lists it visits with a grid stride (window_pass_compact): at most as
   // many workgroups as the dense grid would have, and never more than a launch-full
   if (h.win_blk > 768u) h.win_blk = 768u;
+  h.win_compact = 1;
   const long long wgs = ((long long)max_units + 3) / 4;
   h.n_own = (uint32_t)(wgs < 1024 ? wgs : 1024);                 // (grid stride over the compact unit list)
   h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.win_blk + h.extra.n_blk + h.cold.n_blk;

@@ -202,7 +202,10 @@ class EmbeddingArena:
         goff = np.concatenate([[0], np.cumsum(caps)]).astype(np.int32)
         capT = int(goff[-1])
         i32 = dict(dtype=torch.int32, device=dev)
-        KS = (self.F + capT + 3) & ~3
+        # row-range parts per field of the merge (rsx_uniq_merge): one workgroup per (field, part, rank) keeps the longest list
+        # walk near 8 192 entries -- 1 for deepfm.py at 8 x 256, 4 for dcn.py at 8 x 4 096, 44 for din.py's item table at 8 x 1 024
+        parts = int(os.environ.get("RSX_UX_PARTS", "0")) or max(1, min(_lib.UNIQ_MAX_PARTS, -(-int(caps.max()) * int(world) // 8192)))
+        KS = (self.F + self.F * (parts + 1) + capT + 3) & ~3
 
         def new_local():
             loc = EmbeddingArena(self.row_off_np, self.D, int(sort_capacity or b_local), dev, with_w1=self.with_w1,
@@ -218,7 +221,8 @@ class EmbeddingArena:
         gmax = np.minimum(rows, b_local * world)
         self.ux = SimpleNamespace(
             world=int(world), b=int(b_local), goff_np=goff, goff=torch.tensor(goff, **i32), capT=capT, KS=KS, local=local,
-            keys=keys, src=[], new_local=new_local,
+            keys=keys, src=[], new_local=new_local, parts=parts,
+            part_counts=torch.zeros(_lib.ADAM_WINDOW_MAX * self.F * parts, **i32),
             max_units=int(((gmax + gpw - 1) // gpw).sum()), max_unique=int(gmax.max()), max_entries=int(caps.max()) * int(world))
         self.ux_src_bufs(len(self.sortbufs))
         return self.ux
@@ -263,7 +267,8 @@ class EmbeddingArena:
         jobs = (_lib.UniqPackJob * k)()
         for i, b in enumerate(loc.window_bufs(k)):
             jobs[i].uniq_row, jobs[i].nuniq, jobs[i].keys = b["uniq_row"].data_ptr(), b["nuniq"].data_ptr(), ux.keys[i].data_ptr()
-        check(lib().rsx_uniq_pack(jobs, k, _ptr(ux.goff), self.F, loc.stride, _stream()), "rsx_uniq_pack")
+        check(lib().rsx_uniq_pack(jobs, k, _ptr(ux.goff), _ptr(self.row_off), self.F, loc.stride, ux.parts, _stream()),
+              "rsx_uniq_pack")
         return ux.keys[:k].view(1, k * ux.KS)
 
     def ux_merge(self, keys_g, k):
@@ -277,8 +282,9 @@ class EmbeddingArena:
         for i, b in enumerate(self.window_bufs(k)):
             jobs[i].uniq_row, jobs[i].nuniq, jobs[i].slot = b["uniq_row"].data_ptr(), b["nuniq"].data_ptr(), b["slot"].data_ptr()
             jobs[i].src = srcs[i].data_ptr()
-        check(lib().rsx_uniq_merge(_ptr(keys_g), k * ux.KS, ux.KS, jobs, k, _ptr(ux.goff), _ptr(self.row_off), self.max_rows,
-                                   ux.max_entries, self.F, ux.world, self.stride, _stream()), "rsx_uniq_merge")
+        check(lib().rsx_uniq_merge(_ptr(keys_g), k * ux.KS, ux.KS, jobs, k, _ptr(ux.goff), _ptr(self.row_off),
+                                   _ptr(ux.part_counts), ux.parts, self.max_rows, ux.max_entries, self.F, ux.world, self.stride,
+                                   _stream()), "rsx_uniq_merge")
         self.last_B = ux.max_unique
 
     def ux_segsum_local(self, B, S, dX, gy1, gy2, G_out, gw1_out, pos=0, null_row=-1):
@@ -1346,6 +1352,15 @@ class CinNet:
                          for n in self.sizes]
             self._w16_h = (C.c_void_p * self.L)(*[w.data_ptr() for w in self.w16])
             self._H_h = (C.c_int32 * self.L)(*hs16)
+            # round 5: the weight gradients as a K-split GEMM tile (rsx_cin_bwd_dw_bf16_split): S partial tiles per layer, added
+            # in slice order by a second launch.  RSX_CIN_DW16_SPLIT=0: the one-workgroup-per-tile launch of rounds 2-4
+            self.dw_split = int(os.environ.get("RSX_CIN_DW16_SPLIT", "4"))
+            if any((F * h * n) % 4 for h, n in zip(hs16, self.sizes)):
+                self.dw_split = 0
+            if self.dw_split:
+                self.dw_part = [torch.empty(int(lib().rsx_cin_bf16_dw_split_floats(F, h, n, self.dw_split)), device=dev)
+                                for h, n in zip(hs16, self.sizes)]
+                self._dw_part_h = (C.c_void_p * self.L)(*[t.data_ptr() for t in self.dw_part])
         self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
         self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
         hs = [F] + self.sizes[:-1]
@@ -1419,5 +1434,9 @@ class CinNet:
                                         P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k])
             assert sweeps is None or len(sweeps) == L + 1, "bf16 CinNet.backward: L + 1 sweep slots"
             sw = None if sweeps is None or sweeps[L] is None else C.byref(sweeps[L])
-            check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
+            if self.dw_split:
+                check(lib().rsx_cin_bwd_dw_bf16_split(_ptr(X0), jobs, self._dw_part_h, L, B, self.F, self.D, self.dw_split, sw,
+                                                      _stream()), "rsx_cin_bwd_dw_bf16_split")
+            else:
+                check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
         return dX0[:B]

@@ -94,11 +94,16 @@ def test_loopback_dp_with_distinct_batches_matches_the_oracle(kind, world, B, dr
     assert float(np.abs(zg.cpu().numpy().reshape(-1) - zo).max()) < 1e-5
 
 
-@pytest.mark.parametrize("exchange", ["examples", "unique"])
+@pytest.mark.parametrize("exchange", ["examples", "unique", "unique-parts3", "unique-parts64"])
 @pytest.mark.parametrize("kind,world,B,k", [("deepfm", 2, 48, 3), ("fm", 3, 40, 4), ("dcn", 2, 64, 2)])
 def test_loopback_dp_inside_optimizer_windows_matches_the_oracle(kind, world, B, k, exchange, monkeypatch):
     """The same through optimizer windows (ONE ids collective + k global dedup results + one untouched-row sweep per window,
-    the lazy window pass in every step's optimizer launch): windows of k steps, two windows."""
+    the lazy window pass in every step's optimizer launch): windows of k steps, two windows.
+    unique-partsP: the merge of the unique-row lists with P row-range parts per field (count pass + emit pass: what long lists
+    -- dcn.py at 8 x 4 096, din.py's item table -- run; RSX_UX_PARTS forces it at these sizes)."""
+    if exchange.startswith("unique-parts"):
+        monkeypatch.setenv("RSX_UX_PARTS", exchange[len("unique-parts"):])
+        exchange = "unique"
     import torch
     from oracle import models, nn
     from recsys_amd.dist import loopback_train_step
@@ -258,7 +263,7 @@ def test_loopback_dp_xdeepfm_matches_the_oracle(world, B, cin, window, exchange,
     assert max(perr.values()) < 5e-5, perr
 
 
-@pytest.mark.parametrize("exchange", ["examples", "unique"])
+@pytest.mark.parametrize("exchange", ["examples", "unique", "unique-parts5"])
 @pytest.mark.parametrize("world,B,Pn", [(2, 24, 12), (3, 16, 20), (2, 96, 100)])
 def test_loopback_dp_din_matches_the_oracle(world, B, Pn, exchange, monkeypatch):
     """din.py's fused step (din/din.py:204-206 MirroredStrategy): per-rank batches with ragged histories, target ids 0, the item
@@ -269,6 +274,9 @@ def test_loopback_dp_din_matches_the_oracle(world, B, Pn, exchange, monkeypatch)
     from recsys_amd import din, synthetic
     from recsys_amd.dist import LoopbackDataParallel, loopback_train_step
     from tests.parity_util import make_estimator
+    if exchange.startswith("unique-parts"):
+        monkeypatch.setenv("RSX_UX_PARTS", exchange[len("unique-parts"):])
+        exchange = "unique"
     monkeypatch.setenv("RSX_DP_EXCHANGE", exchange)
     K, n_item, n_cate = 16, 300, 20
     rng = np.random.default_rng(5)
