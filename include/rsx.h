@@ -931,14 +931,6 @@ int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16,
                               rsx_stream_t stream);
 int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
                         const rsx_adam_slice* sweep_h, rsx_stream_t stream);
-/* The weight gradients as a K-split GEMM tile (round 5): workgroup = 2 fields x 64 h x all n-tiles x one of S slices of the batch,
- * the dpre fragments staged through LDS once per workgroup, the S partial tiles written to part_h[k] (one
- * rsx_cin_bf16_dw_split_floats(F, H, N, S) buffer per job) and added in slice order by a second small launch.  Same contract as
- * rsx_cin_bwd_dw_bf16 otherwise; the batch sum is associated differently (slices), within the bf16 path's tolerance.
- * F * H * N must be a multiple of 4 (RSX_EUNSUPPORTED otherwise: use rsx_cin_bwd_dw_bf16).  1 <= S <= 8.                 */
-size_t rsx_cin_bf16_dw_split_floats(int F, int H, int N, int S);
-int rsx_cin_bwd_dw_bf16_split(const float* X0, const rsx_cin_dw_job* jobs_h, float* const* part_h, int njobs, int B, int F,
-                              int D, int S, const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
                             int F, rsx_stream_t stream);
 

@@ -215,8 +215,6 @@ _SIGS = {
     "rsx_cin_layer_bwd_dx_bf16": (_I, [_P] * 8 + [_I, _P, _I, _P] + [_I] * 5 + [_P, _P]),
     "rsx_cin_bwd_dw_bf16": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _P, _P]),
     "rsx_cin_prep_bf16_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
-    "rsx_cin_bf16_dw_split_floats": (C.c_size_t, [_I, _I, _I, _I]),
-    "rsx_cin_bwd_dw_bf16_split": (_I, [_P, C.POINTER(CinDwJob), _P, _I, _I, _I, _I, _I, _P, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd_lin": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

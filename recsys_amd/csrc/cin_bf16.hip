@@ -576,226 +576,6 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ backward: dW, split K
-// Round 5 ("CIN on the matrix cores").  The launch above lives on thread-level parallelism: every wave streams its
-// own operands (683 B of vector-memory traffic per MFMA against the 256 B the CU's 64 B/clk path sustains at the MFMA peak),
-// forms each A fragment for NT = 2..4 MFMAs only, and walks 16 k-steps with one stage in flight.  This one is a GEMM tile:
-//   C[(f, h), n] = sum over k = (b, d) of (X0[b, f, d] Xk[b, h, d]) dpre[b, n, d]
-//   workgroup = 4 waves = (FT = 2 fields) x (4 h-tiles = 64 h) x (ALL n-tiles, <= 8) x one SLICE of the batch (K split S ways);
-//   wave w    = h-tile w: 2 fields x 8 n-tiles = 16 accumulator tiles; an A fragment (8 products + 4 packing conversions) feeds
-//               8 MFMAs, the Xk quad it is made of serves both fields;
-//   B operand = the dX launch's dpre fragments: the <= 8 KiB of one k-step (all n-tiles) are CONTIGUOUS; the workgroup stages two
-//               k-steps (16 KiB) per pipeline stage in LDS with one 64-byte load per thread and every wave reads its fragments
-//               from there (ds_read_b128, conflict free) -- 256 B of vector-memory traffic per MFMA (Xk quads + the shared B);
-//   pipeline  = stage st + 1's global loads (B chunk -> registers, Xk quads -> registers) are in flight while stage st is
-//               multiplied; one barrier per stage (two LDS buffers).
-// Splitting K over S workgroups fills the 256 CUs (60 (f-pair, h-group) tiles x S = 4 at [39 -> 128 -> 128]) and cuts the B
-// stream per workgroup to 1 / S; the S partial tiles are written to a workspace and added IN SLICE ORDER by cin_dw_reduce_k
-// (deterministic; another association of the batch sum than the one-workgroup launch: the bf16 path's own tolerance holds).
-struct CbDw2Job {
-  const float* Xk;        // [B, H, 16]
-  const bf16_t* dpre16;   // fragments [ceil(B/2)][N16/16][64][8]
-  const float* dc_part;   // [ceil(B/2), N16]
-  float* dW;              // [F*H, N]
-  float* dc;              // [N]
-  float* part;            // [S][F*H*N]
-  int H, N, N16, HT, HG;  // HT h-tiles, HG = ceil(HT / 4) h-groups
-  int wg_end;             // exclusive prefix sum of the jobs' workgroup counts (FP * HG * S each)
-};
-struct CbDw2Args {
-  CbDw2Job job[CB_MAXJ];
-  int njobs;
-  const float* X0;        // [B, F, 16]
-  int B, F, FP, S;        // FP = ceil(F / 2) field pairs
-  int nks, kps;           // k-steps (example pairs) in all, per slice (even)
-  AdamSlice sweep;
-};
-
-__global__ __launch_bounds__(256, 2) void cin_dw2_bf16_k(const CbDw2Args p) {
-  extern __shared__ float4 dw2_lds[];
-  constexpr int FT = 2, NTM = 8;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int total = p.job[p.njobs - 1].wg_end;
-  if ((int)blockIdx.x < p.njobs) {                // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
-    const CbDw2Job& jb = p.job[blockIdx.x];
-    const int G = (p.B + 1) / 2;
-    for (int n = tid; n < jb.N; n += 256) {
-      float s = 0.f;
-      int g = 0;
-      for (; g + 8 <= G; g += 8) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = jb.dc_part[(size_t)(g + u) * jb.N16 + n];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += t[u];
-      }
-      for (; g < G; ++g) s += jb.dc_part[(size_t)g * jb.N16 + n];
-      jb.dc[n] = s;
-    }
-    return;
-  }
-  const RiderSplit rs = rider_split(blockIdx.x - (uint32_t)p.njobs, (uint32_t)total, p.sweep.n_blk);
-  if (rs.rider) {
-    if (rs.idx < p.sweep.n_blk) adam_block(p.sweep.args, p.sweep.blk_lo + rs.idx);
-    return;
-  }
-  const int wg = (int)rs.idx;
-  int ji = 0;
-#pragma unroll
-  for (int k = 1; k < CB_MAXJ; ++k)
-    if (k < p.njobs && wg >= p.job[k - 1].wg_end) ji = k;
-  const CbDw2Job& jb = p.job[ji];
-  const int local = wg - (ji ? p.job[ji - 1].wg_end : 0);
-  const int sl = local % p.S, hg = (local / p.S) % jb.HG, fp = local / (p.S * jb.HG);
-  const int i = lane & 15, kq = lane >> 4;
-  const int H = jb.H, ntn = jb.N16 >> 4;
-  const int ht = hg * 4 + wv;
-  const bool wave_on = ht < jb.HT;
-  const int h = 16 * (wave_on ? ht : jb.HT - 1) + i;
-  const int hc = h < H ? h : H - 1;
-  const float hm = (wave_on && h < H) ? 1.f : 0.f;
-  const int d0 = (kq & 1) * 8, eb = kq >> 1;      // k = 8 kq + j  <->  example 2 ks + (kq >> 1), dims d0 .. d0 + 7
-  const int ks0 = sl * p.kps;
-  const int ks1 = ks0 + p.kps < p.nks ? ks0 + p.kps : p.nks;
-  const int nst = (ks1 - ks0 + 1) >> 1;           // pipeline stages of two k-steps
-  // LDS: two B buffers of 2 k-steps x ntn KiB, then the X0 slab [2 kps examples][FT][16] floats
-  const int stage_q = 2 * ntn * 64;               // 16-byte quads of a stage
-  uint4* sB = reinterpret_cast<uint4*>(dw2_lds);
-  float4* sX0 = dw2_lds + 2 * 2 * NTM * 64;
-  {
-    const int nex = 2 * (ks1 - ks0);
-    for (int e = tid; e < nex * FT * 4; e += 256) {
-      const int qd = e & 3, ft = (e >> 2) % FT, ex = (e >> 2) / FT;
-      const int b = 2 * ks0 + ex;
-      const int f = fp * FT + ft < p.F ? fp * FT + ft : p.F - 1;
-      sX0[e] = b < p.B ? reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f) * CB_D)[qd] : F4Z;
-    }
-  }
-  f32x4 acc[FT][NTM];
-#pragma unroll
-  for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-    for (int nt = 0; nt < NTM; ++nt) acc[ft][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // stage loads: the B chunk of k-steps (ka, ka + 1) = stage_q contiguous quads of dpre16 (a k-step past the slice re-reads the
-  // last one: its products are masked out), <= 4 per thread; the wave's Xk quads of both k-steps
-  // (native vector types: an ARRAY of HIP's float4 / uint4 structs that loads land in stays in scratch memory)
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  struct St {
-    u32x4 b[4];
-    f32x4 xk[2][2];
-  };
-  const u32x4* dp = reinterpret_cast<const u32x4*>(jb.dpre16);
-  auto load = [&](int st, St& L) {
-    const int ka = ks0 + 2 * st;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + 256 * u;
-      const int ec = e < stage_q ? e : stage_q - 1;
-      const int kk = ec / (ntn * 64), r = ec - kk * (ntn * 64);
-      const int ks = ka + kk < ks1 ? ka + kk : ks1 - 1;
-      L.b[u] = dp[(size_t)ks * (ntn * 64) + r];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ks = ka + kk < ks1 ? ka + kk : ks1 - 1;
-      const int b = 2 * ks + eb;
-      const int bc = b < p.B ? b : p.B - 1;
-      const f32x4* xk = reinterpret_cast<const f32x4*>(jb.Xk + ((size_t)bc * H + hc) * CB_D + d0);
-      L.xk[kk][0] = xk[0];
-      L.xk[kk][1] = xk[1];
-    }
-  };
-  auto stash = [&](const St& L, int buf) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + 256 * u;
-      if (e < stage_q) reinterpret_cast<u32x4*>(sB)[buf * (2 * NTM * 64) + e] = L.b[u];
-    }
-  };
-  auto run = [&](int st, const St& L, int buf) {
-    const int ka = ks0 + 2 * st;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ks = ka + kk;
-      const int b = 2 * ks + eb;
-      const float m = (ks < ks1 && b < p.B) ? hm : 0.f;
-      const f32x4 q0 = L.xk[kk][0], q1 = L.xk[kk][1];
-      const float4 k0 = make_float4(m * q0[0], m * q0[1], m * q0[2], m * q0[3]);
-      const float4 k1 = make_float4(m * q1[0], m * q1[1], m * q1[2], m * q1[3]);
-      const int ex = 2 * ((ks < ks1 ? ks : ks1 - 1) - ks0) + eb;
-      bf16x8 a[FT];
-#pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-        const float4* x0 = sX0 + ((size_t)ex * FT + ft) * 4 + (d0 >> 2);
-        a[ft] = cvt8(f4_mul(x0[0], k0), f4_mul(x0[1], k1));
-      }
-      const uint4* bb = sB + buf * (2 * NTM * 64) + kk * (ntn * 64) + lane;
-#pragma unroll
-      for (int nt = 0; nt < NTM; ++nt) {
-        if (nt < ntn) {                           // (uniform)
-          const bf16x8 bf = __builtin_bit_cast(bf16x8, bb[nt * 64]);
-#pragma unroll
-          for (int ft = 0; ft < FT; ++ft) acc[ft][nt] = mfma_bf16(a[ft], bf, acc[ft][nt]);
-        }
-      }
-    }
-  };
-  St La, Lb;
-  load(0, La);
-  stash(La, 0);
-  __syncthreads();                                // X0 slab + the first B chunk staged
-  for (int st = 0; st < nst; st += 2) {
-    if (st + 1 < nst) load(st + 1, Lb);
-    run(st, La, 0);
-    if (st + 1 < nst) stash(Lb, 1);
-    __syncthreads();
-    if (st + 1 >= nst) break;
-    if (st + 2 < nst) load(st + 2, La);
-    run(st + 1, Lb, 1);
-    if (st + 2 < nst) stash(La, 0);
-    __syncthreads();
-  }
-  if (!wave_on) return;
-  float* P = jb.part + (size_t)sl * ((size_t)p.F * H * jb.N);
-#pragma unroll
-  for (int ft = 0; ft < FT; ++ft) {
-    const int f = fp * FT + ft;
-#pragma unroll
-    for (int nt = 0; nt < NTM; ++nt) {
-      const int n = 16 * nt + i;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int hh = 16 * ht + 4 * kq + r;
-        if (nt < ntn && f < p.F && hh < H && n < jb.N) P[((size_t)f * H + hh) * jb.N + n] = acc[ft][nt][r];
-      }
-    }
-  }
-}
-
-// dW = part[0] + part[1] + ... + part[S - 1] (slice order), all jobs in one launch
-struct CbDwRedJob { const float* part; float* dW; long long n4; long long end4; };
-struct CbDwRedArgs { CbDwRedJob job[CB_MAXJ]; int njobs, S; };
-__global__ __launch_bounds__(256) void cin_dw_reduce_k(const CbDwRedArgs p) {
-  const long long total = p.job[p.njobs - 1].end4;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    int ji = 0;
-#pragma unroll
-    for (int k = 1; k < CB_MAXJ; ++k)
-      if (k < p.njobs && e >= p.job[k - 1].end4) ji = k;
-    const CbDwRedJob& jb = p.job[ji];
-    const long long le = e - (ji ? p.job[ji - 1].end4 : 0);
-    const float4* src = reinterpret_cast<const float4*>(jb.part) + le;
-    float4 v[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) v[s] = src[(s < p.S ? s : p.S - 1) * jb.n4];
-    float4 t = v[0];
-#pragma unroll
-    for (int s = 1; s < 8; ++s)
-      if (s < p.S) t = f4_add(t, v[s]);
-    reinterpret_cast<float4*>(jb.dW)[le] = t;
-  }
-}
-
 // several layers' filters in one launch
 struct CbPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; int H, N, H16, N16, Hp, Np; long long end; };
 struct CbPrepArgs { CbPrepJob job[CB_MAXJ]; int njobs, F; };
@@ -1006,56 +786,6 @@ extern "C" int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const
 extern "C" int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D,
                                    const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
   return cb_launch_dw(X0, jobs_h, njobs, B, F, D, sweep_h, stream);
-}
-
-extern "C" size_t rsx_cin_bf16_dw_split_floats(int F, int H, int N, int S) {
-  if (F <= 0 || H <= 0 || N <= 0 || S <= 0) return 0;
-  return (size_t)S * (((size_t)F * H * N + 3) & ~(size_t)3);
-}
-
-extern "C" int rsx_cin_bwd_dw_bf16_split(const float* X0, const rsx_cin_dw_job* jobs_h, float* const* part_h, int njobs, int B,
-                                         int F, int D, int S, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
-  if (!X0 || !jobs_h || !part_h || njobs <= 0 || B < 0 || F <= 0 || S < 1 || S > 8) return RSX_EINVAL;
-  if (njobs > CB_MAXJ || D != CB_D) return RSX_EUNSUPPORTED;
-  if (B == 0) return RSX_OK;
-  CbDw2Args w{};
-  CbDwRedArgs rd{};
-  w.njobs = njobs; w.X0 = X0; w.B = B; w.F = F; w.FP = (F + 1) / 2; w.S = S;
-  w.nks = (B + 1) / 2;
-  w.kps = ((w.nks + S - 1) / S + 1) & ~1;          // k-steps per slice, even (stages of two)
-  rd.njobs = njobs; rd.S = S;
-  int wgs = 0;
-  long long e4 = 0;
-  for (int k = 0; k < njobs; ++k) {
-    const rsx_cin_dw_job& j = jobs_h[k];
-    if (!j.Xk || !j.ws || !j.dW || !j.dc || !part_h[k] || j.H <= 0 || j.N <= 0) return RSX_EINVAL;
-    if (j.H > 128 || j.N > 128) return RSX_EUNSUPPORTED;
-    if (((size_t)F * j.H * j.N) & 3) return RSX_EUNSUPPORTED;     // (float4 reduce; the caller falls back to rsx_cin_bwd_dw_bf16)
-    const int H16 = rup(j.H, 16), N16 = rup(j.N, 16);
-    CbDw2Job& d = w.job[k];
-    d.Xk = j.Xk;
-    d.dpre16 = static_cast<const bf16_t*>(j.ws);
-    d.dc_part = reinterpret_cast<const float*>(static_cast<const char*>(j.ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
-    d.dW = j.dW; d.dc = j.dc; d.part = part_h[k]; d.H = j.H; d.N = j.N; d.N16 = N16;
-    d.HT = H16 / 16; d.HG = (d.HT + 3) / 4;
-    wgs += w.FP * d.HG * S;
-    d.wg_end = wgs;
-    CbDwRedJob& r = rd.job[k];
-    r.part = part_h[k]; r.dW = j.dW; r.n4 = ((long long)F * j.H * j.N) >> 2;
-    e4 += r.n4;
-    r.end4 = e4;
-  }
-  const int rcs = adam_build_slice(sweep_h, w.sweep);
-  if (rcs != RSX_OK) return rcs;
-  const unsigned grid = (unsigned)wgs + (unsigned)njobs + w.sweep.n_blk;
-  const size_t lds = (size_t)(2 * 2 * 8 * 64) * 16 + (size_t)(2 * w.kps) * 2 * 4 * 16;
-  if (lds > 64 * 1024) return RSX_EUNSUPPORTED;
-  RSX_LAUNCH(cin_dw2_bf16_k, dim3(grid), dim3(256), lds, rsx_s(stream), w);
-  RSX_CHECK_LAUNCH();
-  const long long rb = (e4 + 255) / 256;
-  RSX_LAUNCH(cin_dw_reduce_k, dim3((unsigned)(rb < 2048 ? rb : 2048)), dim3(256), 0, rsx_s(stream), rd);
-  RSX_CHECK_LAUNCH();
-  return RSX_OK;
 }
 
 extern "C" int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h,

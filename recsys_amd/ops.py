@@ -1352,15 +1352,6 @@ class CinNet:
                          for n in self.sizes]
             self._w16_h = (C.c_void_p * self.L)(*[w.data_ptr() for w in self.w16])
             self._H_h = (C.c_int32 * self.L)(*hs16)
-            # round 5: the weight gradients as a K-split GEMM tile (rsx_cin_bwd_dw_bf16_split): S partial tiles per layer, added
-            # in slice order by a second launch.  RSX_CIN_DW16_SPLIT=0: the one-workgroup-per-tile launch of rounds 2-4
-            self.dw_split = int(os.environ.get("RSX_CIN_DW16_SPLIT", "4"))
-            if any((F * h * n) % 4 for h, n in zip(hs16, self.sizes)):
-                self.dw_split = 0
-            if self.dw_split:
-                self.dw_part = [torch.empty(int(lib().rsx_cin_bf16_dw_split_floats(F, h, n, self.dw_split)), device=dev)
-                                for h, n in zip(hs16, self.sizes)]
-                self._dw_part_h = (C.c_void_p * self.L)(*[t.data_ptr() for t in self.dw_part])
         self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
         self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
         hs = [F] + self.sizes[:-1]
@@ -1434,9 +1425,5 @@ class CinNet:
                                         P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k])
             assert sweeps is None or len(sweeps) == L + 1, "bf16 CinNet.backward: L + 1 sweep slots"
             sw = None if sweeps is None or sweeps[L] is None else C.byref(sweeps[L])
-            if self.dw_split:
-                check(lib().rsx_cin_bwd_dw_bf16_split(_ptr(X0), jobs, self._dw_part_h, L, B, self.F, self.D, self.dw_split, sw,
-                                                      _stream()), "rsx_cin_bwd_dw_bf16_split")
-            else:
-                check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
+            check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
         return dX0[:B]
