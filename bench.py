@@ -227,6 +227,8 @@ def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmu
                 ar = est.store.embeddings["input_layer"]
                 key_fn = lambda pf, ar=ar: ar.ux_peer_keys(pf["ids"])
         emu.set_peers(peers, key_fn)
+        if model == "din" and not getattr(est.store, "dp_unique", False):
+            emu._entry_fn = est.store.din.peer_entry_keys
         emu.warm_keys()
         torch.cuda.synchronize()
     host_pbs = None

@@ -377,7 +377,7 @@ typedef struct {
   int32_t* keys;              /* out: [F + capT] */
 } rsx_uniq_pack_job;
 int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, const int32_t* row_off, int F, int stride,
-                  int parts, rsx_stream_t stream);
+                  int parts, int max_cap /* the largest cap_f: launch shape */, rsx_stream_t stream);
 /* The N ranks' key blocks -> what rsx_field_sort leaves for the GLOBAL batch, without a global sort: per job (a batch of
  * the window) the global unique rows of every field in ascending order (uniq_row [F, stride], nuniq [F]), the slot map (row
  * -> f * stride + j for touched rows; the entries of the workspace's PREVIOUS contents are reset to -1 first, so uniq_row /

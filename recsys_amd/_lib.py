@@ -166,7 +166,7 @@ _SIGS = {
                                    _I, _I, _P]),
     "rsx_field_sort_multi": (_I, [C.POINTER(SortJob), _I, _P]),
     "rsx_segsum_bwd_packed": (_I, [_P] * 11 + [_U64, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "rsx_uniq_pack": (_I, [C.POINTER(UniqPackJob), _I, _P, _P, _I, _I, _I, _P]),
+    "rsx_uniq_pack": (_I, [C.POINTER(UniqPackJob), _I, _P, _P, _I, _I, _I, _I, _P]),
     "rsx_uniq_merge": (_I, [_P, C.c_longlong, _I, C.POINTER(UniqMergeJob), _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rsx_merged_adam_rows": (_I, [_P] * 8 + [C.c_longlong, _I, _P, _P, _P, _P, _U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I,
                                   _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _I, _P]),

@@ -31,6 +31,7 @@ constexpr int UX_MAX_JOBS = RSX_ADAM_WINDOW_MAX;
 constexpr int UX_MAX_RANKS = RSX_UNIQ_MAX_RANKS;
 
 // ---------------------------------------------------------------- pack -------------------------------------------------
+constexpr int UX_PACK_CHUNK = 2048;
 struct UxPack {
   const int32_t* uniq_row[UX_MAX_JOBS];
   const int32_t* nuniq[UX_MAX_JOBS];
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void uniq_pack_k(const UxPack a) {
   const int32_t* ur = a.uniq_row[0];
   const int32_t* nq = a.nuniq[0];
   int32_t* keys = a.keys[0];
+  constexpr int CH = UX_PACK_CHUNK;               // list positions per workgroup (grid z): din.py's item list holds ~45 000
 #pragma unroll
   for (int k = 1; k < UX_MAX_JOBS; ++k) {        // (a dynamically indexed by-value table goes to scratch: unrolled selection)
     if (k == job) {
@@ -62,13 +64,14 @@ __global__ __launch_bounds__(256) void uniq_pack_k(const UxPack a) {
   const int g0 = a.goff[f], cap = a.goff[f + 1] - g0;
   const int nu0 = nq[f];
   const int nu = nu0 < cap ? nu0 : cap;
-  if (tid == 0) keys[f] = nu;
+  if (tid == 0 && blockIdx.z == 0) keys[f] = nu;
   ur += (size_t)f * a.stride;
   const int row0 = a.row_off[f];
   const int rpp = ux_rows_per_part(a.row_off[f + 1] - row0, a.P);
   int32_t* rs = keys + a.F + f * (a.P + 1);
   int32_t* out = keys + a.F + a.F * (a.P + 1) + g0;
-  for (int j = tid; j < cap + 1; j += 256) {
+  const int jend = (int)(blockIdx.z + 1) * CH < cap + 1 ? (int)(blockIdx.z + 1) * CH : cap + 1;
+  for (int j = (int)blockIdx.z * CH + tid; j < jend; j += 256) {
     const int32_t r = ur[j < nu ? j : 0];
     if (j < cap) out[j] = j < nu ? r : -1;
     if (j <= nu) {                                // boundaries crossed between entries j - 1 and j (j == nu: the list's end)
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(256) void uniq_pack_k(const UxPack a) {
 }
 
 extern "C" int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const int32_t* goff, const int32_t* row_off, int F,
-                             int stride, int parts, rsx_stream_t stream) {
+                             int stride, int parts, int max_cap, rsx_stream_t stream) {
+  if (max_cap < 1) return RSX_EINVAL;
   if (!jobs_h || njobs < 1 || njobs > UX_MAX_JOBS || !goff || !row_off || F <= 0 || F > 64 || stride <= 0 || parts < 1 ||
       parts > RSX_UNIQ_MAX_PARTS)
     return RSX_EINVAL;
@@ -91,7 +95,8 @@ extern "C" int rsx_uniq_pack(const rsx_uniq_pack_job* jobs_h, int njobs, const i
     a.uniq_row[k] = j.uniq_row; a.nuniq[k] = j.nuniq; a.keys[k] = j.keys;
   }
   a.goff = goff; a.row_off = row_off; a.F = F; a.stride = stride; a.P = parts;
-  RSX_LAUNCH(uniq_pack_k, dim3((unsigned)F, (unsigned)njobs), dim3(256), 0, rsx_s(stream), a);
+  RSX_LAUNCH(uniq_pack_k, dim3((unsigned)F, (unsigned)njobs, (unsigned)((max_cap + 1 + UX_PACK_CHUNK - 1) / UX_PACK_CHUNK)),
+             dim3(256), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }

@@ -171,6 +171,17 @@ class DinFused:
         self.rows = [torch.empty(B * P + 2 + (B * P + 1023) // 1024, **i32) for _ in range(2)]
         self.ws = [torch.empty(int(_lib.lib().rsx_din_attn_bwd_workspace_floats(B, P, K, n1, n2)), **f32) for _ in range(2)]
 
+    def peer_entry_keys(self, features):
+        """EmulatedDataParallel (per-example exchange): the sort keys [entries, 2] a PEER rank holding `features` would send."""
+        i_id = features["i_id"].to(torch.int32).contiguous()
+        i_cate = features["i_cate"].to(torch.int32).contiguous()
+        hist = [features["u_iid_seq"].to(torch.int32).contiguous(), features["u_icat_seq"].to(torch.int32).contiguous()]
+        B = i_id.shape[0]
+        out = torch.zeros(B * (self.P + 1), 2, dtype=torch.int32, device=i_id.device)
+        _lib.check(_lib.lib().rsx_din_keys(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, self.P, self.n_item,
+                                          self.n_cate, _ptr(out), _stream()), "rsx_din_keys")
+        return out
+
     def ux_peer_keys(self, features):
         """EmulatedDataParallel: the packed key block a PEER rank holding `features` would send -- its sort keys (rsx_din_keys), its
         own dedup sort and pack, on scratch workspaces."""
@@ -269,7 +280,7 @@ class DinFused:
             if dp is not None and not ux:
                 # the optimizer sees the GLOBAL batch (TF concatenates the replicas' IndexedSlices): the dedup sort runs over the
                 # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
-                keys_g = dp.all_gather_rows(keys2)
+                keys_g = dp.all_gather_entry_keys(keys2, features["i_id"], self.peer_entry_keys)
                 vals_full, gbias_full = dp.send_views(N)
             side = self._side_stream() if (dp is None or os.environ.get("RSX_DIN_SIDE_SORT_DP", "1") == "1") else None
             main = torch.cuda.current_stream()
@@ -351,9 +362,15 @@ class DinFused:
                 # global unique-row lists / slot map / src, and the untouched-row sweep, which needs that slot map
                 if side is not None:
                     main.wait_stream(side)
-                a.select(0)
-                a.ux_merge(dp.all_gather_keys(keys_l, a, [features["i_id"]]), 1)
-                cold_sweep()
+                keys_all = dp.all_gather_keys(keys_l, a, [features["i_id"]])
+                # ... and back onto the side stream: the merge and the sweep touch the lists / slot map / untouched rows only, the
+                # backward launches below read touched rows and the rank's OWN sort; joined before the optimizer launch
+                if side is not None:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side if side is not None else main):
+                    a.select(0)
+                    a.ux_merge(keys_all, 1)
+                    cold_sweep()
             vals = self.vals[:N] if (dp is None or ux) else vals_full
             vbase = vals.data_ptr()
             dHp = [C.c_void_p(vbase + 4 * (B * 2 * K + t * K)) for t in range(2)]        # rows B.. of column block t
@@ -385,7 +402,7 @@ class DinFused:
                                                         _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,
                                                         B, P, K, n1, n2, 2 * K, 3 * K, vjobs, st), "rsx_din_attn_finish_pair_defer")
             riders = make_scatter_riders(vec_jobs=list(vjobs)) if ride_fin else None
-            if side is not None and not ux:
+            if side is not None:
                 main.wait_stream(side)            # the scatter (train_op) needs the sort; the sweep must precede its Adam state advance
             if ux:      # the rank's own segment-sum (stage A + packed stage B), written as its block of the send buffer
                 Gv, gbv = dp.send_views(self.ux.capT)

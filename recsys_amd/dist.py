@@ -231,6 +231,11 @@ class DataParallel:
         allg = self.all_gather_rows(torch.stack(ids_list).unsqueeze(0))               # [N, k, b, F]
         return [allg[:, i].reshape(self.world * b, -1).contiguous() for i in range(len(ids_list))]
 
+    def all_gather_entry_keys(self, keys, token=None, peer_fn=None):
+        """din.py's per-example exchange: the sort keys [entries, 2] of the rank's batch -> [N * entries, 2] in rank order.  (token /
+        peer_fn: EmulatedDataParallel derives its peers' keys from other resident batches with them.)"""
+        return self.all_gather_rows(keys)
+
     def all_gather_keys(self, keys, arena=None, ids_list=None):
         """The ids-phase collective of the unique-list exchange: keys [1, k * KS] int32 (EmbeddingArena.ux_sort_pack: the rank's
         packed unique-row lists of the k batches of an optimizer window) -> [N, k * KS].  (arena / ids_list: what the key block
@@ -459,6 +464,10 @@ class EmulatedDataParallel(DataParallel):
 
     def warm_keys(self):
         """Computes every peer key block NOW (outside graph capture and outside the timed region)."""
+        if getattr(self, "_entry_fn", None) is not None:
+            for ptr, plist in self._peers.items():
+                for r, pf in enumerate(plist):
+                    self._key_cache[(ptr, "entry", r)] = self._entry_fn(pf).clone()
         if self._key_fn is None:
             return
         for ptr, plist in self._peers.items():
@@ -472,6 +481,18 @@ class EmulatedDataParallel(DataParallel):
             pl = self._peers.get(ids.data_ptr())
             out.append(ids.repeat(self.world, 1) if pl is None else torch.cat([ids] + [pf["ids"] for pf in pl], 0))
         return out
+
+    def all_gather_entry_keys(self, keys, token=None, peer_fn=None):
+        pl = self._peers.get(token.data_ptr()) if token is not None else None
+        if pl is None or peer_fn is None:
+            return self.all_gather_rows(keys)
+        rows = [keys]
+        for r, pf in enumerate(pl):
+            c = self._key_cache.get((token.data_ptr(), "entry", r))
+            if c is None:
+                c = self._key_cache[(token.data_ptr(), "entry", r)] = peer_fn(pf).clone()
+            rows.append(c)
+        return torch.cat(rows, 0)
 
     def all_gather_keys(self, keys, arena=None, ids_list=None):
         k = len(ids_list) if ids_list else 1

@@ -267,8 +267,8 @@ class EmbeddingArena:
         jobs = (_lib.UniqPackJob * k)()
         for i, b in enumerate(loc.window_bufs(k)):
             jobs[i].uniq_row, jobs[i].nuniq, jobs[i].keys = b["uniq_row"].data_ptr(), b["nuniq"].data_ptr(), ux.keys[i].data_ptr()
-        check(lib().rsx_uniq_pack(jobs, k, _ptr(ux.goff), _ptr(self.row_off), self.F, loc.stride, ux.parts, _stream()),
-              "rsx_uniq_pack")
+        check(lib().rsx_uniq_pack(jobs, k, _ptr(ux.goff), _ptr(self.row_off), self.F, loc.stride, ux.parts,
+                                  ux.max_entries // ux.world, _stream()), "rsx_uniq_pack")
         return ux.keys[:k].view(1, k * ux.KS)
 
     def ux_merge(self, keys_g, k):
