@@ -111,7 +111,6 @@ def _train_fused(store, arena, ids, labels, params, masks):
         if wk > 1 and not overlap:
             raise _lib.RsxError("optimizer windows need the split TF-1 update (adam_mode=tf1_dense, overlap_adam)")
         arena.select(wpos)
-        side, main = None, torch.cuda.current_stream()
         if ux:
             # ids phase of the unique-list exchange (deepfm._train_fused): local sorts -> key blocks -> one all-gather -> merge
             if wpos == 0:
@@ -127,18 +126,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
         elif wk > 1:
             if wpos == 0:
                 from .dist import window_global_ids
-                # RSX_WINDOW_SIDE=1 (single replica): the window's ids-only launches -- the dedup sort of its wk batches and the ONE
-                # sweep over the rows none of them touches -- on a side stream beside step 0's forward / backward (which touch
-                # other rows only); joined before step 0's scatter, which needs the sort and the step sizes the sweep leaves
-                if dp is None and os.environ.get("RSX_WINDOW_SIDE", "0") == "1":
-                    if getattr(store, "_side_stream", None) is None:
-                        store._side_stream = torch.cuda.Stream()
-                    side = store._side_stream
-                    side.wait_stream(main)
-                with torch.cuda.stream(side if side is not None else main):
-                    arena.sort_window(window_global_ids(dp, wfeat))    # data-parallel: one all-gather for all wk batches' ids
-                    cold, _ = arena.adam_split_segments(window_k=wk)
-                    store.opt.window_sweep(cold)
+                arena.sort_window(window_global_ids(dp, wfeat))    # data-parallel: one all-gather for all wk batches' ids
+                cold, _ = arena.adam_split_segments(window_k=wk)
+                store.opt.window_sweep(cold)
             arena.last_B = ids.shape[0] * (dp.world if dp is not None else 1)
             hot = ()
         elif ids_sort.shape[0] <= 2048:              # the sort rides in the first tower-forward launch; larger ones run stand-alone
@@ -169,8 +159,6 @@ def _train_fused(store, arena, ids, labels, params, masks):
         cross_job = store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
                                          gz=gz, wout=oW[nh:], dwout=oG[nh:], defer_reduce=ride)
         riders = make_scatter_riders(store.tower.dw_jobs_pending, cross_job) if ride else None
-        if side is not None:
-            main.wait_stream(side)
         if ux:      # the rank's own sorted segment-sum, written as its block of the send buffer (deepfm._train_fused)
             (Gv,) = dp.send_views(arena.ux.capT)
             arena.ux_segsum_local(dX.shape[0], None, dX, None, None, Gv, None, wpos)

@@ -182,7 +182,6 @@ def _train_fused(store, arena, ids, labels, params, masks):
         zc = dp is not None and store.dp_block and not ux     # outputs of the per-example gradient block written in place
         dXv, Sv, gy2v, gy1v = dp.send_views(ids.shape[0]) if zc else (None,) * 4
         job = None
-        side, main = None, torch.cuda.current_stream()
         if ux:
             # ids phase of the unique-list exchange: the rank's OWN dedup sorts (the window's wk batches in one launch) -> key
             # blocks -> ONE all-gather -> the global lists / slot maps / src of all wk positions (rsx_uniq_merge): 3 launches
@@ -201,15 +200,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
             if wpos == 0:
                 from .dist import window_global_ids
                 win_ids = window_global_ids(dp, wfeat)   # data-parallel: ONE all-gather for the ids of all wk local batches
-                # RSX_WINDOW_SIDE=1 (single replica, opt-in; dcn.py has the note): the window's sort + sweep on a side stream
-                if dp is None and os.environ.get("RSX_WINDOW_SIDE", "0") == "1" and \
-                        os.environ.get("RSX_WINDOW_RIDE", "0") != "1":
-                    if getattr(store, "_side_stream", None) is None:
-                        store._side_stream = torch.cuda.Stream()
-                    side = store._side_stream
-                    side.wait_stream(main)
-                with torch.cuda.stream(side if side is not None else main):
-                    arena.sort_window(win_ids)
+                arena.sort_window(win_ids)
             arena.last_B = ids.shape[0] * (dp.world if dp is not None else 1)
         elif ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
             arena.select(0)
@@ -233,29 +224,14 @@ def _train_fused(store, arena, ids, labels, params, masks):
         elif job is None and wk == 1 and not ux:
             arena.field_sort(ids_sort)
         sweeps, hot, last_sweep = None, None, None
-        # RSX_WINDOW_RIDE=1 (round 4, opt-in; measured and NOT the default): a FULL window's sweep (8 steps) rides in the steps' head
-        # launches, one eighth per step in small blocks (rsx_adam_slice.window_block_u) -- a row no step of the window touches is
-        # read by none of them, so its 8 updates may land at any time inside the window.  Bit-identical (tests/test_gpu_knobs.py),
-        # but the sweep is bandwidth-bound, not idle-CU-bound: a slice moves 43 MB (8.6 us at 5 TB/s) and the head launch grew
-        # from 7.1 to 18.6 us -- more than the 8.8 us per step the stand-alone launch costs (0.0625 vs 0.0600 ms per step,
-        # profiles/r04_e_window_ride_ab.txt).
-        ride = overlap and not ux and wk == _lib.ADAM_WINDOW_MAX and os.environ.get("RSX_WINDOW_RIDE", "0") == "1"
-        if ride:
-            if wpos == 0:
-                cold, hot = arena.adam_split_segments(window_k=wk)
-                store._win_slices = store.opt.cold_slices(cold[::-1], [1.0] * wk, window_block_u=2)
-            hot = ()
-            sweeps = [None] * (2 * len(store.tower.widths) + 1)
-            sweeps[len(store.tower.widths)] = store._win_slices[wpos]
-        elif ux and overlap and wk > 1:
+        if ux and overlap and wk > 1:
             hot = ()            # (the window's sweep ran with the ids phase above)
         elif overlap and wk > 1 and wpos == 0:
             # ONE sweep for the whole window, as a launch of its own: k updates per row in registers make the slices
             # ALU-heavy, and as riders they inherit their carrier's occupancy (measured, DeepFM bs 256: carried 164 us per
             # 4-step window, stand-alone 73 us = 18 us per step against 53-60 us for a one-step sweep)
             cold, hot = arena.adam_split_segments(window_k=wk)
-            with torch.cuda.stream(side if side is not None else main):
-                store.opt.window_sweep(cold[::-1])
+            store.opt.window_sweep(cold[::-1])
         elif overlap and wpos == 0:
             # Exact TF-1 Adam, split: the sort runs first (its slot map says which rows this step touches); the
             # HBM-bound sweep over the UNtouched rows (old state only) then rides along in the tower launches as extra
@@ -286,8 +262,6 @@ def _train_fused(store, arena, ids, labels, params, masks):
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
             sort_job=job, sweeps=sweeps, sort_in_fwd=overlap, outs=(dXv, gy1v, gy2v) if zc else None,
             layer_done=layer_done, gather=(arena, ids, S, y1p, y2) if fuse_gather else None)
-        if side is not None:
-            main.wait_stream(side)
         if ux:
             # the rank's own sorted segment-sum (what a single replica's scatter does), written as its block of the send buffer
             Gv, gw1v = dp.send_views(arena.ux.capT)

@@ -346,10 +346,8 @@ class DinFused:
                 seed=0xD1AD + 7919 * rank,                       # replicas draw independent dropout patterns
                 outs=(None, gbias[:B], None),                    # d loss / d bias lands in the scatter's first-order input
                 # the weight-gradient reduce of the one-launch mlp_layer rides in the pooling-backward launch below
-                # (RSX_MLP_REDUCE_RIDE=0: its own launch; RSX_MLP_REDUCE_SIDE=1: on the side stream -- measured slower, §4c-15)
-                reduce_rider=os.environ.get("RSX_MLP_REDUCE_RIDE", "1") == "1",
-                reduce_stream=side if os.environ.get("RSX_MLP_REDUCE_SIDE", "0") == "1" and
-                os.environ.get("RSX_MLP_REDUCE_RIDE", "1") != "1" else None)
+                # (RSX_MLP_REDUCE_RIDE=0: its own launch)
+                reduce_rider=os.environ.get("RSX_MLP_REDUCE_RIDE", "1") == "1")
             rider = getattr(tw, "mlp_reduce_job", None)
             if B < self.cap_B:
                 # a batch smaller than an earlier one (the final partial batch of an epoch): entries B.. are HISTORY entries now,

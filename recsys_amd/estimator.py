@@ -551,10 +551,12 @@ class Estimator:
             K = self._window_len()
             with torch.cuda.graph(graph):
                 k = 0
-                while k < count:         # optimizer windows never cross a graph: the resident batches ARE the look-ahead
-                    w = min(K, count - k)
+                nwin = -(-count // K)    # windows of the graph, as EVEN as possible (20 steps: 7 + 7 + 6 rather than 8 + 8 + 4:
+                while k < count:         # a window's ONE sweep costs 57 us + ~3 us per step, so short windows are the dear ones)
+                    w = -(-(count - k) // nwin)      # optimizer windows never cross a graph: the resident batches ARE the look-ahead
                     loss = self._train_window([batches[first + k + j].views() for j in range(w)])[-1]
                     k += w
+                    nwin -= 1
             return graph, loss        # `loss`: the static output of the graph's last step
 
         def partial(first, count):
@@ -568,6 +570,12 @@ class Estimator:
             sched.append(partial(pos, cnt))
             pos, left = (pos + cnt) % n, left - cnt
         while left >= spg:
+            if spg < left < spg + spg // 2 and pos + left <= n:
+                # a full group + a short tail (20 steps at 16 per graph): ONE graph for both -- a graph launch costs ~9 us of
+                # start-up and ~8 us at its end on this stack
+                sched.append(partial(pos, left))
+                pos, left = (pos + left) % n, 0
+                break
             gi = pos // spg
             if gi not in g["groups"]:
                 g["groups"][gi] = capture(pos, spg)

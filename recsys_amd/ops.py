@@ -800,7 +800,7 @@ class FusedTower:
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
                    seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None, layer_done=None, gather=None,
-                   reduce_stream=None, reduce_rider=False, defer_dw_reduce=False):
+                   reduce_rider=False, defer_dw_reduce=False):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
@@ -844,20 +844,14 @@ class FusedTower:
             ms.workspace, ms.loss = self._mlp_ws.data_ptr(), self.loss.data_ptr()
             ms.seed, ms.dropout_rate, ms.loss_scale = seed, rate, 1.0 / (B * replicas)
             assert labels.is_contiguous() and o_dX.is_contiguous() and (s0 is None or s0.is_contiguous())
-            # reduce_stream (a torch stream the caller joins before the optimizer): the weight-gradient reduce leaves the step's
-            # chain -- nothing of forward / backward reads the dense gradients
             # reduce_rider: the caller hands self.mlp_reduce_job to a later launch of the step that carries the reduce as extra
             # workgroups (din.py: rsx_din_pool_bwd_pair_ride)
-            ms.defer_reduce = 1 if (reduce_stream is not None or reduce_rider) else 0
+            ms.defer_reduce = 1 if reduce_rider else 0
             check(L.rsx_mlp_nobn_train_step(C.byref(ms), st), "rsx_mlp_nobn_train_step")
             self.mlp_reduce_job = None
             if reduce_rider:
                 self.mlp_reduce_job = _lib.MlpReduceJob()
                 check(L.rsx_mlp_nobn_reduce_job(C.byref(ms), C.byref(self.mlp_reduce_job)), "rsx_mlp_nobn_reduce_job")
-            elif reduce_stream is not None:
-                reduce_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(reduce_stream):
-                    check(L.rsx_mlp_nobn_reduce(C.byref(ms), _stream()), "rsx_mlp_nobn_reduce")
             return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
         g = lambda name: P[name].grad
         bnp = (lambda name: _ptr(P[name])) if self.bn_on else (lambda name: None)        # gamma / beta (None: no batch-norm)

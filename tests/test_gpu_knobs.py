@@ -29,7 +29,6 @@ def _run(model, B, steps, env_extra, bf16=False):
 
 BIT_IDENTICAL = [
     ("deepfm", 256, {"RSX_FUSE_GATHER": "0"}),                # gather as its own launch
-    ("deepfm", 256, {"RSX_WINDOW_RIDE": "1"}),                # the window's sweep as 8 slices riding in the head launches
     ("deepfm", 256, {"RSX_ADAM_WINDOW": "1"}),                # no optimizer windows: every step sorts and carries its sweep slices
     ("deepfm", 256, {"RSX_ADAM_WINDOW": "4"}),
     ("deepfm", 256, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_IN_GATHER": "1", "RSX_FUSE_GATHER": "0"}),   # the sort rides in the gather launch
@@ -43,8 +42,6 @@ BIT_IDENTICAL = [
     ("xdeepfm", 128, {"RSX_ADAM_WINDOW": "1"}),
     ("xdeepfm", 128, {"RSX_XDFM_SORT_RIDE": "0"}),
     # round 4
-    ("deepfm", 256, {"RSX_WINDOW_SIDE": "1"}),                # the window's sort + sweep on a side stream (opt-in: measured slower)
-    ("dcn", 1024, {"RSX_WINDOW_SIDE": "1"}),
     ("dcn", 4096, {"RSX_ADAM_WINDOW": "1"}),                  # stand-alone sort launches of 4 096 keys: several workgroups per field ..
     ("dcn", 4096, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_SPLIT": "0"}),    # .. and one workgroup per field: the same bits
     ("din", 64, {"RSX_DIN_SIDE_SORT": "0"}),                  # din.py: the ids-only branch (sort + sweep) in line instead of on a side stream
@@ -53,7 +50,6 @@ BIT_IDENTICAL = [
     ("din", 64, {"RSX_SCATTER_RIDERS": "0"}),                 # the attention blocks' weight-gradient reduces inside the finish launch
     ("din", 64, {"RSX_DIN_GATHER_RIDE": "0"}),                # the six lookups as their own launch instead of riding in the two prepare launches
     ("din", 64, {"RSX_MLP_REDUCE_RIDE": "0"}),                # the mlp_layer's weight-gradient reduce as its own launch instead of riding in the pooling backward
-    ("din", 64, {"RSX_MLP_REDUCE_RIDE": "0", "RSX_MLP_REDUCE_SIDE": "1"}),   # .. or on the side stream
 ]
 ROUNDING = [
     ("fm", 256, {"RSX_FM_FUSE": "0"}),                        # fp64 reduction of the head's dense gradients instead of the grouped fp32 rows
