@@ -131,7 +131,7 @@ def cpu_baseline(batches, layout, seconds):
 
 WORKLOADS = {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16", "dcn": "Criteo-39 d=16 3 cross layers DNN 100-100",
              "xdeepfm": "Criteo-39 d=16 CIN 128,128 DNN 100-100", "din": "Amazon-Electronics-shaped hist_len=100 K=32"}
-# the launch that takes the largest share of the step in the committed rocprofv3 tables (profiles/r03_*_kernel_stats.txt)
+# the launch that takes the largest share of the step in the committed rocprofv3 tables (profiles/r0N_z_*_kernel_stats.txt, latest round)
 DOMINANT = {"deepfm": "segsum_adam_k (scatter + touched-row Adam; latency-bound) / adam_window_k per window",
             "fm": "segsum_adam_k / adam_window_k per window", "dcn": "tower_bwd_k<true> (fp32 MFMA dW/dX tiles at bs 4096)",
             "xdeepfm": "cin_bwd_dw_k / cin_bwd_dx2_k (fp32 MFMA)", "xdeepfm_bf16": "cin_bwd_dw_bf16_k (bf16 MFMA)",
@@ -393,6 +393,64 @@ def dominant_kernel_fraction(key):
     return None
 
 
+def headline_step_kernels():
+    """The OTHER launches of the headline (deepfm bs 256) step next to the sweep, each against the roof that bounds it, recomputed
+    from the committed evidence: avg duration from the latest profiles/r0N_z_deepfm_kernel_stats.txt, HBM-side traffic from the
+    latest profiles/r0N_*_pmc_{FETCH,WRITE}_SIZE_deepfm.txt (separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KB per launch, at
+    face value: these launches read 64-byte rows, not the wide streams the guide's x2 correction is for).  VERDICT r4 item 7."""
+    import glob
+    import re
+    ks = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_z_deepfm_kernel_stats.txt")))
+    if not ks:
+        return None
+
+    def table(path):
+        out = {}
+        for line in open(path):
+            f = line[72:].split()            # (scripts/rocpd_summary.py: the name in 72 columns, then calls / avg / min / max ...)
+            if len(f) >= 2 and f[0].isdigit() and int(f[0]) > 50:
+                out.setdefault(line[:72].strip(), float(f[1]))
+        return out
+
+    def pmc(name):
+        fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_%s_deepfm.txt" % name)))
+        out = {}
+        if fs:
+            for line in open(fs[-1]):
+                m = re.match(r"^(.*?)\s+%s\s+calls=\s*(\d+)\s+mean=([0-9.]+)" % name, line)
+                if m and int(m.group(2)) > 50:
+                    out.setdefault(m.group(1).strip(), float(m.group(3)))
+        return out, (os.path.basename(fs[-1]) if fs else None)
+
+    avg = table(ks[-1])
+    fetch, fsrc = pmc("FETCH_SIZE")
+    write, _ = pmc("WRITE_SIZE")
+    B, K0, N = 256, 624, 100
+    spec = [("tower_bwd_k", "fp32 MFMA 16x16x4: d(input) + dW tiles of one tower layer (two launches per step: 100x100 and 624x100)",
+             (4 * B * N * N + 4 * B * K0 * N) / 2, 157.3e12, "flop",
+             ((B * N + N * N + B * N) * 4 + (B * K0 + K0 * N + B * N) * 4) / 2),
+            ("segsum_adam_k", "scatter + touched-row Adam + dense Adam + lazy window pass (latency-bound; bytes against HBM)",
+             None, 8e12, "B", 4.4e6)]
+    rows = []
+    for kern, what, flop, peak, unit, alg_read in spec:
+        k = next((n for n in avg if n.startswith("void " + kern) or n.startswith(kern)), None)
+        if k is None:
+            continue
+        us = avg[k]
+        e = {"kernel": kern, "what": what, "avg_us": us, "source": os.path.basename(ks[-1])}
+        if flop is not None:
+            e.update(work_per_launch=int(flop), unit="flop", peak=peak, frac=round(flop / (us * 1e-6) / peak, 4))
+        kf = next((n for n in fetch if kern in n), None)
+        if kf is not None:
+            fb, wb = fetch[kf] * 1024, write.get(kf, 0.0) * 1024
+            e.update(pmc_fetch_bytes=int(fb), pmc_write_bytes=int(wb), alg_bytes=int(alg_read), pmc_source=fsrc,
+                     fetch_over_alg=round(fb / alg_read, 2) if flop is not None else round((fb + wb) / alg_read, 2))
+            if flop is None:
+                e.update(unit="B", peak=peak, frac=round((fb + wb) / (us * 1e-6) / peak, 4))
+        rows.append(e)
+    return rows
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -529,6 +587,11 @@ def main():
         roof.update(step_fractions(est, a.model, B, dt / a.steps * 1e3, wk, a.cin_bf16))
         roof.setdefault("achievable_peak", 6300.0)
         roof.setdefault("frac_of_achievable", round(roof["achieved"] / 6300.0, 4))
+        if a.model == "deepfm" and B == 256:
+            try:
+                roof["other_step_kernels"] = headline_step_kernels()
+            except Exception as ex:
+                roof["other_step_kernels_error"] = repr(ex)[:200]
     try:
         n_launch = launches_per_step(est, t["feats"], wk)
     except Exception as ex:
