@@ -474,6 +474,7 @@ def main():
     if a.emulate_world > 1 and dp is None:
         emu = dist.EmulatedDataParallel(a.emulate_world)
 
+    dp_captured = dist.dp_capture(dp or emu)
     t = time_config(a, a.model, a.batch_size, a.cin_bf16, dp, emu, rank, dev, a.steps, a.warmup, a.repeats)
     est, B, dt, dts, final_loss, host, layout = t["est"], t["B"], t["dt"], t["dts"], t["final_loss"], t["host"], t["layout"]
 
@@ -613,7 +614,7 @@ def main():
                                      ("steps_per_graph=%d" % a.steps_per_graph) if (dp is None and emu is None) else
                                      ("one graph-segment chain per optimizer window (one ids all-gather per window, one gradient "
                                       "all-gather per step), RCCL collectives %s" %
-                                      ("captured" if os.environ.get("RSX_DP_CAPTURE") == "1" else "eager between segments"))),
+                                      ("captured into the graphs (steps_per_graph=%d)" % a.steps_per_graph if dp_captured else "eager between graph segments"))),
                       "global_batch": N * B, "parallelism": ("dp%d" % N) if emu is None else "EMULATED per-rank compute of dp%d (not a throughput claim)" % emu.world, "final_loss": round(final_loss, 5),
                       "adam_window": wk, "launches_per_step": n_launch,
                       **dp_exchange_info(store, B),

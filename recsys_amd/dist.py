@@ -128,6 +128,27 @@ class _AsyncAllReduce:
             self.work = None
 
 
+def dp_capture(dp):
+    """Are the step's collectives CAPTURED into its HIP graphs (one graph per group of steps, like the single-replica schedule)
+    or issued eagerly between graph segments (SegmentedGraph)?  Round 5: captured by default over RCCL -- through RCCL at world 1
+    deepfm.py's step costs 0.0609 ms captured against 0.0795 eager (0.0574 without data parallelism): every segment boundary is a
+    graph launch's ~9 us start-up + ~8 us tail on this stack.  RSX_DP_CAPTURE=0 / 1 overrides; gloo (several ranks on one GPU,
+    the CPU tests) cannot be captured; RSX_DP_OVERLAP's asynchronous per-layer all-reduces keep the eager form."""
+    env = os.environ.get("RSX_DP_CAPTURE")
+    if env is not None:
+        return env == "1"
+    if dp is None:
+        return False
+    if isinstance(dp, (EmulatedDataParallel, LoopbackDataParallel)):
+        return True                     # (no real collective to break a graph for)
+    if dp_overlap_enabled():
+        return False
+    try:
+        return dist.get_backend(dp.group) == "nccl"
+    except Exception:
+        return False
+
+
 def dp_overlap_enabled():
     """RSX_DP_OVERLAP=1 (opt-in, default off): the dense-gradient all-reduce is issued per tower layer from inside
     backward instead of riding in the step's single all-gather.  At DeepFM's size the step is latency-bound and one
@@ -193,7 +214,7 @@ def graph_break(op):
     """Run the collective `op` now; under a SegmentedGraph capture, end the current segment first and record `op` so
     every replay re-issues it between the segments."""
     seg = SegmentedGraph._active
-    if seg is None or os.environ.get("RSX_DP_CAPTURE") == "1":
+    if seg is None:                     # (eager, or a capture that takes the collectives too: dp_capture)
         op()
     else:
         seg.run_eager(op)
@@ -214,7 +235,7 @@ class DataParallel:
         x = x.contiguous()
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         seg = SegmentedGraph._active
-        if prefetchable and seg is not None and os.environ.get("RSX_DP_CAPTURE") != "1" and seg.prefetch is None:
+        if prefetchable and seg is not None and seg.prefetch is None:
             op = _PrefetchableAllGather(out, x, self.group)
             seg.prefetch = op
             seg.run_eager(op)

@@ -363,23 +363,30 @@ class Estimator:
         k = int(os.environ.get("RSX_ADAM_WINDOW", self.params.get("adam_window", self.store.window_k)))
         return max(1, min(k, self.store.window_k))
 
+    def _dp_capture(self):
+        from .dist import dp_capture
+        return dp_capture(self.store.dp)
+
     def _use_graph(self):
         """HIP graphs are on unless the step has data-parallel collectives issued from inside autograd's backward
         (worker thread: the capture cannot be segmented there); RSX_DP_CAPTURE=1 captures the collectives too."""
         if not self.config.use_hip_graph:
             return False
-        return self.store.dp is None or self.store.graph_safe_dp or os.environ.get("RSX_DP_CAPTURE") == "1"
+        return self.store.dp is None or self.store.graph_safe_dp or self._dp_capture()
 
     def _capture(self, fn):
         """-> (replayable, fn's result).  Data-parallel steps become graph segments with eager RCCL calls between
         them (dist.SegmentedGraph); single-process steps one HIP graph."""
         torch.cuda.synchronize()
-        if self.store.dp is not None and os.environ.get("RSX_DP_CAPTURE") != "1":
+        if self.store.dp is not None and not self._dp_capture():
             from .dist import SegmentedGraph
             seg = SegmentedGraph()
             return seg, seg.capture(fn)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # (data parallel with captured collectives: "thread_local" lets ProcessGroupNCCL's watchdog thread poll its events
+        # while THIS thread captures -- see dist.SegmentedGraph._begin)
+        kw = {"capture_error_mode": "thread_local"} if self.store.dp is not None else {}
+        with torch.cuda.graph(graph, **kw):
             out = fn()
         return graph, out
 
@@ -388,7 +395,7 @@ class Estimator:
         plain kernel calls (store.graph_safe_dp): only model_fn is captured; train_op -- pack, the gradient all-gather, 2-3
         launches -- is re-issued eagerly on every replay.  A graph launch costs ~9 us of start-up and ~8 us before the next
         un-captured operation begins (measured through RCCL at world 1): a graph around so few launches loses more than it saves."""
-        if self.store.dp is not None and self.store.graph_safe_dp and os.environ.get("RSX_DP_CAPTURE") != "1" and \
+        if self.store.dp is not None and self.store.graph_safe_dp and not self._dp_capture() and \
                 os.environ.get("RSX_DP_EAGER_TAIL", "1") == "1":
             seg, spec = self._capture(lambda: self._call_model_fn(features, labels, ModeKeys.TRAIN))
             seg.items.append(spec.train_op)      # re-executed (eagerly) by every replay, after the captured segments
@@ -479,7 +486,7 @@ class Estimator:
         buffers directly: no per-step input copy and one graph launch per group ("capture launch-bound inner
         loops in hipGraphs").  An input pipeline refills the buffers in place between replays."""
         n = len(batches)
-        if self._use_graph() and self.store.dp is not None and os.environ.get("RSX_DP_CAPTURE") != "1":
+        if self._use_graph() and self.store.dp is not None and not self._dp_capture():
             # data-parallel with eager collectives: one segmented step per RESIDENT batch, reading its buffer in place
             # (no per-step input copy); steps cannot be grouped because the collectives sit between the segments
             key = ("resident-dp", id(batches[0]), n)
@@ -518,7 +525,10 @@ class Estimator:
                 seg.replay(nxt)
                 s += 1
             return loss if loss is not None else g["steps"][0][1]
-        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
+        # (data parallel with captured collectives -- dist.dp_capture, the default over RCCL: they sit in the groups' graphs like any
+        # other launch)
+        dp_eager = self.store.dp is not None and not self._dp_capture()
+        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or dp_eager:
             for s in range(steps):
                 loss = self._train_step(batches[s % n])
             return loss
@@ -590,7 +600,8 @@ class Estimator:
         afterwards is pure replay.  Capturing itself executes nothing -- but when the resident graphs are still cold this runs
         the TWO eager warm-up training steps first (lazy initialisation, allocator warm-up): real optimizer steps."""
         n = len(batches)
-        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or self.store.dp is not None:
+        dp_eager = self.store.dp is not None and not self._dp_capture()
+        if not self._use_graph() or n % steps_per_graph != 0 or steps_per_graph <= 1 or dp_eager:
             return
         g = self._graphs.get(("resident", id(batches[0]), n, steps_per_graph))
         if g is None or g["warm"] < 2:
