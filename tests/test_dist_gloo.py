@@ -255,3 +255,89 @@ def test_window_ids_all_gather_world2(tmp_path):
     """Optimizer windows under data parallelism: ONE all-gather of the stacked ids of the window's k local batches must give
     the same k global batches (rank order) as k per-step all-gathers."""
     mp.spawn(_window_ids_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _rank_inputs(rank, k, KS, capT, D, n):
+    """What rank `rank` contributes to one step of the unique-list exchange (deterministic, distinct per rank)."""
+    keys = (torch.arange(k * KS, dtype=torch.int32) + 100000 * (rank + 1)).view(1, k * KS)
+    dense = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    G = (torch.arange(capT * D, dtype=torch.float32) + 1000.0 * (rank + 1)).view(capT, D)
+    gw1 = torch.arange(capT, dtype=torch.float32) + 0.5 * (rank + 1)
+    return keys, dense, G, gw1
+
+
+def _unique_exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from recsys_amd import dist as rdist
+    rdist.init_process_group("gloo")
+    dp = rdist.DataParallel()
+    assert rdist.dp_capture(dp) is False                      # gloo collectives cannot sit in a HIP graph
+    k, KS, capT, D, n = 3, 44, 10, 4, 37
+    dense = _FakeDenseArena(n)
+    send = dp.make_send_block(dense, capT, [D, 1])            # [dense | G [capT, D] | gw1 [capT]]
+    keys, dg, G, gw1 = _rank_inputs(rank, k, KS, capT, D, n)
+    keys_g = dp.all_gather_keys(keys)
+    assert keys_g.shape == (world, k * KS) and keys_g.dtype == torch.int32
+    for r in range(world):
+        assert torch.equal(keys_g[r:r + 1], _rank_inputs(r, k, KS, capT, D, n)[0])
+    Gv, gwv = dp.send_views(capT)
+    assert Gv.shape == (capT, D) and gwv.shape == (capT,) and Gv.data_ptr() == send.data_ptr() + 40 * 4
+    dense.grad.copy_(dg)
+    Gv.copy_(G)
+    gwv.copy_(gw1)
+    (G0, gw0), (bb, stride), seg = dp.gather_send_block(capT, fold_dense=True)
+    out = dp._keep
+    assert bb == capT and stride % 4 == 0 and G0.data_ptr() % 16 == 0 and out.shape == (world, stride)
+    for r in range(world):                                    # rank r's block: G0 / gw0 + r * stride floats
+        _, dr, Gr, gr = _rank_inputs(r, k, KS, capT, D, n)
+        base = out.view(-1)
+        o = (G0.data_ptr() - out.data_ptr()) // 4 + r * stride
+        assert torch.equal(base[o:o + capT * D].view(capT, D), Gr)
+        o1 = (gw0.data_ptr() - out.data_ptr()) // 4 + r * stride
+        assert torch.equal(base[o1:o1 + capT], gr)
+        assert torch.equal(out[r, :n], dr)
+    assert seg[0]["B"] == world and seg[0]["stride"] == stride
+    torch.save({"keys_g": keys_g, "out": out.clone(), "stride": stride}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_unique_exchange_plumbing_world2_and_the_loopback_harness_agree(tmp_path):
+    """The two collectives of the unique-row-list exchange over a real 2-process gloo group (key blocks in rank order; the send
+    block [dense | G | gw1] with rank r's block r * stride floats on), and the single-process LoopbackDataParallel harness the
+    GPU parity tests use must hand the optimizer stage the SAME gathered buffers for the same per-rank inputs."""
+    world = 2
+    mp.spawn(_unique_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from recsys_amd import dist as rdist
+    k, KS, capT, D, n = 3, 44, 10, 4, 37
+
+    class _Opt:
+        shadow = False
+
+    class _Store:
+        opt, embeddings, din = _Opt(), {}, None
+
+    lb = rdist.LoopbackDataParallel(world)
+    dense = _FakeDenseArena(n)
+    lb.make_send_block(dense, capT, [D, 1])
+    store = _Store()
+    lb.begin_step()
+    for r in range(world):
+        lb.enter_rank(r, store)
+        assert store.opt.shadow == (r < world - 1)
+        keys, dg, G, gw1 = _rank_inputs(r, k, KS, capT, D, n)
+        keys_g = lb.all_gather_keys(keys)
+        Gv, gwv = lb.send_views(capT)
+        dense.grad.copy_(dg)
+        Gv.copy_(G)
+        gwv.copy_(gw1)
+        lb.leave_rank(store)
+    (G0, gw0), (bb, stride), seg = lb.gather_send_block(capT, fold_dense=True)
+    ref = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    ref1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    assert torch.equal(ref["keys_g"], ref1["keys_g"]) and torch.equal(ref["out"], ref1["out"])
+    assert torch.equal(keys_g, ref["keys_g"])                 # (the LAST rank's pass sees every rank's real key block)
+    assert stride == ref["stride"] and torch.equal(lb._keep, ref["out"])
+    assert rdist.dp_capture(lb) is True and rdist.dp_capture(None) is False
