@@ -1333,8 +1333,7 @@ __global__ __launch_bounds__(256) void segsum_adam_k(const float* __restrict__ S
     const uint32_t wb = blockIdx.x - n_rows;
     RSX_STAMP(40, wb == 0);
     RSX_STAMP_MAX(62, true);                                                           // latest ENTRY of a window-pass workgroup
-    if (h.win_compact) window_pass_compact<D, NR>(h, wb, b1p, b2p, F, stride);
-    else window_pass<D, NR>(h, wb, b1p, b2p, F, stride);
+    window_pass<D, NR>(h, wb, b1p, b2p, F, stride);
   } else if (blockIdx.x >= h.n_own) {     // second table set
     const int q = (threadIdx.x & 63) % LPR;
     bool valid, do1;
@@ -1917,13 +1916,6 @@ extern "C" int rsx_segsum_adam_rows2(float* tables, float* m_t, float* v_t, floa
   const long long waves = (long long)F * seg_waves_per_field(B, gpw, part.P != nullptr);
   h.n_own = (uint32_t)((waves + 3) / 4);
   if (part.P != nullptr && h.n_own > (uint32_t)SEG_STAGE_B_MAX_WG) h.n_own = SEG_STAGE_B_MAX_WG;   // (grid stride, compact units)
-  {
-    // RSX_WIN_COMPACT=1 (round 5, A/B): the lazy window pass walks the COMPACT unit list of the lists it visits with a grid stride
-    // (window_pass_compact) instead of a dense (list, field, block) grid -- same rows, same arithmetic
-    static const int compact = getenv("RSX_WIN_COMPACT") ? atoi(getenv("RSX_WIN_COMPACT")) : 0;
-    h.win_compact = compact != 0 && h.win_blk > 0;
-    if (h.win_compact && h.win_blk > (uint32_t)compact) h.win_blk = (uint32_t)compact;
-  }
   h.total_blocks = (second_h != nullptr ? 2u : 1u) * h.n_own + h.win_blk + h.extra.n_blk + h.cold.n_blk;
   const dim3 grid(h.total_blocks), block(256);
   RSX_DISPATCH_D(D, launch_segsum_adam, grid, block, rsx_s(stream), S, dX, gy1, gy2, perm, seg_off, uniq_row, nuniq,

@@ -13,17 +13,13 @@ scripts/gpu.sh prof ${tag}_xdeepfm_bf16_kernel_stats --model xdeepfm --cin_bf16 
 scripts/gpu.sh prof ${tag}_din_kernel_stats --model din --no_cpu_baseline --no_configs --steps 160 --warmup 16
 TAG=${tag}_default scripts/gpu.sh bench
 TAG=${tag}_steps20 scripts/gpu.sh bench --steps 20
-for m in deepfm fm dcn xdeepfm din; do scripts/gpu.sh emulate $m > /dev/null; done
-cat gpurun_out/emulate_deepfm.txt gpurun_out/emulate_fm.txt gpurun_out/emulate_dcn.txt gpurun_out/emulate_xdeepfm.txt gpurun_out/emulate_din.txt > gpurun_out/${tag}_emulate_world_all_models.txt
+# per-rank compute of an N-rank step (peers = other resident batches), both sparse exchanges, all models
+scripts/emulate_table.sh > /dev/null 2>&1; cp gpurun_out/emulate_table.txt gpurun_out/${tag}_emulate_world_all_models.txt
 scripts/gpu.sh roofline > /dev/null; cp gpurun_out/kernel_roofline_table.txt gpurun_out/${tag}_kernel_roofline_table.txt
 for r in 1 2 3; do echo "# repeat $r"; python scripts/scatter_large.py 4096 65536 2>/dev/null; done > gpurun_out/${tag}_scatter_large_3_repeats.txt
-# the data-parallel code path through RCCL at world 1 (collectives, send block, segmented graphs), all five models
-for m in deepfm fm dcn xdeepfm din; do
-  RSX_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus 1 --model $m --no_cpu_baseline --no_configs 2>/dev/null | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-print('world-1 RCCL: model $m  ms_per_step', d['ms_per_step'], ' adam_window', d['config']['adam_window'], ' launches/step', d['config'].get('launches_per_step'), ' send_bytes/rank', d['config'].get('dp_send_bytes_per_rank_per_step'))"
-done > gpurun_out/${tag}_dp_world1_rccl.txt 2>&1
+# the data-parallel code path through RCCL at world 1 (collectives captured into the graphs: the default), both exchanges,
+# and with eager collectives between graph segments
+scripts/dp_world1.sh > gpurun_out/${tag}_dp_world1_rccl.txt 2>&1
+RSX_DP_CAPTURE=0 MODELS="deepfm dcn" scripts/dp_world1.sh 2>&1 | sed 's/^world-1 RCCL/world-1 RCCL, RSX_DP_CAPTURE=0 (eager collectives)/' >> gpurun_out/${tag}_dp_world1_rccl.txt
 cat gpurun_out/${tag}_dp_world1_rccl.txt
 ls -la gpurun_out | grep $tag
