@@ -109,7 +109,7 @@ def dp_unique_wanted(store, params):
     """The data-parallel sparse exchange of this run: unique-row lists (round 5; the default from two ranks on) need the split
     TF-1 update (the optimizer launch that owns the touched rows); RSX_DP_EXCHANGE=examples: the pre-dedup per-example block of
     rounds 1-4 -- also the default at world 1 (RSX_FORCE_DIST), where there is nothing to merge and the rank-local dedup +
-    segment-sum are pure overhead (through RCCL at world 1: deepfm.py 0.0613 ms against 0.0680)."""
+    segment-sum are pure overhead (through RCCL at world 1: deepfm.py 0.0790 ms against 0.0875)."""
     world = store.dp.world if store.dp is not None else 1
     default = "unique" if world > 1 else "examples"
     return os.environ.get("RSX_DP_EXCHANGE", default) == "unique" and store.adam_mode == "tf1_dense" and \

@@ -130,23 +130,16 @@ class _AsyncAllReduce:
 
 def dp_capture(dp):
     """Are the step's collectives CAPTURED into its HIP graphs (one graph per group of steps, like the single-replica schedule)
-    or issued eagerly between graph segments (SegmentedGraph)?  Round 5: captured by default over RCCL -- through RCCL at world 1
-    deepfm.py's step costs 0.0609 ms captured against 0.0795 eager (0.0574 without data parallelism): every segment boundary is a
-    graph launch's ~9 us start-up + ~8 us tail on this stack.  RSX_DP_CAPTURE=0 / 1 overrides; gloo (several ranks on one GPU,
-    the CPU tests) cannot be captured; RSX_DP_OVERLAP's asynchronous per-layer all-reduces keep the eager form."""
-    env = os.environ.get("RSX_DP_CAPTURE")
-    if env is not None:
-        return env == "1"
-    if dp is None:
-        return False
-    if isinstance(dp, (EmulatedDataParallel, LoopbackDataParallel)):
-        return True                     # (no real collective to break a graph for)
-    if dp_overlap_enabled():
-        return False
-    try:
-        return dist.get_backend(dp.group) == "nccl"
-    except Exception:
-        return False
+    or issued eagerly between graph segments (SegmentedGraph)?  Captured is FASTER -- through RCCL at world 1 deepfm.py's step
+    costs 0.0598 ms captured against 0.0790 eager (0.0571 without data parallelism): every segment boundary is a graph launch's
+    ~9 us start-up + ~8 us tail on this stack -- but NOT the default (RSX_DP_CAPTURE=1 opts in): with this torch / RCCL pair
+    ProcessGroupNCCL's watchdog thread sometimes polls an event that was last recorded in the capturing stream and aborts the
+    process (xdeepfm.py, whose step has an all-reduce beside the all-gather: 4 of 12 world-1 runs; the four other models: 0 of
+    ~40; profiles/r05_z_dp_world1_rccl.txt).  A crash in one run in three is not a default.  The emulation / loopback harnesses
+    have no real collective to break a graph for: always captured."""
+    if dp is not None and isinstance(dp, (EmulatedDataParallel, LoopbackDataParallel)):
+        return True
+    return os.environ.get("RSX_DP_CAPTURE", "0") == "1" and dp is not None
 
 
 def dp_overlap_enabled():
@@ -431,6 +424,14 @@ class DataParallel:
         return dX_g, S_g, gy1_g, gy2_g
 
     def _overlapped_allreduce_allgather(self, grad, out, x):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # captured collectives (dp_capture): synchronous calls only.  An async_op=True collective issued under capture hands
+            # ProcessGroupNCCL's watchdog thread a Work whose end event was recorded in the capturing stream; its next poll
+            # aborts the process ("operation not permitted on an event last recorded in a capturing stream" -- seen in 2 of 4
+            # world-1 runs of xdeepfm.py).  Inside the graph the two collectives are nodes of RCCL's stream either way.
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(out, x, group=self.group)
+            return
         work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         dist.all_gather_into_tensor(out, x, group=self.group)
         work.wait()                     # stream-level wait: the host does not block

@@ -17,9 +17,9 @@ TAG=${tag}_steps20 scripts/gpu.sh bench --steps 20
 scripts/emulate_table.sh > /dev/null 2>&1; cp gpurun_out/emulate_table.txt gpurun_out/${tag}_emulate_world_all_models.txt
 scripts/gpu.sh roofline > /dev/null; cp gpurun_out/kernel_roofline_table.txt gpurun_out/${tag}_kernel_roofline_table.txt
 for r in 1 2 3; do echo "# repeat $r"; python scripts/scatter_large.py 4096 65536 2>/dev/null; done > gpurun_out/${tag}_scatter_large_3_repeats.txt
-# the data-parallel code path through RCCL at world 1 (collectives captured into the graphs: the default), both exchanges,
-# and with eager collectives between graph segments
+# the data-parallel code path through RCCL at world 1, both exchanges: eager collectives between graph segments (the default)
+# and collectives captured into the graphs (RSX_DP_CAPTURE=1; a run that prints no line was aborted by the watchdog, dist.dp_capture)
 scripts/dp_world1.sh > gpurun_out/${tag}_dp_world1_rccl.txt 2>&1
-RSX_DP_CAPTURE=0 MODELS="deepfm dcn" scripts/dp_world1.sh 2>&1 | sed 's/^world-1 RCCL/world-1 RCCL, RSX_DP_CAPTURE=0 (eager collectives)/' >> gpurun_out/${tag}_dp_world1_rccl.txt
+RSX_DP_CAPTURE=1 scripts/dp_world1.sh 2>&1 | grep "world-1 RCCL" | sed 's/^world-1 RCCL/world-1 RCCL, RSX_DP_CAPTURE=1 (captured collectives)/' >> gpurun_out/${tag}_dp_world1_rccl.txt
 cat gpurun_out/${tag}_dp_world1_rccl.txt
 ls -la gpurun_out | grep $tag
