@@ -105,18 +105,6 @@ int rsx_gather_fm_head(const float* tables, const float* w1, const int32_t* row_
                        uint64_t w1_field_mask, const float* c0, const float* wo, const float* bo, const float* labels,
                        float* prob, float* gy1, float* gy2, float* terms, int term_stride, int n_dense, int off_c0,
                        int off_wo, int off_bo, float loss_scale, int B, int F, int D, rsx_stream_t stream);
-/* Dense gradient buckets of the SMALL-VOCABULARY fields (data parallel, round 4): TF's MirroredStrategy sums the replicas'
- * IndexedSlices of every embedding variable (fm/fm.py:184-194, SURVEY A-4/A-12); for a field of a few hundred rows that sum
- * is cheapest as a dense [rows, D] array that rides the dense gradients' collective -- no sort, no ragged counts.
- * bucket_field [nbf] names the fields, bucket_off [nbf + 1] their first rows inside the bucket (nb = bucket_off[nbf] rows);
- * G [nb, D] / gw1 [nb] (nullable) receive, for EVERY bucket row, the sum over the LOCAL batch's examples with that id of
- * (gy2[b] S[b,:] - gy2[b] T[row,:]) + dX[b, f, :]  and of gy1[b] (fields in w1_field_mask) -- the per-entry terms of
- * rsx_segsum_bwd; rows no example names get zeros.  dX or (S, gy2) may be NULL as there.  The replicas' buckets are added in
- * rank order by the optimizer (rsx_adam_seg.g_replicas).  One launch, one wave per bucket row, deterministic.               */
-int rsx_bucket_scatter(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
-                       const int32_t* ids, const int32_t* row_off, const int32_t* bucket_field, const int32_t* bucket_off,
-                       float* G, float* gw1, uint64_t w1_field_mask, int B, int F, int D, int n_bucket_fields,
-                       int n_bucket_rows, rsx_stream_t stream);
 /* A per-field dedup sort job (the arguments of rsx_field_sort) that may ride along in another launch. */
 typedef struct {
   const int32_t* ids;
@@ -129,9 +117,9 @@ typedef struct {
   int32_t* segid;             /* nullable */
   int32_t max_rows_per_field, B, F, stride;
   uint64_t skip_mask;         /* bit f set: field f is NOT sorted -- its workspace rows must be zero-initialised and then keep
-                                 nuniq[f] = 0, so the scatter / optimizer entry points find nothing to do for it.  Used by the
-                                 data-parallel step for the small-vocabulary fields whose gradients travel as dense per-row
-                                 buckets (rsx_bucket_scatter).  Skip a field always or never; 0 = sort every field. */
+                                 nuniq[f] = 0, so the scatter / optimizer entry points find nothing to do for it (a
+                                 caller that handles some fields' gradients elsewhere).  Skip a field always or never; 0 =
+                                 sort every field. */
 } rsx_sort_job;
 /* njobs (<= 8) independent sorts of the same shape (B, F, stride) in ONE launch, F workgroups each: the k batches of an
  * optimizer window (rsx_adam_window), each into its own workspace.  B <= 16384 (the rsx_field_sort range).              */
@@ -245,8 +233,8 @@ typedef struct {
    * in memory (slot_w[j] = slot_w[0] + j * stride, 16-byte aligned: slices of one allocation), else RSX_EINVAL.             */
   const int32_t* slot_w[7];
   /* TABLE_ROWS / VEC_ROWS_DENSE: g is the FIRST of g_replicas (> 1) arrays g_replica_stride floats apart (a multiple of 4) --
-   * the replicas' dense gradient buckets inside an all-gathered buffer (rsx_bucket_scatter) -- added in order r = 0.. before
-   * the update: every replica applies the same sum.  0 / 1: g alone.                                                        */
+   * per-replica gradient rows inside an all-gathered buffer -- added in order r = 0.. before the update: every replica applies
+   * the same sum.  0 / 1: g alone.                                                        */
   int32_t g_replicas;
   int64_t g_replica_stride;
 } rsx_adam_seg;

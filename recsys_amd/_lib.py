@@ -140,7 +140,6 @@ _SIGS = {
     "rsx_gather_fm_fwd_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _U64, _I, _I, _I, _P, _P]),
     "rsx_gather_two_fwd": (_I, [_P] * 10 + [_U64, _I, _I, _I, _I, _P]),
     "rsx_gather_fm_head": (_I, [_P] * 5 + [_U64] + [_P] * 8 + [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P]),
-    "rsx_bucket_scatter": (_I, [_P] * 11 + [_U64, _I, _I, _I, _I, _I, _P]),
     "rsx_field_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rsx_field_sort_large": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
     "rsx_field_sort_large_t": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),

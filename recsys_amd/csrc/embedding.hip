@@ -175,86 +175,6 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ t
   reinterpret_cast<float4*>(out)[e * LPR + q] = reinterpret_cast<const float4*>(table)[row * LPR + q];
 }
 
-// ------------------------------------------------------------------ dense gradient buckets (data parallel) ---
-// The small-vocabulary fields' share of the sparse gradient as DENSE per-row buckets, from the LOCAL batch, without a sort
-// (round 4; TF's MirroredStrategy sums the replicas' IndexedSlices of a variable, fm/fm.py:184-194 -- for a table of a few
-// hundred rows that sum is cheapest as a dense [rows, D] array riding the dense gradients' collective).
-// One wave per bucket row k = (bucket field j, row r): the wave scans the field's B ids (ballots), and sums the matching
-// examples' contributions  (gy2[b] S[b,:] - gy2[b] T[row,:]) + dX[b, f, :]  (+ gy1[b] for the first-order weight) --
-// 64/LPR examples at a time, one per LPR-lane group, reduced by a fixed xor-tree over the groups, chunks of 64 ids in
-// ascending order: deterministic, and EVERY bucket row is written (zeros when no example matches), so the buckets need no
-// clearing.  Per-rank partial sums are added in rank order by the optimizer (rsx_adam_seg.g_replicas): the association
-// differs from the single-process sum over the global batch -- fp32 rounding, 1e-6 relative --, replicas stay bit-identical.
-struct BucketArgs {
-  const float* tables; const float* S; const float* dX; const float* gy1; const float* gy2;
-  const int32_t* ids; const int32_t* row_off;
-  const int32_t* bfield;   // [nbf] field of bucket field j
-  const int32_t* boff;     // [nbf + 1] first bucket row of bucket field j
-  float* G;                // [nb, D]
-  float* gw1;              // [nb] or null
-  uint64_t w1_mask;
-  int B, F, nbf, nb;
-};
-
-template <int D>
-__global__ __launch_bounds__(256) void bucket_scatter_k(const BucketArgs a) {
-  constexpr int LPR = D / 4, NG = RSX_WAVE / LPR;      // lanes per row, example groups per wave
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int k = blockIdx.x * 4 + w;
-  if (k >= a.nb) return;                              // (wave-uniform; no barriers below)
-  // bucket field of row k: the last j with boff[j] <= k (nbf <= 64: one lane per candidate)
-  const int bo = a.boff[lane <= a.nbf ? lane : a.nbf];
-  const int j = __popcll(__builtin_amdgcn_ballot_w64(lane < a.nbf && bo <= k)) - 1;
-  const int f = a.bfield[j];
-  const int r = k - __shfl(bo, j);
-  const int row = a.row_off[f] + r;
-  const int q = lane % LPR, grp = lane / LPR;
-  const bool fm = a.gy2 != nullptr, xg = a.dX != nullptr;
-  const bool do1 = a.gw1 != nullptr && a.gy1 != nullptr && ((a.w1_mask >> f) & 1ull);
-  const float4 T = fm ? reinterpret_cast<const float4*>(a.tables)[(size_t)row * LPR + q] : F4Z;
-  const float4* __restrict__ X4 = reinterpret_cast<const float4*>(xg ? a.dX : a.S);       // (always a valid array)
-  const float4* __restrict__ S4 = reinterpret_cast<const float4*>(fm ? a.S : a.dX);
-  const float* __restrict__ h2 = fm ? a.gy2 : a.dX;
-  const float* __restrict__ h1 = do1 ? a.gy1 : (fm ? a.gy2 : a.dX);
-  const int xF = xg ? a.F : 1, xf = xg ? f : 0;
-  float4 acc = F4Z;
-  float a1 = 0.f;
-  for (int c0 = 0; c0 < a.B; c0 += 64) {
-    const int e0 = c0 + lane;
-    const int id = a.ids[(size_t)(e0 < a.B ? e0 : a.B - 1) * a.F + f];
-    uint64_t m = __builtin_amdgcn_ballot_w64(e0 < a.B && id == r);
-    while (m != 0ull) {                               // (wave-uniform) up to NG matches per round, ascending example order
-      int mine = -1;
-#pragma unroll
-      for (int t = 0; t < NG; ++t) {
-        const int pos = m != 0ull ? __builtin_ctzll(m) : -1;
-        if (grp == t) mine = pos;
-        m = m != 0ull ? (m & (m - 1ull)) : 0ull;
-      }
-      const float okf = mine >= 0 ? 1.f : 0.f;
-      const int e = c0 + (mine >= 0 ? mine : 0);      // unconditional loads on a clamped index, masked by multiplication
-      const float4 x = X4[((size_t)e * xF + xf) * LPR + q];
-      const float4 sv = S4[(size_t)e * LPR + q];
-      const float g2 = h2[e], g1 = h1[e];
-      float4 v;
-      v.x = ((fm ? g2 * sv.x - g2 * T.x : 0.f) + (xg ? x.x : 0.f)) * okf;
-      v.y = ((fm ? g2 * sv.y - g2 * T.y : 0.f) + (xg ? x.y : 0.f)) * okf;
-      v.z = ((fm ? g2 * sv.z - g2 * T.z : 0.f) + (xg ? x.z : 0.f)) * okf;
-      v.w = ((fm ? g2 * sv.w - g2 * T.w : 0.f) + (xg ? x.w : 0.f)) * okf;
-      float u = do1 ? g1 * okf : 0.f;
-#pragma unroll
-      for (int s = LPR; s < RSX_WAVE; s <<= 1) {      // fixed tree over the groups
-        v = f4_add(v, f4_shfl_xor(v, s));
-        u += __shfl_xor(u, s);
-      }
-      acc = f4_add(acc, v);
-      a1 += u;
-    }
-  }
-  if (grp == 0) reinterpret_cast<float4*>(a.G)[(size_t)k * LPR + q] = acc;
-  if (a.gw1 != nullptr && lane == 0) a.gw1[k] = a1;
-}
-
 // ------------------------------------------------------------------ dedup: per-field LDS sort ---
 // One workgroup per field (sort_device.h).  n = padded power of two (>= 128), T = min(1024, n/2) threads.
 __global__ __launch_bounds__(1024) void field_sort_k(const SortArgs a) {
@@ -785,7 +705,7 @@ __device__ __forceinline__ void segsum_tiles_body(const float* __restrict__ tabl
   const int tid = threadIdx.x;
   const int tiles = (B + T::POS - 1) / T::POS;
   const int f = blockIdx.x / tiles;
-  if ((ws.skip >> f) & 1ull) return;               // (workgroup-uniform) a field the sort skipped: its gradients travel as buckets
+  if ((ws.skip >> f) & 1ull) return;               // (workgroup-uniform) a field the sort skipped (rsx_sort_job.skip_mask)
   const int base = (blockIdx.x - f * tiles) * T::POS;
   const int32_t* pf = perm + (size_t)f * stride;
   const int32_t* sid = ws.segid + (size_t)f * stride;
@@ -1620,27 +1540,6 @@ extern "C" int rsx_gather_fm_head(const float* tables, const float* w1, const in
   return RSX_OK;
 }
 
-template <int D>
-static void launch_bucket(dim3 grid, hipStream_t st, const BucketArgs& a) {
-  RSX_COUNT_LAUNCH(); bucket_scatter_k<D><<<grid, dim3(256), 0, st>>>(a);
-}
-
-extern "C" int rsx_bucket_scatter(const float* tables, const float* S, const float* dX, const float* gy1, const float* gy2,
-                                  const int32_t* ids, const int32_t* row_off, const int32_t* bucket_field,
-                                  const int32_t* bucket_off, float* G, float* gw1, uint64_t w1_field_mask, int B, int F,
-                                  int D, int n_bucket_fields, int n_bucket_rows, rsx_stream_t stream) {
-  if (!ids || !row_off || !bucket_field || !bucket_off || !G || B < 0 || F <= 0 || F > 64 || n_bucket_fields <= 0 ||
-      n_bucket_fields > 64 || n_bucket_rows <= 0 || !d_ok(D))
-    return RSX_EINVAL;
-  if (gy2 == nullptr && dX == nullptr) return RSX_EINVAL;          // nothing to sum
-  if (gy2 != nullptr && (S == nullptr || tables == nullptr)) return RSX_EINVAL;
-  if (B == 0) return RSX_EINVAL;                                   // (the buckets would have to be zeroed: callers skip the step)
-  BucketArgs a{tables, S, dX, gy1, gy2, ids, row_off, bucket_field, bucket_off, G, gw1, w1_field_mask, B, F, n_bucket_fields,
-               n_bucket_rows};
-  RSX_DISPATCH_D(D, launch_bucket, dim3((unsigned)((n_bucket_rows + 3) / 4)), rsx_s(stream), a);
-  RSX_CHECK_LAUNCH();
-  return RSX_OK;
-}
 
 extern "C" int rsx_field_sort(const int32_t* ids, const int32_t* row_off, int32_t* perm, int32_t* seg_off,
                               int32_t* uniq_row, int32_t* nuniq, int32_t* slot, int32_t* segid, int max_rows_per_field,
