@@ -59,6 +59,9 @@ def parse():
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
     p.add_argument("--cin_bf16", action="store_true", help="xdeepfm: CIN contraction on the bf16 MFMA path (fp32 accumulate); the "
                    "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
+    p.add_argument("--cin_split", type=int, default=0, choices=[0, 1, 2, 3],
+                   help="xdeepfm: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (csrc/cin_split.hip); 3 = every "
+                        "product exact to 2^-23 (fp32-grade: held to the fp32 path's 1e-5 parity tests)")
     p.add_argument("--no_overlap", action="store_true", help="profiling aid: plain path (stand-alone sort, segment-sum, ONE full "
                    "optimizer sweep) instead of sweep slices riding in the tower launches -- shows every kernel's own duration")
     p.add_argument("--no_configs", action="store_true", help="skip the `configs` list (the other BASELINE configs)")
@@ -135,6 +138,7 @@ WORKLOADS = {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16", "dc
 DOMINANT = {"deepfm": "segsum_adam_k (scatter + touched-row Adam; latency-bound) / adam_window_k per window",
             "fm": "segsum_adam_k / adam_window_k per window", "dcn": "tower_bwd_k<true> (fp32 MFMA dW/dX tiles at bs 4096)",
             "xdeepfm": "cin_bwd_dw_k / cin_bwd_dx2_k (fp32 MFMA)", "xdeepfm_bf16": "cin_bwd_dw_bf16_k (bf16 MFMA)",
+            "xdeepfm_x3": "cin_split_dw_k<3> / cin_split_dx_k<3,4> (bf16 MFMA, 3 planes per operand)",
             "din": "din_attn_bwd_k (fp32 MFMA attention MLP backward)"}
 
 
@@ -158,6 +162,19 @@ def sweep_bytes(est, wk):
     return alg, 24 * n_sparse + 4 * wk * rows, n_sparse, arenas
 
 
+def cin_mode(cin_bf16, cin_split=0):
+    """False (fp32 MFMA) | True (bf16 operands) | 'x1'/'x2'/'x3' (ns bf16 planes per operand)."""
+    return ("x%d" % cin_split) if cin_split else bool(cin_bf16)
+
+
+CIN_DTYPE = {False: "f32", True: "bf16 CIN operands / f32 accumulate, f32 elsewhere",
+             "x1": "bf16 CIN operands (1 plane) / f32 accumulate, f32 elsewhere",
+             "x2": "f32; CIN products as 2 bf16 planes per operand on the bf16 MFMA (3 MFMAs per k-step, 2^-16-grade), f32 accumulate",
+             "x3": "f32; CIN products as 3 bf16 planes per operand on the bf16 MFMA (6 MFMAs per k-step, exact to 2^-23: fp32-grade), f32 accumulate"}
+CIN_TAG = {False: "", True: " --cin_bf16", "x1": " --cin_split 1", "x2": " --cin_split 2", "x3": " --cin_split 3"}
+CIN_KEY = {False: "", True: "_bf16", "x1": "_x1", "x2": "_x2", "x3": "_x3"}
+
+
 def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
     alg, pass_bytes, _, arenas = sweep_bytes(est, wk)
     windowed = wk > 1 and bool(arenas)
@@ -167,9 +184,12 @@ def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
            "moved_bytes_per_step": int(moved), "tf1_equivalent_bytes_per_step": int(alg)}
     if model == "xdeepfm":
         flops = 3 * 2 * B * 16 * (39 * 39 * 128 + 39 * 128 * 128)          # fwd x 3 with backward
+        terms = {"x1": 1, "x2": 3, "x3": 6}.get(cin_bf16, 1)              # bf16 MFMAs issued per algorithmic k-step
         peak = 2.5e15 if cin_bf16 else 157.3e12
-        out["cin_mfma_step_frac"] = round(flops / (ms_per_step * 1e-3) / peak, 4)
+        out["cin_mfma_step_frac"] = round(terms * flops / (ms_per_step * 1e-3) / peak, 4)
         out["cin_flops_per_step"] = flops
+        if terms > 1:
+            out["cin_mfma_flops_issued_per_step"] = terms * flops
         out["mfma_peak"] = "2.5 PF dense bf16" if cin_bf16 else "157.3 TF fp32"
     return out
 
@@ -187,7 +207,8 @@ def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmu
     lin, emb = build_feature_columns(16, linear) if linear else (None, None)
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if model == "din" else 16,
               "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
-              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(model), "cin_bf16": cin_bf16}
+              "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(model), "cin_bf16": cin_bf16 is True,
+              "cin_split": int(cin_bf16[1]) if isinstance(cin_bf16, str) else 0}
     if a.no_overlap:
         params["overlap_adam"] = False
     mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[model]
@@ -291,30 +312,30 @@ def other_configs(a, rank, dev):
     that includes every graph capture (median repeat)."""
     import gc
     out = []
-    for model, bf16 in (("fm", False), ("dcn", False), ("xdeepfm", False), ("xdeepfm", True), ("din", False)):
-        if model == a.model and bf16 == a.cin_bf16:
+    for model, bf16 in (("fm", False), ("dcn", False), ("xdeepfm", False), ("xdeepfm", "x3"), ("xdeepfm", True), ("din", False)):
+        if model == a.model and bf16 == cin_mode(a.cin_bf16, a.cin_split):
             continue
         steps = a.config_steps if model != "din" else max(64, a.config_steps // 2)
         try:
             t = time_config(a, model, 256, bf16, None, None, rank, dev, steps, 64, 3)
         except Exception as e:                                   # a config that fails must not take the headline line with it
-            out.append({"workload": "%s.py%s" % (model, " --cin_bf16" if bf16 else ""), "error": repr(e)[:300]})
+            out.append({"workload": "%s.py%s" % (model, CIN_TAG[bf16]), "error": repr(e)[:300]})
             continue
         ms = t["dt"] / steps * 1e3
         wk = t["est"]._window_len() if (not a.no_graph and not a.no_overlap) else 1
         e = {"workload": "%s.py %s bs=%d%s, full train step (fwd+bwd+TF1 Adam), adam_mode=%s" %
-                         (model, WORKLOADS[model], t["B"], ", bf16 CIN operands / f32 accumulate" if bf16 else "", a.adam_mode),
-             "dtype": "f32" if not bf16 else "bf16 CIN operands / f32 accumulate, f32 elsewhere",
+                         (model, WORKLOADS[model], t["B"], CIN_TAG[bf16].replace(" --", ", "), a.adam_mode),
+             "dtype": CIN_DTYPE[bf16],
              "ms_per_step": round(ms, 5), "examples_per_sec": round(t["B"] * steps / t["dt"], 1), "steps": steps,
              "timed_repeats_ms_per_step": [round(x / steps * 1e3, 5) for x in t["dts"]], "adam_window": wk,
-             "final_loss": round(t["final_loss"], 5), "dominant_kernel": DOMINANT[model + ("_bf16" if bf16 else "")]}
+             "final_loss": round(t["final_loss"], 5), "dominant_kernel": DOMINANT.get(model + CIN_KEY[bf16])}
         e.update(step_fractions(t["est"], model, t["B"], ms, wk, bf16))
         try:
             e["launches_per_step"] = launches_per_step(t["est"], t["feats"], wk)
         except Exception as ex:
             e["launches_per_step"] = None
             e["launches_per_step_error"] = repr(ex)[:200]
-        dk = dominant_kernel_fraction(model + ("_bf16" if bf16 else ""))
+        dk = dominant_kernel_fraction(model + CIN_KEY[bf16])
         if dk is not None:
             e["dominant_kernel_roofline"] = dk
         out.append(e)
@@ -475,7 +496,7 @@ def main():
         emu = dist.EmulatedDataParallel(a.emulate_world)
 
     dp_captured = dist.dp_capture(dp or emu)
-    t = time_config(a, a.model, a.batch_size, a.cin_bf16, dp, emu, rank, dev, a.steps, a.warmup, a.repeats)
+    t = time_config(a, a.model, a.batch_size, cin_mode(a.cin_bf16, a.cin_split), dp, emu, rank, dev, a.steps, a.warmup, a.repeats)
     est, B, dt, dts, final_loss, host, layout = t["est"], t["B"], t["dt"], t["dts"], t["final_loss"], t["host"], t["layout"]
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
@@ -585,7 +606,7 @@ def main():
 
     if roof is not None:
         # step-level fractions, named for what they divide (see the module docstring)
-        roof.update(step_fractions(est, a.model, B, dt / a.steps * 1e3, wk, a.cin_bf16))
+        roof.update(step_fractions(est, a.model, B, dt / a.steps * 1e3, wk, cin_mode(a.cin_bf16, a.cin_split)))
         roof.setdefault("achievable_peak", 6300.0)
         roof.setdefault("frac_of_achievable", round(roof["achieved"] / 6300.0, 4))
         if a.model == "deepfm" and B == 256:
@@ -606,7 +627,7 @@ def main():
     out = {"metric": "examples/sec", "value": round(N * B * a.steps / dt, 1), "unit": "examples/sec", "n_gpus": a.gpus,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if not (a.cin_bf16 and a.model == "xdeepfm") else "bf16 CIN operands / f32 accumulate, f32 elsewhere (max |dlogit| vs f32 path: see DESIGN.md)", "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
+           "dtype": "f32" if a.model != "xdeepfm" else CIN_DTYPE[cin_mode(a.cin_bf16, a.cin_split)], "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
            "config": {"workload": "%s.py %s bs=%d/replica, full train step "
                                   "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, %s"
                                   % (a.model, WORKLOADS[a.model], B,

@@ -912,6 +912,8 @@ typedef struct {
   float* dW;         /* [F*H, N] */
   float* dc;         /* [N] */
   int32_t H, N;
+  int32_t dc_rows;   /* rows of bias-gradient partials in ws: 0 = one per example pair (rsx_cin_layer_bwd_dx_bf16), B = one per
+                        example (rsx_cin_layer_bwd_dx_bf16_parts) */
 } rsx_cin_dw_job;
 int rsx_cin_layer_bwd_dx_bf16(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
                               const float* gs, const float* wout, float* dXk, int acc_dxk, float* dX0, int acc_dx0,
@@ -921,6 +923,43 @@ int rsx_cin_bwd_dw_bf16(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs
                         const rsx_adam_slice* sweep_h, rsx_stream_t stream);
 int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
                             int F, rsx_stream_t stream);
+/* Round 5: the CIN contraction on the bf16 matrix cores with SPLIT operands (csrc/cin_split.hip; xdeepfm/xdeepfm.py:145-169).
+ * An fp32 value is the exact sum of three bf16 values; ns planes of every contraction operand are kept and the products
+ * of planes i, j with i + j <= ns + 1 are accumulated (fp32) by v_mfma_f32_16x16x32_bf16:
+ *   ns = 3: 6 MFMAs per k-step, every product exact to 2^-23 of itself -- fp32-grade, the parity path on the bf16 cores;
+ *   ns = 2: 3 MFMAs, 2^-16-grade;  ns = 1: 1 MFMA, plain bf16 operands (the arithmetic of rsx_cin_layer_fwd_bf16).
+ * Same contract as rsx_cin_layer_fwd / rsx_cin_layer_bwd otherwise (X0 scaling, bias, relu and every sum in fp32).
+ *   rsx_cin_split_prep  W fp32 [F*H, N] of L layers -> w16_h[k] (rsx_cin_split_weight_elems 16-bit elements each)
+ * F <= 40, H, N <= 128, D = 16; RSX_EUNSUPPORTED otherwise.                                                          */
+size_t rsx_cin_split_weight_elems(int F, int H, int N, int ns);
+int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L, int F,
+                       int ns, rsx_stream_t stream);
+int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w16, const float* c, float* out, int B, int F, int H,
+                      int N, int D, int ns, rsx_stream_t stream);
+/* Backward of the same layer.  rsx_cin_split_bwd_dx: the data gradients (contract of rsx_cin_layer_bwd_dx_bf16_parts: dXk
+ * written or accumulated, dX0 left as one partial per 16-wide tile of h in dx0_parts [ceil(H/16)][B][F*16] for
+ * rsx_cin_dx0_reduce); it also leaves dpre = relu'(out) * (dout + gs * wout) -- ns planes of operand fragments -- and the
+ * bias gradient's per-example partial sums in ws (rsx_cin_split_bwd_workspace_bytes(B, N, ns) bytes, one buffer per layer).
+ * rsx_cin_split_bwd_dw: dW [F*H, N] and dc [N] of several layers in ONE launch from those workspaces (rsx_cin_dw_job with
+ * ws = the layer's workspace; dc_rows is ignored); the products X0 * Xk are formed in fp32, rounded once and split.    */
+size_t rsx_cin_split_bwd_workspace_bytes(int B, int N, int ns);
+int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                         const float* gs, const float* wout, float* dXk, int acc_dxk, float* dx0_parts, void* ws, int B,
+                         int F, int H, int N, int D, int ns, rsx_stream_t stream);
+int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
+                         rsx_stream_t stream);
+/* Round 5: the data gradients with EIGHT examples per workgroup (csrc/cin_bf16_wide.hip; xdeepfm/xdeepfm.py:145-169
+ * differentiated).  A workgroup sees one 16-wide tile of h, so dX0 (a sum over h) is left as one partial per tile:
+ * dx0_parts [ceil(H/16)][B][F*16] floats (rsx_cin_bf16_dx0_parts_floats); rsx_cin_dx0_reduce adds the tiles of all layers
+ * in (layer, tile) order: dX0 = (acc ? dX0 : 0) + sum.  dXk as in rsx_cin_layer_bwd_dx_bf16 (the first layer's dXk may BE
+ * dX0: the launch itself never touches dX0).  The workspace's bias-gradient partials are one row per example: the
+ * weight-gradient job of this layer sets dc_rows = B.  RSX_EUNSUPPORTED when F > 40.                                   */
+size_t rsx_cin_bf16_dx0_parts_floats(int B, int F, int H);
+int rsx_cin_layer_bwd_dx_bf16_parts(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                                    const float* gs, const float* wout, float* dXk, int acc_dxk, float* dx0_parts, void* ws,
+                                    int B, int F, int H, int N, int D, rsx_stream_t stream);
+int rsx_cin_dx0_reduce(const float* const* parts_h, const int32_t* tiles_h, int njobs, float* dX0, int acc, int B, int F,
+                       int D, rsx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Streaming reader: the whole `input_fn` front end -- tf.data.TFRecordDataset(filenames)

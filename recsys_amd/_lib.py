@@ -91,7 +91,8 @@ class TableSet(C.Structure):
 
 
 class CinDwJob(C.Structure):
-    _fields_ = [("Xk", C.c_void_p), ("ws", C.c_void_p), ("dW", C.c_void_p), ("dc", C.c_void_p), ("H", C.c_int32), ("N", C.c_int32)]
+    _fields_ = [("Xk", C.c_void_p), ("ws", C.c_void_p), ("dW", C.c_void_p), ("dc", C.c_void_p), ("H", C.c_int32), ("N", C.c_int32),
+                ("dc_rows", C.c_int32)]
 
 
 class UniqPackJob(C.Structure):           # include/rsx.h rsx_uniq_pack_job
@@ -214,6 +215,15 @@ _SIGS = {
     "rsx_cin_layer_bwd_dx_bf16": (_I, [_P] * 8 + [_I, _P, _I, _P] + [_I] * 5 + [_P, _P]),
     "rsx_cin_bwd_dw_bf16": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _P, _P]),
     "rsx_cin_prep_bf16_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "rsx_cin_bf16_dx0_parts_floats": (C.c_size_t, [_I, _I, _I]),
+    "rsx_cin_split_weight_elems": (C.c_size_t, [_I, _I, _I, _I]),
+    "rsx_cin_split_prep": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "rsx_cin_split_fwd": (_I, [_P] * 5 + [_I] * 6 + [_P]),
+    "rsx_cin_split_bwd_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "rsx_cin_split_bwd_dx": (_I, [_P] * 8 + [_I, _P, _P] + [_I] * 6 + [_P]),
+    "rsx_cin_split_bwd_dw": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _I, _P]),
+    "rsx_cin_layer_bwd_dx_bf16_parts": (_I, [_P] * 8 + [_I, _P, _P] + [_I] * 5 + [_P]),
+    "rsx_cin_dx0_reduce": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rsx_cin_out_bwd_lin": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -24,6 +24,7 @@
 // All reductions are in fixed order: deterministic, no atomics.
 #include "rsx_common.h"
 #include "adam_device.h"
+#include "cin_bf16_wide.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -392,7 +393,8 @@ constexpr int CB_MAXJ = 4;
 struct CbDwJob {
   const float* Xk;        // [B, H, 16]
   const bf16_t* dpre16;   // fragments, see CbDxArgs
-  const float* dc_part;   // [ceil(B/2), N16]
+  const float* dc_part;   // [dc_rows, N16]
+  int dc_rows;            // ceil(B/2) (cin_bwd_dx_bf16_k: one row per example pair) or B (cin_bf16_wide.hip: one per example)
   float* dW;              // [F*H, N]
   float* dc;              // [N]
   int H, N, N16;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void cin_bwd_dw_bf16_k(const CbDwArgs p) {
   const int total = p.job[p.njobs - 1].tile_end;
   if ((int)blockIdx.x < p.njobs) {                // dc[n] = sum over the workgroups of cin_bwd_dx_bf16_k, in order
     const CbDwJob& jb = p.job[blockIdx.x];
-    const int G = (p.B + 1) / 2;
+    const int G = jb.dc_rows;
     for (int n = tid; n < jb.N; n += 512) {
       float s = 0.f;
       int g = 0;
@@ -632,7 +634,7 @@ extern "C" size_t rsx_cin_bf16_weight_elems(int F, int H, int N) {
 extern "C" size_t rsx_cin_bf16_bwd_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
   const size_t dp = (size_t)((B + 1) / 2) * 2 * rup(N, 16) * CB_D * 2;      // fragments of whole example pairs
-  return dp + (size_t)((B + 1) / 2) * rup(N, 16) * sizeof(float);
+  return dp + (size_t)B * rup(N, 16) * sizeof(float);       // (one row of bias-gradient partials per example at most)
 }
 
 extern "C" int rsx_cin_prep_bf16(const float* W, void* w16, int F, int H, int N, rsx_stream_t stream) {
@@ -656,6 +658,9 @@ extern "C" int rsx_cin_layer_fwd_bf16(const float* X0, const float* Xk, const vo
   if (D != CB_D || H > 128 || N > 128) return RSX_EUNSUPPORTED;
   const int H16 = rup(H, 16), N16 = rup(N, 16), Hp = rup(H, 32), Np = rup(N, 32);
   const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)F * H16 * Np;
+  // eight examples per workgroup (cin_bf16_wide.hip) unless the launch carries a slice of the optimizer sweep
+  static const int wide_env = getenv("RSX_CIN_WIDE") ? atoi(getenv("RSX_CIN_WIDE")) : 1;
+  if (wide_env != 0 && sweep_h == nullptr && cin_wide_supported(F, H, N)) return cin_wide_fwd(X0, Xk, wt, c, out, B, F, H, N, rsx_s(stream));
   static const int ex_env = getenv("RSX_CIN_FWD16_EX") ? atoi(getenv("RSX_CIN_FWD16_EX")) : 2;     // examples per workgroup
   const int E = ex_env == 4 ? 4 : 2;
   CbFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, (B + E - 1) / E, {}};
@@ -735,6 +740,8 @@ static int cb_launch_dw_t(const float* X0, const rsx_cin_dw_job* jobs_h, int njo
     d.Xk = j.Xk;
     d.dpre16 = static_cast<const bf16_t*>(j.ws);
     d.dc_part = reinterpret_cast<const float*>(static_cast<const char*>(j.ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
+    if (j.dc_rows != 0 && j.dc_rows != B) return RSX_EINVAL;
+    d.dc_rows = j.dc_rows ? j.dc_rows : (B + 1) / 2;
     d.dW = j.dW; d.dc = j.dc; d.H = j.H; d.N = j.N; d.N16 = N16;
     d.gx = (N16 + 16 * NT - 1) / (16 * NT);
     d.HT = H16 / 16;
@@ -820,6 +827,39 @@ extern "C" int rsx_cin_layer_bwd_bf16(const float* X0, const float* Xk, const vo
   if (!dW || !dc) return RSX_EINVAL;
   const int rc = cb_launch_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dX0, acc_dx0, ws, B, F, H, N, D, nullptr, stream);
   if (rc != RSX_OK || B == 0) return rc;
-  const rsx_cin_dw_job job{Xk, ws, dW, dc, H, N};
+  const rsx_cin_dw_job job{Xk, ws, dW, dc, H, N, 0};
   return cb_launch_dw(X0, &job, 1, B, F, D, sweep_h, stream);
+}
+
+// The data gradients with eight examples per workgroup (cin_bf16_wide.hip).  dX0 is NOT written: the launch leaves one
+// partial per 16-wide tile of h in dx0_parts [ceil(H/16)][B][F*16] (rsx_cin_bf16_dx0_parts_floats), rsx_cin_dx0_reduce adds
+// the tiles of every layer in one launch.  The workspace's bias-gradient partials are one row per EXAMPLE
+// (rsx_cin_dw_job.dc_rows = B).  RSX_EUNSUPPORTED (F > 40): use rsx_cin_layer_bwd_dx_bf16.
+extern "C" size_t rsx_cin_bf16_dx0_parts_floats(int B, int F, int H) {
+  if (B <= 0 || F <= 0 || H <= 0) return 0;
+  return (size_t)(rup(H, 16) / 16) * B * F * CB_D;
+}
+
+extern "C" int rsx_cin_layer_bwd_dx_bf16_parts(const float* X0, const float* Xk, const void* w16, const float* out,
+                                               const float* dout, const float* gs, const float* wout, float* dXk,
+                                               int acc_dxk, float* dx0_parts, void* ws, int B, int F, int H, int N, int D,
+                                               rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!X0 || !Xk || !w16 || !out || !dXk || !dx0_parts || !ws) return RSX_EINVAL;
+  if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
+  if (D != CB_D || !cin_wide_supported(F, H, N)) return RSX_EUNSUPPORTED;
+  const int N16 = rup(N, 16);
+  float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)((B + 1) / 2) * 2 * N16 * CB_D * 2);
+  return cin_wide_dx(X0, Xk, w16, out, dout, gs, wout, dXk, acc_dxk, dx0_parts, ws, dc_part, B, F, H, N, rsx_s(stream));
+}
+
+extern "C" int rsx_cin_dx0_reduce(const float* const* parts_h, const int32_t* tiles_h, int njobs, float* dX0, int acc, int B,
+                                  int F, int D, rsx_stream_t stream) {
+  if (!parts_h || !tiles_h || !dX0 || njobs <= 0 || B < 0 || F <= 0) return RSX_EINVAL;
+  if (D != CB_D) return RSX_EUNSUPPORTED;
+  if (B == 0) return RSX_OK;
+  for (int j = 0; j < njobs; ++j)
+    if (!parts_h[j] || tiles_h[j] <= 0) return RSX_EINVAL;
+  return cin_wide_dx0_reduce(parts_h, tiles_h, njobs, dX0, acc, B, F, rsx_s(stream));
 }

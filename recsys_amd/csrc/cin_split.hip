@@ -1,0 +1,901 @@
+// xDeepFM CIN layer on the bf16 matrix cores with SPLIT operands (round 5).
+// Reference call site: xdeepfm/xdeepfm.py:145-172 (formulation: cin.hip).
+//
+// v_mfma_f32_16x16x32_bf16 runs at 16x the rate of v_mfma_f32_16x16x4_f32 (2.5 PFLOP/s against 157 TFLOP/s), multiplies its
+// 8-bit-significand operands EXACTLY and accumulates in fp32.  An fp32 number is the exact sum of three bf16 numbers
+// (x = x1 + x2 + x3, x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2: 8 + 8 + 8 significand bits), so a product of two fp32
+// numbers is the sum of nine exact bf16 products; the six with i + j <= 4 carry everything above 2^-24 of the product:
+//   NS = 3   x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1): fp32-grade (|dropped| < 3 * 2^-24 |xy|), 6 MFMAs = 3/8 of the fp32
+//            MFMA's time for the same k -- this is the PARITY path of the bf16 matrix cores (1e-5 against the oracle)
+//   NS = 2   x1y1 + x1y2 + x2y1: 2^-16-grade products (3 MFMAs)
+//   NS = 1   x1y1: plain bf16 operands (what cin_bf16.hip computes)
+// Everything that is not a contraction operand (X0 row scaling, bias, relu, every sum) is fp32, as in the other two paths.
+//
+// Work split (forward; the backward mirrors it): a workgroup of 8 waves owns 8 examples and one 16-wide tile of outputs n,
+// and walks the fields two at a time -- waves 0,2,4,6 take the even field, waves 1,3,5,7 the odd one, wave pair p the
+// examples 2p, 2p + 1.  The filter fragments of a step (2 fields x NS planes x KS k-steps, 1 KiB each) come through LDS
+// once per workgroup (double buffered, one barrier per step, the next step's loads in flight during the MFMAs), so a
+// fragment is read from L2 once per 8 examples; the Xk operand of a wave's two examples is split once and stays in
+// registers (NS x 2 x KS quads).  Per step and wave: 2 examples x (1 | 3 | 6) terms x KS MFMAs.
+// Sums in fixed order (terms smallest first, k-steps, fields in step order, the two field parities at the end).
+#include "rsx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CS_D = 16;
+constexpr int CS_E = 8;         // examples per workgroup
+constexpr int CS_FP = 40;       // fields, padded (X0 reads as zero past F): F <= 40
+constexpr int CS_MAXJ = 4;
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// two fp32 values -> NS packed bf16 pairs: plane s holds bf16 of what the planes before it left over
+template <int NS>
+__device__ __forceinline__ void split2(float lo, float hi, uint32_t (&out)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const uint32_t pk = pack2(lo, hi);
+    out[s] = pk;
+    if (s + 1 < NS) {
+      lo -= __uint_as_float(pk << 16);
+      hi -= __uint_as_float(pk & 0xffff0000u);
+    }
+  }
+}
+// eight fp32 values (two float4) -> NS operand quads
+template <int NS>
+__device__ __forceinline__ void split8(float4 a, float4 b, bf16x8 (&out)[NS]) {
+  uint32_t p0[NS], p1[NS], p2[NS], p3[NS];
+  split2<NS>(a.x, a.y, p0);
+  split2<NS>(a.z, a.w, p1);
+  split2<NS>(b.x, b.y, p2);
+  split2<NS>(b.z, b.w, p3);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) out[s] = __builtin_bit_cast(bf16x8, (u32x4){p0[s], p1[s], p2[s], p3[s]});
+}
+
+// T += sum over the kept terms (smallest first) and the k-steps of A-plane x B-plane
+template <int NS, int KS>
+__device__ __forceinline__ f32x4 split_mma(const bf16x8 (&a)[NS][KS], const bf16x8 (&b)[NS][KS], f32x4 T) {
+#pragma unroll
+  for (int lvl = NS - 1; lvl >= 0; --lvl)          // lvl = i + j (zero based): 2^-8lvl relative size
+#pragma unroll
+    for (int sa = 0; sa <= lvl; ++sa)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) T = mfma_bf16(a[sa][ks], b[lvl - sa][ks], T);
+  return T;
+}
+template <int NS, int KS>
+__device__ __forceinline__ f32x4 split_mma_ba(const bf16x8 (&a)[NS][KS], const bf16x8 (&b)[NS][KS], f32x4 T) {   // (b as the MFMA's first operand)
+#pragma unroll
+  for (int lvl = NS - 1; lvl >= 0; --lvl)
+#pragma unroll
+    for (int sa = 0; sa <= lvl; ++sa)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) T = mfma_bf16(b[lvl - sa][ks], a[sa][ks], T);
+  return T;
+}
+
+// ------------------------------------------------------------------------------------------------ filter preparation
+// Fragment-major bf16 images, NS planes each (plane stride = the image size):
+//   W16  [NS][F][H16/16][Np/32][64][8]: element j of lane (i, kq) = W[f][h = 16 ht + i][n = 32 ks + 8 kq + j]   (A of dX)
+//   Wt16 [NS][F][N16/16][Hp/32][64][8]: element j of lane (i, kq) = W[f][h = 32 ks + 8 kq + j][n = 16 nt + i]   (B of fwd)
+struct CsPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; int H, N, H16, N16, Hp, Np; long long end; };
+struct CsPrepArgs { CsPrepJob job[CS_MAXJ]; int njobs, F; };
+template <int NS>
+__global__ __launch_bounds__(256) void cin_split_prep_k(const CsPrepArgs p) {
+  const long long total = p.job[p.njobs - 1].end;           // operand quads (of one plane) over all jobs
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < CS_MAXJ; ++k)
+      if (k < p.njobs && e >= p.job[k - 1].end) ji = k;
+    const CsPrepJob& jb = p.job[ji];
+    const long long le = e - (ji ? p.job[ji - 1].end : 0);
+    const long long n1 = ((long long)p.F * jb.H16 * jb.Np) >> 3, n2 = ((long long)p.F * jb.N16 * jb.Hp) >> 3;
+    const bool first = le < n1;
+    const long long q = first ? le : le - n1;
+    const int lane = (int)(q & 63);
+    int r = (int)(q >> 6);
+    const int KS = first ? jb.Np >> 5 : jb.Hp >> 5;
+    const int ks = r % KS;
+    r /= KS;
+    const int T = first ? jb.H16 >> 4 : jb.N16 >> 4;
+    const int t = r % T, f = r / T;
+    float v[8];
+    if (first) {                                   // W16: h = 16 t + (lane & 15), n = 32 ks + 8 (lane >> 4) + j
+      const int h = 16 * t + (lane & 15), n0 = 32 * ks + 8 * (lane >> 4);
+      const float* src = jb.W + ((size_t)f * jb.H + (h < jb.H ? h : jb.H - 1)) * jb.N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = n0 + j;
+        v[j] = src[n < jb.N ? n : jb.N - 1] * ((h < jb.H && n < jb.N) ? 1.f : 0.f);
+      }
+    } else {                                       // Wt16: n = 16 t + (lane & 15), h = 32 ks + 8 (lane >> 4) + j
+      const int n = 16 * t + (lane & 15), h0 = 32 * ks + 8 * (lane >> 4);
+      const float* src = jb.W + (size_t)f * jb.H * jb.N + (n < jb.N ? n : jb.N - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = h0 + j;
+        v[j] = src[(size_t)(h < jb.H ? h : jb.H - 1) * jb.N] * ((h < jb.H && n < jb.N) ? 1.f : 0.f);
+      }
+    }
+    bf16x8 o[NS];
+    split8<NS>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), o);
+    bf16_t* dst = (first ? jb.W16 : jb.Wt16) + q * 8;
+    const size_t plane = (first ? n1 : n2) * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x8*>(dst + (size_t)s * plane) = o[s];
+  }
+}
+
+// X0 of the eight examples -> LDS [E][CS_FP * 16], zeros for the fields past F: 3 float4 per thread, requested together
+struct StageX0 {
+  float4 v[3];
+  __device__ __forceinline__ void load(const float* X0, int b0, int B, int F, int tid) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e4 = tid + 512 * u;
+      const int ex = e4 / (CS_FP * 4), r = e4 % (CS_FP * 4);
+      // (unconditional loads from clamped addresses, zeroed afterwards: a load under a condition becomes a branch, and the
+      // compiler waits for each of them in turn)
+      const int exc = ex < CS_E ? ex : CS_E - 1;
+      const bool ok = e4 < CS_E * CS_FP * 4 && (r >> 2) < F && b0 + ex < B;
+      const int bc = b0 + exc < B ? b0 + exc : B - 1, rc = (r >> 2) < F ? r : 0;
+      const float4 t = reinterpret_cast<const float4*>(X0 + (size_t)bc * F * CS_D)[rc];
+      v[u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* sX0, int tid) const {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e4 = tid + 512 * u;
+      if (e4 < CS_E * CS_FP * 4) reinterpret_cast<float4*>(sX0)[e4] = v[u];
+    }
+  }
+};
+
+// [E][rows][16] fp32 (through `ld(e, row, quarter)`, zeros past the real rows) -> LDS, transposed to dst[e][d][RP] fp32 (rows
+// contiguous: what the MFMA's k index walks), RP = 32 KS + 4.  2 KS float4 per thread, all requested before the first store;
+// lanes = (quarter fastest, row): a wave's 64 scalar stores hit 64 banks.
+template <int KS>
+struct StageRowsF32 {
+  static constexpr int RP = 32 * KS + 4;
+  float4 v[2 * KS];
+  template <typename Load>
+  __device__ __forceinline__ void load(int tid, Load ld) {
+#pragma unroll
+    for (int u = 0; u < 2 * KS; ++u) {
+      const int it = tid + 512 * u;
+      const int dq = it & 3, row = (it >> 2) % (32 * KS), e = it / (128 * KS);
+      v[u] = ld(e, row, dq);
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int tid) const {
+#pragma unroll
+    for (int u = 0; u < 2 * KS; ++u) {
+      const int it = tid + 512 * u;
+      const int dq = it & 3, row = (it >> 2) % (32 * KS), e = it / (128 * KS);
+      float* t = dst + ((size_t)e * 16 + dq * 4) * RP + row;
+      t[0 * RP] = v[u].x;
+      t[1 * RP] = v[u].y;
+      t[2 * RP] = v[u].z;
+      t[3 * RP] = v[u].w;
+    }
+  }
+};
+
+// The filter fragments of one step: 2 fields x NS planes x KS k-steps, 1 KiB each, contiguous in LDS in that order.
+// Item = one 16-byte lane quad; U per thread.  f >= F is clamped (its X0 is zero).
+template <int NS, int KS>
+struct StageW {
+  static constexpr int FRAGS = 2 * NS * KS;
+  static constexpr int U = (FRAGS * 64 + 511) / 512;
+  uint4 v[U];
+  // base: image + (tile * KS) * 512 elements; fstride: elements per field; plane: elements per plane
+  __device__ __forceinline__ void load(const bf16_t* base, size_t fstride, size_t plane, int f0, int F, int tid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = tid + 512 * u;
+      const int lane = it & 63, frag = (it >> 6) < FRAGS ? (it >> 6) : FRAGS - 1;
+      const int ks = frag % KS, sp = (frag / KS) % NS, par = frag / (KS * NS);
+      const int f = f0 + par < F ? f0 + par : F - 1;
+      v[u] = *reinterpret_cast<const uint4*>(base + (size_t)sp * plane + (size_t)f * fstride + (size_t)ks * 512 + lane * 8);
+    }
+  }
+  // (unconditional: a ring slot is padded to U * 512 quads.  Under a condition the compiler sinks the item's global load into
+  // the branch and waits for it there -- one exposed L2 round trip per step)
+  static constexpr int SLOT = U * 512 * 8;         // bf16 elements per ring slot
+  __device__ __forceinline__ void store(bf16_t* buf, int tid) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) reinterpret_cast<uint4*>(buf)[tid + 512 * u] = v[u];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------ forward
+struct CsFwdArgs {
+  const float* X0;      // [B, F, 16]
+  const float* Xk;      // [B, H, 16]
+  const bf16_t* Wt16;   // NS planes, see cin_split_prep_k
+  const float* c;       // [N]
+  float* out;           // [B, N, 16]
+  int B, F, H, N, N16, Hp;
+};
+
+// grid = (N16 / 16, ceil(B / 8)), block = 512.
+// dyn LDS: sX0 8*40*16 f32 | sW 2 x (2 NS KS) KiB | sXk 8*16*(32 KS + 4) f32 (the waves' partial sums alias it at the end)
+template <int NS, int KS>
+__global__ __launch_bounds__(512) void cin_split_fwd_k(const CsFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int E = CS_E, HP = 32 * KS + 4, SLOT = StageW<NS, KS>::SLOT;
+  float* sX0 = lds;                                                   // [E][CS_FP*16]
+  bf16_t* sW = reinterpret_cast<bf16_t*>(sX0 + E * CS_FP * CS_D);     // [2][SLOT]: ring of two steps
+  float* sXk = reinterpret_cast<float*>(sW + 2 * SLOT);               // [E][16][HP]
+  float* sR = sXk;                                                    // [8 waves][2][4][64]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int par = wv & 1, e0 = (wv >> 1) * 2;                         // field parity, first of the wave's two examples
+  const int n0 = blockIdx.x * 16, b0 = blockIdx.y * E;
+  const bf16_t* wbase = p.Wt16 + (size_t)blockIdx.x * KS * 512;
+  const size_t fstride = (size_t)p.N16 * p.Hp, plane = (size_t)p.F * fstride;
+  const int nstep = (p.F + 1) / 2;
+  StageW<NS, KS> sw, sw1;
+  sw.load(wbase, fstride, plane, 0, p.F, tid);
+  sw1.load(wbase, fstride, plane, 2, p.F, tid);
+  StageX0 sx;
+  sx.load(p.X0, b0, p.B, p.F, tid);
+  {
+    StageRowsF32<KS> sr;
+    sr.load(tid, [&](int e, int h, int dq) {
+      const bool ok = b0 + e < p.B && h < p.H;
+      const int bc = b0 + e < p.B ? b0 + e : p.B - 1, hc = h < p.H ? h : p.H - 1;
+      const float4 t = reinterpret_cast<const float4*>(p.Xk + ((size_t)bc * p.H + hc) * CS_D)[dq];
+      return make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    });
+    sw.store(sW, tid);
+    sw1.store(sW + SLOT, tid);
+    sx.store(sX0, tid);
+    sr.store(sXk, tid);
+  }
+  __syncthreads();
+  bf16x8 a[2][NS][KS];                             // Xk[b0 + e0 + e][h = 32 ks + 8 kq + j][d = i], split
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4* src = reinterpret_cast<const float4*>(sXk + ((size_t)(e0 + e) * 16 + i) * HP + 32 * ks + 8 * kq);
+      bf16x8 t[NS];
+      split8<NS>(src[0], src[1], t);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) a[e][s][ks] = t[s];
+    }
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // Step st multiplies the fragments its predecessor read from ring slot st & 1 into registers, while (a) the reads of step
+  // st + 1's fragments (the other slot, complete since the last barrier) and (b) the global loads of step st + 2's are in
+  // flight; (b) lands in slot st & 1 -- every wave's reads of it completed before the last barrier -- before the step's
+  // barrier.  Two steps per trip: the two register sets swap roles without copies.  A step past the last field multiplies
+  // by X0 = 0.
+  // (macros, not lambdas: captured by reference the staging registers and the fragment sets go to scratch memory)
+#define CS_READ_W(ST, W)                                                                                              \
+  {                                                                                                                   \
+    const bf16_t* wb_ = sW + (size_t)((ST) & 1) * SLOT + (par * NS * KS) * 512 + lane * 8;                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_)                                                                 \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                            \
+        W[s_][ks_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb_ + (s_ * KS + ks_) * 512));        \
+  }
+#define CS_FWD_STEP(ST, W, WN)                                                                                        \
+  {                                                                                                                   \
+    sw.load(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid); /* unconditional: under a branch -> scratch */          \
+    CS_READ_W((ST) + 1, WN)                                                                                           \
+    const int f_ = 2 * (ST) + par;                                                                                    \
+    const float m_ = f_ < CS_FP ? 1.f : 0.f;                                                                          \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                   \
+      const f32x4 T = split_mma<NS, KS>(a[e], W, (f32x4){0.f, 0.f, 0.f, 0.f});                                        \
+      const float4 x = *reinterpret_cast<const float4*>(sX0 + ((e0 + e) * CS_FP + (f_ < CS_FP ? f_ : CS_FP - 1)) * CS_D + kq * 4); \
+      acc[e][0] = __builtin_fmaf(x.x * m_, T[0], acc[e][0]);                                                          \
+      acc[e][1] = __builtin_fmaf(x.y * m_, T[1], acc[e][1]);                                                          \
+      acc[e][2] = __builtin_fmaf(x.z * m_, T[2], acc[e][2]);                                                          \
+      acc[e][3] = __builtin_fmaf(x.w * m_, T[3], acc[e][3]);                                                          \
+    }                                                                                                                 \
+    sw.store(sW + (size_t)((ST) & 1) * SLOT, tid);                                                                    \
+    __syncthreads();                                                                                                  \
+  }
+  bf16x8 w0[NS][KS], w1[NS][KS];
+  CS_READ_W(0, w0)
+  __syncthreads();                                 // step 0 refills slot 0: every wave must have read it
+  for (int st = 0; st < nstep; st += 2) {
+    CS_FWD_STEP(st, w0, w1)
+    CS_FWD_STEP(st + 1, w1, w0)
+  }
+#undef CS_FWD_STEP
+#undef CS_READ_W
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = acc[e][r];
+  __syncthreads();
+  {   // wave w finishes example w: even fields' sum + odd fields' sum + bias, relu
+    const int ex = wv, b = b0 + ex;
+    const int w0 = (ex >> 1) * 2, sl = ex & 1;
+    const bool nok = n0 + i < p.N;
+    const float cv = p.c[nok ? n0 + i : 0];
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      o[r] = fmaxf((sR[((w0 * 2 + sl) * 4 + r) * 64 + lane] + sR[(((w0 + 1) * 2 + sl) * 4 + r) * 64 + lane]) + cv, 0.f);
+    if (nok && b < p.B)
+      *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n0 + i) * CS_D + kq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dXk, dX0
+struct CsDxArgs {
+  const float* X0;      // [B, F, 16]
+  const float* Xk;      // [B, H, 16]
+  const bf16_t* W16;    // NS planes, see cin_split_prep_k
+  const float* out;     // [B, N, 16] this layer's relu output
+  const float* dout;    // [B, N, 16] gradient wrt the relu output (nullable when gs is given)
+  const float* gs;      // [B] nullable: direct-connect gradient gs[b] * wout[n], broadcast over d, added to dout
+  const float* wout;    // [N]
+  float* dXk;           // [B, H, 16]
+  float* dx0_parts;     // [HT][B][F*16] out: tile ht's share of dX0
+  bf16_t* dpre16;       // [NS][ceil(B/2)][N16/16][64][8] out (workgroups of tile 0): the dW kernel's B fragments, split
+  float* dc_part;       // [B][N16] out (workgroups of tile 0): per-example column sums of dpre
+  int acc_dxk;
+  int B, F, H, N, H16, N16, Np;
+};
+
+// grid = (H16 / 16, ceil(B / 8)), block = 512: workgroup = 8 examples x the 16 inputs h of tile blockIdx.x; waves as in the
+// forward (field parity x example pair).  U_f^T[h, d] = sum_n W_f[h, n] dpre[b, n, d]: A = W16 fragments (through the LDS ring),
+// B = dpre[b]^T (k = n, column = d) of the wave's two examples, split, in registers.
+//   dXk[b, h, d] += X0[b, f, d] U_f^T[h, d]   summed over the wave's fields in registers, the two parities through LDS
+//   dX0[b, f, d]  = sum_h Xk[b, h, d] U_f^T[h, d] over this tile's 16 h: four lane-quarter partials through LDS, added in
+//                   order, written to dx0_parts[tile] (rsx_cin_dx0_reduce adds the tiles)
+// dyn LDS: sX0 8*40*16 f32 | sW 2 ring slots | R = max(sDp 8*16*(32 KSN + 4), sP 8*40*64) f32 (sDp is dead once the
+// operands are in registers; the parities' dXk partials alias sP after it was consumed).
+template <int NS, int KSN>
+__global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int E = CS_E, NP = 32 * KSN + 4, SLOT = StageW<NS, KSN>::SLOT;
+  float* sX0 = lds;                                                   // [E][CS_FP*16]
+  bf16_t* sW = reinterpret_cast<bf16_t*>(sX0 + E * CS_FP * CS_D);     // [2][SLOT]
+  float* sDp = reinterpret_cast<float*>(sW + 2 * SLOT);               // [E][16][NP]
+  float* sP = sDp;                                                    // [E][CS_FP][4 kq][16 i]   (after the operands were read)
+  float* sR = sDp;                                                    // [8 waves][2][4][64]      (after sP was consumed)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int par = wv & 1, e0 = (wv >> 1) * 2;
+  const int ht = blockIdx.x, b0 = blockIdx.y * E;
+  const bf16_t* wbase = p.W16 + (size_t)ht * KSN * 512;
+  const size_t fstride = (size_t)p.H16 * p.Np, plane = (size_t)p.F * fstride;
+  const int nstep = (p.F + 1) / 2;
+  const bool lead = ht == 0, has_dout = p.dout != nullptr, has_gs = p.gs != nullptr;
+  StageW<NS, KSN> sw, sw1;
+  sw.load(wbase, fstride, plane, 0, p.F, tid);
+  sw1.load(wbase, fstride, plane, 2, p.F, tid);
+  StageX0 sx;
+  sx.load(p.X0, b0, p.B, p.F, tid);
+  float xkv[2][4];                                 // Xk[b0 + e0 + e][h = 16 ht + 4 kq + r][d = i]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + e0 + e, h = 16 * ht + 4 * kq + r;
+      xkv[e][r] = p.Xk[((size_t)(b < p.B ? b : p.B - 1) * p.H + (h < p.H ? h : p.H - 1)) * CS_D + i] * ((b < p.B && h < p.H) ? 1.f : 0.f);
+    }
+  {
+    // dpre = relu'(out) * (dout + gs * wout) of the eight examples -> LDS, transposed (fp32: each wave splits its own two)
+    StageRowsF32<KSN> sr;
+    sr.load(tid, [&](int e, int n, int dq) {
+      const int b = b0 + e;
+      const bool ok = b < p.B && n < p.N;
+      const int bc = b < p.B ? b : p.B - 1, nc = n < p.N ? n : p.N - 1;
+      const size_t at = ((size_t)bc * p.N + nc) * 4 + dq;
+      const float4 o = reinterpret_cast<const float4*>(p.out)[at];
+      float4 g = F4Z;
+      if (has_dout) g = reinterpret_cast<const float4*>(p.dout)[at];       // (workgroup-uniform)
+      if (has_gs) {
+        const float a = p.gs[bc] * p.wout[nc];
+        g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
+      }
+      return make_float4((ok && o.x > 0.f) ? g.x : 0.f, (ok && o.y > 0.f) ? g.y : 0.f, (ok && o.z > 0.f) ? g.z : 0.f,
+                         (ok && o.w > 0.f) ? g.w : 0.f);
+    });
+    sw.store(sW, tid);
+    sw1.store(sW + SLOT, tid);
+    sx.store(sX0, tid);
+    sr.store(sDp, tid);
+  }
+  __syncthreads();
+  bf16x8 bd[2][NS][KSN];                           // dpre[b0 + e0 + e][n = 32 ks + 8 kq + j][d = i], split
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {
+      const float4* src = reinterpret_cast<const float4*>(sDp + ((size_t)(e0 + e) * 16 + i) * NP + 32 * ks + 8 * kq);
+      bf16x8 t[NS];
+      split8<NS>(src[0], src[1], t);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bd[e][s][ks] = t[s];
+    }
+  bf16x8 w0[NS][KSN], w1[NS][KSN];
+#define CS_READ_WA(ST, W)                                                                                             \
+  {                                                                                                                   \
+    const bf16_t* wb_ = sW + (size_t)((ST) & 1) * SLOT + (par * NS * KSN) * 512 + lane * 8;                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_)                                                                 \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < KSN; ++ks_)                                                           \
+        W[s_][ks_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb_ + (s_ * KSN + ks_) * 512));       \
+  }
+  CS_READ_WA(0, w0)
+  if (lead) {   // (workgroup-uniform) the weight-gradient launch's operands and the bias gradient's per-example partials, from
+                // the LDS copy (kept in registers across this branch the staged values go to scratch memory)
+    const size_t dplane = (size_t)((p.B + 1) / 2) * 2 * p.N16 * CS_D;
+#pragma unroll
+    for (int u = 0; u < 2 * KSN; ++u) {
+      const int it = tid + 512 * u;
+      const int dq = it & 3, n = (it >> 2) % (32 * KSN), e = it / (128 * KSN);
+      const int b = b0 + e;
+      const float* t = sDp + ((size_t)e * 16 + dq * 4) * NP + n;
+      const float4 v = make_float4(t[0], t[NP], t[2 * NP], t[3 * NP]);
+      float s = (v.x + v.y) + (v.z + v.w);
+      s += __shfl_xor(s, 1);                       // the 4 d-quarters of row n sit in adjacent lanes
+      s += __shfl_xor(s, 2);
+      if (b < 2 * ((p.B + 1) / 2) && n < p.N16) {            // (the last pair's missing example: zero fragments)
+        if (dq == 0 && b < p.B) p.dc_part[(size_t)b * p.N16 + n] = s;
+        // fragment of the dW kernel: lane (i = n & 15, kq = 2 (b & 1) + (d >> 3)), elements j = d & 7
+        const size_t fr = ((((size_t)(b >> 1) * (p.N16 >> 4) + (n >> 4)) * 64 + (2 * (b & 1) + (dq >> 1)) * 16 + (n & 15)) * 8) + (dq & 1) * 4;
+        uint32_t q0[NS], q1[NS];
+        split2<NS>(v.x, v.y, q0);
+        split2<NS>(v.z, v.w, q1);
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) *reinterpret_cast<uint2*>(p.dpre16 + (size_t)sp * dplane + fr) = make_uint2(q0[sp], q1[sp]);
+      }
+    }
+  }
+  __syncthreads();                                 // every wave has its operands: sDp may become sP
+  f32x4 dxk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#define CS_DX_STEP(ST, W, WN)                                                                                         \
+  {                                                                                                                   \
+    sw.load(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid);                                                         \
+    CS_READ_WA((ST) + 1, WN)                                                                                          \
+    const int f_ = 2 * (ST) + par;                                                                                    \
+    const int fc_ = f_ < CS_FP ? f_ : CS_FP - 1;                                                                      \
+    const float m_ = f_ < CS_FP ? 1.f : 0.f;                                                                          \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                   \
+      const f32x4 U = split_mma_ba<NS, KSN>(bd[e], W, (f32x4){0.f, 0.f, 0.f, 0.f});                                   \
+      const float x = sX0[((e0 + e) * CS_FP + fc_) * CS_D + i] * m_;                                                  \
+      dxk[e][0] = __builtin_fmaf(x, U[0], dxk[e][0]);                                                                 \
+      dxk[e][1] = __builtin_fmaf(x, U[1], dxk[e][1]);                                                                 \
+      dxk[e][2] = __builtin_fmaf(x, U[2], dxk[e][2]);                                                                 \
+      dxk[e][3] = __builtin_fmaf(x, U[3], dxk[e][3]);                                                                 \
+      if (f_ < CS_FP)                                                                                                 \
+        sP[(((e0 + e) * CS_FP + f_) * 4 + kq) * 16 + i] =                                                             \
+            ((U[0] * xkv[e][0] + U[1] * xkv[e][1]) + U[2] * xkv[e][2]) + U[3] * xkv[e][3];                            \
+    }                                                                                                                 \
+    sw.store(sW + (size_t)((ST) & 1) * SLOT, tid);                                                                    \
+    __syncthreads();                                                                                                  \
+  }
+  for (int st = 0; st < nstep; st += 2) {
+    CS_DX_STEP(st, w0, w1)
+    CS_DX_STEP(st + 1, w1, w0)
+  }
+#undef CS_DX_STEP
+#undef CS_READ_WA
+  // this tile's share of dX0: the four lane-quarter partials of every (example, field, d) in order
+  for (int e4 = tid; e4 < E * p.F * 4; e4 += 512) {
+    const int ex = e4 / (p.F * 4), r = e4 - ex * (p.F * 4);
+    const int f = r >> 2, dq = r & 3;
+    const float4* q = reinterpret_cast<const float4*>(sP + ((ex * CS_FP + f) * 4) * 16) + dq;
+    const float4 s = f4_add(f4_add(f4_add(q[0], q[4]), q[8]), q[12]);
+    if (b0 + ex < p.B) reinterpret_cast<float4*>(p.dx0_parts + ((size_t)ht * p.B + b0 + ex) * p.F * CS_D)[r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = dxk[e][r];
+  __syncthreads();
+  {   // wave w finishes example w: dXk[b][h = 16 ht + 4 kq + r][d = i] = even fields' share + odd fields' share
+    const int ex = wv, b = b0 + ex;
+    const int w0i = (ex >> 1) * 2, sl = ex & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = sR[((w0i * 2 + sl) * 4 + r) * 64 + lane] + sR[(((w0i + 1) * 2 + sl) * 4 + r) * 64 + lane];
+      const int h = 16 * ht + 4 * kq + r;
+      if (b < p.B && h < p.H) {
+        float* dst = p.dXk + ((size_t)b * p.H + h) * CS_D + i;
+        *dst = p.acc_dxk ? *dst + s : s;
+      }
+    }
+  }
+}
+
+template <typename K>
+int opt_in_lds(K kernel, size_t lds) {
+  if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return RSX_ELAUNCH;
+  return RSX_OK;
+}
+
+template <int NS, int KS>
+int launch_fwd(const CsFwdArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)(a.N16 / 16), (unsigned)((a.B + CS_E - 1) / CS_E));
+  const size_t lds = (size_t)CS_E * CS_FP * CS_D * 4 + (size_t)2 * StageW<NS, KS>::SLOT * 2 + (size_t)CS_E * 16 * (32 * KS + 4) * 4;
+  const int rc = opt_in_lds(cin_split_fwd_k<NS, KS>, lds);
+  if (rc != RSX_OK) return rc;
+  RSX_LAUNCH((cin_split_fwd_k<NS, KS>), grid, dim3(512), lds, stream, a);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+template <int NS>
+int launch_fwd_ns(const CsFwdArgs& a, hipStream_t stream) {
+  switch (a.Hp / 32) {
+    case 1: return launch_fwd<NS, 1>(a, stream);
+    case 2: return launch_fwd<NS, 2>(a, stream);
+    case 3: return launch_fwd<NS, 3>(a, stream);
+    default: return launch_fwd<NS, 4>(a, stream);
+  }
+}
+
+template <int NS, int KSN>
+int launch_dx(const CsDxArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)(a.H16 / 16), (unsigned)((a.B + CS_E - 1) / CS_E));
+  const size_t sdp = (size_t)CS_E * 16 * (32 * KSN + 4) * 4, sp = (size_t)CS_E * CS_FP * 64 * 4;
+  const size_t lds = (size_t)CS_E * CS_FP * CS_D * 4 + (size_t)2 * StageW<NS, KSN>::SLOT * 2 + (sdp > sp ? sdp : sp);
+  const int rc = opt_in_lds(cin_split_dx_k<NS, KSN>, lds);
+  if (rc != RSX_OK) return rc;
+  RSX_LAUNCH((cin_split_dx_k<NS, KSN>), grid, dim3(512), lds, stream, a);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+template <int NS>
+int launch_dx_ns(const CsDxArgs& a, hipStream_t stream) {
+  switch (a.Np / 32) {
+    case 1: return launch_dx<NS, 1>(a, stream);
+    case 2: return launch_dx<NS, 2>(a, stream);
+    case 3: return launch_dx<NS, 3>(a, stream);
+    default: return launch_dx<NS, 4>(a, stream);
+  }
+}
+
+size_t image_elems(int F, int H, int N) {        // one plane of both layouts
+  return (size_t)F * rup(H, 16) * rup(N, 32) + (size_t)F * rup(N, 16) * rup(H, 32);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------ entry points
+extern "C" size_t rsx_cin_split_weight_elems(int F, int H, int N, int ns) {
+  if (F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > 3) return 0;
+  return (size_t)ns * image_elems(F, H, N);
+}
+
+extern "C" int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
+                                  int F, int ns, rsx_stream_t stream) {
+  if (!W_h || !w16_h || !H_h || !N_h || L <= 0 || F <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (L > CS_MAXJ) return RSX_EUNSUPPORTED;
+  CsPrepArgs a{};
+  a.njobs = L;
+  a.F = F;
+  long long tot = 0;
+  for (int k = 0; k < L; ++k) {
+    const int H = H_h[k], N = N_h[k];
+    if (!W_h[k] || !w16_h[k] || H <= 0 || N <= 0) return RSX_EINVAL;
+    if (H > 128 || N > 128) return RSX_EUNSUPPORTED;
+    CsPrepJob& j = a.job[k];
+    j.W = W_h[k]; j.H = H; j.N = N; j.H16 = rup(H, 16); j.N16 = rup(N, 16); j.Hp = rup(H, 32); j.Np = rup(N, 32);
+    j.W16 = static_cast<bf16_t*>(w16_h[k]);
+    j.Wt16 = j.W16 + (size_t)ns * F * j.H16 * j.Np;
+    tot += ((long long)F * j.H16 * j.Np + (long long)F * j.N16 * j.Hp) >> 3;
+    j.end = tot;
+  }
+  const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+  switch (ns) {
+    case 1: RSX_LAUNCH(cin_split_prep_k<1>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
+    case 2: RSX_LAUNCH(cin_split_prep_k<2>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
+    default: RSX_LAUNCH(cin_split_prep_k<3>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
+  }
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+
+extern "C" int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w16, const float* c, float* out, int B, int F,
+                                 int H, int N, int D, int ns, rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!X0 || !Xk || !w16 || !c || !out) return RSX_EINVAL;
+  if (D != CS_D || H > 128 || N > 128 || F > CS_FP) return RSX_EUNSUPPORTED;
+  const int H16 = rup(H, 16), N16 = rup(N, 16), Hp = rup(H, 32), Np = rup(N, 32);
+  const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)ns * F * H16 * Np;
+  const CsFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp};
+  switch (ns) {
+    case 1: return launch_fwd_ns<1>(a, rsx_s(stream));
+    case 2: return launch_fwd_ns<2>(a, rsx_s(stream));
+    default: return launch_fwd_ns<3>(a, rsx_s(stream));
+  }
+}
+
+// ws: [ns planes of dpre fragments | B x N16 bias-gradient partials]
+extern "C" size_t rsx_cin_split_bwd_workspace_bytes(int B, int N, int ns) {
+  if (B <= 0 || N <= 0 || ns < 1 || ns > 3) return 0;
+  return (size_t)ns * ((B + 1) / 2) * 2 * rup(N, 16) * CS_D * 2 + (size_t)B * rup(N, 16) * sizeof(float);
+}
+
+extern "C" int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
+                                    const float* gs, const float* wout, float* dXk, int acc_dxk, float* dx0_parts, void* ws,
+                                    int B, int F, int H, int N, int D, int ns, rsx_stream_t stream) {
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (B == 0) return RSX_OK;
+  if (!X0 || !Xk || !w16 || !out || !dXk || !dx0_parts || !ws) return RSX_EINVAL;
+  if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
+  if (D != CS_D || H > 128 || N > 128 || F > CS_FP) return RSX_EUNSUPPORTED;
+  const int H16 = rup(H, 16), N16 = rup(N, 16), Np = rup(N, 32);
+  float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)ns * ((B + 1) / 2) * 2 * N16 * CS_D * 2);
+  const CsDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dx0_parts, static_cast<bf16_t*>(ws),
+                   dc_part, acc_dxk, B, F, H, N, H16, N16, Np};
+  switch (ns) {
+    case 1: return launch_dx_ns<1>(a, rsx_s(stream));
+    case 2: return launch_dx_ns<2>(a, rsx_s(stream));
+    default: return launch_dx_ns<3>(a, rsx_s(stream));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dW, dc
+// dW_f[h, n] = sum over (b, d) of Z[b, f, h, d] * dpre[b, n, d], Z = X0 * Xk rounded once to fp32 (as cin.hip forms it) and
+// split into NS planes on the fly; dpre's planes come from the data-gradient launch (fragments of example pairs).
+// One launch for all layers.  Workgroup = 8 waves that split the k-steps (example pairs) of ONE tile = FT fields x 16 h x 64
+// n, partial tiles added in fixed order through LDS; FT is a per-job choice (so that the tiles of all layers together fill
+// the CUs in one round: 4 x 40 + ... see cs_launch_dw).  The X0 slab of the tile's fields sits in LDS (cin_bf16.hip: X0L).
+namespace {
+
+constexpr int CS_NT = 4;
+struct CsDwJob {
+  const float* Xk;        // [B, H, 16]
+  const bf16_t* dpre16;   // NS planes of fragments, see CsDxArgs
+  const float* dc_part;   // [B][N16]
+  float* dW;              // [F*H, N]
+  float* dc;              // [N]
+  int H, N, N16;
+  int ft;                 // fields per tile (3 or 4)
+  int gx, HT;             // tile grid of the job: gx n-groups x HT h tiles x ceil(F / ft) field groups
+  int tile_end;           // exclusive prefix sum of the jobs' tile counts
+};
+struct CsDwArgs {
+  CsDwJob job[CS_MAXJ];
+  int njobs;
+  const float* X0;        // [B, F, 16]
+  int B, F;
+};
+
+template <int NS, int FT>
+__device__ __forceinline__ void cs_dw_tile(const CsDwArgs& p, const CsDwJob& jb, int local, float4* dw_lds) {
+  constexpr int NT = CS_NT;
+  float (*red)[FT * NT][256] = reinterpret_cast<float (*)[FT * NT][256]>(dw_lds);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int bx = local % jb.gx, by = (local / jb.gx) % jb.HT, bz = local / (jb.gx * jb.HT);
+  const int i = lane & 15, kq = lane >> 4;
+  const int ntg = bx * NT, ht = by, f0 = bz * FT;
+  const int NT16 = jb.N16 >> 4;
+  const int H = jb.H;
+  const int h = 16 * ht + i;
+  const int hc = h < H ? h : H - 1;
+  const int d0 = (kq & 1) * 8, eb = kq >> 1;      // k = 8 kq + j  <->  example 2 ks + (kq >> 1), dims d0 .. d0 + 7
+  const int nks = (p.B + 1) / 2;
+  const size_t dplane = (size_t)nks * 2 * jb.N16 * CS_D;
+  f32x4 acc[FT][NT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {                                               // X0[b, f0 + ft, :] -> x0s[(ft * B + b) * 4 + quarter]
+    const int n4 = FT * p.B * 4;
+    for (int e = tid; e < n4; e += 512) {
+      const int qd = e & 3, b = (e >> 2) % p.B, ft = (e >> 2) / p.B;
+      const int f = f0 + ft < p.F ? f0 + ft : p.F - 1;
+      dw_lds[e] = reinterpret_cast<const float4*>(p.X0 + ((size_t)b * p.F + f) * CS_D)[qd];
+    }
+    __syncthreads();
+  }
+  struct Ld {
+    float4 xk[2];
+    uint4 dp[NS][NT];
+    float m;
+    int bc;
+  };
+  auto load = [&](int ks, Ld& L) {
+    const int b = 2 * ks + eb;
+    L.bc = b < p.B ? b : p.B - 1;
+    const int ksc = ks < nks ? ks : nks - 1;
+    L.m = (b < p.B && ks < nks && h < H) ? 1.f : 0.f;
+    const float4* xk = reinterpret_cast<const float4*>(jb.Xk + ((size_t)L.bc * H + hc) * CS_D + d0);
+    L.xk[0] = xk[0];
+    L.xk[1] = xk[1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {             // n tiles past N16 re-read the last tile (never stored)
+        const int t = ntg + nt < NT16 ? ntg + nt : NT16 - 1;
+        L.dp[s][nt] = *reinterpret_cast<const uint4*>(jb.dpre16 + (size_t)s * dplane + (((size_t)ksc * NT16 + t) * 64 + lane) * 8);
+      }
+  };
+  auto run = [&](const Ld& L) {
+    const float4 k0 = f4_scale(L.m, L.xk[0]), k1 = f4_scale(L.m, L.xk[1]);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      const float4* x0 = dw_lds + ((size_t)ft * p.B + L.bc) * 4 + (d0 >> 2);
+      bf16x8 a[NS][1];
+      {
+        bf16x8 t[NS];
+        split8<NS>(f4_mul(x0[0], k0), f4_mul(x0[1], k1), t);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s][0] = t[s];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x8 b[NS][1];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) b[s][0] = __builtin_bit_cast(bf16x8, L.dp[s][nt]);
+        acc[ft][nt] = split_mma<NS, 1>(a, b, acc[ft][nt]);
+      }
+    }
+  };
+  Ld La, Lb;
+  load(wv, La);
+  for (int ks = wv; ks < nks; ks += 16) {         // this wave's k-steps: wv, wv + 8, ...
+    load(ks + 8, Lb);                             // (clamped + masked past the batch)
+    run(La);
+    load(ks + 16, La);
+    run(Lb);
+  }
+  __syncthreads();                                // (the reduce buffer aliases the X0 slab)
+  // partial tiles, fixed order: ((w0 + w4) + (w1 + w5) ... ) as two rounds through one 4-slot LDS buffer
+  if (wv >= 4) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv - 4][ft * NT + nt][r * 64 + lane] = acc[ft][nt][r];
+  }
+  __syncthreads();
+  if (wv < 4) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ft][nt][r] += red[wv][ft * NT + nt][r * 64 + lane];
+  }
+  __syncthreads();
+  if (wv >= 1 && wv < 4) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][ft * NT + nt][r * 64 + lane] = acc[ft][nt][r];
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      const int f = f0 + ft;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * (ntg + nt) + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hh = 16 * ht + 4 * kq + r;
+          const float s = ((acc[ft][nt][r] + red[1][ft * NT + nt][r * 64 + lane]) + red[2][ft * NT + nt][r * 64 + lane]) +
+                          red[3][ft * NT + nt][r * 64 + lane];
+          if (f < p.F && hh < H && n < jb.N) jb.dW[((size_t)f * H + hh) * jb.N + n] = s;
+        }
+      }
+    }
+  }
+}
+
+// grid = njobs (the bias gradients: per-example partials added in order) + the jobs' tiles, block = 512
+template <int NS>
+__global__ __launch_bounds__(512) void cin_split_dw_k(const CsDwArgs p) {
+  extern __shared__ float4 dw_lds[];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < p.njobs) {
+    const CsDwJob& jb = p.job[blockIdx.x];
+    for (int n = tid; n < jb.N; n += 512) {
+      float s = 0.f;
+      int g = 0;
+      for (; g + 8 <= p.B; g += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = jb.dc_part[(size_t)(g + u) * jb.N16 + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+      }
+      for (; g < p.B; ++g) s += jb.dc_part[(size_t)g * jb.N16 + n];
+      jb.dc[n] = s;
+    }
+    return;
+  }
+  const int tile = (int)blockIdx.x - p.njobs;
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < CS_MAXJ; ++k)
+    if (k < p.njobs && tile >= p.job[k - 1].tile_end) ji = k;
+  const CsDwJob& jb = p.job[ji];
+  const int local = tile - (ji ? p.job[ji - 1].tile_end : 0);
+  if (jb.ft == 4) cs_dw_tile<NS, 4>(p, jb, local, dw_lds);
+  else cs_dw_tile<NS, 3>(p, jb, local, dw_lds);
+}
+
+}  // namespace
+
+/* jobs_h: rsx_cin_dw_job with ws = the layer's rsx_cin_split_bwd_dx workspace (dc_rows is ignored: one row per example) */
+extern "C" int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
+                                    rsx_stream_t stream) {
+  if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (njobs > CS_MAXJ || D != CS_D || F > CS_FP) return RSX_EUNSUPPORTED;
+  if (B == 0) return RSX_OK;
+  CsDwArgs w{};
+  w.njobs = njobs; w.X0 = X0; w.B = B; w.F = F;
+  // fields per tile: 4 for the job with the most tiles, 3 for the others -- [128, 128] at F = 39: 160 + 78 = 238 workgroups, one
+  // round on 256 CUs (3 everywhere: 286, a second round for 30 of them)
+  int big = 0;
+  for (int k = 1; k < njobs; ++k)
+    if ((long long)jobs_h[k].H * jobs_h[k].N > (long long)jobs_h[big].H * jobs_h[big].N) big = k;
+  static const int ft_env = getenv("RSX_CIN_SPLIT_DW_FT") ? atoi(getenv("RSX_CIN_SPLIT_DW_FT")) : 0;
+  int tiles = 0;
+  size_t x0_bytes = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const rsx_cin_dw_job& j = jobs_h[k];
+    if (!j.Xk || !j.ws || !j.dW || !j.dc || j.H <= 0 || j.N <= 0) return RSX_EINVAL;
+    if (j.H > 128 || j.N > 128) return RSX_EUNSUPPORTED;
+    const int H16 = rup(j.H, 16), N16 = rup(j.N, 16);
+    CsDwJob& d = w.job[k];
+    d.Xk = j.Xk;
+    d.dpre16 = static_cast<const bf16_t*>(j.ws);
+    d.dc_part = reinterpret_cast<const float*>(static_cast<const char*>(j.ws) + (size_t)ns * ((B + 1) / 2) * 2 * N16 * CS_D * 2);
+    d.dW = j.dW; d.dc = j.dc; d.H = j.H; d.N = j.N; d.N16 = N16;
+    d.ft = ft_env == 3 || ft_env == 4 ? ft_env : ((k == big && njobs > 1) ? 4 : 3);
+    d.gx = (N16 + 16 * CS_NT - 1) / (16 * CS_NT);
+    d.HT = H16 / 16;
+    tiles += d.gx * d.HT * ((F + d.ft - 1) / d.ft);
+    d.tile_end = tiles;
+    const size_t xb = (size_t)d.ft * B * CS_D * 4;
+    x0_bytes = xb > x0_bytes ? xb : x0_bytes;
+  }
+  const size_t red_bytes = (size_t)4 * 4 * CS_NT * 256 * 4;
+  const size_t lds = red_bytes > x0_bytes ? red_bytes : x0_bytes;
+  const unsigned grid = (unsigned)tiles + (unsigned)njobs;
+#define RSX_CS_DW(NS_)                                                       \
+  {                                                                          \
+    const int rc = opt_in_lds(cin_split_dw_k<NS_>, lds);                     \
+    if (rc != RSX_OK) return rc;                                             \
+    RSX_LAUNCH(cin_split_dw_k<NS_>, dim3(grid), dim3(512), lds, rsx_s(stream), w); \
+  }
+  switch (ns) {
+    case 1: RSX_CS_DW(1); break;
+    case 2: RSX_CS_DW(2); break;
+    default: RSX_CS_DW(3); break;
+  }
+#undef RSX_CS_DW
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}

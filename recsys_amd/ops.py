@@ -1330,9 +1330,26 @@ class CinNet:
     broadcast of its gradient back into every layer map happen inside those kernels; the gradients of X^0 from all layers
     (and from its second role as X^k of layer 0) accumulate in one buffer; weight gradients land in the dense arena."""
 
-    def __init__(self, F, D, sizes, capacity, device="cuda", bf16=False):
+    def __init__(self, F, D, sizes, capacity, device="cuda", bf16=False, split=0):
         dev = _require_cuda(device)
         self.F, self.D, self.sizes, self.L = F, D, [int(n) for n in sizes], len(sizes)
+        # split = ns in 1..3: the contraction on the bf16 matrix cores with every operand kept as ns bf16 planes
+        # (csrc/cin_split.hip; ns = 3: every product exact to 2^-23 -- fp32-grade, the parity path on those cores)
+        self.split = int(split or 0)
+        if self.split and not (1 <= self.split <= 3 and F <= 40 and D == 16 and max(sizes) <= 128 and self.L <= 4):
+            raise _lib.RsxError("CinNet: split operands need 1 <= ns <= 3, F <= 40, D = 16, layers <= 128 wide, <= 4 layers")
+        if self.split:
+            bf16 = False
+            hs16 = [F] + self.sizes[:-1]
+            ns = self.split
+            self.w16 = [torch.empty(int(lib().rsx_cin_split_weight_elems(F, h, n, ns)), dtype=torch.int16, device=dev)
+                        for h, n in zip(hs16, self.sizes)]
+            self.ws16 = [torch.empty(int(lib().rsx_cin_split_bwd_workspace_bytes(capacity, n, ns)), dtype=torch.uint8, device=dev)
+                         for n in self.sizes]
+            self._w16_h = (C.c_void_p * self.L)(*[w.data_ptr() for w in self.w16])
+            self._H_h = (C.c_int32 * self.L)(*hs16)
+            self.dx0_parts = [torch.empty(int(lib().rsx_cin_bf16_dx0_parts_floats(capacity, F, h)), device=dev) for h in hs16]
+            self._tiles_h = (C.c_int32 * self.L)(*[(h + 15) // 16 for h in hs16][::-1])
         # bf16=True: the contraction runs on the bf16 MFMA path (csrc/cin_bf16.hip: Xk / W / dpre rounded to bf16, fp32
         # accumulation) -- NOT the parity path; fp32 (False) is the default everywhere
         self.bf16 = bool(bf16)
@@ -1346,6 +1363,12 @@ class CinNet:
                          for n in self.sizes]
             self._w16_h = (C.c_void_p * self.L)(*[w.data_ptr() for w in self.w16])
             self._H_h = (C.c_int32 * self.L)(*hs16)
+            # eight examples per workgroup (csrc/cin_bf16_wide.hip): the data-gradient launches leave dX0 as one partial per
+            # 16-wide tile of h, ONE reduce launch adds the tiles of all layers
+            self.wide = F <= 40 and os.environ.get("RSX_CIN_WIDE", "1") != "0"
+            if self.wide:
+                self.dx0_parts = [torch.empty(int(lib().rsx_cin_bf16_dx0_parts_floats(capacity, F, h)), device=dev) for h in hs16]
+                self._tiles_h = (C.c_int32 * self.L)(*[(h + 15) // 16 for h in hs16][::-1])
         self.outs = [torch.empty(capacity, n, D, device=dev) for n in self.sizes]
         self.dmap = [torch.empty(capacity, n, D, device=dev) for n in self.sizes[:-1]]   # gradient wrt map k (from layer k+1)
         hs = [F] + self.sizes[:-1]
@@ -1361,12 +1384,22 @@ class CinNet:
         optimizer sweep carried by layer k's forward launch."""
         B = X0.shape[0]
         Xk, H = X0, self.F
+        if self.split:    # the split operand images of all layers' filters: one launch
+            W_h = (C.c_void_p * self.L)(*[P[f"cin.W{k}"].data_ptr() for k in range(self.L)])
+            check(lib().rsx_cin_split_prep(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, self.split, _stream()),
+                  "rsx_cin_split_prep")
         if self.bf16:     # the bf16 operand images of all layers' filters: one launch
             W_h = (C.c_void_p * self.L)(*[P[f"cin.W{k}"].data_ptr() for k in range(self.L)])
             check(lib().rsx_cin_prep_bf16_multi(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, _stream()),
                   "rsx_cin_prep_bf16_multi")
         for k, n in enumerate(self.sizes):
             sw = None if sweeps is None or sweeps[k] is None else C.byref(sweeps[k])
+            if self.split:
+                assert sw is None, "the split-operand CIN launches carry no sweep slices"
+                check(lib().rsx_cin_split_fwd(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]),
+                                              B, self.F, H, n, self.D, self.split, _stream()), "rsx_cin_split_fwd")
+                Xk, H = self.outs[k], n
+                continue
             if self.bf16:
                 check(lib().rsx_cin_layer_fwd_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(P[f"cin.c{k}"]), _ptr(self.outs[k]),
                                                    B, self.F, H, n, self.D, sw, _stream()), "rsx_cin_layer_fwd_bf16")
@@ -1392,6 +1425,7 @@ class CinNet:
                                         _ptr(P["cin.Wout"].grad), _ptr(P["cin.bout"].grad), _ptr(lx), _ptr(gl), _ptr(dwn),
                                         0 if lx is None else lx.shape[1], B, self.D, _stream()), "rsx_cin_out_bwd_lin")
         wout = P["cin.Wout"].data_ptr()
+        wide = self.bf16 and self.wide and (sweeps is None or all(x is None for x in sweeps[:L]))
         for k in range(L - 1, -1, -1):
             Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])
             dout = None if k == L - 1 else _ptr(self.dmap[k])
@@ -1399,6 +1433,20 @@ class CinNet:
                 dxk, acc_dxk, acc_dx0 = dX0, 1 if L > 1 else 0, 1
             else:
                 dxk, acc_dxk, acc_dx0 = self.dmap[k - 1], 0, 0 if k == L - 1 else 1
+            if self.split:
+                assert sweeps is None or all(x is None for x in sweeps), "the split-operand CIN launches carry no sweep slices"
+                check(lib().rsx_cin_split_bwd_dx(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
+                                                 C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), 0, _ptr(self.dx0_parts[k]),
+                                                 _ptr(self.ws16[k]), B, self.F, H, self.sizes[k], self.D, self.split, _stream()),
+                      "rsx_cin_split_bwd_dx")
+                continue
+            if self.bf16 and wide:
+                # (layer 0: dXk IS dX0 and nothing has been written there yet -- the other layers' shares arrive with the reduce)
+                check(lib().rsx_cin_layer_bwd_dx_bf16_parts(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout,
+                                                            _ptr(self.gs), C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), 0,
+                                                            _ptr(self.dx0_parts[k]), _ptr(self.ws16[k]), B, self.F, H,
+                                                            self.sizes[k], self.D, _stream()), "rsx_cin_layer_bwd_dx_bf16_parts")
+                continue
             if self.bf16:       # w16[k] was prepared by this step's forward (the filters do not change in between)
                 check(lib().rsx_cin_layer_bwd_dx_bf16(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
                                                       C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
@@ -1411,13 +1459,20 @@ class CinNet:
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
                                           self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
-        if self.bf16:           # every layer's weight gradient in ONE launch
+        if wide or self.split:  # dX0 = layer 0's dXk (already there) + every layer's tile partials, last layer first
+            parts_h = (C.c_void_p * L)(*[self.dx0_parts[k].data_ptr() for k in range(L - 1, -1, -1)])
+            check(lib().rsx_cin_dx0_reduce(parts_h, self._tiles_h, L, _ptr(dX0), 1, B, self.F, self.D, _stream()),
+                  "rsx_cin_dx0_reduce")
+        if self.bf16 or self.split:     # every layer's weight gradient in ONE launch
             jobs = (_lib.CinDwJob * L)()
             for k in range(L):
                 Xk, H = (X0, self.F) if k == 0 else (self.outs[k - 1], self.sizes[k - 1])
                 jobs[k] = _lib.CinDwJob(Xk.data_ptr(), self.ws16[k].data_ptr(), P[f"cin.W{k}"].grad.data_ptr(),
-                                        P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k])
+                                        P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k], B if (wide or self.split) else 0)
             assert sweeps is None or len(sweeps) == L + 1, "bf16 CinNet.backward: L + 1 sweep slots"
+            if self.split:
+                check(lib().rsx_cin_split_bwd_dw(_ptr(X0), jobs, L, B, self.F, self.D, self.split, _stream()), "rsx_cin_split_bwd_dw")
+                return dX0[:B]
             sw = None if sweeps is None or sweeps[L] is None else C.byref(sweeps[L])
             check(lib().rsx_cin_bwd_dw_bf16(_ptr(X0), jobs, L, B, self.F, self.D, sw, _stream()), "rsx_cin_bwd_dw_bf16")
         return dX0[:B]

@@ -88,7 +88,12 @@ def build_variables(store, params, capacity):
         return
     store.tower = FusedTower(store.dense, "dnn", F * D, layers, capacity, store.device)
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
-    store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)))
+    # cin_split = ns (1..3): the contraction on the bf16 matrix cores with ns bf16 planes per operand (csrc/cin_split.hip);
+    # ns = 3 keeps every product to 2^-23 -- fp32-grade, held to the same 1e-5 parity tests as the fp32 MFMA kernels
+    split = int(params.get("cin_split", 0) or 0)
+    if split and not (F <= 40 and D == 16 and max(cin) <= 128 and len(cin) <= 4):
+        split = 0                                    # outside the kernels' envelope: the fp32 MFMA path
+    store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)) and not split, split=split)
     from .deepfm import dp_unique_wanted
     want_ux = store.dp is not None and dp_unique_wanted(store, params) and \
         EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world)
@@ -196,9 +201,11 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 tw = sum(w)
                 nl = len(store.tower.widths)
                 env = os.environ.get("RSX_XDFM_SWEEP_WEIGHTS")
-                nd = L + 1 if store.cin.bf16 else L
+                nd = L + 1 if (store.cin.bf16 or store.cin.split) else L
                 if env:
                     wts = [float(x) for x in env.split(",")]
+                elif store.cin.split:      # (the split-operand CIN launches carry nothing)
+                    wts = [0.0] * L + [0.0] * nl + [1.0] + [2.0] * nl + [0.0] * (L + 1) + [2.0]
                 elif store.cin.bf16:
                     wts = [0.0] * L + [0.0] * nl + [1.0] + [2.0] * nl + [0.0] * L + [2.0] + [2.0]
                 else:
@@ -208,7 +215,7 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 sl_all = store.opt.cold_slices(c1[::-1] + c2, wts)
                 bw = sl_all[L + 2 * nl + 1:L + 2 * nl + 1 + nd]
                 # CinNet.forward: fwd_k; CinNet.backward: layer order (bf16: dx_0..dx_{L-1}, then the dW launch)
-                sweeps = sl_all[:L] + (bw[:L][::-1] + bw[L:] if store.cin.bf16 else bw[::-1])
+                sweeps = sl_all[:L] + (bw[:L][::-1] + bw[L:] if (store.cin.bf16 or store.cin.split) else bw[::-1])
                 tower_sweeps = sl_all[L:L + 2 * nl + 1]
                 last_sweep = sl_all[-1]
                 ride = ride and all(x is None for x in sl_all[:L + 1])    # no slice before the launch that carries the sort
@@ -353,6 +360,8 @@ def define_flags():
     p.add_argument("--cross_layers", default="20,10,10")       # xdeepfm/xdeepfm.py:19 (BASELINE config 3 uses 128,128)
     p.add_argument("--cin_bf16", type=lambda s: s.lower() in ("1", "true", "yes"), default=False,
                    help="CIN contraction on bf16 MFMA (fp32 accumulate); not the reference-parity path")
+    p.add_argument("--cin_split", type=int, default=0,
+                   help="ns in 1..3: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (3 = fp32-grade products)")
     p.add_argument("--eval_steps", type=int, default=200)
     p.set_defaults(num_epochs=5, eval_parts=10, log_steps=50, save_checkpoints_steps=2000)
     return p
@@ -362,7 +371,7 @@ def make_params(FLAGS):
     lin, emb = build_feature_columns(FLAGS.embedding_size, "numeric+indicator")
     return {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": FLAGS.embedding_size,
             "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout, "deep_layers": FLAGS.deep_layers,
-            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size, "cin_bf16": FLAGS.cin_bf16, **({"adam_window": FLAGS.adam_window} if getattr(FLAGS, "adam_window", 0) else {})}
+            "cross_layers": FLAGS.cross_layers, "max_batch_size": FLAGS.batch_size, "cin_bf16": FLAGS.cin_bf16, "cin_split": FLAGS.cin_split, **({"adam_window": FLAGS.adam_window} if getattr(FLAGS, "adam_window", 0) else {})}
 
 
 def main(argv=None):

@@ -22,7 +22,7 @@ def bf16_round(x):
     return r.astype(np.uint32).view(np.float32).reshape(np.shape(x))
 
 
-def _run_layer(B, F, H, N, seed, first_layer=False, with_gs=False, acc=False):
+def _run_layer(B, F, H, N, seed, first_layer=False, with_gs=False, acc=False, parts=False):
     from recsys_amd.ops import _ptr, _stream, check, lib
     rng = np.random.default_rng(seed)
     D = 16
@@ -45,10 +45,23 @@ def _run_layer(B, F, H, N, seed, first_layer=False, with_gs=False, acc=False):
     dXk = dX0 if first_layer else torch.full((B, H, D), 0.25 if acc else float("nan"), device="cuda")
     dW, dc = torch.empty_like(tW), torch.empty_like(tc)
     tgs = t(gs) if with_gs else None
-    check(lib().rsx_cin_layer_bwd_bf16(_ptr(tX0), _ptr(tXk), _ptr(w16), _ptr(out), _ptr(tdout),
-                                       _ptr(tgs) if with_gs else None, _ptr(twout) if with_gs else None, _ptr(dXk),
-                                       1 if (acc or first_layer) else 0, _ptr(dX0), 1 if (acc or first_layer) else 0,
-                                       _ptr(dW), _ptr(dc), _ptr(ws), B, F, H, N, D, None, _stream()))
+    if parts:
+        # eight examples per workgroup (csrc/cin_bf16_wide.hip): dX0 as per-h-tile partials + the reduce launch, the weight
+        # gradient launch told that the workspace holds one row of bias-gradient partials per example
+        from recsys_amd import _lib
+        pt = torch.full((int(lib().rsx_cin_bf16_dx0_parts_floats(B, F, H)),), float("nan"), device="cuda")
+        check(lib().rsx_cin_layer_bwd_dx_bf16_parts(_ptr(tX0), _ptr(tXk), _ptr(w16), _ptr(out), _ptr(tdout),
+                                                    _ptr(tgs) if with_gs else None, _ptr(twout) if with_gs else None, _ptr(dXk),
+                                                    1 if (acc or first_layer) else 0, _ptr(pt), _ptr(ws), B, F, H, N, D, _stream()))
+        check(lib().rsx_cin_dx0_reduce((C.c_void_p * 1)(pt.data_ptr()), (C.c_int32 * 1)((H + 15) // 16), 1, _ptr(dX0),
+                                       1 if (acc or first_layer) else 0, B, F, D, _stream()))
+        job = (_lib.CinDwJob * 1)(_lib.CinDwJob(tXk.data_ptr(), ws.data_ptr(), dW.data_ptr(), dc.data_ptr(), H, N, B))
+        check(lib().rsx_cin_bwd_dw_bf16(_ptr(tX0), job, 1, B, F, D, None, _stream()))
+    else:
+        check(lib().rsx_cin_layer_bwd_bf16(_ptr(tX0), _ptr(tXk), _ptr(w16), _ptr(out), _ptr(tdout),
+                                           _ptr(tgs) if with_gs else None, _ptr(twout) if with_gs else None, _ptr(dXk),
+                                           1 if (acc or first_layer) else 0, _ptr(dX0), 1 if (acc or first_layer) else 0,
+                                           _ptr(dW), _ptr(dc), _ptr(ws), B, F, H, N, D, None, _stream()))
     torch.cuda.synchronize()
     got = dict(out=out.cpu().numpy(), dX0=dX0.cpu().numpy(), dXk=dXk.cpu().numpy(), dW=dW.cpu().numpy(), dc=dc.cpu().numpy())
     # ---- fp64 evaluation with the kernel's roundings ---------------------------------------------------------------
@@ -86,11 +99,14 @@ def _rel(a, b):
     (7, 5, 6, 20, False, True, True),            # ragged everything: odd batch, H, N not multiples of 16 / 32
     (33, 39, 100, 50, False, False, False),
     (1, 3, 16, 16, False, True, False),
+    (250, 40, 128, 128, False, True, False),     # F = 40: every wave of the wide launches has five fields; ragged last group
+    (19, 39, 72, 96, False, False, True),        # three k-steps in both directions
 ])
-def test_cin_bf16_kernels_match_fp64_with_the_same_roundings(B, F, H, N, first, gs, acc):
+@pytest.mark.parametrize("parts", [False, True])
+def test_cin_bf16_kernels_match_fp64_with_the_same_roundings(B, F, H, N, first, gs, acc, parts):
     if first:
         H = F
-    got, ref, _ = _run_layer(B, F, H, N, seed=B * 7 + H, first_layer=first, with_gs=gs, acc=acc)
+    got, ref, _ = _run_layer(B, F, H, N, seed=B * 7 + H, first_layer=first, with_gs=gs, acc=acc, parts=parts)
     for k in ("out", "dc", "dXk", "dX0", "dW"):
         assert np.isfinite(got[k]).all(), k
         assert _rel(got[k], ref[k]) < 2e-5, (k, _rel(got[k], ref[k]))

@@ -52,7 +52,7 @@ def test_cin_first_layer_aliasing_x0():
     np.testing.assert_allclose(tx.grad.cpu().numpy(), d0 + dk, rtol=1e-4, atol=1e-4)
 
 
-def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16):
+def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16, cin_split=0):
     from recsys_amd import xdeepfm
     from recsys_amd.estimator import ModeKeys
     from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
@@ -67,7 +67,7 @@ def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16):
         P[k] += np.float32(0.05)
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": D, "learning_rate": 1e-3,
               "dropout": dropout, "deep_layers": ",".join(map(str, layers)), "cross_layers": ",".join(map(str, cin)),
-              "max_batch_size": B}
+              "max_batch_size": B, "cin_split": cin_split}
     est = make_estimator(xdeepfm.model_fn, params, use_graph=use_graph)
     batches = []
     for _ in range(steps):
@@ -147,6 +147,19 @@ def test_xdeepfm_train_parity_config3():
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 2e-5, losses
+    assert max(perr.values()) < 5e-5, perr
+
+
+@pytest.mark.parametrize("cin,dropout,B,steps", [((8, 4), 0.0, 16, 3), ((20, 10, 10), 0.5, 24, 3), ((128, 128), 0.5, 64, 2)])
+def test_xdeepfm_train_parity_split3(cin, dropout, B, steps):
+    """The same parity bars with the CIN contraction on the bf16 matrix cores, three bf16 planes per operand
+    (csrc/cin_split.hip, cin_split = 3: every product exact to 2^-23): predictions 1e-5, losses 1e-5 / 2e-5, variables 5e-5
+    against the fp64 oracle -- incl. BASELINE config 3's CIN [128,128], DNN 100-100."""
+    err, losses, perr = _xdeepfm_run(B=B, steps=steps, seed=21 if B < 64 else 22, cin=cin, layers=(32, 16) if B < 64 else (100, 100),
+                                     dropout=dropout, cin_split=3)
+    assert err < 1e-5, err
+    for lg, lo in losses:
+        assert abs(lg - lo) < (1e-5 if B < 64 else 2e-5), losses
     assert max(perr.values()) < 5e-5, perr
 
 
