@@ -208,7 +208,7 @@ def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmu
     params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 32 if model == "din" else 16,
               "learning_rate": 1e-3, "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B,
               "cross_layers": {"dcn": 3, "xdeepfm": "128,128"}.get(model), "cin_bf16": cin_bf16 is True,
-              "cin_split": int(cin_bf16[1]) if isinstance(cin_bf16, str) else 0}
+              "cin_split": int(cin_bf16[1]) if isinstance(cin_bf16, str) else 0}     # (explicit: False = the fp32 MFMA kernels)
     if a.no_overlap:
         params["overlap_adam"] = False
     mfn = {"deepfm": deepfm.model_fn, "fm": fm.model_fn, "dcn": dcn.model_fn, "xdeepfm": xdeepfm.model_fn, "din": din.model_fn}[model]

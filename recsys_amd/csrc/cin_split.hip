@@ -384,7 +384,11 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
   const bf16_t* wbase = p.W16 + (size_t)ht * KSN * 512;
   const size_t fstride = (size_t)p.H16 * p.Np, plane = (size_t)p.F * fstride;
   const int nstep = (p.F + 1) / 2;
-  const bool lead = ht == 0, has_dout = p.dout != nullptr, has_gs = p.gs != nullptr;
+  const bool lead = ht == 0;
+  const float* dsrc = p.dout ? p.dout : p.out;
+  const float* gsrc = p.gs ? p.gs : p.out;
+  const float* wsrc = p.gs ? p.wout : p.out;
+  const float dmul = p.dout ? 1.f : 0.f, gmul = p.gs ? 1.f : 0.f;
   StageW<NS, KSN> sw, sw1;
   sw.load(wbase, fstride, plane, 0, p.F, tid);
   sw1.load(wbase, fstride, plane, 2, p.F, tid);
@@ -407,12 +411,10 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
       const int bc = b < p.B ? b : p.B - 1, nc = n < p.N ? n : p.N - 1;
       const size_t at = ((size_t)bc * p.N + nc) * 4 + dq;
       const float4 o = reinterpret_cast<const float4*>(p.out)[at];
-      float4 g = F4Z;
-      if (has_dout) g = reinterpret_cast<const float4*>(p.dout)[at];       // (workgroup-uniform)
-      if (has_gs) {
-        const float a = p.gs[bc] * p.wout[nc];
-        g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
-      }
+      // (no branches: a load under a condition is waited for in its own block -- absent operands read `out` and count zero)
+      float4 g = f4_scale(dmul, reinterpret_cast<const float4*>(dsrc)[at]);
+      const float a = gsrc[bc] * wsrc[nc] * gmul;
+      g = make_float4(g.x + a, g.y + a, g.z + a, g.w + a);
       return make_float4((ok && o.x > 0.f) ? g.x : 0.f, (ok && o.y > 0.f) ? g.y : 0.f, (ok && o.z > 0.f) ? g.z : 0.f,
                          (ok && o.w > 0.f) ? g.w : 0.f);
     });
@@ -469,10 +471,7 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
   }
   __syncthreads();                                 // every wave has its operands: sDp may become sP
   f32x4 dxk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#define CS_DX_STEP(ST, W, WN)                                                                                         \
-  {                                                                                                                   \
-    sw.load(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid);                                                         \
-    CS_READ_WA((ST) + 1, WN)                                                                                          \
+#define CS_DX_BODY(ST, W)                                                                                             \
     const int f_ = 2 * (ST) + par;                                                                                    \
     const int fc_ = f_ < CS_FP ? f_ : CS_FP - 1;                                                                      \
     const float m_ = f_ < CS_FP ? 1.f : 0.f;                                                                          \
@@ -483,10 +482,15 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
       dxk[e][1] = __builtin_fmaf(x, U[1], dxk[e][1]);                                                                 \
       dxk[e][2] = __builtin_fmaf(x, U[2], dxk[e][2]);                                                                 \
       dxk[e][3] = __builtin_fmaf(x, U[3], dxk[e][3]);                                                                 \
-      if (f_ < CS_FP)                                                                                                 \
-        sP[(((e0 + e) * CS_FP + f_) * 4 + kq) * 16 + i] =                                                             \
-            ((U[0] * xkv[e][0] + U[1] * xkv[e][1]) + U[2] * xkv[e][2]) + U[3] * xkv[e][3];                            \
-    }                                                                                                                 \
+      /* (no branch inside a step: across one the staging registers go to scratch; f_ < CS_FP by the loop bound) */  \
+      sP[(((e0 + e) * CS_FP + fc_) * 4 + kq) * 16 + i] =                                                              \
+          ((U[0] * xkv[e][0] + U[1] * xkv[e][1]) + U[2] * xkv[e][2]) + U[3] * xkv[e][3];                              \
+    }
+#define CS_DX_STEP(ST, W, WN)                                                                                         \
+  {                                                                                                                   \
+    sw.load(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid);                                                         \
+    CS_READ_WA((ST) + 1, WN)                                                                                          \
+    CS_DX_BODY(ST, W)                                                                                                 \
     sw.store(sW + (size_t)((ST) & 1) * SLOT, tid);                                                                    \
     __syncthreads();                                                                                                  \
   }
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
     CS_DX_STEP(st, w0, w1)
     CS_DX_STEP(st + 1, w1, w0)
   }
+#undef CS_DX_BODY
 #undef CS_DX_STEP
 #undef CS_READ_WA
   // this tile's share of dX0: the four lane-quarter partials of every (example, field, d) in order

@@ -90,10 +90,14 @@ def build_variables(store, params, capacity):
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     # cin_split = ns (1..3): the contraction on the bf16 matrix cores with ns bf16 planes per operand (csrc/cin_split.hip);
     # ns = 3 keeps every product to 2^-23 -- fp32-grade, held to the same 1e-5 parity tests as the fp32 MFMA kernels
-    split = int(params.get("cin_split", 0) or 0)
+    # Default (cin_split unset, no cin_bf16): 3 -- the fastest path that holds the parity bar; cin_split = 0 selects the fp32
+    # MFMA kernels of csrc/cin.hip.
+    bf16 = bool(params.get("cin_bf16", False))
+    split = params.get("cin_split")
+    split = (0 if bf16 else 3) if split is None else int(split)
     if split and not (F <= 40 and D == 16 and max(cin) <= 128 and len(cin) <= 4):
         split = 0                                    # outside the kernels' envelope: the fp32 MFMA path
-    store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bool(params.get("cin_bf16", False)) and not split, split=split)
+    store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bf16 and not split, split=split)
     from .deepfm import dp_unique_wanted
     want_ux = store.dp is not None and dp_unique_wanted(store, params) and \
         EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world)
@@ -360,8 +364,9 @@ def define_flags():
     p.add_argument("--cross_layers", default="20,10,10")       # xdeepfm/xdeepfm.py:19 (BASELINE config 3 uses 128,128)
     p.add_argument("--cin_bf16", type=lambda s: s.lower() in ("1", "true", "yes"), default=False,
                    help="CIN contraction on bf16 MFMA (fp32 accumulate); not the reference-parity path")
-    p.add_argument("--cin_split", type=int, default=0,
-                   help="ns in 1..3: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (3 = fp32-grade products)")
+    p.add_argument("--cin_split", type=int, default=None,
+                   help="ns in 1..3: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (3 = fp32-grade products, "
+                        "the default); 0 = the fp32 MFMA kernels")
     p.add_argument("--eval_steps", type=int, default=200)
     p.set_defaults(num_epochs=5, eval_parts=10, log_steps=50, save_checkpoints_steps=2000)
     return p

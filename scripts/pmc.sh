@@ -16,7 +16,7 @@ with open(f) as fh:
         agg[k][0] += 1
         agg[k][1] += float(row["Counter_Value"])
 print("# rocprofv3 --pmc %s --kernel-trace: per-kernel mean counter value per dispatch" % ctr)
-for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(__import__("os").environ.get("PMC_ROWS", "12"))]:
     print("%-62s %-12s calls=%6d mean=%.1f" % (k, c, n, s / n))
 PY
 cat $root/gpurun_out/pmc_$name.txt | head -8

@@ -52,7 +52,7 @@ def test_cin_first_layer_aliasing_x0():
     np.testing.assert_allclose(tx.grad.cpu().numpy(), d0 + dk, rtol=1e-4, atol=1e-4)
 
 
-def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16, cin_split=0):
+def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16, cin_split=None):
     from recsys_amd import xdeepfm
     from recsys_amd.estimator import ModeKeys
     from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
@@ -122,7 +122,7 @@ def _xdeepfm_run(B, steps, seed, cin, layers, dropout, use_graph=False, D=16, ci
 
 @pytest.mark.parametrize("cin,dropout,B", [((8, 4), 0.0, 16), ((20, 10, 10), 0.5, 24)])
 def test_xdeepfm_train_parity(cin, dropout, B):
-    err, losses, perr = _xdeepfm_run(B=B, steps=3, seed=21, cin=cin, layers=(32, 16), dropout=dropout)
+    err, losses, perr = _xdeepfm_run(B=B, steps=3, seed=21, cin=cin, layers=(32, 16), dropout=dropout, cin_split=0)   # fp32 MFMA kernels
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 1e-5, losses
@@ -143,7 +143,7 @@ def test_xdeepfm_generic_path_covers_the_flag_envelope(D, cin, layers):
 
 def test_xdeepfm_train_parity_config3():
     """BASELINE config 3: xdeepfm.py Criteo d=16, CIN [128,128], DNN 100-100 (batch reduced for the numpy oracle)."""
-    err, losses, perr = _xdeepfm_run(B=64, steps=2, seed=22, cin=(128, 128), layers=(100, 100), dropout=0.5)
+    err, losses, perr = _xdeepfm_run(B=64, steps=2, seed=22, cin=(128, 128), layers=(100, 100), dropout=0.5, cin_split=0)
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < 2e-5, losses
@@ -163,8 +163,9 @@ def test_xdeepfm_train_parity_split3(cin, dropout, B, steps):
     assert max(perr.values()) < 5e-5, perr
 
 
-def test_xdeepfm_hip_graph():
-    err, losses, perr = _xdeepfm_run(B=32, steps=5, seed=23, cin=(16, 16), layers=(32, 16), dropout=0.0, use_graph=True)
+@pytest.mark.parametrize("cin_split", [0, 3])
+def test_xdeepfm_hip_graph(cin_split):
+    err, losses, perr = _xdeepfm_run(B=32, steps=5, seed=23, cin=(16, 16), layers=(32, 16), dropout=0.0, use_graph=True, cin_split=cin_split)
     assert err < 1e-5 and max(perr.values()) < 5e-5, (err, perr)
 
 
