@@ -857,7 +857,7 @@ extern "C" int rsx_cin_layer_bwd_dx_bf16_parts(const float* X0, const float* Xk,
 extern "C" int rsx_cin_dx0_reduce(const float* const* parts_h, const int32_t* tiles_h, int njobs, float* dX0, int acc, int B,
                                   int F, int D, rsx_stream_t stream) {
   if (!parts_h || !tiles_h || !dX0 || njobs <= 0 || B < 0 || F <= 0) return RSX_EINVAL;
-  if (D != CB_D) return RSX_EUNSUPPORTED;
+  if (D != CB_D || njobs > 4) return RSX_EUNSUPPORTED;
   if (B == 0) return RSX_OK;
   for (int j = 0; j < njobs; ++j)
     if (!parts_h[j] || tiles_h[j] <= 0) return RSX_EINVAL;

@@ -25,11 +25,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16_t;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) float gfloat_t;
 
 namespace {
 
 constexpr int CS_D = 16;
-constexpr int CS_E = 8;         // examples per workgroup
 constexpr int CS_FP = 40;       // fields, padded (X0 reads as zero past F): F <= 40
 constexpr int CS_MAXJ = 4;
 
@@ -70,6 +70,11 @@ __device__ __forceinline__ void split8(float4 a, float4 b, bf16x8 (&out)[NS]) {
 }
 
 // T += sum over the kept terms (smallest first) and the k-steps of A-plane x B-plane
+// RSX_CIN_DBG (probe builds only, scripts/cin_split_where.sh; results are WRONG): 1 = one VALU fma in place of every MFMA, 2 = no
+// global filter loads inside the field loop, 3 = no barrier inside the field loop
+#ifndef RSX_CIN_DBG
+#define RSX_CIN_DBG 0
+#endif
 template <int NS, int KS>
 __device__ __forceinline__ f32x4 split_mma(const bf16x8 (&a)[NS][KS], const bf16x8 (&b)[NS][KS], f32x4 T) {
 #pragma unroll
@@ -77,7 +82,13 @@ __device__ __forceinline__ f32x4 split_mma(const bf16x8 (&a)[NS][KS], const bf16
 #pragma unroll
     for (int sa = 0; sa <= lvl; ++sa)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) T = mfma_bf16(a[sa][ks], b[lvl - sa][ks], T);
+      for (int ks = 0; ks < KS; ++ks) {
+#if RSX_CIN_DBG == 1
+        T[0] = __builtin_fmaf(__builtin_bit_cast(f32x4, a[sa][ks])[0], __builtin_bit_cast(f32x4, b[lvl - sa][ks])[0], T[0]);
+#else
+        T = mfma_bf16(a[sa][ks], b[lvl - sa][ks], T);
+#endif
+      }
   return T;
 }
 template <int NS, int KS>
@@ -144,18 +155,21 @@ __global__ __launch_bounds__(256) void cin_split_prep_k(const CsPrepArgs p) {
   }
 }
 
-// X0 of the eight examples -> LDS [E][CS_FP * 16], zeros for the fields past F: 3 float4 per thread, requested together
+// X0 of the workgroup's E examples -> LDS [E][CS_FP * 16], zeros for the fields past F: 3 float4 per thread (E * 160 items over
+// 64 E threads), requested together
+template <int E>
 struct StageX0 {
+  static constexpr int NTHR = 64 * E;
   float4 v[3];
   __device__ __forceinline__ void load(const float* X0, int b0, int B, int F, int tid) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int e4 = tid + 512 * u;
+      const int e4 = tid + NTHR * u;
       const int ex = e4 / (CS_FP * 4), r = e4 % (CS_FP * 4);
       // (unconditional loads from clamped addresses, zeroed afterwards: a load under a condition becomes a branch, and the
       // compiler waits for each of them in turn)
-      const int exc = ex < CS_E ? ex : CS_E - 1;
-      const bool ok = e4 < CS_E * CS_FP * 4 && (r >> 2) < F && b0 + ex < B;
+      const int exc = ex < E ? ex : E - 1;
+      const bool ok = e4 < E * CS_FP * 4 && (r >> 2) < F && b0 + ex < B;
       const int bc = b0 + exc < B ? b0 + exc : B - 1, rc = (r >> 2) < F ? r : 0;
       const float4 t = reinterpret_cast<const float4*>(X0 + (size_t)bc * F * CS_D)[rc];
       v[u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
@@ -164,8 +178,8 @@ struct StageX0 {
   __device__ __forceinline__ void store(float* sX0, int tid) const {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int e4 = tid + 512 * u;
-      if (e4 < CS_E * CS_FP * 4) reinterpret_cast<float4*>(sX0)[e4] = v[u];
+      const int e4 = tid + NTHR * u;
+      if (e4 < E * CS_FP * 4) reinterpret_cast<float4*>(sX0)[e4] = v[u];
     }
   }
 };
@@ -173,15 +187,15 @@ struct StageX0 {
 // [E][rows][16] fp32 (through `ld(e, row, quarter)`, zeros past the real rows) -> LDS, transposed to dst[e][d][RP] fp32 (rows
 // contiguous: what the MFMA's k index walks), RP = 32 KS + 4.  2 KS float4 per thread, all requested before the first store;
 // lanes = (quarter fastest, row): a wave's 64 scalar stores hit 64 banks.
-template <int KS>
+template <int KS, int E>
 struct StageRowsF32 {
-  static constexpr int RP = 32 * KS + 4;
+  static constexpr int RP = 32 * KS + 4, NTHR = 64 * E;
   float4 v[2 * KS];
   template <typename Load>
   __device__ __forceinline__ void load(int tid, Load ld) {
 #pragma unroll
     for (int u = 0; u < 2 * KS; ++u) {
-      const int it = tid + 512 * u;
+      const int it = tid + NTHR * u;
       const int dq = it & 3, row = (it >> 2) % (32 * KS), e = it / (128 * KS);
       v[u] = ld(e, row, dq);
     }
@@ -189,7 +203,7 @@ struct StageRowsF32 {
   __device__ __forceinline__ void store(float* dst, int tid) const {
 #pragma unroll
     for (int u = 0; u < 2 * KS; ++u) {
-      const int it = tid + 512 * u;
+      const int it = tid + NTHR * u;
       const int dq = it & 3, row = (it >> 2) % (32 * KS), e = it / (128 * KS);
       float* t = dst + ((size_t)e * 16 + dq * 4) * RP + row;
       t[0 * RP] = v[u].x;
@@ -200,31 +214,53 @@ struct StageRowsF32 {
   }
 };
 
-// The filter fragments of one step: 2 fields x NS planes x KS k-steps, 1 KiB each, contiguous in LDS in that order.
-// Item = one 16-byte lane quad; U per thread.  f >= F is clamped (its X0 is zero).
-template <int NS, int KS>
+// The filter fragments of one step: 2 fields x NS planes x KS k-steps, 1 KiB each, contiguous in LDS in that order, copied by
+// global_load_lds_dwordx4 (L2 -> LDS without staging registers or a ds_write pass: the register-staged form spent 13 LDS cycles
+// per 1-KiB ds_write_b128 AFTER the step's MFMAs, before its barrier).  Item = one 16-byte lane quad, U per thread; a wave's 64
+// items are one fragment = 1 KiB contiguous on both sides (the LDS destination of an LDS-DMA is wave-uniform base + lane * 16).
+// f >= F is clamped (its X0 is zero); a ring slot is padded to U * NTHR quads (no conditional issue).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+template <int NS, int KS, int E>
 struct StageW {
-  static constexpr int FRAGS = 2 * NS * KS;
-  static constexpr int U = (FRAGS * 64 + 511) / 512;
-  uint4 v[U];
+  static constexpr int FRAGS = 2 * NS * KS, NTHR = 64 * E;
+  static constexpr int U = (FRAGS * 64 + NTHR - 1) / NTHR;
+  static constexpr int SLOT = U * NTHR * 8;        // bf16 elements per ring slot
   // base: image + (tile * KS) * 512 elements; fstride: elements per field; plane: elements per plane
-  __device__ __forceinline__ void load(const bf16_t* base, size_t fstride, size_t plane, int f0, int F, int tid) {
+  static __device__ __forceinline__ void issue(const bf16_t* base, size_t fstride, size_t plane, int f0, int F, int tid, bf16_t* slot) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int it = tid + 512 * u;
+      const int it = tid + NTHR * u;
       const int lane = it & 63, frag = (it >> 6) < FRAGS ? (it >> 6) : FRAGS - 1;
       const int ks = frag % KS, sp = (frag / KS) % NS, par = frag / (KS * NS);
       const int f = f0 + par < F ? f0 + par : F - 1;
-      v[u] = *reinterpret_cast<const uint4*>(base + (size_t)sp * plane + (size_t)f * fstride + (size_t)ks * 512 + lane * 8);
+      const bf16_t* src = base + (size_t)sp * plane + (size_t)f * fstride + (size_t)ks * 512 + lane * 8;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(slot + (size_t)(it - lane) * 8), 16, 0, 0);
     }
   }
-  // (unconditional: a ring slot is padded to U * 512 quads.  Under a condition the compiler sinks the item's global load into
-  // the branch and waits for it there -- one exposed L2 round trip per step)
-  static constexpr int SLOT = U * 512 * 8;         // bf16 elements per ring slot
-  __device__ __forceinline__ void store(bf16_t* buf, int tid) const {
-#pragma unroll
-    for (int u = 0; u < U; ++u) reinterpret_cast<uint4*>(buf)[tid + 512 * u] = v[u];
-  }
+};
+
+constexpr size_t cs_max(size_t a, size_t b) { return a > b ? a : b; }
+#if RSX_CIN_DBG == 2
+#define CS_DBG_LOAD(X)
+#else
+#define CS_DBG_LOAD(X) X
+#endif
+#if RSX_CIN_DBG == 3
+#define CS_DBG_BARRIER
+#else
+#define CS_DBG_BARRIER __syncthreads();
+#endif
+// LDS of the forward / data-gradient launches: sX0 | ring slot 0 | ring slot 1 | staged operand rows [E][16][32 KS + 4] f32 (dead
+// once the operands are in registers; the waves' partial sums reuse it).  Where two 256-thread workgroups would not fit a CU
+// side by side (80 KiB each), slot 1 ALIASES the staged rows and is filled after they were consumed (one exposed L2 round
+// trip in the prologue).
+template <int NS, int KS, int E>
+struct CsLds {
+  static constexpr size_t X0 = (size_t)E * CS_FP * CS_D * 4, SLOT = (size_t)StageW<NS, KS, E>::SLOT * 2;
+  static constexpr size_t ROWS = cs_max((size_t)E * 16 * (32 * KS + 4) * 4, (size_t)E * 2 * 256 * 4);
+  static constexpr bool ALIAS = E == 4 && X0 + 2 * SLOT + ROWS > 80 * 1024;
+  static constexpr size_t TOTAL = X0 + SLOT + (ALIAS ? cs_max(SLOT, ROWS) : SLOT + ROWS);
 };
 
 // ------------------------------------------------------------------------------------------------------------ forward
@@ -237,16 +273,19 @@ struct CsFwdArgs {
   int B, F, H, N, N16, Hp;
 };
 
-// grid = (N16 / 16, ceil(B / 8)), block = 512.
-// dyn LDS: sX0 8*40*16 f32 | sW 2 x (2 NS KS) KiB | sXk 8*16*(32 KS + 4) f32 (the waves' partial sums alias it at the end)
-template <int NS, int KS>
-__global__ __launch_bounds__(512) void cin_split_fwd_k(const CsFwdArgs p) {
+// grid = (N16 / 16, ceil(B / E)), block = 64 E (E = 4: two workgroups per CU, their barriers independent -- one's MFMAs cover
+// the other's loads, LDS traffic and barrier waits; E = 8: one workgroup per CU, half the filter traffic from L2).
+// dyn LDS: CsLds.
+template <int NS, int KS, int E>
+__global__ __launch_bounds__(64 * E, E == 4 ? 2 : 1) void cin_split_fwd_k(const CsFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int E = CS_E, HP = 32 * KS + 4, SLOT = StageW<NS, KS>::SLOT;
+  constexpr int HP = 32 * KS + 4, SLOT = StageW<NS, KS, E>::SLOT;
   float* sX0 = lds;                                                   // [E][CS_FP*16]
-  bf16_t* sW = reinterpret_cast<bf16_t*>(sX0 + E * CS_FP * CS_D);     // [2][SLOT]: ring of two steps
-  float* sXk = reinterpret_cast<float*>(sW + 2 * SLOT);               // [E][16][HP]
-  float* sR = sXk;                                                    // [8 waves][2][4][64]
+  bf16_t* sW0 = reinterpret_cast<bf16_t*>(sX0 + E * CS_FP * CS_D);    // ring slot 0
+  bf16_t* sW1 = sW0 + SLOT;                                           // ring slot 1
+  constexpr bool ALIAS = CsLds<NS, KS, E>::ALIAS;
+  float* sXk = reinterpret_cast<float*>(ALIAS ? sW1 : sW1 + SLOT);    // [E][16][HP]
+  float* sR = sXk;                                                    // [E waves][2][4][64] at the end
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int par = wv & 1, e0 = (wv >> 1) * 2;                         // field parity, first of the wave's two examples
@@ -254,21 +293,19 @@ __global__ __launch_bounds__(512) void cin_split_fwd_k(const CsFwdArgs p) {
   const bf16_t* wbase = p.Wt16 + (size_t)blockIdx.x * KS * 512;
   const size_t fstride = (size_t)p.N16 * p.Hp, plane = (size_t)p.F * fstride;
   const int nstep = (p.F + 1) / 2;
-  StageW<NS, KS> sw, sw1;
-  sw.load(wbase, fstride, plane, 0, p.F, tid);
-  sw1.load(wbase, fstride, plane, 2, p.F, tid);
-  StageX0 sx;
+  using GW = StageW<NS, KS, E>;
+  GW::issue(wbase, fstride, plane, 0, p.F, tid, sW0);
+  if constexpr (!ALIAS) GW::issue(wbase, fstride, plane, 2, p.F, tid, sW1);
+  StageX0<E> sx;
   sx.load(p.X0, b0, p.B, p.F, tid);
   {
-    StageRowsF32<KS> sr;
+    StageRowsF32<KS, E> sr;
     sr.load(tid, [&](int e, int h, int dq) {
       const bool ok = b0 + e < p.B && h < p.H;
       const int bc = b0 + e < p.B ? b0 + e : p.B - 1, hc = h < p.H ? h : p.H - 1;
       const float4 t = reinterpret_cast<const float4*>(p.Xk + ((size_t)bc * p.H + hc) * CS_D)[dq];
       return make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     });
-    sw.store(sW, tid);
-    sw1.store(sW + SLOT, tid);
     sx.store(sX0, tid);
     sr.store(sXk, tid);
   }
@@ -286,21 +323,20 @@ __global__ __launch_bounds__(512) void cin_split_fwd_k(const CsFwdArgs p) {
     }
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   // Step st multiplies the fragments its predecessor read from ring slot st & 1 into registers, while (a) the reads of step
-  // st + 1's fragments (the other slot, complete since the last barrier) and (b) the global loads of step st + 2's are in
-  // flight; (b) lands in slot st & 1 -- every wave's reads of it completed before the last barrier -- before the step's
-  // barrier.  Two steps per trip: the two register sets swap roles without copies.  A step past the last field multiplies
-  // by X0 = 0.
+  // st + 1's fragments (the other slot, complete since the last barrier) and (b) the LDS-DMA of step st + 2's into slot st & 1
+  // -- every wave's reads of it completed before the last barrier -- are in flight; the step's barrier waits for (b).  Two
+  // steps per trip: the two register sets swap roles without copies.  A step past the last field multiplies by X0 = 0.
   // (macros, not lambdas: captured by reference the staging registers and the fragment sets go to scratch memory)
 #define CS_READ_W(ST, W)                                                                                              \
   {                                                                                                                   \
-    const bf16_t* wb_ = sW + (size_t)((ST) & 1) * SLOT + (par * NS * KS) * 512 + lane * 8;                            \
+    const bf16_t* wb_ = (((ST) & 1) ? sW1 : sW0) + (par * NS * KS) * 512 + lane * 8;                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_)                                                                 \
       _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                            \
         W[s_][ks_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb_ + (s_ * KS + ks_) * 512));        \
   }
 #define CS_FWD_STEP(ST, W, WN)                                                                                        \
   {                                                                                                                   \
-    sw.load(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid); /* unconditional: under a branch -> scratch */          \
+    CS_DBG_LOAD(GW::issue(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid, ((ST) & 1) ? sW1 : sW0);)                  \
     CS_READ_W((ST) + 1, WN)                                                                                           \
     const int f_ = 2 * (ST) + par;                                                                                    \
     const float m_ = f_ < CS_FP ? 1.f : 0.f;                                                                          \
@@ -312,12 +348,15 @@ __global__ __launch_bounds__(512) void cin_split_fwd_k(const CsFwdArgs p) {
       acc[e][2] = __builtin_fmaf(x.z * m_, T[2], acc[e][2]);                                                          \
       acc[e][3] = __builtin_fmaf(x.w * m_, T[3], acc[e][3]);                                                          \
     }                                                                                                                 \
-    sw.store(sW + (size_t)((ST) & 1) * SLOT, tid);                                                                    \
-    __syncthreads();                                                                                                  \
+    CS_DBG_BARRIER /* (its fence waits for the step's LDS-DMA: vmcnt(0)) */                                           \
   }
   bf16x8 w0[NS][KS], w1[NS][KS];
   CS_READ_W(0, w0)
-  __syncthreads();                                 // step 0 refills slot 0: every wave must have read it
+  __syncthreads();                                 // every wave has its operands (sXk is free) and slot 0's fragments
+  if constexpr (ALIAS) {
+    GW::issue(wbase, fstride, plane, 2, p.F, tid, sW1);
+    __syncthreads();
+  }
   for (int st = 0; st < nstep; st += 2) {
     CS_FWD_STEP(st, w0, w1)
     CS_FWD_STEP(st + 1, w1, w0)
@@ -331,13 +370,13 @@ __global__ __launch_bounds__(512) void cin_split_fwd_k(const CsFwdArgs p) {
   __syncthreads();
   {   // wave w finishes example w: even fields' sum + odd fields' sum + bias, relu
     const int ex = wv, b = b0 + ex;
-    const int w0 = (ex >> 1) * 2, sl = ex & 1;
+    const int w0i = (ex >> 1) * 2, sl = ex & 1;
     const bool nok = n0 + i < p.N;
     const float cv = p.c[nok ? n0 + i : 0];
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      o[r] = fmaxf((sR[((w0 * 2 + sl) * 4 + r) * 64 + lane] + sR[(((w0 + 1) * 2 + sl) * 4 + r) * 64 + lane]) + cv, 0.f);
+      o[r] = fmaxf((sR[((w0i * 2 + sl) * 4 + r) * 64 + lane] + sR[(((w0i + 1) * 2 + sl) * 4 + r) * 64 + lane]) + cv, 0.f);
     if (nok && b < p.B)
       *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n0 + i) * CS_D + kq * 4) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -360,23 +399,24 @@ struct CsDxArgs {
   int B, F, H, N, H16, N16, Np;
 };
 
-// grid = (H16 / 16, ceil(B / 8)), block = 512: workgroup = 8 examples x the 16 inputs h of tile blockIdx.x; waves as in the
+// grid = (H16 / 16, ceil(B / E)), block = 64 E: workgroup = E examples x the 16 inputs h of tile blockIdx.x; waves as in the
 // forward (field parity x example pair).  U_f^T[h, d] = sum_n W_f[h, n] dpre[b, n, d]: A = W16 fragments (through the LDS ring),
 // B = dpre[b]^T (k = n, column = d) of the wave's two examples, split, in registers.
 //   dXk[b, h, d] += X0[b, f, d] U_f^T[h, d]   summed over the wave's fields in registers, the two parities through LDS
-//   dX0[b, f, d]  = sum_h Xk[b, h, d] U_f^T[h, d] over this tile's 16 h: four lane-quarter partials through LDS, added in
-//                   order, written to dx0_parts[tile] (rsx_cin_dx0_reduce adds the tiles)
-// dyn LDS: sX0 8*40*16 f32 | sW 2 ring slots | R = max(sDp 8*16*(32 KSN + 4), sP 8*40*64) f32 (sDp is dead once the
-// operands are in registers; the parities' dXk partials alias sP after it was consumed).
-template <int NS, int KSN>
-__global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
+//   dX0[b, f, d]  = sum_h Xk[b, h, d] U_f^T[h, d] over this tile's 16 h: four rows per lane, the four lane quarters by two
+//                   butterfly exchanges, collected in LDS, written to dx0_parts[tile] at the end (rsx_cin_dx0_reduce adds the tiles)
+// dyn LDS: CsLds.
+template <int NS, int KSN, int E>
+__global__ __launch_bounds__(64 * E, E == 4 ? 2 : 1) void cin_split_dx_k(const CsDxArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int E = CS_E, NP = 32 * KSN + 4, SLOT = StageW<NS, KSN>::SLOT;
+  constexpr int NP = 32 * KSN + 4, SLOT = StageW<NS, KSN, E>::SLOT, NTHR = 64 * E;
   float* sX0 = lds;                                                   // [E][CS_FP*16]
-  bf16_t* sW = reinterpret_cast<bf16_t*>(sX0 + E * CS_FP * CS_D);     // [2][SLOT]
-  float* sDp = reinterpret_cast<float*>(sW + 2 * SLOT);               // [E][16][NP]
-  float* sP = sDp;                                                    // [E][CS_FP][4 kq][16 i]   (after the operands were read)
-  float* sR = sDp;                                                    // [8 waves][2][4][64]      (after sP was consumed)
+  bf16_t* sW0 = reinterpret_cast<bf16_t*>(sX0 + E * CS_FP * CS_D);    // ring slot 0
+  bf16_t* sW1 = sW0 + SLOT;                                           // ring slot 1
+  constexpr bool ALIAS = CsLds<NS, KSN, E>::ALIAS;
+  float* sDp = reinterpret_cast<float*>(ALIAS ? sW1 : sW1 + SLOT);    // [E][16][NP]
+  float* sR = sDp;                                                    // [E waves][2][4][64] at the end
+  float* sP = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + CsLds<NS, KSN, E>::TOTAL);   // [E][CS_FP][16]: dX0 of this tile
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int par = wv & 1, e0 = (wv >> 1) * 2;
@@ -389,22 +429,24 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
   const float* gsrc = p.gs ? p.gs : p.out;
   const float* wsrc = p.gs ? p.wout : p.out;
   const float dmul = p.dout ? 1.f : 0.f, gmul = p.gs ? 1.f : 0.f;
-  StageW<NS, KSN> sw, sw1;
-  sw.load(wbase, fstride, plane, 0, p.F, tid);
-  sw1.load(wbase, fstride, plane, 2, p.F, tid);
-  StageX0 sx;
+  using GW = StageW<NS, KSN, E>;
+  GW::issue(wbase, fstride, plane, 0, p.F, tid, sW0);
+  if constexpr (!ALIAS) GW::issue(wbase, fstride, plane, 2, p.F, tid, sW1);
+  StageX0<E> sx;
   sx.load(p.X0, b0, p.B, p.F, tid);
   float xkv[2][4];                                 // Xk[b0 + e0 + e][h = 16 ht + 4 kq + r][d = i]
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
+  for (int e = 0; e < 2; ++e) {
+    const int b = b0 + e0 + e;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int b = b0 + e0 + e, h = 16 * ht + 4 * kq + r;
+      const int h = 16 * ht + 4 * kq + r;
       xkv[e][r] = p.Xk[((size_t)(b < p.B ? b : p.B - 1) * p.H + (h < p.H ? h : p.H - 1)) * CS_D + i] * ((b < p.B && h < p.H) ? 1.f : 0.f);
     }
+  }
   {
-    // dpre = relu'(out) * (dout + gs * wout) of the eight examples -> LDS, transposed (fp32: each wave splits its own two)
-    StageRowsF32<KSN> sr;
+    // dpre = relu'(out) * (dout + gs * wout) of the E examples -> LDS, transposed (fp32: each wave splits its own two)
+    StageRowsF32<KSN, E> sr;
     sr.load(tid, [&](int e, int n, int dq) {
       const int b = b0 + e;
       const bool ok = b < p.B && n < p.N;
@@ -418,8 +460,6 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
       return make_float4((ok && o.x > 0.f) ? g.x : 0.f, (ok && o.y > 0.f) ? g.y : 0.f, (ok && o.z > 0.f) ? g.z : 0.f,
                          (ok && o.w > 0.f) ? g.w : 0.f);
     });
-    sw.store(sW, tid);
-    sw1.store(sW + SLOT, tid);
     sx.store(sX0, tid);
     sr.store(sDp, tid);
   }
@@ -438,7 +478,7 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
   bf16x8 w0[NS][KSN], w1[NS][KSN];
 #define CS_READ_WA(ST, W)                                                                                             \
   {                                                                                                                   \
-    const bf16_t* wb_ = sW + (size_t)((ST) & 1) * SLOT + (par * NS * KSN) * 512 + lane * 8;                           \
+    const bf16_t* wb_ = (((ST) & 1) ? sW1 : sW0) + (par * NS * KSN) * 512 + lane * 8;                                 \
     _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_)                                                                 \
       _Pragma("unroll") for (int ks_ = 0; ks_ < KSN; ++ks_)                                                           \
         W[s_][ks_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb_ + (s_ * KSN + ks_) * 512));       \
@@ -449,7 +489,7 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
     const size_t dplane = (size_t)((p.B + 1) / 2) * 2 * p.N16 * CS_D;
 #pragma unroll
     for (int u = 0; u < 2 * KSN; ++u) {
-      const int it = tid + 512 * u;
+      const int it = tid + NTHR * u;
       const int dq = it & 3, n = (it >> 2) % (32 * KSN), e = it / (128 * KSN);
       const int b = b0 + e;
       const float* t = sDp + ((size_t)e * 16 + dq * 4) * NP + n;
@@ -469,8 +509,13 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
       }
     }
   }
-  __syncthreads();                                 // every wave has its operands: sDp may become sP
+  __syncthreads();                                 // every wave has its operands (sDp is free) and slot 0's fragments
+  if constexpr (ALIAS) {
+    GW::issue(wbase, fstride, plane, 2, p.F, tid, sW1);
+    __syncthreads();
+  }
   f32x4 dxk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // (no branch inside a step: across one the staging registers go to scratch)
 #define CS_DX_BODY(ST, W)                                                                                             \
     const int f_ = 2 * (ST) + par;                                                                                    \
     const int fc_ = f_ < CS_FP ? f_ : CS_FP - 1;                                                                      \
@@ -482,16 +527,18 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
       dxk[e][1] = __builtin_fmaf(x, U[1], dxk[e][1]);                                                                 \
       dxk[e][2] = __builtin_fmaf(x, U[2], dxk[e][2]);                                                                 \
       dxk[e][3] = __builtin_fmaf(x, U[3], dxk[e][3]);                                                                 \
-      /* (no branch inside a step: across one the staging registers go to scratch; f_ < CS_FP by the loop bound) */  \
-      sP[(((e0 + e) * CS_FP + fc_) * 4 + kq) * 16 + i] =                                                              \
-          ((U[0] * xkv[e][0] + U[1] * xkv[e][1]) + U[2] * xkv[e][2]) + U[3] * xkv[e][3];                              \
+      float q = ((U[0] * xkv[e][0] + U[1] * xkv[e][1]) + U[2] * xkv[e][2]) + U[3] * xkv[e][3];                       \
+      q += __shfl_xor(q, 16);                                                                                         \
+      q += __shfl_xor(q, 32);                                                                                         \
+      sP[((e0 + e) * CS_FP + fc_) * CS_D + i] = q;   /* (the four lane quarters hold the same sum and store it four times; */ \
+                                                      /*  LDS, not dx0_parts: a global store inside the step sends the      */ \
+                                                      /*  staging registers through scratch memory)                          */ \
     }
 #define CS_DX_STEP(ST, W, WN)                                                                                         \
   {                                                                                                                   \
-    sw.load(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid);                                                         \
+    GW::issue(wbase, fstride, plane, 2 * ((ST) + 2), p.F, tid, ((ST) & 1) ? sW1 : sW0);                               \
     CS_READ_WA((ST) + 1, WN)                                                                                          \
     CS_DX_BODY(ST, W)                                                                                                 \
-    sw.store(sW + (size_t)((ST) & 1) * SLOT, tid);                                                                    \
     __syncthreads();                                                                                                  \
   }
   for (int st = 0; st < nstep; st += 2) {
@@ -501,19 +548,15 @@ __global__ __launch_bounds__(512) void cin_split_dx_k(const CsDxArgs p) {
 #undef CS_DX_BODY
 #undef CS_DX_STEP
 #undef CS_READ_WA
-  // this tile's share of dX0: the four lane-quarter partials of every (example, field, d) in order
-  for (int e4 = tid; e4 < E * p.F * 4; e4 += 512) {
-    const int ex = e4 / (p.F * 4), r = e4 - ex * (p.F * 4);
-    const int f = r >> 2, dq = r & 3;
-    const float4* q = reinterpret_cast<const float4*>(sP + ((ex * CS_FP + f) * 4) * 16) + dq;
-    const float4 s = f4_add(f4_add(f4_add(q[0], q[4]), q[8]), q[12]);
-    if (b0 + ex < p.B) reinterpret_cast<float4*>(p.dx0_parts + ((size_t)ht * p.B + b0 + ex) * p.F * CS_D)[r] = s;
-  }
-  __syncthreads();
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = dxk[e][r];
+  for (int e4 = tid; e4 < E * p.F * 4; e4 += NTHR) {        // this tile's share of dX0 (the last step's barrier published sP)
+    const int ex = e4 / (p.F * 4), r = e4 - ex * (p.F * 4);
+    if (b0 + ex < p.B)
+      reinterpret_cast<float4*>(p.dx0_parts + ((size_t)ht * p.B + b0 + ex) * p.F * CS_D)[r] = reinterpret_cast<const float4*>(sP + ex * CS_FP * CS_D)[r];
+  }
   __syncthreads();
   {   // wave w finishes example w: dXk[b][h = 16 ht + 4 kq + r][d = i] = even fields' share + odd fields' share
     const int ex = wv, b = b0 + ex;
@@ -539,44 +582,49 @@ int opt_in_lds(K kernel, size_t lds) {
   return RSX_OK;
 }
 
-template <int NS, int KS>
+// examples per workgroup: 4 (two independent 256-thread workgroups per CU); RSX_CIN_SPLIT_E=8 for A/B runs
+int cs_examples() {
+  static const int e = getenv("RSX_CIN_SPLIT_E") ? atoi(getenv("RSX_CIN_SPLIT_E")) : 4;
+  return e == 8 ? 8 : 4;
+}
+
+template <int NS, int KS, int E>
 int launch_fwd(const CsFwdArgs& a, hipStream_t stream) {
-  const dim3 grid((unsigned)(a.N16 / 16), (unsigned)((a.B + CS_E - 1) / CS_E));
-  const size_t lds = (size_t)CS_E * CS_FP * CS_D * 4 + (size_t)2 * StageW<NS, KS>::SLOT * 2 + (size_t)CS_E * 16 * (32 * KS + 4) * 4;
-  const int rc = opt_in_lds(cin_split_fwd_k<NS, KS>, lds);
+  const dim3 grid((unsigned)(a.N16 / 16), (unsigned)((a.B + E - 1) / E));
+  const size_t lds = CsLds<NS, KS, E>::TOTAL;
+  const int rc = opt_in_lds(cin_split_fwd_k<NS, KS, E>, lds);
   if (rc != RSX_OK) return rc;
-  RSX_LAUNCH((cin_split_fwd_k<NS, KS>), grid, dim3(512), lds, stream, a);
+  RSX_LAUNCH((cin_split_fwd_k<NS, KS, E>), grid, dim3(64 * E), lds, stream, a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
-template <int NS>
+template <int NS, int E>
 int launch_fwd_ns(const CsFwdArgs& a, hipStream_t stream) {
   switch (a.Hp / 32) {
-    case 1: return launch_fwd<NS, 1>(a, stream);
-    case 2: return launch_fwd<NS, 2>(a, stream);
-    case 3: return launch_fwd<NS, 3>(a, stream);
-    default: return launch_fwd<NS, 4>(a, stream);
+    case 1: return launch_fwd<NS, 1, E>(a, stream);
+    case 2: return launch_fwd<NS, 2, E>(a, stream);
+    case 3: return launch_fwd<NS, 3, E>(a, stream);
+    default: return launch_fwd<NS, 4, E>(a, stream);
   }
 }
 
-template <int NS, int KSN>
+template <int NS, int KSN, int E>
 int launch_dx(const CsDxArgs& a, hipStream_t stream) {
-  const dim3 grid((unsigned)(a.H16 / 16), (unsigned)((a.B + CS_E - 1) / CS_E));
-  const size_t sdp = (size_t)CS_E * 16 * (32 * KSN + 4) * 4, sp = (size_t)CS_E * CS_FP * 64 * 4;
-  const size_t lds = (size_t)CS_E * CS_FP * CS_D * 4 + (size_t)2 * StageW<NS, KSN>::SLOT * 2 + (sdp > sp ? sdp : sp);
-  const int rc = opt_in_lds(cin_split_dx_k<NS, KSN>, lds);
+  const dim3 grid((unsigned)(a.H16 / 16), (unsigned)((a.B + E - 1) / E));
+  const size_t lds = CsLds<NS, KSN, E>::TOTAL + (size_t)E * CS_FP * CS_D * 4;
+  const int rc = opt_in_lds(cin_split_dx_k<NS, KSN, E>, lds);
   if (rc != RSX_OK) return rc;
-  RSX_LAUNCH((cin_split_dx_k<NS, KSN>), grid, dim3(512), lds, stream, a);
+  RSX_LAUNCH((cin_split_dx_k<NS, KSN, E>), grid, dim3(64 * E), lds, stream, a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
-template <int NS>
+template <int NS, int E>
 int launch_dx_ns(const CsDxArgs& a, hipStream_t stream) {
   switch (a.Np / 32) {
-    case 1: return launch_dx<NS, 1>(a, stream);
-    case 2: return launch_dx<NS, 2>(a, stream);
-    case 3: return launch_dx<NS, 3>(a, stream);
-    default: return launch_dx<NS, 4>(a, stream);
+    case 1: return launch_dx<NS, 1, E>(a, stream);
+    case 2: return launch_dx<NS, 2, E>(a, stream);
+    case 3: return launch_dx<NS, 3, E>(a, stream);
+    default: return launch_dx<NS, 4, E>(a, stream);
   }
 }
 
@@ -630,10 +678,17 @@ extern "C" int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w
   const int H16 = rup(H, 16), N16 = rup(N, 16), Hp = rup(H, 32), Np = rup(N, 32);
   const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)ns * F * H16 * Np;
   const CsFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp};
+  if (cs_examples() == 8) {
+    switch (ns) {
+      case 1: return launch_fwd_ns<1, 8>(a, rsx_s(stream));
+      case 2: return launch_fwd_ns<2, 8>(a, rsx_s(stream));
+      default: return launch_fwd_ns<3, 8>(a, rsx_s(stream));
+    }
+  }
   switch (ns) {
-    case 1: return launch_fwd_ns<1>(a, rsx_s(stream));
-    case 2: return launch_fwd_ns<2>(a, rsx_s(stream));
-    default: return launch_fwd_ns<3>(a, rsx_s(stream));
+    case 1: return launch_fwd_ns<1, 4>(a, rsx_s(stream));
+    case 2: return launch_fwd_ns<2, 4>(a, rsx_s(stream));
+    default: return launch_fwd_ns<3, 4>(a, rsx_s(stream));
   }
 }
 
@@ -655,10 +710,17 @@ extern "C" int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void
   float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)ns * ((B + 1) / 2) * 2 * N16 * CS_D * 2);
   const CsDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dx0_parts, static_cast<bf16_t*>(ws),
                    dc_part, acc_dxk, B, F, H, N, H16, N16, Np};
+  if (cs_examples() == 8) {
+    switch (ns) {
+      case 1: return launch_dx_ns<1, 8>(a, rsx_s(stream));
+      case 2: return launch_dx_ns<2, 8>(a, rsx_s(stream));
+      default: return launch_dx_ns<3, 8>(a, rsx_s(stream));
+    }
+  }
   switch (ns) {
-    case 1: return launch_dx_ns<1>(a, rsx_s(stream));
-    case 2: return launch_dx_ns<2>(a, rsx_s(stream));
-    default: return launch_dx_ns<3>(a, rsx_s(stream));
+    case 1: return launch_dx_ns<1, 4>(a, rsx_s(stream));
+    case 2: return launch_dx_ns<2, 4>(a, rsx_s(stream));
+    default: return launch_dx_ns<3, 4>(a, rsx_s(stream));
   }
 }
 
@@ -687,9 +749,10 @@ struct CsDwArgs {
   int njobs;
   const float* X0;        // [B, F, 16]
   int B, F;
+  int x0l;                // the tiles' X0 slabs sit in LDS (B <= 640)
 };
 
-template <int NS, int FT>
+template <int NS, int FT, bool X0L>
 __device__ __forceinline__ void cs_dw_tile(const CsDwArgs& p, const CsDwJob& jb, int local, float4* dw_lds) {
   constexpr int NT = CS_NT;
   float (*red)[FT * NT][256] = reinterpret_cast<float (*)[FT * NT][256]>(dw_lds);
@@ -709,7 +772,7 @@ __device__ __forceinline__ void cs_dw_tile(const CsDwArgs& p, const CsDwJob& jb,
   for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  {                                               // X0[b, f0 + ft, :] -> x0s[(ft * B + b) * 4 + quarter]
+  if constexpr (X0L) {                            // X0[b, f0 + ft, :] -> x0s[(ft * B + b) * 4 + quarter]
     const int n4 = FT * p.B * 4;
     for (int e = tid; e < n4; e += 512) {
       const int qd = e & 3, b = (e >> 2) % p.B, ft = (e >> 2) / p.B;
@@ -744,7 +807,9 @@ __device__ __forceinline__ void cs_dw_tile(const CsDwArgs& p, const CsDwJob& jb,
     const float4 k0 = f4_scale(L.m, L.xk[0]), k1 = f4_scale(L.m, L.xk[1]);
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
-      const float4* x0 = dw_lds + ((size_t)ft * p.B + L.bc) * 4 + (d0 >> 2);
+      const int fx = f0 + ft < p.F ? f0 + ft : p.F - 1;
+      const float4* x0 = X0L ? dw_lds + ((size_t)ft * p.B + L.bc) * 4 + (d0 >> 2)       // (batches whose slab does not fit the LDS
+                             : reinterpret_cast<const float4*>(p.X0 + ((size_t)L.bc * p.F + fx) * CS_D + d0);   //  read X0 from L2)
       bf16x8 a[NS][1];
       {
         bf16x8 t[NS];
@@ -846,8 +911,12 @@ __global__ __launch_bounds__(512) void cin_split_dw_k(const CsDwArgs p) {
     if (k < p.njobs && tile >= p.job[k - 1].tile_end) ji = k;
   const CsDwJob& jb = p.job[ji];
   const int local = tile - (ji ? p.job[ji - 1].tile_end : 0);
-  if (jb.ft == 4) cs_dw_tile<NS, 4>(p, jb, local, dw_lds);
-  else cs_dw_tile<NS, 3>(p, jb, local, dw_lds);
+  if (p.x0l) {
+    if (jb.ft == 4) cs_dw_tile<NS, 4, true>(p, jb, local, dw_lds);
+    else cs_dw_tile<NS, 3, true>(p, jb, local, dw_lds);
+  } else {
+    cs_dw_tile<NS, 3, false>(p, jb, local, dw_lds);
+  }
 }
 
 }  // namespace
@@ -887,7 +956,17 @@ extern "C" int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_
     x0_bytes = xb > x0_bytes ? xb : x0_bytes;
   }
   const size_t red_bytes = (size_t)4 * 4 * CS_NT * 256 * 4;
-  const size_t lds = red_bytes > x0_bytes ? red_bytes : x0_bytes;
+  w.x0l = x0_bytes <= 160 * 1024;
+  if (!w.x0l) {                                   // large batches: three fields per tile everywhere, X0 from L2
+    tiles = 0;
+    for (int k = 0; k < njobs; ++k) {
+      CsDwJob& d = w.job[k];
+      d.ft = 3;
+      tiles += d.gx * d.HT * ((F + 2) / 3);
+      d.tile_end = tiles;
+    }
+  }
+  const size_t lds = (w.x0l && x0_bytes > red_bytes) ? x0_bytes : red_bytes;
   const unsigned grid = (unsigned)tiles + (unsigned)njobs;
 #define RSX_CS_DW(NS_)                                                       \
   {                                                                          \

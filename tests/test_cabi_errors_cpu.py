@@ -209,3 +209,54 @@ def test_round4_entry_points_reject_bad_arguments(L):
     assert L.rsx_din_prepare2_gather(P, P, P, P, 4, 10, 100, 10, P, 0, P, P, None, P, P, None, None, None, gj, 2, 3, None) == EINVAL
     assert L.rsx_din_prepare2_gather(P, P, P, P, 4, 10, 100, 10, P, 0, P, P, None, P, P, None, None, None, None, 2, 1, None) == EINVAL
     assert L.rsx_din_prepare2_gather(P, P, P, P, 4, 10, 100, 10, P, 0, P, P, None, P, P, None, None, None, gj, 2, 1, None) == EINVAL   # empty jobs: no table
+
+
+def test_round5_cin_entry_points_reject_bad_arguments(L):
+    """csrc/cin_split.hip (split operands on the bf16 matrix cores) and csrc/cin_bf16_wide.hip (dX0 as tile partials)."""
+    from recsys_amd import _lib
+    one = lambda v: (C.c_void_p * 1)(v)
+    i1 = lambda v: (C.c_int32 * 1)(v)
+    # sizes
+    assert L.rsx_cin_split_weight_elems(39, 128, 128, 3) == 3 * 2 * 39 * 128 * 128
+    assert L.rsx_cin_split_weight_elems(39, 39, 128, 1) == 39 * 48 * 128 + 39 * 128 * 64       # H padded to 16 / to 32
+    assert L.rsx_cin_split_weight_elems(39, 128, 128, 4) == 0 and L.rsx_cin_split_weight_elems(39, 128, 128, 0) == 0
+    assert L.rsx_cin_split_bwd_workspace_bytes(256, 128, 3) == 3 * 256 * 128 * 16 * 2 + 256 * 128 * 4
+    assert L.rsx_cin_split_bwd_workspace_bytes(7, 20, 2) == 2 * 8 * 32 * 16 * 2 + 7 * 32 * 4   # odd batch: whole example pairs
+    assert L.rsx_cin_bf16_dx0_parts_floats(256, 39, 128) == 8 * 256 * 39 * 16
+    assert L.rsx_cin_bf16_dx0_parts_floats(256, 39, 39) == 3 * 256 * 39 * 16
+    # prep
+    assert L.rsx_cin_split_prep(one(0x1000), one(0x2000), i1(128), i1(128), 1, 39, 4, None) == EINVAL         # ns out of range
+    assert L.rsx_cin_split_prep(one(0x1000), one(0x2000), i1(129), i1(128), 1, 39, 3, None) == EUNSUPPORTED   # H > 128
+    assert L.rsx_cin_split_prep(one(0), one(0x2000), i1(128), i1(128), 1, 39, 3, None) == EINVAL
+    assert L.rsx_cin_split_prep(None, one(0x2000), i1(128), i1(128), 1, 39, 3, None) == EINVAL
+    assert L.rsx_cin_split_prep(one(0x1000), one(0x2000), i1(128), i1(128), 5, 39, 3, None) == EUNSUPPORTED   # > 4 layers
+    # forward
+    assert L.rsx_cin_split_fwd(P, P, P, P, P, 4, 41, 128, 128, 16, 3, None) == EUNSUPPORTED                   # F > 40
+    assert L.rsx_cin_split_fwd(P, P, P, P, P, 4, 39, 128, 128, 8, 3, None) == EUNSUPPORTED                    # D != 16
+    assert L.rsx_cin_split_fwd(P, P, P, P, P, 4, 39, 128, 128, 16, 0, None) == EINVAL                         # ns
+    assert L.rsx_cin_split_fwd(P, P, None, P, P, 4, 39, 128, 128, 16, 3, None) == EINVAL
+    assert L.rsx_cin_split_fwd(None, None, None, None, None, 0, 39, 128, 128, 16, 3, None) == OK              # empty batch
+    # data gradients: dout or the direct-connect pair, never neither
+    assert L.rsx_cin_split_bwd_dx(P, P, P, P, None, None, None, P, 0, P, P, 4, 39, 128, 128, 16, 3, None) == EINVAL
+    assert L.rsx_cin_split_bwd_dx(P, P, P, P, None, P, None, P, 0, P, P, 4, 39, 128, 128, 16, 3, None) == EINVAL      # gs without wout
+    assert L.rsx_cin_split_bwd_dx(P, P, P, P, P, None, None, P, 0, None, P, 4, 39, 128, 128, 16, 3, None) == EINVAL   # no dx0_parts
+    assert L.rsx_cin_split_bwd_dx(P, P, P, P, P, None, None, P, 0, P, P, 4, 39, 128, 130, 16, 3, None) == EUNSUPPORTED
+    assert L.rsx_cin_split_bwd_dx(P, P, P, P, P, None, None, P, 0, P, P, 0, 39, 128, 128, 16, 3, None) == OK
+    assert L.rsx_cin_layer_bwd_dx_bf16_parts(P, P, P, P, None, None, None, P, 0, P, P, 4, 39, 128, 128, 16, None) == EINVAL
+    assert L.rsx_cin_layer_bwd_dx_bf16_parts(P, P, P, P, P, None, None, P, 0, P, P, 4, 41, 128, 128, 16, None) == EUNSUPPORTED
+    # the reduce of the tile partials
+    assert L.rsx_cin_dx0_reduce(one(0x1000), i1(8), 1, None, 0, 4, 39, 16, None) == EINVAL
+    assert L.rsx_cin_dx0_reduce(one(0x1000), i1(0), 1, P, 0, 4, 39, 16, None) == EINVAL                       # a job without tiles
+    assert L.rsx_cin_dx0_reduce(one(0x1000), i1(8), 5, P, 0, 4, 39, 16, None) == EUNSUPPORTED                 # > 4 jobs
+    assert L.rsx_cin_dx0_reduce(one(0x1000), i1(8), 1, P, 0, 0, 39, 16, None) == OK
+    # weight gradients
+    jobs = (_lib.CinDwJob * 1)(_lib.CinDwJob(0x1000, 0x2000, 0x3000, 0x4000, 128, 128, 0))
+    assert L.rsx_cin_split_bwd_dw(P, jobs, 1, 4, 39, 16, 5, None) == EINVAL
+    assert L.rsx_cin_split_bwd_dw(P, jobs, 5, 4, 39, 16, 3, None) == EUNSUPPORTED
+    assert L.rsx_cin_split_bwd_dw(None, jobs, 1, 4, 39, 16, 3, None) == EINVAL
+    assert L.rsx_cin_split_bwd_dw(P, jobs, 1, 0, 39, 16, 3, None) == OK
+    bad = (_lib.CinDwJob * 1)(_lib.CinDwJob(0x1000, 0, 0x3000, 0x4000, 128, 128, 0))
+    assert L.rsx_cin_split_bwd_dw(P, bad, 1, 4, 39, 16, 3, None) == EINVAL                                    # no workspace
+    # the bf16 weight-gradient launch checks the workspace convention it is told
+    j2 = (_lib.CinDwJob * 1)(_lib.CinDwJob(0x1000, 0x2000, 0x3000, 0x4000, 128, 128, 3))
+    assert L.rsx_cin_bwd_dw_bf16(P, j2, 1, 4, 39, 16, None, None) == EINVAL                                   # dc_rows neither 0 nor B

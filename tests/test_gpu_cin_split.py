@@ -78,6 +78,7 @@ BWD_SHAPES = [
     (1, 3, 16, 16, False, True, False),
     (250, 40, 128, 128, False, True, False),
     (19, 38, 72, 96, False, False, True),
+    (700, 39, 32, 16, False, True, False),       # a batch whose X0 slab does not fit the weight-gradient launch's LDS
 ]
 BTOL = {3: 3e-6, 2: 5e-5, 1: 2e-5}
 
