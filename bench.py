@@ -59,7 +59,7 @@ def parse():
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
     p.add_argument("--cin_bf16", action="store_true", help="xdeepfm: CIN contraction on the bf16 MFMA path (fp32 accumulate); the "
                    "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
-    p.add_argument("--cin_split", type=int, default=0, choices=[0, 1, 2, 3],
+    p.add_argument("--cin_split", type=int, default=0, choices=[0, 1, 2, 3, 4],
                    help="xdeepfm: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (csrc/cin_split.hip); 3 = every "
                         "product exact to 2^-23 (fp32-grade: held to the fp32 path's 1e-5 parity tests)")
     p.add_argument("--no_overlap", action="store_true", help="profiling aid: plain path (stand-alone sort, segment-sum, ONE full "
@@ -138,7 +138,8 @@ WORKLOADS = {"deepfm": "Criteo-39 d=16 DNN 100-100", "fm": "Criteo-39 d=16", "dc
 DOMINANT = {"deepfm": "segsum_adam_k (scatter + touched-row Adam; latency-bound) / adam_window_k per window",
             "fm": "segsum_adam_k / adam_window_k per window", "dcn": "tower_bwd_k<true> (fp32 MFMA dW/dX tiles at bs 4096)",
             "xdeepfm": "cin_bwd_dw_k / cin_bwd_dx2_k (fp32 MFMA)", "xdeepfm_bf16": "cin_bwd_dw_bf16_k (bf16 MFMA)",
-            "xdeepfm_x3": "cin_split_dw_k<3> / cin_split_dx_k<3,4> (bf16 MFMA, 3 planes per operand)",
+            "xdeepfm_x3": "cin_split_dw_k<3> / cin_split_dx8_k<3,4> (bf16 MFMA, 3 planes per operand)",
+            "xdeepfm_x4": "cin_split_dw_k<3> (3 bf16 planes) / cin_split_dx8_k<4,4> (2 fp16 planes per operand)",
             "din": "din_attn_bwd_k (fp32 MFMA attention MLP backward)"}
 
 
@@ -170,9 +171,11 @@ def cin_mode(cin_bf16, cin_split=0):
 CIN_DTYPE = {False: "f32", True: "bf16 CIN operands / f32 accumulate, f32 elsewhere",
              "x1": "bf16 CIN operands (1 plane) / f32 accumulate, f32 elsewhere",
              "x2": "f32; CIN products as 2 bf16 planes per operand on the bf16 MFMA (3 MFMAs per k-step, 2^-16-grade), f32 accumulate",
-             "x3": "f32; CIN products as 3 bf16 planes per operand on the bf16 MFMA (6 MFMAs per k-step, exact to 2^-23: fp32-grade), f32 accumulate"}
-CIN_TAG = {False: "", True: " --cin_bf16", "x1": " --cin_split 1", "x2": " --cin_split 2", "x3": " --cin_split 3"}
-CIN_KEY = {False: "", True: "_bf16", "x1": "_x1", "x2": "_x2", "x3": "_x3"}
+             "x3": "f32; CIN products as 3 bf16 planes per operand on the bf16 MFMA (6 MFMAs per k-step, exact to 2^-23: fp32-grade), f32 accumulate",
+             "x4": "f32; CIN forward / data-gradient products as 2 scaled fp16 planes per operand on the fp16 MFMA (3 MFMAs per k-step, "
+                   "2^-22-grade: held to the fp32 path's tolerances), weight gradients as 3 bf16 planes, f32 accumulate"}
+CIN_TAG = {False: "", True: " --cin_bf16", "x1": " --cin_split 1", "x2": " --cin_split 2", "x3": " --cin_split 3", "x4": " --cin_split 4"}
+CIN_KEY = {False: "", True: "_bf16", "x1": "_x1", "x2": "_x2", "x3": "_x3", "x4": "_x4"}
 
 
 def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
@@ -184,7 +187,8 @@ def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
            "moved_bytes_per_step": int(moved), "tf1_equivalent_bytes_per_step": int(alg)}
     if model == "xdeepfm":
         flops = 3 * 2 * B * 16 * (39 * 39 * 128 + 39 * 128 * 128)          # fwd x 3 with backward
-        terms = {"x1": 1, "x2": 3, "x3": 6}.get(cin_bf16, 1)              # bf16 MFMAs issued per algorithmic k-step
+        # 16-bit MFMAs issued per algorithmic k-step (x4: 3 in the forward and the data gradients, 6 in the weight gradients)
+        terms = {"x1": 1, "x2": 3, "x3": 6, "x4": 4}.get(cin_bf16, 1)
         peak = 2.5e15 if cin_bf16 else 157.3e12
         out["cin_mfma_step_frac"] = round(terms * flops / (ms_per_step * 1e-3) / peak, 4)
         out["cin_flops_per_step"] = flops
@@ -312,7 +316,7 @@ def other_configs(a, rank, dev):
     that includes every graph capture (median repeat)."""
     import gc
     out = []
-    for model, bf16 in (("fm", False), ("dcn", False), ("xdeepfm", False), ("xdeepfm", "x3"), ("xdeepfm", True), ("din", False)):
+    for model, bf16 in (("fm", False), ("dcn", False), ("xdeepfm", False), ("xdeepfm", "x3"), ("xdeepfm", "x4"), ("xdeepfm", True), ("din", False)):
         if model == a.model and bf16 == cin_mode(a.cin_bf16, a.cin_split):
             continue
         steps = a.config_steps if model != "din" else max(64, a.config_steps // 2)

@@ -927,7 +927,10 @@ int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const i
  * An fp32 value is the exact sum of three bf16 values; ns planes of every contraction operand are kept and the products
  * of planes i, j with i + j <= ns + 1 are accumulated (fp32) by v_mfma_f32_16x16x32_bf16:
  *   ns = 3: 6 MFMAs per k-step, every product exact to 2^-23 of itself -- fp32-grade, the parity path on the bf16 cores;
- *   ns = 2: 3 MFMAs, 2^-16-grade;  ns = 1: 1 MFMA, plain bf16 operands (the arithmetic of rsx_cin_layer_fwd_bf16).
+ *   ns = 2: 3 MFMAs, 2^-16-grade;  ns = 1: 1 MFMA, plain bf16 operands (the arithmetic of rsx_cin_layer_fwd_bf16);
+ *   ns = 4: forward and data gradients with TWO fp16 planes per operand (v_mfma_f32_16x16x32_f16, 3 MFMAs per k-step); the
+ *           operand of every accumulation chain is scaled by a power of two (per example / per field, divided out in fp32),
+ *           products to 2^-22 -- held to the tolerances of ns = 3; the weight gradients run on three bf16 planes.
  * Same contract as rsx_cin_layer_fwd / rsx_cin_layer_bwd otherwise (X0 scaling, bias, relu and every sum in fp32).
  *   rsx_cin_split_prep  W fp32 [F*H, N] of L layers -> w16_h[k] (rsx_cin_split_weight_elems 16-bit elements each)
  * F <= 40, H, N <= 128, D = 16; RSX_EUNSUPPORTED otherwise.                                                          */

@@ -106,7 +106,7 @@ __device__ __forceinline__ f32x4 split_mma_ba(const bf16x8 (&a)[NS][KS], const b
 // Fragment-major bf16 images, NS planes each (plane stride = the image size):
 //   W16  [NS][F][H16/16][Np/32][64][8]: element j of lane (i, kq) = W[f][h = 16 ht + i][n = 32 ks + 8 kq + j]   (A of dX)
 //   Wt16 [NS][F][N16/16][Hp/32][64][8]: element j of lane (i, kq) = W[f][h = 32 ks + 8 kq + j][n = 16 nt + i]   (B of fwd)
-struct CsPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; int H, N, H16, N16, Hp, Np; long long end; };
+struct CsPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; float* winv; int H, N, H16, N16, Hp, Np; long long end; };
 struct CsPrepArgs { CsPrepJob job[CS_MAXJ]; int njobs, F; };
 template <int NS>
 __global__ __launch_bounds__(256) void cin_split_prep_k(const CsPrepArgs p) {
@@ -271,6 +271,7 @@ struct CsFwdArgs {
   const float* c;       // [N]
   float* out;           // [B, N, 16]
   int B, F, H, N, N16, Hp;
+  const float* winv;    // [F] inverse scales of the filter planes (mode 4)
 };
 
 // grid = (N16 / 16, ceil(B / E)), block = 64 E (E = 4: two workgroups per CU, their barriers independent -- one's MFMAs cover
@@ -382,6 +383,365 @@ __global__ __launch_bounds__(64 * E, E == 4 ? 2 : 1) void cin_split_fwd_k(const 
   }
 }
 
+// ------------------------------------------------------------------------ deep-ring kernels (the default): forward, dXk / dX0
+// What bounded cin_split_fwd_k / cin_split_dx_k (profiles/r05_y_cin_split_where.txt: 18 us with every MFMA replaced by one VALU
+// op, 12.8 us of MFMA issue at 2.4 GHz, 29 us together):
+//   * the compiler cannot tell an LDS-DMA's destination from the slot a ds_read reads and puts `s_waitcnt vmcnt(0)` in front of
+//     the first LDS read after every DMA issue: the prefetch distance of the ring was never more than the rest of ONE step;
+//   * the whole-step register double buffer (96 VGPRs of filter fragments) did not survive register allocation: the reads were
+//     sunk to their uses, every few MFMAs waited for an LDS read issued just before them;
+//   * the DMA addresses cost ~60 VALU instructions per step (64-bit multiplies of clamped field numbers) between dependent MFMAs;
+//   * and the clock under this load is 2.0 GHz (SQ_BUSY_CYCLES / 32 shader engines / duration), not 2.4: 15.4 us of MFMA issue.
+// Here: ONE workgroup of 8 waves per CU and 8 examples (a fragment is read from L2 once per 8 examples), a ring of R = 5..8
+// slots, the DMA issued from inline assembly (invisible to the compiler's LDS alias check; addresses = SGPR base + lane * 16, all
+// scalar), the step's barrier waits for `vmcnt((R - 3) U)` -- a piece has R - 2 whole steps to land -- and the filter fragments go
+// through a ring of PF <= 6 register quads, each requested PF - 2 fragments ahead of its use (the next step's first ones before
+// the barrier).  A fragment's MFMAs go to one accumulator per (example, magnitude level): 2 NS independent chains; the levels
+// are added smallest first at the end of the step.  Stamps + probe builds (scripts/stamp_probe_cin_split.py): the field loop is
+// MFMA issue now -- without DMA, barrier or fragment reads it is 4-14 % shorter, without the MFMAs half.
+//
+// MODE 4 ("h2"): the same contraction with TWO fp16 planes per operand (x = x1 + x2, 11 + 11 significand bits; the operand of
+// one accumulation chain is scaled by a power of two so that its largest element sits at 2^14: per example for Xk / dpre, per
+// field for the filters, the scales divided out in fp32 after the chain) and the three products x1y1 + x1y2 + x2y1 -- HALF the
+// MFMAs of the three-plane bf16 form.  What it drops (x2y2, the planes' own rounding) is below 2^-22 of a product for every
+// element within 2^17 of its chain's largest and 2^-39 of the largest product below that: 6e-8 of the layer's output in the
+// tests, under the fp32 accumulation's own 2e-6.  The weight gradients stay on three bf16 planes (their chain runs over the
+// batch: no per-example scale can be divided out).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int CS_H2 = 4;
+
+template <int MODE>
+struct SplitMode {                                   // MODE = 1..3: bf16 planes
+  static constexpr int NS = MODE;
+  static constexpr bool SCALED = false;
+  typedef bf16x8 quad;
+  static __device__ __forceinline__ f32x4 mma(quad a, quad b, f32x4 c) { return mfma_bf16(a, b, c); }
+  static __device__ __forceinline__ void split(float4 a, float4 b, quad (&out)[NS]) { split8<NS>(a, b, out); }
+};
+template <>
+struct SplitMode<CS_H2> {
+  static constexpr int NS = 2;
+  static constexpr bool SCALED = true;
+  typedef f16x8 quad;
+  static __device__ __forceinline__ f32x4 mma(quad a, quad b, f32x4 c) {
+#ifdef RSX_CIN_H2_AS_BF16      // (probe builds only, WRONG results: is the fp16 MFMA itself slower than the bf16 one under load?)
+    return mfma_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+  }
+  static __device__ __forceinline__ void split2h(float lo, float hi, uint32_t (&out)[2]) {
+    f16x2 p, q;
+    p[0] = (_Float16)lo;
+    p[1] = (_Float16)hi;
+    q[0] = (_Float16)(lo - (float)p[0]);
+    q[1] = (_Float16)(hi - (float)p[1]);
+    out[0] = __builtin_bit_cast(uint32_t, p);
+    out[1] = __builtin_bit_cast(uint32_t, q);
+  }
+  static __device__ __forceinline__ void split(float4 a, float4 b, quad (&out)[2]) {
+    uint32_t p0[2], p1[2], p2[2], p3[2];
+    split2h(a.x, a.y, p0);
+    split2h(a.z, a.w, p1);
+    split2h(b.x, b.y, p2);
+    split2h(b.z, b.w, p3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) out[s] = __builtin_bit_cast(f16x8, (u32x4){p0[s], p1[s], p2[s], p3[s]});
+  }
+};
+// power-of-two scale that puts `mx` (>= 0) into [2^14, 2^15), and its inverse
+__device__ __forceinline__ void cs_pow2_scale(float mx, float& scale, float& inv) {
+  int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  e = e < 16 ? 16 : (e > 254 ? 254 : e);
+  scale = __uint_as_float((uint32_t)(268 - e) << 23);
+  inv = __uint_as_float((uint32_t)(e - 14) << 23);
+}
+__device__ __forceinline__ float cs_wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+__device__ __forceinline__ void cs_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  // (M0 = wave-uniform LDS byte address of the piece; the hardware adds lane * 16.  The base goes through readfirstlane: an "s"
+  // operand the compiler could not prove uniform is handed over in VGPRs, which the instruction's SGPR-base form rejects)
+  const uint64_t b = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t bs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(bs),
+               "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void cs_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+
+template <int NS, int KS, int EXTRA>
+struct Cs8 {
+  static constexpr int E = 8, NTHR = 512;
+  static constexpr int FR = NS * KS;                          // fragments of one field
+  static constexpr int FRAGS = 2 * FR;                        // of one step (two fields)
+  static constexpr int U = (FRAGS + 7) / 8;                   // DMA pieces per wave and step
+  static constexpr int SLOTB = U * 8 * 1024;                  // bytes per ring slot (padded to whole rounds of the 8 waves)
+  static constexpr int X0B = E * CS_FP * CS_D * 4;
+  static constexpr int RMAX = (160 * 1024 - X0B - EXTRA) / SLOTB;
+  static constexpr int R = RMAX > 8 ? 8 : RMAX;
+  // register ring of filter fragments: the largest divisor of FR up to 6 (FR % PF == 0: a fragment's quad is the same every step)
+  static constexpr int PF = FR % 6 == 0 ? 6 : (FR % 4 == 0 ? 4 : (FR % 3 == 0 ? 3 : (FR % 2 == 0 ? 2 : 1)));
+  static constexpr int VM = (R - 3) * U;                      // pieces that may still be in flight at a step's barrier
+  static constexpr size_t TOTAL = (size_t)X0B + (size_t)R * SLOTB + EXTRA;
+  static_assert(R >= 3, "the ring needs three slots");
+  static_assert(VM <= 63, "vmcnt is a 6-bit counter");
+  // the pieces of step `stn` into ring slot `sl`: wave wv takes fragments wv, wv + 8, ... (clamped: the slot's padding)
+  static __device__ __forceinline__ void issue(const char* img, uint32_t fstrideB, uint32_t planeB, int stn, int F, int wv,
+                                               uint32_t lane16, uint32_t slot_lds) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int fi = wv + 8 * u;
+      const int fr = fi < FRAGS ? fi : FRAGS - 1;
+      const int ks = fr % KS, sp = (fr / KS) % NS, par = fr / FR;
+      const int f = 2 * stn + par < F ? 2 * stn + par : F - 1;          // (a field past F: its X0 is zero)
+      cs_dma16(img + (size_t)sp * planeB + (size_t)f * fstrideB + (size_t)ks * 1024, lane16, slot_lds + (uint32_t)fi * 1024u);
+    }
+  }
+};
+
+// One step's MFMAs of a wave: the FR fragments of its field (ring slot `cur`, from the register ring w) against the split
+// operands of its two examples, T[e][level] += ...; WA: the filter fragment is the MFMA's first operand (data gradients).
+template <int MODE, int KS, int PF, bool WA>
+__device__ __forceinline__ void cs8_step_mma(const typename SplitMode<MODE>::quad (&a)[2][SplitMode<MODE>::NS][KS],
+                                             typename SplitMode<MODE>::quad (&w)[PF], const char* cur, const char* nxt,
+                                             f32x4 (&T)[2][SplitMode<MODE>::NS]) {
+  using M = SplitMode<MODE>;
+  constexpr int NS = M::NS, FR = NS * KS;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int l = 0; l < NS; ++l) T[e][l] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // (the scheduling fences keep the reads where they are written: left alone, the compiler sinks every LDS read to its first use)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < FR; ++j) {                   // fragment j = (k-step j / NS, plane j % NS) sits in register quad j % PF
+    const int ks = j / NS, s = j % NS;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int sa = 0; sa + s < NS; ++sa) {
+#if RSX_CIN_DBG == 1
+        T[e][s + sa][0] = __builtin_fmaf(__builtin_bit_cast(f32x4, a[e][sa][ks])[0], __builtin_bit_cast(f32x4, w[j % PF])[0], T[e][s + sa][0]);
+#else
+        T[e][s + sa] = WA ? M::mma(w[j % PF], a[e][sa][ks], T[e][s + sa]) : M::mma(a[e][sa][ks], w[j % PF], T[e][s + sa]);
+#endif
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // the quad of fragment j - 1 (its MFMAs were issued a fragment ago) takes fragment j - 1 + PF: of this step, or the next one's
+    constexpr int LAG = PF >= 2 ? 1 : 0;           // (a single quad is refilled straight after its use)
+    const int jn = j - LAG + PF;
+    const int jj = jn < FR ? jn : jn - FR;
+    const char* src = (jn < FR ? cur : nxt) + ((jj % NS) * KS + jj / NS) * 1024;
+#if RSX_CIN_DBG != 4
+    w[jn % PF] = __builtin_bit_cast(typename M::quad, *reinterpret_cast<const uint4*>(src));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+#if RSX_CIN_DBG == 2
+#define CS8_STEP_BARRIER(C8) cs_wait_barrier<0>()
+#elif RSX_CIN_DBG == 3
+#define CS8_STEP_BARRIER(C8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define CS8_STEP_BARRIER(C8) cs_wait_barrier<C8::VM>()
+#endif
+
+// grid = (N16 / 16, ceil(B / 8)), block = 512, dyn LDS = Cs8<NS, KS, SCALED ? 256 : 0>::TOTAL: sX0 [8][CS_FP * 16] f32 | R ring slots | the
+// filters' inverse scales [CS_FP] (MODE 4)
+template <int MODE, int KS>
+__global__ __launch_bounds__(512, 1) void cin_split_fwd8_k(const CsFwdArgs p) {
+  using M = SplitMode<MODE>;
+  constexpr int NS = M::NS;
+  using C8 = Cs8<NS, KS, M::SCALED ? 256 : 0>;
+  constexpr int E = 8, R = C8::R, PF = C8::PF, FR = C8::FR, SLOTB = C8::SLOTB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sX0 = lds;
+  char* ring = reinterpret_cast<char*>(lds) + C8::X0B;
+  float* sInv = reinterpret_cast<float*>(ring + (size_t)R * SLOTB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int par = wv & 1, e0 = (wv >> 1) * 2;
+  const int n0 = blockIdx.x * 16, b0 = blockIdx.y * E;
+  const uint32_t fstrideB = (uint32_t)p.N16 * p.Hp * 2u, planeB = (uint32_t)p.F * fstrideB;
+  const char* img = reinterpret_cast<const char*>(p.Wt16) + (size_t)blockIdx.x * KS * 1024;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, lane16 = (uint32_t)lane * 16u;
+  const int nstep = (p.F + 1) / 2;
+  const bool st0 = KS == 4 && blockIdx.x == 0 && blockIdx.y == 0;
+  RSX_STAMP(0, st0); RSX_STAMP_MAX(16, KS == 4);
+#pragma unroll
+  for (int s = 0; s < R - 1; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
+  StageX0<E> sx;
+  sx.load(p.X0, b0, p.B, p.F, tid);
+  if (M::SCALED && tid < CS_FP) sInv[tid] = tid < p.F ? p.winv[tid] : 0.f;
+  typename M::quad a[2][NS][KS];                   // Xk[b0 + e0 + e][h = 32 ks + 8 kq + j][d = i], split; straight from L2
+  float inv_x[2] = {1.f, 1.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int b = b0 + e0 + e;
+    const float* xb = p.Xk + (size_t)(b < p.B ? b : p.B - 1) * p.H * CS_D + i;
+    const float bm = b < p.B ? 1.f : 0.f;
+    float v[KS][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = 32 * ks + 8 * kq + j;
+        v[ks][j] = xb[(size_t)(h < p.H ? h : p.H - 1) * CS_D];
+      }
+    // (every load requested before the first use: with the masks and the maximum folded into the load loop the scheduler kept
+    // the source order -- load, wait, multiply -- and the prologue cost 15 us)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[ks][j] *= (32 * ks + 8 * kq + j) < p.H ? bm : 0.f;
+        if (M::SCALED) mx = fmaxf(mx, fabsf(v[ks][j]));
+      }
+    float sc = 1.f;
+    if (M::SCALED) cs_pow2_scale(cs_wave_max(mx), sc, inv_x[e]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      typename M::quad t[NS];
+      M::split(make_float4(v[ks][0] * sc, v[ks][1] * sc, v[ks][2] * sc, v[ks][3] * sc),
+               make_float4(v[ks][4] * sc, v[ks][5] * sc, v[ks][6] * sc, v[ks][7] * sc), t);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) a[e][s][ks] = t[s];
+    }
+  }
+  RSX_STAMP(1, st0);
+  sx.store(sX0, tid);
+  cs_wait_barrier<0>();                            // sX0 and the first R - 1 slots
+  RSX_STAMP(2, st0);
+  const char* rd = ring + (size_t)par * FR * 1024 + lane16;      // this wave's fragments of slot 0
+  typename M::quad w[PF];                          // at a step's entry: its fragments 0 .. PF - 2 (requested during the step before)
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    w[j] = __builtin_bit_cast(typename M::quad, *reinterpret_cast<const uint4*>(rd + ((j % NS) * KS + j / NS) * 1024));
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  int sl = 0;                                      // ring slot of the current step
+  for (int st = 0; st < nstep; ++st) {
+    const int sln = sl + 1 == R ? 0 : sl + 1, slp = sl == 0 ? R - 1 : sl - 1;
+    const int stn = st + R - 1 < nstep ? st + R - 1 : nstep - 1;
+    CS_DBG_LOAD(C8::issue(img, fstrideB, planeB, stn, p.F, wv, lane16, ring_lds + slp * SLOTB);)      // (slot of step st - 1: free since its barrier)
+    const int f_ = 2 * st + par;
+    float4 x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) x[e] = *reinterpret_cast<const float4*>(sX0 + ((e0 + e) * CS_FP + f_) * CS_D + kq * 4);
+    const float wi = M::SCALED ? sInv[f_] : 1.f;
+    f32x4 T[2][NS];
+    cs8_step_mma<MODE, KS, PF, false>(a, w, rd + (size_t)sl * SLOTB, rd + (size_t)sln * SLOTB, T);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      f32x4 t = T[e][NS - 1];
+#pragma unroll
+      for (int l = NS - 2; l >= 0; --l) t += T[e][l];
+      if (M::SCALED) x[e] = f4_scale(wi * inv_x[e], x[e]);
+      acc[e][0] = __builtin_fmaf(x[e].x, t[0], acc[e][0]);
+      acc[e][1] = __builtin_fmaf(x[e].y, t[1], acc[e][1]);
+      acc[e][2] = __builtin_fmaf(x[e].z, t[2], acc[e][2]);
+      acc[e][3] = __builtin_fmaf(x[e].w, t[3], acc[e][3]);
+    }
+    CS8_STEP_BARRIER(C8);
+    sl = sln;
+  }
+  RSX_STAMP(3, st0);
+  cs_wait_barrier<0>();                            // the tail's redundant pieces have landed: the ring is free
+  RSX_STAMP(4, st0);
+  float* sR = reinterpret_cast<float*>(ring);      // [8 waves][2][4][64]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = acc[e][r];
+  __syncthreads();
+  {   // wave w finishes example w: even fields' sum + odd fields' sum + bias, relu
+    const int ex = wv, b = b0 + ex;
+    const int w0i = (ex >> 1) * 2, sl2 = ex & 1;
+    const bool nok = n0 + i < p.N;
+    const float cv = p.c[nok ? n0 + i : 0];
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      o[r] = fmaxf((sR[((w0i * 2 + sl2) * 4 + r) * 64 + lane] + sR[(((w0i + 1) * 2 + sl2) * 4 + r) * 64 + lane]) + cv, 0.f);
+    if (nok && b < p.B)
+      *reinterpret_cast<float4*>(p.out + ((size_t)b * p.N + n0 + i) * CS_D + kq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  RSX_STAMP(5, st0); RSX_STAMP_MAX(17, KS == 4);
+}
+
+// Filter images of mode 4: CS_H2_PARTS workgroups per (layer, field) -- the field's largest |W| (a power-of-two scale puts it at 2^14; its
+// inverse goes to winv[f]), then both fragment-major images of the field as two fp16 planes of W * scale.
+constexpr int CS_H2_PARTS = 4;                     // workgroups per (layer, field): each finds the field's maximum, converts a quarter
+__global__ __launch_bounds__(256) void cin_split_prep_h2_k(const CsPrepArgs p) {
+  __shared__ float red[4];
+  const int part = (int)blockIdx.x % CS_H2_PARTS, lf = (int)blockIdx.x / CS_H2_PARTS;
+  const int ji = lf / p.F, f = lf % p.F;
+  const CsPrepJob& jb = p.job[ji];
+  const int tid = threadIdx.x;
+  const float* Wf = jb.W + (size_t)f * jb.H * jb.N;
+  const int tot = jb.H * jb.N;
+  float mx = 0.f;
+  for (int e0 = tid; e0 < tot; e0 += 256 * 16) {   // 16 loads in flight per thread
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = Wf[e0 + 256 * u < tot ? e0 + 256 * u : tot - 1];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) mx = fmaxf(mx, fabsf(t[u]));
+  }
+  mx = cs_wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sc, inv;
+  cs_pow2_scale(mx, sc, inv);
+  if (tid == 0 && part == 0) jb.winv[f] = inv;
+  const int n1 = (jb.H16 * jb.Np) >> 3, n2 = (jb.N16 * jb.Hp) >> 3;       // quads of this field in the two layouts
+  const size_t pl1 = ((size_t)p.F * jb.H16 * jb.Np), pl2 = ((size_t)p.F * jb.N16 * jb.Hp);
+  for (int q = part * 256 + tid; q < n1 + n2; q += 256 * CS_H2_PARTS) {
+    const bool first = q < n1;
+    const int lq = first ? q : q - n1;
+    const int lane = lq & 63;
+    int r = lq >> 6;
+    const int KS = first ? jb.Np >> 5 : jb.Hp >> 5;
+    const int ks = r % KS, t = r / KS;
+    float v[8];
+    if (first) {                                   // W16: h = 16 t + (lane & 15), n = 32 ks + 8 (lane >> 4) + j
+      const int h = 16 * t + (lane & 15), n0 = 32 * ks + 8 * (lane >> 4);
+      const float* src = Wf + (size_t)(h < jb.H ? h : jb.H - 1) * jb.N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = n0 + j;
+        v[j] = src[n < jb.N ? n : jb.N - 1] * ((h < jb.H && n < jb.N) ? sc : 0.f);
+      }
+    } else {                                       // Wt16: n = 16 t + (lane & 15), h = 32 ks + 8 (lane >> 4) + j
+      const int n = 16 * t + (lane & 15), h0 = 32 * ks + 8 * (lane >> 4);
+      const float* src = Wf + (n < jb.N ? n : jb.N - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = h0 + j;
+        v[j] = src[(size_t)(h < jb.H ? h : jb.H - 1) * jb.N] * ((h < jb.H && n < jb.N) ? sc : 0.f);
+      }
+    }
+    f16x8 o[2];
+    SplitMode<CS_H2>::split(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), o);
+    const size_t fq = first ? (size_t)f * n1 + lq : (size_t)f * n2 + lq;     // quad index inside a plane of the layout
+    bf16_t* dst = (first ? jb.W16 : jb.Wt16) + fq * 8;
+    const size_t plane = first ? pl1 : pl2;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<f16x8*>(dst + (size_t)s2 * plane) = o[s2];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dXk, dX0
 struct CsDxArgs {
   const float* X0;      // [B, F, 16]
@@ -397,6 +757,8 @@ struct CsDxArgs {
   float* dc_part;       // [B][N16] out (workgroups of tile 0): per-example column sums of dpre
   int acc_dxk;
   int B, F, H, N, H16, N16, Np;
+  const float* winv;    // [F] inverse scales of the filter planes (mode 4)
+  int dw_planes;        // bf16 planes of dpre16 (what the weight-gradient launch multiplies)
 };
 
 // grid = (H16 / 16, ceil(B / E)), block = 64 E: workgroup = E examples x the 16 inputs h of tile blockIdx.x; waves as in the
@@ -573,6 +935,217 @@ __global__ __launch_bounds__(64 * E, E == 4 ? 2 : 1) void cin_split_dx_k(const C
   }
 }
 
+// ------------------------------------------------------------------------------------ backward dXk / dX0, deep ring (default)
+// grid = (H16 / 16, ceil(B / 8)), block = 512: workgroup = 8 examples x the 16 inputs h of tile blockIdx.x, waves = (field
+// parity, example pair) and the ring / register pipeline of cin_split_fwd8_k.  U_f^T[h, d] = sum_n W_f[h, n] dpre[b, n, d]:
+// A = W16 fragments, B = dpre[b]^T of the wave's two examples, formed from out / dout / gs * wout straight from L2 and split.
+// dyn LDS = Cs8<NS, KSN, 20480 + 256>::TOTAL: sX0 | ring | sP [8][CS_FP][16] (this tile's dX0) | inverse filter scales.
+template <int MODE, int KSN>
+__global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
+  using M = SplitMode<MODE>;
+  constexpr int NS = M::NS;
+  constexpr int PB = 8 * CS_FP * CS_D * 4;
+  using C8 = Cs8<NS, KSN, PB + (M::SCALED ? 256 : 0)>;
+  constexpr int E = 8, R = C8::R, PF = C8::PF, FR = C8::FR, SLOTB = C8::SLOTB, NTHR = 512;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sX0 = lds;
+  char* ring = reinterpret_cast<char*>(lds) + C8::X0B;
+  float* sP = reinterpret_cast<float*>(ring + (size_t)R * SLOTB);
+  float* sInv = sP + E * CS_FP * CS_D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int par = wv & 1, e0 = (wv >> 1) * 2;
+  const int ht = blockIdx.x, b0 = blockIdx.y * E;
+  const uint32_t fstrideB = (uint32_t)p.H16 * p.Np * 2u, planeB = (uint32_t)p.F * fstrideB;
+  const char* img = reinterpret_cast<const char*>(p.W16) + (size_t)ht * KSN * 1024;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, lane16 = (uint32_t)lane * 16u;
+  const int nstep = (p.F + 1) / 2;
+  const bool st0 = KSN == 4 && blockIdx.x == 1 && blockIdx.y == 0;
+  RSX_STAMP(32, st0); RSX_STAMP_MAX(48, KSN == 4);
+  const float* dsrc = p.dout ? p.dout : p.out;     // (absent operands read `out` and count zero: no branches around loads)
+  const float* gsrc = p.gs ? p.gs : p.out;
+  const float* wsrc = p.gs ? p.wout : p.out;
+  const float dmul = p.dout ? 1.f : 0.f, gmul = p.gs ? 1.f : 0.f;
+  StageX0<E> sx;
+  sx.load(p.X0, b0, p.B, p.F, tid);
+  if (M::SCALED && tid < CS_FP) sInv[tid] = tid < p.F ? p.winv[tid] : 0.f;
+  float xkv[2][4];                                 // Xk[b0 + e0 + e][h = 16 ht + 4 kq + r][d = i]
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int b = b0 + e0 + e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 16 * ht + 4 * kq + r;
+      xkv[e][r] = p.Xk[((size_t)(b < p.B ? b : p.B - 1) * p.H + (h < p.H ? h : p.H - 1)) * CS_D + i] * ((b < p.B && h < p.H) ? 1.f : 0.f);
+    }
+  }
+  typename M::quad bd[2][NS][KSN];                 // dpre[b0 + e0 + e][n = 32 ks + 8 kq + j][d = i], split
+  float inv_d[2] = {1.f, 1.f};
+  {
+    // dpre = relu'(out) * (dout + gs * wout) of the wave's two examples: whole rows by coalesced float4 loads (32 KSN per lane,
+    // all requested together), transposed through 8 KiB of LDS per wave (the ring's first 64 KiB: the filter DMA starts after
+    // this block), lane (i, kq) then picks rows n = 32 ks + 8 kq + j of column d = i.  (Fetching the 64 elements per lane straight
+    // from L2 cost 6-10 us: 4-byte accesses to 64-byte row pieces, re-read by the 8 tiles' workgroups.)
+    float* scr = reinterpret_cast<float*>(ring) + (size_t)wv * (128 * CS_D);
+    float4 o4[2][2 * KSN], g4[2][2 * KSN];
+    float wo[2 * KSN], gbv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int b = b0 + e0 + e;
+      const int bc = b < p.B ? b : p.B - 1;
+      gbv[e] = gsrc[bc];
+#pragma unroll
+      for (int u = 0; u < 2 * KSN; ++u) {
+        const int it = lane + 64 * u, n = it >> 2, dq = it & 3;
+        const size_t at = ((size_t)bc * p.N + (n < p.N ? n : p.N - 1)) * 4 + dq;
+        o4[e][u] = reinterpret_cast<const float4*>(p.out)[at];
+        g4[e][u] = reinterpret_cast<const float4*>(dsrc)[at];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * KSN; ++u) {
+      const int n = (lane + 64 * u) >> 2;
+      wo[u] = wsrc[n < p.N ? n : p.N - 1] * gmul;
+    }
+    __builtin_amdgcn_sched_barrier(0);             // (every load requested before the first use)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int b = b0 + e0 + e;
+#pragma unroll
+      for (int u = 0; u < 2 * KSN; ++u) {
+        const int it = lane + 64 * u, n = it >> 2;
+        const float m = (b < p.B && n < p.N) ? 1.f : 0.f;
+        const float a = gbv[e] * wo[u];
+        const float4 o = o4[e][u], g = g4[e][u];
+        reinterpret_cast<float4*>(scr)[it] = make_float4((o.x > 0.f ? g.x * dmul + a : 0.f) * m, (o.y > 0.f ? g.y * dmul + a : 0.f) * m,
+                                                         (o.z > 0.f ? g.z * dmul + a : 0.f) * m, (o.w > 0.f ? g.w * dmul + a : 0.f) * m);
+      }
+      float v[KSN][8];
+      float mx = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[ks][j] = scr[(32 * ks + 8 * kq + j) * CS_D + i];
+          if (M::SCALED) mx = fmaxf(mx, fabsf(v[ks][j]));
+        }
+      float sc = 1.f;
+      if (M::SCALED) cs_pow2_scale(cs_wave_max(mx), sc, inv_d[e]);
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks) {
+        typename M::quad t[NS];
+        M::split(make_float4(v[ks][0] * sc, v[ks][1] * sc, v[ks][2] * sc, v[ks][3] * sc),
+                 make_float4(v[ks][4] * sc, v[ks][5] * sc, v[ks][6] * sc, v[ks][7] * sc), t);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bd[e][s][ks] = t[s];
+      }
+    }
+  }
+  if (ht == 0) {   // (workgroup-uniform) the weight-gradient launch's operands (THREE bf16 planes in every mode) and the bias
+                   // gradient's per-example partials: item = (example, row n, quarter of d), rows past N16 are not stored
+    const size_t dplane = (size_t)((p.B + 1) / 2) * 2 * p.N16 * CS_D;
+    const int items = E * p.N16 * 4;
+    for (int it = tid; it < items; it += NTHR) {
+      const int dq = it & 3, n = (it >> 2) % p.N16, e = it / (4 * p.N16);
+      const int b = b0 + e;
+      const int bc = b < p.B ? b : p.B - 1, nc = n < p.N ? n : p.N - 1;
+      const size_t at = ((size_t)bc * p.N + nc) * 4 + dq;
+      const float4 o = reinterpret_cast<const float4*>(p.out)[at];
+      float4 g = f4_scale(dmul, reinterpret_cast<const float4*>(dsrc)[at]);
+      const float a = gsrc[bc] * wsrc[nc] * gmul;
+      const bool ok = b < p.B && n < p.N;
+      const float4 v = make_float4((ok && o.x > 0.f) ? g.x + a : 0.f, (ok && o.y > 0.f) ? g.y + a : 0.f,
+                                   (ok && o.z > 0.f) ? g.z + a : 0.f, (ok && o.w > 0.f) ? g.w + a : 0.f);
+      float s = (v.x + v.y) + (v.z + v.w);
+      s += __shfl_xor(s, 1);                       // the 4 d-quarters of row n sit in adjacent lanes
+      s += __shfl_xor(s, 2);
+      if (b < 2 * ((p.B + 1) / 2)) {               // (the last pair's missing example: zero fragments)
+        if (dq == 0 && b < p.B) p.dc_part[(size_t)b * p.N16 + n] = s;
+        // fragment of the dW kernel: lane (i = n & 15, kq = 2 (b & 1) + (d >> 3)), elements j = d & 7
+        const size_t fr = ((((size_t)(b >> 1) * (p.N16 >> 4) + (n >> 4)) * 64 + (2 * (b & 1) + (dq >> 1)) * 16 + (n & 15)) * 8) + (dq & 1) * 4;
+        uint32_t q0[3], q1[3];
+        split2<3>(v.x, v.y, q0);
+        split2<3>(v.z, v.w, q1);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          if (sp < p.dw_planes) *reinterpret_cast<uint2*>(p.dpre16 + (size_t)sp * dplane + fr) = make_uint2(q0[sp], q1[sp]);
+      }
+    }
+  }
+  RSX_STAMP(33, st0);
+  sx.store(sX0, tid);
+  __syncthreads();                                 // every wave is done with its transposition scratch: the ring is free
+#pragma unroll
+  for (int s = 0; s < R - 1; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
+  cs_wait_barrier<0>();                            // sX0 and the first R - 1 slots
+  RSX_STAMP(34, st0);
+  const char* rd = ring + (size_t)par * FR * 1024 + lane16;
+  typename M::quad w[PF];
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    w[j] = __builtin_bit_cast(typename M::quad, *reinterpret_cast<const uint4*>(rd + ((j % NS) * KSN + j / NS) * 1024));
+  f32x4 dxk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  int sl = 0;
+  for (int st = 0; st < nstep; ++st) {
+    const int sln = sl + 1 == R ? 0 : sl + 1, slp = sl == 0 ? R - 1 : sl - 1;
+    const int stn = st + R - 1 < nstep ? st + R - 1 : nstep - 1;
+    CS_DBG_LOAD(C8::issue(img, fstrideB, planeB, stn, p.F, wv, lane16, ring_lds + slp * SLOTB);)
+    const int f_ = 2 * st + par;
+    float x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) x[e] = sX0[((e0 + e) * CS_FP + f_) * CS_D + i];
+    const float wi = M::SCALED ? sInv[f_] : 1.f;
+    f32x4 T[2][NS];
+    cs8_step_mma<MODE, KSN, PF, true>(bd, w, rd + (size_t)sl * SLOTB, rd + (size_t)sln * SLOTB, T);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      f32x4 U = T[e][NS - 1];
+#pragma unroll
+      for (int l = NS - 2; l >= 0; --l) U += T[e][l];
+      if (M::SCALED) U *= wi * inv_d[e];
+      dxk[e][0] = __builtin_fmaf(x[e], U[0], dxk[e][0]);
+      dxk[e][1] = __builtin_fmaf(x[e], U[1], dxk[e][1]);
+      dxk[e][2] = __builtin_fmaf(x[e], U[2], dxk[e][2]);
+      dxk[e][3] = __builtin_fmaf(x[e], U[3], dxk[e][3]);
+      float q = ((U[0] * xkv[e][0] + U[1] * xkv[e][1]) + U[2] * xkv[e][2]) + U[3] * xkv[e][3];
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      sP[((e0 + e) * CS_FP + f_) * CS_D + i] = q;  // (the four lane quarters hold the same sum and store it four times)
+    }
+    CS8_STEP_BARRIER(C8);
+    sl = sln;
+  }
+  RSX_STAMP(35, st0);
+  cs_wait_barrier<0>();                            // the tail's redundant pieces have landed (the ring is free); sP is complete
+  RSX_STAMP(36, st0);
+  float* sR = reinterpret_cast<float*>(ring);      // [8 waves][2][4][64]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = dxk[e][r];
+  for (int e4 = tid; e4 < E * p.F * 4; e4 += NTHR) {        // this tile's share of dX0
+    const int ex = e4 / (p.F * 4), r = e4 - ex * (p.F * 4);
+    if (b0 + ex < p.B)
+      reinterpret_cast<float4*>(p.dx0_parts + ((size_t)ht * p.B + b0 + ex) * p.F * CS_D)[r] = reinterpret_cast<const float4*>(sP + ex * CS_FP * CS_D)[r];
+  }
+  __syncthreads();
+  {   // wave w finishes example w: dXk[b][h = 16 ht + 4 kq + r][d = i] = even fields' share + odd fields' share
+    const int ex = wv, b = b0 + ex;
+    const int w0i = (ex >> 1) * 2, sl2 = ex & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = sR[((w0i * 2 + sl2) * 4 + r) * 64 + lane] + sR[(((w0i + 1) * 2 + sl2) * 4 + r) * 64 + lane];
+      const int h = 16 * ht + 4 * kq + r;
+      if (b < p.B && h < p.H) {
+        float* dst = p.dXk + ((size_t)b * p.H + h) * CS_D + i;
+        *dst = p.acc_dxk ? *dst + s : s;
+      }
+    }
+  }
+  RSX_STAMP(37, st0); RSX_STAMP_MAX(49, KSN == 4);
+}
+
 template <typename K>
 int opt_in_lds(K kernel, size_t lds) {
   if (lds > 160 * 1024) return RSX_EUNSUPPORTED;
@@ -608,6 +1181,58 @@ int launch_fwd_ns(const CsFwdArgs& a, hipStream_t stream) {
   }
 }
 
+// Which kernels run a mode: 1 = the first form (4 examples per 256-thread workgroup, two workgroups per CU), 2 = the deep-ring
+// form (8 examples per 512-thread workgroup).  Measured inside xdeepfm.py's step (profiles/r05_y_*): for the bf16 modes 1..3 the
+// first form is the faster one (0.2550 against 0.2638 ms per step at ns = 3: two independent workgroups per CU cover each
+// other's barriers and prologues), mode 4 exists in the deep-ring form only.  RSX_CIN_SPLIT_V=1|2 forces one (A/B runs).
+int cs_version(int ns) {
+  static const int v = getenv("RSX_CIN_SPLIT_V") ? atoi(getenv("RSX_CIN_SPLIT_V")) : 0;
+  if (ns == CS_H2) return 2;
+  return v == 2 ? 2 : 1;
+}
+template <int MODE, int KS>
+int launch_fwd8(const CsFwdArgs& a, hipStream_t stream) {
+  using M = SplitMode<MODE>;
+  const dim3 grid((unsigned)(a.N16 / 16), (unsigned)((a.B + 7) / 8));
+  const size_t lds = Cs8<M::NS, KS, M::SCALED ? 256 : 0>::TOTAL;
+  const int rc = opt_in_lds(cin_split_fwd8_k<MODE, KS>, lds);
+  if (rc != RSX_OK) return rc;
+  RSX_LAUNCH((cin_split_fwd8_k<MODE, KS>), grid, dim3(512), lds, stream, a);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+template <int MODE>
+int launch_fwd8_ns(const CsFwdArgs& a, hipStream_t stream) {
+  switch (a.Hp / 32) {
+    case 1: return launch_fwd8<MODE, 1>(a, stream);
+    case 2: return launch_fwd8<MODE, 2>(a, stream);
+    case 3: return launch_fwd8<MODE, 3>(a, stream);
+    default: return launch_fwd8<MODE, 4>(a, stream);
+  }
+}
+template <int MODE, int KSN>
+int launch_dx8(const CsDxArgs& a, hipStream_t stream) {
+  using M = SplitMode<MODE>;
+  const dim3 grid((unsigned)(a.H16 / 16), (unsigned)((a.B + 7) / 8));
+  const size_t lds = Cs8<M::NS, KSN, 8 * CS_FP * CS_D * 4 + (M::SCALED ? 256 : 0)>::TOTAL;
+  const int rc = opt_in_lds(cin_split_dx8_k<MODE, KSN>, lds);
+  if (rc != RSX_OK) return rc;
+  RSX_LAUNCH((cin_split_dx8_k<MODE, KSN>), grid, dim3(512), lds, stream, a);
+  RSX_CHECK_LAUNCH();
+  return RSX_OK;
+}
+template <int MODE>
+int launch_dx8_ns(const CsDxArgs& a, hipStream_t stream) {
+  switch (a.Np / 32) {
+    case 1: return launch_dx8<MODE, 1>(a, stream);
+    case 2: return launch_dx8<MODE, 2>(a, stream);
+    case 3: return launch_dx8<MODE, 3>(a, stream);
+    default: return launch_dx8<MODE, 4>(a, stream);
+  }
+}
+inline int cs_planes(int ns) { return ns == CS_H2 ? 2 : ns; }          // 16-bit planes of the filter images
+inline int cs_dw_planes(int ns) { return ns == CS_H2 ? 3 : ns; }       // bf16 planes the weight-gradient launch multiplies
+
 template <int NS, int KSN, int E>
 int launch_dx(const CsDxArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.H16 / 16), (unsigned)((a.B + E - 1) / E));
@@ -636,14 +1261,15 @@ size_t image_elems(int F, int H, int N) {        // one plane of both layouts
 
 // ------------------------------------------------------------------------------------------------------ entry points
 extern "C" size_t rsx_cin_split_weight_elems(int F, int H, int N, int ns) {
-  if (F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > 3) return 0;
-  return (size_t)ns * image_elems(F, H, N);
+  if (F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > CS_H2) return 0;
+  return (size_t)cs_planes(ns) * image_elems(F, H, N) + (ns == CS_H2 ? 2 * CS_FP : 0);     // (+ the fields' inverse scales, fp32)
 }
 
 extern "C" int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
                                   int F, int ns, rsx_stream_t stream) {
-  if (!W_h || !w16_h || !H_h || !N_h || L <= 0 || F <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
-  if (L > CS_MAXJ) return RSX_EUNSUPPORTED;
+  if (!W_h || !w16_h || !H_h || !N_h || L <= 0 || F <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
+  if (L > CS_MAXJ || (ns == CS_H2 && F > CS_FP)) return RSX_EUNSUPPORTED;
+  const int np = cs_planes(ns);
   CsPrepArgs a{};
   a.njobs = L;
   a.F = F;
@@ -655,9 +1281,15 @@ extern "C" int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, c
     CsPrepJob& j = a.job[k];
     j.W = W_h[k]; j.H = H; j.N = N; j.H16 = rup(H, 16); j.N16 = rup(N, 16); j.Hp = rup(H, 32); j.Np = rup(N, 32);
     j.W16 = static_cast<bf16_t*>(w16_h[k]);
-    j.Wt16 = j.W16 + (size_t)ns * F * j.H16 * j.Np;
+    j.Wt16 = j.W16 + (size_t)np * F * j.H16 * j.Np;
+    j.winv = reinterpret_cast<float*>(j.W16 + (size_t)np * image_elems(F, H, N));
     tot += ((long long)F * j.H16 * j.Np + (long long)F * j.N16 * j.Hp) >> 3;
     j.end = tot;
+  }
+  if (ns == CS_H2) {                                // one workgroup per (layer, field): the field's largest |W| first
+    RSX_LAUNCH(cin_split_prep_h2_k, dim3((unsigned)(L * F * CS_H2_PARTS)), dim3(256), 0, rsx_s(stream), a);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
   }
   const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
   switch (ns) {
@@ -671,13 +1303,23 @@ extern "C" int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, c
 
 extern "C" int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w16, const float* c, float* out, int B, int F,
                                  int H, int N, int D, int ns, rsx_stream_t stream) {
-  if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !w16 || !c || !out) return RSX_EINVAL;
   if (D != CS_D || H > 128 || N > 128 || F > CS_FP) return RSX_EUNSUPPORTED;
   const int H16 = rup(H, 16), N16 = rup(N, 16), Hp = rup(H, 32), Np = rup(N, 32);
-  const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)ns * F * H16 * Np;
-  const CsFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp};
+  const int np = cs_planes(ns);
+  const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)np * F * H16 * Np;
+  const float* winv = reinterpret_cast<const float*>(static_cast<const bf16_t*>(w16) + (size_t)np * image_elems(F, H, N));
+  const CsFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, winv};
+  if (cs_version(ns) == 2) {
+    switch (ns) {
+      case 1: return launch_fwd8_ns<1>(a, rsx_s(stream));
+      case 2: return launch_fwd8_ns<2>(a, rsx_s(stream));
+      case 3: return launch_fwd8_ns<3>(a, rsx_s(stream));
+      default: return launch_fwd8_ns<CS_H2>(a, rsx_s(stream));
+    }
+  }
   if (cs_examples() == 8) {
     switch (ns) {
       case 1: return launch_fwd_ns<1, 8>(a, rsx_s(stream));
@@ -694,22 +1336,32 @@ extern "C" int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w
 
 // ws: [ns planes of dpre fragments | B x N16 bias-gradient partials]
 extern "C" size_t rsx_cin_split_bwd_workspace_bytes(int B, int N, int ns) {
-  if (B <= 0 || N <= 0 || ns < 1 || ns > 3) return 0;
-  return (size_t)ns * ((B + 1) / 2) * 2 * rup(N, 16) * CS_D * 2 + (size_t)B * rup(N, 16) * sizeof(float);
+  if (B <= 0 || N <= 0 || ns < 1 || ns > CS_H2) return 0;
+  return (size_t)cs_dw_planes(ns) * ((B + 1) / 2) * 2 * rup(N, 16) * CS_D * 2 + (size_t)B * rup(N, 16) * sizeof(float);
 }
 
 extern "C" int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void* w16, const float* out, const float* dout,
                                     const float* gs, const float* wout, float* dXk, int acc_dxk, float* dx0_parts, void* ws,
                                     int B, int F, int H, int N, int D, int ns, rsx_stream_t stream) {
-  if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !w16 || !out || !dXk || !dx0_parts || !ws) return RSX_EINVAL;
   if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
   if (D != CS_D || H > 128 || N > 128 || F > CS_FP) return RSX_EUNSUPPORTED;
   const int H16 = rup(H, 16), N16 = rup(N, 16), Np = rup(N, 32);
-  float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)ns * ((B + 1) / 2) * 2 * N16 * CS_D * 2);
+  const int dwp = cs_dw_planes(ns);
+  float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)dwp * ((B + 1) / 2) * 2 * N16 * CS_D * 2);
+  const float* winv = reinterpret_cast<const float*>(static_cast<const bf16_t*>(w16) + (size_t)cs_planes(ns) * image_elems(F, H, N));
   const CsDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dx0_parts, static_cast<bf16_t*>(ws),
-                   dc_part, acc_dxk, B, F, H, N, H16, N16, Np};
+                   dc_part, acc_dxk, B, F, H, N, H16, N16, Np, winv, dwp};
+  if (cs_version(ns) == 2) {
+    switch (ns) {
+      case 1: return launch_dx8_ns<1>(a, rsx_s(stream));
+      case 2: return launch_dx8_ns<2>(a, rsx_s(stream));
+      case 3: return launch_dx8_ns<3>(a, rsx_s(stream));
+      default: return launch_dx8_ns<CS_H2>(a, rsx_s(stream));
+    }
+  }
   if (cs_examples() == 8) {
     switch (ns) {
       case 1: return launch_dx_ns<1, 8>(a, rsx_s(stream));
@@ -924,9 +1576,10 @@ __global__ __launch_bounds__(512) void cin_split_dw_k(const CsDwArgs p) {
 /* jobs_h: rsx_cin_dw_job with ws = the layer's rsx_cin_split_bwd_dx workspace (dc_rows is ignored: one row per example) */
 extern "C" int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
                                     rsx_stream_t stream) {
-  if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0 || ns < 1 || ns > 3) return RSX_EINVAL;
+  if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
   if (njobs > CS_MAXJ || D != CS_D || F > CS_FP) return RSX_EUNSUPPORTED;
   if (B == 0) return RSX_OK;
+  ns = cs_dw_planes(ns);                            // (mode 4: the data-gradient launch left three bf16 planes of dpre)
   CsDwArgs w{};
   w.njobs = njobs; w.X0 = X0; w.B = B; w.F = F;
   // fields per tile: 4 for the job with the most tiles, 3 for the others -- [128, 128] at F = 39: 160 + 78 = 238 workgroups, one
@@ -983,3 +1636,13 @@ extern "C" int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
+
+#ifdef RSX_STAMPS
+extern "C" int rsx_dbg_stamps_cin_split(unsigned long long* out_h) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(rsx_stamps_d), sizeof(rsx_stamps_d)) == hipSuccess ? 0 : 1;
+}
+extern "C" int rsx_dbg_stamps_cin_split_reset() {
+  unsigned long long z[64] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(rsx_stamps_d), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -90,11 +90,13 @@ def build_variables(store, params, capacity):
     # cin_bf16: the CIN contraction on the bf16 MFMA path (csrc/cin_bf16.hip).  Off by default: fp32 is the parity path
     # cin_split = ns (1..3): the contraction on the bf16 matrix cores with ns bf16 planes per operand (csrc/cin_split.hip);
     # ns = 3 keeps every product to 2^-23 -- fp32-grade, held to the same 1e-5 parity tests as the fp32 MFMA kernels
-    # Default (cin_split unset, no cin_bf16): 3 -- the fastest path that holds the parity bar; cin_split = 0 selects the fp32
-    # MFMA kernels of csrc/cin.hip.
+    # cin_split = 4: forward / data gradients with two scaled fp16 planes per operand (half the MFMAs of ns = 3, products to
+    # 2^-22: held to the tolerances of ns = 3 in tests/test_gpu_cin_split.py), weight gradients on three bf16 planes.
+    # Default (cin_split unset, no cin_bf16): 4 -- the fastest path that holds the parity bar (RSX_CIN_SPLIT_DEFAULT overrides:
+    # A/B runs); cin_split = 0 selects the fp32 MFMA kernels of csrc/cin.hip.
     bf16 = bool(params.get("cin_bf16", False))
     split = params.get("cin_split")
-    split = (0 if bf16 else 3) if split is None else int(split)
+    split = (0 if bf16 else int(os.environ.get("RSX_CIN_SPLIT_DEFAULT", "4"))) if split is None else int(split)
     if split and not (F <= 40 and D == 16 and max(cin) <= 128 and len(cin) <= 4):
         split = 0                                    # outside the kernels' envelope: the fp32 MFMA path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bf16 and not split, split=split)

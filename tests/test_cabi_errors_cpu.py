@@ -219,13 +219,15 @@ def test_round5_cin_entry_points_reject_bad_arguments(L):
     # sizes
     assert L.rsx_cin_split_weight_elems(39, 128, 128, 3) == 3 * 2 * 39 * 128 * 128
     assert L.rsx_cin_split_weight_elems(39, 39, 128, 1) == 39 * 48 * 128 + 39 * 128 * 64       # H padded to 16 / to 32
-    assert L.rsx_cin_split_weight_elems(39, 128, 128, 4) == 0 and L.rsx_cin_split_weight_elems(39, 128, 128, 0) == 0
+    assert L.rsx_cin_split_weight_elems(39, 128, 128, 5) == 0 and L.rsx_cin_split_weight_elems(39, 128, 128, 0) == 0
+    assert L.rsx_cin_split_weight_elems(39, 128, 128, 4) == 2 * 2 * 39 * 128 * 128 + 80      # mode 4: two fp16 planes + 40 fp32 scales
+    assert L.rsx_cin_split_bwd_workspace_bytes(256, 128, 4) == L.rsx_cin_split_bwd_workspace_bytes(256, 128, 3)   # dW: three bf16 planes
     assert L.rsx_cin_split_bwd_workspace_bytes(256, 128, 3) == 3 * 256 * 128 * 16 * 2 + 256 * 128 * 4
     assert L.rsx_cin_split_bwd_workspace_bytes(7, 20, 2) == 2 * 8 * 32 * 16 * 2 + 7 * 32 * 4   # odd batch: whole example pairs
     assert L.rsx_cin_bf16_dx0_parts_floats(256, 39, 128) == 8 * 256 * 39 * 16
     assert L.rsx_cin_bf16_dx0_parts_floats(256, 39, 39) == 3 * 256 * 39 * 16
     # prep
-    assert L.rsx_cin_split_prep(one(0x1000), one(0x2000), i1(128), i1(128), 1, 39, 4, None) == EINVAL         # ns out of range
+    assert L.rsx_cin_split_prep(one(0x1000), one(0x2000), i1(128), i1(128), 1, 39, 5, None) == EINVAL         # ns out of range
     assert L.rsx_cin_split_prep(one(0x1000), one(0x2000), i1(129), i1(128), 1, 39, 3, None) == EUNSUPPORTED   # H > 128
     assert L.rsx_cin_split_prep(one(0), one(0x2000), i1(128), i1(128), 1, 39, 3, None) == EINVAL
     assert L.rsx_cin_split_prep(None, one(0x2000), i1(128), i1(128), 1, 39, 3, None) == EINVAL

@@ -2,7 +2,9 @@
   ns = 3 is the parity path: every product exact to 2^-23, so the kernels are compared with the PLAIN fp64 evaluation
   (the oracle's formula, oracle/models.py cin_layer_fwd / cin_layer_bwd) at fp32-accumulation tolerance;
   ns = 1 is compared with the fp64 evaluation in which the operands are rounded to bf16 first (as tests/test_gpu_cin_bf16.py);
-  ns = 2 sits in between (2^-16-grade products)."""
+  ns = 2 sits in between (2^-16-grade products);
+  ns = 4: forward / data gradients with two scaled fp16 planes per operand (three MFMAs per k-step, products to 2^-22), weight
+  gradients on three bf16 planes -- held to the SAME tolerances as ns = 3, plus a test with operands spread over 2^40."""
 import ctypes as C
 
 import numpy as np
@@ -40,10 +42,10 @@ SHAPES = [
     (250, 40, 128, 128, False),
     (19, 38, 72, 96, False),
 ]
-TOL = {3: 2e-6, 2: 3e-5, 1: 2e-5}
+TOL = {4: 2e-6, 3: 2e-6, 2: 3e-5, 1: 2e-5}
 
 
-@pytest.mark.parametrize("ns", [3, 2, 1])
+@pytest.mark.parametrize("ns", [4, 3, 2, 1])
 @pytest.mark.parametrize("B,F,H,N,first", SHAPES)
 def test_cin_split_forward(B, F, H, N, first, ns):
     from recsys_amd.ops import _ptr, _stream, check, lib
@@ -80,10 +82,10 @@ BWD_SHAPES = [
     (19, 38, 72, 96, False, False, True),
     (700, 39, 32, 16, False, True, False),       # a batch whose X0 slab does not fit the weight-gradient launch's LDS
 ]
-BTOL = {3: 3e-6, 2: 5e-5, 1: 2e-5}
+BTOL = {4: 3e-6, 3: 3e-6, 2: 5e-5, 1: 2e-5}
 
 
-@pytest.mark.parametrize("ns", [3, 2, 1])
+@pytest.mark.parametrize("ns", [4, 3, 2, 1])
 @pytest.mark.parametrize("B,F,H,N,first,gs,acc", BWD_SHAPES)
 def test_cin_split_backward(B, F, H, N, first, gs, acc, ns):
     """dXk, dX0 (tile partials + the reduce launch), dW, dc.  ns = 3 / 2: against the plain fp64 gradients of the oracle's
@@ -140,3 +142,35 @@ def test_cin_split_backward(B, F, H, N, first, gs, acc, ns):
         assert np.isfinite(got[k]).all(), k
         err = _rel(got[k], ref[k])
         assert err < BTOL[ns], (k, err)
+
+
+@pytest.mark.parametrize("ns", [4, 3])
+def test_cin_split_forward_wide_dynamic_range(ns):
+    """Operands whose magnitudes are spread over many binades (per example and per field by 2^+-20, elements by another 2^8):
+    the power-of-two scales of mode 4 are per accumulation chain, so every example / field keeps its own precision."""
+    from recsys_amd.ops import _ptr, _stream, check, lib
+    B, F, H, N = 64, 39, 128, 128
+    rng = np.random.default_rng(77)
+    X0 = (rng.standard_normal((B, F, 16)) * 0.3).astype(np.float32)
+    Xk = (np.abs(rng.standard_normal((B, H, 16))) * np.exp2(rng.integers(-8, 1, (B, H, 16))) *
+          np.exp2(rng.integers(-20, 21, (B, 1, 1)))).astype(np.float32)
+    W = (rng.standard_normal((F, H, N)) * np.exp2(rng.integers(-8, 1, (F, H, N))) * np.exp2(rng.integers(-20, 21, (F, 1, 1)))).astype(np.float32)
+    c = np.zeros(N, np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    tX0, tXk, tW, tc = t(X0), t(Xk), t(W.reshape(F * H, N)), t(c)
+    w16 = torch.empty(int(lib().rsx_cin_split_weight_elems(F, H, N, ns)), dtype=torch.int16, device="cuda")
+    out = torch.full((B, N, 16), float("nan"), device="cuda")
+    check(lib().rsx_cin_split_prep((C.c_void_p * 1)(tW.data_ptr()), (C.c_void_p * 1)(w16.data_ptr()), (C.c_int32 * 1)(H),
+                                   (C.c_int32 * 1)(N), 1, F, ns, _stream()))
+    check(lib().rsx_cin_split_fwd(_ptr(tX0), _ptr(tXk), _ptr(w16), _ptr(tc), _ptr(out), B, F, H, N, 16, ns, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float64)
+    f8 = np.float64
+    # per (example, field) term T = Xk W_f, compared per example: err relative to the example's own largest |term sum|
+    pre = np.einsum("bfd,bhd,fhn->bnd", X0.astype(f8), Xk.astype(f8), W.astype(f8), optimize=True)
+    mag = np.einsum("bfd,bhd,fhn->bnd", np.abs(X0).astype(f8), Xk.astype(f8), np.abs(W).astype(f8), optimize=True)
+    ref = np.maximum(pre, 0)
+    assert np.isfinite(got).all()
+    err = float((np.abs(got - ref) / mag.max(axis=(1, 2), keepdims=True)).max())
+    print("ns=%d wide range: max |err| / max_b sum |terms| = %.3g" % (ns, err))
+    assert err < 2e-6, err

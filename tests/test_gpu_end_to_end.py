@@ -145,7 +145,7 @@ def test_fused_inference_equals_the_framework_path(kind):
             pr = np.array([p["prob"] for p in est.predict(fn(3))])
             res.append((ev, pr))
         (e1, p1), (e2, p2) = res
-        # xdeepfm.py: the fused path runs the CIN on the bf16 matrix cores with three planes per operand (csrc/cin_split.hip), the
+        # xdeepfm.py: the fused path runs the CIN on the 16-bit matrix cores with split operands (csrc/cin_split.hip, mode 4), the
         # framework path the fp32 MFMA kernels (csrc/cin.hip) -- two evaluations of the same sums, each inside the 1e-5 parity bar
         tol = 1e-5 if kind == "xdeepfm" else 2e-6
         assert p1.shape == (3 * B,) and np.abs(p1 - p2).max() < tol, (B, np.abs(p1 - p2).max())

@@ -150,20 +150,22 @@ def test_xdeepfm_train_parity_config3():
     assert max(perr.values()) < 5e-5, perr
 
 
+@pytest.mark.parametrize("cin_split", [3, 4])
 @pytest.mark.parametrize("cin,dropout,B,steps", [((8, 4), 0.0, 16, 3), ((20, 10, 10), 0.5, 24, 3), ((128, 128), 0.5, 64, 2)])
-def test_xdeepfm_train_parity_split3(cin, dropout, B, steps):
-    """The same parity bars with the CIN contraction on the bf16 matrix cores, three bf16 planes per operand
-    (csrc/cin_split.hip, cin_split = 3: every product exact to 2^-23): predictions 1e-5, losses 1e-5 / 2e-5, variables 5e-5
-    against the fp64 oracle -- incl. BASELINE config 3's CIN [128,128], DNN 100-100."""
+def test_xdeepfm_train_parity_split3(cin, dropout, B, steps, cin_split):
+    """The same parity bars with the CIN contraction on the 16-bit matrix cores: three bf16 planes per operand
+    (csrc/cin_split.hip, cin_split = 3: every product exact to 2^-23) and cin_split = 4 (xdeepfm.py's default: forward / data
+    gradients with two scaled fp16 planes per operand, weight gradients on three bf16 planes): predictions 1e-5, losses 1e-5 /
+    2e-5, variables 5e-5 against the fp64 oracle -- incl. BASELINE config 3's CIN [128,128], DNN 100-100."""
     err, losses, perr = _xdeepfm_run(B=B, steps=steps, seed=21 if B < 64 else 22, cin=cin, layers=(32, 16) if B < 64 else (100, 100),
-                                     dropout=dropout, cin_split=3)
+                                     dropout=dropout, cin_split=cin_split)
     assert err < 1e-5, err
     for lg, lo in losses:
         assert abs(lg - lo) < (1e-5 if B < 64 else 2e-5), losses
     assert max(perr.values()) < 5e-5, perr
 
 
-@pytest.mark.parametrize("cin_split", [0, 3])
+@pytest.mark.parametrize("cin_split", [0, 3, 4])
 def test_xdeepfm_hip_graph(cin_split):
     err, losses, perr = _xdeepfm_run(B=32, steps=5, seed=23, cin=(16, 16), layers=(32, 16), dropout=0.0, use_graph=True, cin_split=cin_split)
     assert err < 1e-5 and max(perr.values()) < 5e-5, (err, perr)
