@@ -59,9 +59,10 @@ def parse():
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
     p.add_argument("--cin_bf16", action="store_true", help="xdeepfm: CIN contraction on the bf16 MFMA path (fp32 accumulate); the "
                    "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
-    p.add_argument("--cin_split", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                   help="xdeepfm: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (csrc/cin_split.hip); 3 = every "
-                        "product exact to 2^-23 (fp32-grade: held to the fp32 path's 1e-5 parity tests)")
+    p.add_argument("--cin_split", type=int, default=None, choices=[0, 1, 2, 3, 4],
+                   help="xdeepfm: CIN contraction on the 16-bit MFMA with split operands (csrc/cin_split.hip); 3 = three bf16 planes, every "
+                        "product exact to 2^-23; 4 = two scaled fp16 planes forward / data gradients (half the MFMAs) -- both held to "
+                        "the fp32 path's 1e-5 parity tests; 0 = the fp32 MFMA kernels; unset = xdeepfm.py's default (4)")
     p.add_argument("--no_overlap", action="store_true", help="profiling aid: plain path (stand-alone sort, segment-sum, ONE full "
                    "optimizer sweep) instead of sweep slices riding in the tower launches -- shows every kernel's own duration")
     p.add_argument("--no_configs", action="store_true", help="skip the `configs` list (the other BASELINE configs)")
@@ -163,8 +164,11 @@ def sweep_bytes(est, wk):
     return alg, 24 * n_sparse + 4 * wk * rows, n_sparse, arenas
 
 
-def cin_mode(cin_bf16, cin_split=0):
-    """False (fp32 MFMA) | True (bf16 operands) | 'x1'/'x2'/'x3' (ns bf16 planes per operand)."""
+def cin_mode(cin_bf16, cin_split=None):
+    """False (fp32 MFMA) | True (bf16 operands) | 'x1'..'x4' (split operands, csrc/cin_split.hip).  --cin_split unset: xdeepfm.py's
+    own default (mode 4) unless --cin_bf16; --cin_split 0: the fp32 MFMA kernels."""
+    if cin_split is None:
+        return True if cin_bf16 else "x4"
     return ("x%d" % cin_split) if cin_split else bool(cin_bf16)
 
 
@@ -393,6 +397,12 @@ DOMINANT_WORK = {
     "dcn": ("tower_bwd_big_k", 4 * 4096 * 624 * 100, 157.3e12, "flop", "fp32 MFMA: d(input) + dW of the 624-wide layer at batch 4096"),
     "xdeepfm": ("cin_bwd_dw_k", 2 * 256 * 16 * 39 * 128 * 128, 157.3e12, "flop", "fp32 MFMA: dW of the [39*128, 128] CIN layer"),
     "xdeepfm_bf16": ("cin_bwd_dw_bf16_k", 2 * 256 * 16 * (39 * 39 * 128 + 39 * 128 * 128), 2.5e15, "flop", "bf16 MFMA: dW of both CIN layers (one launch)"),
+    # (split operands: the work is the 16-bit MFMA flops the launch ISSUES -- 6 products of planes per algorithmic product)
+    "xdeepfm_x3": ("cin_split_dw_k", 6 * 2 * 256 * 16 * (39 * 39 * 128 + 39 * 128 * 128), 2.5e15, "flop (issued)",
+                   "bf16 MFMA, 3 planes per operand: dW of both CIN layers (one launch), 6 MFMAs per k-step"),
+    "xdeepfm_x4": ("cin_split_dw_k", 6 * 2 * 256 * 16 * (39 * 39 * 128 + 39 * 128 * 128), 2.5e15, "flop (issued)",
+                   "bf16 MFMA, 3 planes per operand: dW of both CIN layers (one launch), 6 MFMAs per k-step (mode 4 keeps the weight "
+                   "gradients on three bf16 planes)"),
     "din": ("din_attn_bwd_k", 2 * 2 * 51200 * (128 * 80 + 80 * 40 + 40), 157.3e12, "flop", "fp32 MFMA: attention MLP backward over ~51 200 valid positions (half of 102 400)"),
 }
 
@@ -408,10 +418,10 @@ def dominant_kernel_fraction(key):
     if not files:
         return None
     for line in open(files[-1]):
-        if kern in line:
-            m = re.search(r"\)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)", line)
-            if m:
-                avg_us = float(m.group(2))
+        if kern in line[:72]:
+            f = line[72:].split()        # (scripts/rocpd_summary.py: the name in 72 columns, then calls / avg / min / max ...)
+            if len(f) >= 4 and f[0].isdigit():
+                avg_us = float(f[1])
                 return {"kernel": kern, "what": what, "work_per_launch": work, "unit": unit, "avg_us": avg_us,
                         "source": os.path.basename(files[-1]), "peak": peak,
                         "frac": round(work / (avg_us * 1e-6) / peak, 4)}

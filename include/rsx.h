@@ -935,6 +935,24 @@ int rsx_cin_prep_bf16_multi(const float* const* W_h, void* const* w16_h, const i
  *   rsx_cin_split_prep  W fp32 [F*H, N] of L layers -> w16_h[k] (rsx_cin_split_weight_elems 16-bit elements each)
  * F <= 40, H, N <= 128, D = 16; RSX_EUNSUPPORTED otherwise.                                                          */
 size_t rsx_cin_split_weight_elems(int F, int H, int N, int ns);
+/* rsx_gather_two_fwd's arguments as a job: rsx_cin_split_prep_gather runs that lookup (xdeepfm/xdeepfm.py:125-131,185; D = 16) as
+ * extra workgroups of the filter-preparation launch -- the two launches at the head of xdeepfm.py's step become one.      */
+typedef struct rsx_gather_two_job {
+  const float* tables1;
+  const float* w1;
+  const float* tables2;
+  const int32_t* row_off;
+  const int32_t* ids;
+  const float* num_x;
+  const float* num_w;
+  float* E1;
+  float* E2;
+  float* y1;
+  uint64_t w1_field_mask;
+  int32_t B, F, D, ND;
+} rsx_gather_two_job;
+int rsx_cin_split_prep_gather(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L, int F,
+                              int ns, const rsx_gather_two_job* g, rsx_stream_t stream);
 int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L, int F,
                        int ns, rsx_stream_t stream);
 int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w16, const float* c, float* out, int B, int F, int H,
@@ -951,6 +969,11 @@ int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void* w16, cons
                          int F, int H, int N, int D, int ns, rsx_stream_t stream);
 int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
                          rsx_stream_t stream);
+/* The same launch with rsx_cin_dx0_reduce riding along as extra workgroups (same sums in the same order: dX0 [B, F, D] =
+ * (acc_dx0 ? dX0 : 0) + the nparts layers' tile partials, tiles_h[j] tiles each): one launch less on the step's chain.   */
+int rsx_cin_split_bwd_dw_dx0(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
+                             const float* const* parts_h, const int32_t* tiles_h, int nparts, float* dX0, int acc_dx0,
+                             rsx_stream_t stream);
 /* Round 5: the data gradients with EIGHT examples per workgroup (csrc/cin_bf16_wide.hip; xdeepfm/xdeepfm.py:145-169
  * differentiated).  A workgroup sees one 16-wide tile of h, so dX0 (a sum over h) is left as one partial per tile:
  * dx0_parts [ceil(H/16)][B][F*16] floats (rsx_cin_bf16_dx0_parts_floats); rsx_cin_dx0_reduce adds the tiles of all layers

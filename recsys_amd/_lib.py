@@ -95,6 +95,12 @@ class CinDwJob(C.Structure):
                 ("dc_rows", C.c_int32)]
 
 
+class GatherTwoJob(C.Structure):          # include/rsx.h rsx_gather_two_job
+    _fields_ = [("tables1", C.c_void_p), ("w1", C.c_void_p), ("tables2", C.c_void_p), ("row_off", C.c_void_p), ("ids", C.c_void_p),
+                ("num_x", C.c_void_p), ("num_w", C.c_void_p), ("E1", C.c_void_p), ("E2", C.c_void_p), ("y1", C.c_void_p),
+                ("w1_field_mask", C.c_uint64), ("B", C.c_int32), ("F", C.c_int32), ("D", C.c_int32), ("ND", C.c_int32)]
+
+
 class UniqPackJob(C.Structure):           # include/rsx.h rsx_uniq_pack_job
     _fields_ = [("uniq_row", C.c_void_p), ("nuniq", C.c_void_p), ("keys", C.c_void_p)]
 
@@ -221,7 +227,9 @@ _SIGS = {
     "rsx_cin_split_fwd": (_I, [_P] * 5 + [_I] * 6 + [_P]),
     "rsx_cin_split_bwd_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "rsx_cin_split_bwd_dx": (_I, [_P] * 8 + [_I, _P, _P] + [_I] * 6 + [_P]),
+    "rsx_cin_split_prep_gather": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(GatherTwoJob), _P]),
     "rsx_cin_split_bwd_dw": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _I, _P]),
+    "rsx_cin_split_bwd_dw_dx0": (_I, [_P, C.POINTER(CinDwJob), _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P]),
     "rsx_cin_layer_bwd_dx_bf16_parts": (_I, [_P] * 8 + [_I, _P, _P] + [_I] * 5 + [_P]),
     "rsx_cin_dx0_reduce": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "rsx_cin_out_fwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _P]),

@@ -19,6 +19,7 @@
 // registers (NS x 2 x KS quads).  Per step and wave: 2 examples x (1 | 3 | 6) terms x KS MFMAs.
 // Sums in fixed order (terms smallest first, k-steps, fields in step order, the two field parities at the end).
 #include "rsx_common.h"
+#include "gather_two_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -107,11 +108,25 @@ __device__ __forceinline__ f32x4 split_mma_ba(const bf16x8 (&a)[NS][KS], const b
 //   W16  [NS][F][H16/16][Np/32][64][8]: element j of lane (i, kq) = W[f][h = 16 ht + i][n = 32 ks + 8 kq + j]   (A of dX)
 //   Wt16 [NS][F][N16/16][Hp/32][64][8]: element j of lane (i, kq) = W[f][h = 32 ks + 8 kq + j][n = 16 nt + i]   (B of fwd)
 struct CsPrepJob { const float* W; bf16_t* W16; bf16_t* Wt16; float* winv; int H, N, H16, N16, Hp, Np; long long end; };
-struct CsPrepArgs { CsPrepJob job[CS_MAXJ]; int njobs, F; };
+struct CsPrepArgs {
+  CsPrepJob job[CS_MAXJ];
+  int njobs, F;
+  // rider (rsx_cin_split_prep_gather): the first n_gather workgroups (4 waves = 4 examples each) run xdeepfm.py's two input_layer
+  // lookups + the linear_net pre-activation -- the launch before this one on the step's chain, as short as this one
+  int n_gather;
+  GatherTwoArgs gt;
+};
+__device__ __forceinline__ bool cs_prep_gather_role(const CsPrepArgs& p) {     // (256-thread workgroups, D = 16)
+  if ((int)blockIdx.x >= p.n_gather) return false;
+  const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (b < p.gt.B) gather_two_example<16>(p.gt, b, (int)(threadIdx.x & 63));
+  return true;
+}
 template <int NS>
 __global__ __launch_bounds__(256) void cin_split_prep_k(const CsPrepArgs p) {
+  if (cs_prep_gather_role(p)) return;
   const long long total = p.job[p.njobs - 1].end;           // operand quads (of one plane) over all jobs
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+  for (long long e = (long long)((int)blockIdx.x - p.n_gather) * 256 + threadIdx.x; e < total; e += (long long)((int)gridDim.x - p.n_gather) * 256) {
     int ji = 0;
 #pragma unroll
     for (int k = 1; k < CS_MAXJ; ++k)
@@ -684,7 +699,9 @@ __global__ __launch_bounds__(512, 1) void cin_split_fwd8_k(const CsFwdArgs p) {
 constexpr int CS_H2_PARTS = 4;                     // workgroups per (layer, field): each finds the field's maximum, converts a quarter
 __global__ __launch_bounds__(256) void cin_split_prep_h2_k(const CsPrepArgs p) {
   __shared__ float red[4];
-  const int part = (int)blockIdx.x % CS_H2_PARTS, lf = (int)blockIdx.x / CS_H2_PARTS;
+  if (cs_prep_gather_role(p)) return;
+  const int bid = (int)blockIdx.x - p.n_gather;
+  const int part = bid % CS_H2_PARTS, lf = bid / CS_H2_PARTS;
   const int ji = lf / p.F, f = lf % p.F;
   const CsPrepJob& jb = p.job[ji];
   const int tid = threadIdx.x;
@@ -1265,8 +1282,23 @@ extern "C" size_t rsx_cin_split_weight_elems(int F, int H, int N, int ns) {
   return (size_t)cs_planes(ns) * image_elems(F, H, N) + (ns == CS_H2 ? 2 * CS_FP : 0);     // (+ the fields' inverse scales, fp32)
 }
 
+static int cs_launch_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L, int F, int ns,
+                          const rsx_gather_two_job* g, rsx_stream_t stream);
 extern "C" int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
                                   int F, int ns, rsx_stream_t stream) {
+  return cs_launch_prep(W_h, w16_h, H_h, N_h, L, F, ns, nullptr, stream);
+}
+extern "C" int rsx_cin_split_prep_gather(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L,
+                                         int F, int ns, const rsx_gather_two_job* g, rsx_stream_t stream) {
+  if (!g) return RSX_EINVAL;
+  if (g->B < 0 || g->F <= 0 || g->F > 64 || g->ND <= 0 || g->ND > 64) return RSX_EINVAL;
+  if (g->D != 16) return RSX_EUNSUPPORTED;
+  if (g->B > 0 && (!g->tables1 || !g->w1 || !g->tables2 || !g->row_off || !g->ids || !g->num_x || !g->num_w || !g->E1 || !g->E2 || !g->y1))
+    return RSX_EINVAL;
+  return cs_launch_prep(W_h, w16_h, H_h, N_h, L, F, ns, g, stream);
+}
+static int cs_launch_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L, int F, int ns,
+                          const rsx_gather_two_job* g, rsx_stream_t stream) {
   if (!W_h || !w16_h || !H_h || !N_h || L <= 0 || F <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
   if (L > CS_MAXJ || (ns == CS_H2 && F > CS_FP)) return RSX_EUNSUPPORTED;
   const int np = cs_planes(ns);
@@ -1286,12 +1318,17 @@ extern "C" int rsx_cin_split_prep(const float* const* W_h, void* const* w16_h, c
     tot += ((long long)F * j.H16 * j.Np + (long long)F * j.N16 * j.Hp) >> 3;
     j.end = tot;
   }
-  if (ns == CS_H2) {                                // one workgroup per (layer, field): the field's largest |W| first
-    RSX_LAUNCH(cin_split_prep_h2_k, dim3((unsigned)(L * F * CS_H2_PARTS)), dim3(256), 0, rsx_s(stream), a);
+  if (g && g->B > 0) {
+    a.n_gather = (g->B + 3) / 4;
+    a.gt = GatherTwoArgs{g->tables1, g->w1, g->tables2, g->row_off, g->ids, g->num_x, g->num_w, g->E1, g->E2, g->y1, g->w1_field_mask,
+                         g->B, g->F, g->ND};
+  }
+  if (ns == CS_H2) {                                // CS_H2_PARTS workgroups per (layer, field): the field's largest |W| first
+    RSX_LAUNCH(cin_split_prep_h2_k, dim3((unsigned)(a.n_gather + L * F * CS_H2_PARTS)), dim3(256), 0, rsx_s(stream), a);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
   }
-  const unsigned blocks = (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+  const unsigned blocks = (unsigned)a.n_gather + (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
   switch (ns) {
     case 1: RSX_LAUNCH(cin_split_prep_k<1>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
     case 2: RSX_LAUNCH(cin_split_prep_k<2>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
@@ -1402,6 +1439,13 @@ struct CsDwArgs {
   const float* X0;        // [B, F, 16]
   int B, F;
   int x0l;                // the tiles' X0 slabs sit in LDS (B <= 640)
+  // riders (rsx_cin_split_bwd_dw_dx0): red_blocks extra workgroups add the data-gradient launches' dX0 tile partials -- what
+  // cin_dx0_reduce_k does in a launch of its own (5.4 us of launch latency for 7 MB; the tiles leave ~18 CUs free)
+  const float* red_parts[CS_MAXJ];
+  int red_tiles[CS_MAXJ];
+  int red_njobs, red_blocks, red_acc;
+  float* red_dX0;
+  unsigned long long red_n4;
 };
 
 template <int NS, int FT, bool X0L>
@@ -1557,6 +1601,18 @@ __global__ __launch_bounds__(512) void cin_split_dw_k(const CsDwArgs p) {
     return;
   }
   const int tile = (int)blockIdx.x - p.njobs;
+  if (tile >= p.job[p.njobs - 1].tile_end) {      // rider: dX0[e] = (acc ? dX0[e] : 0) + the tiles' partials in (job, tile) order
+    const unsigned long long first = (unsigned long long)(tile - p.job[p.njobs - 1].tile_end) * 512 + tid;
+    for (unsigned long long e = first; e < p.red_n4; e += (unsigned long long)p.red_blocks * 512) {
+      float4 s = p.red_acc ? reinterpret_cast<const float4*>(p.red_dX0)[e] : F4Z;
+#pragma unroll
+      for (int j = 0; j < CS_MAXJ; ++j)
+        if (j < p.red_njobs)
+          for (int t = 0; t < p.red_tiles[j]; ++t) s = f4_add(s, reinterpret_cast<const float4*>(p.red_parts[j])[(size_t)t * p.red_n4 + e]);
+      reinterpret_cast<float4*>(p.red_dX0)[e] = s;
+    }
+    return;
+  }
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < CS_MAXJ; ++k)
@@ -1574,8 +1630,25 @@ __global__ __launch_bounds__(512) void cin_split_dw_k(const CsDwArgs p) {
 }  // namespace
 
 /* jobs_h: rsx_cin_dw_job with ws = the layer's rsx_cin_split_bwd_dx workspace (dc_rows is ignored: one row per example) */
+static int cs_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
+                        const float* const* parts_h, const int32_t* tiles_h, int nparts, float* dX0, int acc_dx0,
+                        rsx_stream_t stream);
 extern "C" int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
                                     rsx_stream_t stream) {
+  return cs_launch_dw(X0, jobs_h, njobs, B, F, D, ns, nullptr, nullptr, 0, nullptr, 0, stream);
+}
+extern "C" int rsx_cin_split_bwd_dw_dx0(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
+                                        const float* const* parts_h, const int32_t* tiles_h, int nparts, float* dX0, int acc_dx0,
+                                        rsx_stream_t stream) {
+  if (!parts_h || !tiles_h || nparts <= 0 || !dX0) return RSX_EINVAL;
+  if (nparts > CS_MAXJ) return RSX_EUNSUPPORTED;
+  for (int j = 0; j < nparts; ++j)
+    if (!parts_h[j] || tiles_h[j] <= 0) return RSX_EINVAL;
+  return cs_launch_dw(X0, jobs_h, njobs, B, F, D, ns, parts_h, tiles_h, nparts, dX0, acc_dx0, stream);
+}
+static int cs_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs, int B, int F, int D, int ns,
+                        const float* const* parts_h, const int32_t* tiles_h, int nparts, float* dX0, int acc_dx0,
+                        rsx_stream_t stream) {
   if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
   if (njobs > CS_MAXJ || D != CS_D || F > CS_FP) return RSX_EUNSUPPORTED;
   if (B == 0) return RSX_OK;
@@ -1620,7 +1693,22 @@ extern "C" int rsx_cin_split_bwd_dw(const float* X0, const rsx_cin_dw_job* jobs_
     }
   }
   const size_t lds = (w.x0l && x0_bytes > red_bytes) ? x0_bytes : red_bytes;
-  const unsigned grid = (unsigned)tiles + (unsigned)njobs;
+  if (nparts > 0) {                                 // the dX0 reduce rides along: what the tiles leave of 256 CUs, at least 8 workgroups
+    for (int j = 0; j < nparts; ++j) {
+      w.red_parts[j] = parts_h[j];
+      w.red_tiles[j] = tiles_h[j];
+    }
+    w.red_njobs = nparts;
+    w.red_acc = acc_dx0;
+    w.red_dX0 = dX0;
+    w.red_n4 = (unsigned long long)B * F * CS_D / 4;
+    const int used = (tiles + njobs) % 256;
+    int rb = used == 0 ? 8 : 256 - used;
+    if (rb < 8) rb = 8;
+    const unsigned long long need = (w.red_n4 + 511) / 512;
+    w.red_blocks = (unsigned long long)rb < need ? rb : (int)need;
+  }
+  const unsigned grid = (unsigned)tiles + (unsigned)njobs + (unsigned)w.red_blocks;
 #define RSX_CS_DW(NS_)                                                       \
   {                                                                          \
     const int rc = opt_in_lds(cin_split_dw_k<NS_>, lds);                     \

@@ -5,69 +5,19 @@
 // fields first, then the rows of BOTH table sets and the first-order weights -- all unconditional on clamped field indices.
 // HBM-bound: 4 B of id + 2 x D*4 B of rows read, 2 x D*4 B written per (example, field).
 #include "rsx_common.h"
+#include "gather_two_device.h"
 
 template <int D>
-__global__ void gather_two_fwd_k(const float* __restrict__ tables1, const float* __restrict__ w1,
-                                 const float* __restrict__ tables2, const int32_t* __restrict__ row_off,
-                                 const int32_t* __restrict__ ids, const float* __restrict__ num_x,
-                                 const float* __restrict__ num_w, float* __restrict__ E1, float* __restrict__ E2,
-                                 float* __restrict__ y1, uint64_t w1_mask, int B, int F, int ND) {
-  constexpr int LPR = D / 4;
-  constexpr int PPP = RSX_WAVE / LPR;
+__global__ void gather_two_fwd_k(const GatherTwoArgs g) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const int q = lane % LPR, j = lane / LPR;
-  const float4* __restrict__ T1 = reinterpret_cast<const float4*>(tables1);
-  const float4* __restrict__ T2 = reinterpret_cast<const float4*>(tables2);
-  float4* __restrict__ O1 = reinterpret_cast<float4*>(E1);
-  float4* __restrict__ O2 = reinterpret_cast<float4*>(E2);
-  const int32_t* idb = ids + (size_t)b * F;
-  // numeric part of the linear net: lanes 0 .. ND-1 hold one product each (ND <= 64), added in the final butterfly
-  float a1 = 0.f;
-  {
-    const int c = lane < ND ? lane : 0;
-    const float x = num_x[(size_t)b * ND + c], w = num_w[c];
-    a1 = lane < ND ? x * w : 0.f;
-  }
-  for (int f0 = j; f0 < F; f0 += 4 * PPP) {
-    int row[4];
-    bool ok[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int f = f0 + k * PPP;
-      ok[k] = f < F;
-      const int fc = ok[k] ? f : F - 1;
-      row[k] = row_off[fc] + idb[fc];
-    }
-    float4 e1[4], e2[4];
-    float wv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      e1[k] = T1[(size_t)row[k] * LPR + q];
-      e2[k] = T2[(size_t)row[k] * LPR + q];
-      wv[k] = w1[row[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int f = f0 + k * PPP;
-      if (ok[k]) {
-        O1[((size_t)b * F + f) * LPR + q] = e1[k];
-        O2[((size_t)b * F + f) * LPR + q] = e2[k];
-        if (q == 0 && ((w1_mask >> f) & 1ull)) a1 += wv[k];
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 1; m < RSX_WAVE; m <<= 1) a1 += __shfl_xor(a1, m);
-  if (lane == 0) y1[b] = a1;
+  if (b >= g.B) return;
+  gather_two_example<D>(g, b, lane);
 }
 
 template <int D>
-static void launch_two(dim3 grid, dim3 block, hipStream_t st, const float* t1, const float* w1, const float* t2,
-                       const int32_t* row_off, const int32_t* ids, const float* nx, const float* nw, float* E1, float* E2,
-                       float* y1, uint64_t mask, int B, int F, int ND) {
-  RSX_COUNT_LAUNCH(); gather_two_fwd_k<D><<<grid, block, 0, st>>>(t1, w1, t2, row_off, ids, nx, nw, E1, E2, y1, mask, B, F, ND);
+static void launch_two(dim3 grid, dim3 block, hipStream_t st, const GatherTwoArgs& g) {
+  RSX_COUNT_LAUNCH(); gather_two_fwd_k<D><<<grid, block, 0, st>>>(g);
 }
 
 extern "C" int rsx_gather_two_fwd(const float* tables1, const float* w1, const float* tables2, const int32_t* row_off,
@@ -79,12 +29,13 @@ extern "C" int rsx_gather_two_fwd(const float* tables1, const float* w1, const f
   if (!tables1 || !w1 || !tables2 || !row_off || !ids || !num_x || !num_w || !E1 || !E2 || !y1) return RSX_EINVAL;
   const int waves = B >= 2048 ? 4 : 1;  // small batches: one wave per workgroup spreads over all 256 CUs
   const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+  const GatherTwoArgs g{tables1, w1, tables2, row_off, ids, num_x, num_w, E1, E2, y1, w1_field_mask, B, F, ND};
   switch (D) {
-    case 4: launch_two<4>(grid, block, rsx_s(stream), tables1, w1, tables2, row_off, ids, num_x, num_w, E1, E2, y1, w1_field_mask, B, F, ND); break;
-    case 8: launch_two<8>(grid, block, rsx_s(stream), tables1, w1, tables2, row_off, ids, num_x, num_w, E1, E2, y1, w1_field_mask, B, F, ND); break;
-    case 16: launch_two<16>(grid, block, rsx_s(stream), tables1, w1, tables2, row_off, ids, num_x, num_w, E1, E2, y1, w1_field_mask, B, F, ND); break;
-    case 32: launch_two<32>(grid, block, rsx_s(stream), tables1, w1, tables2, row_off, ids, num_x, num_w, E1, E2, y1, w1_field_mask, B, F, ND); break;
-    default: launch_two<64>(grid, block, rsx_s(stream), tables1, w1, tables2, row_off, ids, num_x, num_w, E1, E2, y1, w1_field_mask, B, F, ND); break;
+    case 4: launch_two<4>(grid, block, rsx_s(stream), g); break;
+    case 8: launch_two<8>(grid, block, rsx_s(stream), g); break;
+    case 16: launch_two<16>(grid, block, rsx_s(stream), g); break;
+    case 32: launch_two<32>(grid, block, rsx_s(stream), g); break;
+    default: launch_two<64>(grid, block, rsx_s(stream), g); break;
   }
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -1381,15 +1381,26 @@ class CinNet:
         self._outs_h = (C.c_void_p * self.L)(*[o.data_ptr() for o in self.outs])
         self.offs = [sum(self.sizes[:k]) for k in range(self.L)]
 
-    def forward(self, X0, P, sweeps=None):
+    def gather_ride_ok(self):
+        """xdeepfm.py's lookup (rsx_gather_two_fwd) can ride in this net's filter-preparation launch (RSX_CIN_GATHER_RIDE=0: two
+        launches, A/B runs)."""
+        return bool(self.split) and self.D == 16 and os.environ.get("RSX_CIN_GATHER_RIDE", "1") != "0"
+
+    def forward(self, X0, P, sweeps=None, gather_job=None):
         """X0 [B,F,D] contiguous -> cin_y [B] (view of an internal buffer).  sweeps[k]: slice of the untouched-row
         optimizer sweep carried by layer k's forward launch."""
         B = X0.shape[0]
         Xk, H = X0, self.F
-        if self.split:    # the split operand images of all layers' filters: one launch
+        if self.split:    # the split operand images of all layers' filters: one launch (+ the caller's lookup as its rider)
             W_h = (C.c_void_p * self.L)(*[P[f"cin.W{k}"].data_ptr() for k in range(self.L)])
-            check(lib().rsx_cin_split_prep(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, self.split, _stream()),
-                  "rsx_cin_split_prep")
+            if gather_job is not None:
+                check(lib().rsx_cin_split_prep_gather(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, self.split,
+                                                      C.byref(gather_job), _stream()), "rsx_cin_split_prep_gather")
+            else:
+                check(lib().rsx_cin_split_prep(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, self.split, _stream()),
+                      "rsx_cin_split_prep")
+        else:
+            assert gather_job is None, "CinNet.forward: a lookup can only ride in the split-operand prep launch (gather_ride_ok)"
         if self.bf16:     # the bf16 operand images of all layers' filters: one launch
             W_h = (C.c_void_p * self.L)(*[P[f"cin.W{k}"].data_ptr() for k in range(self.L)])
             check(lib().rsx_cin_prep_bf16_multi(W_h, self._w16_h, self._H_h, self._sizes_h, self.L, self.F, _stream()),
@@ -1461,10 +1472,12 @@ class CinNet:
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
                                           self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
+        fuse_red = bool(self.split) and os.environ.get("RSX_CIN_DX0_RIDE", "1") != "0"     # (0: the reduce as its own launch, A/B)
         if wide or self.split:  # dX0 = layer 0's dXk (already there) + every layer's tile partials, last layer first
             parts_h = (C.c_void_p * L)(*[self.dx0_parts[k].data_ptr() for k in range(L - 1, -1, -1)])
-            check(lib().rsx_cin_dx0_reduce(parts_h, self._tiles_h, L, _ptr(dX0), 1, B, self.F, self.D, _stream()),
-                  "rsx_cin_dx0_reduce")
+            if not fuse_red:
+                check(lib().rsx_cin_dx0_reduce(parts_h, self._tiles_h, L, _ptr(dX0), 1, B, self.F, self.D, _stream()),
+                      "rsx_cin_dx0_reduce")
         if self.bf16 or self.split:     # every layer's weight gradient in ONE launch
             jobs = (_lib.CinDwJob * L)()
             for k in range(L):
@@ -1472,6 +1485,10 @@ class CinNet:
                 jobs[k] = _lib.CinDwJob(Xk.data_ptr(), self.ws16[k].data_ptr(), P[f"cin.W{k}"].grad.data_ptr(),
                                         P[f"cin.c{k}"].grad.data_ptr(), H, self.sizes[k], B if (wide or self.split) else 0)
             assert sweeps is None or len(sweeps) == L + 1, "bf16 CinNet.backward: L + 1 sweep slots"
+            if self.split and fuse_red:   # the dX0 reduce rides in the weight-gradient launch (the same sums in the same order)
+                check(lib().rsx_cin_split_bwd_dw_dx0(_ptr(X0), jobs, L, B, self.F, self.D, self.split, parts_h, self._tiles_h, L,
+                                                     _ptr(dX0), 1, _stream()), "rsx_cin_split_bwd_dw_dx0")
+                return dX0[:B]
             if self.split:
                 check(lib().rsx_cin_split_bwd_dw(_ptr(X0), jobs, L, B, self.F, self.D, self.split, _stream()), "rsx_cin_split_bwd_dw")
                 return dX0[:B]

@@ -235,11 +235,18 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
         E1 = torch.empty(B, a1.F * a1.D, device=ids.device)
         E2 = torch.empty(B, a1.F * a1.D, device=ids.device)
         lin_pre = torch.empty(B, device=ids.device)
-        _lib.check(_lib.lib().rsx_gather_two_fwd(_ptr(a1.tables), _ptr(a1.w1), _ptr(a2.tables), _ptr(a1.row_off), _ptr(ids),
-                                                 _ptr(logx.contiguous()), _ptr(P["lin.wnum"]), _ptr(E1), _ptr(E2), _ptr(lin_pre), a1.w1_mask,
-                                                 B, a1.F, a1.D, logx.shape[1], _stream()), "rsx_gather_two_fwd")
+        logx_g = logx.contiguous()
+        gjob = None
+        if store.cin.gather_ride_ok():    # the lookup rides in the CIN's filter-preparation launch (one launch less on the chain)
+            gjob = _lib.GatherTwoJob(a1.tables.data_ptr(), a1.w1.data_ptr(), a2.tables.data_ptr(), a1.row_off.data_ptr(), ids.data_ptr(),
+                                     logx_g.data_ptr(), P["lin.wnum"].data_ptr(), E1.data_ptr(), E2.data_ptr(), lin_pre.data_ptr(),
+                                     a1.w1_mask, B, a1.F, a1.D, logx.shape[1])
+        else:
+            _lib.check(_lib.lib().rsx_gather_two_fwd(_ptr(a1.tables), _ptr(a1.w1), _ptr(a2.tables), _ptr(a1.row_off), _ptr(ids),
+                                                     _ptr(logx_g), _ptr(P["lin.wnum"]), _ptr(E1), _ptr(E2), _ptr(lin_pre), a1.w1_mask,
+                                                     B, a1.F, a1.D, logx.shape[1], _stream()), "rsx_gather_two_fwd")
         X0 = E1.view(B, a1.F, a1.D)
-        cin_y = store.cin.forward(X0, P, None if sweeps is None else sweeps[:L])                                   # 'cin_net' (:135-182), csrc/cin.hip
+        cin_y = store.cin.forward(X0, P, None if sweeps is None else sweeps[:L], gather_job=gjob)              # 'cin_net' (:135-182)
         loss, prob, dX2, g_lin, g_cin = store.tower.train_step(
             E2, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=lin_pre, c0="lin.b", s1=cin_y, replicas=dp.world if dp is not None else 1, masks=masks,

@@ -8,8 +8,14 @@ cd $root; mkdir -p gpurun_out
 scripts/gpu.sh prof ${tag}_deepfm_kernel_stats --no_cpu_baseline --no_configs --steps 800 --warmup 96
 scripts/gpu.sh prof ${tag}_fm_kernel_stats --model fm --no_cpu_baseline --no_configs --steps 800 --warmup 96
 scripts/gpu.sh prof ${tag}_dcn_kernel_stats --model dcn --no_cpu_baseline --no_configs --steps 320 --warmup 32
-scripts/gpu.sh prof ${tag}_xdeepfm_f32_kernel_stats --model xdeepfm --no_cpu_baseline --no_configs --steps 320 --warmup 32
+scripts/gpu.sh prof ${tag}_xdeepfm_f32_kernel_stats --model xdeepfm --cin_split 0 --no_cpu_baseline --no_configs --steps 320 --warmup 32
 scripts/gpu.sh prof ${tag}_xdeepfm_bf16_kernel_stats --model xdeepfm --cin_bf16 --no_cpu_baseline --no_configs --steps 320 --warmup 32
+# the split-operand CIN modes: 4 = xdeepfm.py's default (two fp16 planes fwd / dX, three bf16 planes dW), 3 = three bf16 planes
+scripts/gpu.sh prof ${tag}_xdeepfm_x4_kernel_stats --model xdeepfm --cin_split 4 --no_cpu_baseline --no_configs --steps 320 --warmup 32
+scripts/gpu.sh prof ${tag}_xdeepfm_x3_kernel_stats --model xdeepfm --cin_split 3 --no_cpu_baseline --no_configs --steps 320 --warmup 32
+scripts/gpu.sh pmc ${tag}_MFMA_BUSY_xdeepfm_x4 "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" --model xdeepfm --cin_split 4 --no_configs --no_cpu_baseline --steps 32 --warmup 16
+scripts/gpu.sh pmc ${tag}_MFMA_BUSY_xdeepfm_x3 "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" --model xdeepfm --cin_split 3 --no_configs --no_cpu_baseline --steps 32 --warmup 16
+python scripts/cin_split_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/${tag}_cin_split_probe.txt
 scripts/gpu.sh prof ${tag}_din_kernel_stats --model din --no_cpu_baseline --no_configs --steps 160 --warmup 16
 TAG=${tag}_default scripts/gpu.sh bench
 TAG=${tag}_steps20 scripts/gpu.sh bench --steps 20

@@ -259,6 +259,12 @@ def test_round5_cin_entry_points_reject_bad_arguments(L):
     assert L.rsx_cin_split_bwd_dw(P, jobs, 1, 0, 39, 16, 3, None) == OK
     bad = (_lib.CinDwJob * 1)(_lib.CinDwJob(0x1000, 0, 0x3000, 0x4000, 128, 128, 0))
     assert L.rsx_cin_split_bwd_dw(P, bad, 1, 4, 39, 16, 3, None) == EINVAL                                    # no workspace
+    parts, tl = (C.c_void_p * 1)(0x1000), (C.c_int32 * 1)(8)
+    assert L.rsx_cin_split_bwd_dw_dx0(P, jobs, 1, 0, 39, 16, 3, parts, tl, 1, P, 1, None) == OK               # empty batch
+    assert L.rsx_cin_split_bwd_dw_dx0(P, jobs, 1, 4, 39, 16, 3, None, tl, 1, P, 1, None) == EINVAL
+    assert L.rsx_cin_split_bwd_dw_dx0(P, jobs, 1, 4, 39, 16, 3, parts, tl, 1, None, 1, None) == EINVAL        # no dX0
+    assert L.rsx_cin_split_bwd_dw_dx0(P, jobs, 1, 4, 39, 16, 3, parts, tl, 5, P, 1, None) == EUNSUPPORTED     # > 4 layers of partials
+    assert L.rsx_cin_split_bwd_dw_dx0(P, jobs, 1, 4, 39, 16, 3, (C.c_void_p * 1)(0), tl, 1, P, 1, None) == EINVAL
     # the bf16 weight-gradient launch checks the workspace convention it is told
     j2 = (_lib.CinDwJob * 1)(_lib.CinDwJob(0x1000, 0x2000, 0x3000, 0x4000, 128, 128, 3))
     assert L.rsx_cin_bwd_dw_bf16(P, j2, 1, 4, 39, 16, None, None) == EINVAL                                   # dc_rows neither 0 nor B

@@ -142,6 +142,19 @@ def test_cin_split_backward(B, F, H, N, first, gs, acc, ns):
         assert np.isfinite(got[k]).all(), k
         err = _rel(got[k], ref[k])
         assert err < BTOL[ns], (k, err)
+    # the dX0 reduce riding in the weight-gradient launch (rsx_cin_split_bwd_dw_dx0): the same sums in the same order -> the same bits
+    dX0b = torch.full((B, F, 16), 0.5 if a else float("nan"), device="cuda")
+    dXkb = dX0b if first else torch.full((B, H, 16), 0.25 if acc else float("nan"), device="cuda")
+    dWb, dcb = torch.full_like(tW, float("nan")), torch.full_like(tc, float("nan"))
+    pt.fill_(float("nan"))
+    check(lib().rsx_cin_split_bwd_dx(_ptr(tX0), _ptr(tXk), _ptr(w16), _ptr(out), _ptr(tdout), _ptr(tgs) if gs else None,
+                                     _ptr(twout) if gs else None, _ptr(dXkb), a, _ptr(pt), _ptr(ws), B, F, H, N, 16, ns, _stream()))
+    jobb = (_lib.CinDwJob * 1)(_lib.CinDwJob(tXk.data_ptr(), ws.data_ptr(), dWb.data_ptr(), dcb.data_ptr(), H, N, B))
+    check(lib().rsx_cin_split_bwd_dw_dx0(_ptr(tX0), jobb, 1, B, F, 16, ns, (C.c_void_p * 1)(pt.data_ptr()),
+                                         (C.c_int32 * 1)((H + 15) // 16), 1, _ptr(dX0b), a, _stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(dX0b.cpu().numpy(), got["dX0"]) and np.array_equal(dWb.cpu().numpy(), got["dW"])
+    assert np.array_equal(dcb.cpu().numpy(), got["dc"]) and np.array_equal(dXkb.cpu().numpy(), got["dXk"])
 
 
 @pytest.mark.parametrize("ns", [4, 3])
