@@ -697,23 +697,50 @@ __global__ __launch_bounds__(512, 1) void cin_split_fwd8_k(const CsFwdArgs p) {
 // Filter images of mode 4: CS_H2_PARTS workgroups per (layer, field) -- the field's largest |W| (a power-of-two scale puts it at 2^14; its
 // inverse goes to winv[f]), then both fragment-major images of the field as two fp16 planes of W * scale.
 constexpr int CS_H2_PARTS = 4;                     // workgroups per (layer, field): each finds the field's maximum, converts a quarter
+// value j of operand quad lq of field Wf in layout `first` (W16: h = 16 t + (lane & 15), n = 32 ks + 8 (lane >> 4) + j; Wt16:
+// n = 16 t + (lane & 15), h = 32 ks + 8 (lane >> 4) + j): clamped address + the mask the loaded value is multiplied by
+__device__ __forceinline__ const float* cs_h2_src(const CsPrepJob& jb, const float* Wf, bool first, int lq, int j, float& m) {
+  const int lane = lq & 63, r = lq >> 6;
+  const int KS = first ? jb.Np >> 5 : jb.Hp >> 5;
+  const int ks = r % KS, t = r / KS;
+  const int a = 16 * t + (lane & 15), c = 32 * ks + 8 * (lane >> 4) + j;
+  const int h = first ? a : c, n = first ? c : a;
+  m = (h < jb.H && n < jb.N) ? 1.f : 0.f;
+  return Wf + (size_t)(h < jb.H ? h : jb.H - 1) * jb.N + (n < jb.N ? n : jb.N - 1);
+}
 __global__ __launch_bounds__(256) void cin_split_prep_h2_k(const CsPrepArgs p) {
   __shared__ float red[4];
   if (cs_prep_gather_role(p)) return;
   const int bid = (int)blockIdx.x - p.n_gather;
   const int part = bid % CS_H2_PARTS, lf = bid / CS_H2_PARTS;
   const int ji = lf / p.F, f = lf % p.F;
-  const CsPrepJob& jb = p.job[ji];
+  CsPrepJob jb = p.job[0];                         // (compile-time indices into the by-value parameter: a dynamic one goes through scratch)
+#pragma unroll
+  for (int k = 1; k < CS_MAXJ; ++k)
+    if (ji == k) jb = p.job[k];
   const int tid = threadIdx.x;
   const float* Wf = jb.W + (size_t)f * jb.H * jb.N;
   const int tot = jb.H * jb.N;
+  // the field's largest |W|: ONE memory round trip (64 elements per thread requested together; the filters were written by the
+  // previous step's optimizer launch and come from HBM)
   float mx = 0.f;
-  for (int e0 = tid; e0 < tot; e0 += 256 * 16) {   // 16 loads in flight per thread
-    float t[16];
+  if ((tot & 3) == 0 && (reinterpret_cast<uintptr_t>(Wf) & 15) == 0) {
+    const int tot4 = tot >> 2;
+    for (int e0 = tid; e0 < tot4; e0 += 256 * 16) {
+      float4 t[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = Wf[e0 + 256 * u < tot ? e0 + 256 * u : tot - 1];
+      for (int u = 0; u < 16; ++u) t[u] = reinterpret_cast<const float4*>(Wf)[e0 + 256 * u < tot4 ? e0 + 256 * u : tot4 - 1];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) mx = fmaxf(mx, fabsf(t[u]));
+      for (int u = 0; u < 16; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(t[u].x), fabsf(t[u].y))), fmaxf(fabsf(t[u].z), fabsf(t[u].w)));
+    }
+  } else {
+    for (int e0 = tid; e0 < tot; e0 += 256 * 16) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = Wf[e0 + 256 * u < tot ? e0 + 256 * u : tot - 1];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) mx = fmaxf(mx, fabsf(t[u]));
+    }
   }
   mx = cs_wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -724,38 +751,36 @@ __global__ __launch_bounds__(256) void cin_split_prep_h2_k(const CsPrepArgs p) {
   if (tid == 0 && part == 0) jb.winv[f] = inv;
   const int n1 = (jb.H16 * jb.Np) >> 3, n2 = (jb.N16 * jb.Hp) >> 3;       // quads of this field in the two layouts
   const size_t pl1 = ((size_t)p.F * jb.H16 * jb.Np), pl2 = ((size_t)p.F * jb.N16 * jb.Hp);
-  for (int q = part * 256 + tid; q < n1 + n2; q += 256 * CS_H2_PARTS) {
-    const bool first = q < n1;
-    const int lq = first ? q : q - n1;
-    const int lane = lq & 63;
-    int r = lq >> 6;
-    const int KS = first ? jb.Np >> 5 : jb.Hp >> 5;
-    const int ks = r % KS, t = r / KS;
-    float v[8];
-    if (first) {                                   // W16: h = 16 t + (lane & 15), n = 32 ks + 8 (lane >> 4) + j
-      const int h = 16 * t + (lane & 15), n0 = 32 * ks + 8 * (lane >> 4);
-      const float* src = Wf + (size_t)(h < jb.H ? h : jb.H - 1) * jb.N;
+  // four quads per thread and trip: their 32 loads requested together (L2 hits: the max pass has just read the field)
+  for (int q0 = part * 256 + tid; q0 < n1 + n2; q0 += 4 * 256 * CS_H2_PARTS) {
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * 256 * CS_H2_PARTS;
+      const int qc = q < n1 + n2 ? q : n1 + n2 - 1;
+      const bool first = qc < n1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int n = n0 + j;
-        v[j] = src[n < jb.N ? n : jb.N - 1] * ((h < jb.H && n < jb.N) ? sc : 0.f);
-      }
-    } else {                                       // Wt16: n = 16 t + (lane & 15), h = 32 ks + 8 (lane >> 4) + j
-      const int n = 16 * t + (lane & 15), h0 = 32 * ks + 8 * (lane >> 4);
-      const float* src = Wf + (n < jb.N ? n : jb.N - 1);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int h = h0 + j;
-        v[j] = src[(size_t)(h < jb.H ? h : jb.H - 1) * jb.N] * ((h < jb.H && n < jb.N) ? sc : 0.f);
+        float m;
+        const float* src = cs_h2_src(jb, Wf, first, first ? qc : qc - n1, j, m);
+        v[u][j] = *src * (m * sc);
       }
     }
-    f16x8 o[2];
-    SplitMode<CS_H2>::split(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), o);
-    const size_t fq = first ? (size_t)f * n1 + lq : (size_t)f * n2 + lq;     // quad index inside a plane of the layout
-    bf16_t* dst = (first ? jb.W16 : jb.Wt16) + fq * 8;
-    const size_t plane = first ? pl1 : pl2;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<f16x8*>(dst + (size_t)s2 * plane) = o[s2];
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * 256 * CS_H2_PARTS;
+      if (q < n1 + n2) {
+        const bool first = q < n1;
+        const int lq = first ? q : q - n1;
+        f16x8 o[2];
+        SplitMode<CS_H2>::split(make_float4(v[u][0], v[u][1], v[u][2], v[u][3]), make_float4(v[u][4], v[u][5], v[u][6], v[u][7]), o);
+        const size_t fq = first ? (size_t)f * n1 + lq : (size_t)f * n2 + lq;     // quad index inside a plane of the layout
+        bf16_t* dst = (first ? jb.W16 : jb.Wt16) + fq * 8;
+        const size_t plane = first ? pl1 : pl2;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<f16x8*>(dst + (size_t)s2 * plane) = o[s2];
+      }
+    }
   }
 }
 
