@@ -1526,8 +1526,20 @@ __device__ __forceinline__ void cs_dw_tile(const CsDwArgs& p, const CsDwJob& jb,
         L.dp[s][nt] = *reinterpret_cast<const uint4*>(jb.dpre16 + (size_t)s * dplane + (((size_t)ksc * NT16 + t) * 64 + lane) * 8);
       }
   };
-  auto run = [&](const Ld& L) {
+  // One k-step of a stage, and the stage's NEXT k-step (ksn: two k-steps of this wave ahead) requested piece by piece as its
+  // registers fall free: Xk as soon as the Z factors are formed, the dpre fragments of n tile nt after the last field's MFMAs on
+  // them.  (With whole stages reloaded between the runs a request was one k-step ahead of its use -- ~2 500 cycles with the
+  // SIMD's other wave interleaved, under a loaded L2's round trip: the launch waited for its operands, 45 % MFMA-busy.)
+  auto run = [&](Ld& L, const int ksn) {
     const float4 k0 = f4_scale(L.m, L.xk[0]), k1 = f4_scale(L.m, L.xk[1]);
+    const int bn = 2 * ksn + eb;
+    const int bcn = bn < p.B ? bn : p.B - 1;
+    const int kscn = ksn < nks ? ksn : nks - 1;
+    {
+      const float4* xk = reinterpret_cast<const float4*>(jb.Xk + ((size_t)bcn * H + hc) * CS_D + d0);
+      L.xk[0] = xk[0];
+      L.xk[1] = xk[1];
+    }
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
       const int fx = f0 + ft < p.F ? f0 + ft : p.F - 1;
@@ -1546,16 +1558,23 @@ __device__ __forceinline__ void cs_dw_tile(const CsDwArgs& p, const CsDwJob& jb,
 #pragma unroll
         for (int s = 0; s < NS; ++s) b[s][0] = __builtin_bit_cast(bf16x8, L.dp[s][nt]);
         acc[ft][nt] = split_mma<NS, 1>(a, b, acc[ft][nt]);
+        if (ft == FT - 1) {
+          const int t = ntg + nt < NT16 ? ntg + nt : NT16 - 1;
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            L.dp[s][nt] = *reinterpret_cast<const uint4*>(jb.dpre16 + (size_t)s * dplane + (((size_t)kscn * NT16 + t) * 64 + lane) * 8);
+        }
       }
     }
+    L.bc = bcn;
+    L.m = (bn < p.B && ksn < nks && h < H) ? 1.f : 0.f;
   };
   Ld La, Lb;
   load(wv, La);
+  load(wv + 8, Lb);                               // (clamped + masked past the batch)
   for (int ks = wv; ks < nks; ks += 16) {         // this wave's k-steps: wv, wv + 8, ...
-    load(ks + 8, Lb);                             // (clamped + masked past the batch)
-    run(La);
-    load(ks + 16, La);
-    run(Lb);
+    run(La, ks + 16);
+    run(Lb, ks + 24);
   }
   __syncthreads();                                // (the reduce buffer aliases the X0 slab)
   // partial tiles, fixed order: ((w0 + w4) + (w1 + w5) ... ) as two rounds through one 4-slot LDS buffer
