@@ -116,15 +116,16 @@ struct CsPrepArgs {
   int n_gather;
   GatherTwoArgs gt;
 };
-__device__ __forceinline__ bool cs_prep_gather_role(const CsPrepArgs& p) {     // (256-thread workgroups, D = 16)
-  if ((int)blockIdx.x >= p.n_gather) return false;
-  const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-  if (b < p.gt.B) gather_two_example<16>(p.gt, b, (int)(threadIdx.x & 63));
-  return true;
-}
+// (256-thread workgroups, D = 16; a macro: the fields are read off the kernel's own by-value parameter)
+#define CS_PREP_GATHER_ROLE(P)                                                                \
+  if ((int)blockIdx.x < (P).n_gather) {                                                       \
+    const int b_ = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);                             \
+    if (b_ < (P).gt.B) RSX_GATHER_TWO_EXAMPLE(16, (P).gt, b_, (int)(threadIdx.x & 63));       \
+    return;                                                                                   \
+  }
 template <int NS>
 __global__ __launch_bounds__(256) void cin_split_prep_k(const CsPrepArgs p) {
-  if (cs_prep_gather_role(p)) return;
+  CS_PREP_GATHER_ROLE(p)
   const long long total = p.job[p.njobs - 1].end;           // operand quads (of one plane) over all jobs
   for (long long e = (long long)((int)blockIdx.x - p.n_gather) * 256 + threadIdx.x; e < total; e += (long long)((int)gridDim.x - p.n_gather) * 256) {
     int ji = 0;
@@ -710,7 +711,7 @@ __device__ __forceinline__ const float* cs_h2_src(const CsPrepJob& jb, const flo
 }
 __global__ __launch_bounds__(256) void cin_split_prep_h2_k(const CsPrepArgs p) {
   __shared__ float red[4];
-  if (cs_prep_gather_role(p)) return;
+  CS_PREP_GATHER_ROLE(p)
   const int bid = (int)blockIdx.x - p.n_gather;
   const int part = bid % CS_H2_PARTS, lf = bid / CS_H2_PARTS;
   const int ji = lf / p.F, f = lf % p.F;
@@ -1005,6 +1006,14 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   const int nstep = (p.F + 1) / 2;
   const bool st0 = KSN == 4 && blockIdx.x == 1 && blockIdx.y == 0;
   RSX_STAMP(32, st0); RSX_STAMP_MAX(48, KSN == 4);
+  // The dpre transposition scratch (8 waves x 8 KiB) sits at the END of the ring: the first NE slots' fragments are requested
+  // now and land while the operands are formed, the others once the scratch is free.
+  constexpr int SCR_B = 8 * 128 * CS_D * 4;
+  static_assert(R * SLOTB >= SCR_B, "the ring holds the transposition scratch");
+  constexpr int NE_ = (R * SLOTB - SCR_B) / SLOTB;
+  constexpr int NE = NE_ > R - 1 ? R - 1 : NE_;
+#pragma unroll
+  for (int s = 0; s < NE; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
   const float* dsrc = p.dout ? p.dout : p.out;     // (absent operands read `out` and count zero: no branches around loads)
   const float* gsrc = p.gs ? p.gs : p.out;
   const float* wsrc = p.gs ? p.wout : p.out;
@@ -1026,10 +1035,10 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   float inv_d[2] = {1.f, 1.f};
   {
     // dpre = relu'(out) * (dout + gs * wout) of the wave's two examples: whole rows by coalesced float4 loads (32 KSN per lane,
-    // all requested together), transposed through 8 KiB of LDS per wave (the ring's first 64 KiB: the filter DMA starts after
-    // this block), lane (i, kq) then picks rows n = 32 ks + 8 kq + j of column d = i.  (Fetching the 64 elements per lane straight
+    // all requested together), transposed through 8 KiB of LDS per wave (the ring's last 64 KiB: the filter DMA of those slots
+    // starts after this block), lane (i, kq) then picks rows n = 32 ks + 8 kq + j of column d = i.  (Fetching the 64 elements per lane straight
     // from L2 cost 6-10 us: 4-byte accesses to 64-byte row pieces, re-read by the 8 tiles' workgroups.)
-    float* scr = reinterpret_cast<float*>(ring) + (size_t)wv * (128 * CS_D);
+    float* scr = reinterpret_cast<float*>(ring + (size_t)R * SLOTB - SCR_B) + (size_t)wv * (128 * CS_D);
     float4 o4[2][2 * KSN], g4[2][2 * KSN];
     float wo[2 * KSN], gbv[2];
 #pragma unroll
@@ -1119,8 +1128,9 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   sx.store(sX0, tid);
   __syncthreads();                                 // every wave is done with its transposition scratch: the ring is free
 #pragma unroll
-  for (int s = 0; s < R - 1; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
-  cs_wait_barrier<0>();                            // sX0 and the first R - 1 slots
+  for (int s = NE; s < R - 1; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
+  // sX0 and the slots of steps 0 and 1 (the pieces requested just now may still be in flight when they are not those)
+  cs_wait_barrier<(NE >= 2 ? (R - 1 - NE) * C8::U : 0)>();
   RSX_STAMP(34, st0);
   const char* rd = ring + (size_t)par * FR * 1024 + lane16;
   typename M::quad w[PF];

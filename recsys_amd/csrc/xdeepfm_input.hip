@@ -12,7 +12,7 @@ __global__ void gather_two_fwd_k(const GatherTwoArgs g) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= g.B) return;
-  gather_two_example<D>(g, b, lane);
+  RSX_GATHER_TWO_EXAMPLE(D, g, b, lane);
 }
 
 template <int D>
