@@ -50,6 +50,9 @@ BIT_IDENTICAL = [
     ("din", 64, {"RSX_SCATTER_RIDERS": "0"}),                 # the attention blocks' weight-gradient reduces inside the finish launch
     ("din", 64, {"RSX_DIN_GATHER_RIDE": "0"}),                # the six lookups as their own launch instead of riding in the two prepare launches
     ("din", 64, {"RSX_MLP_REDUCE_RIDE": "0"}),                # the mlp_layer's weight-gradient reduce as its own launch instead of riding in the pooling backward
+    # round 5
+    ("xdeepfm", 128, {"RSX_CIN_GATHER_RIDE": "0"}),           # xdeepfm.py's lookup as its own launch instead of riding in the CIN filter preparation
+    ("xdeepfm", 128, {"RSX_CIN_DX0_RIDE": "0"}),              # the dX0 tile reduce as its own launch instead of riding in the CIN weight-gradient launch
 ]
 ROUNDING = [
     ("fm", 256, {"RSX_FM_FUSE": "0"}),                        # fp64 reduction of the head's dense gradients instead of the grouped fp32 rows
@@ -58,7 +61,12 @@ ROUNDING = [
     ("dcn", 1024, {"RSX_TOWER_BIG": "0"}),                    # the batch-256 tiles for the wide first layer
     ("dcn", 1024, {"RSX_TOWER_DXG_SPLIT": "0"}),
     ("dcn", 1024, {"RSX_TOWER_SB_ROWS": "256"}),              # dW row blocks of 256 instead of 512 rows
-    ("xdeepfm", 128, {"RSX_CIN_DX": "1"}),                    # register form of the CIN dX kernel
+    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "0", "RSX_CIN_DX": "1"}),   # the fp32 MFMA CIN kernels, register form of their dX kernel
+    # round 5: the CIN modes against the default (mode 4: two scaled fp16 planes forward / data gradients)
+    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "0"}),         # the fp32 MFMA kernels of csrc/cin.hip
+    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "3"}),         # three bf16 planes per operand, first-form kernels
+    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "3", "RSX_CIN_SPLIT_V": "2"}),   # .. in the deep-ring kernels
+    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "3", "RSX_CIN_SPLIT_E": "8"}),   # .. first form, 8 examples per workgroup
     # round 4
     ("din", 64, {"RSX_MLP_FUSE": "0"}),                       # din.py's 'mlp_layer' as 8 launches instead of the one-launch form
     ("dcn", 4096, {"RSX_TOWER_BIG_MIN_K_BWD": "256"}),        # the batch-256 backward tiles for the 100-wide layer at batch 4 096
