@@ -961,6 +961,9 @@ int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w16, const f
  * written or accumulated, dX0 left as one partial per 16-wide tile of h in dx0_parts [ceil(H/16)][B][F*16] for
  * rsx_cin_dx0_reduce); it also leaves dpre = relu'(out) * (dout + gs * wout) -- ns planes of operand fragments -- and the
  * bias gradient's per-example partial sums in ws (rsx_cin_split_bwd_workspace_bytes(B, N, ns) bytes, one buffer per layer).
+ * acc_dxk = 2 (H == F, the first layer, whose dXk IS dX0 [B, F, D]; ns = 4): the fields are split over TWO workgroups per tile
+ * of h; the first half writes dXk, the second half's share goes to dx0_parts tile ceil(H/16) -- one more [B][F*16] partial the
+ * caller allocates behind the tiles and hands to the reduce.
  * rsx_cin_split_bwd_dw: dW [F*H, N] and dc [N] of several layers in ONE launch from those workspaces (rsx_cin_dw_job with
  * ws = the layer's workspace; dc_rows is ignored); the products X0 * Xk are formed in fp32, rounded once and split.    */
 size_t rsx_cin_split_bwd_workspace_bytes(int B, int N, int ns);

@@ -999,11 +999,17 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   const int par = wv & 1, e0 = (wv >> 1) * 2;
-  const int ht = blockIdx.x, b0 = blockIdx.y * E;
+  // acc_dxk == 2 (layer 0, dXk IS dX0 [B, F, 16]): TWO workgroups per (tile, examples) split the fields -- with three tiles of h
+  // the launch otherwise fills 96 of 256 CUs; the second half's share of dXk goes to dx0_parts tile HT, which the reduce adds
+  const int HT = p.H16 >> 4;
+  const int ht = (int)blockIdx.x % HT, half = (int)blockIdx.x / HT, b0 = blockIdx.y * E;
   const uint32_t fstrideB = (uint32_t)p.H16 * p.Np * 2u, planeB = (uint32_t)p.F * fstrideB;
   const char* img = reinterpret_cast<const char*>(p.W16) + (size_t)ht * KSN * 1024;
   const uint32_t ring_lds = (uint32_t)(uintptr_t)ring, lane16 = (uint32_t)lane * 16u;
-  const int nstep = (p.F + 1) / 2;
+  const int nstep_all = (p.F + 1) / 2;
+  const int nhalf = p.acc_dxk == 2 ? (nstep_all + 1) / 2 : nstep_all;
+  const int sbase = half * nhalf;                                   // this workgroup's steps: sbase .. sbase + nstep - 1
+  const int nstep = nstep_all - sbase < nhalf ? nstep_all - sbase : nhalf;
   const bool st0 = KSN == 4 && blockIdx.x == 1 && blockIdx.y == 0;
   RSX_STAMP(32, st0); RSX_STAMP_MAX(48, KSN == 4);
   // The dpre transposition scratch (8 waves x 8 KiB) sits at the END of the ring: the first NE slots' fragments are requested
@@ -1013,7 +1019,7 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   constexpr int NE_ = (R * SLOTB - SCR_B) / SLOTB;
   constexpr int NE = NE_ > R - 1 ? R - 1 : NE_;
 #pragma unroll
-  for (int s = 0; s < NE; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
+  for (int s = 0; s < NE; ++s) C8::issue(img, fstrideB, planeB, sbase + (s < nstep ? s : nstep - 1), p.F, wv, lane16, ring_lds + s * SLOTB);
   const float* dsrc = p.dout ? p.dout : p.out;     // (absent operands read `out` and count zero: no branches around loads)
   const float* gsrc = p.gs ? p.gs : p.out;
   const float* wsrc = p.gs ? p.wout : p.out;
@@ -1093,7 +1099,7 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
       }
     }
   }
-  if (ht == 0) {   // (workgroup-uniform) the weight-gradient launch's operands (THREE bf16 planes in every mode) and the bias
+  if (ht == 0 && half == 0) {   // (workgroup-uniform) the weight-gradient launch's operands (THREE bf16 planes in every mode) and the bias
                    // gradient's per-example partials: item = (example, row n, quarter of d), rows past N16 are not stored
     const size_t dplane = (size_t)((p.B + 1) / 2) * 2 * p.N16 * CS_D;
     const int items = E * p.N16 * 4;
@@ -1128,7 +1134,7 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   sx.store(sX0, tid);
   __syncthreads();                                 // every wave is done with its transposition scratch: the ring is free
 #pragma unroll
-  for (int s = NE; s < R - 1; ++s) C8::issue(img, fstrideB, planeB, s < nstep ? s : nstep - 1, p.F, wv, lane16, ring_lds + s * SLOTB);
+  for (int s = NE; s < R - 1; ++s) C8::issue(img, fstrideB, planeB, sbase + (s < nstep ? s : nstep - 1), p.F, wv, lane16, ring_lds + s * SLOTB);
   // sX0 and the slots of steps 0 and 1 (the pieces requested just now may still be in flight when they are not those)
   cs_wait_barrier<(NE >= 2 ? (R - 1 - NE) * C8::U : 0)>();
   RSX_STAMP(34, st0);
@@ -1142,8 +1148,8 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   for (int st = 0; st < nstep; ++st) {
     const int sln = sl + 1 == R ? 0 : sl + 1, slp = sl == 0 ? R - 1 : sl - 1;
     const int stn = st + R - 1 < nstep ? st + R - 1 : nstep - 1;
-    CS_DBG_LOAD(C8::issue(img, fstrideB, planeB, stn, p.F, wv, lane16, ring_lds + slp * SLOTB);)
-    const int f_ = 2 * st + par;
+    CS_DBG_LOAD(C8::issue(img, fstrideB, planeB, sbase + stn, p.F, wv, lane16, ring_lds + slp * SLOTB);)
+    const int f_ = 2 * (sbase + st) + par;
     float x[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) x[e] = sX0[((e0 + e) * CS_FP + f_) * CS_D + i];
@@ -1176,10 +1182,14 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
   for (int e = 0; e < 2; ++e)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sR[((wv * 2 + e) * 4 + r) * 64 + lane] = dxk[e][r];
-  for (int e4 = tid; e4 < E * p.F * 4; e4 += NTHR) {        // this tile's share of dX0
-    const int ex = e4 / (p.F * 4), r = e4 - ex * (p.F * 4);
-    if (b0 + ex < p.B)
-      reinterpret_cast<float4*>(p.dx0_parts + ((size_t)ht * p.B + b0 + ex) * p.F * CS_D)[r] = reinterpret_cast<const float4*>(sP + ex * CS_FP * CS_D)[r];
+  {   // this tile's share of dX0: the fields of this workgroup's steps
+    const int fa = 2 * sbase, fb = 2 * (sbase + nstep) < p.F ? 2 * (sbase + nstep) : p.F;
+    const int nf4 = (fb - fa) * 4;
+    for (int e4 = tid; e4 < E * nf4; e4 += NTHR) {
+      const int ex = e4 / nf4, r = fa * 4 + (e4 - ex * nf4);
+      if (b0 + ex < p.B)
+        reinterpret_cast<float4*>(p.dx0_parts + ((size_t)ht * p.B + b0 + ex) * p.F * CS_D)[r] = reinterpret_cast<const float4*>(sP + ex * CS_FP * CS_D)[r];
+    }
   }
   __syncthreads();
   {   // wave w finishes example w: dXk[b][h = 16 ht + 4 kq + r][d = i] = even fields' share + odd fields' share
@@ -1190,8 +1200,12 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
       const float s = sR[((w0i * 2 + sl2) * 4 + r) * 64 + lane] + sR[(((w0i + 1) * 2 + sl2) * 4 + r) * 64 + lane];
       const int h = 16 * ht + 4 * kq + r;
       if (b < p.B && h < p.H) {
-        float* dst = p.dXk + ((size_t)b * p.H + h) * CS_D + i;
-        *dst = p.acc_dxk ? *dst + s : s;
+        if (half == 0) {
+          float* dst = p.dXk + ((size_t)b * p.H + h) * CS_D + i;
+          *dst = p.acc_dxk == 1 ? *dst + s : s;
+        } else {                                   // (H == F: a row of dXk is a row of dX0)
+          p.dx0_parts[((size_t)HT * p.B + b) * p.F * CS_D + (size_t)h * CS_D + i] = s;
+        }
       }
     }
   }
@@ -1265,7 +1279,7 @@ int launch_fwd8_ns(const CsFwdArgs& a, hipStream_t stream) {
 template <int MODE, int KSN>
 int launch_dx8(const CsDxArgs& a, hipStream_t stream) {
   using M = SplitMode<MODE>;
-  const dim3 grid((unsigned)(a.H16 / 16), (unsigned)((a.B + 7) / 8));
+  const dim3 grid((unsigned)(a.H16 / 16) * (a.acc_dxk == 2 ? 2u : 1u), (unsigned)((a.B + 7) / 8));
   const size_t lds = Cs8<M::NS, KSN, 8 * CS_FP * CS_D * 4 + (M::SCALED ? 256 : 0)>::TOTAL;
   const int rc = opt_in_lds(cin_split_dx8_k<MODE, KSN>, lds);
   if (rc != RSX_OK) return rc;
@@ -1420,6 +1434,9 @@ extern "C" int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void
   if (!X0 || !Xk || !w16 || !out || !dXk || !dx0_parts || !ws) return RSX_EINVAL;
   if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
   if (D != CS_D || H > 128 || N > 128 || F > CS_FP) return RSX_EUNSUPPORTED;
+  if (acc_dxk < 0 || acc_dxk > 2) return RSX_EINVAL;
+  // acc_dxk = 2: the fields split over two workgroups per tile, the second half's dXk in dx0_parts tile ceil(H/16) (H == F, deep-ring kernels)
+  if (acc_dxk == 2 && (H != F || cs_version(ns) != 2)) return RSX_EUNSUPPORTED;
   const int H16 = rup(H, 16), N16 = rup(N, 16), Np = rup(N, 32);
   const int dwp = cs_dw_planes(ns);
   float* dc_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)dwp * ((B + 1) / 2) * 2 * N16 * CS_D * 2);

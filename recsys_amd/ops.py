@@ -1350,8 +1350,16 @@ class CinNet:
                          for n in self.sizes]
             self._w16_h = (C.c_void_p * self.L)(*[w.data_ptr() for w in self.w16])
             self._H_h = (C.c_int32 * self.L)(*hs16)
-            self.dx0_parts = [torch.empty(int(lib().rsx_cin_bf16_dx0_parts_floats(capacity, F, h)), device=dev) for h in hs16]
-            self._tiles_h = (C.c_int32 * self.L)(*[(h + 15) // 16 for h in hs16][::-1])
+            # layer 0 in mode 4 (dXk IS dX0; a few tiles of h only): its data-gradient launch splits the FIELDS over two workgroups
+            # per tile when both fit the CUs in one round; the second half's dXk is one more tile partial (RSX_CIN_DX_FSPLIT=0: off)
+            ht0 = (hs16[0] + 15) // 16
+            self.fsplit0 = (ns == 4 and os.environ.get("RSX_CIN_DX_FSPLIT", "1") != "0" and
+                            2 * ht0 * ((capacity + 7) // 8) <= 256)
+            extra = [capacity * F * D if (k == 0 and self.fsplit0) else 0 for k in range(self.L)]
+            self.dx0_parts = [torch.empty(int(lib().rsx_cin_bf16_dx0_parts_floats(capacity, F, h)) + x, device=dev)
+                              for h, x in zip(hs16, extra)]
+            self._tiles_h = (C.c_int32 * self.L)(*[(h + 15) // 16 + (1 if (k == 0 and self.fsplit0) else 0)
+                                                   for k, h in enumerate(hs16)][::-1])
         # bf16=True: the contraction runs on the bf16 MFMA path (csrc/cin_bf16.hip: Xk / W / dpre rounded to bf16, fp32
         # accumulation) -- NOT the parity path; fp32 (False) is the default everywhere
         self.bf16 = bool(bf16)
@@ -1449,7 +1457,8 @@ class CinNet:
             if self.split:
                 assert sweeps is None or all(x is None for x in sweeps), "the split-operand CIN launches carry no sweep slices"
                 check(lib().rsx_cin_split_bwd_dx(_ptr(X0), _ptr(Xk), _ptr(self.w16[k]), _ptr(self.outs[k]), dout, _ptr(self.gs),
-                                                 C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), 0, _ptr(self.dx0_parts[k]),
+                                                 C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), 2 if (k == 0 and self.fsplit0) else 0,
+                                                 _ptr(self.dx0_parts[k]),
                                                  _ptr(self.ws16[k]), B, self.F, H, self.sizes[k], self.D, self.split, _stream()),
                       "rsx_cin_split_bwd_dx")
                 continue

@@ -187,3 +187,48 @@ def test_cin_split_forward_wide_dynamic_range(ns):
     err = float((np.abs(got - ref) / mag.max(axis=(1, 2), keepdims=True)).max())
     print("ns=%d wide range: max |err| / max_b sum |terms| = %.3g" % (ns, err))
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("B,F,N,gs", [(256, 39, 128, False), (250, 39, 128, True), (7, 5, 20, True), (64, 40, 48, False), (9, 17, 33, True)])
+def test_cin_split_first_layer_field_split(B, F, N, gs):
+    """Mode 4, first layer (H = F, dXk IS dX0): rsx_cin_split_bwd_dx with acc_dxk = 2 splits the fields over two workgroups per tile
+    of h; the second half's dXk arrives as one more tile partial.  Same sums, one association different: against the unsplit
+    launch within fp32 rounding of dX0's largest element, and against the fp64 gradients at the backward tolerance."""
+    from recsys_amd.ops import _ptr, _stream, check, lib
+    ns, H = 4, F
+    X0, _, W, c = _inputs(B, F, H, N, B * 3 + F, True)
+    rng = np.random.default_rng(B + 5)
+    dout = rng.standard_normal((B, N, 16)).astype(np.float32)
+    gsv = rng.standard_normal(B).astype(np.float32)
+    wout = rng.standard_normal(N).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    tX0, tW, tc, tdout, tgs, twout = t(X0), t(W), t(c), t(dout), t(gsv), t(wout)
+    w16 = torch.empty(int(lib().rsx_cin_split_weight_elems(F, H, N, ns)), dtype=torch.int16, device="cuda")
+    ws = torch.empty(int(lib().rsx_cin_split_bwd_workspace_bytes(B, N, ns)), dtype=torch.uint8, device="cuda")
+    out = torch.empty(B, N, 16, device="cuda")
+    check(lib().rsx_cin_split_prep((C.c_void_p * 1)(tW.data_ptr()), (C.c_void_p * 1)(w16.data_ptr()), (C.c_int32 * 1)(H),
+                                   (C.c_int32 * 1)(N), 1, F, ns, _stream()))
+    check(lib().rsx_cin_split_fwd(_ptr(tX0), _ptr(tX0), _ptr(w16), _ptr(tc), _ptr(out), B, F, H, N, 16, ns, _stream()))
+    HT = (H + 15) // 16
+    res = []
+    for mode in (0, 2):
+        dX0 = torch.full((B, F, 16), float("nan"), device="cuda")
+        pt = torch.full((int(lib().rsx_cin_bf16_dx0_parts_floats(B, F, H)) + B * F * 16,), float("nan"), device="cuda")
+        check(lib().rsx_cin_split_bwd_dx(_ptr(tX0), _ptr(tX0), _ptr(w16), _ptr(out), _ptr(tdout), _ptr(tgs) if gs else None,
+                                         _ptr(twout) if gs else None, _ptr(dX0), mode, _ptr(pt), _ptr(ws), B, F, H, N, 16, ns, _stream()))
+        check(lib().rsx_cin_dx0_reduce((C.c_void_p * 1)(pt.data_ptr()), (C.c_int32 * 1)(HT + (1 if mode == 2 else 0)), 1, _ptr(dX0), 1,
+                                       B, F, 16, _stream()))
+        torch.cuda.synchronize()
+        res.append(dX0.cpu().numpy())
+    assert np.isfinite(res[1]).all()
+    assert _rel(res[1], res[0]) < 1e-6, _rel(res[1], res[0])
+    f8 = np.float64
+    g = dout.astype(f8) + (gsv[:, None, None] * wout[None, :, None] if gs else 0.0)
+    dpre = g * (out.cpu().numpy() > 0)
+    W3 = W.astype(f8).reshape(F, H, N)
+    ref = np.einsum("bfd,fhn,bnd->bhd", X0.astype(f8), W3, dpre, optimize=True) + np.einsum("bhd,fhn,bnd->bfd", X0.astype(f8), W3, dpre, optimize=True)
+    assert _rel(res[1], ref) < BTOL[4], _rel(res[1], ref)
+    # outside the envelope: H != F
+    bad = lib().rsx_cin_split_bwd_dx(_ptr(tX0), _ptr(tX0), _ptr(w16), _ptr(out), _ptr(tdout), None, None, _ptr(dX0), 2, _ptr(pt), _ptr(ws),
+                                     B, F, H + 1 if H < 128 else H - 1, N, 16, ns, _stream())
+    assert bad != 0
