@@ -1099,12 +1099,17 @@ __global__ __launch_bounds__(512, 1) void cin_split_dx8_k(const CsDxArgs p) {
       }
     }
   }
-  if (ht == 0 && half == 0) {   // (workgroup-uniform) the weight-gradient launch's operands (THREE bf16 planes in every mode) and the bias
-                   // gradient's per-example partials: item = (example, row n, quarter of d), rows past N16 are not stored
+  {   // the weight-gradient launch's operands (THREE bf16 planes in every mode) and the bias gradient's per-example partials of
+      // this example group: every workgroup of the group (all tiles of h, both field halves) takes an equal share of the rows n
+      // -- done by tile 0 alone, those workgroups finished ~3 us after the others and set the launch's duration.
+      // item = (example, row n of the share, quarter of d); rows past N16 are not stored
     const size_t dplane = (size_t)((p.B + 1) / 2) * 2 * p.N16 * CS_D;
-    const int items = E * p.N16 * 4;
+    const int nparts = (int)gridDim.x, part = (int)blockIdx.x;
+    const int nshare = (p.N16 + nparts - 1) / nparts;
+    const int items = E * nshare * 4;
     for (int it = tid; it < items; it += NTHR) {
-      const int dq = it & 3, n = (it >> 2) % p.N16, e = it / (4 * p.N16);
+      const int dq = it & 3, n = part * nshare + (it >> 2) % nshare, e = it / (4 * nshare);
+      if (n >= p.N16) continue;                    // (whole lane quads: the four quarters of a row are skipped together)
       const int b = b0 + e;
       const int bc = b < p.B ? b : p.B - 1, nc = n < p.N ? n : p.N - 1;
       const size_t at = ((size_t)bc * p.N + nc) * 4 + dq;
