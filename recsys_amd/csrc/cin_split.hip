@@ -829,7 +829,6 @@ __global__ __launch_bounds__(64 * E, E == 4 ? 2 : 1) void cin_split_dx_k(const C
   const bf16_t* wbase = p.W16 + (size_t)ht * KSN * 512;
   const size_t fstride = (size_t)p.H16 * p.Np, plane = (size_t)p.F * fstride;
   const int nstep = (p.F + 1) / 2;
-  const bool lead = ht == 0;
   const float* dsrc = p.dout ? p.dout : p.out;
   const float* gsrc = p.gs ? p.gs : p.out;
   const float* wsrc = p.gs ? p.wout : p.out;
@@ -889,13 +888,16 @@ __global__ __launch_bounds__(64 * E, E == 4 ? 2 : 1) void cin_split_dx_k(const C
         W[s_][ks_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb_ + (s_ * KSN + ks_) * 512));       \
   }
   CS_READ_WA(0, w0)
-  if (lead) {   // (workgroup-uniform) the weight-gradient launch's operands and the bias gradient's per-example partials, from
-                // the LDS copy (kept in registers across this branch the staged values go to scratch memory)
+  {   // the weight-gradient launch's operands and the bias gradient's per-example partials, from the LDS copy (kept in registers
+      // across this block the staged values go to scratch memory): every tile's workgroup writes an equal share of the rows n
+      // (tile 0 alone finished after the others and set the launch's duration, see cin_split_dx8_k)
     const size_t dplane = (size_t)((p.B + 1) / 2) * 2 * p.N16 * CS_D;
+    const int nshare = (32 * KSN + (int)gridDim.x - 1) / (int)gridDim.x;
 #pragma unroll
     for (int u = 0; u < 2 * KSN; ++u) {
       const int it = tid + NTHR * u;
       const int dq = it & 3, n = (it >> 2) % (32 * KSN), e = it / (128 * KSN);
+      if (n / nshare != ht) continue;              // (whole lane quads: the four quarters of a row go together)
       const int b = b0 + e;
       const float* t = sDp + ((size_t)e * 16 + dq * 4) * NP + n;
       const float4 v = make_float4(t[0], t[NP], t[2 * NP], t[3 * NP]);
