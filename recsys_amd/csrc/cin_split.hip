@@ -752,37 +752,33 @@ __global__ __launch_bounds__(256) void cin_split_prep_h2_k(const CsPrepArgs p) {
   if (tid == 0 && part == 0) jb.winv[f] = inv;
   const int n1 = (jb.H16 * jb.Np) >> 3, n2 = (jb.N16 * jb.Hp) >> 3;       // quads of this field in the two layouts
   const size_t pl1 = ((size_t)p.F * jb.H16 * jb.Np), pl2 = ((size_t)p.F * jb.N16 * jb.Hp);
-  // four quads per thread and trip: their 32 loads requested together (L2 hits: the max pass has just read the field)
-  for (int q0 = part * 256 + tid; q0 < n1 + n2; q0 += 4 * 256 * CS_H2_PARTS) {
-    float v[4][8];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = q0 + u * 256 * CS_H2_PARTS;
-      const int qc = q < n1 + n2 ? q : n1 + n2 - 1;
-      const bool first = qc < n1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float m;
-        const float* src = cs_h2_src(jb, Wf, first, first ? qc : qc - n1, j, m);
-        v[u][j] = *src * (m * sc);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = q0 + u * 256 * CS_H2_PARTS;
-      if (q < n1 + n2) {
-        const bool first = q < n1;
-        const int lq = first ? q : q - n1;
-        f16x8 o[2];
-        SplitMode<CS_H2>::split(make_float4(v[u][0], v[u][1], v[u][2], v[u][3]), make_float4(v[u][4], v[u][5], v[u][6], v[u][7]), o);
-        const size_t fq = first ? (size_t)f * n1 + lq : (size_t)f * n2 + lq;     // quad index inside a plane of the layout
-        bf16_t* dst = (first ? jb.W16 : jb.Wt16) + fq * 8;
-        const size_t plane = first ? pl1 : pl2;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<f16x8*>(dst + (size_t)s2 * plane) = o[s2];
-      }
-    }
+  // one layout at a time (a per-quad choice of layout compiles to branches around the loads: every quad's loads were waited for
+  // in turn), two quads per thread and trip, their 16 loads requested together (L2 hits: the max pass has just read the field)
+#define CS_H2_LAYOUT(FIRST, NQ, DSTBASE, PLANE)                                                                        \
+  for (int q0 = part * 256 + tid; q0 < (NQ); q0 += 2 * 256 * CS_H2_PARTS) {                                          \
+    float v[2][8];                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                  \
+      const int q = q0 + u * 256 * CS_H2_PARTS;                                                                      \
+      const int qc = q < (NQ) ? q : (NQ) - 1;                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+        float m;                                                                                                     \
+        const float* src = cs_h2_src(jb, Wf, FIRST, qc, j, m);                                                       \
+        v[u][j] = *src * (m * sc);                                                                                   \
+      }                                                                                                              \
+    }                                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                  \
+      const int q = q0 + u * 256 * CS_H2_PARTS;                                                                      \
+      if (q < (NQ)) {                                                                                                \
+        f16x8 o[2];                                                                                                  \
+        SplitMode<CS_H2>::split(make_float4(v[u][0], v[u][1], v[u][2], v[u][3]), make_float4(v[u][4], v[u][5], v[u][6], v[u][7]), o); \
+        bf16_t* dst = (DSTBASE) + ((size_t)f * (NQ) + q) * 8;   /* (quad index inside a plane of the layout) */          \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<f16x8*>(dst + (size_t)s2 * (PLANE)) = o[s2]; \
+      }                                                                                                              \
+    }                                                                                                                \
   }
+  CS_H2_LAYOUT(true, n1, jb.W16, pl1)
+  CS_H2_LAYOUT(false, n2, jb.Wt16, pl2)
+#undef CS_H2_LAYOUT
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dXk, dX0
