@@ -168,8 +168,23 @@ def cin_mode(cin_bf16, cin_split=None):
     """False (fp32 MFMA) | True (bf16 operands) | 'x1'..'x4' (split operands, csrc/cin_split.hip).  --cin_split unset: xdeepfm.py's
     own default (mode 4) unless --cin_bf16; --cin_split 0: the fp32 MFMA kernels."""
     if cin_split is None:
-        return True if cin_bf16 else "x4"
+        if cin_bf16:
+            return True
+        from recsys_amd.xdeepfm import default_cin_split
+        d = default_cin_split()
+        return ("x%d" % d) if d else False
     return ("x%d" % cin_split) if cin_split else bool(cin_bf16)
+
+
+def cin_ran(est, asked):
+    """The CIN arithmetic that actually RAN (est.store.cin after build_variables: the flag may fall back to the fp32 MFMA kernels
+    outside the split kernels' envelope), in cin_mode()'s vocabulary; `asked` for models without a CIN."""
+    c = getattr(est.store, "cin", None)
+    if c is None:
+        return asked
+    if getattr(c, "split", 0):
+        return "x%d" % c.split
+    return bool(getattr(c, "bf16", False))
 
 
 CIN_DTYPE = {False: "f32", True: "bf16 CIN operands / f32 accumulate, f32 elsewhere",
@@ -296,7 +311,7 @@ def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmu
     # EXACTLY `steps` steps per timed region, bracketed by barrier + synchronize on both sides, MAX over ranks; the
     # region is repeated `--repeats` times back to back and the MEDIAN repeat is reported (a 20-step region is 2 ms:
     # one repeat is at the mercy of a single clock ramp or host hiccup).  All repeats are listed in config.
-    dts = []
+    dts, rank_dts = [], []
     for _ in range(max(1, repeats)):
         sync()
         t0 = time.perf_counter()
@@ -308,11 +323,14 @@ def time_config(a, model, batch_size, cin_bf16, dp, emu, rank, dev, steps, warmu
         dt = time.perf_counter() - t0
         if dp is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt = float(t.item())
+            allt = [torch.zeros_like(t) for _ in range(dp.world)]
+            torch.distributed.all_gather(allt, t)
+            rank_dts.append([float(x.item()) for x in allt])
+            dt = max(rank_dts[-1])                      # MAX over ranks
         dts.append(dt)
-    dt = sorted(dts)[len(dts) // 2]
-    return {"est": est, "B": B, "dt": dt, "dts": dts, "final_loss": float(loss), "host": host, "layout": layout, "feats": feats}
+    med = sorted(range(len(dts)), key=lambda i: dts[i])[len(dts) // 2]
+    dt = dts[med]
+    return {"est": est, "rank_dts": rank_dts[med] if rank_dts else None, "B": B, "dt": dt, "dts": dts, "cin": cin_ran(est, cin_bf16) if model == "xdeepfm" else False, "final_loss": float(loss), "host": host, "layout": layout, "feats": feats}
 
 
 def other_configs(a, rank, dev):
@@ -331,6 +349,8 @@ def other_configs(a, rank, dev):
             continue
         ms = t["dt"] / steps * 1e3
         wk = t["est"]._window_len() if (not a.no_graph and not a.no_overlap) else 1
+        if model == "xdeepfm":
+            bf16 = t["cin"]
         e = {"workload": "%s.py %s bs=%d%s, full train step (fwd+bwd+TF1 Adam), adam_mode=%s" %
                          (model, WORKLOADS[model], t["B"], CIN_TAG[bf16].replace(" --", ", "), a.adam_mode),
              "dtype": CIN_DTYPE[bf16],
@@ -490,11 +510,15 @@ def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
     from recsys_amd import build as _build
     from recsys_amd import dist
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher of N ranks (one per GPU; the driver's own form,
+        # `python -m torch.distributed.run ... bench.py --gpus N`, arrives here with WORLD_SIZE set and skips this)
+        _build.build(verbose=False)
+        raise SystemExit(dist.spawn_local_ranks(a.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("bench.py --gpus %d inside a job of WORLD_SIZE=%d: launch N ranks for --gpus N" % (a.gpus, world))
     dp = None
     if world > 1 or os.environ.get("RSX_FORCE_DIST") == "1":
         dist.init_process_group()            # nccl (= RCCL); RSX_DIST_BACKEND=gloo lets several ranks share ONE GPU (smoke runs)
@@ -512,6 +536,7 @@ def main():
     dp_captured = dist.dp_capture(dp or emu)
     t = time_config(a, a.model, a.batch_size, cin_mode(a.cin_bf16, a.cin_split), dp, emu, rank, dev, a.steps, a.warmup, a.repeats)
     est, B, dt, dts, final_loss, host, layout = t["est"], t["B"], t["dt"], t["dts"], t["final_loss"], t["host"], t["layout"]
+    cin_run = t["cin"]
 
     # ---- roofline leg: the dominant kernel, HIP events on the launch stream (torch's current stream) -----
     store = est.store
@@ -620,7 +645,7 @@ def main():
 
     if roof is not None:
         # step-level fractions, named for what they divide (see the module docstring)
-        roof.update(step_fractions(est, a.model, B, dt / a.steps * 1e3, wk, cin_mode(a.cin_bf16, a.cin_split)))
+        roof.update(step_fractions(est, a.model, B, dt / a.steps * 1e3, wk, cin_run))
         roof.setdefault("achievable_peak", 6300.0)
         roof.setdefault("frac_of_achievable", round(roof["achieved"] / 6300.0, 4))
         if a.model == "deepfm" and B == 256:
@@ -632,6 +657,9 @@ def main():
         n_launch = launches_per_step(est, t["feats"], wk)
     except Exception as ex:
         n_launch = None
+    world_seen = torch.distributed.get_world_size() if dp is not None else 1
+    backend = torch.distributed.get_backend() if dp is not None else None
+    rank_dts = t["rank_dts"]
     if dp is not None:
         dp.barrier()
         torch.distributed.destroy_process_group()
@@ -641,7 +669,10 @@ def main():
     out = {"metric": "examples/sec", "value": round(N * B * a.steps / dt, 1), "unit": "examples/sec", "n_gpus": a.gpus,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if a.model != "xdeepfm" else CIN_DTYPE[cin_mode(a.cin_bf16, a.cin_split)], "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
+           "dtype": "f32" if a.model != "xdeepfm" else CIN_DTYPE[cin_run], "data": "synthetic" if not a.host_input else "synthetic, host-resident batches (PCIe inside the timed region)",
+           "world_size_seen": world_seen,
+           **({"rank_ms_per_step": [round(x / a.steps * 1e3, 5) for x in rank_dts], "backend": backend,
+               "ranks_per_gpu": -(-world_seen // max(torch.cuda.device_count(), 1))} if dp is not None else {}),
            "config": {"workload": "%s.py %s bs=%d/replica, full train step "
                                   "(fwd+bwd+TF1 Adam), adam_mode=%s, hip_graph=%s, %s"
                                   % (a.model, WORKLOADS[a.model], B,

@@ -123,12 +123,15 @@ ADAM_WINDOW_MAX = 8
 ADAM_STATE_WORDS = 4 + 32 * 32        # include/rsx.h RSX_ADAM_STATE_WORDS
 
 
-def default_adam_window(capacity):
+def default_adam_window(capacity, unique_exchange=False):
     """Steps per optimizer window (include/rsx.h rsx_adam_window) for a sort workspace of `capacity` examples: the one
     sweep per window costs 57-79 us for 1-8 steps (DeepFM-size state), every step walks the other steps' unique-row lists
     (their length grows with the batch).  Measured on MI355X: 8 steps up to batch 1024, 4 above (dcn.py at 4096 with the
     packed sweep: 0.229 / 0.231 / 0.239 ms per step with windows of 4 / 6 / 8, scripts/gpu_round2_ax.sh)."""
-    if capacity <= 2048:          # (round 5: deepfm.py as 8 ranks x 256 -- 0.1032 ms per step with windows of 4, 0.0977 with 8)
+    # unique-list exchange (the only configuration the 2048 point was measured in -- round 5: deepfm.py as 8 ranks x 256, 0.1032
+    # ms per step with windows of 4, 0.0977 with 8): 8 steps up to a global batch of 2048; everything else keeps the
+    # single-replica measurements' 1024
+    if capacity <= (2048 if unique_exchange else 1024):
         return ADAM_WINDOW_MAX
     return max(1, min(ADAM_WINDOW_MAX, int(os.environ.get("RSX_ADAM_WINDOW_LARGE", "4"))))     # (A/B knob for the large-batch choice)
 

@@ -65,7 +65,7 @@ def build_variables(store, params, capacity):
         # (unique-list exchange: the window's sorts are the ranks' LOCAL ones -- dcn.py at 8 x 4 096 keeps its windows)
         sort_cap = capacity // store.dp.world if want_ux else capacity
         if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and sort_cap <= 16384:
-            store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
+            store.window_k = _lib.default_adam_window(capacity, want_ux)          # optimizer windows (include/rsx.h rsx_adam_window)
             store.window_dp = True
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
@@ -247,7 +247,9 @@ def make_params(FLAGS):
 
 
 def main(argv=None):
-    return run_main(model_fn, define_flags().parse_args(argv), make_params)
+    FLAGS = define_flags().parse_args(argv)
+    FLAGS._argv = argv
+    return run_main(model_fn, FLAGS, make_params)
 
 
 if __name__ == "__main__":

@@ -76,9 +76,11 @@ def build_variables(store, params, capacity, with_dnn=True):
         # optimizer windows (include/rsx.h rsx_adam_window): up to 8 consecutive steps share ONE sweep over the untouched rows
         # (capacity = the GLOBAL batch under data parallelism; the window's sorts are the ranks' LOCAL ones under the unique-list
         # exchange, so only the local batch has to fit the one-launch multi-sort)
-        sort_cap = capacity // store.dp.world if (store.dp is not None and dp_unique_wanted(store, params)) else capacity
+        want_ux = store.dp is not None and params.get("dp_send_block", True) and dp_unique_wanted(store, params) and \
+            EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world)
+        sort_cap = capacity // store.dp.world if want_ux else capacity
         if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and sort_cap <= 16384:
-            store.window_k = _lib.default_adam_window(capacity)
+            store.window_k = _lib.default_adam_window(capacity, want_ux)
             store.window_dp = True
         store.graph_safe_dp = True      # the fused step issues its collectives outside autograd
         store.dp_block = False
@@ -90,7 +92,7 @@ def build_variables(store, params, capacity, with_dnn=True):
             # rank de-duplicates and sums ITS batch, the ranks exchange unique (row, sum) lists (EmbeddingArena.enable_unique_exchange,
             # csrc/uniq_exchange.hip) -- the send block is [dense | G [capT, D] | gw1 [capT]]
             b_local = capacity // store.dp.world
-            if dp_unique_wanted(store, params) and EmbeddingArena.unique_exchange_ok(layout.row_off, store.dp.world):
+            if want_ux:
                 ux = arena.enable_unique_exchange(store.dp.world, b_local)
                 store.dp.make_send_block(store.dense, ux.capT, [D, 1])
                 store.dp_unique = True
@@ -362,6 +364,14 @@ def make_params(FLAGS, linear="indicator_all"):
 
 def run_main(model_fn, FLAGS, make_params_fn):
     """The `main(_)` driver shared by the Criteo scripts (fm/fm.py:173-224, deepfm/deepfm.py:153-234, ...)."""
+    if FLAGS.mirror:
+        # MirroredStrategy() = every GPU of the host (fm/fm.py:184-186): on a multi-GPU box this process becomes the launcher
+        from . import dist
+        rc = dist.maybe_spawn_mirror(FLAGS, model_fn.__module__, getattr(FLAGS, "_argv", None))
+        if rc is not None:
+            if rc != 0:
+                raise SystemExit(rc)
+            return None
     files = [FLAGS.train_path + "part-r-{:0>5}".format(i) for i in range(FLAGS.train_parts)]
     train_files, eval_files = files[:-FLAGS.eval_parts], files[-FLAGS.eval_parts:]
     params = make_params_fn(FLAGS)
@@ -397,7 +407,9 @@ def run_main(model_fn, FLAGS, make_params_fn):
 
 
 def main(argv=None):
-    return run_main(model_fn, define_flags().parse_args(argv), make_params)
+    FLAGS = define_flags().parse_args(argv)
+    FLAGS._argv = argv
+    return run_main(model_fn, FLAGS, make_params)
 
 
 if __name__ == "__main__":

@@ -591,6 +591,13 @@ def input_fn(filenames, batch_size, num_epochs=-1, need_shuffle=False, hist_len=
 
 def main(argv=None):
     FLAGS = define_flags().parse_args(argv)
+    if FLAGS.mirror:                # MirroredStrategy() = every GPU of the host (din/din.py:187-190): become the launcher
+        from . import dist
+        rc = dist.maybe_spawn_mirror(FLAGS, __name__, argv)
+        if rc is not None:
+            if rc != 0:
+                raise SystemExit(rc)
+            return None
     train_files, eval_files = [FLAGS.train_path + "train2"], [FLAGS.train_path + "valid2"]      # din/din.py:197-198
     params = {"embedding_size": FLAGS.embedding_size, "learning_rate": FLAGS.learning_rate, "dropout": FLAGS.dropout,
               "max_batch_size": FLAGS.batch_size, "hist_len": FLAGS.hist_len}

@@ -47,6 +47,75 @@ def init_process_group(backend=None):
     dist.init_process_group(backend)
 
 
+# ---- one command -> all local GPUs ---------------------------------------------------------------------------------------------
+# `tf.distribute.MirroredStrategy()` with no arguments (fm/fm.py:184-186; deepfm/readme.md:22-24) makes `python fm.py` train on
+# EVERY GPU of the host.  Here a replica is a process, so the first process re-launches itself as N ranks (one per visible GPU)
+# through torch.distributed.run on 127.0.0.1 and waits for them; a process that already is a rank (WORLD_SIZE set) never does.
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def local_replica_count(n_devices=None, env=None):
+    """How many ranks `--mirror true` must START from this process: 0 = none (this process already is a rank of a launched job,
+    or the host has at most one GPU), else one per visible GPU.  RSX_MIRROR_REPLICAS=N overrides the device count (N <= 1: never
+    spawn; N > device count: several ranks per GPU over gloo -- smoke runs on a one-GPU box)."""
+    env = os.environ if env is None else env
+    if "WORLD_SIZE" in env or env.get("RSX_FORCE_DIST") == "1":
+        return 0
+    if "RSX_MIRROR_REPLICAS" in env:
+        n = int(env["RSX_MIRROR_REPLICAS"])
+    else:
+        n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) if n_devices is None else int(n_devices)
+    return n if n > 1 else 0
+
+
+def spawn_command(n, args, script=None, module=None, port=None, python=None):
+    """The command line that runs `script args` (or `-m module args`) as n ranks on this host."""
+    import sys
+    assert (script is None) != (module is None)
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port or free_port())]
+    cmd += ["-m", module] if module is not None else [script]
+    return cmd + [str(x) for x in args]
+
+
+def spawn_env(n, n_devices=None, env=None):
+    """Environment of the spawned ranks: more ranks than GPUs (a one-GPU box) cannot use RCCL (it refuses two ranks on one
+    device) -> gloo, unless the caller chose a backend."""
+    env = dict(os.environ if env is None else env)
+    nd = (torch.cuda.device_count() if torch.cuda.is_available() else 0) if n_devices is None else int(n_devices)
+    if n > nd and "RSX_DIST_BACKEND" not in env:
+        env["RSX_DIST_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("RSX_MIRROR_REPLICAS", None)
+    return env
+
+
+def spawn_local_ranks(n, args, script=None, module=None):
+    """Runs this program as n ranks (one per GPU) and returns their exit code."""
+    import subprocess
+    return subprocess.call(spawn_command(n, args, script=script, module=module), env=spawn_env(n))
+
+
+def maybe_spawn_mirror(FLAGS, module, argv=None):
+    """`--mirror true` on a multi-GPU host: re-launch as one rank per GPU and return their exit code; None: carry on in-process."""
+    import sys
+    if not getattr(FLAGS, "mirror", False):
+        return None
+    n = local_replica_count()
+    if not n:
+        return None
+    if module == "__main__":        # (python -m recsys_amd.<script>: the module's real name is in its spec)
+        spec = getattr(sys.modules["__main__"], "__spec__", None)
+        module = spec.name if spec is not None else module
+    print("INFO:--mirror: %d local GPUs -> %d data-parallel ranks (fm/fm.py:184-186 MirroredStrategy)" % (n, n), flush=True)
+    return spawn_local_ranks(n, list(sys.argv[1:] if argv is None else argv), module=module)
+
+
 class SegmentedGraph:
     """A training step captured as HIP-graph SEGMENTS with the RCCL collectives launched eagerly between them:
     [graph | collective | eager callable]* replayed in order on the current stream.  The compute stays launch-free

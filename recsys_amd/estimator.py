@@ -559,7 +559,9 @@ class Estimator:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             K = self._window_len()
-            with torch.cuda.graph(graph):
+            # (data parallel with captured collectives: see _capture -- a communicator thread may poll events meanwhile)
+            kw = {"capture_error_mode": "thread_local"} if self.store.dp is not None else {}
+            with torch.cuda.graph(graph, **kw):
                 k = 0
                 nwin = -(-count // K)    # windows of the graph, as EVEN as possible (20 steps: 7 + 7 + 6 rather than 8 + 8 + 4:
                 while k < count:         # a window's ONE sweep costs 57 us + ~3 us per step, so short windows are the dear ones)
@@ -852,7 +854,8 @@ class Estimator:
         f, l = g["static"].views()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        kw = {"capture_error_mode": "thread_local"} if self.store.dp is not None else {}
+        with torch.cuda.graph(graph, **kw):
             spec = self._call_model_fn(f, l if mode == ModeKeys.EVAL else None, mode)
         g["prob"], g["loss"], g["labels"] = spec.predictions["prob"], spec.loss, (l if has_lab else None)
         g["graph"] = graph

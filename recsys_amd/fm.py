@@ -30,7 +30,7 @@ def model_fn(features, labels, mode, params):
         if store.adam_mode == "tf1_dense" and params.get("fused", True):
             gcap = cap * (store.dp.world if store.dp is not None else 1)
             if (cap if want_ux else gcap) <= 16384:      # (unique-list exchange: the window's sorts are the ranks' local ones)
-                store.window_k = _lib.default_adam_window(gcap)     # optimizer windows (include/rsx.h rsx_adam_window)
+                store.window_k = _lib.default_adam_window(gcap, want_ux)     # optimizer windows (include/rsx.h rsx_adam_window)
                 store.window_dp = True
         store.dp_block = False
         store.dp_unique = False
@@ -190,7 +190,9 @@ def _train_fused(store, arena, ids, labels):
 
 
 def main(argv=None):
-    return run_main(model_fn, define_flags().parse_args(argv), make_params)
+    FLAGS = define_flags().parse_args(argv)
+    FLAGS._argv = argv
+    return run_main(model_fn, FLAGS, make_params)
 
 
 if __name__ == "__main__":

@@ -120,7 +120,7 @@ class EmbeddingArena:
         self._slot_stride = (self.R + 4 + 3) // 4 * 4
         self._slot_all = torch.full((_lib.ADAM_WINDOW_MAX, self._slot_stride), -1, **i32)
         self.sortbufs = [self._new_sortbuf()]
-        self.window_bufs(_lib.default_adam_window(st))      # all of them NOW: never inside a HIP-graph capture (see window_bufs)
+        self.window_bufs(_lib.default_adam_window(st, True))      # all any exchange may use, NOW: never inside a HIP-graph capture (see window_bufs)
         self.select(0)
         # requires-grad hook so autograd calls GatherFM.backward although the tables are raw buffers
         self.hook = torch.zeros((), device=dev, requires_grad=True)

@@ -96,7 +96,7 @@ def build_variables(store, params, capacity):
     # A/B runs); cin_split = 0 selects the fp32 MFMA kernels of csrc/cin.hip.
     bf16 = bool(params.get("cin_bf16", False))
     split = params.get("cin_split")
-    split = (0 if bf16 else int(os.environ.get("RSX_CIN_SPLIT_DEFAULT", "4"))) if split is None else int(split)
+    split = (0 if bf16 else default_cin_split()) if split is None else int(split)
     if split and not (F <= 40 and D == 16 and max(cin) <= 128 and len(cin) <= 4):
         split = 0                                    # outside the kernels' envelope: the fp32 MFMA path
     store.cin = CinNet(F, D, cin, capacity, store.device, bf16=bf16 and not split, split=split)
@@ -106,7 +106,7 @@ def build_variables(store, params, capacity):
     sort_cap = capacity // store.dp.world if want_ux else capacity      # (unique-list exchange: the ranks sort their own batches)
     if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)) and sort_cap <= 16384 and \
             (store.dp is None or params.get("dp_send_block", True)):
-        store.window_k = _lib.default_adam_window(capacity)          # optimizer windows (include/rsx.h rsx_adam_window)
+        store.window_k = _lib.default_adam_window(capacity, want_ux)          # optimizer windows (include/rsx.h rsx_adam_window)
         store.window_dp = True
     store.dp_block = False
     store.dp_unique = False
@@ -368,14 +368,20 @@ def model_fn(features, labels, mode, params):
     return EstimatorSpec(mode, predictions=predictions, loss=loss, eval_metric_ops={"AUC": None, "Accuracy": None})
 
 
+def default_cin_split():
+    """xdeepfm.py's CIN mode when neither --cin_split nor --cin_bf16 is given (RSX_CIN_SPLIT_DEFAULT overrides: A/B runs)."""
+    return int(os.environ.get("RSX_CIN_SPLIT_DEFAULT", "4"))
+
+
 def define_flags():
     p = _deepfm_flags()
     p.add_argument("--cross_layers", default="20,10,10")       # xdeepfm/xdeepfm.py:19 (BASELINE config 3 uses 128,128)
     p.add_argument("--cin_bf16", type=lambda s: s.lower() in ("1", "true", "yes"), default=False,
                    help="CIN contraction on bf16 MFMA (fp32 accumulate); not the reference-parity path")
     p.add_argument("--cin_split", type=int, default=None,
-                   help="ns in 1..3: CIN contraction on the bf16 MFMA with ns bf16 planes per operand (3 = fp32-grade products, "
-                        "the default); 0 = the fp32 MFMA kernels")
+                   help="CIN contraction on the 16-bit MFMA with split operands: 3 = three bf16 planes per operand (products exact "
+                        "to 2^-23), 4 = two scaled fp16 planes forward / data gradients + three bf16 planes weight gradients "
+                        "(2^-22-grade); 0 = the fp32 MFMA kernels; unset = the default (see build_variables)")
     p.add_argument("--eval_steps", type=int, default=200)
     p.set_defaults(num_epochs=5, eval_parts=10, log_steps=50, save_checkpoints_steps=2000)
     return p
@@ -389,7 +395,9 @@ def make_params(FLAGS):
 
 
 def main(argv=None):
-    return run_main(model_fn, define_flags().parse_args(argv), make_params)
+    FLAGS = define_flags().parse_args(argv)
+    FLAGS._argv = argv
+    return run_main(model_fn, FLAGS, make_params)
 
 
 if __name__ == "__main__":

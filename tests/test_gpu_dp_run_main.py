@@ -91,3 +91,41 @@ def test_run_main_world2_disjoint_records_identical_replicas(tmp_path, mod):
     assert max(err.values()) < 1e-4, err
     moved = float(np.abs(v[0]["final.tables"] - v[0]["init.tables"]).max())
     assert moved > 5e-3, moved                                     # (the variables did move: 18 steps at lr 1e-3)
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                            "RSX_FORCE_DIST")}
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the shape of the driver's N = 1 command): the process becomes the
+    launcher of two ranks (one GPU here -> gloo, chosen by dist.spawn_env) and rank 0 prints the one JSON line (VERDICT r5
+    item 2: this used to exit with 'launch with torchrun')."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no_cpu_baseline", "--repeats", "2"], env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["config"]["global_batch"] == 512
+    assert len(d["rank_ms_per_step"]) == 2 and d["backend"] == "gloo" and d["ranks_per_gpu"] == 2
+    assert d["ms_per_step"] == max(d["rank_ms_per_step"]) and d["value"] > 0
+
+
+def test_mirror_true_spawns_one_rank_per_replica(tmp_path):
+    """`python -m recsys_amd.fm --mirror true` with several local replicas (RSX_MIRROR_REPLICAS=2 stands for two visible GPUs on
+    this one-GPU box): ONE command trains data-parallel, as `MirroredStrategy()` does (fm/fm.py:184-186)."""
+    d = str(tmp_path) + "/"
+    _shards(d)
+    model_dir = str(tmp_path / "model")
+    r = subprocess.run([sys.executable, "-m", "recsys_amd.fm", "--task_type", "train", "--train_path", d, "--train_parts", "4",
+                        "--eval_parts", "1", "--batch_size", "64", "--num_epochs", "1", "--model_dir", model_dir, "--mirror", "true",
+                        "--log_steps", "4"], cwd=ROOT, env=_clean_env(RSX_MIRROR_REPLICAS="2"), capture_output=True, text=True,
+                       timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "2 data-parallel ranks" in out and "INFO:loss" in out
+    assert glob.glob(model_dir + "/model.ckpt-*.pt")
