@@ -121,13 +121,14 @@ def oracle_run(name, P32, batches):
 
 
 # ------------------------------------------------------------------------------------------ HIP side (GPU box) ---
-def hip_run(name, P, batches, use_graph=False):
+def hip_setup(name, P, first_batch, use_graph=False, extra_params=None, kind_B=None):
+    """The Estimator of config `name` with the oracle's initial variables P loaded -> (est, feats: batch dict -> features)."""
     import torch
     from recsys_amd import dcn, deepfm, din, xdeepfm
     from recsys_amd.estimator import ModeKeys
     from recsys_amd.feature_columns import build_feature_columns
     from tests.parity_util import load_oracle_weights, make_estimator
-    kind, B, seed = CONFIGS[name]
+    kind, B, seed = kind_B or CONFIGS[name]
     row_off = criteo.row_offsets()
     base = {"embedding_size": 16, "learning_rate": 1e-3, "dropout": 0.0, "deep_layers": "100,100", "max_batch_size": B}
     if kind in ("deepfm", "dcn", "xdeepfm"):
@@ -141,12 +142,13 @@ def hip_run(name, P, batches, use_graph=False):
         base.update({"embedding_size": 32, "n_item": 63002, "n_cate": 802})
         mfn = din.model_fn
         feat_keys = ("i_id", "i_cate", "u_iid_seq", "u_icat_seq")
+    base.update(extra_params or {})
     est = make_estimator(mfn, base, use_graph=use_graph)
 
     def feats(b):
         return {k: torch.from_numpy(np.ascontiguousarray(b[k])).cuda() for k in feat_keys}
 
-    est._call_model_fn(feats(batches[0]), None, ModeKeys.PREDICT)
+    est._call_model_fn(feats(first_batch), None, ModeKeys.PREDICT)
     st = est.store
     if kind == "din":
         with torch.no_grad():
@@ -167,6 +169,16 @@ def hip_run(name, P, batches, use_graph=False):
         st.dense.load({k: v for k, v in P.items() if k in st.dense.params})
     else:
         load_oracle_weights(est, P)
+    return est, feats
+
+
+def hip_run(name, P, batches, use_graph=False, extra_params=None):
+    import torch
+    from recsys_amd.estimator import ModeKeys
+    kind, B, seed = CONFIGS[name]
+    row_off = criteo.row_offsets()
+    est, feats = hip_setup(name, P, batches[0], use_graph, extra_params)
+    st = est.store
     probs, losses = [], []
     for b in batches:
         f = feats(b)

@@ -1,0 +1,83 @@
+"""Long-horizon parity on the GPU: 200 TRAIN steps at batch 256 through the product's optimizer-window
+schedule, then EVAL over 20 held-out batches, against the fp64 oracle's run committed as tests/golden/long_<name>.npz
+(tests/longrun.py; generator tests/golden/make_golden_long.py).
+
+What "matches" can mean over 200 steps.  TF-1 Adam divides by sqrt(v) + 1e-8: a gradient component near the epsilon scale turns
+an absolute rounding difference of 1e-9 into a variable difference of ~1e-5 in ONE step, and the steps compound it.  The oracle
+itself shows it: evaluated in float32 instead of float64 (tests/golden/long_<name>_f32ref.npz, same generator with --f32) it
+agrees with the fp64 run to 1e-7 on the first ~30 train losses, to ~1e-3 on the last ones, to 6e-4 on the eval logloss and 9e-4
+on the AUC (deepfm).  No float32 evaluation of these 200 steps -- TensorFlow's included -- lands closer to the fp64 run than that.
+So the bars are
+  * BEFORE the compounding (first 24 steps): every train loss within 2e-6 of the fp64 oracle;
+  * at the end: |d eval logloss| and |d AUC-200| within 3 x the float32 oracle's own distance from the fp64 one (floors 1e-4 /
+    1e-3 = the bars VERDICT r5 asked for, which hold where the floor is lower), and never above 3e-3 / 3e-3;
+and the MEASURED margins are printed and written to gpurun_out/r06_long_margins.txt (committed under profiles/), for deepfm and for
+every CIN arithmetic of xdeepfm.py (fp32 MFMA kernels, 3 bf16 planes, 2 scaled fp16 planes)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import longrun
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", "long_%s.npz" % name))
+
+
+def _record(tag, row):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    line = "%-28s %s" % (tag, json.dumps(row))
+    print("\nLONG-HORIZON MARGIN " + line)
+    with open(os.path.join(out, "r06_long_margins.txt"), "a") as f:
+        f.write(line + "\n")
+
+
+def _run(name, tag, extra=None):
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "long_%s_f32ref.npz" % name)):
+        pytest.skip("fixture long_%s*.npz not generated yet (tests/golden/make_golden_long.py: an hour of fp64 numpy)" % name)
+    g = _golden(name)
+    r32 = _golden(name + "_f32ref")              # the oracle in float32: the noise floor of the problem, not an expected output
+    P, train, ev, digest = longrun.make_inputs(name)
+    assert digest == str(g["digest"]) == str(r32["digest"]), "inputs regenerated from the seed differ from the fixture's"
+    floor_ll, floor_auc = abs(float(r32["eval_loss"]) - float(g["eval_loss"])), abs(float(r32["auc"]) - float(g["auc"]))
+    got = longrun.hip_run(name, P, train, ev, extra)
+    d_train = np.abs(got["train_losses"] - g["train_losses"])
+    d_dense = max(float(np.abs(got["final_dense"][k].reshape(-1) - g["final." + k].reshape(-1)).max())
+                  for k in got["final_dense"] if "final." + k in g.files)
+    row = {"d_eval_logloss": abs(got["eval_loss"] - float(g["eval_loss"])), "d_auc": abs(got["auc"] - float(g["auc"])),
+           "d_accuracy": abs(got["accuracy"] - float(g["accuracy"])),
+           "max_d_eval_prob": float(np.abs(got["eval_probs"] - g["eval_probs"]).max()),
+           "max_d_eval_batch_loss": float(np.abs(got["eval_losses"] - g["eval_losses"]).max()),
+           "max_d_train_loss_first24": float(d_train[:24].max()), "max_d_train_loss_all200": float(d_train.max()),
+           "f32_oracle_vs_f64": {"d_eval_logloss": floor_ll, "d_auc": floor_auc,
+                                 "max_d_train_loss_first24": float(np.abs(r32["train_losses"] - g["train_losses"])[:24].max()),
+                                 "max_d_train_loss_all200": float(np.abs(r32["train_losses"] - g["train_losses"]).max())},
+           "max_d_dense_var_after_200": d_dense, "window": got["window"],
+           "oracle": {"eval_logloss": float(g["eval_loss"]), "auc": float(g["auc"]), "accuracy": float(g["accuracy"])}}
+    fmt = lambda d: {k: (float("%.3g" % v) if isinstance(v, float) else (fmt(v) if isinstance(v, dict) else v)) for k, v in d.items()}
+    _record(tag, fmt(row))
+    # the training did something: far from the untrained model's AUC 0.5 / logloss ln 2-ish start
+    assert float(g["auc"]) > 0.65 and g["train_losses"][-20:].mean() < g["train_losses"][:20].mean() - 0.05
+    assert row["max_d_train_loss_first24"] <= 2e-6, row                        # before rounding differences compound
+    assert row["d_eval_logloss"] <= min(3e-3, max(1e-4, 3 * floor_ll)), row
+    assert row["d_auc"] <= min(3e-3, max(1e-3, 3 * floor_auc)), row
+    # every one of the 200 per-step losses stays inside the envelope the float32 oracle itself needs
+    assert row["max_d_train_loss_all200"] <= max(1e-3, 3 * row["f32_oracle_vs_f64"]["max_d_train_loss_all200"]), row
+    return row
+
+
+def test_deepfm_200_steps_then_eval_matches_the_fp64_oracle():
+    _run("deepfm_bs256", "deepfm")
+
+
+@pytest.mark.parametrize("split", [0, 3, 4])
+def test_xdeepfm_200_steps_then_eval_matches_the_fp64_oracle(split):
+    """CIN [128,128]: the fp32 MFMA kernels (0), three bf16 planes per operand (3), two scaled fp16 planes (4) -- the same bars."""
+    _run("xdeepfm_bs256_cin128", "xdeepfm cin_split=%d" % split, {"cin_split": split})
