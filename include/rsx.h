@@ -31,7 +31,8 @@ typedef enum {
   RSX_EINVAL = -1,       /* bad argument (null pointer, unsupported D, ...) */
   RSX_ELAUNCH = -2,      /* hipGetLastError() != hipSuccess after a launch */
   RSX_EUNSUPPORTED = -3, /* valid request outside the implemented envelope */
-  RSX_EDATA = -4         /* corrupt input data (TFRecord crc, malformed Example) */
+  RSX_EDATA = -4,        /* corrupt input data (TFRecord crc, malformed Example) */
+  RSX_ECOMM = -5         /* a collective library call failed (rsx_comm_last_error_h() has RCCL's message) */
 } rsx_status;
 
 int rsx_version(void);
@@ -402,6 +403,39 @@ int rsx_merged_adam_rows(float* tables, float* m_t, float* v_t, float* w1, float
                          const rsx_table_set* second_h, const rsx_adam_window* win_h, float* state, int advance_step,
                          float lr, float beta1, float beta2, float eps, int w1_stride, int w1_sparse_formula,
                          rsx_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel step (csrc/comm.cpp), on the step's own stream.
+ * Replace what tf.distribute.MirroredStrategy() puts INTO the training graph (fm/fm.py:184-194, twins deepfm/deepfm.py:
+ * 177-187, xdeepfm/xdeepfm.py:258-268, dcn/dcn.py:215-225, din/din.py:187-190): the cross-replica sum of the dense gradients
+ * (all-reduce) and the aggregation of the replicas' IndexedSlices (concatenation = all-gather).
+ * One process per GPU; the communicator is RCCL's (xGMI inside a node), bound at run time (no link-time dependency: on a
+ * host without RCCL every entry returns RSX_EUNSUPPORTED and the rest of the library works).
+ *   - a communicator is a caller-owned opaque handle; rsx_comm_init_h is COLLECTIVE (every rank calls it with the same
+ *     unique id, rank r in 0 .. world-1) and binds to the calling thread's current HIP device;
+ *   - the unique id (RSX_COMM_UNIQUE_ID_BYTES) is made by ONE rank and handed to the others by the caller (the launcher's
+ *     key-value store);
+ *   - rsx_all_gather / rsx_all_reduce_* only ENQUEUE on `stream` (no host synchronisation, no helper thread): legal under
+ *     hipGraph stream capture, so a training step with its collectives is one graph;
+ *   - buffers are device pointers; recv of rsx_all_gather holds world * bytes_per_rank bytes in rank order; send may not
+ *     overlap recv unless send == recv + rank * bytes_per_rank (in place).
+ * Errors: RSX_ECOMM, message by rsx_comm_last_error_h() (thread-local).                                                   */
+#define RSX_COMM_UNIQUE_ID_BYTES 128
+typedef void* rsx_comm_t;
+int rsx_comm_available_h(int* version_out /* nullable: RCCL's NCCL_VERSION_CODE */);
+const char* rsx_comm_last_error_h(void);
+int rsx_comm_unique_id_h(void* id_out /* [RSX_COMM_UNIQUE_ID_BYTES] host */);
+int rsx_comm_init_h(const void* unique_id, int rank, int world, rsx_comm_t* comm_out);
+int rsx_comm_destroy_h(rsx_comm_t comm);
+int rsx_comm_rank_world_h(rsx_comm_t comm, int* rank, int* world);
+/* IndexedSlices aggregation / batch ids: rank r's `bytes_per_rank` bytes land at recv + r * bytes_per_rank on every rank. */
+int rsx_all_gather(rsx_comm_t comm, const void* send, void* recv, size_t bytes_per_rank, rsx_stream_t stream);
+/* Dense gradients: recv[i] = sum over ranks of send[i] (send == recv allowed: in place). */
+int rsx_all_reduce_sum_f32(rsx_comm_t comm, const float* send, float* recv, size_t n, rsx_stream_t stream);
+/* xdeepfm.py's step: the 3.3 MB of CIN filters take a true all-reduce (in place over grad[n]) BESIDE the all-gather of the
+ * sparse block -- both in one RCCL group (one fused launch).  bytes_per_rank % 4 == 0.                                    */
+int rsx_all_reduce_all_gather(rsx_comm_t comm, float* grad, size_t n, const void* send, void* recv, size_t bytes_per_rank,
+                              rsx_stream_t stream);
+
 /* dst[0 .. nbytes) = src[0 .. nbytes) by a kernel (16-byte aligned, nbytes % 16 == 0); src may be pinned HOST memory (it is
  * mapped into the device's address space): the captured windows of the streaming TRAIN path fetch their staged batches with
  * this launch as their first graph node, so that a window is one graph launch with no hipMemcpyAsync / copy-engine start-up /

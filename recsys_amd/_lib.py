@@ -183,6 +183,15 @@ _SIGS = {
     "rsx_adam_num_blocks_u": (C.c_int64, [C.POINTER(AdamSeg), _I, _I]),
     "rsx_adam_slice_run": (_I, [_P, _P]),
     "rsx_copy_bytes": (_I, [_P, _P, C.c_size_t, _P]),
+    "rsx_comm_available_h": (_I, [C.POINTER(C.c_int)]),
+    "rsx_comm_last_error_h": (C.c_char_p, []),
+    "rsx_comm_unique_id_h": (_I, [_P]),
+    "rsx_comm_init_h": (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
+    "rsx_comm_destroy_h": (_I, [_P]),
+    "rsx_comm_rank_world_h": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rsx_all_gather": (_I, [_P, _P, _P, C.c_size_t, _P]),
+    "rsx_all_reduce_sum_f32": (_I, [_P, _P, _P, C.c_size_t, _P]),
+    "rsx_all_reduce_all_gather": (_I, [_P, _P, C.c_size_t, _P, _P, C.c_size_t, _P]),
     "rsx_adam_fast_math_selftest": (_I, [_P, C.c_uint32, _I, _I, _P]),
     "rsx_cross_fwd": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "rsx_cross_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),

@@ -10,6 +10,7 @@ extern "C" const char* rsx_strerror(int status) {
     case RSX_ELAUNCH: return "kernel launch failed (hipGetLastError)";
     case RSX_EUNSUPPORTED: return "request outside the implemented envelope";
     case RSX_EDATA: return "corrupt input data";
+    case RSX_ECOMM: return "collective library call failed (see rsx_comm_last_error_h)";
     default: return "unknown rsx status";
   }
 }

@@ -116,6 +116,77 @@ def maybe_spawn_mirror(FLAGS, module, argv=None):
     return spawn_local_ranks(n, list(sys.argv[1:] if argv is None else argv), module=module)
 
 
+class DirectComm:
+    """RCCL called through the C ABI (include/rsx.h "Collectives of the data-parallel step", csrc/comm.cpp): ncclAllGather /
+    ncclAllReduce enqueued on the CURRENT stream -- a node of the step's HIP graph when the stream is capturing, as
+    MirroredStrategy's cross-replica sums are nodes of TF's training graph (fm/fm.py:184-194).  No ProcessGroupNCCL Work object,
+    no watchdog thread polling events of a capturing stream.  The unique id travels through torch.distributed's key-value store
+    (the launcher's rendezvous); torch's process group stays the CONTROL plane (barriers, the eval counters, bench timing)."""
+    _n = 0
+
+    def __init__(self, rank, world):
+        import ctypes as C
+        from . import _lib
+        self.C, self.L = C, _lib.lib()
+        L = self.L
+        self._check(L.rsx_comm_available_h(None), "rsx_comm_available_h")
+        store = dist.distributed_c10d._get_default_store()
+        key = "rsx_rccl_unique_id_%d" % DirectComm._n          # (every rank creates its communicators in the same order)
+        DirectComm._n += 1
+        if rank == 0:
+            uid = C.create_string_buffer(128)
+            self._check(L.rsx_comm_unique_id_h(uid), "rsx_comm_unique_id_h")
+            store.set(key, uid.raw)
+            raw = uid.raw
+        else:
+            raw = bytes(store.get(key))
+        h = C.c_void_p()
+        self._check(L.rsx_comm_init_h(raw, int(rank), int(world), C.byref(h)), "rsx_comm_init_h")
+        self.h, self.rank, self.world = h, int(rank), int(world)
+        self._side = None
+
+    def _check(self, rc, what):
+        from . import _lib
+        if rc != 0:
+            msg = self.L.rsx_comm_last_error_h()
+            raise _lib.RsxError("%s failed: %s (%d) %s" % (what, self.L.rsx_strerror(rc).decode(), rc, (msg or b"").decode()))
+
+    def _st(self):
+        return self.C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_gather(self, out, x):
+        assert out.is_contiguous() and x.is_contiguous() and out.numel() * out.element_size() == self.world * x.numel() * x.element_size()
+        self._check(self.L.rsx_all_gather(self.h, x.data_ptr(), out.data_ptr(), x.numel() * x.element_size(), self._st()), "rsx_all_gather")
+
+    def all_reduce_sum(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self._check(self.L.rsx_all_reduce_sum_f32(self.h, t.data_ptr(), t.data_ptr(), t.numel(), self._st()), "rsx_all_reduce_sum_f32")
+
+    def all_reduce_all_gather(self, grad, out, x):
+        assert grad.dtype == torch.float32 and grad.is_contiguous() and out.is_contiguous() and x.is_contiguous()
+        self._check(self.L.rsx_all_reduce_all_gather(self.h, grad.data_ptr(), grad.numel(), x.data_ptr(), out.data_ptr(),
+                                                     x.numel() * x.element_size(), self._st()), "rsx_all_reduce_all_gather")
+
+    def side_stream(self):
+        """The side HIP stream of RSX_DP_OVERLAP: an all-reduce issued from inside backward runs beside the lower layers'
+        backward launches (fork / join by events -- legal under capture: the side stream joins the capture)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            self.L.rsx_comm_destroy_h(self.h)
+            self.h = None
+
+
+def direct_wanted(group=None):
+    """The data plane goes through RCCL directly (DirectComm) when the ranks own DIFFERENT devices -- torch's group is "nccl" --
+    unless RSX_DP_DIRECT=0 (A/B: torch.distributed collectives, rounds 1-5).  Several ranks on one GPU (RSX_DIST_BACKEND=gloo:
+    the one-GPU test box) stay on gloo: RCCL refuses two ranks on one device."""
+    return torch.cuda.is_available() and os.environ.get("RSX_DP_DIRECT", "1") != "0" and dist.get_backend(group) == "nccl"
+
+
 class SegmentedGraph:
     """A training step captured as HIP-graph SEGMENTS with the RCCL collectives launched eagerly between them:
     [graph | collective | eager callable]* replayed in order on the current stream.  The compute stays launch-free
@@ -185,15 +256,25 @@ class SegmentedGraph:
 
 
 class _AsyncAllReduce:
-    def __init__(self, t, group):
-        self.t, self.group, self.work = t, group, None
+    def __init__(self, t, group, comm=None):
+        self.t, self.group, self.work, self.comm = t, group, None, comm
 
     def issue(self):
+        if self.comm is not None:            # DirectComm: on the side stream, forked from / joined to the step's by events
+            side = self.comm.side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.comm.all_reduce_sum(self.t)
+            self.work = side
+            return
         self.work = dist.all_reduce(self.t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait(self):
         if self.work is not None:
-            self.work.wait()
+            if self.comm is not None:
+                torch.cuda.current_stream().wait_stream(self.work)
+            else:
+                self.work.wait()
             self.work = None
 
 
@@ -208,7 +289,12 @@ def dp_capture(dp):
     have no real collective to break a graph for: always captured."""
     if dp is not None and isinstance(dp, (EmulatedDataParallel, LoopbackDataParallel)):
         return True
-    return os.environ.get("RSX_DP_CAPTURE", "0") == "1" and dp is not None
+    if dp is None:
+        return False
+    # Round 6: with the collectives issued through the C ABI on the step's own stream (DirectComm) there is no watchdog and
+    # nothing to abort: captured is the DEFAULT.  Through torch.distributed (RSX_DP_DIRECT=0, or gloo) it stays opt-in.
+    default = "1" if getattr(dp, "comm", None) is not None else "0"
+    return os.environ.get("RSX_DP_CAPTURE", default) == "1"
 
 
 def dp_overlap_enabled():
@@ -257,17 +343,19 @@ class _PrefetchableAllGather:
     """An all-gather whose input is ready before the step starts (the batch ids).  As a SegmentedGraph item it either waits
     for the asynchronous launch a previous step issued for it (`issue`) or runs synchronously."""
 
-    def __init__(self, out, x, group):
-        self.out, self.x, self.group, self.work = out, x, group, None
+    def __init__(self, out, x, group, comm=None):
+        self.out, self.x, self.group, self.work, self.comm = out, x, group, None, comm
 
     def issue(self):
-        if self.work is None:
+        if self.work is None and self.comm is None:      # (DirectComm: in stream order, nothing to issue ahead)
             self.work = dist.all_gather_into_tensor(self.out, self.x, group=self.group, async_op=True)
 
     def __call__(self):
         if self.work is not None:
             self.work.wait()            # the current stream waits for RCCL's; the host does not block
             self.work = None
+        elif self.comm is not None:
+            self.comm.all_gather(self.out, self.x)
         else:
             dist.all_gather_into_tensor(self.out, self.x, group=self.group)
 
@@ -288,6 +376,20 @@ class DataParallel:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.comm = None
+        if direct_wanted(group):
+            try:
+                self.comm = DirectComm(self.rank, self.world)
+            except Exception as e:          # no RCCL to bind, or its init failed: torch.distributed carries the data plane
+                warnings.warn("recsys_amd.dist: RCCL through the C ABI unavailable (%s); collectives go through torch.distributed "
+                              "(eager between graph segments)" % (e,))
+                self.comm = None
+
+    def _ag(self, out, x):
+        if self.comm is not None:
+            self.comm.all_gather(out, x)
+        else:
+            dist.all_gather_into_tensor(out, x, group=self.group)
 
     # -- inputs -------------------------------------------------------------------------------
     def all_gather_rows(self, x, prefetchable=False):
@@ -298,11 +400,11 @@ class DataParallel:
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         seg = SegmentedGraph._active
         if prefetchable and seg is not None and seg.prefetch is None:
-            op = _PrefetchableAllGather(out, x, self.group)
+            op = _PrefetchableAllGather(out, x, self.group, self.comm)
             seg.prefetch = op
             seg.run_eager(op)
         else:
-            graph_break(lambda: dist.all_gather_into_tensor(out, x, group=self.group))
+            graph_break(lambda: self._ag(out, x))
         return out
 
     def all_gather_id_list(self, ids_list, prefetchable=False):
@@ -493,6 +595,9 @@ class DataParallel:
         return dX_g, S_g, gy1_g, gy2_g
 
     def _overlapped_allreduce_allgather(self, grad, out, x):
+        if self.comm is not None:       # one RCCL group on the step's stream: all-reduce(grad) beside all-gather(x)
+            self.comm.all_reduce_all_gather(grad, out, x)
+            return
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             # captured collectives (dp_capture): synchronous calls only.  An async_op=True collective issued under capture hands
             # ProcessGroupNCCL's watchdog thread a Work whose end event was recorded in the capturing stream; its next poll
@@ -506,7 +611,7 @@ class DataParallel:
         work.wait()                     # stream-level wait: the host does not block
 
     def _all_gather_into(self, out, x):
-        dist.all_gather_into_tensor(out, x, group=self.group)
+        self._ag(out, x)
 
     # -- dense gradients ------------------------------------------------------------------------
     def all_reduce_async(self, flat):
@@ -514,7 +619,7 @@ class DataParallel:
         launched) issued NOW on RCCL's stream, asynchronously -- it runs underneath whatever the caller launches next
         (the lower layers' backward).  Returns a handle for wait_all().  Under a SegmentedGraph capture the issue is a
         segment break like every other collective, so this mode trades one graph segment for one per tower layer."""
-        h = _AsyncAllReduce(flat, self.group)
+        h = _AsyncAllReduce(flat, self.group, self.comm if (flat.is_cuda and flat.dtype == torch.float32) else None)
         graph_break(h.issue)
         return h
 
@@ -524,7 +629,10 @@ class DataParallel:
         graph_break(lambda: [h.wait() for h in hs])
 
     def all_reduce_sum(self, flat):
-        graph_break(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
+        if self.comm is not None and flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous():
+            graph_break(lambda: self.comm.all_reduce_sum(flat))
+        else:                           # (integer eval counters, float64 loss sums, CPU tensors: the control plane)
+            graph_break(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
         return flat
 
     def barrier(self):

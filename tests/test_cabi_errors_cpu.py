@@ -268,3 +268,32 @@ def test_round5_cin_entry_points_reject_bad_arguments(L):
     # the bf16 weight-gradient launch checks the workspace convention it is told
     j2 = (_lib.CinDwJob * 1)(_lib.CinDwJob(0x1000, 0x2000, 0x3000, 0x4000, 128, 128, 3))
     assert L.rsx_cin_bwd_dw_bf16(P, j2, 1, 4, 39, 16, None, None) == EINVAL                                   # dc_rows neither 0 nor B
+
+
+def test_round6_collective_entry_points_reject_bad_arguments(L):
+    """include/rsx.h "Collectives of the data-parallel step": argument checks come before any RCCL call; the binding itself
+    (dlopen + dlsym of the RCCL copy this process holds) works without a GPU."""
+    ECOMM = -5
+    v = C.c_int(0)
+    rc = L.rsx_comm_available_h(C.byref(v))
+    assert rc in (OK, EUNSUPPORTED)                      # EUNSUPPORTED: a host without RCCL -- the rest of the library works
+    if rc == OK:
+        assert v.value >= 20000                           # an NCCL_VERSION_CODE
+        uid = C.create_string_buffer(128)
+        assert L.rsx_comm_unique_id_h(uid) == OK and any(uid.raw)
+    assert L.rsx_comm_unique_id_h(None) == EINVAL
+    h = C.c_void_p()
+    assert L.rsx_comm_init_h(None, 0, 1, C.byref(h)) == EINVAL
+    assert L.rsx_comm_init_h(P, 0, 1, None) == EINVAL
+    assert L.rsx_comm_init_h(P, 2, 2, C.byref(h)) == EINVAL           # rank outside 0 .. world-1
+    assert L.rsx_comm_init_h(P, 0, 0, C.byref(h)) == EINVAL
+    assert L.rsx_comm_destroy_h(None) == EINVAL
+    assert L.rsx_comm_rank_world_h(None, None, None) == EINVAL
+    assert L.rsx_all_gather(None, P, P, 16, None) == EINVAL           # no communicator
+    assert L.rsx_all_gather(P, None, P, 16, None) == EINVAL
+    assert L.rsx_all_reduce_sum_f32(None, P, P, 4, None) == EINVAL
+    assert L.rsx_all_reduce_sum_f32(P, P, None, 4, None) == EINVAL
+    assert L.rsx_all_reduce_all_gather(None, P, 4, P, P, 16, None) == EINVAL
+    assert L.rsx_all_reduce_all_gather(P, P, 4, P, P, 18, None) == EINVAL        # block not a multiple of 4 bytes
+    assert L.rsx_strerror(ECOMM).decode().startswith("collective library call failed")
+    assert isinstance(L.rsx_comm_last_error_h(), bytes)

@@ -60,15 +60,79 @@ print("DP_OK")
 """ % ROOT
 
 
-@pytest.mark.parametrize("capture_collectives,overlap", [("0", "0"), ("1", "0"), ("0", "1")])
-def test_dp_world1_rccl_matches_oracle(capture_collectives, overlap):
-    """'0': graph SEGMENTS with eager RCCL calls between them (default); '1': collectives captured into the graph.
-    overlap '1' = RSX_DP_OVERLAP: DeepFM's dense arena all-reduced per tower layer from inside backward (asynchronous RCCL
-    launches between graph segments, awaited in train_op) instead of riding in the step's all-gather."""
+@pytest.mark.parametrize("capture_collectives,overlap,direct", [("1", "0", "1"), ("0", "0", "1"), ("1", "1", "1"), ("0", "1", "1"),
+                                                                ("0", "0", "0"), ("0", "1", "0")])
+def test_dp_world1_rccl_matches_oracle(capture_collectives, overlap, direct):
+    """direct '1' (default, round 6): the collectives are RCCL calls through the C ABI on the step's own stream (dist.DirectComm);
+    '0': torch.distributed (ProcessGroupNCCL), rounds 1-5.  capture '1' (the default with direct): collectives captured into the
+    step's HIP graph; '0': graph SEGMENTS with eager collectives between them.
+    overlap '1' = RSX_DP_OVERLAP: DeepFM's dense arena all-reduced per tower layer from inside backward -- on a side HIP
+    stream forked from the step's (direct), asynchronous ProcessGroupNCCL launches (torch) -- instead of riding in the step's
+    all-gather."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               RSX_DP_CAPTURE=capture_collectives, RSX_DP_OVERLAP=overlap)
+               RSX_DP_CAPTURE=capture_collectives, RSX_DP_OVERLAP=overlap, RSX_DP_DIRECT=direct)
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+COMM_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch
+from recsys_amd import dist as rdist
+rdist.init_process_group("nccl")
+dp = rdist.DataParallel()
+assert dp.comm is not None and (dp.comm.rank, dp.comm.world) == (0, 1), "RCCL through the C ABI did not come up"
+assert rdist.dp_capture(dp)                    # captured collectives are the default with the direct communicator
+g = torch.Generator(device="cuda").manual_seed(3)
+x = torch.randn(1, 4099, device="cuda", generator=g)
+ids = torch.randint(0, 1 << 30, (256, 39), device="cuda", dtype=torch.int32, generator=g)
+grad = torch.randn(1000, device="cuda", generator=g)
+odd = torch.arange(7, device="cuda", dtype=torch.uint8)            # a block that is not a multiple of 4 bytes
+# eager
+assert torch.equal(dp.all_gather_rows(ids), ids) and torch.equal(dp.all_gather_rows(x), x) and torch.equal(dp.all_gather_rows(odd), odd)
+g0 = grad.clone()
+assert torch.equal(dp.all_reduce_sum(grad), g0)
+out = torch.empty(1, 4096, device="cuda")
+xs = torch.randn(1, 4096, device="cuda", generator=g)
+dp._overlapped_allreduce_allgather(grad, out, xs)
+assert torch.equal(out, xs) and torch.equal(grad, g0)
+cnt = torch.tensor([5, 7], device="cuda", dtype=torch.int64)        # integer counters: the control plane (torch)
+assert dp.all_reduce_sum(cnt).tolist() == [5, 7]
+# captured into a HIP graph, replayed on new data: the collectives are graph nodes
+static_in = torch.zeros(1, 4096, device="cuda")
+static_g = torch.zeros(1000, device="cuda")
+static_out = torch.empty(1, 4096, device="cuda")
+torch.cuda.synchronize()
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+    dp._overlapped_allreduce_allgather(static_g, static_out, static_in)
+    y = dp.all_gather_rows(static_in * 2.0)
+    h = dp.all_reduce_async(static_g)          # the side stream of RSX_DP_OVERLAP, forked and joined inside the capture
+    z = static_in + 1.0
+    dp.wait_all([h])
+    w = static_g * 3.0
+for rep in range(3):
+    a = torch.randn(1, 4096, device="cuda", generator=g)
+    b = torch.randn(1000, device="cuda", generator=g)
+    static_in.copy_(a); static_g.copy_(b)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, a) and torch.equal(y, a * 2.0) and torch.equal(z, a + 1.0) and torch.equal(w, b * 3.0)
+dp.comm.close()
+import torch.distributed as dist
+dist.destroy_process_group()
+print("COMM_OK")
+""" % ROOT
+
+
+def test_direct_comm_world1_eager_and_captured():
+    """dist.DirectComm = rsx_comm_* / rsx_all_gather / rsx_all_reduce_* (include/rsx.h) over RCCL at world 1: values, the
+    non-float control-plane fallback, and HIP-graph capture + replay of the collectives (incl. the side-stream fork / join)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("RSX_DP_DIRECT", None)
+    r = subprocess.run([sys.executable, "-c", COMM_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert "COMM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("exchange", ["examples", "unique"])
