@@ -457,7 +457,7 @@ int rsx_adam_fast_math_selftest(unsigned long long* counts, uint32_t seed, int d
  * (deepfm/deepfm.py:103-107, xdeepfm/xdeepfm.py:188-191, dcn/dcn.py:146-149), the 1-unit layer and
  * logits of deepfm/deepfm.py:90-91,108-112 and the mean sigmoid-CE of fm/fm.py:146-149.
  * Workspaces (caller-owned), RT = ceil(B/16):
- *   a_l [B,N_l] relu outputs; fstat_l double[RT,2,N_l] partial (sum a, sum a^2); bn_l [2,N_l] mean,rstd;
+ *   a_l [B,N_l] relu outputs; fstat_l double[RT,2,N_l] partial (sum a, sum a^2) (B > 512: see below); bn_l [2,N_l] mean,rstd;
  *   mask_l [B,N_l] 1 keep / 0 drop, or NULL: the keep mask of layer l is then the counter-based hash
  *   hash32[element ^ key(seed, *rng_step, l)] >= rate*2^32, re-evaluated wherever it is needed (rng_step is a
  *   DEVICE uint32 that changes every step, e.g. word 3 of the Adam state); dy_l [B,N_l] grad wrt BN_l output;
@@ -467,16 +467,25 @@ int rsx_adam_fast_math_selftest(unsigned long long* counts, uint32_t seed, int d
  * entry point (and bn_prev_out / dgamma / dbeta NULL); the statistics workspaces are still required (fstat_prev / bn_prev
  * non-NULL is what marks "there is a previous layer") but their contents are not used.
  * ------------------------------------------------------------------------------------------- */
-/* Batches > 512: every statistics buffer (fstat_l, bstat_l) must be folded by this call between its producer and its
- * consumer (row 0 then holds the column totals and consumers read one row); a no-op for B <= 512.               */
-int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_t stream);
+/* Batches > 512 (round 6; rounds 1-5 folded the row partials with a launch per statistics buffer): fstat_l / bstat_l are then
+ * FIXED-POINT accumulators, int64 [8][Npad_l][4] (Npad = N rounded up to 16; RSX_TOWER_FIXED_STATS_DOUBLES(N) doubles): 8 rows of
+ * per-column hi(sum), lo(sum), hi(sum sq), lo(sum sq) with value = (hi * 2^32 + lo) * 2^-52 -- producer workgroup b adds its partial sums
+ * to row b & 7 with non-returning integer atomics (order-independent, hence deterministic; resolution 2.2e-16, |sum| < 8.8e12;
+ * 8 rows because same-address atomics serialise), every consumer adds the 8 rows: no launch between producer and consumer.
+ * The rows must be ZERO before the step's first producer adds to them.  No consumer can clear it (other workgroups of
+ * the same launch still read it), so later launches of the same stream do, through `zero_stats` / `zero_n` (doubles; NULL / 0:
+ * nothing) of rsx_tower_fwd_layer / rsx_gather_tower_fwd0 / rsx_tower_bwd_layer_defer: the FIRST layer's backward launch (the
+ * step's last tower launch) clears every row of the tower except bstat_0, which it consumes itself; the first layer's forward
+ * launch of the next step clears bstat_0.  Rows start zeroed (caller allocates them so).                                    */
+#define RSX_TOWER_FIXED_STATS_MIN_B 513
+#define RSX_TOWER_FIXED_STATS_DOUBLES(N) (8 * 4 * (((N) + 15) / 16 * 16))
 /* a_out = relu(in' . W + bias); in' = in for the first layer (fstat_prev == NULL), else
  * dropout(BN(in)) with the previous layer's statistics reduced from fstat_prev (bn_prev_out receives them). */
 int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out, double* fstat_out,
                         const double* fstat_prev, const float* gamma_prev, const float* beta_prev,
                         const float* mask_prev, float* bn_prev_out, const uint32_t* rng_step, uint32_t seed,
                         int layer, float dropout_rate, int B, int K, int N, const rsx_sort_job* sort_h,
-                        const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+                        const rsx_adam_slice* sweep_h, double* zero_stats, int zero_n, rsx_stream_t stream);
 /* rsx_gather_fm_fwd + the FIRST rsx_tower_fwd_layer in ONE launch (round 4): the input_layer lookup, first-order sum and FM
  * term of deepfm/deepfm.py:85-98 (= fm/fm.py:117-129) and a_0 = relu(E . W_0 + b_0) of deepfm/deepfm.py:103-104, K = F * D.
  * Every tile workgroup gathers its 16 examples' rows into LDS and feeds the MFMA A operand from there; E / S / y1 / y2 are
@@ -486,7 +495,7 @@ int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, floa
 int rsx_gather_tower_fwd0(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids, float* E,
                           float* S, float* y1, float* y2, uint64_t w1_field_mask, int F, int D, const float* W,
                           const float* bias, float* a_out, double* fstat_out, int B, int N, const rsx_sort_job* sort_h,
-                          const rsx_adam_slice* sweep_h, rsx_stream_t stream);
+                          const rsx_adam_slice* sweep_h, double* zero_stats, int zero_n, rsx_stream_t stream);
 int rsx_gather_tower_fwd0_supported(int B, int F, int D);
 /* o = dropout(BN(a_last)); u = o.wd + bd; z = wo[0]*act0(s0+c0) + wo[1]*s1 + wo[2]*act2(u) + bo (wo NULL: plain sum);
  * prob = sigmoid(z); per-row-tile partials of the loss and of every head gradient; dy_last / bstat_last = gradient
@@ -546,7 +555,7 @@ int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, c
                               float* dbd, float* dwo, float* dbo, float* dc0, float* loss, const uint32_t* rng_step,
                               uint32_t seed, int layer, float dropout_rate, int B, int K, int N, const rsx_sort_job* sort_h,
                               const rsx_adam_slice* sweep_h, float* dw_partials, rsx_dw_reduce_job* reduce_out,
-                              rsx_stream_t stream);
+                              double* zero_stats, int zero_n, rsx_stream_t stream);
 int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njobs, rsx_stream_t stream);
 
 /* sweep_h (host pointer, nullable, on all three tower entry points): a slice of the untouched-row optimizer sweep

@@ -159,15 +159,14 @@ _SIGS = {
     "rsx_segsum_partials_ride": (_I, [_P] * 9 + [_U64, _I, _I, _I, _I, _I, _P, C.POINTER(ScatterRiders), _P]),
     "rsx_adam_state_init_h": (_I, [_P, _F, _F]),
     "rsx_adam_tf1_multi": (_I, [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _F, _P]),
-    "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P]),
-    "rsx_gather_tower_fwd0": (_I, [_P] * 8 + [_U64, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "rsx_tower_fwd_layer": (_I, [_P] * 11 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "rsx_gather_tower_fwd0": (_I, [_P] * 8 + [_U64, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "rsx_gather_tower_fwd0_supported": (_I, [_I, _I, _I]),
-    "rsx_tower_reduce_partials": (_I, [_P, _I, _I, _P]),
     "rsx_tower_head": (_I, [_P] * 22 + [C.c_uint32, _I, _F, _F, _I, _I, _I, _I, _P, _P]),
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
     "rsx_fm_head_terms": (_I, [_P] * 14 + [_I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
-    "rsx_tower_bwd_layer_defer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "rsx_tower_bwd_layer_defer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "rsx_tower_reduce_dw_jobs": (_I, [_P, _I, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),

@@ -15,6 +15,7 @@
 #include "rsx_common.h"
 #include "gather_rows_device.h"
 #include "step_riders_device.h"
+#include "split_device.h"
 RSX_STAMP_DECL
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -236,6 +237,175 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void din_attn_fwd_k(const AttnFwdAr
   }
 }
 
+
+// =====================================================================================================================
+// Forward on the bf16 matrix cores with SPLIT operands (round 6; split_device.h: every product exact to 2^-24 of itself, the
+// fp32 kernel's tolerance tests unchanged).  The fp32 MFMA above spends 7 040 matrix-core cycles per 16-row tile (4K = 128:
+// 32 + 20 k-steps of 4 over 5 + 3 column tiles, 32 cycles each), this one 2 784 (4 + 3 k-steps of 32, six plane products of 16
+// cycles each).  Both GEMMs are computed TRANSPOSED -- the weight fragment is the MFMA's first operand, the activation rows
+// its second: acc[r] = z[row = lane & 15][n = 16 nt + 4 (lane >> 4) + r] -- so that
+//   * a lane holds four consecutive columns of ITS row: a1 / a2 leave as one 16-byte store per column tile and lane (the fp32
+//     kernel stores 4-byte elements of four different rows), and
+//   * the relu + dropout output is already where the next layer's operand wants it: the reduction index of a GEMM may be
+//     permuted freely as long as both operands agree, so layer 1 takes k-step ks, element j of lane (i, kq) to mean
+//     k = 16 (2 ks + (j >> 2)) + 4 kq + (j & 3) -- the lane's own accumulators of column tiles 2 ks and 2 ks + 1 -- and W1's
+//     fragments are staged in LDS with the same permutation.  No LDS transposition tile, no barrier inside the row loop.
+// Weights: split into their three bf16 planes while they are staged (fragment-major: one ds_read_b128 per plane and fragment).
+// dyn LDS: 3 planes x (2 KB x 5 + 3 x 3) fragments x 1 KiB + biases = 87.6 KiB (K = 32), 57.6 KiB (K = 16).
+// =====================================================================================================================
+constexpr int FSP_WAVES = 16;
+template <int KB>
+__global__ __launch_bounds__(64 * FSP_WAVES) void din_attn_fwd_split_k(const AttnFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = 16 * KB, KS0 = 2 * KB, NT1 = 5, NT2 = 3, KS1 = 3;
+  constexpr int FT = 64 * FSP_WAVES;
+  sp_bf16x8* sW0 = reinterpret_cast<sp_bf16x8*>(lds);              // [3][KS0][NT1][64]
+  sp_bf16x8* sW1 = sW0 + 3 * KS0 * NT1 * 64;                       // [3][KS1][NT2][64]
+  float* sb0 = reinterpret_cast<float*>(sW1 + 3 * KS1 * NT2 * 64); // [80]
+  float* sb1 = sb0 + 16 * NT1;                                     // [48]
+  float* sw2 = sb1 + 16 * NT2;                                     // [48]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  // ---- weights -> split fragments (element j of lane (i, kq) of fragment (ks, nt) = W[k][n = 16 nt + i]) ----
+  for (int fr = tid; fr < KS0 * NT1 * 64; fr += FT) {
+    const int l = fr & 63, nt = (fr >> 6) % NT1, ks = (fr >> 6) / NT1;
+    const int n = 16 * nt + (l & 15), k0 = 32 * ks + 8 * (l >> 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p.W0[(size_t)(k0 + j) * p.N1 + (n < p.N1 ? n : 0)];
+    if (n >= p.N1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    sp_bf16x8 pl[3];
+    sp_split8(v, pl);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) sW0[((s * KS0 + ks) * NT1 + nt) * 64 + l] = pl[s];
+  }
+  for (int fr = tid; fr < KS1 * NT2 * 64; fr += FT) {
+    const int l = fr & 63, nt = (fr >> 6) % NT2, ks = (fr >> 6) / NT2;
+    const int n = 16 * nt + (l & 15), q4 = 4 * (l >> 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * (2 * ks + (j >> 2)) + q4 + (j & 3);       // (layer 1's permuted reduction index, see above)
+      const bool ok = k < p.N1 && n < p.N2;
+      const float x = p.W1[(size_t)(k < p.N1 ? k : 0) * p.N2 + (n < p.N2 ? n : 0)];
+      v[j] = ok ? x : 0.f;
+    }
+    sp_bf16x8 pl[3];
+    sp_split8(v, pl);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) sW1[((s * KS1 + ks) * NT2 + nt) * 64 + l] = pl[s];
+  }
+  for (int e = tid; e < 16 * NT1; e += FT) sb0[e] = e < p.N1 ? p.b0[e] : 0.f;
+  for (int e = tid; e < 16 * NT2; e += FT) {
+    sb1[e] = e < p.N2 ? p.b1[e] : 0.f;
+    sw2[e] = e < p.N2 ? p.W2[e] : 0.f;
+  }
+  const DropRng d1 = drop_make(p.rate, p.mask1, p.rng_step, p.seed, p.layer0);
+  const DropRng d2 = drop_make(p.rate, p.mask2, p.rng_step, p.seed, p.layer0 + 1);
+  const float bias2 = p.b2[0];
+  __syncthreads();
+  const int Mv = p.count ? p.count[0] : p.M;
+  const int nblk = (Mv + 16 * FSP_WAVES - 1) / (16 * FSP_WAVES);
+  const sp_f32x4 zf = {0.f, 0.f, 0.f, 0.f};
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {      // persistent: the weights are staged once per workgroup
+    const int jr = (blk * FSP_WAVES + wv) * 16 + i;               // position in the (possibly compacted) row list
+    const bool mok = jr < Mv;
+    const int jc = mok ? jr : 0;
+    const int m = p.rows ? p.rows[jc] : jc;                       // the lane's row (original index)
+    // the lane's eight elements of h and q: K = 32 -> [8 kq, 8 kq + 8); K = 16 -> [8 (kq & 1), ..) (kq >> 1 picks the segment)
+    const int c0 = KB == 2 ? 8 * kq : 8 * (kq & 1);
+    const float4* hp = reinterpret_cast<const float4*>(p.H + (size_t)m * K + c0);
+    const float4* qp = reinterpret_cast<const float4*>(p.q + (size_t)(m / p.P) * K + c0);
+    const float4 h0 = hp[0], h1 = hp[1], q0 = qp[0], q1 = qp[1];
+    const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    // ---- layer 0: z1^T = W0^T . [h, q, h*q, h-q]^T ------------------------------------------------------------
+    sp_f32x4 acc1[NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) acc1[nt] = zf;
+#pragma unroll
+    for (int ks = 0; ks < KS0; ++ks) {
+      float a[8];
+      const int seg = KB == 2 ? ks : 2 * ks + (kq >> 1);          // (K = 16: lane-dependent -- selects, no divergence)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pr = hv[j] * qv[j], df = hv[j] - qv[j];
+        a[j] = seg == 0 ? hv[j] : (seg == 1 ? qv[j] : (seg == 2 ? pr : df));
+      }
+      sp_bf16x8 ap[3];
+      sp_split8(a, ap);
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+        sp_bf16x8 wp[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wp[s] = sW0[((s * KS0 + ks) * NT1 + nt) * 64 + lane];
+        acc1[nt] = sp_mma3(wp, ap, acc1[nt]);
+        // (without the fence the scheduler hoists the fragment reads of ALL 20 (k-step, tile) pairs -- 240 registers -- to the top)
+        if ((nt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // acc1[nt][r] = z1[row i][n = 16 nt + 4 kq + r]: bias, relu, the a1 store, dropout -- and it stays in registers
+    float a1d[NT1 + 1][4];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+      const int n0 = 16 * nt + 4 * kq;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc1[nt][r] + sb0[n0 + r], 0.f);
+      const bool nok = n0 < p.N1;                                 // (N1 % 4 == 0: a quad is valid as a whole)
+      if (mok && nok) *reinterpret_cast<float4*>(p.a1 + (size_t)m * p.N1 + n0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1d[nt][r] = nok ? v[r] * drop_mul(d1, p.mask1, (size_t)m * p.N1 + n0 + r) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a1d[NT1][r] = 0.f;                // (column tile 5: the padding half of layer 1's last k-step)
+    // ---- layer 1: z2^T = W1^T . a1d^T ---------------------------------------------------------------------------
+    sp_f32x4 acc2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) acc2[nt] = zf;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      const float a[8] = {a1d[2 * ks][0], a1d[2 * ks][1], a1d[2 * ks][2], a1d[2 * ks][3],
+                          a1d[2 * ks + 1][0], a1d[2 * ks + 1][1], a1d[2 * ks + 1][2], a1d[2 * ks + 1][3]};
+      sp_bf16x8 ap[3];
+      sp_split8(a, ap);
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) {
+        sp_bf16x8 wp[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wp[s] = sW1[((s * KS1 + ks) * NT2 + nt) * 64 + lane];
+        acc2[nt] = sp_mma3(wp, ap, acc2[nt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- layer 2: w = a2d . W2 + b2 -----------------------------------------------------------------------------
+    float pw = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      const int n0 = 16 * nt + 4 * kq;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[nt][r] + sb1[n0 + r], 0.f);
+      const bool nok = n0 < p.N2;
+      if (mok && nok) *reinterpret_cast<float4*>(p.a2 + (size_t)m * p.N2 + n0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nok) pw += v[r] * drop_mul(d2, p.mask2, (size_t)m * p.N2 + n0 + r) * sw2[n0 + r];
+    }
+    pw += __shfl_xor(pw, 16);                                     // the row's four column quarters (kq = 0 .. 3)
+    pw += __shfl_xor(pw, 32);
+    if (kq == 0 && mok) p.w[m] = pw + bias2;
+  }
+}
+
+static inline size_t attn_fwd_split_lds_bytes(int KB) {
+  return (size_t)3 * (2 * KB * 5 + 3 * 3) * 1024 + (16 * 5 + 2 * 16 * 3) * sizeof(float);
+}
+
 static inline size_t attn_fwd_lds_floats(int KB, int NT1, int NT2) {
   const size_t LD0 = 64 * KB + 4, N1P = 16 * NT1, LD1 = N1P + 4, N2P = 16 * NT2;
   return N1P * LD0 + N2P * LD1 + FWD_WAVES * 16 * LD1 + N1P + 2 * N2P;
@@ -254,6 +424,24 @@ extern "C" int rsx_din_attn_fwd(const float* H, const float* q, const float* W0,
   if ((K != 16 && K != 32) || N1 > 80 || N2 > 48) return RSX_EUNSUPPORTED;     // instantiated envelope (din/din.py:85)
   AttnFwdArgs p{H, q, W0, b0, W1, b1, W2, b2, a1, a2, w, mask1, mask2, rng_step, seed, (uint32_t)layer0, dropout_rate,
                 B * P, P, N1, N2, rows, count};
+  // Round 6: the split-operand kernel on the bf16 matrix cores (din.py's shapes: N1, N2 multiples of 4, 16-byte aligned
+  // activations); RSX_DIN_ATTN_SPLIT=0: the fp32 MFMA kernel (A/B runs)
+  static const int split_env = getenv("RSX_DIN_ATTN_SPLIT") ? atoi(getenv("RSX_DIN_ATTN_SPLIT")) : 1;
+  if (split_env && N1 % 4 == 0 && N2 % 4 == 0 && ((((uintptr_t)H | (uintptr_t)q | (uintptr_t)a1 | (uintptr_t)a2) & 15) == 0)) {
+    const int nb = (p.M + 16 * FSP_WAVES - 1) / (16 * FSP_WAVES);
+    const dim3 g((unsigned)(nb < 256 ? nb : 256)), b(64 * FSP_WAVES);
+    const size_t lds = attn_fwd_split_lds_bytes(K / 16);
+    if (K == 32) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_split_k<2>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (attr != hipSuccess) return RSX_EUNSUPPORTED;
+      RSX_LAUNCH((din_attn_fwd_split_k<2>), g, b, lds, rsx_s(stream), p);
+    } else {
+      RSX_LAUNCH((din_attn_fwd_split_k<1>), g, b, lds, rsx_s(stream), p);
+    }
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+  }
   const int nblk = (p.M + 16 * FWD_WAVES - 1) / (16 * FWD_WAVES);
   const dim3 grid((unsigned)(nblk < 256 ? nblk : 256)), block(64 * FWD_WAVES);    // one workgroup per CU (144 KB of LDS)
   if (K == 32) {

@@ -47,11 +47,92 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// fixed-order fp64 sum of the RT per-row-tile partials of one column.  All loads of a 16-tile block are issued before the
+// ---- batch-norm statistics of LARGE batches (B > 512): order-independent fixed-point accumulators (round 6) -----------------
+// Small batches: every producer workgroup writes its row tile's partial column sums (sum, sum of squares) as one row of
+// st[RT, 2, N] and every consumer workgroup adds the <= 32 rows itself in a fixed order.  At batch 4 096 there are 256 rows;
+// rounds 1-5 folded them with a launch of their own per statistics buffer (tower_reduce_partials_k: 4 launches = 19.6 us of
+// dcn.py's 191 us step, asked for removal four rounds in a row).  A grid-wide fold inside the producer needs a last-arriver
+// hand-off (a returning atomic + an L2 write-back on every producer's tail); a floating-point atomic add
+// would make the sums depend on the arrival order.  Integer addition does not: every producer adds its partial sums to ONE
+// row as FIXED-POINT integers with plain (non-returning) 64-bit atomics -- bit-identical whatever the order, no launch, no
+// tail.  Value v = s * 2^52 (exact: a power-of-two scale) is split into two limbs, hi = rint(v / 2^32) and lo = rint(v - hi *
+// 2^32) in [-2^31, 2^31]: the resolution is 2^-52 = 2.2e-16 absolute (the fp64 sums it replaces round at ~1e-16 relative), the
+// range |s| < 2^43 = 8.8e12, and 2^20 producers cannot overflow the low limb.  Layout of a fixed row: int64 [Npad][4] = per
+// column hi(sum), lo(sum), hi(sum sq), lo(sum sq) (8 such rows per buffer, see STAT_FIX_ROWS).  The rows must be ZERO when the step's first
+// producer runs: the consumers cannot clear it
+// (other workgroups of the same launch still read it), so a LATER launch of the same stream does -- the first layer's backward
+// launch (the last tower launch of a step) clears every row except the one it consumes itself, and the first layer's forward
+// launch of the next step clears that one (`zero_stats`: rsx_tower_fwd_layer / rsx_tower_bwd_layer).
+constexpr int TOWER_FIX_MIN_B = 513;              // B >= this: fixed-point rows (== the old "pre-reduced" threshold)
+constexpr double STAT_FIX_SCALE = 4503599627370496.0;        // 2^52
+constexpr double STAT_FIX_LIMB = 4294967296.0;               // 2^32
+// Same-address atomics serialise (~12 ns each: 256 producers on one row cost 3.5 us per launch, measured stand-alone --
+// scripts/micro/atomic_shard.hip, profiles/r06_c_atomic_shard.txt -- and more at the tail of a real launch, where all producers
+// finish together: dcn.py's step got 12 us SLOWER with one row); 8 rows, producer workgroup b adding to row b & 7, cost 0.3 us.
+// A fixed buffer is therefore int64 [STAT_FIX_ROWS][Npad][4], Npad = N rounded up to 16 (rows start on 128-byte lines);
+// consumers add the 8 rows as integers (exact, order-free).
+constexpr int STAT_FIX_ROWS = 8;
+__host__ __device__ __forceinline__ int stat_fix_npad(const int N) { return (N + 15) & ~15; }
+__device__ __forceinline__ void stat_fix_add(double* __restrict__ st, const int N, const int col, const double s1, const double s2) {
+  const int NP = stat_fix_npad(N);
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(st) + (size_t)(blockIdx.x & (STAT_FIX_ROWS - 1)) * 4 * NP;
+  const double v1 = s1 * STAT_FIX_SCALE, v2 = s2 * STAT_FIX_SCALE;
+  const double h1 = rint(v1 * (1.0 / STAT_FIX_LIMB)), h2 = rint(v2 * (1.0 / STAT_FIX_LIMB));
+  const long long l1 = __double2ll_rn(v1 - h1 * STAT_FIX_LIMB), l2 = __double2ll_rn(v2 - h2 * STAT_FIX_LIMB);
+  // (results unused: the compiler emits the non-returning form -- fire and forget, nothing on the workgroup's tail)
+  // (a column's four limbs are contiguous: the consumers fetch them with two 16-byte loads per row)
+  atomicAdd(a + 4 * col + 0, (unsigned long long)__double2ll_rn(h1));
+  atomicAdd(a + 4 * col + 1, (unsigned long long)l1);
+  atomicAdd(a + 4 * col + 2, (unsigned long long)__double2ll_rn(h2));
+  atomicAdd(a + 4 * col + 3, (unsigned long long)l2);
+}
+__device__ __forceinline__ void stat_fix_read(const double* __restrict__ st, const int N, const int col, double& s1, double& s2) {
+  const int NP = stat_fix_npad(N);
+  typedef long long ll2 __attribute__((ext_vector_type(2)));
+  const ll2* a = reinterpret_cast<const ll2*>(st) + 2 * col;
+  ll2 t[STAT_FIX_ROWS][2];
+#pragma unroll
+  for (int r = 0; r < STAT_FIX_ROWS; ++r) {      // all 16 loads (16 bytes each) in flight: one memory round trip
+    t[r][0] = a[(size_t)r * 2 * NP];
+    t[r][1] = a[(size_t)r * 2 * NP + 1];
+  }
+  long long h1 = 0, l1 = 0, h2 = 0, l2 = 0;
+#pragma unroll
+  for (int r = 0; r < STAT_FIX_ROWS; ++r) {
+    h1 += t[r][0].x; l1 += t[r][0].y; h2 += t[r][1].x; l2 += t[r][1].y;
+  }
+  s1 = ((double)h1 * STAT_FIX_LIMB + (double)l1) * (1.0 / STAT_FIX_SCALE);
+  s2 = ((double)h2 * STAT_FIX_LIMB + (double)l2) * (1.0 / STAT_FIX_SCALE);
+}
+// one producer's partial column sums: a row of the partials array, or an addition to the fixed row
+__device__ __forceinline__ void stat_put(double* __restrict__ st, const int RT, const int row, const int N, const int col,
+                                         const double s1, const double s2) {
+  if (RT == 0) {
+    stat_fix_add(st, N, col, s1, s2);
+  } else {
+    st[((size_t)row * 2 + 0) * N + col] = s1;
+    st[((size_t)row * 2 + 1) * N + col] = s2;
+  }
+}
+// clears fixed rows for the step's later producers (see above): the launch's first STAT_ZERO_WGS workgroups take a slice each
+// (n % 2 == 0, 16-byte aligned: the host lays the buffers out so)
+constexpr int STAT_ZERO_WGS = 8;
+__device__ __forceinline__ void stat_zero(double* __restrict__ z, const int n) {
+  if ((int)blockIdx.x >= STAT_ZERO_WGS) return;
+  double2* z2 = reinterpret_cast<double2*>(z);
+  for (int e = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x; e < (n >> 1); e += STAT_ZERO_WGS * (int)blockDim.x)
+    z2[e] = make_double2(0.0, 0.0);
+}
+
+// fixed-order fp64 sum of the RT per-row-tile partials of one column (RT == 0: the fixed-point row of a large batch).  All loads of a 16-tile block are issued before the
 // first add (batch 256 = 16 row tiles = ONE memory round trip per consumer instead of two; every tower launch starts with
 // this reduction, so the round trip is on the step's critical path five times).
 __device__ __forceinline__ void col_partials(const double* __restrict__ st, int RT, int N, int col, double& s1,
                                              double& s2) {
+  if (RT == 0) {
+    stat_fix_read(st, N, col, s1, s2);
+    return;
+  }
   s1 = 0.0;
   s2 = 0.0;
   int r = 0;
@@ -171,6 +252,8 @@ struct FwdArgs {
   double inv_B;            // 1.0 / B
   int ct, n_own;          // column tiles; ct * row tiles = workgroups of the layer itself
   int n_sort;             // extra workgroups running the step's per-field dedup sort (0: none), before the sweep slice
+  double* zero_p;         // fixed-point statistics rows this launch clears for the step's later producers (stat_zero), or null
+  int zero_n;
   SortArgs sort;
   AdamSlice sweep;        // optional slice of the untouched-row optimizer sweep carried as extra workgroups
 };
@@ -196,10 +279,9 @@ __device__ __forceinline__ void fwd_tile_epilogue(const FwdArgs& p, const float 
       cred[((tid >> 6) * 2 + 1) * 16 + lane] = s2;
     }
     __syncthreads();
-    if (tid < 16 && ocol < p.N) {
-      p.fstat_out[((size_t)by * 2 + 0) * p.N + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
-      p.fstat_out[((size_t)by * 2 + 1) * p.N + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
-    }
+    if (tid < 16 && ocol < p.N)
+      stat_put(p.fstat_out, p.RT, by, p.N, ocol, ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid],
+               ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid]);
   }
 }
 
@@ -208,6 +290,7 @@ __device__ __forceinline__ void fwd_tile_epilogue(const FwdArgs& p, const float 
 template <bool RID>
 __global__ __launch_bounds__(256) void tower_fwd_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.zero_n > 0) stat_zero(p.zero_p, p.zero_n);
   if (RID && (int)blockIdx.x >= p.n_own + p.n_sort) {
     RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
     return;
@@ -313,6 +396,7 @@ __global__ __launch_bounds__(256, 1) void tower_gather_fwd_k(const GatherFwdArgs
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const FwdArgs& p = g.f;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (p.zero_n > 0) stat_zero(p.zero_p, p.zero_n);
   if ((int)blockIdx.x >= p.n_own) {
     const int r = blockIdx.x - p.n_own;
     if (r < g.n_gout) {
@@ -603,8 +687,7 @@ __global__ __launch_bounds__(256) void tower_head_k(const HeadArgs p) {
       sdx[ww] = ((double)d0 * (double)x0 + (double)d1 * (double)x1) + ((double)d2 * (double)x2 + (double)d3 * (double)x3);
       swd[ww] = (log2_[4 * ww][c] + log2_[4 * ww + 1][c]) + (log2_[4 * ww + 2][c] + log2_[4 * ww + 3][c]);
     }
-    p.bstat_last[((size_t)blockIdx.x * 2 + 0) * p.N + c] = sdy[0] + sdy[1] + sdy[2] + sdy[3];
-    p.bstat_last[((size_t)blockIdx.x * 2 + 1) * p.N + c] = sdx[0] + sdx[1] + sdx[2] + sdx[3];
+    stat_put(p.bstat_last, p.RT, (int)blockIdx.x, p.N, c, sdy[0] + sdy[1] + sdy[2] + sdy[3], sdx[0] + sdx[1] + sdx[2] + sdx[3]);
     p.dwd_part[(size_t)blockIdx.x * p.N + c] = swd[0] + swd[1] + swd[2] + swd[3];
   }
   if (tid < 8) {                                   // the 16 rows of the tile in ascending order
@@ -664,6 +747,8 @@ struct BwdArgs {
   int dxg;                   // small batches: column tiles per d(input) workgroup (4: grouped LDS-staged tiles; 0: one tile)
   int n_head;                // 1 when the head-partial reduce block is present
   int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
+  double* zero_p;            // fixed-point statistics rows this launch clears for the NEXT step's producers (stat_zero), or null
+  int zero_n;
   SortArgs sort;
   AdamSlice sweep;           // optional slice of the untouched-row optimizer sweep (after the sort workgroups)
 };
@@ -835,10 +920,7 @@ __device__ __forceinline__ void bwd_dx_group_tile(const BwdArgs& p, const int bi
   if (!first) {
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    if (kq == 0 && wok) {
-      p.bstat_prev[((size_t)rt * 2 + 0) * p.K + ocol] = s1;
-      p.bstat_prev[((size_t)rt * 2 + 1) * p.K + ocol] = s2;
-    }
+    if (kq == 0 && wok) stat_put(p.bstat_prev, p.RT, rt, p.K, ocol, s1, s2);
   }
   RSX_STAMP(first ? 19 : 27, bid == 0);
 }
@@ -901,6 +983,7 @@ __device__ __forceinline__ void tower_head_reduce(const BwdArgs& p, float* part 
 template <bool SPLIT, bool RID>
 __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.zero_n > 0) stat_zero(p.zero_p, p.zero_n);
   float* Lm = lds; float* Lr = lds + p.N; float* Lk = lds + 2 * p.N; float* Ls = lds + 3 * p.N; float* Lx = lds + 4 * p.N;
   float* part = lds + 5 * p.N + ((4 - (5 * p.N) % 4) % 4);         // [4][256], 16-byte aligned
   double* cred = reinterpret_cast<double*>(part + 1024);              // [4][2][16]
@@ -1006,10 +1089,9 @@ __global__ __launch_bounds__(256) void tower_bwd_k(const BwdArgs p) {
         cred[((tid >> 6) * 2 + 1) * 16 + lane] = s2;
       }
       __syncthreads();
-      if (tid < 16 && ocol < p.K) {
-        p.bstat_prev[((size_t)rt * 2 + 0) * p.K + ocol] = ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid];
-        p.bstat_prev[((size_t)rt * 2 + 1) * p.K + ocol] = ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid];
-      }
+      if (tid < 16 && ocol < p.K)
+        stat_put(p.bstat_prev, p.RT, rt, p.K, ocol, ((cred[0 * 16 + tid] + cred[2 * 16 + tid]) + cred[4 * 16 + tid]) + cred[6 * 16 + tid],
+                 ((cred[1 * 16 + tid] + cred[3 * 16 + tid]) + cred[5 * 16 + tid]) + cred[7 * 16 + tid]);
     }
     }
     RSX_STAMP(sb0 + 3, bid == 0);
@@ -1125,45 +1207,6 @@ __global__ __launch_bounds__(256) void tower_reduce_dw_k(const float* __restrict
   }
 }
 
-// Large batches: fold the RT per-row-tile partials of a statistics buffer into row 0 (fixed order), so that every
-// consumer workgroup reads ONE partial per column instead of RT.  grid = ceil(2N/64), block = 64.
-__global__ __launch_bounds__(1024) void tower_reduce_partials_k(double* __restrict__ st, int RT, int N2) {
-  // 16 waves: wave w sums the contiguous row range [w*per, (w+1)*per) of its 64 columns (8 loads in flight), then the
-  // 16 partials are added in ascending wave order -- a fixed association, and 16x shorter dependent chains
-  __shared__ double part[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int per = (RT + 15) / 16;
-  const int r0 = w * per, r1 = r0 + per < RT ? r0 + per : RT;
-  double s = 0.0;
-  if (c < N2) {
-    int r = r0;
-    for (; r + 16 <= r1; r += 16) {      // (batch 4 096: exactly one such batch per wave -- one memory round trip)
-      double t[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) s += t[u];
-    }
-    for (; r + 4 <= r1; r += 4) {
-      double t[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = st[(size_t)(r + u) * N2 + c];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s += t[u];
-    }
-    for (; r < r1; ++r) s += st[(size_t)r * N2 + c];
-  }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < N2) {
-    double t = part[0][lane];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += part[k][lane];
-    st[c] = t;
-  }
-}
-
 // =============================================================================================
 // LARGE BATCHES (B >= TOWER_BIG_MIN_B).  The tiles above are built for batch 256: one 16x16 output tile per workgroup,
 // its reduction split over the 4 waves, operands straight from global memory -- 1 792 workgroups of 7.5 us each for
@@ -1183,7 +1226,10 @@ static inline int tower_big_min_k(bool bwd, int B) {
   static const int f = getenv("RSX_TOWER_BIG_MIN_K_FWD") ? atoi(getenv("RSX_TOWER_BIG_MIN_K_FWD")) : 0;
   static const int b = getenv("RSX_TOWER_BIG_MIN_K_BWD") ? atoi(getenv("RSX_TOWER_BIG_MIN_K_BWD")) : 0;
   if (bwd) return b > 0 ? b : (B >= 4096 ? TOWER_BIG_MIN_K_BWD_4096 : TOWER_BIG_MIN_K);
-  return f > 0 ? f : TOWER_BIG_MIN_K;
+  // (round 6: with the fixed-point statistics every consumer workgroup adds 8 rows of its input columns' accumulators; the
+  // small-tile forward of a 100-wide layer at batch 4 096 is 1 792 workgroups doing so, the large-batch form 256 -- dcn.py's
+  // step 0.1850 -> 0.1817 ms)
+  return f > 0 ? f : (B >= 4096 ? TOWER_BIG_MIN_K_BWD_4096 : TOWER_BIG_MIN_K);
 }
 // LDS row stride of a 16-row operand tile read with ds_read_b128 by lane (row = lane & 15, k-quarter = lane >> 4): a stride
 // == 8 (mod 64) floats puts the 16 lanes of every hardware lane group on distinct banks
@@ -1195,6 +1241,7 @@ __host__ __device__ inline int big_stride(int K) { return (K + 127) / 128 * 128 
 template <int NTW, bool RID>
 __global__ __launch_bounds__(256) void tower_fwd_big_k(const FwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.zero_n > 0) stat_zero(p.zero_p, p.zero_n);
   if (RID) {
     if ((int)blockIdx.x >= p.n_own + p.n_sort) {
       RSX_RIDE_SWEEP(p.sweep.args, p.sweep.blk_lo + (blockIdx.x - p.n_own - p.n_sort));
@@ -1357,10 +1404,7 @@ __global__ __launch_bounds__(256) void tower_fwd_big_k(const FwdArgs p) {
     if (p.fstat_out != nullptr) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      if (kq == 0 && cok) {
-        p.fstat_out[((size_t)rt * 2 + 0) * p.N + col] = s1;
-        p.fstat_out[((size_t)rt * 2 + 1) * p.N + col] = s2;
-      }
+      if (kq == 0 && cok) stat_put(p.fstat_out, p.RT, rt, p.N, col, s1, s2);
     }
   }
   RSX_STAMP(stb + 3, blockIdx.x == 0);
@@ -1386,6 +1430,7 @@ __host__ __device__ inline int big_ld32(int n) { return ((n + 15) & ~15) + 4; } 
 template <int NTX, int NTD, bool RID>
 __global__ __launch_bounds__(256) void tower_bwd_big_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.zero_n > 0) stat_zero(p.zero_p, p.zero_n);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
@@ -1528,10 +1573,7 @@ __global__ __launch_bounds__(256) void tower_bwd_big_k(const BwdArgs p) {
         if (!first) {
           s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-          if (kq == 0 && cok) {
-            p.bstat_prev[((size_t)rt * 2 + 0) * p.K + kc] = s1;
-            p.bstat_prev[((size_t)rt * 2 + 1) * p.K + kc] = s2;
-          }
+          if (kq == 0 && cok) stat_put(p.bstat_prev, p.RT, rt, p.K, kc, s1, s2);
         }
       }
     }
@@ -1749,18 +1791,9 @@ extern "C" int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njo
 }
 
 // validates a piggy-backed sort job for a 256-thread carrier launch and grows the launch's dynamic LDS if needed
-// consumers read pre-reduced statistics (1 row) when the batch is large: see rsx_tower_reduce_partials
-static inline int stat_rows(int B) { return B > 512 ? 1 : (B + TM - 1) / TM; }
+// consumers read ONE fixed-point row when the batch is large (stat_fix_add / stat_fix_read above)
+static inline int stat_rows(int B) { return B >= TOWER_FIX_MIN_B ? 0 : (B + TM - 1) / TM; }       // 0: the fixed-point row
 
-extern "C" int rsx_tower_reduce_partials(double* stat, int B, int N, rsx_stream_t stream) {
-  if (B < 0 || N <= 0) return RSX_EINVAL;
-  if (B <= 512) return RSX_OK;   // small batches: consumers sum the <= 32 partials themselves
-  if (!stat) return RSX_EINVAL;
-  const int RT = (B + TM - 1) / TM;
-  RSX_LAUNCH(tower_reduce_partials_k, dim3((2 * N + 63) / 64), dim3(1024), 0, rsx_s(stream), stat, RT, 2 * N);
-  RSX_CHECK_LAUNCH();
-  return RSX_OK;
-}
 
 // ------------------------------------------------------------------ C ABI ----------------------------
 extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float* bias, float* a_out,
@@ -1768,10 +1801,11 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
                                    const float* beta_prev, const float* mask_prev, float* bn_prev_out,
                                    const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
                                    int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
-                                   rsx_stream_t stream) {
+                                   double* zero_stats, int zero_n, rsx_stream_t stream) {
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!in || !W || !bias || !a_out) return RSX_EINVAL;
+  if (zero_n < 0 || (zero_n > 0 && !zero_stats)) return RSX_EINVAL;
   if (K % 4 != 0) return RSX_EUNSUPPORTED;
   // previous layer with batch-norm: gamma, beta and bn_prev_out all given; without (din MLP): all three NULL
   if (fstat_prev != nullptr && gamma_prev != nullptr && (!beta_prev || !bn_prev_out)) return RSX_EINVAL;
@@ -1784,6 +1818,7 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
   p.rng_step = rng_step; p.seed = seed; p.layer_prev = (uint32_t)(layer - 1);
   p.rate = dropout_rate;
   p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B);
+  p.zero_p = zero_stats; p.zero_n = zero_n;
   p.inv_B = 1.0 / (double)B;
   p.ct = (N + 15) / 16;
   p.n_own = p.ct * ((B + TM - 1) / TM);
@@ -1832,10 +1867,12 @@ extern "C" int rsx_tower_fwd_layer(const float* in, const float* W, const float*
 extern "C" int rsx_gather_tower_fwd0(const float* tables, const float* w1, const int32_t* row_off, const int32_t* ids,
                                      float* E, float* S, float* y1, float* y2, uint64_t w1_field_mask, int F, int D,
                                      const float* W, const float* bias, float* a_out, double* fstat_out, int B, int N,
-                                     const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h, rsx_stream_t stream) {
+                                     const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h, double* zero_stats,
+                                     int zero_n, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || D <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (!tables || !row_off || !ids || !E || !W || !bias || !a_out) return RSX_EINVAL;
+  if (zero_n < 0 || (zero_n > 0 && !zero_stats)) return RSX_EINVAL;
   // the envelope (rsx_gather_tower_fwd0_supported): rows of 16 floats, a batch the small-batch tiles serve, an LDS tile that
   // leaves room for 3 workgroups per CU
   if (D != 16 || F > 64 || B >= TOWER_BIG_MIN_B) return RSX_EUNSUPPORTED;
@@ -1845,6 +1882,7 @@ extern "C" int rsx_gather_tower_fwd0(const float* tables, const float* w1, const
   p.fstat_prev = nullptr; p.gamma_prev = nullptr; p.beta_prev = nullptr; p.mask_prev = nullptr; p.bn_prev_out = nullptr;
   p.rng_step = nullptr; p.seed = 0; p.layer_prev = 0u; p.rate = 0.f;
   p.B = B; p.K = F * D; p.N = N; p.RT = stat_rows(B);
+  p.zero_p = zero_stats; p.zero_n = zero_n;
   p.inv_B = 1.0 / (double)B;
   p.ct = (N + 15) / 16;
   p.n_own = p.ct * ((B + TM - 1) / TM);
@@ -2070,7 +2108,8 @@ extern "C" int rsx_tower_bwd_layer_defer(const float*, const float*, const float
                                          const float*, float*, float*, float*, float*, const float*, const float*, const float*,
                                          const float*, float*, double*, const double*, const float*, float*, float*, float*,
                                          float*, float*, float*, const uint32_t*, uint32_t, int, float, int, int, int,
-                                         const rsx_sort_job*, const rsx_adam_slice*, float*, rsx_dw_reduce_job*, rsx_stream_t);
+                                         const rsx_sort_job*, const rsx_adam_slice*, float*, rsx_dw_reduce_job*, double*, int,
+                                         rsx_stream_t);
 extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const float* dy,
                                    const double* bstat, const float* bn, const float* gamma, float* dW, float* db,
                                    float* dgamma, float* dbeta, const float* bn_prev, const float* gamma_prev,
@@ -2082,7 +2121,7 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    float* dw_partials, rsx_stream_t stream) {
   return rsx_tower_bwd_layer_defer(in, W, a, dy, bstat, bn, gamma, dW, db, dgamma, dbeta, bn_prev, gamma_prev, beta_prev, mask_prev,
                                    dy_prev, bstat_prev, hpart, dwd_part, dwd, dbd, dwo, dbo, dc0, loss, rng_step, seed, layer,
-                                   dropout_rate, B, K, N, sort_h, sweep_h, dw_partials, nullptr, stream);
+                                   dropout_rate, B, K, N, sort_h, sweep_h, dw_partials, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, const float* dy,
@@ -2093,10 +2132,12 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
                                          float* dbd, float* dwo, float* dbo, float* dc0, float* loss,
                                          const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
                                          int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
-                                         float* dw_partials, rsx_dw_reduce_job* reduce_out, rsx_stream_t stream) {
+                                         float* dw_partials, rsx_dw_reduce_job* reduce_out, double* zero_stats,
+                                         int zero_n, rsx_stream_t stream) {
   if (reduce_out != nullptr) reduce_out->sb = 0;          // (0: nothing left to reduce for this layer)
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
+  if (zero_n < 0 || (zero_n > 0 && !zero_stats)) return RSX_EINVAL;
   if (!in || !W || !a || !dy || !bstat || !bn || !dW || !db || !dy_prev) return RSX_EINVAL;
   if (gamma != nullptr && (!dgamma || !dbeta)) return RSX_EINVAL;           // gamma NULL: this layer has no batch-norm
   if (bn_prev != nullptr && !bstat_prev) return RSX_EINVAL;
@@ -2114,6 +2155,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   p.rate = dropout_rate;
   p.has_wo = dwo != nullptr;
   p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B); p.RTh = (B + TM - 1) / TM;
+  p.zero_p = zero_stats; p.zero_n = zero_n;
   p.ct_k = (K + 15) / 16;
   p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;

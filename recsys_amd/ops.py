@@ -760,6 +760,26 @@ class FusedTower:
         self.dy = [torch.empty(B, n, device=dev) for n in self.widths]
         self.fstat = [torch.zeros(RT, 2, n, **f64) for n in self.widths]
         self.bstat = [torch.zeros(RT, 2, n, **f64) for n in self.widths]
+        # batches > 512 (include/rsx.h RSX_TOWER_FIXED_STATS_MIN_B): fixed-point accumulators per statistics buffer,
+        # int64 [8, n rounded up to 16, 4] viewed as doubles, all in one allocation ordered [bstat_0 | fstat_0 .. fstat_{L-1} | bstat_1 .. bstat_{L-1}]:
+        # the first layer's forward launch clears bstat_0 for its step, the first layer's backward launch everything else for the
+        # next one (two contiguous ranges)
+        self.fix = self.fix_eval = None
+        if self.cap > 512:
+            sz = [32 * ((n + 15) // 16 * 16) for n in self.widths]          # RSX_TOWER_FIXED_STATS_DOUBLES(n)
+
+            def fixed_rows():
+                flat = torch.zeros(2 * sum(sz), **f64)
+                o, fs, bs = sz[0], [], [flat[:sz[0]]]
+                for k in sz:
+                    fs.append(flat[o:o + k])
+                    o += k
+                for k in sz[1:]:
+                    bs.append(flat[o:o + k])
+                    o += k
+                return flat, fs, bs
+            self.fix, self.fstat_fix, self.bstat_fix = fixed_rows()
+            self.fix_eval, self.fstat_fix_eval, self.bstat_fix_eval = fixed_rows()     # infer's producers add here (never read)
         self.bn = [torch.zeros(2, n, device=dev) for n in self.widths]
         self.mask_flat = torch.ones(B * sum(self.widths), device=dev)
         self.dX = torch.empty(B, self.k0, device=dev)
@@ -854,6 +874,11 @@ class FusedTower:
                 check(L.rsx_mlp_nobn_reduce_job(C.byref(ms), C.byref(self.mlp_reduce_job)), "rsx_mlp_nobn_reduce_job")
             return self.loss, self.prob[:B], o_dX[:B], o_gs0[:B], o_gs1[:B]
         g = lambda name: P[name].grad
+        big = B > 512                      # fixed-point statistics rows instead of row partials (include/rsx.h)
+        fst = self.fstat_fix if big else self.fstat
+        bst = self.bstat_fix if big else self.bstat
+        z_fwd0 = (_ptr(bst[0]), bst[0].numel()) if big else (None, 0)
+        z_bwd0 = (_ptr(self.fix[bst[0].numel():]), self.fix.numel() - bst[0].numel()) if big else (None, 0)
         bnp = (lambda name: _ptr(P[name])) if self.bn_on else (lambda name: None)        # gamma / beta (None: no batch-norm)
         bng = (lambda name: _ptr(P[name].grad)) if self.bn_on else (lambda name: None)
         rs = _ptr(rng_step)
@@ -866,37 +891,33 @@ class FusedTower:
                 assert ar.F * ar.D == self.k0 and ids.shape[0] == B
                 check(L.rsx_gather_tower_fwd0(_ptr(ar.tables), _ptr(ar.w1) if gy1 is not None else None, _ptr(ar.row_off),
                                               _ptr(ids), _ptr(X), _ptr(gS), _ptr(gy1), _ptr(gy2), ar.w1_mask, ar.F, ar.D,
-                                              _ptr(P[f"{pre}.W0"]), _ptr(P[f"{pre}.b0"]), _ptr(self.a[0]), _ptr(self.fstat[0]),
-                                              B, self.widths[0], ref(sort_job) if sort_in_fwd else None, ref(sw[0]), st),
+                                              _ptr(P[f"{pre}.W0"]), _ptr(P[f"{pre}.b0"]), _ptr(self.a[0]), _ptr(fst[0]),
+                                              B, self.widths[0], ref(sort_job) if sort_in_fwd else None, ref(sw[0]),
+                                              z_fwd0[0], z_fwd0[1], st),
                       "rsx_gather_tower_fwd0")
-                if self.bn_on:
-                    check(L.rsx_tower_reduce_partials(_ptr(self.fstat[0]), B, self.widths[0], st))
                 continue
             check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
-                                        _ptr(self.a[l]), _ptr(self.fstat[l]),
-                                        _ptr(self.fstat[l - 1]) if l else None,
+                                        _ptr(self.a[l]), _ptr(fst[l]),
+                                        _ptr(fst[l - 1]) if l else None,
                                         bnp(f"{pre}.gamma{l - 1}") if l else None,
                                         bnp(f"{pre}.beta{l - 1}") if l else None,
                                         _ptr(mk[l - 1]) if l else None, _ptr(self.bn[l - 1]) if (l and self.bn_on) else None,
                                         rs, seed, l, rate, B, K, self.widths[l],
-                                        ref(sort_job) if (l == 0 and sort_in_fwd) else None, ref(sw[l]), st),
+                                        ref(sort_job) if (l == 0 and sort_in_fwd) else None, ref(sw[l]),
+                                        z_fwd0[0] if l == 0 else None, z_fwd0[1] if l == 0 else 0, st),
                   "rsx_tower_fwd_layer")
-            if self.bn_on:
-                check(L.rsx_tower_reduce_partials(_ptr(self.fstat[l]), B, self.widths[l], st))  # no-op for B <= 512
         # head parameters: a variable name, or an explicit (tensor, grad_tensor) pair (e.g. a slice of out.W)
         pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
         gv = lambda x: None if x is None else (P[x].grad if isinstance(x, str) else x[1])
         wd, bd, wo, bo = head
         n_last = self.widths[-1]
-        check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(self.fstat[-1]), bnp(f"{pre}.gamma{nl - 1}"),
+        check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(fst[-1]), bnp(f"{pre}.gamma{nl - 1}"),
                                bnp(f"{pre}.beta{nl - 1}"), _ptr(mk[-1]), _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)),
                                _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
                                _ptr(pv(bo)), _ptr(labels), _ptr(self.prob), _ptr(self.dy[-1]),
-                               _ptr(self.bstat[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(o_gs0), _ptr(o_gs1),
+                               _ptr(bst[-1]), _ptr(self.dwd_part), _ptr(self.hpart), _ptr(o_gs0), _ptr(o_gs1),
                                rs, seed, nl - 1, rate, 1.0 / (B * replicas), int(relu0), int(relu2), B, n_last, ref(sw[nl]), st),
               "rsx_tower_head")
-        if self.bn_on:
-            check(L.rsx_tower_reduce_partials(_ptr(self.bstat[-1]), B, n_last, st))
         # (large batches: the layers' dW reductions are handed back as jobs and run as ONE launch after the last layer)
         jobs = (_lib.DwReduceJob * max(nl, 1))()
         defer = nl <= 4 and layer_done is None
@@ -905,21 +926,20 @@ class FusedTower:
             last = l == nl - 1
             check(L.rsx_tower_bwd_layer_defer(
                 _ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(self.a[l]), _ptr(self.dy[l]),
-                _ptr(self.bstat[l]), _ptr(self.bn[l]), bnp(f"{pre}.gamma{l}"),
+                _ptr(bst[l]), _ptr(self.bn[l]), bnp(f"{pre}.gamma{l}"),
                 _ptr(g(f"{pre}.W{l}")), _ptr(g(f"{pre}.b{l}")), bng(f"{pre}.gamma{l}"), bng(f"{pre}.beta{l}"),
                 _ptr(self.bn[l - 1]) if l else None, bnp(f"{pre}.gamma{l - 1}") if l else None,
                 bnp(f"{pre}.beta{l - 1}") if l else None, _ptr(mk[l - 1]) if l else None,
-                _ptr(self.dy[l - 1]) if l else _ptr(o_dX), _ptr(self.bstat[l - 1]) if l else None,
+                _ptr(self.dy[l - 1]) if l else _ptr(o_dX), _ptr(bst[l - 1]) if l else None,
                 _ptr(self.hpart) if last else None, _ptr(self.dwd_part) if last else None,
                 _ptr(gv(wd)) if last else None, _ptr(gv(bd)) if last else None,
                 _ptr(gv(wo)) if last else None, _ptr(gv(bo)) if last else None,
                 _ptr(gv(c0)) if last else None, _ptr(self.loss) if last else None,
                 rs, seed, l, rate, B, K, self.widths[l],
                 C.byref(sort_job) if (last and sort_job is not None and not sort_in_fwd) else None,
-                ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), C.byref(jobs[l]) if defer else None, st),
+                ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), C.byref(jobs[l]) if defer else None,
+                z_bwd0[0] if l == 0 else None, z_bwd0[1] if l == 0 else 0, st),
                 "rsx_tower_bwd_layer_defer")
-            if l and self.bn_on:
-                check(L.rsx_tower_reduce_partials(_ptr(self.bstat[l - 1]), B, self.widths[l - 1], st))
             if layer_done is not None:
                 layer_done(l)
         self.dw_jobs_pending = []
@@ -963,24 +983,31 @@ class FusedTower:
         if es is None:             # (first call per batch size: eager, before any capture of this signature)
             es = []
             for n in self.widths:
-                t = torch.zeros(self.fstat[0].shape[0], 2, n, dtype=torch.float64, device=X.device)
-                t[0, 1] = float(B)
+                if B > 512:         # the fixed-point rows (include/rsx.h): sum = 0, sum of squares = B = (hi * 2^32 + lo) * 2^-52
+                    t = torch.zeros(8, (n + 15) // 16 * 16, 4, dtype=torch.int64, device=X.device)
+                    t[0, :, 2] = B << 20
+                    t = t.view(torch.float64)
+                else:
+                    t = torch.zeros(self.fstat[0].shape[0], 2, n, dtype=torch.float64, device=X.device)
+                    t[0, 1] = float(B)
                 es.append(t)
             self._eval_stats[B] = es
         rs = _ptr(rng_step)
         for l in range(nl):
             K = self.k0 if l == 0 else self.widths[l - 1]
             check(L.rsx_tower_fwd_layer(_ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(P[f"{pre}.b{l}"]),
-                                        _ptr(self.a[l]), _ptr(self.fstat[l]), _ptr(es[l - 1]) if l else None,
+                                        _ptr(self.a[l]), _ptr((self.fstat_fix_eval if B > 512 else self.fstat)[l]),
+                                        _ptr(es[l - 1]) if l else None,
                                         bnp(f"{pre}.gamma{l - 1}") if l else None, bnp(f"{pre}.beta{l - 1}") if l else None,
                                         None, _ptr(self.bn[l - 1]) if (l and self.bn_on) else None, rs, 0, l, 0.0, B, K,
-                                        self.widths[l], None, None, st), "rsx_tower_fwd_layer")
+                                        self.widths[l], None, None, None, 0, st), "rsx_tower_fwd_layer")
         pv = lambda x: None if x is None else (P[x] if isinstance(x, str) else x[0])
         wd, bd, wo, bo = head
         lab = labels if labels is not None else self._zero_labels[:B]
         check(L.rsx_tower_head(_ptr(self.a[-1]), _ptr(es[-1]), bnp(f"{pre}.gamma{nl - 1}"), bnp(f"{pre}.beta{nl - 1}"), None,
                                _ptr(self.bn[-1]), _ptr(pv(wd)), _ptr(pv(bd)), _ptr(s0), _ptr(pv(c0)), _ptr(s1), _ptr(pv(wo)),
-                               _ptr(pv(bo)), _ptr(lab), _ptr(self.prob), _ptr(self.dy[-1]), _ptr(self.bstat[-1]),
+                               _ptr(pv(bo)), _ptr(lab), _ptr(self.prob), _ptr(self.dy[-1]),
+                               _ptr((self.bstat_fix_eval if B > 512 else self.bstat)[-1]),
                                _ptr(self.dwd_part), _ptr(self.hpart), _ptr(self.gs0), _ptr(self.gs1), rs, 0, nl - 1, 0.0,
                                1.0 / B, int(relu0), int(relu2), B, self.widths[-1], None, st), "rsx_tower_head")
         loss = None

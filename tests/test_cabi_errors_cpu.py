@@ -55,11 +55,11 @@ def test_cin_entry_points_reject_bad_arguments(L):
 def test_tower_batch_norm_free_mode_is_all_or_nothing(L):
     u32 = C.c_uint32
     # forward: previous layer present (fstat_prev) with gamma but no beta / bn_prev_out
-    assert L.rsx_tower_fwd_layer(P, P, P, P, P, P, P, None, None, None, P, u32(1), 1, 0.0, 8, 16, 16, None, None, None) == EINVAL
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, P, P, None, None, None, P, u32(1), 1, 0.0, 8, 16, 16, None, None, None, 0, None) == EINVAL
     # forward: gamma NULL but beta given
-    assert L.rsx_tower_fwd_layer(P, P, P, P, P, P, None, P, None, None, P, u32(1), 1, 0.0, 8, 16, 16, None, None, None) == EINVAL
-    assert L.rsx_tower_fwd_layer(P, P, P, P, P, None, None, None, None, None, P, u32(1), 0, 0.0, 8, 18, 16, None, None, None) == EUNSUPPORTED  # K % 4
-    assert L.rsx_tower_fwd_layer(P, P, P, P, P, None, None, None, None, None, P, u32(1), 0, 1.0, 8, 16, 16, None, None, None) == EINVAL       # rate
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, P, None, P, None, None, P, u32(1), 1, 0.0, 8, 16, 16, None, None, None, 0, None) == EINVAL
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, None, None, None, None, None, P, u32(1), 0, 0.0, 8, 18, 16, None, None, None, 0, None) == EUNSUPPORTED  # K % 4
+    assert L.rsx_tower_fwd_layer(P, P, P, P, P, None, None, None, None, None, P, u32(1), 0, 1.0, 8, 16, 16, None, None, None, 0, None) == EINVAL       # rate
     # head: gamma NULL with beta non-NULL
     args = [P, P, None, P, None, P, P, P] + [None] * 5 + [P, P, P, P, P, P, None, None, P]
     assert L.rsx_tower_head(*args, u32(1), 0, 0.0, 1.0, 0, 0, 8, 16, None, None) == EINVAL

@@ -380,7 +380,7 @@ def test_dcn_train_parity_criteo():
 
 
 def test_large_batch_tower_and_dcn_parity_bs1024():
-    """B > 512 takes the pre-reduced statistics path (rsx_tower_reduce_partials); B >= 1024 the split-batch dW tiles
+    """B > 512 takes the fixed-point statistics rows (include/rsx.h RSX_TOWER_FIXED_STATS_MIN_B); B >= 1024 the split-batch dW tiles
     (+ tower_reduce_dw_k) and 4 row tiles per d(input) workgroup: DeepFM and DCN at batch
     1024 / 1100 (ragged last tiles) on a small layout vs the oracle."""
     for kind, B in (("deepfm", 1024), ("dcn", 1100)):

@@ -34,7 +34,7 @@ def _two_launches(a, ids_t, W, b, B, N):
     out = torch.zeros(B, N, device="cuda")
     fstat = torch.zeros((B + 15) // 16, 2, N, dtype=torch.float64, device="cuda")
     _lib.check(_lib.lib().rsx_tower_fwd_layer(_ptr(E), _ptr(W), _ptr(b), _ptr(out), _ptr(fstat), None, None, None, None, None,
-                                              None, 0, 0, 0.0, B, a.F * a.D, N, None, None, _stream()), "rsx_tower_fwd_layer")
+                                              None, 0, 0, 0.0, B, a.F * a.D, N, None, None, None, 0, _stream()), "rsx_tower_fwd_layer")
     return E, S, y1, y2, out, fstat
 
 
@@ -47,7 +47,7 @@ def _one_launch(a, ids_t, W, b, B, N, sort_job=None, with_s=True):
     _lib.check(_lib.lib().rsx_gather_tower_fwd0(_ptr(a.tables), _ptr(a.w1) if with_s else None, _ptr(a.row_off), _ptr(ids_t),
                                                 _ptr(E), _ptr(S), _ptr(y1), _ptr(y2), a.w1_mask, a.F, a.D, _ptr(W), _ptr(b),
                                                 _ptr(out), _ptr(fstat), B, N, None if sort_job is None else C.byref(sort_job),
-                                                None, _stream()), "rsx_gather_tower_fwd0")
+                                                None, None, 0, _stream()), "rsx_gather_tower_fwd0")
     return E, S, y1, y2, out, fstat
 
 
@@ -105,7 +105,7 @@ def test_fused_gather_envelope():
     assert L.rsx_gather_tower_fwd0_supported(256, 39, 32) == 0
     d = torch.zeros(64, device="cuda")
     rc = L.rsx_gather_tower_fwd0(d.data_ptr(), None, d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None, None, 0, 2, 32,
-                                 d.data_ptr(), d.data_ptr(), d.data_ptr(), None, 4, 4, None, None, None)
+                                 d.data_ptr(), d.data_ptr(), d.data_ptr(), None, 4, 4, None, None, None, 0, None)
     assert rc == -3      # RSX_EUNSUPPORTED (include/rsx.h)
 
 
