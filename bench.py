@@ -66,6 +66,7 @@ def parse():
     p.add_argument("--no_overlap", action="store_true", help="profiling aid: plain path (stand-alone sort, segment-sum, ONE full "
                    "optimizer sweep) instead of sweep slices riding in the tower launches -- shows every kernel's own duration")
     p.add_argument("--no_configs", action="store_true", help="skip the `configs` list (the other BASELINE configs)")
+    p.add_argument("--no_e2e", action="store_true", help="skip the end-to-end entry of `configs` (deepfm.py from TFRecord shards)")
     p.add_argument("--config_steps", type=int, default=320, help="timed steps per entry of the `configs` list (x 3 repeats)")
     p.add_argument("--steps_per_graph", type=int, default=16, help="training steps captured per HIP graph (1: per-step "
                    "graph fed by one D2D copy of the batch)")
@@ -141,7 +142,7 @@ DOMINANT = {"deepfm": "segsum_adam_k (scatter + touched-row Adam; latency-bound)
             "xdeepfm": "cin_bwd_dw_k / cin_bwd_dx2_k (fp32 MFMA)", "xdeepfm_bf16": "cin_bwd_dw_bf16_k (bf16 MFMA)",
             "xdeepfm_x3": "cin_split_dw_k<3> / cin_split_dx8_k<3,4> (bf16 MFMA, 3 planes per operand)",
             "xdeepfm_x4": "cin_split_dw_k<3> (3 bf16 planes) / cin_split_dx8_k<4,4> (2 fp16 planes per operand)",
-            "din": "din_attn_bwd_k (fp32 MFMA attention MLP backward)"}
+            "din": "din_attn_bwd_k (fp32 MFMA attention MLP backward; the forward runs on the bf16 MFMA with split operands)"}
 
 
 def per_example_bytes(model):
@@ -209,10 +210,15 @@ def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
         # 16-bit MFMAs issued per algorithmic k-step (x4: 3 in the forward and the data gradients, 6 in the weight gradients)
         terms = {"x1": 1, "x2": 3, "x3": 6, "x4": 4}.get(cin_bf16, 1)
         peak = 2.5e15 if cin_bf16 else 157.3e12
+        # ISSUED: the 16-bit MFMA flops the kernels execute (terms plane products per algorithmic product) against the dense bf16
+        # peak; USEFUL: the algorithmic (fp32-equivalent) flops of SURVEY 8(d) against the same peak -- both, side by side
         out["cin_mfma_step_frac"] = round(terms * flops / (ms_per_step * 1e-3) / peak, 4)
+        out["cin_mfma_step_frac_useful"] = round(flops / (ms_per_step * 1e-3) / peak, 4)
+        out["cin_mfma_step_frac_is"] = "issued MFMA flops / step time / peak" if terms > 1 else "algorithmic flops / step time / peak"
         out["cin_flops_per_step"] = flops
         if terms > 1:
             out["cin_mfma_flops_issued_per_step"] = terms * flops
+            out["cin_useful_vs_fp32_mfma_peak"] = round(flops / (ms_per_step * 1e-3) / 157.3e12, 4)
         out["mfma_peak"] = "2.5 PF dense bf16" if cin_bf16 else "157.3 TF fp32"
     return out
 
@@ -373,6 +379,66 @@ def other_configs(a, rank, dev):
     return out
 
 
+def e2e_config(a, dev, resident_ms):
+    """SURVEY 8(f-1) in front of the driver: deepfm.py bs 256 END TO END -- TFRecord shards on disk (written to
+    a temp dir before the clock starts) -> the C++ reader (framing, CRC-32C, Example parse, FarmHash / bucketize, batching) ->
+    Estimator.train (optimizer windows, one H2D copy per batch, HIP graphs): host parse and PCIe are INSIDE the timed region.
+    A `configs` entry, never `value`."""
+    import tempfile
+    from recsys_amd import deepfm, synthetic
+    from recsys_amd import input_pipeline as ip
+    from recsys_amd.estimator import Estimator, RunConfig
+    from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
+    bs, n = 256, 262144
+    lin, emb = build_feature_columns(16, "indicator_all")
+    layout = CriteoLayout.from_columns(emb)
+    with tempfile.TemporaryDirectory() as d:
+        rng = np.random.default_rng(0)
+        files = []
+        for k in range(4):
+            label, cont, cat = synthetic.criteo_raw_batch(rng, n // 4)
+            pth = os.path.join(d, "part-r-%05d" % k)
+            ip.write_criteo_shard(pth, label, cont, cat)
+            files.append(pth)
+        params = {"linear_feature_columns": lin, "embedding_feature_columns": emb, "embedding_size": 16, "learning_rate": 1e-3,
+                  "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": bs}
+        est = Estimator(deepfm.model_fn, None, params, RunConfig(device=str(dev), seed=1, log_step_count_steps=10 ** 9, adam_mode=a.adam_mode))
+        threads = min(32, os.cpu_count() or 1)
+        fn = lambda: ip.criteo_input_fn(files, bs, num_epochs=-1, need_shuffle=True, layout=layout, num_parallel=threads)
+        est.train(fn, steps=304)                        # variables, warm-up, graph captures
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()                        # the pipeline's own start-up (reader threads, the 1 000-batch shuffle buffer)
+        it = iter(fn())
+        next(it)
+        t_start = time.perf_counter() - t0
+        it.close()
+        steps = 12 * ((n // bs) // 8 * 8)               # (~0.8 s per repeat: the 23 ms of pipeline start-up per train() call amortised)
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            est.train(fn, steps=steps)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        dt = sorted(dts)[1]
+        t0 = time.perf_counter()                        # the input pipeline alone: what the host side can deliver
+        it = iter(fn())
+        for _ in range(steps):
+            next(it)
+        dt_in = time.perf_counter() - t0
+        it.close()
+    ms = dt / steps * 1e3
+    return {"workload": "deepfm.py Criteo-39 d=16 DNN 100-100 bs=256 END TO END from TFRecord shards (Estimator.train: host parse + "
+                        "hash + H2D inside the timed region), adam_mode=%s" % a.adam_mode,
+            "dtype": "f32", "data": "synthetic TFRecord shards (%d records, 4 files, written before the clock starts)" % n,
+            "ms_per_step": round(ms, 5), "examples_per_sec": round(bs * steps / dt, 1), "steps": steps,
+            "timed_repeats_ms_per_step": [round(x / steps * 1e3, 5) for x in dts],
+            "ms_per_step_without_pipeline_startup": round((dt - t_start) / steps * 1e3, 5),
+            "pipeline_startup_ms": round(t_start * 1e3, 1),
+            "input_pipeline_alone_examples_per_sec": round(bs * steps / dt_in, 1), "reader_threads": threads,
+            "host_cores": os.cpu_count(), "resident_batch_ms_per_step": round(resident_ms, 5),
+            "ratio_to_resident_batches": round(resident_ms / ms, 4)}
+
+
 def dp_exchange_info(store, B):
     """What one rank contributes to the step's collectives (data parallel / emulated), bytes per step: the gradient collective
     [dense | the rank's block of the sparse exchange] + the ids-phase collective (the packed unique-row lists of the unique-list
@@ -442,9 +508,14 @@ def dominant_kernel_fraction(key):
             f = line[72:].split()        # (scripts/rocpd_summary.py: the name in 72 columns, then calls / avg / min / max ...)
             if len(f) >= 4 and f[0].isdigit():
                 avg_us = float(f[1])
-                return {"kernel": kern, "what": what, "work_per_launch": work, "unit": unit, "avg_us": avg_us,
-                        "source": os.path.basename(files[-1]), "peak": peak,
-                        "frac": round(work / (avg_us * 1e-6) / peak, 4)}
+                out = {"kernel": kern, "what": what, "work_per_launch": work, "unit": unit, "avg_us": avg_us,
+                       "source": os.path.basename(files[-1]), "peak": peak,
+                       "frac": round(work / (avg_us * 1e-6) / peak, 4)}
+                if "issued" in unit:     # six plane products per algorithmic product: the USEFUL fraction beside the issued one
+                    out["frac_is"] = "ISSUED 16-bit MFMA flops / launch time / dense bf16 peak"
+                    out["frac_useful"] = round(work / 6 / (avg_us * 1e-6) / peak, 4)
+                    out["useful_vs_fp32_mfma_peak"] = round(work / 6 / (avg_us * 1e-6) / 157.3e12, 4)
+                return out
     return None
 
 
@@ -689,6 +760,11 @@ def main():
     if N == 1 and emu is None and not a.no_configs and a.model == "deepfm" and not a.host_input and a.adam_mode == "tf1_dense":
         del t, est, store
         out["configs"] = other_configs(a, rank, dev)
+        if not a.no_e2e:
+            try:
+                out["configs"].append(e2e_config(a, dev, out["ms_per_step"]))
+            except Exception as e:                               # (must not take the headline line with it)
+                out["configs"].append({"workload": "deepfm.py end to end from TFRecord shards", "error": repr(e)[:300]})
     if N == 1 and not a.no_cpu_baseline and a.model == "deepfm":
         out["cpu_baseline"] = cpu_baseline(host, layout, a.cpu_seconds)
     print(json.dumps(out), flush=True)
