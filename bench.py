@@ -59,7 +59,7 @@ def parse():
                         "(dcn: bs 4096, 3 cross layers; xdeepfm: CIN 128,128; din: bs 1024, hist 100, K 32)")
     p.add_argument("--cin_bf16", action="store_true", help="xdeepfm: CIN contraction on the bf16 MFMA path (fp32 accumulate); the "
                    "line then reports dtype 'bf16 CIN operands, f32 accumulate, f32 elsewhere'")
-    p.add_argument("--cin_split", type=int, default=None, choices=[0, 1, 2, 3, 4],
+    p.add_argument("--cin_split", type=int, default=None, choices=[0, 3, 4],
                    help="xdeepfm: CIN contraction on the 16-bit MFMA with split operands (csrc/cin_split.hip); 3 = three bf16 planes, every "
                         "product exact to 2^-23; 4 = two scaled fp16 planes forward / data gradients (half the MFMAs) -- both held to "
                         "the fp32 path's 1e-5 parity tests; 0 = the fp32 MFMA kernels; unset = xdeepfm.py's default (4)")
@@ -189,13 +189,11 @@ def cin_ran(est, asked):
 
 
 CIN_DTYPE = {False: "f32", True: "bf16 CIN operands / f32 accumulate, f32 elsewhere",
-             "x1": "bf16 CIN operands (1 plane) / f32 accumulate, f32 elsewhere",
-             "x2": "f32; CIN products as 2 bf16 planes per operand on the bf16 MFMA (3 MFMAs per k-step, 2^-16-grade), f32 accumulate",
              "x3": "f32; CIN products as 3 bf16 planes per operand on the bf16 MFMA (6 MFMAs per k-step, exact to 2^-23: fp32-grade), f32 accumulate",
              "x4": "f32; CIN forward / data-gradient products as 2 scaled fp16 planes per operand on the fp16 MFMA (3 MFMAs per k-step, "
                    "2^-22-grade: held to the fp32 path's tolerances), weight gradients as 3 bf16 planes, f32 accumulate"}
-CIN_TAG = {False: "", True: " --cin_bf16", "x1": " --cin_split 1", "x2": " --cin_split 2", "x3": " --cin_split 3", "x4": " --cin_split 4"}
-CIN_KEY = {False: "", True: "_bf16", "x1": "_x1", "x2": "_x2", "x3": "_x3", "x4": "_x4"}
+CIN_TAG = {False: "", True: " --cin_bf16", "x3": " --cin_split 3", "x4": " --cin_split 4"}
+CIN_KEY = {False: "", True: "_bf16", "x3": "_x3", "x4": "_x4"}
 
 
 def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
@@ -208,7 +206,7 @@ def step_fractions(est, model, B, ms_per_step, wk, cin_bf16=False):
     if model == "xdeepfm":
         flops = 3 * 2 * B * 16 * (39 * 39 * 128 + 39 * 128 * 128)          # fwd x 3 with backward
         # 16-bit MFMAs issued per algorithmic k-step (x4: 3 in the forward and the data gradients, 6 in the weight gradients)
-        terms = {"x1": 1, "x2": 3, "x3": 6, "x4": 4}.get(cin_bf16, 1)
+        terms = {"x3": 6, "x4": 4}.get(cin_bf16, 1)
         peak = 2.5e15 if cin_bf16 else 157.3e12
         # ISSUED: the 16-bit MFMA flops the kernels execute (terms plane products per algorithmic product) against the dense bf16
         # peak; USEFUL: the algorithmic (fp32-equivalent) flops of SURVEY 8(d) against the same peak -- both, side by side
@@ -602,7 +600,8 @@ def main():
     torch.cuda.set_device(dev)
     emu = None
     if a.emulate_world > 1 and dp is None:
-        emu = dist.EmulatedDataParallel(a.emulate_world)
+        from tests.dp_harness import EmulatedDataParallel          # (profiling harness, not product)
+        emu = EmulatedDataParallel(a.emulate_world)
 
     dp_captured = dist.dp_capture(dp or emu)
     t = time_config(a, a.model, a.batch_size, cin_mode(a.cin_bf16, a.cin_split), dp, emu, rank, dev, a.steps, a.warmup, a.repeats)

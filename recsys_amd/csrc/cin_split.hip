@@ -1224,11 +1224,7 @@ int opt_in_lds(K kernel, size_t lds) {
   return RSX_OK;
 }
 
-// examples per workgroup: 4 (two independent 256-thread workgroups per CU); RSX_CIN_SPLIT_E=8 for A/B runs
-int cs_examples() {
-  static const int e = getenv("RSX_CIN_SPLIT_E") ? atoi(getenv("RSX_CIN_SPLIT_E")) : 4;
-  return e == 8 ? 8 : 4;
-}
+// examples per workgroup of the first form: 4 (two independent 256-thread workgroups per CU; 8 measured slower, round 5)
 
 template <int NS, int KS, int E>
 int launch_fwd(const CsFwdArgs& a, hipStream_t stream) {
@@ -1254,11 +1250,10 @@ int launch_fwd_ns(const CsFwdArgs& a, hipStream_t stream) {
 // form (8 examples per 512-thread workgroup).  Measured inside xdeepfm.py's step (profiles/r05_y_*): for the bf16 modes 1..3 the
 // first form is the faster one (0.2550 against 0.2638 ms per step at ns = 3: two independent workgroups per CU cover each
 // other's barriers and prologues), mode 4 exists in the deep-ring form only.  RSX_CIN_SPLIT_V=1|2 forces one (A/B runs).
-int cs_version(int ns) {
-  static const int v = getenv("RSX_CIN_SPLIT_V") ? atoi(getenv("RSX_CIN_SPLIT_V")) : 0;
-  if (ns == CS_H2) return 2;
-  return v == 2 ? 2 : 1;
-}
+// Round 6 (pruned): the losing forms are no longer instantiated -- ns = 3 runs the first form with 4 examples per workgroup, mode
+// 4 the deep-ring form; ns = 1 / 2 (A/B arithmetic of round 5: plain bf16 / 2^-16-grade) are gone (RSX_EUNSUPPORTED; the plain
+// bf16-operand path is csrc/cin_bf16.hip).
+int cs_version(int ns) { return ns == CS_H2 ? 2 : 1; }
 template <int MODE, int KS>
 int launch_fwd8(const CsFwdArgs& a, hipStream_t stream) {
   using M = SplitMode<MODE>;
@@ -1352,6 +1347,7 @@ extern "C" int rsx_cin_split_prep_gather(const float* const* W_h, void* const* w
 static int cs_launch_prep(const float* const* W_h, void* const* w16_h, const int32_t* H_h, const int32_t* N_h, int L, int F, int ns,
                           const rsx_gather_two_job* g, rsx_stream_t stream) {
   if (!W_h || !w16_h || !H_h || !N_h || L <= 0 || F <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
+  if (ns < 3) return RSX_EUNSUPPORTED;       // (round 6: only ns = 3 and mode 4 are built)
   if (L > CS_MAXJ || (ns == CS_H2 && F > CS_FP)) return RSX_EUNSUPPORTED;
   const int np = cs_planes(ns);
   CsPrepArgs a{};
@@ -1381,11 +1377,7 @@ static int cs_launch_prep(const float* const* W_h, void* const* w16_h, const int
     return RSX_OK;
   }
   const unsigned blocks = (unsigned)a.n_gather + (unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
-  switch (ns) {
-    case 1: RSX_LAUNCH(cin_split_prep_k<1>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
-    case 2: RSX_LAUNCH(cin_split_prep_k<2>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
-    default: RSX_LAUNCH(cin_split_prep_k<3>, dim3(blocks), dim3(256), 0, rsx_s(stream), a); break;
-  }
+  RSX_LAUNCH(cin_split_prep_k<3>, dim3(blocks), dim3(256), 0, rsx_s(stream), a);
   RSX_CHECK_LAUNCH();
   return RSX_OK;
 }
@@ -1393,6 +1385,7 @@ static int cs_launch_prep(const float* const* W_h, void* const* w16_h, const int
 extern "C" int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w16, const float* c, float* out, int B, int F,
                                  int H, int N, int D, int ns, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
+  if (ns < 3) return RSX_EUNSUPPORTED;       // (round 6: only ns = 3 and mode 4 are built)
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !w16 || !c || !out) return RSX_EINVAL;
   if (D != CS_D || H > 128 || N > 128 || F > CS_FP) return RSX_EUNSUPPORTED;
@@ -1401,26 +1394,8 @@ extern "C" int rsx_cin_split_fwd(const float* X0, const float* Xk, const void* w
   const bf16_t* wt = static_cast<const bf16_t*>(w16) + (size_t)np * F * H16 * Np;
   const float* winv = reinterpret_cast<const float*>(static_cast<const bf16_t*>(w16) + (size_t)np * image_elems(F, H, N));
   const CsFwdArgs a{X0, Xk, wt, c, out, B, F, H, N, N16, Hp, winv};
-  if (cs_version(ns) == 2) {
-    switch (ns) {
-      case 1: return launch_fwd8_ns<1>(a, rsx_s(stream));
-      case 2: return launch_fwd8_ns<2>(a, rsx_s(stream));
-      case 3: return launch_fwd8_ns<3>(a, rsx_s(stream));
-      default: return launch_fwd8_ns<CS_H2>(a, rsx_s(stream));
-    }
-  }
-  if (cs_examples() == 8) {
-    switch (ns) {
-      case 1: return launch_fwd_ns<1, 8>(a, rsx_s(stream));
-      case 2: return launch_fwd_ns<2, 8>(a, rsx_s(stream));
-      default: return launch_fwd_ns<3, 8>(a, rsx_s(stream));
-    }
-  }
-  switch (ns) {
-    case 1: return launch_fwd_ns<1, 4>(a, rsx_s(stream));
-    case 2: return launch_fwd_ns<2, 4>(a, rsx_s(stream));
-    default: return launch_fwd_ns<3, 4>(a, rsx_s(stream));
-  }
+  if (ns == CS_H2) return launch_fwd8_ns<CS_H2>(a, rsx_s(stream));
+  return launch_fwd_ns<3, 4>(a, rsx_s(stream));
 }
 
 // ws: [ns planes of dpre fragments | B x N16 bias-gradient partials]
@@ -1433,6 +1408,7 @@ extern "C" int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void
                                     const float* gs, const float* wout, float* dXk, int acc_dxk, float* dx0_parts, void* ws,
                                     int B, int F, int H, int N, int D, int ns, rsx_stream_t stream) {
   if (B < 0 || F <= 0 || H <= 0 || N <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
+  if (ns < 3) return RSX_EUNSUPPORTED;       // (round 6: only ns = 3 and mode 4 are built)
   if (B == 0) return RSX_OK;
   if (!X0 || !Xk || !w16 || !out || !dXk || !dx0_parts || !ws) return RSX_EINVAL;
   if ((!dout && !gs) || (gs && !wout)) return RSX_EINVAL;
@@ -1446,26 +1422,8 @@ extern "C" int rsx_cin_split_bwd_dx(const float* X0, const float* Xk, const void
   const float* winv = reinterpret_cast<const float*>(static_cast<const bf16_t*>(w16) + (size_t)cs_planes(ns) * image_elems(F, H, N));
   const CsDxArgs a{X0, Xk, static_cast<const bf16_t*>(w16), out, dout, gs, wout, dXk, dx0_parts, static_cast<bf16_t*>(ws),
                    dc_part, acc_dxk, B, F, H, N, H16, N16, Np, winv, dwp};
-  if (cs_version(ns) == 2) {
-    switch (ns) {
-      case 1: return launch_dx8_ns<1>(a, rsx_s(stream));
-      case 2: return launch_dx8_ns<2>(a, rsx_s(stream));
-      case 3: return launch_dx8_ns<3>(a, rsx_s(stream));
-      default: return launch_dx8_ns<CS_H2>(a, rsx_s(stream));
-    }
-  }
-  if (cs_examples() == 8) {
-    switch (ns) {
-      case 1: return launch_dx_ns<1, 8>(a, rsx_s(stream));
-      case 2: return launch_dx_ns<2, 8>(a, rsx_s(stream));
-      default: return launch_dx_ns<3, 8>(a, rsx_s(stream));
-    }
-  }
-  switch (ns) {
-    case 1: return launch_dx_ns<1, 4>(a, rsx_s(stream));
-    case 2: return launch_dx_ns<2, 4>(a, rsx_s(stream));
-    default: return launch_dx_ns<3, 4>(a, rsx_s(stream));
-  }
+  if (ns == CS_H2) return launch_dx8_ns<CS_H2>(a, rsx_s(stream));
+  return launch_dx_ns<3, 4>(a, rsx_s(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dW, dc
@@ -1726,6 +1684,7 @@ static int cs_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs
                         const float* const* parts_h, const int32_t* tiles_h, int nparts, float* dX0, int acc_dx0,
                         rsx_stream_t stream) {
   if (!X0 || !jobs_h || njobs <= 0 || B < 0 || F <= 0 || ns < 1 || ns > CS_H2) return RSX_EINVAL;
+  if (ns < 3) return RSX_EUNSUPPORTED;       // (round 6: only ns = 3 and mode 4 are built)
   if (njobs > CS_MAXJ || D != CS_D || F > CS_FP) return RSX_EUNSUPPORTED;
   if (B == 0) return RSX_OK;
   ns = cs_dw_planes(ns);                            // (mode 4: the data-gradient launch left three bf16 planes of dpre)
@@ -1791,11 +1750,7 @@ static int cs_launch_dw(const float* X0, const rsx_cin_dw_job* jobs_h, int njobs
     if (rc != RSX_OK) return rc;                                             \
     RSX_LAUNCH(cin_split_dw_k<NS_>, dim3(grid), dim3(512), lds, rsx_s(stream), w); \
   }
-  switch (ns) {
-    case 1: RSX_CS_DW(1); break;
-    case 2: RSX_CS_DW(2); break;
-    default: RSX_CS_DW(3); break;
-  }
+  RSX_CS_DW(3);
 #undef RSX_CS_DW
   RSX_CHECK_LAUNCH();
   return RSX_OK;

@@ -1360,13 +1360,13 @@ class CinNet:
     def __init__(self, F, D, sizes, capacity, device="cuda", bf16=False, split=0):
         dev = _require_cuda(device)
         self.F, self.D, self.sizes, self.L = F, D, [int(n) for n in sizes], len(sizes)
-        # split = ns in 1..3: the contraction on the bf16 matrix cores with every operand kept as ns bf16 planes
-        # (csrc/cin_split.hip; ns = 3: every product exact to 2^-23 -- fp32-grade, the parity path on those cores);
+        # split = 3: the contraction on the bf16 matrix cores with every operand kept as three bf16 planes
+        # (csrc/cin_split.hip: every product exact to 2^-23 -- fp32-grade, the parity path on those cores);
         # split = 4: forward / data gradients with TWO scaled fp16 planes per operand (three MFMAs per k-step instead of six,
         # products to 2^-22), weight gradients on three bf16 planes
         self.split = int(split or 0)
-        if self.split and not (1 <= self.split <= 4 and F <= 40 and D == 16 and max(sizes) <= 128 and self.L <= 4):
-            raise _lib.RsxError("CinNet: split operands need 1 <= ns <= 4, F <= 40, D = 16, layers <= 128 wide, <= 4 layers")
+        if self.split and not (3 <= self.split <= 4 and F <= 40 and D == 16 and max(sizes) <= 128 and self.L <= 4):
+            raise _lib.RsxError("CinNet: split operands need split in (3, 4), F <= 40, D = 16, layers <= 128 wide, <= 4 layers")
         if self.split:
             bf16 = False
             hs16 = [F] + self.sizes[:-1]

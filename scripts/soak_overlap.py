@@ -32,7 +32,7 @@ for overlap, graph in ((True, True), (False, False)):
               "dropout": 0.5, "deep_layers": "100,100", "max_batch_size": B, "overlap_adam": overlap, "cross_layers": 3}
     est = Estimator(mfn, None, params, RunConfig(use_hip_graph=graph, adam_mode="tf1_dense", device="cuda", seed=77))
     if EMU:
-        from recsys_amd.dist import EmulatedDataParallel
+        from tests.dp_harness import EmulatedDataParallel
         est.store.dp = est.dist = EmulatedDataParallel(EMU)
     feats = [PackedBatch({"ids": i}, y, device="cuda") for i, y, _ in host]
     with torch.no_grad():

@@ -319,7 +319,8 @@ def test_unique_exchange_plumbing_world2_and_the_loopback_harness_agree(tmp_path
     class _Store:
         opt, embeddings, din = _Opt(), {}, None
 
-    lb = rdist.LoopbackDataParallel(world)
+    from tests.dp_harness import LoopbackDataParallel
+    lb = LoopbackDataParallel(world)
     dense = _FakeDenseArena(n)
     lb.make_send_block(dense, capT, [D, 1])
     store = _Store()

@@ -322,7 +322,7 @@ def test_windowed_step_of_every_model_is_bit_identical_to_its_single_steps(kind,
     GPU (world 1) and as the data-parallel step of an emulated world (ids all-gather -- ONE for the window's 8 local batches --,
     send block, replica-sum Adam): every variable bit-identical."""
     from recsys_amd import synthetic
-    from recsys_amd.dist import EmulatedDataParallel
+    from tests.dp_harness import EmulatedDataParallel
     from recsys_amd.estimator import PackedBatch
     from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
     B = 128

@@ -42,10 +42,10 @@ SHAPES = [
     (250, 40, 128, 128, False),
     (19, 38, 72, 96, False),
 ]
-TOL = {4: 2e-6, 3: 2e-6, 2: 3e-5, 1: 2e-5}
+TOL = {4: 2e-6, 3: 2e-6}
 
 
-@pytest.mark.parametrize("ns", [4, 3, 2, 1])
+@pytest.mark.parametrize("ns", [4, 3])
 @pytest.mark.parametrize("B,F,H,N,first", SHAPES)
 def test_cin_split_forward(B, F, H, N, first, ns):
     from recsys_amd.ops import _ptr, _stream, check, lib
@@ -82,10 +82,10 @@ BWD_SHAPES = [
     (19, 38, 72, 96, False, False, True),
     (700, 39, 32, 16, False, True, False),       # a batch whose X0 slab does not fit the weight-gradient launch's LDS
 ]
-BTOL = {4: 3e-6, 3: 3e-6, 2: 5e-5, 1: 2e-5}
+BTOL = {4: 3e-6, 3: 3e-6}
 
 
-@pytest.mark.parametrize("ns", [4, 3, 2, 1])
+@pytest.mark.parametrize("ns", [4, 3])
 @pytest.mark.parametrize("B,F,H,N,first,gs,acc", BWD_SHAPES)
 def test_cin_split_backward(B, F, H, N, first, gs, acc, ns):
     """dXk, dX0 (tile partials + the reduce launch), dW, dc.  ns = 3 / 2: against the plain fp64 gradients of the oracle's

@@ -154,7 +154,7 @@ def test_blocked_scatter_of_replicated_batch_equals_single_batch(kind, B, world,
     import torch
     from oracle import init
     from recsys_amd import dcn, deepfm, fm
-    from recsys_amd.dist import EmulatedDataParallel
+    from tests.dp_harness import EmulatedDataParallel
     from recsys_amd.estimator import PackedBatch
     from tests.parity_util import load_oracle_weights, make_estimator, small_columns, synth_ids
     rows, D, layers = (3, 7, 40, 11, 600), 16, (32, 16)
@@ -204,7 +204,7 @@ def test_xdeepfm_blocked_data_parallel_equals_single_batch():
     import numpy as np
     import torch
     from recsys_amd import xdeepfm
-    from recsys_amd.dist import EmulatedDataParallel
+    from tests.dp_harness import EmulatedDataParallel
     from recsys_amd.feature_columns import CriteoLayout, build_feature_columns
     from tests.parity_util import make_estimator, synth_ids
     B, world = 40, 2
@@ -247,7 +247,7 @@ def test_din_fused_step_data_parallel_equals_single_batch(B, Pn, world, use_grap
     import torch
     from oracle import init
     from recsys_amd import din, synthetic
-    from recsys_amd.dist import EmulatedDataParallel
+    from tests.dp_harness import EmulatedDataParallel
     from tests.parity_util import make_estimator
     K, n_item, n_cate = 16, 300, 20
     rng = np.random.default_rng(5)

@@ -16,7 +16,7 @@ def _build(kind, world, B, layers, D, dropout, exchange, monkeypatch, rows=ROWS,
     import torch
     from oracle import init
     from recsys_amd import dcn, deepfm, fm
-    from recsys_amd.dist import LoopbackDataParallel
+    from tests.dp_harness import LoopbackDataParallel
     from tests.parity_util import load_oracle_weights, make_estimator, small_columns
     monkeypatch.setenv("RSX_DP_EXCHANGE", exchange)
     row_off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
@@ -61,7 +61,7 @@ def _param_err(est, P64):
 def test_loopback_dp_with_distinct_batches_matches_the_oracle(kind, world, B, dropout, exchange, monkeypatch):
     import torch
     from oracle import models, nn
-    from recsys_amd.dist import loopback_train_step
+    from tests.dp_harness import loopback_train_step
     from tests.parity_util import synth_ids
     layers, D = ((32, 16), 16) if kind != "fm" else ((), 16)
     est, P, row_off = _build(kind, world, B, layers, D, dropout, exchange, monkeypatch)
@@ -106,7 +106,7 @@ def test_loopback_dp_inside_optimizer_windows_matches_the_oracle(kind, world, B,
         exchange = "unique"
     import torch
     from oracle import models, nn
-    from recsys_amd.dist import loopback_train_step
+    from tests.dp_harness import loopback_train_step
     from tests.parity_util import synth_ids
     layers, D = ((32, 16), 16) if kind != "fm" else ((), 16)
     est, P, row_off = _build(kind, world, B, layers, D, 0.0, exchange, monkeypatch)
@@ -135,7 +135,7 @@ def test_loopback_dp_of_a_batchnorm_free_model_equals_the_single_process_run_on_
     exchange adds per-rank partial sums (another association): 2e-6."""
     import torch
     from recsys_amd import fm
-    from recsys_amd.dist import loopback_train_step
+    from tests.dp_harness import loopback_train_step
     from tests.parity_util import load_oracle_weights, make_estimator, small_columns, synth_ids
     world, B, D = 3, 64, 16
     res = {}
@@ -168,7 +168,7 @@ def test_the_loopback_comparison_fails_when_two_rank_blocks_are_swapped(monkeypa
     oracle must fail by orders of magnitude more than the tolerance."""
     import torch
     from oracle import models, nn
-    from recsys_amd.dist import LoopbackDataParallel, loopback_train_step
+    from tests.dp_harness import LoopbackDataParallel, loopback_train_step
     from tests.parity_util import synth_ids
     world, B, layers, D = 3, 40, (32, 16), 16
     est, P, row_off = _build("deepfm", world, B, layers, D, 0.0, "examples", monkeypatch)
@@ -200,7 +200,7 @@ def test_loopback_dp_xdeepfm_matches_the_oracle(world, B, cin, window, exchange,
     import torch
     from oracle import criteo, init, models, nn
     from recsys_amd import xdeepfm
-    from recsys_amd.dist import LoopbackDataParallel, loopback_train_step
+    from tests.dp_harness import LoopbackDataParallel, loopback_train_step
     from recsys_amd.feature_columns import build_feature_columns
     from tests.parity_util import make_estimator, synth_ids
     monkeypatch.setenv("RSX_DP_EXCHANGE", exchange)
@@ -272,7 +272,7 @@ def test_loopback_dp_din_matches_the_oracle(world, B, Pn, exchange, monkeypatch)
     import torch
     from oracle import init, models, nn
     from recsys_amd import din, synthetic
-    from recsys_amd.dist import LoopbackDataParallel, loopback_train_step
+    from tests.dp_harness import LoopbackDataParallel, loopback_train_step
     from tests.parity_util import make_estimator
     if exchange.startswith("unique-parts"):
         monkeypatch.setenv("RSX_UX_PARTS", exchange[len("unique-parts"):])

@@ -65,8 +65,6 @@ ROUNDING = [
     # round 5: the CIN modes against the default (mode 4: two scaled fp16 planes forward / data gradients)
     ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "0"}),         # the fp32 MFMA kernels of csrc/cin.hip
     ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "3"}),         # three bf16 planes per operand, first-form kernels
-    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "3", "RSX_CIN_SPLIT_V": "2"}),   # .. in the deep-ring kernels
-    ("xdeepfm", 128, {"RSX_CIN_SPLIT_DEFAULT": "3", "RSX_CIN_SPLIT_E": "8"}),   # .. first form, 8 examples per workgroup
     ("xdeepfm", 128, {"RSX_CIN_DX_FSPLIT": "0"}),             # the first CIN layer's data gradients: one workgroup per tile over all fields
     # round 4
     ("din", 64, {"RSX_MLP_FUSE": "0"}),                       # din.py's 'mlp_layer' as 8 launches instead of the one-launch form
