@@ -16,6 +16,55 @@ class RsxError(RuntimeError):
     pass
 
 
+
+# ---- launch-form toggles (round 6: ONE environment variable instead of two dozen) ---------------------------------------------
+# Every fused / riding launch form of the steps keeps the form it replaced for A/B runs and for tests/test_gpu_knobs.py, which
+# holds each alternative against the default schedule's bits.  The defaults are the measured best on the only hardware
+# available; RSX_FORMS="name=value,name=value" overrides them (names below, case-insensitive).
+FORMS = {
+    "scatter_riders": ("1", "reductions only the optimizer reads ride in the scatter's stage-A launch (0: launches of their own)"),
+    "sort_in_gather": ("0", "deepfm.py: the dedup sort rides in the gather launch instead of the first tower-forward launch"),
+    "sort_ride_max": ("2048", "largest global batch whose dedup sort rides in another launch"),
+    "din_side_sort": ("1", "din.py: the ids-only branch (sort + sweep) on a side stream of the step's graph"),
+    "din_side_sort_dp": ("1", "the same under data parallelism"),
+    "din_gather_ride": ("1", "din.py: the history gather rides in the prepare launch"),
+    "mlp_reduce_ride": ("1", "din.py: the fused MLP's gradient reduce rides in the pooling backward launch"),
+    "mlp_fuse": ("1", "a batch-norm-free tower as ONE launch (csrc/mlp_fused.hip) instead of 2L + 2"),
+    "fm_fuse": ("1", "fm.py: forward + head in one launch"),
+    "fuse_gather": ("1", "the input_layer lookup rides in the first tower-forward launch"),
+    "gather_cross": ("1", "dcn.py: lookup + cross forward as one launch"),
+    "win_separate_sorts": ("0", "debugging aid: an optimizer window's k sorts as k launches"),
+    "cin_dx_fsplit": ("1", "xdeepfm.py: the first CIN layer's data gradients split their fields over two workgroups per tile"),
+    "cin_wide": ("1", "xdeepfm.py --cin_bf16: the wide-tile kernels"),
+    "cin_gather_ride": ("1", "xdeepfm.py: the lookup rides in the filter-preparation launch"),
+    "cin_dx0_ride": ("1", "xdeepfm.py: the dX0 tile reduce rides in the weight-gradient launch"),
+    "xdfm_sort_ride": ("1", "xdeepfm.py: the dedup sort rides in a tower launch"),
+    "dp_eager_tail": ("1", "segmented data-parallel graphs: the step's train_op as an eager tail"),
+    "dp_prefetch": ("0", "segmented data-parallel graphs: the next step's ids all-gather issued early"),
+    "window_stage": ("", "'memcpy': staged windows fetched with hipMemcpyAsync instead of the copy kernel"),
+    "window_sets": ("2", "captured instances of a streaming window that take turns"),
+    "input_thread": ("0", "the input iterator on a thread of its own"),
+    "launch_thread": ("0", "streaming windows issued by a thread of their own"),
+    "adam_window_large": ("4", "steps per optimizer window above the small-batch threshold"),
+}
+
+
+def form(name):
+    """Value (a string) of launch-form toggle `name`: RSX_FORMS's override, else the default."""
+    name = name.lower()
+    default = FORMS[name][0]
+    spec = os.environ.get("RSX_FORMS")
+    if spec:
+        for item in spec.split(","):
+            k, _, v = item.partition("=")
+            k = k.strip().lower()
+            if k and k not in FORMS:
+                raise RsxError("RSX_FORMS: unknown launch form %r (known: %s)" % (k, ", ".join(sorted(FORMS))))
+            if k == name:
+                return v.strip()
+    return default
+
+
 class AdamSeg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n", C.c_int64),
                 ("var", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p),
@@ -133,7 +182,7 @@ def default_adam_window(capacity, unique_exchange=False):
     # single-replica measurements' 1024
     if capacity <= (2048 if unique_exchange else 1024):
         return ADAM_WINDOW_MAX
-    return max(1, min(ADAM_WINDOW_MAX, int(os.environ.get("RSX_ADAM_WINDOW_LARGE", "4"))))     # (A/B knob for the large-batch choice)
+    return max(1, min(ADAM_WINDOW_MAX, int(form("adam_window_large"))))     # (A/B knob for the large-batch choice)
 
 
 class AdamWindow(C.Structure):

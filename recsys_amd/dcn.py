@@ -146,7 +146,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # Round 4 (single replica, fused optimizer launch): the tower's dW partial-tile reductions and the cross layers' gradient
         # reduce -- two launches whose results only the optimizer reads -- ride in the scatter's stage-A launch as extra
         # workgroups (rsx_segsum_partials_ride).  Data parallel: the dense gradients go into a collective first, so they stay.
-        ride = dp is None and hot is not None and os.environ.get("RSX_SCATTER_RIDERS", "1") == "1"
+        ride = dp is None and hot is not None and _lib.form("scatter_riders") == "1"
         if not gcross:
             _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
         loss, prob, dX, gz, _ = store.tower.train_step(

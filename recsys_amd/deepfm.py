@@ -208,7 +208,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
                 win_ids = window_global_ids(dp, wfeat)   # data-parallel: ONE all-gather for the ids of all wk local batches
                 arena.sort_window(win_ids)
             arena.last_B = ids.shape[0] * (dp.world if dp is not None else 1)
-        elif ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
+        elif ids_sort.shape[0] <= int(_lib.form("sort_ride_max")):   # rides in another launch; larger sorts are faster with 1024 threads of their own
             arena.select(0)
             job = arena.sort_job(ids_sort)
         else:
@@ -217,7 +217,7 @@ def _train_fused(store, arena, ids, labels, params, masks):
         # launches may carry sweep slices too.  Measured (r02, MI355X): the same 93.4 us with the forward shares at 0, and
         # 106-108 us with any share given to the forward launches ([1,1,1,3,3,2.5] ...): a forward launch is a pure chain of
         # dependent L2 accesses and stretches by more than the slice it hides.  So the default stays the r01 form.
-        in_gather = job is not None and overlap and os.environ.get("RSX_SORT_IN_GATHER", "0") == "1"
+        in_gather = job is not None and overlap and _lib.form("sort_in_gather") == "1"
         # round 4: the gather itself rides in the first tower-forward launch (E tiles gathered straight into LDS as the MFMA
         # A operand, rsx_gather_tower_fwd0): one launch less on the step's dependent chain
         fuse_gather = not in_gather and store.tower.fused_gather_ok(arena, ids.shape[0])

@@ -207,7 +207,7 @@ class DinFused:
         return out
 
     def _side_stream(self):
-        if os.environ.get("RSX_DIN_SIDE_SORT", "1") != "1":
+        if _lib.form("din_side_sort") != "1":
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
@@ -260,7 +260,7 @@ class DinFused:
             # Round 4: the six lookups ride in the two prepare launches as extra workgroups (they depend on the ids only, like the
             # prepare kernels: the 11 us bandwidth-bound gather runs beside two latency-bound launches); RSX_DIN_GATHER_RIDE=0: its
             # own launch after them
-            gride = os.environ.get("RSX_DIN_GATHER_RIDE", "1") == "1"
+            gride = _lib.form("din_gather_ride") == "1"
             gjobs = self._gather_jobs(B, i_id, i_cate, hist) if gride else None
             _lib.check(L.rsx_din_prepare2_gather(_ptr(i_id), _ptr(i_cate), _ptr(hist[0]), _ptr(hist[1]), B, P, self.n_item,
                                                  self.n_cate, _ptr(self.keys_t) if big else _ptr(keys2), self.keys_t.shape[1] if big else 0,
@@ -282,7 +282,7 @@ class DinFused:
                 # all-gathered keys, rank blocks in order -- the entry order of the gathered value block
                 keys_g = dp.all_gather_entry_keys(keys2, features["i_id"], self.peer_entry_keys)
                 vals_full, gbias_full = dp.send_views(N)
-            side = self._side_stream() if (dp is None or os.environ.get("RSX_DIN_SIDE_SORT_DP", "1") == "1") else None
+            side = self._side_stream() if (dp is None or _lib.form("din_side_sort_dp") == "1") else None
             main = torch.cuda.current_stream()
             if side is not None:
                 side.wait_stream(main)
@@ -347,7 +347,7 @@ class DinFused:
                 outs=(None, gbias[:B], None),                    # d loss / d bias lands in the scatter's first-order input
                 # the weight-gradient reduce of the one-launch mlp_layer rides in the pooling-backward launch below
                 # (RSX_MLP_REDUCE_RIDE=0: its own launch)
-                reduce_rider=os.environ.get("RSX_MLP_REDUCE_RIDE", "1") == "1")
+                reduce_rider=_lib.form("mlp_reduce_ride") == "1")
             rider = getattr(tw, "mlp_reduce_job", None)
             if B < self.cap_B:
                 # a batch smaller than an earlier one (the final partial batch of an epoch): entries B.. are HISTORY entries now,
@@ -394,7 +394,7 @@ class DinFused:
             dqp = [C.c_void_p(vbase + 4 * t * K) for t in range(2)]         # rows 0 .. B-1 of column block t
             # (round 4, single replica: the two weight-gradient reduces -- 28 of the launch's 54 MB, read by the optimizer only --
             # come back as jobs and ride in the scatter's stage-A launch; RSX_SCATTER_RIDERS=0: inside this launch)
-            ride_fin = dp is None and os.environ.get("RSX_SCATTER_RIDERS", "1") == "1"
+            ride_fin = dp is None and _lib.form("scatter_riders") == "1"
             vjobs = (_lib.VecReduceJob * 2)() if ride_fin else None
             _lib.check(L.rsx_din_attn_finish_pair_defer(_ptr(self.ws[0]), _ptr(gouts[0]), dqp[0], _ptr(hist[0]), _ptr(dX),
                                                         _ptr(self.ws[1]), _ptr(gouts[1]), dqp[1], _ptr(hist[1]), None,

@@ -144,6 +144,16 @@ class DirectComm:
         self._check(L.rsx_comm_init_h(raw, int(rank), int(world), C.byref(h)), "rsx_comm_init_h")
         self.h, self.rank, self.world = h, int(rank), int(world)
         self._side = None
+        # self-check before anything is captured around it: every rank contributes its own number, every rank must read them all
+        # back in rank order (a mis-wired communicator -- wrong device, wrong id, a library copy that does not reach its peers --
+        # fails HERE, loudly, and DataParallel falls back to torch.distributed)
+        probe = torch.full((4,), self.rank, dtype=torch.int32, device="cuda")
+        got = torch.empty(self.world * 4, dtype=torch.int32, device="cuda")
+        self.all_gather(got, probe)
+        torch.cuda.synchronize()
+        want = torch.arange(self.world, dtype=torch.int32, device="cuda").repeat_interleave(4)
+        if not torch.equal(got, want):
+            raise _lib.RsxError("rsx_all_gather self-check: rank %d of %d read %s" % (self.rank, self.world, got.tolist()))
 
     def _check(self, rc, what):
         from . import _lib

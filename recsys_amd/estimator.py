@@ -298,7 +298,7 @@ class Estimator:
         self._ring = {}        # pinned staging buffers for host batches (see _h2d)
         # captured instances of a streaming window that take turns (_train_window_packed): window w + 1 is staged into the
         # other instance while window w is queued or running (3 measured the same as 2: the stream is GPU-bound)
-        self._window_sets = max(2, int(os.environ.get("RSX_WINDOW_SETS", "2")))
+        self._window_sets = max(2, int(_lib.form("window_sets")))
         self._restored = False
         self._log_t = None
         self.dist = None       # recsys_amd.dist.DataParallel, set by attach_distributed()
@@ -396,7 +396,7 @@ class Estimator:
         launches -- is re-issued eagerly on every replay.  A graph launch costs ~9 us of start-up and ~8 us before the next
         un-captured operation begins (measured through RCCL at world 1): a graph around so few launches loses more than it saves."""
         if self.store.dp is not None and self.store.graph_safe_dp and not self._dp_capture() and \
-                os.environ.get("RSX_DP_EAGER_TAIL", "1") == "1":
+                _lib.form("dp_eager_tail") == "1":
             seg, spec = self._capture(lambda: self._call_model_fn(features, labels, ModeKeys.TRAIN))
             seg.items.append(spec.train_op)      # re-executed (eagerly) by every replay, after the captured segments
             return seg, spec.loss.detach()
@@ -521,7 +521,7 @@ class Estimator:
                 # nothing would consume it before the buffers may be refilled).  Off by default: through RCCL at world 1 the
                 # async launch + stream hand-over costs 7 us more than it hides; whether real xGMI latency reverses that can
                 # only be measured on a multi-GPU node.
-                nxt = g["steps"][(s + 1) % n][0] if (s + 1 < steps and os.environ.get("RSX_DP_PREFETCH", "0") == "1") else None
+                nxt = g["steps"][(s + 1) % n][0] if (s + 1 < steps and _lib.form("dp_prefetch") == "1") else None
                 seg.replay(nxt)
                 s += 1
             return loss if loss is not None else g["steps"][0][1]
@@ -676,7 +676,7 @@ class Estimator:
         # The kernel node reads the pinned staging buffer through the device's mapping of host memory, right after plain host
         # stores: that needs coherent (fine-grained) pinned allocations, torch's default.  RSX_WINDOW_STAGE=memcpy (automatic
         # under HIP_HOST_COHERENT=0) makes the first node a hipMemcpyAsync instead (0.0696 vs 0.0680 ms per DeepFM step).
-        stage_memcpy = os.environ.get("RSX_WINDOW_STAGE", "") == "memcpy" or os.environ.get("HIP_HOST_COHERENT", "1") == "0"
+        stage_memcpy = _lib.form("window_stage") == "memcpy" or os.environ.get("HIP_HOST_COHERENT", "1") == "0"
 
         def window():
             if host and stage_memcpy:
@@ -715,7 +715,7 @@ class Estimator:
     def train(self, input_fn, steps=None, max_steps=None):
         self._check_consistent("train")       # (a poisoned store must be restored from a checkpoint, not trained on)
         it = iter(input_fn())
-        if self._use_graph() and os.environ.get("RSX_INPUT_THREAD", "0") != "0":      # (measured: no gain next to the launch thread)
+        if self._use_graph() and _lib.form("input_thread") != "0":      # (measured: no gain next to the launch thread)
             depth = max(16, 2 * self._window_len())
             # (an iterator that outlives this call keeps its thread and whatever the thread has pulled ahead)
             it = it.threaded(depth) if isinstance(it, _Resumable) else _InputThread(it, depth)
@@ -723,7 +723,7 @@ class Estimator:
         # costs the training thread 22-45 us per 8 steps (scripts/graph_launch_cost.py) and the stream is GPU-bound without
         # it; with a slow input pipeline it takes the launch off the fetching thread (e2e A/B: within the box-to-box noise)
         launcher = None
-        if self._use_graph() and self.store.dp is None and os.environ.get("RSX_LAUNCH_THREAD", "0") != "0":
+        if self._use_graph() and self.store.dp is None and _lib.form("launch_thread") != "0":
             launcher = _LaunchThread(self.config.device)
         try:
             self._train_loop(it, steps, max_steps, launcher)

@@ -135,7 +135,7 @@ def _train_fused(store, arena, ids, labels):
         # contribution to the four dense gradients as a row of `terms` in the dense arena's layout; the optimizer launch adds
         # the rows in example order (an RSX_ADAM_DENSE segment with B = batch "replicas"), the loss is read from the terms when
         # somebody asks (estimator.LazyMeanLoss).  Single replica, windows on (no sweep slice to carry); RSX_FM_FUSE=0: two launches.
-        terms_on = dp is None and os.environ.get("RSX_FM_FUSE", "1") != "0" and P.n + 1 <= 64
+        terms_on = dp is None and _lib.form("fm_fuse") != "0" and P.n + 1 <= 64
         fuse = terms_on and sweep is None
         terms, loss = None, None
         if terms_on:

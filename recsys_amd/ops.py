@@ -371,7 +371,7 @@ class EmbeddingArena:
             self.select(i)
             jobs[i] = self.sort_job(ids)
         self.select(0)
-        if os.environ.get("RSX_WIN_SEPARATE_SORTS") == "1":      # debugging aid: k launches of the single-sort kernel
+        if _lib.form("win_separate_sorts") == "1":      # debugging aid: k launches of the single-sort kernel
             for i, ids in enumerate(ids_list):
                 self.select(i)
                 self.field_sort(ids)
@@ -801,7 +801,7 @@ class FusedTower:
     @staticmethod
     def fused_gather_ok(arena, B):
         """The envelope of the gather riding in the first forward launch (RSX_FUSE_GATHER=0: the two launches, A/B runs)."""
-        return os.environ.get("RSX_FUSE_GATHER", "1") != "0" and \
+        return _lib.form("fuse_gather") != "0" and \
             bool(lib().rsx_gather_tower_fwd0_supported(int(B), int(arena.F), int(arena.D)))
 
     def _masks(self, B, rate, masks):
@@ -959,7 +959,7 @@ class FusedTower:
         ok = getattr(self, "_mlp_ok", None)
         if ok is None:
             w = (C.c_int32 * len(self.widths))(*self.widths)
-            ok = os.environ.get("RSX_MLP_FUSE", "1") == "1" and len(self.widths) <= 3 and \
+            ok = _lib.form("mlp_fuse") == "1" and len(self.widths) <= 3 and \
                 bool(lib().rsx_mlp_nobn_supported(self.k0, w, len(self.widths)))
             if ok:
                 n = int(lib().rsx_mlp_nobn_workspace_floats(self.cap, self.k0, w, len(self.widths)))
@@ -1047,7 +1047,7 @@ class CrossLayers:
 
     def fused_gather_ok(self, arena):
         return arena.D == 16 and arena.F <= 64 and arena.F * arena.D == self.dim and self.L <= 8 and \
-            os.environ.get("RSX_GATHER_CROSS", "1") == "1"
+            _lib.form("gather_cross") == "1"
 
     def backward(self, x0, W, Bc, dW, dB, dX, accumulate, dxL=None, gz=None, wout=None, dwout=None, defer_reduce=False):
         """defer_reduce: the second launch (the gradient partials' sum) comes back as a _lib.CrossReduceJob for the scatter's
@@ -1380,7 +1380,7 @@ class CinNet:
             # layer 0 in mode 4 (dXk IS dX0; a few tiles of h only): its data-gradient launch splits the FIELDS over two workgroups
             # per tile when both fit the CUs in one round; the second half's dXk is one more tile partial (RSX_CIN_DX_FSPLIT=0: off)
             ht0 = (hs16[0] + 15) // 16
-            self.fsplit0 = (ns == 4 and os.environ.get("RSX_CIN_DX_FSPLIT", "1") != "0" and
+            self.fsplit0 = (ns == 4 and _lib.form("cin_dx_fsplit") != "0" and
                             2 * ht0 * ((capacity + 7) // 8) <= 256)
             extra = [capacity * F * D if (k == 0 and self.fsplit0) else 0 for k in range(self.L)]
             self.dx0_parts = [torch.empty(int(lib().rsx_cin_bf16_dx0_parts_floats(capacity, F, h)) + x, device=dev)
@@ -1402,7 +1402,7 @@ class CinNet:
             self._H_h = (C.c_int32 * self.L)(*hs16)
             # eight examples per workgroup (csrc/cin_bf16_wide.hip): the data-gradient launches leave dX0 as one partial per
             # 16-wide tile of h, ONE reduce launch adds the tiles of all layers
-            self.wide = F <= 40 and os.environ.get("RSX_CIN_WIDE", "1") != "0"
+            self.wide = F <= 40 and _lib.form("cin_wide") != "0"
             if self.wide:
                 self.dx0_parts = [torch.empty(int(lib().rsx_cin_bf16_dx0_parts_floats(capacity, F, h)), device=dev) for h in hs16]
                 self._tiles_h = (C.c_int32 * self.L)(*[(h + 15) // 16 for h in hs16][::-1])
@@ -1419,7 +1419,7 @@ class CinNet:
     def gather_ride_ok(self):
         """xdeepfm.py's lookup (rsx_gather_two_fwd) can ride in this net's filter-preparation launch (RSX_CIN_GATHER_RIDE=0: two
         launches, A/B runs)."""
-        return bool(self.split) and self.D == 16 and os.environ.get("RSX_CIN_GATHER_RIDE", "1") != "0"
+        return bool(self.split) and self.D == 16 and _lib.form("cin_gather_ride") != "0"
 
     def forward(self, X0, P, sweeps=None, gather_job=None):
         """X0 [B,F,D] contiguous -> cin_y [B] (view of an internal buffer).  sweeps[k]: slice of the untouched-row
@@ -1508,7 +1508,7 @@ class CinNet:
                                           C.c_void_p(wout + 4 * self.offs[k]), _ptr(dxk), acc_dxk, _ptr(dX0), acc_dx0,
                                           _ptr(P[f"cin.W{k}"].grad), _ptr(P[f"cin.c{k}"].grad), _ptr(self.dpre), B, self.F, H,
                                           self.sizes[k], self.D, sw, _stream()), "rsx_cin_layer_bwd")
-        fuse_red = bool(self.split) and os.environ.get("RSX_CIN_DX0_RIDE", "1") != "0"     # (0: the reduce as its own launch, A/B)
+        fuse_red = bool(self.split) and _lib.form("cin_dx0_ride") != "0"     # (0: the reduce as its own launch, A/B)
         if wide or self.split:  # dX0 = layer 0's dXk (already there) + every layer's tile partials, last layer first
             parts_h = (C.c_void_p * L)(*[self.dx0_parts[k].data_ptr() for k in range(L - 1, -1, -1)])
             if not fuse_red:

@@ -189,8 +189,8 @@ def _train_fused(store, a1, a2, ids, logx, labels, params, masks):
                 a2.last_B = ids_sort.shape[0]
             # The sort (it serves a2 as well, share_sort_of) rides in the tower's first forward launch when no sweep slice is
             # scheduled before or in that launch (slices read the sort's slot map); otherwise it runs first.
-            ride = (not ux and ids_sort.shape[0] <= int(os.environ.get("RSX_SORT_RIDE_MAX", "2048"))
-                    and os.environ.get("RSX_XDFM_SORT_RIDE", "1") == "1")
+            ride = (not ux and ids_sort.shape[0] <= int(_lib.form("sort_ride_max"))
+                    and _lib.form("xdfm_sort_ride") == "1")
             job = a1.sort_job(ids_sort) if not ux else None
             if store.adam_mode == "tf1_dense" and bool(params.get("overlap_adam", True)):
                 # exact split of the TF-1 update (see deepfm.py): the sweep over the UNtouched rows of both table sets

@@ -7,8 +7,8 @@ for m in deepfm fm dcn; do
   ARGS="--model $m --emulate_world 8"
   run "$m N=8 default            " A=1
   run "$m N=8 capture            " RSX_DP_CAPTURE=1
-  run "$m N=8 window8            " RSX_ADAM_WINDOW_LARGE=8
-  run "$m N=8 window8+capture    " RSX_ADAM_WINDOW_LARGE=8 RSX_DP_CAPTURE=1
+  run "$m N=8 window8            " RSX_FORMS=adam_window_large=8
+  run "$m N=8 window8+capture    " RSX_FORMS=adam_window_large=8 RSX_DP_CAPTURE=1
   run "$m N=8 examples (legacy)  " RSX_DP_EXCHANGE=examples
   ARGS="--model $m --emulate_world 8 --emulate_identical"
   run "$m N=8 examples identical " RSX_DP_EXCHANGE=examples

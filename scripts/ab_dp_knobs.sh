@@ -9,6 +9,6 @@ for m in ${MODELS:-deepfm dcn}; do
   ARGS="--model $m --emulate_world ${WORLD:-8}"
   run "$m N=${WORLD:-8} default            " A=1
   run "$m N=${WORLD:-8} NR=1 always        " RSX_WIN_NR4_MIN=1000000
-  run "$m N=${WORLD:-8} window8            " RSX_ADAM_WINDOW_LARGE=8
-  run "$m N=${WORLD:-8} window8 NR=1       " RSX_ADAM_WINDOW_LARGE=8 RSX_WIN_NR4_MIN=1000000
+  run "$m N=${WORLD:-8} window8            " RSX_FORMS=adam_window_large=8
+  run "$m N=${WORLD:-8} window8 NR=1       " RSX_FORMS=adam_window_large=8 RSX_WIN_NR4_MIN=1000000
 done

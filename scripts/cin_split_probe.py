@@ -24,7 +24,7 @@ for (B, H, N) in ((256, 39, 128), (256, 128, 128)):
     w16 = torch.empty(int(lib().rsx_cin_bf16_weight_elems(39, H, N)), dtype=torch.int16, device=dev)
     check(lib().rsx_cin_prep_bf16(_ptr(W), _ptr(w16), 39, H, N, _stream()))
     us = timeit(lambda: check(lib().rsx_cin_layer_fwd_bf16(_ptr(X0), _ptr(Xk), _ptr(w16), _ptr(c), _ptr(out), B, 39, H, N, 16, None, _stream())))
-    print("fwd bf16 (RSX_CIN_WIDE=%s) H=%3d %8.2f us %7.1f TF" % (os.environ.get("RSX_CIN_WIDE", "1"), H, us, fl / us / 1e6))
+    print("fwd bf16 (cin_wide=%s) H=%3d %8.2f us %7.1f TF" % (__import__("recsys_amd._lib", fromlist=["form"]).form("cin_wide"), H, us, fl / us / 1e6))
     for ns in (1, 2, 3, 4):
         ws = torch.empty(int(lib().rsx_cin_split_weight_elems(39, H, N, ns)), dtype=torch.int16, device=dev)
         Wh, wh = (C.c_void_p * 1)(W.data_ptr()), (C.c_void_p * 1)(ws.data_ptr())

@@ -14,7 +14,6 @@ scripts/gpu.sh prof ${tag}_xdeepfm_bf16_kernel_stats --model xdeepfm --cin_bf16 
 scripts/gpu.sh prof ${tag}_xdeepfm_x4_kernel_stats --model xdeepfm --cin_split 4 --no_cpu_baseline --no_configs --steps 320 --warmup 32
 scripts/gpu.sh prof ${tag}_xdeepfm_x3_kernel_stats --model xdeepfm --cin_split 3 --no_cpu_baseline --no_configs --steps 320 --warmup 32
 scripts/gpu.sh pmc ${tag}_MFMA_BUSY_xdeepfm_x4 "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" --model xdeepfm --cin_split 4 --no_configs --no_cpu_baseline --steps 32 --warmup 16
-scripts/gpu.sh pmc ${tag}_MFMA_BUSY_xdeepfm_x3 "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" --model xdeepfm --cin_split 3 --no_configs --no_cpu_baseline --steps 32 --warmup 16
 python scripts/cin_split_probe.py 2>/dev/null | grep -v amdgpu > gpurun_out/${tag}_cin_split_probe.txt
 scripts/gpu.sh prof ${tag}_din_kernel_stats --model din --no_cpu_baseline --no_configs --steps 160 --warmup 16
 TAG=${tag}_default scripts/gpu.sh bench
@@ -23,9 +22,13 @@ TAG=${tag}_steps20 scripts/gpu.sh bench --steps 20
 scripts/emulate_table.sh > /dev/null 2>&1; cp gpurun_out/emulate_table.txt gpurun_out/${tag}_emulate_world_all_models.txt
 scripts/gpu.sh roofline > /dev/null; cp gpurun_out/kernel_roofline_table.txt gpurun_out/${tag}_kernel_roofline_table.txt
 for r in 1 2 3; do echo "# repeat $r"; python scripts/scatter_large.py 4096 65536 2>/dev/null; done > gpurun_out/${tag}_scatter_large_3_repeats.txt
-# the data-parallel code path through RCCL at world 1, both exchanges: eager collectives between graph segments (the default)
-# and collectives captured into the graphs (RSX_DP_CAPTURE=1; a run that prints no line was aborted by the watchdog, dist.dp_capture)
-scripts/dp_world1.sh > gpurun_out/${tag}_dp_world1_rccl.txt 2>&1
-RSX_DP_CAPTURE=1 scripts/dp_world1.sh 2>&1 | grep "world-1 RCCL" | sed 's/^world-1 RCCL/world-1 RCCL, RSX_DP_CAPTURE=1 (captured collectives)/' >> gpurun_out/${tag}_dp_world1_rccl.txt
+# the data-parallel code path through RCCL at world 1 in its default configuration (round 6: collectives through the C ABI,
+# captured into the step's graphs), both exchanges, next to the single-replica step; then 50 xdeepfm.py soak runs
+scripts/dp_world1_r06.sh > gpurun_out/${tag}_dp_world1_rccl.txt 2>&1
 cat gpurun_out/${tag}_dp_world1_rccl.txt
+# MFMA-busy of din.py's attention kernels (the forward runs on the bf16 matrix cores with split operands since round 6)
+scripts/gpu.sh pmc ${tag}_MFMA_BUSY_din "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" --model din --no_configs --no_cpu_baseline --steps 32 --warmup 16
+# the headline's HBM-side traffic, fresh (separate --pmc passes)
+scripts/gpu.sh pmc ${tag}_FETCH_SIZE_deepfm "FETCH_SIZE" --no_configs --no_cpu_baseline --steps 64 --warmup 32
+scripts/gpu.sh pmc ${tag}_WRITE_SIZE_deepfm "WRITE_SIZE" --no_configs --no_cpu_baseline --steps 64 --warmup 32
 ls -la gpurun_out | grep $tag

@@ -101,3 +101,18 @@ def test_layout_transform_matches_oracle(L):
     offs = np.concatenate([[0], np.cumsum([len(v) for v in flat])]).astype(np.int64)
     ids = lay.transform(cont, buf, offs)
     assert np.array_equal(ids, criteo.transform_batch(cont, cat, c2_shift=4.0))
+
+
+def test_launch_form_registry(monkeypatch):
+    """recsys_amd/_lib.py FORMS: the launch-form toggles live behind ONE environment variable; unknown names fail loudly."""
+    from recsys_amd import _lib
+    monkeypatch.delenv("RSX_FORMS", raising=False)
+    assert _lib.form("fm_fuse") == "1" and _lib.form("SORT_RIDE_MAX") == "2048"
+    monkeypatch.setenv("RSX_FORMS", "fm_fuse=0, Sort_Ride_Max=0")
+    assert _lib.form("fm_fuse") == "0" and _lib.form("sort_ride_max") == "0" and _lib.form("mlp_fuse") == "1"
+    monkeypatch.setenv("RSX_FORMS", "no_such_form=1")
+    with pytest.raises(_lib.RsxError):
+        _lib.form("fm_fuse")
+    with pytest.raises(KeyError):
+        monkeypatch.delenv("RSX_FORMS")
+        _lib.form("no_such_form")

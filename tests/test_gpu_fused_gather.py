@@ -111,9 +111,9 @@ def test_fused_gather_envelope():
 
 @pytest.mark.parametrize("fuse", ["1", "0"])
 def test_deepfm_train_parity_with_and_without_the_fused_gather(fuse, monkeypatch):
-    """The DeepFM TRAIN step against the oracle through both forms of the first launch (RSX_FUSE_GATHER)."""
+    """The DeepFM TRAIN step against the oracle through both forms of the first launch (RSX_FORMS fuse_gather)."""
     from tests.parity_util import deepfm_parity_run
-    monkeypatch.setenv("RSX_FUSE_GATHER", fuse)
+    monkeypatch.setenv("RSX_FORMS", "fuse_gather=%s" % fuse)
     err, losses, perr = deepfm_parity_run(B=64, steps=3, seed=21, dropout=0.5, return_all=True)
     assert err < 1e-5, err
     for lg, lo in losses:

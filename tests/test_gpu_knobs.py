@@ -19,7 +19,15 @@ _cache = {}
 def _run(model, B, steps, env_extra, bf16=False):
     key = (model, B, steps, bf16, tuple(sorted(env_extra.items())))
     if key not in _cache:
-        env = dict(os.environ, **env_extra)
+        # launch-form toggles travel in ONE variable since round 6 (recsys_amd/_lib.py FORMS): "RSX_<NAME>" keys of the tables
+        # below whose name is a launch form are folded into RSX_FORMS; the rest (kernel variants read by librsx.so, real knobs)
+        # stay environment variables of their own
+        from recsys_amd._lib import FORMS
+        forms = {k[4:].lower(): v for k, v in env_extra.items() if k[4:].lower() in FORMS}
+        rest = {k: v for k, v in env_extra.items() if k[4:].lower() not in FORMS}
+        if forms:
+            rest["RSX_FORMS"] = ",".join("%s=%s" % kv for kv in sorted(forms.items()))
+        env = dict(os.environ, **rest)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_worker.py"), model, str(B), str(steps), "1" if bf16 else "0"],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
