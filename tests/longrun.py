@@ -93,7 +93,7 @@ def oracle_run(name, P32, train, ev, dtype=np.float64, progress=None):
         probs.append(p)
     return {"train_losses": np.array(losses), "eval_losses": np.array(ev_losses), "eval_probs": np.stack(probs).astype(np.float64),
             "eval_loss": float(np.mean(ev_losses)), "auc": float(auc.result()), "accuracy": hits / float(EVAL_BATCHES * B),
-            "final_dense": {k: P[k].astype(np.float32) for k in P if P[k].ndim <= 2 and P[k].shape[0] < 10000}}
+            "final_dense": {k: P[k].astype(np.float32) for k in P if P[k].ndim <= 2 and P[k].shape[0] < 10000 and P[k].size <= 20000}}
 
 
 def hip_run(name, P, train, ev, extra_params=None, use_graph=False):
