@@ -468,8 +468,8 @@ int rsx_adam_fast_math_selftest(unsigned long long* counts, uint32_t seed, int d
  * non-NULL is what marks "there is a previous layer") but their contents are not used.
  * ------------------------------------------------------------------------------------------- */
 /* Batches > 512 (round 6; rounds 1-5 folded the row partials with a launch per statistics buffer): fstat_l / bstat_l are then
- * FIXED-POINT accumulators, int64 [8][Npad_l][4] (Npad = N rounded up to 16; RSX_TOWER_FIXED_STATS_DOUBLES(N) doubles): 8 rows of
- * per-column hi(sum), lo(sum), hi(sum sq), lo(sum sq) with value = (hi * 2^32 + lo) * 2^-52 -- producer workgroup b adds its partial sums
+ * FIXED-POINT accumulators, int64 [8][4][Npad_l] (Npad = N rounded up to 16; RSX_TOWER_FIXED_STATS_DOUBLES(N) doubles): 8 rows of
+ * the planes hi(sum) | lo(sum) | hi(sum sq) | lo(sum sq) with value = (hi * 2^32 + lo) * 2^-52 -- producer workgroup b adds its partial sums
  * to row b & 7 with non-returning integer atomics (order-independent, hence deterministic; resolution 2.2e-16, |sum| < 8.8e12;
  * 8 rows because same-address atomics serialise), every consumer adds the 8 rows: no launch between producer and consumer.
  * The rows must be ZERO before the step's first producer adds to them.  No consumer can clear it (other workgroups of

@@ -57,8 +57,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // row as FIXED-POINT integers with plain (non-returning) 64-bit atomics -- bit-identical whatever the order, no launch, no
 // tail.  Value v = s * 2^52 (exact: a power-of-two scale) is split into two limbs, hi = rint(v / 2^32) and lo = rint(v - hi *
 // 2^32) in [-2^31, 2^31]: the resolution is 2^-52 = 2.2e-16 absolute (the fp64 sums it replaces round at ~1e-16 relative), the
-// range |s| < 2^43 = 8.8e12, and 2^20 producers cannot overflow the low limb.  Layout of a fixed row: int64 [Npad][4] = per
-// column hi(sum), lo(sum), hi(sum sq), lo(sum sq) (8 such rows per buffer, see STAT_FIX_ROWS).  The rows must be ZERO when the step's first
+// range |s| < 2^43 = 8.8e12, and 2^20 producers cannot overflow the low limb.  Layout of a fixed row: int64 [4][Npad] = the planes
+// hi(sum), lo(sum), hi(sum sq), lo(sum sq) (8 such rows per buffer, see STAT_FIX_ROWS).  The rows must be ZERO when the step's first
 // producer runs: the consumers cannot clear it
 // (other workgroups of the same launch still read it), so a LATER launch of the same stream does -- the first layer's backward
 // launch (the last tower launch of a step) clears every row except the one it consumes itself, and the first layer's forward
@@ -69,7 +69,7 @@ constexpr double STAT_FIX_LIMB = 4294967296.0;               // 2^32
 // Same-address atomics serialise (~12 ns each: 256 producers on one row cost 3.5 us per launch, measured stand-alone --
 // scripts/micro/atomic_shard.hip, profiles/r06_c_atomic_shard.txt -- and more at the tail of a real launch, where all producers
 // finish together: dcn.py's step got 12 us SLOWER with one row); 8 rows, producer workgroup b adding to row b & 7, cost 0.3 us.
-// A fixed buffer is therefore int64 [STAT_FIX_ROWS][Npad][4], Npad = N rounded up to 16 (rows start on 128-byte lines);
+// A fixed buffer is therefore int64 [STAT_FIX_ROWS][4][Npad], Npad = N rounded up to 16 (rows start on 128-byte lines);
 // consumers add the 8 rows as integers (exact, order-free).
 constexpr int STAT_FIX_ROWS = 8;
 __host__ __device__ __forceinline__ int stat_fix_npad(const int N) { return (N + 15) & ~15; }
@@ -80,26 +80,27 @@ __device__ __forceinline__ void stat_fix_add(double* __restrict__ st, const int 
   const double h1 = rint(v1 * (1.0 / STAT_FIX_LIMB)), h2 = rint(v2 * (1.0 / STAT_FIX_LIMB));
   const long long l1 = __double2ll_rn(v1 - h1 * STAT_FIX_LIMB), l2 = __double2ll_rn(v2 - h2 * STAT_FIX_LIMB);
   // (results unused: the compiler emits the non-returning form -- fire and forget, nothing on the workgroup's tail)
-  // (a column's four limbs are contiguous: the consumers fetch them with two 16-byte loads per row)
-  atomicAdd(a + 4 * col + 0, (unsigned long long)__double2ll_rn(h1));
-  atomicAdd(a + 4 * col + 1, (unsigned long long)l1);
-  atomicAdd(a + 4 * col + 2, (unsigned long long)__double2ll_rn(h2));
-  atomicAdd(a + 4 * col + 3, (unsigned long long)l2);
+  // The four limbs live in four PLANES of the row (limb q of column c at [q][c]): a wave's atomics of one limb go to
+  // consecutive words.  With a column's limbs side by side instead ([c][4], so that a consumer fetches them with two 16-byte
+  // loads) the producers' atomics of four limbs hit the same 32 bytes one after the other: dcn.py 0.1913 against 0.1821 ms
+  // (ABAB on one box, profiles/r06_h_stat_layout_ab.txt) -- the consumers' 32 8-byte loads cost nothing measurable.
+  atomicAdd(a + col, (unsigned long long)__double2ll_rn(h1));
+  atomicAdd(a + NP + col, (unsigned long long)l1);
+  atomicAdd(a + 2 * NP + col, (unsigned long long)__double2ll_rn(h2));
+  atomicAdd(a + 3 * NP + col, (unsigned long long)l2);
 }
 __device__ __forceinline__ void stat_fix_read(const double* __restrict__ st, const int N, const int col, double& s1, double& s2) {
   const int NP = stat_fix_npad(N);
-  typedef long long ll2 __attribute__((ext_vector_type(2)));
-  const ll2* a = reinterpret_cast<const ll2*>(st) + 2 * col;
-  ll2 t[STAT_FIX_ROWS][2];
+  const long long* a = reinterpret_cast<const long long*>(st) + col;
+  long long t[STAT_FIX_ROWS][4];
 #pragma unroll
-  for (int r = 0; r < STAT_FIX_ROWS; ++r) {      // all 16 loads (16 bytes each) in flight: one memory round trip
-    t[r][0] = a[(size_t)r * 2 * NP];
-    t[r][1] = a[(size_t)r * 2 * NP + 1];
-  }
+  for (int r = 0; r < STAT_FIX_ROWS; ++r)        // all 32 loads in flight: one memory round trip
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[r][q] = a[((size_t)r * 4 + q) * NP];
   long long h1 = 0, l1 = 0, h2 = 0, l2 = 0;
 #pragma unroll
   for (int r = 0; r < STAT_FIX_ROWS; ++r) {
-    h1 += t[r][0].x; l1 += t[r][0].y; h2 += t[r][1].x; l2 += t[r][1].y;
+    h1 += t[r][0]; l1 += t[r][1]; h2 += t[r][2]; l2 += t[r][3];
   }
   s1 = ((double)h1 * STAT_FIX_LIMB + (double)l1) * (1.0 / STAT_FIX_SCALE);
   s2 = ((double)h2 * STAT_FIX_LIMB + (double)l2) * (1.0 / STAT_FIX_SCALE);

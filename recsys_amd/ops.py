@@ -761,7 +761,7 @@ class FusedTower:
         self.fstat = [torch.zeros(RT, 2, n, **f64) for n in self.widths]
         self.bstat = [torch.zeros(RT, 2, n, **f64) for n in self.widths]
         # batches > 512 (include/rsx.h RSX_TOWER_FIXED_STATS_MIN_B): fixed-point accumulators per statistics buffer,
-        # int64 [8, n rounded up to 16, 4] viewed as doubles, all in one allocation ordered [bstat_0 | fstat_0 .. fstat_{L-1} | bstat_1 .. bstat_{L-1}]:
+        # int64 [8, 4, n rounded up to 16] viewed as doubles, all in one allocation ordered [bstat_0 | fstat_0 .. fstat_{L-1} | bstat_1 .. bstat_{L-1}]:
         # the first layer's forward launch clears bstat_0 for its step, the first layer's backward launch everything else for the
         # next one (two contiguous ranges)
         self.fix = self.fix_eval = None
@@ -984,8 +984,8 @@ class FusedTower:
             es = []
             for n in self.widths:
                 if B > 512:         # the fixed-point rows (include/rsx.h): sum = 0, sum of squares = B = (hi * 2^32 + lo) * 2^-52
-                    t = torch.zeros(8, (n + 15) // 16 * 16, 4, dtype=torch.int64, device=X.device)
-                    t[0, :, 2] = B << 20
+                    t = torch.zeros(8, 4, (n + 15) // 16 * 16, dtype=torch.int64, device=X.device)
+                    t[0, 2] = B << 20
                     t = t.view(torch.float64)
                 else:
                     t = torch.zeros(self.fstat[0].shape[0], 2, n, dtype=torch.float64, device=X.device)
