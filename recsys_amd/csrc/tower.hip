@@ -426,7 +426,10 @@ __global__ __launch_bounds__(256, 1) void tower_gather_fwd_k(const GatherFwdArgs
   float bw[NS][4];
   const float* __restrict__ Wg = p.W;
   const uint32_t Nn = (uint32_t)p.N;
-  const uint32_t woff = (uint32_t)(w * 16 + 4 * kq) * Nn + (uint32_t)colc;
+  // (F < 4, i.e. K < 64 -- test shapes only: a wave whose FIRST k-step lies past K falls back to k-step 0's rows.  Unclamped,
+  // wave 3 of an F = 1 tile read 3 KB past a 1 KB weight matrix: harmless inside the allocator's segment, a GPU memory fault
+  // when the matrix is the segment's last block -- one abort in ~8 runs of the GPU suite, found by soaking it in round 6)
+  const uint32_t woff = (uint32_t)((w < F ? w : 0) * 16 + 4 * kq) * Nn + (uint32_t)colc;
 #pragma unroll
   for (int sI = 0; sI < NS; ++sI) {
     const uint32_t o = w + 4 * sI < F ? woff + (uint32_t)(sI * 64) * Nn : woff;   // (a k-step past K is loaded from a valid
