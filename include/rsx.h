@@ -548,6 +548,7 @@ typedef struct {
   int32_t sb, K, N;
   int32_t layout;            /* 0: [tiles][sb][256] tile-major, 1: [sb][K+1 rounded to 16][N rounded to 16] */
 } rsx_dw_reduce_job;
+struct rsx_tower_bwd_extra_;   /* (defined with the cross layers' entries below: the cross-layer backward riding in this launch) */
 int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, const float* dy, const double* bstat,
                               const float* bn, const float* gamma, float* dW, float* db, float* dgamma, float* dbeta,
                               const float* bn_prev, const float* gamma_prev, const float* beta_prev, const float* mask_prev,
@@ -555,7 +556,7 @@ int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, c
                               float* dbd, float* dwo, float* dbo, float* dc0, float* loss, const uint32_t* rng_step,
                               uint32_t seed, int layer, float dropout_rate, int B, int K, int N, const rsx_sort_job* sort_h,
                               const rsx_adam_slice* sweep_h, float* dw_partials, rsx_dw_reduce_job* reduce_out,
-                              double* zero_stats, int zero_n, rsx_stream_t stream);
+                              double* zero_stats, int zero_n, const struct rsx_tower_bwd_extra_* extra_h, rsx_stream_t stream);
 int rsx_tower_reduce_dw_jobs(const rsx_dw_reduce_job* jobs_h, int njobs, rsx_stream_t stream);
 
 /* sweep_h (host pointer, nullable, on all three tower entry points): a slice of the untouched-row optimizer sweep
@@ -660,6 +661,30 @@ int rsx_cross_bwd_defer(const float* x0, const float* W, const float* Bc, const 
                         const float* wout, float* dX, int accumulate, float* dW, float* dB, float* dwout, float* workspace,
                         int B, int dim, int L, rsx_cross_reduce_job* reduce_out, rsx_stream_t stream);
 int rsx_cross_reduce_run(const rsx_cross_reduce_job* job_h, rsx_stream_t stream);
+/* Round 6 (dcn.py): the cross layers' backward needs only the head's gradient gz (dcn/dcn.py:132-142 feeds the logits beside the
+ * tower), so it can leave the step's dependent chain: as `extra_h` of the LAST tower layer's rsx_tower_bwd_layer_defer it runs as
+ * extra workgroups of that launch (exactly rsx_cross_bwd_defer(x0, cW, cB, s, NULL, gz, wout, dX, accumulate = 0, ...): dX is
+ * WRITTEN, the partials' reduce comes back through reduce_out), and the FIRST tower layer's launch is given accumulate_dx = 1 so
+ * that its d(input) tiles add onto that dX (a + b = b + a: the same bits as the separate launch adding afterwards).  Needs at
+ * least two tower layers (the two roles are different launches).  rsx_tower_bwd_cross_ride_supported says whether both launches
+ * take the kernels that know the roles (batch >= 1024, L == 3, dim % 4 == 0, no sort / sweep riders in the carrying launch).   */
+typedef struct rsx_tower_bwd_extra_ {
+  int32_t accumulate_dx;                 /* first layer only: dy_prev (= dX) += instead of = */
+  const float* x0;                       /* NULL: no rider; else the arguments of rsx_cross_bwd_defer */
+  const float* cW;
+  const float* cB;
+  const float* s;
+  const float* gz;
+  const float* wout;
+  float* dX;
+  float* dcW;
+  float* dcB;
+  float* dwout;
+  float* workspace;
+  int32_t dim, L;
+  rsx_cross_reduce_job* reduce_out;      /* required with the rider */
+} rsx_tower_bwd_extra;
+int rsx_tower_bwd_cross_ride_supported(int B, int K_last, int N_last, int K_first, int N_first, int dim, int L);
 /* Reductions of other launches of the TRAIN step that only the optimizer reads, carried by the scatter's stage-A launch
  * (rsx_segsum_partials_ride) as extra 256-thread workgroups beside its position tiles: the tower's dW partial-tile reductions
  * (the jobs rsx_tower_bwd_layer_defer hands back) and the cross layers' gradient reduce.  dcn.py at batch 4 096: two launches

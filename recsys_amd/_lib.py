@@ -33,6 +33,7 @@ FORMS = {
     "fm_fuse": ("1", "fm.py: forward + head in one launch"),
     "fuse_gather": ("1", "the input_layer lookup rides in the first tower-forward launch"),
     "gather_cross": ("1", "dcn.py: lookup + cross forward as one launch"),
+    "cross_ride": ("1", "dcn.py: the cross layers' backward rides in the last tower layer's backward launch (0: a launch of its own)"),
     "win_separate_sorts": ("0", "debugging aid: an optimizer window's k sorts as k launches"),
     "cin_dx_fsplit": ("1", "xdeepfm.py: the first CIN layer's data gradients split their fields over two workgroups per tile"),
     "cin_wide": ("1", "xdeepfm.py --cin_bf16: the wide-tile kernels"),
@@ -119,6 +120,13 @@ class DwReduceJob(C.Structure):
 class CrossReduceJob(C.Structure):        # include/rsx.h rsx_cross_reduce_job
     _fields_ = [("part", C.c_void_p), ("dW", C.c_void_p), ("dB", C.c_void_p), ("dwout", C.c_void_p), ("RT", C.c_int32),
                 ("n", C.c_int32), ("L", C.c_int32), ("dim", C.c_int32)]
+
+
+class TowerBwdExtra(C.Structure):         # include/rsx.h rsx_tower_bwd_extra
+    _fields_ = [("accumulate_dx", C.c_int32), ("x0", C.c_void_p), ("cW", C.c_void_p), ("cB", C.c_void_p), ("s", C.c_void_p),
+                ("gz", C.c_void_p), ("wout", C.c_void_p), ("dX", C.c_void_p), ("dcW", C.c_void_p), ("dcB", C.c_void_p),
+                ("dwout", C.c_void_p), ("workspace", C.c_void_p), ("dim", C.c_int32), ("L", C.c_int32),
+                ("reduce_out", C.POINTER(CrossReduceJob))]
 
 
 class VecReduceJob(C.Structure):          # include/rsx.h rsx_vec_reduce_job
@@ -215,7 +223,8 @@ _SIGS = {
     "rsx_fm_head": (_I, [_P] * 13 + [_F, _I, _P, _P]),
     "rsx_fm_head_terms": (_I, [_P] * 14 + [_I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "rsx_tower_bwd_layer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P]),
-    "rsx_tower_bwd_layer_defer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "rsx_tower_bwd_layer_defer": (_I, [_P] * 26 + [C.c_uint32, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "rsx_tower_bwd_cross_ride_supported": (_I, [_I] * 7),
     "rsx_tower_reduce_dw_jobs": (_I, [_P, _I, _P]),
     "rsx_tower_bwd_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "rsx_segsum_adam_rows": (_I, [_P] * 14 + [_U64, _I, _I, _I, _I, C.POINTER(AdamSeg), _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P]),

@@ -39,19 +39,6 @@ __global__ __launch_bounds__(256) void cross_fwd_k(const CrossFwdArgs p) {
                  p.cz != nullptr ? p.cz + b : nullptr, p.dim, p.L, lane);
 }
 
-struct CrossBwdArgs {
-  const float* x0;     // [B, dim]
-  const float* W;      // [L, dim]
-  const float* Bc;     // [L, dim]
-  const float* s;      // [B, L]
-  const float* dxL;    // [B, dim] or null
-  const float* gz;     // [B] or null (d loss / d cz)
-  const float* wout;   // [dim] (required with gz)
-  float* dX;           // [B, dim]
-  float* part;         // [RT, 2L+1, dim]: dW (L), dB (L), dwout
-  int accumulate;      // dX += (1) or dX = (0)
-  int B, dim, L;
-};
 
 // grid = ceil(B/epw), block = 64: ONE wave walks `epw` examples and accumulates dW / dB / dwout in its own
 // LDS slab (lane-private float4 slots: no conflicts, no barriers), then writes the slab as one partial.
@@ -149,120 +136,12 @@ __global__ __launch_bounds__(64) void cross_bwd_k(const CrossBwdArgs p, int epw)
   for (int e = lane; e < nvec * n4; e += 64) dst[e] = acc[e];
 }
 
-// Sum over the wave, the same value in every lane: two quad permutes and two row mirrors (DPP, no LDS crossbar: the six
-// ds_bpermute of the xor butterfly cost ~0.3 us per call in the backward's dependent chain), then the four row totals in
-// row order.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  auto dpp = [](float x, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});    // row_mirror
-  const int b = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-  return ((r0 + r1) + r2) + r3;
-}
-
-// The same backward for L <= 3 known at compile time (dcn.py: 3; L = 4 would spill): 4 waves per workgroup, each walking `epw` examples into
-// its OWN slab; the four slabs are added in wave order into one partial per workgroup.  Against cross_bwd_k (one wave per
-// workgroup, loops unrolled to CROSS_MAX_L: 442 registers, one wave per SIMD, one partial per wave): ~190 registers and
-// 70 KB of LDS per workgroup -> two workgroups = 8 waves per CU, a quarter of the partials.
-// grid = ceil(B / (4 epw)), block = 256, dyn LDS: 4 (2L+1) dim floats.
+// (wave_sum_dpp and the body of the L <= 3 backward live in cross_device.h since round 6: tower.hip carries the same body as
+// extra workgroups of a tower-backward launch)
 template <int L>
 __global__ __launch_bounds__(256, 2) void cross_bwd4_k(const CrossBwdArgs p, int epw) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n4 = p.dim >> 2;
-  constexpr int nvec = 2 * L + 1;
-  float4* acc = reinterpret_cast<float4*>(lds) + (size_t)w * nvec * n4;     // this wave's slab (LDS operations of one wave are ordered)
-  for (int e = lane; e < nvec * n4; e += 64) acc[e] = F4Z;
-  float4 wv[L][CROSS_NV];
-#pragma unroll
-  for (int l = 0; l < L; ++l)
-#pragma unroll
-    for (int v = 0; v < CROSS_NV; ++v)
-      wv[l][v] = cross_ld(reinterpret_cast<const float4*>(p.W) + (size_t)l * n4, lane + 64 * v, n4);
-  for (int rr = 0; rr < epw; ++rr) {
-    const int b = (blockIdx.x * 4 + w) * epw + rr;
-    if (b >= p.B) break;
-    float4 x0[CROSS_NV], xs[L][CROSS_NV], x[CROSS_NV], dx[CROSS_NV], dx0[CROSS_NV];
-    float sl[L];
-#pragma unroll
-    for (int v = 0; v < CROSS_NV; ++v) {
-      x0[v] = cross_ld(reinterpret_cast<const float4*>(p.x0) + (size_t)b * n4, lane + 64 * v, n4);
-      x[v] = x0[v];
-      dx0[v] = F4Z;
-    }
-    const float g = p.gz != nullptr ? p.gz[b] : 0.f;
-#pragma unroll
-    for (int v = 0; v < CROSS_NV; ++v) {          // (issued before the recomputation below needs anything)
-      float4 d = F4Z;
-      if (p.dxL != nullptr) d = cross_ld(reinterpret_cast<const float4*>(p.dxL) + (size_t)b * n4, lane + 64 * v, n4);   // uniform
-      dx[v] = d;
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) sl[l] = p.s[(size_t)b * L + l];
-#pragma unroll
-    for (int l = 0; l < L; ++l) {                 // recompute x_0 .. x_{L-1} (and x_L in `x`)
-#pragma unroll
-      for (int v = 0; v < CROSS_NV; ++v) {
-        xs[l][v] = x[v];
-        const float4 bb = cross_ld(reinterpret_cast<const float4*>(p.Bc) + (size_t)l * n4, lane + 64 * v, n4);
-        x[v] = f4_add(f4_add(f4_scale(sl[l], x0[v]), x[v]), bb);
-      }
-    }
-    if (p.gz != nullptr) {
-#pragma unroll
-      for (int v = 0; v < CROSS_NV; ++v) {
-        const int e = lane + 64 * v;
-        dx[v] = f4_add(dx[v], f4_scale(g, cross_ld(reinterpret_cast<const float4*>(p.wout), e, n4)));
-        if (e < n4) {
-          float4* o = acc + (size_t)(2 * L) * n4 + e;
-          *o = f4_add(*o, f4_scale(g, x[v]));                       // d wout += gz * x_L
-        }
-      }
-    }
-#pragma unroll
-    for (int l = L - 1; l >= 0; --l) {
-      float part = 0.f;
-#pragma unroll
-      for (int v = 0; v < CROSS_NV; ++v) part += dot4(dx[v], x0[v]);
-      const float ds = wave_sum_dpp(part);
-#pragma unroll
-      for (int v = 0; v < CROSS_NV; ++v) {
-        const int e = lane + 64 * v;
-        if (e < n4) {
-          float4* db = acc + (size_t)(L + l) * n4 + e;
-          float4* dw = acc + (size_t)l * n4 + e;
-          *db = f4_add(*db, dx[v]);                                  // dB_l += dx_{l+1}
-          *dw = f4_add(*dw, f4_scale(ds, xs[l][v]));                 // dW_l += ds * x_l
-        }
-        dx0[v] = f4_add(dx0[v], f4_scale(sl[l], dx[v]));             // dx0 += s_l * dx_{l+1}
-        dx[v] = f4_add(dx[v], f4_scale(ds, wv[l][v]));               // dx_l = dx_{l+1} + ds * w_l
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < CROSS_NV; ++v) {
-      const int e = lane + 64 * v;
-      if (e < n4) {
-        float4 o = f4_add(dx0[v], dx[v]);
-        float4* dst = reinterpret_cast<float4*>(p.dX) + (size_t)b * n4 + e;
-        if (p.accumulate) o = f4_add(*dst, o);
-        *dst = o;
-      }
-    }
-  }
-  __syncthreads();
-  const float4* sl4 = reinterpret_cast<const float4*>(lds);
-  const int per = nvec * n4;
-  float4* dst = reinterpret_cast<float4*>(p.part) + (size_t)blockIdx.x * per;
-  for (int e = threadIdx.x; e < per; e += 256)
-    dst[e] = f4_add(f4_add(f4_add(sl4[e], sl4[per + e]), sl4[2 * per + e]), sl4[3 * per + e]);
+  cross_bwd4_body<L>(p, epw, lds, (int)blockIdx.x);
 }
 
 // out[j] = sum over the RT per-wave partials (step_riders_device.h cross_reduce_block).  grid = ceil(n/16), block = 256.

@@ -21,6 +21,7 @@
 #include "sort_device.h"
 #include "adam_device.h"
 #include "drop_device.h"
+#include "cross_device.h"
 #include "gather_device.h"
 #include "step_riders_device.h"
 
@@ -753,6 +754,10 @@ struct BwdArgs {
   int n_sort;                // extra workgroups that run the per-field dedup sort of the same step (0: none)
   double* zero_p;            // fixed-point statistics rows this launch clears for the NEXT step's producers (stat_zero), or null
   int zero_n;
+  int acc_dx;                // first layer: dy_prev (= dX) += instead of = (a rider of an EARLIER launch wrote its share already)
+  // rider (round 6, dcn.py): the cross layers' backward as the launch's LAST n_xr workgroups (tower_bwd_big_k<.., XR = true>)
+  int n_xr, xr_epw;
+  CrossBwdArgs xr;
   SortArgs sort;
   AdamSlice sweep;           // optional slice of the untouched-row optimizer sweep (after the sort workgroups)
 };
@@ -1431,13 +1436,23 @@ constexpr int BIG_DW_ROWS = 32;        // batch rows per LDS stage of a dW workg
 __host__ __device__ inline int big_ld32(int n) { return ((n + 15) & ~15) + 4; }   // row stride == 4 (mod 8): ds_read_b32 columns
 
 // NTX: d(input) column tiles per wave and pass; NTD: column tiles of the dW family (N <= 16 * NTD); RID: riders present
-template <int NTX, int NTD, bool RID>
-__global__ __launch_bounds__(256) void tower_bwd_big_k(const BwdArgs p) {
+// XR (round 6): the launch's last n_xr workgroups run dcn.py's cross-layer backward (cross_device.h cross_bwd4_body<3>: it needs
+// only the head's gradient, so it leaves the step's dependent chain; the FIRST layer's launch then accumulates onto its dX)
+// (XR: two waves per SIMD asked for -- the two bodies together took 276 registers, one workgroup per CU for the whole launch)
+template <int NTX, int NTD, bool RID, bool XR = false>
+__global__ __launch_bounds__(256, XR ? 2 : 1) void tower_bwd_big_k(const BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.zero_n > 0) stat_zero(p.zero_p, p.zero_n);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
+  if constexpr (XR) {
+    const int xb = bid - (p.n_din + p.n_dw + p.n_head);
+    if (xb >= 0) {
+      cross_bwd4_body<3>(p.xr, p.xr_epw, lds, xb);
+      return;
+    }
+  }
   const float Bf = (float)p.B;
   const bool first = p.bn_prev == nullptr;
   const bool nobn = p.gamma == nullptr;
@@ -1571,7 +1586,9 @@ __global__ __launch_bounds__(256) void tower_bwd_big_k(const BwdArgs p) {
               s1 += (double)o;
               s2 += (double)o * (double)xh;
             }
-            p.dy_prev[(size_t)orow * p.K + kc] = o;
+            float* dst = p.dy_prev + (size_t)orow * p.K + kc;
+            if (first && p.acc_dx) o = *dst + o;                 // (dX: an earlier launch's rider wrote the cross layers' share)
+            *dst = o;
           }
         }
         if (!first) {
@@ -2108,12 +2125,23 @@ extern "C" size_t rsx_tower_bwd_workspace_floats(int B, int K, int N) {
   return B >= TOWER_BIG_MIN_B && big > small ? big : small;
 }
 
+// does a backward launch of this shape take tower_bwd_big_k (the kernel that knows the cross rider / the accumulating dX)?
+static inline bool tower_bwd_is_big(int B, int K, int N) {
+  static const int big_env = getenv("RSX_TOWER_BIG") ? atoi(getenv("RSX_TOWER_BIG")) : 1;
+  return big_env && B >= TOWER_BIG_MIN_B && K >= tower_big_min_k(true, B) && (N & 3) == 0 && N <= 128 && (K & 3) == 0;
+}
+extern "C" int rsx_tower_bwd_cross_ride_supported(int B, int K_last, int N_last, int K_first, int N_first, int dim, int L) {
+  if (B <= 0 || dim <= 0) return 0;
+  return tower_bwd_is_big(B, K_last, N_last) && K_last <= 128 && tower_bwd_is_big(B, K_first, N_first) && L == 3 &&
+         dim % 4 == 0 && dim <= 256 * CROSS_NV && (size_t)4 * (2 * L + 1) * dim * sizeof(float) <= 80 * 1024;
+}
+
 extern "C" int rsx_tower_bwd_layer_defer(const float*, const float*, const float*, const float*, const double*, const float*,
                                          const float*, float*, float*, float*, float*, const float*, const float*, const float*,
                                          const float*, float*, double*, const double*, const float*, float*, float*, float*,
                                          float*, float*, float*, const uint32_t*, uint32_t, int, float, int, int, int,
                                          const rsx_sort_job*, const rsx_adam_slice*, float*, rsx_dw_reduce_job*, double*, int,
-                                         rsx_stream_t);
+                                         const rsx_tower_bwd_extra*, rsx_stream_t);
 extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float* a, const float* dy,
                                    const double* bstat, const float* bn, const float* gamma, float* dW, float* db,
                                    float* dgamma, float* dbeta, const float* bn_prev, const float* gamma_prev,
@@ -2125,7 +2153,7 @@ extern "C" int rsx_tower_bwd_layer(const float* in, const float* W, const float*
                                    float* dw_partials, rsx_stream_t stream) {
   return rsx_tower_bwd_layer_defer(in, W, a, dy, bstat, bn, gamma, dW, db, dgamma, dbeta, bn_prev, gamma_prev, beta_prev, mask_prev,
                                    dy_prev, bstat_prev, hpart, dwd_part, dwd, dbd, dwo, dbo, dc0, loss, rng_step, seed, layer,
-                                   dropout_rate, B, K, N, sort_h, sweep_h, dw_partials, nullptr, nullptr, 0, stream);
+                                   dropout_rate, B, K, N, sort_h, sweep_h, dw_partials, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const float* a, const float* dy,
@@ -2137,8 +2165,19 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
                                          const uint32_t* rng_step, uint32_t seed, int layer, float dropout_rate, int B,
                                          int K, int N, const rsx_sort_job* sort_h, const rsx_adam_slice* sweep_h,
                                          float* dw_partials, rsx_dw_reduce_job* reduce_out, double* zero_stats,
-                                         int zero_n, rsx_stream_t stream) {
+                                         int zero_n, const rsx_tower_bwd_extra* extra_h, rsx_stream_t stream) {
   if (reduce_out != nullptr) reduce_out->sb = 0;          // (0: nothing left to reduce for this layer)
+  const bool xride = extra_h != nullptr && extra_h->x0 != nullptr;
+  if (xride) {
+    if (!extra_h->cW || !extra_h->cB || !extra_h->s || !extra_h->gz || !extra_h->wout || !extra_h->dX || !extra_h->dcW ||
+        !extra_h->dcB || !extra_h->dwout || !extra_h->workspace || !extra_h->reduce_out)
+      return RSX_EINVAL;
+    extra_h->reduce_out->n = 0;
+    if (!rsx_tower_bwd_cross_ride_supported(B, K, N, K, N, extra_h->dim, extra_h->L) || sort_h != nullptr ||
+        (sweep_h != nullptr) || bn_prev == nullptr)
+      return RSX_EUNSUPPORTED;                              // (the carrying launch: a non-first layer through tower_bwd_big_k, no riders)
+  }
+  if (extra_h != nullptr && extra_h->accumulate_dx && bn_prev != nullptr) return RSX_EINVAL;     // (first layer only)
   if (B < 0 || K <= 0 || N <= 0) return RSX_EINVAL;
   if (B == 0) return RSX_OK;
   if (zero_n < 0 || (zero_n > 0 && !zero_stats)) return RSX_EINVAL;
@@ -2160,6 +2199,15 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   p.has_wo = dwo != nullptr;
   p.B = B; p.K = K; p.N = N; p.RT = stat_rows(B); p.RTh = (B + TM - 1) / TM;
   p.zero_p = zero_stats; p.zero_n = zero_n;
+  p.acc_dx = extra_h != nullptr ? extra_h->accumulate_dx : 0;
+  p.n_xr = 0; p.xr_epw = 1;
+  p.xr = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  if (xride) {
+    p.xr_epw = B <= 1024 ? 1 : (B <= 8192 ? 2 : 4);              // (cross.hip cross_epw4)
+    p.n_xr = (B + 4 * p.xr_epw - 1) / (4 * p.xr_epw);
+    p.xr = CrossBwdArgs{extra_h->x0, extra_h->cW, extra_h->cB, extra_h->s, nullptr, extra_h->gz, extra_h->wout, extra_h->dX,
+                        extra_h->workspace, 0, B, extra_h->dim, extra_h->L};
+  }
   p.ct_k = (K + 15) / 16;
   p.ct_k1 = (K + 1 + 15) / 16;          // +1: the ones-row that yields db
   p.ct_n = (N + 15) / 16;
@@ -2220,9 +2268,31 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
     if ((size_t)5 * NP + 1024 + 64 > lb) lb = (size_t)5 * NP + 1024 + 64;
     lb *= sizeof(float);
     if (lb > lds) lds = lb;                                       // (lds: what a riding sort needs)
-    const dim3 grid(p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk);
     const bool wide = K > 128;                                    // d(input) column tiles per wave and pass: 5 (K = 624: two passes), else 2
     const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;
+    if (xride) {
+      // the cross layers' backward as the launch's last workgroups (4 waves, (2L + 1) dim floats of LDS per wave)
+      const size_t lx = (size_t)4 * (2 * extra_h->L + 1) * extra_h->dim * sizeof(float);
+      if (lx > lds) lds = lx;
+      if (wide || rid || lds > 80 * 1024) return RSX_EUNSUPPORTED;
+      const dim3 gx(p.n_din + p.n_dw + p.n_head + p.n_xr);
+      auto launch = [&](auto kern) -> int {
+        static bool attr_set = false;                             // (> 64 KB of dynamic LDS per workgroup)
+        if (!attr_set) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+            return RSX_EUNSUPPORTED;
+          attr_set = true;
+        }
+        RSX_LAUNCH(kern, gx, dim3(256), lds, rsx_s(stream), p);
+        return RSX_OK;
+      };
+      const int rcx = N <= 64 ? launch(tower_bwd_big_k<2, 4, false, true>) : launch(tower_bwd_big_k<2, 8, false, true>);
+      if (rcx != RSX_OK) return rcx;
+      RSX_CHECK_LAUNCH();
+      *extra_h->reduce_out = rsx_cross_reduce_job{extra_h->workspace, extra_h->dcW, extra_h->dcB, extra_h->dwout, p.n_xr,
+                                                  (2 * extra_h->L + 1) * extra_h->dim, extra_h->L, extra_h->dim};
+    } else {
+    const dim3 grid(p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk);
 #define RSX_BWD_BIG(NTX, NTD)                                                                                 \
   do {                                                                                                        \
     if (rid) RSX_LAUNCH((tower_bwd_big_k<NTX, NTD, true>), grid, dim3(256), lds, rsx_s(stream), p);   \
@@ -2232,6 +2302,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
     else { if (wide) RSX_BWD_BIG(5, 8); else RSX_BWD_BIG(2, 8); }
 #undef RSX_BWD_BIG
     RSX_CHECK_LAUNCH();
+    }
     const int KR = p.ct_k1 * 16;
     if (reduce_out != nullptr) {
       *reduce_out = rsx_dw_reduce_job{dw_partials, dW, db, p.sb, K, N, 1};
@@ -2242,6 +2313,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
     RSX_CHECK_LAUNCH();
     return RSX_OK;
   }
+  if (xride || p.acc_dx) return RSX_EUNSUPPORTED;            // (only tower_bwd_big_k knows these roles: rsx_tower_bwd_cross_ride_supported)
   const int total = p.n_din + p.n_dw + p.n_head + p.n_sort + (int)p.sweep.n_blk;
   const bool rid = p.n_sort + (int)p.sweep.n_blk > 0;        // (no riders: the variant with their code compiled out)
   if (p.sb > 1) {

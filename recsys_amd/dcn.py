@@ -149,15 +149,25 @@ def _train_fused(store, arena, ids, labels, params, masks):
         ride = dp is None and hot is not None and _lib.form("scatter_riders") == "1"
         if not gcross:
             _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
+        # Round 6: the cross layers' backward needs only the head's gradient -- it rides in the second tower layer's backward launch
+        # and the first layer's launch accumulates onto the dX it wrote (single replica: data parallel keeps the separate launch,
+        # whose dX lives in the send block either way but whose dense gradients go through a collective first)
+        # (a launch that carries a slice of the optimizer sweep -- the single-step schedule -- keeps its own riders only)
+        xride = ride and sweeps is None and store.cross.cross_ride_ok(store.tower, ids.shape[0])
+        cr = store.cross.rider_args(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, oW[nh:], oG[nh:]) \
+            if xride else None
         loss, prob, dX, gz, _ = store.tower.train_step(
             x0, labels.reshape(-1).to(torch.float32), params["dropout"], store.opt.state.view(torch.int32)[3:4],
             s0=cz, head=((oW[:nh], oG[:nh]), "out.b", None, None), relu0=False, relu2=False,
             replicas=dp.world if dp is not None else 1, masks=masks,
             seed=0x5eed + (7919 * dp.rank if dp is not None else 0),     # replicas draw independent dropout patterns
             sort_job=job, sweeps=sweeps, sort_in_fwd=True, outs=(dp.send_views(ids.shape[0])[0], None, None) if zc else None,
-            defer_dw_reduce=ride)
-        cross_job = store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
-                                         gz=gz, wout=oW[nh:], dwout=oG[nh:], defer_reduce=ride)
+            defer_dw_reduce=ride, cross_rider=cr)
+        if xride:
+            cross_job = store.tower.cross_job_pending
+        else:
+            cross_job = store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
+                                             gz=gz, wout=oW[nh:], dwout=oG[nh:], defer_reduce=ride)
         riders = make_scatter_riders(store.tower.dw_jobs_pending, cross_job) if ride else None
         if ux:      # the rank's own sorted segment-sum, written as its block of the send buffer (deepfm._train_fused)
             (Gv,) = dp.send_views(arena.ux.capT)

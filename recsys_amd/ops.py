@@ -820,7 +820,7 @@ class FusedTower:
     def train_step(self, X, labels, rate, rng_step, s0=None, c0=None, s1=None,
                    head=("dnn.Wout", "dnn.bout", "out.W", "out.b"), relu0=True, relu2=True, replicas=1, masks=None,
                    seed=0x5eed, sort_job=None, sweeps=None, sort_in_fwd=False, outs=None, layer_done=None, gather=None,
-                   reduce_rider=False, defer_dw_reduce=False):
+                   reduce_rider=False, defer_dw_reduce=False, cross_rider=None):
         """X [B,k0]; s0/s1 [B] extra scalar inputs of the head (first-order pre-activation, FM term);
         c0 = name of the bias added to s0; rng_step = device uint32 tensor that changes every step;
         sort_job = EmbeddingArena.sort_job(ids): the dedup sort rides in the last layer's backward launch, or in the
@@ -834,8 +834,12 @@ class FusedTower:
         layer_done(l): called after layer l's backward launch (l = L-1 .. 0), when that layer's dW/db (and, for l = L-1,
         the head's gradients) have been launched in full -- the hook of the RSX_DP_OVERLAP all-reduces.  The layers' dW
         reductions are then NOT deferred to the end.
+        cross_rider (round 6, dcn.py; CrossLayers.rider_args): the cross layers' backward runs as extra workgroups of the LAST
+        layer's backward launch and the first layer's launch accumulates onto the dX it wrote (include/rsx.h rsx_tower_bwd_extra;
+        the caller checked cross_ride_ok); its gradient-partials reduce comes back as self.cross_job_pending.
         Returns (loss [1], prob [B], dX [B,k0], gs0 [B], gs1 [B])."""
         L, P, pre = lib(), self.P, self.pre
+        self.cross_job_pending = None
         o_dX, o_gs0, o_gs1 = [o if o is not None else d for o, d in zip(outs or (None,) * 3, (self.dX, self.gs0, self.gs1))]
         B = X.shape[0]
         assert B <= self.cap and X.is_contiguous() and X.shape[1] == self.k0
@@ -924,6 +928,19 @@ class FusedTower:
         for l in reversed(range(nl)):
             K = self.k0 if l == 0 else self.widths[l - 1]
             last = l == nl - 1
+            extra = None
+            if cross_rider is not None and (last or l == 0):
+                extra = _lib.TowerBwdExtra()
+                if last:
+                    cr = cross_rider
+                    self.cross_job_pending = _lib.CrossReduceJob()
+                    extra.x0, extra.cW, extra.cB, extra.s = cr["x0"].data_ptr(), cr["W"].data_ptr(), cr["B"].data_ptr(), cr["s"].data_ptr()
+                    extra.gz, extra.wout, extra.dX = o_gs0.data_ptr(), cr["wout"].data_ptr(), o_dX.data_ptr()
+                    extra.dcW, extra.dcB, extra.dwout = cr["dW"].data_ptr(), cr["dB"].data_ptr(), cr["dwout"].data_ptr()
+                    extra.workspace, extra.dim, extra.L = cr["ws"].data_ptr(), int(cr["dim"]), int(cr["L"])
+                    extra.reduce_out = C.pointer(self.cross_job_pending)
+                else:
+                    extra.accumulate_dx = 1
             check(L.rsx_tower_bwd_layer_defer(
                 _ptr(X if l == 0 else self.a[l - 1]), _ptr(P[f"{pre}.W{l}"]), _ptr(self.a[l]), _ptr(self.dy[l]),
                 _ptr(bst[l]), _ptr(self.bn[l]), bnp(f"{pre}.gamma{l}"),
@@ -938,7 +955,7 @@ class FusedTower:
                 rs, seed, l, rate, B, K, self.widths[l],
                 C.byref(sort_job) if (last and sort_job is not None and not sort_in_fwd) else None,
                 ref(sw[nl + 1 + (nl - 1 - l)]), _ptr(self.dwp[l]), C.byref(jobs[l]) if defer else None,
-                z_bwd0[0] if l == 0 else None, z_bwd0[1] if l == 0 else 0, st),
+                z_bwd0[0] if l == 0 else None, z_bwd0[1] if l == 0 else 0, None if extra is None else C.byref(extra), st),
                 "rsx_tower_bwd_layer_defer")
             if layer_done is not None:
                 layer_done(l)
@@ -1048,6 +1065,17 @@ class CrossLayers:
     def fused_gather_ok(self, arena):
         return arena.D == 16 and arena.F <= 64 and arena.F * arena.D == self.dim and self.L <= 8 and \
             _lib.form("gather_cross") == "1"
+
+    def cross_ride_ok(self, tower, B):
+        """Can the backward ride in the tower's last backward launch (rsx_tower_bwd_cross_ride_supported; RSX_FORMS cross_ride=0:
+        the launch of its own)?"""
+        w, nl = tower.widths, len(tower.widths)
+        return nl >= 2 and tower.bn_on and _lib.form("cross_ride") == "1" and bool(lib().rsx_tower_bwd_cross_ride_supported(
+            int(B), w[nl - 2], w[nl - 1], tower.k0, w[0], self.dim, self.L))
+
+    def rider_args(self, x0, W, Bc, dW, dB, wout, dwout):
+        """What FusedTower.train_step(cross_rider=...) needs to run this backward inside its last layer's backward launch."""
+        return dict(x0=x0, W=W, B=Bc, s=self.s, wout=wout, dW=dW, dB=dB, dwout=dwout, ws=self.ws, dim=self.dim, L=self.L)
 
     def backward(self, x0, W, Bc, dW, dB, dX, accumulate, dxL=None, gz=None, wout=None, dwout=None, defer_reduce=False):
         """defer_reduce: the second launch (the gradient partials' sum) comes back as a _lib.CrossReduceJob for the scatter's

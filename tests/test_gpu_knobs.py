@@ -54,6 +54,7 @@ BIT_IDENTICAL = [
     ("dcn", 4096, {"RSX_ADAM_WINDOW": "1", "RSX_SORT_SPLIT": "0"}),    # .. and one workgroup per field: the same bits
     ("din", 64, {"RSX_DIN_SIDE_SORT": "0"}),                  # din.py: the ids-only branch (sort + sweep) in line instead of on a side stream
     ("dcn", 1024, {"RSX_GATHER_CROSS": "0"}),                 # the lookup and the cross layers' forward as two launches
+    ("dcn", 4096, {"RSX_CROSS_RIDE": "0"}),                   # round 6: the cross layers' backward as a launch of its own instead of riding in the second tower layer's backward launch
     ("dcn", 4096, {"RSX_SCATTER_RIDERS": "0"}),               # the dW / cross-gradient reduces as their own launches instead of riding in the scatter's stage A
     ("din", 64, {"RSX_SCATTER_RIDERS": "0"}),                 # the attention blocks' weight-gradient reduces inside the finish launch
     ("din", 64, {"RSX_DIN_GATHER_RIDE": "0"}),                # the six lookups as their own launch instead of riding in the two prepare launches
