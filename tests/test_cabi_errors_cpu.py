@@ -297,3 +297,15 @@ def test_round6_collective_entry_points_reject_bad_arguments(L):
     assert L.rsx_all_reduce_all_gather(P, P, 4, P, P, 18, None) == EINVAL        # block not a multiple of 4 bytes
     assert L.rsx_strerror(ECOMM).decode().startswith("collective library call failed")
     assert isinstance(L.rsx_comm_last_error_h(), bytes)
+
+
+def test_round6_cross_rider_envelope(L):
+    """rsx_tower_bwd_cross_ride_supported (include/rsx.h rsx_tower_bwd_extra): dcn.py's shapes at batch >= 1024 only."""
+    ok = L.rsx_tower_bwd_cross_ride_supported
+    assert ok(4096, 100, 100, 624, 100, 624, 3) == 1           # dcn.py bs 4096: 624 -> 100 -> 100, 3 cross layers
+    assert ok(1024, 100, 100, 624, 100, 624, 3) == 1
+    assert ok(256, 100, 100, 624, 100, 624, 3) == 0            # small batches: the tile kernels do not know the roles
+    assert ok(4096, 100, 100, 624, 100, 624, 2) == 0           # the rider body is instantiated for L = 3
+    assert ok(4096, 624, 100, 624, 100, 624, 3) == 0           # a WIDE carrying layer (two d(input) passes) is not
+    assert ok(4096, 100, 100, 624, 100, 626, 3) == 0           # dim % 4
+    assert ok(0, 100, 100, 624, 100, 624, 3) == 0
