@@ -667,7 +667,7 @@ int rsx_cross_reduce_run(const rsx_cross_reduce_job* job_h, rsx_stream_t stream)
  * WRITTEN, the partials' reduce comes back through reduce_out), and the FIRST tower layer's launch is given accumulate_dx = 1 so
  * that its d(input) tiles add onto that dX (a + b = b + a: the same bits as the separate launch adding afterwards).  Needs at
  * least two tower layers (the two roles are different launches).  rsx_tower_bwd_cross_ride_supported says whether both launches
- * take the kernels that know the roles (batch >= 1024, L == 3, dim % 4 == 0, no sort / sweep riders in the carrying launch).   */
+ * take the kernels that know the roles (both layers through the large-batch backward kernel: batch >= 4096 for a 100-wide layer; L == 3, dim % 4 == 0, no sort / sweep riders in the carrying launch).   */
 typedef struct rsx_tower_bwd_extra_ {
   int32_t accumulate_dx;                 /* first layer only: dy_prev (= dX) += instead of = */
   const float* x0;                       /* NULL: no rider; else the arguments of rsx_cross_bwd_defer */

@@ -300,10 +300,11 @@ def test_round6_collective_entry_points_reject_bad_arguments(L):
 
 
 def test_round6_cross_rider_envelope(L):
-    """rsx_tower_bwd_cross_ride_supported (include/rsx.h rsx_tower_bwd_extra): dcn.py's shapes at batch >= 1024 only."""
+    """rsx_tower_bwd_cross_ride_supported (include/rsx.h rsx_tower_bwd_extra): dcn.py's shapes at batch >= 4096 only."""
     ok = L.rsx_tower_bwd_cross_ride_supported
     assert ok(4096, 100, 100, 624, 100, 624, 3) == 1           # dcn.py bs 4096: 624 -> 100 -> 100, 3 cross layers
-    assert ok(1024, 100, 100, 624, 100, 624, 3) == 1
+    assert ok(8192, 100, 100, 624, 100, 624, 3) == 1
+    assert ok(1024, 100, 100, 624, 100, 624, 3) == 0           # below 4 096 a 100-wide layer's backward takes the tile kernels
     assert ok(256, 100, 100, 624, 100, 624, 3) == 0            # small batches: the tile kernels do not know the roles
     assert ok(4096, 100, 100, 624, 100, 624, 2) == 0           # the rider body is instantiated for L = 3
     assert ok(4096, 624, 100, 624, 100, 624, 3) == 0           # a WIDE carrying layer (two d(input) passes) is not
