@@ -2203,7 +2203,7 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   p.n_xr = 0; p.xr_epw = 1;
   p.xr = CrossBwdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   if (xride) {
-    p.xr_epw = B <= 1024 ? 1 : (B <= 8192 ? 2 : 4);              // (cross.hip cross_epw4)
+    p.xr_epw = B <= 1024 ? 1 : (B <= 8192 ? 2 : 4);              // (cross.hip cross_epw4; 4 / 8 per wave at 4 096: +5 us / equal)
     p.n_xr = (B + 4 * p.xr_epw - 1) / (4 * p.xr_epw);
     p.xr = CrossBwdArgs{extra_h->x0, extra_h->cW, extra_h->cB, extra_h->s, nullptr, extra_h->gz, extra_h->wout, extra_h->dX,
                         extra_h->workspace, 0, B, extra_h->dim, extra_h->L};
@@ -2256,7 +2256,14 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
     const int NP = (N + 15) & ~15;
     p.n_din = p.RTh;
     const int nfg = (K + 1 + 63) / 64;
-    int sbw = 320 / nfg < 1 ? 1 : (320 / nfg > 32 ? 32 : 320 / nfg);                 // row blocks wanted (more, shorter blocks
+    // dW workgroups wanted: up to 320 -- but a workgroup of either family lives ~20 us and two fit a CU (220 registers), so the
+    // launch should not spill a few dozen workgroups into a second round of the 256 CUs: with the 256 d(input) workgroups of
+    // batch 4 096, 286 dW workgroups made the launch 41 us, 242 make it 34.7 (round 6; dcn.py 0.173 -> 0.166 ms, ABAB on one box;
+    // RSX_TOWER_BIG_DW_WGS: A/B knob)
+    static const int dw_env = getenv("RSX_TOWER_BIG_DW_WGS") ? atoi(getenv("RSX_TOWER_BIG_DW_WGS")) : 0;
+    const int room = 2 * 256 - p.n_din - p.n_head;
+    const int dw_wgs = dw_env > 0 ? dw_env : (room >= 128 && room < 320 ? room : 320);
+    int sbw = dw_wgs / nfg < 1 ? 1 : (dw_wgs / nfg > 32 ? 32 : dw_wgs / nfg);         // row blocks wanted (more, shorter blocks
                                                                                       // measured slower: the reduce grows with them)
     int rows = ((B + sbw - 1) / sbw + BIG_DW_ROWS - 1) / BIG_DW_ROWS * BIG_DW_ROWS;  // rows per block: a multiple of the LDS stage
     p.ksb = rows / 16;
