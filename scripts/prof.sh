@@ -18,5 +18,6 @@ print("\n# timeline sample (us from first row; one training step ~ between two f
 for r in rows[mid:mid + 130]:
     print("%-150s start=%10.2f dur=%8.2f" % (r[0][:150], (r[1] - rows[mid][1]) / 1e3, (r[2] - r[1]) / 1e3))
 PY
+python $root/scripts/occupancy_table.py $db > $root/gpurun_out/${name}_occupancy.txt 2>&1
 grep metric $root/gpurun_out/$name.log | cut -c1-300
 rm -rf /tmp/prof_$name
