@@ -131,10 +131,12 @@ def test_mirror_true_spawns_one_rank_per_replica(tmp_path):
     d = str(tmp_path) + "/"
     _shards(d)
     model_dir = str(tmp_path / "model")
-    r = subprocess.run([sys.executable, "-m", "recsys_amd.fm", "--task_type", "train", "--train_path", d, "--train_parts", "4",
-                        "--eval_parts", "1", "--batch_size", "64", "--num_epochs", "1", "--model_dir", model_dir, "--mirror", "true",
-                        "--log_steps", "4"], cwd=ROOT, env=_clean_env(RSX_MIRROR_REPLICAS="2"), capture_output=True, text=True,
-                       timeout=900)
+    cmd = [sys.executable, "-m", "recsys_amd.fm", "--task_type", "train", "--train_path", d, "--train_parts", "4", "--eval_parts", "1",
+           "--batch_size", "64", "--num_epochs", "1", "--model_dir", model_dir, "--mirror", "true", "--log_steps", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(RSX_MIRROR_REPLICAS="2"), capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and not glob.glob(model_dir + "/model.ckpt-*.pt"):      # (see test_bench_gpus2_spawns_its_own_ranks)
+        print("recsys_amd.fm --mirror true: first attempt failed before training (rc %d):\n%s" % (r.returncode, r.stderr[-1500:]))
+        r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(RSX_MIRROR_REPLICAS="2"), capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert "2 data-parallel ranks" in out and "INFO:loss" in out
