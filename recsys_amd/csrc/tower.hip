@@ -2214,11 +2214,14 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   p.sb = rsx_tower_dw_blocks(B, dw_partials != nullptr);
   static const int rtw_env = getenv("RSX_TOWER_RTW") ? atoi(getenv("RSX_TOWER_RTW")) : 4;
   p.din_rtw = p.sb > 1 ? rtw_env : 1;
-  // grouped LDS-staged d(input) tiles (RSX_TOWER_DXG=1): measured better when a sweep slice rides in the launch (step-by-step
-  // optimizer: 93.5 vs ~96 us per DeepFM step) and 1 % worse without riders (optimizer windows, the default: 70.6 vs 69.9 us).
-  // Off by default, and NOT chosen per launch: the two forms add the N products of an output in a different order, and the
-  // windowed, the step-by-step and the plain path must stay bit-identical to each other.
-  static const int dxg_env = getenv("RSX_TOWER_DXG") ? atoi(getenv("RSX_TOWER_DXG")) : 0;
+  // grouped LDS-staged d(input) tiles (RSX_TOWER_DXG=0: the one-tile form).  Round 2 measured them 1 % worse in the windowed
+  // step and left them off; round 6's phase stamps show what the first layer's launch is bound by at batch 256 -- DISPATCH: 624
+  // one-tile d(input) workgroups go out at ~130 per us, so the first dW workgroup (block 624 of 904) starts 4.7 us after the
+  // launch does and the launch lasts dispatch + one workgroup's life (10.5 us).  Grouped: 160 + 280 workgroups.  ABAB on one
+  // box, deepfm.py bs 256: 0.0583 / 0.0583 ms one-tile against 0.0563 / 0.0563 grouped -- the default since round 6.  NOT
+  // chosen per launch: the two forms add the N products of an output in a different order, and the windowed, the step-by-step
+  // and the plain path must stay bit-identical to each other.
+  static const int dxg_env = getenv("RSX_TOWER_DXG") ? atoi(getenv("RSX_TOWER_DXG")) : 1;
   // Large batches (SPLIT, B >= 1024) always take the grouped form (RSX_TOWER_DXG_SPLIT=0 for A/B runs): there the one-tile
   // workgroups (4 row tiles x 1 column tile each, operands as 4-byte strided loads) are throughput-bound -- phase stamps at
   // batch 4096: 12-15 us per workgroup, 2 496 of them over ~1 000 slots -- while a grouped workgroup stages da and W once

@@ -66,7 +66,7 @@ BIT_IDENTICAL = [
 ROUNDING = [
     ("fm", 256, {"RSX_FM_FUSE": "0"}),                        # fp64 reduction of the head's dense gradients instead of the grouped fp32 rows
     ("dcn", 1024, {"RSX_CROSS_BWD4": "0"}),                   # one-wave cross backward: its partials are added in another order
-    ("deepfm", 256, {"RSX_TOWER_DXG": "1"}),                  # grouped d(input) tiles: another order over the N outputs
+    ("deepfm", 256, {"RSX_TOWER_DXG": "0"}),                  # one-tile d(input) workgroups (the default until round 6): another order over the N outputs
     ("dcn", 1024, {"RSX_TOWER_BIG": "0"}),                    # the batch-256 tiles for the wide first layer
     ("dcn", 1024, {"RSX_TOWER_DXG_SPLIT": "0"}),
     ("dcn", 1024, {"RSX_TOWER_SB_ROWS": "256"}),              # dW row blocks of 256 instead of 512 rows
