@@ -2227,7 +2227,10 @@ extern "C" int rsx_tower_bwd_layer_defer(const float* in, const float* W, const 
   // batch 4096: 12-15 us per workgroup, 2 496 of them over ~1 000 slots -- while a grouped workgroup stages da and W once
   // for four column tiles.  Every path of one batch size makes the same choice, so they stay bit-identical to each other.
   static const int dxg_split_env = getenv("RSX_TOWER_DXG_SPLIT") ? atoi(getenv("RSX_TOWER_DXG_SPLIT")) : 1;
-  const bool dxg_want = p.sb > 1 ? dxg_split_env > 0 : dxg_env > 0;
+  // (small batches: only where the one-tile form would launch 256 or more d(input) workgroups -- the 100-wide second layer's 112
+  // are not dispatch-bound, and its launch measured 7.3 us grouped against 6.5 one-tile; a rule of the layer's SHAPE, so every
+  // path of one model and batch size still makes the same choice)
+  const bool dxg_want = p.sb > 1 ? dxg_split_env > 0 : (dxg_env > 0 && p.ct_k * p.RTh >= 256);
   p.dxg = ((N & 3) != 0 || N > 128 || !dxg_want) ? 0 : 4;
   p.n_din = p.dxg > 0 ? ((p.ct_k + p.dxg - 1) / p.dxg) * p.RTh : p.ct_k * ((p.RTh + p.din_rtw - 1) / p.din_rtw);
   p.ksb = ((B + 15) / 16 + p.sb - 1) / p.sb;
