@@ -5,6 +5,7 @@ x0 = the 39x16 = 624-wide embedding vector; `cross_layers` cross layers (csrc/cr
 deep tower [dense(relu) -> BN -> dropout] x n WITHOUT a final 1-unit layer (:144-149);
 logits = dense(concat[deep, x_L], 1) (:151-152).  No first-order term (linear columns are built but unused, :96,128).
 """
+import ctypes as C
 import os
 
 import torch
@@ -15,7 +16,7 @@ from .deepfm import define_flags as _deepfm_flags, dp_unique_wanted
 from .deepfm import input_fn, run_main  # noqa: F401
 from .estimator import EstimatorSpec, ModeKeys, get_variable_store
 from .feature_columns import CriteoLayout, build_feature_columns
-from .ops import make_scatter_riders, CrossFn, CrossLayers, EmbeddingArena, FusedTower, gather_fm
+from .ops import make_scatter_riders, CrossFn, CrossLayers, EmbeddingArena, FusedTower, _stream, gather_fm
 
 
 def build_variables(store, params, capacity):
@@ -150,10 +151,11 @@ def _train_fused(store, arena, ids, labels, params, masks):
         if not gcross:
             _, _, cz = store.cross.forward(x0, P["cross.W"], P["cross.b"], wout=oW[nh:])
         # Round 6: the cross layers' backward needs only the head's gradient -- it rides in the second tower layer's backward launch
-        # and the first layer's launch accumulates onto the dX it wrote (single replica: data parallel keeps the separate launch,
-        # whose dX lives in the send block either way but whose dense gradients go through a collective first)
+        # and the first layer's launch accumulates onto the dX it wrote.  Data parallel too (dX lives in the send block either
+        # way); there the reduce of its gradient partials runs as a launch of its own right behind the tower, because the dense
+        # gradients go through a collective before the scatter that would otherwise carry it.
         # (a launch that carries a slice of the optimizer sweep -- the single-step schedule -- keeps its own riders only)
-        xride = ride and sweeps is None and store.cross.cross_ride_ok(store.tower, ids.shape[0])
+        xride = hot is not None and sweeps is None and store.cross.cross_ride_ok(store.tower, ids.shape[0])
         cr = store.cross.rider_args(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, oW[nh:], oG[nh:]) \
             if xride else None
         loss, prob, dX, gz, _ = store.tower.train_step(
@@ -165,6 +167,9 @@ def _train_fused(store, arena, ids, labels, params, masks):
             defer_dw_reduce=ride, cross_rider=cr)
         if xride:
             cross_job = store.tower.cross_job_pending
+            if not ride:
+                _lib.check(_lib.lib().rsx_cross_reduce_run(C.byref(cross_job), _stream()), "rsx_cross_reduce_run")
+                cross_job = None
         else:
             cross_job = store.cross.backward(x0, P["cross.W"], P["cross.b"], P["cross.W"].grad, P["cross.b"].grad, dX, True,
                                              gz=gz, wout=oW[nh:], dwout=oG[nh:], defer_reduce=ride)
